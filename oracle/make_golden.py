@@ -1,0 +1,134 @@
+"""Generate tests/golden/*.npz by running the REAL reference (imported from
+/root/reference) on CPU.  Run in the build container only:
+
+    python oracle/make_golden.py
+
+TEST INFRASTRUCTURE ONLY (see oracle/vlbert_oracle.py header).  The fixtures pin
+the oracle restatement: the reference ships no golden vectors of its own
+(SURVEY.md §4), so "the reference code executed on CPU" is the ground truth.
+
+What is run: pretrain.modules.ResNetVLBERTForPretraining (precomputed-feature
+configuration), eval() mode so dropout is off (SURVEY.md §8c pitfall ii), with every
+parameter randomised by oracle.init_params(randomize_all=True) and loaded through
+the reference's own load_state_dict, on seeded ragged batches from
+vl-bert_amd/synthetic.py.  Stored: the batch, parameter checksums, logits, losses,
+the encoder output, per-parameter gradient digests (norm, sum, strided sample),
+the global grad norm, and parameters after 3 steps of the reference's AdamW
+(common/nlp/bert/optimization.py:107-187).
+"""
+import importlib
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import ref_import  # noqa: E402
+from oracle.vlbert_oracle import VLBertConfig, init_params  # noqa: E402
+
+synthetic = importlib.import_module("vl-bert_amd.synthetic")
+
+SAMPLE = 4096
+
+CASES = {
+    # ragged lengths, 2 heads, MLM + MVRC (the north-star loss set)
+    "ragged_small": dict(
+        cfg=dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                 vocab_size=512, max_position_embeddings=64, visual_region_classes=50),
+        B=3, T=12, R=5, ragged=True, seed=11, pseed=3),
+    # full lengths, pooler + relationship head on, 3 layers
+    "full_rel": dict(
+        cfg=dict(hidden_size=128, num_hidden_layers=3, num_attention_heads=2, intermediate_size=384,
+                 vocab_size=512, max_position_embeddings=64, visual_region_classes=40,
+                 with_pooler=True, with_rel_loss=True),
+        B=2, T=8, R=4, ragged=False, seed=5, pseed=7),
+    # single head (H=64), longer ragged sequences
+    "ragged_1head": dict(
+        cfg=dict(hidden_size=64, num_hidden_layers=1, num_attention_heads=1, intermediate_size=128,
+                 vocab_size=300, max_position_embeddings=96, visual_region_classes=20),
+        B=4, T=40, R=17, ragged=True, seed=23, pseed=9),
+}
+
+
+def digest(t):
+    t = t.detach().double().reshape(-1)
+    stride = max(1, t.numel() // SAMPLE)
+    return np.array([t.norm().item(), t.sum().item()]), t[::stride][:SAMPLE].float().numpy()
+
+
+def run_case(name, spec):
+    RefModel, RefAdamW = ref_import.import_reference()
+    cfg = VLBertConfig(**spec["cfg"])
+    vocab_dir = ref_import.make_vocab_dir(os.path.join(tempfile.gettempdir(), "vlb_vocab_%s" % name),
+                                          cfg.vocab_size)
+    torch.manual_seed(0)
+    model = RefModel(ref_import.make_reference_config(cfg, vocab_dir))
+    params = init_params(cfg, seed=spec["pseed"])
+    sd = dict(params)
+    sd["vlbert.mlm_head.predictions.decoder.weight"] = sd["vlbert.word_embeddings.weight"]
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert not missing, missing
+    model.eval()
+
+    batch = synthetic.make_batch(spec["B"], spec["T"], spec["R"], vocab_size=cfg.vocab_size,
+                                 region_classes=cfg.visual_region_classes, seed=spec["seed"],
+                                 ragged=spec["ragged"])
+    boxes, im_info, text, rel, mlm_labels, mvrc_ops, mvrc_labels = [t.clone() for t in batch]
+    outputs, loss = model(None, boxes, im_info, text, rel, mlm_labels, mvrc_ops, mvrc_labels)
+    model.zero_grad()
+    loss.backward()
+
+    out = {"cfg_keys": np.array(list(spec["cfg"].keys())),
+           "cfg_vals": np.array([float(v) for v in spec["cfg"].values()]),
+           "B": spec["B"], "T": spec["T"], "R": spec["R"], "ragged": spec["ragged"],
+           "seed": spec["seed"], "pseed": spec["pseed"]}
+    for k, t in zip(("boxes", "im_info", "text", "relationship_label", "mlm_labels", "mvrc_ops", "mvrc_labels"),
+                    batch):
+        out["in_" + k] = t.numpy()
+    out["mlm_logits"] = outputs["mlm_logits"].detach().numpy()
+    out["mvrc_logits"] = outputs["mvrc_logits"].detach().numpy()
+    if outputs["relationship_logits"] is not None:
+        out["relationship_logits"] = outputs["relationship_logits"].detach().numpy()
+    for k in ("relationship_loss", "mlm_loss", "mvrc_loss"):
+        out[k] = float(outputs[k])
+    out["loss"] = float(loss)
+
+    named = dict(model.named_parameters())   # tied decoder.weight is deduplicated by named_parameters
+    total = 0.0
+    names = []
+    for n in sorted(params.keys()):
+        p = named[n]
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        total += float((g.double() ** 2).sum())
+        st, smp = digest(g)
+        out["g_stat/" + n], out["g_smp/" + n] = st, smp
+        st, smp = digest(params[n])
+        out["p_stat/" + n] = st
+        names.append(n)
+    out["names"] = np.array(names)
+    out["grad_norm"] = total ** 0.5
+
+    # three steps of the reference AdamW on the (fixed) gradients above
+    opt = RefAdamW([named[n] for n in names], lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=1e-2,
+                   correct_bias=True)
+    for _ in range(3):
+        opt.step()
+    for n in names:
+        out["adamw_smp/" + n] = digest(named[n])[1]
+
+    path = os.path.join(ROOT, "tests", "golden", name + ".npz")
+    np.savez_compressed(path, **out)
+    print("%s: loss %.6f (mlm %.6f mvrc %.6f rel %.6f) grad_norm %.6f -> %s (%.1f KB)" % (
+        name, out["loss"], out["mlm_loss"], out["mvrc_loss"], out["relationship_loss"], out["grad_norm"],
+        path, os.path.getsize(path) / 1024))
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(4)
+    for name, spec in CASES.items():
+        run_case(name, spec)

@@ -1,0 +1,87 @@
+"""Pins oracle/vlbert_oracle.py against fixtures produced by the REAL reference
+(oracle/make_golden.py, run where /root/reference exists).  CPU only."""
+import glob
+import importlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vlbert_oracle as O
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+SAMPLE = 4096
+
+
+def _digest(t):
+    t = t.detach().double().reshape(-1)
+    stride = max(1, t.numel() // SAMPLE)
+    return np.array([t.norm().item(), t.sum().item()]), t[::stride][:SAMPLE].float().numpy()
+
+
+def load_case(path):
+    z = np.load(path, allow_pickle=False)
+    kw = {}
+    for k, v in zip(z["cfg_keys"], z["cfg_vals"]):
+        k = str(k)
+        kw[k] = bool(v) if k.startswith("with_") else int(v)
+    cfg = O.VLBertConfig(**kw)
+    params = O.init_params(cfg, seed=int(z["pseed"]))
+    batch = tuple(torch.from_numpy(z["in_" + k]) for k in
+                  ("boxes", "im_info", "text", "relationship_label", "mlm_labels", "mvrc_ops", "mvrc_labels"))
+    return z, cfg, params, batch
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_oracle_matches_reference(path):
+    z, cfg, params, batch = load_case(path)
+    # the regenerated parameters are the ones the reference ran with
+    for n in z["names"]:
+        st, _ = _digest(params[str(n)])
+        np.testing.assert_allclose(st, z["p_stat/" + str(n)], rtol=1e-6, atol=1e-7)
+    # the synthetic generator reproduces the stored batch
+    syn = importlib.import_module("vl-bert_amd.synthetic")
+    regen = syn.make_batch(int(z["B"]), int(z["T"]), int(z["R"]), vocab_size=cfg.vocab_size,
+                           region_classes=cfg.visual_region_classes, seed=int(z["seed"]), ragged=bool(z["ragged"]))
+    for a, b in zip(regen, batch):
+        assert torch.equal(a, b)
+
+    outputs, loss, grads, norm = O.loss_and_grads(params, cfg, batch, train=False)
+    np.testing.assert_allclose(outputs["mlm_logits"].detach().numpy(), z["mlm_logits"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(outputs["mvrc_logits"].detach().numpy(), z["mvrc_logits"], rtol=1e-4, atol=2e-5)
+    if "relationship_logits" in z:
+        np.testing.assert_allclose(outputs["relationship_logits"].detach().numpy(), z["relationship_logits"],
+                                   rtol=1e-4, atol=2e-5)
+    for k in ("mlm_loss", "mvrc_loss", "relationship_loss"):
+        assert abs(float(outputs[k]) - float(z[k])) <= 1e-5 * max(1.0, abs(float(z[k])))
+    assert abs(float(loss) - float(z["loss"])) <= 1e-5 * abs(float(z["loss"]))
+    assert abs(norm - float(z["grad_norm"])) <= 1e-5 * float(z["grad_norm"])
+    for n in z["names"]:
+        n = str(n)
+        st, smp = _digest(grads[n])
+        ref = z["g_stat/" + n]
+        assert abs(st[0] - ref[0]) <= 1e-4 * max(ref[0], 1e-6) + 1e-7, n
+        np.testing.assert_allclose(smp, z["g_smp/" + n], rtol=2e-3, atol=1e-6, err_msg=n)
+
+
+@pytest.mark.parametrize("path", GOLDEN[:1], ids=["adamw"])
+def test_oracle_adamw_matches_reference(path):
+    z, cfg, params, batch = load_case(path)
+    _, _, grads, _ = O.loss_and_grads(params, cfg, batch, train=False)
+    for n in z["names"]:
+        n = str(n)
+        p = params[n].clone()
+        m, v = torch.zeros_like(p), torch.zeros_like(p)
+        for step in (1, 2, 3):
+            O.adamw_step(p, grads[n], m, v, step, lr=1e-3, eps=1e-6, weight_decay=1e-2)
+        np.testing.assert_allclose(_digest(p)[1], z["adamw_smp/" + n], rtol=1e-5, atol=1e-6, err_msg=n)
+
+
+def test_coordinate_embedding_shape_and_values():
+    b = torch.tensor([[0.0, 0.0, 599.0, 599.0, 600.0, 600.0]])
+    e = O.coordinate_embeddings(b, 256)
+    assert e.shape == (1, 4, 512)
+    # dim 0: position / 1000**0 ; xc = 299.5/600*100
+    assert abs(float(e[0, 0, 0]) - np.sin(299.5 / 600 * 100)) < 1e-5
+    assert abs(float(e[0, 0, 256]) - np.cos(299.5 / 600 * 100)) < 1e-5

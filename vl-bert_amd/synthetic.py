@@ -1,0 +1,60 @@
+"""Seeded synthetic pre-training batches in the layout the reference's collator
+emits (pretrain/data/collate_batch.py:12-73, conceptual_captions.py:95-97;
+SURVEY.md §8a row a0 / §8d).  Data only -- no model arithmetic lives here.
+
+Tuple order == the reference's `data_names` minus `image` (precomputed features):
+    boxes [B,R,4+2048] f32 (pad rows = -2), im_info [B,5] f32 (w,h,sx,sy,idx),
+    text [B,T] i64 (pad 0), relationship_label [B] i64, mlm_labels [B,T] i64 (pad -1),
+    mvrc_ops [B,R] i64 (pad 0), mvrc_labels [B,R,C] f32 soft labels (pad rows 0).
+"""
+import torch
+
+CLS, SEP, MASK = 101, 102, 103
+
+
+def make_batch(B, T, R, vocab_size=30522, region_classes=1601, feat_dim=2048, seed=0,
+               ragged=False, mlm_prob=0.15, mvrc_prob=0.135):
+    g = torch.Generator().manual_seed(seed)
+    lo = min(1000, vocab_size // 2)
+    text = torch.randint(lo, vocab_size, (B, T), generator=g)
+    text[:, 0] = CLS % vocab_size
+    if ragged:
+        tlen = torch.randint(max(3, T // 2), T + 1, (B,), generator=g)
+        tlen[0] = T
+        nobj = torch.randint(max(1, R // 2), R + 1, (B,), generator=g)
+        nobj[-1] = R
+    else:
+        tlen = torch.full((B,), T)
+        nobj = torch.full((B,), R)
+    ar_t = torch.arange(T).unsqueeze(0)
+    ar_r = torch.arange(R).unsqueeze(0)
+    text[ar_t == (tlen.unsqueeze(1) - 1)] = SEP % vocab_size
+    tpad = ar_t >= tlen.unsqueeze(1)
+    text[tpad] = 0
+
+    mlm_labels = torch.full((B, T), -1, dtype=torch.long)
+    pick = (torch.rand((B, T), generator=g) < mlm_prob) & ~tpad & (ar_t > 0) & (ar_t < tlen.unsqueeze(1) - 1)
+    pick[:, 1] = True  # at least one label per sample
+    mlm_labels[pick] = text[pick]
+    text[pick] = MASK % vocab_size
+
+    x1 = torch.rand((B, R), generator=g) * 400
+    y1 = torch.rand((B, R), generator=g) * 400
+    w = 10 + torch.rand((B, R), generator=g) * 150
+    h = 10 + torch.rand((B, R), generator=g) * 150
+    feats = torch.rand((B, R, feat_dim), generator=g)
+    boxes = torch.cat((torch.stack((x1, y1, x1 + w, y1 + h), -1), feats), -1)
+    boxes[:, 0, :4] = torch.tensor([0.0, 0.0, 599.0, 599.0])   # ADD_IMAGE_AS_A_BOX: whole-image box first
+    rpad = ar_r >= nobj.unsqueeze(1)
+    boxes[rpad] = -2.0
+    im_info = torch.tensor([600.0, 600.0, 1.0, 1.0, 0.0]).repeat(B, 1)
+    im_info[:, 4] = torch.arange(B)
+
+    mvrc_ops = (torch.rand((B, R), generator=g) < mvrc_prob).long()
+    mvrc_ops[:, 0] = 0
+    mvrc_ops[:, min(1, R - 1)] = 1 if R > 1 else 0
+    mvrc_ops[rpad] = 0
+    lab = torch.softmax(torch.randn((B, R, region_classes), generator=g), -1)
+    lab = lab * (mvrc_ops == 1).unsqueeze(-1).float()
+    relationship_label = torch.ones((B,), dtype=torch.long)
+    return (boxes.float(), im_info, text, relationship_label, mlm_labels, mvrc_ops, lab.float())
