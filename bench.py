@@ -1,0 +1,194 @@
+#!/usr/bin/env python
+"""bench.py -- samples/sec of the VL-BERT-base pre-training step on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" = one optimizer step of the whole hot path (zero-grad, forward, backward, RCCL gradient
+all-reduce overlapped with backward, global-norm clip, AdamW, weight refresh) on one synthetic batch
+that is already resident in HBM.  Workload = BASELINE.json configs[1]: VL-BERT-base, 12 layers,
+64 text + 36 regions (S=101), bf16, precomputed 2048-d region features, dropout ON (train mode),
+global batch 256 split over the N ranks (strong scaling: 256/N samples per GPU).
+Prints ONE JSON line on rank 0 (see the driver contract in the task statement).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def flops_per_sample(cfg, T, R):
+    """SURVEY.md §8d algorithmic FLOPs (multiply-add = 2): fwd; fwd+bwd = 3x."""
+    H, I, V, C, L = cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size, cfg.visual_region_classes, cfg.num_hidden_layers
+    S = T + R + 1
+    per_layer = 8 * S * H * H + 4 * S * H * I + 4 * S * S * H
+    fwd = L * per_layer + 2 * T * H * H + 2 * T * H * V + 2 * R * H * H + 2 * R * H * C + 2 * R * 4096 * H
+    return fwd, 3 * fwd
+
+
+def cpu_baseline(cfg_kw, T, R, budget_s=25.0):
+    """The oracle ("port" of the reference modules, oracle/vlbert_oracle.py) timed on this box's host cores:
+    forward + backward + AdamW of the same 12-layer model on a bounded sample (small batch, few iterations)."""
+    from oracle import vlbert_oracle as O
+    syn = importlib.import_module("vl-bert_amd.synthetic")
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = O.VLBertConfig(**cfg_kw)
+    params = O.init_params(cfg, seed=0, randomize_all=False)
+    Bc = 8
+    batch = syn.make_batch(Bc, T, R, seed=0)
+    m = {k: torch.zeros_like(v) for k, v in params.items()}
+    v = {k: torch.zeros_like(v) for k, v in params.items()}
+    times = []
+    t_start = time.time()
+    it = 0
+    while it < 4 and (time.time() - t_start) < budget_s:
+        t0 = time.time()
+        _, _, grads, _ = O.loss_and_grads(params, cfg, batch, train=True)
+        for k in params:
+            O.adamw_step(params[k], grads[k], m[k], v[k], it + 1, 1e-4, eps=1e-6, weight_decay=1e-4)
+        times.append(time.time() - t0)
+        it += 1
+    t = min(times[1:]) if len(times) > 1 else times[0]
+    return {"value": round(Bc / t, 3), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": "oracle fwd+bwd+AdamW, 12-layer base, batch %d x (64+36), fp32, dropout on, %d iterations (best of last %d)"
+                      % (Bc, len(times), max(1, len(times) - 1))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--global-batch", type=int, default=256)
+    ap.add_argument("--layers", type=int, default=12)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a hipGraph")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (MI355X); the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    engine = importlib.import_module("vl-bert_amd.engine")
+    syn = importlib.import_module("vl-bert_amd.synthetic")
+    lib = importlib.import_module("vl-bert_amd._lib")
+    ops = importlib.import_module("vl-bert_amd.ops")
+    arch, cus = lib.device_info(local_rank)
+
+    T, R = 64, 36
+    per_gpu = args.global_batch // world
+    cfg = engine.ModelConfig(num_hidden_layers=args.layers)
+    eng = engine.PretrainEngine(cfg, per_gpu, T, R, device="cuda:%d" % local_rank, train=True, lr=1e-4, weight_decay=1e-4,
+                                max_grad_norm=10.0, seed=1234 + rank)
+    eng.init_random(seed=0)                       # same weights on every rank (DDP broadcast, train.py:332-334)
+    batch = syn.make_batch(per_gpu, T, R, seed=100 + rank)
+    eng.set_batch(*[t.cuda(non_blocking=True) for t in batch])
+    eng.sync_weights()
+    torch.cuda.synchronize()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    use_graph = not args.no_graph and world == 1
+    step = eng.train_step
+    if use_graph:
+        eng.train_step()                            # lazy one-time setup outside capture
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            eng.train_step()
+        step = g.replay
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt)
+    ms = elapsed / args.steps * 1e3
+    value = args.global_batch / (elapsed / args.steps)
+    losses = eng.loss_values()
+
+    # ---- roofline of the dominant kernel (the bf16 MFMA GEMM): one extra, instrumented step ---------------
+    # HIP events are recorded on the stream the kernels are launched on (torch's current stream).
+    rec = []
+    orig = ops.gemm_nt
+
+    def timed_gemm(A, B, C, *a, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = orig(A, B, C, *a, **kw)
+        e1.record()
+        K = kw.get("K") or A.shape[1]
+        rec.append((e0, e1, 2.0 * C.shape[0] * C.shape[1] * K))
+        return out
+
+    ops.gemm_nt = timed_gemm
+    eng.train_step()
+    torch.cuda.synchronize()
+    ops.gemm_nt = orig
+    gemm_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in rec)
+    gemm_flops = sum(f for _, _, f in rec)
+    achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    fwd, fwdbwd = flops_per_sample(cfg, T, R)
+
+    if rank == 0:
+        out = {
+            "metric": "samples/sec VL-BERT-base pretrain (seq 64+36 regions) at 1/2/4/8 MI355X",
+            "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic (random-init weights, random tokens/boxes/features, resident in HBM)",
+            "config": {"workload": "VL-BERT-base %d-layer pretrain step (fwd+bwd+clip+AdamW), 64 text + 36 regions, "
+                                   "precomputed 2048-d region features, dropout on" % args.layers,
+                       "global_batch": args.global_batch, "per_gpu_batch": per_gpu, "seq_len": T + R + 1,
+                       "parallelism": "dp%d" % world, "hipgraph": bool(use_graph), "arch": arch, "cus": cus},
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt_bf16_kernel (all %d launches of one step)" % len(rec),
+                         "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "gemm_ms_per_step": round(gemm_ms, 3), "gemm_share_of_step": round(gemm_ms / ms, 3),
+                         "step_algorithmic_tflops": round(value * fwdbwd / 1e12, 2),
+                         "step_frac_of_peak": round(value * fwdbwd / 1e12 / (world * PEAK_BF16_TFLOPS), 4)},
+            "loss": round(losses["loss"], 4),
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(dict(num_hidden_layers=args.layers), T, R)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,170 @@
+/* libvlbert_hip.so -- C ABI of the MI355X (gfx950) VL-BERT pre-training hot path.
+ *
+ * The drop-in boundary: plain pointers + sizes + a hipStream_t, no torch / ATen
+ * types.  The caller (a thin PyTorch-ROCm wrapper, `vl-bert_amd/_lib.py`) owns every buffer and
+ * passes `tensor.data_ptr()` and `torch.cuda.current_stream().cuda_stream`; kernels are enqueued on
+ * that stream, never synchronise, and keep no global state besides a thread-local error string
+ * (re-entrant per stream, like the reference's ops which enqueue on at::cuda::getCurrentCUDAStream(),
+ * common/lib/roi_pooling/cuda/ROIAlign_cuda.cu:273).
+ *
+ * Conventions
+ *   - return 0 on success, <0 on error (VLB_ERR_ARG = -1 bad argument, VLB_ERR_HIP = -2 launch
+ *     failure); `vlb_last_error()` returns the message (the reference raises RuntimeError through
+ *     AT_ASSERTM / AT_ERROR / THCudaCheck, ROIAlign_cuda.cu:263-264,297 -- the Python wrapper
+ *     re-raises RuntimeError with this text).
+ *   - "bf16" buffers are raw bfloat16 bits (uint16_t); leading dimensions are in ELEMENTS.
+ *   - dropout: `drop_p` in [0,1); `seed` is a DEVICE pointer to one uint32 (so a captured hipGraph
+ *     re-reads it on replay); `tag` identifies the dropout site.  Forward and backward of a site
+ *     must pass the same (seed value, tag).  drop_p == 0 disables dropout (seed may be NULL).
+ *   - empty problems (rows == 0) return 0 immediately, as the reference does
+ *     (ROIAlign_cuda.cu:278-281).
+ *
+ * Each entry point cites the reference code it replaces (paths relative to jackroos/VL-BERT).
+ */
+#ifndef VLBERT_HIP_H
+#define VLBERT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* vlb_stream_t; /* == hipStream_t */
+
+const char* vlb_last_error(void);
+int vlb_version(void);
+/* returns the CU count of `device` and copies its gcnArchName ("gfx950:...") into name */
+int vlb_device_info(int device, char* name, int cap);
+
+/* ---- GEMM -----------------------------------------------------------------------------------
+ * C[M,N] (+)= A[M,K] * B[N,K]^T, bf16 operands, fp32 accumulate, fused epilogue
+ *   v = acc (+ bias[n]) ; act: 0 none | 1 erf-GELU (pre-activation optionally stored to `pre`)
+ *   | 2 ReLU | 3 v *= gelu'(aux[m,n]) ; dropout(v) ; v += res[m,n] ;
+ *   out_mode: 0 store bf16 | 1 store fp32 | 2 fp32 atomicAdd with split-K (`splitk` <= 0: auto).
+ * K % 64 == 0; lda/ldb % 8 == 0; ldc/ldaux/ldpre/ldres % 4 == 0.
+ * Replaces nn.Linear / torch.matmul (cuBLAS) + the separate bias/GELU/dropout/residual kernels of
+ * external/pytorch_pretrained_bert/modeling.py:291-300 (Q,K,V), :330-333 (BertSelfOutput),
+ * :362-364 (BertIntermediate + gelu :114-120), :375-378 (BertOutput), :448-452, :469
+ * (MLM transform / tied decoder), common/visual_linguistic_bert.py:482-502 (MVRC head),
+ * common/fast_rcnn.py:105-109 (obj_downsample Linear+ReLU) and their autograd backward. */
+int vlb_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
+                     const float* bias, int act, const void* aux, long ldaux, void* pre, long ldpre,
+                     const void* res, long ldres, float drop_p, const uint32_t* seed, uint32_t tag,
+                     int out_mode, int splitk, vlb_stream_t stream);
+
+/* out[c][r] = in[r][c] (bf16, out leading dim ldo >= R); colsum[c] += sum_r in[r][c] if non-NULL
+ * (bias gradients).  Feeds the weight-gradient GEMMs (autograd's `grad.t().mm(input)`). */
+int vlb_transpose_bf16(const void* in, long ldi, void* out, long ldo, int R, int C, float* colsum, vlb_stream_t stream);
+
+/* ---- BertLayerNorm (modeling.py:222-235; eps inside the sqrt, biased variance) --------------
+ * fwd: y = LN(x)*gamma+beta, stats[row] = (mean, rstd) (may be NULL).
+ * bwd: dx (bf16), dx_drop = dropout-masked dx (bf16, gradient entering the preceding dense layer),
+ *      dx_acc (fp32 atomicAdd) -- any may be NULL; dgamma/dbeta are accumulated (fp32 atomics).
+ *      dy is bf16, or fp32 when dy_f32 != 0. */
+int vlb_layernorm_fwd(const void* x, long ldx, const float* gamma, const float* beta, void* y, long ldy, float* stats,
+                      int rows, int H, float eps, vlb_stream_t stream);
+int vlb_layernorm_bwd(const void* dy, long lddy, int dy_f32, const void* x, long ldx, const float* stats,
+                      const float* gamma, void* dx, long lddx, void* dx_drop, long lddd, float drop_p,
+                      const uint32_t* seed, uint32_t tag, float* dx_acc, long ldacc, float* dgamma, float* dbeta,
+                      int rows, int H, vlb_stream_t stream);
+
+/* ---- BertSelfAttention core (modeling.py:300-316) --------------------------------------------
+ * qkv [B*S, 3H] bf16 (q | k | v, head h at columns h*64), mask [B,S] fp32 (1 attend / 0 -> -10000),
+ * ctx [B*S, H] bf16, lse [B, heads, S] fp32 (row log-sum-exp, saved for backward).
+ * S <= 128, head dim 64.  bwd recomputes the probabilities; writes dqkv [B*S, 3H] bf16. */
+int vlb_attention_fwd(const void* qkv, const float* mask, void* ctx, float* lse, int B, int S, int H, int nh,
+                      float drop_p, const uint32_t* seed, uint32_t tag, vlb_stream_t stream);
+int vlb_attention_bwd(const void* qkv, const float* mask, const void* ctx, const float* lse, const void* dctx,
+                      void* dqkv, int B, int S, int H, int nh, float drop_p, const uint32_t* seed, uint32_t tag,
+                      vlb_stream_t stream);
+
+/* ---- embedding side (common/visual_linguistic_bert.py:173-241, common/fast_rcnn.py:136-187) ---
+ * vlb_seq_layout: masks (uint8 [B,T], [B,R]) -> code [B,S] (kind<<16 | src index; kind 0 pad,
+ *   1 text, 2 object, 3 END), text_len[B], nobj[B], text_rows [B,T], obj_rows [B,R] (-1 if masked),
+ *   attn_mask [B,S] fp32.  S >= T+R+1.  (replaces the .item()/.nonzero()/boolean-mask scatter
+ *   host-synchronising code at visual_linguistic_bert.py:200-235.) */
+int vlb_seq_layout(const uint8_t* text_mask, const uint8_t* obj_mask, int B, int T, int R, int S, int32_t* code,
+                   int32_t* text_len, int32_t* nobj, int32_t* text_rows, int32_t* obj_rows, float* attn_mask,
+                   vlb_stream_t stream);
+/* boxes [B*R, ldbox] fp32 (x1,y1,x2,y2, 2048 features; x1 <= -1.5 marks padding), im_info [B,5],
+ * mvrc_ops int64 [B*R] (1 -> use mask_emb[2048] instead of the feature) -> out bf16 [B*R, 4096]
+ * = dropout(coordinate_embeddings || feature)  (common/utils/bbox.py:33-65, fast_rcnn.py:165-175,
+ * pretrain/modules/resnet_vlbert_for_pretraining.py:114-117). */
+int vlb_obj_prep_fwd(const float* boxes, long ldbox, const float* im_info, const int64_t* mvrc_ops,
+                     const float* mask_emb, void* out, int B, int R, float drop_p, const uint32_t* seed, uint32_t tag,
+                     vlb_stream_t stream);
+/* dst[c] += sum over rows with sel[row]==1 of src[row][c] * dropout_mask(row*row_elems + col_off + c) */
+int vlb_masked_colsum(const void* src, long lds, const int64_t* sel, int rows, int C, float* dst, float drop_p,
+                      const uint32_t* seed, uint32_t tag, uint32_t row_elems, uint32_t col_off, vlb_stream_t stream);
+/* fused embedding forward: word/visual/linguistic sum + position + token-type -> LayerNorm -> dropout.
+ * text_vis / obj_vis / obj_ling are bf16 with element strides (batch, position); when obj_ling_idx
+ * (int64 [B,R]) is non-NULL obj_ling is a table [n,H] indexed by it.  Saves `pre` (bf16 pre-LN sum)
+ * and stats for backward. */
+int vlb_embed_fwd(const int32_t* code, const int32_t* text_len, const int64_t* text_ids, const int64_t* text_type,
+                  const void* word_emb, const void* pos_emb, const void* type_emb, const void* end_emb,
+                  const void* text_vis, long tv_sb, long tv_st, const void* obj_vis, long ov_sb, long ov_sr,
+                  const void* obj_ling, long ol_sb, long ol_sr, const int64_t* obj_ling_idx, const float* gamma,
+                  const float* beta, void* pre, float* stats, void* out, int B, int T, int R, int S, int H, int V,
+                  int P, float eps, float drop_p, const uint32_t* seed, uint32_t tag, vlb_stream_t stream);
+/* backward of the above: accumulates (fp32 atomics) into the embedding-table gradients and writes the
+ * visual-part gradients (d_text_vis: per token, or per sample when dtv_st == 0; d_obj_vis per object;
+ * d_obj_ling dense, or the [2,H] table gradient in obj_ling_idx mode). */
+int vlb_embed_bwd(const void* dy, const void* pre, const float* stats, const float* gamma, const int32_t* code,
+                  const int32_t* text_len, const int64_t* text_ids, const int64_t* text_type,
+                  const int64_t* obj_ling_idx, float* d_word, float* d_pos, float* d_type, float* d_end,
+                  float* d_gamma, float* d_beta, float* d_text_vis, long dtv_sb, long dtv_st, float* d_obj_vis,
+                  long dov_sb, long dov_sr, float* d_obj_ling, long dol_sb, long dol_sr, int B, int T, int R, int S,
+                  int H, int V, int P, float drop_p, const uint32_t* seed, uint32_t tag, vlb_stream_t stream);
+/* out[i] = src[idx[i]] (rows of H bf16; idx < 0 -> zero row): text/object split of
+ * visual_linguistic_bert.py:146-166 */
+int vlb_gather_rows(const void* src, const int32_t* idx, void* out, int n, int H, vlb_stream_t stream);
+/* inverse of the split: dX[b,s] = (s<T ? d_text[b,s] : 0) + (row is object j ? d_obj[b,j] : 0) */
+int vlb_head_grad_combine(const void* d_text, const void* d_obj, const int32_t* code, void* dx, int B, int T, int R,
+                          int S, int H, vlb_stream_t stream);
+/* out_bf16 = (y > 0) ? g_f32 : 0   (ReLU backward of obj_downsample, fast_rcnn.py:108) */
+int vlb_relu_bwd_cast(const float* g, const void* y, void* out, long n, vlb_stream_t stream);
+/* out = dg * gelu'(u)  (bf16; backward of the erf-GELU at modeling.py:114-120 where it is not fused
+ * into a GEMM epilogue: BertPredictionHeadTransform, modeling.py:448-452) */
+int vlb_dgelu_mul(const void* dg, const void* u, void* out, long n, vlb_stream_t stream);
+
+/* ---- losses, forward+backward fused, gradient written in place over the bf16 logits ----------
+ * MLM: F.cross_entropy(ignore_index=-1) (resnet_vlbert_for_pretraining.py:176-178).
+ * MVRC: soft_cross_entropy (common/utils/misc.py:124-151).  `counts` = 1 device float (n_valid),
+ * `loss_out` is accumulated (+=).  gscale multiplies the gradient (1/grad-accumulation steps).
+ * logits_copy (optional) receives the untouched logits for API parity / metrics. */
+int vlb_ce_fwd_bwd(void* logits, long ld, int rows, int V, const int64_t* labels, float* counts, float gscale,
+                   float* loss_out, void* logits_copy, long ldcopy, vlb_stream_t stream);
+int vlb_soft_ce_fwd_bwd(void* logits, long ld, int rows, int C, const float* target, long ldt, float* tsum,
+                        float* counts, float gscale, float* loss_out, void* logits_copy, long ldcopy,
+                        vlb_stream_t stream);
+
+/* ---- optimizer over flat buffers (common/nlp/bert/optimization.py:129-187,
+ *      torch.nn.utils.clip_grad_norm_ at common/trainer.py:139-145) ---------------------------
+ * state: DEVICE float[8] = {lr, beta1, beta2, eps, weight_decay, step, max_norm, sumsq}.
+ * vlb_sumsq_f32 accumulates sum(g^2) into *out (point it at &state[7]); vlb_adamw_step applies
+ * clip coef = min(1, max_norm/(sqrt(sumsq)*grad_scale+1e-6)) * grad_scale, updates p/m/v, writes
+ * the bf16 copy, then increments step and zeroes sumsq. */
+int vlb_sumsq_f32(const float* g, long n, float* out, vlb_stream_t stream);
+int vlb_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, long n, float* state, float grad_scale,
+                   vlb_stream_t stream);
+int vlb_cast_f32_bf16(const float* in, void* out, long n, vlb_stream_t stream);
+int vlb_cast_bf16_f32(const void* in, float* out, long n, vlb_stream_t stream);
+int vlb_rng_advance(uint32_t* seed, vlb_stream_t stream);
+
+/* ---- ROIAlign (common/lib/roi_pooling: vision.cpp:6-11, ROIAlign.h:11-45) --------------------
+ * NCHW fp32, rois [K,5] = (batch_idx, x1, y1, x2, y2); same math as
+ * cuda/ROIAlign_cuda.cu:15-122 (forward) and :125-254 (backward, atomic scatter into a
+ * zero-initialised grad_input).  Exposed to Python under the reference's own names
+ * roi_align_forward / roi_align_backward by `vl-bert_amd/common/lib/roi_pooling/C_ROIPooling.py`. */
+int vlb_roi_align_fwd(const float* input, const float* rois, float* output, int num_rois, int channels, int height,
+                      int width, int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio,
+                      vlb_stream_t stream);
+int vlb_roi_align_bwd(const float* grad_output, const float* rois, float* grad_input, int num_rois, int batch,
+                      int channels, int height, int width, int pooled_h, int pooled_w, float spatial_scale,
+                      int sampling_ratio, vlb_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VLBERT_HIP_H */

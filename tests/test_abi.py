@@ -1,0 +1,75 @@
+"""CPU checks of the drop-in boundary: the C-ABI library loads, exports every symbol that
+include/vlbert_hip.h declares, and the ctypes signatures match the header prototypes.
+No compute calls (no GPU here)."""
+import importlib
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "vlbert_hip.h")
+
+
+def header_prototypes():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(?:int|const char\*)\s+(vlb_\w+)\s*\(([^)]*)\)\s*;", src):
+        name, args = m.group(1), m.group(2)
+        sig = ""
+        for a in [x.strip() for x in args.split(",") if x.strip() and x.strip() != "void"]:
+            if "vlb_stream_t" in a:
+                sig += "s"
+            elif "*" in a:
+                sig += "p"
+            elif re.match(r"(const\s+)?long\b", a):
+                sig += "l"
+            elif re.match(r"(const\s+)?uint32_t\b", a):
+                sig += "u"
+            elif re.match(r"(const\s+)?float\b", a):
+                sig += "f"
+            elif re.match(r"(const\s+)?int\b", a):
+                sig += "i"
+            else:
+                raise AssertionError("unparsed arg %r in %s" % (a, name))
+        protos[name] = sig
+    return protos
+
+
+def test_header_declares_expected_entry_points():
+    protos = header_prototypes()
+    assert len(protos) >= 25
+    for must in ("vlb_gemm_nt_bf16", "vlb_attention_fwd", "vlb_attention_bwd", "vlb_layernorm_fwd", "vlb_layernorm_bwd",
+                 "vlb_embed_fwd", "vlb_ce_fwd_bwd", "vlb_adamw_step", "vlb_roi_align_fwd", "vlb_roi_align_bwd"):
+        assert must in protos
+
+
+def test_ctypes_signatures_match_header():
+    lib = importlib.import_module("vl-bert_amd._lib")
+    protos = header_prototypes()
+    for name, sig in lib._SIGS.items():
+        assert name in protos, "binding %s has no prototype in include/vlbert_hip.h" % name
+        assert protos[name] == sig, "%s: header %s vs binding %s" % (name, protos[name], sig)
+    for name in protos:
+        assert name in lib._SIGS or name in ("vlb_last_error", "vlb_version", "vlb_device_info"), name
+
+
+def test_library_loads_and_exports_every_symbol():
+    lib = importlib.import_module("vl-bert_amd._lib")
+    if not os.path.isfile(lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    h = lib.load()
+    for name in header_prototypes():
+        assert hasattr(h, name), "libvlbert_hip.so does not export %s" % name
+    assert h.vlb_version() >= 100
+    assert isinstance(h.vlb_last_error(), bytes)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    lib = importlib.import_module("vl-bert_amd._lib")
+    monkeypatch.setattr(lib, "_lib", None)
+    monkeypatch.setattr(lib, "LIB_PATH", "/nonexistent/libvlbert_hip.so")
+    with pytest.raises(RuntimeError, match="no CPU / eager fallback"):
+        lib.load()

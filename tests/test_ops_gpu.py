@@ -1,0 +1,481 @@
+"""Per-kernel parity tests (-m gpu): every HIP kernel, called through the C ABI, against a plain
+PyTorch fp32 CPU statement of the same op on the same (bf16-rounded) inputs.
+
+Tolerances: outputs are bf16 (8-bit mantissa, 2^-8 relative per rounding) with fp32 accumulation,
+so the bar is  max|got-ref| <= atol + rtol*max|ref|  with rtol 1e-2 (north_star's bf16 bound);
+fp32 outputs (weight gradients, optimizer) use 2e-3 / 1e-5.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.gpu_util import bf, dev, drop_scale, drop_thr, keep_mask, pkg, report, to_gpu_bf16
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    o = pkg("ops")
+    name, cus = pkg("_lib").device_info(0)
+    print("device:", name, cus, "CUs")
+    assert name.startswith("gfx950"), "these kernels are built for gfx950 only (got %s)" % name
+    return o
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return bf(torch.randn(*shape, generator=g) * scale)
+
+
+# ------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 256, 128), (300, 200, 192), (3232, 768, 768), (101, 2304, 768),
+                                   (64, 1601, 128), (515, 64, 256)])
+def test_gemm_plain_bias(ops, M, N, K):
+    A, B = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05)
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(3))
+    ldc = (N + 63) // 64 * 64
+    C = torch.zeros((M, ldc), dtype=torch.bfloat16, device=dev())
+    ops.gemm_nt(to_gpu_bf16(A), to_gpu_bf16(B), C[:, :N], bias=bias.to(dev()))
+    ref = A @ B.t() + bias
+    report("gemm %dx%dx%d bias" % (M, N, K), C[:, :N], ref, 1e-3, 1e-2)
+    if ldc > N:
+        assert float(C[:, N:].float().abs().max()) == 0.0, "pad columns were written"
+
+
+def test_gemm_epilogues(ops):
+    M, N, K = 384, 320, 256
+    A, B = rnd(M, K, seed=4), rnd(N, K, seed=5, scale=0.08)
+    bias = 0.3 * torch.randn(N, generator=torch.Generator().manual_seed(6))
+    res, aux = rnd(M, N, seed=7), rnd(M, N, seed=8)
+    Ag, Bg, bg = to_gpu_bf16(A), to_gpu_bf16(B), bias.to(dev())
+    acc = A @ B.t()
+    # gelu + pre-activation
+    C = torch.empty((M, N), dtype=torch.bfloat16, device=dev())
+    pre = torch.empty_like(C)
+    ops.gemm_nt(Ag, Bg, C, bias=bg, act=ops.ACT_GELU, pre=pre)
+    u = acc + bias
+    report("gemm gelu pre", pre, u, 1e-3, 1e-2)
+    report("gemm gelu out", C, u * 0.5 * (1 + torch.erf(u / math.sqrt(2))), 1e-3, 1e-2)
+    # relu
+    ops.gemm_nt(Ag, Bg, C, bias=bg, act=ops.ACT_RELU)
+    report("gemm relu", C, torch.relu(u), 1e-3, 1e-2)
+    # dgelu: acc * gelu'(aux)
+    ops.gemm_nt(Ag, Bg, C, act=ops.ACT_DGELU, aux=to_gpu_bf16(aux))
+    cdf = 0.5 * (1 + torch.erf(aux / math.sqrt(2)))
+    pdf = torch.exp(-0.5 * aux * aux) / math.sqrt(2 * math.pi)
+    report("gemm dgelu", C, acc * (cdf + aux * pdf), 1e-3, 1e-2)
+    # bias + residual
+    ops.gemm_nt(Ag, Bg, C, bias=bg, res=to_gpu_bf16(res))
+    report("gemm bias+res", C, u + res, 1e-3, 1e-2)
+    # fp32 store
+    C32 = torch.empty((M, N), dtype=torch.float32, device=dev())
+    ops.gemm_nt(Ag, Bg, C32, out_mode=ops.OUT_F32)
+    report("gemm fp32 store", C32, acc, 1e-4, 1e-5)
+    # split-K atomic accumulate on top of existing contents
+    base = torch.randn(M, N, generator=torch.Generator().manual_seed(9))
+    for sk in (0, 1, 3, 4):
+        C32 = base.clone().to(dev())
+        ops.gemm_nt(Ag, Bg, C32, out_mode=ops.OUT_F32_ATOMIC, splitk=sk)
+        report("gemm atomic splitk=%d" % sk, C32, base + acc, 1e-4, 2e-5)
+
+
+def test_gemm_wgrad_shape(ops):
+    """dW[N,K] = dY^T[N,Mp] (X^T[K,Mp])^T through the transpose kernel, zero-padded reduction dim."""
+    M, N, K = 1000, 192, 320
+    Mp = (M + 63) // 64 * 64
+    dY, X = rnd(M, N, seed=10), rnd(M, K, seed=11)
+    dYt = torch.zeros((N, Mp), dtype=torch.bfloat16, device=dev())
+    Xt = torch.zeros((K, Mp), dtype=torch.bfloat16, device=dev())
+    db = torch.zeros((N,), dtype=torch.float32, device=dev())
+    ops.transpose(to_gpu_bf16(dY), dYt, colsum=db)
+    ops.transpose(to_gpu_bf16(X), Xt)
+    report("transpose", dYt[:, :M], dY.t(), 0, 0)
+    assert float(dYt[:, M:].float().abs().max()) == 0.0
+    report("transpose colsum", db, dY.sum(0), 1e-3, 1e-5)
+    dW = torch.zeros((N, K), dtype=torch.float32, device=dev())
+    ops.gemm_nt(dYt, Xt, dW, out_mode=ops.OUT_F32_ATOMIC)
+    report("wgrad via transposes", dW, dY.t() @ X, 1e-3, 2e-5)
+
+
+def test_gemm_dropout_and_ln_mask_agree(ops):
+    """The GEMM-epilogue dropout mask and the LayerNorm-backward dx_drop mask are the same function."""
+    M, N, K = 200, 256, 64
+    p, tag, seedv = 0.1, 7, 12345
+    seed = torch.tensor([seedv], dtype=torch.int32, device=dev())
+    A = torch.ones((M, K))
+    B = torch.ones((N, K)) / K
+    C = torch.empty((M, N), dtype=torch.bfloat16, device=dev())
+    ops.gemm_nt(to_gpu_bf16(A), to_gpu_bf16(B), C, drop_p=p, seed=seed, tag=tag)
+    thr = drop_thr(p)
+    keep = keep_mask(seedv, tag, np.arange(M * N), thr).reshape(M, N)
+    ref = torch.from_numpy(keep.astype(np.float32)) * drop_scale(thr)
+    report("gemm dropout mask (numpy RNG)", C, bf(ref), 1e-6, 0)
+    frac = keep.mean()
+    assert abs(frac - 0.9) < 0.01, frac
+    # LayerNorm backward with dx_drop: zero pattern must match
+    x = rnd(M, N, seed=13)
+    dy = rnd(M, N, seed=14)
+    stats = torch.empty((M, 2), dtype=torch.float32, device=dev())
+    gamma = torch.ones(N, device=dev())
+    y = torch.empty((M, N), dtype=torch.bfloat16, device=dev())
+    ops.layernorm_fwd(to_gpu_bf16(x), gamma, torch.zeros(N, device=dev()), y, stats)
+    dx = torch.empty_like(y)
+    dxd = torch.empty_like(y)
+    ops.layernorm_bwd(to_gpu_bf16(dy), to_gpu_bf16(x), stats, gamma, dx=dx, dx_drop=dxd, drop_p=p, seed=seed, tag=tag)
+    report("ln bwd dx_drop == dx*mask", dxd, bf(dx.float().cpu() * ref), 2e-2, 1e-2)
+
+
+# ------------------------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("rows,H", [(7, 128), (333, 768), (64, 1024), (5, 64)])
+def test_layernorm_fwd_bwd(ops, rows, H):
+    x = rnd(rows, H, seed=20, scale=2.0) + 0.5
+    g = torch.Generator().manual_seed(21)
+    gamma = 1 + 0.2 * torch.randn(H, generator=g)
+    beta = 0.1 * torch.randn(H, generator=g)
+    dy = rnd(rows, H, seed=22)
+    xr = x.clone().requires_grad_(True)
+    gr = gamma.clone().requires_grad_(True)
+    br = beta.clone().requires_grad_(True)
+    u = xr.mean(-1, keepdim=True)
+    s = (xr - u).pow(2).mean(-1, keepdim=True)
+    yr = gr * ((xr - u) / torch.sqrt(s + 1e-12)) + br
+    yr.backward(dy)
+    y = torch.empty((rows, H), dtype=torch.bfloat16, device=dev())
+    stats = torch.empty((rows, 2), dtype=torch.float32, device=dev())
+    ops.layernorm_fwd(to_gpu_bf16(x), gamma.to(dev()), beta.to(dev()), y, stats)
+    report("ln fwd %dx%d" % (rows, H), y, yr, 1e-3, 1e-2)
+    dx = torch.empty_like(y)
+    dg = torch.zeros(H, device=dev())
+    db = torch.zeros(H, device=dev())
+    acc = torch.zeros((rows, H), device=dev())
+    ops.layernorm_bwd(to_gpu_bf16(dy), to_gpu_bf16(x), stats, gamma.to(dev()), dx=dx, dx_acc=acc, dgamma=dg, dbeta=db)
+    report("ln bwd dx", dx, xr.grad, 1e-3, 1e-2)
+    report("ln bwd dx_acc(fp32)", acc, xr.grad, 1e-4, 1e-4)
+    report("ln bwd dgamma", dg, gr.grad, 1e-3, 1e-4)
+    report("ln bwd dbeta", db, br.grad, 1e-3, 1e-4)
+    # fp32 dy path
+    acc.zero_()
+    ops.layernorm_bwd(dy.to(dev()), to_gpu_bf16(x), stats, gamma.to(dev()), dx_acc=acc)
+    report("ln bwd (fp32 dy) dx_acc", acc, xr.grad, 1e-4, 1e-4)
+
+
+# ------------------------------------------------------------------------------------ attention
+def attn_ref(qkv, mask, B, S, H, nh, keep=None, scale_drop=1.0):
+    d = H // nh
+    q, k, v = [t.view(B, S, nh, d).permute(0, 2, 1, 3) for t in qkv.view(B, S, 3, H).unbind(2)]
+    sc = q @ k.transpose(-1, -2) / math.sqrt(d) + ((1 - mask) * -10000.0)[:, None, None, :]
+    p = torch.softmax(sc, -1)
+    lse = torch.logsumexp(sc, -1)
+    if keep is not None:
+        p = p * keep * scale_drop
+    ctx = (p @ v).permute(0, 2, 1, 3).reshape(B * S, H)
+    return ctx, lse
+
+
+@pytest.mark.parametrize("B,S,nh,p", [(2, 101, 2, 0.0), (3, 43, 1, 0.0), (1, 128, 3, 0.0), (2, 20, 2, 0.0), (2, 101, 2, 0.1),
+                                      (1, 65, 1, 0.25)])
+def test_attention_fwd_bwd(ops, B, S, nh, p):
+    H = nh * 64
+    qkv = rnd(B * S, 3 * H, seed=30, scale=1.0)
+    g = torch.Generator().manual_seed(31)
+    lens = torch.randint(max(1, S // 2), S + 1, (B,), generator=g)
+    lens[0] = S
+    mask = (torch.arange(S)[None, :] < lens[:, None]).float()
+    dctx = rnd(B * S, H, seed=32)
+    tag, seedv = 3, 777
+    keep = None
+    thr = drop_thr(p)
+    if p > 0:
+        idx = np.arange(B * nh * S * S)
+        keep = torch.from_numpy(keep_mask(seedv, tag, idx, thr).reshape(B, nh, S, S).astype(np.float32))
+    qr = qkv.clone().requires_grad_(True)
+    ctx_ref, lse_ref = attn_ref(qr, mask, B, S, H, nh, keep, drop_scale(thr))
+    ctx_ref.backward(dctx)
+    seed = torch.tensor([seedv], dtype=torch.int32, device=dev())
+    qg, mg = to_gpu_bf16(qkv), mask.to(dev())
+    ctx = torch.zeros((B * S, H), dtype=torch.bfloat16, device=dev())
+    lse = torch.zeros((B, nh, S), dtype=torch.float32, device=dev())
+    ops.attention_fwd(qg, mg, ctx, lse, B, S, H, nh, drop_p=p, seed=seed, tag=tag)
+    name = "attn B%d S%d h%d p%.2f" % (B, S, nh, p)
+    report(name + " lse", lse, lse_ref, 2e-3, 1e-3)
+    report(name + " ctx", ctx, ctx_ref, 2e-3, 1e-2)
+    dqkv = torch.zeros((B * S, 3 * H), dtype=torch.bfloat16, device=dev())
+    ops.attention_bwd(qg, mg, ctx, lse, to_gpu_bf16(dctx), dqkv, B, S, H, nh, drop_p=p, seed=seed, tag=tag)
+    gq = qr.grad
+    report(name + " dq", dqkv[:, :H], gq[:, :H], 2e-3, 2e-2)
+    report(name + " dk", dqkv[:, H:2 * H], gq[:, H:2 * H], 2e-3, 2e-2)
+    report(name + " dv", dqkv[:, 2 * H:], gq[:, 2 * H:], 2e-3, 2e-2)
+
+
+# ------------------------------------------------------------------------------------ embedding side
+def test_seq_layout_and_embedding(ops):
+    from oracle import vlbert_oracle as O
+    syn = pkg("synthetic")
+    cfg = O.VLBertConfig(hidden_size=128, num_hidden_layers=1, num_attention_heads=2, intermediate_size=256,
+                         vocab_size=512, max_position_embeddings=64, visual_region_classes=50)
+    B, T, R = 4, 12, 5
+    S = T + R + 1
+    H = cfg.hidden_size
+    boxes, im_info, text, rel, mlm_labels, mvrc_ops, mvrc_labels = syn.make_batch(B, T, R, vocab_size=512, region_classes=50,
+                                                                                  seed=3, ragged=True)
+    p = {k: bf(v) if v.dim() > 1 else v for k, v in O.init_params(cfg, seed=1).items()}
+    text_mask, box_mask = text > 0, boxes[:, :, 0] > -1.5
+    lay = ops.seq_layout(text_mask.to(dev()), box_mask.to(dev()), S)
+    tl = text_mask.sum(1)
+    no = box_mask.sum(1)
+    assert torch.equal(lay["text_len"].cpu().long(), tl) and torch.equal(lay["nobj"].cpu().long(), no)
+    am = (torch.arange(S)[None, :] <= (tl + no)[:, None]).float()
+    assert torch.equal(lay["attn_mask"].cpu(), am)
+    kinds = lay["code"].cpu() >> 16
+    for b in range(B):
+        exp = [1] * int(tl[b]) + [2] * int(no[b]) + [3] + [0] * (S - int(tl[b]) - int(no[b]) - 1)
+        assert kinds[b].tolist() == exp
+    # embedding forward vs the oracle (inputs: bf16-rounded visual parts)
+    g = torch.Generator().manual_seed(5)
+    text_vis_raw = bf(torch.randn(B, 1, H, generator=g))       # broadcast over tokens
+    obj_vis_raw = bf(torch.randn(B, R, H, generator=g))
+    obj_ling = bf(0.05 * torch.randn(B, R, H, generator=g))
+    tv = bf(O.bert_layer_norm(text_vis_raw, p["vlbert.visual_ln_text.weight"], p["vlbert.visual_ln_text.bias"]))
+    ov = bf(O.bert_layer_norm(obj_vis_raw, p["vlbert.visual_ln_object.weight"], p["vlbert.visual_ln_object.bias"]))
+    # reference: oracle embedding with identity visual LN (feed the already-normalised parts)
+    p_id = dict(p)
+    for nme in ("text", "object"):
+        p_id["vlbert.visual_ln_%s.weight" % nme] = torch.ones(H)
+        p_id["vlbert.visual_ln_%s.bias" % nme] = torch.zeros(H)
+
+    def ref_embed(tvv, ovv, olv, pp):
+        # bypass the visual LN: (x-u)/sqrt(s) of an arbitrary vector is not identity, so add directly
+        bs = B
+        vl_text = F.embedding(text, pp["vlbert.word_embeddings.weight"]) + tvv.expand(B, T, H)
+        vl_obj = olv + ovv
+        grid = torch.arange(S)[None, :].expand(bs, S)
+        te, oe = tl[:, None], (tl + no)[:, None]
+        is_t, is_o, is_e = grid < te, (grid >= te) & (grid < oe), grid == oe
+        vl = torch.zeros(bs, S, H)
+        vl[is_t] = vl_text[text_mask]
+        vl[is_o] = vl_obj[box_mask]
+        vl[is_e] = pp["vlbert.end_embedding.weight"][0]
+        typ = torch.zeros(bs, S, dtype=torch.long)
+        typ[is_o | is_e] = 2
+        pos = grid.clone()
+        pos[is_o] = te.expand(bs, S)[is_o]
+        pos[is_e] = (te + 1).squeeze(1)
+        pre = vl + F.embedding(pos, pp["vlbert.position_embeddings.weight"]) + F.embedding(typ, pp["vlbert.token_type_embeddings.weight"])
+        return pre, O.bert_layer_norm(pre, pp["vlbert.embedding_LayerNorm.weight"], pp["vlbert.embedding_LayerNorm.bias"])
+
+    leaves = {k: p[k].clone().requires_grad_(True) for k in
+              ("vlbert.word_embeddings.weight", "vlbert.end_embedding.weight", "vlbert.position_embeddings.weight",
+               "vlbert.token_type_embeddings.weight", "vlbert.embedding_LayerNorm.weight", "vlbert.embedding_LayerNorm.bias")}
+    tvr, ovr, olr = tv.clone().requires_grad_(True), ov.clone().requires_grad_(True), obj_ling.clone().requires_grad_(True)
+    pre_ref, out_ref = ref_embed(tvr, ovr, olr, {**p, **leaves})
+    dy = rnd(B, S, H, seed=6)
+    valid = am.unsqueeze(-1)
+    (out_ref * dy * valid).sum().backward()
+
+    d = dev()
+    pre = torch.empty((B * S, H), dtype=torch.bfloat16, device=d)
+    out = torch.empty_like(pre)
+    stats = torch.empty((B * S, 2), dtype=torch.float32, device=d)
+    gw = lambda k: to_gpu_bf16(p[k])
+    tvg, ovg, olg = to_gpu_bf16(tv.reshape(B, H)), to_gpu_bf16(ov.reshape(B * R, H)), to_gpu_bf16(obj_ling.reshape(B * R, H))
+    ops.embed_fwd(lay, text.to(d), None, gw("vlbert.word_embeddings.weight"), gw("vlbert.position_embeddings.weight"),
+                  gw("vlbert.token_type_embeddings.weight"), gw("vlbert.end_embedding.weight"), tvg, (H, 0), ovg, (R * H, H),
+                  olg, (R * H, H), None, p["vlbert.embedding_LayerNorm.weight"].to(d), p["vlbert.embedding_LayerNorm.bias"].to(d),
+                  pre, stats, out, B, T, R, S, H)
+    report("embed fwd pre", pre.view(B, S, H), pre_ref, 1e-3, 1e-2)
+    report("embed fwd out", out.view(B, S, H), out_ref, 2e-3, 1e-2)
+    # backward
+    V, P = cfg.vocab_size, cfg.max_position_embeddings
+    z = lambda *s: torch.zeros(s, dtype=torch.float32, device=d)
+    d_word, d_pos, d_type, d_end, d_g, d_b = z(V, H), z(P, H), z(3, H), z(1, H), z(H), z(H)
+    d_tv, d_ov, d_ol = z(B, H), z(B * R, H), z(B * R, H)
+    ops.embed_bwd(to_gpu_bf16((dy * valid).reshape(B * S, H)), pre, stats, p["vlbert.embedding_LayerNorm.weight"].to(d), lay,
+                  text.to(d), None, None, d_word, d_pos, d_type, d_end, d_g, d_b, d_tv, (H, 0), d_ov, (R * H, H), d_ol,
+                  (R * H, H), B, T, R, S, H)
+    report("embed bwd d_word", d_word, leaves["vlbert.word_embeddings.weight"].grad, 2e-3, 1e-2)
+    report("embed bwd d_pos", d_pos, leaves["vlbert.position_embeddings.weight"].grad, 2e-3, 1e-2)
+    report("embed bwd d_type", d_type, leaves["vlbert.token_type_embeddings.weight"].grad, 2e-3, 1e-2)
+    report("embed bwd d_end", d_end, leaves["vlbert.end_embedding.weight"].grad, 2e-3, 1e-2)
+    report("embed bwd d_gamma", d_g, leaves["vlbert.embedding_LayerNorm.weight"].grad, 2e-3, 1e-2)
+    report("embed bwd d_beta", d_b, leaves["vlbert.embedding_LayerNorm.bias"].grad, 2e-3, 1e-2)
+    report("embed bwd d_text_vis", d_tv, tvr.grad.reshape(B, H), 2e-3, 1e-2)
+    report("embed bwd d_obj_vis", d_ov, (ovr.grad * box_mask.unsqueeze(-1)).reshape(B * R, H), 2e-3, 1e-2)
+    report("embed bwd d_obj_ling", d_ol, (olr.grad * box_mask.unsqueeze(-1)).reshape(B * R, H), 2e-3, 1e-2)
+    # table mode for the linguistic part
+    table = bf(0.05 * torch.randn(2, H, generator=g))
+    sel = mvrc_ops.clone()
+    olt = table[sel]
+    pre_ref2, out_ref2 = ref_embed(tv, ov, olt, p)
+    ops.embed_fwd(lay, text.to(d), None, gw("vlbert.word_embeddings.weight"), gw("vlbert.position_embeddings.weight"),
+                  gw("vlbert.token_type_embeddings.weight"), gw("vlbert.end_embedding.weight"), tvg, (H, 0), ovg, (R * H, H),
+                  to_gpu_bf16(table), (0, 0), sel.to(d), p["vlbert.embedding_LayerNorm.weight"].to(d),
+                  p["vlbert.embedding_LayerNorm.bias"].to(d), pre, stats, out, B, T, R, S, H)
+    report("embed fwd (table mode)", out.view(B, S, H), out_ref2, 2e-3, 1e-2)
+
+
+def test_obj_prep(ops):
+    from oracle import vlbert_oracle as O
+    syn = pkg("synthetic")
+    B, R = 3, 6
+    boxes, im_info, text, rel, mlm_labels, mvrc_ops, mvrc_labels = syn.make_batch(B, 8, R, vocab_size=512, region_classes=10,
+                                                                                  seed=9, ragged=True)
+    mask_emb = torch.rand(2048, generator=torch.Generator().manual_seed(1))
+    out = torch.empty((B * R, 4096), dtype=torch.bfloat16, device=dev())
+    ops.obj_prep_fwd(boxes.to(dev()), im_info.to(dev()), mvrc_ops.to(dev()), mask_emb.to(dev()), out)
+    box_mask = boxes[:, :, 0] > -1.5
+    feats = boxes[:, :, 4:].clone()
+    feats[mvrc_ops == 1] = mask_emb
+    b6 = torch.cat((boxes[:, :, :4], im_info[:, None, :2].expand(B, R, 2)), -1).reshape(B * R, 6)
+    coord = O.coordinate_embeddings(b6, 256).reshape(B * R, 2048)
+    ref = torch.cat((coord, feats.reshape(B * R, 2048)), -1) * box_mask.reshape(B * R, 1)
+    report("obj_prep (coord || feature)", out, ref, 4e-3, 4e-3)
+
+
+def test_gather_combine_relu(ops):
+    B, T, R, H = 3, 6, 4, 64
+    S = T + R + 1
+    g = torch.Generator().manual_seed(2)
+    tm = torch.tensor([[1] * 6, [1] * 4 + [0] * 2, [1] * 5 + [0]], dtype=torch.bool)
+    om = torch.tensor([[1, 1, 1, 1], [1, 1, 0, 0], [1, 1, 1, 0]], dtype=torch.bool)
+    lay = ops.seq_layout(tm.to(dev()), om.to(dev()), S)
+    x = rnd(B * S, H, seed=3)
+    tout = torch.empty((B * T, H), dtype=torch.bfloat16, device=dev())
+    oout = torch.empty((B * R, H), dtype=torch.bfloat16, device=dev())
+    ops.gather_rows(to_gpu_bf16(x), lay["text_rows"].view(-1), tout)
+    ops.gather_rows(to_gpu_bf16(x), lay["obj_rows"].view(-1), oout)
+    xv = x.view(B, S, H)
+    report("gather text rows", tout.view(B, T, H), xv[:, :T], 0, 0)
+    ref_o = torch.zeros(B, R, H)
+    tl = tm.sum(1)
+    for b in range(B):
+        n = int(om[b].sum())
+        ref_o[b, :n] = xv[b, int(tl[b]):int(tl[b]) + n]
+    report("gather object rows", oout.view(B, R, H), ref_o, 0, 0)
+    dt, do = rnd(B * T, H, seed=4), rnd(B * R, H, seed=5)
+    dx = torch.empty((B * S, H), dtype=torch.bfloat16, device=dev())
+    ops.head_grad_combine(to_gpu_bf16(dt), to_gpu_bf16(do), lay["code"], dx, B, T, R, S, H)
+    ref = torch.zeros(B, S, H)
+    ref[:, :T] += dt.view(B, T, H)
+    for b in range(B):
+        n = int(om[b].sum())
+        ref[b, int(tl[b]):int(tl[b]) + n] += do.view(B, R, H)[b, :n]
+    report("head grad combine", dx.view(B, S, H), ref, 1e-6, 8e-3)
+    gsrc = torch.randn(B * R * H, generator=g)
+    y = rnd(B * R * H, seed=6)
+    o = torch.empty((B * R * H,), dtype=torch.bfloat16, device=dev())
+    ops.relu_bwd_cast(gsrc.to(dev()), to_gpu_bf16(y), o)
+    report("relu bwd cast", o, gsrc * (y > 0), 1e-6, 8e-3)
+
+
+# ------------------------------------------------------------------------------------ losses
+@pytest.mark.parametrize("rows,V,ld", [(37, 512, 512), (16, 30522, 30528), (9, 300, 304)])
+def test_ce_fwd_bwd(ops, rows, V, ld):
+    x = rnd(rows, V, seed=40, scale=2.0)
+    g = torch.Generator().manual_seed(41)
+    labels = torch.randint(0, V, (rows,), generator=g)
+    labels[torch.rand(rows, generator=g) < 0.5] = -1
+    labels[0] = V - 1
+    xr = x.clone().requires_grad_(True)
+    loss = F.cross_entropy(xr, labels, ignore_index=-1)
+    loss.backward()
+    buf = torch.full((rows, ld), 7.0, dtype=torch.bfloat16, device=dev())
+    buf[:, :V] = to_gpu_bf16(x)
+    counts = torch.zeros(1, device=dev())
+    lo = torch.zeros(1, device=dev())
+    cp = torch.zeros((rows, ld), dtype=torch.bfloat16, device=dev())
+    ops.ce_fwd_bwd(buf, V, labels.to(dev()), counts, lo, logits_copy=cp)
+    report("ce loss V=%d" % V, lo, loss.detach().reshape(1), 1e-4, 1e-3)
+    report("ce dlogits", buf[:, :V], xr.grad, 1e-5, 1e-2)
+    assert float(buf[:, V:].float().abs().max() if ld > V else 0.0) == 0.0
+    report("ce logits copy", cp[:, :V], x, 0, 0)
+    assert float(counts) == float((labels >= 0).sum())
+
+
+def test_soft_ce_fwd_bwd(ops):
+    from oracle import vlbert_oracle as O
+    rows, C, ld = 29, 1601, 1664
+    x = rnd(rows, C, seed=42, scale=2.0)
+    g = torch.Generator().manual_seed(43)
+    t = torch.softmax(torch.randn(rows, C, generator=g), -1)
+    t[torch.rand(rows, generator=g) < 0.4] = 0
+    t[1] = 0
+    t[2] = torch.softmax(torch.randn(C, generator=g), -1) * 1.05
+    xr = x.clone().requires_grad_(True)
+    loss = O.soft_cross_entropy(xr, t)
+    loss.backward()
+    buf = torch.full((rows, ld), 3.0, dtype=torch.bfloat16, device=dev())
+    buf[:, :C] = to_gpu_bf16(x)
+    counts, lo, tsum = torch.zeros(1, device=dev()), torch.zeros(1, device=dev()), torch.zeros(rows, device=dev())
+    ops.soft_ce_fwd_bwd(buf, C, t.to(dev()), tsum, counts, lo)
+    report("soft-ce loss", lo, loss.detach().reshape(1), 1e-4, 1e-3)
+    report("soft-ce dlogits", buf[:, :C], xr.grad, 1e-5, 1e-2)
+    assert float(buf[:, C:].float().abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------ optimizer
+def test_adamw_and_sumsq(ops):
+    from oracle import vlbert_oracle as O
+    n = 100003
+    g0 = torch.Generator().manual_seed(50)
+    p = torch.randn(n, generator=g0)
+    grads = [torch.randn(n, generator=g0) * 3 for _ in range(3)]
+    lr, wd, max_norm = 1e-3, 1e-2, 10.0
+    state = torch.tensor([lr, 0.9, 0.999, 1e-6, wd, 0.0, max_norm, 0.0], dtype=torch.float32, device=dev())
+    pg, m, v = p.clone().to(dev()), torch.zeros(n, device=dev()), torch.zeros(n, device=dev())
+    p16 = torch.empty(n, dtype=torch.bfloat16, device=dev())
+    pr, mr, vr = p.clone(), torch.zeros(n), torch.zeros(n)
+    for step, g in enumerate(grads, 1):
+        gg = g.to(dev())
+        ops.sumsq(gg, state[7:8])
+        if step == 1:
+            report("sumsq", state[7:8], (g.double() ** 2).sum().float().reshape(1), 0, 1e-5)
+        ops.adamw_step(pg, gg, m, v, p16, state)
+        coef = O.clip_coef(float(g.double().norm()), max_norm)
+        O.adamw_step(pr, g * coef, mr, vr, step, lr, eps=1e-6, weight_decay=wd)
+    report("adamw p after 3 steps", pg, pr, 1e-6, 1e-5)
+    report("adamw m", m, mr, 1e-6, 1e-5)
+    report("adamw v", v, vr, 1e-6, 1e-5)
+    report("adamw bf16 copy", p16, pr, 1e-6, 8e-3)
+    assert float(state[5]) == 3.0 and float(state[7]) == 0.0
+
+
+# ------------------------------------------------------------------------------------ ROIAlign
+@pytest.mark.parametrize("sr", [1, 2, 0, 3])
+def test_roi_align(ops, sr):
+    from oracle import roi_align_oracle as R
+    rng = np.random.RandomState(1)
+    x = rng.randn(2, 6, 12, 17).astype(np.float32)
+    rois = np.array([[0, 3.1, 2.2, 150.5, 120.0], [1, -20.0, -8.0, 90.0, 70.0], [1, 100.0, 60.0, 400.0, 300.0],
+                     [0, 10.0, 10.0, 10.5, 10.2], [1, 0, 0, 271.0, 191.0]], dtype=np.float32)
+    ph, pw, scale = 7, 5, 1.0 / 16
+    ref = R.roi_align_forward(x, rois, scale, ph, pw, sr)
+    out = torch.empty((rois.shape[0], 6, ph, pw), dtype=torch.float32, device=dev())
+    ops.roi_align_fwd(torch.from_numpy(x).to(dev()), torch.from_numpy(rois).to(dev()), out, scale, sr)
+    report("roi_align fwd sr=%d" % sr, out, torch.from_numpy(ref).float(), 1e-5, 1e-5)
+    dy = rng.randn(*ref.shape).astype(np.float32)
+    gref = R.roi_align_backward(dy, rois, scale, ph, pw, 2, 6, 12, 17, sr)
+    gin = torch.full((2, 6, 12, 17), 5.0, dtype=torch.float32, device=dev())
+    ops.roi_align_bwd(torch.from_numpy(dy).to(dev()), torch.from_numpy(rois).to(dev()), gin, scale, sr)
+    report("roi_align bwd sr=%d" % sr, gin, torch.from_numpy(gref).float(), 1e-5, 1e-5)
+
+
+def test_roi_align_debug_fixture(ops):
+    """The reference's own fixture (common/lib/roi_pooling/debug.py:10-11)."""
+    feature = torch.arange(81 * 2 * 3).view(2, 3, 9, 9).float().to(dev())
+    rois = torch.tensor([[0, 0, 0, 9, 9], [1, 0, 0, 9, 9], [1, 0, 0, 7, 7]], dtype=torch.float32, device=dev())
+    out = torch.empty((3, 3, 3, 3), dtype=torch.float32, device=dev())
+    ops.roi_align_fwd(feature, rois, out, 1.0, 1)
+    report("roi_align debug.py fixture", out[0, 0], torch.tensor([[15., 18, 21], [42, 45, 48], [69, 72, 75]]), 1e-5, 0)
+
+
+def test_error_path_raises(ops):
+    A = torch.zeros((64, 100), dtype=torch.bfloat16, device=dev())
+    C = torch.zeros((64, 64), dtype=torch.bfloat16, device=dev())
+    with pytest.raises(RuntimeError, match="multiple of 64"):
+        ops.gemm_nt(A[:, :96], A[:, :96], C, K=96)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.cast_f32_bf16(torch.zeros(4), torch.zeros(4, dtype=torch.bfloat16))

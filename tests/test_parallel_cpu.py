@@ -1,0 +1,82 @@
+"""CPU (gloo, world_size 2) tests of the data-parallel gradient exchange: bucket tiling, SUM semantics,
+and 1/world folded into the optimizer scale -- the multi-GPU path is RCCL with the same torch.distributed
+calls (backend "nccl")."""
+import importlib
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _layout():
+    E = importlib.import_module("vl-bert_amd.engine")
+    cfg = E.ModelConfig(hidden_size=64, num_hidden_layers=5, num_attention_heads=1, intermediate_size=128, vocab_size=300,
+                        max_position_embeddings=32, visual_region_classes=20)
+    shapes = E.param_layout(cfg)
+    offsets, off = {}, 0
+    import math
+    for n, s in shapes.items():
+        offsets[n] = off
+        off = E._ru(off + math.prod(s), 64)
+    return cfg, offsets, off
+
+
+def test_buckets_tile_the_flat_buffer():
+    P = importlib.import_module("vl-bert_amd.parallel")
+    cfg, offsets, numel = _layout()
+    for bucket_bytes in (1, 200_000, 1 << 30):
+        b = P.GradBuckets(torch.zeros(numel), offsets, numel, cfg.num_hidden_layers, bucket_bytes=bucket_bytes)
+        cov = b.coverage()
+        assert cov[0][0] == 0 and cov[-1][1] == numel
+        for (lo, hi), (lo2, hi2) in zip(cov[:-1], cov[1:]):
+            assert hi == lo2 and lo < hi
+        # every layer belongs to exactly one bucket that fires at-or-after its own completion
+        fired = sorted(b.layer_bucket)
+        assert fired[0] == 0
+
+
+def _worker(rank, world, port, numel_holder):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    P = importlib.import_module("vl-bert_amd.parallel")
+    cfg, offsets, numel = _layout()
+    g = torch.Generator().manual_seed(rank)
+    grad = torch.randn(numel, generator=g)
+    mine = grad.clone()
+    b = P.GradBuckets(grad, offsets, numel, cfg.num_hidden_layers, bucket_bytes=300_000)
+    # replay the engine's completion order
+    b.on_done("heads")
+    for l in reversed(range(cfg.num_hidden_layers)):
+        b.on_done(l)
+    b.on_done("embed")
+    b.wait()
+    others = [torch.randn(numel, generator=torch.Generator().manual_seed(r)) for r in range(world)]
+    expect = sum(others)
+    assert torch.allclose(grad, expect, atol=1e-5), (grad - expect).abs().max()
+    assert abs(b.grad_scale - 1.0 / world) < 1e-12
+    # bf16 wire format path
+    grad2 = mine.clone()
+    b2 = P.GradBuckets(grad2, offsets, numel, cfg.num_hidden_layers, wire_dtype=torch.bfloat16)
+    for what in ["heads"] + list(reversed(range(cfg.num_hidden_layers))) + ["embed"]:
+        b2.on_done(what)
+    b2.wait()
+    assert torch.allclose(grad2, expect, atol=0.05, rtol=0.02)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_gloo_world2():
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, None), nprocs=2, join=True)

@@ -1,0 +1,89 @@
+"""ctypes binding of the C-ABI library `libvlbert_hip.so` (include/vlbert_hip.h).
+
+There is deliberately NO fallback: if the library is missing or a call fails, a RuntimeError
+is raised (the reference's ops raise RuntimeError through AT_ASSERTM / AT_ERROR,
+common/lib/roi_pooling/cuda/ROIAlign_cuda.cu:263-264,297).  The product path never routes
+through PyTorch eager kernels or the CPU oracle.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvlbert_hip.so")
+
+_P, _L, _I, _F, _U = ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_float, ctypes.c_uint32
+
+# signature strings: p pointer | l long | i int | f float | u uint32 | s stream
+_SIGS = {
+    "vlb_gemm_nt_bf16": "plplpliiipiplplplfpuiis",
+    "vlb_transpose_bf16": "plpliips",
+    "vlb_layernorm_fwd": "plppplpiifs",
+    "vlb_layernorm_bwd": "pliplppplplfpuplppiis",
+    "vlb_attention_fwd": "ppppiiiifpus",
+    "vlb_attention_bwd": "ppppppiiiifpus",
+    "vlb_seq_layout": "ppiiiipppppps",
+    "vlb_obj_prep_fwd": "plppppiifpus",
+    "vlb_masked_colsum": "plpiipfpuuus",
+    "vlb_embed_fwd": "pppp" "pppp" "pll" "pll" "pll" "p" "pp" "ppp" "iiiiiii" "f" "fpu" "s",
+    "vlb_embed_bwd": "pppp" "ppppp" "pppppp" "pll" "pll" "pll" "iiiiiii" "fpu" "s",
+    "vlb_gather_rows": "pppiis",
+    "vlb_head_grad_combine": "ppppiiiiis",
+    "vlb_relu_bwd_cast": "pppls",
+    "vlb_dgelu_mul": "pppls",
+    "vlb_ce_fwd_bwd": "pliippfppls",
+    "vlb_soft_ce_fwd_bwd": "pliiplppfppls",
+    "vlb_sumsq_f32": "plps",
+    "vlb_adamw_step": "ppppplpfs",
+    "vlb_cast_f32_bf16": "ppls",
+    "vlb_cast_bf16_f32": "ppls",
+    "vlb_rng_advance": "ps",
+    "vlb_roi_align_fwd": "pppiiiiiifis",
+    "vlb_roi_align_bwd": "pppiiiiiiifis",
+}
+_CT = {"p": _P, "l": _L, "i": _I, "f": _F, "u": _U, "s": _P}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (idempotent).  Raises RuntimeError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise RuntimeError(
+            "libvlbert_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or vl-bert_amd/csrc/build.sh).  There is no CPU / eager fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.vlb_last_error.restype = ctypes.c_char_p
+    lib.vlb_last_error.argtypes = []
+    lib.vlb_version.restype = _I
+    lib.vlb_device_info.restype = _I
+    lib.vlb_device_info.argtypes = [_I, ctypes.c_char_p, _I]
+    for name, sig in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.restype = _I
+        fn.argtypes = [_CT[c] for c in sig]
+    _lib = lib
+    return lib
+
+
+def exported_names():
+    return ["vlb_last_error", "vlb_version", "vlb_device_info"] + sorted(_SIGS)
+
+
+def call(name, *args):
+    """Invoke an entry point; non-zero return -> RuntimeError(vlb_last_error())."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise RuntimeError("%s failed (%d): %s" % (name, rc, lib.vlb_last_error().decode()))
+
+
+def device_info(device=0):
+    lib = load()
+    buf = ctypes.create_string_buffer(64)
+    cus = lib.vlb_device_info(device, buf, 64)
+    if cus < 0:
+        raise RuntimeError("vlb_device_info failed: %s" % lib.vlb_last_error().decode())
+    return buf.value.decode(), cus

@@ -1,0 +1,593 @@
+// Embedding-side kernels of the VL-BERT hot path (gfx950, HBM-bound gather/scatter work):
+//   * vlb_seq_layout        - per-sample [text || objects || END || pad] layout from the masks
+//   * vlb_obj_prep_fwd      - FastRCNN precomputed branch input: coordinate sin/cos embedding ||
+//                             2048-d region feature (or the mask embedding) -> dropout -> bf16
+//   * vlb_embed_fwd / _bwd  - VisualLinguisticBert.embedding: word/type/position/visual sum,
+//                             seamless concatenation, embedding LayerNorm, dropout
+//   * vlb_gather_rows, vlb_head_grad_combine, vlb_relu_bwd_cast, vlb_masked_colsum - glue
+// Reference semantics: common/visual_linguistic_bert.py:173-241, common/fast_rcnn.py:136-187,
+// common/utils/bbox.py:33-65, pretrain/modules/resnet_vlbert_for_pretraining.py:106-142.
+#include "vlb_common.h"
+
+#define EMB_MAX_IT 8  // H <= 2048, 4 elements per lane per iteration
+
+enum { KIND_PAD = 0, KIND_TEXT = 1, KIND_OBJ = 2, KIND_END = 3 };
+
+// ------------------------------------------------------------------------------------------
+// layout: one thread block per sample; a single lane walks the (<= ~1k) mask entries.
+//   code[b,s] = kind<<16 | source index (t for text, r for object)
+//   text_rows[b,t] = b*S+t (VisualLinguisticBert.forward :152-154 slices [:, :T]),
+//   obj_rows[b,r]  = row of the r-th object if object_mask[b,r] else -1 (:155-157)
+// ------------------------------------------------------------------------------------------
+__global__ void seq_layout_kernel(const uint8_t* __restrict__ text_mask, const uint8_t* __restrict__ obj_mask, int B, int T, int R,
+                                  int S, int32_t* __restrict__ code, int32_t* __restrict__ text_len, int32_t* __restrict__ nobj,
+                                  int32_t* __restrict__ text_rows, int32_t* __restrict__ obj_rows, float* __restrict__ attn_mask) {
+  const int b = blockIdx.x;
+  if (threadIdx.x != 0) return;
+  int n = 0;
+  for (int t = 0; t < T; ++t)
+    if (text_mask[b * T + t]) code[b * S + n++] = (KIND_TEXT << 16) | t;
+  const int tl = n;
+  for (int r = 0; r < R; ++r) {
+    if (obj_mask[b * R + r]) {
+      obj_rows[b * R + r] = b * S + n;
+      code[b * S + n++] = (KIND_OBJ << 16) | r;
+    } else {
+      obj_rows[b * R + r] = -1;
+    }
+  }
+  const int no = n - tl;
+  code[b * S + n++] = (KIND_END << 16);
+  for (int s = n; s < S; ++s) code[b * S + s] = (KIND_PAD << 16);
+  for (int s = 0; s < S; ++s) attn_mask[b * S + s] = (s < n) ? 1.f : 0.f;
+  for (int t = 0; t < T; ++t) text_rows[b * T + t] = b * S + t;
+  text_len[b] = tl;
+  nobj[b] = no;
+}
+
+// ------------------------------------------------------------------------------------------
+// obj_prep: out[b*R+r][0:2048] = coordinate_embeddings(box, im w/h) ; [2048:4096] = feature
+// (common/fast_rcnn.py:165-175 + common/utils/bbox.py:33-65); mvrc_ops==1 rows take
+// object_mask_visual_embedding instead of the precomputed feature
+// (resnet_vlbert_for_pretraining.py:114-117); hard-coded Dropout(p) of obj_downsample.
+// One 256-thread block per region: 8 coord + 8 feature elements per thread, 16/32-B accesses.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void obj_prep_fwd_kernel(const float* __restrict__ boxes, long ldbox, const float* __restrict__ im_info,
+                                                           const int64_t* __restrict__ mvrc_ops, const float* __restrict__ mask_emb,
+                                                           bf16_t* __restrict__ out, int B, int R, uint32_t drop_thr, float drop_scale,
+                                                           const uint32_t* __restrict__ seedp, uint32_t tag) {
+  const int row = blockIdx.x;  // b*R + r
+  const int b = row / R;
+  const float* bx = boxes + (long)row * ldbox;
+  bf16_t* o = out + (long)row * 4096;
+  const int tid = threadIdx.x;
+  const uint32_t seed = (drop_thr && seedp) ? *seedp : 0u;
+  if (!(bx[0] > -1.5f)) {  // padded box (box_mask false): zero row, never consumed
+    *(uint4*)(o + tid * 8) = make_uint4(0, 0, 0, 0);
+    *(uint4*)(o + 2048 + tid * 8) = make_uint4(0, 0, 0, 0);
+    return;
+  }
+  const float W = im_info[b * 5 + 0], Hh = im_info[b * 5 + 1];
+  const float x1 = bx[0], y1 = bx[1], x2 = bx[2], y2 = bx[3];
+  float pos[4];
+  pos[0] = (x1 + x2) / 2 / W * 100;
+  pos[1] = (y1 + y2) / 2 / Hh * 100;
+  pos[2] = (x2 - x1) / W * 100;
+  pos[3] = (y2 - y1) / Hh * 100;
+  const bool masked = mvrc_ops && mvrc_ops[row] == 1;
+  const float* feat = masked ? mask_emb : (bx + 4);
+  // thread t owns elements [4t,4t+4) and [1024+4t, ..+4) of both the coordinate half and the
+  // feature half: every wave-level access is a contiguous 1 KiB (fp32 in) / 512 B (bf16 out) run.
+#pragma unroll
+  for (int part = 0; part < 2; ++part) {
+    const int e0 = part * 1024 + tid * 4;  // element within a 2048-wide half
+    float cv[4], fv[4];
+    {
+      // coordinate half: e -> which = e/512, j = e%512, sin for j<256 else cos, frequency index j%256
+      const int which = e0 >> 9, j0 = e0 & 511;
+      const bool is_cos = j0 >= 256;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float dim = powf(1000.0f, (float)((j0 & 255) + k) / 256.0f);
+        const float a = pos[which] / dim;
+        cv[k] = is_cos ? cosf(a) : sinf(a);
+      }
+      const float4 f = *(const float4*)(feat + e0);
+      fv[0] = f.x; fv[1] = f.y; fv[2] = f.z; fv[3] = f.w;
+    }
+    if (drop_thr) {
+      const uint32_t ic = (uint32_t)row * 4096u + (uint32_t)e0, ifeat = ic + 2048u;
+      const uint32_t h0 = vlb_rng_pair(seed, tag, ic >> 1), h1 = vlb_rng_pair(seed, tag, (ic >> 1) + 1);
+      const uint32_t g0 = vlb_rng_pair(seed, tag, ifeat >> 1), g1 = vlb_rng_pair(seed, tag, (ifeat >> 1) + 1);
+      cv[0] = ((h0 & 0xffffu) >= drop_thr) ? cv[0] * drop_scale : 0.f;
+      cv[1] = ((h0 >> 16) >= drop_thr) ? cv[1] * drop_scale : 0.f;
+      cv[2] = ((h1 & 0xffffu) >= drop_thr) ? cv[2] * drop_scale : 0.f;
+      cv[3] = ((h1 >> 16) >= drop_thr) ? cv[3] * drop_scale : 0.f;
+      fv[0] = ((g0 & 0xffffu) >= drop_thr) ? fv[0] * drop_scale : 0.f;
+      fv[1] = ((g0 >> 16) >= drop_thr) ? fv[1] * drop_scale : 0.f;
+      fv[2] = ((g1 & 0xffffu) >= drop_thr) ? fv[2] * drop_scale : 0.f;
+      fv[3] = ((g1 >> 16) >= drop_thr) ? fv[3] * drop_scale : 0.f;
+    }
+    *(uint2*)(o + e0) = make_uint2(pack2bf(cv[0], cv[1]), pack2bf(cv[2], cv[3]));
+    *(uint2*)(o + 2048 + e0) = make_uint2(pack2bf(fv[0], fv[1]), pack2bf(fv[2], fv[3]));
+  }
+}
+
+// colsum over rows r with sel[r]==1 of src[r][c] * dropmask(row, col_off + c):  dst[c] += ...
+// (gradient of object_mask_visual_embedding: sum over masked regions of dA[:, 2048:]).
+__global__ __launch_bounds__(256) void masked_colsum_kernel(const bf16_t* __restrict__ src, long lds, const int64_t* __restrict__ sel,
+                                                            int rows, int C, float* __restrict__ dst, uint32_t drop_thr,
+                                                            float drop_scale, const uint32_t* __restrict__ seedp, uint32_t tag,
+                                                            uint32_t row_elems, uint32_t col_off) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const uint32_t seed = (drop_thr && seedp) ? *seedp : 0u;
+  float s = 0.f;
+  for (int r = blockIdx.y; r < rows; r += gridDim.y) {
+    if (sel[r] != 1) continue;
+    float v = bf2f(src[(long)r * lds + c]);
+    if (drop_thr) v = vlb_keep(seed, tag, (uint32_t)r * row_elems + col_off + (uint32_t)c, drop_thr) ? v * drop_scale : 0.f;
+    s += v;
+  }
+  atomicAdd(dst + c, s);
+}
+
+// ------------------------------------------------------------------------------------------
+// embedding forward: one wave per output row (b,s).
+// ------------------------------------------------------------------------------------------
+struct EmbedParams {
+  const int32_t* code;        // [B,S]
+  const int32_t* text_len;    // [B]
+  const int64_t* text_ids;    // [B,T]
+  const int64_t* text_type;   // [B,T] or null (all 0)
+  const bf16_t* word_emb;     // [V,H]
+  const bf16_t* pos_emb;      // [P,H]
+  const bf16_t* type_emb;     // [3,H]
+  const bf16_t* end_emb;      // [1,H]
+  const bf16_t* text_vis; long tv_sb, tv_st;   // visual_ln_text output, strides (elements)
+  const bf16_t* obj_vis; long ov_sb, ov_sr;    // visual_ln_object output
+  const bf16_t* obj_ling; long ol_sb, ol_sr;   // dense linguistic part, or
+  const int64_t* obj_ling_idx;                 // [B,R] row selector into obj_ling (table mode, strides ignored)
+  const float* gamma; const float* beta;
+  bf16_t* pre;                // [M,H] pre-LN sum (saved for backward)
+  float* stats;               // [M,2]
+  bf16_t* out;                // [M,H]
+  int B, T, R, S, H, V, P;
+  float eps;
+  uint32_t drop_thr; float drop_scale; const uint32_t* seed; uint32_t tag;
+};
+
+__device__ __forceinline__ void add_row_bf16(const bf16_t* src, int H, int lane, float (*acc)[4]) {
+#pragma unroll
+  for (int i = 0; i < EMB_MAX_IT; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    if (c < H) {
+      const uint2 w = *(const uint2*)(src + c);
+      acc[i][0] += bflo(w.x); acc[i][1] += bfhi(w.x); acc[i][2] += bflo(w.y); acc[i][3] += bfhi(w.y);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const EmbedParams p) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= p.B * p.S) return;
+  const int b = row / p.S, s = row % p.S;
+  const int code = p.code[row], kind = code >> 16, idx = code & 0xffff;
+  const int tl = p.text_len[b];
+  const int H = p.H;
+  float acc[EMB_MAX_IT][4];
+#pragma unroll
+  for (int i = 0; i < EMB_MAX_IT; ++i) acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.f;
+  int type_id = 0, pos_id = s;  // pad rows: zeros + position s + type 0 (visual_linguistic_bert.py:210-227)
+  if (kind == KIND_TEXT) {
+    long id = p.text_ids[b * p.T + idx];
+    id = id < 0 ? 0 : (id >= p.V ? p.V - 1 : id);
+    add_row_bf16(p.word_emb + id * H, H, lane, acc);
+    add_row_bf16(p.text_vis + b * p.tv_sb + idx * p.tv_st, H, lane, acc);
+    type_id = p.text_type ? (int)p.text_type[b * p.T + idx] : 0;
+  } else if (kind == KIND_OBJ) {
+    add_row_bf16(p.obj_vis + b * p.ov_sb + idx * p.ov_sr, H, lane, acc);
+    if (p.obj_ling_idx)
+      add_row_bf16(p.obj_ling + (long)p.obj_ling_idx[b * p.R + idx] * H, H, lane, acc);
+    else
+      add_row_bf16(p.obj_ling + b * p.ol_sb + idx * p.ol_sr, H, lane, acc);
+    type_id = 2;
+    pos_id = tl;
+  } else if (kind == KIND_END) {
+    add_row_bf16(p.end_emb, H, lane, acc);
+    type_id = 2;
+    pos_id = tl + 1;
+  }
+  pos_id = min(pos_id, p.P - 1);
+  add_row_bf16(p.pos_emb + (long)pos_id * H, H, lane, acc);
+  add_row_bf16(p.type_emb + (long)type_id * H, H, lane, acc);
+
+  // the bf16-rounded sum is what backward re-reads, so normalise exactly that
+  bf16_t* pre = p.pre + (long)row * H;
+  float s1 = 0.f;
+#pragma unroll
+  for (int i = 0; i < EMB_MAX_IT; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    if (c < H) {
+      uint2 w = {pack2bf(acc[i][0], acc[i][1]), pack2bf(acc[i][2], acc[i][3])};
+      *(uint2*)(pre + c) = w;
+      acc[i][0] = bflo(w.x); acc[i][1] = bfhi(w.x); acc[i][2] = bflo(w.y); acc[i][3] = bfhi(w.y);
+      s1 += (acc[i][0] + acc[i][1]) + (acc[i][2] + acc[i][3]);
+    }
+  }
+  const float mean = wave_sum(s1) / (float)H;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < EMB_MAX_IT; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    if (c < H) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float d = acc[i][k] - mean;
+        q += d * d;
+      }
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)H + p.eps);
+  if (lane == 0) {
+    p.stats[2 * (long)row] = mean;
+    p.stats[2 * (long)row + 1] = rstd;
+  }
+  const uint32_t seed = (p.drop_thr && p.seed) ? *p.seed : 0u;
+  bf16_t* o = p.out + (long)row * H;
+#pragma unroll
+  for (int i = 0; i < EMB_MAX_IT; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    if (c < H) {
+      const float4 g = *(const float4*)(p.gamma + c);
+      const float4 be = *(const float4*)(p.beta + c);
+      float y[4] = {(acc[i][0] - mean) * rstd * g.x + be.x, (acc[i][1] - mean) * rstd * g.y + be.y,
+                    (acc[i][2] - mean) * rstd * g.z + be.z, (acc[i][3] - mean) * rstd * g.w + be.w};
+      if (p.drop_thr) {
+        const uint32_t e = (uint32_t)row * (uint32_t)H + (uint32_t)c;
+        const uint32_t h0 = vlb_rng_pair(seed, p.tag, e >> 1), h1 = vlb_rng_pair(seed, p.tag, (e >> 1) + 1);
+        y[0] = ((h0 & 0xffffu) >= p.drop_thr) ? y[0] * p.drop_scale : 0.f;
+        y[1] = ((h0 >> 16) >= p.drop_thr) ? y[1] * p.drop_scale : 0.f;
+        y[2] = ((h1 & 0xffffu) >= p.drop_thr) ? y[2] * p.drop_scale : 0.f;
+        y[3] = ((h1 >> 16) >= p.drop_thr) ? y[3] * p.drop_scale : 0.f;
+      }
+      uint2 w = {pack2bf(y[0], y[1]), pack2bf(y[2], y[3])};
+      *(uint2*)(o + c) = w;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// embedding backward: one block per sample, waves stride over its S rows.
+// Per row: dropout-mask dy, LayerNorm backward -> d (fp32, in registers) and then
+//   word_emb[id] / pos_emb[pos] / end_emb   : global fp32 atomics (few duplicates)
+//   type_emb[0..2], position row `text_len` shared by all objects, broadcast text-visual row,
+//   2-row linguistic table                     : accumulated in LDS, one flush per block
+//   d(visual parts)                            : d_text_vis / d_obj_vis fp32 rows
+// ------------------------------------------------------------------------------------------
+struct EmbedBwdParams {
+  const bf16_t* dy;  // [M,H]
+  const bf16_t* pre; const float* stats; const float* gamma;
+  const int32_t* code; const int32_t* text_len;
+  const int64_t* text_ids; const int64_t* text_type; const int64_t* obj_ling_idx;
+  float* d_word; float* d_pos; float* d_type; float* d_end; float* d_gamma; float* d_beta;
+  float* d_text_vis; long dtv_sb, dtv_st;  // dtv_st==0: per-sample sum (broadcast text_visual)
+  float* d_obj_vis; long dov_sb, dov_sr;   // plain stores
+  float* d_obj_ling; long dol_sb, dol_sr;  // table mode (obj_ling_idx): d_obj_ling is the [2,H] table grad
+  int B, T, R, S, H, V, P;
+  uint32_t drop_thr; float drop_scale; const uint32_t* seed; uint32_t tag;
+};
+
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const EmbedBwdParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int H = p.H;
+  float* l_type = lds;             // [3][H]
+  float* l_objpos = lds + 3 * H;   // [H]
+  float* l_tv = lds + 4 * H;       // [H]
+  float* l_tab = lds + 5 * H;      // [2][H]
+  float* l_g = lds + 7 * H;        // [H]
+  float* l_b = lds + 8 * H;        // [H]
+  for (int i = threadIdx.x; i < 9 * H; i += 256) lds[i] = 0.f;
+  __syncthreads();
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tl = p.text_len[b];
+  const uint32_t seed = (p.drop_thr && p.seed) ? *p.seed : 0u;
+  float gs[EMB_MAX_IT][4], bs[EMB_MAX_IT][4];
+#pragma unroll
+  for (int i = 0; i < EMB_MAX_IT; ++i)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) gs[i][k] = bs[i][k] = 0.f;
+
+  for (int s = wave; s < p.S; s += 4) {
+    const long row = (long)b * p.S + s;
+    const int code = p.code[row], kind = code >> 16, idx = code & 0xffff;
+    if (kind == KIND_PAD) continue;  // pad rows never reach a loss; their dy is exactly zero
+    const float mean = p.stats[2 * row], rstd = p.stats[2 * row + 1];
+    float xh[EMB_MAX_IT][4], g[EMB_MAX_IT][4];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < EMB_MAX_IT; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      if (c < H) {
+        const uint2 wx = *(const uint2*)(p.pre + row * H + c);
+        const uint2 wd = *(const uint2*)(p.dy + row * H + c);
+        float x[4] = {bflo(wx.x), bfhi(wx.x), bflo(wx.y), bfhi(wx.y)};
+        float d[4] = {bflo(wd.x), bfhi(wd.x), bflo(wd.y), bfhi(wd.y)};
+        if (p.drop_thr) {
+          const uint32_t e = (uint32_t)row * (uint32_t)H + (uint32_t)c;
+          const uint32_t h0 = vlb_rng_pair(seed, p.tag, e >> 1), h1 = vlb_rng_pair(seed, p.tag, (e >> 1) + 1);
+          d[0] = ((h0 & 0xffffu) >= p.drop_thr) ? d[0] * p.drop_scale : 0.f;
+          d[1] = ((h0 >> 16) >= p.drop_thr) ? d[1] * p.drop_scale : 0.f;
+          d[2] = ((h1 & 0xffffu) >= p.drop_thr) ? d[2] * p.drop_scale : 0.f;
+          d[3] = ((h1 >> 16) >= p.drop_thr) ? d[3] * p.drop_scale : 0.f;
+        }
+        const float4 gm = *(const float4*)(p.gamma + c);
+        const float gg[4] = {gm.x, gm.y, gm.z, gm.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          xh[i][k] = (x[k] - mean) * rstd;
+          gs[i][k] += d[k] * xh[i][k];
+          bs[i][k] += d[k];
+          g[i][k] = d[k] * gg[k];
+          s1 += g[i][k];
+          s2 += g[i][k] * xh[i][k];
+        }
+      }
+    }
+    s1 = wave_sum(s1) / (float)H;
+    s2 = wave_sum(s2) / (float)H;
+    // destinations
+    int type_id = 0, pos_id = s;
+    float* w_dst = nullptr;   // global atomic destination for the "linguistic" row
+    float* v_dst = nullptr;   // plain-store destination for the visual part
+    float* l_ling = nullptr;  // LDS accumulation for the linguistic part
+    bool tv_lds = false, pos_lds = false;
+    if (kind == KIND_TEXT) {
+      long id = p.text_ids[b * p.T + idx];
+      id = id < 0 ? 0 : (id >= p.V ? p.V - 1 : id);
+      w_dst = p.d_word + id * H;
+      type_id = p.text_type ? (int)p.text_type[b * p.T + idx] : 0;
+      if (p.d_text_vis) {
+        if (p.dtv_st == 0) tv_lds = true;
+        else v_dst = p.d_text_vis + b * p.dtv_sb + idx * p.dtv_st;
+      }
+    } else if (kind == KIND_OBJ) {
+      type_id = 2;
+      pos_lds = true;
+      if (p.d_obj_vis) v_dst = p.d_obj_vis + b * p.dov_sb + idx * p.dov_sr;
+      if (p.obj_ling_idx) l_ling = l_tab + (p.obj_ling_idx[b * p.R + idx] ? H : 0);
+    } else {  // END
+      type_id = 2;
+      pos_id = tl + 1;
+      w_dst = p.d_end;
+    }
+    pos_id = min(pos_id, p.P - 1);
+    float* pos_dst = p.d_pos + (long)pos_id * H;
+    float* dl_dst = (kind == KIND_OBJ && !p.obj_ling_idx && p.d_obj_ling) ? p.d_obj_ling + b * p.dol_sb + idx * p.dol_sr : nullptr;
+#pragma unroll
+    for (int i = 0; i < EMB_MAX_IT; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      if (c < H) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float d = rstd * (g[i][k] - s1 - xh[i][k] * s2);
+          atomicAdd(l_type + type_id * H + c + k, d);
+          if (pos_lds) atomicAdd(l_objpos + c + k, d);
+          else atomicAdd(pos_dst + c + k, d);
+          if (w_dst) atomicAdd(w_dst + c + k, d);
+          if (tv_lds) atomicAdd(l_tv + c + k, d);
+          if (l_ling) atomicAdd(l_ling + c + k, d);
+          if (v_dst) v_dst[c + k] = d;
+          if (dl_dst) dl_dst[c + k] = d;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < EMB_MAX_IT; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    if (c < H) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        atomicAdd(l_g + c + k, gs[i][k]);
+        atomicAdd(l_b + c + k, bs[i][k]);
+      }
+    }
+  }
+  __syncthreads();
+  const int pos_obj = min(tl, p.P - 1);
+  for (int c = threadIdx.x; c < H; c += 256) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+      if (l_type[t * H + c] != 0.f) atomicAdd(p.d_type + t * H + c, l_type[t * H + c]);
+    if (l_objpos[c] != 0.f) atomicAdd(p.d_pos + (long)pos_obj * H + c, l_objpos[c]);
+    if (p.d_text_vis && p.dtv_st == 0) p.d_text_vis[b * p.dtv_sb + c] = l_tv[c];
+    if (p.obj_ling_idx && p.d_obj_ling) {
+      if (l_tab[c] != 0.f) atomicAdd(p.d_obj_ling + c, l_tab[c]);
+      if (l_tab[H + c] != 0.f) atomicAdd(p.d_obj_ling + H + c, l_tab[H + c]);
+    }
+    atomicAdd(p.d_gamma + c, l_g[c]);
+    atomicAdd(p.d_beta + c, l_b[c]);
+  }
+}
+
+// out[i] = src[idx[i]] (idx<0 -> zeros); rows of H bf16.
+__global__ __launch_bounds__(256) void gather_rows_kernel(const bf16_t* __restrict__ src, const int32_t* __restrict__ idx, bf16_t* __restrict__ out,
+                                                          int n, int H) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= n) return;
+  const int r = idx[i];
+  for (int c = lane * 8; c < H; c += 512) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (r >= 0) v = *(const uint4*)(src + (long)r * H + c);
+    *(uint4*)(out + (long)i * H + c) = v;
+  }
+}
+
+// dX[b,s] = (s<T ? d_text[b,s] : 0) + (row (b,s) is the j-th object ? d_obj[b,j] : 0)
+// (inverse of the text/object split at common/visual_linguistic_bert.py:146-166).
+__global__ __launch_bounds__(256) void head_grad_combine_kernel(const bf16_t* __restrict__ d_text, const bf16_t* __restrict__ d_obj,
+                                                                const int32_t* __restrict__ code, bf16_t* __restrict__ dx, int B, int T,
+                                                                int R, int S, int H) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= B * S) return;
+  const int b = row / S, s = row % S;
+  const int c_ = code[row], kind = c_ >> 16, idx = c_ & 0xffff;
+  const bf16_t* t = (s < T && d_text) ? d_text + ((long)b * T + s) * H : nullptr;
+  const bf16_t* o = (kind == KIND_OBJ && d_obj) ? d_obj + ((long)b * R + idx) * H : nullptr;
+  for (int c = lane * 4; c < H; c += 256) {
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (t) {
+      const uint2 w = *(const uint2*)(t + c);
+      v[0] += bflo(w.x); v[1] += bfhi(w.x); v[2] += bflo(w.y); v[3] += bfhi(w.y);
+    }
+    if (o) {
+      const uint2 w = *(const uint2*)(o + c);
+      v[0] += bflo(w.x); v[1] += bfhi(w.x); v[2] += bflo(w.y); v[3] += bfhi(w.y);
+    }
+    uint2 w = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+    *(uint2*)(dx + (long)row * H + c) = w;
+  }
+}
+
+// out_bf16[i] = (y[i] > 0) ? g_f32[i] : 0      (ReLU backward of obj_downsample + fp32->bf16)
+__global__ void relu_bwd_cast_kernel(const float* __restrict__ g, const bf16_t* __restrict__ y, bf16_t* __restrict__ out, long n) {
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  const float4 gv = *(const float4*)(g + i);
+  const uint2 w = *(const uint2*)(y + i);
+  uint2 o = {pack2bf(bflo(w.x) > 0.f ? gv.x : 0.f, bfhi(w.x) > 0.f ? gv.y : 0.f),
+             pack2bf(bflo(w.y) > 0.f ? gv.z : 0.f, bfhi(w.y) > 0.f ? gv.w : 0.f)};
+  *(uint2*)(out + i) = o;
+}
+
+// out = dG * gelu'(U)   (GELU backward where no GEMM epilogue is available: MLM transform, whose
+// LayerNorm sits between the activation and the next GEMM -- modeling.py:448-452)
+__global__ void dgelu_mul_kernel(const bf16_t* __restrict__ dg, const bf16_t* __restrict__ u, bf16_t* __restrict__ out, long n) {
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  const uint2 a = *(const uint2*)(dg + i), b = *(const uint2*)(u + i);
+  uint2 o = {pack2bf(bflo(a.x) * dgelu_f(bflo(b.x)), bfhi(a.x) * dgelu_f(bfhi(b.x))),
+             pack2bf(bflo(a.y) * dgelu_f(bflo(b.y)), bfhi(a.y) * dgelu_f(bfhi(b.y)))};
+  *(uint2*)(out + i) = o;
+}
+
+// ---------------------------------------------------------------------------------- C ABI
+extern "C" int vlb_seq_layout(const uint8_t* text_mask, const uint8_t* obj_mask, int B, int T, int R, int S, int32_t* code,
+                              int32_t* text_len, int32_t* nobj, int32_t* text_rows, int32_t* obj_rows, float* attn_mask,
+                              hipStream_t stream) {
+  VLB_CHECK_ARG(B > 0 && T > 0 && R >= 0 && S >= T + R + 1, "vlb_seq_layout: need S >= T+R+1 (B=%d T=%d R=%d S=%d)", B, T, R, S);
+  VLB_CHECK_ARG(T < 65536 && R < 65536, "vlb_seq_layout: T/R too large");
+  hipLaunchKernelGGL(seq_layout_kernel, dim3(B), dim3(64), 0, stream, text_mask, obj_mask, B, T, R, S, code, text_len, nobj,
+                     text_rows, obj_rows, attn_mask);
+  VLB_CHECK_LAUNCH("vlb_seq_layout");
+  return VLB_OK;
+}
+
+extern "C" int vlb_obj_prep_fwd(const float* boxes, long ldbox, const float* im_info, const int64_t* mvrc_ops,
+                                const float* mask_emb, void* out, int B, int R, float drop_p, const uint32_t* seed, uint32_t tag,
+                                hipStream_t stream) {
+  if (B * R <= 0) return VLB_OK;
+  VLB_CHECK_ARG(ldbox >= 4 + 2048 && (ldbox % 4) == 0, "vlb_obj_prep_fwd: ldbox=%ld must be >= 2052 and a multiple of 4", ldbox);
+  VLB_CHECK_ARG(!(drop_p > 0.f) || seed, "vlb_obj_prep_fwd: dropout needs a device seed pointer");
+  const uint32_t thr = vlb_drop_thr(drop_p);
+  hipLaunchKernelGGL(obj_prep_fwd_kernel, dim3(B * R), dim3(256), 0, stream, boxes, ldbox, im_info, mvrc_ops, mask_emb, (bf16_t*)out,
+                     B, R, thr, vlb_drop_scale(thr), seed, tag);
+  VLB_CHECK_LAUNCH("vlb_obj_prep_fwd");
+  return VLB_OK;
+}
+
+extern "C" int vlb_masked_colsum(const void* src, long lds_, const int64_t* sel, int rows, int C, float* dst, float drop_p,
+                                 const uint32_t* seed, uint32_t tag, uint32_t row_elems, uint32_t col_off, hipStream_t stream) {
+  if (rows <= 0 || C <= 0) return VLB_OK;
+  const uint32_t thr = vlb_drop_thr(drop_p);
+  int gy = rows < 64 ? rows : 64;
+  hipLaunchKernelGGL(masked_colsum_kernel, dim3(vlb_cdiv(C, 256), gy), dim3(256), 0, stream, (const bf16_t*)src, lds_, sel, rows, C,
+                     dst, thr, vlb_drop_scale(thr), seed, tag, row_elems, col_off);
+  VLB_CHECK_LAUNCH("vlb_masked_colsum");
+  return VLB_OK;
+}
+
+extern "C" int vlb_embed_fwd(const int32_t* code, const int32_t* text_len, const int64_t* text_ids, const int64_t* text_type,
+                             const void* word_emb, const void* pos_emb, const void* type_emb, const void* end_emb,
+                             const void* text_vis, long tv_sb, long tv_st, const void* obj_vis, long ov_sb, long ov_sr,
+                             const void* obj_ling, long ol_sb, long ol_sr, const int64_t* obj_ling_idx, const float* gamma,
+                             const float* beta, void* pre, float* stats, void* out, int B, int T, int R, int S, int H, int V,
+                             int P, float eps, float drop_p, const uint32_t* seed, uint32_t tag, hipStream_t stream) {
+  VLB_CHECK_ARG(H > 0 && (H % 4) == 0 && H <= 256 * EMB_MAX_IT, "vlb_embed_fwd: unsupported H=%d", H);
+  VLB_CHECK_ARG(code && text_len && text_ids && word_emb && pos_emb && type_emb && end_emb && text_vis && obj_vis && obj_ling,
+                "vlb_embed_fwd: null input");
+  VLB_CHECK_ARG(!(drop_p > 0.f) || seed, "vlb_embed_fwd: dropout needs a device seed pointer");
+  EmbedParams p;
+  p.code = code; p.text_len = text_len; p.text_ids = text_ids; p.text_type = text_type;
+  p.word_emb = (const bf16_t*)word_emb; p.pos_emb = (const bf16_t*)pos_emb; p.type_emb = (const bf16_t*)type_emb;
+  p.end_emb = (const bf16_t*)end_emb;
+  p.text_vis = (const bf16_t*)text_vis; p.tv_sb = tv_sb; p.tv_st = tv_st;
+  p.obj_vis = (const bf16_t*)obj_vis; p.ov_sb = ov_sb; p.ov_sr = ov_sr;
+  p.obj_ling = (const bf16_t*)obj_ling; p.ol_sb = ol_sb; p.ol_sr = ol_sr; p.obj_ling_idx = obj_ling_idx;
+  p.gamma = gamma; p.beta = beta; p.pre = (bf16_t*)pre; p.stats = stats; p.out = (bf16_t*)out;
+  p.B = B; p.T = T; p.R = R; p.S = S; p.H = H; p.V = V; p.P = P; p.eps = eps;
+  p.drop_thr = vlb_drop_thr(drop_p); p.drop_scale = vlb_drop_scale(p.drop_thr); p.seed = seed; p.tag = tag;
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3(vlb_cdiv((long)B * S, 4)), dim3(256), 0, stream, p);
+  VLB_CHECK_LAUNCH("vlb_embed_fwd");
+  return VLB_OK;
+}
+
+extern "C" int vlb_embed_bwd(const void* dy, const void* pre, const float* stats, const float* gamma, const int32_t* code,
+                             const int32_t* text_len, const int64_t* text_ids, const int64_t* text_type,
+                             const int64_t* obj_ling_idx, float* d_word, float* d_pos, float* d_type, float* d_end,
+                             float* d_gamma, float* d_beta, float* d_text_vis, long dtv_sb, long dtv_st, float* d_obj_vis,
+                             long dov_sb, long dov_sr, float* d_obj_ling, long dol_sb, long dol_sr, int B, int T, int R, int S,
+                             int H, int V, int P, float drop_p, const uint32_t* seed, uint32_t tag, hipStream_t stream) {
+  VLB_CHECK_ARG(H > 0 && (H % 4) == 0 && H <= 256 * EMB_MAX_IT, "vlb_embed_bwd: unsupported H=%d", H);
+  VLB_CHECK_ARG(dy && pre && stats && gamma && code && text_len && text_ids && d_word && d_pos && d_type && d_end && d_gamma &&
+                    d_beta, "vlb_embed_bwd: null input");
+  VLB_CHECK_ARG(!(drop_p > 0.f) || seed, "vlb_embed_bwd: dropout needs a device seed pointer");
+  EmbedBwdParams p;
+  p.dy = (const bf16_t*)dy; p.pre = (const bf16_t*)pre; p.stats = stats; p.gamma = gamma; p.code = code; p.text_len = text_len;
+  p.text_ids = text_ids; p.text_type = text_type; p.obj_ling_idx = obj_ling_idx;
+  p.d_word = d_word; p.d_pos = d_pos; p.d_type = d_type; p.d_end = d_end; p.d_gamma = d_gamma; p.d_beta = d_beta;
+  p.d_text_vis = d_text_vis; p.dtv_sb = dtv_sb; p.dtv_st = dtv_st;
+  p.d_obj_vis = d_obj_vis; p.dov_sb = dov_sb; p.dov_sr = dov_sr;
+  p.d_obj_ling = d_obj_ling; p.dol_sb = dol_sb; p.dol_sr = dol_sr;
+  p.B = B; p.T = T; p.R = R; p.S = S; p.H = H; p.V = V; p.P = P;
+  p.drop_thr = vlb_drop_thr(drop_p); p.drop_scale = vlb_drop_scale(p.drop_thr); p.seed = seed; p.tag = tag;
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(B), dim3(256), 9 * H * sizeof(float), stream, p);
+  VLB_CHECK_LAUNCH("vlb_embed_bwd");
+  return VLB_OK;
+}
+
+extern "C" int vlb_gather_rows(const void* src, const int32_t* idx, void* out, int n, int H, hipStream_t stream) {
+  if (n <= 0) return VLB_OK;
+  VLB_CHECK_ARG((H % 8) == 0, "vlb_gather_rows: H must be a multiple of 8");
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(vlb_cdiv(n, 4)), dim3(256), 0, stream, (const bf16_t*)src, idx, (bf16_t*)out, n, H);
+  VLB_CHECK_LAUNCH("vlb_gather_rows");
+  return VLB_OK;
+}
+
+extern "C" int vlb_head_grad_combine(const void* d_text, const void* d_obj, const int32_t* code, void* dx, int B, int T, int R,
+                                     int S, int H, hipStream_t stream) {
+  VLB_CHECK_ARG((H % 4) == 0, "vlb_head_grad_combine: H must be a multiple of 4");
+  hipLaunchKernelGGL(head_grad_combine_kernel, dim3(vlb_cdiv((long)B * S, 4)), dim3(256), 0, stream, (const bf16_t*)d_text,
+                     (const bf16_t*)d_obj, code, (bf16_t*)dx, B, T, R, S, H);
+  VLB_CHECK_LAUNCH("vlb_head_grad_combine");
+  return VLB_OK;
+}
+
+extern "C" int vlb_relu_bwd_cast(const float* g, const void* y, void* out, long n, hipStream_t stream) {
+  if (n <= 0) return VLB_OK;
+  VLB_CHECK_ARG((n % 4) == 0, "vlb_relu_bwd_cast: n must be a multiple of 4");
+  hipLaunchKernelGGL(relu_bwd_cast_kernel, dim3(vlb_cdiv(n / 4, 256)), dim3(256), 0, stream, g, (const bf16_t*)y, (bf16_t*)out, n);
+  VLB_CHECK_LAUNCH("vlb_relu_bwd_cast");
+  return VLB_OK;
+}
+
+extern "C" int vlb_dgelu_mul(const void* dg, const void* u, void* out, long n, hipStream_t stream) {
+  if (n <= 0) return VLB_OK;
+  VLB_CHECK_ARG((n % 4) == 0, "vlb_dgelu_mul: n must be a multiple of 4");
+  hipLaunchKernelGGL(dgelu_mul_kernel, dim3(vlb_cdiv(n / 4, 256)), dim3(256), 0, stream, (const bf16_t*)dg, (const bf16_t*)u,
+                     (bf16_t*)out, n);
+  VLB_CHECK_LAUNCH("vlb_dgelu_mul");
+  return VLB_OK;
+}

@@ -1,0 +1,319 @@
+// bf16 "NT" GEMM for gfx950 (CDNA4):   C[M,N] (+)= A[M,K] · B[N,K]^T   (fp32 accumulate)
+//
+// Every matmul on the VL-BERT hot path is brought to this form by the host:
+//   forward   Y  = X · W^T            (torch Linear weights are [out,in] = [N,K])
+//   dgrad     dX = dY · (W^T)^T       (a bf16 W^T copy is kept next to W)
+//   wgrad     dW = dY^T · (X^T)^T     (reduction over the M rows; split-K + fp32 atomics)
+// (replaces the cuBLAS calls behind nn.Linear / torch.matmul in
+//  external/pytorch_pretrained_bert/modeling.py:291-300,312,330,362,375,469.)
+//
+// Kernel structure (see DESIGN.md "GEMM"):
+//   * 256 threads = 4 waves (2x2), block tile BMxBN (128x128 or 128x64), BK = 64;
+//   * both operand tiles are staged HBM -> LDS with `global_load_lds_dwordx4` (LDS-DMA,
+//     16 B/lane, no VGPR round trip), double buffered, one barrier per K tile;
+//   * LDS image is [row][64 bf16] = 128-B rows; the 16-B slot of logical k-chunk kc of row r is
+//     kc ^ ((r>>1)&7)  (XOR swizzle applied on the *source* address because the LDS-DMA
+//     destination is lane-linear) -> ds_read_b128 fragment reads are bank-conflict free;
+//   * v_mfma_f32_16x16x32_bf16 with the operands swapped (weights as the "A" operand) so
+//     each lane ends up with 4 consecutive output columns of one row -> 8-B bf16 / 16-B
+//     fp32 epilogue accesses;
+//   * fused epilogue: +bias, erf-GELU (optionally also storing the pre-activation), ReLU,
+//     x gelu'(aux) (GELU backward), dropout (counter RNG), +residual, bf16 or fp32 store,
+//     fp32 atomic accumulation for split-K weight gradients.
+#include "vlb_common.h"
+
+struct GemmParams {
+  const bf16_t* A; long lda;
+  const bf16_t* B; long ldb;
+  int M, N, K;
+  int k_per_split;           // K range handled by one blockIdx.y slice (multiple of 64)
+  const float* bias;         // [N] fp32 or null
+  int act;                   // 0 none, 1 gelu, 2 relu, 3 multiply by gelu'(aux)
+  const bf16_t* aux; long ldaux;
+  bf16_t* pre; long ldpre;   // optional pre-activation output (act==1)
+  const bf16_t* res; long ldres;
+  uint32_t drop_thr; float drop_scale; const uint32_t* seed; uint32_t tag;
+  void* C; long ldc;
+  int out_f32;               // 0: bf16 store, 1: fp32 store, 2: fp32 atomicAdd
+  int ntm, ntn;
+};
+
+#define GLDS_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const GemmParams p) {
+  constexpr int BK = 64;
+  constexpr int WM = BM / 2, WN = BN / 2;
+  constexpr int FM = WM / 16, FN = WN / 16;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // XCD-aware tile order: block b runs on XCD b%8; give each XCD a contiguous run of tiles so
+  // tiles sharing an A panel hit the same L2 (bijective for any tile count).
+  const int nt = p.ntm * p.ntn;
+  int t;
+  {
+    const int b = blockIdx.x, xcd = b & 7, q = nt >> 3, r = nt & 7;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  }
+  const int tile_m = t / p.ntn, tile_n = t % p.ntn;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int k_begin = blockIdx.y * p.k_per_split;
+  const int k_end = min(p.K, k_begin + p.k_per_split);
+  const int ntk = (k_end - k_begin) / BK;
+
+  // ---- per-thread staging addresses (16-B chunks; chunk P -> LDS byte 16*P) ----
+  // P = it*256 + tid ; row r = P>>3 ; physical slot s = P&7 ; logical k-chunk kc = s ^ ((r>>1)&7)
+  const bf16_t* a_src[BM / 32];
+  const bf16_t* b_src[BN / 32];
+#pragma unroll
+  for (int it = 0; it < BM / 32; ++it) {
+    const int P = it * 256 + tid, r = P >> 3, kc = (P & 7) ^ ((r >> 1) & 7);
+    a_src[it] = p.A + (long)min(m0 + r, p.M - 1) * p.lda + k_begin + kc * 8;
+  }
+#pragma unroll
+  for (int it = 0; it < BN / 32; ++it) {
+    const int P = it * 256 + tid, r = P >> 3, kc = (P & 7) ^ ((r >> 1) & 7);
+    b_src[it] = p.B + (long)min(n0 + r, p.N - 1) * p.ldb + k_begin + kc * 8;
+  }
+
+  auto stage = [&](int buf, int kt) {
+    char* sa = smem + buf * STAGE;
+    char* sb = sa + A_BYTES;
+    const int koff = kt * BK;
+#pragma unroll
+    for (int it = 0; it < BM / 32; ++it)
+      __builtin_amdgcn_global_load_lds(GLDS_PTR(a_src[it] + koff), LDS_PTR(sa + (it * 256 + wave * 64) * 16), 16, 0, 0);
+#pragma unroll
+    for (int it = 0; it < BN / 32; ++it)
+      __builtin_amdgcn_global_load_lds(GLDS_PTR(b_src[it] + koff), LDS_PTR(sb + (it * 256 + wave * 64) * 16), 16, 0, 0);
+  };
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // fragment read offsets: row = (wave tile row) + f*16 + (lane&15); (row>>1)&7 == (lane&15)>>1
+  const int frow = lane & 15;
+  const int c0 = (((lane >> 4) ^ (frow >> 1)) << 4);  // k-step 0; k-step 1 is c0 ^ 64
+  const int a_off = (wm * WM + frow) * 128 + c0;
+  const int b_off = (wn * WN + frow) * 128 + c0;
+
+  if (ntk > 0) {
+    stage(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < ntk; ++kt) {
+      const int cur = kt & 1;
+      if (kt + 1 < ntk) stage(cur ^ 1, kt + 1);
+      const char* sa = smem + cur * STAGE;
+      const char* sb = sa + A_BYTES;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 af[FM], bfr[FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) af[i] = *(const bf16x8*)(sa + ((a_off + i * 16 * 128) ^ (ks * 64)));
+#pragma unroll
+        for (int j = 0; j < FN; ++j) bfr[j] = *(const bf16x8*)(sb + ((b_off + j * 16 * 128) ^ (ks * 64)));
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+      }
+      __syncthreads();  // next stage landed (hipcc drains the LDS-DMA queue here) + WAR on `cur`
+    }
+  }
+
+  // ---- epilogue: lane holds C[m][n..n+3], m = .. + (lane&15), n = .. + 4*(lane>>4) ----
+  const uint32_t seed = (p.drop_thr && p.seed) ? *p.seed : 0u;
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const int m = m0 + wm * WM + i * 16 + (lane & 15);
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int n = n0 + wn * WN + j * 16 + 4 * (lane >> 4);
+      if (n >= p.N) continue;
+      const bool full = (n + 3 < p.N);
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if (p.bias) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += (full || n + r < p.N) ? p.bias[n + r] : 0.f;
+      }
+      if (p.act == 1) {
+        if (p.pre) {
+          if (full) {
+            uint2 w = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+            *(uint2*)(p.pre + (long)m * p.ldpre + n) = w;
+          } else {
+            for (int r = 0; r < 4 && n + r < p.N; ++r) p.pre[(long)m * p.ldpre + n + r] = f2bf(v[r]);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
+      } else if (p.act == 2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+      } else if (p.act == 3) {
+        float u[4];
+        if (full) {
+          const uint2 w = *(const uint2*)(p.aux + (long)m * p.ldaux + n);
+          u[0] = bflo(w.x); u[1] = bfhi(w.x); u[2] = bflo(w.y); u[3] = bfhi(w.y);
+        } else {
+          for (int r = 0; r < 4; ++r) u[r] = (n + r < p.N) ? bf2f(p.aux[(long)m * p.ldaux + n + r]) : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= dgelu_f(u[r]);
+      }
+      if (p.drop_thr) {
+        const uint32_t idx = (uint32_t)m * (uint32_t)p.N + (uint32_t)n;  // n%4==0 -> pairs (idx, idx+1), (idx+2, idx+3)
+        const uint32_t h0 = vlb_rng_pair(seed, p.tag, idx >> 1), h1 = vlb_rng_pair(seed, p.tag, (idx >> 1) + 1);
+        if ((idx & 1u) == 0) {
+          v[0] = ((h0 & 0xffffu) >= p.drop_thr) ? v[0] * p.drop_scale : 0.f;
+          v[1] = ((h0 >> 16) >= p.drop_thr) ? v[1] * p.drop_scale : 0.f;
+          v[2] = ((h1 & 0xffffu) >= p.drop_thr) ? v[2] * p.drop_scale : 0.f;
+          v[3] = ((h1 >> 16) >= p.drop_thr) ? v[3] * p.drop_scale : 0.f;
+        } else {  // odd N: fall back to the scalar definition
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = vlb_keep(seed, p.tag, idx + r, p.drop_thr) ? v[r] * p.drop_scale : 0.f;
+        }
+      }
+      if (p.res) {
+        if (full) {
+          const uint2 w = *(const uint2*)(p.res + (long)m * p.ldres + n);
+          v[0] += bflo(w.x); v[1] += bfhi(w.x); v[2] += bflo(w.y); v[3] += bfhi(w.y);
+        } else {
+          for (int r = 0; r < 4 && n + r < p.N; ++r) v[r] += bf2f(p.res[(long)m * p.ldres + n + r]);
+        }
+      }
+      if (p.out_f32 == 0) {
+        bf16_t* c = (bf16_t*)p.C + (long)m * p.ldc + n;
+        if (full) {
+          uint2 w = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+          *(uint2*)c = w;
+        } else {
+          for (int r = 0; r < 4 && n + r < p.N; ++r) c[r] = f2bf(v[r]);
+        }
+      } else if (p.out_f32 == 1) {
+        float* c = (float*)p.C + (long)m * p.ldc + n;
+        if (full) {
+          *(float4*)c = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+          for (int r = 0; r < 4 && n + r < p.N; ++r) c[r] = v[r];
+        }
+      } else {
+        float* c = (float*)p.C + (long)m * p.ldc + n;
+        for (int r = 0; r < 4 && n + r < p.N; ++r) atomicAdd(c + r, v[r]);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// bf16 transpose:  out[c][r] = in[r][c]  (out leading dim ldo >= R; pad columns untouched),
+// optional fused column sum  colsum[c] += sum_r in[r][c]  (bias gradients).
+// 64x64 tiles through LDS; both global sides are 128-B coalesced.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ in, long ldi, bf16_t* __restrict__ out,
+                                                             long ldo, int R, int C, float* __restrict__ colsum) {
+  __shared__ bf16_t tile[64][66];
+  __shared__ float csum[4][64];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // ty: 0..3
+  float s = 0.f;
+#pragma unroll 4
+  for (int i = 0; i < 16; ++i) {
+    const int r = r0 + ty * 16 + i, c = c0 + tx;
+    bf16_t v = 0;
+    if (r < R && c < C) v = in[(long)r * ldi + c];
+    tile[ty * 16 + i][tx] = v;
+    s += bf2f(v);
+  }
+  if (colsum) csum[ty][tx] = s;
+  __syncthreads();
+#pragma unroll 4
+  for (int i = 0; i < 16; ++i) {
+    const int c = c0 + ty * 16 + i, r = r0 + tx;
+    if (c < C && r < R) out[(long)c * ldo + r] = tile[tx][ty * 16 + i];
+  }
+  if (colsum && ty == 0 && c0 + tx < C) atomicAdd(colsum + c0 + tx, csum[0][tx] + csum[1][tx] + csum[2][tx] + csum[3][tx]);
+}
+
+// ------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------
+template <int BM, int BN>
+static int launch_gemm(GemmParams& p, int splits, hipStream_t stream) {
+  constexpr int smem = 2 * (BM + BN) * 64 * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_set = true;
+  }
+  p.ntm = vlb_cdiv(p.M, BM);
+  p.ntn = vlb_cdiv(p.N, BN);
+  dim3 grid(p.ntm * p.ntn, splits);
+  hipLaunchKernelGGL((gemm_nt_bf16_kernel<BM, BN>), grid, dim3(256), smem, stream, p);
+  VLB_CHECK_LAUNCH("vlb_gemm_nt_bf16");
+  return VLB_OK;
+}
+
+extern "C" int vlb_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
+                                const float* bias, int act, const void* aux, long ldaux, void* pre, long ldpre,
+                                const void* res, long ldres, float drop_p, const uint32_t* seed, uint32_t tag,
+                                int out_mode, int splitk, hipStream_t stream) {
+  if (M <= 0 || N <= 0) return VLB_OK;
+  VLB_CHECK_ARG(K > 0 && (K % 64) == 0, "vlb_gemm_nt_bf16: K=%d must be a positive multiple of 64", K);
+  VLB_CHECK_ARG(A && B && C, "vlb_gemm_nt_bf16: null operand");
+  VLB_CHECK_ARG((lda % 8) == 0 && (ldb % 8) == 0, "vlb_gemm_nt_bf16: lda/ldb must be multiples of 8 elements");
+  VLB_CHECK_ARG((ldc % 4) == 0, "vlb_gemm_nt_bf16: ldc must be a multiple of 4");
+  VLB_CHECK_ARG(out_mode >= 0 && out_mode <= 2, "vlb_gemm_nt_bf16: bad out_mode %d", out_mode);
+  VLB_CHECK_ARG(act >= 0 && act <= 3, "vlb_gemm_nt_bf16: bad act %d", act);
+  VLB_CHECK_ARG(act != 3 || aux, "vlb_gemm_nt_bf16: act=3 needs aux");
+  VLB_CHECK_ARG(!(drop_p > 0.f) || seed, "vlb_gemm_nt_bf16: dropout needs a device seed pointer");
+  VLB_CHECK_ARG((long)M * (long)N < (1L << 32) || !(drop_p > 0.f), "vlb_gemm_nt_bf16: dropout index overflow");
+  GemmParams p;
+  p.A = (const bf16_t*)A; p.lda = lda; p.B = (const bf16_t*)B; p.ldb = ldb;
+  p.M = M; p.N = N; p.K = K;
+  p.bias = bias; p.act = act; p.aux = (const bf16_t*)aux; p.ldaux = ldaux; p.pre = (bf16_t*)pre; p.ldpre = ldpre;
+  p.res = (const bf16_t*)res; p.ldres = ldres;
+  p.drop_thr = vlb_drop_thr(drop_p); p.drop_scale = vlb_drop_scale(p.drop_thr); p.seed = seed; p.tag = tag;
+  p.C = C; p.ldc = ldc; p.out_f32 = out_mode;
+  int splits = 1;
+  const int ktiles = K / 64;
+  if (out_mode == 2) {
+    splits = splitk > 0 ? splitk : 1;
+    if (splitk <= 0) {  // auto: aim for >= 512 blocks
+      const long tiles = (long)vlb_cdiv(M, 128) * vlb_cdiv(N, 128);
+      splits = (int)((512 + tiles - 1) / tiles);
+    }
+    if (splits > ktiles) splits = ktiles;
+    if (splits < 1) splits = 1;
+  }
+  const int per = vlb_cdiv(ktiles, splits);
+  splits = vlb_cdiv(ktiles, per);
+  p.k_per_split = per * 64;
+  // narrow-N tile when the 128x128 grid would leave most CUs idle
+  const long tiles128 = (long)vlb_cdiv(M, 128) * vlb_cdiv(N, 128) * splits;
+  if (tiles128 < 384 || N <= 64) return launch_gemm<128, 64>(p, splits, stream);
+  return launch_gemm<128, 128>(p, splits, stream);
+}
+
+extern "C" int vlb_transpose_bf16(const void* in, long ldi, void* out, long ldo, int R, int C, float* colsum,
+                                  hipStream_t stream) {
+  if (R <= 0 || C <= 0) return VLB_OK;
+  VLB_CHECK_ARG(in && out && ldo >= R && ldi >= C, "vlb_transpose_bf16: bad arguments");
+  dim3 grid(vlb_cdiv(C, 64), vlb_cdiv(R, 64));
+  hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, stream, (const bf16_t*)in, ldi, (bf16_t*)out, ldo, R, C,
+                     colsum);
+  VLB_CHECK_LAUNCH("vlb_transpose_bf16");
+  return VLB_OK;
+}

@@ -1,0 +1,218 @@
+// BertLayerNorm forward / backward for gfx950 (HBM-bound; one 64-lane wave per row).
+//   y = (x - mean) / sqrt(var + eps) * gamma + beta        (biased variance, eps inside sqrt)
+// Follows external/pytorch_pretrained_bert/modeling.py:222-235 (the pure-torch fallback that
+// defines the reference semantics when apex FusedLayerNorm is absent).  The reference runs it
+// as 8 elementwise passes over the row; here a row is read once (8-B bf16x4 loads), reduced
+// with wave shuffles, and written once.  The residual add / bias / dropout that precede every
+// encoder LayerNorm are fused into the producing GEMM's epilogue (gemm.hip), so `x` already is
+// the pre-LN sum, and it is what backward re-reads (no separate x_hat tensor is stored).
+#include "vlb_common.h"
+
+#define LN_MAX_IT 8  // H <= 2048
+
+struct Row4 {
+  float v[LN_MAX_IT][4];
+};
+
+__device__ __forceinline__ void load_row_bf16(const bf16_t* x, int H, int lane, Row4& r) {
+#pragma unroll
+  for (int i = 0; i < LN_MAX_IT; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    if (c < H) {
+      const uint2 w = *(const uint2*)(x + c);
+      r.v[i][0] = bflo(w.x); r.v[i][1] = bfhi(w.x); r.v[i][2] = bflo(w.y); r.v[i][3] = bfhi(w.y);
+    } else {
+      r.v[i][0] = r.v[i][1] = r.v[i][2] = r.v[i][3] = 0.f;
+    }
+  }
+}
+
+// x: [rows] rows of H bf16 with row stride ldx (elements).  y: row stride ldy.
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __restrict__ x, long ldx, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, bf16_t* __restrict__ y, long ldy,
+                                                            float* __restrict__ stats, int rows, int H, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  Row4 r;
+  load_row_bf16(x + (long)row * ldx, H, lane, r);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAX_IT; ++i) s += (r.v[i][0] + r.v[i][1]) + (r.v[i][2] + r.v[i][3]);
+  const float mean = wave_sum(s) / (float)H;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAX_IT; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    if (c < H) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float d = r.v[i][k] - mean;
+        q += d * d;
+      }
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)H + eps);
+  if (lane == 0 && stats) {
+    stats[2 * (long)row] = mean;
+    stats[2 * (long)row + 1] = rstd;
+  }
+  bf16_t* yr = y + (long)row * ldy;
+#pragma unroll
+  for (int i = 0; i < LN_MAX_IT; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    if (c < H) {
+      const float4 g = *(const float4*)(gamma + c);
+      const float4 b = *(const float4*)(beta + c);
+      uint2 w;
+      w.x = pack2bf((r.v[i][0] - mean) * rstd * g.x + b.x, (r.v[i][1] - mean) * rstd * g.y + b.y);
+      w.y = pack2bf((r.v[i][2] - mean) * rstd * g.z + b.z, (r.v[i][3] - mean) * rstd * g.w + b.w);
+      *(uint2*)(yr + c) = w;
+    }
+  }
+}
+
+// Backward.  dy: bf16 (or fp32 when dy_f32) rows; x: the saved pre-LN rows; stats: (mean, rstd).
+//   dx = rstd * (g - mean_H(g) - xhat * mean_H(g * xhat)),  g = dy * gamma
+//   dgamma += sum_rows dy * xhat ; dbeta += sum_rows dy          (fp32 atomics, one flush per block)
+// Outputs (any may be null): dx bf16, dx_drop bf16 = dx * keep(idx) * scale  (the gradient that
+// flows into the dense layer *before* its dropout; idx = row*H + col matches the GEMM epilogue),
+// dx_acc fp32 (atomicAdd; used when several rows alias one input row, e.g. the broadcast
+// text_visual_embeddings of pretrain/modules/resnet_vlbert_for_pretraining.py:132-135).
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restrict__ dy_, long lddy, int dy_f32, const bf16_t* __restrict__ x,
+                                                            long ldx, const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                            bf16_t* __restrict__ dx, long lddx, bf16_t* __restrict__ dx_drop, long lddd,
+                                                            uint32_t drop_thr, float drop_scale, const uint32_t* __restrict__ seedp,
+                                                            uint32_t tag, float* __restrict__ dx_acc, long ldacc, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int rows, int H) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [2][4 waves][H]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t seed = (drop_thr && seedp) ? *seedp : 0u;
+  float gsum[LN_MAX_IT][4], bsum[LN_MAX_IT][4];
+#pragma unroll
+  for (int i = 0; i < LN_MAX_IT; ++i)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) gsum[i][k] = bsum[i][k] = 0.f;
+
+  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    Row4 xr, dyr;
+    load_row_bf16(x + (long)row * ldx, H, lane, xr);
+    if (dy_f32) {
+      const float* d = (const float*)dy_ + (long)row * lddy;
+#pragma unroll
+      for (int i = 0; i < LN_MAX_IT; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < H) t = *(const float4*)(d + c);
+        dyr.v[i][0] = t.x; dyr.v[i][1] = t.y; dyr.v[i][2] = t.z; dyr.v[i][3] = t.w;
+      }
+    } else {
+      load_row_bf16((const bf16_t*)dy_ + (long)row * lddy, H, lane, dyr);
+    }
+    const float mean = stats[2 * (long)row], rstd = stats[2 * (long)row + 1];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_IT; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      if (c < H) {
+        const float4 g = *(const float4*)(gamma + c);
+        const float gg[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float xh = (xr.v[i][k] - mean) * rstd;
+          const float dyv = dyr.v[i][k];
+          gsum[i][k] += dyv * xh;
+          bsum[i][k] += dyv;
+          const float gv = dyv * gg[k];
+          s1 += gv;
+          s2 += gv * xh;
+          xr.v[i][k] = xh;   // reuse storage: xhat
+          dyr.v[i][k] = gv;  // reuse storage: g
+        }
+      }
+    }
+    s1 = wave_sum(s1) / (float)H;
+    s2 = wave_sum(s2) / (float)H;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_IT; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      if (c < H) {
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = rstd * (dyr.v[i][k] - s1 - xr.v[i][k] * s2);
+        if (dx) {
+          uint2 w = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+          *(uint2*)(dx + (long)row * lddx + c) = w;
+        }
+        if (dx_drop) {
+          float d[4];
+          if (drop_thr) {
+            const uint32_t idx = (uint32_t)row * (uint32_t)H + (uint32_t)c;  // H%4==0 -> idx even
+            const uint32_t h0 = vlb_rng_pair(seed, tag, idx >> 1), h1 = vlb_rng_pair(seed, tag, (idx >> 1) + 1);
+            d[0] = ((h0 & 0xffffu) >= drop_thr) ? o[0] * drop_scale : 0.f;
+            d[1] = ((h0 >> 16) >= drop_thr) ? o[1] * drop_scale : 0.f;
+            d[2] = ((h1 & 0xffffu) >= drop_thr) ? o[2] * drop_scale : 0.f;
+            d[3] = ((h1 >> 16) >= drop_thr) ? o[3] * drop_scale : 0.f;
+          } else {
+            d[0] = o[0]; d[1] = o[1]; d[2] = o[2]; d[3] = o[3];
+          }
+          uint2 w = {pack2bf(d[0], d[1]), pack2bf(d[2], d[3])};
+          *(uint2*)(dx_drop + (long)row * lddd + c) = w;
+        }
+        if (dx_acc) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) atomicAdd(dx_acc + (long)row * ldacc + c + k, o[k]);
+        }
+      }
+    }
+  }
+  if (!dgamma && !dbeta) return;
+  // cross-wave reduce, one atomic per column per block
+  float* rg = red;
+  float* rb = red + 4 * H;
+#pragma unroll
+  for (int i = 0; i < LN_MAX_IT; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    if (c < H) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        rg[wave * H + c + k] = gsum[i][k];
+        rb[wave * H + c + k] = bsum[i][k];
+      }
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < H; c += 256) {
+    if (dgamma) atomicAdd(dgamma + c, rg[c] + rg[H + c] + rg[2 * H + c] + rg[3 * H + c]);
+    if (dbeta) atomicAdd(dbeta + c, rb[c] + rb[H + c] + rb[2 * H + c] + rb[3 * H + c]);
+  }
+}
+
+extern "C" int vlb_layernorm_fwd(const void* x, long ldx, const float* gamma, const float* beta, void* y, long ldy,
+                                 float* stats, int rows, int H, float eps, hipStream_t stream) {
+  if (rows <= 0) return VLB_OK;
+  VLB_CHECK_ARG(H > 0 && (H % 4) == 0 && H <= 256 * LN_MAX_IT, "vlb_layernorm_fwd: unsupported H=%d", H);
+  VLB_CHECK_ARG((ldx % 4) == 0 && (ldy % 4) == 0, "vlb_layernorm_fwd: row strides must be multiples of 4");
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(vlb_cdiv(rows, 4)), dim3(256), 0, stream, (const bf16_t*)x, ldx, gamma, beta,
+                     (bf16_t*)y, ldy, stats, rows, H, eps);
+  VLB_CHECK_LAUNCH("vlb_layernorm_fwd");
+  return VLB_OK;
+}
+
+extern "C" int vlb_layernorm_bwd(const void* dy, long lddy, int dy_f32, const void* x, long ldx, const float* stats,
+                                 const float* gamma, void* dx, long lddx, void* dx_drop, long lddd, float drop_p,
+                                 const uint32_t* seed, uint32_t tag, float* dx_acc, long ldacc, float* dgamma, float* dbeta,
+                                 int rows, int H, hipStream_t stream) {
+  if (rows <= 0) return VLB_OK;
+  VLB_CHECK_ARG(H > 0 && (H % 4) == 0 && H <= 256 * LN_MAX_IT, "vlb_layernorm_bwd: unsupported H=%d", H);
+  VLB_CHECK_ARG(!(drop_p > 0.f) || seed, "vlb_layernorm_bwd: dropout needs a device seed pointer");
+  VLB_CHECK_ARG((long)rows * H < (1L << 32) || !(drop_p > 0.f), "vlb_layernorm_bwd: dropout index overflow");
+  int blocks = vlb_cdiv(rows, 4);
+  if (blocks > 512) blocks = 512;
+  const uint32_t thr = vlb_drop_thr(drop_p);
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 2 * 4 * H * sizeof(float), stream, dy, lddy, dy_f32,
+                     (const bf16_t*)x, ldx, stats, gamma, (bf16_t*)dx, lddx, (bf16_t*)dx_drop, lddd, thr, vlb_drop_scale(thr), seed,
+                     tag, dx_acc, ldacc, dgamma, dbeta, rows, H);
+  VLB_CHECK_LAUNCH("vlb_layernorm_bwd");
+  return VLB_OK;
+}

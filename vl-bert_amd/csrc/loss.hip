@@ -1,0 +1,192 @@
+// Loss kernels of the VL-BERT pre-training heads (gfx950; HBM-bound row reductions).
+//   * MLM: F.cross_entropy(logits[B*T, V], labels, ignore_index=-1), mean over labelled rows
+//          (pretrain/modules/resnet_vlbert_for_pretraining.py:176-178)
+//   * MVRC: soft_cross_entropy (common/utils/misc.py:124-151): rows are valid iff
+//          |sum(target) - 1| < 0.1; loss = mean_valid( -sum_c log_softmax(x)_c * t_c )
+// Forward and backward are fused: one pass computes the row's log-sum-exp (online max/sum), the
+// second writes d(loss)/d(logits) IN PLACE over the bf16 logits (scaled by 1/n_valid * gscale).
+// A copy of the logits is only kept when the caller asks for one (API parity / metrics).
+// n_valid is produced on the device by the count kernels -> no host synchronisation
+// (the reference does `.item()` at misc.py:140).
+#include "vlb_common.h"
+
+__device__ __forceinline__ void online_merge(float& m, float& s, float m2, float s2) {
+  const float mn = fmaxf(m, m2);
+  if (mn == -INFINITY) return;  // both empty
+  s = s * __expf(m - mn) + s2 * __expf(m2 - mn);
+  m = mn;
+}
+
+// block-wide (256 threads) reduction of an online-softmax (max,sum) pair; result broadcast
+__device__ __forceinline__ void block_online_reduce(float& m, float& s, float* sh) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
+    online_merge(m, s, m2, s2);
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) {
+    sh[wave * 2] = m;
+    sh[wave * 2 + 1] = s;
+  }
+  __syncthreads();
+  m = sh[0];
+  s = sh[1];
+#pragma unroll
+  for (int w = 1; w < 4; ++w) online_merge(m, s, sh[w * 2], sh[w * 2 + 1]);
+}
+
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+  v = wave_sum(v);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// counts[0] = #rows with label >= 0
+__global__ void count_labels_kernel(const int64_t* __restrict__ labels, int n, float* __restrict__ counts) {
+  int c = 0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) c += (labels[i] >= 0);
+  float f = wave_sum((float)c);
+  if ((threadIdx.x & 63) == 0 && f != 0.f) atomicAdd(counts, f);
+}
+
+// One block per row.  logits: bf16 [rows, ld] (columns >= V are padding and are zeroed).
+// out: loss_sum += row_loss / n_valid ;  logits <- dlogits * (gscale / n_valid).
+__global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(bf16_t* __restrict__ logits, long ld, int V, const int64_t* __restrict__ labels,
+                                                         const float* __restrict__ n_valid, float gscale, float* __restrict__ loss_out,
+                                                         bf16_t* __restrict__ logits_copy, long ldcopy) {
+  __shared__ float sh[16];
+  const int row = blockIdx.x;
+  bf16_t* x = logits + (long)row * ld;
+  const long label = labels[row];
+  const int ldv = (int)ld;
+  if (logits_copy) {
+    bf16_t* cp = logits_copy + (long)row * ldcopy;
+    for (int c = threadIdx.x * 8; c < V; c += 2048) {
+      if (c + 8 <= V) *(uint4*)(cp + c) = *(const uint4*)(x + c);
+      else for (int k = c; k < V; ++k) cp[k] = x[k];
+    }
+  }
+  if (label < 0 || label >= V) {  // ignore_index: no loss, zero gradient row
+    for (int c = threadIdx.x * 8; c < ldv; c += 2048) *(uint4*)(x + c) = make_uint4(0, 0, 0, 0);
+    return;
+  }
+  float m = -INFINITY, s = 0.f;
+  for (int c = threadIdx.x * 8; c < V; c += 2048) {
+    const uint4 w = *(const uint4*)(x + c);
+    const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float a = bflo(ww[k]), b = bfhi(ww[k]);
+      if (c + 2 * k < V) online_merge(m, s, a, 1.f);
+      if (c + 2 * k + 1 < V) online_merge(m, s, b, 1.f);
+    }
+  }
+  block_online_reduce(m, s, sh);
+  const float lse = m + __logf(s);
+  const float nv = fmaxf(*n_valid, 1.f);
+  if (threadIdx.x == 0) atomicAdd(loss_out, (lse - bf2f(x[label])) / nv);
+  const float sc = gscale / nv;
+  __syncthreads();  // x[label] read above before anyone overwrites it
+  for (int c = threadIdx.x * 8; c < ldv; c += 2048) {
+    const uint4 w = *(const uint4*)(x + c);
+    const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c0 = c + 2 * k, c1 = c0 + 1;
+      float g0 = (c0 < V) ? __expf(bflo(ww[k]) - lse) : 0.f;
+      float g1 = (c1 < V) ? __expf(bfhi(ww[k]) - lse) : 0.f;
+      if (c0 == label) g0 -= 1.f;
+      if (c1 == label) g1 -= 1.f;
+      o[k] = pack2bf(g0 * sc, g1 * sc);
+    }
+    *(uint4*)(x + c) = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// row validity for the soft-label loss: valid[r] = |sum_c t[r,c] - 1| < 0.1 ; counts[0] += #valid
+__global__ __launch_bounds__(256) void soft_valid_kernel(const float* __restrict__ target, long ldt, int C, int rows, float* __restrict__ tsum,
+                                                         float* __restrict__ counts) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* t = target + (long)row * ldt;
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += t[c];
+  s = wave_sum(s);
+  if (lane == 0) {
+    tsum[row] = s;
+    if (fabsf(s - 1.f) < 0.1f) atomicAdd(counts, 1.f);
+  }
+}
+
+// One block per row.  logits bf16 [rows, ld] -> in place d(logits); target fp32 [rows, ldt].
+//   loss_row = lse * sum(t) - sum(t * x);  dlogit_c = (softmax_c * sum(t) - t_c) / n_valid
+__global__ __launch_bounds__(256) void soft_ce_fwd_bwd_kernel(bf16_t* __restrict__ logits, long ld, int C, const float* __restrict__ target,
+                                                              long ldt, const float* __restrict__ tsum, const float* __restrict__ n_valid,
+                                                              float gscale, float* __restrict__ loss_out, bf16_t* __restrict__ logits_copy,
+                                                              long ldcopy) {
+  __shared__ float sh[16];
+  const int row = blockIdx.x;
+  bf16_t* x = logits + (long)row * ld;
+  const float* t = target + (long)row * ldt;
+  const int ldv = (int)ld;
+  if (logits_copy) {
+    bf16_t* cp = logits_copy + (long)row * ldcopy;
+    for (int c = threadIdx.x; c < C; c += 256) cp[c] = x[c];
+  }
+  const float ts = tsum[row];
+  if (!(fabsf(ts - 1.f) < 0.1f)) {
+    for (int c = threadIdx.x; c < ldv; c += 256) x[c] = 0;
+    return;
+  }
+  float m = -INFINITY, s = 0.f, dot = 0.f;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float v = bf2f(x[c]);
+    online_merge(m, s, v, 1.f);
+    dot += t[c] * v;
+  }
+  block_online_reduce(m, s, sh);
+  dot = block_sum(dot, sh + 8);
+  const float lse = m + __logf(s);
+  const float nv = fmaxf(*n_valid, 1.f);
+  if (threadIdx.x == 0) atomicAdd(loss_out, (lse * ts - dot) / nv);
+  const float sc = gscale / nv;
+  for (int c = threadIdx.x; c < ldv; c += 256) {
+    float g = 0.f;
+    if (c < C) g = (__expf(bf2f(x[c]) - lse) * ts - t[c]) * sc;
+    x[c] = f2bf(g);
+  }
+}
+
+extern "C" int vlb_ce_fwd_bwd(void* logits, long ld, int rows, int V, const int64_t* labels, float* counts, float gscale,
+                              float* loss_out, void* logits_copy, long ldcopy, hipStream_t stream) {
+  if (rows <= 0) return VLB_OK;
+  VLB_CHECK_ARG(logits && labels && counts && loss_out, "vlb_ce_fwd_bwd: null argument");
+  VLB_CHECK_ARG(ld >= V && (ld % 8) == 0, "vlb_ce_fwd_bwd: ld=%ld must be >= V=%d and a multiple of 8", ld, V);
+  (void)hipMemsetAsync(counts, 0, sizeof(float), stream);
+  hipLaunchKernelGGL(count_labels_kernel, dim3(vlb_cdiv(rows, 256) > 64 ? 64 : vlb_cdiv(rows, 256)), dim3(256), 0, stream, labels, rows,
+                     counts);
+  hipLaunchKernelGGL(ce_fwd_bwd_kernel, dim3(rows), dim3(256), 0, stream, (bf16_t*)logits, ld, V, labels, counts, gscale, loss_out,
+                     (bf16_t*)logits_copy, ldcopy);
+  VLB_CHECK_LAUNCH("vlb_ce_fwd_bwd");
+  return VLB_OK;
+}
+
+extern "C" int vlb_soft_ce_fwd_bwd(void* logits, long ld, int rows, int C, const float* target, long ldt, float* tsum,
+                                   float* counts, float gscale, float* loss_out, void* logits_copy, long ldcopy,
+                                   hipStream_t stream) {
+  if (rows <= 0) return VLB_OK;
+  VLB_CHECK_ARG(logits && target && tsum && counts && loss_out, "vlb_soft_ce_fwd_bwd: null argument");
+  VLB_CHECK_ARG(ld >= C && ldt >= C, "vlb_soft_ce_fwd_bwd: bad leading dimensions");
+  (void)hipMemsetAsync(counts, 0, sizeof(float), stream);
+  hipLaunchKernelGGL(soft_valid_kernel, dim3(vlb_cdiv(rows, 4)), dim3(256), 0, stream, target, ldt, C, rows, tsum, counts);
+  hipLaunchKernelGGL(soft_ce_fwd_bwd_kernel, dim3(rows), dim3(256), 0, stream, (bf16_t*)logits, ld, C, target, ldt, tsum, counts,
+                     gscale, loss_out, (bf16_t*)logits_copy, ldcopy);
+  VLB_CHECK_LAUNCH("vlb_soft_ce_fwd_bwd");
+  return VLB_OK;
+}

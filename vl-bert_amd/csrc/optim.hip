@@ -1,0 +1,163 @@
+// Optimizer-side kernels over the FLAT parameter buffers (gfx950; pure HBM streaming):
+//   * vlb_sumsq_f32      - sum of squares of the flat fp32 gradient (global-norm clip,
+//                          torch.nn.utils.clip_grad_norm_ as called at common/trainer.py:139-145)
+//   * vlb_adamw_step     - fused multi-tensor AdamW with the reference's semantics
+//                          (common/nlp/bert/optimization.py:155-185: bias-corrected step size,
+//                          eps outside the sqrt, decoupled decay applied AFTER the Adam update
+//                          with the un-corrected lr), the clip coefficient folded in, and the
+//                          bf16 working copy of the weights emitted in the same pass.
+//   * vlb_cast_f32_bf16  - fp32 -> bf16 (initial / externally modified weights)
+// The reference walks ~400 parameters in Python with ~8 elementwise kernels each; here the whole
+// model is one launch over one contiguous buffer.  Hyper-parameters that change every step
+// (lr, step count) live in a small DEVICE struct so a captured hipGraph can be replayed.
+#include "vlb_common.h"
+
+struct VlbAdamState {   // device-resident, 8 floats
+  float lr;             // current lr (schedule applied by the host or by vlb_lr_step)
+  float beta1, beta2, eps, weight_decay;
+  float step;           // number of steps already taken (incremented by the kernel's block 0)
+  float max_norm;       // <=0: no clipping
+  float sumsq;          // sum of squares of the gradient (written by vlb_sumsq_f32)
+};
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ out) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  const long stride = (long)gridDim.x * 256 * 4;
+  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 3 < n) {
+      const float4 v = *(const float4*)(g + i);
+      s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    } else {
+      for (long k = i; k < n; ++k) s += g[k] * g[k];
+    }
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, sh[0] + sh[1] + sh[2] + sh[3]);
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, bf16_t* __restrict__ p16, long n, VlbAdamState* __restrict__ st,
+                                                    float grad_scale) {
+  const float lr = st->lr, b1 = st->beta1, b2 = st->beta2, eps = st->eps, wd = st->weight_decay;
+  const float step = st->step + 1.0f;
+  float coef = grad_scale;
+  if (st->max_norm > 0.f) {
+    const float total = sqrtf(st->sumsq) * grad_scale;
+    coef *= fminf(st->max_norm / (total + 1e-6f), 1.0f);
+  }
+  const float step_size = lr * sqrtf(1.0f - powf(b2, step)) / (1.0f - powf(b1, step));
+  const long stride = (long)gridDim.x * 256 * 4;
+  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+    float pv[4], gv[4], mv[4], vv[4];
+    const bool full = (i + 3 < n);
+    if (full) {
+      const float4 a = *(const float4*)(p + i), b = *(const float4*)(g + i), c = *(const float4*)(m + i), d = *(const float4*)(v + i);
+      pv[0] = a.x; pv[1] = a.y; pv[2] = a.z; pv[3] = a.w;
+      gv[0] = b.x; gv[1] = b.y; gv[2] = b.z; gv[3] = b.w;
+      mv[0] = c.x; mv[1] = c.y; mv[2] = c.z; mv[3] = c.w;
+      vv[0] = d.x; vv[1] = d.y; vv[2] = d.z; vv[3] = d.w;
+    } else {
+      for (int k = 0; k < 4; ++k) {
+        const bool ok = i + k < n;
+        pv[k] = ok ? p[i + k] : 0.f; gv[k] = ok ? g[i + k] : 0.f; mv[k] = ok ? m[i + k] : 0.f; vv[k] = ok ? v[i + k] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gg = gv[k] * coef;
+      mv[k] = mv[k] * b1 + (1.0f - b1) * gg;
+      vv[k] = vv[k] * b2 + (1.0f - b2) * gg * gg;
+      const float denom = sqrtf(vv[k]) + eps;
+      pv[k] -= step_size * (mv[k] / denom);
+      if (wd > 0.f) pv[k] -= lr * wd * pv[k];
+    }
+    if (full) {
+      *(float4*)(p + i) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+      *(float4*)(m + i) = make_float4(mv[0], mv[1], mv[2], mv[3]);
+      *(float4*)(v + i) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+      if (p16) *(uint2*)(p16 + i) = make_uint2(pack2bf(pv[0], pv[1]), pack2bf(pv[2], pv[3]));
+    } else {
+      for (int k = 0; k < 4 && i + k < n; ++k) {
+        p[i + k] = pv[k]; m[i + k] = mv[k]; v[i + k] = vv[k];
+        if (p16) p16[i + k] = f2bf(pv[k]);
+      }
+    }
+  }
+}
+
+// runs after adamw_kernel in the same stream: step += 1, sumsq = 0 (ready for the next step)
+__global__ void adam_advance_kernel(VlbAdamState* st) {
+  st->step += 1.0f;
+  st->sumsq = 0.f;
+}
+
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, long n) {
+  const long stride = (long)gridDim.x * 256 * 4;
+  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 3 < n) {
+      const float4 a = *(const float4*)(in + i);
+      *(uint2*)(out + i) = make_uint2(pack2bf(a.x, a.y), pack2bf(a.z, a.w));
+    } else {
+      for (long k = i; k < n; ++k) out[k] = f2bf(in[k]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const bf16_t* __restrict__ in, float* __restrict__ out, long n) {
+  const long stride = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) out[i] = bf2f(in[i]);
+}
+
+// seed <- hash(seed) : advances the device-resident dropout seed once per step (graph-replayable)
+__global__ void rng_advance_kernel(uint32_t* seed) { *seed = vlb_hash32(*seed + 0x9E3779B9u) | 1u; }
+
+static int grid_for(long n4) {
+  long b = (n4 + 255) / 256;
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+extern "C" int vlb_sumsq_f32(const float* g, long n, float* out, hipStream_t stream) {
+  if (n <= 0) return VLB_OK;
+  VLB_CHECK_ARG(g && out, "vlb_sumsq_f32: null argument");
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, stream, g, n, out);
+  VLB_CHECK_LAUNCH("vlb_sumsq_f32");
+  return VLB_OK;
+}
+
+// state: device pointer to 8 floats {lr, beta1, beta2, eps, weight_decay, step, max_norm, sumsq}
+extern "C" int vlb_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, long n, float* state, float grad_scale,
+                              hipStream_t stream) {
+  if (n <= 0) return VLB_OK;
+  VLB_CHECK_ARG(p && g && m && v && state, "vlb_adamw_step: null argument");
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, stream, p, g, m, v, (bf16_t*)p_bf16, n,
+                     (VlbAdamState*)state, grad_scale);
+  hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(1), 0, stream, (VlbAdamState*)state);
+  VLB_CHECK_LAUNCH("vlb_adamw_step");
+  return VLB_OK;
+}
+
+extern "C" int vlb_cast_f32_bf16(const float* in, void* out, long n, hipStream_t stream) {
+  if (n <= 0) return VLB_OK;
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, stream, in, (bf16_t*)out, n);
+  VLB_CHECK_LAUNCH("vlb_cast_f32_bf16");
+  return VLB_OK;
+}
+
+extern "C" int vlb_cast_bf16_f32(const void* in, float* out, long n, hipStream_t stream) {
+  if (n <= 0) return VLB_OK;
+  hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, stream, (const bf16_t*)in, out, n);
+  VLB_CHECK_LAUNCH("vlb_cast_bf16_f32");
+  return VLB_OK;
+}
+
+extern "C" int vlb_rng_advance(uint32_t* seed, hipStream_t stream) {
+  VLB_CHECK_ARG(seed, "vlb_rng_advance: null seed");
+  hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, stream, seed);
+  VLB_CHECK_LAUNCH("vlb_rng_advance");
+  return VLB_OK;
+}

@@ -1,0 +1,90 @@
+// Shared device/host helpers for libvlbert_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/vlbert_hip.h"  // every extern "C" definition is checked against the public prototypes
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits in memory
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define VLB_WAVE 64
+
+// ---- error plumbing (C ABI: 0 = ok, <0 = error, message via vlb_last_error) ----
+extern "C" const char* vlb_last_error(void);
+void vlb_set_error(const char* fmt, ...);
+#define VLB_OK 0
+#define VLB_ERR_ARG (-1)
+#define VLB_ERR_HIP (-2)
+#define VLB_CHECK_ARG(cond, ...)                 \
+  do {                                           \
+    if (!(cond)) {                               \
+      vlb_set_error(__VA_ARGS__);                \
+      return VLB_ERR_ARG;                        \
+    }                                            \
+  } while (0)
+#define VLB_CHECK_LAUNCH(name)                                              \
+  do {                                                                      \
+    hipError_t e__ = hipGetLastError();                                     \
+    if (e__ != hipSuccess) {                                                \
+      vlb_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+      return VLB_ERR_HIP;                                                   \
+    }                                                                       \
+  } while (0)
+
+// ---- bf16 <-> f32 ----
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }  // RNE (v_cvt_pk_bf16_f32)
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+  return ((uint32_t)f2bf(hi) << 16) | (uint32_t)f2bf(lo);
+}
+__device__ __forceinline__ float bflo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bfhi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+// ---- wave reductions (64 lanes) ----
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- counter-based dropout RNG ----
+// keep(seed, tag, idx): one 32-bit hash per PAIR of elements, 16 bits each.
+// p_eff = thr/65536; the same function is evaluated in forward and backward so no
+// mask tensor is stored.  `seed` lives in device memory (graph replays re-read it).
+__device__ __forceinline__ uint32_t vlb_hash32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ uint32_t vlb_rng_pair(uint32_t seed, uint32_t tag, uint32_t pair_idx) {
+  return vlb_hash32(pair_idx * 0x9E3779B1u + vlb_hash32(seed ^ (tag * 0x85ebca6bu + 0x632be5abu)));
+}
+__device__ __forceinline__ bool vlb_keep(uint32_t seed, uint32_t tag, uint32_t idx, uint32_t thr) {
+  uint32_t h = vlb_rng_pair(seed, tag, idx >> 1);
+  uint32_t bits = (idx & 1u) ? (h >> 16) : (h & 0xffffu);
+  return bits >= thr;
+}
+static inline uint32_t vlb_drop_thr(float p) {
+  if (p <= 0.f) return 0u;
+  double t = (double)p * 65536.0 + 0.5;
+  if (t > 65535.0) t = 65535.0;
+  return (uint32_t)t;
+}
+static inline float vlb_drop_scale(uint32_t thr) { return thr ? 65536.0f / (65536.0f - (float)thr) : 1.0f; }
+
+// ---- erf-GELU and its derivative (external/pytorch_pretrained_bert/modeling.py:114-120) ----
+__device__ __forceinline__ float gelu_f(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_f(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+static inline int vlb_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,538 @@
+"""MI355X-native VL-BERT pre-training engine: the whole training step of
+`ResNetVLBERTForPretraining` (precomputed-feature configuration) as a fixed sequence of
+hand-written HIP kernels called through the C ABI.
+
+Reference path being replaced: pretrain/modules/resnet_vlbert_for_pretraining.py:93-216
+-> common/fast_rcnn.py:128-203 -> common/visual_linguistic_bert.py:95-241,346-380 ->
+external/pytorch_pretrained_bert/modeling.py:268-482, its autograd backward, clip_grad_norm_ +
+AdamW.step (common/trainer.py:123-153, common/nlp/bert/optimization.py:129-187) and the DDP gradient
+all-reduce (pretrain/function/train.py:89-90).
+
+Design: static shapes [B, S=T+R+1] with in-kernel masking (no .item()/.nonzero() host
+syncs), bf16 activations / fp32 accumulation / fp32 master weights, every parameter in ONE flat fp32
+buffer (nn.Parameter views alias it; gradients, Adam moments and the bf16 working copy are flat
+twins), explicit hand-scheduled backward (no autograd) so gradient buckets can be all-reduced over
+RCCL while earlier layers are still running, whole step capturable in a hipGraph.
+
+PyTorch supplies device memory, streams and torch.distributed; no torch arithmetic on the hot path.
+"""
+import math
+from collections import OrderedDict
+from dataclasses import dataclass
+
+import torch
+
+from . import ops
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+VIS_DIM = 2048            # hard-coded in the reference (common/fast_rcnn.py:107, resnet_vlbert_for_pretraining.py:25)
+TAG_EMBED, TAG_DOWNSAMPLE = 1000, 1001
+
+
+def _ru(x, m):
+    return (x + m - 1) // m * m
+
+
+@dataclass
+class ModelConfig:
+    """NETWORK.VLBERT keys the hot path reads (pretrain/function/config.py:86-122)."""
+    hidden_size: int = 768
+    num_hidden_layers: int = 12
+    num_attention_heads: int = 12
+    intermediate_size: int = 3072
+    vocab_size: int = 30522
+    max_position_embeddings: int = 512
+    type_vocab_size: int = 3
+    visual_region_classes: int = 1601
+    hidden_dropout_prob: float = 0.1
+    attention_probs_dropout_prob: float = 0.1
+    obj_downsample_dropout: float = 0.1
+
+    def validate(self):
+        H, nh = self.hidden_size, self.num_attention_heads
+        if H % 64 or H // nh != 64:
+            raise ValueError("engine supports head dim 64 and hidden_size % 64 == 0 (got H=%d, heads=%d)" % (H, nh))
+        if self.intermediate_size % 64:
+            raise ValueError("intermediate_size must be a multiple of 64")
+
+
+def param_layout(cfg):
+    """Ordered {state_dict name: shape} -- the reference's key names (SURVEY.md §8b state-dict contract).
+    Order matters: q/k/v weights (and biases) are adjacent so the fused [3H,H] QKV operand is a plain
+    view; the two object linguistic vectors are adjacent so they form a [2,H] table."""
+    H, I, V, C = cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size, cfg.visual_region_classes
+    s = OrderedDict()
+    s["vlbert.word_embeddings.weight"] = (V, H)
+    s["vlbert.position_embeddings.weight"] = (cfg.max_position_embeddings, H)
+    s["vlbert.token_type_embeddings.weight"] = (cfg.type_vocab_size, H)
+    s["vlbert.end_embedding.weight"] = (1, H)
+    s["object_linguistic_embeddings.weight"] = (1, H)
+    s["object_mask_word_embedding.weight"] = (1, H)
+    s["object_mask_visual_embedding.weight"] = (1, VIS_DIM)
+    s["image_feature_extractor.obj_downsample.1.weight"] = (H, 2 * VIS_DIM)
+    s["image_feature_extractor.obj_downsample.1.bias"] = (H,)
+    for ln in ("embedding_LayerNorm", "visual_ln_text", "visual_ln_object"):
+        s["vlbert.%s.weight" % ln] = (H,)
+        s["vlbert.%s.bias" % ln] = (H,)
+    for l in range(cfg.num_hidden_layers):
+        p = "vlbert.encoder.layer.%d." % l
+        for n in ("query", "key", "value"):
+            s[p + "attention.self.%s.weight" % n] = (H, H)
+        for n in ("query", "key", "value"):
+            s[p + "attention.self.%s.bias" % n] = (H,)
+        s[p + "attention.output.dense.weight"] = (H, H)
+        s[p + "attention.output.dense.bias"] = (H,)
+        s[p + "attention.output.LayerNorm.weight"] = (H,)
+        s[p + "attention.output.LayerNorm.bias"] = (H,)
+        s[p + "intermediate.dense.weight"] = (I, H)
+        s[p + "intermediate.dense.bias"] = (I,)
+        s[p + "output.dense.weight"] = (H, I)
+        s[p + "output.dense.bias"] = (H,)
+        s[p + "output.LayerNorm.weight"] = (H,)
+        s[p + "output.LayerNorm.bias"] = (H,)
+    p = "vlbert.mlm_head.predictions."
+    s[p + "transform.dense.weight"] = (H, H)
+    s[p + "transform.dense.bias"] = (H,)
+    s[p + "transform.LayerNorm.weight"] = (H,)
+    s[p + "transform.LayerNorm.bias"] = (H,)
+    s[p + "bias"] = (V,)
+    s["vlbert.mvrc_head.transform.dense.weight"] = (H, H)
+    s["vlbert.mvrc_head.transform.dense.bias"] = (H,)
+    s["vlbert.mvrc_head.region_cls_pred.weight"] = (C, H)
+    s["vlbert.mvrc_head.region_cls_pred.bias"] = (C,)
+    return s
+
+
+TIED_DECODER_KEY = "vlbert.mlm_head.predictions.decoder.weight"   # alias of word_embeddings.weight (modeling.py:463-466)
+
+
+class FlatParams:
+    """One contiguous buffer per role (fp32 master / fp32 grad / Adam m / Adam v / bf16 copy); every
+    tensor starts on a 64-element boundary (256 B fp32, 128 B bf16)."""
+
+    def __init__(self, cfg, device):
+        self.shapes = param_layout(cfg)
+        self.offsets = OrderedDict()
+        off = 0
+        for name, shape in self.shapes.items():
+            self.offsets[name] = off
+            off = _ru(off + math.prod(shape), 64)
+        self.numel = off
+        self.master = torch.zeros(off, dtype=F32, device=device)
+        self.grad = torch.zeros(off, dtype=F32, device=device)
+        self.m = torch.zeros(off, dtype=F32, device=device)
+        self.v = torch.zeros(off, dtype=F32, device=device)
+        self.w16 = torch.zeros(off, dtype=BF16, device=device)
+
+    def view(self, buf, name, shape=None, span=1):
+        """View of `name` in `buf`; span>1 extends over the following adjacent tensors."""
+        names = list(self.shapes)
+        i = names.index(name)
+        n = sum(math.prod(self.shapes[k]) for k in names[i:i + span])
+        if span > 1:   # adjacency requires no padding in between
+            assert self.offsets[names[i + span - 1]] + math.prod(self.shapes[names[i + span - 1]]) - self.offsets[name] == n
+        t = buf[self.offsets[name]:self.offsets[name] + n]
+        return t.view(*(shape if shape is not None else self.shapes[name]))
+
+    def named(self, buf):
+        return OrderedDict((k, self.view(buf, k)) for k in self.shapes)
+
+
+class PretrainEngine:
+    def __init__(self, cfg, B, T, R, device="cuda:0", train=True, lr=1e-4, weight_decay=1e-4, max_grad_norm=10.0,
+                 betas=(0.9, 0.999), eps=1e-6, seed=1234, grad_accum=1, process_group=None, keep_logits=False):
+        cfg.validate()
+        self.cfg, self.B, self.T, self.R = cfg, B, T, R
+        self.S = T + R + 1
+        if self.S > 128:
+            raise ValueError("sequence %d+%d+1 > 128: the fused attention kernel handles S <= 128" % (T, R))
+        self.dev = torch.device(device)
+        self.train = train
+        self.grad_accum = grad_accum
+        self.pg = process_group
+        self.keep_logits = keep_logits
+        H, I, V, C, L = cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size, cfg.visual_region_classes, cfg.num_hidden_layers
+        self.M, self.BT, self.BR = B * self.S, B * T, B * R
+        self.Mp, self.BTp, self.BRp = _ru(self.M, 64), _ru(self.BT, 64), _ru(self.BR, 64)
+        self.Vp, self.Cp = _ru(V, 64), _ru(C, 64)
+        d = self.dev
+        self.P = FlatParams(cfg, d)
+        P = self.P
+        self.w16 = P.named(P.w16)
+        self.w32 = P.named(P.master)
+        self.g32 = P.named(P.grad)
+
+        def zb(*s):
+            return torch.zeros(s, dtype=BF16, device=d)
+
+        def zf(*s):
+            return torch.zeros(s, dtype=F32, device=d)
+
+        # bf16 transposed weights for dgrad GEMMs (dX = dY . (W^T)^T); refreshed after every optimizer step
+        self.wT = {}
+        for l in range(L):
+            p = "vlbert.encoder.layer.%d." % l
+            self.wT[p + "qkv"] = zb(H, 3 * H)
+            self.wT[p + "attention.output.dense.weight"] = zb(H, H)
+            self.wT[p + "intermediate.dense.weight"] = zb(H, I)
+            self.wT[p + "output.dense.weight"] = zb(I, H)
+        self.wT["vlbert.mlm_head.predictions.transform.dense.weight"] = zb(H, H)
+        self.wT["vlbert.word_embeddings.weight"] = zb(H, self.Vp)
+        self.wT["vlbert.mvrc_head.transform.dense.weight"] = zb(H, H)
+        self.wT["vlbert.mvrc_head.region_cls_pred.weight"] = zb(H, self.Cp)
+        self.wT["image_feature_extractor.obj_downsample.1.weight"] = zb(2 * VIS_DIM, H)
+
+        # device-resident step state
+        self.seed = torch.tensor([seed | 1], dtype=torch.int32, device=d)
+        self.adam = torch.tensor([lr, betas[0], betas[1], eps, weight_decay, 0.0, max_grad_norm, 0.0], dtype=F32, device=d)
+        self.losses = zf(4)       # mlm, mvrc, (unused), (unused)
+        self.counts = zf(2)       # n_valid mlm, n_valid mvrc
+
+        # static batch buffers (graph-capturable: the host copies new batches into them)
+        self.in_boxes = zf(B, R, 4 + VIS_DIM)
+        self.in_im_info = zf(B, 5)
+        self.in_text = torch.zeros((B, T), dtype=torch.int64, device=d)
+        self.in_mlm_labels = torch.zeros((B, T), dtype=torch.int64, device=d)
+        self.in_mvrc_ops = torch.zeros((B, R), dtype=torch.int64, device=d)
+        self.in_mvrc_labels = zf(B, R, C)
+        self.text_mask = torch.zeros((B, T), dtype=torch.uint8, device=d)
+        self.box_mask = torch.zeros((B, R), dtype=torch.uint8, device=d)
+        i32 = lambda *s: torch.zeros(s, dtype=torch.int32, device=d)
+        self.lay = dict(code=i32(B, self.S), text_len=i32(B), nobj=i32(B), text_rows=i32(B, T), obj_rows=i32(B, R),
+                        attn_mask=zf(B, self.S))
+
+        # activations
+        M, BT, BR, S, nh = self.M, self.BT, self.BR, self.S, cfg.num_attention_heads
+        self.a_ds = zb(BR, 2 * VIS_DIM)
+        self.obj_reps = zb(BR, H)
+        self.objvis, self.st_objvis = zb(BR, H), zf(BR, 2)
+        self.textvis, self.st_textvis = zb(B, H), zf(B, 2)
+        self.emb_pre, self.st_emb = zb(M, H), zf(M, 2)
+        self.X = [zb(M, H) for _ in range(L + 1)]
+        self.QKV = [zb(M, 3 * H) for _ in range(L)]
+        self.CTX = [zb(M, H) for _ in range(L)]
+        self.LSE = [zf(B, nh, S) for _ in range(L)]
+        self.Z1, self.ST1, self.Y1 = [zb(M, H) for _ in range(L)], [zf(M, 2) for _ in range(L)], [zb(M, H) for _ in range(L)]
+        self.U, self.G = [zb(M, I) for _ in range(L)], [zb(M, I) for _ in range(L)]
+        self.Z2, self.ST2 = [zb(M, H) for _ in range(L)], [zf(M, 2) for _ in range(L)]
+        self.text_out, self.obj_out = zb(BT, H), zb(BR, H)
+        self.mlm_u, self.mlm_g, self.mlm_h, self.st_mlm = zb(BT, H), zb(BT, H), zb(BT, H), zf(BT, 2)
+        self.mlm_logits = zb(BT, self.Vp)
+        self.mvrc_u, self.mvrc_g = zb(BR, H), zb(BR, H)
+        self.mvrc_logits = zb(BR, self.Cp)
+        self.mvrc_tsum = zf(BR)
+        self.mlm_logits_copy = zb(BT, self.Vp) if keep_logits else None
+        self.mvrc_logits_copy = zb(BR, self.Cp) if keep_logits else None
+
+        # backward scratch
+        self.dXa, self.dXb = zb(M, H), zb(M, H)
+        self.dZ, self.dD = zb(M, H), zb(M, H)
+        self.dU = zb(M, I)
+        self.dCTX, self.dQKV = zb(M, H), zb(M, 3 * H)
+        self.tG = zb(max(3 * H, I), self.Mp)       # transposed gradients (zero padded columns persist)
+        self.tA = zb(max(H, I), self.Mp)           # transposed activations
+        self.tG_bt, self.tA_bt = zb(max(self.Vp, H), self.BTp), zb(H, self.BTp)
+        self.tG_br, self.tA_br = zb(max(self.Cp, H), self.BRp), zb(max(H, 2 * VIS_DIM), self.BRp)
+        self.d_mlm_h, self.d_mlm_g, self.d_mlm_u = zb(BT, H), zb(BT, H), zb(BT, H)
+        self.d_text_out, self.d_obj_out = zb(BT, H), zb(BR, H)
+        self.d_mvrc_u = zb(BR, H)
+        self.d_textvis, self.d_objvis = zf(B, H), zf(BR, H)
+        self.d_obj_reps = zf(BR, H)
+        self.d_yds = zb(BR, H)
+        self.d_afeat = zb(BR, VIS_DIM)
+        self.graph = None
+        self._weights_dirty = True
+        self.buckets = None
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1:
+            from .parallel import GradBuckets
+            self.buckets = GradBuckets(self.P.grad, self.P.offsets, self.P.numel, L, group=process_group)
+
+    # ------------------------------------------------------------------------------------------
+    # parameters
+    # ------------------------------------------------------------------------------------------
+    def load_state_dict(self, sd):
+        """sd: {reference state_dict name: tensor}.  The tied decoder key is accepted and ignored."""
+        for name in self.P.shapes:
+            if name not in sd:
+                raise KeyError("missing parameter %s" % name)
+            self.w32[name].copy_(sd[name].to(F32))
+        self._weights_dirty = True
+
+    def state_dict(self):
+        sd = OrderedDict((k, v.detach().clone()) for k, v in self.w32.items())
+        sd[TIED_DECODER_KEY] = sd["vlbert.word_embeddings.weight"]
+        return sd
+
+    def sync_weights(self):
+        """fp32 master -> bf16 working copy + transposed copies (after load / external modification)."""
+        ops.cast_f32_bf16(self.P.master, self.P.w16)
+        self._refresh_transposes()
+        self._weights_dirty = False
+
+    def _refresh_transposes(self):
+        H, L = self.cfg.hidden_size, self.cfg.num_hidden_layers
+        for l in range(L):
+            p = "vlbert.encoder.layer.%d." % l
+            wqkv = self.P.view(self.P.w16, p + "attention.self.query.weight", (3 * H, H), span=3)
+            ops.transpose(wqkv, self.wT[p + "qkv"])
+            for n in ("attention.output.dense.weight", "intermediate.dense.weight", "output.dense.weight"):
+                ops.transpose(self.w16[p + n], self.wT[p + n])
+        for n in ("vlbert.mlm_head.predictions.transform.dense.weight", "vlbert.word_embeddings.weight",
+                  "vlbert.mvrc_head.transform.dense.weight", "vlbert.mvrc_head.region_cls_pred.weight",
+                  "image_feature_extractor.obj_downsample.1.weight"):
+            ops.transpose(self.w16[n], self.wT[n])
+
+    # ------------------------------------------------------------------------------------------
+    # batch
+    # ------------------------------------------------------------------------------------------
+    def set_batch(self, boxes, im_info, text, relationship_label, mlm_labels, mvrc_ops, mvrc_labels):
+        """Copies a collated batch (pretrain/data/collate_batch.py layout) into the static device buffers
+        and derives the masks exactly as resnet_vlbert_for_pretraining.py:106,134 does
+        (box_mask = boxes[:,:,0] > -1.5 ; text_mask = text > 0).  `relationship_label` is unused
+        (WITH_REL_LOSS false in the north-star configuration)."""
+        self.in_boxes.copy_(boxes, non_blocking=True)
+        self.in_im_info.copy_(im_info, non_blocking=True)
+        self.in_text.copy_(text, non_blocking=True)
+        self.in_mlm_labels.copy_(mlm_labels, non_blocking=True)
+        self.in_mvrc_ops.copy_(mvrc_ops, non_blocking=True)
+        self.in_mvrc_labels.copy_(mvrc_labels, non_blocking=True)
+        torch.gt(self.in_text, 0, out=self.text_mask.view(torch.bool))
+        torch.gt(self.in_boxes[:, :, 0], -1.5, out=self.box_mask.view(torch.bool))
+
+    # ------------------------------------------------------------------------------------------
+    # forward
+    # ------------------------------------------------------------------------------------------
+    def _p(self, train):
+        c = self.cfg
+        if not train:
+            return 0.0, 0.0, 0.0
+        return c.hidden_dropout_prob, c.attention_probs_dropout_prob, c.obj_downsample_dropout
+
+    def forward(self, train=None, gscale=1.0):
+        train = self.train if train is None else train
+        if self._weights_dirty:
+            self.sync_weights()
+        cfg, B, T, R, S = self.cfg, self.B, self.T, self.R, self.S
+        H, I, V, C, L, nh = cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size, cfg.visual_region_classes, \
+            cfg.num_hidden_layers, cfg.num_attention_heads
+        p_h, p_a, p_ds = self._p(train)
+        w16, w32, seed = self.w16, self.w32, self.seed
+        self.losses.zero_()
+        ops.seq_layout_into(self.text_mask, self.box_mask, S, self.lay)
+        # --- FastRCNN precomputed branch: (coord || feature) -> Linear(4096->H) -> ReLU ------------------
+        ops.obj_prep_fwd(self.in_boxes, self.in_im_info, self.in_mvrc_ops.view(-1), w32["object_mask_visual_embedding.weight"],
+                         self.a_ds, drop_p=p_ds, seed=seed, tag=TAG_DOWNSAMPLE)
+        ops.gemm_nt(self.a_ds, w16["image_feature_extractor.obj_downsample.1.weight"], self.obj_reps,
+                    bias=w32["image_feature_extractor.obj_downsample.1.bias"], act=ops.ACT_RELU)
+        # --- visual LayerNorms + fused embedding ---------------------------------------------------------
+        ops.layernorm_fwd(self.obj_reps, w32["vlbert.visual_ln_object.weight"], w32["vlbert.visual_ln_object.bias"], self.objvis,
+                          self.st_objvis)
+        reps0 = self.obj_reps.view(B, R * H)[:, :H]          # obj_reps[:, 0]  (text tags are all 0, :132-135)
+        ops.layernorm_fwd(reps0, w32["vlbert.visual_ln_text.weight"], w32["vlbert.visual_ln_text.bias"], self.textvis,
+                          self.st_textvis)
+        ops.embed_fwd(self.lay, self.in_text, None, w16["vlbert.word_embeddings.weight"], w16["vlbert.position_embeddings.weight"],
+                      w16["vlbert.token_type_embeddings.weight"], w16["vlbert.end_embedding.weight"], self.textvis, (H, 0),
+                      self.objvis, (R * H, H), w16["object_linguistic_embeddings.weight"], (0, 0), self.in_mvrc_ops,
+                      w32["vlbert.embedding_LayerNorm.weight"], w32["vlbert.embedding_LayerNorm.bias"], self.emb_pre, self.st_emb,
+                      self.X[0], B, T, R, S, H, drop_p=p_h, seed=seed, tag=TAG_EMBED)
+        # --- encoder -------------------------------------------------------------------------------------
+        mask = self.lay["attn_mask"]
+        for l in range(L):
+            p = "vlbert.encoder.layer.%d." % l
+            x = self.X[l]
+            wqkv = self.P.view(self.P.w16, p + "attention.self.query.weight", (3 * H, H), span=3)
+            bqkv = self.P.view(self.P.master, p + "attention.self.query.bias", (3 * H,), span=3)
+            ops.gemm_nt(x, wqkv, self.QKV[l], bias=bqkv)
+            ops.attention_fwd(self.QKV[l], mask, self.CTX[l], self.LSE[l], B, S, H, nh, drop_p=p_a, seed=seed, tag=l * 8 + 0)
+            ops.gemm_nt(self.CTX[l], w16[p + "attention.output.dense.weight"], self.Z1[l], bias=w32[p + "attention.output.dense.bias"],
+                        res=x, drop_p=p_h, seed=seed, tag=l * 8 + 1)
+            ops.layernorm_fwd(self.Z1[l], w32[p + "attention.output.LayerNorm.weight"], w32[p + "attention.output.LayerNorm.bias"],
+                              self.Y1[l], self.ST1[l])
+            ops.gemm_nt(self.Y1[l], w16[p + "intermediate.dense.weight"], self.G[l], bias=w32[p + "intermediate.dense.bias"],
+                        act=ops.ACT_GELU, pre=self.U[l])
+            ops.gemm_nt(self.G[l], w16[p + "output.dense.weight"], self.Z2[l], bias=w32[p + "output.dense.bias"], res=self.Y1[l],
+                        drop_p=p_h, seed=seed, tag=l * 8 + 2)
+            ops.layernorm_fwd(self.Z2[l], w32[p + "output.LayerNorm.weight"], w32[p + "output.LayerNorm.bias"], self.X[l + 1],
+                              self.ST2[l])
+        # --- heads ---------------------------------------------------------------------------------------
+        xl = self.X[L]
+        ops.gather_rows(xl, self.lay["text_rows"].view(-1), self.text_out)
+        ops.gather_rows(xl, self.lay["obj_rows"].view(-1), self.obj_out)
+        pm = "vlbert.mlm_head.predictions."
+        ops.gemm_nt(self.text_out, w16[pm + "transform.dense.weight"], self.mlm_g, bias=w32[pm + "transform.dense.bias"],
+                    act=ops.ACT_GELU, pre=self.mlm_u)
+        ops.layernorm_fwd(self.mlm_g, w32[pm + "transform.LayerNorm.weight"], w32[pm + "transform.LayerNorm.bias"], self.mlm_h,
+                          self.st_mlm)
+        ops.gemm_nt(self.mlm_h, w16["vlbert.word_embeddings.weight"], self.mlm_logits[:, :V], bias=w32[pm + "bias"])
+        ops.gemm_nt(self.obj_out, w16["vlbert.mvrc_head.transform.dense.weight"], self.mvrc_g,
+                    bias=w32["vlbert.mvrc_head.transform.dense.bias"], act=ops.ACT_GELU, pre=self.mvrc_u)
+        ops.gemm_nt(self.mvrc_g, w16["vlbert.mvrc_head.region_cls_pred.weight"], self.mvrc_logits[:, :C],
+                    bias=w32["vlbert.mvrc_head.region_cls_pred.bias"])
+        # --- losses (forward + d logits in place) ----------------------------------------------------------
+        ops.ce_fwd_bwd(self.mlm_logits, V, self.in_mlm_labels.view(-1), self.counts[0:1], self.losses[0:1], gscale=gscale,
+                       logits_copy=self.mlm_logits_copy)
+        ops.soft_ce_fwd_bwd(self.mvrc_logits, C, self.in_mvrc_labels.view(self.BR, C), self.mvrc_tsum, self.counts[1:2],
+                            self.losses[1:2], gscale=gscale, logits_copy=self.mvrc_logits_copy)
+
+    # ------------------------------------------------------------------------------------------
+    # backward (explicit; weight gradients are ACCUMULATED into the flat fp32 grad buffer)
+    # ------------------------------------------------------------------------------------------
+    def _wgrad(self, dy, x, gw, gb, tG, tA, rows_p):
+        """gw[N,K] += dy^T x ; gb[N] += colsum(dy) through zero-padded transposes."""
+        N, K = dy.shape[1], x.shape[1]
+        tg, ta = tG[:N, :rows_p], tA[:K, :rows_p]
+        ops.transpose(dy, tg, colsum=gb)
+        ops.transpose(x, ta)
+        ops.gemm_nt(tg, ta, gw, out_mode=ops.OUT_F32_ATOMIC)
+
+    def backward(self, train=None, on_layer_done=None):
+        train = self.train if train is None else train
+        cfg, B, T, R, S = self.cfg, self.B, self.T, self.R, self.S
+        H, I, V, C, L, nh = cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size, cfg.visual_region_classes, \
+            cfg.num_hidden_layers, cfg.num_attention_heads
+        p_h, p_a, p_ds = self._p(train)
+        w16, w32, g32, wT, seed = self.w16, self.w32, self.g32, self.wT, self.seed
+        Mp, BTp, BRp = self.Mp, self.BTp, self.BRp
+        # --- MLM head ------------------------------------------------------------------------------------
+        pm = "vlbert.mlm_head.predictions."
+        dlog = self.mlm_logits                       # [BT, Vp], pad columns zero
+        self._wgrad(dlog[:, :V], self.mlm_h, g32["vlbert.word_embeddings.weight"], g32[pm + "bias"], self.tG_bt, self.tA_bt, BTp)
+        ops.gemm_nt(dlog, wT["vlbert.word_embeddings.weight"], self.d_mlm_h)
+        ops.layernorm_bwd(self.d_mlm_h, self.mlm_g, self.st_mlm, w32[pm + "transform.LayerNorm.weight"], dx=self.d_mlm_g,
+                          dgamma=g32[pm + "transform.LayerNorm.weight"], dbeta=g32[pm + "transform.LayerNorm.bias"])
+        ops.dgelu_mul(self.d_mlm_g, self.mlm_u, self.d_mlm_u)
+        self._wgrad(self.d_mlm_u, self.text_out, g32[pm + "transform.dense.weight"], g32[pm + "transform.dense.bias"], self.tG_bt,
+                    self.tA_bt, BTp)
+        ops.gemm_nt(self.d_mlm_u, wT[pm + "transform.dense.weight"], self.d_text_out)
+        # --- MVRC head -----------------------------------------------------------------------------------
+        dlog2 = self.mvrc_logits                     # [BR, Cp]
+        self._wgrad(dlog2[:, :C], self.mvrc_g, g32["vlbert.mvrc_head.region_cls_pred.weight"],
+                    g32["vlbert.mvrc_head.region_cls_pred.bias"], self.tG_br, self.tA_br, BRp)
+        ops.gemm_nt(dlog2, wT["vlbert.mvrc_head.region_cls_pred.weight"], self.d_mvrc_u, act=ops.ACT_DGELU, aux=self.mvrc_u)
+        self._wgrad(self.d_mvrc_u, self.obj_out, g32["vlbert.mvrc_head.transform.dense.weight"],
+                    g32["vlbert.mvrc_head.transform.dense.bias"], self.tG_br, self.tA_br, BRp)
+        ops.gemm_nt(self.d_mvrc_u, wT["vlbert.mvrc_head.transform.dense.weight"], self.d_obj_out)
+        dx = self.dXa
+        ops.head_grad_combine(self.d_text_out, self.d_obj_out, self.lay["code"], dx, B, T, R, S, H)
+        if on_layer_done:
+            on_layer_done("heads")
+        # --- encoder, last layer first -------------------------------------------------------------------
+        mask = self.lay["attn_mask"]
+        for l in reversed(range(L)):
+            p = "vlbert.encoder.layer.%d." % l
+            dx_next = self.dXb if dx is self.dXa else self.dXa
+            drop = p_h > 0
+            # LN2: dZ2 (residual branch) and dD2 (into output.dense, through its dropout)
+            ops.layernorm_bwd(dx, self.Z2[l], self.ST2[l], w32[p + "output.LayerNorm.weight"], dx=self.dZ,
+                              dx_drop=self.dD if drop else None, drop_p=p_h, seed=seed, tag=l * 8 + 2,
+                              dgamma=g32[p + "output.LayerNorm.weight"], dbeta=g32[p + "output.LayerNorm.bias"])
+            dD2 = self.dD if drop else self.dZ
+            self._wgrad(dD2, self.G[l], g32[p + "output.dense.weight"], g32[p + "output.dense.bias"], self.tG, self.tA, Mp)
+            ops.gemm_nt(dD2, wT[p + "output.dense.weight"], self.dU, act=ops.ACT_DGELU, aux=self.U[l])
+            self._wgrad(self.dU, self.Y1[l], g32[p + "intermediate.dense.weight"], g32[p + "intermediate.dense.bias"], self.tG,
+                        self.tA, Mp)
+            ops.gemm_nt(self.dU, wT[p + "intermediate.dense.weight"], dx_next, res=self.dZ)            # dY1
+            # LN1
+            ops.layernorm_bwd(dx_next, self.Z1[l], self.ST1[l], w32[p + "attention.output.LayerNorm.weight"], dx=self.dZ,
+                              dx_drop=self.dD if drop else None, drop_p=p_h, seed=seed, tag=l * 8 + 1,
+                              dgamma=g32[p + "attention.output.LayerNorm.weight"], dbeta=g32[p + "attention.output.LayerNorm.bias"])
+            dD1 = self.dD if drop else self.dZ
+            self._wgrad(dD1, self.CTX[l], g32[p + "attention.output.dense.weight"], g32[p + "attention.output.dense.bias"],
+                        self.tG, self.tA, Mp)
+            ops.gemm_nt(dD1, wT[p + "attention.output.dense.weight"], self.dCTX)
+            ops.attention_bwd(self.QKV[l], mask, self.CTX[l], self.LSE[l], self.dCTX, self.dQKV, B, S, H, nh, drop_p=p_a,
+                              seed=seed, tag=l * 8 + 0)
+            gwqkv = self.P.view(self.P.grad, p + "attention.self.query.weight", (3 * H, H), span=3)
+            gbqkv = self.P.view(self.P.grad, p + "attention.self.query.bias", (3 * H,), span=3)
+            self._wgrad(self.dQKV, self.X[l], gwqkv, gbqkv, self.tG, self.tA, Mp)
+            ops.gemm_nt(self.dQKV, wT[p + "qkv"], dx_next, res=self.dZ)                                  # dX_l (overwrites dY1)
+            dx = dx_next
+            if on_layer_done:
+                on_layer_done(l)
+        # --- embedding + visual LayerNorms + obj_downsample ---------------------------------------------
+        self.d_objvis.zero_()
+        self.d_obj_reps.zero_()
+        pe = "vlbert.embedding_LayerNorm."
+        ops.embed_bwd(dx, self.emb_pre, self.st_emb, w32[pe + "weight"], self.lay, self.in_text, None, self.in_mvrc_ops,
+                      g32["vlbert.word_embeddings.weight"], g32["vlbert.position_embeddings.weight"],
+                      g32["vlbert.token_type_embeddings.weight"], g32["vlbert.end_embedding.weight"], g32[pe + "weight"],
+                      g32[pe + "bias"], self.d_textvis, (H, 0), self.d_objvis, (R * H, H),
+                      self.P.view(self.P.grad, "object_linguistic_embeddings.weight", (2, H), span=2), (0, 0), B, T, R, S, H,
+                      drop_p=p_h, seed=seed, tag=TAG_EMBED)
+        ops.layernorm_bwd(self.d_objvis, self.obj_reps, self.st_objvis, w32["vlbert.visual_ln_object.weight"],
+                          dx_acc=self.d_obj_reps, dgamma=g32["vlbert.visual_ln_object.weight"],
+                          dbeta=g32["vlbert.visual_ln_object.bias"])
+        reps0 = self.obj_reps.view(B, R * H)[:, :H]
+        ops.layernorm_bwd(self.d_textvis, reps0, self.st_textvis, w32["vlbert.visual_ln_text.weight"],
+                          dx_acc=self.d_obj_reps.view(B, R * H)[:, :H], dgamma=g32["vlbert.visual_ln_text.weight"],
+                          dbeta=g32["vlbert.visual_ln_text.bias"])
+        ops.relu_bwd_cast(self.d_obj_reps, self.obj_reps, self.d_yds)
+        pd = "image_feature_extractor.obj_downsample.1."
+        self._wgrad(self.d_yds, self.a_ds, g32[pd + "weight"], g32[pd + "bias"], self.tG_br, self.tA_br, BRp)
+        # gradient of the mask embedding: feature half of dA = dY W, masked regions only
+        ops.gemm_nt(self.d_yds, wT[pd + "weight"][VIS_DIM:], self.d_afeat)
+        ops.masked_colsum(self.d_afeat, self.in_mvrc_ops.view(-1), g32["object_mask_visual_embedding.weight"].view(-1),
+                          drop_p=p_ds, seed=seed, tag=TAG_DOWNSAMPLE, row_elems=2 * VIS_DIM, col_off=VIS_DIM)
+        if on_layer_done:
+            on_layer_done("embed")
+
+    # ------------------------------------------------------------------------------------------
+    # optimizer
+    # ------------------------------------------------------------------------------------------
+    def zero_grad(self):
+        self.P.grad.zero_()
+
+    def optimizer_step(self, lr=None):
+        """global-norm clip + AdamW + bf16 / transposed weight refresh + dropout seed advance.  With data
+        parallelism the flat gradient holds the SUM over ranks; the 1/world average (DDP semantics,
+        pretrain/function/train.py:89-90) is folded into the AdamW kernel's grad_scale."""
+        if lr is not None:
+            self.adam[0:1].fill_(lr)
+        scale = self.buckets.grad_scale if self.buckets is not None else 1.0
+        ops.sumsq(self.P.grad, self.adam[7:8])
+        ops.adamw_step(self.P.master, self.P.grad, self.P.m, self.P.v, self.P.w16, self.adam, grad_scale=scale)
+        self._refresh_transposes()
+        ops.rng_advance(self.seed)
+
+    def train_step(self, lr=None):
+        """zero_grad -> forward -> backward (gradient buckets all-reduced over RCCL as they complete,
+        overlapped with the rest of backward) -> clip + AdamW: one optimizer step on the batch currently
+        held in the static input buffers."""
+        self.zero_grad()
+        self.forward(True)
+        self.backward(True, on_layer_done=self.buckets.on_done if self.buckets is not None else None)
+        if self.buckets is not None:
+            self.buckets.wait()
+        self.optimizer_step(lr)
+
+    # ------------------------------------------------------------------------------------------
+    # results (host side, sync) -- used by tests / API parity, not by the timed loop
+    # ------------------------------------------------------------------------------------------
+    def loss_values(self):
+        l = self.losses.cpu()
+        return dict(mlm_loss=float(l[0]), mvrc_loss=float(l[1]), loss=float(l[0] + l[1]))
+
+    def grads(self):
+        return OrderedDict((k, v.detach().clone()) for k, v in self.g32.items())
+
+    def grad_norm(self):
+        return float(self.P.grad.double().norm())
+
+    def init_random(self, seed=0, visual_ln_init=0.0):
+        """Reference initialisation statistics on the device (BaseModel.init_weights,
+        common/visual_linguistic_bert.py:14-25,330-332; resnet_vlbert_for_pretraining.py:55-63): N(0, 0.02)
+        weights / embeddings, zero biases, unit LayerNorm gammas, visual_ln gammas = visual_scale_*_init,
+        zero mask-visual embedding.  Used by bench.py / smoke (no checkpoints exist offline)."""
+        g = torch.Generator(device=self.dev).manual_seed(seed)
+        for name, t in self.w32.items():
+            if "LayerNorm.weight" in name:
+                t.fill_(1.0)
+            elif name.endswith("visual_ln_text.weight") or name.endswith("visual_ln_object.weight"):
+                t.fill_(visual_ln_init)
+            elif name.endswith(".bias") or name == "object_mask_visual_embedding.weight":
+                t.zero_()
+            else:
+                t.normal_(0.0, 0.02, generator=g)
+        self._weights_dirty = True

@@ -1,0 +1,216 @@
+"""Thin tensor-level wrappers over the C ABI (vl-bert_amd/_lib.py -> libvlbert_hip.so).
+
+PyTorch is used for device memory and streams only: every function checks dtype/device,
+passes `tensor.data_ptr()` and the current HIP stream, and returns.  No arithmetic is done by
+torch here and there is no eager fallback -- a missing library or a CPU tensor raises.
+"""
+import torch
+
+from . import _lib
+
+BF16 = torch.bfloat16
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_DGELU = 0, 1, 2, 3
+OUT_BF16, OUT_F32, OUT_F32_ATOMIC = 0, 1, 2
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t, dtype=None):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("vl-bert_amd ops need GPU tensors (got %s); there is no CPU path" % t.device)
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError("expected dtype %s, got %s" % (dtype, t.dtype))
+    return t.data_ptr()
+
+
+def _ld(t):
+    """Leading dimension (elements) of a 2-D row-major view."""
+    if t is None:
+        return 0
+    assert t.dim() == 2 and t.stride(1) == 1, "expected a 2-D tensor with unit inner stride"
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
+def gemm_nt(A, B, C, bias=None, act=ACT_NONE, aux=None, pre=None, res=None, drop_p=0.0, seed=None, tag=0,
+            out_mode=OUT_BF16, splitk=0, K=None):
+    """C[M,N] (+)= A[M,K] B[N,K]^T with the fused epilogue of vlb_gemm_nt_bf16."""
+    M, N = C.shape
+    K = A.shape[1] if K is None else K
+    assert A.shape[0] == M and B.shape[0] == N and B.shape[1] >= K and A.shape[1] >= K
+    cdt = BF16 if out_mode == OUT_BF16 else torch.float32
+    _lib.call("vlb_gemm_nt_bf16", _p(A, BF16), _ld(A), _p(B, BF16), _ld(B), _p(C, cdt), _ld(C), M, N, K,
+              _p(bias, torch.float32), act, _p(aux, BF16), _ld(aux), _p(pre, BF16), _ld(pre), _p(res, BF16), _ld(res),
+              float(drop_p), _p(seed), int(tag), out_mode, splitk, _stream())
+    return C
+
+
+def transpose(x, out, colsum=None):
+    """out[c, r] = x[r, c] (out may have a padded leading dimension)."""
+    R, Cc = x.shape
+    _lib.call("vlb_transpose_bf16", _p(x, BF16), _ld(x), _p(out, BF16), _ld(out), R, Cc, _p(colsum, torch.float32), _stream())
+    return out
+
+
+def layernorm_fwd(x, gamma, beta, y, stats=None, eps=1e-12):
+    rows, H = x.shape
+    _lib.call("vlb_layernorm_fwd", _p(x, BF16), _ld(x), _p(gamma, torch.float32), _p(beta, torch.float32), _p(y, BF16),
+              _ld(y), _p(stats, torch.float32), rows, H, float(eps), _stream())
+    return y
+
+
+def layernorm_bwd(dy, x, stats, gamma, dx=None, dx_drop=None, drop_p=0.0, seed=None, tag=0, dx_acc=None, dgamma=None,
+                  dbeta=None):
+    rows, H = x.shape
+    dy_f32 = 1 if dy.dtype == torch.float32 else 0
+    _lib.call("vlb_layernorm_bwd", _p(dy), _ld(dy), dy_f32, _p(x, BF16), _ld(x), _p(stats, torch.float32),
+              _p(gamma, torch.float32), _p(dx, BF16), _ld(dx), _p(dx_drop, BF16), _ld(dx_drop), float(drop_p), _p(seed),
+              int(tag), _p(dx_acc, torch.float32), _ld(dx_acc), _p(dgamma, torch.float32), _p(dbeta, torch.float32), rows, H,
+              _stream())
+
+
+def attention_fwd(qkv, mask, ctx, lse, B, S, H, nh, drop_p=0.0, seed=None, tag=0):
+    _lib.call("vlb_attention_fwd", _p(qkv, BF16), _p(mask, torch.float32), _p(ctx, BF16), _p(lse, torch.float32), B, S, H, nh,
+              float(drop_p), _p(seed), int(tag), _stream())
+    return ctx
+
+
+def attention_bwd(qkv, mask, ctx, lse, dctx, dqkv, B, S, H, nh, drop_p=0.0, seed=None, tag=0):
+    _lib.call("vlb_attention_bwd", _p(qkv, BF16), _p(mask, torch.float32), _p(ctx, BF16), _p(lse, torch.float32),
+              _p(dctx, BF16), _p(dqkv, BF16), B, S, H, nh, float(drop_p), _p(seed), int(tag), _stream())
+    return dqkv
+
+
+def seq_layout(text_mask, obj_mask, S):
+    """masks: uint8/bool [B,T], [B,R] -> dict of layout tensors (all device int32 / fp32)."""
+    B, T = text_mask.shape
+    R = obj_mask.shape[1]
+    dev = text_mask.device
+    tm = text_mask.to(torch.uint8).contiguous()
+    om = obj_mask.to(torch.uint8).contiguous()
+    out = dict(code=torch.empty((B, S), dtype=torch.int32, device=dev), text_len=torch.empty((B,), dtype=torch.int32, device=dev),
+               nobj=torch.empty((B,), dtype=torch.int32, device=dev), text_rows=torch.empty((B, T), dtype=torch.int32, device=dev),
+               obj_rows=torch.empty((B, R), dtype=torch.int32, device=dev), attn_mask=torch.empty((B, S), dtype=torch.float32, device=dev))
+    seq_layout_into(tm, om, S, out)
+    return out
+
+
+def seq_layout_into(tm, om, S, out):
+    B, T = tm.shape
+    R = om.shape[1]
+    _lib.call("vlb_seq_layout", _p(tm, torch.uint8), _p(om, torch.uint8), B, T, R, S, _p(out["code"]), _p(out["text_len"]),
+              _p(out["nobj"]), _p(out["text_rows"]), _p(out["obj_rows"]), _p(out["attn_mask"]), _stream())
+
+
+def obj_prep_fwd(boxes, im_info, mvrc_ops, mask_emb, out, drop_p=0.0, seed=None, tag=0):
+    B, R, ldb = boxes.shape
+    assert boxes.is_contiguous() and out.shape[-1] == 4096
+    _lib.call("vlb_obj_prep_fwd", _p(boxes, torch.float32), ldb, _p(im_info, torch.float32), _p(mvrc_ops, torch.int64),
+              _p(mask_emb, torch.float32), _p(out, BF16), B, R, float(drop_p), _p(seed), int(tag), _stream())
+    return out
+
+
+def masked_colsum(src, sel, dst, drop_p=0.0, seed=None, tag=0, row_elems=0, col_off=0):
+    rows, C = src.shape
+    _lib.call("vlb_masked_colsum", _p(src, BF16), _ld(src), _p(sel, torch.int64), rows, C, _p(dst, torch.float32), float(drop_p),
+              _p(seed), int(tag), int(row_elems), int(col_off), _stream())
+
+
+def embed_fwd(lay, text_ids, text_type, word_emb, pos_emb, type_emb, end_emb, text_vis, tv_strides, obj_vis, ov_strides,
+              obj_ling, ol_strides, obj_ling_idx, gamma, beta, pre, stats, out, B, T, R, S, H, eps=1e-12, drop_p=0.0,
+              seed=None, tag=0):
+    _lib.call("vlb_embed_fwd", _p(lay["code"]), _p(lay["text_len"]), _p(text_ids, torch.int64), _p(text_type, torch.int64),
+              _p(word_emb, BF16), _p(pos_emb, BF16), _p(type_emb, BF16), _p(end_emb, BF16),
+              _p(text_vis, BF16), tv_strides[0], tv_strides[1], _p(obj_vis, BF16), ov_strides[0], ov_strides[1],
+              _p(obj_ling, BF16), ol_strides[0], ol_strides[1], _p(obj_ling_idx, torch.int64),
+              _p(gamma, torch.float32), _p(beta, torch.float32), _p(pre, BF16), _p(stats, torch.float32), _p(out, BF16),
+              B, T, R, S, H, word_emb.shape[0], pos_emb.shape[0], float(eps), float(drop_p), _p(seed), int(tag), _stream())
+    return out
+
+
+def embed_bwd(dy, pre, stats, gamma, lay, text_ids, text_type, obj_ling_idx, d_word, d_pos, d_type, d_end, d_gamma, d_beta,
+              d_text_vis, dtv_strides, d_obj_vis, dov_strides, d_obj_ling, dol_strides, B, T, R, S, H, drop_p=0.0, seed=None,
+              tag=0):
+    _lib.call("vlb_embed_bwd", _p(dy, BF16), _p(pre, BF16), _p(stats, torch.float32), _p(gamma, torch.float32), _p(lay["code"]),
+              _p(lay["text_len"]), _p(text_ids, torch.int64), _p(text_type, torch.int64), _p(obj_ling_idx, torch.int64),
+              _p(d_word, torch.float32), _p(d_pos, torch.float32), _p(d_type, torch.float32), _p(d_end, torch.float32),
+              _p(d_gamma, torch.float32), _p(d_beta, torch.float32),
+              _p(d_text_vis, torch.float32), dtv_strides[0], dtv_strides[1], _p(d_obj_vis, torch.float32), dov_strides[0],
+              dov_strides[1], _p(d_obj_ling, torch.float32), dol_strides[0], dol_strides[1],
+              B, T, R, S, H, d_word.shape[0], d_pos.shape[0], float(drop_p), _p(seed), int(tag), _stream())
+
+
+def gather_rows(src, idx, out):
+    n, H = out.shape
+    _lib.call("vlb_gather_rows", _p(src, BF16), _p(idx, torch.int32), _p(out, BF16), n, H, _stream())
+    return out
+
+
+def head_grad_combine(d_text, d_obj, code, dx, B, T, R, S, H):
+    _lib.call("vlb_head_grad_combine", _p(d_text, BF16), _p(d_obj, BF16), _p(code, torch.int32), _p(dx, BF16), B, T, R, S, H,
+              _stream())
+    return dx
+
+
+def relu_bwd_cast(g, y, out):
+    _lib.call("vlb_relu_bwd_cast", _p(g, torch.float32), _p(y, BF16), _p(out, BF16), g.numel(), _stream())
+    return out
+
+
+def dgelu_mul(dg, u, out):
+    _lib.call("vlb_dgelu_mul", _p(dg, BF16), _p(u, BF16), _p(out, BF16), dg.numel(), _stream())
+    return out
+
+
+def ce_fwd_bwd(logits, V, labels, counts, loss_out, gscale=1.0, logits_copy=None):
+    rows = logits.shape[0]
+    _lib.call("vlb_ce_fwd_bwd", _p(logits, BF16), _ld(logits), rows, V, _p(labels, torch.int64), _p(counts, torch.float32),
+              float(gscale), _p(loss_out, torch.float32), _p(logits_copy, BF16), _ld(logits_copy), _stream())
+
+
+def soft_ce_fwd_bwd(logits, C, target, tsum, counts, loss_out, gscale=1.0, logits_copy=None):
+    rows = logits.shape[0]
+    _lib.call("vlb_soft_ce_fwd_bwd", _p(logits, BF16), _ld(logits), rows, C, _p(target, torch.float32), _ld(target),
+              _p(tsum, torch.float32), _p(counts, torch.float32), float(gscale), _p(loss_out, torch.float32),
+              _p(logits_copy, BF16), _ld(logits_copy), _stream())
+
+
+def sumsq(g, out):
+    _lib.call("vlb_sumsq_f32", _p(g, torch.float32), g.numel(), _p(out, torch.float32), _stream())
+
+
+def adamw_step(p, g, m, v, p16, state, grad_scale=1.0):
+    _lib.call("vlb_adamw_step", _p(p, torch.float32), _p(g, torch.float32), _p(m, torch.float32), _p(v, torch.float32),
+              _p(p16, BF16), p.numel(), _p(state, torch.float32), float(grad_scale), _stream())
+
+
+def cast_f32_bf16(src, dst):
+    _lib.call("vlb_cast_f32_bf16", _p(src, torch.float32), _p(dst, BF16), src.numel(), _stream())
+    return dst
+
+
+def cast_bf16_f32(src, dst):
+    _lib.call("vlb_cast_bf16_f32", _p(src, BF16), _p(dst, torch.float32), src.numel(), _stream())
+    return dst
+
+
+def rng_advance(seed):
+    _lib.call("vlb_rng_advance", _p(seed), _stream())
+
+
+def roi_align_fwd(inp, rois, out, spatial_scale, sampling_ratio):
+    K, C, ph, pw = out.shape
+    _lib.call("vlb_roi_align_fwd", _p(inp, torch.float32), _p(rois, torch.float32), _p(out, torch.float32), K, C, inp.shape[2],
+              inp.shape[3], ph, pw, float(spatial_scale), int(sampling_ratio), _stream())
+    return out
+
+
+def roi_align_bwd(grad_out, rois, grad_in, spatial_scale, sampling_ratio):
+    K, C, ph, pw = grad_out.shape
+    Bn, _, Hh, Ww = grad_in.shape
+    _lib.call("vlb_roi_align_bwd", _p(grad_out, torch.float32), _p(rois, torch.float32), _p(grad_in, torch.float32), K, Bn, C, Hh,
+              Ww, ph, pw, float(spatial_scale), int(sampling_ratio), _stream())
+    return grad_in

@@ -1,0 +1,85 @@
+"""Data-parallel gradient exchange for the flat gradient buffer -- RCCL over xGMI.
+
+Replaces torch.nn.parallel.DistributedDataParallel / apex DDP at pretrain/function/train.py:89-90,353-354.
+One process per GPU (`torch.distributed`, backend "nccl" == RCCL on ROCm; "gloo" in the CPU tests).
+
+Because the backward is hand-scheduled (engine.backward), gradient readiness is known statically:
+the flat buffer is laid out [embeddings | obj_downsample | LayerNorms | layer 0 .. L-1 | heads] and
+backward finishes heads first, then layers L-1 .. 0, then the embedding side.  Buckets are therefore
+CONTIGUOUS slices of the flat buffer; each is all-reduced (SUM) with async_op=True as soon as the
+kernels producing it have been enqueued: the collective waits (on the communicator's stream) for
+exactly those kernels and then overlaps with the rest of backward.  xGMI is point-to-point
+(7 links x ~153 GB/s per GPU) so ring all-reduce is per-link bound: few, large buckets (default
+~64 MB fp32, i.e. 2-3 encoder layers) keep every link busy without serialising on launch latency.
+The 1/world_size average is folded into the AdamW kernel's grad_scale (no extra pass).
+
+Gradient accumulation: call `reduce_*` only on the boundary micro-step (the reference all-reduces on
+every micro-batch, common/trainer.py:117-118,132-153).
+"""
+import torch
+import torch.distributed as dist
+
+
+class GradBuckets:
+    def __init__(self, flat_grad, offsets, numel, num_layers, group=None, bucket_bytes=64 << 20, wire_dtype=None):
+        """flat_grad: the flat fp32 gradient tensor; offsets: {param name: start offset} in layout order."""
+        self.flat = flat_grad
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.wire_dtype = wire_dtype
+        names = list(offsets)
+        layer_start = [offsets["vlbert.encoder.layer.%d.attention.self.query.weight" % l] for l in range(num_layers)]
+        head_start = offsets["vlbert.mlm_head.predictions.transform.dense.weight"]
+        bounds = layer_start + [head_start]
+        self.ranges = {"heads": (head_start, numel), "embed": (0, layer_start[0] if num_layers else head_start)}
+        # group consecutive layers (in backward order) into buckets of ~bucket_bytes
+        self.layer_bucket = {}
+        cur, cur_bytes = [], 0
+        for l in reversed(range(num_layers)):
+            cur.append(l)
+            cur_bytes += (bounds[l + 1] - bounds[l]) * 4
+            if cur_bytes >= bucket_bytes or l == 0:
+                lo, hi = bounds[min(cur)], bounds[max(cur) + 1]
+                self.layer_bucket[min(cur)] = (lo, hi)     # ready once its LOWEST layer finished backward
+                cur, cur_bytes = [], 0
+        self.pending = []
+        assert names[0] in offsets
+
+    def coverage(self):
+        """All ranges, for tests: they must tile [0, numel) exactly."""
+        r = [self.ranges["embed"]] + sorted(self.layer_bucket.values()) + [self.ranges["heads"]]
+        return r
+
+    def _launch(self, lo, hi):
+        if self.world == 1:
+            return
+        t = self.flat[lo:hi]
+        if self.wire_dtype is not None and self.wire_dtype != t.dtype:
+            w = t.to(self.wire_dtype)
+            work = dist.all_reduce(w, group=self.group, async_op=True)
+            self.pending.append((work, t, w))
+        else:
+            work = dist.all_reduce(t, group=self.group, async_op=True)
+            self.pending.append((work, None, None))
+
+    def on_done(self, what):
+        """engine.backward hook: `what` is "heads", a layer index, or "embed"."""
+        if what == "heads":
+            # the tied word-embedding gradient is only complete after the embedding backward -> it lives in
+            # the "embed" range; the head range holds transform / decoder bias / MVRC head gradients
+            self._launch(*self.ranges["heads"])
+        elif what == "embed":
+            self._launch(*self.ranges["embed"])
+        elif what in self.layer_bucket:
+            self._launch(*self.layer_bucket[what])
+
+    def wait(self):
+        for work, dst, wire in self.pending:
+            work.wait()
+            if dst is not None:
+                dst.copy_(wire)
+        self.pending = []
+
+    @property
+    def grad_scale(self):
+        return 1.0 / self.world
