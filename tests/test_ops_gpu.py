@@ -132,7 +132,7 @@ def test_gemm_dropout_and_ln_mask_agree(ops):
 # ------------------------------------------------------------------------------------ LayerNorm
 @pytest.mark.parametrize("rows,H", [(7, 128), (333, 768), (64, 1024), (5, 64)])
 def test_layernorm_fwd_bwd(ops, rows, H):
-    x = rnd(rows, H, seed=20, scale=2.0) + 0.5
+    x = bf(rnd(rows, H, seed=20, scale=2.0) + 0.5)
     g = torch.Generator().manual_seed(21)
     gamma = 1 + 0.2 * torch.randn(H, generator=g)
     beta = 0.1 * torch.randn(H, generator=g)

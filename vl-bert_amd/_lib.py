@@ -50,6 +50,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm bundles its own libamdhip64.so (same SONAME as /opt/rocm's).  Import torch FIRST so the
+    # process has exactly one HIP runtime -- the one that owns torch's streams and allocations; loading this
+    # library first would bind it to /opt/rocm's copy and leave two runtimes fighting over the device.
+    import torch  # noqa: F401
     if not os.path.isfile(LIB_PATH):
         raise RuntimeError(
             "libvlbert_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "

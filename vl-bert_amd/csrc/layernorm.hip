@@ -10,13 +10,16 @@
 
 #define LN_MAX_IT 8  // H <= 2048
 
+// NIT = ceil(H / 256): per-lane register footprint follows the actual row width (H=768 -> 3)
+template <int NIT>
 struct Row4 {
-  float v[LN_MAX_IT][4];
+  float v[NIT][4];
 };
 
-__device__ __forceinline__ void load_row_bf16(const bf16_t* x, int H, int lane, Row4& r) {
+template <int NIT>
+__device__ __forceinline__ void load_row_bf16(const bf16_t* x, int H, int lane, Row4<NIT>& r) {
 #pragma unroll
-  for (int i = 0; i < LN_MAX_IT; ++i) {
+  for (int i = 0; i < NIT; ++i) {
     const int c = (lane + 64 * i) * 4;
     if (c < H) {
       const uint2 w = *(const uint2*)(x + c);
@@ -28,21 +31,22 @@ __device__ __forceinline__ void load_row_bf16(const bf16_t* x, int H, int lane, 
 }
 
 // x: [rows] rows of H bf16 with row stride ldx (elements).  y: row stride ldy.
+template <int NIT>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __restrict__ x, long ldx, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, bf16_t* __restrict__ y, long ldy,
                                                             float* __restrict__ stats, int rows, int H, float eps) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
-  Row4 r;
+  Row4<NIT> r;
   load_row_bf16(x + (long)row * ldx, H, lane, r);
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < LN_MAX_IT; ++i) s += (r.v[i][0] + r.v[i][1]) + (r.v[i][2] + r.v[i][3]);
+  for (int i = 0; i < NIT; ++i) s += (r.v[i][0] + r.v[i][1]) + (r.v[i][2] + r.v[i][3]);
   const float mean = wave_sum(s) / (float)H;
   float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < LN_MAX_IT; ++i) {
+  for (int i = 0; i < NIT; ++i) {
     const int c = (lane + 64 * i) * 4;
     if (c < H) {
 #pragma unroll
@@ -59,7 +63,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __rest
   }
   bf16_t* yr = y + (long)row * ldy;
 #pragma unroll
-  for (int i = 0; i < LN_MAX_IT; ++i) {
+  for (int i = 0; i < NIT; ++i) {
     const int c = (lane + 64 * i) * 4;
     if (c < H) {
       const float4 g = *(const float4*)(gamma + c);
@@ -79,6 +83,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __rest
 // flows into the dense layer *before* its dropout; idx = row*H + col matches the GEMM epilogue),
 // dx_acc fp32 (atomicAdd; used when several rows alias one input row, e.g. the broadcast
 // text_visual_embeddings of pretrain/modules/resnet_vlbert_for_pretraining.py:132-135).
+template <int NIT>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restrict__ dy_, long lddy, int dy_f32, const bf16_t* __restrict__ x,
                                                             long ldx, const float* __restrict__ stats, const float* __restrict__ gamma,
                                                             bf16_t* __restrict__ dx, long lddx, bf16_t* __restrict__ dx_drop, long lddd,
@@ -88,19 +93,19 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
   extern __shared__ __attribute__((aligned(16))) float red[];  // [2][4 waves][H]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t seed = (drop_thr && seedp) ? *seedp : 0u;
-  float gsum[LN_MAX_IT][4], bsum[LN_MAX_IT][4];
+  float gsum[NIT][4], bsum[NIT][4];
 #pragma unroll
-  for (int i = 0; i < LN_MAX_IT; ++i)
+  for (int i = 0; i < NIT; ++i)
 #pragma unroll
     for (int k = 0; k < 4; ++k) gsum[i][k] = bsum[i][k] = 0.f;
 
   for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
-    Row4 xr, dyr;
+    Row4<NIT> xr, dyr;
     load_row_bf16(x + (long)row * ldx, H, lane, xr);
     if (dy_f32) {
       const float* d = (const float*)dy_ + (long)row * lddy;
 #pragma unroll
-      for (int i = 0; i < LN_MAX_IT; ++i) {
+      for (int i = 0; i < NIT; ++i) {
         const int c = (lane + 64 * i) * 4;
         float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
         if (c < H) t = *(const float4*)(d + c);
@@ -112,7 +117,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
     const float mean = stats[2 * (long)row], rstd = stats[2 * (long)row + 1];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAX_IT; ++i) {
+    for (int i = 0; i < NIT; ++i) {
       const int c = (lane + 64 * i) * 4;
       if (c < H) {
         const float4 g = *(const float4*)(gamma + c);
@@ -134,7 +139,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
     s1 = wave_sum(s1) / (float)H;
     s2 = wave_sum(s2) / (float)H;
 #pragma unroll
-    for (int i = 0; i < LN_MAX_IT; ++i) {
+    for (int i = 0; i < NIT; ++i) {
       const int c = (lane + 64 * i) * 4;
       if (c < H) {
         float o[4];
@@ -171,7 +176,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
   float* rg = red;
   float* rb = red + 4 * H;
 #pragma unroll
-  for (int i = 0; i < LN_MAX_IT; ++i) {
+  for (int i = 0; i < NIT; ++i) {
     const int c = (lane + 64 * i) * 4;
     if (c < H) {
 #pragma unroll
@@ -193,8 +198,12 @@ extern "C" int vlb_layernorm_fwd(const void* x, long ldx, const float* gamma, co
   if (rows <= 0) return VLB_OK;
   VLB_CHECK_ARG(H > 0 && (H % 4) == 0 && H <= 256 * LN_MAX_IT, "vlb_layernorm_fwd: unsupported H=%d", H);
   VLB_CHECK_ARG((ldx % 4) == 0 && (ldy % 4) == 0, "vlb_layernorm_fwd: row strides must be multiples of 4");
-  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(vlb_cdiv(rows, 4)), dim3(256), 0, stream, (const bf16_t*)x, ldx, gamma, beta,
-                     (bf16_t*)y, ldy, stats, rows, H, eps);
+#define LN_FWD(NIT)                                                                                                         \
+  hipLaunchKernelGGL(layernorm_fwd_kernel<NIT>, dim3(vlb_cdiv(rows, 4)), dim3(256), 0, stream, (const bf16_t*)x, ldx, gamma, \
+                     beta, (bf16_t*)y, ldy, stats, rows, H, eps)
+  const int nit = vlb_cdiv(H, 256);
+  if (nit <= 1) LN_FWD(1); else if (nit == 2) LN_FWD(2); else if (nit == 3) LN_FWD(3); else if (nit == 4) LN_FWD(4); else LN_FWD(8);
+#undef LN_FWD
   VLB_CHECK_LAUNCH("vlb_layernorm_fwd");
   return VLB_OK;
 }
@@ -210,9 +219,13 @@ extern "C" int vlb_layernorm_bwd(const void* dy, long lddy, int dy_f32, const vo
   int blocks = vlb_cdiv(rows, 4);
   if (blocks > 512) blocks = 512;
   const uint32_t thr = vlb_drop_thr(drop_p);
-  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 2 * 4 * H * sizeof(float), stream, dy, lddy, dy_f32,
-                     (const bf16_t*)x, ldx, stats, gamma, (bf16_t*)dx, lddx, (bf16_t*)dx_drop, lddd, thr, vlb_drop_scale(thr), seed,
-                     tag, dx_acc, ldacc, dgamma, dbeta, rows, H);
+#define LN_BWD(NIT)                                                                                                            \
+  hipLaunchKernelGGL(layernorm_bwd_kernel<NIT>, dim3(blocks), dim3(256), 2 * 4 * H * sizeof(float), stream, dy, lddy, dy_f32,   \
+                     (const bf16_t*)x, ldx, stats, gamma, (bf16_t*)dx, lddx, (bf16_t*)dx_drop, lddd, thr, vlb_drop_scale(thr),  \
+                     seed, tag, dx_acc, ldacc, dgamma, dbeta, rows, H)
+  const int nit = vlb_cdiv(H, 256);
+  if (nit <= 1) LN_BWD(1); else if (nit == 2) LN_BWD(2); else if (nit == 3) LN_BWD(3); else if (nit == 4) LN_BWD(4); else LN_BWD(8);
+#undef LN_BWD
   VLB_CHECK_LAUNCH("vlb_layernorm_bwd");
   return VLB_OK;
 }
