@@ -43,7 +43,9 @@ def cpu_baseline(cfg_kw, T, R, budget_s=25.0):
     forward + backward + AdamW of the same 12-layer model on a bounded sample (small batch, few iterations)."""
     from oracle import vlbert_oracle as O
     syn = importlib.import_module("vl-bert_amd.synthetic")
-    cores = os.cpu_count() or 1
+    # 256 torch threads on the GPU box's host oversubscribe badly (measured: 0.02 samples/s); cap the pool and
+    # report the thread count actually used as `cores`.
+    cores = min(os.cpu_count() or 1, 64)
     torch.set_num_threads(cores)
     cfg = O.VLBertConfig(**cfg_kw)
     params = O.init_params(cfg, seed=0, randomize_all=False)

@@ -172,3 +172,49 @@ def test_dropout_training_step_runs_and_is_deterministic():
     assert abs(vals[0][0] - vals[1][0]) < 1e-4 and abs(vals[0][1] - vals[1][1]) < 1e-3 * vals[0][1]
     eval_loss = O.loss_and_grads(params, cfg, batch, train=False)[1]
     assert abs(vals[0][0] - float(eval_loss)) < 0.5   # dropout perturbs, not destroys
+
+
+def test_dropin_module_matches_reference_training_loop_contract():
+    """The nn.Module mirror: reference constructor/forward signature, state-dict keys, autograd + torch optimizer."""
+    M = pkg("pretrain.modules")
+    syn = pkg("synthetic")
+    z = np.load(GOLDEN[[os.path.basename(p) for p in GOLDEN].index("ragged_small.npz")], allow_pickle=False)
+    kw = {str(k): int(v) for k, v in zip(z["cfg_keys"], z["cfg_vals"])}
+    cfg = O.VLBertConfig(**kw)
+
+    class A(dict):
+        __getattr__ = dict.__getitem__
+    config = A(NETWORK=A(IMAGE_FEAT_PRECOMPUTED=True, IMAGE_SEMANTIC=False, WITH_REL_LOSS=False, WITH_MLM_LOSS=True,
+                         WITH_MVRC_LOSS=True,
+                         VLBERT=A(hidden_size=cfg.hidden_size, visual_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers,
+                                  num_attention_heads=cfg.num_attention_heads, intermediate_size=cfg.intermediate_size,
+                                  vocab_size=cfg.vocab_size, max_position_embeddings=cfg.max_position_embeddings,
+                                  type_vocab_size=3, visual_region_classes=cfg.visual_region_classes, visual_ln=True,
+                                  with_pooler=False, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1,
+                                  initializer_range=0.02, visual_scale_text_init=0.0, visual_scale_object_init=0.0)))
+    net = M.ResNetVLBERTForPretraining(config)
+    # state-dict contract: exactly the reference's parameter names (+ the tied decoder alias)
+    ref_names = set(str(n) for n in z["names"])
+    sd = net.state_dict()
+    assert set(sd) == ref_names | {"vlbert.mlm_head.predictions.decoder.weight"}
+    assert set(n for n, _ in net.named_parameters()) == ref_names
+    params = O.init_params(cfg, seed=int(z["pseed"]))
+    net.load_state_dict({**params, "vlbert.mlm_head.predictions.decoder.weight": params["vlbert.word_embeddings.weight"]})
+    net.eval()
+    batch = tuple(torch.from_numpy(z["in_" + k]).to(dev()) for k in
+                  ("boxes", "im_info", "text", "relationship_label", "mlm_labels", "mvrc_ops", "mvrc_labels"))
+    outputs, loss = net(None, *batch)
+    report("module mlm_logits vs REFERENCE", outputs["mlm_logits"], torch.from_numpy(z["mlm_logits"]), 2e-3, 1e-2)
+    report("module mvrc_logits vs REFERENCE", outputs["mvrc_logits"], torch.from_numpy(z["mvrc_logits"]), 2e-3, 1e-2)
+    assert abs(float(loss) - float(z["loss"])) <= 1e-2 * float(z["loss"])
+    (loss / 2).backward()                                   # upstream scale, as with gradient accumulation
+    total = torch.nn.utils.clip_grad_norm_(net.parameters(), 1e9)
+    assert abs(float(total) - 0.5 * float(z["grad_norm"])) <= 1e-2 * 0.5 * float(z["grad_norm"])
+    # a torch optimizer steps the flat storage; the next forward sees the new weights
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    opt.step()
+    opt.zero_grad()
+    outputs2, loss2 = net(None, *batch)
+    assert float(loss2) < float(loss)
+    loss2.backward()
+    assert all(p.grad is not None for p in net.parameters())

@@ -17,15 +17,16 @@ def bench(M, N, K, mode, iters=20):
     A = (torch.rand((M, K), device=d) * 2 - 1).to(torch.bfloat16)
     B = (torch.rand((N, K), device=d) * 2 - 1).to(torch.bfloat16)
     kw = {}
+    ldc = (N + 63) // 64 * 64
     if mode == "wgrad":
-        C = torch.zeros((M, N), dtype=torch.float32, device=d)
+        C = torch.zeros((M, ldc), dtype=torch.float32, device=d)[:, :N]
         kw = dict(out_mode=ops.OUT_F32_ATOMIC)
     else:
-        C = torch.empty((M, N), dtype=torch.bfloat16, device=d)
+        C = torch.empty((M, ldc), dtype=torch.bfloat16, device=d)[:, :N]
         if mode == "gelu":
-            kw = dict(bias=torch.zeros(N, device=d), act=ops.ACT_GELU, pre=torch.empty_like(C))
+            kw = dict(bias=torch.zeros(N, device=d), act=ops.ACT_GELU, pre=torch.empty((M, ldc), dtype=torch.bfloat16, device=d)[:, :N])
         elif mode == "res":
-            kw = dict(bias=torch.zeros(N, device=d), res=torch.zeros_like(C))
+            kw = dict(bias=torch.zeros(N, device=d), res=torch.zeros((M, ldc), dtype=torch.bfloat16, device=d)[:, :N])
         elif mode == "bias":
             kw = dict(bias=torch.zeros(N, device=d))
     for _ in range(3):

@@ -40,11 +40,12 @@ __device__ __forceinline__ bf16x8 lds_frag(const char* base, int addr) { return 
 
 // Stage one [S][64] head slice (rows b*S.., row stride ld elements) into LDS.
 //   rm  : row-major image (or null)     tr : transposed image (or null)
-// 256 threads, 4 chunks of 16 B each; rows >= S are zero-filled.
+// NT threads, 1024/NT chunks of 16 B each; rows >= S are zero-filled.
+template <int NT>
 __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, long ld, int S, char* rm, char* tr, int tid) {
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int P = it * 256 + tid, row = P >> 3, ch = P & 7;
+  for (int it = 0; it < 1024 / NT; ++it) {
+    const int P = it * NT + tid, row = P >> 3, ch = P & 7;
     uint4 v = make_uint4(0, 0, 0, 0);
     if (row < S) v = *(const uint4*)(g + (long)row * ld + ch * 8);
     if (rm) *(uint4*)(rm + rm_addr(row, ch)) = v;
@@ -91,8 +92,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
   const int S = p.S;
   const long ld = 3L * p.H;
   const bf16_t* qbase = p.qkv + (long)b * S * ld + h * ATT_D;
-  stage_tile(qbase + p.H, ld, S, sK, nullptr, tid);
-  stage_tile(qbase + 2 * p.H, ld, S, nullptr, sVt, tid);
+  stage_tile<256>(qbase + p.H, ld, S, sK, nullptr, tid);
+  stage_tile<256>(qbase + 2 * p.H, ld, S, nullptr, sVt, tid);
   if (tid < ATT_SP) sMB[tid] = (tid < S) ? (1.0f - p.mask[b * S + tid]) * -10000.0f : -INFINITY;
 
   const int q0 = wave * 32;
@@ -207,7 +208,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
 // =============================================================================================
 // backward
 // =============================================================================================
-__global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnParams p) {
+// 512 threads: waves 0-3 run orientation N (dK, dV for keys 32w..), waves 4-7 run orientation T (dQ for
+// queries 32w..) CONCURRENTLY -- the two halves are independent, share the LDS images, and give the CU two
+// waves per SIMD to hide LDS latency.
+__global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sQ = smem;                    // row-major
   char* sK = smem + 1 * TILE_BYTES;
@@ -228,14 +232,14 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnParams p) {
   const bf16_t* qbase = p.qkv + (long)b * S * ld + h * ATT_D;
   const bf16_t* dobase = p.dctx + (long)b * S * p.H + h * ATT_D;
   const bf16_t* obase = p.ctx + (long)b * S * p.H + h * ATT_D;
-  stage_tile(qbase, ld, S, sQ, sQt, tid);
-  stage_tile(qbase + p.H, ld, S, sK, sKt, tid);
-  stage_tile(qbase + 2 * p.H, ld, S, sV, nullptr, tid);
-  stage_tile(dobase, p.H, S, sdO, sdOt, tid);
+  stage_tile<512>(qbase, ld, S, sQ, sQt, tid);
+  stage_tile<512>(qbase + p.H, ld, S, sK, sKt, tid);
+  stage_tile<512>(qbase + 2 * p.H, ld, S, sV, nullptr, tid);
+  stage_tile<512>(dobase, p.H, S, sdO, sdOt, tid);
   // D[q] = sum_d dO[q][d] * O[q][d]   (8 lanes per row, 8 elements each)
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int P = it * 256 + tid, row = P >> 3, ch = P & 7;
+  for (int it = 0; it < 2; ++it) {
+    const int P = it * 512 + tid, row = P >> 3, ch = P & 7;
     float d = 0.f;
     if (row < S) {
       const uint4 a = *(const uint4*)(dobase + (long)row * p.H + ch * 8);
@@ -257,12 +261,13 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnParams p) {
   const uint32_t seed = (p.drop_thr && p.seed) ? *p.seed : 0u;
   const uint32_t bh = (uint32_t)(b * p.nh + h);
   const int U = (S + 31) >> 5;
-  const int w32 = wave * 32;
+  const int w32 = (wave & 3) * 32;
+  const bool role_n = wave < 4;
 
   // ------------------------------------------------------------------------------------------
   // Orientation N (wave owns keys w32 .. w32+31): dV, dK (reductions over queries)
   // ------------------------------------------------------------------------------------------
-  if (w32 < S) {
+  if (role_n && w32 < S) {
     bf16x8 kf[2][2], vf[2][2];  // B operands: lane (c,g) <- K/V[key = w32+16kb+c][32ds+8g..]
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
@@ -342,7 +347,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnParams p) {
   // ------------------------------------------------------------------------------------------
   // Orientation T (wave owns queries w32 .. w32+31): dQ (reduction over keys)
   // ------------------------------------------------------------------------------------------
-  if (w32 < S) {
+  if (!role_n && w32 < S) {
     bf16x8 qf[2][2], dof[2][2];  // B operands: lane (c,g) <- Q/dO[q = w32+16qb+c][32ds+8g..]
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb)
@@ -453,7 +458,7 @@ extern "C" int vlb_attention_bwd(const void* qkv, const float* mask, const void*
     (void)hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
-  hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * nh), dim3(256), smem, stream, p);
+  hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * nh), dim3(512), smem, stream, p);
   VLB_CHECK_LAUNCH("vlb_attention_bwd");
   return VLB_OK;
 }

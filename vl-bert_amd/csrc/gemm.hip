@@ -41,6 +41,100 @@ struct GemmParams {
 #define GLDS_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
+// Epilogue specialised at compile time on (activation, dropout, residual, output mode) so each variant is a
+// straight-line body; the bias vector depends only on the column fragment and is loaded once per column.
+template <int ACT, bool DROP, bool RES, int OUT, int FM, int FN>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[FM][FN], int mb, int nb) {
+  const uint32_t seed = DROP ? *p.seed : 0u;
+  float bias[FN][4];
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    const int n = nb + j * 16;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias[j][r] = 0.f;
+    if (p.bias) {
+      if (n + 3 < p.N) {
+        const float4 b = *(const float4*)(p.bias + n);
+        bias[j][0] = b.x; bias[j][1] = b.y; bias[j][2] = b.z; bias[j][3] = b.w;
+      } else {
+        for (int r = 0; r < 4; ++r) if (n + r < p.N) bias[j][r] = p.bias[n + r];
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const int m = mb + i * 16;
+    if (m >= p.M) continue;
+    const long rowc = (long)m * p.ldc;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int n = nb + j * 16;
+      if (n >= p.N) continue;
+      const bool full = (n + 3 < p.N);
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bias[j][r];
+      if (ACT == 1) {
+        if (p.pre) {
+          bf16_t* q = p.pre + (long)m * p.ldpre + n;
+          if (full) *(uint2*)q = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+          else for (int r = 0; r < 4 && n + r < p.N; ++r) q[r] = f2bf(v[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
+      } else if (ACT == 2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+      } else if (ACT == 3) {
+        float u[4] = {0.f, 0.f, 0.f, 0.f};
+        const bf16_t* q = p.aux + (long)m * p.ldaux + n;
+        if (full) {
+          const uint2 w = *(const uint2*)q;
+          u[0] = bflo(w.x); u[1] = bfhi(w.x); u[2] = bflo(w.y); u[3] = bfhi(w.y);
+        } else {
+          for (int r = 0; r < 4 && n + r < p.N; ++r) u[r] = bf2f(q[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= dgelu_f(u[r]);
+      }
+      if (DROP) {
+        const uint32_t idx = (uint32_t)m * (uint32_t)p.N + (uint32_t)n;
+        if ((idx & 1u) == 0) {  // n%4==0: element pairs (idx,idx+1), (idx+2,idx+3) share one hash each
+          const uint32_t h0 = vlb_rng_pair(seed, p.tag, idx >> 1), h1 = vlb_rng_pair(seed, p.tag, (idx >> 1) + 1);
+          v[0] = ((h0 & 0xffffu) >= p.drop_thr) ? v[0] * p.drop_scale : 0.f;
+          v[1] = ((h0 >> 16) >= p.drop_thr) ? v[1] * p.drop_scale : 0.f;
+          v[2] = ((h1 & 0xffffu) >= p.drop_thr) ? v[2] * p.drop_scale : 0.f;
+          v[3] = ((h1 >> 16) >= p.drop_thr) ? v[3] * p.drop_scale : 0.f;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = vlb_keep(seed, p.tag, idx + r, p.drop_thr) ? v[r] * p.drop_scale : 0.f;
+        }
+      }
+      if (RES) {
+        const bf16_t* q = p.res + (long)m * p.ldres + n;
+        if (full) {
+          const uint2 w = *(const uint2*)q;
+          v[0] += bflo(w.x); v[1] += bfhi(w.x); v[2] += bflo(w.y); v[3] += bfhi(w.y);
+        } else {
+          for (int r = 0; r < 4 && n + r < p.N; ++r) v[r] += bf2f(q[r]);
+        }
+      }
+      if (OUT == 0) {
+        bf16_t* c = (bf16_t*)p.C + rowc + n;
+        if (full) *(uint2*)c = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+        else for (int r = 0; r < 4 && n + r < p.N; ++r) c[r] = f2bf(v[r]);
+      } else if (OUT == 1) {
+        float* c = (float*)p.C + rowc + n;
+        if (full) *(float4*)c = make_float4(v[0], v[1], v[2], v[3]);
+        else for (int r = 0; r < 4 && n + r < p.N; ++r) c[r] = v[r];
+      } else {
+        float* c = (float*)p.C + rowc + n;
+        for (int r = 0; r < 4 && n + r < p.N; ++r) atomicAdd(c + r, v[r]);
+      }
+    }
+  }
+}
+
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const GemmParams p) {
   constexpr int BK = 64;
@@ -133,118 +227,89 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const GemmParams p) {
   }
 
   // ---- epilogue: lane holds C[m][n..n+3], m = .. + (lane&15), n = .. + 4*(lane>>4) ----
-  const uint32_t seed = (p.drop_thr && p.seed) ? *p.seed : 0u;
-#pragma unroll
-  for (int i = 0; i < FM; ++i) {
-    const int m = m0 + wm * WM + i * 16 + (lane & 15);
-    if (m >= p.M) continue;
-#pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      const int n = n0 + wn * WN + j * 16 + 4 * (lane >> 4);
-      if (n >= p.N) continue;
-      const bool full = (n + 3 < p.N);
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      if (p.bias) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += (full || n + r < p.N) ? p.bias[n + r] : 0.f;
-      }
-      if (p.act == 1) {
-        if (p.pre) {
-          if (full) {
-            uint2 w = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-            *(uint2*)(p.pre + (long)m * p.ldpre + n) = w;
-          } else {
-            for (int r = 0; r < 4 && n + r < p.N; ++r) p.pre[(long)m * p.ldpre + n + r] = f2bf(v[r]);
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
-      } else if (p.act == 2) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-      } else if (p.act == 3) {
-        float u[4];
-        if (full) {
-          const uint2 w = *(const uint2*)(p.aux + (long)m * p.ldaux + n);
-          u[0] = bflo(w.x); u[1] = bfhi(w.x); u[2] = bflo(w.y); u[3] = bfhi(w.y);
-        } else {
-          for (int r = 0; r < 4; ++r) u[r] = (n + r < p.N) ? bf2f(p.aux[(long)m * p.ldaux + n + r]) : 0.f;
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] *= dgelu_f(u[r]);
-      }
-      if (p.drop_thr) {
-        const uint32_t idx = (uint32_t)m * (uint32_t)p.N + (uint32_t)n;  // n%4==0 -> pairs (idx, idx+1), (idx+2, idx+3)
-        const uint32_t h0 = vlb_rng_pair(seed, p.tag, idx >> 1), h1 = vlb_rng_pair(seed, p.tag, (idx >> 1) + 1);
-        if ((idx & 1u) == 0) {
-          v[0] = ((h0 & 0xffffu) >= p.drop_thr) ? v[0] * p.drop_scale : 0.f;
-          v[1] = ((h0 >> 16) >= p.drop_thr) ? v[1] * p.drop_scale : 0.f;
-          v[2] = ((h1 & 0xffffu) >= p.drop_thr) ? v[2] * p.drop_scale : 0.f;
-          v[3] = ((h1 >> 16) >= p.drop_thr) ? v[3] * p.drop_scale : 0.f;
-        } else {  // odd N: fall back to the scalar definition
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = vlb_keep(seed, p.tag, idx + r, p.drop_thr) ? v[r] * p.drop_scale : 0.f;
-        }
-      }
-      if (p.res) {
-        if (full) {
-          const uint2 w = *(const uint2*)(p.res + (long)m * p.ldres + n);
-          v[0] += bflo(w.x); v[1] += bfhi(w.x); v[2] += bflo(w.y); v[3] += bfhi(w.y);
-        } else {
-          for (int r = 0; r < 4 && n + r < p.N; ++r) v[r] += bf2f(p.res[(long)m * p.ldres + n + r]);
-        }
-      }
-      if (p.out_f32 == 0) {
-        bf16_t* c = (bf16_t*)p.C + (long)m * p.ldc + n;
-        if (full) {
-          uint2 w = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-          *(uint2*)c = w;
-        } else {
-          for (int r = 0; r < 4 && n + r < p.N; ++r) c[r] = f2bf(v[r]);
-        }
-      } else if (p.out_f32 == 1) {
-        float* c = (float*)p.C + (long)m * p.ldc + n;
-        if (full) {
-          *(float4*)c = make_float4(v[0], v[1], v[2], v[3]);
-        } else {
-          for (int r = 0; r < 4 && n + r < p.N; ++r) c[r] = v[r];
-        }
-      } else {
-        float* c = (float*)p.C + (long)m * p.ldc + n;
-        for (int r = 0; r < 4 && n + r < p.N; ++r) atomicAdd(c + r, v[r]);
-      }
-    }
-  }
+  const int mb = m0 + wm * WM + (lane & 15), nb = n0 + wn * WN + 4 * (lane >> 4);
+  if (p.out_f32 == 2) gemm_epilogue<0, false, false, 2, FM, FN>(p, acc, mb, nb);
+  else if (p.out_f32 == 1) gemm_epilogue<0, false, false, 1, FM, FN>(p, acc, mb, nb);
+  else if (p.act == 1) gemm_epilogue<1, false, false, 0, FM, FN>(p, acc, mb, nb);
+  else if (p.act == 2) gemm_epilogue<2, false, false, 0, FM, FN>(p, acc, mb, nb);
+  else if (p.act == 3) gemm_epilogue<3, false, false, 0, FM, FN>(p, acc, mb, nb);
+  else if (p.res) {
+    if (p.drop_thr) gemm_epilogue<0, true, true, 0, FM, FN>(p, acc, mb, nb);
+    else gemm_epilogue<0, false, true, 0, FM, FN>(p, acc, mb, nb);
+  } else if (p.drop_thr) gemm_epilogue<0, true, false, 0, FM, FN>(p, acc, mb, nb);
+  else gemm_epilogue<0, false, false, 0, FM, FN>(p, acc, mb, nb);
 }
 
 // ------------------------------------------------------------------------------------
 // bf16 transpose:  out[c][r] = in[r][c]  (out leading dim ldo >= R; pad columns untouched),
 // optional fused column sum  colsum[c] += sum_r in[r][c]  (bias gradients).
-// 64x64 tiles through LDS; both global sides are 128-B coalesced.
+// 64x64 tiles through an XOR-swizzled LDS image; BOTH global sides move 16 B per lane with 8 lanes
+// covering one 128-B row segment.  Element (r,c) lives at row r, 16-B chunk (c>>3)^(r>>3): the gather of
+// 8 rows x one column that builds a transposed 16-B chunk is then bank-conflict free.
+// Fast path needs 16-B aligned rows on both sides (ldi, ldo multiples of 8); otherwise scalar accesses.
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ in, long ldi, bf16_t* __restrict__ out,
-                                                             long ldo, int R, int C, float* __restrict__ colsum) {
-  __shared__ bf16_t tile[64][66];
+                                                             long ldo, int R, int C, float* __restrict__ colsum, int vec) {
+  __shared__ __attribute__((aligned(16))) bf16_t tile[64 * 64];
   __shared__ float csum[4][64];
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // ty: 0..3
-  float s = 0.f;
-#pragma unroll 4
-  for (int i = 0; i < 16; ++i) {
-    const int r = r0 + ty * 16 + i, c = c0 + tx;
-    bf16_t v = 0;
-    if (r < R && c < C) v = in[(long)r * ldi + c];
-    tile[ty * 16 + i][tx] = v;
-    s += bf2f(v);
+  const int tid = threadIdx.x, sub = tid & 7, grp = tid >> 3;  // 8 lanes per 128-B row segment, 32 row groups
+  float cs[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) cs[k] = 0.f;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int rl = grp + 32 * it, r = r0 + rl, c = c0 + sub * 8;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (r < R) {
+      if (vec && c + 8 <= C) {
+        v = *(const uint4*)(in + (long)r * ldi + c);
+      } else {
+        bf16_t e[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) e[k] = (c + k < C) ? in[(long)r * ldi + c + k] : (bf16_t)0;
+        v = make_uint4(e[0] | (uint32_t)e[1] << 16, e[2] | (uint32_t)e[3] << 16, e[4] | (uint32_t)e[5] << 16, e[6] | (uint32_t)e[7] << 16);
+      }
+    }
+    *(uint4*)(tile + rl * 64 + ((sub ^ (rl >> 3)) << 3)) = v;
+    if (colsum) {
+      cs[0] += bflo(v.x); cs[1] += bfhi(v.x); cs[2] += bflo(v.y); cs[3] += bfhi(v.y);
+      cs[4] += bflo(v.z); cs[5] += bfhi(v.z); cs[6] += bflo(v.w); cs[7] += bfhi(v.w);
+    }
   }
-  if (colsum) csum[ty][tx] = s;
+  if (colsum) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {  // lanes with equal `sub` hold the same 8 columns: reduce over xor 8,16,32
+      cs[k] += __shfl_xor(cs[k], 8, 64);
+      cs[k] += __shfl_xor(cs[k], 16, 64);
+      cs[k] += __shfl_xor(cs[k], 32, 64);
+    }
+    if ((tid & 63) < 8) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) csum[tid >> 6][sub * 8 + k] = cs[k];
+    }
+  }
   __syncthreads();
-#pragma unroll 4
-  for (int i = 0; i < 16; ++i) {
-    const int c = c0 + ty * 16 + i, r = r0 + tx;
-    if (c < C && r < R) out[(long)c * ldo + r] = tile[tx][ty * 16 + i];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int cl = grp + 32 * it, c = c0 + cl, rb = sub * 8;  // output row c, rows rb..rb+7 of the tile
+    bf16_t e[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) e[k] = tile[(rb + k) * 64 + (((cl >> 3) ^ sub) << 3) + (cl & 7)];
+    if (c < C) {
+      const int r = r0 + rb;
+      bf16_t* o = out + (long)c * ldo + r;
+      if (vec && r + 8 <= R) {
+        *(uint4*)o = make_uint4(e[0] | (uint32_t)e[1] << 16, e[2] | (uint32_t)e[3] << 16, e[4] | (uint32_t)e[5] << 16,
+                                e[6] | (uint32_t)e[7] << 16);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (r + k < R) o[k] = e[k];
+      }
+    }
   }
-  if (colsum && ty == 0 && c0 + tx < C) atomicAdd(colsum + c0 + tx, csum[0][tx] + csum[1][tx] + csum[2][tx] + csum[3][tx]);
+  if (colsum && tid < 64 && c0 + tid < C) atomicAdd(colsum + c0 + tid, csum[0][tid] + csum[1][tid] + csum[2][tid] + csum[3][tid]);
 }
 
 // ------------------------------------------------------------------------------------
@@ -278,6 +343,8 @@ extern "C" int vlb_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb
   VLB_CHECK_ARG(out_mode >= 0 && out_mode <= 2, "vlb_gemm_nt_bf16: bad out_mode %d", out_mode);
   VLB_CHECK_ARG(act >= 0 && act <= 3, "vlb_gemm_nt_bf16: bad act %d", act);
   VLB_CHECK_ARG(act != 3 || aux, "vlb_gemm_nt_bf16: act=3 needs aux");
+  VLB_CHECK_ARG(act == 0 || (!(drop_p > 0.f) && !res), "vlb_gemm_nt_bf16: an activation cannot be combined with dropout/residual");
+  VLB_CHECK_ARG(out_mode == 0 || (act == 0 && !(drop_p > 0.f) && !res), "vlb_gemm_nt_bf16: fp32 outputs take bias only");
   VLB_CHECK_ARG(!(drop_p > 0.f) || seed, "vlb_gemm_nt_bf16: dropout needs a device seed pointer");
   VLB_CHECK_ARG((long)M * (long)N < (1L << 32) || !(drop_p > 0.f), "vlb_gemm_nt_bf16: dropout index overflow");
   GemmParams p;
@@ -291,9 +358,19 @@ extern "C" int vlb_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb
   const int ktiles = K / 64;
   if (out_mode == 2) {
     splits = splitk > 0 ? splitk : 1;
-    if (splitk <= 0) {  // auto: aim for >= 512 blocks
+    if (splitk <= 0) {
+      // auto split-K: 2 workgroups are resident per CU (64 KB LDS each) -> 512 slots on 256 CUs.  Pick the
+      // smallest split count whose grid fills whole rounds of slots best (quantisation, not block count,
+      // is what hurt: 540 blocks = 2 rounds at 53 % vs 504 blocks = 1 round at 98 %).
       const long tiles = (long)vlb_cdiv(M, 128) * vlb_cdiv(N, 128);
-      splits = (int)((512 + tiles - 1) / tiles);
+      const long slots = 512;
+      double best = -1.0;
+      for (int sp = 1; sp <= 32 && sp <= ktiles; ++sp) {
+        const long blocks = tiles * sp;
+        const long rounds = (blocks + slots - 1) / slots;
+        const double eff = (double)blocks / (double)(rounds * slots);
+        if (eff > best + 0.04) { best = eff; splits = sp; }
+      }
     }
     if (splits > ktiles) splits = ktiles;
     if (splits < 1) splits = 1;
@@ -312,8 +389,9 @@ extern "C" int vlb_transpose_bf16(const void* in, long ldi, void* out, long ldo,
   if (R <= 0 || C <= 0) return VLB_OK;
   VLB_CHECK_ARG(in && out && ldo >= R && ldi >= C, "vlb_transpose_bf16: bad arguments");
   dim3 grid(vlb_cdiv(C, 64), vlb_cdiv(R, 64));
+  const int vec = ((ldi % 8) == 0 && (ldo % 8) == 0 && ((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0) ? 1 : 0;
   hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, stream, (const bf16_t*)in, ldi, (bf16_t*)out, ldo, R, C,
-                     colsum);
+                     colsum, vec);
   VLB_CHECK_LAUNCH("vlb_transpose_bf16");
   return VLB_OK;
 }

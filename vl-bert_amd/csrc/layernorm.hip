@@ -217,7 +217,7 @@ extern "C" int vlb_layernorm_bwd(const void* dy, long lddy, int dy_f32, const vo
   VLB_CHECK_ARG(!(drop_p > 0.f) || seed, "vlb_layernorm_bwd: dropout needs a device seed pointer");
   VLB_CHECK_ARG((long)rows * H < (1L << 32) || !(drop_p > 0.f), "vlb_layernorm_bwd: dropout index overflow");
   int blocks = vlb_cdiv(rows, 4);
-  if (blocks > 512) blocks = 512;
+  if (blocks > 1024) blocks = 1024;   // 4 workgroups per CU: enough waves in flight for an HBM-bound kernel
   const uint32_t thr = vlb_drop_thr(drop_p);
 #define LN_BWD(NIT)                                                                                                            \
   hipLaunchKernelGGL(layernorm_bwd_kernel<NIT>, dim3(blocks), dim3(256), 2 * 4 * H * sizeof(float), stream, dy, lddy, dy_f32,   \

@@ -141,7 +141,7 @@ class FlatParams:
 
 class PretrainEngine:
     def __init__(self, cfg, B, T, R, device="cuda:0", train=True, lr=1e-4, weight_decay=1e-4, max_grad_norm=10.0,
-                 betas=(0.9, 0.999), eps=1e-6, seed=1234, grad_accum=1, process_group=None, keep_logits=False):
+                 betas=(0.9, 0.999), eps=1e-6, seed=1234, grad_accum=1, process_group=None, keep_logits=False, flat=None):
         cfg.validate()
         self.cfg, self.B, self.T, self.R = cfg, B, T, R
         self.S = T + R + 1
@@ -157,7 +157,7 @@ class PretrainEngine:
         self.Mp, self.BTp, self.BRp = _ru(self.M, 64), _ru(self.BT, 64), _ru(self.BR, 64)
         self.Vp, self.Cp = _ru(V, 64), _ru(C, 64)
         d = self.dev
-        self.P = FlatParams(cfg, d)
+        self.P = flat if flat is not None else FlatParams(cfg, d)   # `flat`: share storage with an nn.Module mirror
         P = self.P
         self.w16 = P.named(P.w16)
         self.w32 = P.named(P.master)

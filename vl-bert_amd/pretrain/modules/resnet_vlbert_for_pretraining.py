@@ -1,0 +1,177 @@
+"""Drop-in `ResNetVLBERTForPretraining` (pretrain/modules/resnet_vlbert_for_pretraining.py:14-216) backed by
+the HIP engine: same constructor argument (the `config` tree of pretrain/function/config.py), same
+`forward(image, boxes, im_info, text, relationship_label, mlm_labels, mvrc_ops, mvrc_labels) -> (outputs, loss)`,
+same parameter names / shapes (state-dict contract), so the reference's training loop
+(common/trainer.py:101-189: `outputs, loss = net(*batch); loss.backward(); clip_grad_norm_; optimizer.step()`)
+and its checkpoints work unchanged.
+
+How it maps onto the engine:
+  * every nn.Parameter is a VIEW into the engine's flat fp32 master buffer (and `.grad` a view into the flat
+    gradient buffer), so torch optimizers / clip_grad_norm_ / state_dict operate on the engine's storage;
+  * `forward` runs the HIP forward and returns a scalar loss with a custom autograd node; `loss.backward()`
+    runs the hand-scheduled HIP backward and leaves the gradients in `param.grad`;
+  * engines are built per (batch, text length, regions) shape on first use and share the parameter storage.
+Supported configuration = the north-star one (cfgs/pretrain/base_prec_withouttextonly_4x16G_fp32.yaml):
+IMAGE_FEAT_PRECOMPUTED, WITH_MLM_LOSS, WITH_MVRC_LOSS, no relationship head, no pooler, visual_ln.
+Anything else raises NotImplementedError (nothing silently falls back to PyTorch eager).
+"""
+import torch
+import torch.nn as nn
+
+from ... import engine as _engine
+from ... import ops
+
+
+def _get(obj, name, default=None):
+    return getattr(obj, name, default) if not isinstance(obj, dict) else obj.get(name, default)
+
+
+class _HipLoss(torch.autograd.Function):
+    """Scalar loss whose backward is the engine's explicit backward pass."""
+
+    @staticmethod
+    def forward(ctx, anchor, module, eng):
+        ctx.module, ctx.eng = module, eng
+        return (eng.losses[0] + eng.losses[1]).clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        module, eng = ctx.module, ctx.eng
+        g = float(grad_out)            # compat path only (the reference's own loop syncs every step, trainer.py:159-171)
+        if g != 1.0:                    # re-derive d(logits) with the upstream scale (grad accumulation / loss scaling)
+            V, C = eng.cfg.vocab_size, eng.cfg.visual_region_classes
+            eng.mlm_logits.copy_(eng.mlm_logits_copy)
+            eng.mvrc_logits.copy_(eng.mvrc_logits_copy)
+            scratch = torch.zeros(2, device=eng.dev)
+            ops.ce_fwd_bwd(eng.mlm_logits, V, eng.in_mlm_labels.view(-1), eng.counts[0:1], scratch[0:1], gscale=g)
+            ops.soft_ce_fwd_bwd(eng.mvrc_logits, C, eng.in_mvrc_labels.view(eng.BR, C), eng.mvrc_tsum, eng.counts[1:2],
+                                scratch[1:2], gscale=g)
+        module._prepare_grads()
+        eng.backward(train=module.training)
+        return None, None, None
+
+
+class ResNetVLBERTForPretraining(nn.Module):
+    def __init__(self, config, device=None):
+        super().__init__()
+        self.config = config
+        net = _get(config, "NETWORK")
+        vl = _get(net, "VLBERT")
+        if not _get(net, "IMAGE_FEAT_PRECOMPUTED", False):
+            raise NotImplementedError("end-to-end ResNet-101/RoIAlign image path is not built yet (SURVEY.md §8f rank 3)")
+        if _get(net, "WITH_REL_LOSS", False) or _get(vl, "with_pooler", False):
+            raise NotImplementedError("relationship head / pooler are not part of the accelerated configuration")
+        if not (_get(net, "WITH_MLM_LOSS", True) and _get(net, "WITH_MVRC_LOSS", True) and _get(vl, "visual_ln", True)):
+            raise NotImplementedError("accelerated path needs WITH_MLM_LOSS, WITH_MVRC_LOSS and visual_ln")
+        if _get(net, "IMAGE_SEMANTIC", False) or _get(vl, "word_embedding_frozen", False) or _get(vl, "pos_embedding_frozen", False):
+            raise NotImplementedError("IMAGE_SEMANTIC / frozen embeddings are not supported")
+        if _get(vl, "visual_size", _get(vl, "hidden_size")) != _get(vl, "hidden_size"):
+            raise NotImplementedError("visual_size != hidden_size (visual_1x1 projections) is not supported")
+        self.cfg = _engine.ModelConfig(
+            hidden_size=_get(vl, "hidden_size"), num_hidden_layers=_get(vl, "num_hidden_layers"),
+            num_attention_heads=_get(vl, "num_attention_heads"), intermediate_size=_get(vl, "intermediate_size"),
+            vocab_size=_get(vl, "vocab_size", 30522), max_position_embeddings=_get(vl, "max_position_embeddings", 512),
+            type_vocab_size=_get(vl, "type_vocab_size", 3), visual_region_classes=_get(vl, "visual_region_classes", 1601),
+            hidden_dropout_prob=_get(vl, "hidden_dropout_prob", 0.1),
+            attention_probs_dropout_prob=_get(vl, "attention_probs_dropout_prob", 0.1))
+        self.cfg.validate()
+        if not torch.cuda.is_available():
+            raise RuntimeError("ResNetVLBERTForPretraining (HIP) needs an MI355X: there is no CPU fallback")
+        self.device_ = torch.device(device or ("cuda:%d" % torch.cuda.current_device()))
+        self._engines = {}
+        self.flat = _engine.FlatParams(self.cfg, self.device_)
+        self._init_scale = (_get(vl, "visual_scale_text_init", 0.0), _get(vl, "visual_scale_object_init", 0.0),
+                            _get(vl, "initializer_range", 0.02))
+        # parameters: views of the flat master buffer, registered under the reference's names
+        self._pnames = {}
+        for name, t in self.flat.named(self.flat.master).items():
+            self._register(name, nn.Parameter(t, requires_grad=True))
+        self.init_weight()
+
+    # -- parameter plumbing -----------------------------------------------------------------------
+    def _register(self, dotted, param):
+        mod = self
+        parts = dotted.split(".")
+        for p in parts[:-1]:
+            if not hasattr(mod, p):
+                mod.add_module(p, nn.Module())
+            mod = getattr(mod, p)
+        mod.register_parameter(parts[-1], param)
+        self._pnames[dotted] = param
+
+    def init_weight(self):
+        """BaseModel.init_weights / ResNetVLBERTForPretraining.init_weight statistics
+        (common/visual_linguistic_bert.py:14-25,330-332; resnet_vlbert_for_pretraining.py:55-63)."""
+        vt, vo, std = self._init_scale
+        with torch.no_grad():
+            for name, p in self._pnames.items():
+                if name.endswith("visual_ln_text.weight"):
+                    p.fill_(vt)
+                elif name.endswith("visual_ln_object.weight"):
+                    p.fill_(vo)
+                elif "LayerNorm.weight" in name:
+                    p.fill_(1.0)
+                elif name.endswith(".bias") or name == "object_mask_visual_embedding.weight":
+                    p.zero_()
+                else:
+                    p.normal_(0.0, std)
+
+    def state_dict(self, *args, **kwargs):
+        sd = super().state_dict(*args, **kwargs)
+        prefix = kwargs.get("prefix", args[1] if len(args) > 1 else "")
+        sd[prefix + _engine.TIED_DECODER_KEY] = sd[prefix + "vlbert.word_embeddings.weight"]   # tied (modeling.py:463-466)
+        return sd
+
+    def load_state_dict(self, state_dict, strict=True):
+        state_dict = dict(state_dict)
+        state_dict.pop(_engine.TIED_DECODER_KEY, None)
+        return super().load_state_dict(state_dict, strict=strict)
+
+    def _prepare_grads(self):
+        """torch zero_grad(set_to_none=True) drops `.grad`; re-attach the flat views (zeroed) so accumulation
+        semantics match autograd: first backward after zero_grad starts from zero, later ones accumulate."""
+        fresh = any(p.grad is None for p in self._pnames.values())
+        if fresh:
+            self.flat.grad.zero_()
+            for name, t in self.flat.named(self.flat.grad).items():
+                self._pnames[name].grad = t
+
+    def _engine_for(self, B, T, R):
+        key = (B, T, R)
+        if key not in self._engines:
+            eng = _engine.PretrainEngine(self.cfg, B, T, R, device=str(self.device_), keep_logits=True, flat=self.flat)
+            self._engines[key] = eng
+        return self._engines[key]
+
+    # -- forward ------------------------------------------------------------------------------------
+    def forward(self, image, boxes, im_info, text, relationship_label, mlm_labels, mvrc_ops, mvrc_labels):
+        if image is not None:
+            raise NotImplementedError("precomputed-feature configuration: pass image=None")
+        B, R = boxes.shape[0], boxes.shape[1]
+        T = text.shape[1]
+        eng = self._engine_for(B, T, R)
+        version = self.flat.master._version                       # bumped by any in-place update of a parameter view
+        if getattr(eng, "_synced_version", None) != version:      # optimizer step / load_state_dict: refresh bf16 + W^T copies
+            eng.sync_weights()
+            eng._synced_version = version
+        eng._weights_dirty = False
+        eng.set_batch(boxes, im_info, text, relationship_label, mlm_labels, mvrc_ops, mvrc_labels)
+        eng.forward(train=self.training)
+        if self.training:
+            ops.rng_advance(eng.seed)      # fresh dropout masks next step (the fused optimizer path does this itself)
+        loss = _HipLoss.apply(self._pnames["vlbert.word_embeddings.weight"], self, eng)
+        V, C = self.cfg.vocab_size, self.cfg.visual_region_classes
+        # API parity: logits re-padded exactly like the reference (:165-167, :195-200) -- needs max_len (host sync)
+        max_len = int(eng.lay["nobj"].max())
+        mlm_logits = torch.empty((B, T, V), dtype=torch.float32, device=self.device_)
+        ops.cast_bf16_f32(eng.mlm_logits_copy[:, :V].contiguous(), mlm_logits)
+        mvrc = torch.empty((B, R, C), dtype=torch.float32, device=self.device_)
+        ops.cast_bf16_f32(eng.mvrc_logits_copy[:, :C].contiguous(), mvrc)
+        mvrc[:, max_len:] = -10000.0
+        outputs = {
+            "relationship_logits": None, "relationship_label": None,
+            "mlm_logits": mlm_logits, "mlm_label": mlm_labels,
+            "mvrc_logits": mvrc, "mvrc_label": mvrc_labels,
+            "relationship_loss": im_info.new_zeros(()), "mlm_loss": eng.losses[0].clone(), "mvrc_loss": eng.losses[1].clone(),
+        }
+        return outputs, loss
