@@ -41,7 +41,8 @@ int vlb_device_info(int device, char* name, int cap);
  * C[M,N] (+)= A[M,K] * B[N,K]^T, bf16 operands, fp32 accumulate, fused epilogue
  *   v = acc (+ bias[n]) ; act: 0 none | 1 erf-GELU (pre-activation optionally stored to `pre`)
  *   | 2 ReLU | 3 v *= gelu'(aux[m,n]) ; dropout(v) ; v += res[m,n] ;
- *   out_mode: 0 store bf16 | 1 store fp32 | 2 fp32 atomicAdd with split-K (`splitk` <= 0: auto).
+ *   out_mode: 0 store bf16 | 1 store fp32 | 2 fp32 atomicAdd with split-K (`splitk` <= 0: auto) |
+ *             3 fp32 accumulate C += (single K pass, no atomics).
  * K % 64 == 0; lda/ldb % 8 == 0; ldc/ldaux/ldpre/ldres % 4 == 0.
  * Replaces nn.Linear / torch.matmul (cuBLAS) + the separate bias/GELU/dropout/residual kernels of
  * external/pytorch_pretrained_bert/modeling.py:291-300 (Q,K,V), :330-333 (BertSelfOutput),
@@ -52,6 +53,14 @@ int vlb_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb, void* C, 
                      const float* bias, int act, const void* aux, long ldaux, void* pre, long ldpre,
                      const void* res, long ldres, float drop_p, const uint32_t* seed, uint32_t tag,
                      int out_mode, int splitk, vlb_stream_t stream);
+
+/* Weight-gradient form: C[M,N] (fp32) += A[M,K] B[N,K]^T for few output tiles and a very long K (K = padded
+ * row count of the activations; autograd's `grad_output.t().mm(input)` behind every nn.Linear).  Split-K
+ * through fp32 workspace slabs + a streaming reduce (no atomics); splits chosen by an internal cost model, capped
+ * by the workspace the caller provides (vlb_wgrad_workspace_floats gives the amount the model would like). */
+long vlb_wgrad_workspace_floats(int M, int N, int K);
+int vlb_wgrad_nt_bf16(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, int K,
+                      float* workspace, long workspace_floats, vlb_stream_t stream);
 
 /* out[c][r] = in[r][c] (bf16, out leading dim ldo >= R); colsum[c] += sum_r in[r][c] if non-NULL
  * (bias gradients).  Feeds the weight-gradient GEMMs (autograd's `grad.t().mm(input)`). */

@@ -15,7 +15,7 @@ def header_prototypes():
     src = open(HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     protos = {}
-    for m in re.finditer(r"\b(?:int|const char\*)\s+(vlb_\w+)\s*\(([^)]*)\)\s*;", src):
+    for m in re.finditer(r"\b(?:int|long|const char\*)\s+(vlb_\w+)\s*\(([^)]*)\)\s*;", src):
         name, args = m.group(1), m.group(2)
         sig = ""
         for a in [x.strip() for x in args.split(",") if x.strip() and x.strip() != "void"]:
@@ -52,7 +52,7 @@ def test_ctypes_signatures_match_header():
         assert name in protos, "binding %s has no prototype in include/vlbert_hip.h" % name
         assert protos[name] == sig, "%s: header %s vs binding %s" % (name, protos[name], sig)
     for name in protos:
-        assert name in lib._SIGS or name in ("vlb_last_error", "vlb_version", "vlb_device_info"), name
+        assert name in lib._SIGS or name in ("vlb_last_error", "vlb_version", "vlb_device_info", "vlb_wgrad_workspace_floats"), name
 
 
 def test_library_loads_and_exports_every_symbol():

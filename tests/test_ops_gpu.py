@@ -101,6 +101,23 @@ def test_gemm_wgrad_shape(ops):
     report("wgrad via transposes", dW, dY.t() @ X, 1e-3, 2e-5)
 
 
+@pytest.mark.parametrize("M,N,K,ws", [(192, 320, 1024, True), (768, 768, 8192, True), (300, 70, 640, True), (256, 256, 2048, False),
+                                      (1601, 128, 1152, True)])
+def test_wgrad_slab_splitk(ops, M, N, K, ws):
+    """C += A B^T through fp32 slabs + reduce (no atomics); accumulates on top of existing contents."""
+    A, B = rnd(M, K, seed=15), rnd(N, K, seed=16, scale=0.1)
+    base = torch.randn(M, N, generator=torch.Generator().manual_seed(17))
+    ldc = (N + 3) // 4 * 4
+    C = torch.zeros((M, ldc), dtype=torch.float32, device=dev())
+    C[:, :N] = base.to(dev())
+    work = torch.empty(max(ops.wgrad_workspace_floats(M, N, K), 4), dtype=torch.float32, device=dev()) if ws else None
+    print("wgrad %dx%dx%d workspace floats: %d" % (M, N, K, 0 if work is None else work.numel()))
+    ops.wgrad_nt(to_gpu_bf16(A), to_gpu_bf16(B), C[:, :N], workspace=work)
+    report("wgrad slab split-K %dx%dx%d ws=%s" % (M, N, K, ws), C[:, :N], base + A @ B.t(), 1e-3, 2e-5)
+    if ldc > N:
+        assert float(C[:, N:].abs().max()) == 0.0
+
+
 def test_gemm_dropout_and_ln_mask_agree(ops):
     """The GEMM-epilogue dropout mask and the LayerNorm-backward dx_drop mask are the same function."""
     M, N, K = 200, 256, 64

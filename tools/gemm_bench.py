@@ -29,12 +29,17 @@ def bench(M, N, K, mode, iters=20):
             kw = dict(bias=torch.zeros(N, device=d), res=torch.zeros((M, ldc), dtype=torch.bfloat16, device=d)[:, :N])
         elif mode == "bias":
             kw = dict(bias=torch.zeros(N, device=d))
+    if mode == "wgrad":
+        work = torch.empty(max(ops.wgrad_workspace_floats(M, N, K), 4), dtype=torch.float32, device=d)
+        run = lambda: ops.wgrad_nt(A, B, C, workspace=work)
+    else:
+        run = lambda: ops.gemm_nt(A, B, C, **kw)
     for _ in range(3):
-        ops.gemm_nt(A, B, C, **kw)
+        run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
-        ops.gemm_nt(A, B, C, **kw)
+        run()
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters

@@ -17,6 +17,7 @@ _P, _L, _I, _F, _U = ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_floa
 _SIGS = {
     "vlb_gemm_nt_bf16": "plplpliiipiplplplfpuiis",
     "vlb_transpose_bf16": "plpliips",
+    "vlb_wgrad_nt_bf16": "plplpliiipls",
     "vlb_layernorm_fwd": "plppplpiifs",
     "vlb_layernorm_bwd": "pliplppplplfpuplppiis",
     "vlb_attention_fwd": "ppppiiiifpus",
@@ -64,6 +65,8 @@ def load():
     lib.vlb_version.restype = _I
     lib.vlb_device_info.restype = _I
     lib.vlb_device_info.argtypes = [_I, ctypes.c_char_p, _I]
+    lib.vlb_wgrad_workspace_floats.restype = _L
+    lib.vlb_wgrad_workspace_floats.argtypes = [_I, _I, _I]
     for name, sig in _SIGS.items():
         fn = getattr(lib, name)
         fn.restype = _I
@@ -73,7 +76,7 @@ def load():
 
 
 def exported_names():
-    return ["vlb_last_error", "vlb_version", "vlb_device_info"] + sorted(_SIGS)
+    return ["vlb_last_error", "vlb_version", "vlb_device_info", "vlb_wgrad_workspace_floats"] + sorted(_SIGS)
 
 
 def call(name, *args):

@@ -34,6 +34,7 @@ struct GemmParams {
   const bf16_t* res; long ldres;
   uint32_t drop_thr; float drop_scale; const uint32_t* seed; uint32_t tag;
   void* C; long ldc;
+  long c_split_stride;       // elements between the outputs of consecutive K splits (slab split-K), 0 otherwise
   int out_f32;               // 0: bf16 store, 1: fp32 store, 2: fp32 atomicAdd
   int ntm, ntn;
 };
@@ -41,9 +42,12 @@ struct GemmParams {
 #define GLDS_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
-// Epilogue specialised at compile time on (activation, dropout, residual, output mode) so each variant is a
-// straight-line body; the bias vector depends only on the column fragment and is loaded once per column.
-template <int ACT, bool DROP, bool RES, int OUT, int FM, int FN>
+// Epilogue specialised at compile time on (activation, dropout, residual, output mode, interior tile) so each
+// variant is a straight-line body: interior tiles (the overwhelming majority) carry no bounds checks, row base
+// pointers are formed once per fragment row and the 16-column fragment steps fold into immediate offsets; the
+// bias vector depends only on the column fragment and is loaded once per column.
+// OUT: 0 bf16 store | 1 fp32 store | 2 fp32 atomicAdd | 3 fp32 read-modify-write accumulate (tile owned by one block)
+template <int ACT, bool DROP, bool RES, int OUT, bool INTERIOR, int FM, int FN>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[FM][FN], int mb, int nb) {
   const uint32_t seed = DROP ? *p.seed : 0u;
   float bias[FN][4];
@@ -53,7 +57,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 #pragma unroll
     for (int r = 0; r < 4; ++r) bias[j][r] = 0.f;
     if (p.bias) {
-      if (n + 3 < p.N) {
+      if (INTERIOR || n + 3 < p.N) {
         const float4 b = *(const float4*)(p.bias + n);
         bias[j][0] = b.x; bias[j][1] = b.y; bias[j][2] = b.z; bias[j][3] = b.w;
       } else {
@@ -64,19 +68,23 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
     const int m = mb + i * 16;
-    if (m >= p.M) continue;
-    const long rowc = (long)m * p.ldc;
+    if (!INTERIOR && m >= p.M) continue;
+    const long offc = (long)m * p.ldc + nb + (long)blockIdx.y * p.c_split_stride;
+    const bf16_t* aux_row = (ACT == 3) ? p.aux + (long)m * p.ldaux + nb : nullptr;
+    bf16_t* pre_row = (ACT == 1 && p.pre) ? p.pre + (long)m * p.ldpre + nb : nullptr;
+    const bf16_t* res_row = RES ? p.res + (long)m * p.ldres + nb : nullptr;
+    const uint32_t idx_row = DROP ? (uint32_t)m * (uint32_t)p.N + (uint32_t)nb : 0u;
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
       const int n = nb + j * 16;
-      if (n >= p.N) continue;
-      const bool full = (n + 3 < p.N);
+      if (!INTERIOR && n >= p.N) continue;
+      const bool full = INTERIOR || (n + 3 < p.N);
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bias[j][r];
       if (ACT == 1) {
-        if (p.pre) {
-          bf16_t* q = p.pre + (long)m * p.ldpre + n;
+        if (pre_row) {
+          bf16_t* q = pre_row + j * 16;
           if (full) *(uint2*)q = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
           else for (int r = 0; r < 4 && n + r < p.N; ++r) q[r] = f2bf(v[r]);
         }
@@ -87,7 +95,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
       } else if (ACT == 3) {
         float u[4] = {0.f, 0.f, 0.f, 0.f};
-        const bf16_t* q = p.aux + (long)m * p.ldaux + n;
+        const bf16_t* q = aux_row + j * 16;
         if (full) {
           const uint2 w = *(const uint2*)q;
           u[0] = bflo(w.x); u[1] = bfhi(w.x); u[2] = bflo(w.y); u[3] = bfhi(w.y);
@@ -98,7 +106,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
         for (int r = 0; r < 4; ++r) v[r] *= dgelu_f(u[r]);
       }
       if (DROP) {
-        const uint32_t idx = (uint32_t)m * (uint32_t)p.N + (uint32_t)n;
+        const uint32_t idx = idx_row + j * 16;
         if ((idx & 1u) == 0) {  // n%4==0: element pairs (idx,idx+1), (idx+2,idx+3) share one hash each
           const uint32_t h0 = vlb_rng_pair(seed, p.tag, idx >> 1), h1 = vlb_rng_pair(seed, p.tag, (idx >> 1) + 1);
           v[0] = ((h0 & 0xffffu) >= p.drop_thr) ? v[0] * p.drop_scale : 0.f;
@@ -111,7 +119,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
         }
       }
       if (RES) {
-        const bf16_t* q = p.res + (long)m * p.ldres + n;
+        const bf16_t* q = res_row + j * 16;
         if (full) {
           const uint2 w = *(const uint2*)q;
           v[0] += bflo(w.x); v[1] += bfhi(w.x); v[2] += bflo(w.y); v[3] += bfhi(w.y);
@@ -120,19 +128,42 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
         }
       }
       if (OUT == 0) {
-        bf16_t* c = (bf16_t*)p.C + rowc + n;
+        bf16_t* c = (bf16_t*)p.C + offc + j * 16;
         if (full) *(uint2*)c = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
         else for (int r = 0; r < 4 && n + r < p.N; ++r) c[r] = f2bf(v[r]);
       } else if (OUT == 1) {
-        float* c = (float*)p.C + rowc + n;
+        float* c = (float*)p.C + offc + j * 16;
         if (full) *(float4*)c = make_float4(v[0], v[1], v[2], v[3]);
         else for (int r = 0; r < 4 && n + r < p.N; ++r) c[r] = v[r];
+      } else if (OUT == 2) {
+        float* c = (float*)p.C + offc + j * 16;
+        for (int r = 0; r < 4 && (INTERIOR || n + r < p.N); ++r) atomicAdd(c + r, v[r]);
       } else {
-        float* c = (float*)p.C + rowc + n;
-        for (int r = 0; r < 4 && n + r < p.N; ++r) atomicAdd(c + r, v[r]);
+        float* c = (float*)p.C + offc + j * 16;
+        if (full) {
+          const float4 o = *(const float4*)c;
+          *(float4*)c = make_float4(o.x + v[0], o.y + v[1], o.z + v[2], o.w + v[3]);
+        } else {
+          for (int r = 0; r < 4 && n + r < p.N; ++r) c[r] += v[r];
+        }
       }
     }
   }
+}
+
+template <bool INTERIOR, int FM, int FN>
+__device__ __forceinline__ void gemm_epilogue_dispatch(const GemmParams& p, f32x4 (&acc)[FM][FN], int mb, int nb) {
+  if (p.out_f32 == 3) gemm_epilogue<0, false, false, 3, INTERIOR, FM, FN>(p, acc, mb, nb);
+  else if (p.out_f32 == 2) gemm_epilogue<0, false, false, 2, INTERIOR, FM, FN>(p, acc, mb, nb);
+  else if (p.out_f32 == 1) gemm_epilogue<0, false, false, 1, INTERIOR, FM, FN>(p, acc, mb, nb);
+  else if (p.act == 1) gemm_epilogue<1, false, false, 0, INTERIOR, FM, FN>(p, acc, mb, nb);
+  else if (p.act == 2) gemm_epilogue<2, false, false, 0, INTERIOR, FM, FN>(p, acc, mb, nb);
+  else if (p.act == 3) gemm_epilogue<3, false, false, 0, INTERIOR, FM, FN>(p, acc, mb, nb);
+  else if (p.res) {
+    if (p.drop_thr) gemm_epilogue<0, true, true, 0, INTERIOR, FM, FN>(p, acc, mb, nb);
+    else gemm_epilogue<0, false, true, 0, INTERIOR, FM, FN>(p, acc, mb, nb);
+  } else if (p.drop_thr) gemm_epilogue<0, true, false, 0, INTERIOR, FM, FN>(p, acc, mb, nb);
+  else gemm_epilogue<0, false, false, 0, INTERIOR, FM, FN>(p, acc, mb, nb);
 }
 
 template <int BM, int BN>
@@ -228,16 +259,8 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const GemmParams p) {
 
   // ---- epilogue: lane holds C[m][n..n+3], m = .. + (lane&15), n = .. + 4*(lane>>4) ----
   const int mb = m0 + wm * WM + (lane & 15), nb = n0 + wn * WN + 4 * (lane >> 4);
-  if (p.out_f32 == 2) gemm_epilogue<0, false, false, 2, FM, FN>(p, acc, mb, nb);
-  else if (p.out_f32 == 1) gemm_epilogue<0, false, false, 1, FM, FN>(p, acc, mb, nb);
-  else if (p.act == 1) gemm_epilogue<1, false, false, 0, FM, FN>(p, acc, mb, nb);
-  else if (p.act == 2) gemm_epilogue<2, false, false, 0, FM, FN>(p, acc, mb, nb);
-  else if (p.act == 3) gemm_epilogue<3, false, false, 0, FM, FN>(p, acc, mb, nb);
-  else if (p.res) {
-    if (p.drop_thr) gemm_epilogue<0, true, true, 0, FM, FN>(p, acc, mb, nb);
-    else gemm_epilogue<0, false, true, 0, FM, FN>(p, acc, mb, nb);
-  } else if (p.drop_thr) gemm_epilogue<0, true, false, 0, FM, FN>(p, acc, mb, nb);
-  else gemm_epilogue<0, false, false, 0, FM, FN>(p, acc, mb, nb);
+  if (m0 + BM <= p.M && n0 + BN <= p.N) gemm_epilogue_dispatch<true, FM, FN>(p, acc, mb, nb);
+  else gemm_epilogue_dispatch<false, FM, FN>(p, acc, mb, nb);
 }
 
 // ------------------------------------------------------------------------------------
@@ -340,7 +363,7 @@ extern "C" int vlb_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb
   VLB_CHECK_ARG(A && B && C, "vlb_gemm_nt_bf16: null operand");
   VLB_CHECK_ARG((lda % 8) == 0 && (ldb % 8) == 0, "vlb_gemm_nt_bf16: lda/ldb must be multiples of 8 elements");
   VLB_CHECK_ARG((ldc % 4) == 0, "vlb_gemm_nt_bf16: ldc must be a multiple of 4");
-  VLB_CHECK_ARG(out_mode >= 0 && out_mode <= 2, "vlb_gemm_nt_bf16: bad out_mode %d", out_mode);
+  VLB_CHECK_ARG(out_mode >= 0 && out_mode <= 3, "vlb_gemm_nt_bf16: bad out_mode %d", out_mode);
   VLB_CHECK_ARG(act >= 0 && act <= 3, "vlb_gemm_nt_bf16: bad act %d", act);
   VLB_CHECK_ARG(act != 3 || aux, "vlb_gemm_nt_bf16: act=3 needs aux");
   VLB_CHECK_ARG(act == 0 || (!(drop_p > 0.f) && !res), "vlb_gemm_nt_bf16: an activation cannot be combined with dropout/residual");
@@ -353,7 +376,7 @@ extern "C" int vlb_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb
   p.bias = bias; p.act = act; p.aux = (const bf16_t*)aux; p.ldaux = ldaux; p.pre = (bf16_t*)pre; p.ldpre = ldpre;
   p.res = (const bf16_t*)res; p.ldres = ldres;
   p.drop_thr = vlb_drop_thr(drop_p); p.drop_scale = vlb_drop_scale(p.drop_thr); p.seed = seed; p.tag = tag;
-  p.C = C; p.ldc = ldc; p.out_f32 = out_mode;
+  p.C = C; p.ldc = ldc; p.out_f32 = out_mode; p.c_split_stride = 0;
   int splits = 1;
   const int ktiles = K / 64;
   if (out_mode == 2) {
@@ -382,6 +405,92 @@ extern "C" int vlb_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb
   const long tiles128 = (long)vlb_cdiv(M, 128) * vlb_cdiv(N, 128) * splits;
   if (tiles128 < 384 || N <= 64) return launch_gemm<128, 64>(p, splits, stream);
   return launch_gemm<128, 128>(p, splits, stream);
+}
+
+// ------------------------------------------------------------------------------------
+// Weight-gradient GEMM:  C[M,N] (fp32) += A[M,K] B[N,K]^T  with the reduction dimension K = (padded) row count
+// of the activation, i.e. few output tiles and a very long K.  Split-K WITHOUT atomics: every K slice writes its
+// fp32 partial tile to a workspace slab with plain 16-B stores, a streaming reduce kernel adds the slabs into C.
+// (fp32 atomics cost ~75 us per 8M adds on this chip -- more than the MFMA work of the slices they merged.)
+// The split count comes from a small cost model: rounds of 512 resident workgroups x K tiles per slice + slab
+// traffic; splits == 1 accumulates straight into C (each tile owned by one workgroup, no atomics either).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, long slab_stride, int splits,
+                                                            float* __restrict__ C, long ldc, int M, int N, int ldw) {
+  const int n4 = ldw >> 2;
+  const long total = (long)M * n4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int m = (int)(i / n4), n = (int)(i % n4) * 4;
+    const float* src = slabs + (long)m * ldw + n;
+    float4 a = *(const float4*)src;
+    for (int sp = 1; sp < splits; ++sp) {
+      const float4 b = *(const float4*)(src + sp * slab_stride);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    float* c = C + (long)m * ldc + n;
+    if (n + 3 < N) {
+      const float4 o = *(const float4*)c;
+      *(float4*)c = make_float4(o.x + a.x, o.y + a.y, o.z + a.z, o.w + a.w);
+    } else {
+      const float av[4] = {a.x, a.y, a.z, a.w};
+      for (int r = 0; r < 4 && n + r < N; ++r) c[r] += av[r];
+    }
+  }
+}
+
+static int wgrad_pick_splits(int M, int N, int K, long workspace_floats) {
+  const int ktiles = K / 64;
+  const long tiles = (long)vlb_cdiv(M, 128) * vlb_cdiv(N, 128);
+  const long ldw = (N + 3) / 4 * 4;
+  const double t_k = 1.15, t_fix = 4.0, bw = 4.0e6;  // us per K tile (2 workgroups/CU), us per tile, bytes/us
+  int best = 1;
+  double best_t = 1e30;
+  for (int sp = 1; sp <= 32 && sp <= ktiles; ++sp) {
+    if (sp > 1 && (long)sp * M * ldw > workspace_floats) break;
+    const long rounds = (tiles * sp + 511) / 512;
+    const double t = rounds * (vlb_cdiv(ktiles, sp) * t_k + t_fix) + (sp > 1 ? 2.0 * sp * M * ldw * 4.0 / bw : 0.0);
+    if (t < best_t * 0.97) { best_t = t; best = sp; }
+  }
+  return best;
+}
+
+extern "C" long vlb_wgrad_workspace_floats(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  const int sp = wgrad_pick_splits(M, N, K, 1L << 40);
+  return sp > 1 ? (long)sp * M * ((N + 3) / 4 * 4) : 0;
+}
+
+extern "C" int vlb_wgrad_nt_bf16(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, int K,
+                                 float* workspace, long workspace_floats, hipStream_t stream) {
+  if (M <= 0 || N <= 0) return VLB_OK;
+  VLB_CHECK_ARG(K > 0 && (K % 64) == 0, "vlb_wgrad_nt_bf16: K=%d must be a positive multiple of 64", K);
+  VLB_CHECK_ARG(A && B && C, "vlb_wgrad_nt_bf16: null operand");
+  VLB_CHECK_ARG((lda % 8) == 0 && (ldb % 8) == 0 && (ldc % 4) == 0, "vlb_wgrad_nt_bf16: bad leading dimensions");
+  const int splits = wgrad_pick_splits(M, N, K, workspace ? workspace_floats : 0);
+  const int ktiles = K / 64;
+  const int per = vlb_cdiv(ktiles, splits);
+  const int nsp = vlb_cdiv(ktiles, per);
+  const long ldw = (N + 3) / 4 * 4;
+  GemmParams p;
+  p.A = (const bf16_t*)A; p.lda = lda; p.B = (const bf16_t*)B; p.ldb = ldb;
+  p.M = M; p.N = N; p.K = K; p.k_per_split = per * 64;
+  p.bias = nullptr; p.act = 0; p.aux = nullptr; p.ldaux = 0; p.pre = nullptr; p.ldpre = 0; p.res = nullptr; p.ldres = 0;
+  p.drop_thr = 0; p.drop_scale = 1.f; p.seed = nullptr; p.tag = 0;
+  if (nsp == 1) {
+    p.C = C; p.ldc = ldc; p.out_f32 = 3; p.c_split_stride = 0;
+  } else {
+    p.C = workspace; p.ldc = ldw; p.out_f32 = 1; p.c_split_stride = (long)M * ldw;
+  }
+  int rc = launch_gemm<128, 128>(p, nsp, stream);
+  if (rc) return rc;
+  if (nsp > 1) {
+    long blocks = ((long)M * (ldw / 4) + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)blocks), dim3(256), 0, stream, workspace, (long)M * ldw, nsp, C, ldc, M, N,
+                       (int)ldw);
+    VLB_CHECK_LAUNCH("vlb_wgrad_nt_bf16(reduce)");
+  }
+  return VLB_OK;
 }
 
 extern "C" int vlb_transpose_bf16(const void* in, long ldi, void* out, long ldo, int R, int C, float* colsum,

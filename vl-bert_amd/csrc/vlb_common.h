@@ -85,7 +85,7 @@ static inline float vlb_drop_scale(uint32_t thr) { return thr ? 65536.0f / (6553
 // epilogue runs 64 times per lane per GEMM tile, so this is on the critical path of the FFN GEMMs.
 __device__ __forceinline__ float erf_fast(float x) {
   const float ax = fabsf(x);
-  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));   // v_rcp_f32 (1 ulp), not the IEEE divide sequence
   float p = fmaf(1.061405429f, t, -1.453152027f);
   p = fmaf(p, t, 1.421413741f);
   p = fmaf(p, t, -0.284496736f);

@@ -241,6 +241,11 @@ class PretrainEngine:
         self.d_obj_reps = zf(BR, H)
         self.d_yds = zb(BR, H)
         self.d_afeat = zb(BR, VIS_DIM)
+        # fp32 slab workspace for split-K weight gradients (largest request over this engine's wgrad shapes)
+        need = [ops.wgrad_workspace_floats(n, k, rp) for n, k, rp in
+                ((3 * H, H, self.Mp), (H, H, self.Mp), (I, H, self.Mp), (H, I, self.Mp), (V, H, self.BTp), (H, H, self.BTp),
+                 (C, H, self.BRp), (H, H, self.BRp), (H, 2 * VIS_DIM, self.BRp))]
+        self.wg_ws = zf(max(max(need), 4))
         self.graph = None
         self._weights_dirty = True
         self.buckets = None
@@ -385,7 +390,7 @@ class PretrainEngine:
         tg, ta = tG[:N, :rows_p], tA[:K, :rows_p]
         ops.transpose(dy, tg, colsum=gb)
         ops.transpose(x, ta)
-        ops.gemm_nt(tg, ta, gw, out_mode=ops.OUT_F32_ATOMIC)
+        ops.wgrad_nt(tg, ta, gw, workspace=self.wg_ws)
 
     def backward(self, train=None, on_layer_done=None):
         train = self.train if train is None else train

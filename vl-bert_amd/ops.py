@@ -48,6 +48,20 @@ def gemm_nt(A, B, C, bias=None, act=ACT_NONE, aux=None, pre=None, res=None, drop
     return C
 
 
+def wgrad_nt(A, B, C, workspace=None):
+    """C[M,N] (fp32) += A[M,K] B[N,K]^T  (slab split-K, no atomics)."""
+    M, N = C.shape
+    K = A.shape[1]
+    assert A.shape[0] == M and B.shape[0] == N and B.shape[1] == K
+    _lib.call("vlb_wgrad_nt_bf16", _p(A, BF16), _ld(A), _p(B, BF16), _ld(B), _p(C, torch.float32), _ld(C), M, N, K,
+              _p(workspace, torch.float32), workspace.numel() if workspace is not None else 0, _stream())
+    return C
+
+
+def wgrad_workspace_floats(M, N, K):
+    return int(_lib.load().vlb_wgrad_workspace_floats(M, N, K))
+
+
 def transpose(x, out, colsum=None):
     """out[c, r] = x[r, c] (out may have a padded leading dimension)."""
     R, Cc = x.shape
