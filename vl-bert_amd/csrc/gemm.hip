@@ -20,6 +20,8 @@
 //   * fused epilogue: +bias, erf-GELU (optionally also storing the pre-activation), ReLU,
 //     x gelu'(aux) (GELU backward), dropout (counter RNG), +residual, bf16 or fp32 store,
 //     fp32 atomic accumulation for split-K weight gradients.
+#include <stdlib.h>
+
 #include "vlb_common.h"
 
 struct GemmParams {
@@ -37,6 +39,7 @@ struct GemmParams {
   long c_split_stride;       // elements between the outputs of consecutive K splits (slab split-K), 0 otherwise
   int out_f32;               // 0: bf16 store, 1: fp32 store, 2: fp32 atomicAdd
   int ntm, ntn;
+  int tile_group;            // tile-rows per L2 group (see the kernel's tile order)
 };
 
 #define GLDS_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
@@ -166,10 +169,11 @@ __device__ __forceinline__ void gemm_epilogue_dispatch(const GemmParams& p, f32x
   else gemm_epilogue<0, false, false, 0, INTERIOR, FM, FN>(p, acc, mb, nb);
 }
 
-template <int BM, int BN>
-__global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const GemmParams p) {
+template <int BM, int BN, int WGM, int WGN>   // WGM x WGN waves per workgroup
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_bf16_kernel(const GemmParams p) {
   constexpr int BK = 64;
-  constexpr int WM = BM / 2, WN = BN / 2;
+  constexpr int NT = 64 * WGM * WGN;
+  constexpr int WM = BM / WGM, WN = BN / WGN;
   constexpr int FM = WM / 16, FN = WN / 16;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const GemmParams p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WGN, wn = wave % WGN;
 
   // XCD-aware tile order: block b runs on XCD b%8; give each XCD a contiguous run of tiles so
   // tiles sharing an A panel hit the same L2 (bijective for any tile count).
@@ -187,7 +191,16 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const GemmParams p) {
     const int b = blockIdx.x, xcd = b & 7, q = nt >> 3, r = nt & 7;
     t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
   }
-  const int tile_m = t / p.ntn, tile_n = t % p.ntn;
+  // Within an XCD's run, tiles are visited in groups of `tile_group` tile-rows, column-major inside the
+  // group: the ~64 workgroups resident on one XCD then share <= tile_group A panels and a few B panels
+  // (working set fits the 4 MB L2) instead of sweeping the whole B matrix for every A panel.
+  int tile_m, tile_n;
+  {
+    const int gm = p.tile_group, per_group = gm * p.ntn, gid = t / per_group, first = gid * gm;
+    const int gsz = min(p.ntm - first, gm), rem = t - gid * per_group;
+    tile_m = first + rem % gsz;
+    tile_n = rem / gsz;
+  }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int k_begin = blockIdx.y * p.k_per_split;
   const int k_end = min(p.K, k_begin + p.k_per_split);
@@ -195,16 +208,16 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const GemmParams p) {
 
   // ---- per-thread staging addresses (16-B chunks; chunk P -> LDS byte 16*P) ----
   // P = it*256 + tid ; row r = P>>3 ; physical slot s = P&7 ; logical k-chunk kc = s ^ ((r>>1)&7)
-  const bf16_t* a_src[BM / 32];
-  const bf16_t* b_src[BN / 32];
+  const bf16_t* a_src[BM * 8 / NT];
+  const bf16_t* b_src[BN * 8 / NT];
 #pragma unroll
-  for (int it = 0; it < BM / 32; ++it) {
-    const int P = it * 256 + tid, r = P >> 3, kc = (P & 7) ^ ((r >> 1) & 7);
+  for (int it = 0; it < BM * 8 / NT; ++it) {
+    const int P = it * NT + tid, r = P >> 3, kc = (P & 7) ^ ((r >> 1) & 7);
     a_src[it] = p.A + (long)min(m0 + r, p.M - 1) * p.lda + k_begin + kc * 8;
   }
 #pragma unroll
-  for (int it = 0; it < BN / 32; ++it) {
-    const int P = it * 256 + tid, r = P >> 3, kc = (P & 7) ^ ((r >> 1) & 7);
+  for (int it = 0; it < BN * 8 / NT; ++it) {
+    const int P = it * NT + tid, r = P >> 3, kc = (P & 7) ^ ((r >> 1) & 7);
     b_src[it] = p.B + (long)min(n0 + r, p.N - 1) * p.ldb + k_begin + kc * 8;
   }
 
@@ -213,11 +226,11 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const GemmParams p) {
     char* sb = sa + A_BYTES;
     const int koff = kt * BK;
 #pragma unroll
-    for (int it = 0; it < BM / 32; ++it)
-      __builtin_amdgcn_global_load_lds(GLDS_PTR(a_src[it] + koff), LDS_PTR(sa + (it * 256 + wave * 64) * 16), 16, 0, 0);
+    for (int it = 0; it < BM * 8 / NT; ++it)
+      __builtin_amdgcn_global_load_lds(GLDS_PTR(a_src[it] + koff), LDS_PTR(sa + (it * NT + wave * 64) * 16), 16, 0, 0);
 #pragma unroll
-    for (int it = 0; it < BN / 32; ++it)
-      __builtin_amdgcn_global_load_lds(GLDS_PTR(b_src[it] + koff), LDS_PTR(sb + (it * 256 + wave * 64) * 16), 16, 0, 0);
+    for (int it = 0; it < BN * 8 / NT; ++it)
+      __builtin_amdgcn_global_load_lds(GLDS_PTR(b_src[it] + koff), LDS_PTR(sb + (it * NT + wave * 64) * 16), 16, 0, 0);
   };
 
   f32x4 acc[FM][FN];
@@ -338,20 +351,34 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __res
 // ------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------
-template <int BM, int BN>
-static int launch_gemm(GemmParams& p, int splits, hipStream_t stream) {
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+
+template <int BM, int BN, int WGM, int WGN>
+static int launch_gemm_cfg(GemmParams& p, int splits, hipStream_t stream) {
   constexpr int smem = 2 * (BM + BN) * 64 * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_kernel<BM, BN, WGM, WGN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
+  static const int group = env_int("VLB_GEMM_TILE_GROUP", 8);
   p.ntm = vlb_cdiv(p.M, BM);
   p.ntn = vlb_cdiv(p.N, BN);
+  p.tile_group = group < 1 ? 1 : group;
   dim3 grid(p.ntm * p.ntn, splits);
-  hipLaunchKernelGGL((gemm_nt_bf16_kernel<BM, BN>), grid, dim3(256), smem, stream, p);
+  hipLaunchKernelGGL((gemm_nt_bf16_kernel<BM, BN, WGM, WGN>), grid, dim3(64 * WGM * WGN), smem, stream, p);
   VLB_CHECK_LAUNCH("vlb_gemm_nt_bf16");
   return VLB_OK;
+}
+
+template <int BM, int BN>
+static int launch_gemm(GemmParams& p, int splits, hipStream_t stream) {
+  static const int waves8 = env_int("VLB_GEMM_WAVES8", 0);   // experiment: 2x4 waves (64x32 per wave) instead of 2x2
+  if (waves8 && BN == 128) return launch_gemm_cfg<BM, 128, 2, 4>(p, splits, stream);
+  return launch_gemm_cfg<BM, BN, 2, 2>(p, splits, stream);
 }
 
 extern "C" int vlb_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
