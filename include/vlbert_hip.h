@@ -62,6 +62,12 @@ long vlb_wgrad_workspace_floats(int M, int N, int K);
 int vlb_wgrad_nt_bf16(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, int K,
                       float* workspace, long workspace_floats, vlb_stream_t stream);
 
+/* Same product taken straight from the row-major tensors the forward/backward passes already hold:
+ * C[Mo,No] (fp32) += A[R,Mo]^T * B[R,No] (reduction over the R rows; LDS transpose reads, no transposed copies);
+ * colsum[Mo] += column sums of A when non-NULL (the bias gradient).  lda/ldb % 8 == 0, 16-byte aligned operands. */
+int vlb_wgrad_tn_bf16(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int R, int Mo, int No,
+                      float* colsum, float* workspace, long workspace_floats, vlb_stream_t stream);
+
 /* out[c][r] = in[r][c] (bf16, out leading dim ldo >= R); colsum[c] += sum_r in[r][c] if non-NULL
  * (bias gradients).  Feeds the weight-gradient GEMMs (autograd's `grad.t().mm(input)`). */
 int vlb_transpose_bf16(const void* in, long ldi, void* out, long ldo, int R, int C, float* colsum, vlb_stream_t stream);

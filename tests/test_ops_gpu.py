@@ -118,6 +118,30 @@ def test_wgrad_slab_splitk(ops, M, N, K, ws):
         assert float(C[:, N:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("R,Mo,No", [(1000, 192, 320), (2048, 768, 768), (300, 70, 200), (101, 1601, 128), (6464, 2304, 768),
+                                     (64, 128, 128), (4096, 30522, 64)])
+def test_wgrad_tn_lds_transpose_reads(ops, R, Mo, No):
+    """dW += dY^T X and db += colsum(dY) straight from row-major operands (ds_read_b64_tr_b16 fragments)."""
+    lda, ldb = (Mo + 63) // 64 * 64, (No + 7) // 8 * 8
+    dY, X = rnd(R, Mo, seed=18), rnd(R, No, seed=19, scale=0.2)
+    dYg = torch.full((R, lda), 9.0, dtype=torch.bfloat16, device=dev())   # pad columns hold junk on purpose
+    Xg = torch.full((R, ldb), 7.0, dtype=torch.bfloat16, device=dev())
+    dYg[:, :Mo] = to_gpu_bf16(dY)
+    Xg[:, :No] = to_gpu_bf16(X)
+    base = torch.randn(Mo, No, generator=torch.Generator().manual_seed(20))
+    ldc = (No + 3) // 4 * 4
+    C = torch.zeros((Mo, ldc), dtype=torch.float32, device=dev())
+    C[:, :No] = base.to(dev())
+    db = torch.ones(Mo, dtype=torch.float32, device=dev())
+    Rp = (R + 63) // 64 * 64
+    work = torch.empty(max(ops.wgrad_workspace_floats(Mo, No, Rp), 4), dtype=torch.float32, device=dev())
+    ops.wgrad_tn(dYg[:, :Mo], Xg[:, :No], C[:, :No], colsum=db, workspace=work)
+    report("wgrad TN %dx%dx%d" % (R, Mo, No), C[:, :No], base + dY.t() @ X, 1e-3, 2e-5)
+    report("wgrad TN colsum", db, 1 + dY.sum(0), 1e-3, 1e-5)
+    if ldc > No:
+        assert float(C[:, No:].abs().max()) == 0.0
+
+
 def test_gemm_dropout_and_ln_mask_agree(ops):
     """The GEMM-epilogue dropout mask and the LayerNorm-backward dx_drop mask are the same function."""
     M, N, K = 200, 256, 64

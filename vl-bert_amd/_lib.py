@@ -18,6 +18,7 @@ _SIGS = {
     "vlb_gemm_nt_bf16": "plplpliiipiplplplfpuiis",
     "vlb_transpose_bf16": "plpliips",
     "vlb_wgrad_nt_bf16": "plplpliiipls",
+    "vlb_wgrad_tn_bf16": "plplpliiippls",
     "vlb_layernorm_fwd": "plppplpiifs",
     "vlb_layernorm_bwd": "pliplppplplfpuplppiis",
     "vlb_attention_fwd": "ppppiiiifpus",

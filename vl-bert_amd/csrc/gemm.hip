@@ -277,6 +277,148 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_bf16_kernel(const Gemm
 }
 
 // ------------------------------------------------------------------------------------
+// "TN" GEMM for weight gradients:  C[Mo,No] (fp32) (+)= A[R,Mo]^T · B[R,No]   (reduction over the R ROWS)
+//   dW[n_out, k_in] = sum_rows dY[row, n_out] * X[row, k_in]        (autograd's grad_output.t().mm(input))
+// Both operands are consumed exactly as the forward pass left them (row-major activations / gradients): no
+// transposed copies in HBM.  A stage holds two [64 rows][128 cols] bf16 images (256-B rows) filled by LDS-DMA;
+// MFMA fragments need 8 consecutive ROWS of one column per lane, which is what the gfx950 LDS transpose read
+// ds_read_b64_tr_b16 delivers: within a 16-lane group, lane L supplies the 8-byte address of (row L>>2, 4 columns
+// (L&3)*4..) of a 4x16 block and receives the block's column L (4 rows).  Two such reads (rows +0..3, +4..7) form
+// one bf16x8 operand.  Bank conflicts: rows are 256 B = one full bank row, so the 32-B column block index is
+// XOR-swizzled with f(row) = (row&3) | ((row>>3)&1)<<2  -> the 8 row segments one instruction pass touches
+// (4 rows x 2 lane groups) fall on 8 distinct 32-B bank groups; as with the NT kernel the swizzle is applied to
+// the per-lane SOURCE address of the lane-linear LDS-DMA.
+// Rows >= R are sourced from a 16-B zero block (LDS-DMA cannot predicate), columns are clamped in-bounds (their
+// products land in output rows/cols that the epilogue masks).
+// Optional fused column sums of A (bias gradient): accumulated from the A fragments by the tile_n == 0 workgroups.
+// ------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) uint4 vlb_zero16[2];
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+__device__ __forceinline__ bf16x8 lds_tr_frag(const char* base, int addr_lo, int addr_hi) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + addr_lo));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + addr_hi));
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const GemmParams p, float* __restrict__ colsum) {
+  constexpr int BM = 128, BN = 128, BR = 64;          // output tile, reduction rows per stage
+  constexpr int FM = 4, FN = 4;
+  constexpr int IMG = BR * 128 * 2, STAGE = 2 * IMG;  // 16 KiB per operand image
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nt = p.ntm * p.ntn;
+  int t;
+  {
+    const int b = blockIdx.x, xcd = b & 7, q = nt >> 3, r = nt & 7;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  }
+  const int tile_m = t / p.ntn, tile_n = t % p.ntn;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int r_begin = blockIdx.y * p.k_per_split;
+  const int r_end = min(p.K, r_begin + p.k_per_split);       // p.K = number of reduction rows R
+  const int ntk = (r_end - r_begin + BR - 1) / BR;
+
+  // staging: chunk P = it*256 + tid -> row = P>>4 (0..63), physical 16-B chunk c = P&15;
+  // physical 32-B block c>>1 holds logical block (c>>1) ^ f(row)
+  int a_col[4], b_col[4], s_row[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int P = it * 256 + tid, row = P >> 4, c = P & 15;
+    const int f = (row & 3) | (((row >> 3) & 1) << 2);
+    const int lc = ((((c >> 1) ^ f) << 1) | (c & 1)) * 8;     // logical column offset inside the 128-wide tile
+    s_row[it] = row;
+    a_col[it] = min(m0 + lc, (int)p.lda - 8);
+    b_col[it] = min(n0 + lc, (int)p.ldb - 8);
+  }
+  const bf16_t* zero = (const bf16_t*)vlb_zero16;
+  auto stage = [&](int buf, int kt) {
+    char* sa = smem + buf * STAGE;
+    char* sb = sa + IMG;
+    const int rbase = r_begin + kt * BR;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = rbase + s_row[it];
+      const bool ok = row < r_end;
+      const bf16_t* ga = ok ? p.A + (long)row * p.lda + a_col[it] : zero;
+      const bf16_t* gb = ok ? p.B + (long)row * p.ldb + b_col[it] : zero;
+      __builtin_amdgcn_global_load_lds(GLDS_PTR(ga), LDS_PTR(sa + (it * 256 + wave * 64) * 16), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GLDS_PTR(gb), LDS_PTR(sb + (it * 256 + wave * 64) * 16), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float csum[FM] = {0.f, 0.f, 0.f, 0.f};
+  const bool do_colsum = (colsum != nullptr) && (tile_n == 0);
+
+  // fragment addressing (see header comment): L = lane&15, g = lane>>4
+  const int L = lane & 15, g = lane >> 4;
+  const int fl = (L >> 2) | ((g & 1) << 2);
+  const int row_lo = 8 * g + (L >> 2);                        // + 32*ks (+4 for the high half)
+  const int lane_off = row_lo * 256 + (L & 3) * 8;
+  int a_cb[FM], b_cb[FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) a_cb[i] = (((wm * 4 + i) ^ fl) << 5);
+#pragma unroll
+  for (int j = 0; j < FN; ++j) b_cb[j] = (((wn * 4 + j) ^ fl) << 5);
+
+  if (ntk > 0) {
+    stage(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < ntk; ++kt) {
+      const int cur = kt & 1;
+      if (kt + 1 < ntk) stage(cur ^ 1, kt + 1);
+      const char* sa = smem + cur * STAGE;
+      const char* sb = sa + IMG;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int base = lane_off + ks * 32 * 256;
+        bf16x8 af[FM], bfr[FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) af[i] = lds_tr_frag(sa, base + a_cb[i], base + 4 * 256 + a_cb[i]);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) bfr[j] = lds_tr_frag(sb, base + b_cb[j], base + 4 * 256 + b_cb[j]);
+        if (do_colsum) {
+#pragma unroll
+          for (int i = 0; i < FM; ++i) {
+            const uint4 w = __builtin_bit_cast(uint4, af[i]);
+            csum[i] += (bflo(w.x) + bfhi(w.x)) + (bflo(w.y) + bfhi(w.y)) + (bflo(w.z) + bfhi(w.z)) + (bflo(w.w) + bfhi(w.w));
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+      }
+      __syncthreads();
+    }
+  }
+  if (do_colsum && wn == 0) {   // the wn==1 waves hold the same A fragments: count them once
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      float v = csum[i];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      const int m = m0 + wm * 64 + i * 16 + L;
+      if (g == 0 && m < p.M) atomicAdd(colsum + m, v);
+    }
+  }
+  const int mb = m0 + wm * 64 + (lane & 15), nb = n0 + wn * 64 + 4 * (lane >> 4);
+  if (m0 + BM <= p.M && n0 + BN <= p.N) gemm_epilogue_dispatch<true, FM, FN>(p, acc, mb, nb);
+  else gemm_epilogue_dispatch<false, FM, FN>(p, acc, mb, nb);
+}
+
+// ------------------------------------------------------------------------------------
 // bf16 transpose:  out[c][r] = in[r][c]  (out leading dim ldo >= R; pad columns untouched),
 // optional fused column sum  colsum[c] += sum_r in[r][c]  (bias gradients).
 // 64x64 tiles through an XOR-swizzled LDS image; BOTH global sides move 16 B per lane with 8 lanes
@@ -364,7 +506,7 @@ static int launch_gemm_cfg(GemmParams& p, int splits, hipStream_t stream) {
     (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_kernel<BM, BN, WGM, WGN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
-  static const int group = env_int("VLB_GEMM_TILE_GROUP", 8);
+  static const int group = env_int("VLB_GEMM_TILE_GROUP", 4);
   p.ntm = vlb_cdiv(p.M, BM);
   p.ntn = vlb_cdiv(p.N, BN);
   p.tile_group = group < 1 ? 1 : group;
@@ -376,7 +518,7 @@ static int launch_gemm_cfg(GemmParams& p, int splits, hipStream_t stream) {
 
 template <int BM, int BN>
 static int launch_gemm(GemmParams& p, int splits, hipStream_t stream) {
-  static const int waves8 = env_int("VLB_GEMM_WAVES8", 0);   // experiment: 2x4 waves (64x32 per wave) instead of 2x2
+  static const int waves8 = env_int("VLB_GEMM_WAVES8", 1);   // 2x4 waves (64x32 per wave): 16 waves/CU hide LDS/barrier latency better than 2x2
   if (waves8 && BN == 128) return launch_gemm_cfg<BM, 128, 2, 4>(p, splits, stream);
   return launch_gemm_cfg<BM, BN, 2, 2>(p, splits, stream);
 }
@@ -516,6 +658,48 @@ extern "C" int vlb_wgrad_nt_bf16(const void* A, long lda, const void* B, long ld
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)blocks), dim3(256), 0, stream, workspace, (long)M * ldw, nsp, C, ldc, M, N,
                        (int)ldw);
     VLB_CHECK_LAUNCH("vlb_wgrad_nt_bf16(reduce)");
+  }
+  return VLB_OK;
+}
+
+// dW[Mo,No] (fp32) += A[R,Mo]^T B[R,No]; optional colsum[Mo] += column sums of A (bias gradient).
+extern "C" int vlb_wgrad_tn_bf16(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int R, int Mo, int No,
+                                 float* colsum, float* workspace, long workspace_floats, hipStream_t stream) {
+  if (Mo <= 0 || No <= 0 || R <= 0) return VLB_OK;
+  VLB_CHECK_ARG(A && B && C, "vlb_wgrad_tn_bf16: null operand");
+  VLB_CHECK_ARG((lda % 8) == 0 && (ldb % 8) == 0 && (ldc % 4) == 0 && lda >= 8 && ldb >= 8, "vlb_wgrad_tn_bf16: bad leading dimensions");
+  VLB_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "vlb_wgrad_tn_bf16: operands must be 16-byte aligned");
+  const int Rp = vlb_cdiv(R, 64) * 64;
+  const int splits = wgrad_pick_splits(Mo, No, Rp, workspace ? workspace_floats : 0);
+  const int ktiles = Rp / 64;
+  const int per = vlb_cdiv(ktiles, splits);
+  const int nsp = vlb_cdiv(ktiles, per);
+  const long ldw = (No + 3) / 4 * 4;
+  GemmParams p;
+  p.A = (const bf16_t*)A; p.lda = lda; p.B = (const bf16_t*)B; p.ldb = ldb;
+  p.M = Mo; p.N = No; p.K = R; p.k_per_split = per * 64;
+  p.bias = nullptr; p.act = 0; p.aux = nullptr; p.ldaux = 0; p.pre = nullptr; p.ldpre = 0; p.res = nullptr; p.ldres = 0;
+  p.drop_thr = 0; p.drop_scale = 1.f; p.seed = nullptr; p.tag = 0;
+  if (nsp == 1) {
+    p.C = C; p.ldc = ldc; p.out_f32 = 3; p.c_split_stride = 0;
+  } else {
+    p.C = workspace; p.ldc = ldw; p.out_f32 = 1; p.c_split_stride = (long)Mo * ldw;
+  }
+  p.ntm = vlb_cdiv(Mo, 128); p.ntn = vlb_cdiv(No, 128); p.tile_group = 1;
+  constexpr int smem = 2 * 2 * 64 * 128 * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_tn_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3(p.ntm * p.ntn, nsp), dim3(256), smem, stream, p, colsum);
+  VLB_CHECK_LAUNCH("vlb_wgrad_tn_bf16");
+  if (nsp > 1) {
+    long blocks = ((long)Mo * (ldw / 4) + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)blocks), dim3(256), 0, stream, workspace, (long)Mo * ldw, nsp, C, ldc, Mo, No,
+                       (int)ldw);
+    VLB_CHECK_LAUNCH("vlb_wgrad_tn_bf16(reduce)");
   }
   return VLB_OK;
 }

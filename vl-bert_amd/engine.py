@@ -248,6 +248,8 @@ class PretrainEngine:
         self.wg_ws = zf(max(max(need), 4))
         self.graph = None
         self._weights_dirty = True
+        import os
+        self.use_tn_wgrad = os.environ.get("VLB_WGRAD_TN", "1") != "0"
         self.buckets = None
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1:
@@ -386,6 +388,9 @@ class PretrainEngine:
     # ------------------------------------------------------------------------------------------
     def _wgrad(self, dy, x, gw, gb, tG, tA, rows_p):
         """gw[N,K] += dy^T x ; gb[N] += colsum(dy) through zero-padded transposes."""
+        if self.use_tn_wgrad:   # straight from the row-major operands (LDS transpose reads), bias gradient fused
+            ops.wgrad_tn(dy, x, gw, colsum=gb, workspace=self.wg_ws)
+            return
         N, K = dy.shape[1], x.shape[1]
         tg, ta = tG[:N, :rows_p], tA[:K, :rows_p]
         ops.transpose(dy, tg, colsum=gb)

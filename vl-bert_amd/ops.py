@@ -58,6 +58,16 @@ def wgrad_nt(A, B, C, workspace=None):
     return C
 
 
+def wgrad_tn(dy, x, C, colsum=None, workspace=None):
+    """C[Mo,No] (fp32) += dy[R,Mo]^T x[R,No]  (+ colsum[Mo] += dy.sum(0)); operands as the passes left them."""
+    Mo, No = C.shape
+    R = dy.shape[0]
+    assert dy.shape[1] == Mo and x.shape[1] == No and x.shape[0] == R
+    _lib.call("vlb_wgrad_tn_bf16", _p(dy, BF16), _ld(dy), _p(x, BF16), _ld(x), _p(C, torch.float32), _ld(C), R, Mo, No,
+              _p(colsum, torch.float32), _p(workspace, torch.float32), workspace.numel() if workspace is not None else 0, _stream())
+    return C
+
+
 def wgrad_workspace_floats(M, N, K):
     return int(_lib.load().vlb_wgrad_workspace_floats(M, N, K))
 
