@@ -304,6 +304,32 @@ __device__ __forceinline__ bf16x8 lds_tr_frag(const char* base, int addr_lo, int
   return __builtin_bit_cast(bf16x8, v);
 }
 
+template <bool COLSUM>
+__device__ __forceinline__ void tn_compute_stage(const char* sa, const char* sb, int lane_off, const int (&a_cb)[4], const int (&b_cb)[4],
+                                                 f32x4 (&acc)[4][4], float (&csum)[4]) {
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int base = lane_off + ks * 32 * 256;
+    bf16x8 af[4], bfr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[i] = lds_tr_frag(sa, base + a_cb[i], base + 4 * 256 + a_cb[i]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bfr[j] = lds_tr_frag(sb, base + b_cb[j], base + 4 * 256 + b_cb[j]);
+    if (COLSUM) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint4 w = __builtin_bit_cast(uint4, af[i]);
+        csum[i] += (bflo(w.x) + bfhi(w.x)) + (bflo(w.y) + bfhi(w.y)) + (bflo(w.z) + bfhi(w.z)) + (bflo(w.w) + bfhi(w.w));
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+  }
+}
+
 __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const GemmParams p, float* __restrict__ colsum) {
   constexpr int BM = 128, BN = 128, BR = 64;          // output tile, reduction rows per stage
   constexpr int FM = 4, FN = 4;
@@ -323,33 +349,52 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const GemmParams p, f
   const int r_begin = blockIdx.y * p.k_per_split;
   const int r_end = min(p.K, r_begin + p.k_per_split);       // p.K = number of reduction rows R
   const int ntk = (r_end - r_begin + BR - 1) / BR;
+  const int nfull = (r_end - r_begin) / BR;                   // stages whose 64 rows all exist
 
   // staging: chunk P = it*256 + tid -> row = P>>4 (0..63), physical 16-B chunk c = P&15;
-  // physical 32-B block c>>1 holds logical block (c>>1) ^ f(row)
-  int a_col[4], b_col[4], s_row[4];
+  // physical 32-B block c>>1 holds logical block (c>>1) ^ f(row).  Source pointers advance by 64 rows per stage.
+  const bf16_t* a_ptr[4];
+  const bf16_t* b_ptr[4];
+  int s_row[4];
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const int P = it * 256 + tid, row = P >> 4, c = P & 15;
     const int f = (row & 3) | (((row >> 3) & 1) << 2);
     const int lc = ((((c >> 1) ^ f) << 1) | (c & 1)) * 8;     // logical column offset inside the 128-wide tile
     s_row[it] = row;
-    a_col[it] = min(m0 + lc, (int)p.lda - 8);
-    b_col[it] = min(n0 + lc, (int)p.ldb - 8);
+    a_ptr[it] = p.A + (long)(r_begin + row) * p.lda + min(m0 + lc, (int)p.lda - 8);
+    b_ptr[it] = p.B + (long)(r_begin + row) * p.ldb + min(n0 + lc, (int)p.ldb - 8);
   }
+  const long a_step = 64 * p.lda, b_step = 64 * p.ldb;
   const bf16_t* zero = (const bf16_t*)vlb_zero16;
-  auto stage = [&](int buf, int kt) {
+
+  auto stage_full = [&](int buf) {   // all 64 rows in range: unconditional LDS-DMA, pointers bumped afterwards
+    char* sa = smem + buf * STAGE;
+    char* sb = sa + IMG;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      __builtin_amdgcn_global_load_lds(GLDS_PTR(a_ptr[it]), LDS_PTR(sa + (it * 256 + wave * 64) * 16), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GLDS_PTR(b_ptr[it]), LDS_PTR(sb + (it * 256 + wave * 64) * 16), 16, 0, 0);
+      a_ptr[it] += a_step;
+      b_ptr[it] += b_step;
+    }
+  };
+  auto stage_tail = [&](int buf, int kt) {   // last, partial stage: rows >= r_end come from the zero block
     char* sa = smem + buf * STAGE;
     char* sb = sa + IMG;
     const int rbase = r_begin + kt * BR;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
-      const int row = rbase + s_row[it];
-      const bool ok = row < r_end;
-      const bf16_t* ga = ok ? p.A + (long)row * p.lda + a_col[it] : zero;
-      const bf16_t* gb = ok ? p.B + (long)row * p.ldb + b_col[it] : zero;
+      const bool ok = rbase + s_row[it] < r_end;
+      const bf16_t* ga = ok ? a_ptr[it] : zero;
+      const bf16_t* gb = ok ? b_ptr[it] : zero;
       __builtin_amdgcn_global_load_lds(GLDS_PTR(ga), LDS_PTR(sa + (it * 256 + wave * 64) * 16), 16, 0, 0);
       __builtin_amdgcn_global_load_lds(GLDS_PTR(gb), LDS_PTR(sb + (it * 256 + wave * 64) * 16), 16, 0, 0);
     }
+  };
+  auto stage = [&](int buf, int kt) {
+    if (kt < nfull) stage_full(buf);
+    else stage_tail(buf, kt);
   };
 
   f32x4 acc[FM][FN];
@@ -358,13 +403,12 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const GemmParams p, f
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float csum[FM] = {0.f, 0.f, 0.f, 0.f};
-  const bool do_colsum = (colsum != nullptr) && (tile_n == 0);
+  const bool do_colsum = (colsum != nullptr) && (tile_n == 0) && (wn == 0);   // wn==1 waves hold the same A fragments
 
   // fragment addressing (see header comment): L = lane&15, g = lane>>4
   const int L = lane & 15, g = lane >> 4;
   const int fl = (L >> 2) | ((g & 1) << 2);
-  const int row_lo = 8 * g + (L >> 2);                        // + 32*ks (+4 for the high half)
-  const int lane_off = row_lo * 256 + (L & 3) * 8;
+  const int lane_off = (8 * g + (L >> 2)) * 256 + (L & 3) * 8;    // + 32*256*ks, + 4*256 for the high half
   int a_cb[FM], b_cb[FN];
 #pragma unroll
   for (int i = 0; i < FM; ++i) a_cb[i] = (((wm * 4 + i) ^ fl) << 5);
@@ -379,31 +423,12 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const GemmParams p, f
       if (kt + 1 < ntk) stage(cur ^ 1, kt + 1);
       const char* sa = smem + cur * STAGE;
       const char* sb = sa + IMG;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const int base = lane_off + ks * 32 * 256;
-        bf16x8 af[FM], bfr[FN];
-#pragma unroll
-        for (int i = 0; i < FM; ++i) af[i] = lds_tr_frag(sa, base + a_cb[i], base + 4 * 256 + a_cb[i]);
-#pragma unroll
-        for (int j = 0; j < FN; ++j) bfr[j] = lds_tr_frag(sb, base + b_cb[j], base + 4 * 256 + b_cb[j]);
-        if (do_colsum) {
-#pragma unroll
-          for (int i = 0; i < FM; ++i) {
-            const uint4 w = __builtin_bit_cast(uint4, af[i]);
-            csum[i] += (bflo(w.x) + bfhi(w.x)) + (bflo(w.y) + bfhi(w.y)) + (bflo(w.z) + bfhi(w.z)) + (bflo(w.w) + bfhi(w.w));
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-          for (int j = 0; j < FN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-      }
+      if (do_colsum) tn_compute_stage<true>(sa, sb, lane_off, a_cb, b_cb, acc, csum);
+      else tn_compute_stage<false>(sa, sb, lane_off, a_cb, b_cb, acc, csum);
       __syncthreads();
     }
   }
-  if (do_colsum && wn == 0) {   // the wn==1 waves hold the same A fragments: count them once
+  if (do_colsum) {
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       float v = csum[i];
