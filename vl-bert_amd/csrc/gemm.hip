@@ -22,6 +22,8 @@
 //     fp32 atomic accumulation for split-K weight gradients.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "vlb_common.h"
 
 struct GemmParams {
@@ -415,7 +417,11 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const GemmParams p, f
 #pragma unroll
   for (int j = 0; j < FN; ++j) b_cb[j] = (((wn * 4 + j) ^ fl) << 5);
 
-  if (ntk > 0) {
+  // The K loop is instantiated twice OUTSIDE the column-sum branch: selecting the variant inside the loop makes
+  // the 64 accumulator registers live across a branch and hipcc then shuttles them VGPR<->AGPR every iteration
+  // (89 v_accvgpr_write per stage, as slow as the MFMAs themselves).
+  auto k_loop = [&](auto with_colsum) {
+    constexpr bool CS = decltype(with_colsum)::value;
     stage(0, 0);
     __syncthreads();
     for (int kt = 0; kt < ntk; ++kt) {
@@ -423,10 +429,13 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const GemmParams p, f
       if (kt + 1 < ntk) stage(cur ^ 1, kt + 1);
       const char* sa = smem + cur * STAGE;
       const char* sb = sa + IMG;
-      if (do_colsum) tn_compute_stage<true>(sa, sb, lane_off, a_cb, b_cb, acc, csum);
-      else tn_compute_stage<false>(sa, sb, lane_off, a_cb, b_cb, acc, csum);
+      tn_compute_stage<CS>(sa, sb, lane_off, a_cb, b_cb, acc, csum);
       __syncthreads();
     }
+  };
+  if (ntk > 0) {
+    if (do_colsum) k_loop(std::true_type{});
+    else k_loop(std::false_type{});
   }
   if (do_colsum) {
 #pragma unroll
