@@ -146,7 +146,7 @@ def main():
     # ---- roofline of the dominant kernel (the bf16 MFMA GEMM): one extra, instrumented step ---------------
     # HIP events are recorded on the stream the kernels are launched on (torch's current stream).
     rec = []
-    orig, orig_w = ops.gemm_nt, ops.wgrad_nt
+    orig, orig_w, orig_t = ops.gemm_nt, ops.wgrad_nt, ops.wgrad_tn
 
     def timed(fn):
         def wrapper(A, B, C, *a, **kw):
@@ -154,15 +154,15 @@ def main():
             e0.record()
             out = fn(A, B, C, *a, **kw)
             e1.record()
-            K = kw.get("K") or A.shape[1]
+            K = kw.get("K") or (A.shape[0] if fn is orig_t else A.shape[1])      # TN form reduces over the rows
             rec.append((e0, e1, 2.0 * C.shape[0] * C.shape[1] * K))
             return out
         return wrapper
 
-    ops.gemm_nt, ops.wgrad_nt = timed(orig), timed(orig_w)   # wgrad_nt = the same GEMM kernel + its slab reduce
+    ops.gemm_nt, ops.wgrad_nt, ops.wgrad_tn = timed(orig), timed(orig_w), timed(orig_t)   # wgrad_* include their slab reduce
     eng.train_step()
     torch.cuda.synchronize()
-    ops.gemm_nt, ops.wgrad_nt = orig, orig_w
+    ops.gemm_nt, ops.wgrad_nt, ops.wgrad_tn = orig, orig_w, orig_t
     gemm_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in rec)
     gemm_flops = sum(f for _, _, f in rec)
     achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
@@ -178,7 +178,7 @@ def main():
                                    "precomputed 2048-d region features, dropout on" % args.layers,
                        "global_batch": args.global_batch, "per_gpu_batch": per_gpu, "seq_len": T + R + 1,
                        "parallelism": "dp%d" % world, "hipgraph": bool(use_graph), "arch": arch, "cus": cus},
-            "roofline": {"bound": "mfma", "kernel": "gemm_nt_bf16_kernel (all %d launches of one step)" % len(rec),
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt_bf16_kernel + gemm_tn_bf16_kernel (all %d GEMM launches of one step)" % len(rec),
                          "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
                          "gemm_ms_per_step": round(gemm_ms, 3), "gemm_share_of_step": round(gemm_ms / ms, 3),

@@ -177,6 +177,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_bf16_kernel(const Gemm
   constexpr int NT = 64 * WGM * WGN;
   constexpr int WM = BM / WGM, WN = BN / WGN;
   constexpr int FM = WM / 16, FN = WN / 16;
+  constexpr int NA = BM * 8 / NT, NB = BN * 8 / NT;   // 16-B chunks per thread per stage
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -184,54 +185,48 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_bf16_kernel(const Gemm
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WGN, wn = wave % WGN;
-
-  // XCD-aware tile order: block b runs on XCD b%8; give each XCD a contiguous run of tiles so
-  // tiles sharing an A panel hit the same L2 (bijective for any tile count).
   const int nt = p.ntm * p.ntn;
-  int t;
-  {
-    const int b = blockIdx.x, xcd = b & 7, q = nt >> 3, r = nt & 7;
-    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-  }
-  // Within an XCD's run, tiles are visited in groups of `tile_group` tile-rows, column-major inside the
-  // group: the ~64 workgroups resident on one XCD then share <= tile_group A panels and a few B panels
-  // (working set fits the 4 MB L2) instead of sweeping the whole B matrix for every A panel.
-  int tile_m, tile_n;
-  {
-    const int gm = p.tile_group, per_group = gm * p.ntn, gid = t / per_group, first = gid * gm;
-    const int gsz = min(p.ntm - first, gm), rem = t - gid * per_group;
-    tile_m = first + rem % gsz;
-    tile_n = rem / gsz;
-  }
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int k_begin = blockIdx.y * p.k_per_split;
   const int k_end = min(p.K, k_begin + p.k_per_split);
   const int ntk = (k_end - k_begin) / BK;
+  if ((int)blockIdx.x >= nt || ntk <= 0) return;
 
-  // ---- per-thread staging addresses (16-B chunks; chunk P -> LDS byte 16*P) ----
-  // P = it*256 + tid ; row r = P>>3 ; physical slot s = P&7 ; logical k-chunk kc = s ^ ((r>>1)&7)
-  const bf16_t* a_src[BM * 8 / NT];
-  const bf16_t* b_src[BN * 8 / NT];
+  // PERSISTENT workgroups: block b walks work items w = b, b+grid, b+2*grid, ... (grid = resident workgroups).
+  // w -> tile: XCD-aware (block b runs on XCD b%8 and grid%8==0, so w%8 is this block's XCD: each XCD owns a
+  // contiguous run of tiles, bijective for any tile count), then visited in groups of `tile_group` tile-rows,
+  // column-major inside the group, so the ~64 workgroups resident on one XCD share <= tile_group A panels and a
+  // few B panels (working set fits the 4 MB L2) instead of sweeping all of B for every A panel.
+  auto tile_of = [&](int w, int& m0, int& n0) {
+    const int xcd = w & 7, q = nt >> 3, r = nt & 7;
+    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (w >> 3);
+    const int gm = p.tile_group, per_group = gm * p.ntn, gid = t / per_group, first = gid * gm;
+    const int gsz = min(p.ntm - first, gm), rem = t - gid * per_group;
+    m0 = (first + rem % gsz) * BM;
+    n0 = (rem / gsz) * BN;
+  };
+  // per-thread staging addresses (16-B chunks; chunk P -> LDS byte 16*P):
+  // P = it*NT + tid ; row r = P>>3 ; physical slot s = P&7 ; logical k-chunk kc = s ^ ((r>>1)&7)
+  auto setup = [&](const bf16_t* (&a_src)[NA], const bf16_t* (&b_src)[NB], int m0, int n0) {
 #pragma unroll
-  for (int it = 0; it < BM * 8 / NT; ++it) {
-    const int P = it * NT + tid, r = P >> 3, kc = (P & 7) ^ ((r >> 1) & 7);
-    a_src[it] = p.A + (long)min(m0 + r, p.M - 1) * p.lda + k_begin + kc * 8;
-  }
+    for (int it = 0; it < NA; ++it) {
+      const int P = it * NT + tid, r = P >> 3, kc = (P & 7) ^ ((r >> 1) & 7);
+      a_src[it] = p.A + (long)min(m0 + r, p.M - 1) * p.lda + k_begin + kc * 8;
+    }
 #pragma unroll
-  for (int it = 0; it < BN * 8 / NT; ++it) {
-    const int P = it * NT + tid, r = P >> 3, kc = (P & 7) ^ ((r >> 1) & 7);
-    b_src[it] = p.B + (long)min(n0 + r, p.N - 1) * p.ldb + k_begin + kc * 8;
-  }
-
-  auto stage = [&](int buf, int kt) {
+    for (int it = 0; it < NB; ++it) {
+      const int P = it * NT + tid, r = P >> 3, kc = (P & 7) ^ ((r >> 1) & 7);
+      b_src[it] = p.B + (long)min(n0 + r, p.N - 1) * p.ldb + k_begin + kc * 8;
+    }
+  };
+  auto stage = [&](const bf16_t* (&a_src)[NA], const bf16_t* (&b_src)[NB], int buf, int kt) {
     char* sa = smem + buf * STAGE;
     char* sb = sa + A_BYTES;
     const int koff = kt * BK;
 #pragma unroll
-    for (int it = 0; it < BM * 8 / NT; ++it)
+    for (int it = 0; it < NA; ++it)
       __builtin_amdgcn_global_load_lds(GLDS_PTR(a_src[it] + koff), LDS_PTR(sa + (it * NT + wave * 64) * 16), 16, 0, 0);
 #pragma unroll
-    for (int it = 0; it < BN * 8 / NT; ++it)
+    for (int it = 0; it < NB; ++it)
       __builtin_amdgcn_global_load_lds(GLDS_PTR(b_src[it] + koff), LDS_PTR(sb + (it * NT + wave * 64) * 16), 16, 0, 0);
   };
 
@@ -247,13 +242,28 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_bf16_kernel(const Gemm
   const int a_off = (wm * WM + frow) * 128 + c0;
   const int b_off = (wn * WN + frow) * 128 + c0;
 
-  if (ntk > 0) {
-    stage(0, 0);
-    __syncthreads();
+  const bf16_t* a_src[NA];
+  const bf16_t* b_src[NB];
+  int w = blockIdx.x, m0, n0, buf = 0;
+  tile_of(w, m0, n0);
+  setup(a_src, b_src, m0, n0);
+  stage(a_src, b_src, 0, 0);
+  __syncthreads();
+  for (;;) {
+    const int w_next = w + gridDim.x;
+    const bool has_next = w_next < nt;
+    int m0n = 0, n0n = 0;
+    const bf16_t* a_nx[NA];
+    const bf16_t* b_nx[NB];
     for (int kt = 0; kt < ntk; ++kt) {
-      const int cur = kt & 1;
-      if (kt + 1 < ntk) stage(cur ^ 1, kt + 1);
-      const char* sa = smem + cur * STAGE;
+      if (kt + 1 < ntk) {
+        stage(a_src, b_src, buf ^ 1, kt + 1);
+      } else if (has_next) {   // last K tile: the first stage of the NEXT output tile streams in under the epilogue
+        tile_of(w_next, m0n, n0n);
+        setup(a_nx, b_nx, m0n, n0n);
+        stage(a_nx, b_nx, buf ^ 1, 0);
+      }
+      const char* sa = smem + buf * STAGE;
       const char* sb = sa + A_BYTES;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
@@ -268,14 +278,28 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_bf16_kernel(const Gemm
           for (int j = 0; j < FN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
       }
-      __syncthreads();  // next stage landed (hipcc drains the LDS-DMA queue here) + WAR on `cur`
+      if (kt + 1 < ntk) {
+        __syncthreads();  // next stage landed (hipcc drains the LDS-DMA queue here) + WAR on the buffer just read
+        buf ^= 1;
+      }
     }
+    // ---- epilogue: lane holds C[m][n..n+3], m = .. + (lane&15), n = .. + 4*(lane>>4) ----
+    const int mb = m0 + wm * WM + (lane & 15), nb = n0 + wn * WN + 4 * (lane >> 4);
+    if (m0 + BM <= p.M && n0 + BN <= p.N) gemm_epilogue_dispatch<true, FM, FN>(p, acc, mb, nb);
+    else gemm_epilogue_dispatch<false, FM, FN>(p, acc, mb, nb);
+    if (!has_next) break;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int it = 0; it < NA; ++it) a_src[it] = a_nx[it];
+#pragma unroll
+    for (int it = 0; it < NB; ++it) b_src[it] = b_nx[it];
+    w = w_next; m0 = m0n; n0 = n0n;
+    __syncthreads();   // the prefetched first stage of the next tile has landed; everyone left the old buffers
+    buf ^= 1;
   }
-
-  // ---- epilogue: lane holds C[m][n..n+3], m = .. + (lane&15), n = .. + 4*(lane>>4) ----
-  const int mb = m0 + wm * WM + (lane & 15), nb = n0 + wn * WN + 4 * (lane >> 4);
-  if (m0 + BM <= p.M && n0 + BN <= p.N) gemm_epilogue_dispatch<true, FM, FN>(p, acc, mb, nb);
-  else gemm_epilogue_dispatch<false, FM, FN>(p, acc, mb, nb);
 }
 
 // ------------------------------------------------------------------------------------
@@ -544,7 +568,15 @@ static int launch_gemm_cfg(GemmParams& p, int splits, hipStream_t stream) {
   p.ntm = vlb_cdiv(p.M, BM);
   p.ntn = vlb_cdiv(p.N, BN);
   p.tile_group = group < 1 ? 1 : group;
-  dim3 grid(p.ntm * p.ntn, splits);
+  // persistent grid: the workgroups that are resident at once (2 per CU with 48-64 KB LDS each on 256 CUs),
+  // a multiple of 8 so that work item w and block b stay on the same XCD
+  static const int resident = env_int("VLB_GEMM_RESIDENT", 512);
+  int gx = p.ntm * p.ntn;
+  int cap = resident / splits;
+  if (cap < 8) cap = 8;
+  cap &= ~7;
+  if (gx > cap) gx = cap;
+  dim3 grid(gx, splits);
   hipLaunchKernelGGL((gemm_nt_bf16_kernel<BM, BN, WGM, WGN>), grid, dim3(64 * WGM * WGN), smem, stream, p);
   VLB_CHECK_LAUNCH("vlb_gemm_nt_bf16");
   return VLB_OK;
