@@ -52,8 +52,40 @@ struct GemmParams {
 // pointers are formed once per fragment row and the 16-column fragment steps fold into immediate offsets; the
 // bias vector depends only on the column fragment and is loaded once per column.
 // OUT: 0 bf16 store | 1 fp32 store | 2 fp32 atomicAdd | 3 fp32 read-modify-write accumulate (tile owned by one block)
+//
+// bf16 results of interior tiles are STAGED through LDS (the stage buffer the K loop just finished with): the MFMA
+// layout gives a lane 4 columns of one row, i.e. a wave store would touch 16 rows x 32 B -- half cache lines, and
+// the L2 write-transaction rate (not bytes) bounded the short-K GEMMs.  From LDS every lane writes 16 B and a wave
+// covers whole tile rows.  Tile image: [128 rows][BN*2 B], 16-B chunk index XOR (row & (BN/8-1)): conflict-free for
+// the ds_write_b64 fragment writes, whose 16-lane groups hold 16 different rows at one column.
+struct EpiStage {
+  char* lds;         // 32 KiB staging image
+  int m0, n0;        // tile origin
+  int row_l, col_l;  // this lane's position inside the tile for fragment (0,0): row = row_l + 16 i, col = col_l + 16 j
+  int tid, nthreads, bn;
+};
+
+__device__ __forceinline__ void epi_stage_put(const EpiStage& st, int i, int j, const float (&v)[4]) {
+  const int row = st.row_l + i * 16, colb = (st.col_l + j * 16) * 2;
+  const int pitch = st.bn * 2, mask = (st.bn >> 3) - 1;      // image rows are exactly BN bf16 wide
+  *(uint2*)(st.lds + row * pitch + ((((colb >> 4) ^ (row & mask)) << 4) | (colb & 15))) =
+      make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+}
+
+__device__ __forceinline__ void epi_copy_out(const EpiStage& st, bf16_t* C, long ldc) {
+  __syncthreads();
+  const int ch_per_row = st.bn >> 3;                  // 16-B chunks per tile row (16 for BN=128, 8 for BN=64)
+  for (int q = st.tid; q < 128 * ch_per_row; q += st.nthreads) {
+    const int row = q / ch_per_row, ch = q % ch_per_row;
+    const uint4 v = *(const uint4*)(st.lds + row * (st.bn * 2) + ((ch ^ (row & (ch_per_row - 1))) << 4));
+    *(uint4*)(C + (long)(st.m0 + row) * ldc + st.n0 + ch * 8) = v;
+  }
+  __syncthreads();
+}
+
 template <int ACT, bool DROP, bool RES, int OUT, bool INTERIOR, int FM, int FN>
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[FM][FN], int mb, int nb) {
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[FM][FN], int mb, int nb, const EpiStage& st) {
+  constexpr bool STAGED = INTERIOR && OUT == 0;       // block-uniform: every thread takes the same path
   const uint32_t seed = DROP ? *p.seed : 0u;
   float bias[FN][4];
 #pragma unroll
@@ -70,13 +102,32 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
       }
     }
   }
+  if (STAGED && ACT == 1 && p.pre) {   // first pass: the pre-activation tile (saved for the GELU backward)
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = acc[i][j][r] + bias[j][r];
+          acc[i][j][r] = v[r];
+          }
+        epi_stage_put(st, i, j, v);
+      }
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bias[j][r] = 0.f;
+    epi_copy_out(st, p.pre, p.ldpre);
+  }
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
     const int m = mb + i * 16;
     if (!INTERIOR && m >= p.M) continue;
     const long offc = (long)m * p.ldc + nb + (long)blockIdx.y * p.c_split_stride;
     const bf16_t* aux_row = (ACT == 3) ? p.aux + (long)m * p.ldaux + nb : nullptr;
-    bf16_t* pre_row = (ACT == 1 && p.pre) ? p.pre + (long)m * p.ldpre + nb : nullptr;
+    bf16_t* pre_row = (ACT == 1 && p.pre && !STAGED) ? p.pre + (long)m * p.ldpre + nb : nullptr;
     const bf16_t* res_row = RES ? p.res + (long)m * p.ldres + nb : nullptr;
     const uint32_t idx_row = DROP ? (uint32_t)m * (uint32_t)p.N + (uint32_t)nb : 0u;
 #pragma unroll
@@ -133,9 +184,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
         }
       }
       if (OUT == 0) {
-        bf16_t* c = (bf16_t*)p.C + offc + j * 16;
-        if (full) *(uint2*)c = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
-        else for (int r = 0; r < 4 && n + r < p.N; ++r) c[r] = f2bf(v[r]);
+        if (STAGED) {
+          epi_stage_put(st, i, j, v);
+        } else {
+          bf16_t* c = (bf16_t*)p.C + offc + j * 16;
+          if (full) *(uint2*)c = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+          else for (int r = 0; r < 4 && n + r < p.N; ++r) c[r] = f2bf(v[r]);
+        }
       } else if (OUT == 1) {
         float* c = (float*)p.C + offc + j * 16;
         if (full) *(float4*)c = make_float4(v[0], v[1], v[2], v[3]);
@@ -154,21 +209,22 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
       }
     }
   }
+  if (STAGED) epi_copy_out(st, (bf16_t*)p.C, p.ldc);
 }
 
 template <bool INTERIOR, int FM, int FN>
-__device__ __forceinline__ void gemm_epilogue_dispatch(const GemmParams& p, f32x4 (&acc)[FM][FN], int mb, int nb) {
-  if (p.out_f32 == 3) gemm_epilogue<0, false, false, 3, INTERIOR, FM, FN>(p, acc, mb, nb);
-  else if (p.out_f32 == 2) gemm_epilogue<0, false, false, 2, INTERIOR, FM, FN>(p, acc, mb, nb);
-  else if (p.out_f32 == 1) gemm_epilogue<0, false, false, 1, INTERIOR, FM, FN>(p, acc, mb, nb);
-  else if (p.act == 1) gemm_epilogue<1, false, false, 0, INTERIOR, FM, FN>(p, acc, mb, nb);
-  else if (p.act == 2) gemm_epilogue<2, false, false, 0, INTERIOR, FM, FN>(p, acc, mb, nb);
-  else if (p.act == 3) gemm_epilogue<3, false, false, 0, INTERIOR, FM, FN>(p, acc, mb, nb);
+__device__ __forceinline__ void gemm_epilogue_dispatch(const GemmParams& p, f32x4 (&acc)[FM][FN], int mb, int nb, const EpiStage& st) {
+  if (p.out_f32 == 3) gemm_epilogue<0, false, false, 3, INTERIOR, FM, FN>(p, acc, mb, nb, st);
+  else if (p.out_f32 == 2) gemm_epilogue<0, false, false, 2, INTERIOR, FM, FN>(p, acc, mb, nb, st);
+  else if (p.out_f32 == 1) gemm_epilogue<0, false, false, 1, INTERIOR, FM, FN>(p, acc, mb, nb, st);
+  else if (p.act == 1) gemm_epilogue<1, false, false, 0, INTERIOR, FM, FN>(p, acc, mb, nb, st);
+  else if (p.act == 2) gemm_epilogue<2, false, false, 0, INTERIOR, FM, FN>(p, acc, mb, nb, st);
+  else if (p.act == 3) gemm_epilogue<3, false, false, 0, INTERIOR, FM, FN>(p, acc, mb, nb, st);
   else if (p.res) {
-    if (p.drop_thr) gemm_epilogue<0, true, true, 0, INTERIOR, FM, FN>(p, acc, mb, nb);
-    else gemm_epilogue<0, false, true, 0, INTERIOR, FM, FN>(p, acc, mb, nb);
-  } else if (p.drop_thr) gemm_epilogue<0, true, false, 0, INTERIOR, FM, FN>(p, acc, mb, nb);
-  else gemm_epilogue<0, false, false, 0, INTERIOR, FM, FN>(p, acc, mb, nb);
+    if (p.drop_thr) gemm_epilogue<0, true, true, 0, INTERIOR, FM, FN>(p, acc, mb, nb, st);
+    else gemm_epilogue<0, false, true, 0, INTERIOR, FM, FN>(p, acc, mb, nb, st);
+  } else if (p.drop_thr) gemm_epilogue<0, true, false, 0, INTERIOR, FM, FN>(p, acc, mb, nb, st);
+  else gemm_epilogue<0, false, false, 0, INTERIOR, FM, FN>(p, acc, mb, nb, st);
 }
 
 template <int BM, int BN, int WGM, int WGN>   // WGM x WGN waves per workgroup
@@ -285,8 +341,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_bf16_kernel(const Gemm
     }
     // ---- epilogue: lane holds C[m][n..n+3], m = .. + (lane&15), n = .. + 4*(lane>>4) ----
     const int mb = m0 + wm * WM + (lane & 15), nb = n0 + wn * WN + 4 * (lane >> 4);
-    if (m0 + BM <= p.M && n0 + BN <= p.N) gemm_epilogue_dispatch<true, FM, FN>(p, acc, mb, nb);
-    else gemm_epilogue_dispatch<false, FM, FN>(p, acc, mb, nb);
+    // staging image = the stage buffer the last K tile was read from (the other one is receiving the next tile)
+    const EpiStage st = {smem + buf * STAGE, m0, n0, wm * WM + (lane & 15), wn * WN + 4 * (lane >> 4), tid, NT, BN};
+    if (m0 + BM <= p.M && n0 + BN <= p.N) {
+      __syncthreads();   // every wave finished reading the K-loop operands of this buffer
+      gemm_epilogue_dispatch<true, FM, FN>(p, acc, mb, nb, st);
+    } else {
+      gemm_epilogue_dispatch<false, FM, FN>(p, acc, mb, nb, st);
+    }
     if (!has_next) break;
 #pragma unroll
     for (int i = 0; i < FM; ++i)
@@ -472,8 +534,9 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const GemmParams p, f
     }
   }
   const int mb = m0 + wm * 64 + (lane & 15), nb = n0 + wn * 64 + 4 * (lane >> 4);
-  if (m0 + BM <= p.M && n0 + BN <= p.N) gemm_epilogue_dispatch<true, FM, FN>(p, acc, mb, nb);
-  else gemm_epilogue_dispatch<false, FM, FN>(p, acc, mb, nb);
+  const EpiStage st = {smem, m0, n0, wm * 64 + (lane & 15), wn * 64 + 4 * (lane >> 4), tid, 256, 128};   // fp32 outputs: unused
+  if (m0 + BM <= p.M && n0 + BN <= p.N) gemm_epilogue_dispatch<true, FM, FN>(p, acc, mb, nb, st);
+  else gemm_epilogue_dispatch<false, FM, FN>(p, acc, mb, nb, st);
 }
 
 // ------------------------------------------------------------------------------------
