@@ -228,7 +228,9 @@ __device__ __forceinline__ void gemm_epilogue_dispatch(const GemmParams& p, f32x
 }
 
 template <int BM, int BN, int WGM, int WGN>   // WGM x WGN waves per workgroup
-__global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_bf16_kernel(const GemmParams p) {
+// 2 workgroups per CU (LDS-limited) must also fit the register file: 16 waves/CU = 4 per SIMD for the 8-wave shape
+// (<= 128 VGPRs), 2 per SIMD for the 4-wave shape; the second launch-bound argument is waves per SIMD.
+__global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN >= 8) ? 4 : 2) void gemm_nt_bf16_kernel(const GemmParams p) {
   constexpr int BK = 64;
   constexpr int NT = 64 * WGM * WGN;
   constexpr int WM = BM / WGM, WN = BN / WGN;
@@ -418,7 +420,7 @@ __device__ __forceinline__ void tn_compute_stage(const char* sa, const char* sb,
   }
 }
 
-__global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const GemmParams p, float* __restrict__ colsum) {
+__global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const GemmParams p, float* __restrict__ colsum) {
   constexpr int BM = 128, BN = 128, BR = 64;          // output tile, reduction rows per stage
   constexpr int FM = 4, FN = 4;
   constexpr int IMG = BR * 128 * 2, STAGE = 2 * IMG;  // 16 KiB per operand image
