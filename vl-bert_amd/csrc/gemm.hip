@@ -394,17 +394,17 @@ __device__ __forceinline__ bf16x8 lds_tr_frag(const char* base, int addr_lo, int
   return __builtin_bit_cast(bf16x8, v);
 }
 
-template <bool COLSUM>
-__device__ __forceinline__ void tn_compute_stage(const char* sa, const char* sb, int lane_off, const int (&a_cb)[4], const int (&b_cb)[4],
-                                                 f32x4 (&acc)[4][4], float (&csum)[4]) {
+template <bool COLSUM, int FN>
+__device__ __forceinline__ void tn_compute_stage(const char* sa, const char* sb, int lane_off, const int (&a_cb)[4], const int (&b_cb)[FN],
+                                                 f32x4 (&acc)[4][FN], float (&csum)[4]) {
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
     const int base = lane_off + ks * 32 * 256;
-    bf16x8 af[4], bfr[4];
+    bf16x8 af[4], bfr[FN];
 #pragma unroll
     for (int i = 0; i < 4; ++i) af[i] = lds_tr_frag(sa, base + a_cb[i], base + 4 * 256 + a_cb[i]);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) bfr[j] = lds_tr_frag(sb, base + b_cb[j], base + 4 * 256 + b_cb[j]);
+    for (int j = 0; j < FN; ++j) bfr[j] = lds_tr_frag(sb, base + b_cb[j], base + 4 * 256 + b_cb[j]);
     if (COLSUM) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -415,19 +415,21 @@ __device__ __forceinline__ void tn_compute_stage(const char* sa, const char* sb,
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < FN; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
   }
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const GemmParams p, float* __restrict__ colsum) {
+template <int WGN>   // 2 x WGN waves: WGN = 4 -> 8 waves of 64x32 (two 8-wave workgroups per CU hide LDS/barrier latency)
+__global__ __launch_bounds__(128 * WGN, WGN) void gemm_tn_bf16_kernel(const GemmParams p, float* __restrict__ colsum) {
   constexpr int BM = 128, BN = 128, BR = 64;          // output tile, reduction rows per stage
-  constexpr int FM = 4, FN = 4;
+  constexpr int NT = 128 * WGN, NIT = 1024 / NT;      // threads, 16-B chunks per thread per operand image
+  constexpr int FM = 4, FN = 8 / WGN;
   constexpr int IMG = BR * 128 * 2, STAGE = 2 * IMG;  // 16 KiB per operand image
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WGN, wn = wave % WGN;
   const int nt = p.ntm * p.ntn;
   int t;
   {
@@ -443,12 +445,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const GemmParams p
 
   // staging: chunk P = it*256 + tid -> row = P>>4 (0..63), physical 16-B chunk c = P&15;
   // physical 32-B block c>>1 holds logical block (c>>1) ^ f(row).  Source pointers advance by 64 rows per stage.
-  const bf16_t* a_ptr[4];
-  const bf16_t* b_ptr[4];
-  int s_row[4];
+  const bf16_t* a_ptr[NIT];
+  const bf16_t* b_ptr[NIT];
+  int s_row[NIT];
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int P = it * 256 + tid, row = P >> 4, c = P & 15;
+  for (int it = 0; it < NIT; ++it) {
+    const int P = it * NT + tid, row = P >> 4, c = P & 15;
     const int f = (row & 3) | (((row >> 3) & 1) << 2);
     const int lc = ((((c >> 1) ^ f) << 1) | (c & 1)) * 8;     // logical column offset inside the 128-wide tile
     s_row[it] = row;
@@ -462,9 +464,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const GemmParams p
     char* sa = smem + buf * STAGE;
     char* sb = sa + IMG;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      __builtin_amdgcn_global_load_lds(GLDS_PTR(a_ptr[it]), LDS_PTR(sa + (it * 256 + wave * 64) * 16), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(GLDS_PTR(b_ptr[it]), LDS_PTR(sb + (it * 256 + wave * 64) * 16), 16, 0, 0);
+    for (int it = 0; it < NIT; ++it) {
+      __builtin_amdgcn_global_load_lds(GLDS_PTR(a_ptr[it]), LDS_PTR(sa + (it * NT + wave * 64) * 16), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GLDS_PTR(b_ptr[it]), LDS_PTR(sb + (it * NT + wave * 64) * 16), 16, 0, 0);
       a_ptr[it] += a_step;
       b_ptr[it] += b_step;
     }
@@ -474,12 +476,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const GemmParams p
     char* sb = sa + IMG;
     const int rbase = r_begin + kt * BR;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < NIT; ++it) {
       const bool ok = rbase + s_row[it] < r_end;
       const bf16_t* ga = ok ? a_ptr[it] : zero;
       const bf16_t* gb = ok ? b_ptr[it] : zero;
-      __builtin_amdgcn_global_load_lds(GLDS_PTR(ga), LDS_PTR(sa + (it * 256 + wave * 64) * 16), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(GLDS_PTR(gb), LDS_PTR(sb + (it * 256 + wave * 64) * 16), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GLDS_PTR(ga), LDS_PTR(sa + (it * NT + wave * 64) * 16), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GLDS_PTR(gb), LDS_PTR(sb + (it * NT + wave * 64) * 16), 16, 0, 0);
     }
   };
   auto stage = [&](int buf, int kt) {
@@ -503,7 +505,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const GemmParams p
 #pragma unroll
   for (int i = 0; i < FM; ++i) a_cb[i] = (((wm * 4 + i) ^ fl) << 5);
 #pragma unroll
-  for (int j = 0; j < FN; ++j) b_cb[j] = (((wn * 4 + j) ^ fl) << 5);
+  for (int j = 0; j < FN; ++j) b_cb[j] = (((wn * FN + j) ^ fl) << 5);
 
   // The K loop is instantiated twice OUTSIDE the column-sum branch: selecting the variant inside the loop makes
   // the 64 accumulator registers live across a branch and hipcc then shuttles them VGPR<->AGPR every iteration
@@ -517,7 +519,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const GemmParams p
       if (kt + 1 < ntk) stage(cur ^ 1, kt + 1);
       const char* sa = smem + cur * STAGE;
       const char* sb = sa + IMG;
-      tn_compute_stage<CS>(sa, sb, lane_off, a_cb, b_cb, acc, csum);
+      tn_compute_stage<CS, FN>(sa, sb, lane_off, a_cb, b_cb, acc, csum);
       __syncthreads();
     }
   };
@@ -535,8 +537,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const GemmParams p
       if (g == 0 && m < p.M) atomicAdd(colsum + m, v);
     }
   }
-  const int mb = m0 + wm * 64 + (lane & 15), nb = n0 + wn * 64 + 4 * (lane >> 4);
-  const EpiStage st = {smem, m0, n0, wm * 64 + (lane & 15), wn * 64 + 4 * (lane >> 4), tid, 256, 128};   // fp32 outputs: unused
+  const int mb = m0 + wm * 64 + (lane & 15), nb = n0 + wn * (16 * FN) + 4 * (lane >> 4);
+  const EpiStage st = {smem, m0, n0, wm * 64 + (lane & 15), wn * (16 * FN) + 4 * (lane >> 4), tid, NT, 128};   // fp32 outputs: unused
   if (m0 + BM <= p.M && n0 + BN <= p.N) gemm_epilogue_dispatch<true, FM, FN>(p, acc, mb, nb, st);
   else gemm_epilogue_dispatch<false, FM, FN>(p, acc, mb, nb, st);
 }
@@ -820,10 +822,13 @@ extern "C" int vlb_wgrad_tn_bf16(const void* A, long lda, const void* B, long ld
   constexpr int smem = 2 * 2 * 64 * 128 * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_tn_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)gemm_tn_bf16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)gemm_tn_bf16_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
-  hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3(p.ntm * p.ntn, nsp), dim3(256), smem, stream, p, colsum);
+  static const int waves8 = env_int("VLB_GEMM_TN_WAVES8", 1);
+  if (waves8) hipLaunchKernelGGL(gemm_tn_bf16_kernel<4>, dim3(p.ntm * p.ntn, nsp), dim3(512), smem, stream, p, colsum);
+  else hipLaunchKernelGGL(gemm_tn_bf16_kernel<2>, dim3(p.ntm * p.ntn, nsp), dim3(256), smem, stream, p, colsum);
   VLB_CHECK_LAUNCH("vlb_wgrad_tn_bf16");
   if (nsp > 1) {
     long blocks = ((long)Mo * (ldw / 4) + 255) / 256;
