@@ -2,22 +2,25 @@
 // on gfx950 -- BertSelfAttention (external/pytorch_pretrained_bert/modeling.py:290-319):
 //     scores = Q K^T / sqrt(d) + (1-mask)*-10000 ; P = softmax(scores) ; P = dropout(P) ; ctx = P V
 // The reference materialises [B,h,S,S] scores/probs in HBM (15.7 MB per layer at B=32) and runs
-// softmax/dropout as separate elementwise passes; here one 4-wave workgroup owns one (batch, head):
-// K/V (and, in backward, Q/dO and their transposes) live in LDS, the SxS tile lives only in
-// registers, and the backward recomputes P from the saved row log-sum-exp.
+// softmax/dropout as separate elementwise passes; here one 8-wave workgroup owns one (batch, head):
+// the [S][64] head slices of Q/K/V (and dO in backward) live in LDS as ROW-MAJOR images, the SxS tile
+// lives only in registers, and the backward recomputes P from the saved row log-sum-exp.
 //
-// MFMA (v_mfma_f32_16x16x32_bf16) operand plan -- no register transposes anywhere:
-//  * the score tile is computed TRANSPOSED, S^T = K Q^T, with the 16 K-rows of a tile taken in the
-//    order  key = 32u + 8(i>>2) + 4*half + (i&3).  In the C layout (lane: col = lane&15, rows
-//    4*(lane>>4)+r) a lane then holds, for ONE query, keys 32u + 8g + [0..8) -- exactly the
-//    (col, k = 8g+j) B-operand layout of the next MFMA whose reduction runs over keys
-//    (ctx^T = V^T P^T forward, dQ^T = K^T dS^T backward).
-//  * reductions over QUERIES (dV^T = dO^T P, dK^T = Q^T dS) use the other orientation, S = Q K^T
-//    with permuted Q rows, recomputed by the wave that owns those keys (MFMA is cheap, LDS
-//    round-trips of a 128x128 tile are not).
-//  * "transposed" operands (V^T, K^T, Q^T, dO^T: rows = head dim, 8 contiguous keys/queries per
-//    lane) come from LDS images written once per workgroup with an XOR-16 swizzle; row-major
-//    images use the GEMM's (row>>1)&7 swizzle.  All fragment reads are ds_read_b128.
+// MFMA (v_mfma_f32_16x16x32_bf16) operand plan -- no register transposes, no transposed copies:
+//  * score tiles are computed TRANSPOSED, S^T = K Q^T, with the 16 K-rows of a tile taken in the order
+//    key = 32u + 8(i>>2) + 4*half + (i&3).  In the C layout (lane: col = lane&15, rows 4*(lane>>4)+r) a lane
+//    then holds, for ONE query, keys 32u + 8g + [0..8) -- exactly the (col, k = 8g+j) B-operand layout of the
+//    next MFMA whose reduction runs over keys (ctx^T = V^T P^T forward, dQ^T = K^T dS^T backward).
+//  * reductions over QUERIES (dV^T = dO^T P, dK^T = Q^T dS) use the other orientation, S = Q K^T with permuted
+//    Q rows, recomputed by the wave that owns those keys (MFMA is cheap, LDS round-trips of the tile are not).
+//  * LDS images store sequence row s at row rho(s) = (s & ~31) | bit2(s)<<4 | bits34(s)<<2 | (s&3), i.e. in the
+//    permuted order above: the 16 rows of an A-operand fragment are CONSECUTIVE (bank-conflict-free
+//    ds_read_b128 with the GEMM's (row>>1)&7 chunk swizzle), and the four keys 8g+4h+[0..4) of a transposed
+//    fragment are four consecutive rows too.
+//  * "transposed" operands (V^T, K^T, Q^T, dO^T: lane = head-dim row, 8 consecutive keys/queries) come straight
+//    from the row-major images through the LDS transpose read ds_read_b64_tr_b16 (two per fragment).
+//  * every wave owns a 16-row slice (8 waves x 16 = 128) and plays both roles in backward (dK/dV of its keys, then
+//    dQ of its queries) so the register budget stays under 128 VGPRs and two workgroups fit a CU (LDS 66 KB).
 //  * every output fragment has 4 consecutive head-dim elements per lane -> 8-B bf16 stores.
 // Dropout uses the counter RNG of vlb_common.h keyed on (b, h, q, key): forward and both backward
 // orientations regenerate identical masks, nothing is stored.
@@ -25,44 +28,70 @@
 
 #define ATT_SP 128      // padded sequence length handled by one workgroup
 #define ATT_D 64
-#define TILE_BYTES (ATT_SP * ATT_D * 2)  // 16 KiB, both for [128][64] and [64][128] images
+#define TILE_BYTES (ATT_SP * ATT_D * 2)  // 16 KiB per [128][64] image
+#define ATT_THREADS 512
 
-// ---- LDS address helpers -------------------------------------------------------------------
-// row-major image [128 rows][64]: 128-B rows, 8 x 16-B slots, slot' = slot ^ ((row>>1)&7)
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+// ---- LDS image addressing ------------------------------------------------------------------
+__device__ __forceinline__ int rho(int s) { return (s & ~31) | (((s >> 2) & 1) << 4) | (((s >> 3) & 3) << 2) | (s & 3); }
+// byte address of 16-B chunk `chunk` (0..7) of LDS row `row`
 __device__ __forceinline__ int rm_addr(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
-// transposed image [64 d][128 seq]: 256-B rows, 16 slots, slot' = slot ^ (d&15)
-__device__ __forceinline__ int tr_addr(int d, int chunk) { return d * 256 + ((chunk ^ (d & 15)) << 4); }
-__device__ __forceinline__ int tr_elem_addr(int d, int s) { return d * 256 + ((((s >> 3) ^ (d & 15))) << 4) + (s & 7) * 2; }
-// row of the permuted "A operand" order: tile (blk32, half), fragment row i = lane&15
-__device__ __forceinline__ int perm_row(int blk, int half, int i) { return 32 * blk + 8 * (i >> 2) + 4 * half + (i & 3); }
-
 __device__ __forceinline__ bf16x8 lds_frag(const char* base, int addr) { return *(const bf16x8*)(base + addr); }
 
-// Stage one [S][64] head slice (rows b*S.., row stride ld elements) into LDS.
-//   rm  : row-major image (or null)     tr : transposed image (or null)
-// NT threads, 1024/NT chunks of 16 B each; rows >= S are zero-filled.
-template <int NT>
-__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, long ld, int S, char* rm, char* tr, int tid) {
+// A-operand fragment in permuted order: tile (blk32, half) = LDS rows 32*blk + 16*half + [0..16)
+__device__ __forceinline__ bf16x8 frag_perm(const char* img, int blk, int half, int c, int chunk) {
+  return lds_frag(img, rm_addr(32 * blk + 16 * half + c, chunk));
+}
+// B-operand fragment for 16 consecutive sequence positions s0..s0+15 (lane c -> position s0+c)
+__device__ __forceinline__ bf16x8 frag_nat(const char* img, int s0, int c, int chunk) {
+  return lds_frag(img, rm_addr(rho(s0 + c), chunk));
+}
+// Transposed fragment: lane (i = L, g) <- X[seq 32*blk + 8g + j][d0 + L], j = 0..7   (two ds_read_b64_tr_b16)
+__device__ __forceinline__ bf16x8 frag_tr(const char* img, int blk, int d0, int lane) {
+  const int L = lane & 15, g = lane >> 4;
+  const int b = d0 * 2 + (L & 3) * 8;                    // byte offset of this lane's 4 columns inside the row
+  const int r_lo = 32 * blk + 4 * g + (L >> 2);          // rho of keys 8g+0..3 ; +16 for keys 8g+4..7
+  const int r_hi = r_lo + 16;
+  const int a_lo = r_lo * 128 + ((((b >> 4) ^ ((r_lo >> 1) & 7)) << 4) | (b & 15));
+  const int a_hi = r_hi * 128 + ((((b >> 4) ^ ((r_hi >> 1) & 7)) << 4) | (b & 15));
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(img + a_lo));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(img + a_hi));
+  const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+// Stage one [S][64] head slice (row stride ld elements) into a row-major image at permuted rows; rows >= S zero.
+__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, long ld, int S, char* img, int tid) {
 #pragma unroll
-  for (int it = 0; it < 1024 / NT; ++it) {
-    const int P = it * NT + tid, row = P >> 3, ch = P & 7;
+  for (int it = 0; it < 1024 / ATT_THREADS; ++it) {
+    const int P = it * ATT_THREADS + tid, s = P >> 3, ch = P & 7;
     uint4 v = make_uint4(0, 0, 0, 0);
-    if (row < S) v = *(const uint4*)(g + (long)row * ld + ch * 8);
-    if (rm) *(uint4*)(rm + rm_addr(row, ch)) = v;
-    if (tr) {
-      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        *(bf16_t*)(tr + tr_elem_addr(ch * 8 + 2 * k, row)) = (bf16_t)(w[k] & 0xffffu);
-        *(bf16_t*)(tr + tr_elem_addr(ch * 8 + 2 * k + 1, row)) = (bf16_t)(w[k] >> 16);
-      }
-    }
+    if (s < S) v = *(const uint4*)(g + (long)s * ld + ch * 8);
+    *(uint4*)(img + rm_addr(rho(s), ch)) = v;
   }
 }
 
 __device__ __forceinline__ bf16x8 pack8(const float* v) {
   uint32_t w[4] = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
   return __builtin_bit_cast(bf16x8, *(uint4*)w);
+}
+
+// keep-mask x scale for 8 consecutive element indices base..base+7 (any parity): the RNG yields one 32-bit hash per
+// PAIR of elements (idx>>1), 16 bits each -- 5 hashes cover the (at most) 5 pairs the run of 8 touches.
+__device__ __forceinline__ void drop8(float* v, uint32_t key, uint32_t base, uint32_t thr, float scale) {
+  const uint32_t odd = base & 1u, p0 = base >> 1;
+  uint32_t h[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) h[k] = vlb_hash32((p0 + k) * 0x9E3779B1u + key);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const uint32_t hs = odd ? h[(j + 1) >> 1] : h[j >> 1];              // pair of element base+j
+    const uint32_t member = (j & 1) ^ odd;                               // (base + j) & 1
+    const uint32_t bits = member ? (hs >> 16) : (hs & 0xffffu);
+    v[j] = (bits >= thr) ? v[j] * scale : 0.f;
+  }
 }
 
 struct AttnParams {
@@ -78,12 +107,12 @@ struct AttnParams {
 };
 
 // =============================================================================================
-// forward
+// forward: wave w owns queries 16w .. 16w+15
 // =============================================================================================
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
+__global__ __launch_bounds__(ATT_THREADS, 4) void attn_fwd_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* sK = smem;                                  // row-major [128][64]
-  char* sVt = smem + TILE_BYTES;                    // transposed [64][128]
+  char* sK = smem;
+  char* sV = smem + TILE_BYTES;
   float* sMB = (float*)(smem + 2 * TILE_BYTES);     // [128] additive mask (-inf beyond S)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -92,135 +121,104 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
   const int S = p.S;
   const long ld = 3L * p.H;
   const bf16_t* qbase = p.qkv + (long)b * S * ld + h * ATT_D;
-  stage_tile<256>(qbase + p.H, ld, S, sK, nullptr, tid);
-  stage_tile<256>(qbase + 2 * p.H, ld, S, nullptr, sVt, tid);
+  stage_tile(qbase + p.H, ld, S, sK, tid);
+  stage_tile(qbase + 2 * p.H, ld, S, sV, tid);
   if (tid < ATT_SP) sMB[tid] = (tid < S) ? (1.0f - p.mask[b * S + tid]) * -10000.0f : -INFINITY;
 
-  const int q0 = wave * 32;
-  if (q0 >= S) {  // whole wave beyond the sequence: nothing to compute (still must hit the barrier)
-    __syncthreads();
-    return;
-  }
-  // Q fragments straight from global in B-operand layout: lane (c, g) <- Q[q0+16qb+c][32ds+8g ..+8)
-  bf16x8 qf[2][2];
+  const int q0 = wave * 16;
+  // Q fragment straight from global in B-operand layout: lane (c, g) <- Q[q0+c][32ds+8g ..+8)
+  bf16x8 qf[2];
+  {
+    const int q = min(q0 + c, S - 1);
 #pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
-    const int q = min(q0 + qb * 16 + c, S - 1);
-#pragma unroll
-    for (int ds = 0; ds < 2; ++ds) qf[qb][ds] = *(const bf16x8*)(qbase + (long)q * ld + ds * 32 + g * 8);
+    for (int ds = 0; ds < 2; ++ds) qf[ds] = *(const bf16x8*)(qbase + (long)q * ld + ds * 32 + g * 8);
   }
   __syncthreads();
+  if (q0 >= S) return;
 
   const int U = (S + 31) >> 5;  // key blocks of 32 actually present
-  f32x4 sc[4][2][2];            // [u][half][qb] : S^T tiles
+  f32x4 sc[4][2];               // [u][half] : S^T tiles (keys x this wave's 16 queries)
 #pragma unroll
   for (int u = 0; u < 4; ++u)
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
-      sc[u][hf][0] = sc[u][hf][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      sc[u][hf] = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (u < U) {
 #pragma unroll
-        for (int ds = 0; ds < 2; ++ds) {
-          const bf16x8 kf = lds_frag(sK, rm_addr(perm_row(u, hf, c), ds * 4 + g));
-          sc[u][hf][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[0][ds], sc[u][hf][0], 0, 0, 0);
-          sc[u][hf][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][ds], sc[u][hf][1], 0, 0, 0);
-        }
+        for (int ds = 0; ds < 2; ++ds)
+          sc[u][hf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_perm(sK, u, hf, c, ds * 4 + g), qf[ds], sc[u][hf], 0, 0, 0);
       }
     }
 
-  // softmax over keys for the lane's query (one per qb): lane-local 32 values, then across g
-  const uint32_t seed = (p.drop_thr && p.seed) ? *p.seed : 0u;
-  bf16x8 pf[2][4];  // [qb][u]  P (after dropout) as MFMA operand, k = 8g + (4*half + r)
+  // softmax over keys for the lane's query: lane-local 32 values, then across g
+  float mx = -INFINITY;
 #pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
-    float mx = -INFINITY;
+  for (int u = 0; u < 4; ++u)
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
-      for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = 32 * u + 8 * g + 4 * hf + r;
-          const float v = (u < U) ? sc[u][hf][qb][r] * p.scale + sMB[key] : -INFINITY;
-          sc[u][hf][qb][r] = v;
-          mx = fmaxf(mx, v);
-        }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    float sum = 0.f;
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float e = __expf(sc[u][hf][qb][r] - mx);
-          sc[u][hf][qb][r] = e;
-          sum += e;
-        }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
-    const float inv = 1.0f / sum;
-    const int q = q0 + qb * 16 + c;
-    if (g == 0 && q < S) p.lse[((long)b * p.nh + h) * S + q] = mx + __logf(sum);
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      float v[8];
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[4 * hf + r] = sc[u][hf][qb][r] * inv;
-      if (p.drop_thr) {
-        // idx = ((b*nh+h)*S + q)*S + key ; keys 32u+8g .. +8 are consecutive
-        const uint32_t base = (((uint32_t)(b * p.nh + h) * (uint32_t)S + (uint32_t)min(q, S - 1)) * (uint32_t)S) + 32u * u + 8u * g;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = vlb_keep(seed, p.tag, base + j, p.drop_thr) ? v[j] * p.drop_scale : 0.f;
+      for (int r = 0; r < 4; ++r) {
+        const float v = (u < U) ? sc[u][hf][r] * p.scale + sMB[32 * u + 8 * g + 4 * hf + r] : -INFINITY;
+        sc[u][hf][r] = v;
+        mx = fmaxf(mx, v);
       }
-      pf[qb][u] = pack8(v);
-    }
+  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = __expf(sc[u][hf][r] - mx);
+        sc[u][hf][r] = e;
+        sum += e;
+      }
+  sum += __shfl_xor(sum, 16, 64);
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.0f / sum;
+  const int q = q0 + c;
+  if (g == 0 && q < S) p.lse[((long)b * p.nh + h) * S + q] = mx + __logf(sum);
+
+  const uint32_t seed = (p.drop_thr && p.seed) ? *p.seed : 0u;
+  const uint32_t key = vlb_hash32(seed ^ (p.tag * 0x85ebca6bu + 0x632be5abu));
+  const uint32_t qrow = ((uint32_t)(b * p.nh + h) * (uint32_t)S + (uint32_t)min(q, S - 1)) * (uint32_t)S;
+  bf16x8 pf[4];  // [u]  P (after dropout) as MFMA operand, k = 8g + (4*half + r)
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    float v[8];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[4 * hf + r] = sc[u][hf][r] * inv;
+    if (p.drop_thr) drop8(v, key, qrow + 32u * u + 8u * g, p.drop_thr, p.drop_scale);   // keys 32u+8g..+8 consecutive
+    pf[u] = pack8(v);
   }
 
-  // ctx^T[d][q] = sum_key V^T[d][key] P^T[key][q]
+  // ctx^T[d][q] = sum_key V^T[d][key] P^T[key][q]     (all lanes take part in the wave-wide MFMAs)
+  bf16_t* orow = p.ctx + ((long)b * S + min(q, S - 1)) * p.H + h * ATT_D + 4 * g;
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) {
-    f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      if (u < U) {
-        const bf16x8 vf = lds_frag(sVt, tr_addr(dt * 16 + c, 4 * u + g));
-        o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[0][u], o0, 0, 0, 0);
-        o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[1][u], o1, 0, 0, 0);
-      }
-    }
-    // C layout: col = query c, rows = d = dt*16 + 4g + r
-    const int qa = q0 + c, qb_ = q0 + 16 + c;
-    if (qa < S) {
-      uint2 w = {pack2bf(o0[0], o0[1]), pack2bf(o0[2], o0[3])};
-      *(uint2*)(p.ctx + ((long)b * S + qa) * p.H + h * ATT_D + dt * 16 + 4 * g) = w;
-    }
-    if (qb_ < S) {
-      uint2 w = {pack2bf(o1[0], o1[1]), pack2bf(o1[2], o1[3])};
-      *(uint2*)(p.ctx + ((long)b * S + qb_) * p.H + h * ATT_D + dt * 16 + 4 * g) = w;
-    }
+    for (int u = 0; u < 4; ++u)
+      if (u < U) o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(sV, u, dt * 16, lane), pf[u], o, 0, 0, 0);
+    if (q < S) *(uint2*)(orow + dt * 16) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));   // rows d = dt*16 + 4g + r
   }
 }
 
 // =============================================================================================
-// backward
+// backward: wave w owns sequence positions 16w .. 16w+15, first as KEYS (dK, dV; reductions over all
+// queries), then as QUERIES (dQ; reduction over all keys)
 // =============================================================================================
-// 512 threads: waves 0-3 run orientation N (dK, dV for keys 32w..), waves 4-7 run orientation T (dQ for
-// queries 32w..) CONCURRENTLY -- the two halves are independent, share the LDS images, and give the CU two
-// waves per SIMD to hide LDS latency.
-__global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnParams p) {
+__global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* sQ = smem;                    // row-major
+  char* sQ = smem;
   char* sK = smem + 1 * TILE_BYTES;
   char* sV = smem + 2 * TILE_BYTES;
   char* sdO = smem + 3 * TILE_BYTES;
-  char* sQt = smem + 4 * TILE_BYTES;  // transposed
-  char* sKt = smem + 5 * TILE_BYTES;
-  char* sdOt = smem + 6 * TILE_BYTES;
-  float* sMB = (float*)(smem + 7 * TILE_BYTES);  // [128]
+  float* sMB = (float*)(smem + 4 * TILE_BYTES);  // [128]
   float* sLSE = sMB + ATT_SP;                    // [128]
   float* sD = sLSE + ATT_SP;                     // [128]  rowsum(dO * O)
 
@@ -232,14 +230,14 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnParams p) {
   const bf16_t* qbase = p.qkv + (long)b * S * ld + h * ATT_D;
   const bf16_t* dobase = p.dctx + (long)b * S * p.H + h * ATT_D;
   const bf16_t* obase = p.ctx + (long)b * S * p.H + h * ATT_D;
-  stage_tile<512>(qbase, ld, S, sQ, sQt, tid);
-  stage_tile<512>(qbase + p.H, ld, S, sK, sKt, tid);
-  stage_tile<512>(qbase + 2 * p.H, ld, S, sV, nullptr, tid);
-  stage_tile<512>(dobase, p.H, S, sdO, sdOt, tid);
+  stage_tile(qbase, ld, S, sQ, tid);
+  stage_tile(qbase + p.H, ld, S, sK, tid);
+  stage_tile(qbase + 2 * p.H, ld, S, sV, tid);
+  stage_tile(dobase, p.H, S, sdO, tid);
   // D[q] = sum_d dO[q][d] * O[q][d]   (8 lanes per row, 8 elements each)
 #pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const int P = it * 512 + tid, row = P >> 3, ch = P & 7;
+  for (int it = 0; it < 1024 / ATT_THREADS; ++it) {
+    const int P = it * ATT_THREADS + tid, row = P >> 3, ch = P & 7;
     float d = 0.f;
     if (row < S) {
       const uint4 a = *(const uint4*)(dobase + (long)row * p.H + ch * 8);
@@ -258,160 +256,124 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnParams p) {
   }
   __syncthreads();
 
+  const int w16 = wave * 16;
+  if (w16 >= S) return;
   const uint32_t seed = (p.drop_thr && p.seed) ? *p.seed : 0u;
+  const uint32_t key = vlb_hash32(seed ^ (p.tag * 0x85ebca6bu + 0x632be5abu));
   const uint32_t bh = (uint32_t)(b * p.nh + h);
   const int U = (S + 31) >> 5;
-  const int w32 = (wave & 3) * 32;
-  const bool role_n = wave < 4;
+  const int pos = w16 + c;                          // this lane's key (role N) / query (role T)
+  const bool pos_ok = pos < S;
 
   // ------------------------------------------------------------------------------------------
-  // Orientation N (wave owns keys w32 .. w32+31): dV, dK (reductions over queries)
+  // role N: keys pos;  S[q][key] tiles = Q(perm rows) K^T ;  dV^T = dO^T Pd ,  dK^T = Q^T dS
   // ------------------------------------------------------------------------------------------
-  if (role_n && w32 < S) {
-    bf16x8 kf[2][2], vf[2][2];  // B operands: lane (c,g) <- K/V[key = w32+16kb+c][32ds+8g..]
+  {
+    bf16x8 kf[2], vf[2];  // B operands: lane (c,g) <- K/V[key = w16+c][32ds+8g..]
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+    for (int ds = 0; ds < 2; ++ds) {
+      kf[ds] = frag_nat(sK, w16, c, ds * 4 + g);
+      vf[ds] = frag_nat(sV, w16, c, ds * 4 + g);
+    }
+    f32x4 dv[4], dk[4];
 #pragma unroll
-      for (int ds = 0; ds < 2; ++ds) {
-        kf[kb][ds] = lds_frag(sK, rm_addr(w32 + 16 * kb + c, ds * 4 + g));
-        vf[kb][ds] = lds_frag(sV, rm_addr(w32 + 16 * kb + c, ds * 4 + g));
-      }
-    f32x4 dv[2][4], dk[2][4];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) dv[kb][dt] = dk[kb][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
+    for (int dt = 0; dt < 4; ++dt) dv[dt] = dk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float mb = sMB[pos];
+    const uint32_t kcol = (uint32_t)min(pos, S - 1);
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
       if (v < U) {
-        bf16x8 pd[2], dsf[2];  // per kb: dropped P and dS as operands (col = key c, k = query 8g+j)
+        float pv[8], dsv[8];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-          float pv[8], dsv[8];
+        for (int hf = 0; hf < 2; ++hf) {
+          f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int hf = 0; hf < 2; ++hf) {
-            f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ds = 0; ds < 2; ++ds) {
-              const int a = rm_addr(perm_row(v, hf, c), ds * 4 + g);
-              s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(sQ, a), kf[kb][ds], s, 0, 0, 0);
-              dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(sdO, a), vf[kb][ds], dp, 0, 0, 0);
-            }
-            const int key = w32 + 16 * kb + c;
-            const float mb = sMB[key];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int q = 32 * v + 8 * g + 4 * hf + r;
-              const float pr = __expf(s[r] * p.scale + mb - sLSE[q]);
-              float keepf = 1.f;
-              if (p.drop_thr)
-                keepf = vlb_keep(seed, p.tag, (bh * (uint32_t)S + (uint32_t)min(q, S - 1)) * (uint32_t)S + (uint32_t)key, p.drop_thr)
-                            ? p.drop_scale : 0.f;
-              pv[4 * hf + r] = pr * keepf;
-              dsv[4 * hf + r] = pr * (dp[r] * keepf - sD[q]);
-            }
+          for (int ds = 0; ds < 2; ++ds) {
+            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_perm(sQ, v, hf, c, ds * 4 + g), kf[ds], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_perm(sdO, v, hf, c, ds * 4 + g), vf[ds], dp, 0, 0, 0);
           }
-          pd[kb] = pack8(pv);
-          dsf[kb] = pack8(dsv);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int q = 32 * v + 8 * g + 4 * hf + r;
+            const float pr = __expf(s[r] * p.scale + mb - sLSE[q]);
+            float keepf = 1.f;
+            if (p.drop_thr) {
+              const uint32_t idx = (bh * (uint32_t)S + (uint32_t)min(q, S - 1)) * (uint32_t)S + kcol;
+              const uint32_t hsh = vlb_hash32((idx >> 1) * 0x9E3779B1u + key);
+              keepf = (((idx & 1u) ? (hsh >> 16) : (hsh & 0xffffu)) >= p.drop_thr) ? p.drop_scale : 0.f;
+            }
+            pv[4 * hf + r] = pr * keepf;
+            dsv[4 * hf + r] = pr * (dp[r] * keepf - sD[q]);
+          }
         }
+        const bf16x8 pd = pack8(pv), dsf = pack8(dsv);   // operands: col = key c, k = query 32v + 8g + j
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-          const bf16x8 dot = lds_frag(sdOt, tr_addr(dt * 16 + c, 4 * v + g));
-          const bf16x8 qt = lds_frag(sQt, tr_addr(dt * 16 + c, 4 * v + g));
-#pragma unroll
-          for (int kb = 0; kb < 2; ++kb) {
-            dv[kb][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot, pd[kb], dv[kb][dt], 0, 0, 0);
-            dk[kb][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt, dsf[kb], dk[kb][dt], 0, 0, 0);
-          }
+          dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(sdO, v, dt * 16, lane), pd, dv[dt], 0, 0, 0);
+          dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(sQ, v, dt * 16, lane), dsf, dk[dt], 0, 0, 0);
         }
       }
     }
+    if (pos_ok) {
+      bf16_t* orow = p.dqkv + ((long)b * S + pos) * ld + h * ATT_D + 4 * g;
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      const int key = w32 + 16 * kb + c;
-      if (key < S) {
-        bf16_t* orow = p.dqkv + ((long)b * S + key) * ld + h * ATT_D;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          uint2 wk = {pack2bf(dk[kb][dt][0] * p.scale, dk[kb][dt][1] * p.scale),
-                      pack2bf(dk[kb][dt][2] * p.scale, dk[kb][dt][3] * p.scale)};
-          uint2 wv = {pack2bf(dv[kb][dt][0], dv[kb][dt][1]), pack2bf(dv[kb][dt][2], dv[kb][dt][3])};
-          *(uint2*)(orow + p.H + dt * 16 + 4 * g) = wk;
-          *(uint2*)(orow + 2 * p.H + dt * 16 + 4 * g) = wv;
-        }
+      for (int dt = 0; dt < 4; ++dt) {
+        *(uint2*)(orow + p.H + dt * 16) = make_uint2(pack2bf(dk[dt][0] * p.scale, dk[dt][1] * p.scale),
+                                                     pack2bf(dk[dt][2] * p.scale, dk[dt][3] * p.scale));
+        *(uint2*)(orow + 2 * p.H + dt * 16) = make_uint2(pack2bf(dv[dt][0], dv[dt][1]), pack2bf(dv[dt][2], dv[dt][3]));
       }
     }
   }
 
   // ------------------------------------------------------------------------------------------
-  // Orientation T (wave owns queries w32 .. w32+31): dQ (reduction over keys)
+  // role T: queries pos;  S^T[key][q] tiles = K(perm rows) Q^T ;  dQ^T = K^T dS^T
   // ------------------------------------------------------------------------------------------
-  if (!role_n && w32 < S) {
-    bf16x8 qf[2][2], dof[2][2];  // B operands: lane (c,g) <- Q/dO[q = w32+16qb+c][32ds+8g..]
+  {
+    bf16x8 qf[2], dof[2];  // B operands: lane (c,g) <- Q/dO[q = w16+c][32ds+8g..]
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb)
+    for (int ds = 0; ds < 2; ++ds) {
+      qf[ds] = frag_nat(sQ, w16, c, ds * 4 + g);
+      dof[ds] = frag_nat(sdO, w16, c, ds * 4 + g);
+    }
+    f32x4 dq[4];
 #pragma unroll
-      for (int ds = 0; ds < 2; ++ds) {
-        qf[qb][ds] = lds_frag(sQ, rm_addr(w32 + 16 * qb + c, ds * 4 + g));
-        dof[qb][ds] = lds_frag(sdO, rm_addr(w32 + 16 * qb + c, ds * 4 + g));
-      }
-    f32x4 dq[2][4];
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) dq[qb][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int dt = 0; dt < 4; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float lse = sLSE[pos], dd = sD[pos];
+    const uint32_t qrow = (bh * (uint32_t)S + (uint32_t)min(pos, S - 1)) * (uint32_t)S;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       if (u < U) {
-        bf16x8 dsf[2];
+        float pr[8], dpv[8];
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
-          float dsv[8];
-          const int q = w32 + 16 * qb + c;
-          const float lse = sLSE[q], dd = sD[q];
+        for (int hf = 0; hf < 2; ++hf) {
+          f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int hf = 0; hf < 2; ++hf) {
-            f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ds = 0; ds < 2; ++ds) {
-              const int a = rm_addr(perm_row(u, hf, c), ds * 4 + g);
-              s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(sK, a), qf[qb][ds], s, 0, 0, 0);
-              dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(sV, a), dof[qb][ds], dp, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int key = 32 * u + 8 * g + 4 * hf + r;
-              const float pr = __expf(s[r] * p.scale + sMB[key] - lse);
-              float keepf = 1.f;
-              if (p.drop_thr)
-                keepf = vlb_keep(seed, p.tag, (bh * (uint32_t)S + (uint32_t)min(q, S - 1)) * (uint32_t)S + (uint32_t)key, p.drop_thr)
-                            ? p.drop_scale : 0.f;
-              dsv[4 * hf + r] = pr * (dp[r] * keepf - dd);
-            }
+          for (int ds = 0; ds < 2; ++ds) {
+            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_perm(sK, u, hf, c, ds * 4 + g), qf[ds], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_perm(sV, u, hf, c, ds * 4 + g), dof[ds], dp, 0, 0, 0);
           }
-          dsf[qb] = pack8(dsv);
-        }
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          const bf16x8 kt = lds_frag(sKt, tr_addr(dt * 16 + c, 4 * u + g));
-          dq[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt, dsf[0], dq[0][dt], 0, 0, 0);
-          dq[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt, dsf[1], dq[1][dt], 0, 0, 0);
+          for (int r = 0; r < 4; ++r) {
+            pr[4 * hf + r] = __expf(s[r] * p.scale + sMB[32 * u + 8 * g + 4 * hf + r] - lse);
+            dpv[4 * hf + r] = dp[r];
+          }
         }
+        if (p.drop_thr) drop8(dpv, key, qrow + 32u * u + 8u * g, p.drop_thr, p.drop_scale);   // dP = dPd * keep * scale
+        float dsv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dsv[j] = pr[j] * (dpv[j] - dd);
+        const bf16x8 dsf = pack8(dsv);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+          dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(sK, u, dt * 16, lane), dsf, dq[dt], 0, 0, 0);
       }
     }
+    if (pos_ok) {
+      bf16_t* orow = p.dqkv + ((long)b * S + pos) * ld + h * ATT_D + 4 * g;
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-      const int q = w32 + 16 * qb + c;
-      if (q < S) {
-        bf16_t* orow = p.dqkv + ((long)b * S + q) * ld + h * ATT_D;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          uint2 wq = {pack2bf(dq[qb][dt][0] * p.scale, dq[qb][dt][1] * p.scale),
-                      pack2bf(dq[qb][dt][2] * p.scale, dq[qb][dt][3] * p.scale)};
-          *(uint2*)(orow + dt * 16 + 4 * g) = wq;
-        }
-      }
+      for (int dt = 0; dt < 4; ++dt)
+        *(uint2*)(orow + dt * 16) = make_uint2(pack2bf(dq[dt][0] * p.scale, dq[dt][1] * p.scale),
+                                               pack2bf(dq[dt][2] * p.scale, dq[dt][3] * p.scale));
     }
   }
 }
@@ -435,7 +397,7 @@ extern "C" int vlb_attention_fwd(const void* qkv, const float* mask, void* ctx, 
   p.B = B; p.S = S; p.H = H; p.nh = nh; p.scale = 0.125f;
   p.drop_thr = vlb_drop_thr(drop_p); p.drop_scale = vlb_drop_scale(p.drop_thr); p.seed = seed; p.tag = tag;
   const int smem = 2 * TILE_BYTES + ATT_SP * 4;
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * nh), dim3(256), smem, stream, p);
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * nh), dim3(ATT_THREADS), smem, stream, p);
   VLB_CHECK_LAUNCH("vlb_attention_fwd");
   return VLB_OK;
 }
@@ -452,13 +414,13 @@ extern "C" int vlb_attention_bwd(const void* qkv, const float* mask, const void*
   p.dqkv = (bf16_t*)dqkv;
   p.B = B; p.S = S; p.H = H; p.nh = nh; p.scale = 0.125f;
   p.drop_thr = vlb_drop_thr(drop_p); p.drop_scale = vlb_drop_scale(p.drop_thr); p.seed = seed; p.tag = tag;
-  const int smem = 7 * TILE_BYTES + 3 * ATT_SP * 4;
+  const int smem = 4 * TILE_BYTES + 3 * ATT_SP * 4;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
-  hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * nh), dim3(512), smem, stream, p);
+  hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * nh), dim3(ATT_THREADS), smem, stream, p);
   VLB_CHECK_LAUNCH("vlb_attention_bwd");
   return VLB_OK;
 }
