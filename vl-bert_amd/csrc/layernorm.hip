@@ -90,106 +90,137 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
                                                             uint32_t drop_thr, float drop_scale, const uint32_t* __restrict__ seedp,
                                                             uint32_t tag, float* __restrict__ dx_acc, long ldacc, float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta, int rows, int H) {
-  extern __shared__ __attribute__((aligned(16))) float red[];  // [2][4 waves][H]
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [2][H] block accumulators for dgamma / dbeta
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t seed = (drop_thr && seedp) ? *seedp : 0u;
+  const bool want_gb = (dgamma != nullptr) || (dbeta != nullptr);
+  if (want_gb) {
+    for (int i = threadIdx.x; i < 2 * H; i += 256) red[i] = 0.f;
+    __syncthreads();
+  }
   float gsum[NIT][4], bsum[NIT][4];
 #pragma unroll
   for (int i = 0; i < NIT; ++i)
 #pragma unroll
     for (int k = 0; k < 4; ++k) gsum[i][k] = bsum[i][k] = 0.f;
+  float gam[NIT][4];
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < H) g = *(const float4*)(gamma + c);
+    gam[i][0] = g.x; gam[i][1] = g.y; gam[i][2] = g.z; gam[i][3] = g.w;
+  }
 
-  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
-    Row4<NIT> xr, dyr;
-    load_row_bf16(x + (long)row * ldx, H, lane, xr);
-    if (dy_f32) {
-      const float* d = (const float*)dy_ + (long)row * lddy;
+  // Two rows per wave iteration: both rows' loads are issued before either row's reductions (memory-level
+  // parallelism for an HBM-bound kernel that otherwise waits a full round trip per row).
+  const int step = gridDim.x * 4;
+  for (int row0 = blockIdx.x * 4 + wave; row0 < rows; row0 += 2 * step) {
+    const int row1 = row0 + step;
+    const bool has1 = row1 < rows;
+    Row4<NIT> xr[2], dyr[2];
+    float mean[2], rstd[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int row = t ? (has1 ? row1 : row0) : row0;
+      load_row_bf16(x + (long)row * ldx, H, lane, xr[t]);
+      if (dy_f32) {
+        const float* d = (const float*)dy_ + (long)row * lddy;
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+          const int c = (lane + 64 * i) * 4;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (c < H) v = *(const float4*)(d + c);
+          dyr[t].v[i][0] = v.x; dyr[t].v[i][1] = v.y; dyr[t].v[i][2] = v.z; dyr[t].v[i][3] = v.w;
+        }
+      } else {
+        load_row_bf16((const bf16_t*)dy_ + (long)row * lddy, H, lane, dyr[t]);
+      }
+      mean[t] = stats[2 * (long)row];
+      rstd[t] = stats[2 * (long)row + 1];
+    }
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const float live = (t == 0 || has1) ? 1.f : 0.f;   // the duplicate of row0 must not count twice
 #pragma unroll
       for (int i = 0; i < NIT; ++i) {
         const int c = (lane + 64 * i) * 4;
-        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (c < H) t = *(const float4*)(d + c);
-        dyr.v[i][0] = t.x; dyr.v[i][1] = t.y; dyr.v[i][2] = t.z; dyr.v[i][3] = t.w;
-      }
-    } else {
-      load_row_bf16((const bf16_t*)dy_ + (long)row * lddy, H, lane, dyr);
-    }
-    const float mean = stats[2 * (long)row], rstd = stats[2 * (long)row + 1];
-    float s1 = 0.f, s2 = 0.f;
+        if (c < H) {
 #pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-      const int c = (lane + 64 * i) * 4;
-      if (c < H) {
-        const float4 g = *(const float4*)(gamma + c);
-        const float gg[4] = {g.x, g.y, g.z, g.w};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float xh = (xr.v[i][k] - mean) * rstd;
-          const float dyv = dyr.v[i][k];
-          gsum[i][k] += dyv * xh;
-          bsum[i][k] += dyv;
-          const float gv = dyv * gg[k];
-          s1 += gv;
-          s2 += gv * xh;
-          xr.v[i][k] = xh;   // reuse storage: xhat
-          dyr.v[i][k] = gv;  // reuse storage: g
-        }
-      }
-    }
-    s1 = wave_sum(s1) / (float)H;
-    s2 = wave_sum(s2) / (float)H;
-#pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-      const int c = (lane + 64 * i) * 4;
-      if (c < H) {
-        float o[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) o[k] = rstd * (dyr.v[i][k] - s1 - xr.v[i][k] * s2);
-        if (dx) {
-          uint2 w = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
-          *(uint2*)(dx + (long)row * lddx + c) = w;
-        }
-        if (dx_drop) {
-          float d[4];
-          if (drop_thr) {
-            const uint32_t idx = (uint32_t)row * (uint32_t)H + (uint32_t)c;  // H%4==0 -> idx even
-            const uint32_t h0 = vlb_rng_pair(seed, tag, idx >> 1), h1 = vlb_rng_pair(seed, tag, (idx >> 1) + 1);
-            d[0] = ((h0 & 0xffffu) >= drop_thr) ? o[0] * drop_scale : 0.f;
-            d[1] = ((h0 >> 16) >= drop_thr) ? o[1] * drop_scale : 0.f;
-            d[2] = ((h1 & 0xffffu) >= drop_thr) ? o[2] * drop_scale : 0.f;
-            d[3] = ((h1 >> 16) >= drop_thr) ? o[3] * drop_scale : 0.f;
-          } else {
-            d[0] = o[0]; d[1] = o[1]; d[2] = o[2]; d[3] = o[3];
+          for (int k = 0; k < 4; ++k) {
+            const float xh = (xr[t].v[i][k] - mean[t]) * rstd[t];
+            const float dyv = dyr[t].v[i][k] * live;
+            gsum[i][k] += dyv * xh;
+            bsum[i][k] += dyv;
+            const float gv = dyv * gam[i][k];
+            s1[t] += gv;
+            s2[t] += gv * xh;
+            xr[t].v[i][k] = xh;   // reuse storage: xhat
+            dyr[t].v[i][k] = gv;  // reuse storage: g
           }
-          uint2 w = {pack2bf(d[0], d[1]), pack2bf(d[2], d[3])};
-          *(uint2*)(dx_drop + (long)row * lddd + c) = w;
         }
-        if (dx_acc) {
+      }
+    }
 #pragma unroll
-          for (int k = 0; k < 4; ++k) atomicAdd(dx_acc + (long)row * ldacc + c + k, o[k]);
+    for (int o = 32; o > 0; o >>= 1) {   // four independent butterflies interleaved
+      s1[0] += __shfl_xor(s1[0], o, 64); s2[0] += __shfl_xor(s2[0], o, 64);
+      s1[1] += __shfl_xor(s1[1], o, 64); s2[1] += __shfl_xor(s2[1], o, 64);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      if (t == 1 && !has1) break;
+      const int row = t ? row1 : row0;
+      const float m1 = s1[t] / (float)H, m2 = s2[t] / (float)H;
+#pragma unroll
+      for (int i = 0; i < NIT; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < H) {
+          float o[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) o[k] = rstd[t] * (dyr[t].v[i][k] - m1 - xr[t].v[i][k] * m2);
+          if (dx) *(uint2*)(dx + (long)row * lddx + c) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+          if (dx_drop) {
+            float d[4];
+            if (drop_thr) {
+              const uint32_t idx = (uint32_t)row * (uint32_t)H + (uint32_t)c;  // H%4==0 -> idx even
+              const uint32_t h0 = vlb_rng_pair(seed, tag, idx >> 1), h1 = vlb_rng_pair(seed, tag, (idx >> 1) + 1);
+              d[0] = ((h0 & 0xffffu) >= drop_thr) ? o[0] * drop_scale : 0.f;
+              d[1] = ((h0 >> 16) >= drop_thr) ? o[1] * drop_scale : 0.f;
+              d[2] = ((h1 & 0xffffu) >= drop_thr) ? o[2] * drop_scale : 0.f;
+              d[3] = ((h1 >> 16) >= drop_thr) ? o[3] * drop_scale : 0.f;
+            } else {
+              d[0] = o[0]; d[1] = o[1]; d[2] = o[2]; d[3] = o[3];
+            }
+            *(uint2*)(dx_drop + (long)row * lddd + c) = make_uint2(pack2bf(d[0], d[1]), pack2bf(d[2], d[3]));
+          }
+          if (dx_acc) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) atomicAdd(dx_acc + (long)row * ldacc + c + k, o[k]);
+          }
         }
       }
     }
   }
-  if (!dgamma && !dbeta) return;
-  // cross-wave reduce, one atomic per column per block
+  if (!want_gb) return;
+  // per-wave partials -> LDS atomics -> one global atomic per column per block
   float* rg = red;
-  float* rb = red + 4 * H;
+  float* rb = red + H;
 #pragma unroll
   for (int i = 0; i < NIT; ++i) {
     const int c = (lane + 64 * i) * 4;
     if (c < H) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        rg[wave * H + c + k] = gsum[i][k];
-        rb[wave * H + c + k] = bsum[i][k];
+        atomicAdd(rg + c + k, gsum[i][k]);
+        atomicAdd(rb + c + k, bsum[i][k]);
       }
     }
   }
   __syncthreads();
   for (int c = threadIdx.x; c < H; c += 256) {
-    if (dgamma) atomicAdd(dgamma + c, rg[c] + rg[H + c] + rg[2 * H + c] + rg[3 * H + c]);
-    if (dbeta) atomicAdd(dbeta + c, rb[c] + rb[H + c] + rb[2 * H + c] + rb[3 * H + c]);
+    if (dgamma) atomicAdd(dgamma + c, rg[c]);
+    if (dbeta) atomicAdd(dbeta + c, rb[c]);
   }
 }
 
@@ -216,11 +247,12 @@ extern "C" int vlb_layernorm_bwd(const void* dy, long lddy, int dy_f32, const vo
   VLB_CHECK_ARG(H > 0 && (H % 4) == 0 && H <= 256 * LN_MAX_IT, "vlb_layernorm_bwd: unsupported H=%d", H);
   VLB_CHECK_ARG(!(drop_p > 0.f) || seed, "vlb_layernorm_bwd: dropout needs a device seed pointer");
   VLB_CHECK_ARG((long)rows * H < (1L << 32) || !(drop_p > 0.f), "vlb_layernorm_bwd: dropout index overflow");
-  int blocks = vlb_cdiv(rows, 4);
-  if (blocks > 1024) blocks = 1024;   // 4 workgroups per CU: enough waves in flight for an HBM-bound kernel
+  int blocks = vlb_cdiv(rows, 8);      // a wave handles two rows per iteration
+  if (blocks < 1) blocks = 1;
+  if (blocks > 768) blocks = 768;      // 3 workgroups per CU; fewer blocks = fewer dgamma/dbeta atomics
   const uint32_t thr = vlb_drop_thr(drop_p);
 #define LN_BWD(NIT)                                                                                                            \
-  hipLaunchKernelGGL(layernorm_bwd_kernel<NIT>, dim3(blocks), dim3(256), 2 * 4 * H * sizeof(float), stream, dy, lddy, dy_f32,   \
+  hipLaunchKernelGGL(layernorm_bwd_kernel<NIT>, dim3(blocks), dim3(256), 2 * H * sizeof(float), stream, dy, lddy, dy_f32,       \
                      (const bf16_t*)x, ldx, stats, gamma, (bf16_t*)dx, lddx, (bf16_t*)dx_drop, lddd, thr, vlb_drop_scale(thr),  \
                      seed, tag, dx_acc, ldacc, dgamma, dbeta, rows, H)
   const int nit = vlb_cdiv(H, 256);
