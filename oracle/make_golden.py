@@ -46,6 +46,11 @@ CASES = {
                  vocab_size=512, max_position_embeddings=64, visual_region_classes=40,
                  with_pooler=True, with_rel_loss=True),
         B=2, T=8, R=4, ragged=False, seed=5, pseed=7),
+    # multitask wrapper: 2 auxiliary text-only samples appended (aux text longer than the caption length)
+    "multitask_small": dict(
+        cfg=dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                 vocab_size=512, max_position_embeddings=64, visual_region_classes=50, multitask=True),
+        B=3, T=10, R=5, ragged=True, seed=31, pseed=13, aux=(2, 14)),
     # single head (H=64), longer ragged sequences
     "ragged_1head": dict(
         cfg=dict(hidden_size=64, num_hidden_layers=1, num_attention_heads=1, intermediate_size=128,
@@ -63,6 +68,8 @@ def digest(t):
 def run_case(name, spec):
     RefModel, RefAdamW = ref_import.import_reference()
     cfg = VLBertConfig(**spec["cfg"])
+    if cfg.multitask:
+        RefModel = ref_import.import_reference_multitask()
     vocab_dir = ref_import.make_vocab_dir(os.path.join(tempfile.gettempdir(), "vlb_vocab_%s" % name),
                                           cfg.vocab_size)
     torch.manual_seed(0)
@@ -79,7 +86,10 @@ def run_case(name, spec):
                                  region_classes=cfg.visual_region_classes, seed=spec["seed"],
                                  ragged=spec["ragged"])
     boxes, im_info, text, rel, mlm_labels, mvrc_ops, mvrc_labels = [t.clone() for t in batch]
-    outputs, loss = model(None, boxes, im_info, text, rel, mlm_labels, mvrc_ops, mvrc_labels)
+    aux = ()
+    if cfg.multitask:
+        aux = synthetic.make_aux_text(spec["aux"][0], spec["aux"][1], vocab_size=cfg.vocab_size, seed=spec["seed"])
+    outputs, loss = model(None, boxes, im_info, text, rel, mlm_labels, mvrc_ops, mvrc_labels, *[t.clone() for t in aux])
     model.zero_grad()
     loss.backward()
 
@@ -90,12 +100,21 @@ def run_case(name, spec):
     for k, t in zip(("boxes", "im_info", "text", "relationship_label", "mlm_labels", "mvrc_ops", "mvrc_labels"),
                     batch):
         out["in_" + k] = t.numpy()
-    out["mlm_logits"] = outputs["mlm_logits"].detach().numpy()
-    out["mvrc_logits"] = outputs["mvrc_logits"].detach().numpy()
-    if outputs["relationship_logits"] is not None:
-        out["relationship_logits"] = outputs["relationship_logits"].detach().numpy()
-    for k in ("relationship_loss", "mlm_loss", "mvrc_loss"):
-        out[k] = float(outputs[k])
+    if cfg.multitask:
+        out["in_aux_text"], out["in_aux_mlm_labels"] = aux[0].numpy(), aux[1].numpy()
+        out["aux_shape"] = np.array(spec["aux"])
+        out["mlm_logits_wvc"] = outputs["mlm_logits_wvc"].detach().numpy()
+        out["mlm_logits_aux"] = outputs["mlm_logits_aux"].detach().numpy()
+        out["mvrc_logits"] = outputs["mvrc_logits"].detach().numpy()
+        for k in ("mlm_loss_wvc", "mlm_loss_aux", "mvrc_loss"):
+            out[k] = float(outputs[k])
+    else:
+        out["mlm_logits"] = outputs["mlm_logits"].detach().numpy()
+        out["mvrc_logits"] = outputs["mvrc_logits"].detach().numpy()
+        if outputs["relationship_logits"] is not None:
+            out["relationship_logits"] = outputs["relationship_logits"].detach().numpy()
+        for k in ("relationship_loss", "mlm_loss", "mvrc_loss"):
+            out[k] = float(outputs[k])
     out["loss"] = float(loss)
 
     named = dict(model.named_parameters())   # tied decoder.weight is deduplicated by named_parameters
@@ -123,9 +142,7 @@ def run_case(name, spec):
 
     path = os.path.join(ROOT, "tests", "golden", name + ".npz")
     np.savez_compressed(path, **out)
-    print("%s: loss %.6f (mlm %.6f mvrc %.6f rel %.6f) grad_norm %.6f -> %s (%.1f KB)" % (
-        name, out["loss"], out["mlm_loss"], out["mvrc_loss"], out["relationship_loss"], out["grad_norm"],
-        path, os.path.getsize(path) / 1024))
+    print("%s: loss %.6f grad_norm %.6f -> %s (%.1f KB)" % (name, out["loss"], out["grad_norm"], path, os.path.getsize(path) / 1024))
 
 
 if __name__ == "__main__":

@@ -94,13 +94,19 @@ def import_reference():
     return ResNetVLBERTForPretraining, AdamW
 
 
+def import_reference_multitask():
+    import_reference()
+    from pretrain.modules.resnet_vlbert_for_pretraining_multitask import ResNetVLBERTForPretrainingMultitask
+    return ResNetVLBERTForPretrainingMultitask
+
+
 def make_reference_config(cfg, vocab_dir):
     """Attr-dict in the shape pretrain/function/config.py:52-132 defines, filled
     from an oracle `VLBertConfig` (cfgs/pretrain/base_prec_withouttextonly_4x16G_fp32.yaml)."""
     E = _EasyDict
     return E(dict(
         NETWORK=dict(
-            IMAGE_FEAT_PRECOMPUTED=True, IMAGE_SEMANTIC=False, IMAGE_FROZEN_BN=True,
+            IMAGE_FEAT_PRECOMPUTED=True, IMAGE_SEMANTIC=False, IMAGE_FROZEN_BN=True, MASK_RAW_PIXELS=True,
             IMAGE_FINAL_DIM=cfg.hidden_size, BERT_MODEL_NAME=vocab_dir, BERT_PRETRAINED="",
             BERT_PRETRAINED_EPOCH=0,
             WITH_REL_LOSS=cfg.with_rel_loss, WITH_MLM_LOSS=True, WITH_MVRC_LOSS=True,

@@ -41,6 +41,7 @@ class VLBertConfig:
     obj_downsample_dropout: float = 0.1  # hard-coded p=0.1 (common/fast_rcnn.py:106)
     with_pooler: bool = False
     with_rel_loss: bool = False
+    multitask: bool = False              # ResNetVLBERTForPretrainingMultitask: adds aux_text_visual_embedding
 
     def to_dict(self):
         return asdict(self)
@@ -281,6 +282,60 @@ def pretrain_forward(p, cfg, boxes, im_info, text, relationship_label, mlm_label
     return outputs, rel_loss + mlm_loss + mvrc_loss
 
 
+def pretrain_multitask_forward(p, cfg, boxes, im_info, text, relationship_label, mlm_labels, mvrc_ops, mvrc_labels,
+                               aux_text, aux_mlm_labels, train=False):
+    """pretrain/modules/resnet_vlbert_for_pretraining_multitask.py:96-290 (precomputed features, one auxiliary
+    text-only dataset): the aux captions are appended as extra samples without objects whose text-visual embedding is
+    the learned `aux_text_visual_embedding`; MLM loss is split into the with-visual-content and aux parts."""
+    boxes = boxes.clone()
+    box_mask = boxes[:, :, 0] > -1.5
+    origin_len = boxes.shape[1]
+    max_len = int(box_mask.sum(1).max())
+    box_mask, boxes = box_mask[:, :max_len], boxes[:, :max_len]
+    mvrc_ops, mvrc_labels = mvrc_ops[:, :max_len], mvrc_labels[:, :max_len]
+    feats = boxes[:, :, 4:].clone()
+    feats[mvrc_ops == 1] = p["object_mask_visual_embedding.weight"][0]
+    boxes = torch.cat((boxes[:, :, :4], feats), -1)
+    obj_reps = fast_rcnn_precomputed(p, cfg, boxes, box_mask, im_info, train)
+    B, R = box_mask.shape
+    Ba = aux_text.shape[0]
+    H = cfg.hidden_size
+    ling = p["object_linguistic_embeddings.weight"][0].expand(B, R, -1).clone()
+    ling[mvrc_ops == 1] = p["object_mask_word_embedding.weight"][0]
+    obj_vl = torch.cat((obj_reps, ling), -1)
+
+    T = max(text.shape[1], aux_text.shape[1])
+    text_multi = text.new_zeros((B + Ba, T))
+    text_multi[:B, :text.shape[1]] = text
+    text_multi[B:, :aux_text.shape[1]] = aux_text
+    tv = obj_reps.new_zeros((B + Ba, T, H))
+    tv[:B, :text.shape[1]] = obj_reps[:, 0:1].expand(-1, text.shape[1], -1)
+    tv[B:] = p["aux_text_visual_embedding.weight"][0]
+    obj_vl_multi = obj_vl.new_zeros((B + Ba, R, 2 * H))
+    obj_vl_multi[:B] = obj_vl
+    box_mask_multi = box_mask.new_zeros((B + Ba, R))
+    box_mask_multi[:B] = box_mask
+
+    text_out, obj_out, pooled, seq = vlbert_forward(p, cfg, text_multi, torch.zeros_like(text_multi), tv, text_multi > 0,
+                                                    obj_vl_multi, box_mask_multi, train)
+    mlm_logits = mlm_head(p, text_out)
+    mvrc_logits = mvrc_head(p, obj_out)[:B]
+    labels_multi = mlm_labels.new_full((B + Ba, T), -1)
+    labels_multi[:B, :mlm_labels.shape[1]] = mlm_labels
+    labels_multi[B:, :aux_mlm_labels.shape[1]] = aux_mlm_labels
+    V = mlm_logits.shape[-1]
+    mlm_loss_wvc = F.cross_entropy(mlm_logits[:B].reshape(-1, V), labels_multi[:B].reshape(-1), ignore_index=-1)
+    mlm_loss_aux = F.cross_entropy(mlm_logits[B:].reshape(-1, V), labels_multi[B:].reshape(-1), ignore_index=-1)
+    mvrc_loss = soft_cross_entropy(mvrc_logits.reshape(-1, mvrc_logits.shape[-1]),
+                                   mvrc_labels.reshape(-1, mvrc_logits.shape[-1]))
+    pad = mvrc_logits.new_full((B, origin_len, mvrc_logits.shape[2]), -10000.0)
+    pad[:, :mvrc_logits.shape[1]] = mvrc_logits
+    outputs = {"mlm_logits_wvc": mlm_logits[:B], "mlm_logits_aux": mlm_logits[B:], "mlm_label_wvc": labels_multi[:B],
+               "mlm_label_aux": labels_multi[B:], "mvrc_logits": pad, "mlm_loss_wvc": mlm_loss_wvc,
+               "mlm_loss_aux": mlm_loss_aux, "mvrc_loss": mvrc_loss, "sequence_output": seq}
+    return outputs, mlm_loss_wvc + mlm_loss_aux + mvrc_loss
+
+
 # --------------------------------------------------------------------------- #
 # parameters
 # --------------------------------------------------------------------------- #
@@ -294,6 +349,7 @@ def param_shapes(cfg):
         "object_linguistic_embeddings.weight": (1, H),
         "object_mask_visual_embedding.weight": (1, cfg.visual_feat_dim),
         "object_mask_word_embedding.weight": (1, H),
+        **({"aux_text_visual_embedding.weight": (1, H)} if cfg.multitask else {}),
         "vlbert.word_embeddings.weight": (V, H),
         "vlbert.end_embedding.weight": (1, H),
         "vlbert.position_embeddings.weight": (cfg.max_position_embeddings, H),
@@ -374,7 +430,8 @@ def loss_and_grads(p, cfg, batch, train=False):
     """Forward + autograd backward.  Returns (outputs, loss, {name: grad}, global L2 grad norm)
     -- the tied MLM decoder weight is counted once (SURVEY.md §8c pitfall v)."""
     leaves = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
-    outputs, loss = pretrain_forward(leaves, cfg, *batch, train=train)
+    fwd = pretrain_multitask_forward if len(batch) == 9 else pretrain_forward
+    outputs, loss = fwd(leaves, cfg, *batch, train=train)
     loss.backward()
     grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaves.items()}
     norm = torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values())).item()

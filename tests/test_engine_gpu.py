@@ -25,7 +25,7 @@ def make_engine(cfg, B, T, R, **kw):
                        visual_region_classes=cfg.visual_region_classes,
                        hidden_dropout_prob=cfg.hidden_dropout_prob,
                        attention_probs_dropout_prob=cfg.attention_probs_dropout_prob,
-                       obj_downsample_dropout=cfg.obj_downsample_dropout)
+                       obj_downsample_dropout=cfg.obj_downsample_dropout, multitask=getattr(cfg, "multitask", False))
     return E.PretrainEngine(mc, B, T, R, device="cuda:0", keep_logits=True, **kw)
 
 
@@ -77,7 +77,9 @@ def test_engine_matches_reference_golden(path):
     z = np.load(path, allow_pickle=False)
     kw = {}
     for k, v in zip(z["cfg_keys"], z["cfg_vals"]):
-        kw[str(k)] = bool(v) if str(k).startswith("with_") else int(v)
+        kw[str(k)] = bool(v) if str(k).startswith("with_") or str(k) == "multitask" else int(v)
+    if kw.get("multitask"):
+        pytest.skip("covered by test_engine_multitask_matches_reference")
     if kw.get("with_rel_loss"):
         pytest.skip("relationship head / pooler are not part of the north-star configuration (WITH_REL_LOSS false)")
     cfg = O.VLBertConfig(**kw)
@@ -103,6 +105,55 @@ def test_engine_matches_reference_golden(path):
             continue
         err = np.linalg.norm(smp - ref) / max(np.linalg.norm(ref), 1e-12)
         assert err <= 4e-2, (n, err)
+
+
+def test_engine_multitask_matches_reference():
+    """ResNetVLBERTForPretrainingMultitask: B image-caption samples + B_aux text-only samples in one
+    encoder pass, three losses; against the oracle and the real reference's fixture."""
+    path = os.path.join(os.path.dirname(__file__), "golden", "multitask_small.npz")
+    z = np.load(path, allow_pickle=False)
+    kw = {str(k): (bool(v) if str(k) == "multitask" else int(v)) for k, v in zip(z["cfg_keys"], z["cfg_vals"])}
+    cfg = O.VLBertConfig(**kw)
+    params = O.init_params(cfg, seed=int(z["pseed"]))
+    batch = tuple(torch.from_numpy(z["in_" + k]) for k in
+                  ("boxes", "im_info", "text", "relationship_label", "mlm_labels", "mvrc_ops", "mvrc_labels",
+                   "aux_text", "aux_mlm_labels"))
+    B, T, R = int(z["B"]), int(z["T"]), int(z["R"])
+    Ba, Ta = [int(x) for x in z["aux_shape"]]
+    Tm = max(T, Ta)
+    eng = make_engine(cfg, B, Tm, R, train=False, B_aux=Ba)
+    eng.load_state_dict({k: v.to(dev()) for k, v in params.items()})
+    eng.set_batch(*[t.to(dev()) for t in batch])
+    eng.zero_grad()
+    eng.forward(train=False)
+    eng.backward(train=False)
+    torch.cuda.synchronize()
+    outputs, loss, grads, norm = O.loss_and_grads(params, cfg, batch, train=False)
+    V, C = cfg.vocab_size, cfg.visual_region_classes
+    logits = eng.mlm_logits_copy[:, :V].view(B + Ba, Tm, V)
+    report("multitask mlm_logits_wvc vs REFERENCE", logits[:B, :z["mlm_logits_wvc"].shape[1]], torch.from_numpy(z["mlm_logits_wvc"]), 2e-3, 1e-2)
+    report("multitask mlm_logits_aux vs REFERENCE", logits[B:, :z["mlm_logits_aux"].shape[1]], torch.from_numpy(z["mlm_logits_aux"]), 2e-3, 1e-2)
+    max_len = z["mvrc_logits"].shape[1]
+    report("multitask mvrc_logits vs REFERENCE", eng.mvrc_logits_copy[:, :C].view(B, R, C)[:, :max_len], torch.from_numpy(z["mvrc_logits"]), 2e-3, 1e-2)
+    lv = eng.loss_values()
+    for k in ("mlm_loss_wvc", "mlm_loss_aux", "mvrc_loss"):
+        print("multitask %s: hip %.6f reference %.6f oracle %.6f" % (k, lv[k], float(z[k]), float(outputs[k])))
+        assert abs(lv[k] - float(z[k])) <= 1e-2 * max(1.0, abs(float(z[k])))
+    assert abs(lv["loss"] - float(z["loss"])) <= 1e-2 * float(z["loss"])
+    gn = eng.grad_norm()
+    print("multitask grad_norm: hip %.6f reference %.6f" % (gn, float(z["grad_norm"])))
+    assert abs(gn - float(z["grad_norm"])) <= 1e-2 * float(z["grad_norm"])
+    worst = []
+    for name, g in eng.grads().items():
+        ref = grads[name]
+        if float(ref.norm()) < 1e-6 * norm:
+            continue
+        worst.append((rel_fro(g, ref), name))
+    worst.sort(reverse=True)
+    for e, n in worst[:6]:
+        print("   rel-fro grad err %.3e  %s" % (e, n))
+    assert worst[0][0] <= 5e-2, worst[:5]
+    assert rel_fro(eng.g32["aux_text_visual_embedding.weight"], grads["aux_text_visual_embedding.weight"]) <= 5e-2
 
 
 def test_engine_c1_shape_vs_oracle():
@@ -174,6 +225,46 @@ def test_dropout_training_step_runs_and_is_deterministic():
     assert abs(vals[0][0] - float(eval_loss)) < 0.5   # dropout perturbs, not destroys
 
 
+def _module_config(cfg):
+    class A(dict):
+        __getattr__ = dict.__getitem__
+    return A(NETWORK=A(IMAGE_FEAT_PRECOMPUTED=True, IMAGE_SEMANTIC=False, WITH_REL_LOSS=False, WITH_MLM_LOSS=True,
+                       WITH_MVRC_LOSS=True,
+                       VLBERT=A(hidden_size=cfg.hidden_size, visual_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers,
+                                num_attention_heads=cfg.num_attention_heads, intermediate_size=cfg.intermediate_size,
+                                vocab_size=cfg.vocab_size, max_position_embeddings=cfg.max_position_embeddings,
+                                type_vocab_size=3, visual_region_classes=cfg.visual_region_classes, visual_ln=True,
+                                with_pooler=False, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1,
+                                initializer_range=0.02, visual_scale_text_init=0.0, visual_scale_object_init=0.0)))
+
+
+def test_dropin_multitask_module_matches_reference():
+    """ResNetVLBERTForPretrainingMultitask mirror: forward(image, ..., *aux) contract, output keys, losses, autograd."""
+    M = pkg("pretrain.modules")
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "multitask_small.npz"), allow_pickle=False)
+    kw = {str(k): (bool(v) if str(k) == "multitask" else int(v)) for k, v in zip(z["cfg_keys"], z["cfg_vals"])}
+    cfg = O.VLBertConfig(**kw)
+    net = M.ResNetVLBERTForPretrainingMultitask(_module_config(cfg))
+    ref_names = set(str(n) for n in z["names"])
+    assert "aux_text_visual_embedding.weight" in ref_names
+    assert set(n for n, _ in net.named_parameters()) == ref_names
+    params = O.init_params(cfg, seed=int(z["pseed"]))
+    net.load_state_dict(params)
+    net.eval()
+    batch = tuple(torch.from_numpy(z["in_" + k]).to(dev()) for k in
+                  ("boxes", "im_info", "text", "relationship_label", "mlm_labels", "mvrc_ops", "mvrc_labels",
+                   "aux_text", "aux_mlm_labels"))
+    outputs, loss = net(None, *batch)
+    for k in ("mlm_logits_wvc", "mlm_logits_aux", "mvrc_logits"):
+        report("multitask module %s vs REFERENCE" % k, outputs[k], torch.from_numpy(z[k]), 2e-3, 1e-2)
+    for k in ("mlm_loss_wvc", "mlm_loss_aux", "mvrc_loss"):
+        assert abs(float(outputs[k]) - float(z[k])) <= 1e-2 * max(1.0, abs(float(z[k]))), k
+    assert abs(float(loss) - float(z["loss"])) <= 1e-2 * float(z["loss"])
+    loss.backward()
+    total = torch.nn.utils.clip_grad_norm_(net.parameters(), 1e9)
+    assert abs(float(total) - float(z["grad_norm"])) <= 1e-2 * float(z["grad_norm"])
+
+
 def test_dropin_module_matches_reference_training_loop_contract():
     """The nn.Module mirror: reference constructor/forward signature, state-dict keys, autograd + torch optimizer."""
     M = pkg("pretrain.modules")
@@ -182,16 +273,7 @@ def test_dropin_module_matches_reference_training_loop_contract():
     kw = {str(k): int(v) for k, v in zip(z["cfg_keys"], z["cfg_vals"])}
     cfg = O.VLBertConfig(**kw)
 
-    class A(dict):
-        __getattr__ = dict.__getitem__
-    config = A(NETWORK=A(IMAGE_FEAT_PRECOMPUTED=True, IMAGE_SEMANTIC=False, WITH_REL_LOSS=False, WITH_MLM_LOSS=True,
-                         WITH_MVRC_LOSS=True,
-                         VLBERT=A(hidden_size=cfg.hidden_size, visual_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers,
-                                  num_attention_heads=cfg.num_attention_heads, intermediate_size=cfg.intermediate_size,
-                                  vocab_size=cfg.vocab_size, max_position_embeddings=cfg.max_position_embeddings,
-                                  type_vocab_size=3, visual_region_classes=cfg.visual_region_classes, visual_ln=True,
-                                  with_pooler=False, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1,
-                                  initializer_range=0.02, visual_scale_text_init=0.0, visual_scale_object_init=0.0)))
+    config = _module_config(cfg)
     net = M.ResNetVLBERTForPretraining(config)
     # state-dict contract: exactly the reference's parameter names (+ the tied decoder alias)
     ref_names = set(str(n) for n in z["names"])

@@ -25,11 +25,13 @@ def load_case(path):
     kw = {}
     for k, v in zip(z["cfg_keys"], z["cfg_vals"]):
         k = str(k)
-        kw[k] = bool(v) if k.startswith("with_") else int(v)
+        kw[k] = bool(v) if (k.startswith("with_") or k == "multitask") else int(v)
     cfg = O.VLBertConfig(**kw)
     params = O.init_params(cfg, seed=int(z["pseed"]))
-    batch = tuple(torch.from_numpy(z["in_" + k]) for k in
-                  ("boxes", "im_info", "text", "relationship_label", "mlm_labels", "mvrc_ops", "mvrc_labels"))
+    keys = ("boxes", "im_info", "text", "relationship_label", "mlm_labels", "mvrc_ops", "mvrc_labels")
+    if cfg.multitask:
+        keys += ("aux_text", "aux_mlm_labels")
+    batch = tuple(torch.from_numpy(z["in_" + k]) for k in keys)
     return z, cfg, params, batch
 
 
@@ -46,14 +48,19 @@ def test_oracle_matches_reference(path):
                            region_classes=cfg.visual_region_classes, seed=int(z["seed"]), ragged=bool(z["ragged"]))
     for a, b in zip(regen, batch):
         assert torch.equal(a, b)
+    if cfg.multitask:
+        aux = syn.make_aux_text(int(z["aux_shape"][0]), int(z["aux_shape"][1]), vocab_size=cfg.vocab_size, seed=int(z["seed"]))
+        assert torch.equal(aux[0], batch[7]) and torch.equal(aux[1], batch[8])
 
     outputs, loss, grads, norm = O.loss_and_grads(params, cfg, batch, train=False)
-    np.testing.assert_allclose(outputs["mlm_logits"].detach().numpy(), z["mlm_logits"], rtol=1e-4, atol=2e-5)
-    np.testing.assert_allclose(outputs["mvrc_logits"].detach().numpy(), z["mvrc_logits"], rtol=1e-4, atol=2e-5)
+    logit_keys = ("mlm_logits_wvc", "mlm_logits_aux", "mvrc_logits") if cfg.multitask else ("mlm_logits", "mvrc_logits")
+    loss_keys = ("mlm_loss_wvc", "mlm_loss_aux", "mvrc_loss") if cfg.multitask else ("mlm_loss", "mvrc_loss", "relationship_loss")
+    for k in logit_keys:
+        np.testing.assert_allclose(outputs[k].detach().numpy(), z[k], rtol=1e-4, atol=2e-5, err_msg=k)
     if "relationship_logits" in z:
         np.testing.assert_allclose(outputs["relationship_logits"].detach().numpy(), z["relationship_logits"],
                                    rtol=1e-4, atol=2e-5)
-    for k in ("mlm_loss", "mvrc_loss", "relationship_loss"):
+    for k in loss_keys:
         assert abs(float(outputs[k]) - float(z[k])) <= 1e-5 * max(1.0, abs(float(z[k])))
     assert abs(float(loss) - float(z["loss"])) <= 1e-5 * abs(float(z["loss"]))
     assert abs(norm - float(z["grad_norm"])) <= 1e-5 * float(z["grad_norm"])

@@ -48,6 +48,7 @@ class ModelConfig:
     hidden_dropout_prob: float = 0.1
     attention_probs_dropout_prob: float = 0.1
     obj_downsample_dropout: float = 0.1
+    multitask: bool = False      # ResNetVLBERTForPretrainingMultitask: text-only auxiliary samples (+1 parameter)
 
     def validate(self):
         H, nh = self.hidden_size, self.num_attention_heads
@@ -69,6 +70,8 @@ def param_layout(cfg):
     s["vlbert.end_embedding.weight"] = (1, H)
     s["object_linguistic_embeddings.weight"] = (1, H)
     s["object_mask_word_embedding.weight"] = (1, H)
+    if cfg.multitask:
+        s["aux_text_visual_embedding.weight"] = (1, H)     # resnet_vlbert_for_pretraining_multitask.py:28
     s["object_mask_visual_embedding.weight"] = (1, VIS_DIM)
     s["image_feature_extractor.obj_downsample.1.weight"] = (H, 2 * VIS_DIM)
     s["image_feature_extractor.obj_downsample.1.bias"] = (H,)
@@ -141,9 +144,17 @@ class FlatParams:
 
 class PretrainEngine:
     def __init__(self, cfg, B, T, R, device="cuda:0", train=True, lr=1e-4, weight_decay=1e-4, max_grad_norm=10.0,
-                 betas=(0.9, 0.999), eps=1e-6, seed=1234, grad_accum=1, process_group=None, keep_logits=False, flat=None):
+                 betas=(0.9, 0.999), eps=1e-6, seed=1234, grad_accum=1, process_group=None, keep_logits=False, flat=None,
+                 B_aux=0):
         cfg.validate()
         self.cfg, self.B, self.T, self.R = cfg, B, T, R
+        # multitask: B_aux text-only samples are appended after the B image-caption samples; they have no
+        # objects, their text-visual embedding is the learned aux_text_visual_embedding and their MLM loss is
+        # accounted separately (resnet_vlbert_for_pretraining_multitask.py:96-290).  T = max(caption, aux) length.
+        self.Ba = B_aux
+        if B_aux and not cfg.multitask:
+            raise ValueError("B_aux > 0 needs ModelConfig(multitask=True)")
+        self.Bt = B + B_aux
         self.S = T + R + 1
         if self.S > 128:
             raise ValueError("sequence %d+%d+1 > 128: the fused attention kernel handles S <= 128" % (T, R))
@@ -153,7 +164,7 @@ class PretrainEngine:
         self.pg = process_group
         self.keep_logits = keep_logits
         H, I, V, C, L = cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size, cfg.visual_region_classes, cfg.num_hidden_layers
-        self.M, self.BT, self.BR = B * self.S, B * T, B * R
+        self.M, self.BT, self.BR = self.Bt * self.S, self.Bt * T, B * R
         self.Mp, self.BTp, self.BRp = _ru(self.M, 64), _ru(self.BT, 64), _ru(self.BR, 64)
         self.Vp, self.Cp = _ru(V, 64), _ru(C, 64)
         d = self.dev
@@ -186,33 +197,34 @@ class PretrainEngine:
         # device-resident step state
         self.seed = torch.tensor([seed | 1], dtype=torch.int32, device=d)
         self.adam = torch.tensor([lr, betas[0], betas[1], eps, weight_decay, 0.0, max_grad_norm, 0.0], dtype=F32, device=d)
-        self.losses = zf(4)       # mlm, mvrc, (unused), (unused)
-        self.counts = zf(2)       # n_valid mlm, n_valid mvrc
+        self.losses = zf(4)       # mlm (with visual content), mvrc, mlm (aux text), (unused)
+        self.counts = zf(4)       # n_valid mlm, n_valid mvrc, n_valid mlm aux
 
         # static batch buffers (graph-capturable: the host copies new batches into them)
         self.in_boxes = zf(B, R, 4 + VIS_DIM)
         self.in_im_info = zf(B, 5)
-        self.in_text = torch.zeros((B, T), dtype=torch.int64, device=d)
-        self.in_mlm_labels = torch.zeros((B, T), dtype=torch.int64, device=d)
+        Bt = self.Bt
+        self.in_text = torch.zeros((Bt, T), dtype=torch.int64, device=d)
+        self.in_mlm_labels = torch.full((Bt, T), -1, dtype=torch.int64, device=d)
         self.in_mvrc_ops = torch.zeros((B, R), dtype=torch.int64, device=d)
         self.in_mvrc_labels = zf(B, R, C)
-        self.text_mask = torch.zeros((B, T), dtype=torch.uint8, device=d)
-        self.box_mask = torch.zeros((B, R), dtype=torch.uint8, device=d)
+        self.text_mask = torch.zeros((Bt, T), dtype=torch.uint8, device=d)
+        self.box_mask = torch.zeros((Bt, R), dtype=torch.uint8, device=d)     # aux rows stay 0: no objects
         i32 = lambda *s: torch.zeros(s, dtype=torch.int32, device=d)
-        self.lay = dict(code=i32(B, self.S), text_len=i32(B), nobj=i32(B), text_rows=i32(B, T), obj_rows=i32(B, R),
-                        attn_mask=zf(B, self.S))
+        self.lay = dict(code=i32(Bt, self.S), text_len=i32(Bt), nobj=i32(Bt), text_rows=i32(Bt, T), obj_rows=i32(Bt, R),
+                        attn_mask=zf(Bt, self.S))
 
         # activations
         M, BT, BR, S, nh = self.M, self.BT, self.BR, self.S, cfg.num_attention_heads
         self.a_ds = zb(BR, 2 * VIS_DIM)
         self.obj_reps = zb(BR, H)
         self.objvis, self.st_objvis = zb(BR, H), zf(BR, 2)
-        self.textvis, self.st_textvis = zb(B, H), zf(B, 2)
+        self.textvis, self.st_textvis = zb(Bt, H), zf(Bt, 2)
         self.emb_pre, self.st_emb = zb(M, H), zf(M, 2)
         self.X = [zb(M, H) for _ in range(L + 1)]
         self.QKV = [zb(M, 3 * H) for _ in range(L)]
         self.CTX = [zb(M, H) for _ in range(L)]
-        self.LSE = [zf(B, nh, S) for _ in range(L)]
+        self.LSE = [zf(Bt, nh, S) for _ in range(L)]
         self.Z1, self.ST1, self.Y1 = [zb(M, H) for _ in range(L)], [zf(M, 2) for _ in range(L)], [zb(M, H) for _ in range(L)]
         self.U, self.G = [zb(M, I) for _ in range(L)], [zb(M, I) for _ in range(L)]
         self.Z2, self.ST2 = [zb(M, H) for _ in range(L)], [zf(M, 2) for _ in range(L)]
@@ -237,7 +249,7 @@ class PretrainEngine:
         self.d_mlm_h, self.d_mlm_g, self.d_mlm_u = zb(BT, H), zb(BT, H), zb(BT, H)
         self.d_text_out, self.d_obj_out = zb(BT, H), zb(BR, H)
         self.d_mvrc_u = zb(BR, H)
-        self.d_textvis, self.d_objvis = zf(B, H), zf(BR, H)
+        self.d_textvis, self.d_objvis = zf(Bt, H), zf(BR, H)
         self.d_obj_reps = zf(BR, H)
         self.d_yds = zb(BR, H)
         self.d_afeat = zb(BR, VIS_DIM)
@@ -294,19 +306,29 @@ class PretrainEngine:
     # ------------------------------------------------------------------------------------------
     # batch
     # ------------------------------------------------------------------------------------------
-    def set_batch(self, boxes, im_info, text, relationship_label, mlm_labels, mvrc_ops, mvrc_labels):
+    def set_batch(self, boxes, im_info, text, relationship_label, mlm_labels, mvrc_ops, mvrc_labels, aux_text=None,
+                  aux_mlm_labels=None):
         """Copies a collated batch (pretrain/data/collate_batch.py layout) into the static device buffers
         and derives the masks exactly as resnet_vlbert_for_pretraining.py:106,134 does
         (box_mask = boxes[:,:,0] > -1.5 ; text_mask = text > 0).  `relationship_label` is unused
         (WITH_REL_LOSS false in the north-star configuration)."""
+        B = self.B
         self.in_boxes.copy_(boxes, non_blocking=True)
         self.in_im_info.copy_(im_info, non_blocking=True)
-        self.in_text.copy_(text, non_blocking=True)
-        self.in_mlm_labels.copy_(mlm_labels, non_blocking=True)
+        if self.Ba or text.shape[1] != self.T:
+            self.in_text.zero_()
+            self.in_mlm_labels.fill_(-1)
+        self.in_text[:B, :text.shape[1]].copy_(text, non_blocking=True)
+        self.in_mlm_labels[:B, :mlm_labels.shape[1]].copy_(mlm_labels, non_blocking=True)
+        if self.Ba:
+            if aux_text is None or aux_text.shape[0] != self.Ba:
+                raise ValueError("engine built with B_aux=%d needs aux_text of that many rows" % self.Ba)
+            self.in_text[B:, :aux_text.shape[1]].copy_(aux_text, non_blocking=True)
+            self.in_mlm_labels[B:, :aux_mlm_labels.shape[1]].copy_(aux_mlm_labels, non_blocking=True)
         self.in_mvrc_ops.copy_(mvrc_ops, non_blocking=True)
         self.in_mvrc_labels.copy_(mvrc_labels, non_blocking=True)
         torch.gt(self.in_text, 0, out=self.text_mask.view(torch.bool))
-        torch.gt(self.in_boxes[:, :, 0], -1.5, out=self.box_mask.view(torch.bool))
+        torch.gt(self.in_boxes[:, :, 0], -1.5, out=self.box_mask[:B].view(torch.bool))
 
     # ------------------------------------------------------------------------------------------
     # forward
@@ -321,7 +343,7 @@ class PretrainEngine:
         train = self.train if train is None else train
         if self._weights_dirty:
             self.sync_weights()
-        cfg, B, T, R, S = self.cfg, self.B, self.T, self.R, self.S
+        cfg, B, T, R, S, Bt, Ba = self.cfg, self.B, self.T, self.R, self.S, self.Bt, self.Ba
         H, I, V, C, L, nh = cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size, cfg.visual_region_classes, \
             cfg.num_hidden_layers, cfg.num_attention_heads
         p_h, p_a, p_ds = self._p(train)
@@ -337,13 +359,16 @@ class PretrainEngine:
         ops.layernorm_fwd(self.obj_reps, w32["vlbert.visual_ln_object.weight"], w32["vlbert.visual_ln_object.bias"], self.objvis,
                           self.st_objvis)
         reps0 = self.obj_reps.view(B, R * H)[:, :H]          # obj_reps[:, 0]  (text tags are all 0, :132-135)
-        ops.layernorm_fwd(reps0, w32["vlbert.visual_ln_text.weight"], w32["vlbert.visual_ln_text.bias"], self.textvis,
-                          self.st_textvis)
+        ops.layernorm_fwd(reps0, w32["vlbert.visual_ln_text.weight"], w32["vlbert.visual_ln_text.bias"], self.textvis[:B],
+                          self.st_textvis[:B])
+        if Ba:   # aux text-only samples: every token sees LN(aux_text_visual_embedding) (multitask.py:176)
+            ops.layernorm_fwd(w16["aux_text_visual_embedding.weight"], w32["vlbert.visual_ln_text.weight"],
+                              w32["vlbert.visual_ln_text.bias"], self.textvis[B:], self.st_textvis[B:], rows=Ba, ldx=0)
         ops.embed_fwd(self.lay, self.in_text, None, w16["vlbert.word_embeddings.weight"], w16["vlbert.position_embeddings.weight"],
                       w16["vlbert.token_type_embeddings.weight"], w16["vlbert.end_embedding.weight"], self.textvis, (H, 0),
                       self.objvis, (R * H, H), w16["object_linguistic_embeddings.weight"], (0, 0), self.in_mvrc_ops,
                       w32["vlbert.embedding_LayerNorm.weight"], w32["vlbert.embedding_LayerNorm.bias"], self.emb_pre, self.st_emb,
-                      self.X[0], B, T, R, S, H, drop_p=p_h, seed=seed, tag=TAG_EMBED)
+                      self.X[0], Bt, T, R, S, H, drop_p=p_h, seed=seed, tag=TAG_EMBED)
         # --- encoder -------------------------------------------------------------------------------------
         mask = self.lay["attn_mask"]
         for l in range(L):
@@ -352,7 +377,7 @@ class PretrainEngine:
             wqkv = self.P.view(self.P.w16, p + "attention.self.query.weight", (3 * H, H), span=3)
             bqkv = self.P.view(self.P.master, p + "attention.self.query.bias", (3 * H,), span=3)
             ops.gemm_nt(x, wqkv, self.QKV[l], bias=bqkv)
-            ops.attention_fwd(self.QKV[l], mask, self.CTX[l], self.LSE[l], B, S, H, nh, drop_p=p_a, seed=seed, tag=l * 8 + 0)
+            ops.attention_fwd(self.QKV[l], mask, self.CTX[l], self.LSE[l], Bt, S, H, nh, drop_p=p_a, seed=seed, tag=l * 8 + 0)
             ops.gemm_nt(self.CTX[l], w16[p + "attention.output.dense.weight"], self.Z1[l], bias=w32[p + "attention.output.dense.bias"],
                         res=x, drop_p=p_h, seed=seed, tag=l * 8 + 1)
             ops.layernorm_fwd(self.Z1[l], w32[p + "attention.output.LayerNorm.weight"], w32[p + "attention.output.LayerNorm.bias"],
@@ -366,7 +391,7 @@ class PretrainEngine:
         # --- heads ---------------------------------------------------------------------------------------
         xl = self.X[L]
         ops.gather_rows(xl, self.lay["text_rows"].view(-1), self.text_out)
-        ops.gather_rows(xl, self.lay["obj_rows"].view(-1), self.obj_out)
+        ops.gather_rows(xl, self.lay["obj_rows"].view(-1)[:self.BR], self.obj_out)
         pm = "vlbert.mlm_head.predictions."
         ops.gemm_nt(self.text_out, w16[pm + "transform.dense.weight"], self.mlm_g, bias=w32[pm + "transform.dense.bias"],
                     act=ops.ACT_GELU, pre=self.mlm_u)
@@ -377,11 +402,26 @@ class PretrainEngine:
                     bias=w32["vlbert.mvrc_head.transform.dense.bias"], act=ops.ACT_GELU, pre=self.mvrc_u)
         ops.gemm_nt(self.mvrc_g, w16["vlbert.mvrc_head.region_cls_pred.weight"], self.mvrc_logits[:, :C],
                     bias=w32["vlbert.mvrc_head.region_cls_pred.bias"])
-        # --- losses (forward + d logits in place) ----------------------------------------------------------
-        ops.ce_fwd_bwd(self.mlm_logits, V, self.in_mlm_labels.view(-1), self.counts[0:1], self.losses[0:1], gscale=gscale,
-                       logits_copy=self.mlm_logits_copy)
+        self._losses_fwd_bwd(gscale, True)
+
+    def _losses_fwd_bwd(self, gscale, keep):
+        """Loss values + d(logits) written in place over the logits.  Called again by the nn.Module mirror (keep=False:
+        logits restored from the kept copies, loss slots untouched) when autograd hands down an upstream scale != 1."""
+        B, T, Ba, V, C = self.B, self.T, self.Ba, self.cfg.vocab_size, self.cfg.visual_region_classes
+        if keep:
+            losses, mcopy, vcopy = self.losses, self.mlm_logits_copy, self.mvrc_logits_copy
+        else:
+            self.mlm_logits.copy_(self.mlm_logits_copy)
+            self.mvrc_logits.copy_(self.mvrc_logits_copy)
+            losses, mcopy, vcopy = torch.zeros_like(self.losses), None, None
+        nw = B * T     # rows of the image-caption samples; the aux rows follow and get their own mean (multitask.py:224-246)
+        ops.ce_fwd_bwd(self.mlm_logits[:nw], V, self.in_mlm_labels.view(-1)[:nw], self.counts[0:1], losses[0:1], gscale=gscale,
+                       logits_copy=mcopy[:nw] if mcopy is not None else None)
+        if Ba:
+            ops.ce_fwd_bwd(self.mlm_logits[nw:], V, self.in_mlm_labels.view(-1)[nw:], self.counts[2:3], losses[2:3],
+                           gscale=gscale, logits_copy=mcopy[nw:] if mcopy is not None else None)
         ops.soft_ce_fwd_bwd(self.mvrc_logits, C, self.in_mvrc_labels.view(self.BR, C), self.mvrc_tsum, self.counts[1:2],
-                            self.losses[1:2], gscale=gscale, logits_copy=self.mvrc_logits_copy)
+                            losses[1:2], gscale=gscale, logits_copy=vcopy)
 
     # ------------------------------------------------------------------------------------------
     # backward (explicit; weight gradients are ACCUMULATED into the flat fp32 grad buffer)
@@ -399,7 +439,7 @@ class PretrainEngine:
 
     def backward(self, train=None, on_layer_done=None):
         train = self.train if train is None else train
-        cfg, B, T, R, S = self.cfg, self.B, self.T, self.R, self.S
+        cfg, B, T, R, S, Bt, Ba = self.cfg, self.B, self.T, self.R, self.S, self.Bt, self.Ba
         H, I, V, C, L, nh = cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size, cfg.visual_region_classes, \
             cfg.num_hidden_layers, cfg.num_attention_heads
         p_h, p_a, p_ds = self._p(train)
@@ -425,7 +465,7 @@ class PretrainEngine:
                     g32["vlbert.mvrc_head.transform.dense.bias"], self.tG_br, self.tA_br, BRp)
         ops.gemm_nt(self.d_mvrc_u, wT["vlbert.mvrc_head.transform.dense.weight"], self.d_obj_out)
         dx = self.dXa
-        ops.head_grad_combine(self.d_text_out, self.d_obj_out, self.lay["code"], dx, B, T, R, S, H)
+        ops.head_grad_combine(self.d_text_out, self.d_obj_out, self.lay["code"], dx, Bt, T, R, S, H)
         if on_layer_done:
             on_layer_done("heads")
         # --- encoder, last layer first -------------------------------------------------------------------
@@ -452,7 +492,7 @@ class PretrainEngine:
             self._wgrad(dD1, self.CTX[l], g32[p + "attention.output.dense.weight"], g32[p + "attention.output.dense.bias"],
                         self.tG, self.tA, Mp)
             ops.gemm_nt(dD1, wT[p + "attention.output.dense.weight"], self.dCTX)
-            ops.attention_bwd(self.QKV[l], mask, self.CTX[l], self.LSE[l], self.dCTX, self.dQKV, B, S, H, nh, drop_p=p_a,
+            ops.attention_bwd(self.QKV[l], mask, self.CTX[l], self.LSE[l], self.dCTX, self.dQKV, Bt, S, H, nh, drop_p=p_a,
                               seed=seed, tag=l * 8 + 0)
             gwqkv = self.P.view(self.P.grad, p + "attention.self.query.weight", (3 * H, H), span=3)
             gbqkv = self.P.view(self.P.grad, p + "attention.self.query.bias", (3 * H,), span=3)
@@ -469,15 +509,20 @@ class PretrainEngine:
                       g32["vlbert.word_embeddings.weight"], g32["vlbert.position_embeddings.weight"],
                       g32["vlbert.token_type_embeddings.weight"], g32["vlbert.end_embedding.weight"], g32[pe + "weight"],
                       g32[pe + "bias"], self.d_textvis, (H, 0), self.d_objvis, (R * H, H),
-                      self.P.view(self.P.grad, "object_linguistic_embeddings.weight", (2, H), span=2), (0, 0), B, T, R, S, H,
+                      self.P.view(self.P.grad, "object_linguistic_embeddings.weight", (2, H), span=2), (0, 0), Bt, T, R, S, H,
                       drop_p=p_h, seed=seed, tag=TAG_EMBED)
         ops.layernorm_bwd(self.d_objvis, self.obj_reps, self.st_objvis, w32["vlbert.visual_ln_object.weight"],
                           dx_acc=self.d_obj_reps, dgamma=g32["vlbert.visual_ln_object.weight"],
                           dbeta=g32["vlbert.visual_ln_object.bias"])
         reps0 = self.obj_reps.view(B, R * H)[:, :H]
-        ops.layernorm_bwd(self.d_textvis, reps0, self.st_textvis, w32["vlbert.visual_ln_text.weight"],
+        ops.layernorm_bwd(self.d_textvis[:B], reps0, self.st_textvis[:B], w32["vlbert.visual_ln_text.weight"],
                           dx_acc=self.d_obj_reps.view(B, R * H)[:, :H], dgamma=g32["vlbert.visual_ln_text.weight"],
                           dbeta=g32["vlbert.visual_ln_text.bias"])
+        if Ba:   # all aux samples share one input row: stride-0 input, gradient accumulated into the single parameter row
+            ops.layernorm_bwd(self.d_textvis[B:], w16["aux_text_visual_embedding.weight"], self.st_textvis[B:],
+                              w32["vlbert.visual_ln_text.weight"], dx_acc=g32["aux_text_visual_embedding.weight"],
+                              dgamma=g32["vlbert.visual_ln_text.weight"], dbeta=g32["vlbert.visual_ln_text.bias"],
+                              rows=Ba, ldx=0, ldacc=0)
         ops.relu_bwd_cast(self.d_obj_reps, self.obj_reps, self.d_yds)
         pd = "image_feature_extractor.obj_downsample.1."
         self._wgrad(self.d_yds, self.a_ds, g32[pd + "weight"], g32[pd + "bias"], self.tG_br, self.tA_br, BRp)
@@ -522,7 +567,10 @@ class PretrainEngine:
     # ------------------------------------------------------------------------------------------
     def loss_values(self):
         l = self.losses.cpu()
-        return dict(mlm_loss=float(l[0]), mvrc_loss=float(l[1]), loss=float(l[0] + l[1]))
+        out = dict(mlm_loss=float(l[0]), mvrc_loss=float(l[1]), loss=float(l[0] + l[1] + l[2]))
+        if self.Ba:
+            out.update(mlm_loss_wvc=float(l[0]), mlm_loss_aux=float(l[2]))
+        return out
 
     def grads(self):
         return OrderedDict((k, v.detach().clone()) for k, v in self.g32.items())

@@ -79,21 +79,24 @@ def transpose(x, out, colsum=None):
     return out
 
 
-def layernorm_fwd(x, gamma, beta, y, stats=None, eps=1e-12):
-    rows, H = x.shape
-    _lib.call("vlb_layernorm_fwd", _p(x, BF16), _ld(x), _p(gamma, torch.float32), _p(beta, torch.float32), _p(y, BF16),
+def layernorm_fwd(x, gamma, beta, y, stats=None, eps=1e-12, rows=None, ldx=None):
+    """`rows`/`ldx` override the view-derived values (ldx=0 broadcasts one input row to every output row)."""
+    H = x.shape[1]
+    rows = x.shape[0] if rows is None else rows
+    _lib.call("vlb_layernorm_fwd", _p(x, BF16), _ld(x) if ldx is None else ldx, _p(gamma, torch.float32), _p(beta, torch.float32), _p(y, BF16),
               _ld(y), _p(stats, torch.float32), rows, H, float(eps), _stream())
     return y
 
 
 def layernorm_bwd(dy, x, stats, gamma, dx=None, dx_drop=None, drop_p=0.0, seed=None, tag=0, dx_acc=None, dgamma=None,
-                  dbeta=None):
-    rows, H = x.shape
+                  dbeta=None, rows=None, ldx=None, ldacc=None):
+    H = x.shape[1]
+    rows = x.shape[0] if rows is None else rows
     dy_f32 = 1 if dy.dtype == torch.float32 else 0
-    _lib.call("vlb_layernorm_bwd", _p(dy), _ld(dy), dy_f32, _p(x, BF16), _ld(x), _p(stats, torch.float32),
+    _lib.call("vlb_layernorm_bwd", _p(dy), _ld(dy), dy_f32, _p(x, BF16), _ld(x) if ldx is None else ldx, _p(stats, torch.float32),
               _p(gamma, torch.float32), _p(dx, BF16), _ld(dx), _p(dx_drop, BF16), _ld(dx_drop), float(drop_p), _p(seed),
-              int(tag), _p(dx_acc, torch.float32), _ld(dx_acc), _p(dgamma, torch.float32), _p(dbeta, torch.float32), rows, H,
-              _stream())
+              int(tag), _p(dx_acc, torch.float32), _ld(dx_acc) if ldacc is None else ldacc, _p(dgamma, torch.float32),
+              _p(dbeta, torch.float32), rows, H, _stream())
 
 
 def attention_fwd(qkv, mask, ctx, lse, B, S, H, nh, drop_p=0.0, seed=None, tag=0):

@@ -1,1 +1,1 @@
-from .resnet_vlbert_for_pretraining import ResNetVLBERTForPretraining  # noqa: F401
+from .resnet_vlbert_for_pretraining import ResNetVLBERTForPretraining, ResNetVLBERTForPretrainingMultitask  # noqa: F401

@@ -32,26 +32,22 @@ class _HipLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, module, eng):
         ctx.module, ctx.eng = module, eng
-        return (eng.losses[0] + eng.losses[1]).clone()
+        return (eng.losses[0] + eng.losses[1] + eng.losses[2]).clone()
 
     @staticmethod
     def backward(ctx, grad_out):
         module, eng = ctx.module, ctx.eng
         g = float(grad_out)            # compat path only (the reference's own loop syncs every step, trainer.py:159-171)
         if g != 1.0:                    # re-derive d(logits) with the upstream scale (grad accumulation / loss scaling)
-            V, C = eng.cfg.vocab_size, eng.cfg.visual_region_classes
-            eng.mlm_logits.copy_(eng.mlm_logits_copy)
-            eng.mvrc_logits.copy_(eng.mvrc_logits_copy)
-            scratch = torch.zeros(2, device=eng.dev)
-            ops.ce_fwd_bwd(eng.mlm_logits, V, eng.in_mlm_labels.view(-1), eng.counts[0:1], scratch[0:1], gscale=g)
-            ops.soft_ce_fwd_bwd(eng.mvrc_logits, C, eng.in_mvrc_labels.view(eng.BR, C), eng.mvrc_tsum, eng.counts[1:2],
-                                scratch[1:2], gscale=g)
+            eng._losses_fwd_bwd(g, keep=False)
         module._prepare_grads()
         eng.backward(train=module.training)
         return None, None, None
 
 
 class ResNetVLBERTForPretraining(nn.Module):
+    MULTITASK = False
+
     def __init__(self, config, device=None):
         super().__init__()
         self.config = config
@@ -73,7 +69,7 @@ class ResNetVLBERTForPretraining(nn.Module):
             vocab_size=_get(vl, "vocab_size", 30522), max_position_embeddings=_get(vl, "max_position_embeddings", 512),
             type_vocab_size=_get(vl, "type_vocab_size", 3), visual_region_classes=_get(vl, "visual_region_classes", 1601),
             hidden_dropout_prob=_get(vl, "hidden_dropout_prob", 0.1),
-            attention_probs_dropout_prob=_get(vl, "attention_probs_dropout_prob", 0.1))
+            attention_probs_dropout_prob=_get(vl, "attention_probs_dropout_prob", 0.1), multitask=self.MULTITASK)
         self.cfg.validate()
         if not torch.cuda.is_available():
             raise RuntimeError("ResNetVLBERTForPretraining (HIP) needs an MI355X: there is no CPU fallback")
@@ -136,12 +132,29 @@ class ResNetVLBERTForPretraining(nn.Module):
             for name, t in self.flat.named(self.flat.grad).items():
                 self._pnames[name].grad = t
 
-    def _engine_for(self, B, T, R):
-        key = (B, T, R)
+    def _engine_for(self, B, T, R, B_aux=0):
+        key = (B, T, R, B_aux)
         if key not in self._engines:
-            eng = _engine.PretrainEngine(self.cfg, B, T, R, device=str(self.device_), keep_logits=True, flat=self.flat)
+            eng = _engine.PretrainEngine(self.cfg, B, T, R, device=str(self.device_), keep_logits=True, flat=self.flat,
+                                         B_aux=B_aux)
             self._engines[key] = eng
-        return self._engines[key]
+        eng = self._engines[key]
+        version = self.flat.master._version                       # bumped by any in-place update of a parameter view
+        if getattr(eng, "_synced_version", None) != version:      # optimizer step / load_state_dict: refresh bf16 + W^T copies
+            eng.sync_weights()
+            eng._synced_version = version
+        eng._weights_dirty = False
+        return eng
+
+    def _padded_logits(self, eng, Bt):
+        """fp32 logits re-padded like the reference (:165-167, :195-200) -- needs max_len (host sync)."""
+        V, C = self.cfg.vocab_size, self.cfg.visual_region_classes
+        mlm_logits = torch.empty((Bt, eng.T, V), dtype=torch.float32, device=self.device_)
+        ops.cast_bf16_f32(eng.mlm_logits_copy[:, :V].contiguous(), mlm_logits)
+        mvrc = torch.empty((eng.B, eng.R, C), dtype=torch.float32, device=self.device_)
+        ops.cast_bf16_f32(eng.mvrc_logits_copy[:, :C].contiguous(), mvrc)
+        mvrc[:, int(eng.lay["nobj"].max()):] = -10000.0
+        return mlm_logits, mvrc
 
     # -- forward ------------------------------------------------------------------------------------
     def forward(self, image, boxes, im_info, text, relationship_label, mlm_labels, mvrc_ops, mvrc_labels):
@@ -150,28 +163,57 @@ class ResNetVLBERTForPretraining(nn.Module):
         B, R = boxes.shape[0], boxes.shape[1]
         T = text.shape[1]
         eng = self._engine_for(B, T, R)
-        version = self.flat.master._version                       # bumped by any in-place update of a parameter view
-        if getattr(eng, "_synced_version", None) != version:      # optimizer step / load_state_dict: refresh bf16 + W^T copies
-            eng.sync_weights()
-            eng._synced_version = version
-        eng._weights_dirty = False
         eng.set_batch(boxes, im_info, text, relationship_label, mlm_labels, mvrc_ops, mvrc_labels)
         eng.forward(train=self.training)
         if self.training:
             ops.rng_advance(eng.seed)      # fresh dropout masks next step (the fused optimizer path does this itself)
         loss = _HipLoss.apply(self._pnames["vlbert.word_embeddings.weight"], self, eng)
-        V, C = self.cfg.vocab_size, self.cfg.visual_region_classes
-        # API parity: logits re-padded exactly like the reference (:165-167, :195-200) -- needs max_len (host sync)
-        max_len = int(eng.lay["nobj"].max())
-        mlm_logits = torch.empty((B, T, V), dtype=torch.float32, device=self.device_)
-        ops.cast_bf16_f32(eng.mlm_logits_copy[:, :V].contiguous(), mlm_logits)
-        mvrc = torch.empty((B, R, C), dtype=torch.float32, device=self.device_)
-        ops.cast_bf16_f32(eng.mvrc_logits_copy[:, :C].contiguous(), mvrc)
-        mvrc[:, max_len:] = -10000.0
+        mlm_logits, mvrc = self._padded_logits(eng, B)
         outputs = {
             "relationship_logits": None, "relationship_label": None,
             "mlm_logits": mlm_logits, "mlm_label": mlm_labels,
             "mvrc_logits": mvrc, "mvrc_label": mvrc_labels,
             "relationship_loss": im_info.new_zeros(()), "mlm_loss": eng.losses[0].clone(), "mvrc_loss": eng.losses[1].clone(),
+        }
+        return outputs, loss
+
+
+class ResNetVLBERTForPretrainingMultitask(ResNetVLBERTForPretraining):
+    """Drop-in for pretrain/modules/resnet_vlbert_for_pretraining_multitask.py:14-290: the image-caption batch plus
+    text-only auxiliary batches (`*aux` = text_0, mlm_labels_0, text_1, ...) share ONE encoder pass; the aux samples have no
+    regions and see the learned `aux_text_visual_embedding` as their visual half.  Loss = mlm_wvc + mlm_aux + mvrc."""
+    MULTITASK = True
+
+    def forward(self, image, boxes, im_info, text, relationship_label, mlm_labels, mvrc_ops, mvrc_labels, *aux):
+        if image is not None:
+            raise NotImplementedError("precomputed-feature configuration: pass image=None")
+        if len(aux) == 0 or len(aux) % 2:
+            raise ValueError("aux must be (text, mlm_labels) pairs")
+        texts, labels = aux[0::2], aux[1::2]
+        Ba, Ta = sum(t.shape[0] for t in texts), max(t.shape[1] for t in texts)
+        aux_text = texts[0].new_zeros((Ba, Ta))
+        aux_labels = labels[0].new_full((Ba, Ta), -1)
+        cur = 0
+        for t, l in zip(texts, labels):                          # concat the corpora, right-padded (:106-120)
+            aux_text[cur:cur + t.shape[0], :t.shape[1]] = t
+            aux_labels[cur:cur + t.shape[0], :t.shape[1]] = l
+            cur += t.shape[0]
+        B, R = boxes.shape[0], boxes.shape[1]
+        T = max(text.shape[1], Ta)
+        eng = self._engine_for(B, T, R, Ba)
+        eng.set_batch(boxes, im_info, text, relationship_label, mlm_labels, mvrc_ops, mvrc_labels, aux_text, aux_labels)
+        eng.forward(train=self.training)
+        if self.training:
+            ops.rng_advance(eng.seed)
+        loss = _HipLoss.apply(self._pnames["vlbert.word_embeddings.weight"], self, eng)
+        mlm_logits, mvrc = self._padded_logits(eng, B + Ba)
+        lab = eng.in_mlm_labels
+        outputs = {
+            "relationship_logits": None, "relationship_label": None,
+            "mlm_logits_wvc": mlm_logits[:B], "mlm_label_wvc": lab[:B].clone(),
+            "mlm_logits_aux": mlm_logits[B:], "mlm_label_aux": lab[B:].clone(),
+            "mvrc_logits": mvrc, "mvrc_label": mvrc_labels,
+            "relationship_loss": im_info.new_zeros(()), "mlm_loss_wvc": eng.losses[0].clone(),
+            "mlm_loss_aux": eng.losses[2].clone(), "mvrc_loss": eng.losses[1].clone(),
         }
         return outputs, loss

@@ -58,3 +58,24 @@ def make_batch(B, T, R, vocab_size=30522, region_classes=1601, feat_dim=2048, se
     lab = lab * (mvrc_ops == 1).unsqueeze(-1).float()
     relationship_label = torch.ones((B,), dtype=torch.long)
     return (boxes.float(), im_info, text, relationship_label, mlm_labels, mvrc_ops, lab.float())
+
+
+def make_aux_text(Ba, Ta, vocab_size=30522, seed=0, ragged=True, mlm_prob=0.15):
+    """Text-only auxiliary batch of the multitask pre-training (GeneralCorpus, pretrain/data/datasets/general_corpus.py):
+    (aux_text [Ba,Ta] i64 pad 0, aux_mlm_labels [Ba,Ta] i64 pad -1)."""
+    g = torch.Generator().manual_seed(seed + 7919)
+    lo = min(1000, vocab_size // 2)
+    text = torch.randint(lo, vocab_size, (Ba, Ta), generator=g)
+    text[:, 0] = CLS % vocab_size
+    tlen = torch.randint(max(3, Ta // 2), Ta + 1, (Ba,), generator=g) if ragged else torch.full((Ba,), Ta)
+    tlen[0] = Ta
+    ar = torch.arange(Ta).unsqueeze(0)
+    text[ar == (tlen.unsqueeze(1) - 1)] = SEP % vocab_size
+    pad = ar >= tlen.unsqueeze(1)
+    text[pad] = 0
+    labels = torch.full((Ba, Ta), -1, dtype=torch.long)
+    pick = (torch.rand((Ba, Ta), generator=g) < mlm_prob) & ~pad & (ar > 0) & (ar < tlen.unsqueeze(1) - 1)
+    pick[:, 1] = True
+    labels[pick] = text[pick]
+    text[pick] = MASK % vocab_size
+    return text, labels
