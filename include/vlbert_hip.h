@@ -40,7 +40,8 @@ int vlb_device_info(int device, char* name, int cap);
 /* ---- GEMM -----------------------------------------------------------------------------------
  * C[M,N] (+)= A[M,K] * B[N,K]^T, bf16 operands, fp32 accumulate, fused epilogue
  *   v = acc (+ bias[n]) ; act: 0 none | 1 erf-GELU (pre-activation optionally stored to `pre`)
- *   | 2 ReLU | 3 v *= gelu'(aux[m,n]) ; dropout(v) ; v += res[m,n] ;
+ *   | 2 ReLU | 3 v *= gelu'(aux[m,n]) | 4 erf-GELU with gelu'(v) stored to `pre` (the derivative shares the
+ *   forward's exponential, so the backward epilogue becomes act 5) | 5 v *= aux[m,n] ; dropout(v) ; v += res[m,n] ;
  *   out_mode: 0 store bf16 | 1 store fp32 | 2 fp32 atomicAdd with split-K (`splitk` <= 0: auto) |
  *             3 fp32 accumulate C += (single K pass, no atomics).
  * K % 64 == 0; lda/ldb % 8 == 0; ldc/ldaux/ldpre/ldres % 4 == 0.
@@ -75,14 +76,17 @@ int vlb_transpose_bf16(const void* in, long ldi, void* out, long ldo, int R, int
 /* ---- BertLayerNorm (modeling.py:222-235; eps inside the sqrt, biased variance) --------------
  * fwd: y = LN(x)*gamma+beta, stats[row] = (mean, rstd) (may be NULL).
  * bwd: dx (bf16), dx_drop = dropout-masked dx (bf16, gradient entering the preceding dense layer),
- *      dx_acc (fp32 atomicAdd) -- any may be NULL; dgamma/dbeta are accumulated (fp32 atomics).
- *      dy is bf16, or fp32 when dy_f32 != 0. */
+ *      dx_acc (fp32 atomicAdd) -- any may be NULL; dgamma/dbeta are accumulated.
+ *      dy is bf16, or fp32 when dy_f32 != 0; H % 8 == 0, row strides % 8 == 0.
+ *      workspace: NULL (dgamma/dbeta by direct fp32 atomics) or vlb_layernorm_bwd_workspace_floats(H) floats of
+ *      scratch (per-workgroup partial sums stored without atomics, column-summed by a 2nd kernel). */
 int vlb_layernorm_fwd(const void* x, long ldx, const float* gamma, const float* beta, void* y, long ldy, float* stats,
                       int rows, int H, float eps, vlb_stream_t stream);
 int vlb_layernorm_bwd(const void* dy, long lddy, int dy_f32, const void* x, long ldx, const float* stats,
                       const float* gamma, void* dx, long lddx, void* dx_drop, long lddd, float drop_p,
                       const uint32_t* seed, uint32_t tag, float* dx_acc, long ldacc, float* dgamma, float* dbeta,
-                      int rows, int H, vlb_stream_t stream);
+                      float* workspace, int rows, int H, vlb_stream_t stream);
+long vlb_layernorm_bwd_workspace_floats(int H);
 
 /* ---- BertSelfAttention core (modeling.py:300-316) --------------------------------------------
  * qkv [B*S, 3H] bf16 (q | k | v, head h at columns h*64), mask [B,S] fp32 (1 attend / 0 -> -10000),
@@ -142,6 +146,8 @@ int vlb_relu_bwd_cast(const float* g, const void* y, void* out, long n, vlb_stre
 /* out = dg * gelu'(u)  (bf16; backward of the erf-GELU at modeling.py:114-120 where it is not fused
  * into a GEMM epilogue: BertPredictionHeadTransform, modeling.py:448-452) */
 int vlb_dgelu_mul(const void* dg, const void* u, void* out, long n, vlb_stream_t stream);
+/* out = a * b (bf16, n % 8 == 0): the same backward when the forward GEMM saved gelu'(u) (act 4) instead of u */
+int vlb_mul_bf16(const void* a, const void* b, void* out, long n, vlb_stream_t stream);
 
 /* ---- losses, forward+backward fused, gradient written in place over the bf16 logits ----------
  * MLM: F.cross_entropy(ignore_index=-1) (resnet_vlbert_for_pretraining.py:176-178).

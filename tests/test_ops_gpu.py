@@ -68,6 +68,16 @@ def test_gemm_epilogues(ops):
     cdf = 0.5 * (1 + torch.erf(aux / math.sqrt(2)))
     pdf = torch.exp(-0.5 * aux * aux) / math.sqrt(2 * math.pi)
     report("gemm dgelu", C, acc * (cdf + aux * pdf), 1e-3, 1e-2)
+    # gelu with the derivative saved for backward (act 4) and the plain-multiply backward epilogue (act 5)
+    ops.gemm_nt(Ag, Bg, C, bias=bg, act=ops.ACT_GELU_D, pre=pre)
+    cdf_u = 0.5 * (1 + torch.erf(u / math.sqrt(2)))
+    report("gemm gelu_d out", C, u * cdf_u, 1e-3, 1e-2)
+    report("gemm gelu_d deriv", pre, cdf_u + u * torch.exp(-0.5 * u * u) / math.sqrt(2 * math.pi), 1e-3, 1e-2)
+    ops.gemm_nt(Ag, Bg, C, act=ops.ACT_MULAUX, aux=to_gpu_bf16(aux))
+    report("gemm mulaux", C, acc * bf(aux), 1e-3, 1e-2)
+    out = torch.empty_like(C)
+    ops.mul_bf16(to_gpu_bf16(res), to_gpu_bf16(aux), out)
+    report("mul_bf16", out, bf(res) * bf(aux), 1e-3, 1e-2)
     # bias + residual
     ops.gemm_nt(Ag, Bg, C, bias=bg, res=to_gpu_bf16(res))
     report("gemm bias+res", C, u + res, 1e-3, 1e-2)
@@ -171,7 +181,7 @@ def test_gemm_dropout_and_ln_mask_agree(ops):
 
 
 # ------------------------------------------------------------------------------------ LayerNorm
-@pytest.mark.parametrize("rows,H", [(7, 128), (333, 768), (64, 1024), (5, 64)])
+@pytest.mark.parametrize("rows,H", [(7, 128), (333, 768), (64, 1024), (5, 64), (7001, 768)])
 def test_layernorm_fwd_bwd(ops, rows, H):
     x = bf(rnd(rows, H, seed=20, scale=2.0) + 0.5)
     g = torch.Generator().manual_seed(21)
@@ -194,6 +204,12 @@ def test_layernorm_fwd_bwd(ops, rows, H):
     db = torch.zeros(H, device=dev())
     acc = torch.zeros((rows, H), device=dev())
     ops.layernorm_bwd(to_gpu_bf16(dy), to_gpu_bf16(x), stats, gamma.to(dev()), dx=dx, dx_acc=acc, dgamma=dg, dbeta=db)
+    # workspace path for the parameter gradients (per-workgroup partial vectors + column-sum kernel; accumulates on top)
+    ws = torch.full((ops.ln_bwd_workspace_floats(H),), 7.0, device=dev())
+    dg2, db2 = dg.clone(), db.clone()
+    ops.layernorm_bwd(to_gpu_bf16(dy), to_gpu_bf16(x), stats, gamma.to(dev()), dgamma=dg2, dbeta=db2, workspace=ws)
+    report("ln bwd dgamma via workspace", dg2, 2 * dg.cpu(), 2e-3, 2e-3)
+    report("ln bwd dbeta via workspace", db2, 2 * db.cpu(), 2e-3, 2e-3)
     report("ln bwd dx", dx, xr.grad, 1e-3, 1e-2)
     report("ln bwd dx_acc(fp32)", acc, xr.grad, 1e-4, 1e-4)
     report("ln bwd dgamma", dg, gr.grad, 1e-3, 1e-4)

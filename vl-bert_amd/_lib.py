@@ -20,7 +20,7 @@ _SIGS = {
     "vlb_wgrad_nt_bf16": "plplpliiipls",
     "vlb_wgrad_tn_bf16": "plplpliiippls",
     "vlb_layernorm_fwd": "plppplpiifs",
-    "vlb_layernorm_bwd": "pliplppplplfpuplppiis",
+    "vlb_layernorm_bwd": "pliplppplplfpuplpppiis",
     "vlb_attention_fwd": "ppppiiiifpus",
     "vlb_attention_bwd": "ppppppiiiifpus",
     "vlb_seq_layout": "ppiiiipppppps",
@@ -32,6 +32,7 @@ _SIGS = {
     "vlb_head_grad_combine": "ppppiiiiis",
     "vlb_relu_bwd_cast": "pppls",
     "vlb_dgelu_mul": "pppls",
+    "vlb_mul_bf16": "pppls",
     "vlb_ce_fwd_bwd": "pliippfppls",
     "vlb_soft_ce_fwd_bwd": "pliiplppfppls",
     "vlb_sumsq_f32": "plps",
@@ -69,6 +70,8 @@ def load():
     lib.vlb_device_info.argtypes = [_I, ctypes.c_char_p, _I]
     lib.vlb_wgrad_workspace_floats.restype = _L
     lib.vlb_wgrad_workspace_floats.argtypes = [_I, _I, _I]
+    lib.vlb_layernorm_bwd_workspace_floats.restype = _L
+    lib.vlb_layernorm_bwd_workspace_floats.argtypes = [_I]
     for name, sig in _SIGS.items():
         fn = getattr(lib, name)
         fn.restype = _I
@@ -78,7 +81,8 @@ def load():
 
 
 def exported_names():
-    return ["vlb_last_error", "vlb_version", "vlb_device_info", "vlb_wgrad_workspace_floats"] + sorted(_SIGS)
+    return ["vlb_last_error", "vlb_version", "vlb_device_info", "vlb_wgrad_workspace_floats",
+            "vlb_layernorm_bwd_workspace_floats"] + sorted(_SIGS)
 
 
 def call(name, *args):

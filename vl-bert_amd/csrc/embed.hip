@@ -279,36 +279,45 @@ struct EmbedBwdParams {
   uint32_t drop_thr; float drop_scale; const uint32_t* seed; uint32_t tag;
 };
 
-__global__ __launch_bounds__(256) void embed_bwd_kernel(const EmbedBwdParams p) {
+// NIT = ceil(H/256) (register footprint follows H); 512 threads = 8 waves per sample.  The block-shared accumulators
+// live in LDS in LANE-MAJOR order (element (i,k) of lane l at (i*4+k)*64 + l): ds_add_f32 from consecutive lanes hits
+// consecutive banks (the natural column order puts lanes 4 floats apart = 8-way conflicts on every one of the
+// ~40 LDS atomics a row issues).  LWD = NIT*256 floats per accumulator.
+template <int NIT>
+__global__ __launch_bounds__(512) void embed_bwd_kernel(const EmbedBwdParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int LWD = NIT * 256;
   const int H = p.H;
-  float* l_type = lds;             // [3][H]
-  float* l_objpos = lds + 3 * H;   // [H]
-  float* l_tv = lds + 4 * H;       // [H]
-  float* l_tab = lds + 5 * H;      // [2][H]
-  float* l_g = lds + 7 * H;        // [H]
-  float* l_b = lds + 8 * H;        // [H]
-  for (int i = threadIdx.x; i < 9 * H; i += 256) lds[i] = 0.f;
+  float* l_type = lds;               // [3][LWD]
+  float* l_objpos = lds + 3 * LWD;   // [LWD]
+  float* l_tv = lds + 4 * LWD;       // [LWD]
+  float* l_tab = lds + 5 * LWD;      // [2][LWD]
+  float* l_g = lds + 7 * LWD;        // [LWD]
+  float* l_b = lds + 8 * LWD;        // [LWD]
+  float* rowbuf = lds + 9 * LWD + (threadIdx.x >> 6) * LWD;   // per-wave row image (natural column order)
+  for (int i = threadIdx.x; i < 9 * LWD; i += blockDim.x) lds[i] = 0.f;
   __syncthreads();
-  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
   const int tl = p.text_len[b];
   const uint32_t seed = (p.drop_thr && p.seed) ? *p.seed : 0u;
-  float gs[EMB_MAX_IT][4], bs[EMB_MAX_IT][4];
+  float gs[NIT][4], bs[NIT][4];
 #pragma unroll
-  for (int i = 0; i < EMB_MAX_IT; ++i)
+  for (int i = 0; i < NIT; ++i)
 #pragma unroll
     for (int k = 0; k < 4; ++k) gs[i][k] = bs[i][k] = 0.f;
 
-  for (int s = wave; s < p.S; s += 4) {
+  for (int s = wave; s < p.S; s += nwave) {
     const long row = (long)b * p.S + s;
     const int code = p.code[row], kind = code >> 16, idx = code & 0xffff;
     if (kind == KIND_PAD) continue;  // pad rows never reach a loss; their dy is exactly zero
     const float mean = p.stats[2 * row], rstd = p.stats[2 * row + 1];
-    float xh[EMB_MAX_IT][4], g[EMB_MAX_IT][4];
+    float xh[NIT][4], g[NIT][4];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < EMB_MAX_IT; ++i) {
+    for (int i = 0; i < NIT; ++i) {
       const int c = (lane + 64 * i) * 4;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) xh[i][k] = g[i][k] = 0.f;
       if (c < H) {
         const uint2 wx = *(const uint2*)(p.pre + row * H + c);
         const uint2 wd = *(const uint2*)(p.dy + row * H + c);
@@ -356,7 +365,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const EmbedBwdParams p) 
       type_id = 2;
       pos_lds = true;
       if (p.d_obj_vis) v_dst = p.d_obj_vis + b * p.dov_sb + idx * p.dov_sr;
-      if (p.obj_ling_idx) l_ling = l_tab + (p.obj_ling_idx[b * p.R + idx] ? H : 0);
+      if (p.obj_ling_idx) l_ling = l_tab + (p.obj_ling_idx[b * p.R + idx] ? LWD : 0);
     } else {  // END
       type_id = 2;
       pos_id = tl + 1;
@@ -366,49 +375,61 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const EmbedBwdParams p) 
     float* pos_dst = p.d_pos + (long)pos_id * H;
     float* dl_dst = (kind == KIND_OBJ && !p.obj_ling_idx && p.d_obj_ling) ? p.d_obj_ling + b * p.dol_sb + idx * p.dol_sr : nullptr;
 #pragma unroll
-    for (int i = 0; i < EMB_MAX_IT; ++i) {
+    for (int i = 0; i < NIT; ++i) {
       const int c = (lane + 64 * i) * 4;
       if (c < H) {
+        float d[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const float d = rstd * (g[i][k] - s1 - xh[i][k] * s2);
-          atomicAdd(l_type + type_id * H + c + k, d);
-          if (pos_lds) atomicAdd(l_objpos + c + k, d);
-          else atomicAdd(pos_dst + c + k, d);
-          if (w_dst) atomicAdd(w_dst + c + k, d);
-          if (tv_lds) atomicAdd(l_tv + c + k, d);
-          if (l_ling) atomicAdd(l_ling + c + k, d);
-          if (v_dst) v_dst[c + k] = d;
-          if (dl_dst) dl_dst[c + k] = d;
+          d[k] = rstd * (g[i][k] - s1 - xh[i][k] * s2);
+          const int q = (i * 4 + k) * 64 + lane;
+          atomicAdd(l_type + type_id * LWD + q, d[k]);
+          if (pos_lds) atomicAdd(l_objpos + q, d[k]);
+          if (tv_lds) atomicAdd(l_tv + q, d[k]);
+          if (l_ling) atomicAdd(l_ling + q, d[k]);
         }
+        if (v_dst) *(float4*)(v_dst + c) = make_float4(d[0], d[1], d[2], d[3]);
+        if (dl_dst) *(float4*)(dl_dst + c) = make_float4(d[0], d[1], d[2], d[3]);
+        *(float4*)(rowbuf + c) = make_float4(d[0], d[1], d[2], d[3]);
       }
     }
-  }
-#pragma unroll
-  for (int i = 0; i < EMB_MAX_IT; ++i) {
-    const int c = (lane + 64 * i) * 4;
-    if (c < H) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        atomicAdd(l_g + c + k, gs[i][k]);
-        atomicAdd(l_b + c + k, bs[i][k]);
+    // Global atomics go out LANE-CONSECUTIVE (64 lanes = 256 contiguous bytes per instruction) through a per-wave LDS
+    // row image: in the 4-floats-per-lane register layout one atomic instruction touches every 4th float of 1 KB,
+    // i.e. four times the cache-line requests for the same data, and this kernel is bound by exactly that rate.
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the row image is wave-private: order the writes above before the reads below
+    __builtin_amdgcn_wave_barrier();
+    if (!pos_lds || w_dst) {
+      for (int c = lane; c < H; c += 64) {
+        const float d = rowbuf[c];
+        if (!pos_lds) atomicAdd(pos_dst + c, d);
+        if (w_dst) atomicAdd(w_dst + c, d);
       }
     }
+    __builtin_amdgcn_wave_barrier();
   }
+#pragma unroll
+  for (int i = 0; i < NIT; ++i)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int q = (i * 4 + k) * 64 + lane;
+      atomicAdd(l_g + q, gs[i][k]);
+      atomicAdd(l_b + q, bs[i][k]);
+    }
   __syncthreads();
   const int pos_obj = min(tl, p.P - 1);
-  for (int c = threadIdx.x; c < H; c += 256) {
+  for (int c = threadIdx.x; c < H; c += blockDim.x) {
+    const int chunk = c >> 2, q = (((chunk >> 6) * 4 + (c & 3)) << 6) + (chunk & 63);   // natural column -> lane-major slot
 #pragma unroll
     for (int t = 0; t < 3; ++t)
-      if (l_type[t * H + c] != 0.f) atomicAdd(p.d_type + t * H + c, l_type[t * H + c]);
-    if (l_objpos[c] != 0.f) atomicAdd(p.d_pos + (long)pos_obj * H + c, l_objpos[c]);
-    if (p.d_text_vis && p.dtv_st == 0) p.d_text_vis[b * p.dtv_sb + c] = l_tv[c];
+      if (l_type[t * LWD + q] != 0.f) atomicAdd(p.d_type + t * H + c, l_type[t * LWD + q]);
+    if (l_objpos[q] != 0.f) atomicAdd(p.d_pos + (long)pos_obj * H + c, l_objpos[q]);
+    if (p.d_text_vis && p.dtv_st == 0) p.d_text_vis[b * p.dtv_sb + c] = l_tv[q];
     if (p.obj_ling_idx && p.d_obj_ling) {
-      if (l_tab[c] != 0.f) atomicAdd(p.d_obj_ling + c, l_tab[c]);
-      if (l_tab[H + c] != 0.f) atomicAdd(p.d_obj_ling + H + c, l_tab[H + c]);
+      if (l_tab[q] != 0.f) atomicAdd(p.d_obj_ling + c, l_tab[q]);
+      if (l_tab[LWD + q] != 0.f) atomicAdd(p.d_obj_ling + H + c, l_tab[LWD + q]);
     }
-    atomicAdd(p.d_gamma + c, l_g[c]);
-    atomicAdd(p.d_beta + c, l_b[c]);
+    atomicAdd(p.d_gamma + c, l_g[q]);
+    atomicAdd(p.d_beta + c, l_b[q]);
   }
 }
 
@@ -471,6 +492,19 @@ __global__ void dgelu_mul_kernel(const bf16_t* __restrict__ dg, const bf16_t* __
   uint2 o = {pack2bf(bflo(a.x) * dgelu_f(bflo(b.x)), bfhi(a.x) * dgelu_f(bfhi(b.x))),
              pack2bf(bflo(a.y) * dgelu_f(bflo(b.y)), bfhi(a.y) * dgelu_f(bfhi(b.y)))};
   *(uint2*)(out + i) = o;
+}
+
+// out = a * b  (GELU backward with the derivative tile saved by the forward GEMM epilogue, act 4)
+__global__ void mul_bf16_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, bf16_t* __restrict__ out, long n) {
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 8;
+  if (i >= n) return;
+  const uint4 x = *(const uint4*)(a + i), y = *(const uint4*)(b + i);
+  uint4 o;
+  o.x = pack2bf(bflo(x.x) * bflo(y.x), bfhi(x.x) * bfhi(y.x));
+  o.y = pack2bf(bflo(x.y) * bflo(y.y), bfhi(x.y) * bfhi(y.y));
+  o.z = pack2bf(bflo(x.z) * bflo(y.z), bfhi(x.z) * bfhi(y.z));
+  o.w = pack2bf(bflo(x.w) * bflo(y.w), bfhi(x.w) * bfhi(y.w));
+  *(uint4*)(out + i) = o;
 }
 
 // ---------------------------------------------------------------------------------- C ABI
@@ -553,7 +587,18 @@ extern "C" int vlb_embed_bwd(const void* dy, const void* pre, const float* stats
   p.d_obj_ling = d_obj_ling; p.dol_sb = dol_sb; p.dol_sr = dol_sr;
   p.B = B; p.T = T; p.R = R; p.S = S; p.H = H; p.V = V; p.P = P;
   p.drop_thr = vlb_drop_thr(drop_p); p.drop_scale = vlb_drop_scale(p.drop_thr); p.seed = seed; p.tag = tag;
-  hipLaunchKernelGGL(embed_bwd_kernel, dim3(B), dim3(256), 9 * H * sizeof(float), stream, p);
+  VLB_CHECK_ARG((dtv_sb % 4) == 0 && (dtv_st % 4) == 0 && (dov_sb % 4) == 0 && (dov_sr % 4) == 0 && (dol_sb % 4) == 0 &&
+                    (dol_sr % 4) == 0, "vlb_embed_bwd: output strides must be multiples of 4 floats");
+  const int nit = vlb_cdiv(H, 256);
+#define EMB_BWD(NIT)                                                                                                         \
+  do {                                                                                                                       \
+    constexpr int smem = (9 + 8) * NIT * 256 * (int)sizeof(float);                                                                 \
+    if (smem > 48 * 1024)                                                                                                    \
+      (void)hipFuncSetAttribute((const void*)embed_bwd_kernel<NIT>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);       \
+    hipLaunchKernelGGL(embed_bwd_kernel<NIT>, dim3(B), dim3(512), smem, stream, p);                                          \
+  } while (0)
+  if (nit <= 1) EMB_BWD(1); else if (nit == 2) EMB_BWD(2); else if (nit == 3) EMB_BWD(3); else if (nit == 4) EMB_BWD(4); else EMB_BWD(8);
+#undef EMB_BWD
   VLB_CHECK_LAUNCH("vlb_embed_bwd");
   return VLB_OK;
 }
@@ -589,5 +634,14 @@ extern "C" int vlb_dgelu_mul(const void* dg, const void* u, void* out, long n, h
   hipLaunchKernelGGL(dgelu_mul_kernel, dim3(vlb_cdiv(n / 4, 256)), dim3(256), 0, stream, (const bf16_t*)dg, (const bf16_t*)u,
                      (bf16_t*)out, n);
   VLB_CHECK_LAUNCH("vlb_dgelu_mul");
+  return VLB_OK;
+}
+
+extern "C" int vlb_mul_bf16(const void* a, const void* b, void* out, long n, hipStream_t stream) {
+  if (n <= 0) return VLB_OK;
+  VLB_CHECK_ARG((n % 8) == 0, "vlb_mul_bf16: n must be a multiple of 8");
+  hipLaunchKernelGGL(mul_bf16_kernel, dim3(vlb_cdiv(n / 8, 256)), dim3(256), 0, stream, (const bf16_t*)a, (const bf16_t*)b,
+                     (bf16_t*)out, n);
+  VLB_CHECK_LAUNCH("vlb_mul_bf16");
   return VLB_OK;
 }

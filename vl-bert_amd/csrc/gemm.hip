@@ -18,7 +18,7 @@
 //     each lane ends up with 4 consecutive output columns of one row -> 8-B bf16 / 16-B
 //     fp32 epilogue accesses;
 //   * fused epilogue: +bias, erf-GELU (optionally also storing the pre-activation), ReLU,
-//     x gelu'(aux) (GELU backward), dropout (counter RNG), +residual, bf16 or fp32 store,
+//     x gelu'(aux) or x aux (GELU backward), dropout (counter RNG), +residual, bf16 or fp32 store,
 //     fp32 atomic accumulation for split-K weight gradients.
 #include <stdlib.h>
 
@@ -32,7 +32,7 @@ struct GemmParams {
   int M, N, K;
   int k_per_split;           // K range handled by one blockIdx.y slice (multiple of 64)
   const float* bias;         // [N] fp32 or null
-  int act;                   // 0 none, 1 gelu, 2 relu, 3 multiply by gelu'(aux)
+  int act;                   // 0 none, 1 gelu, 2 relu, 3 multiply by gelu'(aux), 4 gelu with gelu'(x) -> pre, 5 multiply by aux
   const bf16_t* aux; long ldaux;
   bf16_t* pre; long ldpre;   // optional pre-activation output (act==1)
   const bf16_t* res; long ldres;
@@ -102,7 +102,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
       }
     }
   }
-  if (STAGED && ACT == 1 && p.pre) {   // first pass: the pre-activation tile (saved for the GELU backward)
+  constexpr bool GELU = (ACT == 1 || ACT == 4);
+  const bool pre_staged = STAGED && GELU && p.pre;
+  if (pre_staged) {   // first pass: the tile saved for the GELU backward (pre-activation, or gelu'(x) for act 4)
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -111,9 +113,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           v[r] = acc[i][j][r] + bias[j][r];
-          acc[i][j][r] = v[r];
+          if (ACT == 4) {   // acc <- gelu(x) (final), v <- gelu'(x)
+            float g, d;
+            gelu_both(v[r], g, d);
+            acc[i][j][r] = g;
+            v[r] = d;
+          } else {
+            acc[i][j][r] = v[r];
           }
+        }
         epi_stage_put(st, i, j, v);
+        if (ACT == 4) asm volatile("" ::: "memory");   // keep the scheduler from interleaving all 32 gelu_both chains (it spilled)
       }
 #pragma unroll
     for (int j = 0; j < FN; ++j)
@@ -126,8 +136,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
     const int m = mb + i * 16;
     if (!INTERIOR && m >= p.M) continue;
     const long offc = (long)m * p.ldc + nb + (long)blockIdx.y * p.c_split_stride;
-    const bf16_t* aux_row = (ACT == 3) ? p.aux + (long)m * p.ldaux + nb : nullptr;
-    bf16_t* pre_row = (ACT == 1 && p.pre && !STAGED) ? p.pre + (long)m * p.ldpre + nb : nullptr;
+    const bf16_t* aux_row = (ACT == 3 || ACT == 5) ? p.aux + (long)m * p.ldaux + nb : nullptr;
+    bf16_t* pre_row = (GELU && p.pre && !STAGED) ? p.pre + (long)m * p.ldpre + nb : nullptr;
     const bf16_t* res_row = RES ? p.res + (long)m * p.ldres + nb : nullptr;
     const uint32_t idx_row = DROP ? (uint32_t)m * (uint32_t)p.N + (uint32_t)nb : 0u;
 #pragma unroll
@@ -138,18 +148,35 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bias[j][r];
-      if (ACT == 1) {
-        if (pre_row) {
-          bf16_t* q = pre_row + j * 16;
-          if (full) *(uint2*)q = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
-          else for (int r = 0; r < 4 && n + r < p.N; ++r) q[r] = f2bf(v[r]);
-        }
+      if (GELU) {
+        if (ACT == 4) {
+          if (!pre_staged) {             // (staged: gelu already applied in the first pass)
+            float d[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
+            for (int r = 0; r < 4; ++r) {
+              float g;
+              gelu_both(v[r], g, d[r]);
+              v[r] = g;
+            }
+            if (pre_row) {
+              bf16_t* q = pre_row + j * 16;
+              if (full) *(uint2*)q = make_uint2(pack2bf(d[0], d[1]), pack2bf(d[2], d[3]));
+              else for (int r = 0; r < 4 && n + r < p.N; ++r) q[r] = f2bf(d[r]);
+            }
+          }
+        } else {
+          if (pre_row) {
+            bf16_t* q = pre_row + j * 16;
+            if (full) *(uint2*)q = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+            else for (int r = 0; r < 4 && n + r < p.N; ++r) q[r] = f2bf(v[r]);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
+        }
       } else if (ACT == 2) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-      } else if (ACT == 3) {
+      } else if (ACT == 3 || ACT == 5) {
         float u[4] = {0.f, 0.f, 0.f, 0.f};
         const bf16_t* q = aux_row + j * 16;
         if (full) {
@@ -159,7 +186,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
           for (int r = 0; r < 4 && n + r < p.N; ++r) u[r] = bf2f(q[r]);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] *= dgelu_f(u[r]);
+        for (int r = 0; r < 4; ++r) v[r] *= (ACT == 3) ? dgelu_f(u[r]) : u[r];
       }
       if (DROP) {
         const uint32_t idx = idx_row + j * 16;
@@ -220,6 +247,8 @@ __device__ __forceinline__ void gemm_epilogue_dispatch(const GemmParams& p, f32x
   else if (p.act == 1) gemm_epilogue<1, false, false, 0, INTERIOR, FM, FN>(p, acc, mb, nb, st);
   else if (p.act == 2) gemm_epilogue<2, false, false, 0, INTERIOR, FM, FN>(p, acc, mb, nb, st);
   else if (p.act == 3) gemm_epilogue<3, false, false, 0, INTERIOR, FM, FN>(p, acc, mb, nb, st);
+  else if (p.act == 4) gemm_epilogue<4, false, false, 0, INTERIOR, FM, FN>(p, acc, mb, nb, st);
+  else if (p.act == 5) gemm_epilogue<5, false, false, 0, INTERIOR, FM, FN>(p, acc, mb, nb, st);
   else if (p.res) {
     if (p.drop_thr) gemm_epilogue<0, true, true, 0, INTERIOR, FM, FN>(p, acc, mb, nb, st);
     else gemm_epilogue<0, false, true, 0, INTERIOR, FM, FN>(p, acc, mb, nb, st);
@@ -227,7 +256,20 @@ __device__ __forceinline__ void gemm_epilogue_dispatch(const GemmParams& p, f32x
   else gemm_epilogue<0, false, false, 0, INTERIOR, FM, FN>(p, acc, mb, nb, st);
 }
 
-template <int BM, int BN, int WGM, int WGN>   // WGM x WGN waves per workgroup
+// EPI >= 0 compiles ONE fused epilogue into the kernel (bf16 output): 0 bias | 1 bias+GELU, gelu'(x) -> pre |
+// 2 x aux | 3 bias+dropout+residual | 4 bias+residual | 5 bias+ReLU.  With every variant inlined behind the runtime
+// dispatch (EPI = -1, kept for the fp32 / rarely used forms) the 128-register 8-wave kernel spilled in its epilogues.
+template <int EPI, bool INTERIOR, int FM, int FN>
+__device__ __forceinline__ void gemm_epilogue_select(const GemmParams& p, f32x4 (&acc)[FM][FN], int mb, int nb, const EpiStage& st) {
+  if constexpr (EPI < 0) {
+    gemm_epilogue_dispatch<INTERIOR, FM, FN>(p, acc, mb, nb, st);
+  } else {
+    constexpr int ACT = EPI == 1 ? 4 : EPI == 2 ? 5 : EPI == 5 ? 2 : 0;
+    gemm_epilogue<ACT, EPI == 3, EPI == 3 || EPI == 4, 0, INTERIOR, FM, FN>(p, acc, mb, nb, st);
+  }
+}
+
+template <int BM, int BN, int WGM, int WGN, int EPI>   // WGM x WGN waves per workgroup
 // 2 workgroups per CU (LDS-limited) must also fit the register file: 16 waves/CU = 4 per SIMD for the 8-wave shape
 // (<= 128 VGPRs), 2 per SIMD for the 4-wave shape; the second launch-bound argument is waves per SIMD.
 __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN >= 8) ? 4 : 2) void gemm_nt_bf16_kernel(const GemmParams p) {
@@ -248,7 +290,6 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN >= 8) ? 4 : 2) void gemm
   const int k_end = min(p.K, k_begin + p.k_per_split);
   const int ntk = (k_end - k_begin) / BK;
   if ((int)blockIdx.x >= nt || ntk <= 0) return;
-
   // PERSISTENT workgroups: block b walks work items w = b, b+grid, b+2*grid, ... (grid = resident workgroups).
   // w -> tile: XCD-aware (block b runs on XCD b%8 and grid%8==0, so w%8 is this block's XCD: each XCD owns a
   // contiguous run of tiles, bijective for any tile count), then visited in groups of `tile_group` tile-rows,
@@ -347,9 +388,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN >= 8) ? 4 : 2) void gemm
     const EpiStage st = {smem + buf * STAGE, m0, n0, wm * WM + (lane & 15), wn * WN + 4 * (lane >> 4), tid, NT, BN};
     if (m0 + BM <= p.M && n0 + BN <= p.N) {
       __syncthreads();   // every wave finished reading the K-loop operands of this buffer
-      gemm_epilogue_dispatch<true, FM, FN>(p, acc, mb, nb, st);
+      gemm_epilogue_select<EPI, true, FM, FN>(p, acc, mb, nb, st);
     } else {
-      gemm_epilogue_dispatch<false, FM, FN>(p, acc, mb, nb, st);
+      gemm_epilogue_select<EPI, false, FM, FN>(p, acc, mb, nb, st);
     }
     if (!has_next) break;
 #pragma unroll
@@ -623,12 +664,12 @@ static int env_int(const char* name, int dflt) {
   return v ? atoi(v) : dflt;
 }
 
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, int EPI>
 static int launch_gemm_cfg(GemmParams& p, int splits, hipStream_t stream) {
   constexpr int smem = 2 * (BM + BN) * 64 * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_kernel<BM, BN, WGM, WGN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_kernel<BM, BN, WGM, WGN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
   static const int group = env_int("VLB_GEMM_TILE_GROUP", 4);
@@ -644,16 +685,39 @@ static int launch_gemm_cfg(GemmParams& p, int splits, hipStream_t stream) {
   cap &= ~7;
   if (gx > cap) gx = cap;
   dim3 grid(gx, splits);
-  hipLaunchKernelGGL((gemm_nt_bf16_kernel<BM, BN, WGM, WGN>), grid, dim3(64 * WGM * WGN), smem, stream, p);
+  hipLaunchKernelGGL((gemm_nt_bf16_kernel<BM, BN, WGM, WGN, EPI>), grid, dim3(64 * WGM * WGN), smem, stream, p);
   VLB_CHECK_LAUNCH("vlb_gemm_nt_bf16");
   return VLB_OK;
 }
 
+// which single-epilogue instantiation serves this call (-1: the generic kernel with the runtime dispatch)
+static int epi_class(const GemmParams& p) {
+  static const int specialise = env_int("VLB_GEMM_EPI_SPECIALISE", 1);
+  if (!specialise || p.out_f32 != 0) return -1;
+  if (p.act == 0) return p.res ? (p.drop_thr ? 3 : 4) : (p.drop_thr ? -1 : 0);
+  if (p.act == 4) return 1;
+  if (p.act == 5) return 2;
+  if (p.act == 2) return 5;
+  return -1;
+}
+
+template <int BM, int BN, int WGM, int WGN>
+static int launch_gemm_epi(GemmParams& p, int splits, hipStream_t stream) {
+  switch (epi_class(p)) {
+    case 0: return launch_gemm_cfg<BM, BN, WGM, WGN, 0>(p, splits, stream);
+    case 1: return launch_gemm_cfg<BM, BN, WGM, WGN, 1>(p, splits, stream);
+    case 2: return launch_gemm_cfg<BM, BN, WGM, WGN, 2>(p, splits, stream);
+    case 3: return launch_gemm_cfg<BM, BN, WGM, WGN, 3>(p, splits, stream);
+    case 4: return launch_gemm_cfg<BM, BN, WGM, WGN, 4>(p, splits, stream);
+    case 5: return launch_gemm_cfg<BM, BN, WGM, WGN, 5>(p, splits, stream);
+    default: return launch_gemm_cfg<BM, BN, WGM, WGN, -1>(p, splits, stream);
+  }
+}
+
 template <int BM, int BN>
 static int launch_gemm(GemmParams& p, int splits, hipStream_t stream) {
-  static const int waves8 = env_int("VLB_GEMM_WAVES8", 1);   // 2x4 waves (64x32 per wave): 16 waves/CU hide LDS/barrier latency better than 2x2
-  if (waves8 && BN == 128) return launch_gemm_cfg<BM, 128, 2, 4>(p, splits, stream);
-  return launch_gemm_cfg<BM, BN, 2, 2>(p, splits, stream);
+  if (BN == 128) return launch_gemm_epi<BM, 128, 2, 4>(p, splits, stream);   // 8 waves of 64x32: 16 waves/CU hide LDS/barrier latency
+  return launch_gemm_epi<BM, BN, 2, 2>(p, splits, stream);
 }
 
 extern "C" int vlb_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
@@ -666,8 +730,8 @@ extern "C" int vlb_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb
   VLB_CHECK_ARG((lda % 8) == 0 && (ldb % 8) == 0, "vlb_gemm_nt_bf16: lda/ldb must be multiples of 8 elements");
   VLB_CHECK_ARG((ldc % 4) == 0, "vlb_gemm_nt_bf16: ldc must be a multiple of 4");
   VLB_CHECK_ARG(out_mode >= 0 && out_mode <= 3, "vlb_gemm_nt_bf16: bad out_mode %d", out_mode);
-  VLB_CHECK_ARG(act >= 0 && act <= 3, "vlb_gemm_nt_bf16: bad act %d", act);
-  VLB_CHECK_ARG(act != 3 || aux, "vlb_gemm_nt_bf16: act=3 needs aux");
+  VLB_CHECK_ARG(act >= 0 && act <= 5, "vlb_gemm_nt_bf16: bad act %d", act);
+  VLB_CHECK_ARG((act != 3 && act != 5) || aux, "vlb_gemm_nt_bf16: act=3/5 needs aux");
   VLB_CHECK_ARG(act == 0 || (!(drop_p > 0.f) && !res), "vlb_gemm_nt_bf16: an activation cannot be combined with dropout/residual");
   VLB_CHECK_ARG(out_mode == 0 || (act == 0 && !(drop_p > 0.f) && !res), "vlb_gemm_nt_bf16: fp32 outputs take bias only");
   VLB_CHECK_ARG(!(drop_p > 0.f) || seed, "vlb_gemm_nt_bf16: dropout needs a device seed pointer");

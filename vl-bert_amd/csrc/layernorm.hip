@@ -6,9 +6,15 @@
 // with wave shuffles, and written once.  The residual add / bias / dropout that precede every
 // encoder LayerNorm are fused into the producing GEMM's epilogue (gemm.hip), so `x` already is
 // the pre-LN sum, and it is what backward re-reads (no separate x_hat tensor is stored).
+#include <stdlib.h>
+
 #include "vlb_common.h"
 
 #define LN_MAX_IT 8  // H <= 2048
+// The dgamma/dbeta flush of 768 workgroups x 2H fp32 atomics (~1.2 M) costs as much as the whole HBM-bound row pass
+// (atomic throughput, ~40 G/s).  With a workspace every workgroup stores its partial vector with plain 16-B stores
+// and a small second kernel column-sums the LN_MAX_BLOCKS x 2H slab (4.7 MB at H=768) into the gradients.
+#define LN_MAX_BLOCKS 768   // 3 workgroups per CU
 
 // NIT = ceil(H / 256): per-lane register footprint follows the actual row width (H=768 -> 3)
 template <int NIT>
@@ -83,82 +89,93 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __rest
 // flows into the dense layer *before* its dropout; idx = row*H + col matches the GEMM epilogue),
 // dx_acc fp32 (atomicAdd; used when several rows alias one input row, e.g. the broadcast
 // text_visual_embeddings of pretrain/modules/resnet_vlbert_for_pretraining.py:132-135).
-template <int NIT>
+// Lane layout: 16-B accesses, lane owns columns (lane + 64 i) * 8 .. +7 (H = 768: one full pass + one half-wave
+// pass); two rows per wave iteration with all four row loads issued before the first reduction.
+template <int NP>
+struct Row8 {
+  float v[NP][8];
+};
+
+template <int NP>
+__device__ __forceinline__ void load_row8_bf16(const bf16_t* x, int H, int lane, Row8<NP>& r) {
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int c = (lane + 64 * i) * 8;
+    uint4 w = make_uint4(0u, 0u, 0u, 0u);
+    if (c < H) w = *(const uint4*)(x + c);
+    r.v[i][0] = bflo(w.x); r.v[i][1] = bfhi(w.x); r.v[i][2] = bflo(w.y); r.v[i][3] = bfhi(w.y);
+    r.v[i][4] = bflo(w.z); r.v[i][5] = bfhi(w.z); r.v[i][6] = bflo(w.w); r.v[i][7] = bfhi(w.w);
+  }
+}
+
+template <int NP>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restrict__ dy_, long lddy, int dy_f32, const bf16_t* __restrict__ x,
                                                             long ldx, const float* __restrict__ stats, const float* __restrict__ gamma,
                                                             bf16_t* __restrict__ dx, long lddx, bf16_t* __restrict__ dx_drop, long lddd,
                                                             uint32_t drop_thr, float drop_scale, const uint32_t* __restrict__ seedp,
                                                             uint32_t tag, float* __restrict__ dx_acc, long ldacc, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta, int rows, int H) {
-  extern __shared__ __attribute__((aligned(16))) float red[];  // [2][H] block accumulators for dgamma / dbeta
+                                                            float* __restrict__ dbeta, float* __restrict__ ws, int rows, int H) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][2][LW] per-wave partial dgamma / dbeta (lane-major)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t seed = (drop_thr && seedp) ? *seedp : 0u;
   const bool want_gb = (dgamma != nullptr) || (dbeta != nullptr);
-  if (want_gb) {
-    for (int i = threadIdx.x; i < 2 * H; i += 256) red[i] = 0.f;
-    __syncthreads();
-  }
-  float gsum[NIT][4], bsum[NIT][4];
+  float gsum[NP][8], bsum[NP][8], gam[NP][8];
 #pragma unroll
-  for (int i = 0; i < NIT; ++i)
+  for (int i = 0; i < NP; ++i) {
+    const int c = (lane + 64 * i) * 8;
+    float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0;
+    if (c < H) { g0 = *(const float4*)(gamma + c); g1 = *(const float4*)(gamma + c + 4); }
+    gam[i][0] = g0.x; gam[i][1] = g0.y; gam[i][2] = g0.z; gam[i][3] = g0.w;
+    gam[i][4] = g1.x; gam[i][5] = g1.y; gam[i][6] = g1.z; gam[i][7] = g1.w;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) gsum[i][k] = bsum[i][k] = 0.f;
-  float gam[NIT][4];
-#pragma unroll
-  for (int i = 0; i < NIT; ++i) {
-    const int c = (lane + 64 * i) * 4;
-    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (c < H) g = *(const float4*)(gamma + c);
-    gam[i][0] = g.x; gam[i][1] = g.y; gam[i][2] = g.z; gam[i][3] = g.w;
+    for (int k = 0; k < 8; ++k) gsum[i][k] = bsum[i][k] = 0.f;
   }
 
-  // Two rows per wave iteration: both rows' loads are issued before either row's reductions (memory-level
-  // parallelism for an HBM-bound kernel that otherwise waits a full round trip per row).
-  const int step = gridDim.x * 4;
-  for (int row0 = blockIdx.x * 4 + wave; row0 < rows; row0 += 2 * step) {
+  const int nw = blockDim.x >> 6, step = gridDim.x * nw;
+  for (int row0 = blockIdx.x * nw + wave; row0 < rows; row0 += 2 * step) {
     const int row1 = row0 + step;
     const bool has1 = row1 < rows;
-    Row4<NIT> xr[2], dyr[2];
+    Row8<NP> xr[2], dyr[2];
     float mean[2], rstd[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int row = t ? (has1 ? row1 : row0) : row0;
-      load_row_bf16(x + (long)row * ldx, H, lane, xr[t]);
+      load_row8_bf16(x + (long)row * ldx, H, lane, xr[t]);
       if (dy_f32) {
         const float* d = (const float*)dy_ + (long)row * lddy;
 #pragma unroll
-        for (int i = 0; i < NIT; ++i) {
-          const int c = (lane + 64 * i) * 4;
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (c < H) v = *(const float4*)(d + c);
-          dyr[t].v[i][0] = v.x; dyr[t].v[i][1] = v.y; dyr[t].v[i][2] = v.z; dyr[t].v[i][3] = v.w;
+        for (int i = 0; i < NP; ++i) {
+          const int c = (lane + 64 * i) * 8;
+          float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+          if (c < H) { v0 = *(const float4*)(d + c); v1 = *(const float4*)(d + c + 4); }
+          dyr[t].v[i][0] = v0.x; dyr[t].v[i][1] = v0.y; dyr[t].v[i][2] = v0.z; dyr[t].v[i][3] = v0.w;
+          dyr[t].v[i][4] = v1.x; dyr[t].v[i][5] = v1.y; dyr[t].v[i][6] = v1.z; dyr[t].v[i][7] = v1.w;
         }
       } else {
-        load_row_bf16((const bf16_t*)dy_ + (long)row * lddy, H, lane, dyr[t]);
+        load_row8_bf16((const bf16_t*)dy_ + (long)row * lddy, H, lane, dyr[t]);
       }
-      mean[t] = stats[2 * (long)row];
-      rstd[t] = stats[2 * (long)row + 1];
+      const float2 ms = *(const float2*)(stats + 2 * (long)row);
+      mean[t] = ms.x;
+      rstd[t] = ms.y;
     }
     float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const float live = (t == 0 || has1) ? 1.f : 0.f;   // the duplicate of row0 must not count twice
 #pragma unroll
-      for (int i = 0; i < NIT; ++i) {
-        const int c = (lane + 64 * i) * 4;
-        if (c < H) {
+      for (int i = 0; i < NP; ++i) {
+        const bool in = (lane + 64 * i) * 8 < H;         // out-of-range lanes hold zeros for dy: only xhat needs masking
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const float xh = (xr[t].v[i][k] - mean[t]) * rstd[t];
-            const float dyv = dyr[t].v[i][k] * live;
-            gsum[i][k] += dyv * xh;
-            bsum[i][k] += dyv;
-            const float gv = dyv * gam[i][k];
-            s1[t] += gv;
-            s2[t] += gv * xh;
-            xr[t].v[i][k] = xh;   // reuse storage: xhat
-            dyr[t].v[i][k] = gv;  // reuse storage: g
-          }
+        for (int k = 0; k < 8; ++k) {
+          const float xh = in ? (xr[t].v[i][k] - mean[t]) * rstd[t] : 0.f;
+          const float dyv = dyr[t].v[i][k] * live;
+          gsum[i][k] += dyv * xh;
+          bsum[i][k] += dyv;
+          const float gv = dyv * gam[i][k];
+          s1[t] += gv;
+          s2[t] += gv * xh;
+          xr[t].v[i][k] = xh;   // reuse storage: xhat
+          dyr[t].v[i][k] = gv;  // reuse storage: g
         }
       }
     }
@@ -173,54 +190,83 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
       const int row = t ? row1 : row0;
       const float m1 = s1[t] / (float)H, m2 = s2[t] / (float)H;
 #pragma unroll
-      for (int i = 0; i < NIT; ++i) {
-        const int c = (lane + 64 * i) * 4;
+      for (int i = 0; i < NP; ++i) {
+        const int c = (lane + 64 * i) * 8;
         if (c < H) {
-          float o[4];
+          float o[8];
 #pragma unroll
-          for (int k = 0; k < 4; ++k) o[k] = rstd[t] * (dyr[t].v[i][k] - m1 - xr[t].v[i][k] * m2);
-          if (dx) *(uint2*)(dx + (long)row * lddx + c) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+          for (int k = 0; k < 8; ++k) o[k] = rstd[t] * (dyr[t].v[i][k] - m1 - xr[t].v[i][k] * m2);
+          if (dx) *(uint4*)(dx + (long)row * lddx + c) = make_uint4(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7]));
           if (dx_drop) {
-            float d[4];
+            float d[8];
             if (drop_thr) {
-              const uint32_t idx = (uint32_t)row * (uint32_t)H + (uint32_t)c;  // H%4==0 -> idx even
-              const uint32_t h0 = vlb_rng_pair(seed, tag, idx >> 1), h1 = vlb_rng_pair(seed, tag, (idx >> 1) + 1);
-              d[0] = ((h0 & 0xffffu) >= drop_thr) ? o[0] * drop_scale : 0.f;
-              d[1] = ((h0 >> 16) >= drop_thr) ? o[1] * drop_scale : 0.f;
-              d[2] = ((h1 & 0xffffu) >= drop_thr) ? o[2] * drop_scale : 0.f;
-              d[3] = ((h1 >> 16) >= drop_thr) ? o[3] * drop_scale : 0.f;
+              const uint32_t idx = (uint32_t)row * (uint32_t)H + (uint32_t)c;  // H%8==0 -> idx even
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const uint32_t h = vlb_rng_pair(seed, tag, (idx >> 1) + q);
+                d[2 * q] = ((h & 0xffffu) >= drop_thr) ? o[2 * q] * drop_scale : 0.f;
+                d[2 * q + 1] = ((h >> 16) >= drop_thr) ? o[2 * q + 1] * drop_scale : 0.f;
+              }
             } else {
-              d[0] = o[0]; d[1] = o[1]; d[2] = o[2]; d[3] = o[3];
+#pragma unroll
+              for (int k = 0; k < 8; ++k) d[k] = o[k];
             }
-            *(uint2*)(dx_drop + (long)row * lddd + c) = make_uint2(pack2bf(d[0], d[1]), pack2bf(d[2], d[3]));
+            *(uint4*)(dx_drop + (long)row * lddd + c) = make_uint4(pack2bf(d[0], d[1]), pack2bf(d[2], d[3]), pack2bf(d[4], d[5]), pack2bf(d[6], d[7]));
           }
           if (dx_acc) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) atomicAdd(dx_acc + (long)row * ldacc + c + k, o[k]);
+            for (int k = 0; k < 8; ++k) atomicAdd(dx_acc + (long)row * ldacc + c + k, o[k]);
           }
         }
       }
     }
   }
   if (!want_gb) return;
-  // per-wave partials -> LDS atomics -> one global atomic per column per block
-  float* rg = red;
-  float* rb = red + H;
+  // Per-wave partials -> LDS in LANE-MAJOR order (element (i,k) of lane l at (i*8+k)*64 + l: conflict-free plain stores,
+  // no LDS atomics -- the natural column order has lanes 8 floats apart = 16-way bank conflicts), summed over the 4 waves
+  // by the whole workgroup in the same order.  q -> column: ln_col_of().
+  constexpr int LW = NP * 512;
+  float* mine = red + wave * 2 * LW;
 #pragma unroll
-  for (int i = 0; i < NIT; ++i) {
-    const int c = (lane + 64 * i) * 4;
-    if (c < H) {
+  for (int i = 0; i < NP; ++i)
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        atomicAdd(rg + c + k, gsum[i][k]);
-        atomicAdd(rb + c + k, bsum[i][k]);
-      }
+    for (int k = 0; k < 8; ++k) {
+      mine[(i * 8 + k) * 64 + lane] = gsum[i][k];
+      mine[LW + (i * 8 + k) * 64 + lane] = bsum[i][k];
     }
-  }
   __syncthreads();
-  for (int c = threadIdx.x; c < H; c += 256) {
-    if (dgamma) atomicAdd(dgamma + c, rg[c]);
-    if (dbeta) atomicAdd(dbeta + c, rb[c]);
+  for (int q = threadIdx.x; q < 2 * LW; q += 256) {
+    const float v = (red[q] + red[2 * LW + q]) + (red[4 * LW + q] + red[6 * LW + q]);
+    if (ws) ws[(long)blockIdx.x * 2 * LW + q] = v;   // partial vector of this workgroup; ln_param_finalize_kernel column-sums them
+    else red[q] = v;                                  // (only this thread reads red[q])
+  }
+  if (ws) return;
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * H; c += 256) {    // no workspace: coalesced atomics in natural column order
+    const int which = c >= H, col = c - which * H, chunk = col >> 3;
+    const float v = red[which * LW + (((chunk >> 6) * 8 + (col & 7)) << 6) + (chunk & 63)];
+    float* dst = which ? dbeta : dgamma;
+    if (dst) atomicAdd(dst + col, v);
+  }
+}
+
+// dgamma/dbeta += column sums of the `nslab` lane-major partial vectors [2][LW]: grid (2 LW / 64, 8)
+__global__ __launch_bounds__(256) void ln_param_finalize_kernel(const float* __restrict__ ws, int nslab, int LW, float* __restrict__ dgamma,
+                                                                float* __restrict__ dbeta, int H) {
+  __shared__ float part[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int q = blockIdx.x * 64 + tx;
+  float s = 0.f;
+  for (int r = blockIdx.y * 4 + ty; r < nslab; r += 4 * gridDim.y) s += ws[(long)r * 2 * LW + q];
+  part[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0) {
+    s = (part[0][tx] + part[1][tx]) + (part[2][tx] + part[3][tx]);
+    const int r = q % LW, col = ((r & 63) + 64 * (r >> 9)) * 8 + ((r >> 6) & 7);
+    if (col < H) {
+      if (q < LW) { if (dgamma) atomicAdd(dgamma + col, s); }
+      else if (dbeta) atomicAdd(dbeta + col, s);
+    }
   }
 }
 
@@ -242,22 +288,36 @@ extern "C" int vlb_layernorm_fwd(const void* x, long ldx, const float* gamma, co
 extern "C" int vlb_layernorm_bwd(const void* dy, long lddy, int dy_f32, const void* x, long ldx, const float* stats,
                                  const float* gamma, void* dx, long lddx, void* dx_drop, long lddd, float drop_p,
                                  const uint32_t* seed, uint32_t tag, float* dx_acc, long ldacc, float* dgamma, float* dbeta,
-                                 int rows, int H, hipStream_t stream) {
+                                 float* workspace, int rows, int H, hipStream_t stream) {
   if (rows <= 0) return VLB_OK;
-  VLB_CHECK_ARG(H > 0 && (H % 4) == 0 && H <= 256 * LN_MAX_IT, "vlb_layernorm_bwd: unsupported H=%d", H);
+  VLB_CHECK_ARG(H > 0 && (H % 8) == 0 && H <= 2048, "vlb_layernorm_bwd: unsupported H=%d (multiple of 8, <= 2048)", H);
+  VLB_CHECK_ARG((lddy % 8) == 0 && (ldx % 8) == 0 && (lddx % 8) == 0 && (lddd % 8) == 0,
+                "vlb_layernorm_bwd: row strides must be multiples of 8");
   VLB_CHECK_ARG(!(drop_p > 0.f) || seed, "vlb_layernorm_bwd: dropout needs a device seed pointer");
   VLB_CHECK_ARG((long)rows * H < (1L << 32) || !(drop_p > 0.f), "vlb_layernorm_bwd: dropout index overflow");
   int blocks = vlb_cdiv(rows, 8);      // a wave handles two rows per iteration
   if (blocks < 1) blocks = 1;
-  if (blocks > 768) blocks = 768;      // 3 workgroups per CU; fewer blocks = fewer dgamma/dbeta atomics
+  if (blocks > LN_MAX_BLOCKS) blocks = LN_MAX_BLOCKS;
+  float* ws = (workspace && (dgamma || dbeta) && blocks > 32) ? workspace : nullptr;
   const uint32_t thr = vlb_drop_thr(drop_p);
-#define LN_BWD(NIT)                                                                                                            \
-  hipLaunchKernelGGL(layernorm_bwd_kernel<NIT>, dim3(blocks), dim3(256), 2 * H * sizeof(float), stream, dy, lddy, dy_f32,       \
+#define LN_BWD(NP)                                                                                                             \
+  hipLaunchKernelGGL(layernorm_bwd_kernel<NP>, dim3(blocks), dim3(256), 8 * NP * 512 * sizeof(float), stream, dy, lddy, dy_f32,  \
                      (const bf16_t*)x, ldx, stats, gamma, (bf16_t*)dx, lddx, (bf16_t*)dx_drop, lddd, thr, vlb_drop_scale(thr),  \
-                     seed, tag, dx_acc, ldacc, dgamma, dbeta, rows, H)
-  const int nit = vlb_cdiv(H, 256);
-  if (nit <= 1) LN_BWD(1); else if (nit == 2) LN_BWD(2); else if (nit == 3) LN_BWD(3); else if (nit == 4) LN_BWD(4); else LN_BWD(8);
+                     seed, tag, dx_acc, ldacc, dgamma, dbeta, ws, rows, H)
+  const int np = vlb_cdiv(H, 512);
+  if (np <= 1) LN_BWD(1); else if (np == 2) LN_BWD(2); else if (np == 3) LN_BWD(3); else LN_BWD(4);
 #undef LN_BWD
   VLB_CHECK_LAUNCH("vlb_layernorm_bwd");
+  if (ws) {
+    const int LW = (np <= 3 ? np : 4) * 512;
+    hipLaunchKernelGGL(ln_param_finalize_kernel, dim3(2 * LW / 64, 8), dim3(256), 0, stream, ws, blocks, LW, dgamma, dbeta, H);
+    VLB_CHECK_LAUNCH("vlb_layernorm_bwd(finalize)");
+  }
   return VLB_OK;
+}
+
+extern "C" long vlb_layernorm_bwd_workspace_floats(int H) {
+  if (H <= 0) return 0;
+  const int np = vlb_cdiv(H, 512);
+  return (long)LN_MAX_BLOCKS * 2 * (np <= 3 ? np : 4) * 512;
 }

@@ -258,6 +258,7 @@ class PretrainEngine:
                 ((3 * H, H, self.Mp), (H, H, self.Mp), (I, H, self.Mp), (H, I, self.Mp), (V, H, self.BTp), (H, H, self.BTp),
                  (C, H, self.BRp), (H, H, self.BRp), (H, 2 * VIS_DIM, self.BRp))]
         self.wg_ws = zf(max(max(need), 4))
+        self.ln_ws = zf(ops.ln_bwd_workspace_floats(H))     # per-workgroup partial dgamma/dbeta sums of the LayerNorm backward
         self.graph = None
         self._weights_dirty = True
         import os
@@ -383,7 +384,7 @@ class PretrainEngine:
             ops.layernorm_fwd(self.Z1[l], w32[p + "attention.output.LayerNorm.weight"], w32[p + "attention.output.LayerNorm.bias"],
                               self.Y1[l], self.ST1[l])
             ops.gemm_nt(self.Y1[l], w16[p + "intermediate.dense.weight"], self.G[l], bias=w32[p + "intermediate.dense.bias"],
-                        act=ops.ACT_GELU, pre=self.U[l])
+                        act=ops.ACT_GELU_D, pre=self.U[l])
             ops.gemm_nt(self.G[l], w16[p + "output.dense.weight"], self.Z2[l], bias=w32[p + "output.dense.bias"], res=self.Y1[l],
                         drop_p=p_h, seed=seed, tag=l * 8 + 2)
             ops.layernorm_fwd(self.Z2[l], w32[p + "output.LayerNorm.weight"], w32[p + "output.LayerNorm.bias"], self.X[l + 1],
@@ -394,12 +395,12 @@ class PretrainEngine:
         ops.gather_rows(xl, self.lay["obj_rows"].view(-1)[:self.BR], self.obj_out)
         pm = "vlbert.mlm_head.predictions."
         ops.gemm_nt(self.text_out, w16[pm + "transform.dense.weight"], self.mlm_g, bias=w32[pm + "transform.dense.bias"],
-                    act=ops.ACT_GELU, pre=self.mlm_u)
+                    act=ops.ACT_GELU_D, pre=self.mlm_u)
         ops.layernorm_fwd(self.mlm_g, w32[pm + "transform.LayerNorm.weight"], w32[pm + "transform.LayerNorm.bias"], self.mlm_h,
                           self.st_mlm)
         ops.gemm_nt(self.mlm_h, w16["vlbert.word_embeddings.weight"], self.mlm_logits[:, :V], bias=w32[pm + "bias"])
         ops.gemm_nt(self.obj_out, w16["vlbert.mvrc_head.transform.dense.weight"], self.mvrc_g,
-                    bias=w32["vlbert.mvrc_head.transform.dense.bias"], act=ops.ACT_GELU, pre=self.mvrc_u)
+                    bias=w32["vlbert.mvrc_head.transform.dense.bias"], act=ops.ACT_GELU_D, pre=self.mvrc_u)
         ops.gemm_nt(self.mvrc_g, w16["vlbert.mvrc_head.region_cls_pred.weight"], self.mvrc_logits[:, :C],
                     bias=w32["vlbert.mvrc_head.region_cls_pred.bias"])
         self._losses_fwd_bwd(gscale, True)
@@ -451,8 +452,9 @@ class PretrainEngine:
         self._wgrad(dlog[:, :V], self.mlm_h, g32["vlbert.word_embeddings.weight"], g32[pm + "bias"], self.tG_bt, self.tA_bt, BTp)
         ops.gemm_nt(dlog, wT["vlbert.word_embeddings.weight"], self.d_mlm_h)
         ops.layernorm_bwd(self.d_mlm_h, self.mlm_g, self.st_mlm, w32[pm + "transform.LayerNorm.weight"], dx=self.d_mlm_g,
-                          dgamma=g32[pm + "transform.LayerNorm.weight"], dbeta=g32[pm + "transform.LayerNorm.bias"])
-        ops.dgelu_mul(self.d_mlm_g, self.mlm_u, self.d_mlm_u)
+                          dgamma=g32[pm + "transform.LayerNorm.weight"], dbeta=g32[pm + "transform.LayerNorm.bias"],
+                          workspace=self.ln_ws)
+        ops.mul_bf16(self.d_mlm_g, self.mlm_u, self.d_mlm_u)
         self._wgrad(self.d_mlm_u, self.text_out, g32[pm + "transform.dense.weight"], g32[pm + "transform.dense.bias"], self.tG_bt,
                     self.tA_bt, BTp)
         ops.gemm_nt(self.d_mlm_u, wT[pm + "transform.dense.weight"], self.d_text_out)
@@ -460,7 +462,7 @@ class PretrainEngine:
         dlog2 = self.mvrc_logits                     # [BR, Cp]
         self._wgrad(dlog2[:, :C], self.mvrc_g, g32["vlbert.mvrc_head.region_cls_pred.weight"],
                     g32["vlbert.mvrc_head.region_cls_pred.bias"], self.tG_br, self.tA_br, BRp)
-        ops.gemm_nt(dlog2, wT["vlbert.mvrc_head.region_cls_pred.weight"], self.d_mvrc_u, act=ops.ACT_DGELU, aux=self.mvrc_u)
+        ops.gemm_nt(dlog2, wT["vlbert.mvrc_head.region_cls_pred.weight"], self.d_mvrc_u, act=ops.ACT_MULAUX, aux=self.mvrc_u)
         self._wgrad(self.d_mvrc_u, self.obj_out, g32["vlbert.mvrc_head.transform.dense.weight"],
                     g32["vlbert.mvrc_head.transform.dense.bias"], self.tG_br, self.tA_br, BRp)
         ops.gemm_nt(self.d_mvrc_u, wT["vlbert.mvrc_head.transform.dense.weight"], self.d_obj_out)
@@ -477,17 +479,19 @@ class PretrainEngine:
             # LN2: dZ2 (residual branch) and dD2 (into output.dense, through its dropout)
             ops.layernorm_bwd(dx, self.Z2[l], self.ST2[l], w32[p + "output.LayerNorm.weight"], dx=self.dZ,
                               dx_drop=self.dD if drop else None, drop_p=p_h, seed=seed, tag=l * 8 + 2,
-                              dgamma=g32[p + "output.LayerNorm.weight"], dbeta=g32[p + "output.LayerNorm.bias"])
+                              dgamma=g32[p + "output.LayerNorm.weight"], dbeta=g32[p + "output.LayerNorm.bias"],
+                              workspace=self.ln_ws)
             dD2 = self.dD if drop else self.dZ
             self._wgrad(dD2, self.G[l], g32[p + "output.dense.weight"], g32[p + "output.dense.bias"], self.tG, self.tA, Mp)
-            ops.gemm_nt(dD2, wT[p + "output.dense.weight"], self.dU, act=ops.ACT_DGELU, aux=self.U[l])
+            ops.gemm_nt(dD2, wT[p + "output.dense.weight"], self.dU, act=ops.ACT_MULAUX, aux=self.U[l])
             self._wgrad(self.dU, self.Y1[l], g32[p + "intermediate.dense.weight"], g32[p + "intermediate.dense.bias"], self.tG,
                         self.tA, Mp)
             ops.gemm_nt(self.dU, wT[p + "intermediate.dense.weight"], dx_next, res=self.dZ)            # dY1
             # LN1
             ops.layernorm_bwd(dx_next, self.Z1[l], self.ST1[l], w32[p + "attention.output.LayerNorm.weight"], dx=self.dZ,
                               dx_drop=self.dD if drop else None, drop_p=p_h, seed=seed, tag=l * 8 + 1,
-                              dgamma=g32[p + "attention.output.LayerNorm.weight"], dbeta=g32[p + "attention.output.LayerNorm.bias"])
+                              dgamma=g32[p + "attention.output.LayerNorm.weight"], dbeta=g32[p + "attention.output.LayerNorm.bias"],
+                              workspace=self.ln_ws)
             dD1 = self.dD if drop else self.dZ
             self._wgrad(dD1, self.CTX[l], g32[p + "attention.output.dense.weight"], g32[p + "attention.output.dense.bias"],
                         self.tG, self.tA, Mp)
@@ -513,7 +517,7 @@ class PretrainEngine:
                       drop_p=p_h, seed=seed, tag=TAG_EMBED)
         ops.layernorm_bwd(self.d_objvis, self.obj_reps, self.st_objvis, w32["vlbert.visual_ln_object.weight"],
                           dx_acc=self.d_obj_reps, dgamma=g32["vlbert.visual_ln_object.weight"],
-                          dbeta=g32["vlbert.visual_ln_object.bias"])
+                          dbeta=g32["vlbert.visual_ln_object.bias"], workspace=self.ln_ws)
         reps0 = self.obj_reps.view(B, R * H)[:, :H]
         ops.layernorm_bwd(self.d_textvis[:B], reps0, self.st_textvis[:B], w32["vlbert.visual_ln_text.weight"],
                           dx_acc=self.d_obj_reps.view(B, R * H)[:, :H], dgamma=g32["vlbert.visual_ln_text.weight"],

@@ -9,7 +9,7 @@ import torch
 from . import _lib
 
 BF16 = torch.bfloat16
-ACT_NONE, ACT_GELU, ACT_RELU, ACT_DGELU = 0, 1, 2, 3
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_DGELU, ACT_GELU_D, ACT_MULAUX = 0, 1, 2, 3, 4, 5
 OUT_BF16, OUT_F32, OUT_F32_ATOMIC = 0, 1, 2
 
 
@@ -68,6 +68,10 @@ def wgrad_tn(dy, x, C, colsum=None, workspace=None):
     return C
 
 
+def ln_bwd_workspace_floats(H):
+    return int(_lib.load().vlb_layernorm_bwd_workspace_floats(H))
+
+
 def wgrad_workspace_floats(M, N, K):
     return int(_lib.load().vlb_wgrad_workspace_floats(M, N, K))
 
@@ -89,14 +93,15 @@ def layernorm_fwd(x, gamma, beta, y, stats=None, eps=1e-12, rows=None, ldx=None)
 
 
 def layernorm_bwd(dy, x, stats, gamma, dx=None, dx_drop=None, drop_p=0.0, seed=None, tag=0, dx_acc=None, dgamma=None,
-                  dbeta=None, rows=None, ldx=None, ldacc=None):
+                  dbeta=None, rows=None, ldx=None, ldacc=None, workspace=None):
+    """workspace: fp32 scratch tensor of ln_bwd_workspace_floats(H) elements, or None (direct atomics)."""
     H = x.shape[1]
     rows = x.shape[0] if rows is None else rows
     dy_f32 = 1 if dy.dtype == torch.float32 else 0
     _lib.call("vlb_layernorm_bwd", _p(dy), _ld(dy), dy_f32, _p(x, BF16), _ld(x) if ldx is None else ldx, _p(stats, torch.float32),
               _p(gamma, torch.float32), _p(dx, BF16), _ld(dx), _p(dx_drop, BF16), _ld(dx_drop), float(drop_p), _p(seed),
               int(tag), _p(dx_acc, torch.float32), _ld(dx_acc) if ldacc is None else ldacc, _p(dgamma, torch.float32),
-              _p(dbeta, torch.float32), rows, H, _stream())
+              _p(dbeta, torch.float32), _p(workspace, torch.float32), rows, H, _stream())
 
 
 def attention_fwd(qkv, mask, ctx, lse, B, S, H, nh, drop_p=0.0, seed=None, tag=0):
@@ -189,6 +194,11 @@ def relu_bwd_cast(g, y, out):
 
 def dgelu_mul(dg, u, out):
     _lib.call("vlb_dgelu_mul", _p(dg, BF16), _p(u, BF16), _p(out, BF16), dg.numel(), _stream())
+    return out
+
+
+def mul_bf16(a, b, out):
+    _lib.call("vlb_mul_bf16", _p(a, BF16), _p(b, BF16), _p(out, BF16), a.numel(), _stream())
     return out
 
 
