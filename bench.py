@@ -146,23 +146,28 @@ def main():
     # ---- roofline of the dominant kernel (the bf16 MFMA GEMM): one extra, instrumented step ---------------
     # HIP events are recorded on the stream the kernels are launched on (torch's current stream).
     rec = []
-    orig, orig_w, orig_t = ops.gemm_nt, ops.wgrad_nt, ops.wgrad_tn
+    names = ("gemm_nt", "gemm_nt_splitk", "wgrad_nt", "wgrad_tn")     # wgrad_* / *_splitk include their slab reduce
+    orig = {n: getattr(ops, n) for n in names}
 
-    def timed(fn):
+    def timed(name):
+        fn = orig[name]
+
         def wrapper(A, B, C, *a, **kw):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             out = fn(A, B, C, *a, **kw)
             e1.record()
-            K = kw.get("K") or (A.shape[0] if fn is orig_t else A.shape[1])      # TN form reduces over the rows
+            K = A.shape[0] if name == "wgrad_tn" else A.shape[1]      # TN form reduces over the rows
             rec.append((e0, e1, 2.0 * C.shape[0] * C.shape[1] * K))
             return out
         return wrapper
 
-    ops.gemm_nt, ops.wgrad_nt, ops.wgrad_tn = timed(orig), timed(orig_w), timed(orig_t)   # wgrad_* include their slab reduce
+    for n in names:
+        setattr(ops, n, timed(n))
     eng.train_step()
     torch.cuda.synchronize()
-    ops.gemm_nt, ops.wgrad_nt, ops.wgrad_tn = orig, orig_w, orig_t
+    for n in names:
+        setattr(ops, n, orig[n])
     gemm_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in rec)
     gemm_flops = sum(f for _, _, f in rec)
     achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0

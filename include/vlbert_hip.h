@@ -55,6 +55,11 @@ int vlb_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb, void* C, 
                      const void* res, long ldres, float drop_p, const uint32_t* seed, uint32_t tag,
                      int out_mode, int splitk, vlb_stream_t stream);
 
+/* bf16 C[M,N] = A[M,K] B[N,K]^T, no epilogue, for few output tiles and a very long K (tied-decoder dgrad at small batch):
+ * slab split-K through `workspace` (vlb_wgrad_workspace_floats(M, N, K) floats) + a reduce that converts to bf16. */
+int vlb_gemm_nt_bf16_splitk(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
+                            float* workspace, long workspace_floats, vlb_stream_t stream);
+
 /* Weight-gradient form: C[M,N] (fp32) += A[M,K] B[N,K]^T for few output tiles and a very long K (K = padded
  * row count of the activations; autograd's `grad_output.t().mm(input)` behind every nn.Linear).  Split-K
  * through fp32 workspace slabs + a streaming reduce (no atomics); splits chosen by an internal cost model, capped
@@ -72,6 +77,10 @@ int vlb_wgrad_tn_bf16(const void* A, long lda, const void* B, long ldb, float* C
 /* out[c][r] = in[r][c] (bf16, out leading dim ldo >= R); colsum[c] += sum_r in[r][c] if non-NULL
  * (bias gradients).  Feeds the weight-gradient GEMMs (autograd's `grad.t().mm(input)`). */
 int vlb_transpose_bf16(const void* in, long ldi, void* out, long ldo, int R, int C, float* colsum, vlb_stream_t stream);
+/* n transposes in one launch: desc (device) = n x {in ptr, ldi, out ptr, ldo, R, C} as int64; tile_start (device, n+1
+ * int32) = running count of 64x64 tiles, tile_start[n] == total_tiles.  Used for the per-step refresh of the
+ * transposed bf16 weight copies read by the dgrad GEMMs (autograd's `grad_output.mm(weight)`). */
+int vlb_transpose_batched_bf16(const int64_t* desc, const int32_t* tile_start, int n, int total_tiles, vlb_stream_t stream);
 
 /* ---- BertLayerNorm (modeling.py:222-235; eps inside the sqrt, biased variance) --------------
  * fwd: y = LN(x)*gamma+beta, stats[row] = (mean, rstd) (may be NULL).

@@ -46,6 +46,34 @@ def test_gemm_plain_bias(ops, M, N, K):
         assert float(C[:, N:].float().abs().max()) == 0.0, "pad columns were written"
 
 
+def test_gemm_splitk_bf16_and_batched_transpose(ops):
+    # few output tiles, very long K: slab split-K with the bf16-converting reduce
+    M, N, K = 200, 136, 64 * 150
+    A, B = rnd(M, K, seed=31, scale=0.5), rnd(N, K, seed=32, scale=0.05)
+    C = torch.zeros((M, 192), dtype=torch.bfloat16, device=dev())[:, :N]
+    ws = torch.empty(max(ops.wgrad_workspace_floats(M, N, K), 4), device=dev())
+    assert ws.numel() > 4, "cost model should split this shape"
+    ops.gemm_nt_splitk(to_gpu_bf16(A), to_gpu_bf16(B), C, workspace=ws)
+    report("gemm splitk bf16", C, A @ B.t(), 1e-3, 1e-2)
+    C2 = torch.zeros_like(C)
+    ops.gemm_nt_splitk(to_gpu_bf16(A), to_gpu_bf16(B), C2, workspace=None)        # single pass fallback
+    report("gemm splitk bf16 (no workspace)", C2, A @ B.t(), 1e-3, 1e-2)
+    # batched transposes: ragged shapes, padded destinations
+    g = torch.Generator().manual_seed(33)
+    pairs, refs = [], []
+    for R, C_ in ((70, 130), (64, 64), (300, 72), (5, 8)):
+        src = torch.randn((R, C_), generator=g).to(torch.bfloat16).to(dev())
+        dst = torch.zeros((C_, (R + 63) // 64 * 64), dtype=torch.bfloat16, device=dev())
+        pairs.append((src, dst))
+        refs.append(src.float().cpu().t())
+    tb = ops.TransposeBatch(pairs, dev())
+    tb.run()
+    for (src, dst), ref in zip(pairs, refs):
+        R = src.shape[0]
+        assert torch.equal(dst[:, :R].float().cpu(), ref)
+        assert float(dst[:, R:].float().abs().max() if dst.shape[1] > R else 0.0) == 0.0
+
+
 def test_gemm_epilogues(ops):
     M, N, K = 384, 320, 256
     A, B = rnd(M, K, seed=4), rnd(N, K, seed=5, scale=0.08)

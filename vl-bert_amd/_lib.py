@@ -16,6 +16,8 @@ _P, _L, _I, _F, _U = ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_floa
 # signature strings: p pointer | l long | i int | f float | u uint32 | s stream
 _SIGS = {
     "vlb_gemm_nt_bf16": "plplpliiipiplplplfpuiis",
+    "vlb_transpose_batched_bf16": "ppiis",
+    "vlb_gemm_nt_bf16_splitk": "plplpliiipls",
     "vlb_transpose_bf16": "plpliips",
     "vlb_wgrad_nt_bf16": "plplpliiipls",
     "vlb_wgrad_tn_bf16": "plplpliiippls",

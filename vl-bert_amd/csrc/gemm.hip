@@ -592,11 +592,10 @@ __global__ __launch_bounds__(128 * WGN, WGN) void gemm_tn_bf16_kernel(const Gemm
 // 8 rows x one column that builds a transposed 16-B chunk is then bank-conflict free.
 // Fast path needs 16-B aligned rows on both sides (ldi, ldo multiples of 8); otherwise scalar accesses.
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ in, long ldi, bf16_t* __restrict__ out,
-                                                             long ldo, int R, int C, float* __restrict__ colsum, int vec) {
+__device__ __forceinline__ void transpose_tile(const bf16_t* __restrict__ in, long ldi, bf16_t* __restrict__ out, long ldo, int R, int C,
+                                               float* __restrict__ colsum, int vec, int r0, int c0) {
   __shared__ __attribute__((aligned(16))) bf16_t tile[64 * 64];
   __shared__ float csum[4][64];
-  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
   const int tid = threadIdx.x, sub = tid & 7, grp = tid >> 3;  // 8 lanes per 128-B row segment, 32 row groups
   float cs[8];
 #pragma unroll
@@ -654,6 +653,30 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __res
     }
   }
   if (colsum && tid < 64 && c0 + tid < C) atomicAdd(colsum + c0 + tid, csum[0][tid] + csum[1][tid] + csum[2][tid] + csum[3][tid]);
+}
+
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ in, long ldi, bf16_t* __restrict__ out,
+                                                             long ldo, int R, int C, float* __restrict__ colsum, int vec) {
+  transpose_tile(in, ldi, out, ldo, R, C, colsum, vec, blockIdx.y * 64, blockIdx.x * 64);
+}
+
+// Many small transposes in ONE launch (the per-step refresh of the ~50 transposed weight copies the dgrad GEMMs read:
+// 5 us of launch + ramp each when issued one by one).  desc[m] = {in, ldi, out, ldo, R, C} (device, int64), tile_start[m] =
+// first 64x64 tile of matrix m in the flat grid (n+1 entries); a block finds its matrix by binary search.
+__global__ __launch_bounds__(256) void transpose_batched_kernel(const long* __restrict__ desc, const int* __restrict__ tile_start, int n) {
+  int lo = 0, hi = n;   // tile_start[lo] <= blockIdx.x < tile_start[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if ((int)blockIdx.x >= tile_start[mid]) lo = mid; else hi = mid;
+  }
+  const long* d = desc + 6 * lo;
+  const bf16_t* in = (const bf16_t*)d[0];
+  bf16_t* out = (bf16_t*)d[2];
+  const long ldi = d[1], ldo = d[3];
+  const int R = (int)d[4], C = (int)d[5];
+  const int t = blockIdx.x - tile_start[lo], tx = (C + 63) >> 6;
+  const int vec = ((ldi % 8) == 0 && (ldo % 8) == 0 && ((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0) ? 1 : 0;
+  transpose_tile(in, ldi, out, ldo, R, C, nullptr, vec, (t / tx) * 64, (t % tx) * 64);
 }
 
 // ------------------------------------------------------------------------------------
@@ -782,7 +805,8 @@ extern "C" int vlb_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb
 // traffic; splits == 1 accumulates straight into C (each tile owned by one workgroup, no atomics either).
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, long slab_stride, int splits,
-                                                            float* __restrict__ C, long ldc, int M, int N, int ldw) {
+                                                            float* __restrict__ C, long ldc, int M, int N, int ldw,
+                                                            bf16_t* __restrict__ Cb, long ldcb) {
   const int n4 = ldw >> 2;
   const long total = (long)M * n4;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -792,6 +816,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     for (int sp = 1; sp < splits; ++sp) {
       const float4 b = *(const float4*)(src + sp * slab_stride);
       a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    if (Cb) {   // bf16 result, overwritten (split-K dgrad)
+      bf16_t* c = Cb + (long)m * ldcb + n;
+      if (n + 3 < N) {
+        *(uint2*)c = make_uint2(pack2bf(a.x, a.y), pack2bf(a.z, a.w));
+      } else {
+        const float av[4] = {a.x, a.y, a.z, a.w};
+        for (int r = 0; r < 4 && n + r < N; ++r) c[r] = f2bf(av[r]);
+      }
+      continue;
     }
     float* c = C + (long)m * ldc + n;
     if (n + 3 < N) {
@@ -853,9 +887,41 @@ extern "C" int vlb_wgrad_nt_bf16(const void* A, long lda, const void* B, long ld
     long blocks = ((long)M * (ldw / 4) + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)blocks), dim3(256), 0, stream, workspace, (long)M * ldw, nsp, C, ldc, M, N,
-                       (int)ldw);
+                       (int)ldw, (bf16_t*)nullptr, 0L);
     VLB_CHECK_LAUNCH("vlb_wgrad_nt_bf16(reduce)");
   }
+  return VLB_OK;
+}
+
+// bf16 C[M,N] = A[M,K] B[N,K]^T for FEW output tiles and a very long K (the tied-decoder dgrad d_h = dlogits . E with
+// K = vocabulary, at small per-GPU batch: 96 tiles for 256 CUs): same slab split-K as the weight gradients, the
+// reduce kernel converts to bf16.  One K pass (splits == 1 or no workspace) falls through to the plain GEMM.
+extern "C" int vlb_gemm_nt_bf16_splitk(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
+                                       float* workspace, long workspace_floats, hipStream_t stream) {
+  if (M <= 0 || N <= 0) return VLB_OK;
+  VLB_CHECK_ARG(K > 0 && (K % 64) == 0, "vlb_gemm_nt_bf16_splitk: K=%d must be a positive multiple of 64", K);
+  VLB_CHECK_ARG(A && B && C, "vlb_gemm_nt_bf16_splitk: null operand");
+  VLB_CHECK_ARG((lda % 8) == 0 && (ldb % 8) == 0 && (ldc % 4) == 0, "vlb_gemm_nt_bf16_splitk: bad leading dimensions");
+  const int splits = wgrad_pick_splits(M, N, K, workspace ? workspace_floats : 0);
+  const int ktiles = K / 64;
+  const int per = vlb_cdiv(ktiles, splits);
+  const int nsp = vlb_cdiv(ktiles, per);
+  if (nsp <= 1)
+    return vlb_gemm_nt_bf16(A, lda, B, ldb, C, ldc, M, N, K, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0.f, nullptr, 0, 0, 0, stream);
+  const long ldw = (N + 3) / 4 * 4;
+  GemmParams p;
+  p.A = (const bf16_t*)A; p.lda = lda; p.B = (const bf16_t*)B; p.ldb = ldb;
+  p.M = M; p.N = N; p.K = K; p.k_per_split = per * 64;
+  p.bias = nullptr; p.act = 0; p.aux = nullptr; p.ldaux = 0; p.pre = nullptr; p.ldpre = 0; p.res = nullptr; p.ldres = 0;
+  p.drop_thr = 0; p.drop_scale = 1.f; p.seed = nullptr; p.tag = 0;
+  p.C = workspace; p.ldc = ldw; p.out_f32 = 1; p.c_split_stride = (long)M * ldw;
+  int rc = launch_gemm<128, 128>(p, nsp, stream);
+  if (rc) return rc;
+  long blocks = ((long)M * (ldw / 4) + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)blocks), dim3(256), 0, stream, workspace, (long)M * ldw, nsp, (float*)nullptr, 0L, M, N,
+                     (int)ldw, (bf16_t*)C, ldc);
+  VLB_CHECK_LAUNCH("vlb_gemm_nt_bf16_splitk(reduce)");
   return VLB_OK;
 }
 
@@ -898,7 +964,7 @@ extern "C" int vlb_wgrad_tn_bf16(const void* A, long lda, const void* B, long ld
     long blocks = ((long)Mo * (ldw / 4) + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)blocks), dim3(256), 0, stream, workspace, (long)Mo * ldw, nsp, C, ldc, Mo, No,
-                       (int)ldw);
+                       (int)ldw, (bf16_t*)nullptr, 0L);
     VLB_CHECK_LAUNCH("vlb_wgrad_tn_bf16(reduce)");
   }
   return VLB_OK;
@@ -913,5 +979,13 @@ extern "C" int vlb_transpose_bf16(const void* in, long ldi, void* out, long ldo,
   hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, stream, (const bf16_t*)in, ldi, (bf16_t*)out, ldo, R, C,
                      colsum, vec);
   VLB_CHECK_LAUNCH("vlb_transpose_bf16");
+  return VLB_OK;
+}
+
+extern "C" int vlb_transpose_batched_bf16(const int64_t* desc, const int32_t* tile_start, int n, int total_tiles, hipStream_t stream) {
+  if (n <= 0 || total_tiles <= 0) return VLB_OK;
+  VLB_CHECK_ARG(desc && tile_start, "vlb_transpose_batched_bf16: null descriptor table");
+  hipLaunchKernelGGL(transpose_batched_kernel, dim3(total_tiles), dim3(256), 0, stream, (const long*)desc, (const int*)tile_start, n);
+  VLB_CHECK_LAUNCH("vlb_transpose_batched_bf16");
   return VLB_OK;
 }

@@ -182,6 +182,7 @@ class PretrainEngine:
 
         # bf16 transposed weights for dgrad GEMMs (dX = dY . (W^T)^T); refreshed after every optimizer step
         self.wT = {}
+        self._tbatch = None
         for l in range(L):
             p = "vlbert.encoder.layer.%d." % l
             self.wT[p + "qkv"] = zb(H, 3 * H)
@@ -257,6 +258,7 @@ class PretrainEngine:
         need = [ops.wgrad_workspace_floats(n, k, rp) for n, k, rp in
                 ((3 * H, H, self.Mp), (H, H, self.Mp), (I, H, self.Mp), (H, I, self.Mp), (V, H, self.BTp), (H, H, self.BTp),
                  (C, H, self.BRp), (H, H, self.BRp), (H, 2 * VIS_DIM, self.BRp))]
+        need.append(ops.wgrad_workspace_floats(self.BT, H, self.Vp))     # tied-decoder dgrad (K = vocabulary) at small batch
         self.wg_ws = zf(max(max(need), 4))
         self.ln_ws = zf(ops.ln_bwd_workspace_floats(H))     # per-workgroup partial dgamma/dbeta sums of the LayerNorm backward
         self.graph = None
@@ -292,17 +294,22 @@ class PretrainEngine:
         self._weights_dirty = False
 
     def _refresh_transposes(self):
-        H, L = self.cfg.hidden_size, self.cfg.num_hidden_layers
-        for l in range(L):
-            p = "vlbert.encoder.layer.%d." % l
-            wqkv = self.P.view(self.P.w16, p + "attention.self.query.weight", (3 * H, H), span=3)
-            ops.transpose(wqkv, self.wT[p + "qkv"])
-            for n in ("attention.output.dense.weight", "intermediate.dense.weight", "output.dense.weight"):
-                ops.transpose(self.w16[p + n], self.wT[p + n])
-        for n in ("vlbert.mlm_head.predictions.transform.dense.weight", "vlbert.word_embeddings.weight",
-                  "vlbert.mvrc_head.transform.dense.weight", "vlbert.mvrc_head.region_cls_pred.weight",
-                  "image_feature_extractor.obj_downsample.1.weight"):
-            ops.transpose(self.w16[n], self.wT[n])
+        """bf16 W^T copies for the dgrad GEMMs (dX = dY W as an NT product): all ~50 of them in one launch."""
+        if self._tbatch is None:
+            H, L = self.cfg.hidden_size, self.cfg.num_hidden_layers
+            pairs = []
+            for l in range(L):
+                p = "vlbert.encoder.layer.%d." % l
+                wqkv = self.P.view(self.P.w16, p + "attention.self.query.weight", (3 * H, H), span=3)
+                pairs.append((wqkv, self.wT[p + "qkv"]))
+                for n in ("attention.output.dense.weight", "intermediate.dense.weight", "output.dense.weight"):
+                    pairs.append((self.w16[p + n], self.wT[p + n]))
+            for n in ("vlbert.mlm_head.predictions.transform.dense.weight", "vlbert.word_embeddings.weight",
+                      "vlbert.mvrc_head.transform.dense.weight", "vlbert.mvrc_head.region_cls_pred.weight",
+                      "image_feature_extractor.obj_downsample.1.weight"):
+                pairs.append((self.w16[n], self.wT[n]))
+            self._tbatch = ops.TransposeBatch(pairs, self.dev)
+        self._tbatch.run()
 
     # ------------------------------------------------------------------------------------------
     # batch
@@ -450,7 +457,7 @@ class PretrainEngine:
         pm = "vlbert.mlm_head.predictions."
         dlog = self.mlm_logits                       # [BT, Vp], pad columns zero
         self._wgrad(dlog[:, :V], self.mlm_h, g32["vlbert.word_embeddings.weight"], g32[pm + "bias"], self.tG_bt, self.tA_bt, BTp)
-        ops.gemm_nt(dlog, wT["vlbert.word_embeddings.weight"], self.d_mlm_h)
+        ops.gemm_nt_splitk(dlog, wT["vlbert.word_embeddings.weight"], self.d_mlm_h, workspace=self.wg_ws)
         ops.layernorm_bwd(self.d_mlm_h, self.mlm_g, self.st_mlm, w32[pm + "transform.LayerNorm.weight"], dx=self.d_mlm_g,
                           dgamma=g32[pm + "transform.LayerNorm.weight"], dbeta=g32[pm + "transform.LayerNorm.bias"],
                           workspace=self.ln_ws)

@@ -68,6 +68,35 @@ def wgrad_tn(dy, x, C, colsum=None, workspace=None):
     return C
 
 
+def gemm_nt_splitk(A, B, C, workspace=None):
+    """C (bf16) = A B^T with slab split-K when the output has too few tiles to fill the chip (long-K dgrad)."""
+    M, K = A.shape
+    N = B.shape[0]
+    _lib.call("vlb_gemm_nt_bf16_splitk", _p(A, BF16), _ld(A), _p(B, BF16), _ld(B), _p(C, BF16), _ld(C), M, N, K,
+              _p(workspace, torch.float32), workspace.numel() if workspace is not None else 0, _stream())
+    return C
+
+
+class TransposeBatch:
+    """Descriptor table for vlb_transpose_batched_bf16: built once for fixed (src, dst) buffer pairs, replayed every step."""
+
+    def __init__(self, pairs, device):
+        desc, starts, total = [], [0], 0
+        self.keep = list(pairs)                      # the tensors own the memory the raw pointers refer to
+        for src, dst in pairs:
+            R, C = src.shape
+            assert dst.shape[0] == C and dst.shape[1] >= R and src.dtype == BF16 and dst.dtype == BF16
+            desc.append([src.data_ptr(), _ld(src), dst.data_ptr(), _ld(dst), R, C])
+            total += ((R + 63) // 64) * ((C + 63) // 64)
+            starts.append(total)
+        self.n, self.total = len(desc), total
+        self.desc = torch.tensor(desc, dtype=torch.int64).to(device)
+        self.starts = torch.tensor(starts, dtype=torch.int32).to(device)
+
+    def run(self):
+        _lib.call("vlb_transpose_batched_bf16", self.desc.data_ptr(), self.starts.data_ptr(), self.n, self.total, _stream())
+
+
 def ln_bwd_workspace_floats(H):
     return int(_lib.load().vlb_layernorm_bwd_workspace_floats(H))
 
