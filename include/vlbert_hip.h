@@ -137,13 +137,16 @@ int vlb_embed_fwd(const int32_t* code, const int32_t* text_len, const int64_t* t
                   int P, float eps, float drop_p, const uint32_t* seed, uint32_t tag, vlb_stream_t stream);
 /* backward of the above: accumulates (fp32 atomics) into the embedding-table gradients and writes the
  * visual-part gradients (d_text_vis: per token, or per sample when dtv_st == 0; d_obj_vis per object;
- * d_obj_ling dense, or the [2,H] table gradient in obj_ling_idx mode). */
+ * d_obj_ling dense, or the [2,H] table gradient in obj_ling_idx mode).
+ * text_vis_zeroed != 0: the caller has zeroed d_text_vis, which lets several workgroups share one sample in the
+ * per-sample (dtv_st == 0) mode (their partial sums are then added atomically); 0 keeps one workgroup per sample. */
 int vlb_embed_bwd(const void* dy, const void* pre, const float* stats, const float* gamma, const int32_t* code,
                   const int32_t* text_len, const int64_t* text_ids, const int64_t* text_type,
                   const int64_t* obj_ling_idx, float* d_word, float* d_pos, float* d_type, float* d_end,
                   float* d_gamma, float* d_beta, float* d_text_vis, long dtv_sb, long dtv_st, float* d_obj_vis,
                   long dov_sb, long dov_sr, float* d_obj_ling, long dol_sb, long dol_sr, int B, int T, int R, int S,
-                  int H, int V, int P, float drop_p, const uint32_t* seed, uint32_t tag, vlb_stream_t stream);
+                  int H, int V, int P, float drop_p, const uint32_t* seed, uint32_t tag, int text_vis_zeroed,
+                  vlb_stream_t stream);
 /* out[i] = src[idx[i]] (rows of H bf16; idx < 0 -> zero row): text/object split of
  * visual_linguistic_bert.py:146-166 */
 int vlb_gather_rows(const void* src, const int32_t* idx, void* out, int n, int H, vlb_stream_t stream);

@@ -390,6 +390,15 @@ def test_seq_layout_and_embedding(ops):
     report("embed bwd d_text_vis", d_tv, tvr.grad.reshape(B, H), 2e-3, 1e-2)
     report("embed bwd d_obj_vis", d_ov, (ovr.grad * box_mask.unsqueeze(-1)).reshape(B * R, H), 2e-3, 1e-2)
     report("embed bwd d_obj_ling", d_ol, (olr.grad * box_mask.unsqueeze(-1)).reshape(B * R, H), 2e-3, 1e-2)
+    # several workgroups per sample (the caller vouches that d_text_vis is zero): same results
+    d_word2, d_pos2, d_type2, d_end2, d_g2, d_b2 = z(V, H), z(P, H), z(3, H), z(1, H), z(H), z(H)
+    d_tv2, d_ov2, d_ol2 = z(B, H), z(B * R, H), z(B * R, H)
+    ops.embed_bwd(to_gpu_bf16((dy * valid).reshape(B * S, H)), pre, stats, p["vlbert.embedding_LayerNorm.weight"].to(d), lay,
+                  text.to(d), None, None, d_word2, d_pos2, d_type2, d_end2, d_g2, d_b2, d_tv2, (H, 0), d_ov2, (R * H, H), d_ol2,
+                  (R * H, H), B, T, R, S, H, text_vis_zeroed=True)
+    for name, a, b in (("d_word", d_word2, d_word), ("d_pos", d_pos2, d_pos), ("d_type", d_type2, d_type), ("d_end", d_end2, d_end),
+                       ("d_gamma", d_g2, d_g), ("d_beta", d_b2, d_b), ("d_text_vis", d_tv2, d_tv), ("d_obj_vis", d_ov2, d_ov)):
+        report("embed bwd split " + name, a, b.cpu(), 1e-4, 1e-4)
     # table mode for the linguistic part
     table = bf(0.05 * torch.randn(2, H, generator=g))
     sel = mvrc_ops.clone()

@@ -29,7 +29,7 @@ _SIGS = {
     "vlb_obj_prep_fwd": "plppppiifpus",
     "vlb_masked_colsum": "plpiipfpuuus",
     "vlb_embed_fwd": "pppp" "pppp" "pll" "pll" "pll" "p" "pp" "ppp" "iiiiiii" "f" "fpu" "s",
-    "vlb_embed_bwd": "pppp" "ppppp" "pppppp" "pll" "pll" "pll" "iiiiiii" "fpu" "s",
+    "vlb_embed_bwd": "pppp" "ppppp" "pppppp" "pll" "pll" "pll" "iiiiiii" "fpu" "i" "s",
     "vlb_gather_rows": "pppiis",
     "vlb_head_grad_combine": "ppppiiiiis",
     "vlb_relu_bwd_cast": "pppls",

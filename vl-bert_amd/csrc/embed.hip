@@ -306,7 +306,9 @@ __global__ __launch_bounds__(512) void embed_bwd_kernel(const EmbedBwdParams p) 
 #pragma unroll
     for (int k = 0; k < 4; ++k) gs[i][k] = bs[i][k] = 0.f;
 
-  for (int s = wave; s < p.S; s += nwave) {
+  // gridDim.y workgroups share one sample: each takes a contiguous chunk of its S rows
+  const int rows_per = (p.S + gridDim.y - 1) / gridDim.y, s_lo = blockIdx.y * rows_per, s_hi = min(p.S, s_lo + rows_per);
+  for (int s = s_lo + wave; s < s_hi; s += nwave) {
     const long row = (long)b * p.S + s;
     const int code = p.code[row], kind = code >> 16, idx = code & 0xffff;
     if (kind == KIND_PAD) continue;  // pad rows never reach a loss; their dy is exactly zero
@@ -423,7 +425,10 @@ __global__ __launch_bounds__(512) void embed_bwd_kernel(const EmbedBwdParams p) 
     for (int t = 0; t < 3; ++t)
       if (l_type[t * LWD + q] != 0.f) atomicAdd(p.d_type + t * H + c, l_type[t * LWD + q]);
     if (l_objpos[q] != 0.f) atomicAdd(p.d_pos + (long)pos_obj * H + c, l_objpos[q]);
-    if (p.d_text_vis && p.dtv_st == 0) p.d_text_vis[b * p.dtv_sb + c] = l_tv[q];
+    if (p.d_text_vis && p.dtv_st == 0) {   // per-sample sum over the text rows: plain store when one workgroup owns the sample
+      if (gridDim.y == 1) p.d_text_vis[b * p.dtv_sb + c] = l_tv[q];
+      else if (l_tv[q] != 0.f) atomicAdd(p.d_text_vis + b * p.dtv_sb + c, l_tv[q]);
+    }
     if (p.obj_ling_idx && p.d_obj_ling) {
       if (l_tab[q] != 0.f) atomicAdd(p.d_obj_ling + c, l_tab[q]);
       if (l_tab[LWD + q] != 0.f) atomicAdd(p.d_obj_ling + H + c, l_tab[LWD + q]);
@@ -573,7 +578,8 @@ extern "C" int vlb_embed_bwd(const void* dy, const void* pre, const float* stats
                              const int64_t* obj_ling_idx, float* d_word, float* d_pos, float* d_type, float* d_end,
                              float* d_gamma, float* d_beta, float* d_text_vis, long dtv_sb, long dtv_st, float* d_obj_vis,
                              long dov_sb, long dov_sr, float* d_obj_ling, long dol_sb, long dol_sr, int B, int T, int R, int S,
-                             int H, int V, int P, float drop_p, const uint32_t* seed, uint32_t tag, hipStream_t stream) {
+                             int H, int V, int P, float drop_p, const uint32_t* seed, uint32_t tag, int text_vis_zeroed,
+                             hipStream_t stream) {
   VLB_CHECK_ARG(H > 0 && (H % 4) == 0 && H <= 256 * EMB_MAX_IT, "vlb_embed_bwd: unsupported H=%d", H);
   VLB_CHECK_ARG(dy && pre && stats && gamma && code && text_len && text_ids && d_word && d_pos && d_type && d_end && d_gamma &&
                     d_beta, "vlb_embed_bwd: null input");
@@ -590,12 +596,21 @@ extern "C" int vlb_embed_bwd(const void* dy, const void* pre, const float* stats
   VLB_CHECK_ARG((dtv_sb % 4) == 0 && (dtv_st % 4) == 0 && (dov_sb % 4) == 0 && (dov_sr % 4) == 0 && (dol_sb % 4) == 0 &&
                     (dol_sr % 4) == 0, "vlb_embed_bwd: output strides must be multiples of 4 floats");
   const int nit = vlb_cdiv(H, 256);
+  // small batches: several workgroups per sample so that >= ~512 are in flight (needs d_text_vis zeroed by the caller
+  // in the broadcast mode, where the per-sample sum is then accumulated with atomics)
+  int split = 1;
+  if (d_text_vis == nullptr || dtv_st != 0 || text_vis_zeroed) {
+    split = vlb_cdiv(512, B);
+    if (split > 8) split = 8;
+    if (split > S) split = S;
+    if (split < 1) split = 1;
+  }
 #define EMB_BWD(NIT)                                                                                                         \
   do {                                                                                                                       \
     constexpr int smem = (9 + 8) * NIT * 256 * (int)sizeof(float);                                                                 \
     if (smem > 48 * 1024)                                                                                                    \
       (void)hipFuncSetAttribute((const void*)embed_bwd_kernel<NIT>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);       \
-    hipLaunchKernelGGL(embed_bwd_kernel<NIT>, dim3(B), dim3(512), smem, stream, p);                                          \
+    hipLaunchKernelGGL(embed_bwd_kernel<NIT>, dim3(B, split), dim3(512), smem, stream, p);                                   \
   } while (0)
   if (nit <= 1) EMB_BWD(1); else if (nit == 2) EMB_BWD(2); else if (nit == 3) EMB_BWD(3); else if (nit == 4) EMB_BWD(4); else EMB_BWD(8);
 #undef EMB_BWD

@@ -515,13 +515,14 @@ class PretrainEngine:
         # --- embedding + visual LayerNorms + obj_downsample ---------------------------------------------
         self.d_objvis.zero_()
         self.d_obj_reps.zero_()
+        self.d_textvis.zero_()
         pe = "vlbert.embedding_LayerNorm."
         ops.embed_bwd(dx, self.emb_pre, self.st_emb, w32[pe + "weight"], self.lay, self.in_text, None, self.in_mvrc_ops,
                       g32["vlbert.word_embeddings.weight"], g32["vlbert.position_embeddings.weight"],
                       g32["vlbert.token_type_embeddings.weight"], g32["vlbert.end_embedding.weight"], g32[pe + "weight"],
                       g32[pe + "bias"], self.d_textvis, (H, 0), self.d_objvis, (R * H, H),
                       self.P.view(self.P.grad, "object_linguistic_embeddings.weight", (2, H), span=2), (0, 0), Bt, T, R, S, H,
-                      drop_p=p_h, seed=seed, tag=TAG_EMBED)
+                      drop_p=p_h, seed=seed, tag=TAG_EMBED, text_vis_zeroed=True)
         ops.layernorm_bwd(self.d_objvis, self.obj_reps, self.st_objvis, w32["vlbert.visual_ln_object.weight"],
                           dx_acc=self.d_obj_reps, dgamma=g32["vlbert.visual_ln_object.weight"],
                           dbeta=g32["vlbert.visual_ln_object.bias"], workspace=self.ln_ws)
