@@ -70,9 +70,10 @@ int vlb_wgrad_nt_bf16(const void* A, long lda, const void* B, long ldb, float* C
 
 /* Same product taken straight from the row-major tensors the forward/backward passes already hold:
  * C[Mo,No] (fp32) += A[R,Mo]^T * B[R,No] (reduction over the R rows; LDS transpose reads, no transposed copies);
- * colsum[Mo] += column sums of A when non-NULL (the bias gradient).  lda/ldb % 8 == 0, 16-byte aligned operands. */
+ * colsum[Mo] += column sums of A when non-NULL (the bias gradient).  lda/ldb % 8 == 0, 16-byte aligned operands.
+ * accumulate == 0 overwrites C instead (first micro-batch of an optimizer step: no zero fill, no read-modify-write). */
 int vlb_wgrad_tn_bf16(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int R, int Mo, int No,
-                      float* colsum, float* workspace, long workspace_floats, vlb_stream_t stream);
+                      float* colsum, float* workspace, long workspace_floats, int accumulate, vlb_stream_t stream);
 
 /* out[c][r] = in[r][c] (bf16, out leading dim ldo >= R); colsum[c] += sum_r in[r][c] if non-NULL
  * (bias gradients).  Feeds the weight-gradient GEMMs (autograd's `grad.t().mm(input)`). */
@@ -178,6 +179,11 @@ int vlb_soft_ce_fwd_bwd(void* logits, long ld, int rows, int C, const float* tar
  * vlb_sumsq_f32 accumulates sum(g^2) into *out (point it at &state[7]); vlb_adamw_step applies
  * clip coef = min(1, max_norm/(sqrt(sumsq)*grad_scale+1e-6)) * grad_scale, updates p/m/v, writes
  * the bf16 copy, then increments step and zeroes sumsq. */
+/* zero n ranges of one fp32 buffer in one launch: ranges (device) = n x {start, length} int64, block_start (device, n+1
+ * int32) = running count of 1024-float blocks, block_start[n] == total_blocks.  Used for the gradients that are accumulated by
+ * atomics (biases, LayerNorm parameters, small tables) when the GEMM weight gradients are written with accumulate = 0. */
+int vlb_zero_ranges_f32(float* base, const int64_t* ranges, const int32_t* block_start, int n, int total_blocks, vlb_stream_t stream);
+
 int vlb_sumsq_f32(const float* g, long n, float* out, vlb_stream_t stream);
 int vlb_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, long n, float* state, float grad_scale,
                    vlb_stream_t stream);

@@ -178,6 +178,19 @@ def test_wgrad_tn_lds_transpose_reads(ops, R, Mo, No):
     report("wgrad TN colsum", db, 1 + dY.sum(0), 1e-3, 1e-5)
     if ldc > No:
         assert float(C[:, No:].abs().max()) == 0.0
+    # overwrite mode: previous contents (here: the accumulated result) are ignored, the bias sum still accumulates
+    ops.wgrad_tn(dYg[:, :Mo], Xg[:, :No], C[:, :No], colsum=db, workspace=work, accumulate=False)
+    report("wgrad TN overwrite %dx%dx%d" % (R, Mo, No), C[:, :No], dY.t() @ X, 1e-3, 2e-5)
+    report("wgrad TN colsum (2nd)", db, 1 + 2 * dY.sum(0), 1e-3, 2e-5)
+    if ldc > No:
+        assert float(C[:, No:].abs().max()) == 0.0
+    # ranged zero helper
+    buf = torch.ones(5000, device=dev())
+    zr = ops.ZeroRanges(buf, [(0, 3), (10, 10), (17, 1100), (4000, 5000)])
+    zr.run()
+    ref = torch.ones(5000)
+    ref[0:3] = 0; ref[17:1100] = 0; ref[4000:] = 0
+    assert torch.equal(buf.cpu(), ref)
 
 
 def test_gemm_dropout_and_ln_mask_agree(ops):

@@ -20,7 +20,8 @@ _SIGS = {
     "vlb_gemm_nt_bf16_splitk": "plplpliiipls",
     "vlb_transpose_bf16": "plpliips",
     "vlb_wgrad_nt_bf16": "plplpliiipls",
-    "vlb_wgrad_tn_bf16": "plplpliiippls",
+    "vlb_wgrad_tn_bf16": "plplpliiipplis",
+    "vlb_zero_ranges_f32": "pppiis",
     "vlb_layernorm_fwd": "plppplpiifs",
     "vlb_layernorm_bwd": "pliplppplplfpuplpppiis",
     "vlb_attention_fwd": "ppppiiiifpus",

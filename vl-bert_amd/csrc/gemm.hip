@@ -806,7 +806,7 @@ extern "C" int vlb_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, long slab_stride, int splits,
                                                             float* __restrict__ C, long ldc, int M, int N, int ldw,
-                                                            bf16_t* __restrict__ Cb, long ldcb) {
+                                                            bf16_t* __restrict__ Cb, long ldcb, int accumulate) {
   const int n4 = ldw >> 2;
   const long total = (long)M * n4;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -829,11 +829,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
     float* c = C + (long)m * ldc + n;
     if (n + 3 < N) {
-      const float4 o = *(const float4*)c;
-      *(float4*)c = make_float4(o.x + a.x, o.y + a.y, o.z + a.z, o.w + a.w);
+      if (accumulate) {
+        const float4 o = *(const float4*)c;
+        a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+      }
+      *(float4*)c = a;
     } else {
       const float av[4] = {a.x, a.y, a.z, a.w};
-      for (int r = 0; r < 4 && n + r < N; ++r) c[r] += av[r];
+      for (int r = 0; r < 4 && n + r < N; ++r) c[r] = accumulate ? c[r] + av[r] : av[r];
     }
   }
 }
@@ -887,7 +890,7 @@ extern "C" int vlb_wgrad_nt_bf16(const void* A, long lda, const void* B, long ld
     long blocks = ((long)M * (ldw / 4) + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)blocks), dim3(256), 0, stream, workspace, (long)M * ldw, nsp, C, ldc, M, N,
-                       (int)ldw, (bf16_t*)nullptr, 0L);
+                       (int)ldw, (bf16_t*)nullptr, 0L, 1);
     VLB_CHECK_LAUNCH("vlb_wgrad_nt_bf16(reduce)");
   }
   return VLB_OK;
@@ -920,14 +923,15 @@ extern "C" int vlb_gemm_nt_bf16_splitk(const void* A, long lda, const void* B, l
   long blocks = ((long)M * (ldw / 4) + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)blocks), dim3(256), 0, stream, workspace, (long)M * ldw, nsp, (float*)nullptr, 0L, M, N,
-                     (int)ldw, (bf16_t*)C, ldc);
+                     (int)ldw, (bf16_t*)C, ldc, 0);
   VLB_CHECK_LAUNCH("vlb_gemm_nt_bf16_splitk(reduce)");
   return VLB_OK;
 }
 
-// dW[Mo,No] (fp32) += A[R,Mo]^T B[R,No]; optional colsum[Mo] += column sums of A (bias gradient).
+// dW[Mo,No] (fp32) (+)= A[R,Mo]^T B[R,No]; optional colsum[Mo] += column sums of A (bias gradient).
+// accumulate == 0 overwrites dW (first micro-batch of an optimizer step: no zero fill and no read-modify-write).
 extern "C" int vlb_wgrad_tn_bf16(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int R, int Mo, int No,
-                                 float* colsum, float* workspace, long workspace_floats, hipStream_t stream) {
+                                 float* colsum, float* workspace, long workspace_floats, int accumulate, hipStream_t stream) {
   if (Mo <= 0 || No <= 0 || R <= 0) return VLB_OK;
   VLB_CHECK_ARG(A && B && C, "vlb_wgrad_tn_bf16: null operand");
   VLB_CHECK_ARG((lda % 8) == 0 && (ldb % 8) == 0 && (ldc % 4) == 0 && lda >= 8 && ldb >= 8, "vlb_wgrad_tn_bf16: bad leading dimensions");
@@ -944,7 +948,7 @@ extern "C" int vlb_wgrad_tn_bf16(const void* A, long lda, const void* B, long ld
   p.bias = nullptr; p.act = 0; p.aux = nullptr; p.ldaux = 0; p.pre = nullptr; p.ldpre = 0; p.res = nullptr; p.ldres = 0;
   p.drop_thr = 0; p.drop_scale = 1.f; p.seed = nullptr; p.tag = 0;
   if (nsp == 1) {
-    p.C = C; p.ldc = ldc; p.out_f32 = 3; p.c_split_stride = 0;
+    p.C = C; p.ldc = ldc; p.out_f32 = accumulate ? 3 : 1; p.c_split_stride = 0;
   } else {
     p.C = workspace; p.ldc = ldw; p.out_f32 = 1; p.c_split_stride = (long)Mo * ldw;
   }
@@ -964,7 +968,7 @@ extern "C" int vlb_wgrad_tn_bf16(const void* A, long lda, const void* B, long ld
     long blocks = ((long)Mo * (ldw / 4) + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)blocks), dim3(256), 0, stream, workspace, (long)Mo * ldw, nsp, C, ldc, Mo, No,
-                       (int)ldw, (bf16_t*)nullptr, 0L);
+                       (int)ldw, (bf16_t*)nullptr, 0L, accumulate);
     VLB_CHECK_LAUNCH("vlb_wgrad_tn_bf16(reduce)");
   }
   return VLB_OK;

@@ -161,3 +161,32 @@ extern "C" int vlb_rng_advance(uint32_t* seed, hipStream_t stream) {
   VLB_CHECK_LAUNCH("vlb_rng_advance");
   return VLB_OK;
 }
+
+// Zero several ranges of one fp32 buffer in a single launch (the gradients that are ACCUMULATED by atomics -- biases,
+// LayerNorm parameters, small embedding tables -- while the GEMM weight gradients are overwritten by their producer).
+// ranges (device int64): n x {start, length}; block_start (device int32, n+1): running count of 1024-float blocks.
+__global__ __launch_bounds__(256) void zero_ranges_kernel(float* __restrict__ base, const long* __restrict__ ranges,
+                                                          const int* __restrict__ block_start, int n) {
+  int lo = 0, hi = n;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if ((int)blockIdx.x >= block_start[mid]) lo = mid; else hi = mid;
+  }
+  const long start = ranges[2 * lo], len = ranges[2 * lo + 1];
+  const long i = (long)(blockIdx.x - block_start[lo]) * 1024 + threadIdx.x * 4;
+  float* q = base + start + i;
+  if (i + 3 < len && ((uintptr_t)q % 16) == 0) {
+    *(float4*)q = make_float4(0.f, 0.f, 0.f, 0.f);
+  } else {
+    for (int k = 0; k < 4 && i + k < len; ++k) q[k] = 0.f;
+  }
+}
+
+extern "C" int vlb_zero_ranges_f32(float* base, const int64_t* ranges, const int32_t* block_start, int n, int total_blocks,
+                                   hipStream_t stream) {
+  if (n <= 0 || total_blocks <= 0) return VLB_OK;
+  VLB_CHECK_ARG(base && ranges && block_start, "vlb_zero_ranges_f32: null argument");
+  hipLaunchKernelGGL(zero_ranges_kernel, dim3(total_blocks), dim3(256), 0, stream, base, (const long*)ranges, (const int*)block_start, n);
+  VLB_CHECK_LAUNCH("vlb_zero_ranges_f32");
+  return VLB_OK;
+}

@@ -183,6 +183,7 @@ class PretrainEngine:
         # bf16 transposed weights for dgrad GEMMs (dX = dY . (W^T)^T); refreshed after every optimizer step
         self.wT = {}
         self._tbatch = None
+        self._zero_small, self._fresh_grads = None, False
         for l in range(L):
             p = "vlbert.encoder.layer.%d." % l
             self.wT[p + "qkv"] = zb(H, 3 * H)
@@ -437,7 +438,7 @@ class PretrainEngine:
     def _wgrad(self, dy, x, gw, gb, tG, tA, rows_p):
         """gw[N,K] += dy^T x ; gb[N] += colsum(dy) through zero-padded transposes."""
         if self.use_tn_wgrad:   # straight from the row-major operands (LDS transpose reads), bias gradient fused
-            ops.wgrad_tn(dy, x, gw, colsum=gb, workspace=self.wg_ws)
+            ops.wgrad_tn(dy, x, gw, colsum=gb, workspace=self.wg_ws, accumulate=not self._fresh_grads)
             return
         N, K = dy.shape[1], x.shape[1]
         tg, ta = tG[:N, :rows_p], tA[:K, :rows_p]
@@ -542,6 +543,7 @@ class PretrainEngine:
         ops.gemm_nt(self.d_yds, wT[pd + "weight"][VIS_DIM:], self.d_afeat)
         ops.masked_colsum(self.d_afeat, self.in_mvrc_ops.view(-1), g32["object_mask_visual_embedding.weight"].view(-1),
                           drop_p=p_ds, seed=seed, tag=TAG_DOWNSAMPLE, row_elems=2 * VIS_DIM, col_off=VIS_DIM)
+        self._fresh_grads = False       # a further backward before the next zero_grad() accumulates
         if on_layer_done:
             on_layer_done("embed")
 
@@ -549,7 +551,33 @@ class PretrainEngine:
     # optimizer
     # ------------------------------------------------------------------------------------------
     def zero_grad(self):
-        self.P.grad.zero_()
+        """Start of an optimizer step.  With the TN weight-gradient path the Linear weight gradients (97 % of the buffer)
+        are OVERWRITTEN by the first backward, so only the ranges that are accumulated with atomics are cleared."""
+        if not self.use_tn_wgrad:
+            self.P.grad.zero_()
+            return
+        if self._zero_small is None:
+            covered = sorted((self.P.offsets[n], self.P.offsets[n] + math.prod(self.P.shapes[n])) for n in self._gemm_weight_names())
+            ranges, cur = [], 0
+            for lo, hi in covered:
+                ranges.append((cur, lo))
+                cur = hi
+            ranges.append((cur, self.P.numel))
+            self._zero_small = ops.ZeroRanges(self.P.grad, ranges)
+        self._zero_small.run()
+        self._fresh_grads = True
+
+    def _gemm_weight_names(self):
+        """Parameters whose gradient is produced (whole tensor) by exactly one _wgrad call per backward."""
+        L = self.cfg.num_hidden_layers
+        names = ["image_feature_extractor.obj_downsample.1.weight", "vlbert.word_embeddings.weight",
+                 "vlbert.mlm_head.predictions.transform.dense.weight", "vlbert.mvrc_head.transform.dense.weight",
+                 "vlbert.mvrc_head.region_cls_pred.weight"]
+        for l in range(L):
+            p = "vlbert.encoder.layer.%d." % l
+            names += [p + "attention.self.query.weight", p + "attention.self.key.weight", p + "attention.self.value.weight",
+                      p + "attention.output.dense.weight", p + "intermediate.dense.weight", p + "output.dense.weight"]
+        return names
 
     def optimizer_step(self, lr=None):
         """global-norm clip + AdamW + bf16 / transposed weight refresh + dropout seed advance.  With data

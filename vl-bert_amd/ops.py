@@ -58,14 +58,38 @@ def wgrad_nt(A, B, C, workspace=None):
     return C
 
 
-def wgrad_tn(dy, x, C, colsum=None, workspace=None):
-    """C[Mo,No] (fp32) += dy[R,Mo]^T x[R,No]  (+ colsum[Mo] += dy.sum(0)); operands as the passes left them."""
+def wgrad_tn(dy, x, C, colsum=None, workspace=None, accumulate=True):
+    """C[Mo,No] (fp32) (+)= dy[R,Mo]^T x[R,No]  (+ colsum[Mo] += dy.sum(0)); operands as the passes left them.
+    accumulate=False overwrites C (colsum is always accumulated)."""
     Mo, No = C.shape
     R = dy.shape[0]
     assert dy.shape[1] == Mo and x.shape[1] == No and x.shape[0] == R
     _lib.call("vlb_wgrad_tn_bf16", _p(dy, BF16), _ld(dy), _p(x, BF16), _ld(x), _p(C, torch.float32), _ld(C), R, Mo, No,
-              _p(colsum, torch.float32), _p(workspace, torch.float32), workspace.numel() if workspace is not None else 0, _stream())
+              _p(colsum, torch.float32), _p(workspace, torch.float32), workspace.numel() if workspace is not None else 0,
+              int(bool(accumulate)), _stream())
     return C
+
+
+class ZeroRanges:
+    """Zeroes a fixed set of [lo, hi) ranges of one fp32 buffer in one launch (vlb_zero_ranges_f32)."""
+
+    def __init__(self, base, ranges):
+        self.base = base
+        rows, starts, total = [], [0], 0
+        for lo, hi in ranges:
+            if hi <= lo:
+                continue
+            rows.append([lo, hi - lo])
+            total += (hi - lo + 1023) // 1024
+            starts.append(total)
+        self.n, self.total = len(rows), total
+        self.ranges = torch.tensor(rows, dtype=torch.int64).to(base.device) if rows else None
+        self.starts = torch.tensor(starts, dtype=torch.int32).to(base.device)
+
+    def run(self):
+        if self.n:
+            _lib.call("vlb_zero_ranges_f32", _p(self.base, torch.float32), self.ranges.data_ptr(), self.starts.data_ptr(), self.n,
+                      self.total, _stream())
 
 
 def gemm_nt_splitk(A, B, C, workspace=None):
