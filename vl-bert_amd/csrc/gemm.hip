@@ -427,41 +427,90 @@ __device__ __attribute__((aligned(16))) uint4 vlb_zero16[2];
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
-__device__ __forceinline__ bf16x8 lds_tr_frag(const char* base, int addr_lo, int addr_hi) {
-  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + addr_lo));
-  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + addr_hi));
+// The transpose reads are INLINE ASM: for the compiler-visible builtin hipcc orders every read behind ALL pending
+// LDS-DMA (s_waitcnt vmcnt(0) at the top of the K loop, right after the next stage's loads were issued), which
+// serialised "fetch stage k+1" and "compute stage k" -- the TN kernel ran 25 % below the NT kernel for that reason.
+// The asm reads are ordered by the workgroup barrier that published the stage; their results are released to the MFMAs
+// by explicit lgkmcnt waits (LDS returns in order; a pending scalar load can only make a counted wait conservative).
+template <int OFF>
+__device__ __forceinline__ void lds_tr_read(s16x4& dst, uint32_t vaddr) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(vaddr), "n"(OFF));
+}
+
+template <int KS, int IMG_OFF, int N>   // the N fragments of k-step KS of one operand image: rows +0..3 (lo) and +4..7 (hi)
+__device__ __forceinline__ void tn_issue(s16x4 (&lo)[N], s16x4 (&hi)[N], const uint32_t (&va)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    lds_tr_read<IMG_OFF + KS * 32 * 256>(lo[i], va[i]);
+    lds_tr_read<IMG_OFF + KS * 32 * 256 + 4 * 256>(hi[i], va[i]);
+  }
+}
+
+template <int CNT, int NA, int NB>   // s_waitcnt lgkmcnt(CNT); the fragments it releases are tied in as operands
+__device__ __forceinline__ void tn_wait(s16x4 (&alo)[NA], s16x4 (&ahi)[NA], s16x4 (&blo)[NB], s16x4 (&bhi)[NB]) {
+  static_assert(NA == 4 && (NB == 2 || NB == 4), "written out for 4 A and 2|4 B fragments");
+  if constexpr (NB == 2) {
+    asm volatile("s_waitcnt lgkmcnt(%12)"
+                 : "+v"(alo[0]), "+v"(ahi[0]), "+v"(alo[1]), "+v"(ahi[1]), "+v"(alo[2]), "+v"(ahi[2]), "+v"(alo[3]), "+v"(ahi[3]),
+                   "+v"(blo[0]), "+v"(bhi[0]), "+v"(blo[1]), "+v"(bhi[1])
+                 : "n"(CNT));
+  } else {
+    asm volatile("s_waitcnt lgkmcnt(%16)"
+                 : "+v"(alo[0]), "+v"(ahi[0]), "+v"(alo[1]), "+v"(ahi[1]), "+v"(alo[2]), "+v"(ahi[2]), "+v"(alo[3]), "+v"(ahi[3]),
+                   "+v"(blo[0]), "+v"(bhi[0]), "+v"(blo[1]), "+v"(bhi[1]), "+v"(blo[2]), "+v"(bhi[2]), "+v"(blo[3]), "+v"(bhi[3])
+                 : "n"(CNT));
+  }
+}
+
+__device__ __forceinline__ bf16x8 tn_frag(s16x4 lo, s16x4 hi) {
   typedef __attribute__((ext_vector_type(8))) short s16x8;
   const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
   return __builtin_bit_cast(bf16x8, v);
 }
 
 template <bool COLSUM, int FN>
-__device__ __forceinline__ void tn_compute_stage(const char* sa, const char* sb, int lane_off, const int (&a_cb)[4], const int (&b_cb)[FN],
-                                                 f32x4 (&acc)[4][FN], float (&csum)[4]) {
+__device__ __forceinline__ void tn_mfma_step(s16x4 (&alo)[4], s16x4 (&ahi)[4], s16x4 (&blo)[FN], s16x4 (&bhi)[FN], f32x4 (&acc)[4][FN],
+                                             float (&csum)[4]) {
+  bf16x8 af[4], bfr[FN];
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    const int base = lane_off + ks * 32 * 256;
-    bf16x8 af[4], bfr[FN];
+  for (int i = 0; i < 4; ++i) af[i] = tn_frag(alo[i], ahi[i]);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) af[i] = lds_tr_frag(sa, base + a_cb[i], base + 4 * 256 + a_cb[i]);
+  for (int j = 0; j < FN; ++j) bfr[j] = tn_frag(blo[j], bhi[j]);
+  if (COLSUM) {
 #pragma unroll
-    for (int j = 0; j < FN; ++j) bfr[j] = lds_tr_frag(sb, base + b_cb[j], base + 4 * 256 + b_cb[j]);
-    if (COLSUM) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const uint4 w = __builtin_bit_cast(uint4, af[i]);
-        csum[i] += (bflo(w.x) + bfhi(w.x)) + (bflo(w.y) + bfhi(w.y)) + (bflo(w.z) + bfhi(w.z)) + (bflo(w.w) + bfhi(w.w));
-      }
+    for (int i = 0; i < 4; ++i) {
+      const uint4 w = __builtin_bit_cast(uint4, af[i]);
+      csum[i] += (bflo(w.x) + bfhi(w.x)) + (bflo(w.y) + bfhi(w.y)) + (bflo(w.z) + bfhi(w.z)) + (bflo(w.w) + bfhi(w.w));
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < FN; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
   }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
 }
 
-template <int WGN>   // 2 x WGN waves: WGN = 4 -> 8 waves of 64x32 (two 8-wave workgroups per CU hide LDS/barrier latency)
+// one stage = 64 reduction rows = 2 k-steps; va / vb: per-fragment LDS byte addresses inside the stage's A image
+// (the B image follows at +16 KiB, folded into the instruction offsets)
+template <bool COLSUM, int FN>
+__device__ __forceinline__ void tn_compute_stage(const uint32_t (&va)[4], const uint32_t (&vb)[FN], f32x4 (&acc)[4][FN], float (&csum)[4]) {
+  constexpr int IMG = 64 * 128 * 2;
+  s16x4 alo[2][4], ahi[2][4], blo[2][FN], bhi[2][FN];
+  tn_issue<0, 0, 4>(alo[0], ahi[0], va);
+  tn_issue<0, IMG, FN>(blo[0], bhi[0], vb);
+  tn_issue<1, 0, 4>(alo[1], ahi[1], va);
+  tn_issue<1, IMG, FN>(blo[1], bhi[1], vb);
+  // k-step 0 is complete once at most k-step 1's 2*(4+FN) reads are outstanding (lgkmcnt is a 4-bit counter: <= 15)
+  tn_wait<(2 * (4 + FN) <= 15 ? 2 * (4 + FN) : 0), 4, FN>(alo[0], ahi[0], blo[0], bhi[0]);
+  tn_mfma_step<COLSUM, FN>(alo[0], ahi[0], blo[0], bhi[0], acc, csum);
+  __builtin_amdgcn_sched_barrier(0);   // keep k-step 0's MFMAs in front of the second wait (they cover k-step 1's LDS latency)
+  tn_wait<0, 4, FN>(alo[1], ahi[1], blo[1], bhi[1]);
+  tn_mfma_step<COLSUM, FN>(alo[1], ahi[1], blo[1], bhi[1], acc, csum);
+  __builtin_amdgcn_sched_barrier(0);   // ... and all MFMAs in front of the stage barrier, whose vmcnt(0) they overlap
+}
+
+// OUT: 1 fp32 store (split-K slab, or overwrite) | 3 fp32 accumulate -- one instantiation each, like the NT kernels
+template <int WGN, int OUT>   // 2 x WGN waves: WGN = 4 -> 8 waves of 64x32 (two 8-wave workgroups per CU hide LDS/barrier latency)
 __global__ __launch_bounds__(128 * WGN, WGN) void gemm_tn_bf16_kernel(const GemmParams p, float* __restrict__ colsum) {
   constexpr int BM = 128, BN = 128, BR = 64;          // output tile, reduction rows per stage
   constexpr int NT = 128 * WGN, NIT = 1024 / NT;      // threads, 16-B chunks per thread per operand image
@@ -542,11 +591,12 @@ __global__ __launch_bounds__(128 * WGN, WGN) void gemm_tn_bf16_kernel(const Gemm
   const int L = lane & 15, g = lane >> 4;
   const int fl = (L >> 2) | ((g & 1) << 2);
   const int lane_off = (8 * g + (L >> 2)) * 256 + (L & 3) * 8;    // + 32*256*ks, + 4*256 for the high half
-  int a_cb[FM], b_cb[FN];
+  const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(smem);
+  uint32_t a_fo[FM], b_fo[FN];   // fragment byte offsets inside an operand image: lane part + swizzled 32-B column block
 #pragma unroll
-  for (int i = 0; i < FM; ++i) a_cb[i] = (((wm * 4 + i) ^ fl) << 5);
+  for (int i = 0; i < FM; ++i) a_fo[i] = lds0 + lane_off + (((wm * 4 + i) ^ fl) << 5);
 #pragma unroll
-  for (int j = 0; j < FN; ++j) b_cb[j] = (((wn * FN + j) ^ fl) << 5);
+  for (int j = 0; j < FN; ++j) b_fo[j] = lds0 + lane_off + (((wn * FN + j) ^ fl) << 5);
 
   // The K loop is instantiated twice OUTSIDE the column-sum branch: selecting the variant inside the loop makes
   // the 64 accumulator registers live across a branch and hipcc then shuttles them VGPR<->AGPR every iteration
@@ -558,9 +608,12 @@ __global__ __launch_bounds__(128 * WGN, WGN) void gemm_tn_bf16_kernel(const Gemm
     for (int kt = 0; kt < ntk; ++kt) {
       const int cur = kt & 1;
       if (kt + 1 < ntk) stage(cur ^ 1, kt + 1);
-      const char* sa = smem + cur * STAGE;
-      const char* sb = sa + IMG;
-      tn_compute_stage<CS, FN>(sa, sb, lane_off, a_cb, b_cb, acc, csum);
+      uint32_t va[FM], vb[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) va[i] = a_fo[i] + cur * STAGE;
+#pragma unroll
+      for (int j = 0; j < FN; ++j) vb[j] = b_fo[j] + cur * STAGE;
+      tn_compute_stage<CS, FN>(va, vb, acc, csum);
       __syncthreads();
     }
   };
@@ -580,8 +633,8 @@ __global__ __launch_bounds__(128 * WGN, WGN) void gemm_tn_bf16_kernel(const Gemm
   }
   const int mb = m0 + wm * 64 + (lane & 15), nb = n0 + wn * (16 * FN) + 4 * (lane >> 4);
   const EpiStage st = {smem, m0, n0, wm * 64 + (lane & 15), wn * (16 * FN) + 4 * (lane >> 4), tid, NT, 128};   // fp32 outputs: unused
-  if (m0 + BM <= p.M && n0 + BN <= p.N) gemm_epilogue_dispatch<true, FM, FN>(p, acc, mb, nb, st);
-  else gemm_epilogue_dispatch<false, FM, FN>(p, acc, mb, nb, st);
+  if (m0 + BM <= p.M && n0 + BN <= p.N) gemm_epilogue<0, false, false, OUT, true, FM, FN>(p, acc, mb, nb, st);
+  else gemm_epilogue<0, false, false, OUT, false, FM, FN>(p, acc, mb, nb, st);
 }
 
 // ------------------------------------------------------------------------------------
@@ -956,13 +1009,21 @@ extern "C" int vlb_wgrad_tn_bf16(const void* A, long lda, const void* B, long ld
   constexpr int smem = 2 * 2 * 64 * 128 * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_tn_bf16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    (void)hipFuncSetAttribute((const void*)gemm_tn_bf16_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)gemm_tn_bf16_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)gemm_tn_bf16_kernel<2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)gemm_tn_bf16_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)gemm_tn_bf16_kernel<4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
   static const int waves8 = env_int("VLB_GEMM_TN_WAVES8", 1);
-  if (waves8) hipLaunchKernelGGL(gemm_tn_bf16_kernel<4>, dim3(p.ntm * p.ntn, nsp), dim3(512), smem, stream, p, colsum);
-  else hipLaunchKernelGGL(gemm_tn_bf16_kernel<2>, dim3(p.ntm * p.ntn, nsp), dim3(256), smem, stream, p, colsum);
+  const dim3 grid(p.ntm * p.ntn, nsp);
+  if (waves8) {
+    if (p.out_f32 == 3) hipLaunchKernelGGL((gemm_tn_bf16_kernel<4, 3>), grid, dim3(512), smem, stream, p, colsum);
+    else hipLaunchKernelGGL((gemm_tn_bf16_kernel<4, 1>), grid, dim3(512), smem, stream, p, colsum);
+  } else {
+    if (p.out_f32 == 3) hipLaunchKernelGGL((gemm_tn_bf16_kernel<2, 3>), grid, dim3(256), smem, stream, p, colsum);
+    else hipLaunchKernelGGL((gemm_tn_bf16_kernel<2, 1>), grid, dim3(256), smem, stream, p, colsum);
+  }
   VLB_CHECK_LAUNCH("vlb_wgrad_tn_bf16");
   if (nsp > 1) {
     long blocks = ((long)Mo * (ldw / 4) + 255) / 256;
