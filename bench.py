@@ -158,7 +158,8 @@ def main():
             out = fn(A, B, C, *a, **kw)
             e1.record()
             K = A.shape[0] if name == "wgrad_tn" else A.shape[1]      # TN form reduces over the rows
-            rec.append((e0, e1, 2.0 * C.shape[0] * C.shape[1] * K))
+            nbytes = A.shape[0] * A.shape[1] * 2 + B.shape[0] * B.shape[1] * 2 + C.shape[0] * C.shape[1] * C.element_size()
+            rec.append((e0, e1, 2.0 * C.shape[0] * C.shape[1] * K, nbytes))
             return out
         return wrapper
 
@@ -168,10 +169,21 @@ def main():
     torch.cuda.synchronize()
     for n in names:
         setattr(ops, n, orig[n])
-    gemm_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in rec)
-    gemm_flops = sum(f for _, _, f in rec)
+    gemm_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in rec)
+    gemm_flops = sum(f for _, _, f, _ in rec)
+    gemm_alg_gb = sum(b for _, _, _, b in rec) / max(len(rec), 1) / 1e9      # operands read once + result written once
     achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     fwd, fwdbwd = flops_per_sample(cfg, T, R)
+    # HBM bytes per GEMM launch come from PMC counters, which need their own rocprofv3 passes (tools/make_profiles.sh);
+    # the committed summary of those passes is reported here when it was taken on this workload, else null.
+    traffic, traffic_unit = None, None
+    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_gemm_traffic.json")
+    if world == 1 and args.global_batch == 256 and args.layers == 12 and os.path.isfile(tpath):
+        with open(tpath) as f:
+            tj = json.load(f)
+        traffic = round(tj["gemm_hbm_GB_per_launch"], 4)
+        traffic_unit = "GB per GEMM launch (avg over %d launches/step; rocprofv3 2xFETCH_SIZE+WRITE_SIZE, profiles/r01_gemm_traffic.json)" \
+            % round(tj["gemm_launches_per_step"])
 
     if rank == 0:
         out = {
@@ -185,7 +197,8 @@ def main():
                        "parallelism": "dp%d" % world, "hipgraph": bool(use_graph), "arch": arch, "cus": cus},
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_bf16_kernel + gemm_tn_bf16_kernel (all %d GEMM launches of one step)" % len(rec),
                          "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": traffic_unit,
+                         "algorithmic_GB_per_launch": round(gemm_alg_gb, 4),
                          "gemm_ms_per_step": round(gemm_ms, 3), "gemm_share_of_step": round(gemm_ms / ms, 3),
                          "step_algorithmic_tflops": round(value * fwdbwd / 1e12, 2),
                          "step_frac_of_peak": round(value * fwdbwd / 1e12 / (world * PEAK_BF16_TFLOPS), 4)},

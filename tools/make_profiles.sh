@@ -1,0 +1,16 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (through gpurun): rocprofv3 passes over the default bench workload; raw outputs -> gpurun_out/final_*.
+#   1. --kernel-trace --stats            : per-kernel time
+#   2. --kernel-trace --pmc <SQ set>     : wave / MFMA / LDS counters          (separate pass, kernel-trace only)
+#   3. --kernel-trace --pmc FETCH_SIZE   : HBM-side read bytes                 (separate pass)
+#   4. --kernel-trace --pmc WRITE_SIZE   : HBM-side write bytes                (separate pass)
+set -u
+ROOT="${GRAFT_REPO_ROOT:-/root/repo}"
+OUT="$ROOT/gpurun_out"
+cd /tmp && export TMPDIR=/tmp
+CMD="python $ROOT/bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats -d "$OUT/final_trace" -o r -- $CMD > "$OUT/final_trace.log" 2>&1
+rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY -d "$OUT/final_sq" -o r -- $CMD > "$OUT/final_sq.log" 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/final_fetch" -o r -- $CMD > "$OUT/final_fetch.log" 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/final_write" -o r -- $CMD > "$OUT/final_write.log" 2>&1
+grep '"metric"' "$OUT/final_trace.log" | tail -1 | cut -c1-200

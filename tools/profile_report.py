@@ -1,0 +1,122 @@
+#!/usr/bin/env python
+"""Turns the rocprofv3 (rocpd sqlite) outputs of tools/make_profiles.sh into the text summaries kept under profiles/.
+
+    python tools/profile_report.py gpurun_out profiles r01 [steps_in_run]
+
+Writes  profiles/<tag>_kernel_stats.txt   per-kernel time of the traced bench run (+ the bench JSON line of that run)
+        profiles/<tag>_gemm_pmc.txt       SQ counters per GEMM kernel family, averaged per launch
+        profiles/<tag>_hbm_traffic.txt    FETCH_SIZE / WRITE_SIZE per kernel family
+        profiles/<tag>_gemm_traffic.json  HBM bytes per GEMM launch (read by bench.py for roofline.traffic)
+FETCH_SIZE is doubled for the kernels that stream 16 B/lane (MI355X_MICROARCH.md, HBM: on gfx950 the counter tallies a
+128-B request as 64 B); WRITE_SIZE is taken as reported (uncalibrated per the same guide).
+"""
+import glob
+import json
+import os
+import re
+import sqlite3
+import sys
+
+src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+steps = float(sys.argv[4]) if len(sys.argv) > 4 else 5.0     # 1 warm-up + 3 timed + 1 instrumented step
+
+
+def db(name):
+    return sqlite3.connect(glob.glob(os.path.join(src, name, "*.db"))[0])
+
+
+def short(n):
+    n = re.sub(r"\(.*$", "", n)
+    return re.sub(r"^void ", "", n)[:64]
+
+
+def family(n):
+    if "gemm_nt_bf16" in n:
+        return "gemm_nt_bf16_kernel"
+    if "gemm_tn_bf16" in n:
+        return "gemm_tn_bf16_kernel"
+    return short(n)
+
+
+# ---------------------------------------------------------------- kernel time
+cur = db("final_trace").cursor()
+rows = cur.execute("select name, end - start from kernels").fetchall()
+agg = {}
+for n, d in rows:
+    a = agg.setdefault(short(n), [0, 0.0, 1e30, 0.0])
+    a[0] += 1; a[1] += d; a[2] = min(a[2], d); a[3] = max(a[3], d)
+total = sum(a[1] for a in agg.values())
+line = ""
+for l in open(os.path.join(src, "final_trace.log"), errors="replace"):
+    if '"metric"' in l:
+        line = l.strip()
+with open(os.path.join(dst, tag + "_kernel_stats.txt"), "w") as f:
+    f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline   (MI355X; %d steps in\n"
+            "# the process: 1 warm-up + 3 timed + 1 instrumented; the fill / copy kernels are mostly one-time buffer setup)\n" % steps)
+    f.write("# summarised from the rocpd sqlite output by tools/profile_report.py; bench line of the same (profiled) run:\n# %s\n" % line)
+    f.write("%-66s %7s %10s %10s %9s %9s %9s %7s\n" % ("kernel", "calls", "total_ms", "ms/step", "avg_us", "min_us", "max_us", "share"))
+    for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        f.write("%-66s %7d %10.3f %10.3f %9.2f %9.2f %9.2f %6.1f%%\n" % (k, a[0], a[1] / 1e6, a[1] / 1e6 / steps, a[1] / a[0] / 1e3,
+                                                                      a[2] / 1e3, a[3] / 1e3, 100 * a[1] / total))
+    f.write("%-66s %7s %10.3f %10.3f\n" % ("TOTAL kernel time", "", total / 1e6, total / 1e6 / steps))
+
+
+# ---------------------------------------------------------------- PMC helpers
+def pmc(name):
+    cur = db(name).cursor()
+    rows = cur.execute("select dispatch_id, kernel_name, counter_name, value, duration from counters_collection").fetchall()
+    disp = {}
+    for did, kn, cn, v, dur in rows:
+        d = disp.setdefault(did, {"k": kn, "dur": dur, "c": {}})
+        d["c"][cn] = d["c"].get(cn, 0.0) + v
+    fam = {}
+    for d in disp.values():
+        a = fam.setdefault(family(d["k"]), {"n": 0, "dur": 0.0, "c": {}})
+        a["n"] += 1; a["dur"] += d["dur"]
+        for k, v in d["c"].items():
+            a["c"][k] = a["c"].get(k, 0.0) + v
+    return fam
+
+
+sq = pmc("final_sq")
+with open(os.path.join(dst, tag + "_gemm_pmc.txt"), "w") as f:
+    f.write("# rocprofv3 --kernel-trace --pmc SQ_* (one separate pass) over the same bench command; per kernel family, AVERAGE PER LAUNCH.\n"
+            "# SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_ANY count quad-cycles summed over waves; SQ_VALU_MFMA_BUSY_CYCLES and\n"
+            "# SQ_LDS_* count cycles summed over SIMDs / CUs (MI355X_MICROARCH.md, PMC slots).\n")
+    names = sorted({k for a in sq.values() for k in a["c"]})
+    f.write("%-34s %6s %9s " % ("kernel family", "calls", "avg_us") + " ".join("%24s" % n for n in names) + "\n")
+    for k, a in sorted(sq.items(), key=lambda kv: -kv[1]["dur"])[:8]:
+        f.write("%-34s %6d %9.1f " % (k[:34], a["n"], a["dur"] / a["n"] / 1e3) + " ".join("%24.4g" % (a["c"].get(n, 0) / a["n"]) for n in names) + "\n")
+    for k in ("gemm_nt_bf16_kernel", "gemm_tn_bf16_kernel"):
+        if k in sq:
+            c = sq[k]["c"]
+            f.write("# %s: MFMA pipe busy %.0f %% of SIMD-cycles at the nominal 2.4 GHz (DVFS runs lower, so this is a lower bound) ; of the wave-cycles "
+                    "%.0f %% parked on s_waitcnt/barrier (WAIT_ANY), %.0f %% issue-stalled (WAIT_INST_ANY), %.0f %% issuing ; "
+                    "LDS bank-conflict cycles / LDS active = %.2f %%\n" % (
+                        k, 100 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / sq[k]["n"] / (1024 * sq[k]["dur"] / sq[k]["n"] * 2.4),
+                        100 * c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 100 * c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"],
+                        100 * c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"], 100 * c["SQ_LDS_BANK_CONFLICT"] / max(c["SQ_LDS_IDX_ACTIVE"], 1)))
+
+fe, wr = pmc("final_fetch"), pmc("final_write")
+traffic = {}
+with open(os.path.join(dst, tag + "_hbm_traffic.txt"), "w") as f:
+    f.write("# rocprofv3 --kernel-trace --pmc FETCH_SIZE and (separate pass) --pmc WRITE_SIZE over the same bench command.\n"
+            "# Counters are in KB per dispatch; 'read' = 2 x FETCH_SIZE for the kernels that stream 16 B/lane (gfx950 correction,\n"
+            "# MI355X_MICROARCH.md HBM section), WRITE_SIZE as reported.  MB per launch (average) and MB per step.\n")
+    f.write("%-40s %6s %12s %12s %12s %14s\n" % ("kernel family", "calls", "read MB", "write MB", "total MB", "MB per step"))
+    for k, a in sorted(fe.items(), key=lambda kv: -kv[1]["dur"])[:14]:
+        rd = 2.0 * a["c"].get("FETCH_SIZE", 0.0) / a["n"] / 1e3
+        w = wr.get(k, {"c": {}, "n": 1})
+        wm = w["c"].get("WRITE_SIZE", 0.0) / max(w["n"], 1) / 1e3
+        f.write("%-40s %6d %12.2f %12.2f %12.2f %14.1f\n" % (k[:40], a["n"], rd, wm, rd + wm, (rd + wm) * a["n"] / steps))
+        traffic[k] = {"launches_per_step": a["n"] / steps, "read_MB_per_launch": rd, "write_MB_per_launch": wm}
+g = [traffic[k] for k in ("gemm_nt_bf16_kernel", "gemm_tn_bf16_kernel") if k in traffic]
+n = sum(t["launches_per_step"] for t in g)
+out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), tools/make_profiles.sh + tools/profile_report.py",
+       "correction": "read = 2 x FETCH_SIZE (gfx950, 16 B/lane streaming reads); WRITE_SIZE as reported",
+       "workload": "bench.py default (global batch 256, 1 GPU)",
+       "gemm_launches_per_step": n,
+       "gemm_hbm_GB_per_launch": sum((t["read_MB_per_launch"] + t["write_MB_per_launch"]) * t["launches_per_step"] for t in g) / n / 1e3,
+       "families": traffic}
+json.dump(out, open(os.path.join(dst, tag + "_gemm_traffic.json"), "w"), indent=1)
+print("wrote", dst, tag, "GEMM GB/launch", out["gemm_hbm_GB_per_launch"])

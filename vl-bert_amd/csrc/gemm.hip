@@ -20,6 +20,7 @@
 //   * fused epilogue: +bias, erf-GELU (optionally also storing the pre-activation), ReLU,
 //     x gelu'(aux) or x aux (GELU backward), dropout (counter RNG), +residual, bf16 or fp32 store,
 //     fp32 atomic accumulation for split-K weight gradients.
+#include <math.h>
 #include <stdlib.h>
 
 #include <type_traits>
@@ -521,12 +522,19 @@ __global__ __launch_bounds__(128 * WGN, WGN) void gemm_tn_bf16_kernel(const Gemm
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WGN, wn = wave % WGN;
   const int nt = p.ntm * p.ntn;
-  int t;
+  // tile order: each XCD owns a contiguous run of tiles (block b runs on XCD b%8 when the grid width is a multiple of 8),
+  // walked in groups of `tile_group` tile-rows, column-major inside a group, so that the ~tiles/8 workgroups sharing an
+  // L2 cover a near-square patch of the output: with a row-major run a wide output (dW of output.dense: 6 x 24 tiles)
+  // had every XCD stream all of X -- the profile showed 3.3x the algorithmic HBM bytes, at 4.8 TB/s.
+  int tile_m, tile_n;
   {
     const int b = blockIdx.x, xcd = b & 7, q = nt >> 3, r = nt & 7;
-    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    const int gm = p.tile_group, per_group = gm * p.ntn, gid = t / per_group, first = gid * gm;
+    const int gsz = min(p.ntm - first, gm), rem = t - gid * per_group;
+    tile_m = first + rem % gsz;
+    tile_n = rem / gsz;
   }
-  const int tile_m = t / p.ntn, tile_n = t % p.ntn;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int r_begin = blockIdx.y * p.k_per_split;
   const int r_end = min(p.K, r_begin + p.k_per_split);       // p.K = number of reduction rows R
@@ -1005,7 +1013,19 @@ extern "C" int vlb_wgrad_tn_bf16(const void* A, long lda, const void* B, long ld
   } else {
     p.C = workspace; p.ldc = ldw; p.out_f32 = 1; p.c_split_stride = (long)Mo * ldw;
   }
-  p.ntm = vlb_cdiv(Mo, 128); p.ntn = vlb_cdiv(No, 128); p.tile_group = 1;
+  p.ntm = vlb_cdiv(Mo, 128); p.ntn = vlb_cdiv(No, 128);
+  {   // near-square per-XCD patches for wide outputs; tall outputs (decoder: 239 x 6 tiles) already share their A panel row-wise
+    static const int tn_group = env_int("VLB_GEMM_TN_GROUP", -1);
+    int gm = 1;
+    if (tn_group > 0) gm = tn_group;
+    else if (2 * p.ntn >= p.ntm) {
+      const double per_xcd = (double)p.ntm * p.ntn / 8.0;
+      gm = (int)(sqrt(per_xcd) + 0.5);
+    }
+    if (gm > p.ntm) gm = p.ntm;
+    if (gm < 1) gm = 1;
+    p.tile_group = gm;
+  }
   constexpr int smem = 2 * 2 * 64 * 128 * 2;
   static bool attr_set = false;
   if (!attr_set) {
