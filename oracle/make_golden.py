@@ -145,7 +145,70 @@ def run_case(name, spec):
     print("%s: loss %.6f grad_norm %.6f -> %s (%.1f KB)" % (name, out["loss"], out["grad_norm"], path, os.path.getsize(path) / 1024))
 
 
+def run_core_case(name="core_small"):
+    """Module-API fixture: the reference's common.visual_linguistic_bert.VisualLinguisticBertForPretraining driven with
+    random per-token text-visual embeddings and [visual || linguistic] object embeddings (ragged masks); scalar
+    objective = <mlm_logits, Wm> + <mvrc_logits, Wv> with fixed random weights, so d(logits) is known to the test."""
+    ref_import.import_reference()
+    from common.visual_linguistic_bert import VisualLinguisticBertForPretraining as RefCore
+    cfg = VLBertConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                       vocab_size=512, max_position_embeddings=64, visual_region_classes=50)
+    B, T, R, H = 3, 11, 6, cfg.hidden_size
+    vocab_dir = ref_import.make_vocab_dir(os.path.join(tempfile.gettempdir(), "vlb_vocab_%s" % name), cfg.vocab_size)
+    vcfg = ref_import.make_reference_config(cfg, vocab_dir).NETWORK.VLBERT
+    torch.manual_seed(0)
+    model = RefCore(vcfg, language_pretrained_model_path=None, with_rel_head=False, with_mlm_head=True, with_mvrc_head=True)
+    params = init_params(cfg, seed=21)
+    sd = {k[len("vlbert."):]: v for k, v in params.items() if k.startswith("vlbert.")}
+    sd["mlm_head.predictions.decoder.weight"] = sd["word_embeddings.weight"]
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected and not missing, (missing, unexpected)
+    model.eval()
+    g = torch.Generator().manual_seed(77)
+    tlen = torch.tensor([T, 7, 9])
+    nobj = torch.tensor([4, R, 5])
+    text_mask = torch.arange(T).unsqueeze(0) < tlen.unsqueeze(1)
+    obj_mask = torch.arange(R).unsqueeze(0) < nobj.unsqueeze(1)
+    text_ids = torch.randint(1, cfg.vocab_size, (B, T), generator=g) * text_mask
+    text_type = torch.randint(0, 2, (B, T), generator=g) * text_mask
+    # inputs are rounded to bf16-representable values: the HIP path takes them as bf16
+    text_vis = torch.randn((B, T, H), generator=g).bfloat16().float().requires_grad_(True)
+    obj_vl = torch.randn((B, R, 2 * H), generator=g).bfloat16().float().requires_grad_(True)
+    wm = torch.randn((B, T, cfg.vocab_size), generator=g) * 0.05 * text_mask.unsqueeze(-1)
+    wv = torch.randn((B, R, cfg.visual_region_classes), generator=g) * 0.05 * obj_mask.unsqueeze(-1)
+    _, mlm_logits, mvrc_logits = model(text_ids, text_type, text_vis, text_mask, obj_vl, obj_mask)
+    obj = (mlm_logits * wm).sum() + (mvrc_logits * wv).sum()
+    model.zero_grad()
+    obj.backward()
+    out = {"B": B, "T": T, "R": R, "pseed": 21,
+           "cfg_keys": np.array(["hidden_size", "num_hidden_layers", "num_attention_heads", "intermediate_size", "vocab_size",
+                                 "max_position_embeddings", "visual_region_classes"]),
+           "cfg_vals": np.array([128.0, 2, 2, 256, 512, 64, 50]),
+           "in_text_ids": text_ids.numpy(), "in_text_type": text_type.numpy(), "in_text_vis": text_vis.detach().numpy(),
+           "in_text_mask": text_mask.numpy(), "in_obj_vl": obj_vl.detach().numpy(), "in_obj_mask": obj_mask.numpy(),
+           "w_mlm": wm.numpy(), "w_mvrc": wv.numpy(),
+           "mlm_logits": mlm_logits.detach().numpy(), "mvrc_logits": mvrc_logits.detach().numpy(), "objective": float(obj),
+           "d_text_vis": text_vis.grad.numpy(), "d_obj_vl": obj_vl.grad.numpy()}
+    named = dict(model.named_parameters())
+    total, names = 0.0, []
+    for n in sorted(named):
+        gr = named[n].grad if named[n].grad is not None else torch.zeros_like(named[n])
+        total += float((gr.double() ** 2).sum())
+        out["g_stat/" + n], out["g_smp/" + n] = digest(gr)
+        names.append(n)
+    out["names"] = np.array(names)
+    out["grad_norm"] = total ** 0.5
+    path = os.path.join(ROOT, "tests", "golden", "core", name + ".npz")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    np.savez_compressed(path, **out)
+    print("%s: objective %.6f grad_norm %.6f -> %s (%.1f KB)" % (name, out["objective"], out["grad_norm"], path, os.path.getsize(path) / 1024))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
-    for name, spec in CASES.items():
-        run_case(name, spec)
+    if len(sys.argv) > 1 and sys.argv[1] == "core":
+        run_core_case()
+    else:
+        for name, spec in CASES.items():
+            run_case(name, spec)
+        run_core_case()

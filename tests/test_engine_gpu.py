@@ -300,3 +300,80 @@ def test_dropin_module_matches_reference_training_loop_contract():
     assert float(loss2) < float(loss)
     loss2.backward()
     assert all(p.grad is not None for p in net.parameters())
+
+
+def _core_fixture():
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "core", "core_small.npz"), allow_pickle=False)
+    cfg = O.VLBertConfig(**{str(k): int(v) for k, v in zip(z["cfg_keys"], z["cfg_vals"])})
+    params = {k[len("vlbert."):]: v for k, v in O.init_params(cfg, seed=int(z["pseed"])).items() if k.startswith("vlbert.")}
+    ins = [torch.from_numpy(z["in_" + k]).to(dev()) for k in ("text_ids", "text_type", "text_vis", "text_mask", "obj_vl", "obj_mask")]
+    return z, cfg, params, ins
+
+
+def test_module_api_pretraining_heads_match_reference():
+    """common.visual_linguistic_bert.VisualLinguisticBertForPretraining mirror: logits, gradients of the two embedding
+    inputs and of the parameters against the fixture produced by the reference module itself."""
+    VL = pkg("common.visual_linguistic_bert")
+    z, cfg, params, ins = _core_fixture()
+    vcfg = _module_config(cfg)["NETWORK"]["VLBERT"]
+    net = VL.VisualLinguisticBertForPretraining(vcfg, with_rel_head=False)
+    assert set(n for n, _ in net.named_parameters()) == set(str(n) for n in z["names"])
+    net.load_state_dict(params)
+    net.eval()
+    tv = ins[2].clone().requires_grad_(True)
+    ovl = ins[4].clone().requires_grad_(True)
+    rel, mlm, mvrc = net(ins[0], ins[1], tv, ins[3], ovl, ins[5])
+    assert rel is None
+    tm, om = torch.from_numpy(z["in_text_mask"]), torch.from_numpy(z["in_obj_mask"])
+    report("module-API mlm_logits vs REFERENCE (valid text positions)", mlm.cpu() * tm.unsqueeze(-1),
+           torch.from_numpy(z["mlm_logits"]) * tm.unsqueeze(-1), 2e-3, 1e-2)
+    report("module-API mvrc_logits vs REFERENCE", mvrc, torch.from_numpy(z["mvrc_logits"]), 2e-3, 1e-2)
+    obj = (mlm * torch.from_numpy(z["w_mlm"]).to(dev())).sum() + (mvrc * torch.from_numpy(z["w_mvrc"]).to(dev())).sum()
+    assert abs(float(obj) - float(z["objective"])) <= 2e-2 * max(1.0, abs(float(z["objective"])))
+    obj.backward()
+    e_tv = rel_fro(tv.grad, torch.from_numpy(z["d_text_vis"]))
+    e_ovl = rel_fro(ovl.grad, torch.from_numpy(z["d_obj_vl"]))
+    print("module-API input gradients: rel-fro err text_visual %.3e object_vl %.3e" % (e_tv, e_ovl))
+    assert e_tv <= 3e-2 and e_ovl <= 3e-2
+    total = torch.nn.utils.clip_grad_norm_(net.parameters(), 1e9)
+    print("module-API grad_norm hip %.5f reference %.5f" % (float(total), float(z["grad_norm"])))
+    assert abs(float(total) - float(z["grad_norm"])) <= 1e-2 * float(z["grad_norm"])
+    named = dict(net.named_parameters())
+    for n in z["names"]:
+        n = str(n)
+        ref = z["g_smp/" + n]
+        if np.linalg.norm(ref) < 1e-6 * float(z["grad_norm"]):
+            continue
+        g = named[n].grad.detach().double().cpu().reshape(-1)
+        smp = g[::max(1, g.numel() // SAMPLE)][:SAMPLE].float().numpy()
+        err = np.linalg.norm(smp - ref) / max(np.linalg.norm(ref), 1e-12)
+        assert err <= 5e-2, (n, err)
+
+
+def test_module_api_hidden_states_match_oracle():
+    """VisualLinguisticBert mirror (no heads): text / object hidden states and the input gradients for a random cotangent."""
+    VL = pkg("common.visual_linguistic_bert")
+    z, cfg, params, ins = _core_fixture()
+    net = VL.VisualLinguisticBert(_module_config(cfg)["NETWORK"]["VLBERT"])
+    net.load_state_dict({k: v for k, v in params.items() if not k.startswith(("mlm_head.", "mvrc_head."))})
+    net.eval()
+    tv = ins[2].clone().requires_grad_(True)
+    ovl = ins[4].clone().requires_grad_(True)
+    text_out, obj_out, pooled = net(ins[0], ins[1], tv, ins[3], ovl, ins[5], output_all_encoded_layers=False,
+                                    output_text_and_object_separately=True)
+    assert pooled is None
+    p = {k: v.clone().requires_grad_(True) for k, v in O.init_params(cfg, seed=int(z["pseed"])).items()}
+    tvc, ovlc = ins[2].cpu().clone().requires_grad_(True), ins[4].cpu().clone().requires_grad_(True)
+    rt, ro, _, _ = O.vlbert_forward(p, cfg, ins[0].cpu(), ins[1].cpu(), tvc, ins[3].cpu(), ovlc, ins[5].cpu(), False)
+    tm = ins[3].cpu().unsqueeze(-1).float()
+    report("module-API text_out vs oracle (valid positions)", text_out.cpu() * tm, rt * tm, 2e-3, 1.5e-2)
+    report("module-API object_out vs oracle", obj_out, ro, 2e-3, 1.5e-2)
+    g = torch.Generator().manual_seed(5)
+    ct, co = torch.randn(rt.shape, generator=g) * tm, torch.randn(ro.shape, generator=g) * ins[5].cpu().unsqueeze(-1).float()
+    ((rt * ct).sum() + (ro * co).sum()).backward()
+    ((text_out * ct.to(dev())).sum() + (obj_out * co.to(dev())).sum()).backward()
+    e_tv, e_ovl = rel_fro(tv.grad, tvc.grad), rel_fro(ovl.grad, ovlc.grad)
+    print("module-API (hidden) input gradients: rel-fro err text_visual %.3e object_vl %.3e" % (e_tv, e_ovl))
+    assert e_tv <= 3e-2 and e_ovl <= 3e-2
+    gw = dict(net.named_parameters())["encoder.layer.0.intermediate.dense.weight"].grad
+    assert rel_fro(gw, p["vlbert.encoder.layer.0.intermediate.dense.weight"].grad) <= 5e-2

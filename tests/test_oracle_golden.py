@@ -92,3 +92,34 @@ def test_coordinate_embedding_shape_and_values():
     # dim 0: position / 1000**0 ; xc = 299.5/600*100
     assert abs(float(e[0, 0, 0]) - np.sin(299.5 / 600 * 100)) < 1e-5
     assert abs(float(e[0, 0, 256]) - np.cos(299.5 / 600 * 100)) < 1e-5
+
+
+def test_oracle_module_api_matches_reference_fixture():
+    """common.visual_linguistic_bert.VisualLinguisticBertForPretraining driven with explicit embeddings (per-token
+    text-visual inputs, token types, dense object linguistic halves): oracle vs the fixture produced by the reference."""
+    import os
+    import numpy as np
+    import torch
+    from oracle import vlbert_oracle as O
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "core", "core_small.npz"), allow_pickle=False)
+    cfg = O.VLBertConfig(**{str(k): int(v) for k, v in zip(z["cfg_keys"], z["cfg_vals"])})
+    p = {k: v.clone().requires_grad_(True) for k, v in O.init_params(cfg, seed=int(z["pseed"])).items()}
+    tv = torch.from_numpy(z["in_text_vis"]).requires_grad_(True)
+    ovl = torch.from_numpy(z["in_obj_vl"]).requires_grad_(True)
+    text_out, obj_out, _, _ = O.vlbert_forward(p, cfg, torch.from_numpy(z["in_text_ids"]), torch.from_numpy(z["in_text_type"]), tv,
+                                               torch.from_numpy(z["in_text_mask"]), ovl, torch.from_numpy(z["in_obj_mask"]), False)
+    mlm, mvrc = O.mlm_head(p, text_out), O.mvrc_head(p, obj_out)
+    assert torch.allclose(mlm, torch.from_numpy(z["mlm_logits"]), atol=2e-5, rtol=1e-5)
+    assert torch.allclose(mvrc, torch.from_numpy(z["mvrc_logits"]), atol=2e-5, rtol=1e-5)
+    obj = (mlm * torch.from_numpy(z["w_mlm"])).sum() + (mvrc * torch.from_numpy(z["w_mvrc"])).sum()
+    assert abs(float(obj) - float(z["objective"])) < 1e-4 * max(1.0, abs(float(z["objective"])))
+    obj.backward()
+    assert torch.allclose(tv.grad, torch.from_numpy(z["d_text_vis"]), atol=1e-5, rtol=1e-4)
+    assert torch.allclose(ovl.grad, torch.from_numpy(z["d_obj_vl"]), atol=1e-5, rtol=1e-4)
+    total = 0.0
+    for n in z["names"]:
+        g = p["vlbert." + str(n)].grad
+        g = torch.zeros_like(p["vlbert." + str(n)]) if g is None else g
+        total += float((g.double() ** 2).sum())
+        assert abs(float(g.double().norm()) - float(z["g_stat/" + str(n)][0])) <= 1e-4 * max(1.0, float(z["g_stat/" + str(n)][0])), n
+    assert abs(total ** 0.5 - float(z["grad_norm"])) <= 1e-5 * float(z["grad_norm"])

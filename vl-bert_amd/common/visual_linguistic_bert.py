@@ -1,0 +1,180 @@
+"""Drop-in `VisualLinguisticBert` / `VisualLinguisticBertForPretraining` (common/visual_linguistic_bert.py:31-241,
+:335-380) backed by the HIP engine in module-API mode: the reference's constructor argument (the `NETWORK.VLBERT`
+config node), forward signatures and state-dict keys, so the callers that build their own text-visual / object
+embeddings (pretrain/modules/resnet_vlbert_for_pretraining.py:42-48, vqa/modules/resnet_vlbert_for_vqa.py:49-50,
+vcr/modules/resnet_vlbert_for_vcr.py:60) can construct it unchanged.
+
+    VisualLinguisticBert.forward(text_input_ids, text_token_type_ids, text_visual_embeddings, text_mask,
+                                 object_vl_embeddings, object_mask, output_all_encoded_layers=False,
+                                 output_text_and_object_separately=True) -> (text_out, object_out, pooled=None)
+    VisualLinguisticBertForPretraining.forward(same six tensors) -> (relationship_logits=None, mlm_logits, mvrc_logits)
+
+Both are differentiable w.r.t. the parameters and the two embedding inputs (custom autograd node -> the engine's explicit
+backward).  Supported: visual_size == hidden_size, visual_ln, no pooler / relationship head, last layer only,
+text and objects returned separately; anything else raises NotImplementedError (no silent eager fallback).
+Parameters are views of the engine's flat fp32 master buffer, `.grad` views of its flat gradient buffer.
+"""
+import torch
+import torch.nn as nn
+
+from .. import engine as _engine
+
+_PREFIX = "vlbert."
+
+
+def _get(obj, name, default=None):
+    return getattr(obj, name, default) if not isinstance(obj, dict) else obj.get(name, default)
+
+
+class _CoreFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, text_vis, obj_vl, anchor, module, eng):
+        ctx.module, ctx.eng = module, eng
+        mlm, mvrc, text_out, obj_out = eng.forward_core(train=module.training)
+        ctx.in_dtypes = (text_vis.dtype, obj_vl.dtype)
+        if eng.with_heads:
+            return mlm.float(), mvrc.float()
+        return text_out.float(), obj_out.float()
+
+    @staticmethod
+    def backward(ctx, g0, g1):
+        module, eng = ctx.module, ctx.eng
+        module._prepare_grads()
+        if eng.with_heads:
+            d_tv, d_ovl = eng.backward_core(g0, g1, train=module.training)
+        else:
+            d_tv, d_ovl = eng.backward_core_hidden(g0, g1, train=module.training)
+        return d_tv.to(ctx.in_dtypes[0]), d_ovl.to(ctx.in_dtypes[1]), None, None, None
+
+
+class VisualLinguisticBert(nn.Module):
+    WITH_HEADS = False
+
+    def __init__(self, config, language_pretrained_model_path=None, device=None):
+        super().__init__()
+        if language_pretrained_model_path is not None:
+            raise NotImplementedError("loading a language-only BERT checkpoint is host glue that is not mirrored; use load_state_dict")
+        if _get(config, "visual_size", _get(config, "hidden_size")) != _get(config, "hidden_size"):
+            raise NotImplementedError("visual_size != hidden_size (visual_1x1 projections) is not supported")
+        if not _get(config, "visual_ln", True) or _get(config, "with_pooler", False):
+            raise NotImplementedError("accelerated path needs visual_ln and no pooler")
+        if _get(config, "word_embedding_frozen", False) or _get(config, "pos_embedding_frozen", False):
+            raise NotImplementedError("frozen embeddings are not supported")
+        self.config = config
+        self.cfg = _engine.ModelConfig(
+            hidden_size=_get(config, "hidden_size"), num_hidden_layers=_get(config, "num_hidden_layers"),
+            num_attention_heads=_get(config, "num_attention_heads"), intermediate_size=_get(config, "intermediate_size"),
+            vocab_size=_get(config, "vocab_size", 30522), max_position_embeddings=_get(config, "max_position_embeddings", 512),
+            type_vocab_size=_get(config, "type_vocab_size", 3), visual_region_classes=_get(config, "visual_region_classes", 1601),
+            hidden_dropout_prob=_get(config, "hidden_dropout_prob", 0.1),
+            attention_probs_dropout_prob=_get(config, "attention_probs_dropout_prob", 0.1))
+        self.cfg.validate()
+        if not torch.cuda.is_available():
+            raise RuntimeError("VisualLinguisticBert (HIP) needs an MI355X: there is no CPU fallback")
+        self.device_ = torch.device(device or ("cuda:%d" % torch.cuda.current_device()))
+        self.flat = _engine.FlatParams(self.cfg, self.device_)
+        self._engines = {}
+        self._pnames = {}
+        heads = ("mlm_head.", "mvrc_head.")
+        for name, t in self.flat.named(self.flat.master).items():
+            if not name.startswith(_PREFIX):
+                continue                                       # wrapper-level parameters are not part of this module
+            short = name[len(_PREFIX):]
+            if not self.WITH_HEADS and short.startswith(heads):
+                continue
+            self._register(short, nn.Parameter(t, requires_grad=True))
+        vt, vo, std = _get(config, "visual_scale_text_init", 0.0), _get(config, "visual_scale_object_init", 0.0), \
+            _get(config, "initializer_range", 0.02)
+        with torch.no_grad():                                  # BaseModel.init_weights + :330-332
+            for name, p in self._pnames.items():
+                if name.endswith("visual_ln_text.weight"):
+                    p.fill_(vt)
+                elif name.endswith("visual_ln_object.weight"):
+                    p.fill_(vo)
+                elif "LayerNorm.weight" in name:
+                    p.fill_(1.0)
+                elif name.endswith(".bias"):
+                    p.zero_()
+                else:
+                    p.normal_(0.0, std)
+
+    def _register(self, dotted, param):
+        mod = self
+        parts = dotted.split(".")
+        for q in parts[:-1]:
+            if not hasattr(mod, q):
+                mod.add_module(q, nn.Module())
+            mod = getattr(mod, q)
+        mod.register_parameter(parts[-1], param)
+        self._pnames[dotted] = param
+
+    def _prepare_grads(self):
+        if any(p.grad is None for p in self._pnames.values()):
+            self.flat.grad.zero_()
+            named = self.flat.named(self.flat.grad)
+            for name, p in self._pnames.items():
+                p.grad = named[_PREFIX + name]
+
+    def _engine_for(self, B, T, R):
+        key = (B, T, R)
+        if key not in self._engines:
+            self._engines[key] = _engine.PretrainEngine(self.cfg, B, T, R, device=str(self.device_), flat=self.flat, core=True,
+                                                        core_heads=self.WITH_HEADS)
+        eng = self._engines[key]
+        version = self.flat.master._version
+        if getattr(eng, "_synced_version", None) != version:
+            eng.sync_weights()
+            eng._synced_version = version
+        eng._weights_dirty = False
+        return eng
+
+    def _run(self, text_input_ids, text_token_type_ids, text_visual_embeddings, text_mask, object_vl_embeddings, object_mask):
+        B, T = text_input_ids.shape
+        R = object_vl_embeddings.shape[1]
+        eng = self._engine_for(B, T, R)
+        eng.set_core_inputs(text_input_ids, text_token_type_ids, text_visual_embeddings, text_mask, object_vl_embeddings, object_mask)
+        anchor = next(iter(self._pnames.values()))
+        out = _CoreFn.apply(text_visual_embeddings, object_vl_embeddings, anchor, self, eng)
+        if self.training:
+            from .. import ops
+            ops.rng_advance(eng.seed)
+        return out
+
+    def forward(self, text_input_ids, text_token_type_ids, text_visual_embeddings, text_mask, object_vl_embeddings, object_mask,
+                output_all_encoded_layers=True, output_text_and_object_separately=False, output_attention_probs=False):
+        if output_all_encoded_layers or not output_text_and_object_separately or output_attention_probs:
+            raise NotImplementedError("supported call form: output_all_encoded_layers=False, "
+                                      "output_text_and_object_separately=True, output_attention_probs=False")
+        text_out, obj_out = self._run(text_input_ids, text_token_type_ids, text_visual_embeddings, text_mask,
+                                      object_vl_embeddings, object_mask)
+        return text_out, obj_out, None
+
+
+class VisualLinguisticBertForPretraining(VisualLinguisticBert):
+    WITH_HEADS = True
+
+    def __init__(self, config, language_pretrained_model_path=None, with_rel_head=True, with_mlm_head=True, with_mvrc_head=True,
+                 device=None):
+        if with_rel_head:
+            raise NotImplementedError("relationship head needs the pooler, which is not part of the accelerated configuration "
+                                      "(WITH_REL_LOSS is false in every shipped pretrain cfg)")
+        if not (with_mlm_head and with_mvrc_head):
+            raise NotImplementedError("accelerated path computes both the MLM and the MVRC head")
+        super().__init__(config, language_pretrained_model_path, device=device)
+
+    def state_dict(self, *args, **kwargs):
+        sd = super().state_dict(*args, **kwargs)
+        prefix = kwargs.get("prefix", args[1] if len(args) > 1 else "")
+        sd[prefix + "mlm_head.predictions.decoder.weight"] = sd[prefix + "word_embeddings.weight"]   # tied (modeling.py:463-466)
+        return sd
+
+    def load_state_dict(self, state_dict, strict=True):
+        state_dict = dict(state_dict)
+        state_dict.pop("mlm_head.predictions.decoder.weight", None)
+        return super().load_state_dict(state_dict, strict=strict)
+
+    def forward(self, text_input_ids, text_token_type_ids, text_visual_embeddings, text_mask, object_vl_embeddings, object_mask,
+                output_all_encoded_layers=True, output_text_and_object_separately=False):
+        mlm_logits, mvrc_logits = self._run(text_input_ids, text_token_type_ids, text_visual_embeddings, text_mask,
+                                            object_vl_embeddings, object_mask)
+        return None, mlm_logits, mvrc_logits

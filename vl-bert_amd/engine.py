@@ -145,12 +145,18 @@ class FlatParams:
 class PretrainEngine:
     def __init__(self, cfg, B, T, R, device="cuda:0", train=True, lr=1e-4, weight_decay=1e-4, max_grad_norm=10.0,
                  betas=(0.9, 0.999), eps=1e-6, seed=1234, grad_accum=1, process_group=None, keep_logits=False, flat=None,
-                 B_aux=0):
+                 B_aux=0, core=False, core_heads=True):
         cfg.validate()
         self.cfg, self.B, self.T, self.R = cfg, B, T, R
         # multitask: B_aux text-only samples are appended after the B image-caption samples; they have no
         # objects, their text-visual embedding is the learned aux_text_visual_embedding and their MLM loss is
         # accounted separately (resnet_vlbert_for_pretraining_multitask.py:96-290).  T = max(caption, aux) length.
+        # core=True: the engine is driven through the module API of common/visual_linguistic_bert.py:95-171,346-380 --
+        # per-token text-visual embeddings and [visual || linguistic] object embeddings come in as tensors, logits go
+        # out, d(logits) comes back in (set_core_inputs / forward_core / backward_core); the FastRCNN front end, the
+        # losses and the wrapper-level parameters are not used.
+        self.core = core
+        self.with_heads = core_heads or not core      # core_heads=False: hidden states out, d(hidden states) in
         self.Ba = B_aux
         if B_aux and not cfg.multitask:
             raise ValueError("B_aux > 0 needs ModelConfig(multitask=True)")
@@ -255,6 +261,12 @@ class PretrainEngine:
         self.d_obj_reps = zf(BR, H)
         self.d_yds = zb(BR, H)
         self.d_afeat = zb(BR, VIS_DIM)
+        if core:
+            self.in_text_type = torch.zeros((Bt, T), dtype=torch.int64, device=d)
+            self.tv_in, self.ovl_in = zb(BT, H), zb(BR, 2 * H)          # inputs as bf16: text_visual [B,T,H], object_vl [B,R,2H]
+            self.tv_n, self.st_tv = zb(BT, H), zf(BT, 2)                # visual_ln_text per token
+            self.d_tv_n, self.d_ol = zf(BT, H), zf(BR, H)               # d(LN(text_visual)), d(object linguistic half)
+            self.d_tv_in, self.d_ovl_in = zb(BT, H), zb(BR, 2 * H)      # gradients handed back to autograd
         # fp32 slab workspace for split-K weight gradients (largest request over this engine's wgrad shapes)
         need = [ops.wgrad_workspace_floats(n, k, rp) for n, k, rp in
                 ((3 * H, H, self.Mp), (H, H, self.Mp), (I, H, self.Mp), (H, I, self.Mp), (V, H, self.BTp), (H, H, self.BTp),
@@ -359,6 +371,33 @@ class PretrainEngine:
         w16, w32, seed = self.w16, self.w32, self.seed
         self.losses.zero_()
         ops.seq_layout_into(self.text_mask, self.box_mask, S, self.lay)
+        if self.core:
+            self._front_core_fwd(p_h)
+        else:
+            self._front_pretrain_fwd(p_h, p_ds)
+        self._encoder_heads_fwd(p_h, p_a)
+        if not self.core:
+            self._losses_fwd_bwd(gscale, True)
+
+    def _front_core_fwd(self, p_h):
+        """VisualLinguisticBert.embedding (common/visual_linguistic_bert.py:173-241) on caller-provided embeddings."""
+        cfg, T, R, S, Bt = self.cfg, self.T, self.R, self.S, self.Bt
+        H = cfg.hidden_size
+        w16, w32, seed = self.w16, self.w32, self.seed
+        ops.layernorm_fwd(self.tv_in, w32["vlbert.visual_ln_text.weight"], w32["vlbert.visual_ln_text.bias"], self.tv_n, self.st_tv)
+        ops.layernorm_fwd(self.ovl_in[:, :H], w32["vlbert.visual_ln_object.weight"], w32["vlbert.visual_ln_object.bias"], self.objvis,
+                          self.st_objvis)
+        ops.embed_fwd(self.lay, self.in_text, self.in_text_type, w16["vlbert.word_embeddings.weight"],
+                      w16["vlbert.position_embeddings.weight"], w16["vlbert.token_type_embeddings.weight"],
+                      w16["vlbert.end_embedding.weight"], self.tv_n, (T * H, H), self.objvis, (R * H, H),
+                      self.ovl_in[:, H:], (R * 2 * H, 2 * H), None, w32["vlbert.embedding_LayerNorm.weight"],
+                      w32["vlbert.embedding_LayerNorm.bias"], self.emb_pre, self.st_emb, self.X[0], Bt, T, R, S, H, drop_p=p_h,
+                      seed=seed, tag=TAG_EMBED)
+
+    def _front_pretrain_fwd(self, p_h, p_ds):
+        cfg, B, T, R, S, Bt, Ba = self.cfg, self.B, self.T, self.R, self.S, self.Bt, self.Ba
+        H = cfg.hidden_size
+        w16, w32, seed = self.w16, self.w32, self.seed
         # --- FastRCNN precomputed branch: (coord || feature) -> Linear(4096->H) -> ReLU ------------------
         ops.obj_prep_fwd(self.in_boxes, self.in_im_info, self.in_mvrc_ops.view(-1), w32["object_mask_visual_embedding.weight"],
                          self.a_ds, drop_p=p_ds, seed=seed, tag=TAG_DOWNSAMPLE)
@@ -378,6 +417,11 @@ class PretrainEngine:
                       self.objvis, (R * H, H), w16["object_linguistic_embeddings.weight"], (0, 0), self.in_mvrc_ops,
                       w32["vlbert.embedding_LayerNorm.weight"], w32["vlbert.embedding_LayerNorm.bias"], self.emb_pre, self.st_emb,
                       self.X[0], Bt, T, R, S, H, drop_p=p_h, seed=seed, tag=TAG_EMBED)
+
+    def _encoder_heads_fwd(self, p_h, p_a):
+        cfg, S, Bt = self.cfg, self.S, self.Bt
+        H, V, C, L, nh = cfg.hidden_size, cfg.vocab_size, cfg.visual_region_classes, cfg.num_hidden_layers, cfg.num_attention_heads
+        w16, w32, seed = self.w16, self.w32, self.seed
         # --- encoder -------------------------------------------------------------------------------------
         mask = self.lay["attn_mask"]
         for l in range(L):
@@ -401,6 +445,8 @@ class PretrainEngine:
         xl = self.X[L]
         ops.gather_rows(xl, self.lay["text_rows"].view(-1), self.text_out)
         ops.gather_rows(xl, self.lay["obj_rows"].view(-1)[:self.BR], self.obj_out)
+        if not self.with_heads:
+            return
         pm = "vlbert.mlm_head.predictions."
         ops.gemm_nt(self.text_out, w16[pm + "transform.dense.weight"], self.mlm_g, bias=w32[pm + "transform.dense.bias"],
                     act=ops.ACT_GELU_D, pre=self.mlm_u)
@@ -411,7 +457,6 @@ class PretrainEngine:
                     bias=w32["vlbert.mvrc_head.transform.dense.bias"], act=ops.ACT_GELU_D, pre=self.mvrc_u)
         ops.gemm_nt(self.mvrc_g, w16["vlbert.mvrc_head.region_cls_pred.weight"], self.mvrc_logits[:, :C],
                     bias=w32["vlbert.mvrc_head.region_cls_pred.bias"])
-        self._losses_fwd_bwd(gscale, True)
 
     def _losses_fwd_bwd(self, gscale, keep):
         """Loss values + d(logits) written in place over the logits.  Called again by the nn.Module mirror (keep=False:
@@ -454,26 +499,27 @@ class PretrainEngine:
         p_h, p_a, p_ds = self._p(train)
         w16, w32, g32, wT, seed = self.w16, self.w32, self.g32, self.wT, self.seed
         Mp, BTp, BRp = self.Mp, self.BTp, self.BRp
-        # --- MLM head ------------------------------------------------------------------------------------
-        pm = "vlbert.mlm_head.predictions."
-        dlog = self.mlm_logits                       # [BT, Vp], pad columns zero
-        self._wgrad(dlog[:, :V], self.mlm_h, g32["vlbert.word_embeddings.weight"], g32[pm + "bias"], self.tG_bt, self.tA_bt, BTp)
-        ops.gemm_nt_splitk(dlog, wT["vlbert.word_embeddings.weight"], self.d_mlm_h, workspace=self.wg_ws)
-        ops.layernorm_bwd(self.d_mlm_h, self.mlm_g, self.st_mlm, w32[pm + "transform.LayerNorm.weight"], dx=self.d_mlm_g,
-                          dgamma=g32[pm + "transform.LayerNorm.weight"], dbeta=g32[pm + "transform.LayerNorm.bias"],
-                          workspace=self.ln_ws)
-        ops.mul_bf16(self.d_mlm_g, self.mlm_u, self.d_mlm_u)
-        self._wgrad(self.d_mlm_u, self.text_out, g32[pm + "transform.dense.weight"], g32[pm + "transform.dense.bias"], self.tG_bt,
-                    self.tA_bt, BTp)
-        ops.gemm_nt(self.d_mlm_u, wT[pm + "transform.dense.weight"], self.d_text_out)
-        # --- MVRC head -----------------------------------------------------------------------------------
-        dlog2 = self.mvrc_logits                     # [BR, Cp]
-        self._wgrad(dlog2[:, :C], self.mvrc_g, g32["vlbert.mvrc_head.region_cls_pred.weight"],
-                    g32["vlbert.mvrc_head.region_cls_pred.bias"], self.tG_br, self.tA_br, BRp)
-        ops.gemm_nt(dlog2, wT["vlbert.mvrc_head.region_cls_pred.weight"], self.d_mvrc_u, act=ops.ACT_MULAUX, aux=self.mvrc_u)
-        self._wgrad(self.d_mvrc_u, self.obj_out, g32["vlbert.mvrc_head.transform.dense.weight"],
-                    g32["vlbert.mvrc_head.transform.dense.bias"], self.tG_br, self.tA_br, BRp)
-        ops.gemm_nt(self.d_mvrc_u, wT["vlbert.mvrc_head.transform.dense.weight"], self.d_obj_out)
+        if self.with_heads:
+            # --- MLM head ------------------------------------------------------------------------------------
+            pm = "vlbert.mlm_head.predictions."
+            dlog = self.mlm_logits                       # [BT, Vp], pad columns zero
+            self._wgrad(dlog[:, :V], self.mlm_h, g32["vlbert.word_embeddings.weight"], g32[pm + "bias"], self.tG_bt, self.tA_bt, BTp)
+            ops.gemm_nt_splitk(dlog, wT["vlbert.word_embeddings.weight"], self.d_mlm_h, workspace=self.wg_ws)
+            ops.layernorm_bwd(self.d_mlm_h, self.mlm_g, self.st_mlm, w32[pm + "transform.LayerNorm.weight"], dx=self.d_mlm_g,
+                              dgamma=g32[pm + "transform.LayerNorm.weight"], dbeta=g32[pm + "transform.LayerNorm.bias"],
+                              workspace=self.ln_ws)
+            ops.mul_bf16(self.d_mlm_g, self.mlm_u, self.d_mlm_u)
+            self._wgrad(self.d_mlm_u, self.text_out, g32[pm + "transform.dense.weight"], g32[pm + "transform.dense.bias"], self.tG_bt,
+                        self.tA_bt, BTp)
+            ops.gemm_nt(self.d_mlm_u, wT[pm + "transform.dense.weight"], self.d_text_out)
+            # --- MVRC head -----------------------------------------------------------------------------------
+            dlog2 = self.mvrc_logits                     # [BR, Cp]
+            self._wgrad(dlog2[:, :C], self.mvrc_g, g32["vlbert.mvrc_head.region_cls_pred.weight"],
+                        g32["vlbert.mvrc_head.region_cls_pred.bias"], self.tG_br, self.tA_br, BRp)
+            ops.gemm_nt(dlog2, wT["vlbert.mvrc_head.region_cls_pred.weight"], self.d_mvrc_u, act=ops.ACT_MULAUX, aux=self.mvrc_u)
+            self._wgrad(self.d_mvrc_u, self.obj_out, g32["vlbert.mvrc_head.transform.dense.weight"],
+                        g32["vlbert.mvrc_head.transform.dense.bias"], self.tG_br, self.tA_br, BRp)
+            ops.gemm_nt(self.d_mvrc_u, wT["vlbert.mvrc_head.transform.dense.weight"], self.d_obj_out)
         dx = self.dXa
         ops.head_grad_combine(self.d_text_out, self.d_obj_out, self.lay["code"], dx, Bt, T, R, S, H)
         if on_layer_done:
@@ -513,6 +559,40 @@ class PretrainEngine:
             dx = dx_next
             if on_layer_done:
                 on_layer_done(l)
+        if self.core:
+            self._front_core_bwd(dx, p_h)
+        else:
+            self._front_pretrain_bwd(dx, p_h, p_ds)
+        self._fresh_grads = False       # a further backward before the next zero_grad() accumulates
+        if on_layer_done:
+            on_layer_done("embed")
+
+    def _front_core_bwd(self, dx, p_h):
+        cfg, T, R, S, Bt = self.cfg, self.T, self.R, self.S, self.Bt
+        H = cfg.hidden_size
+        w32, g32, seed = self.w32, self.g32, self.seed
+        self.d_tv_n.zero_()
+        self.d_objvis.zero_()
+        self.d_ol.zero_()
+        pe = "vlbert.embedding_LayerNorm."
+        ops.embed_bwd(dx, self.emb_pre, self.st_emb, w32[pe + "weight"], self.lay, self.in_text, self.in_text_type, None,
+                      g32["vlbert.word_embeddings.weight"], g32["vlbert.position_embeddings.weight"],
+                      g32["vlbert.token_type_embeddings.weight"], g32["vlbert.end_embedding.weight"], g32[pe + "weight"],
+                      g32[pe + "bias"], self.d_tv_n, (T * H, H), self.d_objvis, (R * H, H), self.d_ol, (R * H, H), Bt, T, R, S, H,
+                      drop_p=p_h, seed=seed, tag=TAG_EMBED)
+        # gradients of the two inputs (padded positions: zero rows, as the reference's masked scatter gives)
+        ops.layernorm_bwd(self.d_tv_n, self.tv_in, self.st_tv, w32["vlbert.visual_ln_text.weight"], dx=self.d_tv_in,
+                          dgamma=g32["vlbert.visual_ln_text.weight"], dbeta=g32["vlbert.visual_ln_text.bias"], workspace=self.ln_ws)
+        ops.layernorm_bwd(self.d_objvis, self.ovl_in[:, :H], self.st_objvis, w32["vlbert.visual_ln_object.weight"],
+                          dx=self.d_ovl_in[:, :H], dgamma=g32["vlbert.visual_ln_object.weight"],
+                          dbeta=g32["vlbert.visual_ln_object.bias"], workspace=self.ln_ws)
+        self.d_ovl_in[:, H:].copy_(self.d_ol)      # fp32 -> bf16 strided copy (glue: hands the gradient to autograd)
+
+    def _front_pretrain_bwd(self, dx, p_h, p_ds):
+        cfg, B, T, R, S, Bt, Ba = self.cfg, self.B, self.T, self.R, self.S, self.Bt, self.Ba
+        H = cfg.hidden_size
+        w16, w32, g32, wT, seed = self.w16, self.w32, self.g32, self.wT, self.seed
+        BRp = self.BRp
         # --- embedding + visual LayerNorms + obj_downsample ---------------------------------------------
         self.d_objvis.zero_()
         self.d_obj_reps.zero_()
@@ -543,9 +623,62 @@ class PretrainEngine:
         ops.gemm_nt(self.d_yds, wT[pd + "weight"][VIS_DIM:], self.d_afeat)
         ops.masked_colsum(self.d_afeat, self.in_mvrc_ops.view(-1), g32["object_mask_visual_embedding.weight"].view(-1),
                           drop_p=p_ds, seed=seed, tag=TAG_DOWNSAMPLE, row_elems=2 * VIS_DIM, col_off=VIS_DIM)
-        self._fresh_grads = False       # a further backward before the next zero_grad() accumulates
-        if on_layer_done:
-            on_layer_done("embed")
+
+    # ------------------------------------------------------------------------------------------
+    # module-API mode (core=True)
+    # ------------------------------------------------------------------------------------------
+    def set_core_inputs(self, text_input_ids, text_token_type_ids, text_visual_embeddings, text_mask, object_vl_embeddings,
+                        object_mask):
+        """Arguments of VisualLinguisticBert.forward (common/visual_linguistic_bert.py:95-104), device tensors."""
+        if not self.core:
+            raise RuntimeError("engine was not built with core=True")
+        Bt, T, R, H = self.Bt, self.T, self.R, self.cfg.hidden_size
+        if tuple(text_input_ids.shape) != (Bt, T) or tuple(object_vl_embeddings.shape) != (Bt, R, 2 * H) or \
+                tuple(text_visual_embeddings.shape) != (Bt, T, H):
+            raise ValueError("core inputs must be text [%d,%d], text_visual [%d,%d,%d], object_vl [%d,%d,%d]"
+                             % (Bt, T, Bt, T, H, Bt, R, 2 * H))
+        self.in_text.copy_(text_input_ids)
+        self.in_text_type.copy_(text_token_type_ids)
+        self.tv_in.view(Bt, T, H).copy_(text_visual_embeddings)            # dtype conversion to bf16 (glue)
+        self.ovl_in.view(Bt, R, 2 * H).copy_(object_vl_embeddings)
+        self.text_mask.view(torch.bool).copy_(text_mask)
+        self.box_mask.view(torch.bool).copy_(object_mask)
+
+    def forward_core(self, train=None):
+        """-> (mlm_logits [B,T,V] bf16 view, mvrc_logits [B,R,C] bf16 view, text_out [B,T,H], obj_out [B,R,H])."""
+        self.forward(train)
+        V, C, H = self.cfg.vocab_size, self.cfg.visual_region_classes, self.cfg.hidden_size
+        return (self.mlm_logits[:, :V].view(self.Bt, self.T, V), self.mvrc_logits[:, :C].view(self.B, self.R, C),
+                self.text_out.view(self.Bt, self.T, H), self.obj_out.view(self.B, self.R, H))
+
+    def backward_core_hidden(self, d_text_out, d_obj_out, train=None):
+        """core_heads=False: d(text_out) [B,T,H] / d(obj_out) [B,R,H] -> input gradients (see backward_core)."""
+        H = self.cfg.hidden_size
+        if d_text_out is None:
+            self.d_text_out.zero_()
+        else:
+            self.d_text_out.copy_(d_text_out.reshape(self.BT, H))
+        if d_obj_out is None:
+            self.d_obj_out.zero_()
+        else:
+            self.d_obj_out.copy_(d_obj_out.reshape(self.BR, H))
+        self.backward(train)
+        return self.d_tv_in.view(self.Bt, self.T, H), self.d_ovl_in.view(self.Bt, self.R, 2 * H)
+
+    def backward_core(self, d_mlm_logits, d_mvrc_logits, train=None):
+        """d(logits) [B,T,V] / [B,R,C] (any float dtype; None = zero) -> parameter gradients accumulated into the flat
+        gradient, returns (d text_visual_embeddings [B,T,H], d object_vl_embeddings [B,R,2H]) as bf16 views."""
+        V, C, H = self.cfg.vocab_size, self.cfg.visual_region_classes, self.cfg.hidden_size
+        if d_mlm_logits is None:
+            self.mlm_logits.zero_()
+        else:
+            self.mlm_logits[:, :V].copy_(d_mlm_logits.reshape(self.BT, V))
+        if d_mvrc_logits is None:
+            self.mvrc_logits.zero_()
+        else:
+            self.mvrc_logits[:, :C].copy_(d_mvrc_logits.reshape(self.BR, C))
+        self.backward(train)
+        return self.d_tv_in.view(self.Bt, self.T, H), self.d_ovl_in.view(self.Bt, self.R, 2 * H)
 
     # ------------------------------------------------------------------------------------------
     # optimizer
@@ -553,8 +686,9 @@ class PretrainEngine:
     def zero_grad(self):
         """Start of an optimizer step.  With the TN weight-gradient path the Linear weight gradients (97 % of the buffer)
         are OVERWRITTEN by the first backward, so only the ranges that are accumulated with atomics are cleared."""
-        if not self.use_tn_wgrad:
+        if not self.use_tn_wgrad or self.core:      # (module-API mode may run without the heads: nothing overwrites their gradients)
             self.P.grad.zero_()
+            self._fresh_grads = False
             return
         if self._zero_small is None:
             covered = sorted((self.P.offsets[n], self.P.offsets[n] + math.prod(self.P.shapes[n])) for n in self._gemm_weight_names())
