@@ -41,7 +41,8 @@ int vlb_device_info(int device, char* name, int cap);
  * C[M,N] (+)= A[M,K] * B[N,K]^T, bf16 operands, fp32 accumulate, fused epilogue
  *   v = acc (+ bias[n]) ; act: 0 none | 1 erf-GELU (pre-activation optionally stored to `pre`)
  *   | 2 ReLU | 3 v *= gelu'(aux[m,n]) | 4 erf-GELU with gelu'(v) stored to `pre` (the derivative shares the
- *   forward's exponential, so the backward epilogue becomes act 5) | 5 v *= aux[m,n] ; dropout(v) ; v += res[m,n] ;
+ *   forward's exponential, so the backward epilogue becomes act 5) | 5 v *= aux[m,n] | 6 tanh (BertPooler,
+ *   modeling.py:430-436) ; dropout(v) ; v += res[m,n] ;
  *   out_mode: 0 store bf16 | 1 store fp32 | 2 fp32 atomicAdd with split-K (`splitk` <= 0: auto) |
  *             3 fp32 accumulate C += (single K pass, no atomics).
  * K % 64 == 0; lda/ldb % 8 == 0; ldc/ldaux/ldpre/ldres % 4 == 0.
@@ -161,6 +162,8 @@ int vlb_relu_bwd_cast(const float* g, const void* y, void* out, long n, vlb_stre
 int vlb_dgelu_mul(const void* dg, const void* u, void* out, long n, vlb_stream_t stream);
 /* out = a * b (bf16, n % 8 == 0): the same backward when the forward GEMM saved gelu'(u) (act 4) instead of u */
 int vlb_mul_bf16(const void* a, const void* b, void* out, long n, vlb_stream_t stream);
+/* out = dy * (1 - y^2): backward of the pooler's tanh (y = the saved bf16 output), n % 4 == 0 */
+int vlb_tanh_bwd(const void* dy, const void* y, void* out, long n, vlb_stream_t stream);
 
 /* ---- losses, forward+backward fused, gradient written in place over the bf16 logits ----------
  * MLM: F.cross_entropy(ignore_index=-1) (resnet_vlbert_for_pretraining.py:176-178).

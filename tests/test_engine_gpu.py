@@ -25,7 +25,8 @@ def make_engine(cfg, B, T, R, **kw):
                        visual_region_classes=cfg.visual_region_classes,
                        hidden_dropout_prob=cfg.hidden_dropout_prob,
                        attention_probs_dropout_prob=cfg.attention_probs_dropout_prob,
-                       obj_downsample_dropout=cfg.obj_downsample_dropout, multitask=getattr(cfg, "multitask", False))
+                       obj_downsample_dropout=cfg.obj_downsample_dropout, multitask=getattr(cfg, "multitask", False),
+                       with_pooler=cfg.with_pooler, with_rel_loss=cfg.with_rel_loss)
     return E.PretrainEngine(mc, B, T, R, device="cuda:0", keep_logits=True, **kw)
 
 
@@ -52,10 +53,12 @@ def check_against_oracle(tag, cfg, params, batch, grad_tol=5e-2):
     report(tag + " encoder output", eng.X[-1].view(B, eng.S, -1)[:, :outputs["sequence_output"].shape[1]] *
            eng.lay["attn_mask"].view(B, eng.S, 1)[:, :outputs["sequence_output"].shape[1]].to(torch.bfloat16),
            outputs["sequence_output"] * (eng.lay["attn_mask"].cpu().view(B, eng.S, 1)[:, :outputs["sequence_output"].shape[1]]), 2e-3, 1.5e-2)
-    for k in ("mlm_loss", "mvrc_loss"):
+    for k in ("mlm_loss", "mvrc_loss") + (("relationship_loss",) if cfg.with_rel_loss else ()):
         ref = float(outputs[k])
         print("%s %s: hip %.6f oracle %.6f" % (tag, k, lv[k], ref))
         assert abs(lv[k] - ref) <= 1e-2 * max(1.0, abs(ref)), (k, lv[k], ref)
+    if cfg.with_rel_loss:
+        report(tag + " relationship_logits", eng.rel_logits_copy[:, :2], outputs["relationship_logits"], 2e-3, 1e-2)
     gn = eng.grad_norm()
     print("%s grad_norm: hip %.6f oracle %.6f rel %.3e" % (tag, gn, norm, abs(gn - norm) / norm))
     assert abs(gn - norm) <= 1e-2 * norm
@@ -80,8 +83,6 @@ def test_engine_matches_reference_golden(path):
         kw[str(k)] = bool(v) if str(k).startswith("with_") or str(k) == "multitask" else int(v)
     if kw.get("multitask"):
         pytest.skip("covered by test_engine_multitask_matches_reference")
-    if kw.get("with_rel_loss"):
-        pytest.skip("relationship head / pooler are not part of the north-star configuration (WITH_REL_LOSS false)")
     cfg = O.VLBertConfig(**kw)
     params = O.init_params(cfg, seed=int(z["pseed"]))
     batch = tuple(torch.from_numpy(z["in_" + k]) for k in
@@ -92,6 +93,8 @@ def test_engine_matches_reference_golden(path):
     B, T, R = int(z["B"]), int(z["T"]), int(z["R"])
     V = cfg.vocab_size
     report(name + " mlm_logits vs REFERENCE", eng.mlm_logits_copy[:, :V].view(B, T, V), torch.from_numpy(z["mlm_logits"]), 2e-3, 1e-2)
+    if cfg.with_rel_loss:
+        report(name + " relationship_logits vs REFERENCE", eng.rel_logits_copy[:, :2], torch.from_numpy(z["relationship_logits"]), 2e-3, 1e-2)
     lv = eng.loss_values()
     assert abs(lv["loss"] - float(z["loss"])) <= 1e-2 * float(z["loss"])
     assert abs(eng.grad_norm() - float(z["grad_norm"])) <= 1e-2 * float(z["grad_norm"])
@@ -377,3 +380,44 @@ def test_module_api_hidden_states_match_oracle():
     assert e_tv <= 3e-2 and e_ovl <= 3e-2
     gw = dict(net.named_parameters())["encoder.layer.0.intermediate.dense.weight"].grad
     assert rel_fro(gw, p["vlbert.encoder.layer.0.intermediate.dense.weight"].grad) <= 5e-2
+
+
+def test_module_api_pooler_and_relationship_head_vs_oracle():
+    """with_pooler + with_rel_head through the module API: pooled output (base class) and relationship logits
+    (pretraining class) and their gradients against the oracle (whose pooler / relationship head are pinned by the
+    reference's full_rel fixture)."""
+    VL = pkg("common.visual_linguistic_bert")
+    z, cfg0, _, ins = _core_fixture()
+    cfg = O.VLBertConfig(**{**{str(k): int(v) for k, v in zip(z["cfg_keys"], z["cfg_vals"])}, "with_pooler": True, "with_rel_loss": True})
+    full = O.init_params(cfg, seed=5)
+    params = {k[len("vlbert."):]: v for k, v in full.items() if k.startswith("vlbert.")}
+    vcfg = _module_config(cfg)["NETWORK"]["VLBERT"]
+    vcfg["with_pooler"] = True
+    net = VL.VisualLinguisticBertForPretraining(vcfg, with_rel_head=True)
+    net.load_state_dict(params)
+    net.eval()
+    tv, ovl = ins[2].clone().requires_grad_(True), ins[4].clone().requires_grad_(True)
+    rel, mlm, mvrc = net(ins[0], ins[1], tv, ins[3], ovl, ins[5])
+    p = {k: v.clone().requires_grad_(True) for k, v in full.items()}
+    tvc, ovlc = ins[2].cpu().clone().requires_grad_(True), ins[4].cpu().clone().requires_grad_(True)
+    rt, ro, pooled, _ = O.vlbert_forward(p, cfg, ins[0].cpu(), ins[1].cpu(), tvc, ins[3].cpu(), ovlc, ins[5].cpu(), False)
+    rel_ref = O.linear(pooled, p, "vlbert.relationsip_head.caption_image_relationship")
+    report("module-API relationship_logits vs oracle", rel, rel_ref, 2e-3, 1e-2)
+    g = torch.Generator().manual_seed(6)
+    cr = torch.randn(rel_ref.shape, generator=g)
+    (rel_ref * cr).sum().backward()
+    (rel * cr.to(dev())).sum().backward()
+    e_tv, e_ovl = rel_fro(tv.grad, tvc.grad), rel_fro(ovl.grad, ovlc.grad)
+    print("module-API (relationship head only) input gradients: rel-fro err text_visual %.3e object_vl %.3e" % (e_tv, e_ovl))
+    assert e_tv <= 3e-2 and e_ovl <= 3e-2
+    named = dict(net.named_parameters())
+    for n in ("pooler.dense.weight", "pooler.dense.bias", "relationsip_head.caption_image_relationship.weight",
+              "encoder.layer.1.output.dense.weight"):
+        assert rel_fro(named[n].grad, p["vlbert." + n].grad) <= 5e-2, n
+    # base class: pooled output
+    base = VL.VisualLinguisticBert(vcfg)
+    base.load_state_dict({k: v for k, v in params.items() if not k.startswith(("mlm_head.", "mvrc_head.", "relationsip_head."))})
+    base.eval()
+    _, _, pooled_hip = base(ins[0], ins[1], ins[2], ins[3], ins[4], ins[5], output_all_encoded_layers=False,
+                            output_text_and_object_separately=True)
+    report("module-API pooled_output vs oracle", pooled_hip, pooled, 2e-3, 1e-2)

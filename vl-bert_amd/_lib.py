@@ -36,6 +36,7 @@ _SIGS = {
     "vlb_relu_bwd_cast": "pppls",
     "vlb_dgelu_mul": "pppls",
     "vlb_mul_bf16": "pppls",
+    "vlb_tanh_bwd": "pppls",
     "vlb_ce_fwd_bwd": "pliippfppls",
     "vlb_soft_ce_fwd_bwd": "pliiplppfppls",
     "vlb_sumsq_f32": "plps",

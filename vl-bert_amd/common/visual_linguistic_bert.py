@@ -10,7 +10,7 @@ vcr/modules/resnet_vlbert_for_vcr.py:60) can construct it unchanged.
     VisualLinguisticBertForPretraining.forward(same six tensors) -> (relationship_logits=None, mlm_logits, mvrc_logits)
 
 Both are differentiable w.r.t. the parameters and the two embedding inputs (custom autograd node -> the engine's explicit
-backward).  Supported: visual_size == hidden_size, visual_ln, no pooler / relationship head, last layer only,
+backward).  Supported: visual_size == hidden_size, visual_ln, optional pooler / relationship head, last layer only,
 text and objects returned separately; anything else raises NotImplementedError (no silent eager fallback).
 Parameters are views of the engine's flat fp32 master buffer, `.grad` views of its flat gradient buffer.
 """
@@ -30,20 +30,24 @@ class _CoreFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, text_vis, obj_vl, anchor, module, eng):
         ctx.module, ctx.eng = module, eng
-        mlm, mvrc, text_out, obj_out = eng.forward_core(train=module.training)
+        mlm, mvrc, text_out, obj_out, pooled, rel = eng.forward_core(train=module.training)
         ctx.in_dtypes = (text_vis.dtype, obj_vl.dtype)
+        third = (rel if eng.with_heads else pooled)
+        third = third.float() if third is not None else text_vis.new_zeros(())     # placeholder keeps the arity fixed
+        ctx.has_third = (rel if eng.with_heads else pooled) is not None
         if eng.with_heads:
-            return mlm.float(), mvrc.float()
-        return text_out.float(), obj_out.float()
+            return mlm.float(), mvrc.float(), third
+        return text_out.float(), obj_out.float(), third
 
     @staticmethod
-    def backward(ctx, g0, g1):
+    def backward(ctx, g0, g1, g2):
         module, eng = ctx.module, ctx.eng
         module._prepare_grads()
+        g2 = g2 if ctx.has_third else None
         if eng.with_heads:
-            d_tv, d_ovl = eng.backward_core(g0, g1, train=module.training)
+            d_tv, d_ovl = eng.backward_core(g0, g1, g2, train=module.training)
         else:
-            d_tv, d_ovl = eng.backward_core_hidden(g0, g1, train=module.training)
+            d_tv, d_ovl = eng.backward_core_hidden(g0, g1, g2, train=module.training)
         return d_tv.to(ctx.in_dtypes[0]), d_ovl.to(ctx.in_dtypes[1]), None, None, None
 
 
@@ -56,8 +60,9 @@ class VisualLinguisticBert(nn.Module):
             raise NotImplementedError("loading a language-only BERT checkpoint is host glue that is not mirrored; use load_state_dict")
         if _get(config, "visual_size", _get(config, "hidden_size")) != _get(config, "hidden_size"):
             raise NotImplementedError("visual_size != hidden_size (visual_1x1 projections) is not supported")
-        if not _get(config, "visual_ln", True) or _get(config, "with_pooler", False):
-            raise NotImplementedError("accelerated path needs visual_ln and no pooler")
+        if not _get(config, "visual_ln", True):
+            raise NotImplementedError("accelerated path needs visual_ln")
+        self.with_pooler = bool(_get(config, "with_pooler", False))
         if _get(config, "word_embedding_frozen", False) or _get(config, "pos_embedding_frozen", False):
             raise NotImplementedError("frozen embeddings are not supported")
         self.config = config
@@ -67,7 +72,8 @@ class VisualLinguisticBert(nn.Module):
             vocab_size=_get(config, "vocab_size", 30522), max_position_embeddings=_get(config, "max_position_embeddings", 512),
             type_vocab_size=_get(config, "type_vocab_size", 3), visual_region_classes=_get(config, "visual_region_classes", 1601),
             hidden_dropout_prob=_get(config, "hidden_dropout_prob", 0.1),
-            attention_probs_dropout_prob=_get(config, "attention_probs_dropout_prob", 0.1))
+            attention_probs_dropout_prob=_get(config, "attention_probs_dropout_prob", 0.1), with_pooler=self.with_pooler,
+            with_rel_loss=bool(getattr(self, "with_rel_head", False)))
         self.cfg.validate()
         if not torch.cuda.is_available():
             raise RuntimeError("VisualLinguisticBert (HIP) needs an MI355X: there is no CPU fallback")
@@ -75,7 +81,7 @@ class VisualLinguisticBert(nn.Module):
         self.flat = _engine.FlatParams(self.cfg, self.device_)
         self._engines = {}
         self._pnames = {}
-        heads = ("mlm_head.", "mvrc_head.")
+        heads = ("mlm_head.", "mvrc_head.", "relationsip_head.")
         for name, t in self.flat.named(self.flat.master).items():
             if not name.startswith(_PREFIX):
                 continue                                       # wrapper-level parameters are not part of this module
@@ -145,9 +151,9 @@ class VisualLinguisticBert(nn.Module):
         if output_all_encoded_layers or not output_text_and_object_separately or output_attention_probs:
             raise NotImplementedError("supported call form: output_all_encoded_layers=False, "
                                       "output_text_and_object_separately=True, output_attention_probs=False")
-        text_out, obj_out = self._run(text_input_ids, text_token_type_ids, text_visual_embeddings, text_mask,
-                                      object_vl_embeddings, object_mask)
-        return text_out, obj_out, None
+        text_out, obj_out, pooled = self._run(text_input_ids, text_token_type_ids, text_visual_embeddings, text_mask,
+                                              object_vl_embeddings, object_mask)
+        return text_out, obj_out, (pooled if self.with_pooler else None)
 
 
 class VisualLinguisticBertForPretraining(VisualLinguisticBert):
@@ -155,11 +161,11 @@ class VisualLinguisticBertForPretraining(VisualLinguisticBert):
 
     def __init__(self, config, language_pretrained_model_path=None, with_rel_head=True, with_mlm_head=True, with_mvrc_head=True,
                  device=None):
-        if with_rel_head:
-            raise NotImplementedError("relationship head needs the pooler, which is not part of the accelerated configuration "
-                                      "(WITH_REL_LOSS is false in every shipped pretrain cfg)")
+        if with_rel_head and not _get(config, "with_pooler", False):
+            raise ValueError("with_rel_head needs config.with_pooler (the relationship head reads the pooled output)")
         if not (with_mlm_head and with_mvrc_head):
             raise NotImplementedError("accelerated path computes both the MLM and the MVRC head")
+        self.__dict__["with_rel_head"] = bool(with_rel_head)     # read by the base constructor (before nn.Module.__init__)
         super().__init__(config, language_pretrained_model_path, device=device)
 
     def state_dict(self, *args, **kwargs):
@@ -175,6 +181,6 @@ class VisualLinguisticBertForPretraining(VisualLinguisticBert):
 
     def forward(self, text_input_ids, text_token_type_ids, text_visual_embeddings, text_mask, object_vl_embeddings, object_mask,
                 output_all_encoded_layers=True, output_text_and_object_separately=False):
-        mlm_logits, mvrc_logits = self._run(text_input_ids, text_token_type_ids, text_visual_embeddings, text_mask,
-                                            object_vl_embeddings, object_mask)
-        return None, mlm_logits, mvrc_logits
+        mlm_logits, mvrc_logits, rel_logits = self._run(text_input_ids, text_token_type_ids, text_visual_embeddings, text_mask,
+                                                        object_vl_embeddings, object_mask)
+        return (rel_logits if self.with_rel_head else None), mlm_logits, mvrc_logits

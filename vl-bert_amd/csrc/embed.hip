@@ -512,6 +512,17 @@ __global__ void mul_bf16_kernel(const bf16_t* __restrict__ a, const bf16_t* __re
   *(uint4*)(out + i) = o;
 }
 
+// out = dy * (1 - y^2)   (backward of y = tanh(x), BertPooler)
+__global__ void tanh_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ y, bf16_t* __restrict__ out, long n) {
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  const uint2 a = *(const uint2*)(dy + i), b = *(const uint2*)(y + i);
+  const float y0 = bflo(b.x), y1 = bfhi(b.x), y2 = bflo(b.y), y3 = bfhi(b.y);
+  uint2 o = {pack2bf(bflo(a.x) * (1.f - y0 * y0), bfhi(a.x) * (1.f - y1 * y1)),
+             pack2bf(bflo(a.y) * (1.f - y2 * y2), bfhi(a.y) * (1.f - y3 * y3))};
+  *(uint2*)(out + i) = o;
+}
+
 // ---------------------------------------------------------------------------------- C ABI
 extern "C" int vlb_seq_layout(const uint8_t* text_mask, const uint8_t* obj_mask, int B, int T, int R, int S, int32_t* code,
                               int32_t* text_len, int32_t* nobj, int32_t* text_rows, int32_t* obj_rows, float* attn_mask,
@@ -658,5 +669,14 @@ extern "C" int vlb_mul_bf16(const void* a, const void* b, void* out, long n, hip
   hipLaunchKernelGGL(mul_bf16_kernel, dim3(vlb_cdiv(n / 8, 256)), dim3(256), 0, stream, (const bf16_t*)a, (const bf16_t*)b,
                      (bf16_t*)out, n);
   VLB_CHECK_LAUNCH("vlb_mul_bf16");
+  return VLB_OK;
+}
+
+extern "C" int vlb_tanh_bwd(const void* dy, const void* y, void* out, long n, hipStream_t stream) {
+  if (n <= 0) return VLB_OK;
+  VLB_CHECK_ARG((n % 4) == 0, "vlb_tanh_bwd: n must be a multiple of 4");
+  hipLaunchKernelGGL(tanh_bwd_kernel, dim3(vlb_cdiv(n / 4, 256)), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)y,
+                     (bf16_t*)out, n);
+  VLB_CHECK_LAUNCH("vlb_tanh_bwd");
   return VLB_OK;
 }

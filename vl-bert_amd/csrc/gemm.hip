@@ -33,7 +33,7 @@ struct GemmParams {
   int M, N, K;
   int k_per_split;           // K range handled by one blockIdx.y slice (multiple of 64)
   const float* bias;         // [N] fp32 or null
-  int act;                   // 0 none, 1 gelu, 2 relu, 3 multiply by gelu'(aux), 4 gelu with gelu'(x) -> pre, 5 multiply by aux
+  int act;                   // 0 none, 1 gelu, 2 relu, 3 multiply by gelu'(aux), 4 gelu with gelu'(x) -> pre, 5 multiply by aux, 6 tanh
   const bf16_t* aux; long ldaux;
   bf16_t* pre; long ldpre;   // optional pre-activation output (act==1)
   const bf16_t* res; long ldres;
@@ -177,6 +177,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
       } else if (ACT == 2) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+      } else if (ACT == 6) {     // BertPooler (modeling.py:430-436): tanh(x) = 1 - 2 / (exp(2x) + 1)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * v[r]) + 1.0f);
       } else if (ACT == 3 || ACT == 5) {
         float u[4] = {0.f, 0.f, 0.f, 0.f};
         const bf16_t* q = aux_row + j * 16;
@@ -250,6 +253,7 @@ __device__ __forceinline__ void gemm_epilogue_dispatch(const GemmParams& p, f32x
   else if (p.act == 3) gemm_epilogue<3, false, false, 0, INTERIOR, FM, FN>(p, acc, mb, nb, st);
   else if (p.act == 4) gemm_epilogue<4, false, false, 0, INTERIOR, FM, FN>(p, acc, mb, nb, st);
   else if (p.act == 5) gemm_epilogue<5, false, false, 0, INTERIOR, FM, FN>(p, acc, mb, nb, st);
+  else if (p.act == 6) gemm_epilogue<6, false, false, 0, INTERIOR, FM, FN>(p, acc, mb, nb, st);
   else if (p.res) {
     if (p.drop_thr) gemm_epilogue<0, true, true, 0, INTERIOR, FM, FN>(p, acc, mb, nb, st);
     else gemm_epilogue<0, false, true, 0, INTERIOR, FM, FN>(p, acc, mb, nb, st);
@@ -814,7 +818,7 @@ extern "C" int vlb_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb
   VLB_CHECK_ARG((lda % 8) == 0 && (ldb % 8) == 0, "vlb_gemm_nt_bf16: lda/ldb must be multiples of 8 elements");
   VLB_CHECK_ARG((ldc % 4) == 0, "vlb_gemm_nt_bf16: ldc must be a multiple of 4");
   VLB_CHECK_ARG(out_mode >= 0 && out_mode <= 3, "vlb_gemm_nt_bf16: bad out_mode %d", out_mode);
-  VLB_CHECK_ARG(act >= 0 && act <= 5, "vlb_gemm_nt_bf16: bad act %d", act);
+  VLB_CHECK_ARG(act >= 0 && act <= 6, "vlb_gemm_nt_bf16: bad act %d", act);
   VLB_CHECK_ARG((act != 3 && act != 5) || aux, "vlb_gemm_nt_bf16: act=3/5 needs aux");
   VLB_CHECK_ARG(act == 0 || (!(drop_p > 0.f) && !res), "vlb_gemm_nt_bf16: an activation cannot be combined with dropout/residual");
   VLB_CHECK_ARG(out_mode == 0 || (act == 0 && !(drop_p > 0.f) && !res), "vlb_gemm_nt_bf16: fp32 outputs take bias only");

@@ -49,6 +49,8 @@ class ModelConfig:
     attention_probs_dropout_prob: float = 0.1
     obj_downsample_dropout: float = 0.1
     multitask: bool = False      # ResNetVLBERTForPretrainingMultitask: text-only auxiliary samples (+1 parameter)
+    with_pooler: bool = False    # BertPooler on the first token (modeling.py:424-436)
+    with_rel_loss: bool = False  # relationship head on the pooled output + its CE loss (needs with_pooler)
 
     def validate(self):
         H, nh = self.hidden_size, self.num_attention_heads
@@ -56,6 +58,8 @@ class ModelConfig:
             raise ValueError("engine supports head dim 64 and hidden_size % 64 == 0 (got H=%d, heads=%d)" % (H, nh))
         if self.intermediate_size % 64:
             raise ValueError("intermediate_size must be a multiple of 64")
+        if self.with_rel_loss and not self.with_pooler:
+            raise ValueError("with_rel_loss needs with_pooler (the relationship head reads the pooled output)")
 
 
 def param_layout(cfg):
@@ -94,6 +98,12 @@ def param_layout(cfg):
         s[p + "output.dense.bias"] = (H,)
         s[p + "output.LayerNorm.weight"] = (H,)
         s[p + "output.LayerNorm.bias"] = (H,)
+    if cfg.with_pooler:
+        s["vlbert.pooler.dense.weight"] = (H, H)
+        s["vlbert.pooler.dense.bias"] = (H,)
+    if cfg.with_rel_loss:       # [sic] the typo is part of the reference's key (common/visual_linguistic_bert.py:322)
+        s["vlbert.relationsip_head.caption_image_relationship.weight"] = (2, H)
+        s["vlbert.relationsip_head.caption_image_relationship.bias"] = (2,)
     p = "vlbert.mlm_head.predictions."
     s[p + "transform.dense.weight"] = (H, H)
     s[p + "transform.dense.bias"] = (H,)
@@ -201,11 +211,15 @@ class PretrainEngine:
         self.wT["vlbert.mvrc_head.transform.dense.weight"] = zb(H, H)
         self.wT["vlbert.mvrc_head.region_cls_pred.weight"] = zb(H, self.Cp)
         self.wT["image_feature_extractor.obj_downsample.1.weight"] = zb(2 * VIS_DIM, H)
+        if cfg.with_pooler:
+            self.wT["vlbert.pooler.dense.weight"] = zb(H, H)
+        if cfg.with_rel_loss:
+            self.wT["vlbert.relationsip_head.caption_image_relationship.weight"] = zb(H, 64)   # K padded to one 64-wide tile
 
         # device-resident step state
         self.seed = torch.tensor([seed | 1], dtype=torch.int32, device=d)
         self.adam = torch.tensor([lr, betas[0], betas[1], eps, weight_decay, 0.0, max_grad_norm, 0.0], dtype=F32, device=d)
-        self.losses = zf(4)       # mlm (with visual content), mvrc, mlm (aux text), (unused)
+        self.losses = zf(4)       # mlm (with visual content), mvrc, mlm (aux text), relationship
         self.counts = zf(4)       # n_valid mlm, n_valid mvrc, n_valid mlm aux
 
         # static batch buffers (graph-capturable: the host copies new batches into them)
@@ -216,6 +230,7 @@ class PretrainEngine:
         self.in_mlm_labels = torch.full((Bt, T), -1, dtype=torch.int64, device=d)
         self.in_mvrc_ops = torch.zeros((B, R), dtype=torch.int64, device=d)
         self.in_mvrc_labels = zf(B, R, C)
+        self.in_rel_label = torch.zeros((B,), dtype=torch.int64, device=d)
         self.text_mask = torch.zeros((Bt, T), dtype=torch.uint8, device=d)
         self.box_mask = torch.zeros((Bt, R), dtype=torch.uint8, device=d)     # aux rows stay 0: no objects
         i32 = lambda *s: torch.zeros(s, dtype=torch.int32, device=d)
@@ -242,6 +257,11 @@ class PretrainEngine:
         self.mvrc_u, self.mvrc_g = zb(BR, H), zb(BR, H)
         self.mvrc_logits = zb(BR, self.Cp)
         self.mvrc_tsum = zf(BR)
+        if cfg.with_pooler:
+            self.pooled, self.d_pooled, self.d_pool_pre = zb(B, H), zb(B, H), zb(B, H)
+        if cfg.with_rel_loss:
+            self.rel_logits = zb(B, 64)                   # 2 logits, row padded to 64 (pad columns stay zero)
+            self.rel_logits_copy = zb(B, 64) if keep_logits else None
         self.mlm_logits_copy = zb(BT, self.Vp) if keep_logits else None
         self.mvrc_logits_copy = zb(BR, self.Cp) if keep_logits else None
 
@@ -317,9 +337,11 @@ class PretrainEngine:
                 pairs.append((wqkv, self.wT[p + "qkv"]))
                 for n in ("attention.output.dense.weight", "intermediate.dense.weight", "output.dense.weight"):
                     pairs.append((self.w16[p + n], self.wT[p + n]))
-            for n in ("vlbert.mlm_head.predictions.transform.dense.weight", "vlbert.word_embeddings.weight",
+            extra = [n for n in ("vlbert.pooler.dense.weight", "vlbert.relationsip_head.caption_image_relationship.weight")
+                     if n in self.wT]
+            for n in ["vlbert.mlm_head.predictions.transform.dense.weight", "vlbert.word_embeddings.weight",
                       "vlbert.mvrc_head.transform.dense.weight", "vlbert.mvrc_head.region_cls_pred.weight",
-                      "image_feature_extractor.obj_downsample.1.weight"):
+                      "image_feature_extractor.obj_downsample.1.weight"] + extra:
                 pairs.append((self.w16[n], self.wT[n]))
             self._tbatch = ops.TransposeBatch(pairs, self.dev)
         self._tbatch.run()
@@ -331,8 +353,8 @@ class PretrainEngine:
                   aux_mlm_labels=None):
         """Copies a collated batch (pretrain/data/collate_batch.py layout) into the static device buffers
         and derives the masks exactly as resnet_vlbert_for_pretraining.py:106,134 does
-        (box_mask = boxes[:,:,0] > -1.5 ; text_mask = text > 0).  `relationship_label` is unused
-        (WITH_REL_LOSS false in the north-star configuration)."""
+        (box_mask = boxes[:,:,0] > -1.5 ; text_mask = text > 0).  `relationship_label` is only read
+        with ModelConfig(with_rel_loss=True) (WITH_REL_LOSS is false in the north-star configuration)."""
         B = self.B
         self.in_boxes.copy_(boxes, non_blocking=True)
         self.in_im_info.copy_(im_info, non_blocking=True)
@@ -348,6 +370,8 @@ class PretrainEngine:
             self.in_mlm_labels[B:, :aux_mlm_labels.shape[1]].copy_(aux_mlm_labels, non_blocking=True)
         self.in_mvrc_ops.copy_(mvrc_ops, non_blocking=True)
         self.in_mvrc_labels.copy_(mvrc_labels, non_blocking=True)
+        if self.cfg.with_rel_loss:
+            self.in_rel_label.copy_(relationship_label, non_blocking=True)
         torch.gt(self.in_text, 0, out=self.text_mask.view(torch.bool))
         torch.gt(self.in_boxes[:, :, 0], -1.5, out=self.box_mask[:B].view(torch.bool))
 
@@ -445,8 +469,14 @@ class PretrainEngine:
         xl = self.X[L]
         ops.gather_rows(xl, self.lay["text_rows"].view(-1), self.text_out)
         ops.gather_rows(xl, self.lay["obj_rows"].view(-1)[:self.BR], self.obj_out)
+        if cfg.with_pooler:       # BertPooler: tanh(dense(first token)) for the image-caption samples; A operand = strided view of X[L]
+            x0 = xl.view(Bt, S * H)[:self.B, :H]
+            ops.gemm_nt(x0, w16["vlbert.pooler.dense.weight"], self.pooled, bias=w32["vlbert.pooler.dense.bias"], act=ops.ACT_TANH)
         if not self.with_heads:
             return
+        if cfg.with_rel_loss:     # relationsip_head: Linear(H -> 2) on the pooled output (common/visual_linguistic_bert.py:505-516)
+            pr = "vlbert.relationsip_head.caption_image_relationship."
+            ops.gemm_nt(self.pooled, w16[pr + "weight"], self.rel_logits[:, :2], bias=w32[pr + "bias"])
         pm = "vlbert.mlm_head.predictions."
         ops.gemm_nt(self.text_out, w16[pm + "transform.dense.weight"], self.mlm_g, bias=w32[pm + "transform.dense.bias"],
                     act=ops.ACT_GELU_D, pre=self.mlm_u)
@@ -476,6 +506,11 @@ class PretrainEngine:
                            gscale=gscale, logits_copy=mcopy[nw:] if mcopy is not None else None)
         ops.soft_ce_fwd_bwd(self.mvrc_logits, C, self.in_mvrc_labels.view(self.BR, C), self.mvrc_tsum, self.counts[1:2],
                             losses[1:2], gscale=gscale, logits_copy=vcopy)
+        if self.cfg.with_rel_loss:     # F.cross_entropy(relationship_logits, relationship_label) (resnet_vlbert_for_pretraining.py:160-161)
+            if not keep:
+                self.rel_logits.copy_(self.rel_logits_copy)
+            ops.ce_fwd_bwd(self.rel_logits, 2, self.in_rel_label, self.counts[3:4], losses[3:4], gscale=gscale,
+                           logits_copy=self.rel_logits_copy if keep else None)
 
     # ------------------------------------------------------------------------------------------
     # backward (explicit; weight gradients are ACCUMULATED into the flat fp32 grad buffer)
@@ -520,8 +555,20 @@ class PretrainEngine:
             self._wgrad(self.d_mvrc_u, self.obj_out, g32["vlbert.mvrc_head.transform.dense.weight"],
                         g32["vlbert.mvrc_head.transform.dense.bias"], self.tG_br, self.tA_br, BRp)
             ops.gemm_nt(self.d_mvrc_u, wT["vlbert.mvrc_head.transform.dense.weight"], self.d_obj_out)
+            if cfg.with_rel_loss:
+                pr = "vlbert.relationsip_head.caption_image_relationship."
+                self._wgrad(self.rel_logits[:, :2], self.pooled, g32[pr + "weight"], g32[pr + "bias"], None, None, 0)
+                ops.gemm_nt(self.rel_logits, wT[pr + "weight"], self.d_pooled)      # K = 64: two logits + zero padding
         dx = self.dXa
         ops.head_grad_combine(self.d_text_out, self.d_obj_out, self.lay["code"], dx, Bt, T, R, S, H)
+        if cfg.with_pooler and (cfg.with_rel_loss or not self.with_heads):
+            # d(pooled) came from the relationship head (or from the caller in hidden-state mode): through tanh and the
+            # dense layer, then ADDED to the first-token rows of dX (gemm epilogue residual = its own output rows)
+            ops.tanh_bwd(self.d_pooled, self.pooled, self.d_pool_pre)
+            x0 = self.X[L].view(Bt, S * H)[:self.B, :H]
+            self._wgrad(self.d_pool_pre, x0, g32["vlbert.pooler.dense.weight"], g32["vlbert.pooler.dense.bias"], None, None, 0)
+            dx0 = dx.view(Bt, S * H)[:self.B, :H]
+            ops.gemm_nt(self.d_pool_pre, wT["vlbert.pooler.dense.weight"], dx0, res=dx0)
         if on_layer_done:
             on_layer_done("heads")
         # --- encoder, last layer first -------------------------------------------------------------------
@@ -645,15 +692,22 @@ class PretrainEngine:
         self.box_mask.view(torch.bool).copy_(object_mask)
 
     def forward_core(self, train=None):
-        """-> (mlm_logits [B,T,V] bf16 view, mvrc_logits [B,R,C] bf16 view, text_out [B,T,H], obj_out [B,R,H])."""
+        """-> (mlm_logits [B,T,V], mvrc_logits [B,R,C], text_out [B,T,H], obj_out [B,R,H], pooled [B,H] | None,
+        relationship_logits [B,2] | None) as bf16 views of the engine buffers."""
         self.forward(train)
         V, C, H = self.cfg.vocab_size, self.cfg.visual_region_classes, self.cfg.hidden_size
         return (self.mlm_logits[:, :V].view(self.Bt, self.T, V), self.mvrc_logits[:, :C].view(self.B, self.R, C),
-                self.text_out.view(self.Bt, self.T, H), self.obj_out.view(self.B, self.R, H))
+                self.text_out.view(self.Bt, self.T, H), self.obj_out.view(self.B, self.R, H),
+                self.pooled if self.cfg.with_pooler else None, self.rel_logits[:, :2] if self.cfg.with_rel_loss else None)
 
-    def backward_core_hidden(self, d_text_out, d_obj_out, train=None):
-        """core_heads=False: d(text_out) [B,T,H] / d(obj_out) [B,R,H] -> input gradients (see backward_core)."""
+    def backward_core_hidden(self, d_text_out, d_obj_out, d_pooled=None, train=None):
+        """core_heads=False: d(text_out) [B,T,H] / d(obj_out) [B,R,H] (/ d(pooled) [B,H]) -> input gradients (see backward_core)."""
         H = self.cfg.hidden_size
+        if self.cfg.with_pooler:
+            if d_pooled is None:
+                self.d_pooled.zero_()
+            else:
+                self.d_pooled.copy_(d_pooled)
         if d_text_out is None:
             self.d_text_out.zero_()
         else:
@@ -665,7 +719,7 @@ class PretrainEngine:
         self.backward(train)
         return self.d_tv_in.view(self.Bt, self.T, H), self.d_ovl_in.view(self.Bt, self.R, 2 * H)
 
-    def backward_core(self, d_mlm_logits, d_mvrc_logits, train=None):
+    def backward_core(self, d_mlm_logits, d_mvrc_logits, d_rel_logits=None, train=None):
         """d(logits) [B,T,V] / [B,R,C] (any float dtype; None = zero) -> parameter gradients accumulated into the flat
         gradient, returns (d text_visual_embeddings [B,T,H], d object_vl_embeddings [B,R,2H]) as bf16 views."""
         V, C, H = self.cfg.vocab_size, self.cfg.visual_region_classes, self.cfg.hidden_size
@@ -677,6 +731,11 @@ class PretrainEngine:
             self.mvrc_logits.zero_()
         else:
             self.mvrc_logits[:, :C].copy_(d_mvrc_logits.reshape(self.BR, C))
+        if self.cfg.with_rel_loss:
+            if d_rel_logits is None:
+                self.rel_logits.zero_()
+            else:
+                self.rel_logits[:, :2].copy_(d_rel_logits)
         self.backward(train)
         return self.d_tv_in.view(self.Bt, self.T, H), self.d_ovl_in.view(self.Bt, self.R, 2 * H)
 
@@ -707,6 +766,8 @@ class PretrainEngine:
         names = ["image_feature_extractor.obj_downsample.1.weight", "vlbert.word_embeddings.weight",
                  "vlbert.mlm_head.predictions.transform.dense.weight", "vlbert.mvrc_head.transform.dense.weight",
                  "vlbert.mvrc_head.region_cls_pred.weight"]
+        if self.cfg.with_rel_loss:
+            names += ["vlbert.pooler.dense.weight", "vlbert.relationsip_head.caption_image_relationship.weight"]
         for l in range(L):
             p = "vlbert.encoder.layer.%d." % l
             names += [p + "attention.self.query.weight", p + "attention.self.key.weight", p + "attention.self.value.weight",
@@ -741,7 +802,7 @@ class PretrainEngine:
     # ------------------------------------------------------------------------------------------
     def loss_values(self):
         l = self.losses.cpu()
-        out = dict(mlm_loss=float(l[0]), mvrc_loss=float(l[1]), loss=float(l[0] + l[1] + l[2]))
+        out = dict(mlm_loss=float(l[0]), mvrc_loss=float(l[1]), relationship_loss=float(l[3]), loss=float(l[0] + l[1] + l[2] + l[3]))
         if self.Ba:
             out.update(mlm_loss_wvc=float(l[0]), mlm_loss_aux=float(l[2]))
         return out

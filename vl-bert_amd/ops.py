@@ -9,7 +9,7 @@ import torch
 from . import _lib
 
 BF16 = torch.bfloat16
-ACT_NONE, ACT_GELU, ACT_RELU, ACT_DGELU, ACT_GELU_D, ACT_MULAUX = 0, 1, 2, 3, 4, 5
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_DGELU, ACT_GELU_D, ACT_MULAUX, ACT_TANH = 0, 1, 2, 3, 4, 5, 6
 OUT_BF16, OUT_F32, OUT_F32_ATOMIC = 0, 1, 2
 
 
@@ -248,6 +248,11 @@ def relu_bwd_cast(g, y, out):
 
 def dgelu_mul(dg, u, out):
     _lib.call("vlb_dgelu_mul", _p(dg, BF16), _p(u, BF16), _p(out, BF16), dg.numel(), _stream())
+    return out
+
+
+def tanh_bwd(dy, y, out):
+    _lib.call("vlb_tanh_bwd", _p(dy, BF16), _p(y, BF16), _p(out, BF16), dy.numel(), _stream())
     return out
 
 

@@ -12,7 +12,8 @@ How it maps onto the engine:
     runs the hand-scheduled HIP backward and leaves the gradients in `param.grad`;
   * engines are built per (batch, text length, regions) shape on first use and share the parameter storage.
 Supported configuration = the north-star one (cfgs/pretrain/base_prec_withouttextonly_4x16G_fp32.yaml):
-IMAGE_FEAT_PRECOMPUTED, WITH_MLM_LOSS, WITH_MVRC_LOSS, no relationship head, no pooler, visual_ln.
+IMAGE_FEAT_PRECOMPUTED, WITH_MLM_LOSS, WITH_MVRC_LOSS, visual_ln; the pooler and the relationship head / loss
+(WITH_REL_LOSS, off in every shipped pretrain cfg) are available too.
 Anything else raises NotImplementedError (nothing silently falls back to PyTorch eager).
 """
 import torch
@@ -32,7 +33,7 @@ class _HipLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, module, eng):
         ctx.module, ctx.eng = module, eng
-        return (eng.losses[0] + eng.losses[1] + eng.losses[2]).clone()
+        return (eng.losses[0] + eng.losses[1] + eng.losses[2] + eng.losses[3]).clone()
 
     @staticmethod
     def backward(ctx, grad_out):
@@ -55,8 +56,11 @@ class ResNetVLBERTForPretraining(nn.Module):
         vl = _get(net, "VLBERT")
         if not _get(net, "IMAGE_FEAT_PRECOMPUTED", False):
             raise NotImplementedError("end-to-end ResNet-101/RoIAlign image path is not built yet (SURVEY.md §8f rank 3)")
-        if _get(net, "WITH_REL_LOSS", False) or _get(vl, "with_pooler", False):
-            raise NotImplementedError("relationship head / pooler are not part of the accelerated configuration")
+        self.with_rel = bool(_get(net, "WITH_REL_LOSS", False))
+        if self.with_rel and not _get(vl, "with_pooler", False):
+            raise ValueError("WITH_REL_LOSS needs VLBERT.with_pooler (the relationship head reads the pooled output)")
+        if self.with_rel and self.MULTITASK:
+            raise NotImplementedError("relationship loss in the multitask wrapper is not supported")
         if not (_get(net, "WITH_MLM_LOSS", True) and _get(net, "WITH_MVRC_LOSS", True) and _get(vl, "visual_ln", True)):
             raise NotImplementedError("accelerated path needs WITH_MLM_LOSS, WITH_MVRC_LOSS and visual_ln")
         if _get(net, "IMAGE_SEMANTIC", False) or _get(vl, "word_embedding_frozen", False) or _get(vl, "pos_embedding_frozen", False):
@@ -69,7 +73,8 @@ class ResNetVLBERTForPretraining(nn.Module):
             vocab_size=_get(vl, "vocab_size", 30522), max_position_embeddings=_get(vl, "max_position_embeddings", 512),
             type_vocab_size=_get(vl, "type_vocab_size", 3), visual_region_classes=_get(vl, "visual_region_classes", 1601),
             hidden_dropout_prob=_get(vl, "hidden_dropout_prob", 0.1),
-            attention_probs_dropout_prob=_get(vl, "attention_probs_dropout_prob", 0.1), multitask=self.MULTITASK)
+            attention_probs_dropout_prob=_get(vl, "attention_probs_dropout_prob", 0.1), multitask=self.MULTITASK,
+            with_pooler=bool(_get(vl, "with_pooler", False)), with_rel_loss=self.with_rel)
         self.cfg.validate()
         if not torch.cuda.is_available():
             raise RuntimeError("ResNetVLBERTForPretraining (HIP) needs an MI355X: there is no CPU fallback")
@@ -170,10 +175,12 @@ class ResNetVLBERTForPretraining(nn.Module):
         loss = _HipLoss.apply(self._pnames["vlbert.word_embeddings.weight"], self, eng)
         mlm_logits, mvrc = self._padded_logits(eng, B)
         outputs = {
-            "relationship_logits": None, "relationship_label": None,
+            "relationship_logits": eng.rel_logits_copy[:, :2].float() if self.with_rel else None,
+            "relationship_label": relationship_label if self.with_rel else None,
             "mlm_logits": mlm_logits, "mlm_label": mlm_labels,
             "mvrc_logits": mvrc, "mvrc_label": mvrc_labels,
-            "relationship_loss": im_info.new_zeros(()), "mlm_loss": eng.losses[0].clone(), "mvrc_loss": eng.losses[1].clone(),
+            "relationship_loss": eng.losses[3].clone() if self.with_rel else im_info.new_zeros(()),
+            "mlm_loss": eng.losses[0].clone(), "mvrc_loss": eng.losses[1].clone(),
         }
         return outputs, loss
 
