@@ -10,7 +10,7 @@ import pytest
 import torch
 
 from oracle import vlbert_oracle as O
-from tests.gpu_util import dev, pkg, report
+from tests.gpu_util import bf, dev, pkg, report
 
 pytestmark = pytest.mark.gpu
 GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
@@ -421,3 +421,103 @@ def test_module_api_pooler_and_relationship_head_vs_oracle():
     _, _, pooled_hip = base(ins[0], ins[1], ins[2], ins[3], ins[4], ins[5], output_all_encoded_layers=False,
                             output_text_and_object_separately=True)
     report("module-API pooled_output vs oracle", pooled_hip, pooled, 2e-3, 1e-2)
+
+
+def test_module_api_vqa_style_composition_vs_oracle():
+    """The call pattern of vqa/modules/resnet_vlbert_for_vqa.py:169-245 on the mirrors: FastRCNN (precomputed branch) ->
+    text-visual = obj_reps[:, 0], object_vl = [obj_reps || linguistic embedding] -> VisualLinguisticBert(..., packed
+    sequence out) -> hidden state at the answer position.  Values and gradients (downsample weights through the
+    FastRCNN node, the torch-side linguistic embedding through d(object_vl), an encoder weight) against the oracle."""
+    VL, FR = pkg("common.visual_linguistic_bert"), pkg("common.fast_rcnn")
+    syn = pkg("synthetic")
+    cfg = O.VLBertConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, vocab_size=512,
+                         max_position_embeddings=64, visual_region_classes=50)
+    B, T, R, H = 3, 9, 5, cfg.hidden_size
+    full = O.init_params(cfg, seed=17)
+    boxes, im_info, text, _, _, _, _ = syn.make_batch(B, T, R, vocab_size=cfg.vocab_size, region_classes=50, seed=4, ragged=True)
+    box_mask, text_mask = boxes[:, :, 0] > -1.5, text > 0
+    ans_pos = (text_mask.sum(1) - 2).clamp(min=1)
+    cot = torch.randn((B, H), generator=torch.Generator().manual_seed(8))
+
+    class A(dict):
+        __getattr__ = dict.__getitem__
+    frcnn = FR.FastRCNN(A(NETWORK=A(IMAGE_FEAT_PRECOMPUTED=True, IMAGE_SEMANTIC=False)), final_dim=H)
+    frcnn.load_state_dict({"obj_downsample.1.weight": full["image_feature_extractor.obj_downsample.1.weight"],
+                           "obj_downsample.1.bias": full["image_feature_extractor.obj_downsample.1.bias"]})
+    vlbert = VL.VisualLinguisticBert(_module_config(cfg)["NETWORK"]["VLBERT"])
+    vlbert.load_state_dict({k[len("vlbert."):]: v for k, v in full.items()
+                            if k.startswith("vlbert.") and not k.startswith(("vlbert.mlm_head.", "vlbert.mvrc_head."))})
+    frcnn.eval(); vlbert.eval()
+    ling = full["object_linguistic_embeddings.weight"].clone().to(dev()).requires_grad_(True)
+
+    def compose(fr, vb, ling_w, to):
+        obj = fr(None, to(boxes), to(box_mask), to(im_info))["obj_reps"]
+        text_vis = obj[:, 0:1].expand(B, T, H)
+        ovl = torch.cat((obj, ling_w.view(1, 1, H).expand(B, R, H)), -1)
+        seq, pooled = vb(to(text), torch.zeros_like(to(text)), text_vis, to(text_mask), ovl, to(box_mask),
+                         output_all_encoded_layers=False)
+        return seq[torch.arange(B), to(ans_pos)]
+
+    hm = compose(frcnn, vlbert, ling, lambda t: t.to(dev()))
+    p = {k: v.clone().requires_grad_(True) for k, v in full.items()}
+
+    def fr_ref(images, bx, bm, ii):
+        return {"obj_reps": O.fast_rcnn_precomputed(p, cfg, bx, bm, ii, False)}
+
+    def vb_ref(ids, types, tv, tm, ovl, om, output_all_encoded_layers=False):
+        return O.vlbert_forward(p, cfg, ids, types, tv, tm, ovl, om, False)[3], None
+    hm_ref = compose(fr_ref, vb_ref, p["object_linguistic_embeddings.weight"], lambda t: t)
+    report("VQA-style hidden state at the answer position vs oracle", hm, hm_ref, 2e-3, 1.5e-2)
+    (hm_ref * cot).sum().backward()
+    (hm * cot.to(dev())).sum().backward()
+    checks = [("obj_downsample.1.weight", getattr(frcnn.obj_downsample, "1").weight.grad, p["image_feature_extractor.obj_downsample.1.weight"].grad),
+              ("obj_downsample.1.bias", getattr(frcnn.obj_downsample, "1").bias.grad, p["image_feature_extractor.obj_downsample.1.bias"].grad),
+              ("object_linguistic_embeddings", ling.grad, p["object_linguistic_embeddings.weight"].grad),
+              ("encoder.layer.0.attention.self.query.weight", dict(vlbert.named_parameters())["encoder.layer.0.attention.self.query.weight"].grad,
+               p["vlbert.encoder.layer.0.attention.self.query.weight"].grad)]
+    for name, g, ref in checks:
+        e = rel_fro(g, ref)
+        print("   VQA-style composition: rel-fro grad err %.3e  %s" % (e, name))
+        assert e <= 5e-2, name
+
+
+def test_fast_rcnn_mirror_mask_embedding_gradient():
+    """FastRCNN mirror with mvrc_ops / mask_visual_embed (common/fast_rcnn.py:170-172): output, obj_reps_raw and the
+    gradient that flows back into the mask embedding."""
+    FR, syn = pkg("common.fast_rcnn"), pkg("synthetic")
+    H, B, T, R = 128, 3, 6, 7
+    cfg = O.VLBertConfig(hidden_size=H, num_hidden_layers=1, num_attention_heads=2, intermediate_size=256, vocab_size=512,
+                         max_position_embeddings=64, visual_region_classes=50)
+    full = O.init_params(cfg, seed=19)
+    boxes, im_info, _, _, _, mvrc_ops, _ = syn.make_batch(B, T, R, vocab_size=512, region_classes=50, seed=9, ragged=True)
+    box_mask = boxes[:, :, 0] > -1.5
+
+    class A(dict):
+        __getattr__ = dict.__getitem__
+    fr = FR.FastRCNN(A(NETWORK=A(IMAGE_FEAT_PRECOMPUTED=True, IMAGE_SEMANTIC=False)), final_dim=H)
+    fr.load_state_dict({"obj_downsample.1.weight": full["image_feature_extractor.obj_downsample.1.weight"],
+                        "obj_downsample.1.bias": full["image_feature_extractor.obj_downsample.1.bias"]})
+    fr.eval()
+    emb = bf(full["object_mask_visual_embedding.weight"].clone())
+    emb_g = emb.clone().to(dev()).requires_grad_(True)
+    out = fr(None, boxes.to(dev()), box_mask.to(dev()), im_info.to(dev()), mvrc_ops=mvrc_ops.to(dev()), mask_visual_embed=emb_g)
+    p = {k: v.clone().requires_grad_(True) for k, v in full.items()}
+    emb_r = emb.clone().requires_grad_(True)
+    bx = boxes.clone()
+    feats = torch.where((mvrc_ops == 1).unsqueeze(-1), emb_r.view(1, 1, -1).expand(B, R, -1), bx[:, :, 4:])
+    bx = torch.cat((bx[:, :, :4], feats), -1)
+    ref = O.fast_rcnn_precomputed(p, cfg, bx, box_mask, im_info, False)
+    report("FastRCNN mirror obj_reps vs oracle", out["obj_reps"], ref, 2e-3, 1e-2)
+    raw_ref = feats * box_mask.unsqueeze(-1)
+    report("FastRCNN mirror obj_reps_raw", out["obj_reps_raw"], raw_ref.detach(), 1e-6, 1e-6)
+    # cotangent only on units whose ReLU state cannot differ between bf16 and fp32 arithmetic (|pre-activation| near 0
+    # flips ~1 % of the units; with 4 masked regions x 128 units that alone is a 10 % gradient difference)
+    hip = out["obj_reps"].detach().cpu()
+    safe = (ref.detach() > 0.05) | ((ref.detach() == 0) & (hip == 0))
+    cot = torch.randn(ref.shape, generator=torch.Generator().manual_seed(3)) * safe
+    (ref * cot).sum().backward()
+    (out["obj_reps"] * cot.to(dev())).sum().backward()
+    e = rel_fro(emb_g.grad, emb_r.grad)
+    print("FastRCNN mirror: rel-fro err of d(mask_visual_embed) %.3e" % e)
+    assert e <= 3e-2
+    assert rel_fro(getattr(fr.obj_downsample, "1").weight.grad, p["image_feature_extractor.obj_downsample.1.weight"].grad) <= 3e-2

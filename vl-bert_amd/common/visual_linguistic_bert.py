@@ -6,7 +6,8 @@ vcr/modules/resnet_vlbert_for_vcr.py:60) can construct it unchanged.
 
     VisualLinguisticBert.forward(text_input_ids, text_token_type_ids, text_visual_embeddings, text_mask,
                                  object_vl_embeddings, object_mask, output_all_encoded_layers=False,
-                                 output_text_and_object_separately=True) -> (text_out, object_out, pooled=None)
+                                 output_text_and_object_separately=True) -> (text_out, object_out, pooled)
+                         ... output_text_and_object_separately=False   -> (sequence_output [B, max_len, H], pooled)
     VisualLinguisticBertForPretraining.forward(same six tensors) -> (relationship_logits=None, mlm_logits, mvrc_logits)
 
 Both are differentiable w.r.t. the parameters and the two embedding inputs (custom autograd node -> the engine's explicit
@@ -37,6 +38,9 @@ class _CoreFn(torch.autograd.Function):
         ctx.has_third = (rel if eng.with_heads else pooled) is not None
         if eng.with_heads:
             return mlm.float(), mvrc.float(), third
+        if eng.seq_out:      # trimmed to the batch's longest packed sequence like the reference (:202; one host sync)
+            n = int((eng.lay["text_len"] + eng.lay["nobj"]).max()) + 1
+            return eng.sequence_output()[:, :n].float(), text_vis.new_zeros(()), third
         return text_out.float(), obj_out.float(), third
 
     @staticmethod
@@ -46,6 +50,8 @@ class _CoreFn(torch.autograd.Function):
         g2 = g2 if ctx.has_third else None
         if eng.with_heads:
             d_tv, d_ovl = eng.backward_core(g0, g1, g2, train=module.training)
+        elif eng.seq_out:
+            d_tv, d_ovl = eng.backward_core_sequence(g0, g2, train=module.training)
         else:
             d_tv, d_ovl = eng.backward_core_hidden(g0, g1, g2, train=module.training)
         return d_tv.to(ctx.in_dtypes[0]), d_ovl.to(ctx.in_dtypes[1]), None, None, None
@@ -121,11 +127,11 @@ class VisualLinguisticBert(nn.Module):
             for name, p in self._pnames.items():
                 p.grad = named[_PREFIX + name]
 
-    def _engine_for(self, B, T, R):
-        key = (B, T, R)
+    def _engine_for(self, B, T, R, sequence=False):
+        key = (B, T, R, sequence)
         if key not in self._engines:
             self._engines[key] = _engine.PretrainEngine(self.cfg, B, T, R, device=str(self.device_), flat=self.flat, core=True,
-                                                        core_heads=self.WITH_HEADS)
+                                                        core_heads=self.WITH_HEADS, core_sequence=sequence)
         eng = self._engines[key]
         version = self.flat.master._version
         if getattr(eng, "_synced_version", None) != version:
@@ -134,10 +140,11 @@ class VisualLinguisticBert(nn.Module):
         eng._weights_dirty = False
         return eng
 
-    def _run(self, text_input_ids, text_token_type_ids, text_visual_embeddings, text_mask, object_vl_embeddings, object_mask):
+    def _run(self, text_input_ids, text_token_type_ids, text_visual_embeddings, text_mask, object_vl_embeddings, object_mask,
+             sequence=False):
         B, T = text_input_ids.shape
         R = object_vl_embeddings.shape[1]
-        eng = self._engine_for(B, T, R)
+        eng = self._engine_for(B, T, R, sequence)
         eng.set_core_inputs(text_input_ids, text_token_type_ids, text_visual_embeddings, text_mask, object_vl_embeddings, object_mask)
         anchor = next(iter(self._pnames.values()))
         out = _CoreFn.apply(text_visual_embeddings, object_vl_embeddings, anchor, self, eng)
@@ -148,9 +155,12 @@ class VisualLinguisticBert(nn.Module):
 
     def forward(self, text_input_ids, text_token_type_ids, text_visual_embeddings, text_mask, object_vl_embeddings, object_mask,
                 output_all_encoded_layers=True, output_text_and_object_separately=False, output_attention_probs=False):
-        if output_all_encoded_layers or not output_text_and_object_separately or output_attention_probs:
-            raise NotImplementedError("supported call form: output_all_encoded_layers=False, "
-                                      "output_text_and_object_separately=True, output_attention_probs=False")
+        if output_all_encoded_layers or output_attention_probs:
+            raise NotImplementedError("supported call forms: output_all_encoded_layers=False, output_attention_probs=False")
+        if not output_text_and_object_separately:     # VQA / VCR callers: (sequence_output, pooled_output)  (:139-171)
+            seq, _, pooled = self._run(text_input_ids, text_token_type_ids, text_visual_embeddings, text_mask,
+                                       object_vl_embeddings, object_mask, sequence=True)
+            return seq, (pooled if self.with_pooler else None)
         text_out, obj_out, pooled = self._run(text_input_ids, text_token_type_ids, text_visual_embeddings, text_mask,
                                               object_vl_embeddings, object_mask)
         return text_out, obj_out, (pooled if self.with_pooler else None)

@@ -155,7 +155,7 @@ class FlatParams:
 class PretrainEngine:
     def __init__(self, cfg, B, T, R, device="cuda:0", train=True, lr=1e-4, weight_decay=1e-4, max_grad_norm=10.0,
                  betas=(0.9, 0.999), eps=1e-6, seed=1234, grad_accum=1, process_group=None, keep_logits=False, flat=None,
-                 B_aux=0, core=False, core_heads=True):
+                 B_aux=0, core=False, core_heads=True, core_sequence=False):
         cfg.validate()
         self.cfg, self.B, self.T, self.R = cfg, B, T, R
         # multitask: B_aux text-only samples are appended after the B image-caption samples; they have no
@@ -167,6 +167,7 @@ class PretrainEngine:
         # losses and the wrapper-level parameters are not used.
         self.core = core
         self.with_heads = core_heads or not core      # core_heads=False: hidden states out, d(hidden states) in
+        self.seq_out = bool(core and core_sequence and not core_heads)   # the packed [B,S,H] sequence instead of text / object splits
         self.Ba = B_aux
         if B_aux and not cfg.multitask:
             raise ValueError("B_aux > 0 needs ModelConfig(multitask=True)")
@@ -560,7 +561,8 @@ class PretrainEngine:
                 self._wgrad(self.rel_logits[:, :2], self.pooled, g32[pr + "weight"], g32[pr + "bias"], None, None, 0)
                 ops.gemm_nt(self.rel_logits, wT[pr + "weight"], self.d_pooled)      # K = 64: two logits + zero padding
         dx = self.dXa
-        ops.head_grad_combine(self.d_text_out, self.d_obj_out, self.lay["code"], dx, Bt, T, R, S, H)
+        if not self.seq_out:      # (sequence mode: the caller's d(sequence_output) is already in dXa)
+            ops.head_grad_combine(self.d_text_out, self.d_obj_out, self.lay["code"], dx, Bt, T, R, S, H)
         if cfg.with_pooler and (cfg.with_rel_loss or not self.with_heads):
             # d(pooled) came from the relationship head (or from the caller in hidden-state mode): through tanh and the
             # dense layer, then ADDED to the first-token rows of dX (gemm epilogue residual = its own output rows)
@@ -716,6 +718,25 @@ class PretrainEngine:
             self.d_obj_out.zero_()
         else:
             self.d_obj_out.copy_(d_obj_out.reshape(self.BR, H))
+        self.backward(train)
+        return self.d_tv_in.view(self.Bt, self.T, H), self.d_ovl_in.view(self.Bt, self.R, 2 * H)
+
+    def sequence_output(self):
+        """Last encoder layer as the packed [B, S, H] sequence (text || objects || END || padding), bf16 view."""
+        return self.X[self.cfg.num_hidden_layers].view(self.Bt, self.S, self.cfg.hidden_size)
+
+    def backward_core_sequence(self, d_seq, d_pooled=None, train=None):
+        """core_sequence=True: d(sequence_output) [B, <=S, H] (rows beyond the given length are zero) -> input gradients."""
+        H = self.cfg.hidden_size
+        dx = self.dXa.view(self.Bt, self.S, H)
+        dx.zero_()
+        if d_seq is not None:
+            dx[:, :d_seq.shape[1]].copy_(d_seq)
+        if self.cfg.with_pooler:
+            if d_pooled is None:
+                self.d_pooled.zero_()
+            else:
+                self.d_pooled.copy_(d_pooled)
         self.backward(train)
         return self.d_tv_in.view(self.Bt, self.T, H), self.d_ovl_in.view(self.Bt, self.R, 2 * H)
 
