@@ -268,7 +268,7 @@ class PretrainEngine:
 
         # backward scratch
         self.dXa, self.dXb = zb(M, H), zb(M, H)
-        self.dZ, self.dD = zb(M, H), zb(M, H)
+        self.dZ, self.dD, self.dDb = zb(M, H), zb(M, H), zb(M, H)     # dD / dDb: LN2 / LN1 outputs (a side-stream wgrad may still read one)
         self.dU = zb(M, I)
         self.dCTX, self.dQKV = zb(M, H), zb(M, 3 * H)
         self.tG = zb(max(3 * H, I), self.Mp)       # transposed gradients (zero padded columns persist)
@@ -294,6 +294,15 @@ class PretrainEngine:
                  (C, H, self.BRp), (H, H, self.BRp), (H, 2 * VIS_DIM, self.BRp))]
         need.append(ops.wgrad_workspace_floats(self.BT, H, self.Vp))     # tied-decoder dgrad (K = vocabulary) at small batch
         self.wg_ws = zf(max(max(need), 4))
+        # Weight gradients run on a second stream: they only feed the optimizer, while the dgrad chain is the critical
+        # path, and at small per-GPU batch neither fills the chip (312 + 432 workgroups for 512 slots at B = 32).
+        # Hazards: a wgrad reads the gradient buffer the main stream produced (event after the producer) and the main
+        # stream must not overwrite that buffer before the wgrad is done (event recorded after it, waited by the
+        # next writer -- a full layer later thanks to the dD / dDb double buffer).  VLB_WGRAD_STREAM=0 serialises.
+        import os as _os
+        self.side = torch.cuda.Stream(device=d) if (d.type == "cuda" and _os.environ.get("VLB_WGRAD_STREAM", "1") != "0") else None
+        self.wg_ws_main = zf(max(need[-1], 4)) if self.side is not None else self.wg_ws    # decoder dgrad split-K (main stream)
+        self._pending = {}
         self.ln_ws = zf(ops.ln_bwd_workspace_floats(H))     # per-workgroup partial dgamma/dbeta sums of the LayerNorm backward
         self.graph = None
         self._weights_dirty = True
@@ -519,13 +528,38 @@ class PretrainEngine:
     def _wgrad(self, dy, x, gw, gb, tG, tA, rows_p):
         """gw[N,K] += dy^T x ; gb[N] += colsum(dy) through zero-padded transposes."""
         if self.use_tn_wgrad:   # straight from the row-major operands (LDS transpose reads), bias gradient fused
-            ops.wgrad_tn(dy, x, gw, colsum=gb, workspace=self.wg_ws, accumulate=not self._fresh_grads)
+            if self.side is None:
+                ops.wgrad_tn(dy, x, gw, colsum=gb, workspace=self.wg_ws, accumulate=not self._fresh_grads)
+                return
+            ready = torch.cuda.Event()
+            ready.record()                                   # everything the operands depend on is enqueued on the main stream
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(ready)
+                ops.wgrad_tn(dy, x, gw, colsum=gb, workspace=self.wg_ws, accumulate=not self._fresh_grads)
+                done = torch.cuda.Event()
+                done.record()
+            self._pending[dy.data_ptr()] = done              # whoever overwrites `dy` next must wait for this
             return
         N, K = dy.shape[1], x.shape[1]
         tg, ta = tG[:N, :rows_p], tA[:K, :rows_p]
         ops.transpose(dy, tg, colsum=gb)
         ops.transpose(x, ta)
         ops.wgrad_nt(tg, ta, gw, workspace=self.wg_ws)
+
+    def _before_write(self, *bufs):
+        """Main stream is about to overwrite these buffers: wait for side-stream weight gradients still reading them."""
+        for b in bufs:
+            ev = self._pending.pop(b.data_ptr(), None)
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)
+
+    def _join_side(self):
+        """All side-stream weight gradients issued so far complete before later main-stream work."""
+        if self.side is not None:
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+            torch.cuda.current_stream().wait_event(ev)
+            self._pending.clear()
 
     def backward(self, train=None, on_layer_done=None):
         train = self.train if train is None else train
@@ -540,7 +574,7 @@ class PretrainEngine:
             pm = "vlbert.mlm_head.predictions."
             dlog = self.mlm_logits                       # [BT, Vp], pad columns zero
             self._wgrad(dlog[:, :V], self.mlm_h, g32["vlbert.word_embeddings.weight"], g32[pm + "bias"], self.tG_bt, self.tA_bt, BTp)
-            ops.gemm_nt_splitk(dlog, wT["vlbert.word_embeddings.weight"], self.d_mlm_h, workspace=self.wg_ws)
+            ops.gemm_nt_splitk(dlog, wT["vlbert.word_embeddings.weight"], self.d_mlm_h, workspace=self.wg_ws_main)
             ops.layernorm_bwd(self.d_mlm_h, self.mlm_g, self.st_mlm, w32[pm + "transform.LayerNorm.weight"], dx=self.d_mlm_g,
                               dgamma=g32[pm + "transform.LayerNorm.weight"], dbeta=g32[pm + "transform.LayerNorm.bias"],
                               workspace=self.ln_ws)
@@ -572,6 +606,7 @@ class PretrainEngine:
             dx0 = dx.view(Bt, S * H)[:self.B, :H]
             ops.gemm_nt(self.d_pool_pre, wT["vlbert.pooler.dense.weight"], dx0, res=dx0)
         if on_layer_done:
+            self._join_side()
             on_layer_done("heads")
         # --- encoder, last layer first -------------------------------------------------------------------
         mask = self.lay["attn_mask"]
@@ -580,25 +615,29 @@ class PretrainEngine:
             dx_next = self.dXb if dx is self.dXa else self.dXa
             drop = p_h > 0
             # LN2: dZ2 (residual branch) and dD2 (into output.dense, through its dropout)
+            self._before_write(self.dZ, self.dD)
             ops.layernorm_bwd(dx, self.Z2[l], self.ST2[l], w32[p + "output.LayerNorm.weight"], dx=self.dZ,
                               dx_drop=self.dD if drop else None, drop_p=p_h, seed=seed, tag=l * 8 + 2,
                               dgamma=g32[p + "output.LayerNorm.weight"], dbeta=g32[p + "output.LayerNorm.bias"],
                               workspace=self.ln_ws)
             dD2 = self.dD if drop else self.dZ
             self._wgrad(dD2, self.G[l], g32[p + "output.dense.weight"], g32[p + "output.dense.bias"], self.tG, self.tA, Mp)
+            self._before_write(self.dU)
             ops.gemm_nt(dD2, wT[p + "output.dense.weight"], self.dU, act=ops.ACT_MULAUX, aux=self.U[l])
             self._wgrad(self.dU, self.Y1[l], g32[p + "intermediate.dense.weight"], g32[p + "intermediate.dense.bias"], self.tG,
                         self.tA, Mp)
             ops.gemm_nt(self.dU, wT[p + "intermediate.dense.weight"], dx_next, res=self.dZ)            # dY1
             # LN1
+            self._before_write(self.dZ, self.dDb)
             ops.layernorm_bwd(dx_next, self.Z1[l], self.ST1[l], w32[p + "attention.output.LayerNorm.weight"], dx=self.dZ,
-                              dx_drop=self.dD if drop else None, drop_p=p_h, seed=seed, tag=l * 8 + 1,
+                              dx_drop=self.dDb if drop else None, drop_p=p_h, seed=seed, tag=l * 8 + 1,
                               dgamma=g32[p + "attention.output.LayerNorm.weight"], dbeta=g32[p + "attention.output.LayerNorm.bias"],
                               workspace=self.ln_ws)
-            dD1 = self.dD if drop else self.dZ
+            dD1 = self.dDb if drop else self.dZ
             self._wgrad(dD1, self.CTX[l], g32[p + "attention.output.dense.weight"], g32[p + "attention.output.dense.bias"],
                         self.tG, self.tA, Mp)
             ops.gemm_nt(dD1, wT[p + "attention.output.dense.weight"], self.dCTX)
+            self._before_write(self.dQKV)
             ops.attention_bwd(self.QKV[l], mask, self.CTX[l], self.LSE[l], self.dCTX, self.dQKV, Bt, S, H, nh, drop_p=p_a,
                               seed=seed, tag=l * 8 + 0)
             gwqkv = self.P.view(self.P.grad, p + "attention.self.query.weight", (3 * H, H), span=3)
@@ -607,11 +646,14 @@ class PretrainEngine:
             ops.gemm_nt(self.dQKV, wT[p + "qkv"], dx_next, res=self.dZ)                                  # dX_l (overwrites dY1)
             dx = dx_next
             if on_layer_done:
+                self._join_side()           # the bucket's weight gradients must be complete before its all-reduce reads them
                 on_layer_done(l)
+        self._join_side()               # embed_bwd adds into the word-embedding gradient the decoder wgrad wrote
         if self.core:
             self._front_core_bwd(dx, p_h)
         else:
             self._front_pretrain_bwd(dx, p_h, p_ds)
+        self._join_side()
         self._fresh_grads = False       # a further backward before the next zero_grad() accumulates
         if on_layer_done:
             on_layer_done("embed")
