@@ -521,3 +521,36 @@ def test_fast_rcnn_mirror_mask_embedding_gradient():
     print("FastRCNN mirror: rel-fro err of d(mask_visual_embed) %.3e" % e)
     assert e <= 3e-2
     assert rel_fro(getattr(fr.obj_downsample, "1").weight.grad, p["image_feature_extractor.obj_downsample.1.weight"].grad) <= 3e-2
+
+
+def test_side_stream_weight_gradients_match_serial_and_bucket_hook_order():
+    """The weight gradients run on a second stream; (a) the result equals the serialised schedule, (b) the
+    data-parallel hook sees complete gradients: at every on_layer_done the bucket it would all-reduce is final."""
+    syn = pkg("synthetic")
+    cfg = O.VLBertConfig(num_hidden_layers=3)
+    params = O.init_params(cfg, seed=12)
+    batch = syn.make_batch(8, 64, 36, seed=13, ragged=False)
+    grads = []
+    for side in (True, False):
+        eng = make_engine(cfg, 8, 64, 36, train=True, seed=5)
+        if not side:
+            eng.side = None
+        eng.load_state_dict({k: v.to(dev()) for k, v in params.items()})
+        eng.set_batch(*[t.to(dev()) for t in batch])
+        eng.zero_grad()
+        eng.forward(True)
+        seen = {}
+
+        def hook(what, eng=eng, seen=seen):
+            torch.cuda.current_stream().synchronize()          # what an all-reduce launched here would read
+            if isinstance(what, int):
+                n = "vlbert.encoder.layer.%d.intermediate.dense.weight" % what
+                seen[what] = eng.g32[n].detach().clone()
+        eng.backward(True, on_layer_done=hook)
+        torch.cuda.synchronize()
+        for l, g in seen.items():
+            assert torch.equal(g, eng.g32["vlbert.encoder.layer.%d.intermediate.dense.weight" % l]), "layer %d gradient changed after its hook" % l
+        grads.append({k: v.clone() for k, v in eng.grads().items()})
+    worst = max((rel_fro(grads[0][k], grads[1][k]), k) for k in grads[0] if float(grads[1][k].norm()) > 0)
+    print("side-stream vs serial weight gradients: worst rel-fro difference %.3e (%s)" % worst)
+    assert worst[0] < 1e-5, worst
