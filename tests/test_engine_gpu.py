@@ -554,3 +554,27 @@ def test_side_stream_weight_gradients_match_serial_and_bucket_hook_order():
     worst = max((rel_fro(grads[0][k], grads[1][k]), k) for k in grads[0] if float(grads[1][k].norm()) > 0)
     print("side-stream vs serial weight gradients: worst rel-fro difference %.3e (%s)" % worst)
     assert worst[0] < 1e-5, worst
+
+
+def test_engine_maximum_sequence_length_vs_oracle():
+    """S = T + R + 1 = 128: the longest packed sequence the fused attention kernel accepts (ragged batch)."""
+    syn = pkg("synthetic")
+    cfg = O.VLBertConfig(num_hidden_layers=1, max_position_embeddings=128)
+    params = O.init_params(cfg, seed=31)
+    batch = syn.make_batch(3, 91, 36, seed=32, ragged=True)
+    check_against_oracle("S=128", cfg, params, batch)
+    E = pkg("engine")
+    with pytest.raises(ValueError):
+        E.PretrainEngine(E.ModelConfig(num_hidden_layers=1), 1, 92, 36, device="cuda:0")
+
+
+def test_engine_large_model_width_vs_oracle():
+    """VL-BERT-large layer shape (H = 1024, 16 heads, I = 4096): exercises the wider LayerNorm / embedding register tilings."""
+    syn = pkg("synthetic")
+    cfg = O.VLBertConfig(hidden_size=1024, num_attention_heads=16, intermediate_size=4096, num_hidden_layers=1, vocab_size=2048,
+                         visual_region_classes=100)
+    params = O.init_params(cfg, seed=33)
+    batch = syn.make_batch(2, 24, 9, vocab_size=2048, region_classes=100, seed=34, ragged=True)
+    # obj_downsample gradients: a ReLU unit whose pre-activation is within bf16 rounding of 0 flips state against the fp32
+    # oracle; each flip changes a full gradient row, so ~1 % flipped units is a 10 % Frobenius difference whatever the batch
+    check_against_oracle("large-width", cfg, params, batch, grad_tol=0.12)
