@@ -74,6 +74,22 @@ def test_gemm_splitk_bf16_and_batched_transpose(ops):
         assert float(dst[:, R:].float().abs().max() if dst.shape[1] > R else 0.0) == 0.0
 
 
+def test_gemm_256_tile_kernel_large_b_operand(ops):
+    """Plain / bias GEMM whose B operand exceeds the L2s and that has >= 512 tiles of 256x256: served by the 3-stage
+    256x256 kernel (interior tiles staged through LDS, ragged last tile row / column, non-multiple-of-64 N)."""
+    M, N, K = 4096 + 40, 8197, 1536
+    g = torch.Generator().manual_seed(41)
+    A = (torch.rand((M, K), generator=g) * 2 - 1).to(torch.bfloat16)
+    B = ((torch.rand((N, K), generator=g) * 2 - 1) * 0.05).to(torch.bfloat16)
+    bias = 0.2 * torch.randn(N, generator=g)
+    ldc = (N + 63) // 64 * 64
+    C = torch.zeros((M, ldc), dtype=torch.bfloat16, device=dev())
+    ops.gemm_nt(A.to(dev()), B.to(dev()), C[:, :N], bias=bias.to(dev()))
+    ref = A.float() @ B.float().t() + bias
+    report("gemm 256-tile kernel %dx%dx%d bias" % (M, N, K), C[:, :N], ref, 1e-3, 1e-2)
+    assert float(C[:, N:].float().abs().max()) == 0.0, "pad columns were written"
+
+
 def test_gemm_epilogues(ops):
     M, N, K = 384, 320, 256
     A, B = rnd(M, K, seed=4), rnd(N, K, seed=5, scale=0.08)

@@ -413,6 +413,212 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN >= 8) ? 4 : 2) void gemm
 }
 
 // ------------------------------------------------------------------------------------
+// NT GEMM with 256x256 tiles for the plain (bias-only, bf16-out) GEMMs with many output tiles: the tied decoder
+// (N = vocabulary) and the QKV projection.
+//
+// The 128x128 kernel above streams 1/64 B of operands per FLOP through L2 -> LDS and that stream, not the MFMA pipe,
+// is its ceiling.  A 256x256 tile halves the bytes per FLOP.  It costs 128 accumulator registers per wave
+// (8 waves of 128x64, 2 per SIMD, ONE workgroup per CU), so the operand stream has to hide its latency without a second
+// workgroup: a 3-stage ring of BK = 32 slabs (3 x 32 KB), LDS-DMA loads for stage g+2 issued in iteration g and
+// retired by a COUNTED s_waitcnt vmcnt -- the queue is never drained in steady state -- plus a bare s_barrier.
+// Fragment reads are inline asm (a compiler-visible LDS read that may alias a pending LDS-DMA gets an s_waitcnt
+// vmcnt(0) from hipcc, which would drain the ring); their results are released to the MFMAs by an explicit lgkmcnt
+// wait.  Counted waits go through __builtin_amdgcn_s_waitcnt so that the compiler's own bookkeeping sees them.
+// Operand image: [rows][32 bf16] = 64-B rows, 16-B chunk c of row r at chunk c ^ G[(r>>2)&3], G = {0,3,2,1} (the
+// 16-lane service groups of ds_read_b128 then cover 16 distinct bank slots); as everywhere the swizzle is applied to
+// the LDS-DMA source address.  The ring runs across output tiles (persistent workgroups): the next tile's first stages
+// stream in under the epilogue, which stages bf16 rows through the ring slot consumed last (64-row slabs) and drains
+// the queue once per tile (vmcnt also counts stores).
+// ------------------------------------------------------------------------------------
+template <int OFF>
+__device__ __forceinline__ void lds_read_b128_asm(bf16x8& dst, uint32_t vaddr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(vaddr), "n"(OFF));
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_nt_256_kernel(const GemmParams p) {
+  constexpr int BM = 256, BN = 256, NT = 512, NS = 3;
+  constexpr int WM = 128, WN = 64, FM = 8, FN = 4;
+  constexpr int NA = BM * 4 / NT, NB = BN * 4 / NT;            // 16-B chunks per thread per stage (4 per 64-B row)
+  constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64, STAGE = A_BYTES + B_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int nt = p.ntm * p.ntn;
+  const int ntk = p.K / 32;
+  if ((int)blockIdx.x >= nt) return;
+
+  auto tile_of = [&](int w, int& m0, int& n0) {   // same XCD-aware grouped order as the 2-stage kernel
+    const int xcd = w & 7, q = nt >> 3, r = nt & 7;
+    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (w >> 3);
+    const int gm = p.tile_group, per_group = gm * p.ntn, gid = t / per_group, first = gid * gm;
+    const int gsz = min(p.ntm - first, gm), rem = t - gid * per_group;
+    m0 = (first + rem % gsz) * BM;
+    n0 = (rem / gsz) * BN;
+  };
+  // ---- producer: the (tile, k) of the next stage to issue and its per-thread source pointers (advanced in place)
+  const bf16_t* a_src[NA];
+  const bf16_t* b_src[NB];
+  int w_p = blockIdx.x, kt_p = 0, issued = 0;
+  auto setup = [&](int w) {
+    int m0, n0;
+    tile_of(w, m0, n0);
+#pragma unroll
+    for (int it = 0; it < NA; ++it) {
+      const int P = it * NT + tid, r = P >> 2, kc = (P & 3) ^ ((4 - ((r >> 2) & 3)) & 3);
+      a_src[it] = p.A + (long)min(m0 + r, p.M - 1) * p.lda + kc * 8;
+    }
+#pragma unroll
+    for (int it = 0; it < NB; ++it) {
+      const int P = it * NT + tid, r = P >> 2, kc = (P & 3) ^ ((4 - ((r >> 2) & 3)) & 3);
+      b_src[it] = p.B + (long)min(n0 + r, p.N - 1) * p.ldb + kc * 8;
+    }
+  };
+  auto produce = [&]() {
+    if (w_p >= nt) return;
+    char* sa = smem + (issued % NS) * STAGE;
+    char* sb = sa + A_BYTES;
+#pragma unroll
+    for (int it = 0; it < NA; ++it) {
+      __builtin_amdgcn_global_load_lds(GLDS_PTR(a_src[it]), LDS_PTR(sa + (it * NT + wave * 64) * 16), 16, 0, 0);
+      a_src[it] += 32;
+    }
+#pragma unroll
+    for (int it = 0; it < NB; ++it) {
+      __builtin_amdgcn_global_load_lds(GLDS_PTR(b_src[it]), LDS_PTR(sb + (it * NT + wave * 64) * 16), 16, 0, 0);
+      b_src[it] += 32;
+    }
+    ++issued;
+    if (++kt_p == ntk) {
+      kt_p = 0;
+      w_p += gridDim.x;
+      if (w_p < nt) setup(w_p);
+    }
+  };
+
+  f32x4 acc[FM][FN];
+  const int frow = lane & 15;
+  const int pc = ((lane >> 4) ^ ((4 - (frow >> 2)) & 3)) << 4;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(smem);
+  const uint32_t a_off = lds0 + (wm * WM + frow) * 64 + pc;
+  const uint32_t b_off = lds0 + A_BYTES + (wn * WN + frow) * 64 + pc;
+
+  setup(w_p);
+  produce();
+  produce();
+  int g = 0;   // stages consumed so far (ring slot = g % NS)
+  for (int w = blockIdx.x; w < nt; w += gridDim.x) {
+    int m0, n0;
+    tile_of(w, m0, n0);
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < ntk; ++kt, ++g) {
+      // stage g has landed once at most the NA+NB loads of stage g+1 are outstanding (gfx9 s_waitcnt immediate:
+      // vmcnt = imm[3:0], expcnt = 7 and lgkmcnt = 15 mean "no wait")
+      if (issued - g >= 2) __builtin_amdgcn_s_waitcnt(0x0F70 | (NA + NB));
+      else __builtin_amdgcn_s_waitcnt(0x0F70);
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();     // every wave's part of stage g is in LDS; everyone is done reading stage g-1
+      asm volatile("" ::: "memory");
+      produce();                        // stage g+2 -> slot (g-1) % NS
+      const uint32_t so = (uint32_t)((g % NS) * STAGE);
+      const uint32_t va = so + a_off, vb = so + b_off;
+      bf16x8 af[FM], bfr[FN];
+      lds_read_b128_asm<0 * 1024>(bfr[0], vb); lds_read_b128_asm<1 * 1024>(bfr[1], vb);
+      lds_read_b128_asm<2 * 1024>(bfr[2], vb); lds_read_b128_asm<3 * 1024>(bfr[3], vb);
+      lds_read_b128_asm<0 * 1024>(af[0], va); lds_read_b128_asm<1 * 1024>(af[1], va);
+      lds_read_b128_asm<2 * 1024>(af[2], va); lds_read_b128_asm<3 * 1024>(af[3], va);
+      lds_read_b128_asm<4 * 1024>(af[4], va); lds_read_b128_asm<5 * 1024>(af[5], va);
+      lds_read_b128_asm<6 * 1024>(af[6], va); lds_read_b128_asm<7 * 1024>(af[7], va);
+      // the first half of the wave tile (A fragments 0-3) starts under the LDS latency of fragments 4-7
+      asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bfr[0]), "+v"(bfr[1]), "+v"(bfr[2]), "+v"(bfr[3]), "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]));
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[4]), "+v"(af[5]), "+v"(af[6]), "+v"(af[7]));
+#pragma unroll
+      for (int i = 4; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- epilogue (+bias, bf16): lane holds C[m][n..n+3], m = .. + (lane&15) + 16 i, n = .. + 4 (lane>>4) + 16 j
+    const int row_l = wm * WM + (lane & 15), col_l = wn * WN + 4 * (lane >> 4);
+    float bias[FN][4];
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + col_l + j * 16 + r;
+        bias[j][r] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+      }
+    bf16_t* C = (bf16_t*)p.C;
+    if (m0 + BM <= p.M && n0 + BN <= p.N) {
+      // interior tile: 64-row slabs through the ring slot consumed last ([64][512 B], 16-B chunk XOR (row & 31)), then
+      // whole 512-B rows out with 16 B per lane
+      char* st = smem + ((g - 1) % NS) * STAGE;
+      for (int h = 0; h < 4; ++h) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();      // (h = 0: every wave's MFMAs have consumed their fragments of that slot)
+        asm volatile("" ::: "memory");
+        if (wm == (h >> 1)) {
+#pragma unroll
+          for (int i4 = 0; i4 < 4; ++i4) {
+            const int i = (h & 1) * 4 + i4;
+            const int row = (row_l + i * 16) & 63;
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+              const int colb = (col_l + j * 16) * 2;
+              *(uint2*)(st + row * 512 + ((((colb >> 4) ^ (row & 31)) << 4) | (colb & 15))) =
+                  make_uint2(pack2bf(acc[i][j][0] + bias[j][0], acc[i][j][1] + bias[j][1]),
+                             pack2bf(acc[i][j][2] + bias[j][2], acc[i][j][3] + bias[j][3]));
+            }
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < 64 * 32 / NT; ++it) {
+          const int q = it * NT + tid, row = q >> 5, ch = q & 31;
+          const uint4 v = *(const uint4*)(st + row * 512 + ((ch ^ (row & 31)) << 4));
+          *(uint4*)(C + (long)(m0 + h * 64 + row) * p.ldc + n0 + ch * 8) = v;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const int m = m0 + row_l + i * 16;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const int n = n0 + col_l + j * 16;
+          bf16_t* c = C + (long)m * p.ldc + n;
+          if (n + 3 < p.N) {
+            *(uint2*)c = make_uint2(pack2bf(acc[i][j][0] + bias[j][0], acc[i][j][1] + bias[j][1]),
+                                    pack2bf(acc[i][j][2] + bias[j][2], acc[i][j][3] + bias[j][3]));
+          } else {
+            for (int r = 0; r < 4 && n + r < p.N; ++r) c[r] = f2bf(acc[i][j][r] + bias[j][r]);
+          }
+        }
+      }
+    }
+    // one full drain per output tile, visible to the compiler (stores / spill traffic cannot force a vmcnt(0) into the
+    // next K loop); the stages prefetched for the next tile have had the whole epilogue to land
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();          // nobody re-fills the staging slot while someone still copies out of it
+    asm volatile("" ::: "memory");
+  }
+}
+
+// ------------------------------------------------------------------------------------
 // "TN" GEMM for weight gradients:  C[Mo,No] (fp32) (+)= A[R,Mo]^T · B[R,No]   (reduction over the R ROWS)
 //   dW[n_out, k_in] = sum_rows dY[row, n_out] * X[row, k_in]        (autograd's grad_output.t().mm(input))
 // Both operands are consumed exactly as the forward pass left them (row-major activations / gradients): no
@@ -855,6 +1061,31 @@ extern "C" int vlb_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb
   const int per = vlb_cdiv(ktiles, splits);
   splits = vlb_cdiv(ktiles, per);
   p.k_per_split = per * 64;
+  // 256x256 tiles (half the operand bytes per FLOP) for plain bf16 GEMMs whose B operand does not fit the L2s and that
+  // have enough tiles for one workgroup per CU: the tied decoder X . E^T (B = 47 MB word embeddings; 1.00 -> 0.80 ms).
+  // With an L2-resident weight matrix and K = 768 (QKV, FFN) the 128x128 kernel is as fast (measured) and keeps two
+  // workgroups per CU.  VLB_GEMM_256: 0 off | 1 this rule (default) | n >= 2: every plain GEMM with at least n tiles.
+  static const int use256 = env_int("VLB_GEMM_256", 1);
+  const long tiles256 = (long)vlb_cdiv(M, 256) * vlb_cdiv(N, 256);
+  const bool big_b = (long)N * K * 2 >= (24L << 20) && tiles256 >= 512;
+  if (use256 && out_mode == 0 && splits == 1 && act == 0 && !res && !p.drop_thr &&
+      (use256 == 1 ? big_b : tiles256 >= use256)) {
+    constexpr int smem = 3 * (256 + 256) * 64;
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)gemm_nt_256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+      attr_set = true;
+    }
+    static const int group5 = env_int("VLB_GEMM_256_GROUP", 2);
+    p.ntm = vlb_cdiv(M, 256);
+    p.ntn = vlb_cdiv(N, 256);
+    p.tile_group = group5 < 1 ? 1 : group5;
+    int gx = p.ntm * p.ntn;
+    if (gx > 256) gx = 256;             // one workgroup per CU
+    hipLaunchKernelGGL(gemm_nt_256_kernel, dim3(gx), dim3(512), smem, stream, p);
+    VLB_CHECK_LAUNCH("vlb_gemm_nt_bf16(256)");
+    return VLB_OK;
+  }
   // narrow-N tile when the 128x128 grid would leave most CUs idle
   const long tiles128 = (long)vlb_cdiv(M, 128) * vlb_cdiv(N, 128) * splits;
   if (tiles128 < 384 || N <= 64) return launch_gemm<128, 64>(p, splits, stream);
