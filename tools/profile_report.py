@@ -31,8 +31,8 @@ def short(n):
 
 
 def family(n):
-    if "gemm_nt_bf16" in n:
-        return "gemm_nt_bf16_kernel"
+    if "gemm_nt_bf16" in n or "gemm_nt_256" in n:
+        return "gemm_nt_bf16_kernel"          # (incl. the 256x256-tile instantiation used by the decoder)
     if "gemm_tn_bf16" in n:
         return "gemm_tn_bf16_kernel"
     return short(n)
@@ -51,8 +51,10 @@ for l in open(os.path.join(src, "final_trace.log"), errors="replace"):
     if '"metric"' in l:
         line = l.strip()
 with open(os.path.join(dst, tag + "_kernel_stats.txt"), "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline   (MI355X; %d steps in\n"
-            "# the process: 1 warm-up + 3 timed + 1 instrumented; the fill / copy kernels are mostly one-time buffer setup)\n" % steps)
+    f.write("# VLB_WGRAD_STREAM=0 rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline\n"
+            "# (MI355X; %d steps in the process: 1 warm-up + 3 timed + 1 instrumented; the fill / copy kernels are mostly one-time\n"
+            "# buffer setup; weight-gradient stream serialised so that per-kernel durations are not inflated by overlap --\n"
+            "# the default bench run overlaps them)\n" % steps)
     f.write("# summarised from the rocpd sqlite output by tools/profile_report.py; bench line of the same (profiled) run:\n# %s\n" % line)
     f.write("%-66s %7s %10s %10s %9s %9s %9s %7s\n" % ("kernel", "calls", "total_ms", "ms/step", "avg_us", "min_us", "max_us", "share"))
     for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
