@@ -143,6 +143,28 @@ def main():
     value = args.global_batch / (elapsed / args.steps)
     losses = eng.loss_values()
 
+    # ---- forward-only and forward+backward times (SURVEY.md §8d asks for them next to the step time); outside the timed region
+    def timed_loop(fn, n=5):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+
+    fwd_ms = fwd_bwd_ms = None
+    if world == 1:
+        fwd_ms = timed_loop(lambda: eng.forward(True))
+
+        def fwd_bwd():
+            eng.zero_grad()
+            eng.forward(True)
+            eng.backward(True)
+        fwd_bwd_ms = timed_loop(fwd_bwd)
+
     # ---- roofline of the dominant kernel (the bf16 MFMA GEMM): one extra, instrumented step ---------------
     # HIP events are recorded on the stream the kernels are launched on (torch's current stream).
     rec = []
@@ -204,6 +226,8 @@ def main():
                          "gemm_ms_per_step": round(gemm_ms, 3), "gemm_share_of_step": round(gemm_ms / ms, 3),
                          "step_algorithmic_tflops": round(value * fwdbwd / 1e12, 2),
                          "step_frac_of_peak": round(value * fwdbwd / 1e12 / (world * PEAK_BF16_TFLOPS), 4)},
+            "fwd_ms": round(fwd_ms, 3) if fwd_ms is not None else None,
+            "fwd_bwd_ms": round(fwd_bwd_ms, 3) if fwd_bwd_ms is not None else None,
             "loss": round(losses["loss"], 4),
         }
         if not args.no_cpu_baseline and world == 1:
