@@ -578,3 +578,33 @@ def test_engine_large_model_width_vs_oracle():
     # obj_downsample gradients: a ReLU unit whose pre-activation is within bf16 rounding of 0 flips state against the fp32
     # oracle; each flip changes a full gradient row, so ~1 % flipped units is a 10 % Frobenius difference whatever the batch
     check_against_oracle("large-width", cfg, params, batch, grad_tol=0.12)
+
+
+def test_gradient_accumulation_over_micro_batches():
+    """zero_grad -> (forward, backward) x 2 on different batches: the first backward overwrites the Linear weight gradients,
+    the second accumulates; the sum must equal the two single-batch gradients added (common/trainer.py:117-153 semantics)."""
+    syn = pkg("synthetic")
+    cfg = O.VLBertConfig(num_hidden_layers=2)
+    params = O.init_params(cfg, seed=41)
+    b1 = syn.make_batch(4, 32, 10, seed=42, ragged=True)
+    b2 = syn.make_batch(4, 32, 10, seed=43, ragged=True)
+    eng = make_engine(cfg, 4, 32, 10, train=False)
+    eng.load_state_dict({k: v.to(dev()) for k, v in params.items()})
+    single = []
+    for b in (b1, b2):
+        eng.set_batch(*[t.to(dev()) for t in b])
+        eng.zero_grad()
+        eng.forward(False)
+        eng.backward(False)
+        torch.cuda.synchronize()
+        single.append({k: v.clone() for k, v in eng.grads().items()})
+    eng.zero_grad()
+    for b in (b1, b2):
+        eng.set_batch(*[t.to(dev()) for t in b])
+        eng.forward(False)
+        eng.backward(False)
+    torch.cuda.synchronize()
+    acc = eng.grads()
+    worst = max((rel_fro(acc[k], single[0][k] + single[1][k]), k) for k in acc if float((single[0][k] + single[1][k]).norm()) > 0)
+    print("gradient accumulation: worst rel-fro difference %.3e (%s)" % worst)
+    assert worst[0] < 1e-4, worst
