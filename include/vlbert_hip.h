@@ -190,6 +190,11 @@ int vlb_zero_ranges_f32(float* base, const int64_t* ranges, const int32_t* block
 int vlb_sumsq_f32(const float* g, long n, float* out, vlb_stream_t stream);
 int vlb_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, long n, float* state, float grad_scale,
                    vlb_stream_t stream);
+/* lr schedule evaluated on the device from state[5] (steps taken): state[0] = base_lr * lambda(step + 1), matching the
+ * reference's scheduler.step() -> optimizer.step() order (common/trainer.py:131-135).  kind 0 = ConstantLRSchedule,
+ * 1 = WarmupConstantSchedule, 2 = WarmupLinearSchedule (common/nlp/bert/optimization.py:27-62).  Call before
+ * vlb_adamw_step; graph-replayable (no host value changes between steps). */
+int vlb_lr_schedule_step(float* state, int kind, float base_lr, float warmup_steps, float t_total, vlb_stream_t stream);
 int vlb_cast_f32_bf16(const float* in, void* out, long n, vlb_stream_t stream);
 int vlb_cast_bf16_f32(const void* in, float* out, long n, vlb_stream_t stream);
 int vlb_rng_advance(uint32_t* seed, vlb_stream_t stream);

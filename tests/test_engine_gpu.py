@@ -168,7 +168,8 @@ def test_engine_c1_shape_vs_oracle():
     check_against_oracle("C1", cfg, params, batch)
 
 
-def test_engine_optimizer_step_matches_oracle():
+@pytest.mark.parametrize("schedule", [None, "triangle"])
+def test_engine_optimizer_step_matches_oracle(schedule):
     """clip + AdamW + bf16 refresh on the engine's own gradients (gradient parity is checked above; Adam's first
     step is sign-like, so feeding the ORACLE gradients instead would measure bf16 sign flips, not the optimizer)."""
     syn = pkg("synthetic")
@@ -176,7 +177,10 @@ def test_engine_optimizer_step_matches_oracle():
     params = O.init_params(cfg, seed=4)
     batch = syn.make_batch(2, 16, 6, seed=8, ragged=True)
     lr, wd, max_norm = 1e-3, 1e-2, 1.0
-    eng = make_engine(cfg, 2, 16, 6, train=False, lr=lr, weight_decay=wd, max_grad_norm=max_norm)
+    # "triangle": WarmupLinearSchedule evaluated on the device from the step counter (pretrain/function/train.py:316-320)
+    warm, total = 3, 10
+    eng = make_engine(cfg, 2, 16, 6, train=False, lr=lr, weight_decay=wd, max_grad_norm=max_norm,
+                      lr_schedule=schedule, warmup_steps=warm, t_total=total)
     eng.load_state_dict({k: v.to(dev()) for k, v in params.items()})
     eng.set_batch(*[t.to(dev()) for t in batch])
     m = {k: torch.zeros_like(v) for k, v in params.items()}
@@ -193,7 +197,8 @@ def test_engine_optimizer_step_matches_oracle():
         torch.cuda.synchronize()
         worst = (0.0, "")
         for n in ref:
-            O.adamw_step(ref[n], grads[n] * coef, m[n], v[n], step, lr, eps=1e-6, weight_decay=wd)
+            lr_k = lr * (O.warmup_linear_lr(step, warm, total) if schedule else 1.0)
+            O.adamw_step(ref[n], grads[n] * coef, m[n], v[n], step, lr_k, eps=1e-6, weight_decay=wd)
             err = float((eng.w32[n].cpu() - ref[n]).abs().max())
             worst = max(worst, (err, n))
             assert torch.equal(eng.w16[n].cpu(), eng.w32[n].cpu().to(torch.bfloat16)), n

@@ -566,6 +566,40 @@ def test_adamw_and_sumsq(ops):
     assert float(state[5]) == 3.0 and float(state[7]) == 0.0
 
 
+def test_lr_schedule_on_device(ops):
+    """vlb_lr_schedule_step against torch's LambdaLR driven with the oracle's lr_lambda in the reference's order:
+    scheduler.step() then optimizer.step() (common/trainer.py:131-147), so optimizer step k uses lambda(k)."""
+    from oracle import vlbert_oracle as O
+    base, warm, total = 1e-4, 5, 23
+    w = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([w], lr=base)
+    sch = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: O.warmup_linear_lr(s, warm, total))
+    state = torch.tensor([123.0, 0.9, 0.999, 1e-6, 0.0, 0.0, 0.0, 0.0], dtype=torch.float32, device=dev())
+    n = 64
+    p, g, m, v = (torch.zeros(n, device=dev()) for _ in range(4))
+    for k in range(1, total + 4):
+        w.grad = torch.zeros(1)
+        opt.step()
+        sch.step()                    # lr used by optimizer step k in the reference's loop
+        want = opt.param_groups[0]["lr"]
+        ops.lr_schedule_step(state, ops.LR_WARMUP_LINEAR, base, warm, total)
+        got = float(state[0])
+        assert abs(got - want) <= 1e-6 * base + 1e-12, (k, got, want)
+        ops.adamw_step(p, g, m, v, None, state)        # advances state[5]
+    assert float(state[5]) == total + 3 and float(state[0]) == 0.0
+    # warmup-constant and constant kinds
+    state[5] = 2.0
+    ops.lr_schedule_step(state, ops.LR_WARMUP_CONSTANT, base, 10, 0)
+    assert abs(float(state[0]) - base * 0.3) < 1e-10
+    state[5] = 50.0
+    ops.lr_schedule_step(state, ops.LR_WARMUP_CONSTANT, base, 10, 0)
+    assert abs(float(state[0]) - base) < 1e-12
+    ops.lr_schedule_step(state, ops.LR_CONSTANT, 3e-5, 0, 0)
+    assert abs(float(state[0]) - 3e-5) < 1e-12
+    with pytest.raises(Exception):
+        ops.lr_schedule_step(state, 7, base, 0, 0)
+
+
 # ------------------------------------------------------------------------------------ ROIAlign
 @pytest.mark.parametrize("sr", [1, 2, 0, 3])
 def test_roi_align(ops, sr):

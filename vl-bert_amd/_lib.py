@@ -41,6 +41,7 @@ _SIGS = {
     "vlb_soft_ce_fwd_bwd": "pliiplppfppls",
     "vlb_sumsq_f32": "plps",
     "vlb_adamw_step": "ppppplpfs",
+    "vlb_lr_schedule_step": "pifffs",
     "vlb_cast_f32_bf16": "ppls",
     "vlb_cast_bf16_f32": "ppls",
     "vlb_rng_advance": "ps",

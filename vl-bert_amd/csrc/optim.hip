@@ -13,7 +13,7 @@
 #include "vlb_common.h"
 
 struct VlbAdamState {   // device-resident, 8 floats
-  float lr;             // current lr (schedule applied by the host or by vlb_lr_step)
+  float lr;             // current lr (set by the host, or on the device by vlb_lr_schedule_step)
   float beta1, beta2, eps, weight_decay;
   float step;           // number of steps already taken (incremented by the kernel's block 0)
   float max_norm;       // <=0: no clipping
@@ -94,6 +94,21 @@ __global__ void adam_advance_kernel(VlbAdamState* st) {
   st->sumsq = 0.f;
 }
 
+// Learning-rate schedule evaluated ON THE DEVICE from the step counter, so that a captured hipGraph replays
+// with the right lr each step.  The reference steps its scheduler BEFORE optimizer.step() (common/trainer.py:131-135),
+// and LambdaLR starts at last_epoch = 0, so optimizer step k (1-based) runs with base_lr * lambda(k) where
+// k = steps already taken + 1.  kind: 0 ConstantLRSchedule | 1 WarmupConstantSchedule | 2 WarmupLinearSchedule
+// (common/nlp/bert/optimization.py:27-62; "triangle" in pretrain/function/train.py:316-320).
+__global__ void lr_schedule_kernel(VlbAdamState* st, int kind, float base_lr, float warmup_steps, float t_total) {
+  const float k = st->step + 1.0f;
+  float f = 1.0f;
+  if (kind != 0) {
+    if (k < warmup_steps) f = k / fmaxf(1.0f, warmup_steps);
+    else if (kind == 2) f = fmaxf(0.0f, (t_total - k) / fmaxf(1.0f, t_total - warmup_steps));
+  }
+  st->lr = base_lr * f;
+}
+
 __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, long n) {
   const long stride = (long)gridDim.x * 256 * 4;
   for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
@@ -138,6 +153,15 @@ extern "C" int vlb_adamw_step(float* p, const float* g, float* m, float* v, void
                      (VlbAdamState*)state, grad_scale);
   hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(1), 0, stream, (VlbAdamState*)state);
   VLB_CHECK_LAUNCH("vlb_adamw_step");
+  return VLB_OK;
+}
+
+extern "C" int vlb_lr_schedule_step(float* state, int kind, float base_lr, float warmup_steps, float t_total, hipStream_t stream) {
+  VLB_CHECK_ARG(state, "vlb_lr_schedule_step: null state");
+  VLB_CHECK_ARG(kind >= 0 && kind <= 2, "vlb_lr_schedule_step: kind must be 0 (constant), 1 (warmup-constant) or 2 (warmup-linear)");
+  VLB_CHECK_ARG(base_lr >= 0.f && warmup_steps >= 0.f, "vlb_lr_schedule_step: negative base_lr / warmup_steps");
+  hipLaunchKernelGGL(lr_schedule_kernel, dim3(1), dim3(1), 0, stream, (VlbAdamState*)state, kind, base_lr, warmup_steps, t_total);
+  VLB_CHECK_LAUNCH("vlb_lr_schedule_step");
   return VLB_OK;
 }
 

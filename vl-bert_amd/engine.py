@@ -155,8 +155,17 @@ class FlatParams:
 class PretrainEngine:
     def __init__(self, cfg, B, T, R, device="cuda:0", train=True, lr=1e-4, weight_decay=1e-4, max_grad_norm=10.0,
                  betas=(0.9, 0.999), eps=1e-6, seed=1234, grad_accum=1, process_group=None, keep_logits=False, flat=None,
-                 B_aux=0, core=False, core_heads=True, core_sequence=False):
+                 B_aux=0, core=False, core_heads=True, core_sequence=False, lr_schedule=None, warmup_steps=0, t_total=0):
         cfg.validate()
+        # lr_schedule: None (host sets lr) | "constant" | "warmup_constant" | "triangle" (WarmupLinearSchedule,
+        # pretrain/function/train.py:316-320) -- evaluated on the device from the step counter each optimizer step.
+        kinds = {None: None, "constant": ops.LR_CONSTANT, "warmup_constant": ops.LR_WARMUP_CONSTANT,
+                 "triangle": ops.LR_WARMUP_LINEAR, "warmup_linear": ops.LR_WARMUP_LINEAR}
+        if lr_schedule not in kinds:
+            raise ValueError("lr_schedule must be one of %s" % sorted(k for k in kinds if k))
+        if kinds[lr_schedule] == ops.LR_WARMUP_LINEAR and t_total <= warmup_steps:
+            raise ValueError("triangle schedule needs t_total > warmup_steps")
+        self.lr_kind, self.base_lr, self.warmup_steps, self.t_total = kinds[lr_schedule], lr, warmup_steps, t_total
         self.cfg, self.B, self.T, self.R = cfg, B, T, R
         # multitask: B_aux text-only samples are appended after the B image-caption samples; they have no
         # objects, their text-visual embedding is the learned aux_text_visual_embedding and their MLM loss is
@@ -842,7 +851,11 @@ class PretrainEngine:
         parallelism the flat gradient holds the SUM over ranks; the 1/world average (DDP semantics,
         pretrain/function/train.py:89-90) is folded into the AdamW kernel's grad_scale."""
         if lr is not None:
+            if self.lr_kind is not None:
+                raise ValueError("optimizer_step(lr=...) conflicts with the device-side lr_schedule of this engine")
             self.adam[0:1].fill_(lr)
+        if self.lr_kind is not None:
+            ops.lr_schedule_step(self.adam, self.lr_kind, self.base_lr, self.warmup_steps, self.t_total)
         scale = self.buckets.grad_scale if self.buckets is not None else 1.0
         ops.sumsq(self.P.grad, self.adam[7:8])
         ops.adamw_step(self.P.master, self.P.grad, self.P.m, self.P.v, self.P.w16, self.adam, grad_scale=scale)

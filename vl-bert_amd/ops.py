@@ -283,6 +283,15 @@ def adamw_step(p, g, m, v, p16, state, grad_scale=1.0):
               _p(p16, BF16), p.numel(), _p(state, torch.float32), float(grad_scale), _stream())
 
 
+LR_CONSTANT, LR_WARMUP_CONSTANT, LR_WARMUP_LINEAR = 0, 1, 2
+
+
+def lr_schedule_step(state, kind, base_lr, warmup_steps=0, t_total=0):
+    """state[0] = base_lr * lambda(steps_taken + 1) on the device (common/nlp/bert/optimization.py:27-62)."""
+    _lib.call("vlb_lr_schedule_step", _p(state, torch.float32), int(kind), float(base_lr), float(warmup_steps), float(t_total),
+              _stream())
+
+
 def cast_f32_bf16(src, dst):
     _lib.call("vlb_cast_f32_bf16", _p(src, torch.float32), _p(dst, BF16), src.numel(), _stream())
     return dst
