@@ -199,6 +199,51 @@ int vlb_cast_f32_bf16(const float* in, void* out, long n, vlb_stream_t stream);
 int vlb_cast_bf16_f32(const void* in, float* out, long n, vlb_stream_t stream);
 int vlb_rng_advance(uint32_t* seed, vlb_stream_t stream);
 
+/* ---- end-to-end vision path: NHWC bf16 convolution support (common/backbone/resnet/resnet.py:75-199 Bottleneck /
+ *      ResNet.forward, common/fast_rcnn.py:55-100,144-156 backbone + RoI head) ---------------------------------------
+ * A feature map is a row-major [N*H*W, C] bf16 matrix.  1x1 convolutions call vlb_gemm_nt_bf16 on it directly; 3x3
+ * convolutions call it on the vlb_im2col_nhwc_bf16 image ([rows, KH*KW*C], tap-major); frozen BatchNorm
+ * (common/fast_rcnn.py:88-100, eval mode :122-126) is folded: y = conv(x, w*scale) + shift, scale = gamma/sqrt(var+eps),
+ * shift = beta - mean*scale.  GEMM act 7 = relu(acc + bias + res) (Bottleneck tail, resnet.py:112-116), act 8 =
+ * (acc [+ res]) where aux > 0 (ReLU backward).
+ * vlb_conv_weight_prepare: master w fp32 [O, taps, I] (taps = KH*KW, row-major ky,kx) -> wf bf16 [O, kf] (forward / wgrad
+ *   layout, kf >= taps*I, padding untouched), wb bf16 [I, taps*O] with mirrored taps (dgrad operand: dX = im2col(dY) . wb^T
+ *   for stride 1, padding = dilation*(KH-1)/2), scale/shift fp32 [O] (any of wb/scale/shift may be NULL; gamma NULL = no BN).
+ * vlb_conv_wgrad_finalize: g[O, kreal] (+)= scale[o] * dwf[O, kf][:, :kreal]. */
+int vlb_conv_weight_prepare(const float* w, const float* gamma, const float* beta, const float* mean, const float* var,
+                            float eps, void* wf, void* wb, float* scale, float* shift, int O, int I, int taps, int kf,
+                            vlb_stream_t stream);
+int vlb_conv_wgrad_finalize(const float* dwf, const float* scale, float* g, int O, int kreal, int kf, int accumulate,
+                            vlb_stream_t stream);
+int vlb_im2col_nhwc_bf16(const void* x, void* col, long ldcol, int N, int H, int W, int C, int KH, int KW, int stride,
+                         int pad, int dil, vlb_stream_t stream);
+/* stem (resnet.py:137-141): fp32 NCHW image -> [N*OH*OW, ldcol] bf16, column (ky*KW+kx)*Cin + c, zero padded to ldcol */
+int vlb_im2col_image_f32(const float* img, void* col, int ldcol, int N, int Cin, int H, int W, int KH, int KW, int stride,
+                         int pad, vlb_stream_t stream);
+int vlb_maxpool3x3s2_nhwc(const void* x, void* y, int N, int H, int W, int C, vlb_stream_t stream);
+/* stride-2 1x1 convolutions (caffe-style stride_in_1x1, resnet.py:79): y = x[:, ::2, ::2, :]; its adjoint writes all of dx */
+int vlb_subsample2_nhwc(const void* x, void* y, int N, int H, int W, int C, vlb_stream_t stream);
+int vlb_upsample2_zero_nhwc(const void* dy, void* dx, int N, int H, int W, int C, vlb_stream_t stream);
+/* ROIAlign on NHWC bf16 features (same arithmetic as vlb_roi_align_fwd/bwd below).  RoI k = image k / boxes_per_image,
+ * (x1,y1,x2,y2) = boxes[k*ldbox + 0..3] -- the rows common/fast_rcnn.py:145-149 assembles; boxes with x1 <= -1.5 are
+ * padding (pretrain/data/collate_batch.py:39): zero output, no gradient.  out / dout: [K, ph, pw, C] bf16.
+ * Backward zeroes dfeat (fp32 [N,H,W,C]) and scatters with atomics. */
+int vlb_roi_align_nhwc_fwd(const void* feat, const float* boxes, long ldbox, int boxes_per_image, void* out, int K, int C,
+                           int H, int W, int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio,
+                           vlb_stream_t stream);
+int vlb_roi_align_nhwc_bwd(const void* dout, const float* boxes, long ldbox, int boxes_per_image, float* dfeat, int K, int N,
+                           int C, int H, int W, int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio,
+                           vlb_stream_t stream);
+/* dz (bf16) = g (fp32) where y (bf16) > 0 else 0; n % 8 == 0 */
+int vlb_relu_mask_cast(const float* g, const void* y, void* dz, long n, vlb_stream_t stream);
+/* AvgPool2d(14)+Flattener (common/fast_rcnn.py:80-84): y [K,P,C] bf16 -> out[k*ld + col0 + c] fp32 (the feature slots of
+ * the padded box rows); backward: dz[k,p,c] = (y>0) * keep(k*drop_row_elems + drop_col0 + c) * dfeat[k*lddf + c] / P, with
+ * the input-dropout mask of obj_downsample (common/fast_rcnn.py:106) regenerated from (seed, tag); padded boxes get 0. */
+int vlb_avgpool_rows_fwd(const void* y, float* out, long ld, int col0, int K, int P, int C, vlb_stream_t stream);
+int vlb_avgpool_rows_bwd(const void* dfeat, long lddf, const void* y, const float* boxes, long ldbox, void* dz, int K, int P,
+                         int C, float drop_p, const uint32_t* seed, uint32_t tag, uint32_t drop_row_elems, uint32_t drop_col0,
+                         vlb_stream_t stream);
+
 /* ---- ROIAlign (common/lib/roi_pooling: vision.cpp:6-11, ROIAlign.h:11-45) --------------------
  * NCHW fp32, rois [K,5] = (batch_idx, x1, y1, x2, y2); same math as
  * cuda/ROIAlign_cuda.cu:15-122 (forward) and :125-254 (backward, atomic scatter into a

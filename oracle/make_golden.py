@@ -204,10 +204,82 @@ def run_core_case(name="core_small"):
     print("%s: objective %.6f grad_norm %.6f -> %s (%.1f KB)" % (name, out["objective"], out["grad_norm"], path, os.path.getsize(path) / 1024))
 
 
+def run_vision_case(name="vision_small", num_layers=50):
+    """e2e fixture: the reference's own FastRCNN module (common/fast_rcnn.py, IMAGE_FEAT_PRECOMPUTED false: ResNet trunk ->
+    ROIAlign -> dilated layer4 head -> avg-pool) on a small image batch with one padded box, parameters from
+    oracle/vision_oracle.init_vision_params (handed to the reference through its own `torch.load(pretrained_model_path)` call).
+    Objective <obj_reps_raw, Wr>; stores the pooled features, body4 statistics and per-parameter gradient norms."""
+    from . import vision_oracle as VO
+    ref_import.import_reference()
+    ref_import.install_roi_align_oracle()
+    import common.lib.roi_pooling as rp
+    rp.C_ROIPooling = sys.modules["common.lib.roi_pooling.C_ROIPooling"]
+    import common.lib.roi_pooling.roi_align as ra_mod
+    ra_mod.C_ROIPooling = rp.C_ROIPooling
+    from common.fast_rcnn import FastRCNN as RefFastRCNN
+    seed = 7
+    P = VO.init_vision_params(seed, num_layers)
+    E = ref_import._EasyDict
+    cfg = E(dict(NETWORK=dict(IMAGE_FEAT_PRECOMPUTED=False, IMAGE_SEMANTIC=False, IMAGE_STRIDE_IN_1x1=True, IMAGE_C5_DILATED=True,
+                              IMAGE_NUM_LAYERS=num_layers, IMAGE_PRETRAINED="oracle_init", IMAGE_PRETRAINED_EPOCH=0,
+                              OUTPUT_CONV5=False, IMAGE_FROZEN_BN=True, IMAGE_FROZEN_BACKBONE_STAGES=[1, 2])))
+    real_load = torch.load
+    torch.load = lambda path, *a, **k: dict(P) if str(path).startswith("oracle_init") else real_load(path, *a, **k)
+    try:
+        model = RefFastRCNN(cfg, average_pool=True, final_dim=768, enable_cnn_reg_loss=False)
+        model.init_weight()
+    finally:
+        torch.load = real_load
+    model.train()
+    model.bn_eval()                      # common/fast_rcnn.py:122-126, called by the trainer every iteration
+    model.obj_downsample[0].p = 0.0      # the objective below does not involve obj_downsample; keep the run deterministic
+    g = torch.Generator().manual_seed(seed + 1)
+    B, R, Hi, Wi = 2, 3, 96, 128
+    img = torch.randn(B, 3, Hi, Wi, generator=g) * 50.0
+    boxes = torch.tensor([[[4.0, 6.0, 90.0, 80.0], [30.5, 10.25, 120.0, 60.0], [0.0, 0.0, 127.0, 95.0]],
+                          [[10.0, 20.0, 50.0, 70.0], [64.0, 8.0, 100.0, 40.0], [-2.0, -2.0, -2.0, -2.0]]])
+    im_info = torch.tensor([[Wi, Hi, 1.0, 1.0, 0.0], [Wi, Hi, 1.0, 1.0, 1.0]])
+    box_mask = boxes[:, :, 0] > -1.5
+    out = model(images=img, boxes=boxes.clone(), box_mask=box_mask, im_info=im_info, classes=None, segms=None, mvrc_ops=None,
+                mask_visual_embed=None)
+    raw = out["obj_reps_raw"]                                    # [B, R, 2048], zero rows for padded boxes
+    Wr = torch.randn(raw.shape, generator=g) / raw.numel() ** 0.5
+    (raw * Wr).sum().backward()
+    names = VO.split_state_dict(P)
+    ref_params = dict(model.named_parameters())
+    frozen = {("roi_head_feature_extractor." + k[7:]) if k.startswith("layer4.") else ("backbone." + k) for k in VO.frozen_names(P)}
+    gnorm, gsample = {}, {}
+    for k in names:
+        if k not in ref_params:
+            continue                                              # BN running statistics are buffers
+        p = ref_params[k]
+        assert (p.grad is None or float(p.grad.abs().sum()) == 0.0) == (k in frozen), k
+        if k not in frozen:
+            gnorm[k] = float(p.grad.double().norm())
+            gsample[k] = p.grad.reshape(-1)[:: max(1, p.grad.numel() // 64)][:64].numpy().copy()
+    # the restatement, same inputs
+    Po = {k: v.clone().requires_grad_(k not in VO.frozen_names(P)) for k, v in P.items()}
+    feats, body4 = VO.e2e_features(img, boxes, Po, num_layers)
+    err = float((feats - raw[box_mask]).abs().max())
+    print("%s: restatement vs reference |d feats|max = %.3e (|feats| max %.3f)" % (name, err, float(raw.abs().max())))
+    assert err < 1e-4
+    path = os.path.join(ROOT, "tests", "golden", "vision", name + ".npz")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    keys = sorted(gnorm)
+    np.savez_compressed(path, seed=seed, num_layers=num_layers, img=img.numpy(), boxes=boxes.numpy(), im_info=im_info.numpy(),
+                        Wr=Wr.numpy(), obj_reps_raw=raw.detach().numpy(), body4_mean=float(body4.mean()),
+                        body4_abs_mean=float(body4.abs().mean()), body4_sample=body4.detach().reshape(-1)[::97][:512].numpy(),
+                        grad_names=np.array(keys), grad_norms=np.array([gnorm[k] for k in keys]),
+                        grad_samples=np.stack([gsample[k] if gsample[k].size == 64 else np.resize(gsample[k], 64) for k in keys]))
+    print("%s -> %s (%.1f KB), %d trainable tensors" % (name, path, os.path.getsize(path) / 1024, len(keys)))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     if len(sys.argv) > 1 and sys.argv[1] == "core":
         run_core_case()
+    elif len(sys.argv) > 1 and sys.argv[1] == "vision":
+        run_vision_case()
     else:
         for name, spec in CASES.items():
             run_case(name, spec)

@@ -67,6 +67,27 @@ def install_stubs():
         sys.modules[name] = m
 
 
+def install_roi_align_oracle():
+    """Route the reference's `_ROIAlign` autograd function (common/lib/roi_pooling/roi_align.py:11-44) to
+    oracle/roi_align_oracle.py: the reference's compiled op has no CPU backward (ROIAlign.h:44) and is not built here.
+    Used only to drive the reference's own FastRCNN e2e module for the vision golden fixture."""
+    import numpy as np
+    import torch
+    from . import roi_align_oracle as RA
+    install_stubs()
+    m = sys.modules["common.lib.roi_pooling.C_ROIPooling"]
+
+    def fwd(inp, rois, scale, ph, pw, sr):
+        return torch.from_numpy(np.ascontiguousarray(RA.roi_align_forward(inp.detach().numpy().astype(np.float32),
+                                                                          rois.numpy().astype(np.float32), scale, ph, pw, sr), dtype=np.float32))
+
+    def bwd(grad, rois, scale, ph, pw, b, c, h, w, sr):
+        return torch.from_numpy(np.ascontiguousarray(RA.roi_align_backward(grad.contiguous().numpy().astype(np.float32),
+                                                                           rois.numpy().astype(np.float32), scale, ph, pw, b, c, h, w, sr), dtype=np.float32))
+
+    m.roi_align_forward, m.roi_align_backward = fwd, bwd
+
+
 def make_vocab_dir(path, vocab_size):
     """Synthetic vocab.txt so BertTokenizer.from_pretrained(<dir>) works offline
     (external/pytorch_pretrained_bert/tokenization.py:119-153)."""

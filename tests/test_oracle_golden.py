@@ -123,3 +123,39 @@ def test_oracle_module_api_matches_reference_fixture():
         total += float((g.double() ** 2).sum())
         assert abs(float(g.double().norm()) - float(z["g_stat/" + str(n)][0])) <= 1e-4 * max(1.0, float(z["g_stat/" + str(n)][0])), n
     assert abs(total ** 0.5 - float(z["grad_norm"])) <= 1e-5 * float(z["grad_norm"])
+
+
+def load_vision_case():
+    from oracle import vision_oracle as VO
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "vision", "vision_small.npz"), allow_pickle=False)
+    nl = int(z["num_layers"])
+    P = VO.init_vision_params(int(z["seed"]), nl)
+    return z, nl, P
+
+
+def test_vision_oracle_matches_reference_fast_rcnn_e2e():
+    """oracle/vision_oracle.py (ResNet trunk -> ROIAlign -> dilated layer4 -> avg-pool, frozen BN / stages) against the fixture the
+    REFERENCE's FastRCNN e2e module produced (oracle/make_golden.py vision): pooled features, body4 samples and the gradient
+    norm + 64 samples of every trainable tensor."""
+    from oracle import vision_oracle as VO
+    z, nl, P = load_vision_case()
+    frozen = VO.frozen_names(P)
+    Po = {k: v.clone().requires_grad_(k not in frozen) for k, v in P.items()}
+    img, boxes = torch.from_numpy(z["img"]), torch.from_numpy(z["boxes"])
+    feats, body4 = VO.e2e_features(img, boxes, Po, nl)
+    mask = boxes[:, :, 0] > -1.5
+    raw = torch.from_numpy(z["obj_reps_raw"])
+    assert float((feats - raw[mask]).abs().max()) < 1e-4
+    assert float(raw[~mask].abs().max()) == 0.0
+    assert np.allclose(body4.detach().reshape(-1)[::97][:512].numpy(), z["body4_sample"], atol=1e-5)
+    (feats * torch.from_numpy(z["Wr"])[mask]).sum().backward()
+    names = VO.split_state_dict(P)
+    inv = {v_name: k for k, v_name in zip(P.keys(), names.keys())}
+    for k, want_norm, want_s in zip(z["grad_names"], z["grad_norms"], z["grad_samples"]):
+        g = Po[inv[str(k)]].grad
+        assert g is not None, k
+        assert abs(float(g.double().norm()) - want_norm) <= 1e-4 * want_norm + 1e-9, k
+        s = g.reshape(-1)[:: max(1, g.numel() // 64)][:64].numpy()
+        assert np.allclose(np.resize(s, 64), want_s, rtol=1e-3, atol=1e-6 * want_norm), k
+    for k in frozen:
+        assert Po[k].grad is None

@@ -42,6 +42,18 @@ _SIGS = {
     "vlb_sumsq_f32": "plps",
     "vlb_adamw_step": "ppppplpfs",
     "vlb_lr_schedule_step": "pifffs",
+    "vlb_conv_weight_prepare": "pppppfppppiiiis",
+    "vlb_conv_wgrad_finalize": "pppiiiis",
+    "vlb_im2col_nhwc_bf16": "ppliiiiiiiiis",
+    "vlb_im2col_image_f32": "ppiiiiiiiiis",
+    "vlb_maxpool3x3s2_nhwc": "ppiiiis",
+    "vlb_subsample2_nhwc": "ppiiiis",
+    "vlb_upsample2_zero_nhwc": "ppiiiis",
+    "vlb_roi_align_nhwc_fwd": "pplipiiiiiifis",
+    "vlb_roi_align_nhwc_bwd": "pplipiiiiiiifis",
+    "vlb_relu_mask_cast": "pppls",
+    "vlb_avgpool_rows_fwd": "ppliiiis",
+    "vlb_avgpool_rows_bwd": "plpplpiiifpuuus",
     "vlb_cast_f32_bf16": "ppls",
     "vlb_cast_bf16_f32": "ppls",
     "vlb_rng_advance": "ps",

@@ -137,7 +137,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
     const int m = mb + i * 16;
     if (!INTERIOR && m >= p.M) continue;
     const long offc = (long)m * p.ldc + nb + (long)blockIdx.y * p.c_split_stride;
-    const bf16_t* aux_row = (ACT == 3 || ACT == 5) ? p.aux + (long)m * p.ldaux + nb : nullptr;
+    const bf16_t* aux_row = (ACT == 3 || ACT == 5 || ACT == 8) ? p.aux + (long)m * p.ldaux + nb : nullptr;
     bf16_t* pre_row = (GELU && p.pre && !STAGED) ? p.pre + (long)m * p.ldpre + nb : nullptr;
     const bf16_t* res_row = RES ? p.res + (long)m * p.ldres + nb : nullptr;
     const uint32_t idx_row = DROP ? (uint32_t)m * (uint32_t)p.N + (uint32_t)nb : 0u;
@@ -214,6 +214,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
           for (int r = 0; r < 4 && n + r < p.N; ++r) v[r] += bf2f(q[r]);
         }
       }
+      if (ACT == 7) {            // Bottleneck tail (common/backbone/resnet/resnet.py:112-116): relu(conv + shift + residual)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+      } else if (ACT == 8) {     // ReLU backward on a gradient: (acc [+ res]) where the saved activation aux > 0
+        const bf16_t* q = aux_row + j * 16;
+        if (full) {
+          const uint2 w = *(const uint2*)q;
+          v[0] = bflo(w.x) > 0.f ? v[0] : 0.f; v[1] = bfhi(w.x) > 0.f ? v[1] : 0.f;
+          v[2] = bflo(w.y) > 0.f ? v[2] : 0.f; v[3] = bfhi(w.y) > 0.f ? v[3] : 0.f;
+        } else {
+          for (int r = 0; r < 4 && n + r < p.N; ++r) v[r] = bf2f(q[r]) > 0.f ? v[r] : 0.f;
+        }
+      }
       if (OUT == 0) {
         if (STAGED) {
           epi_stage_put(st, i, j, v);
@@ -254,7 +267,11 @@ __device__ __forceinline__ void gemm_epilogue_dispatch(const GemmParams& p, f32x
   else if (p.act == 4) gemm_epilogue<4, false, false, 0, INTERIOR, FM, FN>(p, acc, mb, nb, st);
   else if (p.act == 5) gemm_epilogue<5, false, false, 0, INTERIOR, FM, FN>(p, acc, mb, nb, st);
   else if (p.act == 6) gemm_epilogue<6, false, false, 0, INTERIOR, FM, FN>(p, acc, mb, nb, st);
-  else if (p.res) {
+  else if (p.act == 7) gemm_epilogue<7, false, true, 0, INTERIOR, FM, FN>(p, acc, mb, nb, st);
+  else if (p.act == 8) {
+    if (p.res) gemm_epilogue<8, false, true, 0, INTERIOR, FM, FN>(p, acc, mb, nb, st);
+    else gemm_epilogue<8, false, false, 0, INTERIOR, FM, FN>(p, acc, mb, nb, st);
+  } else if (p.res) {
     if (p.drop_thr) gemm_epilogue<0, true, true, 0, INTERIOR, FM, FN>(p, acc, mb, nb, st);
     else gemm_epilogue<0, false, true, 0, INTERIOR, FM, FN>(p, acc, mb, nb, st);
   } else if (p.drop_thr) gemm_epilogue<0, true, false, 0, INTERIOR, FM, FN>(p, acc, mb, nb, st);
@@ -262,15 +279,16 @@ __device__ __forceinline__ void gemm_epilogue_dispatch(const GemmParams& p, f32x
 }
 
 // EPI >= 0 compiles ONE fused epilogue into the kernel (bf16 output): 0 bias | 1 bias+GELU, gelu'(x) -> pre |
-// 2 x aux | 3 bias+dropout+residual | 4 bias+residual | 5 bias+ReLU.  With every variant inlined behind the runtime
+// 2 x aux | 3 bias+dropout+residual | 4 bias+residual | 5 bias+ReLU | 6 relu(bias+residual) | 7 (acc+residual) where
+// aux>0 | 8 acc where aux>0 (6-8: the frozen-BN Bottleneck forward tail and its ReLU backward, vision.py).  With every variant inlined behind the runtime
 // dispatch (EPI = -1, kept for the fp32 / rarely used forms) the 128-register 8-wave kernel spilled in its epilogues.
 template <int EPI, bool INTERIOR, int FM, int FN>
 __device__ __forceinline__ void gemm_epilogue_select(const GemmParams& p, f32x4 (&acc)[FM][FN], int mb, int nb, const EpiStage& st) {
   if constexpr (EPI < 0) {
     gemm_epilogue_dispatch<INTERIOR, FM, FN>(p, acc, mb, nb, st);
   } else {
-    constexpr int ACT = EPI == 1 ? 4 : EPI == 2 ? 5 : EPI == 5 ? 2 : 0;
-    gemm_epilogue<ACT, EPI == 3, EPI == 3 || EPI == 4, 0, INTERIOR, FM, FN>(p, acc, mb, nb, st);
+    constexpr int ACT = EPI == 1 ? 4 : EPI == 2 ? 5 : EPI == 5 ? 2 : EPI == 6 ? 7 : (EPI == 7 || EPI == 8) ? 8 : 0;
+    gemm_epilogue<ACT, EPI == 3, EPI == 3 || EPI == 4 || EPI == 6 || EPI == 7, 0, INTERIOR, FM, FN>(p, acc, mb, nb, st);
   }
 }
 
@@ -992,6 +1010,8 @@ static int epi_class(const GemmParams& p) {
   if (p.act == 4) return 1;
   if (p.act == 5) return 2;
   if (p.act == 2) return 5;
+  if (p.act == 7) return 6;
+  if (p.act == 8) return p.res ? 7 : 8;
   return -1;
 }
 
@@ -1004,6 +1024,9 @@ static int launch_gemm_epi(GemmParams& p, int splits, hipStream_t stream) {
     case 3: return launch_gemm_cfg<BM, BN, WGM, WGN, 3>(p, splits, stream);
     case 4: return launch_gemm_cfg<BM, BN, WGM, WGN, 4>(p, splits, stream);
     case 5: return launch_gemm_cfg<BM, BN, WGM, WGN, 5>(p, splits, stream);
+    case 6: return launch_gemm_cfg<BM, BN, WGM, WGN, 6>(p, splits, stream);
+    case 7: return launch_gemm_cfg<BM, BN, WGM, WGN, 7>(p, splits, stream);
+    case 8: return launch_gemm_cfg<BM, BN, WGM, WGN, 8>(p, splits, stream);
     default: return launch_gemm_cfg<BM, BN, WGM, WGN, -1>(p, splits, stream);
   }
 }
@@ -1024,9 +1047,11 @@ extern "C" int vlb_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb
   VLB_CHECK_ARG((lda % 8) == 0 && (ldb % 8) == 0, "vlb_gemm_nt_bf16: lda/ldb must be multiples of 8 elements");
   VLB_CHECK_ARG((ldc % 4) == 0, "vlb_gemm_nt_bf16: ldc must be a multiple of 4");
   VLB_CHECK_ARG(out_mode >= 0 && out_mode <= 3, "vlb_gemm_nt_bf16: bad out_mode %d", out_mode);
-  VLB_CHECK_ARG(act >= 0 && act <= 6, "vlb_gemm_nt_bf16: bad act %d", act);
-  VLB_CHECK_ARG((act != 3 && act != 5) || aux, "vlb_gemm_nt_bf16: act=3/5 needs aux");
-  VLB_CHECK_ARG(act == 0 || (!(drop_p > 0.f) && !res), "vlb_gemm_nt_bf16: an activation cannot be combined with dropout/residual");
+  VLB_CHECK_ARG(act >= 0 && act <= 8, "vlb_gemm_nt_bf16: bad act %d", act);
+  VLB_CHECK_ARG((act != 3 && act != 5 && act != 8) || aux, "vlb_gemm_nt_bf16: act=3/5/8 needs aux");
+  VLB_CHECK_ARG(act != 7 || res, "vlb_gemm_nt_bf16: act=7 (relu after residual) needs res");
+  VLB_CHECK_ARG(act == 0 || act >= 7 || (!(drop_p > 0.f) && !res), "vlb_gemm_nt_bf16: an activation cannot be combined with dropout/residual");
+  VLB_CHECK_ARG(act < 7 || !(drop_p > 0.f), "vlb_gemm_nt_bf16: act=7/8 cannot be combined with dropout");
   VLB_CHECK_ARG(out_mode == 0 || (act == 0 && !(drop_p > 0.f) && !res), "vlb_gemm_nt_bf16: fp32 outputs take bias only");
   VLB_CHECK_ARG(!(drop_p > 0.f) || seed, "vlb_gemm_nt_bf16: dropout needs a device seed pointer");
   VLB_CHECK_ARG((long)M * (long)N < (1L << 32) || !(drop_p > 0.f), "vlb_gemm_nt_bf16: dropout index overflow");

@@ -1,0 +1,507 @@
+// End-to-end vision path for gfx950: the memory-bound kernels around the convolution GEMMs of the ResNet trunk and
+// RoI head (common/backbone/resnet/resnet.py:75-199, common/fast_rcnn.py:55-100,144-156).
+//
+// Layout: activations are NHWC bf16 -- a feature map is a row-major [N*H*W, C] matrix, so a 1x1 convolution IS the
+// MFMA NT GEMM of gemm.hip on the tensor as it lies (the reference's NCHW needs cuDNN's implicit transposes), a 3x3
+// convolution is that GEMM over a gathered [rows, 9C] operand, frozen BatchNorm is folded into the bf16 working weights
+// (scale) and the GEMM bias (shift), and ReLU / residual-add / ReLU-backward ride in the GEMM epilogues (act 2 / 7 / 8).
+// What is left for this file is data movement, all of it 16-B per lane and coalesced along C:
+//   vlb_conv_weight_prepare     fp32 master [O,KH,KW,I] x BN(gamma,beta,mean,var) -> bf16 forward operand [O,K],
+//                               bf16 dgrad operand [I, mirrored taps, O], per-channel scale / shift
+//   vlb_conv_wgrad_finalize     dW_master (+)= scale[o] * dW_folded
+//   vlb_im2col_nhwc_bf16        [N,H,W,C] -> [N*OH*OW, KH*KW*C] (zero padding, stride, dilation)
+//   vlb_im2col_image_f32        the 7x7/2 stem: fp32 NCHW image -> [N*OH*OW, 192] bf16 (147 taps x channels + pad)
+//   vlb_maxpool3x3s2_nhwc       stem max-pool (forward only: stages 1-2 are frozen, resnet.py:223-233)
+//   vlb_subsample2_nhwc / vlb_upsample2_zero_nhwc   the stride of the caffe-style stride-in-1x1 blocks (resnet.py:79)
+//   vlb_roi_align_nhwc_fwd/bwd  ROIAlign (roi_align.py:11-44) on NHWC bf16 features; backward = fp32 atomics, dense per wave
+//   vlb_relu_mask_cast          fp32 gradient -> bf16 where the saved activation > 0
+//   vlb_avgpool_rows_fwd/bwd    AvgPool2d(14) + Flattener (common/fast_rcnn.py:80-84) into / out of the [B,R,4+2048] box rows
+#include "vlb_common.h"
+
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_weight_prepare_kernel(const float* __restrict__ w, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, const float* __restrict__ mean,
+                                                                  const float* __restrict__ var, float eps, bf16_t* __restrict__ wf,
+                                                                  bf16_t* __restrict__ wb, float* __restrict__ scale,
+                                                                  float* __restrict__ shift, int O, int I, int T, int kf) {
+  const long total = (long)O * T * I;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int i = (int)(idx % I);
+    const int t = (int)((idx / I) % T);
+    const int o = (int)(idx / ((long)I * T));
+    const float s = gamma ? gamma[o] / sqrtf(var[o] + eps) : 1.0f;
+    const bf16_t v = f2bf(w[idx] * s);
+    wf[(long)o * kf + (long)t * I + i] = v;
+    if (wb) wb[(long)i * T * O + (long)(T - 1 - t) * O + o] = v;
+    if (i == 0 && t == 0) {
+      if (scale) scale[o] = s;
+      if (shift) shift[o] = gamma ? beta[o] - mean[o] * s : 0.f;
+    }
+  }
+}
+
+extern "C" int vlb_conv_weight_prepare(const float* w, const float* gamma, const float* beta, const float* mean, const float* var,
+                                       float eps, void* wf, void* wb, float* scale, float* shift, int O, int I, int taps, int kf,
+                                       hipStream_t stream) {
+  VLB_CHECK_ARG(w && wf, "vlb_conv_weight_prepare: null weight");
+  VLB_CHECK_ARG(O > 0 && I > 0 && taps > 0 && kf >= taps * I, "vlb_conv_weight_prepare: bad shape O=%d I=%d taps=%d kf=%d", O, I, taps, kf);
+  VLB_CHECK_ARG(!gamma || (beta && mean && var), "vlb_conv_weight_prepare: incomplete BatchNorm statistics");
+  const long total = (long)O * taps * I;
+  int blocks = vlb_cdiv(total, 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(conv_weight_prepare_kernel, dim3(blocks), dim3(256), 0, stream, w, gamma, beta, mean, var, eps, (bf16_t*)wf,
+                     (bf16_t*)wb, scale, shift, O, I, taps, kf);
+  VLB_CHECK_LAUNCH("vlb_conv_weight_prepare");
+  return VLB_OK;
+}
+
+__global__ __launch_bounds__(256) void conv_wgrad_finalize_kernel(const float* __restrict__ dwf, const float* __restrict__ scale,
+                                                                  float* __restrict__ g, int O, int kreal, int kf, int accumulate) {
+  const long total = (long)O * kreal;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int o = (int)(idx / kreal), k = (int)(idx % kreal);
+    const float v = dwf[(long)o * kf + k] * (scale ? scale[o] : 1.0f);
+    g[idx] = accumulate ? g[idx] + v : v;
+  }
+}
+
+extern "C" int vlb_conv_wgrad_finalize(const float* dwf, const float* scale, float* g, int O, int kreal, int kf, int accumulate,
+                                       hipStream_t stream) {
+  VLB_CHECK_ARG(dwf && g && O > 0 && kreal > 0 && kf >= kreal, "vlb_conv_wgrad_finalize: bad argument");
+  int blocks = vlb_cdiv((long)O * kreal, 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(conv_wgrad_finalize_kernel, dim3(blocks), dim3(256), 0, stream, dwf, scale, g, O, kreal, kf, accumulate);
+  VLB_CHECK_LAUNCH("vlb_conv_wgrad_finalize");
+  return VLB_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// im2col: one 16-B chunk (8 channels of one tap of one output pixel) per thread
+__global__ __launch_bounds__(256) void im2col_nhwc_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ col, int N, int H, int W,
+                                                          int C, int KH, int KW, int stride, int pad, int dil, int OH, int OW,
+                                                          long ldcol) {
+  const int c8n = C >> 3;
+  const long per_row = (long)KH * KW * c8n;
+  const long total = (long)N * OH * OW * per_row;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const long row = idx / per_row;
+    const int q = (int)(idx % per_row);
+    const int t = q / c8n, c8 = q % c8n;
+    const int ky = t / KW, kx = t % KW;
+    const int ox = (int)(row % OW);
+    const int oy = (int)((row / OW) % OH);
+    const int n = (int)(row / ((long)OW * OH));
+    const int iy = oy * stride - pad + ky * dil, ix = ox * stride - pad + kx * dil;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = *(const uint4*)(x + (((long)n * H + iy) * W + ix) * C + c8 * 8);
+    *(uint4*)(col + row * ldcol + (long)t * C + c8 * 8) = v;
+  }
+}
+
+extern "C" int vlb_im2col_nhwc_bf16(const void* x, void* col, long ldcol, int N, int H, int W, int C, int KH, int KW, int stride,
+                                    int pad, int dil, hipStream_t stream) {
+  if (N <= 0) return VLB_OK;
+  VLB_CHECK_ARG(x && col, "vlb_im2col_nhwc_bf16: null argument");
+  VLB_CHECK_ARG(C > 0 && (C % 8) == 0 && (ldcol % 8) == 0 && ldcol >= (long)KH * KW * C, "vlb_im2col_nhwc_bf16: C=%d ldcol=%ld", C, ldcol);
+  VLB_CHECK_ARG(stride >= 1 && dil >= 1 && pad >= 0 && KH >= 1 && KW >= 1, "vlb_im2col_nhwc_bf16: bad geometry");
+  const int OH = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1, OW = (W + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
+  VLB_CHECK_ARG(OH > 0 && OW > 0, "vlb_im2col_nhwc_bf16: empty output");
+  const long total = (long)N * OH * OW * KH * KW * (C / 8);
+  long blocks = (total + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(im2col_nhwc_kernel, dim3((int)blocks), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)col, N, H, W, C, KH, KW,
+                     stride, pad, dil, OH, OW, ldcol);
+  VLB_CHECK_LAUNCH("vlb_im2col_nhwc_bf16");
+  return VLB_OK;
+}
+
+// stem: fp32 NCHW image, 7x7 stride 2 pad 3 (resnet.py:137-138); column k = (ky*7 + kx)*3 + c, zero from 147 up to ldcol
+__global__ __launch_bounds__(256) void im2col_image_kernel(const float* __restrict__ img, bf16_t* __restrict__ col, int N, int Cin, int H,
+                                                           int W, int KH, int KW, int stride, int pad, int OH, int OW, int ldcol) {
+  const int k8n = ldcol >> 3;
+  const int kreal = KH * KW * Cin;
+  const long total = (long)N * OH * OW * k8n;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const long row = idx / k8n;
+    const int k0 = (int)(idx % k8n) * 8;
+    const int ox = (int)(row % OW);
+    const int oy = (int)((row / OW) % OH);
+    const int n = (int)(row / ((long)OW * OH));
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = k0 + e;
+      v[e] = 0.f;
+      if (k < kreal) {
+        const int c = k % Cin, t = k / Cin, ky = t / KW, kx = t % KW;
+        const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) v[e] = img[(((long)n * Cin + c) * H + iy) * W + ix];
+      }
+    }
+    *(uint4*)(col + row * ldcol + k0) = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+  }
+}
+
+extern "C" int vlb_im2col_image_f32(const float* img, void* col, int ldcol, int N, int Cin, int H, int W, int KH, int KW, int stride,
+                                    int pad, hipStream_t stream) {
+  if (N <= 0) return VLB_OK;
+  VLB_CHECK_ARG(img && col, "vlb_im2col_image_f32: null argument");
+  VLB_CHECK_ARG((ldcol % 8) == 0 && ldcol >= KH * KW * Cin, "vlb_im2col_image_f32: ldcol=%d too small / unaligned", ldcol);
+  const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+  VLB_CHECK_ARG(OH > 0 && OW > 0, "vlb_im2col_image_f32: empty output");
+  const long total = (long)N * OH * OW * (ldcol / 8);
+  long blocks = (total + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(im2col_image_kernel, dim3((int)blocks), dim3(256), 0, stream, img, (bf16_t*)col, N, Cin, H, W, KH, KW, stride, pad,
+                     OH, OW, ldcol);
+  VLB_CHECK_LAUNCH("vlb_im2col_image_f32");
+  return VLB_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void unpack8(const uint4& u, float (&f)[8]) {
+  f[0] = bflo(u.x); f[1] = bfhi(u.x); f[2] = bflo(u.y); f[3] = bfhi(u.y);
+  f[4] = bflo(u.z); f[5] = bfhi(u.z); f[6] = bflo(u.w); f[7] = bfhi(u.w);
+}
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+  return make_uint4(pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7]));
+}
+
+// MaxPool2d(kernel 3, stride 2, padding 1) (resnet.py:141): padding never wins the max
+__global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int N, int H, int W, int C,
+                                                           int OH, int OW) {
+  const int c8n = C >> 3;
+  const long total = (long)N * OH * OW * c8n;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int c8 = (int)(idx % c8n);
+    const long row = idx / c8n;
+    const int ox = (int)(row % OW);
+    const int oy = (int)((row / OW) % OH);
+    const int n = (int)(row / ((long)OW * OH));
+    float m[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m[e] = -3.0e38f;
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = oy * 2 - 1 + ky;
+      if (iy < 0 || iy >= H) continue;
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = ox * 2 - 1 + kx;
+        if (ix < 0 || ix >= W) continue;
+        float f[8];
+        unpack8(*(const uint4*)(x + (((long)n * H + iy) * W + ix) * C + c8 * 8), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], f[e]);
+      }
+    }
+    *(uint4*)(y + row * C + c8 * 8) = pack8(m);
+  }
+}
+
+extern "C" int vlb_maxpool3x3s2_nhwc(const void* x, void* y, int N, int H, int W, int C, hipStream_t stream) {
+  if (N <= 0) return VLB_OK;
+  VLB_CHECK_ARG(x && y && C > 0 && (C % 8) == 0 && H > 0 && W > 0, "vlb_maxpool3x3s2_nhwc: bad argument");
+  const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+  const long total = (long)N * OH * OW * (C / 8);
+  long blocks = (total + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3((int)blocks), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, N, H, W, C, OH, OW);
+  VLB_CHECK_LAUNCH("vlb_maxpool3x3s2_nhwc");
+  return VLB_OK;
+}
+
+// y[n,oy,ox,:] = x[n,2oy,2ox,:]  (a 1x1 convolution with stride 2 reads exactly these pixels, resnet.py:79,158-160)
+__global__ __launch_bounds__(256) void subsample2_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int N, int H, int W, int C, int OH,
+                                                         int OW) {
+  const int c8n = C >> 3;
+  const long total = (long)N * OH * OW * c8n;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int c8 = (int)(idx % c8n);
+    const long row = idx / c8n;
+    const int ox = (int)(row % OW);
+    const int oy = (int)((row / OW) % OH);
+    const int n = (int)(row / ((long)OW * OH));
+    *(uint4*)(y + row * C + c8 * 8) = *(const uint4*)(x + (((long)n * H + 2 * oy) * W + 2 * ox) * C + c8 * 8);
+  }
+}
+
+// dx[n,iy,ix,:] = dy[n,iy/2,ix/2,:] on even (iy,ix), 0 elsewhere (every element of dx is written)
+__global__ __launch_bounds__(256) void upsample2_zero_kernel(const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx, int N, int H, int W, int C,
+                                                             int OH, int OW) {
+  const int c8n = C >> 3;
+  const long total = (long)N * H * W * c8n;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int c8 = (int)(idx % c8n);
+    const long row = idx / c8n;
+    const int ix = (int)(row % W);
+    const int iy = (int)((row / W) % H);
+    const int n = (int)(row / ((long)W * H));
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (((iy | ix) & 1) == 0) v = *(const uint4*)(dy + (((long)n * OH + (iy >> 1)) * OW + (ix >> 1)) * C + c8 * 8);
+    *(uint4*)(dx + row * C + c8 * 8) = v;
+  }
+}
+
+extern "C" int vlb_subsample2_nhwc(const void* x, void* y, int N, int H, int W, int C, hipStream_t stream) {
+  if (N <= 0) return VLB_OK;
+  VLB_CHECK_ARG(x && y && C > 0 && (C % 8) == 0 && H > 0 && W > 0, "vlb_subsample2_nhwc: bad argument");
+  const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+  long blocks = ((long)N * OH * OW * (C / 8) + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(subsample2_kernel, dim3((int)blocks), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, N, H, W, C, OH, OW);
+  VLB_CHECK_LAUNCH("vlb_subsample2_nhwc");
+  return VLB_OK;
+}
+
+extern "C" int vlb_upsample2_zero_nhwc(const void* dy, void* dx, int N, int H, int W, int C, hipStream_t stream) {
+  if (N <= 0) return VLB_OK;
+  VLB_CHECK_ARG(dy && dx && C > 0 && (C % 8) == 0 && H > 0 && W > 0, "vlb_upsample2_zero_nhwc: bad argument");
+  const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+  long blocks = ((long)N * H * W * (C / 8) + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(upsample2_zero_kernel, dim3((int)blocks), dim3(256), 0, stream, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, OH, OW);
+  VLB_CHECK_LAUNCH("vlb_upsample2_zero_nhwc");
+  return VLB_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// ROIAlign on NHWC bf16 features.  Same sampling arithmetic as roi_align.hip (cuda/ROIAlign_cuda.cu:15-122,125-254):
+// one WAVE per output bin, lanes across channels (16-B chunks), so the four neighbour reads of a sample are four
+// contiguous C*2-byte rows and the backward atomics of a wave hit consecutive addresses.  RoIs come straight from the
+// padded box rows of the batch: box k belongs to image k / boxes_per_image, coordinates boxes[k*ldbox + 0..3]
+// (common/fast_rcnn.py:145-149 builds the same (batch_idx, x1, y1, x2, y2) rows); padded boxes (x1 <= -1.5,
+// pretrain/data/collate_batch.py:39) produce zeros forward and receive no gradient.
+// ------------------------------------------------------------------------------------------------------------------
+struct NhwcSample {
+  long p1, p2, p3, p4;   // pixel indices inside the image plane, -1: outside
+  float w1, w2, w3, w4;
+};
+
+__device__ __forceinline__ NhwcSample nhwc_sample(float y, float x, int height, int width) {
+  NhwcSample g;
+  if (y < -1.0f || y > (float)height || x < -1.0f || x > (float)width) {
+    g.p1 = g.p2 = g.p3 = g.p4 = -1;
+    g.w1 = g.w2 = g.w3 = g.w4 = 0.f;
+    return g;
+  }
+  if (y <= 0.f) y = 0.f;
+  if (x <= 0.f) x = 0.f;
+  int y_low = (int)y, x_low = (int)x, y_high, x_high;
+  if (y_low >= height - 1) { y_high = y_low = height - 1; y = (float)y_low; } else { y_high = y_low + 1; }
+  if (x_low >= width - 1) { x_high = x_low = width - 1; x = (float)x_low; } else { x_high = x_low + 1; }
+  const float ly = y - (float)y_low, lx = x - (float)x_low, hy = 1.f - ly, hx = 1.f - lx;
+  g.p1 = (long)y_low * width + x_low; g.p2 = (long)y_low * width + x_high;
+  g.p3 = (long)y_high * width + x_low; g.p4 = (long)y_high * width + x_high;
+  g.w1 = hy * hx; g.w2 = hy * lx; g.w3 = ly * hx; g.w4 = ly * lx;
+  return g;
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void roi_align_nhwc_kernel(const bf16_t* __restrict__ feat, float* __restrict__ dfeat,
+                                                             const float* __restrict__ boxes, long ldbox, int boxes_per_image,
+                                                             bf16_t* __restrict__ out, const bf16_t* __restrict__ dout, int K, int C, int H,
+                                                             int W, int ph_n, int pw_n, float scale, int sampling_ratio) {
+  const int lane = threadIdx.x & 63;
+  const int bins = ph_n * pw_n;
+  const long gw = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (gw >= (long)K * bins) return;
+  const int k = (int)(gw / bins), bin = (int)(gw % bins);
+  const int ph = bin / pw_n, pw = bin % pw_n;
+  const float* bx = boxes + (long)k * ldbox;
+  const int batch = k / boxes_per_image;
+  const int c8n = C >> 3;
+  if (!(bx[0] > -1.5f)) {   // padded box
+    if (!BWD)
+      for (int c8 = lane; c8 < c8n; c8 += 64) *(uint4*)(out + gw * C + c8 * 8) = make_uint4(0, 0, 0, 0);
+    return;
+  }
+  const float start_w = bx[0] * scale, start_h = bx[1] * scale, end_w = bx[2] * scale, end_h = bx[3] * scale;
+  const float rw = fmaxf(end_w - start_w, 1.f), rh = fmaxf(end_h - start_h, 1.f);
+  const float bin_h = rh / (float)ph_n, bin_w = rw / (float)pw_n;
+  const int grid_h = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rh / (float)ph_n);
+  const int grid_w = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rw / (float)pw_n);
+  const float inv_count = 1.0f / (float)(grid_h * grid_w);
+  const long plane = (long)H * W;
+  for (int c8 = lane; c8 < c8n; c8 += 64) {
+    float acc[8];
+    if (BWD) {
+      unpack8(*(const uint4*)(dout + gw * C + c8 * 8), acc);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] *= inv_count;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    }
+    for (int iy = 0; iy < grid_h; ++iy) {
+      const float y = start_h + ph * bin_h + (iy + .5f) * bin_h / (float)grid_h;
+      for (int ix = 0; ix < grid_w; ++ix) {
+        const float x = start_w + pw * bin_w + (ix + .5f) * bin_w / (float)grid_w;
+        const NhwcSample g = nhwc_sample(y, x, H, W);
+        if (g.p1 < 0) continue;
+        const long base = (long)batch * plane;
+        if (!BWD) {
+          float a[8], b[8], c[8], d[8];
+          unpack8(*(const uint4*)(feat + (base + g.p1) * C + c8 * 8), a);
+          unpack8(*(const uint4*)(feat + (base + g.p2) * C + c8 * 8), b);
+          unpack8(*(const uint4*)(feat + (base + g.p3) * C + c8 * 8), c);
+          unpack8(*(const uint4*)(feat + (base + g.p4) * C + c8 * 8), d);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] += g.w1 * a[e] + g.w2 * b[e] + g.w3 * c[e] + g.w4 * d[e];
+        } else {
+          float* q1 = dfeat + (base + g.p1) * C + c8 * 8;
+          float* q2 = dfeat + (base + g.p2) * C + c8 * 8;
+          float* q3 = dfeat + (base + g.p3) * C + c8 * 8;
+          float* q4 = dfeat + (base + g.p4) * C + c8 * 8;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            atomicAdd(q1 + e, acc[e] * g.w1);
+            atomicAdd(q2 + e, acc[e] * g.w2);
+            atomicAdd(q3 + e, acc[e] * g.w3);
+            atomicAdd(q4 + e, acc[e] * g.w4);
+          }
+        }
+      }
+    }
+    if (!BWD) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] *= inv_count;
+      *(uint4*)(out + gw * C + c8 * 8) = pack8(acc);
+    }
+  }
+}
+
+extern "C" int vlb_roi_align_nhwc_fwd(const void* feat, const float* boxes, long ldbox, int boxes_per_image, void* out, int K, int C,
+                                      int H, int W, int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio,
+                                      hipStream_t stream) {
+  if (K <= 0) return VLB_OK;
+  VLB_CHECK_ARG(feat && boxes && out, "vlb_roi_align_nhwc_fwd: null argument");
+  VLB_CHECK_ARG(C > 0 && (C % 8) == 0 && H > 0 && W > 0 && pooled_h > 0 && pooled_w > 0 && boxes_per_image > 0 && ldbox >= 4,
+                "vlb_roi_align_nhwc_fwd: bad geometry");
+  const long waves = (long)K * pooled_h * pooled_w;
+  hipLaunchKernelGGL(roi_align_nhwc_kernel<false>, dim3(vlb_cdiv(waves, 4)), dim3(256), 0, stream, (const bf16_t*)feat, (float*)nullptr,
+                     boxes, ldbox, boxes_per_image, (bf16_t*)out, (const bf16_t*)nullptr, K, C, H, W, pooled_h, pooled_w, spatial_scale,
+                     sampling_ratio);
+  VLB_CHECK_LAUNCH("vlb_roi_align_nhwc_fwd");
+  return VLB_OK;
+}
+
+// dfeat (fp32 [N,H,W,C]) is zeroed here, like the reference's at::zeros grad_input (ROIAlign_cuda.cu:316)
+extern "C" int vlb_roi_align_nhwc_bwd(const void* dout, const float* boxes, long ldbox, int boxes_per_image, float* dfeat, int K, int N,
+                                      int C, int H, int W, int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio,
+                                      hipStream_t stream) {
+  VLB_CHECK_ARG(dfeat || (long)N * C == 0, "vlb_roi_align_nhwc_bwd: null dfeat");
+  if ((long)N * C * H * W > 0) (void)hipMemsetAsync(dfeat, 0, sizeof(float) * (size_t)N * C * H * W, stream);
+  if (K <= 0) return VLB_OK;
+  VLB_CHECK_ARG(dout && boxes, "vlb_roi_align_nhwc_bwd: null argument");
+  VLB_CHECK_ARG(C > 0 && (C % 8) == 0 && H > 0 && W > 0 && pooled_h > 0 && pooled_w > 0 && boxes_per_image > 0 && ldbox >= 4,
+                "vlb_roi_align_nhwc_bwd: bad geometry");
+  const long waves = (long)K * pooled_h * pooled_w;
+  hipLaunchKernelGGL(roi_align_nhwc_kernel<true>, dim3(vlb_cdiv(waves, 4)), dim3(256), 0, stream, (const bf16_t*)nullptr, dfeat, boxes,
+                     ldbox, boxes_per_image, (bf16_t*)nullptr, (const bf16_t*)dout, K, C, H, W, pooled_h, pooled_w, spatial_scale,
+                     sampling_ratio);
+  VLB_CHECK_LAUNCH("vlb_roi_align_nhwc_bwd");
+  return VLB_OK;
+}
+
+// dz = g where y > 0 else 0  (fp32 gradient of a post-ReLU activation -> bf16 gradient of its pre-activation)
+__global__ __launch_bounds__(256) void relu_mask_cast_kernel(const float* __restrict__ g, const bf16_t* __restrict__ y, bf16_t* __restrict__ dz,
+                                                             long n8) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    const float4 a = *(const float4*)(g + i * 8), b = *(const float4*)(g + i * 8 + 4);
+    float f[8];
+    unpack8(*(const uint4*)(y + i * 8), f);
+    const float v[8] = {f[0] > 0.f ? a.x : 0.f, f[1] > 0.f ? a.y : 0.f, f[2] > 0.f ? a.z : 0.f, f[3] > 0.f ? a.w : 0.f,
+                        f[4] > 0.f ? b.x : 0.f, f[5] > 0.f ? b.y : 0.f, f[6] > 0.f ? b.z : 0.f, f[7] > 0.f ? b.w : 0.f};
+    *(uint4*)(dz + i * 8) = pack8(v);
+  }
+}
+
+extern "C" int vlb_relu_mask_cast(const float* g, const void* y, void* dz, long n, hipStream_t stream) {
+  if (n <= 0) return VLB_OK;
+  VLB_CHECK_ARG(g && y && dz && (n % 8) == 0, "vlb_relu_mask_cast: null argument or n=%ld not a multiple of 8", n);
+  long blocks = (n / 8 + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(relu_mask_cast_kernel, dim3((int)blocks), dim3(256), 0, stream, g, (const bf16_t*)y, (bf16_t*)dz, n / 8);
+  VLB_CHECK_LAUNCH("vlb_relu_mask_cast");
+  return VLB_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// AvgPool2d(14) + Flattener over the RoI head output y [K, P, C] (P = 14*14 pixels) written as fp32 into the feature
+// slots of the padded box rows (row k, columns col0 .. col0+C of a [K, ld] fp32 matrix: boxes[..., 4:]) -- the input the
+// precomputed-feature path reads, so everything downstream (obj_prep, obj_downsample) is shared.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void avgpool_rows_fwd_kernel(const bf16_t* __restrict__ y, float* __restrict__ out, long ld, int col0, int P,
+                                                               int C) {
+  const int k = blockIdx.x;
+  const int c8n = C >> 3;
+  const float inv = 1.0f / (float)P;
+  for (int c8 = threadIdx.x; c8 < c8n; c8 += 256) {
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bf16_t* src = y + (long)k * P * C + c8 * 8;
+    for (int p = 0; p < P; ++p) {
+      float f[8];
+      unpack8(*(const uint4*)(src + (long)p * C), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += f[e];
+    }
+    float* o = out + (long)k * ld + col0 + c8 * 8;
+    *(float4*)o = make_float4(s[0] * inv, s[1] * inv, s[2] * inv, s[3] * inv);
+    *(float4*)(o + 4) = make_float4(s[4] * inv, s[5] * inv, s[6] * inv, s[7] * inv);
+  }
+}
+
+extern "C" int vlb_avgpool_rows_fwd(const void* y, float* out, long ld, int col0, int K, int P, int C, hipStream_t stream) {
+  if (K <= 0) return VLB_OK;
+  VLB_CHECK_ARG(y && out && P > 0 && C > 0 && (C % 8) == 0, "vlb_avgpool_rows_fwd: bad argument");
+  VLB_CHECK_ARG((ld % 4) == 0 && (col0 % 4) == 0 && ld >= col0 + C, "vlb_avgpool_rows_fwd: ld=%ld col0=%d must be multiples of 4", ld, col0);
+  hipLaunchKernelGGL(avgpool_rows_fwd_kernel, dim3(K), dim3(256), 0, stream, (const bf16_t*)y, out, ld, col0, P, C);
+  VLB_CHECK_LAUNCH("vlb_avgpool_rows_fwd");
+  return VLB_OK;
+}
+
+// backward of [ReLU ->] AvgPool -> (input dropout of obj_downsample, common/fast_rcnn.py:106):
+//   dz[k,p,c] = (y[k,p,c] > 0) * keep(k, drop_col0 + c) * drop_scale * dfeat[k,c] / P ;  boxes with x1 <= -1.5 (padding) get 0.
+// keep() is the counter hash obj_prep_fwd used for element (row k, column drop_col0 + c) of its [K, drop_row_elems] output.
+__global__ __launch_bounds__(256) void avgpool_rows_bwd_kernel(const bf16_t* __restrict__ dfeat, long lddf, const bf16_t* __restrict__ y,
+                                                               const float* __restrict__ boxes, long ldbox, bf16_t* __restrict__ dz, int K,
+                                                               int P, int C, uint32_t drop_thr, float drop_scale,
+                                                               const uint32_t* __restrict__ seedp, uint32_t tag, uint32_t drop_row_elems,
+                                                               uint32_t drop_col0) {
+  const int c8n = C >> 3;
+  const long total = (long)K * P * c8n;
+  const uint32_t seed = (drop_thr && seedp) ? *seedp : 0u;
+  const float inv = 1.0f / (float)P;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int c8 = (int)(idx % c8n);
+    const long row = idx / c8n;          // k*P + p
+    const int k = (int)(row / P);
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (!boxes || boxes[(long)k * ldbox] > -1.5f) {
+      float d[8], f[8];
+      unpack8(*(const uint4*)(dfeat + (long)k * lddf + c8 * 8), d);
+      unpack8(*(const uint4*)(y + row * C + c8 * 8), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float g = d[e] * inv;
+        if (drop_thr) g = vlb_keep(seed, tag, (uint32_t)k * drop_row_elems + drop_col0 + (uint32_t)(c8 * 8 + e), drop_thr) ? g * drop_scale : 0.f;
+        v[e] = f[e] > 0.f ? g : 0.f;
+      }
+    }
+    *(uint4*)(dz + row * C + c8 * 8) = pack8(v);
+  }
+}
+
+extern "C" int vlb_avgpool_rows_bwd(const void* dfeat, long lddf, const void* y, const float* boxes, long ldbox, void* dz, int K, int P,
+                                    int C, float drop_p, const uint32_t* seed, uint32_t tag, uint32_t drop_row_elems, uint32_t drop_col0,
+                                    hipStream_t stream) {
+  if (K <= 0) return VLB_OK;
+  VLB_CHECK_ARG(dfeat && y && dz && P > 0 && C > 0 && (C % 8) == 0 && (lddf % 8) == 0, "vlb_avgpool_rows_bwd: bad argument");
+  VLB_CHECK_ARG(!(drop_p > 0.f) || seed, "vlb_avgpool_rows_bwd: dropout needs a device seed pointer");
+  const uint32_t thr = vlb_drop_thr(drop_p);
+  long blocks = ((long)K * P * (C / 8) + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(avgpool_rows_bwd_kernel, dim3((int)blocks), dim3(256), 0, stream, (const bf16_t*)dfeat, lddf, (const bf16_t*)y, boxes,
+                     ldbox, (bf16_t*)dz, K, P, C, thr, vlb_drop_scale(thr), seed, tag, drop_row_elems, drop_col0);
+  VLB_CHECK_LAUNCH("vlb_avgpool_rows_bwd");
+  return VLB_OK;
+}
