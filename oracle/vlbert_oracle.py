@@ -227,10 +227,13 @@ def mvrc_head(p, x):
 # a1: the pre-training module
 # --------------------------------------------------------------------------- #
 def pretrain_forward(p, cfg, boxes, im_info, text, relationship_label, mlm_labels, mvrc_ops, mvrc_labels,
-                     train=False):
-    """pretrain/modules/resnet_vlbert_for_pretraining.py:93-216, precomputed-feature
-    configuration (image=None).  Returns (outputs dict, loss) with the reference's
-    shapes (logits re-padded to the original lengths with -10000)."""
+                     train=False, image=None, vision_params=None, image_num_layers=101):
+    """pretrain/modules/resnet_vlbert_for_pretraining.py:93-216.  image=None: precomputed-feature
+    configuration.  image [B,3,H,W] + vision_params (oracle/vision_oracle.py, torchvision-style names): the e2e
+    configuration -- box features come from the ResNet trunk / ROIAlign / layer4 head (common/fast_rcnn.py:144-156)
+    and, as the raw pixels were masked by the dataset, no mask embedding is substituted (:114-127 passes
+    mask_visual_embed=None).  Returns (outputs dict, loss) with the reference's shapes (logits re-padded to
+    the original lengths with -10000)."""
     boxes = boxes.clone()                                   # the reference mutates its input (:115-117)
     box_mask = boxes[:, :, 0] > -1.5
     origin_len = boxes.shape[1]
@@ -238,8 +241,13 @@ def pretrain_forward(p, cfg, boxes, im_info, text, relationship_label, mlm_label
     box_mask, boxes = box_mask[:, :max_len], boxes[:, :max_len]
     mvrc_ops, mvrc_labels = mvrc_ops[:, :max_len], mvrc_labels[:, :max_len]
 
-    feats = boxes[:, :, 4:].clone()
-    feats[mvrc_ops == 1] = p["object_mask_visual_embedding.weight"][0]
+    if image is not None:
+        from . import vision_oracle as VO
+        valid, _ = VO.e2e_features(image, boxes[:, :, :4], vision_params, image_num_layers)
+        feats = valid.new_zeros((*box_mask.shape, valid.shape[1])).masked_scatter(box_mask[:, :, None], valid)
+    else:
+        feats = boxes[:, :, 4:].clone()
+        feats[mvrc_ops == 1] = p["object_mask_visual_embedding.weight"][0]
     boxes = torch.cat((boxes[:, :, :4], feats), -1)
     obj_reps = fast_rcnn_precomputed(p, cfg, boxes, box_mask, im_info, train)
 

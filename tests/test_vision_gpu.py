@@ -1,0 +1,297 @@
+"""-m gpu parity tests of the end-to-end vision path: every kernel of csrc/vision.hip and the
+convolution epilogues of csrc/gemm.hip against plain torch-CPU fp32 statements, then the whole VisionStack (ResNet trunk ->
+ROIAlign -> dilated layer4 head -> avg-pool, forward + hand-scheduled backward) against oracle/vision_oracle.py on the fixture
+the REFERENCE's FastRCNN e2e module produced (tests/golden/vision/vision_small.npz), then one e2e pretraining step of the engine.
+
+Tolerances: bf16 activations (2^-8 per rounding) through up to 19 Bottlenecks: features within 2e-2 of the tensor scale;
+weight gradients by relative Frobenius error per tensor (ReLU sign flips of bf16-vs-fp32 pre-activations near 0 add gradient
+noise that is not a kernel error, cf. tests/test_engine_gpu.py).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import roi_align_oracle as RA
+from oracle import vision_oracle as VO
+from oracle import vlbert_oracle as O
+from tests.gpu_util import bf, dev, drop_scale, drop_thr, keep_mask, pkg, report, to_gpu_bf16
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    return pkg("ops")
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return bf(torch.randn(*shape, generator=g) * scale)
+
+
+def nhwc(x):     # [N,C,H,W] -> rows [N*H*W, C]
+    return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]).contiguous()
+
+
+def rel_fro(a, b):
+    a, b = a.double().cpu().reshape(-1), b.double().cpu().reshape(-1)
+    return float((a - b).norm() / max(float(b.norm()), 1e-12))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(200, 256, 128), (515, 64, 64), (1000, 2048, 512)])
+def test_gemm_conv_epilogues(ops, M, N, K):
+    A, B = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.1)
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(3))
+    res, aux = rnd(M, N, seed=4), rnd(M, N, seed=5)
+    aux[::3] = 0.0                                   # exact zeros are "not > 0"
+    a, b, r, x = to_gpu_bf16(A), to_gpu_bf16(B), to_gpu_bf16(res), to_gpu_bf16(aux)
+    C = torch.zeros((M, N), dtype=torch.bfloat16, device=dev())
+    ops.gemm_nt(a, b, C, bias=bias.to(dev()), res=r, act=ops.ACT_RES_RELU)
+    report("gemm relu(bias+res) %dx%dx%d" % (M, N, K), C, torch.relu(A @ B.t() + bias + res), 1e-3, 1e-2)
+    ops.gemm_nt(a, b, C, res=r, act=ops.ACT_RELU_MASK, aux=x)
+    report("gemm (acc+res)*(aux>0)", C, (A @ B.t() + res) * (aux > 0), 1e-3, 1e-2)
+    ops.gemm_nt(a, b, C, act=ops.ACT_RELU_MASK, aux=x)
+    report("gemm acc*(aux>0)", C, (A @ B.t()) * (aux > 0), 1e-3, 1e-2)
+
+
+@pytest.mark.parametrize("k,stride,pad,dil", [(3, 1, 1, 1), (3, 1, 2, 2), (3, 2, 1, 1), (1, 1, 0, 1)])
+def test_im2col_nhwc(ops, k, stride, pad, dil):
+    N, C, H, W = 2, 16, 9, 13
+    x = rnd(N, C, H, W, seed=6)
+    OH, OW = ops.conv_out_size(H, k, stride, pad, dil), ops.conv_out_size(W, k, stride, pad, dil)
+    col = torch.full((N * OH * OW, k * k * C + 8), 7.0, dtype=torch.bfloat16, device=dev())
+    ops.im2col_nhwc(to_gpu_bf16(nhwc(x)), col[:, :k * k * C], N, H, W, C, k, stride, pad, dil)
+    ref = F.unfold(x, k, dilation=dil, padding=pad, stride=stride)            # [N, C*k*k, L], channel-major
+    ref = ref.view(N, C, k * k, OH * OW).permute(0, 3, 2, 1).reshape(N * OH * OW, k * k * C)
+    report("im2col k%d s%d p%d d%d" % (k, stride, pad, dil), col[:, :k * k * C], ref, 0, 0)
+    assert float((col[:, k * k * C:].float() - 7.0).abs().max()) == 0.0
+
+
+def test_im2col_image_and_stem_conv(ops):
+    N, H, W = 2, 37, 50
+    img = torch.randn(N, 3, H, W, generator=torch.Generator().manual_seed(7)) * 50
+    OH, OW = ops.conv_out_size(H, 7, 2, 3, 1), ops.conv_out_size(W, 7, 2, 3, 1)
+    col = torch.zeros((N * OH * OW, 192), dtype=torch.bfloat16, device=dev())
+    ops.im2col_image(img.to(dev()), col)
+    ref = F.unfold(img, 7, padding=3, stride=2).view(N, 3, 49, OH * OW).permute(0, 3, 2, 1).reshape(N * OH * OW, 147)
+    report("im2col image", col[:, :147], bf(ref), 0, 0)
+    assert float(col[:, 147:].float().abs().max()) == 0.0
+    # stem conv through the prepared weight
+    w = torch.randn(64, 3, 7, 7, generator=torch.Generator().manual_seed(8)) * 0.05
+    bn = [0.5 + torch.rand(64), torch.randn(64) * 0.1, torch.randn(64) * 0.1, 0.5 + torch.rand(64)]
+    wf = torch.zeros((64, 192), dtype=torch.bfloat16, device=dev())
+    scale, shift = torch.zeros(64, device=dev()), torch.zeros(64, device=dev())
+    ops.conv_weight_prepare(w.permute(0, 2, 3, 1).reshape(64, 49, 3).contiguous().to(dev()), [t.to(dev()) for t in bn], wf, None, scale, shift)
+    y = torch.zeros((N * OH * OW, 64), dtype=torch.bfloat16, device=dev())
+    ops.gemm_nt(col, wf, y, bias=shift, act=ops.ACT_RELU)
+    ref = torch.relu(F.batch_norm(F.conv2d(bf(img), w, stride=2, padding=3), bn[2], bn[3], bn[0], bn[1], False, eps=1e-5))
+    report("stem conv+bn+relu", y, nhwc(ref), 1e-2, 1e-2)
+
+
+def test_conv_weight_prepare_and_finalize(ops):
+    O, I, k = 24, 16, 3
+    g = torch.Generator().manual_seed(9)
+    w = torch.randn(O, I, k, k, generator=g)
+    bn = [0.5 + torch.rand(O, generator=g), torch.randn(O, generator=g), torch.randn(O, generator=g), 0.5 + torch.rand(O, generator=g)]
+    w_ohwi = w.permute(0, 2, 3, 1).reshape(O, k * k, I).contiguous()
+    wf = torch.zeros((O, k * k * I), dtype=torch.bfloat16, device=dev())
+    wb = torch.zeros((I, k * k * O), dtype=torch.bfloat16, device=dev())
+    scale, shift = torch.zeros(O, device=dev()), torch.zeros(O, device=dev())
+    ops.conv_weight_prepare(w_ohwi.to(dev()), [t.to(dev()) for t in bn], wf, wb, scale, shift)
+    s = bn[0] / torch.sqrt(bn[3] + 1e-5)
+    report("bn scale", scale, s, 1e-6, 1e-6)
+    report("bn shift", shift, bn[1] - bn[2] * s, 1e-6, 1e-6)
+    folded = w_ohwi * s[:, None, None]
+    report("wf", wf, folded.reshape(O, -1), 0, 4e-3)
+    ref_wb = folded.flip(1).permute(2, 1, 0).reshape(I, k * k * O)             # [i, mirrored tap, o]
+    report("wb", wb, ref_wb, 0, 4e-3)
+    dwf = torch.randn(O, k * k * I + 8, generator=g)
+    gacc = torch.randn(O, k * k * I, generator=g)
+    gg = gacc.clone().to(dev())
+    ops.conv_wgrad_finalize(dwf.to(dev()), scale, gg, accumulate=True)
+    report("wgrad finalize", gg, gacc + dwf[:, :k * k * I] * s[:, None], 1e-6, 1e-6)
+
+
+def test_pool_and_resample(ops):
+    N, C, H, W = 2, 24, 11, 14
+    x = rnd(N, C, H, W, seed=10)
+    xg = to_gpu_bf16(nhwc(x))
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.zeros((N * OH * OW, C), dtype=torch.bfloat16, device=dev())
+    ops.maxpool3x3s2_nhwc(xg, y, N, H, W, C)
+    report("maxpool", y, nhwc(F.max_pool2d(x, 3, 2, 1)), 0, 0)
+    ops.subsample2_nhwc(xg, y, N, H, W, C)
+    report("subsample2", y, nhwc(x[:, :, ::2, ::2]), 0, 0)
+    dx = torch.full((N * H * W, C), 3.0, dtype=torch.bfloat16, device=dev())
+    ops.upsample2_zero_nhwc(y, dx, N, H, W, C)
+    ref = torch.zeros_like(x)
+    ref[:, :, ::2, ::2] = x[:, :, ::2, ::2]
+    report("upsample2_zero", dx, nhwc(ref), 0, 0)
+
+
+@pytest.mark.parametrize("sr", [1, 2])
+def test_roi_align_nhwc(ops, sr):
+    N, C, H, W, R = 2, 16, 9, 12, 3
+    feat = rnd(N, C, H, W, seed=11)
+    boxes = torch.tensor([[[10.0, 20.0, 150.0, 120.0, 9.0], [0.0, 0.0, 191.0, 143.0, 9.0], [60.5, 30.25, 70.0, 35.0, 9.0]],
+                          [[100.0, 8.0, 180.0, 140.0, 9.0], [-20.0, -10.0, 40.0, 50.0, 9.0], [-2.0, -2.0, -2.0, -2.0, 9.0]]])
+    mask = boxes[:, :, 0] > -1.5
+    rois = torch.cat((mask.nonzero()[:, :1].float(), boxes[mask][:, :4]), 1).numpy()
+    ph = 4
+    out = torch.zeros((N * R * ph * ph, C), dtype=torch.bfloat16, device=dev())
+    bx = boxes.view(N * R, 5).contiguous().to(dev())
+    ops.roi_align_nhwc_fwd(to_gpu_bf16(nhwc(feat)), bx, R, out, N, H, W, C, pooled=ph, spatial_scale=1.0 / 16, sampling_ratio=sr)
+    ref = torch.from_numpy(RA.roi_align_forward(feat.numpy(), rois, 1.0 / 16, ph, ph, sr).astype(np.float32))   # [K,C,ph,pw]
+    got = out.float().cpu().view(N * R, ph, ph, C).permute(0, 3, 1, 2)
+    report("roi_align nhwc fwd sr%d" % sr, got[mask.view(-1)], ref, 1e-3, 1e-2)
+    assert float(got[~mask.view(-1)].abs().max()) == 0.0
+    dout = rnd(N * R, C, ph, ph, seed=12)
+    dfeat = torch.full((N * H * W, C), 5.0, device=dev())
+    ops.roi_align_nhwc_bwd(to_gpu_bf16(dout.permute(0, 2, 3, 1).reshape(-1, C)), bx, R, dfeat, N, H, W, C, pooled=ph,
+                           spatial_scale=1.0 / 16, sampling_ratio=sr)
+    refb = torch.from_numpy(RA.roi_align_backward(dout[mask.view(-1)].numpy(), rois, 1.0 / 16, ph, ph, N, C, H, W, sr).astype(np.float32))
+    report("roi_align nhwc bwd sr%d" % sr, dfeat, nhwc(refb), 1e-4, 1e-4)
+
+
+def test_avgpool_rows_and_relu_mask(ops):
+    K, P, C, ld = 5, 9, 32, 4 + 32
+    y = torch.relu(rnd(K * P, C, seed=13))
+    boxes = torch.full((K, ld), -1.0)
+    boxes[:, 0] = torch.tensor([1.0, 2.0, -2.0, 0.0, 5.0])
+    bx = boxes.to(dev())
+    ops.avgpool_rows_fwd(to_gpu_bf16(y), bx, 4, K, P, C)
+    report("avgpool fwd", bx[:, 4:], y.view(K, P, C).mean(1), 1e-6, 1e-5)
+    assert torch.equal(bx[:, :4].cpu(), boxes[:, :4])
+    d = rnd(K, C, seed=14)
+    seed, tag, p = 4321, 77, 0.25
+    seed_t = torch.tensor([seed], dtype=torch.int32, device=dev())
+    dz = torch.zeros((K * P, C), dtype=torch.bfloat16, device=dev())
+    ops.avgpool_rows_bwd(to_gpu_bf16(d), to_gpu_bf16(y), bx, dz, K, P, C, drop_p=p, seed=seed_t, tag=tag, drop_row_elems=2 * C, drop_col0=C)
+    idx = (np.arange(K)[:, None] * 2 * C + C + np.arange(C)[None, :])
+    keep = torch.from_numpy(keep_mask(seed, tag, idx, drop_thr(p)))
+    g = d * keep * drop_scale(drop_thr(p)) / P
+    g[boxes[:, 0] <= -1.5] = 0
+    ref = g[:, None, :].expand(K, P, C).reshape(K * P, C) * (y > 0)
+    report("avgpool bwd (+dropout mask, padded boxes)", dz, ref, 1e-6, 1e-2)
+    g32 = torch.randn(K * P, C)
+    out = torch.zeros((K * P, C), dtype=torch.bfloat16, device=dev())
+    ops.relu_mask_cast(g32.to(dev()), to_gpu_bf16(y), out)
+    report("relu_mask_cast", out, g32 * (y > 0), 0, 4e-3)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def _vision_fixture():
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "vision", "vision_small.npz"), allow_pickle=False)
+    nl = int(z["num_layers"])
+    P = VO.init_vision_params(int(z["seed"]), nl)
+    return z, nl, P
+
+
+def _prefixed(P):
+    return {"image_feature_extractor." + k: v for k, v in VO.split_state_dict(P).items()}
+
+
+def test_vision_stack_matches_reference_golden():
+    """VisionStack forward + backward against the fixture of the reference's FastRCNN e2e module and the oracle's gradients."""
+    V = pkg("vision")
+    z, nl, P = _vision_fixture()
+    img, boxes4 = torch.from_numpy(z["img"]), torch.from_numpy(z["boxes"])
+    N, R = boxes4.shape[:2]
+    vs = V.VisionStack(N, img.shape[2], img.shape[3], R, device=dev(), num_layers=nl)
+    vs.load_state_dict({k: v.to(dev()) for k, v in _prefixed(P).items()})
+    boxes = torch.zeros((N, R, 4 + 2048), device=dev())
+    boxes[:, :, :4] = boxes4.to(dev())
+    vs.forward(img.to(dev()), boxes)
+    torch.cuda.synchronize()
+    raw = torch.from_numpy(z["obj_reps_raw"])
+    report("e2e post_roialign vs reference", boxes[:, :, 4:], raw, 2e-2, 2e-2)
+    mask = boxes4[:, :, 0] > -1.5
+    assert float(boxes[:, :, 4:].cpu()[~mask].abs().max()) == 0.0
+    body4 = vs.body4.float().cpu().view(N, vs.H3, vs.W3, -1).permute(0, 3, 1, 2).reshape(-1)[::97][:512]
+    report("body4 samples vs reference", body4, torch.from_numpy(z["body4_sample"]), 2e-2, 2e-2)
+    # backward of <post_roialign, Wr>
+    Wr = torch.from_numpy(z["Wr"])
+    vs.zero_grad()
+    vs.backward(to_gpu_bf16(Wr.view(N * R, -1)), boxes)
+    torch.cuda.synchronize()
+    got = vs.grads()
+    want_norm = dict(zip([str(k) for k in z["grad_names"]], z["grad_norms"]))
+    frozen = VO.frozen_names(P)
+    Po = {k: v.clone().requires_grad_(k not in frozen) for k, v in P.items()}
+    feats, _ = VO.e2e_features(img, boxes4, Po, nl)
+    (feats * Wr[mask]).sum().backward()
+    names = dict(zip(VO.split_state_dict(P).keys(), P.keys()))
+    worst = (0.0, "")
+    errs = []
+    for name, g in got.items():
+        short = name[len("image_feature_extractor."):]
+        ref = Po[names[short]].grad
+        e = rel_fro(g, ref)
+        errs.append(e)
+        worst = max(worst, (e, short))
+        assert abs(float(ref.double().norm()) - want_norm[short]) <= 1e-3 * want_norm[short]      # oracle == reference (pinned on CPU too)
+    print("vision stack: %d weight gradients, median rel-fro %.3e, worst %.3e (%s)" % (len(errs), float(np.median(errs)), worst[0], worst[1]))
+    assert set(n[len("image_feature_extractor."):] for n in got) == set(want_norm)
+    assert np.median(errs) < 3e-2 and worst[0] < 0.12, worst
+
+
+def test_engine_e2e_step_vs_oracle():
+    """One e2e pretraining step (image -> CNN -> VL-BERT -> losses -> gradients) of the engine against the composed oracle."""
+    E, syn = pkg("engine"), pkg("synthetic")
+    z, nl, P = _vision_fixture()
+    img, boxes4 = torch.from_numpy(z["img"]), torch.from_numpy(z["boxes"])
+    B, R = boxes4.shape[:2]
+    T = 12
+    cfg = O.VLBertConfig(num_hidden_layers=1)
+    params = O.init_params(cfg, seed=21)
+    batch = list(syn.make_batch(B, T, R, seed=22, ragged=False))
+    batch[0] = torch.cat((boxes4, torch.zeros(B, R, 2048)), -1)          # boxes of the fixture (one padded), features unused
+    batch[1] = torch.from_numpy(z["im_info"])
+    pad = boxes4[:, :, 0] <= -1.5
+    batch[5][pad] = 0                                                     # mvrc_ops / labels of the padded box
+    batch[6][pad] = 0
+    mc = E.ModelConfig(num_hidden_layers=1, e2e=True, image_num_layers=nl)
+    eng = E.PretrainEngine(mc, B, T, R, device="cuda:0", train=False, keep_logits=True, image_size=tuple(img.shape[2:]))
+    sd = {k: v.to(dev()) for k, v in params.items()}
+    sd.update({k: v.to(dev()) for k, v in _prefixed(P).items()})
+    eng.load_state_dict(sd)
+    eng.set_batch(*[t.to(dev()) for t in batch], image=img.to(dev()))
+    eng.zero_grad()
+    eng.forward(False)
+    eng.backward(False)
+    torch.cuda.synchronize()
+    frozen = VO.frozen_names(P)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    Po = {k: v.clone().requires_grad_(k not in frozen) for k, v in P.items()}
+    out, loss = O.pretrain_forward(leaves, cfg, *batch, train=False, image=img, vision_params=Po, image_num_layers=nl)
+    loss.backward()
+    lv = eng.loss_values()
+    print("e2e losses: hip mlm %.5f mvrc %.5f | oracle mlm %.5f mvrc %.5f" % (lv["mlm_loss"], lv["mvrc_loss"], float(out["mlm_loss"]),
+                                                                              float(out["mvrc_loss"])))
+    assert abs(lv["mlm_loss"] - float(out["mlm_loss"])) < 2e-2 * max(1.0, abs(float(out["mlm_loss"])))
+    assert abs(lv["mvrc_loss"] - float(out["mvrc_loss"])) < 2e-2 * max(1.0, abs(float(out["mvrc_loss"])))
+    names = dict(zip(VO.split_state_dict(P).keys(), P.keys()))
+    errs = []
+    for name, g in eng.vision.grads().items():
+        ref = Po[names[name[len("image_feature_extractor."):]]].grad
+        errs.append((rel_fro(g, ref), name))
+    print("e2e engine: conv weight gradients median rel-fro %.3e worst %.3e (%s)" % (float(np.median([e for e, _ in errs])), *max(errs)))
+    assert np.median([e for e, _ in errs]) < 5e-2 and max(errs)[0] < 0.2
+    assert leaves["object_mask_visual_embedding.weight"].grad is None or float(leaves["object_mask_visual_embedding.weight"].grad.abs().sum()) == 0.0
+    assert float(eng.g32["object_mask_visual_embedding.weight"].abs().sum()) == 0.0
+    for k in ("image_feature_extractor.obj_downsample.1.weight", "vlbert.encoder.layer.0.output.dense.weight"):
+        e = rel_fro(eng.g32[k], leaves[k].grad)
+        print("  %s rel-fro %.3e" % (k, e))
+        assert e < 5e-2, k
+    # one optimizer step moves the trainable convolutions and leaves the frozen stages / BatchNorm alone
+    before = eng.vision.state_dict()
+    eng.optimizer_step()
+    torch.cuda.synchronize()
+    after = eng.vision.state_dict()
+    moved = [k for k in before if not torch.equal(before[k], after[k])]
+    trainable = set(eng.vision.grads())
+    assert set(moved) == trainable, (set(moved) ^ trainable)

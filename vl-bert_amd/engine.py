@@ -51,6 +51,9 @@ class ModelConfig:
     multitask: bool = False      # ResNetVLBERTForPretrainingMultitask: text-only auxiliary samples (+1 parameter)
     with_pooler: bool = False    # BertPooler on the first token (modeling.py:424-436)
     with_rel_loss: bool = False  # relationship head on the pooled output + its CE loss (needs with_pooler)
+    e2e: bool = False            # IMAGE_FEAT_PRECOMPUTED false: ResNet trunk -> ROIAlign -> layer4 head on the device (vision.py)
+    image_num_layers: int = 101  # NETWORK.IMAGE_NUM_LAYERS (50 / 101 / 152)
+    image_frozen_stages: tuple = (1, 2)   # NETWORK.IMAGE_FROZEN_BACKBONE_STAGES (BatchNorm is always frozen: IMAGE_FROZEN_BN)
 
     def validate(self):
         H, nh = self.hidden_size, self.num_attention_heads
@@ -114,6 +117,9 @@ def param_layout(cfg):
     s["vlbert.mvrc_head.transform.dense.bias"] = (H,)
     s["vlbert.mvrc_head.region_cls_pred.weight"] = (C, H)
     s["vlbert.mvrc_head.region_cls_pred.bias"] = (C,)
+    if cfg.e2e:      # trainable convolution weights of the vision path, LAST (their gradients complete last; parallel.GradBuckets)
+        from .vision import vision_param_layout
+        s.update(vision_param_layout(cfg.image_num_layers, cfg.image_frozen_stages))
     return s
 
 
@@ -155,8 +161,11 @@ class FlatParams:
 class PretrainEngine:
     def __init__(self, cfg, B, T, R, device="cuda:0", train=True, lr=1e-4, weight_decay=1e-4, max_grad_norm=10.0,
                  betas=(0.9, 0.999), eps=1e-6, seed=1234, grad_accum=1, process_group=None, keep_logits=False, flat=None,
-                 B_aux=0, core=False, core_heads=True, core_sequence=False, lr_schedule=None, warmup_steps=0, t_total=0):
+                 B_aux=0, core=False, core_heads=True, core_sequence=False, lr_schedule=None, warmup_steps=0, t_total=0,
+                 image_size=None):
         cfg.validate()
+        if cfg.e2e and (core or B_aux or image_size is None):
+            raise ValueError("e2e needs image_size=(H, W) and the plain pretraining wrapper (no core / multitask mode)")
         # lr_schedule: None (host sets lr) | "constant" | "warmup_constant" | "triangle" (WarmupLinearSchedule,
         # pretrain/function/train.py:316-320) -- evaluated on the device from the step counter each optimizer step.
         kinds = {None: None, "constant": ops.LR_CONSTANT, "warmup_constant": ops.LR_WARMUP_CONSTANT,
@@ -199,6 +208,12 @@ class PretrainEngine:
         self.w16 = P.named(P.w16)
         self.w32 = P.named(P.master)
         self.g32 = P.named(P.grad)
+        self.vision = None
+        if cfg.e2e:
+            from .vision import VisionStack
+            self.vision = VisionStack(B, image_size[0], image_size[1], R, device=d, num_layers=cfg.image_num_layers,
+                                      frozen_stages=cfg.image_frozen_stages, storage=lambda n, shape: (self.w32[n], self.g32[n]))
+            self.in_image = torch.zeros((B, 3, image_size[0], image_size[1]), dtype=F32, device=d)
 
         def zb(*s):
             return torch.zeros(s, dtype=BF16, device=d)
@@ -321,28 +336,45 @@ class PretrainEngine:
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1:
             from .parallel import GradBuckets
-            self.buckets = GradBuckets(self.P.grad, self.P.offsets, self.P.numel, L, group=process_group)
+            vstart = min((o for n, o in self.P.offsets.items() if n.startswith("image_feature_extractor.") and
+                          not n.startswith("image_feature_extractor.obj_downsample")), default=None)
+            self.buckets = GradBuckets(self.P.grad, self.P.offsets, self.P.numel, L, group=process_group, vision_start=vstart)
 
     # ------------------------------------------------------------------------------------------
     # parameters
     # ------------------------------------------------------------------------------------------
     def load_state_dict(self, sd):
         """sd: {reference state_dict name: tensor}.  The tied decoder key is accepted and ignored."""
+        vis = self._vision_names()
         for name in self.P.shapes:
+            if name in vis:
+                continue
             if name not in sd:
                 raise KeyError("missing parameter %s" % name)
             self.w32[name].copy_(sd[name].to(F32))
+        if self.vision is not None:     # conv weights ([O,I,KH,KW] in the reference) + BatchNorm tensors + frozen stages
+            self.vision.load_state_dict(sd)
         self._weights_dirty = True
 
+    def _vision_names(self):
+        if self.vision is None:
+            return ()
+        return {"image_feature_extractor." + k + ".weight" for k, c in self.vision.convs.items() if c.trainable}
+
     def state_dict(self):
-        sd = OrderedDict((k, v.detach().clone()) for k, v in self.w32.items())
+        vis = self._vision_names()
+        sd = OrderedDict((k, v.detach().clone()) for k, v in self.w32.items() if k not in vis)
         sd[TIED_DECODER_KEY] = sd["vlbert.word_embeddings.weight"]
+        if self.vision is not None:
+            sd.update(self.vision.state_dict())
         return sd
 
     def sync_weights(self):
         """fp32 master -> bf16 working copy + transposed copies (after load / external modification)."""
         ops.cast_f32_bf16(self.P.master, self.P.w16)
         self._refresh_transposes()
+        if self.vision is not None:
+            self.vision.refresh_weights()
         self._weights_dirty = False
 
     def _refresh_transposes(self):
@@ -369,13 +401,19 @@ class PretrainEngine:
     # batch
     # ------------------------------------------------------------------------------------------
     def set_batch(self, boxes, im_info, text, relationship_label, mlm_labels, mvrc_ops, mvrc_labels, aux_text=None,
-                  aux_mlm_labels=None):
+                  aux_mlm_labels=None, image=None):
         """Copies a collated batch (pretrain/data/collate_batch.py layout) into the static device buffers
         and derives the masks exactly as resnet_vlbert_for_pretraining.py:106,134 does
         (box_mask = boxes[:,:,0] > -1.5 ; text_mask = text > 0).  `relationship_label` is only read
         with ModelConfig(with_rel_loss=True) (WITH_REL_LOSS is false in the north-star configuration)."""
         B = self.B
-        self.in_boxes.copy_(boxes, non_blocking=True)
+        if self.vision is not None:     # e2e: `image` [B,3,H,W] fp32 (mean-subtracted, collate_batch.py), boxes [B,R,4]; features come from the CNN
+            if image is None:
+                raise ValueError("engine built with e2e=True needs image=")
+            self.in_image.copy_(image, non_blocking=True)
+            self.in_boxes[:, :, :4].copy_(boxes[:, :, :4], non_blocking=True)
+        else:
+            self.in_boxes.copy_(boxes, non_blocking=True)
         self.in_im_info.copy_(im_info, non_blocking=True)
         if self.Ba or text.shape[1] != self.T:
             self.in_text.zero_()
@@ -441,9 +479,14 @@ class PretrainEngine:
         cfg, B, T, R, S, Bt, Ba = self.cfg, self.B, self.T, self.R, self.S, self.Bt, self.Ba
         H = cfg.hidden_size
         w16, w32, seed = self.w16, self.w32, self.seed
-        # --- FastRCNN precomputed branch: (coord || feature) -> Linear(4096->H) -> ReLU ------------------
-        ops.obj_prep_fwd(self.in_boxes, self.in_im_info, self.in_mvrc_ops.view(-1), w32["object_mask_visual_embedding.weight"],
-                         self.a_ds, drop_p=p_ds, seed=seed, tag=TAG_DOWNSAMPLE)
+        # --- e2e: ResNet trunk -> ROIAlign -> layer4 head -> avg-pool, written into the feature slots of in_boxes; the raw
+        #     pixels are masked by the dataset, so no mask embedding is substituted (mask_visual_embed=None, :120-127) ----
+        e2e = self.vision is not None
+        if e2e:
+            self.vision.forward(self.in_image, self.in_boxes)
+        # --- FastRCNN: (coord || feature) -> Dropout -> Linear(4096->H) -> ReLU (common/fast_rcnn.py:165-175) -------
+        ops.obj_prep_fwd(self.in_boxes, self.in_im_info, None if e2e else self.in_mvrc_ops.view(-1),
+                         w32["object_mask_visual_embedding.weight"], self.a_ds, drop_p=p_ds, seed=seed, tag=TAG_DOWNSAMPLE)
         ops.gemm_nt(self.a_ds, w16["image_feature_extractor.obj_downsample.1.weight"], self.obj_reps,
                     bias=w32["image_feature_extractor.obj_downsample.1.bias"], act=ops.ACT_RELU)
         # --- visual LayerNorms + fused embedding ---------------------------------------------------------
@@ -666,6 +709,7 @@ class PretrainEngine:
         self._fresh_grads = False       # a further backward before the next zero_grad() accumulates
         if on_layer_done:
             on_layer_done("embed")
+            on_layer_done("vision")
 
     def _front_core_bwd(self, dx, p_h):
         cfg, T, R, S, Bt = self.cfg, self.T, self.R, self.S, self.Bt
@@ -721,6 +765,10 @@ class PretrainEngine:
         self._wgrad(self.d_yds, self.a_ds, g32[pd + "weight"], g32[pd + "bias"], self.tG_br, self.tA_br, BRp)
         # gradient of the mask embedding: feature half of dA = dY W, masked regions only
         ops.gemm_nt(self.d_yds, wT[pd + "weight"][VIS_DIM:], self.d_afeat)
+        if self.vision is not None:      # the features are activations of the CNN: RoI head, ROIAlign and trunk backward
+            self._join_side()
+            self.vision.backward(self.d_afeat, self.in_boxes, drop_p=p_ds, seed=seed, tag=TAG_DOWNSAMPLE)
+            return
         ops.masked_colsum(self.d_afeat, self.in_mvrc_ops.view(-1), g32["object_mask_visual_embedding.weight"].view(-1),
                           drop_p=p_ds, seed=seed, tag=TAG_DOWNSAMPLE, row_elems=2 * VIS_DIM, col_off=VIS_DIM)
 
@@ -860,6 +908,8 @@ class PretrainEngine:
         ops.sumsq(self.P.grad, self.adam[7:8])
         ops.adamw_step(self.P.master, self.P.grad, self.P.m, self.P.v, self.P.w16, self.adam, grad_scale=scale)
         self._refresh_transposes()
+        if self.vision is not None:
+            self.vision.refresh_weights(trainable_only=True)
         ops.rng_advance(self.seed)
 
     def train_step(self, lr=None):

@@ -319,3 +319,86 @@ def roi_align_bwd(grad_out, rois, grad_in, spatial_scale, sampling_ratio):
     _lib.call("vlb_roi_align_bwd", _p(grad_out, torch.float32), _p(rois, torch.float32), _p(grad_in, torch.float32), K, Bn, C, Hh,
               Ww, ph, pw, float(spatial_scale), int(sampling_ratio), _stream())
     return grad_in
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# end-to-end vision path (NHWC bf16): see csrc/vision.hip
+# ---------------------------------------------------------------------------------------------------------------
+ACT_RES_RELU, ACT_RELU_MASK = 7, 8     # relu(acc + bias + res) ; (acc [+ res]) where aux > 0
+
+
+def conv_out_size(n, k, stride, pad, dil):
+    return (n + 2 * pad - dil * (k - 1) - 1) // stride + 1
+
+
+def conv_weight_prepare(w, bn, wf, wb=None, scale=None, shift=None, eps=1e-5):
+    """w fp32 [O, taps, I] (+ bn = (gamma, beta, mean, var) or None) -> wf bf16 [O, kf], wb bf16 [I, taps*O], scale/shift [O]."""
+    O, taps, I = w.shape
+    g, b, m, v = bn if bn is not None else (None, None, None, None)
+    _lib.call("vlb_conv_weight_prepare", _p(w, torch.float32), _p(g, torch.float32), _p(b, torch.float32), _p(m, torch.float32),
+              _p(v, torch.float32), float(eps), _p(wf, BF16), _p(wb, BF16), _p(scale, torch.float32), _p(shift, torch.float32),
+              O, I, taps, wf.shape[1], _stream())
+
+
+def conv_wgrad_finalize(dwf, scale, g, accumulate=True):
+    """g fp32 [O, kreal] (+)= scale[o] * dwf[O, kf][:, :kreal]"""
+    O, kreal = g.shape
+    _lib.call("vlb_conv_wgrad_finalize", _p(dwf, torch.float32), _p(scale, torch.float32), _p(g, torch.float32), O, kreal,
+              dwf.shape[1], int(bool(accumulate)), _stream())
+
+
+def im2col_nhwc(x, col, N, H, W, C, k, stride, pad, dil):
+    _lib.call("vlb_im2col_nhwc_bf16", _p(x, BF16), _p(col, BF16), _ld(col), N, H, W, C, k, k, stride, pad, dil, _stream())
+    return col
+
+
+def im2col_image(img, col, k=7, stride=2, pad=3):
+    N, Cin, H, W = img.shape
+    _lib.call("vlb_im2col_image_f32", _p(img, torch.float32), _p(col, BF16), col.shape[1], N, Cin, H, W, k, k, stride, pad, _stream())
+    return col
+
+
+def maxpool3x3s2_nhwc(x, y, N, H, W, C):
+    _lib.call("vlb_maxpool3x3s2_nhwc", _p(x, BF16), _p(y, BF16), N, H, W, C, _stream())
+    return y
+
+
+def subsample2_nhwc(x, y, N, H, W, C):
+    _lib.call("vlb_subsample2_nhwc", _p(x, BF16), _p(y, BF16), N, H, W, C, _stream())
+    return y
+
+
+def upsample2_zero_nhwc(dy, dx, N, H, W, C):
+    _lib.call("vlb_upsample2_zero_nhwc", _p(dy, BF16), _p(dx, BF16), N, H, W, C, _stream())
+    return dx
+
+
+def roi_align_nhwc_fwd(feat, boxes, boxes_per_image, out, N, H, W, C, pooled=14, spatial_scale=1.0 / 16, sampling_ratio=1):
+    """feat bf16 [N*H*W, C]; boxes fp32 [K, ld] (x1,y1,x2,y2 first; x1 <= -1.5 = padding); out bf16 [K*pooled*pooled, C]."""
+    K = boxes.shape[0]
+    _lib.call("vlb_roi_align_nhwc_fwd", _p(feat, BF16), _p(boxes, torch.float32), _ld(boxes), boxes_per_image, _p(out, BF16), K, C,
+              H, W, pooled, pooled, float(spatial_scale), sampling_ratio, _stream())
+    return out
+
+
+def roi_align_nhwc_bwd(dout, boxes, boxes_per_image, dfeat, N, H, W, C, pooled=14, spatial_scale=1.0 / 16, sampling_ratio=1):
+    K = boxes.shape[0]
+    _lib.call("vlb_roi_align_nhwc_bwd", _p(dout, BF16), _p(boxes, torch.float32), _ld(boxes), boxes_per_image,
+              _p(dfeat, torch.float32), K, N, C, H, W, pooled, pooled, float(spatial_scale), sampling_ratio, _stream())
+    return dfeat
+
+
+def relu_mask_cast(g, y, dz):
+    _lib.call("vlb_relu_mask_cast", _p(g, torch.float32), _p(y, BF16), _p(dz, BF16), g.numel(), _stream())
+    return dz
+
+
+def avgpool_rows_fwd(y, out, col0, K, P, C):
+    """y bf16 [K*P, C] -> out fp32 [K, ld][:, col0:col0+C] = mean over the P pixels"""
+    _lib.call("vlb_avgpool_rows_fwd", _p(y, BF16), _p(out, torch.float32), _ld(out), col0, K, P, C, _stream())
+
+
+def avgpool_rows_bwd(dfeat, y, boxes, dz, K, P, C, drop_p=0.0, seed=None, tag=0, drop_row_elems=0, drop_col0=0):
+    _lib.call("vlb_avgpool_rows_bwd", _p(dfeat, BF16), _ld(dfeat), _p(y, BF16), _p(boxes, torch.float32), _ld(boxes) if boxes is not None else 0,
+              _p(dz, BF16), K, P, C, float(drop_p), _p(seed), int(tag), int(drop_row_elems), int(drop_col0), _stream())
+    return dz

@@ -21,8 +21,10 @@ import torch.distributed as dist
 
 
 class GradBuckets:
-    def __init__(self, flat_grad, offsets, numel, num_layers, group=None, bucket_bytes=64 << 20, wire_dtype=None):
-        """flat_grad: the flat fp32 gradient tensor; offsets: {param name: start offset} in layout order."""
+    def __init__(self, flat_grad, offsets, numel, num_layers, group=None, bucket_bytes=64 << 20, wire_dtype=None, vision_start=None):
+        """flat_grad: the flat fp32 gradient tensor; offsets: {param name: start offset} in layout order.
+        vision_start: offset of the e2e convolution weights appended after the heads (their gradients are produced LAST, after the
+        embedding side, by vision.VisionStack.backward) -- they form their own bucket, launched on on_done("vision")."""
         self.flat = flat_grad
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -31,7 +33,10 @@ class GradBuckets:
         layer_start = [offsets["vlbert.encoder.layer.%d.attention.self.query.weight" % l] for l in range(num_layers)]
         head_start = offsets["vlbert.mlm_head.predictions.transform.dense.weight"]
         bounds = layer_start + [head_start]
-        self.ranges = {"heads": (head_start, numel), "embed": (0, layer_start[0] if num_layers else head_start)}
+        tail = numel if vision_start is None else vision_start
+        self.ranges = {"heads": (head_start, tail), "embed": (0, layer_start[0] if num_layers else head_start)}
+        if vision_start is not None:
+            self.ranges["vision"] = (vision_start, numel)
         # group consecutive layers (in backward order) into buckets of ~bucket_bytes
         self.layer_bucket = {}
         cur, cur_bytes = [], 0
@@ -48,6 +53,8 @@ class GradBuckets:
     def coverage(self):
         """All ranges, for tests: they must tile [0, numel) exactly."""
         r = [self.ranges["embed"]] + sorted(self.layer_bucket.values()) + [self.ranges["heads"]]
+        if "vision" in self.ranges:
+            r.append(self.ranges["vision"])
         return r
 
     def _launch(self, lo, hi):
@@ -70,6 +77,9 @@ class GradBuckets:
             self._launch(*self.ranges["heads"])
         elif what == "embed":
             self._launch(*self.ranges["embed"])
+        elif what == "vision":
+            if "vision" in self.ranges:
+                self._launch(*self.ranges["vision"])
         elif what in self.layer_bucket:
             self._launch(*self.layer_bucket[what])
 
