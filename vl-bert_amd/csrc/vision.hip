@@ -431,10 +431,11 @@ extern "C" int vlb_relu_mask_cast(const float* g, const void* y, void* dz, long 
 // precomputed-feature path reads, so everything downstream (obj_prep, obj_downsample) is shared.
 // ------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void avgpool_rows_fwd_kernel(const bf16_t* __restrict__ y, float* __restrict__ out, long ld, int col0, int P,
-                                                               int C) {
+                                                               int C, int pad_col) {
   const int k = blockIdx.x;
   const int c8n = C >> 3;
-  const float inv = 1.0f / (float)P;
+  // padded box (x1 <= -1.5 in column pad_col of the same row): zero features, like the reference's zero-padded obj_reps_raw
+  const float inv = (pad_col >= 0 && !(out[(long)k * ld + pad_col] > -1.5f)) ? 0.f : 1.0f / (float)P;
   for (int c8 = threadIdx.x; c8 < c8n; c8 += 256) {
     float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const bf16_t* src = y + (long)k * P * C + c8 * 8;
@@ -450,11 +451,12 @@ __global__ __launch_bounds__(256) void avgpool_rows_fwd_kernel(const bf16_t* __r
   }
 }
 
-extern "C" int vlb_avgpool_rows_fwd(const void* y, float* out, long ld, int col0, int K, int P, int C, hipStream_t stream) {
+extern "C" int vlb_avgpool_rows_fwd(const void* y, float* out, long ld, int col0, int pad_col, int K, int P, int C, hipStream_t stream) {
   if (K <= 0) return VLB_OK;
   VLB_CHECK_ARG(y && out && P > 0 && C > 0 && (C % 8) == 0, "vlb_avgpool_rows_fwd: bad argument");
   VLB_CHECK_ARG((ld % 4) == 0 && (col0 % 4) == 0 && ld >= col0 + C, "vlb_avgpool_rows_fwd: ld=%ld col0=%d must be multiples of 4", ld, col0);
-  hipLaunchKernelGGL(avgpool_rows_fwd_kernel, dim3(K), dim3(256), 0, stream, (const bf16_t*)y, out, ld, col0, P, C);
+  VLB_CHECK_ARG(pad_col < col0, "vlb_avgpool_rows_fwd: pad_col=%d must lie in front of the feature columns", pad_col);
+  hipLaunchKernelGGL(avgpool_rows_fwd_kernel, dim3(K), dim3(256), 0, stream, (const bf16_t*)y, out, ld, col0, P, C, pad_col);
   VLB_CHECK_LAUNCH("vlb_avgpool_rows_fwd");
   return VLB_OK;
 }

@@ -279,7 +279,7 @@ class VisionStack:
                 self.body4 = x
                 x = ops.roi_align_nhwc_fwd(x, box_rows, self.R, self.roi, N, self.H3, self.W3, self.C3, self.pooled, self.scale, self.sr)
             x = self._block_fwd(b, x)
-        ops.avgpool_rows_fwd(x, box_rows, 4, K, self.P_roi, self.Cout)
+        ops.avgpool_rows_fwd(x, box_rows, 4, K, self.P_roi, self.Cout, pad_col=0)
         return x
 
     # ------------------------------------------------------------------------------------------------------------------
