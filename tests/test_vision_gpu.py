@@ -133,11 +133,14 @@ def test_pool_and_resample(ops):
     report("upsample2_zero", dx, nhwc(ref), 0, 0)
 
 
-@pytest.mark.parametrize("sr", [1, 2])
-def test_roi_align_nhwc(ops, sr):
-    N, C, H, W, R = 2, 16, 9, 12, 3
+@pytest.mark.parametrize("sr,C,H,W", [(1, 16, 9, 12), (2, 16, 9, 12), (1, 64, 9, 12), (2, 64, 9, 12), (1, 32, 24, 30), (0, 32, 24, 30)])
+def test_roi_align_nhwc(ops, sr, C, H, W):
+    """C % 32 == 0 takes the LDS-window backward (whole-map boxes on the 24x30 map exceed the LDS budget -> direct atomics);
+    other widths the wave-per-bin kernel.  sr = 0: adaptive sampling grid."""
+    N, R = 2, 3
     feat = rnd(N, C, H, W, seed=11)
-    boxes = torch.tensor([[[10.0, 20.0, 150.0, 120.0, 9.0], [0.0, 0.0, 191.0, 143.0, 9.0], [60.5, 30.25, 70.0, 35.0, 9.0]],
+    X, Y = 16.0 * W - 1, 16.0 * H - 1
+    boxes = torch.tensor([[[10.0, 20.0, 150.0, 120.0, 9.0], [0.0, 0.0, X, Y, 9.0], [60.5, 30.25, 70.0, 35.0, 9.0]],
                           [[100.0, 8.0, 180.0, 140.0, 9.0], [-20.0, -10.0, 40.0, 50.0, 9.0], [-2.0, -2.0, -2.0, -2.0, 9.0]]])
     mask = boxes[:, :, 0] > -1.5
     rois = torch.cat((mask.nonzero()[:, :1].float(), boxes[mask][:, :4]), 1).numpy()
@@ -147,14 +150,14 @@ def test_roi_align_nhwc(ops, sr):
     ops.roi_align_nhwc_fwd(to_gpu_bf16(nhwc(feat)), bx, R, out, N, H, W, C, pooled=ph, spatial_scale=1.0 / 16, sampling_ratio=sr)
     ref = torch.from_numpy(RA.roi_align_forward(feat.numpy(), rois, 1.0 / 16, ph, ph, sr).astype(np.float32))   # [K,C,ph,pw]
     got = out.float().cpu().view(N * R, ph, ph, C).permute(0, 3, 1, 2)
-    report("roi_align nhwc fwd sr%d" % sr, got[mask.view(-1)], ref, 1e-3, 1e-2)
+    report("roi_align nhwc fwd sr%d C%d %dx%d" % (sr, C, H, W), got[mask.view(-1)], ref, 1e-3, 1e-2)
     assert float(got[~mask.view(-1)].abs().max()) == 0.0
     dout = rnd(N * R, C, ph, ph, seed=12)
     dfeat = torch.full((N * H * W, C), 5.0, device=dev())
     ops.roi_align_nhwc_bwd(to_gpu_bf16(dout.permute(0, 2, 3, 1).reshape(-1, C)), bx, R, dfeat, N, H, W, C, pooled=ph,
                            spatial_scale=1.0 / 16, sampling_ratio=sr)
     refb = torch.from_numpy(RA.roi_align_backward(dout[mask.view(-1)].numpy(), rois, 1.0 / 16, ph, ph, N, C, H, W, sr).astype(np.float32))
-    report("roi_align nhwc bwd sr%d" % sr, dfeat, nhwc(refb), 1e-4, 1e-4)
+    report("roi_align nhwc bwd sr%d C%d %dx%d" % (sr, C, H, W), dfeat, nhwc(refb), 1e-4, 1e-4)
 
 
 def test_avgpool_rows_and_relu_mask(ops):

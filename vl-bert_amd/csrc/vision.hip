@@ -369,6 +369,78 @@ __global__ __launch_bounds__(256) void roi_align_nhwc_kernel(const bf16_t* __res
   }
 }
 
+
+// Backward with the RoI's feature window staged in LDS.  A 14x14 bin grid over an RoI that is a few feature pixels wide
+// sends most of its 196 x 4 bilinear contributions per channel to the SAME handful of pixels: straight global atomics
+// serialise on those addresses (5.8 ms for 288 RoIs x 1024 channels).  Here a workgroup owns (RoI, 32-channel slice),
+// accumulates the slice of the RoI's window [wh x ww pixels][32 ch] with LDS atomics (lanes = channels: conflict-free
+// within a pixel) and flushes every window element with ONE global atomic, 128 B per pixel row.  Windows that do not
+// fit the LDS budget (whole-image boxes) fall back to direct atomics -- their contributions are spread out anyway.
+#define ROI_BWD_CC 32
+#define ROI_BWD_LDS_FLOATS 12288   // 48 KiB
+__global__ __launch_bounds__(256) void roi_align_nhwc_bwd_lds_kernel(const bf16_t* __restrict__ dout, const float* __restrict__ boxes,
+                                                                     long ldbox, int boxes_per_image, float* __restrict__ dfeat, int C,
+                                                                     int H, int W, int ph_n, int pw_n, float scale, int sampling_ratio) {
+  __shared__ float win[ROI_BWD_LDS_FLOATS];
+  const int k = blockIdx.x;
+  const int c0 = blockIdx.y * ROI_BWD_CC;
+  const float* bx = boxes + (long)k * ldbox;
+  if (!(bx[0] > -1.5f)) return;   // padded box: no gradient
+  const int batch = k / boxes_per_image;
+  const int bins = ph_n * pw_n;
+  const float start_w = bx[0] * scale, start_h = bx[1] * scale, end_w = bx[2] * scale, end_h = bx[3] * scale;
+  const float rw = fmaxf(end_w - start_w, 1.f), rh = fmaxf(end_h - start_h, 1.f);
+  const float bin_h = rh / (float)ph_n, bin_w = rw / (float)pw_n;
+  const int grid_h = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rh / (float)ph_n);
+  const int grid_w = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rw / (float)pw_n);
+  const float inv_count = 1.0f / (float)(grid_h * grid_w);
+  // pixel window that any in-range sample of this RoI can touch
+  const int ymin = max(0, (int)floorf(start_h)), ymax = min(H - 1, (int)floorf(start_h + rh) + 1);
+  const int xmin = max(0, (int)floorf(start_w)), xmax = min(W - 1, (int)floorf(start_w + rw) + 1);
+  if (ymin > ymax || xmin > xmax) return;   // RoI entirely outside the map: every sample is skipped
+  const int wh = ymax - ymin + 1, ww = xmax - xmin + 1;
+  const bool staged = (long)wh * ww * ROI_BWD_CC <= ROI_BWD_LDS_FLOATS;   // block-uniform
+  if (staged) {
+    for (int i = threadIdx.x; i < wh * ww * ROI_BWD_CC; i += 256) win[i] = 0.f;
+    __syncthreads();
+  }
+  const int c = threadIdx.x & (ROI_BWD_CC - 1);
+  const long plane0 = (long)batch * H * W;
+  for (int bin = threadIdx.x / ROI_BWD_CC; bin < bins; bin += 256 / ROI_BWD_CC) {
+    const int ph = bin / pw_n, pw = bin % pw_n;
+    const float go = bf2f(dout[((long)k * bins + bin) * C + c0 + c]) * inv_count;
+    for (int iy = 0; iy < grid_h; ++iy) {
+      const float y = start_h + ph * bin_h + (iy + .5f) * bin_h / (float)grid_h;
+      for (int ix = 0; ix < grid_w; ++ix) {
+        const float x = start_w + pw * bin_w + (ix + .5f) * bin_w / (float)grid_w;
+        const NhwcSample g = nhwc_sample(y, x, H, W);
+        if (g.p1 < 0) continue;
+        if (staged) {
+          const int y1 = (int)(g.p1 / W) - ymin, x1 = (int)(g.p1 % W) - xmin, y4 = (int)(g.p4 / W) - ymin, x4 = (int)(g.p4 % W) - xmin;
+          atomicAdd(&win[(y1 * ww + x1) * ROI_BWD_CC + c], go * g.w1);
+          atomicAdd(&win[(y1 * ww + x4) * ROI_BWD_CC + c], go * g.w2);
+          atomicAdd(&win[(y4 * ww + x1) * ROI_BWD_CC + c], go * g.w3);
+          atomicAdd(&win[(y4 * ww + x4) * ROI_BWD_CC + c], go * g.w4);
+        } else {
+          atomicAdd(dfeat + (plane0 + g.p1) * C + c0 + c, go * g.w1);
+          atomicAdd(dfeat + (plane0 + g.p2) * C + c0 + c, go * g.w2);
+          atomicAdd(dfeat + (plane0 + g.p3) * C + c0 + c, go * g.w3);
+          atomicAdd(dfeat + (plane0 + g.p4) * C + c0 + c, go * g.w4);
+        }
+      }
+    }
+  }
+  if (!staged) return;
+  __syncthreads();
+  for (int i = threadIdx.x; i < wh * ww * ROI_BWD_CC; i += 256) {
+    const float v = win[i];
+    if (v == 0.f) continue;
+    const int pix = i / ROI_BWD_CC, cc = i % ROI_BWD_CC;
+    const int py = ymin + pix / ww, px = xmin + pix % ww;
+    atomicAdd(dfeat + (plane0 + (long)py * W + px) * C + c0 + cc, v);
+  }
+}
+
 extern "C" int vlb_roi_align_nhwc_fwd(const void* feat, const float* boxes, long ldbox, int boxes_per_image, void* out, int K, int C,
                                       int H, int W, int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio,
                                       hipStream_t stream) {
@@ -394,10 +466,15 @@ extern "C" int vlb_roi_align_nhwc_bwd(const void* dout, const float* boxes, long
   VLB_CHECK_ARG(dout && boxes, "vlb_roi_align_nhwc_bwd: null argument");
   VLB_CHECK_ARG(C > 0 && (C % 8) == 0 && H > 0 && W > 0 && pooled_h > 0 && pooled_w > 0 && boxes_per_image > 0 && ldbox >= 4,
                 "vlb_roi_align_nhwc_bwd: bad geometry");
-  const long waves = (long)K * pooled_h * pooled_w;
-  hipLaunchKernelGGL(roi_align_nhwc_kernel<true>, dim3(vlb_cdiv(waves, 4)), dim3(256), 0, stream, (const bf16_t*)nullptr, dfeat, boxes,
-                     ldbox, boxes_per_image, (bf16_t*)nullptr, (const bf16_t*)dout, K, C, H, W, pooled_h, pooled_w, spatial_scale,
-                     sampling_ratio);
+  if ((C % ROI_BWD_CC) == 0) {
+    hipLaunchKernelGGL(roi_align_nhwc_bwd_lds_kernel, dim3(K, C / ROI_BWD_CC), dim3(256), 0, stream, (const bf16_t*)dout, boxes, ldbox,
+                       boxes_per_image, dfeat, C, H, W, pooled_h, pooled_w, spatial_scale, sampling_ratio);
+  } else {
+    const long waves = (long)K * pooled_h * pooled_w;
+    hipLaunchKernelGGL(roi_align_nhwc_kernel<true>, dim3(vlb_cdiv(waves, 4)), dim3(256), 0, stream, (const bf16_t*)nullptr, dfeat, boxes,
+                       ldbox, boxes_per_image, (bf16_t*)nullptr, (const bf16_t*)dout, K, C, H, W, pooled_h, pooled_w, spatial_scale,
+                       sampling_ratio);
+  }
   VLB_CHECK_LAUNCH("vlb_roi_align_nhwc_bwd");
   return VLB_OK;
 }
