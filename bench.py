@@ -74,7 +74,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--global-batch", type=int, default=256)
+    ap.add_argument("--global-batch", type=int, default=None, help="default 256 (strong scaling); with --e2e: 8 per GPU (weak scaling)")
+    ap.add_argument("--e2e", action="store_true", help="config C3 (cfgs/pretrain/base_e2e_16x16G_fp16.yaml): ResNet-101 trunk + ROIAlign + "
+                    "layer4 head on 600x1000 images, 8 images per GPU, in front of the same VL-BERT step")
+    ap.add_argument("--image-size", type=int, nargs=2, default=(600, 1000))
     ap.add_argument("--layers", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a hipGraph")
@@ -102,13 +105,28 @@ def main():
     arch, cus = lib.device_info(local_rank)
 
     T, R = 64, 36
+    if args.global_batch is None:
+        args.global_batch = 8 * world if args.e2e else 256
     per_gpu = args.global_batch // world
-    cfg = engine.ModelConfig(num_hidden_layers=args.layers)
+    cfg = engine.ModelConfig(num_hidden_layers=args.layers, e2e=args.e2e)
     eng = engine.PretrainEngine(cfg, per_gpu, T, R, device="cuda:%d" % local_rank, train=True, lr=1e-4, weight_decay=1e-4,
-                                max_grad_norm=10.0, seed=1234 + rank)
-    eng.init_random(seed=0)                       # same weights on every rank (DDP broadcast, train.py:332-334)
+                                max_grad_norm=10.0, seed=1234 + rank, image_size=tuple(args.image_size) if args.e2e else None)
+    eng.init_random(seed=0, visual_ln_init=1.0 if args.e2e else 0.0)   # same weights on every rank (DDP broadcast, train.py:332-334)
     batch = syn.make_batch(per_gpu, T, R, seed=100 + rank)
-    eng.set_batch(*[t.cuda(non_blocking=True) for t in batch])
+    if args.e2e:      # images as the dataset hands them over (mean-subtracted pixels), boxes inside the image
+        gi = torch.Generator().manual_seed(200 + rank)
+        Hi, Wi = args.image_size
+        image = torch.randn(per_gpu, 3, Hi, Wi, generator=gi) * 50.0
+        bx = batch[0]
+        bx[:, :, 0].clamp_(0, Wi - 170)
+        bx[:, :, 1].clamp_(0, Hi - 170)
+        bx[:, :, 2] = torch.minimum(bx[:, :, 2], torch.full_like(bx[:, :, 2], Wi - 1.0))
+        bx[:, :, 3] = torch.minimum(bx[:, :, 3], torch.full_like(bx[:, :, 3], Hi - 1.0))
+        bx[:, 0, :4] = torch.tensor([0.0, 0.0, Wi - 1.0, Hi - 1.0])
+        batch[1][:, 0], batch[1][:, 1] = Wi, Hi
+        eng.set_batch(*[t.cuda(non_blocking=True) for t in batch], image=image.cuda(non_blocking=True))
+    else:
+        eng.set_batch(*[t.cuda(non_blocking=True) for t in batch])
     eng.sync_weights()
     torch.cuda.synchronize()
 
@@ -198,6 +216,20 @@ def main():
     gemm_alg_gb = sum(b for _, _, _, b in rec) / max(len(rec), 1) / 1e9      # operands read once + result written once
     achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     fwd, fwdbwd = flops_per_sample(cfg, T, R)
+    if args.e2e:      # + convolution FLOPs of the vision path (forward of every conv; dgrad + wgrad of the trainable stages)
+        vs = eng.vision
+        need_dx = vs._dgrad_set()
+        vf = 2.0 * vs.N * vs.H1 * vs.W1 * 147 * 64
+        vb = 0.0
+        for b in vs.blocks:
+            k, M, P, C = b["key"], b["M"], b["planes"], b["inplanes"]
+            per = {"conv1": 2.0 * M * C * P, "conv2": 2.0 * M * 9 * P * P, "conv3": 2.0 * M * P * 4 * P}
+            if b["downsample"]:
+                per["downsample.0"] = 2.0 * M * C * 4 * P
+            vf += sum(per.values())
+            if b["trainable"]:
+                vb += sum(f * (2 if k + n in need_dx else 1) for n, f in per.items())
+        fwd, fwdbwd = fwd + vf / per_gpu, fwdbwd + (vf + vb) / per_gpu
     # HBM bytes per GEMM launch come from PMC counters, which need their own rocprofv3 passes (tools/make_profiles.sh);
     # the committed summary of those passes is reported here when it was taken on this workload, else null.
     traffic, traffic_unit = None, None
@@ -211,12 +243,14 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "samples/sec VL-BERT-base pretrain (seq 64+36 regions) at 1/2/4/8 MI355X",
+            "metric": ("samples/sec VL-BERT-base e2e pretrain (ResNet-101 on %dx%d images + seq 64+36 regions)" % tuple(args.image_size))
+            if args.e2e else "samples/sec VL-BERT-base pretrain (seq 64+36 regions) at 1/2/4/8 MI355X",
             "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak" if args.e2e else "strong", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic (random-init weights, random tokens/boxes/features, resident in HBM)",
             "config": {"workload": "VL-BERT-base %d-layer pretrain step (fwd+bwd+clip+AdamW), 64 text + 36 regions, "
-                                   "precomputed 2048-d region features, dropout on" % args.layers,
+                                   "%s, dropout on" % (args.layers, "ResNet-101 trunk + ROIAlign + dilated layer4 head on the device "
+                                                       "(stages 1-2 and BatchNorm frozen)" if args.e2e else "precomputed 2048-d region features"),
                        "global_batch": args.global_batch, "per_gpu_batch": per_gpu, "seq_len": T + R + 1,
                        "parallelism": "dp%d" % world, "hipgraph": bool(use_graph), "arch": arch, "cus": cus},
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_bf16_kernel + gemm_tn_bf16_kernel (all %d GEMM launches of one step)" % len(rec),
@@ -230,7 +264,7 @@ def main():
             "fwd_bwd_ms": round(fwd_bwd_ms, 3) if fwd_bwd_ms is not None else None,
             "loss": round(losses["loss"], 4),
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not args.e2e:
             out["cpu_baseline"] = cpu_baseline(dict(num_hidden_layers=args.layers), T, R)
         print(json.dumps(out), flush=True)
     if dist is not None:

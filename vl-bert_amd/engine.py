@@ -945,7 +945,12 @@ class PretrainEngine:
         weights / embeddings, zero biases, unit LayerNorm gammas, visual_ln gammas = visual_scale_*_init,
         zero mask-visual embedding.  Used by bench.py / smoke (no checkpoints exist offline)."""
         g = torch.Generator(device=self.dev).manual_seed(seed)
+        vis = self._vision_names()
+        if self.vision is not None:
+            self.vision.init_random(seed + 1)
         for name, t in self.w32.items():
+            if name in vis:
+                continue
             if "LayerNorm.weight" in name:
                 t.fill_(1.0)
             elif name.endswith("visual_ln_text.weight") or name.endswith("visual_ln_object.weight"):

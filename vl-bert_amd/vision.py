@@ -226,6 +226,18 @@ class VisionStack:
                 sd[name] = t.detach().clone()
         return sd
 
+    def init_random(self, seed=0):
+        """Convolutions ~ N(0, sqrt(2 / fan_out)) (resnet.py:153-155); BatchNorm identity except a 0.2 gain on the BN that closes
+        each residual branch and the stem, which keeps random-init activations O(1) through 33 blocks (bench / smoke only)."""
+        g = torch.Generator(device=self.dev).manual_seed(seed)
+        for c in self.convs.values():
+            c.w32.normal_(0.0, (2.0 / (c.O * c.taps)) ** 0.5, generator=g)
+            c.bn[0].fill_(0.2 if (c.key.endswith("conv3") or c.key == "backbone.conv1") else 1.0)
+            c.bn[1].zero_()
+            c.bn[2].zero_()
+            c.bn[3].fill_(1.0)
+        self._dirty = True
+
     def grads(self):
         """{reference name: gradient in the reference's [O,I,KH,KW] layout} of the trainable convolutions."""
         return OrderedDict((PREFIX + key + ".weight", c.g32.detach().view(c.O, c.k, c.k, c.I).permute(0, 3, 1, 2).contiguous().clone())
