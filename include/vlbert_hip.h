@@ -215,6 +215,13 @@ int vlb_conv_weight_prepare(const float* w, const float* gamma, const float* bet
                             vlb_stream_t stream);
 int vlb_conv_wgrad_finalize(const float* dwf, const float* scale, float* g, int O, int kreal, int kf, int accumulate,
                             vlb_stream_t stream);
+/* implicit 3x3 convolution, stride 1, padding = dilation: y[N*H*W, O] = epi(im2col(x) . w^T) without the im2col image in HBM
+ * (the gather runs in the GEMM's LDS-DMA address generator).  x: NHWC bf16 [N*H*W, C], C % 64 == 0; w: [O, 9*C] tap-major
+ * (vlb_conv_weight_prepare's wf, or its wb for the data gradient); act 0 bias | 2 bias+ReLU | 8 x (aux > 0); zero16: >= 16 B
+ * of device zeros (source of out-of-image taps). */
+int vlb_conv3x3_nhwc_bf16(const void* x, int N, int H, int W, int C, int dil, const void* w, long ldw, void* y, long ldy,
+                          int O, const float* bias, int act, const void* aux, long ldaux, const void* zero16,
+                          vlb_stream_t stream);
 int vlb_im2col_nhwc_bf16(const void* x, void* col, long ldcol, int N, int H, int W, int C, int KH, int KW, int stride,
                          int pad, int dil, vlb_stream_t stream);
 /* stem (resnet.py:137-141): fp32 NCHW image -> [N*OH*OW, ldcol] bf16, column (ky*KW+kx)*Cin + c, zero padded to ldcol */

@@ -188,6 +188,23 @@ def test_avgpool_rows_and_relu_mask(ops):
     report("relu_mask_cast", out, g32 * (y > 0), 0, 4e-3)
 
 
+@pytest.mark.parametrize("N,I,O,H,W,dil", [(3, 128, 256, 38, 63, 1), (40, 512, 512, 14, 14, 2)])
+def test_conv3x3_implicit_equals_explicit_at_size(ops, N, I, O, H, W, dil):
+    """layer2 / RoI-head sized convolutions (multiple tiles, persistent workgroups, tile tails): bit-identical to im2col + GEMM."""
+    M = N * H * W
+    x, w = to_gpu_bf16(rnd(M, I, seed=40)), to_gpu_bf16(rnd(O, 9 * I, seed=41, scale=0.05))
+    bias = torch.randn(O, generator=torch.Generator().manual_seed(42)).to(dev())
+    zero16 = torch.zeros(64, dtype=torch.bfloat16, device=dev())
+    col = torch.zeros((M, 9 * I), dtype=torch.bfloat16, device=dev())
+    y1 = torch.zeros((M, O), dtype=torch.bfloat16, device=dev())
+    y2 = torch.zeros_like(y1)
+    ops.im2col_nhwc(x, col, N, H, W, I, 3, 1, dil, dil)
+    ops.gemm_nt(col, w, y1, bias=bias, act=ops.ACT_RELU)
+    ops.conv3x3_nhwc(x, w, y2, N, H, W, I, dil, zero16, bias=bias, act=ops.ACT_RELU)
+    torch.cuda.synchronize()
+    assert torch.equal(y1, y2), "max diff %g" % float((y1.float() - y2.float()).abs().max())
+
+
 @pytest.mark.parametrize("dil", [1, 2])
 def test_conv3x3_forward_dgrad_wgrad_vs_autograd(ops, dil):
     """One folded-BN 3x3 convolution end to end: im2col + NT GEMM forward, mirrored-tap dgrad, TN wgrad + finalize,
@@ -214,12 +231,25 @@ def test_conv3x3_forward_dgrad_wgrad_vs_autograd(ops, dil):
     xr = x.clone().requires_grad_(True)
     yr = F.conv2d(xr, wq, padding=dil, dilation=dil) + shift.cpu().view(1, O, 1, 1)
     report("conv3x3 d%d forward" % dil, y, nhwc(yr), 1e-3, 1e-2)
+    # implicit GEMM (gather in the LDS-DMA address generator): same numbers without the im2col image
+    zero16 = torch.zeros(64, dtype=torch.bfloat16, device=dev())
+    y2 = torch.zeros_like(y)
+    ops.conv3x3_nhwc(xg, wf, y2, N, H, W, I, dil, zero16, bias=shift)
+    assert torch.equal(y2, y), "implicit and explicit forward differ"
+    ops.conv3x3_nhwc(xg, wf, y2, N, H, W, I, dil, zero16, bias=shift, act=ops.ACT_RELU)
+    report("conv3x3 d%d implicit forward + relu" % dil, y2, torch.relu(nhwc(yr)), 1e-3, 1e-2)
     (yr * dy).sum().backward()
     dcol = torch.zeros((M, 9 * O), dtype=torch.bfloat16, device=dev())
     dx = torch.zeros((M, I), dtype=torch.bfloat16, device=dev())
     ops.im2col_nhwc(dyg, dcol, N, H, W, O, 3, 1, dil, dil)
     ops.gemm_nt(dcol, wb, dx)
     report("conv3x3 d%d dgrad (mirrored taps)" % dil, dx, nhwc(xr.grad), 1e-3, 1e-2)
+    dx2 = torch.zeros_like(dx)
+    ops.conv3x3_nhwc(dyg, wb, dx2, N, H, W, O, dil, zero16)
+    assert torch.equal(dx2, dx), "implicit and explicit dgrad differ"
+    aux = rnd(M, I, seed=33)
+    ops.conv3x3_nhwc(dyg, wb, dx2, N, H, W, O, dil, zero16, act=ops.ACT_RELU_MASK, aux=to_gpu_bf16(aux))
+    report("conv3x3 d%d implicit dgrad x (aux>0)" % dil, dx2, nhwc(xr.grad) * (aux > 0), 1e-3, 1e-2)
     dwf = torch.zeros((O, 9 * I), device=dev())
     ws = torch.zeros(max(ops.wgrad_workspace_floats(O, 9 * I, M), 4), device=dev())
     ops.wgrad_tn(dyg, col, dwf, workspace=ws, accumulate=False)

@@ -44,6 +44,7 @@ _SIGS = {
     "vlb_lr_schedule_step": "pifffs",
     "vlb_conv_weight_prepare": "pppppfppppiiiis",
     "vlb_conv_wgrad_finalize": "pppiiiis",
+    "vlb_conv3x3_nhwc_bf16": "piiiiiplplipiplps",
     "vlb_im2col_nhwc_bf16": "ppliiiiiiiiis",
     "vlb_im2col_image_f32": "ppiiiiiiiiis",
     "vlb_maxpool3x3s2_nhwc": "ppiiiis",

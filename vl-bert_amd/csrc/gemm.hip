@@ -43,6 +43,10 @@ struct GemmParams {
   int out_f32;               // 0: bf16 store, 1: fp32 store, 2: fp32 atomicAdd
   int ntm, ntn;
   int tile_group;            // tile-rows per L2 group (see the kernel's tile order)
+  // implicit 3x3 convolution (CONV kernels): A = NHWC activation [rows = n*H*W, conv_C], K = 9*conv_C, K tile kt reads tap
+  // kt / (conv_C/64), channels (kt % (conv_C/64))*64.. of pixel (y + (tap/3-1)*dil, x + (tap%3-1)*dil); out-of-image taps read `zero`
+  int conv_C, conv_H, conv_W, conv_dil;
+  const bf16_t* zero;        // >= 16 B of zeros
 };
 
 #define GLDS_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
@@ -292,7 +296,7 @@ __device__ __forceinline__ void gemm_epilogue_select(const GemmParams& p, f32x4 
   }
 }
 
-template <int BM, int BN, int WGM, int WGN, int EPI>   // WGM x WGN waves per workgroup
+template <int BM, int BN, int WGM, int WGN, int EPI, bool CONV = false>   // WGM x WGN waves per workgroup
 // 2 workgroups per CU (LDS-limited) must also fit the register file: 16 waves/CU = 4 per SIMD for the 8-wave shape
 // (<= 128 VGPRs), 2 per SIMD for the 4-wave shape; the second launch-bound argument is waves per SIMD.
 __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN >= 8) ? 4 : 2) void gemm_nt_bf16_kernel(const GemmParams p) {
@@ -328,11 +332,23 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN >= 8) ? 4 : 2) void gemm
   };
   // per-thread staging addresses (16-B chunks; chunk P -> LDS byte 16*P):
   // P = it*NT + tid ; row r = P>>3 ; physical slot s = P&7 ; logical k-chunk kc = s ^ ((r>>1)&7)
-  auto setup = [&](const bf16_t* (&a_src)[NA], const bf16_t* (&b_src)[NB], int m0, int n0) {
+  // CONV: a_src = the centre pixel's channel chunk, a_msk = which of the 9 taps fall inside the image for that pixel
+  auto setup = [&](const bf16_t* (&a_src)[NA], uint32_t (&a_msk)[NA], const bf16_t* (&b_src)[NB], int m0, int n0) {
 #pragma unroll
     for (int it = 0; it < NA; ++it) {
       const int P = it * NT + tid, r = P >> 3, kc = (P & 7) ^ ((r >> 1) & 7);
-      a_src[it] = p.A + (long)min(m0 + r, p.M - 1) * p.lda + k_begin + kc * 8;
+      const int m = min(m0 + r, p.M - 1);
+      a_src[it] = p.A + (long)m * p.lda + k_begin + kc * 8;
+      if constexpr (CONV) {
+        const int ox = m % p.conv_W, oy = (m / p.conv_W) % p.conv_H;
+        uint32_t msk = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int iy = oy + (t / 3 - 1) * p.conv_dil, ix = ox + (t % 3 - 1) * p.conv_dil;
+          msk |= (uint32_t)(iy >= 0 && iy < p.conv_H && ix >= 0 && ix < p.conv_W) << t;
+        }
+        a_msk[it] = msk;
+      }
     }
 #pragma unroll
     for (int it = 0; it < NB; ++it) {
@@ -340,13 +356,24 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN >= 8) ? 4 : 2) void gemm
       b_src[it] = p.B + (long)min(n0 + r, p.N - 1) * p.ldb + k_begin + kc * 8;
     }
   };
-  auto stage = [&](const bf16_t* (&a_src)[NA], const bf16_t* (&b_src)[NB], int buf, int kt) {
+  const int conv_cpt = CONV ? p.conv_C / BK : 1;     // K tiles per tap
+  auto stage = [&](const bf16_t* (&a_src)[NA], uint32_t (&a_msk)[NA], const bf16_t* (&b_src)[NB], int buf, int kt) {
     char* sa = smem + buf * STAGE;
     char* sb = sa + A_BYTES;
     const int koff = kt * BK;
+    if constexpr (CONV) {
+      const int t = kt / conv_cpt, cb = kt - t * conv_cpt;                       // wave-uniform
+      const long aoff = ((long)(t / 3 - 1) * p.conv_W + (t % 3 - 1)) * p.conv_dil * p.conv_C + cb * BK;
 #pragma unroll
-    for (int it = 0; it < NA; ++it)
-      __builtin_amdgcn_global_load_lds(GLDS_PTR(a_src[it] + koff), LDS_PTR(sa + (it * NT + wave * 64) * 16), 16, 0, 0);
+      for (int it = 0; it < NA; ++it) {
+        const bf16_t* src = ((a_msk[it] >> t) & 1u) ? a_src[it] + aoff : p.zero;
+        __builtin_amdgcn_global_load_lds(GLDS_PTR(src), LDS_PTR(sa + (it * NT + wave * 64) * 16), 16, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < NA; ++it)
+        __builtin_amdgcn_global_load_lds(GLDS_PTR(a_src[it] + koff), LDS_PTR(sa + (it * NT + wave * 64) * 16), 16, 0, 0);
+    }
 #pragma unroll
     for (int it = 0; it < NB; ++it)
       __builtin_amdgcn_global_load_lds(GLDS_PTR(b_src[it] + koff), LDS_PTR(sb + (it * NT + wave * 64) * 16), 16, 0, 0);
@@ -366,10 +393,11 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN >= 8) ? 4 : 2) void gemm
 
   const bf16_t* a_src[NA];
   const bf16_t* b_src[NB];
+  uint32_t a_msk[NA];
   int w = blockIdx.x, m0, n0, buf = 0;
   tile_of(w, m0, n0);
-  setup(a_src, b_src, m0, n0);
-  stage(a_src, b_src, 0, 0);
+  setup(a_src, a_msk, b_src, m0, n0);
+  stage(a_src, a_msk, b_src, 0, 0);
   __syncthreads();
   for (;;) {
     const int w_next = w + gridDim.x;
@@ -377,13 +405,14 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN >= 8) ? 4 : 2) void gemm
     int m0n = 0, n0n = 0;
     const bf16_t* a_nx[NA];
     const bf16_t* b_nx[NB];
+    uint32_t m_nx[NA];
     for (int kt = 0; kt < ntk; ++kt) {
       if (kt + 1 < ntk) {
-        stage(a_src, b_src, buf ^ 1, kt + 1);
+        stage(a_src, a_msk, b_src, buf ^ 1, kt + 1);
       } else if (has_next) {   // last K tile: the first stage of the NEXT output tile streams in under the epilogue
         tile_of(w_next, m0n, n0n);
-        setup(a_nx, b_nx, m0n, n0n);
-        stage(a_nx, b_nx, buf ^ 1, 0);
+        setup(a_nx, m_nx, b_nx, m0n, n0n);
+        stage(a_nx, m_nx, b_nx, buf ^ 1, 0);
       }
       const char* sa = smem + buf * STAGE;
       const char* sb = sa + A_BYTES;
@@ -421,7 +450,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN >= 8) ? 4 : 2) void gemm
 #pragma unroll
       for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int it = 0; it < NA; ++it) a_src[it] = a_nx[it];
+    for (int it = 0; it < NA; ++it) { a_src[it] = a_nx[it]; if constexpr (CONV) a_msk[it] = m_nx[it]; }
 #pragma unroll
     for (int it = 0; it < NB; ++it) b_src[it] = b_nx[it];
     w = w_next; m0 = m0n; n0 = n0n;
@@ -1115,6 +1144,56 @@ extern "C" int vlb_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb
   const long tiles128 = (long)vlb_cdiv(M, 128) * vlb_cdiv(N, 128) * splits;
   if (tiles128 < 384 || N <= 64) return launch_gemm<128, 64>(p, splits, stream);
   return launch_gemm<128, 128>(p, splits, stream);
+}
+
+// ------------------------------------------------------------------------------------
+// Implicit 3x3 convolution (stride 1, padding = dilation) on an NHWC bf16 activation: the NT GEMM above with the im2col
+// gather done by the LDS-DMA address generator -- no [rows, 9C] image in HBM, the activation is read through L2 nine
+// times instead.  y[M, O] = epilogue( sum_taps x[pixel + tap] . w[O, tap, :]^T ), w = [O, 9*C] tap-major.
+// Epilogues: bias (act 0), bias + ReLU (act 2: the Bottleneck's conv2), x (aux > 0) (act 8: its data gradient with the
+// mirrored-tap operand of vlb_conv_weight_prepare).
+// ------------------------------------------------------------------------------------
+template <int BN, int WGN, int EPI>
+static int launch_conv_cfg(GemmParams& p, hipStream_t stream) {
+  constexpr int smem = 2 * (128 + BN) * 64 * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_kernel<128, BN, 2, WGN, EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_set = true;
+  }
+  static const int group = env_int("VLB_GEMM_TILE_GROUP", 4);
+  p.ntm = vlb_cdiv(p.M, 128);
+  p.ntn = vlb_cdiv(p.N, BN);
+  p.tile_group = group < 1 ? 1 : group;
+  int gx = p.ntm * p.ntn;
+  if (gx > 512) gx = 512;
+  hipLaunchKernelGGL((gemm_nt_bf16_kernel<128, BN, 2, WGN, EPI, true>), dim3(gx, 1), dim3(64 * 2 * WGN), smem, stream, p);
+  VLB_CHECK_LAUNCH("vlb_conv3x3_nhwc_bf16");
+  return VLB_OK;
+}
+
+extern "C" int vlb_conv3x3_nhwc_bf16(const void* x, int N, int H, int W, int C, int dil, const void* w, long ldw, void* y, long ldy,
+                                     int O, const float* bias, int act, const void* aux, long ldaux, const void* zero16,
+                                     hipStream_t stream) {
+  if (N <= 0 || O <= 0) return VLB_OK;
+  VLB_CHECK_ARG(x && w && y && zero16, "vlb_conv3x3_nhwc_bf16: null argument");
+  VLB_CHECK_ARG(C > 0 && (C % 64) == 0, "vlb_conv3x3_nhwc_bf16: C=%d must be a multiple of 64", C);
+  VLB_CHECK_ARG(H > 0 && W > 0 && dil >= 1, "vlb_conv3x3_nhwc_bf16: bad geometry");
+  VLB_CHECK_ARG((ldw % 8) == 0 && ldw >= 9L * C && (ldy % 4) == 0, "vlb_conv3x3_nhwc_bf16: bad leading dimensions");
+  VLB_CHECK_ARG(act == 0 || act == 2 || (act == 8 && aux), "vlb_conv3x3_nhwc_bf16: act must be 0, 2 or 8 (with aux)");
+  VLB_CHECK_ARG((long)N * H * W < (1L << 31), "vlb_conv3x3_nhwc_bf16: too many rows");
+  GemmParams p;
+  p.A = (const bf16_t*)x; p.lda = C; p.B = (const bf16_t*)w; p.ldb = ldw;
+  p.M = N * H * W; p.N = O; p.K = 9 * C; p.k_per_split = 9 * C;
+  p.bias = bias; p.act = act; p.aux = (const bf16_t*)aux; p.ldaux = ldaux; p.pre = nullptr; p.ldpre = 0; p.res = nullptr; p.ldres = 0;
+  p.drop_thr = 0; p.drop_scale = 1.f; p.seed = nullptr; p.tag = 0;
+  p.C = y; p.ldc = ldy; p.out_f32 = 0; p.c_split_stride = 0;
+  p.conv_C = C; p.conv_H = H; p.conv_W = W; p.conv_dil = dil; p.zero = (const bf16_t*)zero16;
+  const long tiles128 = (long)vlb_cdiv(p.M, 128) * vlb_cdiv(O, 128);
+  const bool narrow = tiles128 < 384 || O <= 64;
+  if (act == 0) return narrow ? launch_conv_cfg<64, 2, 0>(p, stream) : launch_conv_cfg<128, 4, 0>(p, stream);
+  if (act == 2) return narrow ? launch_conv_cfg<64, 2, 5>(p, stream) : launch_conv_cfg<128, 4, 5>(p, stream);
+  return narrow ? launch_conv_cfg<64, 2, 8>(p, stream) : launch_conv_cfg<128, 4, 8>(p, stream);
 }
 
 // ------------------------------------------------------------------------------------

@@ -347,6 +347,15 @@ def conv_wgrad_finalize(dwf, scale, g, accumulate=True):
               dwf.shape[1], int(bool(accumulate)), _stream())
 
 
+def conv3x3_nhwc(x, w, y, N, H, W, C, dil, zero16, bias=None, act=ACT_NONE, aux=None):
+    """y[N*H*W, O] = epi(implicit im2col(x) . w^T): 3x3, stride 1, padding = dilation; w bf16 [O, 9C] tap-major."""
+    O = w.shape[0]
+    assert x.shape[0] == N * H * W and x.shape[1] == C and x.is_contiguous() and y.shape[0] == x.shape[0] and y.shape[1] == O
+    _lib.call("vlb_conv3x3_nhwc_bf16", _p(x, BF16), N, H, W, C, dil, _p(w, BF16), _ld(w), _p(y, BF16), _ld(y), O,
+              _p(bias, torch.float32), act, _p(aux, BF16), _ld(aux), _p(zero16, BF16), _stream())
+    return y
+
+
 def im2col_nhwc(x, col, N, H, W, C, k, stride, pad, dil):
     _lib.call("vlb_im2col_nhwc_bf16", _p(x, BF16), _p(col, BF16), _ld(col), N, H, W, C, k, k, stride, pad, dil, _stream())
     return col

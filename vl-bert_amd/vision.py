@@ -23,6 +23,7 @@ MI355X design (not the reference's NCHW + cuDNN):
 Convention for backward: the gradient handed to a block is dL/d(pre-ReLU block output), i.e. already masked by (y > 0) by
 whoever produced it (the next block's last dgrad epilogue, the ROIAlign-backward cast, the avg-pool backward).
 """
+import os
 from collections import OrderedDict
 
 import torch
@@ -97,6 +98,10 @@ class VisionStack:
         zb = lambda *s: torch.zeros(s, dtype=BF16, device=d)
         zf = lambda *s: torch.zeros(s, dtype=F32, device=d)
         self.blocks = block_table(num_layers, True, c5_dilated)
+        # 3x3 convolutions: implicit GEMM (gather in the GEMM's LDS-DMA address generator) for forward and data gradient; the
+        # im2col image is only materialised in backward, for the TN weight gradient.  VLB_CONV_IMPLICIT=0: explicit im2col + GEMM.
+        self.implicit = os.environ.get("VLB_CONV_IMPLICIT", "1") != "0"
+        self.zero16 = torch.zeros(64, dtype=BF16, device=d)
         min_train = min(b["stage"] for b in self.blocks if b["stage"] not in self.frozen_stages)
         if any(b["stage"] in self.frozen_stages and b["stage"] > min_train for b in self.blocks):
             raise NotImplementedError("frozen stages must be a prefix of the network")
@@ -158,17 +163,19 @@ class VisionStack:
             b["xs"] = zb(M, C) if b["stride"] == 2 else None
             b["a"], b["b"], b["y"] = zb(M, P), zb(M, P), zb(M, 4 * P)
             b["r"] = zb(M, 4 * P) if b["downsample"] else None
-            if tr:
+            if tr and not self.implicit:
                 b["col"] = zb(M, 9 * P)                      # kept for the weight gradient
-            else:
+            elif tr or not self.implicit:                    # implicit: built in backward for the wgrad, shared; frozen + implicit: none
                 if (M, P) not in shared_col:
                     shared_col[(M, P)] = zb(M, 9 * P)
                 b["col"] = shared_col[(M, P)]
+            else:
+                b["col"] = None
             if L not in self.groups:
                 g = dict(M=M, P=P, C=C, n=n, h=h, w=w)
                 if tr:
-                    g.update(dzA=zb(M, 4 * P), dzB=zb(M, 4 * P), da=zb(M, P), db=zb(M, P), dcol=zb(M, 9 * P),
-                             tmp=zb(M, C), dxs=zb(M, C))
+                    g.update(dzA=zb(M, 4 * P), dzB=zb(M, 4 * P), da=zb(M, P), db=zb(M, P),
+                             dcol=None if self.implicit else zb(M, 9 * P), tmp=zb(M, C), dxs=zb(M, C))
                 self.groups[L] = g
             if tr:
                 for (mo, no) in ((4 * P, P), (P, 9 * P), (P, C), (4 * P, C)):
@@ -264,8 +271,11 @@ class VisionStack:
             xs = ops.subsample2_nhwc(x, b["xs"], n, hin, win, b["inplanes"])
         c1, c2, c3 = cv[k + "conv1"], cv[k + "conv2"], cv[k + "conv3"]
         ops.gemm_nt(xs, c1.wf, b["a"], bias=c1.shift, act=ops.ACT_RELU)
-        ops.im2col_nhwc(b["a"], b["col"], n, h, w, P, 3, 1, b["dil"], b["dil"])
-        ops.gemm_nt(b["col"], c2.wf, b["b"], bias=c2.shift, act=ops.ACT_RELU)
+        if self.implicit:
+            ops.conv3x3_nhwc(b["a"], c2.wf, b["b"], n, h, w, P, b["dil"], self.zero16, bias=c2.shift, act=ops.ACT_RELU)
+        else:
+            ops.im2col_nhwc(b["a"], b["col"], n, h, w, P, 3, 1, b["dil"], b["dil"])
+            ops.gemm_nt(b["col"], c2.wf, b["b"], bias=c2.shift, act=ops.ACT_RELU)
         res = x
         if b["downsample"]:
             cd = cv[k + "downsample.0"]
@@ -313,9 +323,14 @@ class VisionStack:
         da, db = g["da"], g["db"]
         self._wgrad(c3, dz, b["b"])
         ops.gemm_nt(dz, c3.wb, db, act=ops.ACT_RELU_MASK, aux=b["b"])
-        self._wgrad(c2, db, b["col"])
-        ops.im2col_nhwc(db, g["dcol"], n, h, w, P, 3, 1, b["dil"], b["dil"])
-        ops.gemm_nt(g["dcol"], c2.wb, da, act=ops.ACT_RELU_MASK, aux=b["a"])
+        if self.implicit:
+            ops.im2col_nhwc(b["a"], b["col"], n, h, w, P, 3, 1, b["dil"], b["dil"])
+            self._wgrad(c2, db, b["col"])
+            ops.conv3x3_nhwc(db, c2.wb, da, n, h, w, P, b["dil"], self.zero16, act=ops.ACT_RELU_MASK, aux=b["a"])
+        else:
+            self._wgrad(c2, db, b["col"])
+            ops.im2col_nhwc(db, g["dcol"], n, h, w, P, 3, 1, b["dil"], b["dil"])
+            ops.gemm_nt(g["dcol"], c2.wb, da, act=ops.ACT_RELU_MASK, aux=b["a"])
         self._wgrad(c1, da, xs)
         cd = cv[k + "downsample.0"] if b["downsample"] else None
         if cd is not None:
