@@ -222,6 +222,10 @@ int vlb_conv_wgrad_finalize(const float* dwf, const float* scale, float* g, int 
 int vlb_conv3x3_nhwc_bf16(const void* x, int N, int H, int W, int C, int dil, const void* w, long ldw, void* y, long ldy,
                           int O, const float* bias, int act, const void* aux, long ldaux, const void* zero16,
                           vlb_stream_t stream);
+/* weight gradient of the same convolution without the im2col image: dW[O, 9*C] fp32 (+)= dy[N*H*W, O]^T . im2col(x); the TN
+ * GEMM gathers the shifted pixels of x itself.  C % 128 == 0; workspace as vlb_wgrad_tn_bf16 (vlb_wgrad_workspace_floats(O, 9C, rows)). */
+int vlb_conv3x3_wgrad_tn_bf16(const void* dy, long lddy, const void* x, int N, int H, int W, int C, int dil, float* dW,
+                              long lddw, int O, float* workspace, long workspace_floats, int accumulate, vlb_stream_t stream);
 int vlb_im2col_nhwc_bf16(const void* x, void* col, long ldcol, int N, int H, int W, int C, int KH, int KW, int stride,
                          int pad, int dil, vlb_stream_t stream);
 /* stem (resnet.py:137-141): fp32 NCHW image -> [N*OH*OW, ldcol] bf16, column (ky*KW+kx)*Cin + c, zero padded to ldcol */

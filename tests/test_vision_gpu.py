@@ -203,6 +203,17 @@ def test_conv3x3_implicit_equals_explicit_at_size(ops, N, I, O, H, W, dil):
     ops.conv3x3_nhwc(x, w, y2, N, H, W, I, dil, zero16, bias=bias, act=ops.ACT_RELU)
     torch.cuda.synchronize()
     assert torch.equal(y1, y2), "max diff %g" % float((y1.float() - y2.float()).abs().max())
+    # weight gradient: TN GEMM over the im2col image vs the gather inside the TN kernel (same split-K plan -> same bits)
+    dy = to_gpu_bf16(rnd(M, O, seed=43))
+    ws = torch.zeros(max(ops.wgrad_workspace_floats(O, 9 * I, M), 4), device=dev())
+    g1 = torch.zeros((O, 9 * I), device=dev())
+    g2 = torch.full((O, 9 * I), 3.0, device=dev())
+    ops.wgrad_tn(dy, col, g1, workspace=ws, accumulate=False)
+    ops.conv3x3_wgrad_tn(dy, x, g2, N, H, W, I, dil, workspace=ws, accumulate=False)
+    torch.cuda.synchronize()
+    assert torch.equal(g1, g2), "wgrad max diff %g (scale %g)" % (float((g1 - g2).abs().max()), float(g1.abs().max()))
+    ops.conv3x3_wgrad_tn(dy, x, g2, N, H, W, I, dil, workspace=None, accumulate=True)      # single pass, accumulate
+    report("conv3x3 implicit wgrad, accumulate, no workspace", g2, 2 * g1, 1e-3, 1e-4)
 
 
 @pytest.mark.parametrize("dil", [1, 2])

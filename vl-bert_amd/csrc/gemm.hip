@@ -768,7 +768,9 @@ __device__ __forceinline__ void tn_compute_stage(const uint32_t (&va)[4], const 
 }
 
 // OUT: 1 fp32 store (split-K slab, or overwrite) | 3 fp32 accumulate -- one instantiation each, like the NT kernels
-template <int WGN, int OUT>   // 2 x WGN waves: WGN = 4 -> 8 waves of 64x32 (two 8-wave workgroups per CU hide LDS/barrier latency)
+// CONV: B is an NHWC activation [R = n*H*W rows, conv_C] and the output columns are the 9*conv_C im2col columns (conv_C % 128
+// == 0, so a 128-wide column tile lies inside ONE tap): the weight gradient of a 3x3 convolution without the im2col image.
+template <int WGN, int OUT, bool CONV = false>   // 2 x WGN waves: WGN = 4 -> 8 waves of 64x32 (two 8-wave workgroups per CU hide LDS/barrier latency)
 __global__ __launch_bounds__(128 * WGN, WGN) void gemm_tn_bf16_kernel(const GemmParams p, float* __restrict__ colsum) {
   constexpr int BM = 128, BN = 128, BR = 64;          // output tile, reduction rows per stage
   constexpr int NT = 128 * WGN, NIT = 1024 / NT;      // threads, 16-B chunks per thread per operand image
@@ -803,6 +805,8 @@ __global__ __launch_bounds__(128 * WGN, WGN) void gemm_tn_bf16_kernel(const Gemm
   const bf16_t* a_ptr[NIT];
   const bf16_t* b_ptr[NIT];
   int s_row[NIT];
+  const int conv_tap = CONV ? n0 / p.conv_C : 0;
+  const int conv_dy = (conv_tap / 3 - 1) * p.conv_dil, conv_dx = (conv_tap % 3 - 1) * p.conv_dil;
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int P = it * NT + tid, row = P >> 4, c = P & 15;
@@ -810,7 +814,10 @@ __global__ __launch_bounds__(128 * WGN, WGN) void gemm_tn_bf16_kernel(const Gemm
     const int lc = ((((c >> 1) ^ f) << 1) | (c & 1)) * 8;     // logical column offset inside the 128-wide tile
     s_row[it] = row;
     a_ptr[it] = p.A + (long)(r_begin + row) * p.lda + min(m0 + lc, (int)p.lda - 8);
-    b_ptr[it] = p.B + (long)(r_begin + row) * p.ldb + min(n0 + lc, (int)p.ldb - 8);
+    if constexpr (CONV)   // the shifted pixel's channel chunk; validity is decided per stage from the row's (y, x)
+      b_ptr[it] = p.B + ((long)(r_begin + row) + (long)conv_dy * p.conv_W + conv_dx) * p.conv_C + (n0 - conv_tap * p.conv_C) + lc;
+    else
+      b_ptr[it] = p.B + (long)(r_begin + row) * p.ldb + min(n0 + lc, (int)p.ldb - 8);
   }
   const long a_step = 64 * p.lda, b_step = 64 * p.ldb;
   const bf16_t* zero = (const bf16_t*)vlb_zero16;
@@ -839,9 +846,38 @@ __global__ __launch_bounds__(128 * WGN, WGN) void gemm_tn_bf16_kernel(const Gemm
       __builtin_amdgcn_global_load_lds(GLDS_PTR(gb), LDS_PTR(sb + (it * NT + wave * 64) * 16), 16, 0, 0);
     }
   };
+  const float inv_w = CONV ? 1.0f / (float)p.conv_W : 0.f, inv_h = CONV ? 1.0f / (float)p.conv_H : 0.f;
+  auto stage_conv = [&](int buf, int kt) {   // B rows gathered at (y + dy, x + dx) with zero fill outside the image
+    char* sa = smem + buf * STAGE;
+    char* sb = sa + IMG;
+    const int rbase = r_begin + kt * BR;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int m = rbase + s_row[it];
+      const bool ok = m < r_end;
+      // m -> (y, x): float reciprocal + one correction step (m < 2^24)
+      int q = (int)((float)m * inv_w);
+      int x = m - q * p.conv_W;
+      if (x < 0) { x += p.conv_W; --q; } else if (x >= p.conv_W) { x -= p.conv_W; ++q; }
+      int q2 = (int)((float)q * inv_h);
+      int y = q - q2 * p.conv_H;
+      if (y < 0) y += p.conv_H; else if (y >= p.conv_H) y -= p.conv_H;
+      const bool in = ok && (unsigned)(y + conv_dy) < (unsigned)p.conv_H && (unsigned)(x + conv_dx) < (unsigned)p.conv_W;
+      const bf16_t* ga = ok ? a_ptr[it] : zero;
+      const bf16_t* gb = in ? b_ptr[it] : zero;
+      __builtin_amdgcn_global_load_lds(GLDS_PTR(ga), LDS_PTR(sa + (it * NT + wave * 64) * 16), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GLDS_PTR(gb), LDS_PTR(sb + (it * NT + wave * 64) * 16), 16, 0, 0);
+      a_ptr[it] += a_step;
+      b_ptr[it] += b_step;
+    }
+  };
   auto stage = [&](int buf, int kt) {
-    if (kt < nfull) stage_full(buf);
-    else stage_tail(buf, kt);
+    if constexpr (CONV) {
+      stage_conv(buf, kt);
+    } else {
+      if (kt < nfull) stage_full(buf);
+      else stage_tail(buf, kt);
+    }
   };
 
   f32x4 acc[FM][FN];
@@ -1390,6 +1426,62 @@ extern "C" int vlb_wgrad_tn_bf16(const void* A, long lda, const void* B, long ld
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)blocks), dim3(256), 0, stream, workspace, (long)Mo * ldw, nsp, C, ldc, Mo, No,
                        (int)ldw, (bf16_t*)nullptr, 0L, accumulate);
     VLB_CHECK_LAUNCH("vlb_wgrad_tn_bf16(reduce)");
+  }
+  return VLB_OK;
+}
+
+// dW[O, 9C] (fp32) (+)= dy[R, O]^T . im2col(x)[R, 9C] for a 3x3 / stride 1 / padding = dilation convolution on the NHWC
+// activation x [R = N*H*W, C], C % 128 == 0 -- the TN kernel gathers the shifted pixels itself (no im2col image).
+extern "C" int vlb_conv3x3_wgrad_tn_bf16(const void* dy, long lddy, const void* x, int N, int H, int W, int C, int dil, float* dW,
+                                         long lddw, int O, float* workspace, long workspace_floats, int accumulate, hipStream_t stream) {
+  if (N <= 0 || O <= 0) return VLB_OK;
+  VLB_CHECK_ARG(dy && x && dW, "vlb_conv3x3_wgrad_tn_bf16: null operand");
+  VLB_CHECK_ARG(C > 0 && (C % 128) == 0, "vlb_conv3x3_wgrad_tn_bf16: C=%d must be a multiple of 128", C);
+  VLB_CHECK_ARG((lddy % 8) == 0 && lddy >= O && (lddw % 4) == 0 && lddw >= 9L * C, "vlb_conv3x3_wgrad_tn_bf16: bad leading dimensions");
+  VLB_CHECK_ARG(H > 0 && W > 0 && dil >= 1 && (long)N * H * W < (1L << 24), "vlb_conv3x3_wgrad_tn_bf16: bad geometry (rows must be < 2^24)");
+  const int R = N * H * W, Mo = O, No = 9 * C;
+  const int Rp = vlb_cdiv(R, 64) * 64;
+  const int splits = wgrad_pick_splits(Mo, No, Rp, workspace ? workspace_floats : 0);
+  const int ktiles = Rp / 64;
+  const int per = vlb_cdiv(ktiles, splits);
+  const int nsp = vlb_cdiv(ktiles, per);
+  const long ldw = No;
+  GemmParams p;
+  p.A = (const bf16_t*)dy; p.lda = lddy; p.B = (const bf16_t*)x; p.ldb = C;
+  p.M = Mo; p.N = No; p.K = R; p.k_per_split = per * 64;
+  p.bias = nullptr; p.act = 0; p.aux = nullptr; p.ldaux = 0; p.pre = nullptr; p.ldpre = 0; p.res = nullptr; p.ldres = 0;
+  p.drop_thr = 0; p.drop_scale = 1.f; p.seed = nullptr; p.tag = 0;
+  p.conv_C = C; p.conv_H = H; p.conv_W = W; p.conv_dil = dil; p.zero = nullptr;
+  if (nsp == 1) {
+    p.C = dW; p.ldc = lddw; p.out_f32 = accumulate ? 3 : 1; p.c_split_stride = 0;
+  } else {
+    p.C = workspace; p.ldc = ldw; p.out_f32 = 1; p.c_split_stride = (long)Mo * ldw;
+  }
+  p.ntm = vlb_cdiv(Mo, 128); p.ntn = No / 128;
+  {
+    const double per_xcd = (double)p.ntm * p.ntn / 8.0;
+    int gm = (2 * p.ntn >= p.ntm) ? (int)(sqrt(per_xcd) + 0.5) : 1;
+    if (gm > p.ntm) gm = p.ntm;
+    if (gm < 1) gm = 1;
+    p.tile_group = gm;
+  }
+  constexpr int smem = 2 * 2 * 64 * 128 * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_tn_bf16_kernel<4, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)gemm_tn_bf16_kernel<4, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_set = true;
+  }
+  const dim3 grid(p.ntm * p.ntn, nsp);
+  if (p.out_f32 == 3) hipLaunchKernelGGL((gemm_tn_bf16_kernel<4, 3, true>), grid, dim3(512), smem, stream, p, (float*)nullptr);
+  else hipLaunchKernelGGL((gemm_tn_bf16_kernel<4, 1, true>), grid, dim3(512), smem, stream, p, (float*)nullptr);
+  VLB_CHECK_LAUNCH("vlb_conv3x3_wgrad_tn_bf16");
+  if (nsp > 1) {
+    long blocks = ((long)Mo * (ldw / 4) + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)blocks), dim3(256), 0, stream, workspace, (long)Mo * ldw, nsp, dW, lddw, Mo, No,
+                       (int)ldw, (bf16_t*)nullptr, 0L, accumulate);
+    VLB_CHECK_LAUNCH("vlb_conv3x3_wgrad_tn_bf16(reduce)");
   }
   return VLB_OK;
 }

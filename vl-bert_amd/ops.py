@@ -356,6 +356,15 @@ def conv3x3_nhwc(x, w, y, N, H, W, C, dil, zero16, bias=None, act=ACT_NONE, aux=
     return y
 
 
+def conv3x3_wgrad_tn(dy, x, dW, N, H, W, C, dil, workspace=None, accumulate=True):
+    """dW fp32 [O, 9C] (+)= dy[N*H*W, O]^T . im2col(x) with the gather inside the TN GEMM (C % 128 == 0)."""
+    O = dW.shape[0]
+    assert dy.shape[0] == N * H * W and dy.shape[1] == O and x.shape[0] == dy.shape[0] and x.shape[1] == C and x.is_contiguous()
+    _lib.call("vlb_conv3x3_wgrad_tn_bf16", _p(dy, BF16), _ld(dy), _p(x, BF16), N, H, W, C, dil, _p(dW, torch.float32), _ld(dW), O,
+              _p(workspace, torch.float32), workspace.numel() if workspace is not None else 0, int(bool(accumulate)), _stream())
+    return dW
+
+
 def im2col_nhwc(x, col, N, H, W, C, k, stride, pad, dil):
     _lib.call("vlb_im2col_nhwc_bf16", _p(x, BF16), _p(col, BF16), _ld(col), N, H, W, C, k, k, stride, pad, dil, _stream())
     return col

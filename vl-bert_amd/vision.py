@@ -165,7 +165,7 @@ class VisionStack:
             b["r"] = zb(M, 4 * P) if b["downsample"] else None
             if tr and not self.implicit:
                 b["col"] = zb(M, 9 * P)                      # kept for the weight gradient
-            elif tr or not self.implicit:                    # implicit: built in backward for the wgrad, shared; frozen + implicit: none
+            elif (tr and P % 128 != 0) or not self.implicit:  # implicit: only when the TN gather cannot be used (C % 128), built in backward
                 if (M, P) not in shared_col:
                     shared_col[(M, P)] = zb(M, 9 * P)
                 b["col"] = shared_col[(M, P)]
@@ -324,8 +324,13 @@ class VisionStack:
         self._wgrad(c3, dz, b["b"])
         ops.gemm_nt(dz, c3.wb, db, act=ops.ACT_RELU_MASK, aux=b["b"])
         if self.implicit:
-            ops.im2col_nhwc(b["a"], b["col"], n, h, w, P, 3, 1, b["dil"], b["dil"])
-            self._wgrad(c2, db, b["col"])
+            if b["col"] is None:      # weight gradient with the gather inside the TN GEMM
+                dw = self.dwf[:c2.O * c2.kf].view(c2.O, c2.kf)
+                ops.conv3x3_wgrad_tn(db, b["a"], dw, n, h, w, P, b["dil"], workspace=self.wg_ws, accumulate=False)
+                ops.conv_wgrad_finalize(dw, c2.scale, c2.g32, accumulate=True)
+            else:
+                ops.im2col_nhwc(b["a"], b["col"], n, h, w, P, 3, 1, b["dil"], b["dil"])
+                self._wgrad(c2, db, b["col"])
             ops.conv3x3_nhwc(db, c2.wb, da, n, h, w, P, b["dil"], self.zero16, act=ops.ACT_RELU_MASK, aux=b["a"])
         else:
             self._wgrad(c2, db, b["col"])
