@@ -102,6 +102,12 @@ class VisionStack:
         # im2col image is only materialised in backward, for the TN weight gradient.  VLB_CONV_IMPLICIT=0: explicit im2col + GEMM.
         self.implicit = os.environ.get("VLB_CONV_IMPLICIT", "1") != "0"
         self.zero16 = torch.zeros(64, dtype=BF16, device=d)
+        # Weight gradients run on a second stream (they only feed the optimizer; the dgrad chain is the critical path and these
+        # GEMMs are too small to fill 256 CUs one at a time).  Hazards are tracked per buffer: a wgrad starts after the event
+        # recorded behind its producers, and whoever overwrites one of its inputs first waits for the event recorded behind it
+        # (da / db are double-buffered by block parity so that wait is two blocks old).  VLB_VISION_WGRAD_STREAM=0 serialises.
+        self.side = torch.cuda.Stream(device=d) if (d.type == "cuda" and os.environ.get("VLB_VISION_WGRAD_STREAM", "1") != "0") else None
+        self._pending = {}
         min_train = min(b["stage"] for b in self.blocks if b["stage"] not in self.frozen_stages)
         if any(b["stage"] in self.frozen_stages and b["stage"] > min_train for b in self.blocks):
             raise NotImplementedError("frozen stages must be a prefix of the network")
@@ -174,7 +180,7 @@ class VisionStack:
             if L not in self.groups:
                 g = dict(M=M, P=P, C=C, n=n, h=h, w=w)
                 if tr:
-                    g.update(dzA=zb(M, 4 * P), dzB=zb(M, 4 * P), da=zb(M, P), db=zb(M, P),
+                    g.update(dzA=zb(M, 4 * P), dzB=zb(M, 4 * P), da=[zb(M, P), zb(M, P)], db=[zb(M, P), zb(M, P)],
                              dcol=None if self.implicit else zb(M, 9 * P), tmp=zb(M, C), dxs=zb(M, C))
                 self.groups[L] = g
             if tr:
@@ -305,11 +311,45 @@ class VisionStack:
         return x
 
     # ------------------------------------------------------------------------------------------------------------------
-    def _wgrad(self, c, dy, x):
-        """g32 += scale[o] * (dy^T x) for the folded operand."""
-        dw = self.dwf[:c.O * c.kf].view(c.O, c.kf)
-        ops.wgrad_tn(dy, x, dw, workspace=self.wg_ws, accumulate=False)
-        ops.conv_wgrad_finalize(dw, c.scale, c.g32, accumulate=True)
+    def _side_run(self, fn, *reads):
+        """Run fn on the weight-gradient stream after everything enqueued so far; `reads` are the transient buffers it reads."""
+        if self.side is None:
+            fn()
+            return
+        ready = torch.cuda.Event()
+        ready.record()
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ready)
+            fn()
+            done = torch.cuda.Event()
+            done.record()
+        for t in reads:
+            self._pending[t.data_ptr()] = done
+
+    def _before_write(self, *bufs):
+        for t in bufs:
+            ev = self._pending.pop(t.data_ptr(), None) if t is not None else None
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)
+
+    def _join_side(self):
+        if self.side is not None:
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+            torch.cuda.current_stream().wait_event(ev)
+            self._pending.clear()
+
+    def _wgrad(self, c, dy, x, conv=None):
+        """g32 += scale[o] * (dy^T x) for the folded operand; conv = (n, h, w, C, dil): x is the NHWC activation and the im2col
+        gather happens inside the TN GEMM."""
+        def run():
+            dw = self.dwf[:c.O * c.kf].view(c.O, c.kf)
+            if conv is None:
+                ops.wgrad_tn(dy, x, dw, workspace=self.wg_ws, accumulate=False)
+            else:
+                ops.conv3x3_wgrad_tn(dy, x, dw, *conv, workspace=self.wg_ws, accumulate=False)
+            ops.conv_wgrad_finalize(dw, c.scale, c.g32, accumulate=True)
+        self._side_run(run, dy)
 
     def _block_bwd(self, b, dz, dx_out, need_dx, mask_input):
         """dz: masked gradient of this block's pre-ReLU output [M, 4P].  Writes the (masked) gradient of the block input into
@@ -320,15 +360,16 @@ class VisionStack:
         c1, c2, c3 = cv[k + "conv1"], cv[k + "conv2"], cv[k + "conv3"]
         x = b["x"]
         xs = b["xs"] if b["stride"] == 2 else x
-        da, db = g["da"], g["db"]
+        da, db = g["da"][b["index"] & 1], g["db"][b["index"] & 1]
         self._wgrad(c3, dz, b["b"])
+        self._before_write(db)
         ops.gemm_nt(dz, c3.wb, db, act=ops.ACT_RELU_MASK, aux=b["b"])
+        self._before_write(da)
         if self.implicit:
             if b["col"] is None:      # weight gradient with the gather inside the TN GEMM
-                dw = self.dwf[:c2.O * c2.kf].view(c2.O, c2.kf)
-                ops.conv3x3_wgrad_tn(db, b["a"], dw, n, h, w, P, b["dil"], workspace=self.wg_ws, accumulate=False)
-                ops.conv_wgrad_finalize(dw, c2.scale, c2.g32, accumulate=True)
+                self._wgrad(c2, db, b["a"], conv=(n, h, w, P, b["dil"]))
             else:
+                self._join_side()     # (shared im2col buffer)
                 ops.im2col_nhwc(b["a"], b["col"], n, h, w, P, 3, 1, b["dil"], b["dil"])
                 self._wgrad(c2, db, b["col"])
             ops.conv3x3_nhwc(db, c2.wb, da, n, h, w, P, b["dil"], self.zero16, act=ops.ACT_RELU_MASK, aux=b["a"])
@@ -346,6 +387,7 @@ class VisionStack:
         if cd is not None:
             res = ops.gemm_nt(dz, cd.wb, g["tmp"])
         target = g["dxs"] if b["stride"] == 2 else dx_out
+        self._before_write(dx_out)
         if mask_input:
             ops.gemm_nt(da, c1.wb, target, res=res, act=ops.ACT_RELU_MASK, aux=xs)
         else:
@@ -356,12 +398,17 @@ class VisionStack:
     def backward(self, d_feat, boxes, drop_p=0.0, seed=None, tag=0, drop_row_elems=2 * VIS_DIM, drop_col0=VIS_DIM):
         """d_feat bf16 [K, 2048]: gradient w.r.t. the feature half of obj_downsample's (dropped-out) input; accumulates the weight
         gradients of the trainable convolutions."""
+        self._backward(d_feat, boxes, drop_p, seed, tag, drop_row_elems, drop_col0)
+        self._join_side()        # every weight gradient is complete for whatever the caller enqueues next
+
+    def _backward(self, d_feat, boxes, drop_p, seed, tag, drop_row_elems, drop_col0):
         K = self.K
         box_rows = boxes.view(K, boxes.shape[2])
         blocks = [b for b in self.blocks if b["trainable"]]
         first = blocks[0]
         last = self.blocks[-1]
         g4 = self.groups[4]
+        self._before_write(g4["dzA"])
         cur = ops.avgpool_rows_bwd(d_feat, last["y"], box_rows, g4["dzA"], K, self.P_roi, self.Cout, drop_p=drop_p, seed=seed, tag=tag,
                                    drop_row_elems=drop_row_elems, drop_col0=drop_col0)
         for b in reversed(blocks):
@@ -380,6 +427,7 @@ class VisionStack:
                 ops.roi_align_nhwc_bwd(g["dxs"], box_rows, self.R, self.dfeat32, self.N, self.H3, self.W3, self.C3, self.pooled,
                                        self.scale, self.sr)
                 g3 = self.groups[3]
+                self._before_write(g3["dzA"])
                 cur = ops.relu_mask_cast(self.dfeat32, self.body4, g3["dzA"])
             elif b is first:
                 self._block_bwd(b, cur, None, False, False)
