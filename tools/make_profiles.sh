@@ -17,4 +17,8 @@ rocprofv3 --kernel-trace --stats -d "$OUT/final_trace" -o r -- $CMD > "$OUT/fina
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY -d "$OUT/final_sq" -o r -- $CMD > "$OUT/final_sq.log" 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/final_fetch" -o r -- $CMD > "$OUT/final_fetch.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/final_write" -o r -- $CMD > "$OUT/final_write.log" 2>&1
+# e2e configuration (C3: ResNet-101 trunk + ROIAlign + layer4 head in front of the same step), kernel trace only
+export VLB_VISION_WGRAD_STREAM=0
+rocprofv3 --kernel-trace --stats -d "$OUT/final_e2e_trace" -o r -- $CMD --e2e > "$OUT/final_e2e_trace.log" 2>&1
 grep '"metric"' "$OUT/final_trace.log" | tail -1 | cut -c1-200
+grep '"metric"' "$OUT/final_e2e_trace.log" | tail -1 | cut -c1-200

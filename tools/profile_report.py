@@ -39,28 +39,37 @@ def family(n):
 
 
 # ---------------------------------------------------------------- kernel time
-cur = db("final_trace").cursor()
-rows = cur.execute("select name, end - start from kernels").fetchall()
-agg = {}
-for n, d in rows:
-    a = agg.setdefault(short(n), [0, 0.0, 1e30, 0.0])
-    a[0] += 1; a[1] += d; a[2] = min(a[2], d); a[3] = max(a[3], d)
-total = sum(a[1] for a in agg.values())
-line = ""
-for l in open(os.path.join(src, "final_trace.log"), errors="replace"):
-    if '"metric"' in l:
-        line = l.strip()
-with open(os.path.join(dst, tag + "_kernel_stats.txt"), "w") as f:
-    f.write("# VLB_WGRAD_STREAM=0 rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline\n"
-            "# (MI355X; %d steps in the process: 1 warm-up + 3 timed + 1 instrumented; the fill / copy kernels are mostly one-time\n"
-            "# buffer setup; weight-gradient stream serialised so that per-kernel durations are not inflated by overlap --\n"
-            "# the default bench run overlaps them)\n" % steps)
-    f.write("# summarised from the rocpd sqlite output by tools/profile_report.py; bench line of the same (profiled) run:\n# %s\n" % line)
-    f.write("%-66s %7s %10s %10s %9s %9s %9s %7s\n" % ("kernel", "calls", "total_ms", "ms/step", "avg_us", "min_us", "max_us", "share"))
-    for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-        f.write("%-66s %7d %10.3f %10.3f %9.2f %9.2f %9.2f %6.1f%%\n" % (k, a[0], a[1] / 1e6, a[1] / 1e6 / steps, a[1] / a[0] / 1e3,
-                                                                      a[2] / 1e3, a[3] / 1e3, 100 * a[1] / total))
-    f.write("%-66s %7s %10.3f %10.3f\n" % ("TOTAL kernel time", "", total / 1e6, total / 1e6 / steps))
+def kernel_stats(trace, out_name, cmd_note):
+    cur = db(trace).cursor()
+    rows = cur.execute("select name, end - start from kernels").fetchall()
+    agg = {}
+    for n, d in rows:
+        a = agg.setdefault(short(n), [0, 0.0, 1e30, 0.0])
+        a[0] += 1; a[1] += d; a[2] = min(a[2], d); a[3] = max(a[3], d)
+    total = sum(a[1] for a in agg.values())
+    line = ""
+    for l in open(os.path.join(src, trace + ".log"), errors="replace"):
+        if '"metric"' in l:
+            line = l.strip()
+    with open(os.path.join(dst, out_name), "w") as f:
+        f.write(cmd_note)
+        f.write("# (MI355X; %d steps in the process: 1 warm-up + 3 timed + 1 instrumented; the fill / copy kernels are mostly one-time\n"
+                "# buffer setup; weight-gradient streams serialised so that per-kernel durations are not inflated by overlap --\n"
+                "# the default bench run overlaps them)\n" % steps)
+        f.write("# summarised from the rocpd sqlite output by tools/profile_report.py; bench line of the same (profiled) run:\n# %s\n" % line)
+        f.write("%-66s %7s %10s %10s %9s %9s %9s %7s\n" % ("kernel", "calls", "total_ms", "ms/step", "avg_us", "min_us", "max_us", "share"))
+        for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            f.write("%-66s %7d %10.3f %10.3f %9.2f %9.2f %9.2f %6.1f%%\n" % (k, a[0], a[1] / 1e6, a[1] / 1e6 / steps, a[1] / a[0] / 1e3,
+                                                                          a[2] / 1e3, a[3] / 1e3, 100 * a[1] / total))
+        f.write("%-66s %7s %10.3f %10.3f\n" % ("TOTAL kernel time", "", total / 1e6, total / 1e6 / steps))
+
+
+kernel_stats("final_trace", tag + "_kernel_stats.txt",
+             "# VLB_WGRAD_STREAM=0 rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline\n")
+if glob.glob(os.path.join(src, "final_e2e_trace", "*.db")):
+    kernel_stats("final_e2e_trace", tag + "_e2e_kernel_stats.txt",
+                 "# VLB_WGRAD_STREAM=0 VLB_VISION_WGRAD_STREAM=0 rocprofv3 --kernel-trace --stats -- python bench.py --e2e --steps 3 --warmup 1 "
+                 "--no-graph --no-cpu-baseline\n# (config C3: 8 images of 600x1000, ResNet-101 trunk + ROIAlign + dilated layer4 head + the VL-BERT step)\n")
 
 
 # ---------------------------------------------------------------- PMC helpers
