@@ -360,10 +360,10 @@ def test_engine_e2e_step_vs_oracle():
     out, loss = O.pretrain_forward(leaves, cfg, *batch, train=False, image=img, vision_params=Po, image_num_layers=nl)
     loss.backward()
     lv = eng.loss_values()
-    print("e2e losses: hip mlm %.5f mvrc %.5f | oracle mlm %.5f mvrc %.5f" % (lv["mlm_loss"], lv["mvrc_loss"], float(out["mlm_loss"]),
-                                                                              float(out["mvrc_loss"])))
+    print("e2e losses: hip mlm %.5f mvrc %.5f | oracle mlm %.5f mvrc %.5f" % (lv["mlm_loss"], lv["mvrc_loss"], float(out["mlm_loss"].detach()),
+                                                                              float(out["mvrc_loss"].detach())))
     assert abs(lv["mlm_loss"] - float(out["mlm_loss"])) < 2e-2 * max(1.0, abs(float(out["mlm_loss"])))
-    assert abs(lv["mvrc_loss"] - float(out["mvrc_loss"])) < 2e-2 * max(1.0, abs(float(out["mvrc_loss"])))
+    assert abs(lv["mvrc_loss"] - float(out["mvrc_loss"])) < 2e-2 * max(1.0, abs(float(out["mvrc_loss"].detach())))
     names = dict(zip(VO.split_state_dict(P).keys(), P.keys()))
     errs = []
     for name, g in eng.vision.grads().items():
@@ -385,3 +385,61 @@ def test_engine_e2e_step_vs_oracle():
     moved = [k for k in before if not torch.equal(before[k], after[k])]
     trainable = set(eng.vision.grads())
     assert set(moved) == trainable, (set(moved) ^ trainable)
+
+
+def test_dropin_module_e2e_training_loop_contract():
+    """The `ResNetVLBERTForPretraining` mirror in the e2e configuration (IMAGE_FEAT_PRECOMPUTED false): reference-layout
+    checkpoint in, `outputs, loss = net(image, boxes, ...)`, `loss.backward()`, torch optimizer step, reference-layout checkpoint out."""
+    from tests.test_engine_gpu import _module_config
+    M = pkg("pretrain.modules.resnet_vlbert_for_pretraining")
+    syn = pkg("synthetic")
+    z, nl, P = _vision_fixture()
+    img, boxes4 = torch.from_numpy(z["img"]), torch.from_numpy(z["boxes"])
+    B, R, T = boxes4.shape[0], boxes4.shape[1], 12
+    cfg = O.VLBertConfig(num_hidden_layers=1)
+    params = O.init_params(cfg, seed=21)
+    conf = _module_config(cfg)
+    conf["NETWORK"].update(IMAGE_FEAT_PRECOMPUTED=False, IMAGE_NUM_LAYERS=nl, IMAGE_FROZEN_BACKBONE_STAGES=[1, 2], IMAGE_FROZEN_BN=True,
+                           IMAGE_STRIDE_IN_1x1=True, IMAGE_C5_DILATED=True)
+    net = M.ResNetVLBERTForPretraining(conf, device="cuda:0")
+    ref_sd = dict(params)
+    ref_sd.update(_prefixed(P))
+    net.load_state_dict({k: v for k, v in ref_sd.items()})
+    net.eval()
+    batch = list(syn.make_batch(B, T, R, seed=22, ragged=False))
+    batch[0] = boxes4.clone()                                             # e2e collate: boxes [B,R,4]
+    batch[1] = torch.from_numpy(z["im_info"])
+    pad = boxes4[:, :, 0] <= -1.5
+    batch[5][pad] = 0
+    batch[6][pad] = 0
+    outputs, loss = net(img.to(dev()), *[t.to(dev()) for t in batch])
+    frozen = VO.frozen_names(P)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    Po = {k: v.clone().requires_grad_(k not in frozen) for k, v in P.items()}
+    obatch = list(batch)
+    obatch[0] = torch.cat((boxes4, torch.zeros(B, R, 2048)), -1)
+    out, oloss = O.pretrain_forward(leaves, cfg, *obatch, train=False, image=img, vision_params=Po, image_num_layers=nl)
+    print("e2e module loss: hip %.5f oracle %.5f" % (float(loss), float(oloss)))
+    assert abs(float(loss) - float(oloss)) < 2e-2 * abs(float(oloss))
+    report("e2e module mlm_logits", outputs["mlm_logits"], out["mlm_logits"].detach(), 5e-2, 2e-2)
+    loss.backward()
+    oloss.backward()
+    name = "image_feature_extractor.roi_head_feature_extractor.2.conv2.weight"
+    g = dict(net.named_parameters())[name].grad                           # engine layout [O,KH,KW,I]
+    e = rel_fro(g.permute(0, 3, 1, 2), Po["layer4.2.conv2.weight"].grad)
+    print("e2e module: d %s rel-fro %.3e" % (name, e))
+    assert e < 5e-2
+    trainable = {n for n, p in net.named_parameters() if p.requires_grad}
+    assert "image_feature_extractor.backbone.layer1.0.conv1.weight" not in trainable      # frozen stage: a buffer
+    assert "image_feature_extractor.backbone.layer2.0.conv1.weight" in trainable
+    # checkpoint round trip in the reference's layout
+    sd = net.state_dict()
+    for k, v in _prefixed(P).items():
+        assert k in sd and tuple(sd[k].shape) == tuple(v.shape), k
+        assert torch.equal(sd[k].cpu(), v), k
+    opt = torch.optim.SGD([p for p in net.parameters() if p.requires_grad], lr=1e-3)
+    before = sd[name].clone()
+    opt.step()
+    _, loss2 = net(img.to(dev()), *[t.to(dev()) for t in batch])          # weights re-synchronised (bf16 / folded copies) on use
+    assert not torch.equal(net.state_dict()[name], before)
+    assert torch.isfinite(loss2)

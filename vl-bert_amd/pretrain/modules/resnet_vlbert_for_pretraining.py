@@ -14,6 +14,10 @@ How it maps onto the engine:
 Supported configuration = the north-star one (cfgs/pretrain/base_prec_withouttextonly_4x16G_fp32.yaml):
 IMAGE_FEAT_PRECOMPUTED, WITH_MLM_LOSS, WITH_MVRC_LOSS, visual_ln; the pooler and the relationship head / loss
 (WITH_REL_LOSS, off in every shipped pretrain cfg) are available too.
+IMAGE_FEAT_PRECOMPUTED: false (cfgs/pretrain/base_e2e_16x16G_fp16.yaml) runs the ResNet trunk / ROIAlign / layer4 head of
+vision.py in front: `forward(image, boxes[B,R,4], ...)`.  The trainable convolution weights are Parameters that view the
+flat buffer in the engine's [O,KH,KW,I] layout (state_dict / load_state_dict convert from / to the reference's [O,I,KH,KW]);
+BatchNorm tensors and the frozen stages are buffers under the reference's names.  One image size per module (static shapes).
 Anything else raises NotImplementedError (nothing silently falls back to PyTorch eager).
 """
 import torch
@@ -54,8 +58,14 @@ class ResNetVLBERTForPretraining(nn.Module):
         self.config = config
         net = _get(config, "NETWORK")
         vl = _get(net, "VLBERT")
-        if not _get(net, "IMAGE_FEAT_PRECOMPUTED", False):
-            raise NotImplementedError("end-to-end ResNet-101/RoIAlign image path is not built yet (SURVEY.md §8f rank 3)")
+        self.e2e = not _get(net, "IMAGE_FEAT_PRECOMPUTED", False)
+        if self.e2e:
+            if self.MULTITASK:
+                raise NotImplementedError("e2e image path in the multitask wrapper is not supported")
+            if not (_get(net, "IMAGE_FROZEN_BN", True) and _get(net, "IMAGE_STRIDE_IN_1x1", True) and _get(net, "IMAGE_C5_DILATED", True)):
+                raise NotImplementedError("e2e path needs IMAGE_FROZEN_BN, IMAGE_STRIDE_IN_1x1 and IMAGE_C5_DILATED (the shipped e2e cfgs)")
+            if _get(net, "OUTPUT_CONV5", False):
+                raise NotImplementedError("OUTPUT_CONV5 is not supported")
         self.with_rel = bool(_get(net, "WITH_REL_LOSS", False))
         if self.with_rel and not _get(vl, "with_pooler", False):
             raise ValueError("WITH_REL_LOSS needs VLBERT.with_pooler (the relationship head reads the pooled output)")
@@ -74,7 +84,9 @@ class ResNetVLBERTForPretraining(nn.Module):
             type_vocab_size=_get(vl, "type_vocab_size", 3), visual_region_classes=_get(vl, "visual_region_classes", 1601),
             hidden_dropout_prob=_get(vl, "hidden_dropout_prob", 0.1),
             attention_probs_dropout_prob=_get(vl, "attention_probs_dropout_prob", 0.1), multitask=self.MULTITASK,
-            with_pooler=bool(_get(vl, "with_pooler", False)), with_rel_loss=self.with_rel)
+            with_pooler=bool(_get(vl, "with_pooler", False)), with_rel_loss=self.with_rel, e2e=self.e2e,
+            image_num_layers=int(_get(net, "IMAGE_NUM_LAYERS", 101)),
+            image_frozen_stages=tuple(_get(net, "IMAGE_FROZEN_BACKBONE_STAGES", (1, 2))))
         self.cfg.validate()
         if not torch.cuda.is_available():
             raise RuntimeError("ResNetVLBERTForPretraining (HIP) needs an MI355X: there is no CPU fallback")
@@ -87,6 +99,16 @@ class ResNetVLBERTForPretraining(nn.Module):
         self._pnames = {}
         for name, t in self.flat.named(self.flat.master).items():
             self._register(name, nn.Parameter(t, requires_grad=True))
+        self._vision_buffers = {}
+        if self.e2e:      # BatchNorm tensors + frozen-stage weights: buffers in the reference's layout, handed to each engine's VisionStack
+            from ... import vision as _vision
+            for key, O, I, k, bn, tr in _vision.conv_table(self.cfg.image_num_layers, self.cfg.image_frozen_stages):
+                if not tr:
+                    self._register_buffer(_vision.PREFIX + key + ".weight", torch.zeros((O, I, k, k), device=self.device_))
+                for suffix, fill in (("weight", 1.0), ("bias", 0.0), ("running_mean", 0.0), ("running_var", 1.0)):
+                    self._register_buffer(_vision.PREFIX + bn + "." + suffix, torch.full((O,), fill, device=self.device_))
+            self._vision_names = set(_vision.vision_param_layout(self.cfg.image_num_layers, self.cfg.image_frozen_stages))
+            self._image_size = None
         self.init_weight()
 
     # -- parameter plumbing -----------------------------------------------------------------------
@@ -99,6 +121,16 @@ class ResNetVLBERTForPretraining(nn.Module):
             mod = getattr(mod, p)
         mod.register_parameter(parts[-1], param)
         self._pnames[dotted] = param
+
+    def _register_buffer(self, dotted, t):
+        mod = self
+        parts = dotted.split(".")
+        for p in parts[:-1]:
+            if not hasattr(mod, p):
+                mod.add_module(p, nn.Module())
+            mod = getattr(mod, p)
+        mod.register_buffer(parts[-1], t)
+        self._vision_buffers[dotted] = t
 
     def init_weight(self):
         """BaseModel.init_weights / ResNetVLBERTForPretraining.init_weight statistics
@@ -114,18 +146,33 @@ class ResNetVLBERTForPretraining(nn.Module):
                     p.fill_(1.0)
                 elif name.endswith(".bias") or name == "object_mask_visual_embedding.weight":
                     p.zero_()
+                elif self.e2e and name in self._vision_names:      # kaiming fan_out (resnet.py:153-155); a checkpoint normally follows
+                    p.normal_(0.0, (2.0 / (p.shape[0] * p.shape[1] * p.shape[2])) ** 0.5)
                 else:
                     p.normal_(0.0, std)
+            for name, t in self._vision_buffers.items():
+                if name.endswith(".weight") and t.dim() == 4:
+                    t.normal_(0.0, (2.0 / (t.shape[0] * t.shape[2] * t.shape[3])) ** 0.5)
+        self._buffers_version = getattr(self, "_buffers_version", 0) + 1
 
     def state_dict(self, *args, **kwargs):
         sd = super().state_dict(*args, **kwargs)
         prefix = kwargs.get("prefix", args[1] if len(args) > 1 else "")
         sd[prefix + _engine.TIED_DECODER_KEY] = sd[prefix + "vlbert.word_embeddings.weight"]   # tied (modeling.py:463-466)
+        if self.e2e:      # trainable convolutions: engine layout [O,KH,KW,I] -> reference layout [O,I,KH,KW]
+            for name in self._vision_names:
+                sd[prefix + name] = sd[prefix + name].permute(0, 3, 1, 2).contiguous()
         return sd
 
     def load_state_dict(self, state_dict, strict=True):
         state_dict = dict(state_dict)
         state_dict.pop(_engine.TIED_DECODER_KEY, None)
+        if self.e2e:
+            for name in self._vision_names:
+                if name in state_dict:
+                    state_dict[name] = state_dict[name].permute(0, 2, 3, 1).contiguous()
+            state_dict = {k: v for k, v in state_dict.items() if not k.endswith("num_batches_tracked")}
+            self._buffers_version += 1
         return super().load_state_dict(state_dict, strict=strict)
 
     def _prepare_grads(self):
@@ -137,13 +184,17 @@ class ResNetVLBERTForPretraining(nn.Module):
             for name, t in self.flat.named(self.flat.grad).items():
                 self._pnames[name].grad = t
 
-    def _engine_for(self, B, T, R, B_aux=0):
-        key = (B, T, R, B_aux)
+    def _engine_for(self, B, T, R, B_aux=0, image_size=None):
+        key = (B, T, R, B_aux, image_size)
         if key not in self._engines:
             eng = _engine.PretrainEngine(self.cfg, B, T, R, device=str(self.device_), keep_logits=True, flat=self.flat,
-                                         B_aux=B_aux)
+                                         B_aux=B_aux, image_size=image_size)
             self._engines[key] = eng
         eng = self._engines[key]
+        if self.e2e and getattr(eng, "_buffers_version", None) != self._buffers_version:
+            eng.vision.load_state_dict(self._vision_buffers, strict=False)      # BatchNorm tensors + frozen stages (trainables live in flat)
+            eng._buffers_version = self._buffers_version
+            eng._synced_version = None
         version = self.flat.master._version                       # bumped by any in-place update of a parameter view
         if getattr(eng, "_synced_version", None) != version:      # optimizer step / load_state_dict: refresh bf16 + W^T copies
             eng.sync_weights()
@@ -163,12 +214,16 @@ class ResNetVLBERTForPretraining(nn.Module):
 
     # -- forward ------------------------------------------------------------------------------------
     def forward(self, image, boxes, im_info, text, relationship_label, mlm_labels, mvrc_ops, mvrc_labels):
-        if image is not None:
-            raise NotImplementedError("precomputed-feature configuration: pass image=None")
+        if (image is not None) != self.e2e:
+            raise NotImplementedError("IMAGE_FEAT_PRECOMPUTED configuration takes image=None, the e2e configuration an image batch")
         B, R = boxes.shape[0], boxes.shape[1]
         T = text.shape[1]
-        eng = self._engine_for(B, T, R)
-        eng.set_batch(boxes, im_info, text, relationship_label, mlm_labels, mvrc_ops, mvrc_labels)
+        if self.e2e:
+            eng = self._engine_for(B, T, R, image_size=(int(image.shape[2]), int(image.shape[3])))
+            eng.set_batch(boxes, im_info, text, relationship_label, mlm_labels, mvrc_ops, mvrc_labels, image=image.float())
+        else:
+            eng = self._engine_for(B, T, R)
+            eng.set_batch(boxes, im_info, text, relationship_label, mlm_labels, mvrc_ops, mvrc_labels)
         eng.forward(train=self.training)
         if self.training:
             ops.rng_advance(eng.seed)      # fresh dropout masks next step (the fused optimizer path does this itself)
