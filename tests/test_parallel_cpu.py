@@ -46,6 +46,32 @@ def test_buckets_tile_the_flat_buffer():
         assert fired[0] == 0
 
 
+def test_buckets_with_vision_tail_tile_the_flat_buffer():
+    """e2e layout: the trainable convolution weights sit behind the heads and form their own (last) bucket."""
+    E = importlib.import_module("vl-bert_amd.engine")
+    P = importlib.import_module("vl-bert_amd.parallel")
+    import math
+    cfg = E.ModelConfig(hidden_size=64, num_hidden_layers=2, num_attention_heads=1, intermediate_size=128, vocab_size=300,
+                        max_position_embeddings=32, visual_region_classes=20, e2e=True, image_num_layers=50)
+    shapes = E.param_layout(cfg)
+    offsets, off = {}, 0
+    for n, s in shapes.items():
+        offsets[n] = off
+        off = E._ru(off + math.prod(s), 64)
+    vis = [n for n in shapes if n.startswith("image_feature_extractor.") and "obj_downsample" not in n]
+    assert len(vis) == 42 and list(shapes)[-len(vis):] == vis            # appended LAST, contiguous
+    vstart = min(offsets[n] for n in vis)
+    b = P.GradBuckets(torch.zeros(off), offsets, off, cfg.num_hidden_layers, bucket_bytes=1 << 20, vision_start=vstart)
+    cov = b.coverage()
+    assert cov[0][0] == 0 and cov[-1] == (vstart, off)
+    for (lo, hi), (lo2, hi2) in zip(cov[:-1], cov[1:]):
+        assert hi == lo2 and lo < hi
+    launched = []
+    b._launch = lambda lo, hi: launched.append((lo, hi))
+    b.on_done("heads"); b.on_done(1); b.on_done(0); b.on_done("embed"); b.on_done("vision")
+    assert sorted(launched) == sorted(cov) and launched[-1] == (vstart, off)
+
+
 def _worker(rank, world, port, numel_holder):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
