@@ -188,6 +188,9 @@ int vlb_soft_ce_fwd_bwd(void* logits, long ld, int rows, int C, const float* tar
 int vlb_zero_ranges_f32(float* base, const int64_t* ranges, const int32_t* block_start, int n, int total_blocks, vlb_stream_t stream);
 
 int vlb_sumsq_f32(const float* g, long n, float* out, vlb_stream_t stream);
+/* same sum with a fixed summation order (per-block partials in `partials[partials_len]`, then one block): bit-identical on every
+ * data-parallel rank for identical gradients, so the clip coefficient -- and therefore the replicas' parameters -- cannot drift. */
+int vlb_sumsq_f32_det(const float* g, long n, float* partials, int partials_len, float* out, vlb_stream_t stream);
 int vlb_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, long n, float* state, float grad_scale,
                    vlb_stream_t stream);
 /* lr schedule evaluated on the device from state[5] (steps taken): state[0] = base_lr * lambda(step + 1), matching the

@@ -566,6 +566,25 @@ def test_adamw_and_sumsq(ops):
     assert float(state[5]) == 3.0 and float(state[7]) == 0.0
 
 
+def test_sumsq_deterministic(ops):
+    """vlb_sumsq_f32_det: right value, accumulates into *out, and the same bits on every call (the atomic version is not)."""
+    n = 3_000_017
+    g = torch.randn(n, generator=torch.Generator().manual_seed(51)).to(dev())
+    ws = torch.zeros(2048, device=dev())
+    outs = []
+    for _ in range(4):
+        out = torch.tensor([1.5], device=dev())
+        ops.sumsq_det(g, ws, out)
+        outs.append(float(out))
+    want = float((g.double() ** 2).sum()) + 1.5
+    assert abs(outs[0] - want) <= 2e-6 * want, (outs[0], want)
+    assert len(set(outs)) == 1, outs
+    small = torch.tensor([3.0, 4.0], device=dev())
+    out = torch.zeros(1, device=dev())
+    ops.sumsq_det(small, ws[:1], out)
+    assert float(out) == 25.0
+
+
 def test_lr_schedule_on_device(ops):
     """vlb_lr_schedule_step against torch's LambdaLR driven with the oracle's lr_lambda in the reference's order:
     scheduler.step() then optimizer.step() (common/trainer.py:131-147), so optimizer step k uses lambda(k)."""

@@ -51,7 +51,9 @@ def main():
     cov = eng.buckets.coverage()
     print("rank %d: reduced-vs-summed gradient max rel err %.2e over %d buckets (vision bucket: %s)" %
           (rank, err, len(cov), "vision" in eng.buckets.ranges), flush=True)
-    assert err < 1e-6, err
+    # two backward passes of one rank are not bit-identical (fp32 atomics: LayerNorm / embedding sums; e2e: ROIAlign backward, whose
+    # rounding to bf16 then propagates through the trunk), so this compares to a tolerance; check (1) below is exact
+    assert err < (1e-3 if e2e else 1e-6), err
     assert float((eng.P.grad - local).abs().max()) > 0
     # (1) two full steps -> identical parameters on both ranks
     for _ in range(2):
@@ -61,7 +63,8 @@ def main():
     other = mine.clone()
     dist.broadcast(other, src=0)
     same = bool(torch.equal(mine, other))
-    print("rank %d: parameters identical to rank 0 after 2 DP steps: %s ; loss %.4f" % (rank, same, eng.loss_values()["loss"]), flush=True)
+    print("rank %d: parameters identical to rank 0 after 2 DP steps: %s (max |diff| %.3e) ; loss %.4f" %
+          (rank, same, float((mine - other).abs().max()), eng.loss_values()["loss"]), flush=True)
     assert same
     dist.barrier()
     dist.destroy_process_group()

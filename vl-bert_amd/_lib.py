@@ -40,6 +40,7 @@ _SIGS = {
     "vlb_ce_fwd_bwd": "pliippfppls",
     "vlb_soft_ce_fwd_bwd": "pliiplppfppls",
     "vlb_sumsq_f32": "plps",
+    "vlb_sumsq_f32_det": "plpips",
     "vlb_adamw_step": "ppppplpfs",
     "vlb_lr_schedule_step": "pifffs",
     "vlb_conv_weight_prepare": "pppppfppppiiiis",

@@ -38,6 +38,37 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   if (threadIdx.x == 0) atomicAdd(out, sh[0] + sh[1] + sh[2] + sh[3]);
 }
 
+// Deterministic variant: per-block partial sums to a workspace, one block adds them in a fixed order.  The clip coefficient
+// derived from this sum multiplies every gradient, so with data parallelism a run-to-run / rank-to-rank difference in the
+// last bit (atomicAdd order above) makes the replicas' parameters drift apart; this one gives every rank the same bits.
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, long n, float* __restrict__ partials) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  const long stride = (long)gridDim.x * 256 * 4;
+  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 3 < n) {
+      const float4 v = *(const float4*)(g + i);
+      s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    } else {
+      for (long k = i; k < n; ++k) s += g[k] * g[k];
+    }
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restrict__ partials, int nparts, float* __restrict__ out) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += 256) s += partials[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) *out += (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, bf16_t* __restrict__ p16, long n, VlbAdamState* __restrict__ st,
                                                     float grad_scale) {
@@ -141,6 +172,17 @@ extern "C" int vlb_sumsq_f32(const float* g, long n, float* out, hipStream_t str
   VLB_CHECK_ARG(g && out, "vlb_sumsq_f32: null argument");
   hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, stream, g, n, out);
   VLB_CHECK_LAUNCH("vlb_sumsq_f32");
+  return VLB_OK;
+}
+
+extern "C" int vlb_sumsq_f32_det(const float* g, long n, float* partials, int partials_len, float* out, hipStream_t stream) {
+  if (n <= 0) return VLB_OK;
+  VLB_CHECK_ARG(g && out && partials && partials_len >= 1, "vlb_sumsq_f32_det: null argument");
+  int blocks = grid_for((n + 3) / 4);
+  if (blocks > partials_len) blocks = partials_len;
+  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(blocks), dim3(256), 0, stream, g, n, partials);
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, stream, partials, blocks, out);
+  VLB_CHECK_LAUNCH("vlb_sumsq_f32_det");
   return VLB_OK;
 }
 

@@ -244,6 +244,7 @@ class PretrainEngine:
         # device-resident step state
         self.seed = torch.tensor([seed | 1], dtype=torch.int32, device=d)
         self.adam = torch.tensor([lr, betas[0], betas[1], eps, weight_decay, 0.0, max_grad_norm, 0.0], dtype=F32, device=d)
+        self.sumsq_ws = zf(2048)  # per-block partial sums of the gradient norm
         self.losses = zf(4)       # mlm (with visual content), mvrc, mlm (aux text), relationship
         self.counts = zf(4)       # n_valid mlm, n_valid mvrc, n_valid mlm aux
 
@@ -905,7 +906,7 @@ class PretrainEngine:
         if self.lr_kind is not None:
             ops.lr_schedule_step(self.adam, self.lr_kind, self.base_lr, self.warmup_steps, self.t_total)
         scale = self.buckets.grad_scale if self.buckets is not None else 1.0
-        ops.sumsq(self.P.grad, self.adam[7:8])
+        ops.sumsq_det(self.P.grad, self.sumsq_ws, self.adam[7:8])     # fixed summation order: replicas stay bit-identical
         ops.adamw_step(self.P.master, self.P.grad, self.P.m, self.P.v, self.P.w16, self.adam, grad_scale=scale)
         self._refresh_transposes()
         if self.vision is not None:

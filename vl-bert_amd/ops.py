@@ -278,6 +278,12 @@ def sumsq(g, out):
     _lib.call("vlb_sumsq_f32", _p(g, torch.float32), g.numel(), _p(out, torch.float32), _stream())
 
 
+def sumsq_det(g, partials, out):
+    """out += sum(g^2) with a fixed summation order (same bits on every data-parallel rank)."""
+    _lib.call("vlb_sumsq_f32_det", _p(g, torch.float32), g.numel(), _p(partials, torch.float32), partials.numel(), _p(out, torch.float32),
+              _stream())
+
+
 def adamw_step(p, g, m, v, p16, state, grad_scale=1.0):
     _lib.call("vlb_adamw_step", _p(p, torch.float32), _p(g, torch.float32), _p(m, torch.float32), _p(v, torch.float32),
               _p(p16, BF16), p.numel(), _p(state, torch.float32), float(grad_scale), _stream())
