@@ -612,9 +612,9 @@ def test_lr_schedule_on_device(ops):
     assert abs(float(state[0]) - base * 0.3) < 1e-10
     state[5] = 50.0
     ops.lr_schedule_step(state, ops.LR_WARMUP_CONSTANT, base, 10, 0)
-    assert abs(float(state[0]) - base) < 1e-12
+    assert abs(float(state[0]) - base) < 1e-7 * base          # fp32 storage of the lr
     ops.lr_schedule_step(state, ops.LR_CONSTANT, 3e-5, 0, 0)
-    assert abs(float(state[0]) - 3e-5) < 1e-12
+    assert abs(float(state[0]) - 3e-5) < 1e-7 * 3e-5
     with pytest.raises(Exception):
         ops.lr_schedule_step(state, 7, base, 0, 0)
 
