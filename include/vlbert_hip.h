@@ -216,6 +216,10 @@ int vlb_rng_advance(uint32_t* seed, vlb_stream_t stream);
 int vlb_conv_weight_prepare(const float* w, const float* gamma, const float* beta, const float* mean, const float* var,
                             float eps, void* wf, void* wb, float* scale, float* shift, int O, int I, int taps, int kf,
                             vlb_stream_t stream);
+/* n convolutions in one launch: desc (device) = n x 13 int64 {w, gamma, beta, mean, var, wf, wb, scale, shift, O, I, taps, kf} (pointers
+ * as integers, 0 = NULL), block_start (device, n int32) = index of each convolution's first 1024-element block, total_blocks = their sum. */
+int vlb_conv_weight_prepare_batched(const int64_t* desc, const int32_t* block_start, int n, int total_blocks, float eps,
+                                    vlb_stream_t stream);
 int vlb_conv_wgrad_finalize(const float* dwf, const float* scale, float* g, int O, int kreal, int kf, int accumulate,
                             vlb_stream_t stream);
 /* implicit 3x3 convolution, stride 1, padding = dilation: y[N*H*W, O] = epi(im2col(x) . w^T) without the im2col image in HBM
@@ -228,7 +232,13 @@ int vlb_conv3x3_nhwc_bf16(const void* x, int N, int H, int W, int C, int dil, co
 /* weight gradient of the same convolution without the im2col image: dW[O, 9*C] fp32 (+)= dy[N*H*W, O]^T . im2col(x); the TN
  * GEMM gathers the shifted pixels of x itself.  C % 128 == 0; workspace as vlb_wgrad_tn_bf16 (vlb_wgrad_workspace_floats(O, 9C, rows)). */
 int vlb_conv3x3_wgrad_tn_bf16(const void* dy, long lddy, const void* x, int N, int H, int W, int C, int dil, float* dW,
-                              long lddw, int O, float* workspace, long workspace_floats, int accumulate, vlb_stream_t stream);
+                              long lddw, int O, const float* rowscale, float* workspace, long workspace_floats, int accumulate,
+                              vlb_stream_t stream);
+/* vlb_wgrad_tn_bf16 with output row m scaled by rowscale[m] (folded frozen-BatchNorm: dW_master = scale[o] * dW_folded) in the
+ * slab reduce -- no separate finalize pass.  rowscale (also optional in vlb_conv3x3_wgrad_tn_bf16) needs
+ * workspace >= splits * Mo * round4(No) floats, at least Mo * round4(No). */
+int vlb_wgrad_tn_rowscale_bf16(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int R, int Mo, int No,
+                               const float* rowscale, float* workspace, long workspace_floats, int accumulate, vlb_stream_t stream);
 int vlb_im2col_nhwc_bf16(const void* x, void* col, long ldcol, int N, int H, int W, int C, int KH, int KW, int stride,
                          int pad, int dil, vlb_stream_t stream);
 /* stem (resnet.py:137-141): fp32 NCHW image -> [N*OH*OW, ldcol] bf16, column (ky*KW+kx)*Cin + c, zero padded to ldcol */

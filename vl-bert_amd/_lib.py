@@ -44,9 +44,11 @@ _SIGS = {
     "vlb_adamw_step": "ppppplpfs",
     "vlb_lr_schedule_step": "pifffs",
     "vlb_conv_weight_prepare": "pppppfppppiiiis",
+    "vlb_conv_weight_prepare_batched": "ppiifs",
     "vlb_conv_wgrad_finalize": "pppiiiis",
     "vlb_conv3x3_nhwc_bf16": "piiiiiplplipiplps",
-    "vlb_conv3x3_wgrad_tn_bf16": "plpiiiiipliplis",
+    "vlb_conv3x3_wgrad_tn_bf16": "plpiiiiiplipplis",
+    "vlb_wgrad_tn_rowscale_bf16": "plplpliiipplis",
     "vlb_im2col_nhwc_bf16": "ppliiiiiiiiis",
     "vlb_im2col_image_f32": "ppiiiiiiiiis",
     "vlb_maxpool3x3s2_nhwc": "ppiiiis",

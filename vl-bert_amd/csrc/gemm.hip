@@ -1242,7 +1242,8 @@ extern "C" int vlb_conv3x3_nhwc_bf16(const void* x, int N, int H, int W, int C, 
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, long slab_stride, int splits,
                                                             float* __restrict__ C, long ldc, int M, int N, int ldw,
-                                                            bf16_t* __restrict__ Cb, long ldcb, int accumulate) {
+                                                            bf16_t* __restrict__ Cb, long ldcb, int accumulate,
+                                                            const float* __restrict__ rowscale = nullptr) {
   const int n4 = ldw >> 2;
   const long total = (long)M * n4;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -1252,6 +1253,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     for (int sp = 1; sp < splits; ++sp) {
       const float4 b = *(const float4*)(src + sp * slab_stride);
       a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    if (rowscale) {   // folded-BatchNorm weight gradient: dW_master = scale[o] * dW_folded (vision path)
+      const float sc = rowscale[m];
+      a.x *= sc; a.y *= sc; a.z *= sc; a.w *= sc;
     }
     if (Cb) {   // bf16 result, overwritten (split-K dgrad)
       bf16_t* c = Cb + (long)m * ldcb + n;
@@ -1366,8 +1371,8 @@ extern "C" int vlb_gemm_nt_bf16_splitk(const void* A, long lda, const void* B, l
 
 // dW[Mo,No] (fp32) (+)= A[R,Mo]^T B[R,No]; optional colsum[Mo] += column sums of A (bias gradient).
 // accumulate == 0 overwrites dW (first micro-batch of an optimizer step: no zero fill and no read-modify-write).
-extern "C" int vlb_wgrad_tn_bf16(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int R, int Mo, int No,
-                                 float* colsum, float* workspace, long workspace_floats, int accumulate, hipStream_t stream) {
+static int wgrad_tn_impl(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int R, int Mo, int No, float* colsum,
+                         const float* rowscale, float* workspace, long workspace_floats, int accumulate, hipStream_t stream) {
   if (Mo <= 0 || No <= 0 || R <= 0) return VLB_OK;
   VLB_CHECK_ARG(A && B && C, "vlb_wgrad_tn_bf16: null operand");
   VLB_CHECK_ARG((lda % 8) == 0 && (ldb % 8) == 0 && (ldc % 4) == 0 && lda >= 8 && ldb >= 8, "vlb_wgrad_tn_bf16: bad leading dimensions");
@@ -1378,12 +1383,15 @@ extern "C" int vlb_wgrad_tn_bf16(const void* A, long lda, const void* B, long ld
   const int per = vlb_cdiv(ktiles, splits);
   const int nsp = vlb_cdiv(ktiles, per);
   const long ldw = (No + 3) / 4 * 4;
+  const bool slab = nsp > 1 || rowscale != nullptr;      // a row scale is applied by the reduce kernel: always go through a slab
+  VLB_CHECK_ARG(!rowscale || (workspace && workspace_floats >= (long)nsp * Mo * ldw), "vlb_wgrad_tn: rowscale needs a workspace of %ld floats",
+                (long)nsp * Mo * ldw);
   GemmParams p;
   p.A = (const bf16_t*)A; p.lda = lda; p.B = (const bf16_t*)B; p.ldb = ldb;
   p.M = Mo; p.N = No; p.K = R; p.k_per_split = per * 64;
   p.bias = nullptr; p.act = 0; p.aux = nullptr; p.ldaux = 0; p.pre = nullptr; p.ldpre = 0; p.res = nullptr; p.ldres = 0;
   p.drop_thr = 0; p.drop_scale = 1.f; p.seed = nullptr; p.tag = 0;
-  if (nsp == 1) {
+  if (!slab) {
     p.C = C; p.ldc = ldc; p.out_f32 = accumulate ? 3 : 1; p.c_split_stride = 0;
   } else {
     p.C = workspace; p.ldc = ldw; p.out_f32 = 1; p.c_split_stride = (long)Mo * ldw;
@@ -1420,20 +1428,35 @@ extern "C" int vlb_wgrad_tn_bf16(const void* A, long lda, const void* B, long ld
     else hipLaunchKernelGGL((gemm_tn_bf16_kernel<2, 1>), grid, dim3(256), smem, stream, p, colsum);
   }
   VLB_CHECK_LAUNCH("vlb_wgrad_tn_bf16");
-  if (nsp > 1) {
+  if (slab) {
     long blocks = ((long)Mo * (ldw / 4) + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)blocks), dim3(256), 0, stream, workspace, (long)Mo * ldw, nsp, C, ldc, Mo, No,
-                       (int)ldw, (bf16_t*)nullptr, 0L, accumulate);
+                       (int)ldw, (bf16_t*)nullptr, 0L, accumulate, rowscale);
     VLB_CHECK_LAUNCH("vlb_wgrad_tn_bf16(reduce)");
   }
   return VLB_OK;
 }
 
+extern "C" int vlb_wgrad_tn_bf16(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int R, int Mo, int No,
+                                 float* colsum, float* workspace, long workspace_floats, int accumulate, hipStream_t stream) {
+  return wgrad_tn_impl(A, lda, B, ldb, C, ldc, R, Mo, No, colsum, nullptr, workspace, workspace_floats, accumulate, stream);
+}
+
+// same product with every output ROW m multiplied by rowscale[m] before it is written / accumulated (the gradient of a weight
+// whose frozen-BatchNorm scale was folded into the bf16 operand); needs workspace >= splits * Mo * round4(No) floats.
+extern "C" int vlb_wgrad_tn_rowscale_bf16(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int R, int Mo, int No,
+                                          const float* rowscale, float* workspace, long workspace_floats, int accumulate,
+                                          hipStream_t stream) {
+  VLB_CHECK_ARG(rowscale, "vlb_wgrad_tn_rowscale_bf16: null rowscale");
+  return wgrad_tn_impl(A, lda, B, ldb, C, ldc, R, Mo, No, nullptr, rowscale, workspace, workspace_floats, accumulate, stream);
+}
+
 // dW[O, 9C] (fp32) (+)= dy[R, O]^T . im2col(x)[R, 9C] for a 3x3 / stride 1 / padding = dilation convolution on the NHWC
 // activation x [R = N*H*W, C], C % 128 == 0 -- the TN kernel gathers the shifted pixels itself (no im2col image).
 extern "C" int vlb_conv3x3_wgrad_tn_bf16(const void* dy, long lddy, const void* x, int N, int H, int W, int C, int dil, float* dW,
-                                         long lddw, int O, float* workspace, long workspace_floats, int accumulate, hipStream_t stream) {
+                                         long lddw, int O, const float* rowscale, float* workspace, long workspace_floats, int accumulate,
+                                         hipStream_t stream) {
   if (N <= 0 || O <= 0) return VLB_OK;
   VLB_CHECK_ARG(dy && x && dW, "vlb_conv3x3_wgrad_tn_bf16: null operand");
   VLB_CHECK_ARG(C > 0 && (C % 128) == 0, "vlb_conv3x3_wgrad_tn_bf16: C=%d must be a multiple of 128", C);
@@ -1446,13 +1469,16 @@ extern "C" int vlb_conv3x3_wgrad_tn_bf16(const void* dy, long lddy, const void* 
   const int per = vlb_cdiv(ktiles, splits);
   const int nsp = vlb_cdiv(ktiles, per);
   const long ldw = No;
+  const bool slab = nsp > 1 || rowscale != nullptr;
+  VLB_CHECK_ARG(!rowscale || (workspace && workspace_floats >= (long)nsp * Mo * ldw), "vlb_conv3x3_wgrad_tn_bf16: rowscale needs a workspace of %ld floats",
+                (long)nsp * Mo * ldw);
   GemmParams p;
   p.A = (const bf16_t*)dy; p.lda = lddy; p.B = (const bf16_t*)x; p.ldb = C;
   p.M = Mo; p.N = No; p.K = R; p.k_per_split = per * 64;
   p.bias = nullptr; p.act = 0; p.aux = nullptr; p.ldaux = 0; p.pre = nullptr; p.ldpre = 0; p.res = nullptr; p.ldres = 0;
   p.drop_thr = 0; p.drop_scale = 1.f; p.seed = nullptr; p.tag = 0;
   p.conv_C = C; p.conv_H = H; p.conv_W = W; p.conv_dil = dil; p.zero = nullptr;
-  if (nsp == 1) {
+  if (!slab) {
     p.C = dW; p.ldc = lddw; p.out_f32 = accumulate ? 3 : 1; p.c_split_stride = 0;
   } else {
     p.C = workspace; p.ldc = ldw; p.out_f32 = 1; p.c_split_stride = (long)Mo * ldw;
@@ -1476,11 +1502,11 @@ extern "C" int vlb_conv3x3_wgrad_tn_bf16(const void* dy, long lddy, const void* 
   if (p.out_f32 == 3) hipLaunchKernelGGL((gemm_tn_bf16_kernel<4, 3, true>), grid, dim3(512), smem, stream, p, (float*)nullptr);
   else hipLaunchKernelGGL((gemm_tn_bf16_kernel<4, 1, true>), grid, dim3(512), smem, stream, p, (float*)nullptr);
   VLB_CHECK_LAUNCH("vlb_conv3x3_wgrad_tn_bf16");
-  if (nsp > 1) {
+  if (slab) {
     long blocks = ((long)Mo * (ldw / 4) + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)blocks), dim3(256), 0, stream, workspace, (long)Mo * ldw, nsp, dW, lddw, Mo, No,
-                       (int)ldw, (bf16_t*)nullptr, 0L, accumulate);
+                       (int)ldw, (bf16_t*)nullptr, 0L, accumulate, rowscale);
     VLB_CHECK_LAUNCH("vlb_conv3x3_wgrad_tn_bf16(reduce)");
   }
   return VLB_OK;

@@ -55,6 +55,55 @@ extern "C" int vlb_conv_weight_prepare(const float* w, const float* gamma, const
   return VLB_OK;
 }
 
+// All convolutions of the network in ONE launch (93 trainable ones are re-folded after every optimizer step): desc[c] =
+// {w, gamma, beta, mean, var, wf, wb, scale, shift, O, I, T, kf} as int64, block_start[c] = first 1024-element block of conv c.
+__global__ __launch_bounds__(256) void conv_weight_prepare_batched_kernel(const int64_t* __restrict__ desc, const int32_t* __restrict__ block_start,
+                                                                          int n, float eps) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {   // last conv whose first block is <= blockIdx.x
+    const int mid = (lo + hi + 1) >> 1;
+    if (block_start[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const int64_t* d = desc + (long)lo * 13;
+  const float* w = (const float*)d[0];
+  const float* gamma = (const float*)d[1];
+  const float* beta = (const float*)d[2];
+  const float* mean = (const float*)d[3];
+  const float* var = (const float*)d[4];
+  bf16_t* wf = (bf16_t*)d[5];
+  bf16_t* wb = (bf16_t*)d[6];
+  float* scale = (float*)d[7];
+  float* shift = (float*)d[8];
+  const int O = (int)d[9], I = (int)d[10], T = (int)d[11], kf = (int)d[12];
+  const long total = (long)O * T * I;
+  const long base = (long)((int)blockIdx.x - block_start[lo]) * 1024;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const long idx = base + e * 256 + threadIdx.x;
+    if (idx >= total) break;
+    const int i = (int)(idx % I);
+    const int t = (int)((idx / I) % T);
+    const int o = (int)(idx / ((long)I * T));
+    const float s = gamma ? gamma[o] / sqrtf(var[o] + eps) : 1.0f;
+    const bf16_t v = f2bf(w[idx] * s);
+    wf[(long)o * kf + (long)t * I + i] = v;
+    if (wb) wb[(long)i * T * O + (long)(T - 1 - t) * O + o] = v;
+    if (i == 0 && t == 0) {
+      if (scale) scale[o] = s;
+      if (shift) shift[o] = gamma ? beta[o] - mean[o] * s : 0.f;
+    }
+  }
+}
+
+extern "C" int vlb_conv_weight_prepare_batched(const int64_t* desc, const int32_t* block_start, int n, int total_blocks, float eps,
+                                               hipStream_t stream) {
+  if (n <= 0 || total_blocks <= 0) return VLB_OK;
+  VLB_CHECK_ARG(desc && block_start, "vlb_conv_weight_prepare_batched: null table");
+  hipLaunchKernelGGL(conv_weight_prepare_batched_kernel, dim3(total_blocks), dim3(256), 0, stream, desc, block_start, n, eps);
+  VLB_CHECK_LAUNCH("vlb_conv_weight_prepare_batched");
+  return VLB_OK;
+}
+
 __global__ __launch_bounds__(256) void conv_wgrad_finalize_kernel(const float* __restrict__ dwf, const float* __restrict__ scale,
                                                                   float* __restrict__ g, int O, int kreal, int kf, int accumulate) {
   const long total = (long)O * kreal;

@@ -346,6 +346,30 @@ def conv_weight_prepare(w, bn, wf, wb=None, scale=None, shift=None, eps=1e-5):
               O, I, taps, wf.shape[1], _stream())
 
 
+class ConvPrepareBatch:
+    """vlb_conv_weight_prepare for a fixed list of convolutions in one launch: items = [(w [O,taps,I], bn 4-tuple or None, wf, wb,
+    scale, shift)], built once, replayed after every optimizer step."""
+
+    def __init__(self, items, device, eps=1e-5):
+        self.keep = list(items)
+        desc, starts, total = [], [], 0
+        ptr = lambda t: 0 if t is None else t.data_ptr()
+        for w, bn, wf, wb, scale, shift in items:
+            O, taps, I = w.shape
+            g, b, m, v = bn if bn is not None else (None, None, None, None)
+            desc.append([ptr(w), ptr(g), ptr(b), ptr(m), ptr(v), ptr(wf), ptr(wb), ptr(scale), ptr(shift), O, I, taps, wf.shape[1]])
+            starts.append(total)
+            total += (O * taps * I + 1023) // 1024
+        self.n, self.total, self.eps = len(desc), total, eps
+        self.desc = torch.tensor(desc, dtype=torch.int64).to(device) if desc else None
+        self.starts = torch.tensor(starts, dtype=torch.int32).to(device) if desc else None
+
+    def run(self):
+        if self.n:
+            _lib.call("vlb_conv_weight_prepare_batched", self.desc.data_ptr(), self.starts.data_ptr(), self.n, self.total, float(self.eps),
+                      _stream())
+
+
 def conv_wgrad_finalize(dwf, scale, g, accumulate=True):
     """g fp32 [O, kreal] (+)= scale[o] * dwf[O, kf][:, :kreal]"""
     O, kreal = g.shape
@@ -362,13 +386,24 @@ def conv3x3_nhwc(x, w, y, N, H, W, C, dil, zero16, bias=None, act=ACT_NONE, aux=
     return y
 
 
-def conv3x3_wgrad_tn(dy, x, dW, N, H, W, C, dil, workspace=None, accumulate=True):
-    """dW fp32 [O, 9C] (+)= dy[N*H*W, O]^T . im2col(x) with the gather inside the TN GEMM (C % 128 == 0)."""
+def conv3x3_wgrad_tn(dy, x, dW, N, H, W, C, dil, workspace=None, accumulate=True, rowscale=None):
+    """dW fp32 [O, 9C] (+)= rowscale[o] * dy[N*H*W, O]^T . im2col(x) with the gather inside the TN GEMM (C % 128 == 0)."""
     O = dW.shape[0]
     assert dy.shape[0] == N * H * W and dy.shape[1] == O and x.shape[0] == dy.shape[0] and x.shape[1] == C and x.is_contiguous()
     _lib.call("vlb_conv3x3_wgrad_tn_bf16", _p(dy, BF16), _ld(dy), _p(x, BF16), N, H, W, C, dil, _p(dW, torch.float32), _ld(dW), O,
-              _p(workspace, torch.float32), workspace.numel() if workspace is not None else 0, int(bool(accumulate)), _stream())
+              _p(rowscale, torch.float32), _p(workspace, torch.float32), workspace.numel() if workspace is not None else 0,
+              int(bool(accumulate)), _stream())
     return dW
+
+
+def wgrad_tn_rowscale(dy, x, C, rowscale, workspace, accumulate=True):
+    """C[Mo,No] (fp32) (+)= rowscale[m] * (dy[R,Mo]^T x[R,No])"""
+    Mo, No = C.shape
+    R = dy.shape[0]
+    assert dy.shape[1] == Mo and x.shape[1] == No and x.shape[0] == R
+    _lib.call("vlb_wgrad_tn_rowscale_bf16", _p(dy, BF16), _ld(dy), _p(x, BF16), _ld(x), _p(C, torch.float32), _ld(C), R, Mo, No,
+              _p(rowscale, torch.float32), _p(workspace, torch.float32), workspace.numel(), int(bool(accumulate)), _stream())
+    return C
 
 
 def im2col_nhwc(x, col, N, H, W, C, k, stride, pad, dil):

@@ -141,6 +141,7 @@ class VisionStack:
             c.scale, c.shift = zf(O), zf(O)
             self.convs[key] = c
         self._dirty = True
+        self._prep = {}
         # ---- geometry + activations -------------------------------------------------------------------------------
         cs = ops.conv_out_size
         self.H1, self.W1 = cs(Himg, 7, 2, 3, 1), cs(Wimg, 7, 2, 3, 1)
@@ -193,8 +194,7 @@ class VisionStack:
             raise ValueError("RoI head width %d != %d" % (self.Cout, VIS_DIM))
         self.P_roi = self.blocks[-1]["h"] * self.blocks[-1]["w"]
         self.dfeat32 = zf(self.M3, self.C3)
-        self.wg_ws = zf(max(max_wg, 4))
-        self.dwf = zf(max(max_dwf, 4))
+        self.wg_ws = zf(max(max_wg, max_dwf, 4))         # split-K slabs (at least one slab of the largest weight)
 
     # ------------------------------------------------------------------------------------------------------------------
     def _dgrad_set(self):
@@ -262,10 +262,11 @@ class VisionStack:
 
     def refresh_weights(self, trainable_only=False):
         """fp32 master (+ frozen BN) -> folded bf16 operands; after load_state_dict and after every optimizer step."""
-        for c in self.convs.values():
-            if trainable_only and not c.trainable:
-                continue
-            ops.conv_weight_prepare(c.w32, c.bn, c.wf, c.wb, c.scale, c.shift, eps=BN_EPS)
+        key = bool(trainable_only)
+        if key not in self._prep:
+            self._prep[key] = ops.ConvPrepareBatch([(c.w32, c.bn, c.wf, c.wb, c.scale, c.shift) for c in self.convs.values()
+                                                    if c.trainable or not trainable_only], self.dev, eps=BN_EPS)
+        self._prep[key].run()
         self._dirty = False
 
     # ------------------------------------------------------------------------------------------------------------------
@@ -342,13 +343,11 @@ class VisionStack:
     def _wgrad(self, c, dy, x, conv=None):
         """g32 += scale[o] * (dy^T x) for the folded operand; conv = (n, h, w, C, dil): x is the NHWC activation and the im2col
         gather happens inside the TN GEMM."""
-        def run():
-            dw = self.dwf[:c.O * c.kf].view(c.O, c.kf)
+        def run():   # the BatchNorm scale is applied by the split-K slab reduce (no separate finalize pass)
             if conv is None:
-                ops.wgrad_tn(dy, x, dw, workspace=self.wg_ws, accumulate=False)
+                ops.wgrad_tn_rowscale(dy, x, c.g32, c.scale, self.wg_ws, accumulate=True)
             else:
-                ops.conv3x3_wgrad_tn(dy, x, dw, *conv, workspace=self.wg_ws, accumulate=False)
-            ops.conv_wgrad_finalize(dw, c.scale, c.g32, accumulate=True)
+                ops.conv3x3_wgrad_tn(dy, x, c.g32, *conv, workspace=self.wg_ws, accumulate=True, rowscale=c.scale)
         self._side_run(run, dy)
 
     def _block_bwd(self, b, dz, dx_out, need_dx, mask_input):
