@@ -63,13 +63,20 @@ def test_buckets_with_vision_tail_tile_the_flat_buffer():
     vstart = min(offsets[n] for n in vis)
     b = P.GradBuckets(torch.zeros(off), offsets, off, cfg.num_hidden_layers, bucket_bytes=1 << 20, vision_start=vstart)
     cov = b.coverage()
-    assert cov[0][0] == 0 and cov[-1] == (vstart, off)
+    assert cov[0][0] == 0 and cov[-1][1] == off and b.vision_keys == ["vision2", "vision3", "vision4"]
+    assert b.ranges["vision2"][0] == vstart and b.ranges["vision4"][1] == off
     for (lo, hi), (lo2, hi2) in zip(cov[:-1], cov[1:]):
         assert hi == lo2 and lo < hi
     launched = []
     b._launch = lambda lo, hi: launched.append((lo, hi))
-    b.on_done("heads"); b.on_done(1); b.on_done(0); b.on_done("embed"); b.on_done("vision")
-    assert sorted(launched) == sorted(cov) and launched[-1] == (vstart, off)
+    # the engine's order in e2e mode: heads, layers, embed (before the CNN backward), RoI head, layer3, layer2, then the catch-alls
+    for what in ("heads", 1, 0, "embed", "vision4", "vision3", "vision2", "embed", "vision"):
+        b.on_done(what)
+    assert sorted(launched) == sorted(cov) and len(launched) == len(cov)          # every range exactly once
+    assert launched[-3:] == [b.ranges["vision4"], b.ranges["vision3"], b.ranges["vision2"]]
+    b.wait()
+    b.on_done("vision")
+    assert len(launched) == len(cov) + 3                                            # re-armed for the next step
 
 
 def _worker(rank, world, port, numel_holder):

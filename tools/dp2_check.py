@@ -49,8 +49,8 @@ def main():
     torch.cuda.synchronize()
     err = float((eng.P.grad - total).abs().max()) / max(float(total.abs().max()), 1e-30)
     cov = eng.buckets.coverage()
-    print("rank %d: reduced-vs-summed gradient max rel err %.2e over %d buckets (vision bucket: %s)" %
-          (rank, err, len(cov), "vision" in eng.buckets.ranges), flush=True)
+    print("rank %d: reduced-vs-summed gradient max rel err %.2e over %d buckets (vision buckets: %s)" %
+          (rank, err, len(cov), eng.buckets.vision_keys), flush=True)
     # two backward passes of one rank are not bit-identical (fp32 atomics: LayerNorm / embedding sums; e2e: ROIAlign backward, whose
     # rounding to bf16 then propagates through the trunk), so this compares to a tolerance; check (1) below is exact
     assert err < (1e-3 if e2e else 1e-6), err

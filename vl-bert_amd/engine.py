@@ -705,7 +705,7 @@ class PretrainEngine:
         if self.core:
             self._front_core_bwd(dx, p_h)
         else:
-            self._front_pretrain_bwd(dx, p_h, p_ds)
+            self._front_pretrain_bwd(dx, p_h, p_ds, on_layer_done)
         self._join_side()
         self._fresh_grads = False       # a further backward before the next zero_grad() accumulates
         if on_layer_done:
@@ -733,7 +733,7 @@ class PretrainEngine:
                           dbeta=g32["vlbert.visual_ln_object.bias"], workspace=self.ln_ws)
         self.d_ovl_in[:, H:].copy_(self.d_ol)      # fp32 -> bf16 strided copy (glue: hands the gradient to autograd)
 
-    def _front_pretrain_bwd(self, dx, p_h, p_ds):
+    def _front_pretrain_bwd(self, dx, p_h, p_ds, on_layer_done=None):
         cfg, B, T, R, S, Bt, Ba = self.cfg, self.B, self.T, self.R, self.S, self.Bt, self.Ba
         H = cfg.hidden_size
         w16, w32, g32, wT, seed = self.w16, self.w32, self.g32, self.wT, self.seed
@@ -768,7 +768,11 @@ class PretrainEngine:
         ops.gemm_nt(self.d_yds, wT[pd + "weight"][VIS_DIM:], self.d_afeat)
         if self.vision is not None:      # the features are activations of the CNN: RoI head, ROIAlign and trunk backward
             self._join_side()
-            self.vision.backward(self.d_afeat, self.in_boxes, drop_p=p_ds, seed=seed, tag=TAG_DOWNSAMPLE)
+            hook = None
+            if on_layer_done:     # everything but the convolutions is complete: its bucket goes out under the CNN backward
+                on_layer_done("embed")
+                hook = lambda layer: on_layer_done("vision%d" % layer)
+            self.vision.backward(self.d_afeat, self.in_boxes, drop_p=p_ds, seed=seed, tag=TAG_DOWNSAMPLE, on_stage_done=hook)
             return
         ops.masked_colsum(self.d_afeat, self.in_mvrc_ops.view(-1), g32["object_mask_visual_embedding.weight"].view(-1),
                           drop_p=p_ds, seed=seed, tag=TAG_DOWNSAMPLE, row_elems=2 * VIS_DIM, col_off=VIS_DIM)

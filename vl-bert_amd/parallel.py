@@ -35,8 +35,28 @@ class GradBuckets:
         bounds = layer_start + [head_start]
         tail = numel if vision_start is None else vision_start
         self.ranges = {"heads": (head_start, tail), "embed": (0, layer_start[0] if num_layers else head_start)}
+        self.vision_keys = []
         if vision_start is not None:
-            self.ranges["vision"] = (vision_start, numel)
+            # one bucket per stage of the vision path, in layout order (layer2 | layer3 | RoI head): VisionStack.backward finishes
+            # the RoI head first and the trunk stage by stage, so each stage's 40-100 MB all-reduce overlaps the rest of it
+            def stage(n):
+                if "roi_head_feature_extractor" in n:
+                    return "vision4"
+                for L in (1, 2, 3):
+                    if ".backbone.layer%d." % L in n:
+                        return "vision%d" % L
+                return "vision0"
+            vnames = [n for n in names if offsets[n] >= vision_start]
+            starts = []
+            for n in vnames:
+                k = stage(n)
+                if not starts or starts[-1][0] != k:
+                    assert k not in [q for q, _ in starts], "vision parameters of one stage must be contiguous in the flat buffer"
+                    starts.append((k, offsets[n]))
+            for i, (k, lo) in enumerate(starts):
+                self.ranges[k] = (lo, starts[i + 1][1] if i + 1 < len(starts) else numel)
+                self.vision_keys.append(k)
+        self.launched = set()
         # group consecutive layers (in backward order) into buckets of ~bucket_bytes
         self.layer_bucket = {}
         cur, cur_bytes = [], 0
@@ -53,8 +73,7 @@ class GradBuckets:
     def coverage(self):
         """All ranges, for tests: they must tile [0, numel) exactly."""
         r = [self.ranges["embed"]] + sorted(self.layer_bucket.values()) + [self.ranges["heads"]]
-        if "vision" in self.ranges:
-            r.append(self.ranges["vision"])
+        r += [self.ranges[k] for k in self.vision_keys]
         return r
 
     def _launch(self, lo, hi):
@@ -70,16 +89,23 @@ class GradBuckets:
             self.pending.append((work, None, None))
 
     def on_done(self, what):
-        """engine.backward hook: `what` is "heads", a layer index, or "embed"."""
-        if what == "heads":
+        """engine.backward hook: `what` is "heads", a layer index, "embed", "vision<stage>" or "vision" (= every vision stage not
+        reduced yet).  A range is launched once per step (wait() re-arms)."""
+        if what == "vision":
+            for k in self.vision_keys:
+                self.on_done(k)
+            return
+        if what in self.launched:
+            return
+        self.launched.add(what)
+        if what in self.vision_keys:
+            self._launch(*self.ranges[what])
+        elif what == "heads":
             # the tied word-embedding gradient is only complete after the embedding backward -> it lives in
             # the "embed" range; the head range holds transform / decoder bias / MVRC head gradients
             self._launch(*self.ranges["heads"])
         elif what == "embed":
             self._launch(*self.ranges["embed"])
-        elif what == "vision":
-            if "vision" in self.ranges:
-                self._launch(*self.ranges["vision"])
         elif what in self.layer_bucket:
             self._launch(*self.layer_bucket[what])
 
@@ -89,6 +115,7 @@ class GradBuckets:
             if dst is not None:
                 dst.copy_(wire)
         self.pending = []
+        self.launched = set()
 
     @property
     def grad_scale(self):

@@ -394,13 +394,19 @@ class VisionStack:
         if b["stride"] == 2:
             ops.upsample2_zero_nhwc(target, dx_out, n, b["hin"], b["win"], C)
 
-    def backward(self, d_feat, boxes, drop_p=0.0, seed=None, tag=0, drop_row_elems=2 * VIS_DIM, drop_col0=VIS_DIM):
+    def backward(self, d_feat, boxes, drop_p=0.0, seed=None, tag=0, drop_row_elems=2 * VIS_DIM, drop_col0=VIS_DIM, on_stage_done=None):
         """d_feat bf16 [K, 2048]: gradient w.r.t. the feature half of obj_downsample's (dropped-out) input; accumulates the weight
-        gradients of the trainable convolutions."""
-        self._backward(d_feat, boxes, drop_p, seed, tag, drop_row_elems, drop_col0)
+        gradients of the trainable convolutions.  on_stage_done(layer) is called when every weight gradient of layer 4 (RoI head),
+        3, 2 is complete on the current stream (data-parallel bucket hook)."""
+        self._backward(d_feat, boxes, drop_p, seed, tag, drop_row_elems, drop_col0, on_stage_done)
         self._join_side()        # every weight gradient is complete for whatever the caller enqueues next
 
-    def _backward(self, d_feat, boxes, drop_p, seed, tag, drop_row_elems, drop_col0):
+    def _stage_done(self, hook, layer):
+        if hook is not None:
+            self._join_side()
+            hook(layer)
+
+    def _backward(self, d_feat, boxes, drop_p, seed, tag, drop_row_elems, drop_col0, hook):
         K = self.K
         box_rows = boxes.view(K, boxes.shape[2])
         blocks = [b for b in self.blocks if b["trainable"]]
@@ -421,8 +427,10 @@ class VisionStack:
             if L == 4:
                 if 4 in self.frozen_stages or all(bb["layer"] == 4 for bb in blocks):
                     self._block_bwd(b, cur, None, False, False)
+                    self._stage_done(hook, 4)
                     return
                 self._block_bwd(b, cur, g["dxs"], True, False)          # ROIAlign output: no ReLU in front, no mask
+                self._stage_done(hook, 4)
                 ops.roi_align_nhwc_bwd(g["dxs"], box_rows, self.R, self.dfeat32, self.N, self.H3, self.W3, self.C3, self.pooled,
                                        self.scale, self.sr)
                 g3 = self.groups[3]
@@ -430,7 +438,9 @@ class VisionStack:
                 cur = ops.relu_mask_cast(self.dfeat32, self.body4, g3["dzA"])
             elif b is first:
                 self._block_bwd(b, cur, None, False, False)
+                self._stage_done(hook, L)
             else:
                 prev = self.groups[L - 1]
                 self._block_bwd(b, cur, prev["dzA"], True, True)
                 cur = prev["dzA"]
+                self._stage_done(hook, L)
