@@ -74,3 +74,26 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(lib, "LIB_PATH", "/nonexistent/libvlbert_hip.so")
     with pytest.raises(RuntimeError, match="no CPU / eager fallback"):
         lib.load()
+
+
+def test_train_end2end_entry_point_dry_run(tmp_path):
+    """The reference-style command line (pretrain/train_end2end.py) resolves a cfgs/pretrain/*.yaml the reference's way: lr scaled by
+    world x batch x accumulate (pretrain/function/train.py:133-138), triangle schedule totals (:316-320); without a GPU it refuses
+    to run (no CPU path) unless --dry-run."""
+    import torch
+    tr = importlib.import_module("vl-bert_amd.pretrain.train_end2end")
+    y = tmp_path / "cfg.yaml"
+    y.write_text("MODULE: ResNetVLBERTForPretraining\nRNG_SEED: 7\nSCALES: [600, 1000]\n"
+                 "NETWORK:\n  IMAGE_FEAT_PRECOMPUTED: false\n  IMAGE_NUM_LAYERS: 101\n  VLBERT:\n    num_hidden_layers: 12\n    hidden_size: 768\n"
+                 "TRAIN:\n  BATCH_IMAGES: 8\n  LR: 1.0e-7\n  WD: 0.0001\n  CLIP_GRAD_NORM: 10\n  LR_SCHEDULE: triangle\n  WARMUP: true\n"
+                 "  WARMUP_STEPS: 8000\n  END_EPOCH: 10\n  GRAD_ACCUMULATE_STEPS: 2\n  FP16: true\n")
+    r = tr.main(["--cfg", str(y), "--dry-run", "--steps-per-epoch", "1000"])
+    assert r["e2e"] and r["image_size"] == (600, 1000) and r["per_gpu_batch"] == 8 and r["accumulate"] == 2
+    assert abs(r["lr"] - 1e-7 * 8 * 2) < 1e-15 and r["warmup_steps"] == 8000 and r["t_total"] == 5000 and r["lr_schedule"] == "triangle"
+    ref = "/root/reference/cfgs/pretrain/base_prec_withouttextonly_4x16G_fp32.yaml"
+    if os.path.isfile(ref):            # the reference's own file, as it is
+        r2 = tr.main(["--cfg", ref, "--dry-run"])
+        assert not r2["e2e"] and r2["per_gpu_batch"] == 64 and abs(r2["lr"] - 64e-7) < 1e-15 and not r2["multitask"]
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no CPU execution path"):
+            tr.main(["--cfg", str(y), "--steps", "1"])

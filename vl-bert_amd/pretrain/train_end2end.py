@@ -1,0 +1,205 @@
+"""Entry point with the reference's command line (pretrain/train_end2end.py:11-48) over the HIP engine:
+
+    python -m vl-bert_amd.pretrain.train_end2end --cfg cfgs/pretrain/base_prec_withouttextonly_4x16G_fp32.yaml [--dist]
+           [--steps N] [--steps-per-epoch M] [--batch-images B] [--dry-run]
+
+It reads the reference's YAML files as they are (the keys of pretrain/function/config.py that the hot path consumes: NETWORK.*,
+TRAIN.{BATCH_IMAGES, LR, WD, CLIP_GRAD_NORM, LR_SCHEDULE, WARMUP, WARMUP_STEPS, END_EPOCH, BEGIN_EPOCH, GRAD_ACCUMULATE_STEPS},
+SCALES, RNG_SEED, LOG_FREQUENT, MODULE) and runs the fused training step of vl-bert_amd/engine.py with the reference's
+hyper-parameter conventions:
+  * lr = TRAIN.LR x world_size x BATCH_IMAGES x GRAD_ACCUMULATE_STEPS               (pretrain/function/train.py:133-138)
+  * 'triangle' = WarmupLinearSchedule(WARMUP_STEPS, t_total = END_EPOCH x steps/epoch / accumulate)     (:316-320)
+  * clip_grad_norm_(CLIP_GRAD_NORM), AdamW(betas 0.9/0.999, eps 1e-6, WD, bias-corrected)               (:146-160)
+  * one process per GPU with --dist (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* from the launcher; backend nccl = RCCL).
+What it does NOT reproduce is the data side (pretrain/data/: datasets, tokeniser, image decoding -- out of scope):
+batches are synthetic, in the collated layout of pretrain/data/collate_batch.py.  There is no CPU execution path: without a GPU
+the program stops with an error unless --dry-run is given, which only resolves and prints the configuration (the "plumbing"
+check of the reference's scripts/nondist_run.sh case).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+
+class AttrDict(dict):
+    __getattr__ = dict.__getitem__
+
+    @staticmethod
+    def wrap(x):
+        if isinstance(x, dict):
+            return AttrDict({k: AttrDict.wrap(v) for k, v in x.items()})
+        if isinstance(x, (list, tuple)):
+            return type(x)(AttrDict.wrap(v) for v in x)
+        return x
+
+
+DEFAULTS = {
+    "RNG_SEED": 12345, "MODULE": "ResNetVLBERTForPretraining", "LOG_FREQUENT": 100, "SCALES": (600, 1000),
+    "NETWORK": {"IMAGE_FEAT_PRECOMPUTED": True, "IMAGE_NUM_LAYERS": 101, "IMAGE_C5_DILATED": True, "IMAGE_STRIDE_IN_1x1": True,
+                "IMAGE_FROZEN_BACKBONE_STAGES": [1, 2], "IMAGE_FROZEN_BN": True, "IMAGE_SEMANTIC": False, "OUTPUT_CONV5": False,
+                "WITH_REL_LOSS": False, "WITH_MLM_LOSS": True, "WITH_MVRC_LOSS": True, "VLBERT": {}},
+    "TRAIN": {"BATCH_IMAGES": 64, "LR": 1.0e-7, "WD": 1.0e-4, "CLIP_GRAD_NORM": 10, "LR_SCHEDULE": "triangle", "WARMUP": True,
+              "WARMUP_STEPS": 8000, "BEGIN_EPOCH": 0, "END_EPOCH": 10, "GRAD_ACCUMULATE_STEPS": 1, "OPTIMIZER": "AdamW", "FP16": False},
+}
+
+
+def _merge(dst, src):
+    for k, v in src.items():
+        if isinstance(v, dict) and isinstance(dst.get(k), dict):
+            _merge(dst[k], v)
+        else:
+            dst[k] = v
+    return dst
+
+
+def load_config(path):
+    """update_config (pretrain/function/config.py:134-163): YAML over defaults, nested keys merged."""
+    import copy
+    import yaml
+    cfg = copy.deepcopy(DEFAULTS)
+    if path:
+        with open(path) as f:
+            _merge(cfg, yaml.safe_load(f) or {})
+    return AttrDict.wrap(cfg)
+
+
+def resolve(config, world, args):
+    """The numbers the step needs, with the reference's conventions."""
+    tr = config.TRAIN
+    bi = tr.BATCH_IMAGES
+    per_gpu = args.batch_images or (sum(bi) if isinstance(bi, (list, tuple)) else int(bi))
+    accum = int(tr.GRAD_ACCUMULATE_STEPS)
+    steps_per_epoch = args.steps_per_epoch
+    if tr.OPTIMIZER != "AdamW":
+        raise NotImplementedError("TRAIN.OPTIMIZER %s: the fused step implements AdamW (every shipped pretrain cfg)" % tr.OPTIMIZER)
+    sched = {"triangle": "triangle", "constant": "constant"}.get(tr.LR_SCHEDULE)
+    if sched is None:
+        raise NotImplementedError("TRAIN.LR_SCHEDULE %s (supported: triangle, constant)" % tr.LR_SCHEDULE)
+    multitask = config.MODULE == "ResNetVLBERTForPretrainingMultitask"
+    if config.MODULE not in ("ResNetVLBERTForPretraining", "ResNetVLBERTForPretrainingMultitask"):
+        raise NotImplementedError("MODULE %s" % config.MODULE)
+    return dict(per_gpu_batch=per_gpu, world=world, global_batch=per_gpu * world, accumulate=accum,
+                lr=float(tr.LR) * world * per_gpu * accum, weight_decay=float(tr.WD), clip_grad_norm=float(tr.CLIP_GRAD_NORM),
+                lr_schedule=sched, warmup_steps=int(tr.WARMUP_STEPS) if tr.WARMUP else 0,
+                t_total=int(int(tr.END_EPOCH) * steps_per_epoch / accum), steps_per_epoch=steps_per_epoch,
+                e2e=not config.NETWORK.IMAGE_FEAT_PRECOMPUTED, image_size=tuple(config.SCALES), multitask=multitask,
+                fp16_requested=bool(tr.FP16), seed=int(config.RNG_SEED))
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser("Train VL-BERT on the MI355X engine")
+    ap.add_argument("--cfg", type=str, help="path to a reference-style config file (cfgs/pretrain/*.yaml)")
+    ap.add_argument("--model-dir", type=str, help="accepted for command-line compatibility (checkpoint I/O is host glue, not built)")
+    ap.add_argument("--log-dir", type=str, help="accepted for command-line compatibility")
+    ap.add_argument("--dist", action="store_true", help="one process per GPU (torch.distributed.run / SLURM environment)")
+    ap.add_argument("--slurm", action="store_true")
+    ap.add_argument("--do-test", action="store_true")
+    ap.add_argument("--cudnn-off", action="store_true", help="accepted and ignored (no cuDNN / MIOpen on this path)")
+    ap.add_argument("--steps", type=int, default=20, help="optimizer steps to run on synthetic batches")
+    ap.add_argument("--steps-per-epoch", type=int, default=10000, help="stands in for len(train_loader) in the LR schedule")
+    ap.add_argument("--batch-images", type=int, default=0, help="override TRAIN.BATCH_IMAGES (per GPU)")
+    ap.add_argument("--text-len", type=int, default=64)
+    ap.add_argument("--regions", type=int, default=36)
+    ap.add_argument("--dry-run", action="store_true", help="resolve and print the configuration, touch no GPU")
+    return ap.parse_args(argv)
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    config = load_config(args.cfg)
+    if args.slurm:
+        os.environ.setdefault("RANK", os.environ.get("SLURM_PROCID", "0"))
+        os.environ.setdefault("WORLD_SIZE", os.environ.get("SLURM_NTASKS", "1"))
+    world = int(os.environ.get("WORLD_SIZE", "1")) if args.dist else 1
+    rank = int(os.environ.get("RANK", "0")) if args.dist else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if args.dist else 0
+    r = resolve(config, world, args)
+    if args.dry_run:
+        if rank == 0:
+            print(json.dumps({"resolved": r, "NETWORK.VLBERT": dict(config.NETWORK.VLBERT)}, indent=1, default=str))
+        return r
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("train_end2end: no GPU visible.  The MI355X engine has no CPU execution path (use --dry-run to check a "
+                           "configuration without a GPU)")
+    pkg = __package__.rsplit(".", 1)[0]
+    engine = importlib.import_module(pkg + ".engine")
+    syn = importlib.import_module(pkg + ".synthetic")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    vl = config.NETWORK.VLBERT
+    g = lambda k, d: vl[k] if k in vl else d
+    mc = engine.ModelConfig(hidden_size=g("hidden_size", 768), num_hidden_layers=g("num_hidden_layers", 12),
+                            num_attention_heads=g("num_attention_heads", 12), intermediate_size=g("intermediate_size", 3072),
+                            vocab_size=g("vocab_size", 30522), max_position_embeddings=g("max_position_embeddings", 512),
+                            type_vocab_size=g("type_vocab_size", 3), visual_region_classes=g("visual_region_classes", 1601),
+                            hidden_dropout_prob=g("hidden_dropout_prob", 0.1),
+                            attention_probs_dropout_prob=g("attention_probs_dropout_prob", 0.1), multitask=r["multitask"],
+                            with_pooler=bool(g("with_pooler", False)), with_rel_loss=bool(config.NETWORK.WITH_REL_LOSS), e2e=r["e2e"],
+                            image_num_layers=int(config.NETWORK.IMAGE_NUM_LAYERS),
+                            image_frozen_stages=tuple(config.NETWORK.IMAGE_FROZEN_BACKBONE_STAGES))
+    B, T, R = r["per_gpu_batch"], args.text_len, args.regions
+    B_aux = B if r["multitask"] else 0
+    eng = engine.PretrainEngine(mc, B, T, R, device="cuda:%d" % local_rank, train=True, lr=r["lr"], weight_decay=r["weight_decay"],
+                                max_grad_norm=r["clip_grad_norm"], seed=r["seed"] + rank, B_aux=B_aux,
+                                lr_schedule=r["lr_schedule"], warmup_steps=r["warmup_steps"], t_total=max(r["t_total"], r["warmup_steps"] + 1),
+                                image_size=r["image_size"] if r["e2e"] else None, grad_accum=r["accumulate"])
+    eng.init_random(seed=r["seed"], visual_ln_init=float(g("visual_scale_object_init", 0.0)))
+    if rank == 0:
+        print("train_end2end: %s | %d GPU(s) x batch %d | lr %.3e wd %.1e clip %.1f | schedule %s warmup %d t_total %d%s" %
+              (config.MODULE, world, B, r["lr"], r["weight_decay"], r["clip_grad_norm"], r["lr_schedule"], r["warmup_steps"], r["t_total"],
+               " | fp16 requested -> bf16 compute (no loss scaling needed)" if r["fp16_requested"] else ""), flush=True)
+    t0, seen = time.time(), 0
+    def load_batch(seed_off):
+        batch = list(syn.make_batch(B, T, R, seed=1000 * rank + seed_off))
+        kw = {}
+        if r["multitask"]:
+            aux_text, aux_lab = syn.make_aux_text(B_aux, T, seed=5000 * (rank + 1) + seed_off)
+            kw.update(aux_text=aux_text.cuda(non_blocking=True), aux_mlm_labels=aux_lab.cuda(non_blocking=True))
+        if r["e2e"]:
+            Hi, Wi = r["image_size"]
+            gi = torch.Generator().manual_seed(7000 * (rank + 1) + seed_off)
+            kw["image"] = (torch.randn(B, 3, Hi, Wi, generator=gi) * 50.0).cuda(non_blocking=True)
+            batch[0][:, :, 0].clamp_(0, Wi - 170)
+            batch[0][:, :, 1].clamp_(0, Hi - 170)
+            batch[0][:, :, 2] = torch.minimum(batch[0][:, :, 2], torch.full_like(batch[0][:, :, 2], Wi - 1.0))
+            batch[0][:, :, 3] = torch.minimum(batch[0][:, :, 3], torch.full_like(batch[0][:, :, 3], Hi - 1.0))
+            batch[1][:, 0], batch[1][:, 1] = Wi, Hi
+        eng.set_batch(*[t.cuda(non_blocking=True) for t in batch], **kw)
+
+    accum = r["accumulate"]
+    for step in range(args.steps):
+        if accum == 1:
+            load_batch(step)
+            eng.train_step()
+        else:      # common/trainer.py:117-153: loss / accumulate per micro-batch, exchange + optimizer on the boundary micro-step
+            eng.zero_grad()
+            for micro in range(accum):
+                load_batch(step * accum + micro)
+                eng.forward(True, gscale=1.0 / accum)
+                last = micro == accum - 1
+                eng.backward(True, on_layer_done=eng.buckets.on_done if (last and eng.buckets is not None) else None)
+            if eng.buckets is not None:
+                eng.buckets.wait()
+            eng.optimizer_step()
+        seen += B * world * accum
+        if (step + 1) % max(1, min(int(config.LOG_FREQUENT), args.steps)) == 0 or step + 1 == args.steps:
+            lv = eng.loss_values()          # host sync, like the reference's Speedometer + metric readout
+            if rank == 0:
+                print("step %d  lr %.3e  loss %.4f (mlm %.4f mvrc %.4f)  %.1f samples/s" %
+                      (step + 1, float(eng.adam[0]), lv["loss"], lv["mlm_loss"], lv["mvrc_loss"], seen / (time.time() - t0)), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return eng
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])
