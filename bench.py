@@ -107,6 +107,7 @@ def main():
     ap.add_argument("--image-size", type=int, nargs=2, default=(600, 1000))
     ap.add_argument("--layers", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-phase-times", action="store_true", help="skip the separate forward / forward+backward timing loops (profiling runs)")
     ap.add_argument("--graph", action="store_true", help="replay the step as one hipGraph (single GPU).  Off by default: the step is "
                     "GPU-bound, not launch-bound -- measured on MI355X the eager stream launches are 3-5 %% FASTER than the graph replay "
                     "(26.97 vs 27.84 ms at batch 256, 6.72 vs 7.11 ms at batch 32)")
@@ -204,7 +205,7 @@ def main():
         return e0.elapsed_time(e1) / n
 
     fwd_ms = fwd_bwd_ms = None
-    if world == 1:
+    if world == 1 and not args.no_phase_times:
         fwd_ms = timed_loop(lambda: eng.forward(True))
 
         def fwd_bwd():

@@ -65,11 +65,11 @@ def kernel_stats(trace, out_name, cmd_note):
 
 
 kernel_stats("final_trace", tag + "_kernel_stats.txt",
-             "# VLB_WGRAD_STREAM=0 rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline\n")
+             "# VLB_WGRAD_STREAM=0 rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-phase-times\n")
 if glob.glob(os.path.join(src, "final_e2e_trace", "*.db")):
     kernel_stats("final_e2e_trace", tag + "_e2e_kernel_stats.txt",
                  "# VLB_WGRAD_STREAM=0 VLB_VISION_WGRAD_STREAM=0 rocprofv3 --kernel-trace --stats -- python bench.py --e2e --steps 3 --warmup 1 "
-                 "--no-graph --no-cpu-baseline\n# (config C3: 8 images of 600x1000, ResNet-101 trunk + ROIAlign + dilated layer4 head + the VL-BERT step)\n")
+                 "--no-graph --no-cpu-baseline --no-phase-times\n# (config C3: 8 images of 600x1000, ResNet-101 trunk + ROIAlign + dilated layer4 head + the VL-BERT step)\n")
 
 
 # ---------------------------------------------------------------- PMC helpers
