@@ -570,7 +570,17 @@ def test_engine_maximum_sequence_length_vs_oracle():
     check_against_oracle("S=128", cfg, params, batch)
     E = pkg("engine")
     with pytest.raises(ValueError):
-        E.PretrainEngine(E.ModelConfig(num_hidden_layers=1), 1, 92, 36, device="cuda:0")
+        E.PretrainEngine(E.ModelConfig(num_hidden_layers=1), 1, 156, 100, device="cuda:0")
+
+
+def test_engine_long_sequence_128_text_100_regions_vs_oracle():
+    """S = 128 + 100 + 1 = 229 (the VL-BERT-large VQA / VCR sequence shape of BASELINE.json configs 4-5) through the
+    8-key-block attention instantiation, ragged batch, 2 layers."""
+    syn = pkg("synthetic")
+    cfg = O.VLBertConfig(num_hidden_layers=2, max_position_embeddings=512)
+    params = O.init_params(cfg, seed=33)
+    batch = syn.make_batch(2, 128, 100, seed=34, ragged=True)
+    check_against_oracle("S=229", cfg, params, batch)
 
 
 def test_engine_large_model_width_vs_oracle():

@@ -291,7 +291,9 @@ def attn_ref(qkv, mask, B, S, H, nh, keep=None, scale_drop=1.0):
 
 
 @pytest.mark.parametrize("B,S,nh,p", [(2, 101, 2, 0.0), (3, 43, 1, 0.0), (1, 128, 3, 0.0), (2, 20, 2, 0.0), (2, 101, 2, 0.1),
-                                      (1, 65, 1, 0.25)])
+                                      (1, 65, 1, 0.25),
+                                      # S > 128: the 8-key-block / two-slices-per-wave instantiation (large + VCR configurations)
+                                      (2, 229, 2, 0.0), (1, 256, 1, 0.0), (2, 129, 1, 0.0), (2, 200, 2, 0.1)])
 def test_attention_fwd_bwd(ops, B, S, nh, p):
     H = nh * 64
     qkv = rnd(B * S, 3 * H, seed=30, scale=1.0)

@@ -1,4 +1,5 @@
-// Fused multi-head self-attention forward / backward for short sequences (S <= 128, d = 64)
+// Fused multi-head self-attention forward / backward for short sequences (S <= 128, or S <= 256 with two 16-row slices per
+// wave: the large / VCR configurations with 128 text + 100 regions; d = 64)
 // on gfx950 -- BertSelfAttention (external/pytorch_pretrained_bert/modeling.py:290-319):
 //     scores = Q K^T / sqrt(d) + (1-mask)*-10000 ; P = softmax(scores) ; P = dropout(P) ; ctx = P V
 // The reference materialises [B,h,S,S] scores/probs in HBM (15.7 MB per layer at B=32) and runs
@@ -26,9 +27,8 @@
 // orientations regenerate identical masks, nothing is stored.
 #include "vlb_common.h"
 
-#define ATT_SP 128      // padded sequence length handled by one workgroup
+#define ATT_SP_MAX 256  // longest padded sequence one workgroup handles (template NU = SP / 32 key blocks: 4 or 8)
 #define ATT_D 64
-#define TILE_BYTES (ATT_SP * ATT_D * 2)  // 16 KiB per [128][64] image
 #define ATT_THREADS 512
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -63,9 +63,10 @@ __device__ __forceinline__ bf16x8 frag_tr(const char* img, int blk, int d0, int 
 }
 
 // Stage one [S][64] head slice (row stride ld elements) into a row-major image at permuted rows; rows >= S zero.
+template <int SP>
 __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, long ld, int S, char* img, int tid) {
 #pragma unroll
-  for (int it = 0; it < 1024 / ATT_THREADS; ++it) {
+  for (int it = 0; it < SP * 8 / ATT_THREADS; ++it) {
     const int P = it * ATT_THREADS + tid, s = P >> 3, ch = P & 7;
     uint4 v = make_uint4(0, 0, 0, 0);
     if (s < S) v = *(const uint4*)(g + (long)s * ld + ch * 8);
@@ -109,11 +110,13 @@ struct AttnParams {
 // =============================================================================================
 // forward: wave w owns queries 16w .. 16w+15
 // =============================================================================================
-__global__ __launch_bounds__(ATT_THREADS, 4) void attn_fwd_kernel(const AttnParams p) {
+template <int NU, int QS>   // NU key blocks of 32 (padded length SP = 32 NU), QS 16-query slices per wave (8 waves x QS x 16 = SP)
+__global__ __launch_bounds__(ATT_THREADS, NU <= 4 ? 4 : 2) void attn_fwd_kernel(const AttnParams p) {
+  constexpr int ATT_SP = 32 * NU, TILE_BYTES = ATT_SP * ATT_D * 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sK = smem;
   char* sV = smem + TILE_BYTES;
-  float* sMB = (float*)(smem + 2 * TILE_BYTES);     // [128] additive mask (-inf beyond S)
+  float* sMB = (float*)(smem + 2 * TILE_BYTES);     // [SP] additive mask (-inf beyond S)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
@@ -121,11 +124,18 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_fwd_kernel(const AttnPara
   const int S = p.S;
   const long ld = 3L * p.H;
   const bf16_t* qbase = p.qkv + (long)b * S * ld + h * ATT_D;
-  stage_tile(qbase + p.H, ld, S, sK, tid);
-  stage_tile(qbase + 2 * p.H, ld, S, sV, tid);
+  stage_tile<ATT_SP>(qbase + p.H, ld, S, sK, tid);
+  stage_tile<ATT_SP>(qbase + 2 * p.H, ld, S, sV, tid);
   if (tid < ATT_SP) sMB[tid] = (tid < S) ? (1.0f - p.mask[b * S + tid]) * -10000.0f : -INFINITY;
+  __syncthreads();
+  const uint32_t seed = (p.drop_thr && p.seed) ? *p.seed : 0u;
+  const uint32_t key = vlb_hash32(seed ^ (p.tag * 0x85ebca6bu + 0x632be5abu));
+  const int U = (S + 31) >> 5;  // key blocks of 32 actually present
 
-  const int q0 = wave * 16;
+#pragma unroll 1
+  for (int qs = 0; qs < QS; ++qs) {
+  const int q0 = (wave + 8 * qs) * 16;
+  if (q0 >= S) break;
   // Q fragment straight from global in B-operand layout: lane (c, g) <- Q[q0+c][32ds+8g ..+8)
   bf16x8 qf[2];
   {
@@ -133,13 +143,10 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_fwd_kernel(const AttnPara
 #pragma unroll
     for (int ds = 0; ds < 2; ++ds) qf[ds] = *(const bf16x8*)(qbase + (long)q * ld + ds * 32 + g * 8);
   }
-  __syncthreads();
-  if (q0 >= S) return;
 
-  const int U = (S + 31) >> 5;  // key blocks of 32 actually present
-  f32x4 sc[4][2];               // [u][half] : S^T tiles (keys x this wave's 16 queries)
+  f32x4 sc[NU][2];              // [u][half] : S^T tiles (keys x this wave's 16 queries)
 #pragma unroll
-  for (int u = 0; u < 4; ++u)
+  for (int u = 0; u < NU; ++u)
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
       sc[u][hf] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -153,7 +160,7 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_fwd_kernel(const AttnPara
   // softmax over keys for the lane's query: lane-local 32 values, then across g
   float mx = -INFINITY;
 #pragma unroll
-  for (int u = 0; u < 4; ++u)
+  for (int u = 0; u < NU; ++u)
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
@@ -166,7 +173,7 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_fwd_kernel(const AttnPara
   mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
   float sum = 0.f;
 #pragma unroll
-  for (int u = 0; u < 4; ++u)
+  for (int u = 0; u < NU; ++u)
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
@@ -181,12 +188,10 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_fwd_kernel(const AttnPara
   const int q = q0 + c;
   if (g == 0 && q < S) p.lse[((long)b * p.nh + h) * S + q] = mx + __logf(sum);
 
-  const uint32_t seed = (p.drop_thr && p.seed) ? *p.seed : 0u;
-  const uint32_t key = vlb_hash32(seed ^ (p.tag * 0x85ebca6bu + 0x632be5abu));
   const uint32_t qrow = ((uint32_t)(b * p.nh + h) * (uint32_t)S + (uint32_t)min(q, S - 1)) * (uint32_t)S;
-  bf16x8 pf[4];  // [u]  P (after dropout) as MFMA operand, k = 8g + (4*half + r)
+  bf16x8 pf[NU];  // [u]  P (after dropout) as MFMA operand, k = 8g + (4*half + r)
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
+  for (int u = 0; u < NU; ++u) {
     float v[8];
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf)
@@ -202,17 +207,20 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_fwd_kernel(const AttnPara
   for (int dt = 0; dt < 4; ++dt) {
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < NU; ++u)
       if (u < U) o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(sV, u, dt * 16, lane), pf[u], o, 0, 0, 0);
     if (q < S) *(uint2*)(orow + dt * 16) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));   // rows d = dt*16 + 4g + r
   }
+  }   // qs
 }
 
 // =============================================================================================
 // backward: wave w owns sequence positions 16w .. 16w+15, first as KEYS (dK, dV; reductions over all
 // queries), then as QUERIES (dQ; reduction over all keys)
 // =============================================================================================
-__global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_kernel(const AttnParams p) {
+template <int NU, int QS>
+__global__ __launch_bounds__(ATT_THREADS, NU <= 4 ? 4 : 2) void attn_bwd_kernel(const AttnParams p) {
+  constexpr int ATT_SP = 32 * NU, TILE_BYTES = ATT_SP * ATT_D * 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sQ = smem;
   char* sK = smem + 1 * TILE_BYTES;
@@ -230,13 +238,13 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_kernel(const AttnPara
   const bf16_t* qbase = p.qkv + (long)b * S * ld + h * ATT_D;
   const bf16_t* dobase = p.dctx + (long)b * S * p.H + h * ATT_D;
   const bf16_t* obase = p.ctx + (long)b * S * p.H + h * ATT_D;
-  stage_tile(qbase, ld, S, sQ, tid);
-  stage_tile(qbase + p.H, ld, S, sK, tid);
-  stage_tile(qbase + 2 * p.H, ld, S, sV, tid);
-  stage_tile(dobase, p.H, S, sdO, tid);
+  stage_tile<ATT_SP>(qbase, ld, S, sQ, tid);
+  stage_tile<ATT_SP>(qbase + p.H, ld, S, sK, tid);
+  stage_tile<ATT_SP>(qbase + 2 * p.H, ld, S, sV, tid);
+  stage_tile<ATT_SP>(dobase, p.H, S, sdO, tid);
   // D[q] = sum_d dO[q][d] * O[q][d]   (8 lanes per row, 8 elements each)
 #pragma unroll
-  for (int it = 0; it < 1024 / ATT_THREADS; ++it) {
+  for (int it = 0; it < ATT_SP * 8 / ATT_THREADS; ++it) {
     const int P = it * ATT_THREADS + tid, row = P >> 3, ch = P & 7;
     float d = 0.f;
     if (row < S) {
@@ -256,12 +264,14 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_kernel(const AttnPara
   }
   __syncthreads();
 
-  const int w16 = wave * 16;
-  if (w16 >= S) return;
   const uint32_t seed = (p.drop_thr && p.seed) ? *p.seed : 0u;
   const uint32_t key = vlb_hash32(seed ^ (p.tag * 0x85ebca6bu + 0x632be5abu));
   const uint32_t bh = (uint32_t)(b * p.nh + h);
   const int U = (S + 31) >> 5;
+#pragma unroll 1
+  for (int qs = 0; qs < QS; ++qs) {
+  const int w16 = (wave + 8 * qs) * 16;
+  if (w16 >= S) break;
   const int pos = w16 + c;                          // this lane's key (role N) / query (role T)
   const bool pos_ok = pos < S;
 
@@ -280,8 +290,9 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_kernel(const AttnPara
     for (int dt = 0; dt < 4; ++dt) dv[dt] = dk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const float mb = sMB[pos];
     const uint32_t kcol = (uint32_t)min(pos, S - 1);
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
+    // (the 8-block instantiation is NOT unrolled across blocks: interleaving eight iterations blew the register budget)
+#pragma unroll (NU <= 4 ? NU : 1)
+    for (int v = 0; v < NU; ++v) {
       if (v < U) {
         float pv[8], dsv[8];
 #pragma unroll
@@ -340,8 +351,8 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_kernel(const AttnPara
     for (int dt = 0; dt < 4; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const float lse = sLSE[pos], dd = sD[pos];
     const uint32_t qrow = (bh * (uint32_t)S + (uint32_t)min(pos, S - 1)) * (uint32_t)S;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
+#pragma unroll (NU <= 4 ? NU : 1)
+    for (int u = 0; u < NU; ++u) {
       if (u < U) {
         float pr[8], dpv[8];
 #pragma unroll
@@ -376,11 +387,12 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_kernel(const AttnPara
                                                pack2bf(dq[dt][2] * p.scale, dq[dt][3] * p.scale));
     }
   }
+  }   // qs
 }
 
 // ---------------------------------------------------------------------------------- C ABI
 static int check_attn(const char* name, int B, int S, int H, int nh) {
-  VLB_CHECK_ARG(B > 0 && S > 0 && S <= ATT_SP, "%s: S=%d unsupported (1..%d)", name, S, ATT_SP);
+  VLB_CHECK_ARG(B > 0 && S > 0 && S <= ATT_SP_MAX, "%s: S=%d unsupported (1..%d)", name, S, ATT_SP_MAX);
   VLB_CHECK_ARG(nh > 0 && H == nh * ATT_D, "%s: head dim must be 64 (H=%d, heads=%d)", name, H, nh);
   VLB_CHECK_ARG((long)B * nh * S * S < (1L << 32), "%s: dropout index overflow", name);
   return VLB_OK;
@@ -396,8 +408,18 @@ extern "C" int vlb_attention_fwd(const void* qkv, const float* mask, void* ctx, 
   p.qkv = (const bf16_t*)qkv; p.mask = mask; p.ctx = (bf16_t*)ctx; p.lse = lse; p.dctx = nullptr; p.dqkv = nullptr;
   p.B = B; p.S = S; p.H = H; p.nh = nh; p.scale = 0.125f;
   p.drop_thr = vlb_drop_thr(drop_p); p.drop_scale = vlb_drop_scale(p.drop_thr); p.seed = seed; p.tag = tag;
-  const int smem = 2 * TILE_BYTES + ATT_SP * 4;
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * nh), dim3(ATT_THREADS), smem, stream, p);
+  if (S <= 128) {
+    const int smem = 2 * (128 * ATT_D * 2) + 128 * 4;
+    hipLaunchKernelGGL((attn_fwd_kernel<4, 1>), dim3(B * nh), dim3(ATT_THREADS), smem, stream, p);
+  } else {
+    const int smem = 2 * (256 * ATT_D * 2) + 256 * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((attn_fwd_kernel<8, 2>), dim3(B * nh), dim3(ATT_THREADS), smem, stream, p);
+  }
   VLB_CHECK_LAUNCH("vlb_attention_fwd");
   return VLB_OK;
 }
@@ -414,13 +436,16 @@ extern "C" int vlb_attention_bwd(const void* qkv, const float* mask, const void*
   p.dqkv = (bf16_t*)dqkv;
   p.B = B; p.S = S; p.H = H; p.nh = nh; p.scale = 0.125f;
   p.drop_thr = vlb_drop_thr(drop_p); p.drop_scale = vlb_drop_scale(p.drop_thr); p.seed = seed; p.tag = tag;
-  const int smem = 4 * TILE_BYTES + 3 * ATT_SP * 4;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (128 * ATT_D * 2) + 3 * 128 * 4);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (256 * ATT_D * 2) + 3 * 256 * 4);
     attr_set = true;
   }
-  hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * nh), dim3(ATT_THREADS), smem, stream, p);
+  if (S <= 128)
+    hipLaunchKernelGGL((attn_bwd_kernel<4, 1>), dim3(B * nh), dim3(ATT_THREADS), 4 * (128 * ATT_D * 2) + 3 * 128 * 4, stream, p);
+  else
+    hipLaunchKernelGGL((attn_bwd_kernel<8, 2>), dim3(B * nh), dim3(ATT_THREADS), 4 * (256 * ATT_D * 2) + 3 * 256 * 4, stream, p);
   VLB_CHECK_LAUNCH("vlb_attention_bwd");
   return VLB_OK;
 }

@@ -191,8 +191,8 @@ class PretrainEngine:
             raise ValueError("B_aux > 0 needs ModelConfig(multitask=True)")
         self.Bt = B + B_aux
         self.S = T + R + 1
-        if self.S > 128:
-            raise ValueError("sequence %d+%d+1 > 128: the fused attention kernel handles S <= 128" % (T, R))
+        if self.S > 256:
+            raise ValueError("sequence %d+%d+1 > 256: the fused attention kernels handle S <= 256" % (T, R))
         self.dev = torch.device(device)
         self.train = train
         self.grad_accum = grad_accum
