@@ -65,8 +65,8 @@ def cpu_baseline(cfg_kw, T, R, budget_s=25.0):
         it += 1
     t = min(times[1:]) if len(times) > 1 else times[0]
     return {"value": round(Bc / t, 3), "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": "oracle fwd+bwd+AdamW, 12-layer base, batch %d x (64+36), fp32, dropout on, %d iterations (best of last %d)"
-                      % (Bc, len(times), max(1, len(times) - 1))}
+            "sample": "oracle fwd+bwd+AdamW, %d-layer hidden %d, batch %d x (%d+%d), fp32, dropout on, %d iterations (best of last %d)"
+                      % (cfg.num_hidden_layers, cfg.hidden_size, Bc, T, R, len(times), max(1, len(times) - 1))}
 
 
 def cpu_baseline_e2e(cfg_kw, T, R, image_size, vlbert):
@@ -105,6 +105,8 @@ def main():
     ap.add_argument("--e2e", action="store_true", help="config C3 (cfgs/pretrain/base_e2e_16x16G_fp16.yaml): ResNet-101 trunk + ROIAlign + "
                     "layer4 head on 600x1000 images, 8 images per GPU, in front of the same VL-BERT step")
     ap.add_argument("--image-size", type=int, nargs=2, default=(600, 1000))
+    ap.add_argument("--large", action="store_true", help="VL-BERT-large shape of BASELINE.json configs 4-5 through the same pretraining step: "
+                    "24 layers, hidden 1024, 16 heads, FFN 4096, 128 text + 100 regions (S = 229); default global batch 64")
     ap.add_argument("--layers", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-phase-times", action="store_true", help="skip the separate forward / forward+backward timing loops (profiling runs)")
@@ -135,11 +137,15 @@ def main():
     ops = importlib.import_module("vl-bert_amd.ops")
     arch, cus = lib.device_info(local_rank)
 
-    T, R = 64, 36
+    T, R = (128, 100) if args.large else (64, 36)
     if args.global_batch is None:
-        args.global_batch = 8 * world if args.e2e else 256
+        args.global_batch = 8 * world if args.e2e else (64 if args.large else 256)
     per_gpu = args.global_batch // world
-    cfg = engine.ModelConfig(num_hidden_layers=args.layers, e2e=args.e2e)
+    if args.large:
+        args.layers = 24
+        cfg = engine.ModelConfig(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096, e2e=args.e2e)
+    else:
+        cfg = engine.ModelConfig(num_hidden_layers=args.layers, e2e=args.e2e)
     eng = engine.PretrainEngine(cfg, per_gpu, T, R, device="cuda:%d" % local_rank, train=True, lr=1e-4, weight_decay=1e-4,
                                 max_grad_norm=10.0, seed=1234 + rank, image_size=tuple(args.image_size) if args.e2e else None)
     eng.init_random(seed=0, visual_ln_init=1.0 if args.e2e else 0.0)   # same weights on every rank (DDP broadcast, train.py:332-334)
@@ -274,13 +280,13 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": ("samples/sec VL-BERT-base e2e pretrain (ResNet-101 on %dx%d images + seq 64+36 regions)" % tuple(args.image_size))
+            "metric": "samples/sec VL-BERT-large pretrain step (seq 128+100 regions)" if args.large else ("samples/sec VL-BERT-base e2e pretrain (ResNet-101 on %dx%d images + seq 64+36 regions)" % tuple(args.image_size))
             if args.e2e else "samples/sec VL-BERT-base pretrain (seq 64+36 regions) at 1/2/4/8 MI355X",
             "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak" if args.e2e else "strong", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic (random-init weights, random tokens/boxes/features, resident in HBM)",
-            "config": {"workload": "VL-BERT-base %d-layer pretrain step (fwd+bwd+clip+AdamW), 64 text + 36 regions, "
-                                   "%s, dropout on" % (args.layers, "ResNet-101 trunk + ROIAlign + dilated layer4 head on the device "
+            "config": {"workload": "VL-BERT-%s %d-layer pretrain step (fwd+bwd+clip+AdamW), %d text + %d regions, "
+                                   "%s, dropout on" % ("large" if args.large else "base", args.layers, T, R, "ResNet-101 trunk + ROIAlign + dilated layer4 head on the device "
                                                        "(stages 1-2 and BatchNorm frozen)" if args.e2e else "precomputed 2048-d region features"),
                        "global_batch": args.global_batch, "per_gpu_batch": per_gpu, "seq_len": T + R + 1,
                        "parallelism": "dp%d" % world, "hipgraph": bool(use_graph), "arch": arch, "cus": cus},
@@ -296,7 +302,9 @@ def main():
             "loss": round(losses["loss"], 4),
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(dict(num_hidden_layers=args.layers), T, R, budget_s=12.0 if args.e2e else 25.0)
+            ckw = dict(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096) if args.large \
+                else dict(num_hidden_layers=args.layers)
+            out["cpu_baseline"] = cpu_baseline(ckw, T, R, budget_s=12.0 if args.e2e else 25.0)
             if args.e2e:
                 out["cpu_baseline"] = cpu_baseline_e2e(dict(num_hidden_layers=args.layers), T, R, tuple(args.image_size), out["cpu_baseline"])
         print(json.dumps(out), flush=True)
