@@ -97,3 +97,37 @@ def test_train_end2end_entry_point_dry_run(tmp_path):
     if not torch.cuda.is_available():
         with pytest.raises(RuntimeError, match="no CPU execution path"):
             tr.main(["--cfg", str(y), "--steps", "1"])
+
+
+def test_vision_host_tables_match_the_reference_state_dict_layout():
+    """Host logic of the e2e path (no GPU): the convolution / parameter tables of vl-bert_amd/vision.py name exactly the tensors of the
+    reference's FastRCNN state dict (as restated by oracle/vision_oracle.py, itself pinned to the reference module), with the
+    reference's shapes up to the documented [O,I,KH,KW] -> [O,KH,KW,I] permutation, and the frozen / trainable split of
+    IMAGE_FROZEN_BACKBONE_STAGES = [1, 2] + IMAGE_FROZEN_BN."""
+    from oracle import vision_oracle as VO
+    V = importlib.import_module("vl-bert_amd.vision")
+    for nl in (50, 101):
+        P = VO.init_vision_params(0, nl, randomize_bn=False)
+        ref = {"image_feature_extractor." + k: v for k, v in VO.split_state_dict(P).items()}
+        frozen = {"image_feature_extractor." + k for k in VO.split_state_dict({n: P[n] for n in VO.frozen_names(P)})}
+        convs = V.conv_table(nl, (1, 2))
+        names = set()
+        for key, O, I, k, bn, tr in convs:
+            w = "image_feature_extractor." + key + ".weight"
+            assert tuple(ref[w].shape) == (O, I, k, k), w
+            assert (w in frozen) == (not tr), w
+            names.add(w)
+            for suffix in ("weight", "bias", "running_mean", "running_var"):
+                b = "image_feature_extractor." + bn + "." + suffix
+                assert tuple(ref[b].shape) == (O,) and b in frozen, b
+                names.add(b)
+        assert names == set(ref), names ^ set(ref)
+        lay = V.vision_param_layout(nl, (1, 2))
+        assert set(lay) == {n for n in ref if n not in frozen}
+        for n, shp in lay.items():
+            O, I, kh, kw = ref[n].shape
+            assert shp == (O, kh, kw, I), n
+        # geometry of the e2e configuration: 600x1000 -> stride-16 body4 of 38x63, 14x14 RoI maps
+        blocks = V.block_table(nl)
+        assert [b["stride"] for b in blocks if b["index"] == 0] == [1, 2, 2, 1] and blocks[-1]["dil"] == 2
+        assert sum(b["downsample"] for b in blocks) == 4
