@@ -274,12 +274,72 @@ def run_vision_case(name="vision_small", num_layers=50):
     print("%s -> %s (%.1f KB), %d trainable tensors" % (name, path, os.path.getsize(path) / 1024, len(keys)))
 
 
+def run_vqa_case(name="vqa_small"):
+    """VQA fixture: the reference's own vqa.modules.resnet_vlbert_for_vqa.ResNetVLBERT (precomputed features, "2fc" classifier) in
+    eval-free train_forward with every dropout at p = 0, parameters from oracle/vqa_oracle.init_vqa_params; stores inputs, logits,
+    loss and gradient digests; checks the restatement against it."""
+    from . import vqa_oracle as VQ
+    ref_import.import_reference()
+    from vqa.modules.resnet_vlbert_for_vqa import ResNetVLBERT as RefVQA
+    cfg = VLBertConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                       vocab_size=512, max_position_embeddings=64, visual_region_classes=50, hidden_dropout_prob=0.0,
+                       attention_probs_dropout_prob=0.0, obj_downsample_dropout=0.0)
+    A, hidden = 37, 96
+    vocab_dir = ref_import.make_vocab_dir(os.path.join(tempfile.gettempdir(), "vlb_vocab_%s" % name), cfg.vocab_size)
+    rc = ref_import.make_reference_config(cfg, vocab_dir)
+    E = ref_import._EasyDict
+    rc.NETWORK.update(dict(BLIND=False, NO_GROUNDING=False, ENABLE_CNN_REG_LOSS=False, CLASSIFIER_TYPE="2fc", CLASSIFIER_DROPOUT=0.0,
+                           CLASSIFIER_HIDDEN_SIZE=hidden, CLASSIFIER_PRETRAINED=False))
+    for k, v in dict(BLIND=False, NO_GROUNDING=False, ENABLE_CNN_REG_LOSS=False, CLASSIFIER_TYPE="2fc", CLASSIFIER_DROPOUT=0.0,
+                     CLASSIFIER_HIDDEN_SIZE=hidden).items():
+        setattr(rc.NETWORK, k, v)
+    rc.DATASET = E(dict(ANSWER_VOCAB_SIZE=A))
+    torch.manual_seed(0)
+    model = RefVQA(rc)
+    pseed = 9
+    params = VQ.init_vqa_params(cfg, pseed, A, "2fc", hidden)
+    sd = model.state_dict()
+    missing = [k for k in sd if k not in params and not k.endswith("num_batches_tracked")]
+    assert not missing, missing
+    model.load_state_dict({k: params[k] for k in sd}, strict=True)
+    model.train()
+    model.image_feature_extractor.obj_downsample[0].p = 0.0
+    B, Lq, R = 3, 9, 6
+    syn = importlib.import_module("vl-bert_amd.synthetic")
+    batch = syn.make_batch(B, 8, R, vocab_size=cfg.vocab_size, region_classes=cfg.visual_region_classes, seed=13, ragged=True)
+    boxes, im_info = batch[0], batch[1]
+    g = torch.Generator().manual_seed(14)
+    question = torch.randint(200, cfg.vocab_size, (B, Lq), generator=g)
+    qlen = torch.tensor([Lq, 5, 7])
+    question[torch.arange(Lq)[None, :] >= qlen[:, None]] = 0
+    label = (torch.rand(B, A, generator=g) < 0.1).float() * torch.rand(B, A, generator=g)       # soft VQA scores
+    outputs, loss = model(None, boxes.clone(), im_info, question, label)
+    loss.backward()
+    ref_grads = {k: v.grad.detach() for k, v in model.named_parameters() if v.grad is not None}
+    out2, loss2 = VQ.vqa_forward({k: v.clone().requires_grad_(True) for k, v in params.items()}, cfg, boxes, im_info, question, label,
+                                 classifier="2fc", classifier_dropout=0.0, train=False)
+    err = float((out2["label_logits"] - outputs["label_logits"]).abs().max())
+    print("%s: restatement vs reference |d logits|max %.3e, loss %.6f vs %.6f" % (name, err, float(loss2), float(loss)))
+    assert err < 1e-4 and abs(float(loss2) - float(loss)) < 1e-5
+    keys = sorted(ref_grads)
+    path = os.path.join(ROOT, "tests", "golden", "vqa", name + ".npz")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    np.savez_compressed(path, pseed=pseed, answer_vocab=A, classifier_hidden=hidden, boxes=boxes.numpy(), im_info=im_info.numpy(),
+                        question=question.numpy(), label=label.numpy(), logits=outputs["label_logits"].detach().numpy(),
+                        loss=float(loss), grad_names=np.array(keys),
+                        grad_norms=np.array([float(ref_grads[k].double().norm()) for k in keys]),
+                        grad_total_norm=float(torch.sqrt(sum((g_.double() ** 2).sum() for g_ in ref_grads.values()))))
+    print("%s -> %s (%.1f KB), %d gradient tensors" % (name, path, os.path.getsize(path) / 1024, len(keys)))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     if len(sys.argv) > 1 and sys.argv[1] == "core":
         run_core_case()
     elif len(sys.argv) > 1 and sys.argv[1] == "vision":
         run_vision_case()
+    elif len(sys.argv) > 1 and sys.argv[1] == "vqa":
+        run_vqa_case()
     else:
         for name, spec in CASES.items():
             run_case(name, spec)

@@ -159,3 +159,35 @@ def test_vision_oracle_matches_reference_fast_rcnn_e2e():
         assert np.allclose(np.resize(s, 64), want_s, rtol=1e-3, atol=1e-6 * want_norm), k
     for k in frozen:
         assert Po[k].grad is None
+
+
+def load_vqa_case():
+    from oracle import vqa_oracle as VQ
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "vqa", "vqa_small.npz"), allow_pickle=False)
+    cfg = O.VLBertConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, vocab_size=512,
+                         max_position_embeddings=64, visual_region_classes=50, hidden_dropout_prob=0.0,
+                         attention_probs_dropout_prob=0.0, obj_downsample_dropout=0.0)
+    params = VQ.init_vqa_params(cfg, int(z["pseed"]), int(z["answer_vocab"]), "2fc", int(z["classifier_hidden"]))
+    batch = tuple(torch.from_numpy(z[k]) for k in ("boxes", "im_info", "question", "label"))
+    return z, cfg, params, batch
+
+
+def test_vqa_oracle_matches_reference_module():
+    """oracle/vqa_oracle.py against the fixture produced by the reference's own vqa ResNetVLBERT.train_forward: logits, loss and the
+    gradient norm of every parameter."""
+    from oracle import vqa_oracle as VQ
+    z, cfg, params, batch = load_vqa_case()
+    leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    out, loss = VQ.vqa_forward(leaves, cfg, *batch, classifier="2fc", classifier_dropout=0.0, train=False)
+    assert np.allclose(out["label_logits"].detach().numpy(), z["logits"], atol=1e-5)
+    assert abs(float(loss) - float(z["loss"])) < 1e-5
+    loss.backward()
+    for k, n in zip(z["grad_names"], z["grad_norms"]):
+        g = leaves[str(k)].grad
+        assert g is not None and abs(float(g.double().norm()) - n) <= 1e-4 * n + 1e-9, k
+    # text preparation: [CLS] q [SEP] [MASK] [SEP], answer position = the [MASK]
+    ids, types, mask, ans_pos = VQ.prepare_text_from_qa(batch[2])
+    for b in range(ids.shape[0]):
+        L = int((batch[2][b] > 0).sum())
+        assert ids[b, 0] == 101 and ids[b, L + 1] == 102 and ids[b, L + 2] == 103 and ids[b, L + 3] == 102 and int(ans_pos[b]) == L + 2
+        assert int(mask[b].sum()) == L + 4 and types[b, L + 2] == 1 and types[b, L + 1] == 0

@@ -40,6 +40,8 @@ _SIGS = {
     "vlb_ce_fwd_bwd": "pliippfppls",
     "vlb_soft_ce_fwd_bwd": "pliiplppfppls",
     "vlb_sumsq_f32": "plps",
+    "vlb_bce_logits_fwd_bwd": "pliiplfppls",
+    "vlb_dropout_bf16": "pplfpus",
     "vlb_sumsq_f32_det": "plpips",
     "vlb_adamw_step": "ppppplpfs",
     "vlb_lr_schedule_step": "pifffs",

@@ -190,3 +190,69 @@ extern "C" int vlb_soft_ce_fwd_bwd(void* logits, long ld, int rows, int C, const
   VLB_CHECK_LAUNCH("vlb_soft_ce_fwd_bwd");
   return VLB_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// VQA answer loss (vqa/modules/resnet_vlbert_for_vqa.py:226): F.binary_cross_entropy_with_logits(logits[B,A], label) * A,
+// i.e. (1/B) sum_b sum_a ( max(x,0) - x y + log(1 + exp(-|x|)) ); d/dx = (sigmoid(x) - y) / B.  Forward and backward fused like
+// the CE kernels: logits (bf16 [rows, ld], columns >= A are padding and are zeroed) are overwritten by gscale * d(loss)/dx, the
+// untouched logits are copied out when asked for (label_logits of the reference's outputs dict).  One block per row.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bce_logits_fwd_bwd_kernel(bf16_t* __restrict__ logits, long ld, int A, const float* __restrict__ label,
+                                                                 long ldl, int rows, float gscale, float* __restrict__ loss_out,
+                                                                 bf16_t* __restrict__ logits_copy, long ldcopy) {
+  __shared__ float sh[4];
+  const int row = blockIdx.x;
+  bf16_t* x = logits + (long)row * ld;
+  const float* y = label + (long)row * ldl;
+  const float inv_rows = 1.0f / (float)rows;
+  float acc = 0.f;
+  for (int a = threadIdx.x; a < (int)ld; a += 256) {
+    if (a < A) {
+      const float v = bf2f(x[a]), t = y[a];
+      if (logits_copy) logits_copy[(long)row * ldcopy + a] = x[a];
+      const float e = __expf(-fabsf(v));
+      acc += fmaxf(v, 0.f) - v * t + log1pf(e);
+      const float sig = v >= 0.f ? 1.0f / (1.0f + e) : e / (1.0f + e);
+      x[a] = f2bf((sig - t) * inv_rows * gscale);
+    } else {
+      x[a] = 0;
+      if (logits_copy && a < (int)ldcopy) logits_copy[(long)row * ldcopy + a] = 0;
+    }
+  }
+  const float s = block_sum(acc, sh);
+  if (threadIdx.x == 0) atomicAdd(loss_out, s * inv_rows);
+}
+
+extern "C" int vlb_bce_logits_fwd_bwd(void* logits, long ld, int rows, int A, const float* label, long ldl, float gscale, float* loss_out,
+                                      void* logits_copy, long ldcopy, hipStream_t stream) {
+  if (rows <= 0) return VLB_OK;
+  VLB_CHECK_ARG(logits && label && loss_out && A > 0 && ld >= A && ldl >= A, "vlb_bce_logits_fwd_bwd: bad argument");
+  VLB_CHECK_ARG(!logits_copy || ldcopy >= A, "vlb_bce_logits_fwd_bwd: ldcopy too small");
+  hipLaunchKernelGGL(bce_logits_fwd_bwd_kernel, dim3(rows), dim3(256), 0, stream, (bf16_t*)logits, ld, A, label, ldl, rows, gscale,
+                     loss_out, (bf16_t*)logits_copy, ldcopy);
+  VLB_CHECK_LAUNCH("vlb_bce_logits_fwd_bwd");
+  return VLB_OK;
+}
+
+// y = x * keep(idx) / (1 - p) with the counter RNG (element index = position in the [n] array); the same call on dy is the backward.
+__global__ __launch_bounds__(256) void dropout_bf16_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, long n, uint32_t drop_thr,
+                                                           float drop_scale, const uint32_t* __restrict__ seedp, uint32_t tag) {
+  const uint32_t seed = (drop_thr && seedp) ? *seedp : 0u;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float v = bf2f(x[i]);
+    y[i] = f2bf((!drop_thr || vlb_keep(seed, tag, (uint32_t)i, drop_thr)) ? v * (drop_thr ? drop_scale : 1.0f) : 0.f);
+  }
+}
+
+extern "C" int vlb_dropout_bf16(const void* x, void* y, long n, float drop_p, const uint32_t* seed, uint32_t tag, hipStream_t stream) {
+  if (n <= 0) return VLB_OK;
+  VLB_CHECK_ARG(x && y && n < (1L << 32), "vlb_dropout_bf16: bad argument");
+  VLB_CHECK_ARG(!(drop_p > 0.f) || seed, "vlb_dropout_bf16: dropout needs a device seed pointer");
+  const uint32_t thr = vlb_drop_thr(drop_p);
+  long blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(dropout_bf16_kernel, dim3((int)blocks), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, n, thr, vlb_drop_scale(thr),
+                     seed, tag);
+  VLB_CHECK_LAUNCH("vlb_dropout_bf16");
+  return VLB_OK;
+}
