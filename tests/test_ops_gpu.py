@@ -568,6 +568,34 @@ def test_adamw_and_sumsq(ops):
     assert float(state[5]) == 3.0 and float(state[7]) == 0.0
 
 
+def test_bce_logits_and_dropout(ops):
+    """vlb_bce_logits_fwd_bwd (VQA answer loss x answers, gradient in place, padded columns zeroed) and vlb_dropout_bf16."""
+    B, A, Ap = 5, 37, 64
+    g = torch.Generator().manual_seed(60)
+    x = bf(torch.randn(B, A, generator=g) * 3)
+    y = (torch.rand(B, A, generator=g) < 0.2).float() * torch.rand(B, A, generator=g)
+    logits = torch.full((B, Ap), 9.0, dtype=torch.bfloat16, device=dev())
+    logits[:, :A] = x.to(dev())
+    copy = torch.zeros_like(logits)
+    loss = torch.tensor([0.25], device=dev())
+    ops.bce_logits_fwd_bwd(logits, A, y.to(dev()), loss, gscale=2.0, logits_copy=copy)
+    xr = x.clone().requires_grad_(True)
+    ref = F.binary_cross_entropy_with_logits(xr, y) * A
+    ref.backward()
+    assert abs(float(loss) - 0.25 - float(ref)) < 1e-4 * float(ref)
+    report("bce dlogits (x gscale)", logits[:, :A], 2.0 * xr.grad, 1e-4, 1e-2)
+    assert float(logits[:, A:].float().abs().max()) == 0.0 and torch.equal(copy[:, :A].float().cpu(), x)
+    n = 10007
+    v = rnd(n, seed=61)
+    out = torch.zeros(n, dtype=torch.bfloat16, device=dev())
+    seed = torch.tensor([777], dtype=torch.int32, device=dev())
+    ops.dropout_bf16(to_gpu_bf16(v), out, 0.3, seed, 5)
+    keep = torch.from_numpy(keep_mask(777, 5, np.arange(n), drop_thr(0.3)))
+    report("dropout_bf16", out, v * keep * drop_scale(drop_thr(0.3)), 0, 8e-3)
+    ops.dropout_bf16(to_gpu_bf16(v), out, 0.0, None, 5)
+    report("dropout_bf16 p=0", out, v, 0, 0)
+
+
 def test_sumsq_deterministic(ops):
     """vlb_sumsq_f32_det: right value, accumulates into *out, and the same bits on every call (the atomic version is not)."""
     n = 3_000_017
