@@ -491,3 +491,41 @@ def test_fast_rcnn_mirror_image_branch_vs_oracle():
     back = net.state_dict()
     for k, v in VO.split_state_dict(P).items():
         assert torch.equal(back[k].cpu(), v), k
+
+
+@pytest.mark.parametrize("Hi,Wi", [(75, 101), (130, 66)])
+def test_vision_stack_odd_image_sizes_vs_oracle(Hi, Wi):
+    """Image sizes that are not multiples of the strides (odd stem / pool / stride-2 output sizes, body4 of 5x7 / 9x5): forward and one
+    weight gradient per stage against oracle/vision_oracle.py (itself pinned to the reference module)."""
+    V = pkg("vision")
+    nl = 50
+    P = VO.init_vision_params(3, nl)
+    g = torch.Generator().manual_seed(4)
+    N, R = 2, 2
+    img = torch.randn(N, 3, Hi, Wi, generator=g) * 50
+    boxes4 = torch.tensor([[[3.0, 4.0, Wi - 5.0, Hi - 6.0], [Wi * 0.3, Hi * 0.2, Wi * 0.9, Hi * 0.7]],
+                           [[0.0, 0.0, Wi - 1.0, Hi - 1.0], [-2.0, -2.0, -2.0, -2.0]]])
+    vs = V.VisionStack(N, Hi, Wi, R, device=dev(), num_layers=nl)
+    vs.load_state_dict({k: v.to(dev()) for k, v in _prefixed(P).items()})
+    boxes = torch.zeros((N, R, 4 + 2048), device=dev())
+    boxes[:, :, :4] = boxes4.to(dev())
+    vs.forward(img.to(dev()), boxes)
+    frozen = VO.frozen_names(P)
+    Po = {k: v.clone().requires_grad_(k not in frozen) for k, v in P.items()}
+    feats, body4 = VO.e2e_features(img, boxes4, Po, nl)
+    mask = boxes4[:, :, 0] > -1.5
+    assert (vs.H3, vs.W3) == tuple(body4.shape[2:])
+    report("odd %dx%d body4" % (Hi, Wi), vs.body4.float().cpu().view(N, vs.H3, vs.W3, -1).permute(0, 3, 1, 2), body4.detach(), 2e-2, 2e-2)
+    report("odd %dx%d post_roialign" % (Hi, Wi), boxes[:, :, 4:].cpu()[mask], feats.detach(), 2e-2, 2e-2)
+    W = torch.randn(N, R, 2048, generator=g) / 64.0
+    vs.zero_grad()
+    vs.backward(to_gpu_bf16(W.view(N * R, -1)), boxes)
+    torch.cuda.synchronize()
+    (feats * W[mask]).sum().backward()
+    got = vs.grads()
+    for short, ref_name in (("roi_head_feature_extractor.0.conv2.weight", "layer4.0.conv2.weight"),
+                            ("backbone.layer3.0.downsample.0.weight", "layer3.0.downsample.0.weight"),
+                            ("backbone.layer2.0.conv1.weight", "layer2.0.conv1.weight")):
+        e = rel_fro(got["image_feature_extractor." + short], Po[ref_name].grad)
+        print("   odd %dx%d d %s rel-fro %.3e" % (Hi, Wi, short, e))
+        assert e < 0.15, short
