@@ -271,11 +271,13 @@ int vlb_roi_align_nhwc_bwd(const void* dout, const float* boxes, long ldbox, int
 int vlb_relu_mask_cast(const float* g, const void* y, void* dz, long n, vlb_stream_t stream);
 /* AvgPool2d(14)+Flattener (common/fast_rcnn.py:80-84): y [K,P,C] bf16 -> out[k*ld + col0 + c] fp32 (the feature slots of
  * the padded box rows; rows whose column pad_col (>= 0) holds x1 <= -1.5 are padding and get zeros); backward: dz[k,p,c] = (y>0) * keep(k*drop_row_elems + drop_col0 + c) * dfeat[k*lddf + c] / P, with
- * the input-dropout mask of obj_downsample (common/fast_rcnn.py:106) regenerated from (seed, tag); padded boxes get 0. */
-int vlb_avgpool_rows_fwd(const void* y, float* out, long ld, int col0, int pad_col, int K, int P, int C, vlb_stream_t stream);
+ * the input-dropout mask of obj_downsample (common/fast_rcnn.py:106) regenerated from (seed, tag); padded boxes get 0.
+ * segm (optional, fp32 [K, P]): VCR's per-pixel object mask, multiplied into the RoI-head output before pooling (:152-156). */
+int vlb_avgpool_rows_fwd(const void* y, float* out, long ld, int col0, int pad_col, int K, int P, int C, const float* segm,
+                         vlb_stream_t stream);
 int vlb_avgpool_rows_bwd(const void* dfeat, long lddf, const void* y, const float* boxes, long ldbox, void* dz, int K, int P,
                          int C, float drop_p, const uint32_t* seed, uint32_t tag, uint32_t drop_row_elems, uint32_t drop_col0,
-                         vlb_stream_t stream);
+                         const float* segm, vlb_stream_t stream);
 
 /* ---- ROIAlign (common/lib/roi_pooling: vision.cpp:6-11, ROIAlign.h:11-45) --------------------
  * NCHW fp32, rois [K,5] = (batch_idx, x1, y1, x2, y2); same math as

@@ -263,11 +263,22 @@ def run_vision_case(name="vision_small", num_layers=50):
     err = float((feats - raw[box_mask]).abs().max())
     print("%s: restatement vs reference |d feats|max = %.3e (|feats| max %.3f)" % (name, err, float(raw.abs().max())))
     assert err < 1e-4
+    # the VCR call form: per-pixel object masks multiplied into the RoI-head output before the pool (common/fast_rcnn.py:152-156)
+    segms = (torch.rand(B, R, 14, 14, generator=g) < 0.6).float()
+    with torch.no_grad():
+        out_s = model(images=img, boxes=boxes.clone(), box_mask=box_mask, im_info=im_info, classes=None, segms=segms, mvrc_ops=None,
+                      mask_visual_embed=None)
+        feats_s, _ = VO.e2e_features(img, boxes, Po, num_layers, segms=segms)
+    raw_s = out_s["obj_reps_raw"]
+    err_s = float((feats_s - raw_s[box_mask]).abs().max())
+    print("%s: segms variant restatement vs reference |d feats|max = %.3e" % (name, err_s))
+    assert err_s < 1e-4
     path = os.path.join(ROOT, "tests", "golden", "vision", name + ".npz")
     os.makedirs(os.path.dirname(path), exist_ok=True)
     keys = sorted(gnorm)
     np.savez_compressed(path, seed=seed, num_layers=num_layers, img=img.numpy(), boxes=boxes.numpy(), im_info=im_info.numpy(),
-                        Wr=Wr.numpy(), obj_reps_raw=raw.detach().numpy(), body4_mean=float(body4.mean()),
+                        Wr=Wr.numpy(), obj_reps_raw=raw.detach().numpy(), segms=segms.numpy(), obj_reps_raw_segms=raw_s.numpy(),
+                        body4_mean=float(body4.mean()),
                         body4_abs_mean=float(body4.abs().mean()), body4_sample=body4.detach().reshape(-1)[::97][:512].numpy(),
                         grad_names=np.array(keys), grad_norms=np.array([gnorm[k] for k in keys]),
                         grad_samples=np.stack([gsample[k] if gsample[k].size == 64 else np.resize(gsample[k], 64) for k in keys]))

@@ -131,12 +131,15 @@ def backbone(img, P, num_layers=101):
     return x
 
 
-def roi_head(roi_feats, P, num_layers=101):
-    """common/fast_rcnn.py:80-84: layer4 (dilated, stride 1) -> AvgPool2d(14) -> flatten."""
+def roi_head(roi_feats, P, num_layers=101, segms=None):
+    """common/fast_rcnn.py:80-84: layer4 (dilated, stride 1) -> AvgPool2d(14) -> flatten; with `segms` [K,14,14] the layer4 output is
+    multiplied by the object mask first (:152-156, the VCR call)."""
     x = roi_feats
     for prefix, inpl, planes, stride, dil, ds, s1 in block_specs(num_layers):
         if prefix.startswith("layer4"):
             x = bottleneck(x, P, prefix, stride, dil, ds, s1)
+    if segms is not None:
+        x = x * segms[:, None].to(x.dtype)
     return F.avg_pool2d(x, x.shape[-1], stride=1).flatten(1)
 
 
@@ -171,12 +174,13 @@ def rois_from_boxes(boxes):
     return torch.cat((inds[:, 0, None].to(boxes.dtype), boxes[inds[:, 0], inds[:, 1]][:, :4]), 1), inds
 
 
-def e2e_features(img, boxes, P, num_layers=101):
-    """-> (post_roialign [K, 2048] for the valid boxes in batch-major order, body4)."""
+def e2e_features(img, boxes, P, num_layers=101, segms=None):
+    """-> (post_roialign [K, 2048] for the valid boxes in batch-major order, body4).  segms: [B, R, 14, 14] or None."""
     body4 = backbone(img, P, num_layers)
-    rois, _ = rois_from_boxes(boxes)
+    rois, inds = rois_from_boxes(boxes)
     pooled = roi_align(body4, rois)
-    return roi_head(pooled, P, num_layers), body4
+    sel = segms[inds[:, 0], inds[:, 1]] if segms is not None else None
+    return roi_head(pooled, P, num_layers, sel), body4
 
 
 def split_state_dict(P):

@@ -159,6 +159,10 @@ def test_vision_oracle_matches_reference_fast_rcnn_e2e():
         assert np.allclose(np.resize(s, 64), want_s, rtol=1e-3, atol=1e-6 * want_norm), k
     for k in frozen:
         assert Po[k].grad is None
+    # VCR call form: object masks multiplied into the RoI-head output before the pool (common/fast_rcnn.py:152-156)
+    with torch.no_grad():
+        feats_s, _ = VO.e2e_features(img, boxes, Po, nl, segms=torch.from_numpy(z["segms"]))
+    assert float((feats_s - torch.from_numpy(z["obj_reps_raw_segms"])[mask]).abs().max()) < 1e-4
 
 
 def load_vqa_case():

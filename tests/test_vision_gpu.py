@@ -327,6 +327,23 @@ def test_vision_stack_matches_reference_golden():
         print("   %-22s max rel-fro %.3e" % (k, max(by_layer[k])))
     assert set(n[len("image_feature_extractor."):] for n in got) == set(want_norm)
     assert np.median(errs) < 6e-2 and worst[0] < 0.15, worst
+    # VCR call form: object masks inside the RoI head -- forward against the reference fixture, masked-pool backward against the oracle
+    segms = torch.from_numpy(z["segms"])
+    vs.forward(img.to(dev()), boxes, segms.to(dev()))
+    report("e2e post_roialign with segms vs reference", boxes[:, :, 4:], torch.from_numpy(z["obj_reps_raw_segms"]), 2e-2, 2e-2)
+    vs.zero_grad()
+    vs.backward(to_gpu_bf16(Wr.view(N * R, -1)), boxes)
+    torch.cuda.synchronize()
+    Ps = {k: v.clone().requires_grad_(k not in frozen) for k, v in P.items()}
+    feats_s, _ = VO.e2e_features(img, boxes4, Ps, nl, segms=segms)
+    (feats_s * Wr[mask]).sum().backward()
+    gs = vs.grads()
+    for short, ref_name in (("roi_head_feature_extractor.2.conv3.weight", "layer4.2.conv3.weight"),
+                            ("roi_head_feature_extractor.0.conv1.weight", "layer4.0.conv1.weight"),
+                            ("backbone.layer3.5.conv2.weight", "layer3.5.conv2.weight")):
+        e = rel_fro(gs["image_feature_extractor." + short], Ps[ref_name].grad)
+        print("   with segms: d %s rel-fro %.3e" % (short, e))
+        assert e < (3e-2 if "roi_head" in short else 8e-2), short
 
 
 def test_engine_e2e_step_vs_oracle():
@@ -491,6 +508,22 @@ def test_fast_rcnn_mirror_image_branch_vs_oracle():
     back = net.state_dict()
     for k, v in VO.split_state_dict(P).items():
         assert torch.equal(back[k].cpu(), v), k
+    # VCR call form: `segms` object masks inside the RoI head (common/fast_rcnn.py:152-156), against the reference fixture + oracle grads
+    segms = torch.from_numpy(z["segms"])
+    for q in net.parameters():
+        q.grad = None
+    out_s = net(img.to(dev()), boxes4.to(dev()), mask.to(dev()), im_info.to(dev()), segms=segms.to(dev()))
+    report("FastRCNN e2e obj_reps_raw with segms vs reference fixture", out_s["obj_reps_raw"], torch.from_numpy(z["obj_reps_raw_segms"]), 2e-2, 2e-2)
+    Po2 = {k: v.clone().requires_grad_(k not in frozen) for k, v in P.items()}
+    leaves2 = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    feats_s, _ = VO.e2e_features(img, boxes4, Po2, nl, segms=segms)
+    full_s = torch.cat((boxes4, feats_s.new_zeros(B, R, 2048).masked_scatter(mask[:, :, None], feats_s)), -1)
+    want_s = O.fast_rcnn_precomputed(leaves2, cfg, full_s, mask, im_info, train=False)
+    (out_s["obj_reps"] * W.to(dev())).sum().backward()
+    (want_s * W).sum().backward()
+    e4 = rel_fro(dict(net.named_parameters())["roi_head_feature_extractor.2.conv3.weight"].grad.permute(0, 3, 1, 2), Po2["layer4.2.conv3.weight"].grad)
+    print("FastRCNN e2e with segms: d head conv3 rel-fro %.3e" % e4)
+    assert e4 < 0.12      # (through obj_downsample's bf16 ReLU flips; the sharp check of the masked pool backward is in the stack test)
 
 
 @pytest.mark.parametrize("Hi,Wi", [(75, 101), (130, 66)])

@@ -59,8 +59,8 @@ _SIGS = {
     "vlb_roi_align_nhwc_fwd": "pplipiiiiiifis",
     "vlb_roi_align_nhwc_bwd": "pplipiiiiiiifis",
     "vlb_relu_mask_cast": "pppls",
-    "vlb_avgpool_rows_fwd": "ppliiiiis",
-    "vlb_avgpool_rows_bwd": "plpplpiiifpuuus",
+    "vlb_avgpool_rows_fwd": "ppliiiiips",
+    "vlb_avgpool_rows_bwd": "plpplpiiifpuuups",
     "vlb_cast_f32_bf16": "ppls",
     "vlb_cast_bf16_f32": "ppls",
     "vlb_rng_advance": "ps",

@@ -14,8 +14,9 @@ IMAGE_FEAT_PRECOMPUTED false (the image branch, :144-156): `forward(images [B,3,
 `vision.VisionStack` (ResNet trunk -> ROIAlign -> dilated layer4 head -> avg-pool) in front of the same node; its backward
 continues through the RoI head, ROIAlign and the trainable trunk stages.  Parameters / buffers carry the reference's names
 (`backbone.*`, `roi_head_feature_extractor.*`); trainable convolution weights are stored as [O,KH,KW,I] (state_dict /
-load_state_dict convert from / to the reference's [O,I,KH,KW]).  Not supported on this branch: `segms` (VCR's mask
-multiplication inside the head), `classes` / IMAGE_SEMANTIC, `mask_visual_embed`, cnn_reg_loss, OUTPUT_CONV5.
+load_state_dict convert from / to the reference's [O,I,KH,KW]).  `segms` [B,R,14,14] (VCR's object masks) are multiplied into the
+RoI-head output before the pool (:152-156).  Not supported on this branch: `classes` / IMAGE_SEMANTIC, `mask_visual_embed`,
+cnn_reg_loss, OUTPUT_CONV5.
 """
 import torch
 import torch.nn as nn
@@ -75,13 +76,13 @@ class _FnE2E(torch.autograd.Function):
     autograd delivers their gradients (accumulated by VisionStack.backward into the module's flat-layout buffers)."""
 
     @staticmethod
-    def forward(ctx, weight, bias, module, vs, images, boxes_full, im_info, idx, train, *conv_weights):
+    def forward(ctx, weight, bias, module, vs, images, boxes_full, im_info, idx, train, segms, *conv_weights):
         B, R = boxes_full.shape[0], boxes_full.shape[1]
         H = weight.shape[0]
         st = module._state(B, R, boxes_full.device)
         module._sync_weights()
         module._sync_vision(vs)
-        vs.forward(images, boxes_full)                           # fills boxes_full[:, :, 4:] with post_roialign
+        vs.forward(images, boxes_full, segms)                    # fills boxes_full[:, :, 4:] with post_roialign
         p = module.drop_p if train else 0.0
         ops.obj_prep_fwd(boxes_full, im_info, None, module._zero_embed, st["a"], drop_p=p, seed=module._seed, tag=_TAG)
         ops.gemm_nt(st["a"], module._w16, st["y"], bias=bias.detach(), act=ops.ACT_RELU)
@@ -105,7 +106,7 @@ class _FnE2E(torch.autograd.Function):
         vs.backward(st["dfeat"], ctx.boxes, drop_p=ctx.p, seed=module._seed, tag=_TAG)
         if ctx.p > 0:
             ops.rng_advance(module._seed)
-        return (gw, gb, None, None, None, None, None, None, None) + tuple(t.clone() for t in module._conv_grads.values())
+        return (gw, gb, None, None, None, None, None, None, None, None) + tuple(t.clone() for t in module._conv_grads.values())
 
 
 class FastRCNN(nn.Module):
@@ -235,8 +236,8 @@ class FastRCNN(nn.Module):
         return self._states[key]
 
     def _forward_e2e(self, images, boxes, box_mask, im_info, classes, segms, mvrc_ops, mask_visual_embed):
-        if classes is not None or segms is not None or mask_visual_embed is not None:
-            raise NotImplementedError("image branch: classes / segms / mask_visual_embed are not supported")
+        if classes is not None or mask_visual_embed is not None:
+            raise NotImplementedError("image branch: classes / mask_visual_embed are not supported")
         B, R = boxes.shape[0], boxes.shape[1]
         dev = boxes.device
         full = torch.zeros((B, R, 4 + VIS_DIM), dtype=torch.float32, device=dev)
@@ -247,7 +248,7 @@ class FastRCNN(nn.Module):
         idx = torch.where(box_mask.reshape(-1).bool(), ar, torch.full_like(ar, -1))
         lin = getattr(self.obj_downsample, "1")
         obj_reps = _FnE2E.apply(lin.weight, lin.bias, self, vs, images.float().contiguous(), full, im_info.float().contiguous(), idx,
-                                self.training, *self._conv_params.values())
+                                self.training, segms, *self._conv_params.values())
         return {"obj_reps_raw": full[:, :, 4:].detach().clone(), "obj_reps": obj_reps}
 
     def forward(self, images, boxes, box_mask, im_info, classes=None, segms=None, mvrc_ops=None, mask_visual_embed=None):

@@ -556,8 +556,10 @@ extern "C" int vlb_relu_mask_cast(const float* g, const void* y, void* dz, long 
 // slots of the padded box rows (row k, columns col0 .. col0+C of a [K, ld] fp32 matrix: boxes[..., 4:]) -- the input the
 // precomputed-feature path reads, so everything downstream (obj_prep, obj_downsample) is shared.
 // ------------------------------------------------------------------------------------------------------------------
+// segm (optional, fp32 [K, P]): the per-pixel object mask VCR multiplies the RoI-head output with before pooling
+// (common/fast_rcnn.py:152-156): out = mean_p( y[k,p,:] * segm[k,p] ).
 __global__ __launch_bounds__(256) void avgpool_rows_fwd_kernel(const bf16_t* __restrict__ y, float* __restrict__ out, long ld, int col0, int P,
-                                                               int C, int pad_col) {
+                                                               int C, int pad_col, const float* __restrict__ segm) {
   const int k = blockIdx.x;
   const int c8n = C >> 3;
   // padded box (x1 <= -1.5 in column pad_col of the same row): zero features, like the reference's zero-padded obj_reps_raw
@@ -568,8 +570,9 @@ __global__ __launch_bounds__(256) void avgpool_rows_fwd_kernel(const bf16_t* __r
     for (int p = 0; p < P; ++p) {
       float f[8];
       unpack8(*(const uint4*)(src + (long)p * C), f);
+      const float m = segm ? segm[(long)k * P + p] : 1.0f;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) s[e] += f[e];
+      for (int e = 0; e < 8; ++e) s[e] += f[e] * m;
     }
     float* o = out + (long)k * ld + col0 + c8 * 8;
     *(float4*)o = make_float4(s[0] * inv, s[1] * inv, s[2] * inv, s[3] * inv);
@@ -577,12 +580,13 @@ __global__ __launch_bounds__(256) void avgpool_rows_fwd_kernel(const bf16_t* __r
   }
 }
 
-extern "C" int vlb_avgpool_rows_fwd(const void* y, float* out, long ld, int col0, int pad_col, int K, int P, int C, hipStream_t stream) {
+extern "C" int vlb_avgpool_rows_fwd(const void* y, float* out, long ld, int col0, int pad_col, int K, int P, int C, const float* segm,
+                                    hipStream_t stream) {
   if (K <= 0) return VLB_OK;
   VLB_CHECK_ARG(y && out && P > 0 && C > 0 && (C % 8) == 0, "vlb_avgpool_rows_fwd: bad argument");
   VLB_CHECK_ARG((ld % 4) == 0 && (col0 % 4) == 0 && ld >= col0 + C, "vlb_avgpool_rows_fwd: ld=%ld col0=%d must be multiples of 4", ld, col0);
   VLB_CHECK_ARG(pad_col < col0, "vlb_avgpool_rows_fwd: pad_col=%d must lie in front of the feature columns", pad_col);
-  hipLaunchKernelGGL(avgpool_rows_fwd_kernel, dim3(K), dim3(256), 0, stream, (const bf16_t*)y, out, ld, col0, P, C, pad_col);
+  hipLaunchKernelGGL(avgpool_rows_fwd_kernel, dim3(K), dim3(256), 0, stream, (const bf16_t*)y, out, ld, col0, P, C, pad_col, segm);
   VLB_CHECK_LAUNCH("vlb_avgpool_rows_fwd");
   return VLB_OK;
 }
@@ -594,7 +598,7 @@ __global__ __launch_bounds__(256) void avgpool_rows_bwd_kernel(const bf16_t* __r
                                                                const float* __restrict__ boxes, long ldbox, bf16_t* __restrict__ dz, int K,
                                                                int P, int C, uint32_t drop_thr, float drop_scale,
                                                                const uint32_t* __restrict__ seedp, uint32_t tag, uint32_t drop_row_elems,
-                                                               uint32_t drop_col0) {
+                                                               uint32_t drop_col0, const float* __restrict__ segm) {
   const int c8n = C >> 3;
   const long total = (long)K * P * c8n;
   const uint32_t seed = (drop_thr && seedp) ? *seedp : 0u;
@@ -610,7 +614,7 @@ __global__ __launch_bounds__(256) void avgpool_rows_bwd_kernel(const bf16_t* __r
       unpack8(*(const uint4*)(y + row * C + c8 * 8), f);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        float g = d[e] * inv;
+        float g = d[e] * inv * (segm ? segm[row] : 1.0f);
         if (drop_thr) g = vlb_keep(seed, tag, (uint32_t)k * drop_row_elems + drop_col0 + (uint32_t)(c8 * 8 + e), drop_thr) ? g * drop_scale : 0.f;
         v[e] = f[e] > 0.f ? g : 0.f;
       }
@@ -621,7 +625,7 @@ __global__ __launch_bounds__(256) void avgpool_rows_bwd_kernel(const bf16_t* __r
 
 extern "C" int vlb_avgpool_rows_bwd(const void* dfeat, long lddf, const void* y, const float* boxes, long ldbox, void* dz, int K, int P,
                                     int C, float drop_p, const uint32_t* seed, uint32_t tag, uint32_t drop_row_elems, uint32_t drop_col0,
-                                    hipStream_t stream) {
+                                    const float* segm, hipStream_t stream) {
   if (K <= 0) return VLB_OK;
   VLB_CHECK_ARG(dfeat && y && dz && P > 0 && C > 0 && (C % 8) == 0 && (lddf % 8) == 0, "vlb_avgpool_rows_bwd: bad argument");
   VLB_CHECK_ARG(!(drop_p > 0.f) || seed, "vlb_avgpool_rows_bwd: dropout needs a device seed pointer");
@@ -629,7 +633,7 @@ extern "C" int vlb_avgpool_rows_bwd(const void* dfeat, long lddf, const void* y,
   long blocks = ((long)K * P * (C / 8) + 255) / 256;
   if (blocks > 65536) blocks = 65536;
   hipLaunchKernelGGL(avgpool_rows_bwd_kernel, dim3((int)blocks), dim3(256), 0, stream, (const bf16_t*)dfeat, lddf, (const bf16_t*)y, boxes,
-                     ldbox, (bf16_t*)dz, K, P, C, thr, vlb_drop_scale(thr), seed, tag, drop_row_elems, drop_col0);
+                     ldbox, (bf16_t*)dz, K, P, C, thr, vlb_drop_scale(thr), seed, tag, drop_row_elems, drop_col0, segm);
   VLB_CHECK_LAUNCH("vlb_avgpool_rows_bwd");
   return VLB_OK;
 }

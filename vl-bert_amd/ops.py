@@ -464,12 +464,12 @@ def relu_mask_cast(g, y, dz):
     return dz
 
 
-def avgpool_rows_fwd(y, out, col0, K, P, C, pad_col=-1):
-    """y bf16 [K*P, C] -> out fp32 [K, ld][:, col0:col0+C] = mean over the P pixels (0 where out[:, pad_col] <= -1.5: padded box)"""
-    _lib.call("vlb_avgpool_rows_fwd", _p(y, BF16), _p(out, torch.float32), _ld(out), col0, pad_col, K, P, C, _stream())
+def avgpool_rows_fwd(y, out, col0, K, P, C, pad_col=-1, segm=None):
+    """y bf16 [K*P, C] -> out fp32 [K, ld][:, col0:col0+C] = mean over the P pixels of y (* segm [K,P]) (0 where out[:, pad_col] <= -1.5)"""
+    _lib.call("vlb_avgpool_rows_fwd", _p(y, BF16), _p(out, torch.float32), _ld(out), col0, pad_col, K, P, C, _p(segm, torch.float32), _stream())
 
 
-def avgpool_rows_bwd(dfeat, y, boxes, dz, K, P, C, drop_p=0.0, seed=None, tag=0, drop_row_elems=0, drop_col0=0):
+def avgpool_rows_bwd(dfeat, y, boxes, dz, K, P, C, drop_p=0.0, seed=None, tag=0, drop_row_elems=0, drop_col0=0, segm=None):
     _lib.call("vlb_avgpool_rows_bwd", _p(dfeat, BF16), _ld(dfeat), _p(y, BF16), _p(boxes, torch.float32), _ld(boxes) if boxes is not None else 0,
-              _p(dz, BF16), K, P, C, float(drop_p), _p(seed), int(tag), int(drop_row_elems), int(drop_col0), _stream())
+              _p(dz, BF16), K, P, C, float(drop_p), _p(seed), int(tag), int(drop_row_elems), int(drop_col0), _p(segm, torch.float32), _stream())
     return dz

@@ -291,8 +291,10 @@ class VisionStack:
         b["x"] = x
         return b["y"]
 
-    def forward(self, images, boxes):
-        """images fp32 [N,3,Himg,Wimg]; boxes fp32 [N,R,4+2048] (padded rows x1 = -2): fills boxes[:, :, 4:] with post_roialign."""
+    def forward(self, images, boxes, segms=None):
+        """images fp32 [N,3,Himg,Wimg]; boxes fp32 [N,R,4+2048] (padded rows x1 = -2): fills boxes[:, :, 4:] with post_roialign.
+        segms (optional, fp32 [N,R,pooled,pooled]): VCR's object masks, multiplied into the RoI-head output before the average pool
+        (common/fast_rcnn.py:152-156); remembered for backward."""
         if self._dirty:
             self.refresh_weights()
         N, K = self.N, self.K
@@ -308,7 +310,11 @@ class VisionStack:
                 self.body4 = x
                 x = ops.roi_align_nhwc_fwd(x, box_rows, self.R, self.roi, N, self.H3, self.W3, self.C3, self.pooled, self.scale, self.sr)
             x = self._block_fwd(b, x)
-        ops.avgpool_rows_fwd(x, box_rows, 4, K, self.P_roi, self.Cout, pad_col=0)
+        self._segm = None
+        if segms is not None:
+            assert tuple(segms.shape) == (N, self.R, self.pooled, self.pooled) and self.P_roi == self.pooled * self.pooled
+            self._segm = segms.to(F32).contiguous().view(K, self.P_roi)
+        ops.avgpool_rows_fwd(x, box_rows, 4, K, self.P_roi, self.Cout, pad_col=0, segm=self._segm)
         return x
 
     # ------------------------------------------------------------------------------------------------------------------
@@ -415,7 +421,7 @@ class VisionStack:
         g4 = self.groups[4]
         self._before_write(g4["dzA"])
         cur = ops.avgpool_rows_bwd(d_feat, last["y"], box_rows, g4["dzA"], K, self.P_roi, self.Cout, drop_p=drop_p, seed=seed, tag=tag,
-                                   drop_row_elems=drop_row_elems, drop_col0=drop_col0)
+                                   drop_row_elems=drop_row_elems, drop_col0=drop_col0, segm=getattr(self, "_segm", None))
         for b in reversed(blocks):
             L, g = b["layer"], self.groups[b["layer"]]
             if b["index"] > 0:
