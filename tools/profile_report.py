@@ -89,38 +89,56 @@ def pmc(name):
     return fam
 
 
-sq = pmc("final_sq")
-with open(os.path.join(dst, tag + "_gemm_pmc.txt"), "w") as f:
-    f.write("# rocprofv3 --kernel-trace --pmc SQ_* (one separate pass) over the same bench command; per kernel family, AVERAGE PER LAUNCH.\n"
-            "# SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_ANY count quad-cycles summed over waves; SQ_VALU_MFMA_BUSY_CYCLES and\n"
-            "# SQ_LDS_* count cycles summed over SIMDs / CUs (MI355X_MICROARCH.md, PMC slots).\n")
-    names = sorted({k for a in sq.values() for k in a["c"]})
-    f.write("%-34s %6s %9s " % ("kernel family", "calls", "avg_us") + " ".join("%24s" % n for n in names) + "\n")
-    for k, a in sorted(sq.items(), key=lambda kv: -kv[1]["dur"])[:8]:
-        f.write("%-34s %6d %9.1f " % (k[:34], a["n"], a["dur"] / a["n"] / 1e3) + " ".join("%24.4g" % (a["c"].get(n, 0) / a["n"]) for n in names) + "\n")
-    for k in ("gemm_nt_bf16_kernel", "gemm_tn_bf16_kernel"):
-        if k in sq:
-            c = sq[k]["c"]
-            f.write("# %s: MFMA pipe busy %.0f %% of SIMD-cycles at the nominal 2.4 GHz (DVFS runs lower, so this is a lower bound) ; of the wave-cycles "
-                    "%.0f %% parked on s_waitcnt/barrier (WAIT_ANY), %.0f %% issue-stalled (WAIT_INST_ANY), %.0f %% issuing ; "
-                    "LDS bank-conflict cycles / LDS active = %.2f %%\n" % (
-                        k, 100 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / sq[k]["n"] / (1024 * sq[k]["dur"] / sq[k]["n"] * 2.4),
-                        100 * c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 100 * c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"],
-                        100 * c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"], 100 * c["SQ_LDS_BANK_CONFLICT"] / max(c["SQ_LDS_IDX_ACTIVE"], 1)))
+def family_e2e(n):
+    conv = ", true>" in n
+    if "gemm_nt_bf16" in n or "gemm_nt_256" in n:
+        return "gemm_nt_bf16_kernel<..,CONV>" if conv else "gemm_nt_bf16_kernel"
+    if "gemm_tn_bf16" in n:
+        return "gemm_tn_bf16_kernel<..,CONV>" if conv else "gemm_tn_bf16_kernel"
+    return short(n)
 
-fe, wr = pmc("final_fetch"), pmc("final_write")
-traffic = {}
-with open(os.path.join(dst, tag + "_hbm_traffic.txt"), "w") as f:
-    f.write("# rocprofv3 --kernel-trace --pmc FETCH_SIZE and (separate pass) --pmc WRITE_SIZE over the same bench command.\n"
-            "# Counters are in KB per dispatch; 'read' = 2 x FETCH_SIZE for the kernels that stream 16 B/lane (gfx950 correction,\n"
-            "# MI355X_MICROARCH.md HBM section), WRITE_SIZE as reported.  MB per launch (average) and MB per step.\n")
-    f.write("%-40s %6s %12s %12s %12s %14s\n" % ("kernel family", "calls", "read MB", "write MB", "total MB", "MB per step"))
-    for k, a in sorted(fe.items(), key=lambda kv: -kv[1]["dur"])[:14]:
-        rd = 2.0 * a["c"].get("FETCH_SIZE", 0.0) / a["n"] / 1e3
-        w = wr.get(k, {"c": {}, "n": 1})
-        wm = w["c"].get("WRITE_SIZE", 0.0) / max(w["n"], 1) / 1e3
-        f.write("%-40s %6d %12.2f %12.2f %12.2f %14.1f\n" % (k[:40], a["n"], rd, wm, rd + wm, (rd + wm) * a["n"] / steps))
-        traffic[k] = {"launches_per_step": a["n"] / steps, "read_MB_per_launch": rd, "write_MB_per_launch": wm}
+
+def write_sq(sq_dir, out_name, what, gemm_keys):
+    sq = pmc(sq_dir)
+    with open(os.path.join(dst, out_name), "w") as f:
+        f.write("# rocprofv3 --kernel-trace --pmc SQ_* (one separate pass) over %s; per kernel family, AVERAGE PER LAUNCH.\n"
+                "# SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_ANY count quad-cycles summed over waves; SQ_VALU_MFMA_BUSY_CYCLES and\n"
+                "# SQ_LDS_* count cycles summed over SIMDs / CUs (MI355X_MICROARCH.md, PMC slots).\n" % what)
+        names = sorted({k for a in sq.values() for k in a["c"]})
+        f.write("%-34s %6s %9s " % ("kernel family", "calls", "avg_us") + " ".join("%24s" % n for n in names) + "\n")
+        for k, a in sorted(sq.items(), key=lambda kv: -kv[1]["dur"])[:10]:
+            f.write("%-34s %6d %9.1f " % (k[:34], a["n"], a["dur"] / a["n"] / 1e3) + " ".join("%24.4g" % (a["c"].get(n, 0) / a["n"]) for n in names) + "\n")
+        for k in gemm_keys:
+            if k in sq:
+                c = sq[k]["c"]
+                f.write("# %s: MFMA pipe busy %.0f %% of SIMD-cycles at the nominal 2.4 GHz (DVFS runs lower, so this is a lower bound) ; of the wave-cycles "
+                        "%.0f %% parked on s_waitcnt/barrier (WAIT_ANY), %.0f %% issue-stalled (WAIT_INST_ANY), %.0f %% issuing ; "
+                        "LDS bank-conflict cycles / LDS active = %.2f %%\n" % (
+                            k, 100 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / sq[k]["n"] / (1024 * sq[k]["dur"] / sq[k]["n"] * 2.4),
+                            100 * c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 100 * c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"],
+                            100 * c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"], 100 * c["SQ_LDS_BANK_CONFLICT"] / max(c["SQ_LDS_IDX_ACTIVE"], 1)))
+
+
+def write_traffic(fetch_dir, write_dir, out_name, what, top=14):
+    fe, wr = pmc(fetch_dir), pmc(write_dir)
+    traffic = {}
+    with open(os.path.join(dst, out_name), "w") as f:
+        f.write("# rocprofv3 --kernel-trace --pmc FETCH_SIZE and (separate pass) --pmc WRITE_SIZE over %s.\n"
+                "# Counters are in KB per dispatch; 'read' = 2 x FETCH_SIZE for the kernels that stream 16 B/lane (gfx950 correction,\n"
+                "# MI355X_MICROARCH.md HBM section), WRITE_SIZE as reported.  MB per launch (average), achieved GB/s = total / avg duration, MB per step.\n" % what)
+        f.write("%-40s %6s %10s %10s %10s %10s %12s\n" % ("kernel family", "calls", "read MB", "write MB", "total MB", "GB/s", "MB per step"))
+        for k, a in sorted(fe.items(), key=lambda kv: -kv[1]["dur"])[:top]:
+            rd = 2.0 * a["c"].get("FETCH_SIZE", 0.0) / a["n"] / 1e3
+            w = wr.get(k, {"c": {}, "n": 1})
+            wm = w["c"].get("WRITE_SIZE", 0.0) / max(w["n"], 1) / 1e3
+            gbs = (rd + wm) / 1e3 / (a["dur"] / a["n"] / 1e9) if a["dur"] > 0 else 0.0
+            f.write("%-40s %6d %10.2f %10.2f %10.2f %10.0f %12.1f\n" % (k[:40], a["n"], rd, wm, rd + wm, gbs, (rd + wm) * a["n"] / steps))
+            traffic[k] = {"launches_per_step": a["n"] / steps, "read_MB_per_launch": rd, "write_MB_per_launch": wm}
+    return traffic
+
+
+write_sq("final_sq", tag + "_gemm_pmc.txt", "the same bench command", ("gemm_nt_bf16_kernel", "gemm_tn_bf16_kernel"))
+traffic = write_traffic("final_fetch", "final_write", tag + "_hbm_traffic.txt", "the same bench command")
 g = [traffic[k] for k in ("gemm_nt_bf16_kernel", "gemm_tn_bf16_kernel") if k in traffic]
 n = sum(t["launches_per_step"] for t in g)
 out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), tools/make_profiles.sh + tools/profile_report.py",
@@ -131,3 +149,8 @@ out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), too
        "families": traffic}
 json.dump(out, open(os.path.join(dst, tag + "_gemm_traffic.json"), "w"), indent=1)
 print("wrote", dst, tag, "GEMM GB/launch", out["gemm_hbm_GB_per_launch"])
+if glob.glob(os.path.join(src, "final_e2e_sq", "*.db")):        # the e2e configuration: convolution / ROIAlign kernels
+    family = family_e2e
+    write_sq("final_e2e_sq", tag + "_e2e_pmc.txt", "python bench.py --e2e (config C3)",
+             ("gemm_nt_bf16_kernel<..,CONV>", "gemm_tn_bf16_kernel<..,CONV>", "gemm_nt_bf16_kernel", "gemm_tn_bf16_kernel"))
+    write_traffic("final_e2e_fetch", "final_e2e_write", tag + "_e2e_hbm_traffic.txt", "python bench.py --e2e (config C3)", top=18)
