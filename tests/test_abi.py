@@ -131,3 +131,27 @@ def test_vision_host_tables_match_the_reference_state_dict_layout():
         blocks = V.block_table(nl)
         assert [b["stride"] for b in blocks if b["index"] == 0] == [1, 2, 2, 1] and blocks[-1]["dil"] == 2
         assert sum(b["downsample"] for b in blocks) == 4
+
+
+def test_vision_stack_geometry_on_host():
+    """VisionStack bookkeeping without a GPU (buffers on the CPU device, no kernel is launched): the e2e configuration's geometry --
+    600x1000 images -> 300x500 stem -> 150x250 -> layer2 75x125 -> layer3 (body4) 38x63, 14x14 RoI maps for every box slot --
+    and the hazard-free buffer plan (ping-pong gradients, parity-double-buffered da / db, no im2col image with the implicit GEMMs)."""
+    V = importlib.import_module("vl-bert_amd.vision")
+    vs = V.VisionStack(2, 600, 1000, 36, device="cpu", num_layers=101)
+    assert (vs.H1, vs.W1, vs.Hp, vs.Wp, vs.H3, vs.W3, vs.C3, vs.P_roi, vs.Cout) == (300, 500, 150, 250, 38, 63, 1024, 196, 2048)
+    by = {b["key"]: b for b in vs.blocks}
+    assert by["backbone.layer2.0."]["M"] == 2 * 75 * 125 and by["backbone.layer2.0."]["stride"] == 2
+    assert by["backbone.layer3.22."]["M"] == 2 * 38 * 63 and by["roi_head_feature_extractor.0."]["M"] == 72 * 196
+    assert by["roi_head_feature_extractor.0."]["dil"] == 2 and by["roi_head_feature_extractor.0."]["downsample"]
+    assert not by["backbone.layer1.0."]["trainable"] and by["backbone.layer2.0."]["trainable"]
+    assert all(b["col"] is None for b in vs.blocks if b["trainable"])                 # implicit GEMM: no im2col image kept
+    g3 = vs.groups[3]
+    assert g3["dzA"].shape == (2 * 38 * 63, 1024) and g3["da"][0].data_ptr() != g3["da"][1].data_ptr() and g3["dxs"].shape == (2 * 38 * 63, 512)
+    assert len(vs.convs) == 104 and sum(c.trainable for c in vs.convs.values()) == 93
+    need = vs._dgrad_set()
+    assert "backbone.layer2.0.conv1" not in need and "backbone.layer2.0.conv2" in need and "roi_head_feature_extractor.0.downsample.0" in need
+    sd = vs.state_dict()
+    assert tuple(sd["image_feature_extractor.backbone.layer2.0.conv2.weight"].shape) == (128, 128, 3, 3)      # reference layout out
+    with pytest.raises(NotImplementedError):
+        V.VisionStack(1, 64, 64, 2, device="cpu", num_layers=50, frozen_stages=(2,))
