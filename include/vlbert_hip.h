@@ -124,6 +124,8 @@ int vlb_seq_layout(const uint8_t* text_mask, const uint8_t* obj_mask, int B, int
 int vlb_obj_prep_fwd(const float* boxes, long ldbox, const float* im_info, const int64_t* mvrc_ops,
                      const float* mask_emb, void* out, int B, int R, float drop_p, const uint32_t* seed, uint32_t tag,
                      vlb_stream_t stream);
+/* x[r, :] = 0 where boxes[r*ldbox] <= -1.5 (padded box): the zero rows pad_sequence leaves in obj_reps (common/fast_rcnn.py:176-186) */
+int vlb_zero_padded_rows_bf16(void* x, long ld, const float* boxes, long ldbox, int rows, int H, vlb_stream_t stream);
 /* dst[c] += sum over rows with sel[row]==1 of src[row][c] * dropout_mask(row*row_elems + col_off + c) */
 int vlb_masked_colsum(const void* src, long lds, const int64_t* sel, int rows, int C, float* dst, float drop_p,
                       const uint32_t* seed, uint32_t tag, uint32_t row_elems, uint32_t col_off, vlb_stream_t stream);

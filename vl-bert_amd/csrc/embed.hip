@@ -113,6 +113,24 @@ __global__ __launch_bounds__(256) void obj_prep_fwd_kernel(const float* __restri
   }
 }
 
+// x[r, :] = 0 for the rows of padded boxes (boxes[r*ldbox] <= -1.5): obj_downsample is only applied to valid boxes in the reference and
+// pad_sequence fills the rest with zeros (common/fast_rcnn.py:176-186); the GEMM over the zeroed input row leaves relu(bias) there,
+// which matters when box 0 of a sample is padding (its row feeds every text token's visual embedding, :132-135).
+__global__ __launch_bounds__(256) void zero_padded_rows_kernel(bf16_t* __restrict__ x, long ld, const float* __restrict__ boxes, long ldbox,
+                                                               int rows, int H) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows || boxes[(long)row * ldbox] > -1.5f) return;
+  for (int c = lane * 8; c < H; c += 512) *(uint4*)(x + (long)row * ld + c) = make_uint4(0, 0, 0, 0);
+}
+
+extern "C" int vlb_zero_padded_rows_bf16(void* x, long ld, const float* boxes, long ldbox, int rows, int H, hipStream_t stream) {
+  if (rows <= 0) return VLB_OK;
+  VLB_CHECK_ARG(x && boxes && H > 0 && (H % 8) == 0 && (ld % 8) == 0, "vlb_zero_padded_rows_bf16: bad argument");
+  hipLaunchKernelGGL(zero_padded_rows_kernel, dim3(vlb_cdiv(rows, 4)), dim3(256), 0, stream, (bf16_t*)x, ld, boxes, ldbox, rows, H);
+  VLB_CHECK_LAUNCH("vlb_zero_padded_rows_bf16");
+  return VLB_OK;
+}
+
 // colsum over rows r with sel[r]==1 of src[r][c] * dropmask(row, col_off + c):  dst[c] += ...
 // (gradient of object_mask_visual_embedding: sum over masked regions of dA[:, 2048:]).
 __global__ __launch_bounds__(256) void masked_colsum_kernel(const bf16_t* __restrict__ src, long lds, const int64_t* __restrict__ sel,

@@ -490,6 +490,7 @@ class PretrainEngine:
                          w32["object_mask_visual_embedding.weight"], self.a_ds, drop_p=p_ds, seed=seed, tag=TAG_DOWNSAMPLE)
         ops.gemm_nt(self.a_ds, w16["image_feature_extractor.obj_downsample.1.weight"], self.obj_reps,
                     bias=w32["image_feature_extractor.obj_downsample.1.bias"], act=ops.ACT_RELU)
+        ops.zero_padded_rows(self.obj_reps, self.in_boxes)      # pad_sequence zeros (a padded box 0 feeds the text tokens' visual embedding)
         # --- visual LayerNorms + fused embedding ---------------------------------------------------------
         ops.layernorm_fwd(self.obj_reps, w32["vlbert.visual_ln_object.weight"], w32["vlbert.visual_ln_object.bias"], self.objvis,
                           self.st_objvis)

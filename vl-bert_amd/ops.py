@@ -198,6 +198,13 @@ def obj_prep_fwd(boxes, im_info, mvrc_ops, mask_emb, out, drop_p=0.0, seed=None,
     return out
 
 
+def zero_padded_rows(x, boxes):
+    """x bf16 [B*R, H]: rows whose box (boxes fp32 [B,R,ld], x1 <= -1.5) is padding become 0."""
+    B, R, ldb = boxes.shape
+    _lib.call("vlb_zero_padded_rows_bf16", _p(x, BF16), _ld(x), _p(boxes, torch.float32), ldb, B * R, x.shape[1], _stream())
+    return x
+
+
 def masked_colsum(src, sel, dst, drop_p=0.0, seed=None, tag=0, row_elems=0, col_off=0):
     rows, C = src.shape
     _lib.call("vlb_masked_colsum", _p(src, BF16), _ld(src), _p(sel, torch.int64), rows, C, _p(dst, torch.float32), float(drop_p),
