@@ -721,3 +721,17 @@ def test_engine_degenerate_samples_vs_oracle():
     # pieces are mutually consistent, cf. test_fast_rcnn_mirror_mask_embedding_gradient) -> looser per-tensor tolerance; logits,
     # losses and the gradient norm keep the standard bars
     check_against_oracle("degenerate samples", cfg, params, tuple(batch), grad_tol=0.12)
+
+
+def test_engine_no_valid_mvrc_rows_and_single_sample_vs_oracle():
+    """soft_cross_entropy returns 0 when no row has a valid soft label (common/utils/misc.py:139-140) -- the device-side count must not
+    divide by zero; and batch size 1."""
+    syn = pkg("synthetic")
+    cfg = O.VLBertConfig(num_hidden_layers=1)
+    params = O.init_params(cfg, seed=61)
+    batch = list(syn.make_batch(1, 20, 7, seed=62, ragged=True))
+    batch[5].zero_()                       # no masked regions ...
+    batch[6].zero_()                       # ... and no soft labels at all
+    eng = check_against_oracle("B=1, no MVRC labels", cfg, params, tuple(batch), grad_tol=0.12)
+    assert eng.loss_values()["mvrc_loss"] == 0.0
+    assert float(eng.g32["vlbert.mvrc_head.region_cls_pred.weight"].abs().max()) == 0.0
