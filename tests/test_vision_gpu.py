@@ -346,11 +346,15 @@ def test_vision_stack_matches_reference_golden():
         assert e < (3e-2 if "roi_head" in short else 8e-2), short
 
 
-def test_engine_e2e_step_vs_oracle():
-    """One e2e pretraining step (image -> CNN -> VL-BERT -> losses -> gradients) of the engine against the composed oracle."""
+@pytest.mark.parametrize("empty_sample", [False, True])
+def test_engine_e2e_step_vs_oracle(empty_sample):
+    """One e2e pretraining step (image -> CNN -> VL-BERT -> losses -> gradients) of the engine against the composed oracle.
+    empty_sample: the second image has no valid box at all (every RoI slot padded)."""
     E, syn = pkg("engine"), pkg("synthetic")
     z, nl, P = _vision_fixture()
-    img, boxes4 = torch.from_numpy(z["img"]), torch.from_numpy(z["boxes"])
+    img, boxes4 = torch.from_numpy(z["img"]), torch.from_numpy(z["boxes"]).clone()
+    if empty_sample:
+        boxes4[1] = -2.0
     B, R = boxes4.shape[:2]
     T = 12
     cfg = O.VLBertConfig(num_hidden_layers=1)
