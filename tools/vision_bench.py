@@ -4,7 +4,6 @@ Usage: python tools/vision_bench.py [N] [H] [W] [R] [layers]"""
 import importlib
 import os
 import sys
-import time
 
 import torch
 

@@ -1,6 +1,5 @@
 """`ROIAlign` module / `roi_align` function with the reference's API
 (common/lib/roi_pooling/roi_align.py:11-70), running the HIP kernels behind C_ROIPooling."""
-import torch
 from torch import nn
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable

@@ -16,7 +16,6 @@ The 1/world_size average is folded into the AdamW kernel's grad_scale (no extra 
 Gradient accumulation: call `reduce_*` only on the boundary micro-step (the reference all-reduces on
 every micro-batch, common/trainer.py:117-118,132-153).
 """
-import torch
 import torch.distributed as dist
 
 
