@@ -209,7 +209,7 @@ def run_vision_case(name="vision_small", num_layers=50):
     ROIAlign -> dilated layer4 head -> avg-pool) on a small image batch with one padded box, parameters from
     oracle/vision_oracle.init_vision_params (handed to the reference through its own `torch.load(pretrained_model_path)` call).
     Objective <obj_reps_raw, Wr>; stores the pooled features, body4 statistics and per-parameter gradient norms."""
-    from . import vision_oracle as VO
+    from oracle import vision_oracle as VO
     ref_import.import_reference()
     ref_import.install_roi_align_oracle()
     import common.lib.roi_pooling as rp
@@ -289,7 +289,7 @@ def run_vqa_case(name="vqa_small"):
     """VQA fixture: the reference's own vqa.modules.resnet_vlbert_for_vqa.ResNetVLBERT (precomputed features, "2fc" classifier) in
     eval-free train_forward with every dropout at p = 0, parameters from oracle/vqa_oracle.init_vqa_params; stores inputs, logits,
     loss and gradient digests; checks the restatement against it."""
-    from . import vqa_oracle as VQ
+    from oracle import vqa_oracle as VQ
     ref_import.import_reference()
     from vqa.modules.resnet_vlbert_for_vqa import ResNetVLBERT as RefVQA
     cfg = VLBertConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,

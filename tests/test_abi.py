@@ -94,6 +94,11 @@ def test_train_end2end_entry_point_dry_run(tmp_path):
     if os.path.isfile(ref):            # the reference's own file, as it is
         r2 = tr.main(["--cfg", ref, "--dry-run"])
         assert not r2["e2e"] and r2["per_gpu_batch"] == 64 and abs(r2["lr"] - 64e-7) < 1e-15 and not r2["multitask"]
+    ref3 = "/root/reference/cfgs/pretrain/base_e2e_16x16G_fp16.yaml"
+    if os.path.isfile(ref3):           # multitask cfg: BATCH_IMAGES [8, 8] = 8 caption + 8 text-only samples per GPU, lr scaled by their sum
+        r3 = tr.main(["--cfg", ref3, "--dry-run"])
+        assert r3["multitask"] and r3["e2e"] and r3["per_gpu_batch"] == 8 and r3["per_gpu_aux_batch"] == 8
+        assert r3["global_batch"] == 16 and abs(r3["lr"] - 1.0e-7 * 16 * r3["accumulate"]) < 1e-15
     if not torch.cuda.is_available():
         with pytest.raises(RuntimeError, match="no CPU execution path"):
             tr.main(["--cfg", str(y), "--steps", "1"])

@@ -310,6 +310,65 @@ def test_dropin_module_matches_reference_training_loop_contract():
     assert all(p.grad is not None for p in net.parameters())
 
 
+def test_dropin_module_train_mode_backward_uses_forward_dropout_masks():
+    """net.train(); loss.backward() of the nn.Module mirrors: dropout masks are regenerated from the device seed, so the backward
+    must see the seed its forward used (the mirrors used to advance it in between).  Gradients of the mirror's autograd path must
+    equal engine.forward / engine.backward run directly under the same seed; the next training forward draws fresh masks."""
+    M = pkg("pretrain.modules")
+    syn = pkg("synthetic")
+    cfg = O.VLBertConfig(num_hidden_layers=2)
+    net = M.ResNetVLBERTForPretraining(_module_config(cfg))
+    net.load_state_dict(O.init_params(cfg, seed=81))
+    batch = tuple(t.to(dev()) for t in syn.make_batch(4, 32, 10, seed=82, ragged=True))
+    net.train()
+    losses = []
+    for it in range(2):
+        net.zero_grad()
+        outputs, loss = net(None, *batch)
+        loss.backward()
+        torch.cuda.synchronize()
+        got = {n: p.grad.detach().clone() for n, p in net.named_parameters()}
+        eng = next(iter(net._engines.values()))
+        seed_now = int(eng.seed.cpu())
+        eng.P.grad.zero_()
+        eng._fresh_grads = False
+        eng.forward(train=True)
+        eng.backward(train=True)
+        torch.cuda.synchronize()
+        assert int(eng.seed.cpu()) == seed_now
+        assert abs(float(loss) - eng.loss_values()["loss"]) < 1e-5 * max(1.0, abs(float(loss)))
+        worst = max((rel_fro(got[n], eng.g32[n]), n) for n in got if float(eng.g32[n].norm()) > 0)
+        print("train-mode mirror vs engine (same seed), iteration %d: worst rel-fro %.3e (%s)" % ((it,) + worst))
+        assert worst[0] < 1e-4, worst
+        losses.append(float(loss))
+    assert losses[0] != losses[1]          # second training forward advanced the seed: different masks
+    # module-API mirror (the VQA wrapper's net.vlbert): same property through _CoreFn
+    VL = pkg("common.visual_linguistic_bert")
+    z, ccfg, params, ins = _core_fixture()
+    core = VL.VisualLinguisticBertForPretraining(_module_config(ccfg)["NETWORK"]["VLBERT"], with_rel_head=False)
+    core.load_state_dict(params)
+    core.train()
+    tv = ins[2].clone().requires_grad_(True)
+    ovl = ins[4].clone().requires_grad_(True)
+    _, mlm, mvrc = core(ins[0], ins[1], tv, ins[3], ovl, ins[5], output_all_encoded_layers=False, output_text_and_object_separately=True)
+    g = torch.Generator().manual_seed(9)
+    c0 = torch.randn(mlm.shape, generator=g).to(dev()) * 1e-2
+    c1 = torch.randn(mvrc.shape, generator=g).to(dev()) * 1e-2
+    ((mlm * c0).sum() + (mvrc * c1).sum()).backward()
+    torch.cuda.synchronize()
+    got = {n: p.grad.detach().clone() for n, p in core.named_parameters()}
+    eng = next(iter(core._engines.values()))
+    eng.P.grad.zero_()
+    eng._fresh_grads = False
+    eng.forward_core(train=True)
+    eng.backward_core(c0, c1, None, train=True)
+    torch.cuda.synchronize()
+    named = eng.P.named(eng.P.grad)
+    worst = max((rel_fro(got[n], named["vlbert." + n]), n) for n in got if float(named["vlbert." + n].norm()) > 0)
+    print("train-mode module-API mirror vs engine (same seed): worst rel-fro %.3e (%s)" % worst)
+    assert worst[0] < 1e-4, worst
+
+
 def _core_fixture():
     z = np.load(os.path.join(os.path.dirname(__file__), "golden", "core", "core_small.npz"), allow_pickle=False)
     cfg = O.VLBertConfig(**{str(k): int(v) for k, v in zip(z["cfg_keys"], z["cfg_vals"])})
@@ -735,3 +794,62 @@ def test_engine_no_valid_mvrc_rows_and_single_sample_vs_oracle():
     eng = check_against_oracle("B=1, no MVRC labels", cfg, params, tuple(batch), grad_tol=0.12)
     assert eng.loss_values()["mvrc_loss"] == 0.0
     assert float(eng.g32["vlbert.mvrc_head.region_cls_pred.weight"].abs().max()) == 0.0
+
+
+def _per_layer_report(tag, eng, grads, norm, L):
+    """rel-Frobenius gradient error aggregated per encoder layer index (depth growth of the bf16 error is visible in the log)."""
+    rows = []
+    for l in range(L):
+        p = "vlbert.encoder.layer.%d." % l
+        num = den = 0.0
+        for name, g in eng.g32.items():
+            if name.startswith(p):
+                d = (g.detach().double().cpu() - grads[name].double()).norm() ** 2
+                num += float(d)
+                den += float(grads[name].double().norm() ** 2)
+        rows.append((l, (num / max(den, 1e-300)) ** 0.5))
+    line = "%s per-layer rel-fro grad err: %s" % (tag, "  ".join("L%d %.2e" % r for r in rows))
+    print(line)
+    try:
+        from tests.gpu_util import REPORT
+        with open(REPORT, "a") as f:
+            f.write(line + "\n")
+    except OSError:
+        pass
+    return rows
+
+
+def test_engine_headline_c2_12_layers_vs_oracle():
+    """BASELINE.json configs[1] EXACTLY as bench.py times it: VL-BERT-base, 12 layers, H = 768, 64 text + 36 regions (S = 101),
+    V = 30522, C = 1601 -- ragged batch of 6, eval mode, against oracle.loss_and_grads: logits <= 1e-2 of the tensor scale, global
+    gradient norm <= 1e-2, per-tensor rel-Frobenius bounded, per-layer error printed so the bf16 error growth with depth is visible."""
+    syn = pkg("synthetic")
+    cfg = O.VLBertConfig(num_hidden_layers=12)
+    params = O.init_params(cfg, seed=71)
+    batch = syn.make_batch(6, 64, 36, seed=72, ragged=True)
+    eng = check_against_oracle("C2 12-layer", cfg, params, batch, grad_tol=6e-2)
+    _, _, grads, norm = O.loss_and_grads(params, cfg, batch, train=False)
+    rows = _per_layer_report("C2 12-layer", eng, grads, norm, 12)
+    assert max(e for _, e in rows) <= 4e-2, rows
+
+
+def test_engine_headline_c2_full_length_batch_vs_oracle():
+    """Same configuration with the full-length (non-ragged) batch layout of the bench workload (every sample 64 + 36)."""
+    syn = pkg("synthetic")
+    cfg = O.VLBertConfig(num_hidden_layers=12)
+    params = O.init_params(cfg, seed=73)
+    batch = syn.make_batch(4, 64, 36, seed=74, ragged=False)
+    check_against_oracle("C2 12-layer full-length", cfg, params, batch, grad_tol=6e-2)
+
+
+def test_engine_large_4_layers_s229_vs_oracle():
+    """VL-BERT-large (H = 1024, 16 heads, I = 4096) at 4 layers with the 128 text + 100 regions sequence (S = 229) of
+    BASELINE.json configs 4-5, full vocabulary, ragged batch of 2."""
+    syn = pkg("synthetic")
+    cfg = O.VLBertConfig(hidden_size=1024, num_attention_heads=16, intermediate_size=4096, num_hidden_layers=4)
+    params = O.init_params(cfg, seed=75)
+    batch = syn.make_batch(2, 128, 100, seed=76, ragged=True)
+    eng = check_against_oracle("large 4-layer S=229", cfg, params, batch, grad_tol=0.12)
+    _, _, grads, norm = O.loss_and_grads(params, cfg, batch, train=False)
+    rows = _per_layer_report("large 4-layer S=229", eng, grads, norm, 4)
+    assert max(e for _, e in rows) <= 4e-2, rows

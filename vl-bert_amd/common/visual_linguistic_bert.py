@@ -31,7 +31,9 @@ class _CoreFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, text_vis, obj_vl, anchor, module, eng):
         ctx.module, ctx.eng = module, eng
+        eng.mirror_pre_forward(module.training)   # fresh dropout masks for this forward and ITS backward (seed advanced before, not after)
         mlm, mvrc, text_out, obj_out, pooled, rel = eng.forward_core(train=module.training)
+        ctx.seed_snap = eng.seed_snapshot()
         ctx.in_dtypes = (text_vis.dtype, obj_vl.dtype)
         third = (rel if eng.with_heads else pooled)
         third = third.float() if third is not None else text_vis.new_zeros(())     # placeholder keeps the arity fixed
@@ -48,12 +50,13 @@ class _CoreFn(torch.autograd.Function):
         module, eng = ctx.module, ctx.eng
         module._prepare_grads()
         g2 = g2 if ctx.has_third else None
-        if eng.with_heads:
-            d_tv, d_ovl = eng.backward_core(g0, g1, g2, train=module.training)
-        elif eng.seq_out:
-            d_tv, d_ovl = eng.backward_core_sequence(g0, g2, train=module.training)
-        else:
-            d_tv, d_ovl = eng.backward_core_hidden(g0, g1, g2, train=module.training)
+        with eng.seed_guard(ctx.seed_snap):
+            if eng.with_heads:
+                d_tv, d_ovl = eng.backward_core(g0, g1, g2, train=module.training)
+            elif eng.seq_out:
+                d_tv, d_ovl = eng.backward_core_sequence(g0, g2, train=module.training)
+            else:
+                d_tv, d_ovl = eng.backward_core_hidden(g0, g1, g2, train=module.training)
         return d_tv.to(ctx.in_dtypes[0]), d_ovl.to(ctx.in_dtypes[1]), None, None, None
 
 
@@ -147,11 +150,7 @@ class VisualLinguisticBert(nn.Module):
         eng = self._engine_for(B, T, R, sequence)
         eng.set_core_inputs(text_input_ids, text_token_type_ids, text_visual_embeddings, text_mask, object_vl_embeddings, object_mask)
         anchor = next(iter(self._pnames.values()))
-        out = _CoreFn.apply(text_visual_embeddings, object_vl_embeddings, anchor, self, eng)
-        if self.training:
-            from .. import ops
-            ops.rng_advance(eng.seed)
-        return out
+        return _CoreFn.apply(text_visual_embeddings, object_vl_embeddings, anchor, self, eng)
 
     def forward(self, text_input_ids, text_token_type_ids, text_visual_embeddings, text_mask, object_vl_embeddings, object_mask,
                 output_all_encoded_layers=True, output_text_and_object_separately=False, output_attention_probs=False):

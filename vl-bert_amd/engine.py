@@ -242,7 +242,9 @@ class PretrainEngine:
             self.wT["vlbert.relationsip_head.caption_image_relationship.weight"] = zb(H, 64)   # K padded to one 64-wide tile
 
         # device-resident step state
-        self.seed = torch.tensor([seed | 1], dtype=torch.int32, device=d)
+        # odd (the advance kernel keeps it odd) and injective in `seed`: `seed | 1` collapsed ranks 2k / 2k+1 of a
+        # seed = RNG_SEED + rank launch onto one dropout stream
+        self.seed = torch.tensor([((seed * 2 + 1) & 0x7FFFFFFF)], dtype=torch.int32, device=d)
         self.adam = torch.tensor([lr, betas[0], betas[1], eps, weight_decay, 0.0, max_grad_norm, 0.0], dtype=F32, device=d)
         self.sumsq_ws = zf(2048)  # per-block partial sums of the gradient norm
         self.losses = zf(4)       # mlm (with visual content), mvrc, mlm (aux text), relationship
@@ -917,6 +919,35 @@ class PretrainEngine:
         if self.vision is not None:
             self.vision.refresh_weights(trainable_only=True)
         ops.rng_advance(self.seed)
+
+    # -- dropout seed discipline of the nn.Module mirrors (reference-style loop: net.train(); loss.backward(); optimizer.step()) --
+    # Masks are never stored: forward and backward regenerate them from the device-resident seed, so the seed a backward sees must
+    # be the one its forward used.  The mirrors therefore advance the seed BEFORE each training forward (not after it) and the
+    # autograd nodes run their backward under the seed value snapshotted right after the forward (robust to interleaved
+    # forward / backward orders and to several engines sharing autograd).
+    def mirror_pre_forward(self, training):
+        if training:
+            if getattr(self, "_seed_used", False):
+                ops.rng_advance(self.seed)
+            self._seed_used = True
+
+    def seed_snapshot(self):
+        return self.seed.clone()
+
+    class _SeedGuard:
+        def __init__(self, eng, snap):
+            self.eng, self.snap = eng, snap
+
+        def __enter__(self):
+            self.cur = self.eng.seed.clone()
+            self.eng.seed.copy_(self.snap)
+
+        def __exit__(self, *exc):
+            self.eng.seed.copy_(self.cur)
+            return False
+
+    def seed_guard(self, snap):
+        return PretrainEngine._SeedGuard(self, snap)
 
     def train_step(self, lr=None):
         """zero_grad -> forward -> backward (gradient buckets all-reduced over RCCL as they complete,

@@ -37,6 +37,7 @@ class _HipLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, module, eng):
         ctx.module, ctx.eng = module, eng
+        ctx.seed_snap = eng.seed_snapshot()       # the backward regenerates this forward's dropout masks (engine.mirror_pre_forward)
         return (eng.losses[0] + eng.losses[1] + eng.losses[2] + eng.losses[3]).clone()
 
     @staticmethod
@@ -46,7 +47,8 @@ class _HipLoss(torch.autograd.Function):
         if g != 1.0:                    # re-derive d(logits) with the upstream scale (grad accumulation / loss scaling)
             eng._losses_fwd_bwd(g, keep=False)
         module._prepare_grads()
-        eng.backward(train=module.training)
+        with eng.seed_guard(ctx.seed_snap):
+            eng.backward(train=module.training)
         return None, None, None
 
 
@@ -224,9 +226,8 @@ class ResNetVLBERTForPretraining(nn.Module):
         else:
             eng = self._engine_for(B, T, R)
             eng.set_batch(boxes, im_info, text, relationship_label, mlm_labels, mvrc_ops, mvrc_labels)
+        eng.mirror_pre_forward(self.training)      # fresh dropout masks for this forward AND its backward
         eng.forward(train=self.training)
-        if self.training:
-            ops.rng_advance(eng.seed)      # fresh dropout masks next step (the fused optimizer path does this itself)
         loss = _HipLoss.apply(self._pnames["vlbert.word_embeddings.weight"], self, eng)
         mlm_logits, mvrc = self._padded_logits(eng, B)
         outputs = {
@@ -264,9 +265,8 @@ class ResNetVLBERTForPretrainingMultitask(ResNetVLBERTForPretraining):
         T = max(text.shape[1], Ta)
         eng = self._engine_for(B, T, R, Ba)
         eng.set_batch(boxes, im_info, text, relationship_label, mlm_labels, mvrc_ops, mvrc_labels, aux_text, aux_labels)
+        eng.mirror_pre_forward(self.training)
         eng.forward(train=self.training)
-        if self.training:
-            ops.rng_advance(eng.seed)
         loss = _HipLoss.apply(self._pnames["vlbert.word_embeddings.weight"], self, eng)
         mlm_logits, mvrc = self._padded_logits(eng, B + Ba)
         lab = eng.in_mlm_labels

@@ -70,7 +70,15 @@ def resolve(config, world, args):
     """The numbers the step needs, with the reference's conventions."""
     tr = config.TRAIN
     bi = tr.BATCH_IMAGES
-    per_gpu = args.batch_images or (sum(bi) if isinstance(bi, (list, tuple)) else int(bi))
+    # multitask cfgs: BATCH_IMAGES = [caption batch, text-only batch, ...] per GPU (MultiTaskDataLoader,
+    # common/utils/multi_task_dataloader.py:17-57); the LR scales with their SUM (pretrain/function/train.py:133-138)
+    if isinstance(bi, (list, tuple)):
+        per_gpu, per_gpu_aux = int(bi[0]), int(sum(bi[1:]))
+    else:
+        per_gpu, per_gpu_aux = int(bi), 0
+    if args.batch_images:
+        per_gpu_aux = args.batch_images if per_gpu_aux else 0
+        per_gpu = args.batch_images
     accum = int(tr.GRAD_ACCUMULATE_STEPS)
     steps_per_epoch = args.steps_per_epoch
     if tr.OPTIMIZER != "AdamW":
@@ -81,8 +89,11 @@ def resolve(config, world, args):
     multitask = config.MODULE == "ResNetVLBERTForPretrainingMultitask"
     if config.MODULE not in ("ResNetVLBERTForPretraining", "ResNetVLBERTForPretrainingMultitask"):
         raise NotImplementedError("MODULE %s" % config.MODULE)
-    return dict(per_gpu_batch=per_gpu, world=world, global_batch=per_gpu * world, accumulate=accum,
-                lr=float(tr.LR) * world * per_gpu * accum, weight_decay=float(tr.WD), clip_grad_norm=float(tr.CLIP_GRAD_NORM),
+    if not multitask:
+        per_gpu, per_gpu_aux = per_gpu + per_gpu_aux, 0
+    total = per_gpu + per_gpu_aux
+    return dict(per_gpu_batch=per_gpu, per_gpu_aux_batch=per_gpu_aux, world=world, global_batch=total * world, accumulate=accum,
+                lr=float(tr.LR) * world * total * accum, weight_decay=float(tr.WD), clip_grad_norm=float(tr.CLIP_GRAD_NORM),
                 lr_schedule=sched, warmup_steps=int(tr.WARMUP_STEPS) if tr.WARMUP else 0,
                 t_total=int(int(tr.END_EPOCH) * steps_per_epoch / accum), steps_per_epoch=steps_per_epoch,
                 e2e=not config.NETWORK.IMAGE_FEAT_PRECOMPUTED, image_size=tuple(config.SCALES), multitask=multitask,
@@ -146,7 +157,7 @@ def main(argv=None):
                             image_num_layers=int(config.NETWORK.IMAGE_NUM_LAYERS),
                             image_frozen_stages=tuple(config.NETWORK.IMAGE_FROZEN_BACKBONE_STAGES))
     B, T, R = r["per_gpu_batch"], args.text_len, args.regions
-    B_aux = B if r["multitask"] else 0
+    B_aux = r["per_gpu_aux_batch"]
     eng = engine.PretrainEngine(mc, B, T, R, device="cuda:%d" % local_rank, train=True, lr=r["lr"], weight_decay=r["weight_decay"],
                                 max_grad_norm=r["clip_grad_norm"], seed=r["seed"] + rank, B_aux=B_aux,
                                 lr_schedule=r["lr_schedule"], warmup_steps=r["warmup_steps"], t_total=max(r["t_total"], r["warmup_steps"] + 1),
@@ -154,7 +165,7 @@ def main(argv=None):
     eng.init_random(seed=r["seed"], visual_ln_init=float(g("visual_scale_object_init", 0.0)))
     if rank == 0:
         print("train_end2end: %s | %d GPU(s) x batch %d | lr %.3e wd %.1e clip %.1f | schedule %s warmup %d t_total %d%s" %
-              (config.MODULE, world, B, r["lr"], r["weight_decay"], r["clip_grad_norm"], r["lr_schedule"], r["warmup_steps"], r["t_total"],
+              (config.MODULE, world, B + B_aux, r["lr"], r["weight_decay"], r["clip_grad_norm"], r["lr_schedule"], r["warmup_steps"], r["t_total"],
                " | fp16 requested -> bf16 compute (no loss scaling needed)" if r["fp16_requested"] else ""), flush=True)
     t0, seen = time.time(), 0
     def load_batch(seed_off):
@@ -189,7 +200,7 @@ def main(argv=None):
             if eng.buckets is not None:
                 eng.buckets.wait()
             eng.optimizer_step()
-        seen += B * world * accum
+        seen += (B + B_aux) * world * accum
         if (step + 1) % max(1, min(int(config.LOG_FREQUENT), args.steps)) == 0 or step + 1 == args.steps:
             lv = eng.loss_values()          # host sync, like the reference's Speedometer + metric readout
             if rank == 0:
