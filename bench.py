@@ -116,20 +116,42 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="(default behaviour; kept for older command lines)")
     args = ap.parse_args()
 
+    if "RANK" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: re-launch ourselves as N ranks (one per GPU) under torch.distributed.run, exactly the
+        # command line the driver would use; rank 0 of that job prints the JSON line, its exit code becomes ours
+        import socket
+        import subprocess
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "8")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node %d (or without torch.distributed.run: bench.py "
+                         "re-launches itself)" % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (MI355X); the product path has no CPU fallback")
+    ndev = torch.cuda.device_count()
+    shared = world > ndev        # more ranks than GPUs (CI on a 1-GPU box): ranks share devices; RCCL refuses that, gloo carries the exchange
+    local_rank = local_rank % ndev
     torch.cuda.set_device(local_rank)
     dist = None
+    backend = os.environ.get("VLB_BENCH_BACKEND", "gloo" if shared else "nccl")
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     engine = importlib.import_module("vl-bert_amd.engine")
     syn = importlib.import_module("vl-bert_amd.synthetic")
@@ -148,7 +170,8 @@ def main():
         cfg = engine.ModelConfig(num_hidden_layers=args.layers, e2e=args.e2e)
     eng = engine.PretrainEngine(cfg, per_gpu, T, R, device="cuda:%d" % local_rank, train=True, lr=1e-4, weight_decay=1e-4,
                                 max_grad_norm=10.0, seed=1234 + rank, image_size=tuple(args.image_size) if args.e2e else None)
-    eng.init_random(seed=0, visual_ln_init=1.0 if args.e2e else 0.0)   # same weights on every rank (DDP broadcast, train.py:332-334)
+    eng.init_random(seed=rank, visual_ln_init=1.0 if args.e2e else 0.0)
+    eng.broadcast_parameters(src=0)      # rank 0's parameters everywhere (the DDP start-up broadcast, pretrain/function/train.py:331-334)
     batch = syn.make_batch(per_gpu, T, R, seed=100 + rank)
     if args.e2e:      # images as the dataset hands them over (mean-subtracted pixels), boxes inside the image
         gi = torch.Generator().manual_seed(200 + rank)
@@ -289,7 +312,10 @@ def main():
                                    "%s, dropout on" % ("large" if args.large else "base", args.layers, T, R, "ResNet-101 trunk + ROIAlign + dilated layer4 head on the device "
                                                        "(stages 1-2 and BatchNorm frozen)" if args.e2e else "precomputed 2048-d region features"),
                        "global_batch": args.global_batch, "per_gpu_batch": per_gpu, "seq_len": T + R + 1,
-                       "parallelism": "dp%d" % world, "hipgraph": bool(use_graph), "arch": arch, "cus": cus},
+                       "parallelism": "dp%d" % world, "hipgraph": bool(use_graph), "arch": arch, "cus": cus,
+                       "collective_backend": (("RCCL (nccl)" if backend == "nccl" else backend) if world > 1 else None),
+                       "grad_wire_dtype": (str(eng.buckets.reduced.dtype).replace("torch.", "") if eng.buckets is not None else None),
+                       "ranks_share_devices": bool(shared)},
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_bf16_kernel + gemm_tn_bf16_kernel (all %d GEMM launches of one step)" % len(rec),
                          "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": traffic_unit,

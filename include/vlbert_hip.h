@@ -204,6 +204,11 @@ int vlb_sumsq_f32(const float* g, long n, float* out, vlb_stream_t stream);
 int vlb_sumsq_f32_det(const float* g, long n, float* partials, int partials_len, float* out, vlb_stream_t stream);
 int vlb_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, long n, float* state, float grad_scale,
                    vlb_stream_t stream);
+/* the same two steps on a bf16 gradient image: the wire format of the data-parallel exchange (DDP all-reduce of
+ * pretrain/function/train.py:89-90 carried out in bf16 over RCCL); the reduced gradient is consumed as it arrived. */
+int vlb_sumsq_bf16_det(const void* g_bf16, long n, float* partials, int partials_len, float* out, vlb_stream_t stream);
+int vlb_adamw_step_gbf16(float* p, const void* g_bf16, float* m, float* v, void* p_bf16, long n, float* state, float grad_scale,
+                         vlb_stream_t stream);
 /* lr schedule evaluated on the device from state[5] (steps taken): state[0] = base_lr * lambda(step + 1), matching the
  * reference's scheduler.step() -> optimizer.step() order (common/trainer.py:131-135).  kind 0 = ConstantLRSchedule,
  * 1 = WarmupConstantSchedule, 2 = WarmupLinearSchedule (common/nlp/bert/optimization.py:27-62).  Call before

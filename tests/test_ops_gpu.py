@@ -568,6 +568,36 @@ def test_adamw_and_sumsq(ops):
     assert float(state[5]) == 3.0 and float(state[7]) == 0.0
 
 
+def test_adamw_and_sumsq_on_bf16_wire_gradient(ops):
+    """vlb_sumsq_bf16_det / vlb_adamw_step_gbf16: the optimizer fed with the bf16 wire image of the data-parallel exchange must
+    equal the fp32 entry points fed with the same (bf16-representable) values; grad_scale = 1/world folded in."""
+    from oracle import vlbert_oracle as O
+    n = 70001
+    g0 = torch.Generator().manual_seed(51)
+    p = torch.randn(n, generator=g0)
+    g = bf(torch.randn(n, generator=g0) * 2)
+    lr, wd, max_norm, scale = 1e-3, 1e-2, 1.0, 0.125
+    mk = lambda: torch.tensor([lr, 0.9, 0.999, 1e-6, wd, 0.0, max_norm, 0.0], dtype=torch.float32, device=dev())
+    part = torch.zeros(2048, device=dev())
+    res = []
+    for wire in (torch.float32, torch.bfloat16):
+        state = mk()
+        pg, m, v = p.clone().to(dev()), torch.zeros(n, device=dev()), torch.zeros(n, device=dev())
+        p16 = torch.empty(n, dtype=torch.bfloat16, device=dev())
+        gg = g.to(dev()).to(wire)
+        ops.sumsq_det(gg, part, state[7:8])
+        ss = float(state[7])
+        ops.adamw_step(pg, gg, m, v, p16, state, grad_scale=scale)
+        res.append((ss, pg.cpu(), m.cpu(), v.cpu(), p16.float().cpu()))
+    assert res[0][0] == res[1][0]
+    for a, b in zip(res[0][1:], res[1][1:]):
+        assert torch.equal(a, b)
+    pr, mr, vr = p.clone(), torch.zeros(n), torch.zeros(n)
+    coef = O.clip_coef(float(g.double().norm()) * scale, max_norm) * scale
+    O.adamw_step(pr, g * coef, mr, vr, 1, lr, eps=1e-6, weight_decay=wd)
+    report("adamw (bf16 wire gradient) p", res[1][1], pr, 1e-6, 1e-5)
+
+
 def test_bce_logits_and_dropout(ops):
     """vlb_bce_logits_fwd_bwd (VQA answer loss x answers, gradient in place, padded columns zeroed) and vlb_dropout_bf16."""
     B, A, Ap = 5, 37, 64

@@ -70,7 +70,7 @@ def test_buckets_with_vision_tail_tile_the_flat_buffer():
     launched = []
     b._launch = lambda lo, hi: launched.append((lo, hi))
     # the engine's order in e2e mode: heads, layers, embed (before the CNN backward), RoI head, layer3, layer2, then the catch-alls
-    for what in ("heads", 1, 0, "embed", "vision4", "vision3", "vision2", "embed", "vision"):
+    for what in ("heads", 1, 0, "word_emb", "embed", "vision4", "vision3", "vision2", "embed", "vision"):
         b.on_done(what)
     assert sorted(launched) == sorted(cov) and len(launched) == len(cov)          # every range exactly once
     assert launched[-3:] == [b.ranges["vision4"], b.ranges["vision3"], b.ranges["vision2"]]
@@ -88,7 +88,8 @@ def _worker(rank, world, port, numel_holder):
     g = torch.Generator().manual_seed(rank)
     grad = torch.randn(numel, generator=g)
     mine = grad.clone()
-    b = P.GradBuckets(grad, offsets, numel, cfg.num_hidden_layers, bucket_bytes=300_000)
+    b = P.GradBuckets(grad, offsets, numel, cfg.num_hidden_layers, bucket_bytes=300_000, wire_dtype=None)
+    assert b.reduced is grad
     # replay the engine's completion order
     b.on_done("heads")
     for l in reversed(range(cfg.num_hidden_layers)):
@@ -99,13 +100,23 @@ def _worker(rank, world, port, numel_holder):
     expect = sum(others)
     assert torch.allclose(grad, expect, atol=1e-5), (grad - expect).abs().max()
     assert abs(b.grad_scale - 1.0 / world) < 1e-12
-    # bf16 wire format path
+    # bf16 wire format (the default): the reduced gradient stays in the persistent bf16 image the optimizer reads; the word-embedding
+    # table goes as its own bucket in front of the rest of the front end
     grad2 = mine.clone()
-    b2 = P.GradBuckets(grad2, offsets, numel, cfg.num_hidden_layers, wire_dtype=torch.bfloat16)
-    for what in ["heads"] + list(reversed(range(cfg.num_hidden_layers))) + ["embed"]:
+    b2 = P.GradBuckets(grad2, offsets, numel, cfg.num_hidden_layers)
+    assert b2.wire_dtype == torch.bfloat16 and b2.reduced.dtype == torch.bfloat16 and b2.reduced.numel() == numel
+    launched = []
+    orig = b2._launch
+    b2._launch = lambda lo, hi: (launched.append((lo, hi)), orig(lo, hi))[1]
+    for what in ["heads"] + list(reversed(range(cfg.num_hidden_layers))) + ["word_emb", "embed"]:
         b2.on_done(what)
     b2.wait()
-    assert torch.allclose(grad2, expect, atol=0.05, rtol=0.02)
+    assert launched[-2] == b2.ranges["word_emb"] and launched[-1] == b2.ranges["embed"] and sorted(launched) == sorted(b2.coverage())
+    assert torch.equal(grad2, mine)                                    # the local fp32 gradient is left untouched
+    assert torch.allclose(b2.reduced.float(), expect, atol=0.05, rtol=0.02)
+    same = b2.reduced.clone()
+    dist.broadcast(same, src=0)
+    assert torch.equal(same, b2.reduced)                               # every rank holds the same reduced bits
     dist.barrier()
     dist.destroy_process_group()
 

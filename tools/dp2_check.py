@@ -47,14 +47,16 @@ def main():
     eng.backward(True, on_layer_done=eng.buckets.on_done)
     eng.buckets.wait()
     torch.cuda.synchronize()
-    err = float((eng.P.grad - total).abs().max()) / max(float(total.abs().max()), 1e-30)
+    red = eng.buckets.reduced              # fp32 flat gradient, or the bf16 wire image (default) the optimizer reads
+    wire16 = red.dtype == torch.bfloat16
+    err = float((red.float() - total).abs().max()) / max(float(total.abs().max()), 1e-30)
     cov = eng.buckets.coverage()
     print("rank %d: reduced-vs-summed gradient max rel err %.2e over %d buckets (vision buckets: %s)" %
           (rank, err, len(cov), eng.buckets.vision_keys), flush=True)
     # two backward passes of one rank are not bit-identical (fp32 atomics: LayerNorm / embedding sums; e2e: ROIAlign backward, whose
     # rounding to bf16 then propagates through the trunk), so this compares to a tolerance; check (1) below is exact
-    assert err < (1e-3 if e2e else 1e-6), err
-    assert float((eng.P.grad - local).abs().max()) > 0
+    assert err < (1e-2 if wire16 else (1e-3 if e2e else 1e-6)), err
+    assert float((red.float() - local).abs().max()) > 0
     # (1) two full steps -> identical parameters on both ranks
     for _ in range(2):
         eng.train_step()

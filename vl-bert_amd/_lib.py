@@ -45,6 +45,8 @@ _SIGS = {
     "vlb_dropout_bf16": "pplfpus",
     "vlb_sumsq_f32_det": "plpips",
     "vlb_adamw_step": "ppppplpfs",
+    "vlb_adamw_step_gbf16": "ppppplpfs",
+    "vlb_sumsq_bf16_det": "plpips",
     "vlb_lr_schedule_step": "pifffs",
     "vlb_conv_weight_prepare": "pppppfppppiiiis",
     "vlb_conv_weight_prepare_batched": "ppiifs",

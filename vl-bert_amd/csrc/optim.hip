@@ -41,16 +41,26 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
 // Deterministic variant: per-block partial sums to a workspace, one block adds them in a fixed order.  The clip coefficient
 // derived from this sum multiplies every gradient, so with data parallelism a run-to-run / rank-to-rank difference in the
 // last bit (atomicAdd order above) makes the replicas' parameters drift apart; this one gives every rank the same bits.
-__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, long n, float* __restrict__ partials) {
+// 4 consecutive gradient elements as fp32: fp32 buffer, or the bf16 wire image of the data-parallel exchange (parallel.py)
+__device__ __forceinline__ float4 load_grad4(const float* g, long i) { return *(const float4*)(g + i); }
+__device__ __forceinline__ float4 load_grad4(const bf16_t* g, long i) {
+  const uint2 w = *(const uint2*)(g + i);
+  return make_float4(bflo(w.x), bfhi(w.x), bflo(w.y), bfhi(w.y));
+}
+__device__ __forceinline__ float load_grad1(const float* g, long i) { return g[i]; }
+__device__ __forceinline__ float load_grad1(const bf16_t* g, long i) { return bf2f(g[i]); }
+
+template <typename GT>
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const GT* __restrict__ g, long n, float* __restrict__ partials) {
   __shared__ float sh[4];
   float s = 0.f;
   const long stride = (long)gridDim.x * 256 * 4;
   for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
     if (i + 3 < n) {
-      const float4 v = *(const float4*)(g + i);
+      const float4 v = load_grad4(g, i);
       s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
     } else {
-      for (long k = i; k < n; ++k) s += g[k] * g[k];
+      for (long k = i; k < n; ++k) { const float x = load_grad1(g, k); s += x * x; }
     }
   }
   s = wave_sum(s);
@@ -69,7 +79,8 @@ __global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restric
   if (threadIdx.x == 0) *out += (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
-__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+template <typename GT>
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const GT* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, bf16_t* __restrict__ p16, long n, VlbAdamState* __restrict__ st,
                                                     float grad_scale) {
   const float lr = st->lr, b1 = st->beta1, b2 = st->beta2, eps = st->eps, wd = st->weight_decay;
@@ -85,7 +96,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     float pv[4], gv[4], mv[4], vv[4];
     const bool full = (i + 3 < n);
     if (full) {
-      const float4 a = *(const float4*)(p + i), b = *(const float4*)(g + i), c = *(const float4*)(m + i), d = *(const float4*)(v + i);
+      const float4 a = *(const float4*)(p + i), b = load_grad4(g, i), c = *(const float4*)(m + i), d = *(const float4*)(v + i);
       pv[0] = a.x; pv[1] = a.y; pv[2] = a.z; pv[3] = a.w;
       gv[0] = b.x; gv[1] = b.y; gv[2] = b.z; gv[3] = b.w;
       mv[0] = c.x; mv[1] = c.y; mv[2] = c.z; mv[3] = c.w;
@@ -93,7 +104,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     } else {
       for (int k = 0; k < 4; ++k) {
         const bool ok = i + k < n;
-        pv[k] = ok ? p[i + k] : 0.f; gv[k] = ok ? g[i + k] : 0.f; mv[k] = ok ? m[i + k] : 0.f; vv[k] = ok ? v[i + k] : 0.f;
+        pv[k] = ok ? p[i + k] : 0.f; gv[k] = ok ? load_grad1(g, i + k) : 0.f; mv[k] = ok ? m[i + k] : 0.f; vv[k] = ok ? v[i + k] : 0.f;
       }
     }
 #pragma unroll
@@ -180,9 +191,23 @@ extern "C" int vlb_sumsq_f32_det(const float* g, long n, float* partials, int pa
   VLB_CHECK_ARG(g && out && partials && partials_len >= 1, "vlb_sumsq_f32_det: null argument");
   int blocks = grid_for((n + 3) / 4);
   if (blocks > partials_len) blocks = partials_len;
-  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(blocks), dim3(256), 0, stream, g, n, partials);
+  hipLaunchKernelGGL(sumsq_partial_kernel<float>, dim3(blocks), dim3(256), 0, stream, g, n, partials);
   hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, stream, partials, blocks, out);
   VLB_CHECK_LAUNCH("vlb_sumsq_f32_det");
+  return VLB_OK;
+}
+
+// the same on a bf16 gradient image (the wire format of the data-parallel exchange: the reduced gradient is consumed as it
+// arrived, no conversion pass back to fp32)
+extern "C" int vlb_sumsq_bf16_det(const void* g, long n, float* partials, int partials_len, float* out, hipStream_t stream) {
+  if (n <= 0) return VLB_OK;
+  VLB_CHECK_ARG(g && out && partials && partials_len >= 1, "vlb_sumsq_bf16_det: null argument");
+  VLB_CHECK_ARG(((uintptr_t)g % 8) == 0, "vlb_sumsq_bf16_det: gradient must be 8-byte aligned");
+  int blocks = grid_for((n + 3) / 4);
+  if (blocks > partials_len) blocks = partials_len;
+  hipLaunchKernelGGL(sumsq_partial_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, (const bf16_t*)g, n, partials);
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, stream, partials, blocks, out);
+  VLB_CHECK_LAUNCH("vlb_sumsq_bf16_det");
   return VLB_OK;
 }
 
@@ -191,10 +216,23 @@ extern "C" int vlb_adamw_step(float* p, const float* g, float* m, float* v, void
                               hipStream_t stream) {
   if (n <= 0) return VLB_OK;
   VLB_CHECK_ARG(p && g && m && v && state, "vlb_adamw_step: null argument");
-  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, stream, p, g, m, v, (bf16_t*)p_bf16, n,
+  hipLaunchKernelGGL(adamw_kernel<float>, dim3(grid_for((n + 3) / 4)), dim3(256), 0, stream, p, g, m, v, (bf16_t*)p_bf16, n,
                      (VlbAdamState*)state, grad_scale);
   hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(1), 0, stream, (VlbAdamState*)state);
   VLB_CHECK_LAUNCH("vlb_adamw_step");
+  return VLB_OK;
+}
+
+// vlb_adamw_step with the gradient given as a bf16 image (see vlb_sumsq_bf16_det)
+extern "C" int vlb_adamw_step_gbf16(float* p, const void* g_bf16, float* m, float* v, void* p_bf16, long n, float* state,
+                                    float grad_scale, hipStream_t stream) {
+  if (n <= 0) return VLB_OK;
+  VLB_CHECK_ARG(p && g_bf16 && m && v && state, "vlb_adamw_step_gbf16: null argument");
+  VLB_CHECK_ARG(((uintptr_t)g_bf16 % 8) == 0, "vlb_adamw_step_gbf16: gradient must be 8-byte aligned");
+  hipLaunchKernelGGL(adamw_kernel<bf16_t>, dim3(grid_for((n + 3) / 4)), dim3(256), 0, stream, p, (const bf16_t*)g_bf16, m, v,
+                     (bf16_t*)p_bf16, n, (VlbAdamState*)state, grad_scale);
+  hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(1), 0, stream, (VlbAdamState*)state);
+  VLB_CHECK_LAUNCH("vlb_adamw_step_gbf16");
   return VLB_OK;
 }
 

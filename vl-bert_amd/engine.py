@@ -752,6 +752,8 @@ class PretrainEngine:
                       g32[pe + "bias"], self.d_textvis, (H, 0), self.d_objvis, (R * H, H),
                       self.P.view(self.P.grad, "object_linguistic_embeddings.weight", (2, H), span=2), (0, 0), Bt, T, R, S, H,
                       drop_p=p_h, seed=seed, tag=TAG_EMBED, text_vis_zeroed=True)
+        if on_layer_done:      # the tied word-embedding gradient (decoder wgrad + this scatter-add) is complete: its 94 MB go out first
+            on_layer_done("word_emb")
         ops.layernorm_bwd(self.d_objvis, self.obj_reps, self.st_objvis, w32["vlbert.visual_ln_object.weight"],
                           dx_acc=self.d_obj_reps, dgamma=g32["vlbert.visual_ln_object.weight"],
                           dbeta=g32["vlbert.visual_ln_object.bias"], workspace=self.ln_ws)
@@ -913,8 +915,10 @@ class PretrainEngine:
         if self.lr_kind is not None:
             ops.lr_schedule_step(self.adam, self.lr_kind, self.base_lr, self.warmup_steps, self.t_total)
         scale = self.buckets.grad_scale if self.buckets is not None else 1.0
-        ops.sumsq_det(self.P.grad, self.sumsq_ws, self.adam[7:8])     # fixed summation order: replicas stay bit-identical
-        ops.adamw_step(self.P.master, self.P.grad, self.P.m, self.P.v, self.P.w16, self.adam, grad_scale=scale)
+        # data parallel: the reduced gradient is read where the exchange left it (the bf16 wire image by default, parallel.py)
+        grad = self.buckets.reduced if self.buckets is not None else self.P.grad
+        ops.sumsq_det(grad, self.sumsq_ws, self.adam[7:8])     # fixed summation order: replicas stay bit-identical
+        ops.adamw_step(self.P.master, grad, self.P.m, self.P.v, self.P.w16, self.adam, grad_scale=scale)
         self._refresh_transposes()
         if self.vision is not None:
             self.vision.refresh_weights(trainable_only=True)
@@ -948,6 +952,19 @@ class PretrainEngine:
 
     def seed_guard(self, snap):
         return PretrainEngine._SeedGuard(self, snap)
+
+    def broadcast_parameters(self, src=0):
+        """Rank `src`'s parameters, optimizer state and (e2e) frozen vision tensors to every rank -- the start-up broadcast of
+        pretrain/function/train.py:331-334, so that a checkpoint loaded on rank 0 only cannot leave the replicas diverged."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.pg) == 1:
+            return
+        for t in (self.P.master, self.P.m, self.P.v, self.adam):
+            dist.broadcast(t, src=src, group=self.pg)
+        if self.vision is not None:
+            for t in self.vision.broadcast_tensors():
+                dist.broadcast(t, src=src, group=self.pg)
+        self._weights_dirty = True
 
     def train_step(self, lr=None):
         """zero_grad -> forward -> backward (gradient buckets all-reduced over RCCL as they complete,

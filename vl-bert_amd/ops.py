@@ -298,12 +298,20 @@ def sumsq(g, out):
 
 
 def sumsq_det(g, partials, out):
-    """out += sum(g^2) with a fixed summation order (same bits on every data-parallel rank)."""
+    """out += sum(g^2) with a fixed summation order (same bits on every data-parallel rank); g fp32, or the bf16 wire image."""
+    if g.dtype == BF16:
+        _lib.call("vlb_sumsq_bf16_det", _p(g, BF16), g.numel(), _p(partials, torch.float32), partials.numel(), _p(out, torch.float32),
+                  _stream())
+        return
     _lib.call("vlb_sumsq_f32_det", _p(g, torch.float32), g.numel(), _p(partials, torch.float32), partials.numel(), _p(out, torch.float32),
               _stream())
 
 
 def adamw_step(p, g, m, v, p16, state, grad_scale=1.0):
+    if g.dtype == BF16:
+        _lib.call("vlb_adamw_step_gbf16", _p(p, torch.float32), _p(g, BF16), _p(m, torch.float32), _p(v, torch.float32),
+                  _p(p16, BF16), p.numel(), _p(state, torch.float32), float(grad_scale), _stream())
+        return
     _lib.call("vlb_adamw_step", _p(p, torch.float32), _p(g, torch.float32), _p(m, torch.float32), _p(v, torch.float32),
               _p(p16, BF16), p.numel(), _p(state, torch.float32), float(grad_scale), _stream())
 

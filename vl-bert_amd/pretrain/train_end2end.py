@@ -163,6 +163,7 @@ def main(argv=None):
                                 lr_schedule=r["lr_schedule"], warmup_steps=r["warmup_steps"], t_total=max(r["t_total"], r["warmup_steps"] + 1),
                                 image_size=r["image_size"] if r["e2e"] else None, grad_accum=r["accumulate"])
     eng.init_random(seed=r["seed"], visual_ln_init=float(g("visual_scale_object_init", 0.0)))
+    eng.broadcast_parameters(src=0)       # rank 0's parameters / optimizer state everywhere (pretrain/function/train.py:331-334)
     if rank == 0:
         print("train_end2end: %s | %d GPU(s) x batch %d | lr %.3e wd %.1e clip %.1f | schedule %s warmup %d t_total %d%s" %
               (config.MODULE, world, B + B_aux, r["lr"], r["weight_decay"], r["clip_grad_norm"], r["lr_schedule"], r["warmup_steps"], r["t_total"],

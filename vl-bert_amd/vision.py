@@ -230,6 +230,12 @@ class VisionStack:
                 raise KeyError("missing buffer %s" % name)
         self._dirty = True
 
+    def broadcast_tensors(self):
+        """fp32 tensors that are NOT in the engine's flat parameter buffer (BatchNorm tensors, weights of the frozen stages):
+        what a start-up parameter broadcast has to cover besides the flat buffer (engine.broadcast_parameters)."""
+        self._dirty = True
+        return [t for t in self.frozen.values() if t.is_contiguous()]
+
     def state_dict(self):
         sd = OrderedDict()
         for key, c in self.convs.items():
