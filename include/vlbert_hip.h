@@ -60,6 +60,10 @@ int vlb_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb, void* C, 
  * slab split-K through `workspace` (vlb_wgrad_workspace_floats(M, N, K) floats) + a reduce that converts to bf16. */
 int vlb_gemm_nt_bf16_splitk(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
                             float* workspace, long workspace_floats, vlb_stream_t stream);
+/* Run-time tuning knob of the GEMM dispatcher (the environment variables VLB_GEMM_P8* give the defaults): name = "p8_mode"
+ * (0: 128x128 kernels only | 1: cost model | 4 / 5: force 256- / 320-row tiles), "p8_keepb", "p8_group", "p8_min_tiles". */
+int vlb_gemm_set_option(const char* name, int value);
+
 
 /* Weight-gradient form: C[M,N] (fp32) += A[M,K] B[N,K]^T for few output tiles and a very long K (K = padded
  * row count of the activations; autograd's `grad_output.t().mm(input)` behind every nn.Linear).  Split-K

@@ -137,6 +137,101 @@ def test_gemm_epilogues(ops):
         report("gemm atomic splitk=%d" % sk, C32, base + acc, 1e-4, 2e-5)
 
 
+@pytest.fixture
+def force_p8():
+    """Route every eligible bf16 GEMM through the large-tile 8-phase core (gemm_p8.hip) whatever its tile count."""
+    lib = pkg("_lib")
+    lib.gemm_set_option("p8_min_tiles", 1)
+    yield lib
+    lib.gemm_set_option("p8_min_tiles", 160)
+    lib.gemm_set_option("p8_mode", 1)
+
+
+@pytest.mark.parametrize("tile", [4, 5])
+@pytest.mark.parametrize("M,N,K", [(2048, 1024, 256), (1000, 520, 128), (2600, 768, 768), (700, 2306, 384)])
+def test_gemm_large_tile_core_epilogues(ops, force_p8, tile, M, N, K):
+    """vl-bert_amd/csrc/gemm_p8.hip (256- and 320-row tiles, 8-phase schedule, fp32-staged epilogue): every fused epilogue of the
+    training step against the fp32 statement of the same op, interior and edge tiles (M, N not multiples of the tile, N % 8 != 0),
+    the shortest K the pipeline accepts (two K tiles), several output tiles per workgroup; dropout against the numpy restatement of
+    the counter RNG.  Padding columns of C must stay untouched."""
+    force_p8.gemm_set_option("p8_mode", tile)
+    A, B = rnd(M, K, seed=4), rnd(N, K, seed=5, scale=0.08)
+    bias = 0.3 * torch.randn(N, generator=torch.Generator().manual_seed(6))
+    res, aux = rnd(M, N, seed=7), rnd(M, N, seed=8)
+    Ag, Bg, bg = to_gpu_bf16(A), to_gpu_bf16(B), bias.to(dev())
+    ldc = (N + 63) // 64 * 64
+    pad = lambda t: torch.cat((t, torch.zeros(M, ldc - N)), 1).to(torch.bfloat16).to(dev())[:, :N]
+    resg, auxg = pad(res), pad(aux)
+    acc = A @ B.t()
+    u = acc + bias
+    Cf = torch.full((M, ldc), 3.0, dtype=torch.bfloat16, device=dev())
+    C = Cf[:, :N]
+    pre = torch.full((M, ldc), 3.0, dtype=torch.bfloat16, device=dev())[:, :N]
+    tag = "p8/%d %dx%dx%d " % (64 * tile, M, N, K)
+    ops.gemm_nt(Ag, Bg, C, bias=bg)
+    report(tag + "bias", C, u, 1e-3, 1e-2)
+    assert bool((Cf[:, N:] == 3.0).all())
+    ops.gemm_nt(Ag, Bg, C)
+    report(tag + "plain", C, acc, 1e-3, 1e-2)
+    ops.gemm_nt(Ag, Bg, C, bias=bg, act=ops.ACT_GELU_D, pre=pre)
+    cdf_u = 0.5 * (1 + torch.erf(u / math.sqrt(2)))
+    report(tag + "gelu_d out", C, u * cdf_u, 1e-3, 1e-2)
+    report(tag + "gelu_d deriv", pre, cdf_u + u * torch.exp(-0.5 * u * u) / math.sqrt(2 * math.pi), 1e-3, 1e-2)
+    ops.gemm_nt(Ag, Bg, C, act=ops.ACT_MULAUX, aux=auxg)
+    report(tag + "mulaux", C, acc * aux, 1e-3, 1e-2)
+    ops.gemm_nt(Ag, Bg, C, bias=bg, res=resg)
+    report(tag + "bias+res", C, u + res, 1e-3, 1e-2)
+    ops.gemm_nt(Ag, Bg, C, bias=bg, act=ops.ACT_RELU)
+    report(tag + "relu", C, torch.relu(u), 1e-3, 1e-2)
+    # in-place residual (C aliases res): the epilogue reads and writes the same 16-B group from one thread
+    Cr = resg.clone()
+    Crf = torch.zeros((M, ldc), dtype=torch.bfloat16, device=dev())
+    Crf[:, :N] = Cr
+    ops.gemm_nt(Ag, Bg, Crf[:, :N], bias=bg, res=Crf[:, :N])
+    report(tag + "in-place residual", Crf[:, :N], u + res, 1e-3, 1e-2)
+    # dropout + residual against the numpy RNG
+    p, seed_v, tg = 0.1, 4242, 9
+    seed = torch.tensor([seed_v], dtype=torch.int32, device=dev())
+    ops.gemm_nt(Ag, Bg, C, bias=bg, res=resg, drop_p=p, seed=seed, tag=tg)
+    thr = drop_thr(p)
+    idx = (np.arange(M, dtype=np.int64)[:, None] * N + np.arange(N, dtype=np.int64)[None, :])
+    keep = torch.from_numpy(keep_mask(seed_v, tg, idx.reshape(-1), thr).reshape(M, N))
+    report(tag + "dropout+res", C, torch.where(keep, u * drop_scale(thr), torch.zeros_like(u)) + res, 1e-3, 1e-2)
+    assert bool((Cf[:, N:] == 3.0).all())
+
+
+def test_engine_step_through_large_tile_core(force_p8):
+    """The whole VL-BERT step with EVERY eligible GEMM forced through gemm_p8.hip (one mostly-clamped 256-row tile at this size)
+    against the same engine on the 128x128 kernels: logits / losses / gradients must agree to bf16 rounding."""
+    from oracle import vlbert_oracle as O
+    E, syn = pkg("engine"), pkg("synthetic")
+    cfg = O.VLBertConfig(num_hidden_layers=2)
+    params = O.init_params(cfg, seed=91)
+    batch = syn.make_batch(4, 32, 10, seed=92, ragged=True)
+    outs = []
+    for mode in (0, 4, 5):
+        force_p8.gemm_set_option("p8_mode", mode)
+        mc = E.ModelConfig(num_hidden_layers=2)
+        eng = E.PretrainEngine(mc, 4, 32, 10, device="cuda:0", keep_logits=True, train=False)
+        eng.load_state_dict({k: v.to(dev()) for k, v in params.items()})
+        eng.set_batch(*[t.to(dev()) for t in batch])
+        eng.zero_grad()
+        eng.forward(train=False)
+        eng.backward(train=False)
+        torch.cuda.synchronize()
+        outs.append((eng.mlm_logits_copy.float().cpu(), eng.loss_values()["loss"], eng.grad_norm(), {k: v.cpu() for k, v in eng.grads().items()}))
+    for k in (1, 2):
+        report("engine via p8 (mode %d) mlm logits vs 128x128 kernels" % (4 if k == 1 else 5), outs[k][0], outs[0][0], 2e-3, 1e-2)
+        assert abs(outs[k][1] - outs[0][1]) < 2e-3 * abs(outs[0][1])
+        assert abs(outs[k][2] - outs[0][2]) < 5e-3 * outs[0][2]
+        # (obj_downsample: a ReLU unit within bf16 rounding of 0 may flip between two kernels' roundings -- whole gradient rows change)
+        worst = max((float((outs[k][3][n].double() - g.double()).norm() / max(float(g.double().norm()), 1e-12)) /
+                     (4.0 if "obj_downsample" in n else 1.0), n)
+                    for n, g in outs[0][3].items() if float(g.norm()) > 1e-6 * outs[0][2])
+        print("engine via p8: worst per-tensor rel-fro gradient difference %.3e (%s)" % worst)
+        assert worst[0] < 3e-2, worst
+
+
 def test_gemm_wgrad_shape(ops):
     """dW[N,K] = dY^T[N,Mp] (X^T[K,Mp])^T through the transpose kernel, zero-padded reduction dim."""
     M, N, K = 1000, 192, 320

@@ -99,6 +99,8 @@ def load():
     lib.vlb_wgrad_workspace_floats.argtypes = [_I, _I, _I]
     lib.vlb_layernorm_bwd_workspace_floats.restype = _L
     lib.vlb_layernorm_bwd_workspace_floats.argtypes = [_I]
+    lib.vlb_gemm_set_option.restype = _I
+    lib.vlb_gemm_set_option.argtypes = [ctypes.c_char_p, _I]
     for name, sig in _SIGS.items():
         fn = getattr(lib, name)
         fn.restype = _I
@@ -109,7 +111,13 @@ def load():
 
 def exported_names():
     return ["vlb_last_error", "vlb_version", "vlb_device_info", "vlb_wgrad_workspace_floats",
-            "vlb_layernorm_bwd_workspace_floats"] + sorted(_SIGS)
+            "vlb_layernorm_bwd_workspace_floats", "vlb_gemm_set_option"] + sorted(_SIGS)
+
+
+def gemm_set_option(name, value):
+    lib = load()
+    if lib.vlb_gemm_set_option(name.encode(), int(value)) != 0:
+        raise RuntimeError("vlb_gemm_set_option: %s" % lib.vlb_last_error().decode())
 
 
 def call(name, *args):

@@ -27,30 +27,8 @@
 
 #include "vlb_common.h"
 
-struct GemmParams {
-  const bf16_t* A; long lda;
-  const bf16_t* B; long ldb;
-  int M, N, K;
-  int k_per_split;           // K range handled by one blockIdx.y slice (multiple of 64)
-  const float* bias;         // [N] fp32 or null
-  int act;                   // 0 none, 1 gelu, 2 relu, 3 multiply by gelu'(aux), 4 gelu with gelu'(x) -> pre, 5 multiply by aux, 6 tanh
-  const bf16_t* aux; long ldaux;
-  bf16_t* pre; long ldpre;   // optional pre-activation output (act==1)
-  const bf16_t* res; long ldres;
-  uint32_t drop_thr; float drop_scale; const uint32_t* seed; uint32_t tag;
-  void* C; long ldc;
-  long c_split_stride;       // elements between the outputs of consecutive K splits (slab split-K), 0 otherwise
-  int out_f32;               // 0: bf16 store, 1: fp32 store, 2: fp32 atomicAdd
-  int ntm, ntn;
-  int tile_group;            // tile-rows per L2 group (see the kernel's tile order)
-  // implicit 3x3 convolution (CONV kernels): A = NHWC activation [rows = n*H*W, conv_C], K = 9*conv_C, K tile kt reads tap
-  // kt / (conv_C/64), channels (kt % (conv_C/64))*64.. of pixel (y + (tap/3-1)*dil, x + (tap%3-1)*dil); out-of-image taps read `zero`
-  int conv_C, conv_H, conv_W, conv_dil;
-  const bf16_t* zero;        // >= 16 B of zeros
-};
+#include "gemm_params.h"
 
-#define GLDS_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
-#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
 // Epilogue specialised at compile time on (activation, dropout, residual, output mode, interior tile) so each
 // variant is a straight-line body: interior tiles (the overwhelming majority) carry no bounds checks, row base
@@ -1151,6 +1129,12 @@ extern "C" int vlb_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb
   const int per = vlb_cdiv(ktiles, splits);
   splits = vlb_cdiv(ktiles, per);
   p.k_per_split = per * 64;
+  // large-tile 8-phase core (gemm_p8.hip): bf16 outputs with the fused epilogues of the training step, enough tiles to give
+  // every CU a 256-row tile
+  if (splits == 1 && out_mode == 0) {
+    const int took = vlb_gemm_p8_try(p, stream);
+    if (took != 0) return took < 0 ? took : VLB_OK;
+  }
   // 256x256 tiles (half the operand bytes per FLOP) for plain bf16 GEMMs whose B operand does not fit the L2s and that
   // have enough tiles for one workgroup per CU: the tied decoder X . E^T (B = 47 MB word embeddings; 1.00 -> 0.80 ms).
   // With an L2-resident weight matrix and K = 768 (QKV, FFN) the 128x128 kernel is as fast (measured) and keeps two

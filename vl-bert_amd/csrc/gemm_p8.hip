@@ -1,0 +1,516 @@
+// bf16 "NT" GEMM for gfx950 (CDNA4), large-tile core:  C[M,N] = epilogue(A[M,K] . B[N,K]^T)   (fp32 accumulate, bf16 out)
+//
+// The 128x128 kernels of gemm.hip stream 1/64 B of operands per FLOP through L2 -> LDS and park half their wave cycles on the
+// s_waitcnt / barrier that drains the LDS-DMA queue at every K tile (profiles/r01_gemm_pmc.txt: MFMA pipe 30 % busy).  This
+// kernel is the structure the CDNA4 guide measures at 1.3-1.5 PFLOP/s (cdna_hip_programming.md §5, "8-phase" schedule):
+//
+//   * ONE 8-wave workgroup per CU, 256 (or 320) x 256 output tile, BK = 64: 1/128 B of operands per FLOP.  Waves are 2 (M) x 4 (N);
+//     a wave owns rows {half h} x [wm*16*FMH, +16*FMH) and columns {half h} x [wn*32, +32) of BOTH tile halves, so an operand
+//     half-image (AH rows x 64 k, 128-B rows) is consumed by all waves in ONE phase and can be re-staged right after it.
+//   * LDS = two K-tile buffers of four half-images [A0 | A1 | B0 | B1] (2 x 64 KiB) + a 32 KiB epilogue staging slab.  Operands
+//     arrive by LDS-DMA (`buffer_load_dwordx4 ... lds`, one SRD per operand, k offset in an SGPR) ONE HALF-IMAGE PER PHASE, two
+//     K tiles ahead of their use, and are retired by a COUNTED `s_waitcnt vmcnt(4)` once per K tile -- the queue is never
+//     drained inside the stream, which runs across output tiles (persistent workgroups: the next tile's operands land under
+//     the epilogue of the current one).
+//   * A K tile is 4 phases = the 4 quadrants (A-half x B-half) of the wave tile, 16 MFMAs each, in the order (0,0) (0,1) (1,1)
+//     (1,0) so that a phase reads ONE new operand sub-tile.  Every phase is {LOAD: fragment reads + one half-image of DMA} |
+//     barrier | {COMPUTE: 16 x v_mfma_f32_16x16x32_bf16 under s_setprio 1} | barrier, and the wm = 1 waves run ONE segment
+//     behind the wm = 0 waves (they take one extra barrier at the start): on every SIMD one wave is in its MFMA segment
+//     while its partner reads LDS / issues DMA -- "matrix beside memory", enforced, not statistical.
+//   * Rules that make the counted waits sound (guide, "Read a staged buffer one phase AFTER the wait that retires it"):
+//     the vmcnt wait sits in the LOAD segment of phase 4, in front of that segment's barrier, and the buffer is first read in
+//     phase 1 of the next K tile (two barriers later for the lagging wave group); a half-image is re-staged no earlier than two
+//     phases after its last read.  Fragment reads are inline asm (a compiler-visible LDS read that may alias a pending LDS-DMA
+//     gets `s_waitcnt vmcnt(0)` from hipcc), released to the MFMAs by an explicit lgkmcnt(0) + sched_barrier.
+//   * Epilogue in TWO passes over LDS-staged fp32 (the single-pass fused epilogues of the 128-register kernels spilled): the
+//     raw accumulators go to the staging slab 32 rows at a time (ds_write_b128, XOR-swizzled), then every thread owns 8
+//     CONSECUTIVE columns of a row: bias / GELU (+ GELU' saved) / x aux / dropout (counter RNG) / + residual / ReLU run on
+//     whole 16-B groups with coalesced 16-B global accesses and one rounding to bf16.
+//   * Tile-count quantisation: a 256-row tile gives 303 tiles for N = 768 at M = 25856 (2 rounds of 256 CUs at 59 %); the
+//     FMH = 5 instantiation (320-row tiles, 160 accumulator registers) gives 243 (one round at 95 %).  The launcher picks the
+//     tile height from a cost model over {256, 320}.
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <type_traits>
+
+#include "gemm_params.h"
+
+namespace {
+
+template <int OFF>
+__device__ __forceinline__ void p8_lds_read(bf16x8& dst, uint32_t vaddr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(vaddr), "n"(OFF));
+}
+
+template <int OFF>
+__device__ __forceinline__ void p8_lds_write_f4(uint32_t vaddr, const f32x4& v) {
+  asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(vaddr), "v"(v), "n"(OFF) : "memory");
+}
+
+template <int OFF>   // two 16-B reads of the staging slab (8 consecutive fp32 of one row), waited for in the same statement
+__device__ __forceinline__ void p8_stage_read(f32x4& x0, f32x4& x1, uint32_t a0, uint32_t a1) {
+  asm volatile("ds_read_b128 %0, %2 offset:%4\n\tds_read_b128 %1, %3 offset:%4\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(x0), "=&v"(x1) : "v"(a0), "v"(a1), "n"(OFF) : "memory");
+}
+
+__device__ __forceinline__ void p8_barrier() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// 8 consecutive output columns of one row: the whole fused epilogue on fp32 values, one rounding to bf16.
+// EPI: 0 bias | 1 bias + GELU, GELU'(x) -> pre | 2 x aux | 3 bias + dropout + residual | 4 bias + residual | 5 bias + ReLU
+template <int EPI>
+__device__ __forceinline__ void p8_epilogue8(const GemmParams& p, float (&v)[8], int m, int n, uint32_t seed, const uint4& side) {
+  if (p.bias) {
+    const float4 b0 = *(const float4*)(p.bias + n), b1 = *(const float4*)(p.bias + n + 4);
+    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+    v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+  }
+  if (EPI == 1) {
+    float d[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float g;
+      gelu_both(v[e], g, d[e]);
+      v[e] = g;
+    }
+    if (p.pre)
+      *(uint4*)(p.pre + (long)m * p.ldpre + n) = make_uint4(pack2bf(d[0], d[1]), pack2bf(d[2], d[3]), pack2bf(d[4], d[5]), pack2bf(d[6], d[7]));
+  } else if (EPI == 2) {
+    v[0] *= bflo(side.x); v[1] *= bfhi(side.x); v[2] *= bflo(side.y); v[3] *= bfhi(side.y);
+    v[4] *= bflo(side.z); v[5] *= bfhi(side.z); v[6] *= bflo(side.w); v[7] *= bfhi(side.w);
+  } else if (EPI == 5) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+  }
+  if (EPI == 3) {
+    const uint32_t idx = (uint32_t)m * (uint32_t)p.N + (uint32_t)n;
+    if ((idx & 1u) == 0) {   // element pairs share one 32-bit hash (vlb_common.h)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t h = vlb_rng_pair(seed, p.tag, (idx >> 1) + q);
+        v[2 * q] = ((h & 0xffffu) >= p.drop_thr) ? v[2 * q] * p.drop_scale : 0.f;
+        v[2 * q + 1] = ((h >> 16) >= p.drop_thr) ? v[2 * q + 1] * p.drop_scale : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = vlb_keep(seed, p.tag, idx + e, p.drop_thr) ? v[e] * p.drop_scale : 0.f;
+    }
+  }
+  if (EPI == 3 || EPI == 4) {
+    v[0] += bflo(side.x); v[1] += bfhi(side.x); v[2] += bflo(side.y); v[3] += bfhi(side.y);
+    v[4] += bflo(side.z); v[5] += bfhi(side.z); v[6] += bflo(side.w); v[7] += bfhi(side.w);
+  }
+}
+
+// scalar tail of the same (last, partial 8-column group of a row when N % 8 != 0)
+template <int EPI>
+__device__ __forceinline__ float p8_epilogue1(const GemmParams& p, float v, int m, int n, uint32_t seed) {
+  if (p.bias) v += p.bias[n];
+  if (EPI == 1) {
+    float g, d;
+    gelu_both(v, g, d);
+    if (p.pre) p.pre[(long)m * p.ldpre + n] = f2bf(d);
+    v = g;
+  } else if (EPI == 2) {
+    v *= bf2f(p.aux[(long)m * p.ldaux + n]);
+  } else if (EPI == 5) {
+    v = fmaxf(v, 0.f);
+  }
+  if (EPI == 3) v = vlb_keep(seed, p.tag, (uint32_t)m * (uint32_t)p.N + (uint32_t)n, p.drop_thr) ? v * p.drop_scale : 0.f;
+  if (EPI == 3 || EPI == 4) v += bf2f(p.res[(long)m * p.ldres + n]);
+  return v;
+}
+
+// FMH: 16-row accumulator fragments per wave per tile half (4 -> 256-row tiles, 5 -> 320-row tiles)
+// KEEPB: keep the B0 fragments in registers for the 4th quadrant (16 more VGPRs) instead of re-reading them
+template <int FMH, int EPI, bool KEEPB>
+__global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(const GemmParams p) {
+  constexpr int AH = 32 * FMH;                 // rows of an A half-image (2 wave rows x FMH fragments x 16)
+  constexpr int BM = 2 * AH, BN = 256;
+  constexpr int AHB = AH * 128, BHB = 128 * 128;
+  constexpr int OFF_A0 = 0, OFF_A1 = AHB, OFF_B0 = 2 * AHB, OFF_B1 = 2 * AHB + BHB;
+  constexpr int BUF = 2 * AHB + 2 * BHB;       // one K tile: 64 KiB (FMH 4) / 72 KiB (FMH 5)
+  constexpr int STG = 2 * BUF;                 // epilogue staging slab
+  constexpr int SR = (163840 - STG) / 1024;    // its rows of 256 fp32: 32 / 16
+  constexpr int NLA = (AH * 8 + 511) / 512;    // LDS-DMA instructions per thread per A half-image: 2 / 3 (third: waves 0-3)
+  static_assert(SR == 32 || SR == 16, "staging slab");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int nt = p.ntm * p.ntn;
+  const int nk = p.K >> 6;                      // K tiles per output tile (even: K % 128 == 0)
+  if ((int)blockIdx.x >= nt) return;
+
+  auto tile_of = [&](int w, int& m0, int& n0) {   // XCD-aware grouped order (see gemm_nt_bf16_kernel)
+    const int xcd = w & 7, q = nt >> 3, r = nt & 7;
+    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (w >> 3);
+    const int gm = p.tile_group, per_group = gm * p.ntn, gid = t / per_group, first = gid * gm;
+    const int gsz = min(p.ntm - first, gm), rem = t - gid * per_group;
+    m0 = (first + rem % gsz) * BM;
+    n0 = (rem / gsz) * BN;
+  };
+
+  // ---------------- producer: a continuous stream of K tiles over this workgroup's work items ----------------
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7FFFFFFF, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, 0x7FFFFFFF, 0x00020000);
+  // This thread's 16-B chunk P = it*512 + tid of a half-image lies in row (P >> 3) = it*64 + (tid >> 3), physical slot P & 7, which
+  // holds k-chunk kc = (P & 7) ^ ((row >> 1) & 7) -- independent of `it`.  Byte offset inside the operand = (tile row origin + half
+  // + it*64) * ld (wave-uniform, SALU) + rowX (per thread), clamped to the chunk of the operand's last row (edge tiles re-read
+  // that row; the rows / columns it feeds are masked by the epilogue).  No per-tile VGPR state.
+  const int ldaB = (int)p.lda * 2, ldbB = (int)p.ldb * 2;
+  const int kcb = (((tid & 7) ^ ((tid >> 4) & 7)) << 4);
+  const int rowA = (tid >> 3) * ldaB + kcb, maxA = (p.M - 1) * ldaB + kcb;
+  const int rowB = (tid >> 3) * ldbB + kcb, maxB = (p.N - 1) * ldbB + kcb;
+  int w_p = blockIdx.x, kt_p = 0, tiles_issued = 0, pm0 = 0, pn0 = 0;
+  bool live = true;
+  auto setup = [&](int w) { tile_of(w, pm0, pn0); };
+  // half-image WHICH (0 A0 | 1 A1 | 2 B0 | 3 B1) of the producer's current K tile -> buffer `buf`
+  auto stage = [&](auto which_c, auto buf_c) {
+    constexpr int WHICH = decltype(which_c)::value, B_ = decltype(buf_c)::value;
+    if (!live) return;
+    const int koff = kt_p * 128;
+    if constexpr (WHICH < 2) {
+      char* dst = smem + B_ * BUF + (WHICH == 0 ? OFF_A0 : OFF_A1);
+#pragma unroll
+      for (int it = 0; it < NLA; ++it) {
+        if (it * 512 + 511 < AH * 8 || wave < (AH * 8 - it * 512) / 64) {
+          const int vo = min((pm0 + WHICH * AH + it * 64) * ldaB + rowA, maxA);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(dst + (it * 512 + wave * 64) * 16), 16, vo, koff, 0, 0);
+        }
+      }
+    } else {
+      char* dst = smem + B_ * BUF + (WHICH == 2 ? OFF_B0 : OFF_B1);
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int vo = min((pn0 + (WHICH - 2) * 128 + it * 64) * ldbB + rowB, maxB);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(dst + (it * 512 + wave * 64) * 16), 16, vo, koff, 0, 0);
+      }
+    }
+  };
+  auto advance = [&]() {     // the producer moves on to the next K tile (called in front of its first half-image)
+    if (!live) return;
+    if (++kt_p == nk) {
+      kt_p = 0;
+      w_p += gridDim.x;
+      if (w_p < nt) setup(w_p);
+      else live = false;
+    }
+    if (live) ++tiles_issued;
+  };
+  // staging order of the four half-images of a K tile: the first is always A0 (read first, free first)
+  constexpr int ORD1 = KEEPB ? 2 : 3, ORD2 = KEEPB ? 3 : 1, ORD3 = KEEPB ? 1 : 2;   // KEEPB: A0 B0 B1 A1 | else: A0 B1 A1 B0
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using W0 = std::integral_constant<int, 0>;
+  using W1 = std::integral_constant<int, ORD1>;
+  using W2 = std::integral_constant<int, ORD2>;
+  using W3 = std::integral_constant<int, ORD3>;
+
+  // ---------------- consumer state ----------------
+  f32x4 acc[2 * FMH][4];           // [tile half x fragment row][B half x fragment column]
+  bf16x8 af[FMH][2], bfr[2][2], bkeep[2][2];
+  const int frow = lane & 15;
+  const uint32_t c0 = (uint32_t)((((lane >> 4) ^ (frow >> 1)) << 4));
+  const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(smem);
+  const uint32_t a_rd = lds0 + (uint32_t)((wm * FMH * 16 + frow) * 128) + c0;       // + buf*BUF + half*AHB + i*2048, ^64 for k-step 1
+  const uint32_t b_rd = lds0 + (uint32_t)(OFF_B0 + (wn * 32 + frow) * 128) + c0;    // + buf*BUF + half*BHB + j*2048
+
+  auto read_a = [&](auto buf_c, auto half_c) {
+    constexpr int B_ = decltype(buf_c)::value, H_ = decltype(half_c)::value;
+    const uint32_t v0 = a_rd + B_ * BUF, v1 = v0 ^ 64u;
+    constexpr int O = H_ * AHB;
+    p8_lds_read<O + 0 * 2048>(af[0][0], v0); p8_lds_read<O + 0 * 2048>(af[0][1], v1);
+    p8_lds_read<O + 1 * 2048>(af[1][0], v0); p8_lds_read<O + 1 * 2048>(af[1][1], v1);
+    p8_lds_read<O + 2 * 2048>(af[2][0], v0); p8_lds_read<O + 2 * 2048>(af[2][1], v1);
+    p8_lds_read<O + 3 * 2048>(af[3][0], v0); p8_lds_read<O + 3 * 2048>(af[3][1], v1);
+    if constexpr (FMH == 5) {
+      p8_lds_read<O + 4 * 2048>(af[4][0], v0); p8_lds_read<O + 4 * 2048>(af[4][1], v1);
+    }
+  };
+  auto read_b = [&](auto buf_c, auto half_c, bf16x8 (&dst)[2][2]) {
+    constexpr int B_ = decltype(buf_c)::value, H_ = decltype(half_c)::value;
+    const uint32_t v0 = b_rd + B_ * BUF, v1 = v0 ^ 64u;
+    constexpr int O = H_ * BHB;
+    p8_lds_read<O>(dst[0][0], v0); p8_lds_read<O>(dst[0][1], v1);
+    p8_lds_read<O + 2048>(dst[1][0], v0); p8_lds_read<O + 2048>(dst[1][1], v1);
+  };
+  // release the fragments of this phase to the MFMAs (every asm read above is retired), then the quadrant's 16 (20) MFMAs
+  auto compute = [&](auto ha_c, auto hb_c, bf16x8 (&bq)[2][2]) {
+    constexpr int HA = decltype(ha_c)::value, HB = decltype(hb_c)::value;
+    if constexpr (FMH == 4) {
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[1][0]), "+v"(af[1][1]), "+v"(af[2][0]), "+v"(af[2][1]), "+v"(af[3][0]),
+                     "+v"(af[3][1]), "+v"(bq[0][0]), "+v"(bq[0][1]), "+v"(bq[1][0]), "+v"(bq[1][1]));
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[1][0]), "+v"(af[1][1]), "+v"(af[2][0]), "+v"(af[2][1]), "+v"(af[3][0]),
+                     "+v"(af[3][1]), "+v"(af[4][0]), "+v"(af[4][1]), "+v"(bq[0][0]), "+v"(bq[0][1]), "+v"(bq[1][0]), "+v"(bq[1][1]));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < FMH; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[HA * FMH + i][HB * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[j][ks], af[i][ks], acc[HA * FMH + i][HB * 2 + j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // ---------------- prologue: K tile 0 complete, the first two half-images of K tile 1 in flight ----------------
+  setup(w_p);
+  tiles_issued = 1;
+  stage(W0{}, I0{}); stage(W1{}, I0{}); stage(W2{}, I0{}); stage(W3{}, I0{});
+  advance();
+  stage(W0{}, I1{}); stage(W1{}, I1{});
+  if (live) __builtin_amdgcn_s_waitcnt(0x0F70 | 4);
+  else __builtin_amdgcn_s_waitcnt(0x0F70);
+  p8_barrier();
+  if (wm == 1) p8_barrier();       // the wm = 1 waves run one segment behind
+
+  int g = 0;                       // K tiles consumed by this workgroup so far
+  const uint32_t seed = (EPI == 3) ? *p.seed : 0u;
+  for (int w = blockIdx.x; w < nt; w += gridDim.x) {
+#pragma unroll
+    for (int i = 0; i < 2 * FMH; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int kt = 0; kt < nk; kt += 2, g += 2) {
+      // ======== K tile g (buffer 0) ========
+      // phase 1: A0 + B0 -> quadrant (0,0)
+      if constexpr (KEEPB) read_b(I0{}, I0{}, bkeep); else read_b(I0{}, I0{}, bfr);
+      __builtin_amdgcn_sched_barrier(0);
+      read_a(I0{}, I0{});
+      stage(W2{}, I1{});
+      p8_barrier();
+      if constexpr (KEEPB) compute(I0{}, I0{}, bkeep); else compute(I0{}, I0{}, bfr);
+      p8_barrier();
+      // phase 2: B1 -> (0,1)
+      read_b(I0{}, I1{}, bfr);
+      stage(W3{}, I1{});
+      p8_barrier();
+      compute(I0{}, I1{}, bfr);
+      p8_barrier();
+      // phase 3: A1 -> (1,1)
+      read_a(I0{}, I1{});
+      advance();
+      stage(W0{}, I0{});
+      p8_barrier();
+      compute(I1{}, I1{}, bfr);
+      p8_barrier();
+      // phase 4: (B0 again) -> (1,0); K tile g+1 retired
+      if constexpr (!KEEPB) read_b(I0{}, I0{}, bfr);
+      stage(W1{}, I0{});
+      if (tiles_issued >= g + 3) __builtin_amdgcn_s_waitcnt(0x0F70 | 4);
+      else __builtin_amdgcn_s_waitcnt(0x0F70);
+      p8_barrier();
+      if constexpr (KEEPB) compute(I1{}, I0{}, bkeep); else compute(I1{}, I0{}, bfr);
+      p8_barrier();
+      // ======== K tile g+1 (buffer 1) ========
+      if constexpr (KEEPB) read_b(I1{}, I0{}, bkeep); else read_b(I1{}, I0{}, bfr);
+      __builtin_amdgcn_sched_barrier(0);
+      read_a(I1{}, I0{});
+      stage(W2{}, I0{});
+      p8_barrier();
+      if constexpr (KEEPB) compute(I0{}, I0{}, bkeep); else compute(I0{}, I0{}, bfr);
+      p8_barrier();
+      read_b(I1{}, I1{}, bfr);
+      stage(W3{}, I0{});
+      p8_barrier();
+      compute(I0{}, I1{}, bfr);
+      p8_barrier();
+      read_a(I1{}, I1{});
+      advance();
+      stage(W0{}, I1{});
+      p8_barrier();
+      compute(I1{}, I1{}, bfr);
+      p8_barrier();
+      if constexpr (!KEEPB) read_b(I1{}, I0{}, bfr);
+      stage(W1{}, I1{});
+      if (tiles_issued >= g + 4) __builtin_amdgcn_s_waitcnt(0x0F70 | 4);
+      else __builtin_amdgcn_s_waitcnt(0x0F70);
+      p8_barrier();
+      if constexpr (KEEPB) compute(I1{}, I0{}, bkeep); else compute(I1{}, I0{}, bfr);
+      p8_barrier();
+    }
+    if (wm == 0) p8_barrier();     // let the lagging wave group finish its last quadrant: the epilogue runs aligned
+
+    // ---------------- epilogue: raw fp32 accumulators -> staging slab -> fused math on 8-column groups -> bf16 ----------------
+    int m0, n0;
+    tile_of(w, m0, n0);
+    {
+      constexpr int ROUNDS = (SR == 32) ? 2 * FMH : 4 * FMH;
+      const uint32_t stg = lds0 + STG;
+      // write side: this lane's row inside the slab and its 16-B chunk (4 fp32) per fragment column
+      const int wrow = (SR == 32 ? wm * 16 : 0) + frow;
+      const uint32_t wr_base = stg + (uint32_t)(wrow * 1024);
+      uint32_t wr_off[4];
+#pragma unroll
+      for (int cj = 0; cj < 4; ++cj) {
+        const int c = (cj >> 1) * 32 + wn * 8 + (cj & 1) * 4 + (lane >> 4);
+        wr_off[cj] = wr_base + (uint32_t)(((c ^ (wrow & 7)) << 4));
+      }
+      // read side: thread -> (row rho, 8-column group q); SR = 32: two rows per thread (rho, rho + 16)
+      const int q = tid & 31, rho = tid >> 5;
+      const uint32_t rd0 = stg + (uint32_t)(rho * 1024 + (((2 * q) ^ (rho & 7)) << 4));
+      const uint32_t rd1 = stg + (uint32_t)(rho * 1024 + (((2 * q + 1) ^ (rho & 7)) << 4));
+      const int n = n0 + q * 8;
+      bf16_t* const C = (bf16_t*)p.C;
+#pragma unroll      // (fully unrolled: R becomes a compile-time index into the accumulator registers, the ladder below folds away)
+      for (int r = 0; r < ROUNDS; ++r) {
+        // which accumulator row fragment this round drains, and the tile rows the slab then holds
+        const int R = (SR == 32) ? r : (r >> 1);                  // SR = 16: wave rows alternate (wm = r & 1 writes)
+        const int ha = R / FMH, i = R - ha * FMH;
+        if (SR == 32 || wm == (r & 1)) {
+          // acc[R][*] with a run-time R: walk the fragments with a uniform branch ladder (register arrays need static indices)
+#pragma unroll
+          for (int RR = 0; RR < 2 * FMH; ++RR) {
+            if (RR == R) {
+              p8_lds_write_f4<0>(wr_off[0], acc[RR][0]);
+              p8_lds_write_f4<0>(wr_off[1], acc[RR][1]);
+              p8_lds_write_f4<0>(wr_off[2], acc[RR][2]);
+              p8_lds_write_f4<0>(wr_off[3], acc[RR][3]);
+            }
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        p8_barrier();
+        // row of the tile held by slab row rho (+16): SR = 32: rows 0-15 from the wm = 0 waves, 16-31 from wm = 1
+#pragma unroll
+        for (int pass = 0; pass < SR / 16; ++pass) {
+          const int grp = (SR == 32) ? pass : (r & 1);
+          const int m = m0 + ha * AH + grp * FMH * 16 + i * 16 + rho;
+          f32x4 x0, x1;
+          if (pass == 0) p8_stage_read<0>(x0, x1, rd0, rd1);
+          else p8_stage_read<16 * 1024>(x0, x1, rd0, rd1);     // second half of the slab: +16 rows (same swizzle term rho & 7)
+          if (m < p.M && n < p.N) {
+            float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+            if (n + 8 <= p.N) {
+              uint4 side = make_uint4(0, 0, 0, 0);
+              if (EPI == 2) side = *(const uint4*)(p.aux + (long)m * p.ldaux + n);
+              if (EPI == 3 || EPI == 4) side = *(const uint4*)(p.res + (long)m * p.ldres + n);
+              p8_epilogue8<EPI>(p, v, m, n, seed, side);
+              *(uint4*)(C + (long)m * p.ldc + n) = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+            } else {
+              for (int e = 0; e < 8 && n + e < p.N; ++e) C[(long)m * p.ldc + n + e] = f2bf(p8_epilogue1<EPI>(p, v[e], m, n + e, seed));
+            }
+          }
+        }
+        p8_barrier();              // the slab is free for the next round
+      }
+    }
+    // one full drain per output tile (stores and LDS-DMA share vmcnt and may retire out of order with respect to each other:
+    // counted waits are only sound on a queue of loads); the K tiles prefetched for the next output tile had the whole epilogue
+    // to land, so this waits for the last stores only
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    p8_barrier();
+    if (wm == 1 && w + (int)gridDim.x < nt) p8_barrier();   // re-establish the one-segment lag for the next output tile
+  }
+}
+
+template <int FMH, int EPI, bool KEEPB>
+int p8_launch(GemmParams& p, int group, hipStream_t stream) {
+  constexpr int smem = 163840;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_p8_kernel<FMH, EPI, KEEPB>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) {
+      vlb_set_error("gemm_p8: cannot reserve %d bytes of LDS: %s", smem, hipGetErrorString(e));
+      return VLB_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  p.ntm = vlb_cdiv(p.M, 64 * FMH);
+  p.ntn = vlb_cdiv(p.N, 256);
+  p.tile_group = group;
+  int gx = p.ntm * p.ntn;
+  if (gx > 256) gx = 256;          // one persistent workgroup per CU (a multiple of 8: work item w and block b share an XCD)
+  hipLaunchKernelGGL((gemm_nt_p8_kernel<FMH, EPI, KEEPB>), dim3(gx), dim3(512), smem, stream, p);
+  VLB_CHECK_LAUNCH("vlb_gemm_nt_bf16(p8)");
+  return 1;
+}
+
+template <int FMH, bool KEEPB>
+int p8_launch_epi(GemmParams& p, int epi, int group, hipStream_t stream) {
+  switch (epi) {
+    case 0: return p8_launch<FMH, 0, KEEPB>(p, group, stream);
+    case 1: return p8_launch<FMH, 1, KEEPB>(p, group, stream);
+    case 2: return p8_launch<FMH, 2, KEEPB>(p, group, stream);
+    case 3: return p8_launch<FMH, 3, KEEPB>(p, group, stream);
+    case 4: return p8_launch<FMH, 4, KEEPB>(p, group, stream);
+    default: return p8_launch<FMH, 5, KEEPB>(p, group, stream);
+  }
+}
+
+int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+
+inline bool aligned16(const void* q) { return ((uintptr_t)q & 15) == 0; }
+
+}  // namespace
+
+// tuning knobs (environment defaults, run-time override through vlb_gemm_set_option for A/B measurements inside one process)
+// p8_mode: 0 off | 1 cost model (default) | 4 / 5: force the 256- / 320-row tile wherever the kernel applies
+static int g_opt[4] = {-1, -1, -1, -1};
+static const char* const g_opt_name[4] = {"p8_mode", "p8_keepb", "p8_group", "p8_min_tiles"};
+static void p8_options_init() {
+  if (g_opt[0] >= 0) return;
+  g_opt[0] = env_int("VLB_GEMM_P8", 1);
+  g_opt[1] = env_int("VLB_GEMM_P8_KEEPB", 1);
+  g_opt[2] = env_int("VLB_GEMM_P8_GROUP", 2);
+  g_opt[3] = env_int("VLB_GEMM_P8_MIN_TILES", 160);
+}
+
+extern "C" int vlb_gemm_set_option(const char* name, int value) {
+  p8_options_init();
+  VLB_CHECK_ARG(name && value >= 0, "vlb_gemm_set_option: null name / negative value");
+  for (int i = 0; i < 4; ++i)
+    if (!strcmp(name, g_opt_name[i])) {
+      g_opt[i] = value;
+      return VLB_OK;
+    }
+  vlb_set_error("vlb_gemm_set_option: unknown option %s", name);
+  return VLB_ERR_ARG;
+}
+
+int vlb_gemm_p8_try(GemmParams& p, hipStream_t stream) {
+  p8_options_init();
+  const int mode = g_opt[0], keepb = g_opt[1], group = g_opt[2], min_tiles = g_opt[3];
+  if (!mode || p.out_f32 != 0 || p.c_split_stride != 0) return 0;
+  if ((p.K % 128) != 0 || p.k_per_split < p.K) return 0;
+  int epi;
+  if (p.act == 0) epi = p.res ? (p.drop_thr ? 3 : 4) : (p.drop_thr ? -1 : 0);
+  else if (p.act == 4) epi = 1;
+  else if (p.act == 5) epi = 2;
+  else if (p.act == 2) epi = 5;
+  else epi = -1;
+  if (epi < 0) return 0;
+  // 16-B vector accesses on every side tensor; 31-bit byte offsets inside A and B
+  if ((p.ldc % 8) || !aligned16(p.C) || (p.lda % 8) || (p.ldb % 8) || !aligned16(p.A) || !aligned16(p.B)) return 0;
+  if (p.res && ((p.ldres % 8) || !aligned16(p.res))) return 0;
+  if (epi == 2 && ((p.ldaux % 8) || !aligned16(p.aux))) return 0;
+  if (epi == 1 && p.pre && ((p.ldpre % 8) || !aligned16(p.pre))) return 0;
+  if (p.bias && ((uintptr_t)p.bias & 15)) return 0;
+  if ((long)p.M * p.lda * 2 >= (1L << 31) || (long)p.N * p.ldb * 2 >= (1L << 31)) return 0;
+  // tile height: whole rounds of 256 resident workgroups, time per round ~ tile area
+  const long t4 = (long)vlb_cdiv(p.M, 256) * vlb_cdiv(p.N, 256), t5 = (long)vlb_cdiv(p.M, 320) * vlb_cdiv(p.N, 256);
+  if (t4 < min_tiles) return 0;    // too few tiles for one workgroup per CU: the 128x128 kernel fills the chip better
+  const double c4 = (double)((t4 + 255) / 256) * 256.0, c5 = (double)((t5 + 255) / 256) * 320.0;
+  int fmh = (c5 < 0.97 * c4) ? 5 : 4;
+  if (mode == 4 || mode == 5) fmh = mode;
+  const int g = group < 1 ? 1 : group;
+  if (fmh == 5) return p8_launch_epi<5, false>(p, epi, g, stream);
+  return keepb ? p8_launch_epi<4, true>(p, epi, g, stream) : p8_launch_epi<4, false>(p, epi, g, stream);
+}

@@ -1,0 +1,32 @@
+// Parameter block shared by the GEMM kernels of libvlbert_hip.so (gemm.hip, gemm_p8.hip).
+#pragma once
+#include "vlb_common.h"
+
+struct GemmParams {
+  const bf16_t* A; long lda;
+  const bf16_t* B; long ldb;
+  int M, N, K;
+  int k_per_split;           // K range handled by one blockIdx.y slice (multiple of 64)
+  const float* bias;         // [N] fp32 or null
+  int act;                   // 0 none, 1 gelu, 2 relu, 3 multiply by gelu'(aux), 4 gelu with gelu'(x) -> pre, 5 multiply by aux, 6 tanh
+  const bf16_t* aux; long ldaux;
+  bf16_t* pre; long ldpre;   // optional pre-activation output (act==1)
+  const bf16_t* res; long ldres;
+  uint32_t drop_thr; float drop_scale; const uint32_t* seed; uint32_t tag;
+  void* C; long ldc;
+  long c_split_stride;       // elements between the outputs of consecutive K splits (slab split-K), 0 otherwise
+  int out_f32;               // 0: bf16 store, 1: fp32 store, 2: fp32 atomicAdd
+  int ntm, ntn;
+  int tile_group;            // tile-rows per L2 group (see the kernel's tile order)
+  // implicit 3x3 convolution (CONV kernels): A = NHWC activation [rows = n*H*W, conv_C], K = 9*conv_C, K tile kt reads tap
+  // kt / (conv_C/64), channels (kt % (conv_C/64))*64.. of pixel (y + (tap/3-1)*dil, x + (tap%3-1)*dil); out-of-image taps read `zero`
+  int conv_C, conv_H, conv_W, conv_dil;
+  const bf16_t* zero;        // >= 16 B of zeros
+};
+
+#define GLDS_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+// gemm_p8.hip: 256x256 / 320x256 tiles, 8-phase schedule.  Returns 1 when it took the call, 0 when the shape / epilogue /
+// alignment is outside what it covers (the caller then uses the 128x128 kernel), < 0 on error.
+int vlb_gemm_p8_try(GemmParams& p, hipStream_t stream);
