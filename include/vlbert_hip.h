@@ -55,6 +55,16 @@ int vlb_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb, void* C, 
                      const float* bias, int act, const void* aux, long ldaux, void* pre, long ldpre,
                      const void* res, long ldres, float drop_p, const uint32_t* seed, uint32_t tag,
                      int out_mode, int splitk, vlb_stream_t stream);
+/* vlb_gemm_nt_bf16 with (a) the "LayerNorm residual": res = the fp16 PRE-LayerNorm rows of the sublayer whose output is the
+ * residual, res_stats = [M][2] fp32 (mean, rstd) of that LayerNorm, res_gamma / res_beta = its parameters; the term added is
+ * (res - mean) * rstd * gamma + beta evaluated in fp32 (needs act 0, out_mode 0); (b) out_f16 != 0: the 16-bit result is stored as
+ * IEEE fp16.  With both, BertSelfOutput / BertOutput (modeling.py:329-333,374-378) keep their residual stream out of bf16. */
+int vlb_gemm_nt_bf16_ex(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
+                        const float* bias, int act, const void* aux, long ldaux, void* pre, long ldpre,
+                        const void* res, long ldres, const float* res_stats, const float* res_gamma, const float* res_beta,
+                        int out_f16, float drop_p, const uint32_t* seed, uint32_t tag, int out_mode, int splitk,
+                        vlb_stream_t stream);
+
 
 /* bf16 C[M,N] = A[M,K] B[N,K]^T, no epilogue, for few output tiles and a very long K (tied-decoder dgrad at small batch):
  * slab split-K through `workspace` (vlb_wgrad_workspace_floats(M, N, K) floats) + a reduce that converts to bf16. */
@@ -93,14 +103,15 @@ int vlb_transpose_batched_bf16(const int64_t* desc, const int32_t* tile_start, i
  * bwd: dx (bf16), dx_drop = dropout-masked dx (bf16, gradient entering the preceding dense layer),
  *      dx_acc (fp32 atomicAdd) -- any may be NULL; dgamma/dbeta are accumulated.
  *      dy is bf16, or fp32 when dy_f32 != 0; H % 8 == 0, row strides % 8 == 0.
+ *      x_f16 != 0: the rows of x are IEEE fp16 (the pre-LayerNorm sums written by vlb_gemm_nt_bf16_ex(out_f16)), else bf16.
  *      workspace: NULL (dgamma/dbeta by direct fp32 atomics) or vlb_layernorm_bwd_workspace_floats(H) floats of
  *      scratch (per-workgroup partial sums stored without atomics, column-summed by a 2nd kernel). */
 int vlb_layernorm_fwd(const void* x, long ldx, const float* gamma, const float* beta, void* y, long ldy, float* stats,
-                      int rows, int H, float eps, vlb_stream_t stream);
+                      int rows, int H, float eps, int x_f16, vlb_stream_t stream);
 int vlb_layernorm_bwd(const void* dy, long lddy, int dy_f32, const void* x, long ldx, const float* stats,
                       const float* gamma, void* dx, long lddx, void* dx_drop, long lddd, float drop_p,
                       const uint32_t* seed, uint32_t tag, float* dx_acc, long ldacc, float* dgamma, float* dbeta,
-                      float* workspace, int rows, int H, vlb_stream_t stream);
+                      float* workspace, int rows, int H, int x_f16, vlb_stream_t stream);
 long vlb_layernorm_bwd_workspace_floats(int H);
 
 /* ---- BertSelfAttention core (modeling.py:300-316) --------------------------------------------

@@ -200,6 +200,70 @@ def test_gemm_large_tile_core_epilogues(ops, force_p8, tile, M, N, K):
     assert bool((Cf[:, N:] == 3.0).all())
 
 
+@pytest.mark.parametrize("core", ["128x128", "p8-256", "p8-320"])
+def test_gemm_layernorm_residual_fp16_stream(ops, force_p8, core):
+    """vlb_gemm_nt_bf16_ex: residual = LayerNorm output re-materialised in fp32 from fp16 pre-LN rows + (mean, rstd) + gamma / beta,
+    result stored as fp16 (the encoder's residual stream, BertSelfOutput / BertOutput); with and without dropout; and the LayerNorm
+    kernels reading fp16 rows.  Reference: fp32 torch on the same (fp16 / bf16 rounded) inputs."""
+    lib = force_p8
+    lib.gemm_set_option("p8_mode", {"128x128": 0, "p8-256": 4, "p8-320": 5}[core])
+    M, N, K = 1300, 776, 256
+    A, B = rnd(M, K, seed=14), rnd(N, K, seed=15, scale=0.08)
+    bias = 0.3 * torch.randn(N, generator=torch.Generator().manual_seed(16))
+    gam = 1.0 + 0.2 * torch.randn(N, generator=torch.Generator().manual_seed(17))
+    bet = 0.1 * torch.randn(N, generator=torch.Generator().manual_seed(18))
+    zprev = (torch.randn(M, N, generator=torch.Generator().manual_seed(19)) * 2.0 + 0.3).half().float()
+    mean = zprev.mean(1, keepdim=True)
+    rstd = 1.0 / torch.sqrt(zprev.var(1, unbiased=False, keepdim=True) + 1e-12)
+    ln_out = (zprev - mean) * rstd * gam + bet
+    u = A @ B.t() + bias
+    ldc = (N + 63) // 64 * 64
+    zg = torch.zeros((M, ldc), dtype=torch.float16, device=dev())[:, :N]
+    zg.copy_(zprev.to(dev()))
+    st = torch.cat((mean, rstd), 1).contiguous().to(dev())
+    Cf = torch.full((M, ldc), 3.0, dtype=torch.float16, device=dev())
+    C = Cf[:, :N]
+    Ag, Bg = to_gpu_bf16(A), to_gpu_bf16(B)
+    ops.gemm_nt(Ag, Bg, C, bias=bias.to(dev()), res=zg, res_ln=(st, gam.to(dev()), bet.to(dev())))
+    ref = u + ln_out
+    report("gemm LN-residual -> fp16 (%s)" % core, C, ref, 2e-3, 2e-3)          # fp16 output: 2^-11 relative
+    assert bool((Cf[:, N:] == 3.0).all())
+    p, seed_v, tg = 0.1, 777, 5
+    seed = torch.tensor([seed_v], dtype=torch.int32, device=dev())
+    ops.gemm_nt(Ag, Bg, C, bias=bias.to(dev()), res=zg, res_ln=(st, gam.to(dev()), bet.to(dev())), drop_p=p, seed=seed, tag=tg)
+    thr = drop_thr(p)
+    idx = (np.arange(M, dtype=np.int64)[:, None] * N + np.arange(N, dtype=np.int64)[None, :])
+    keep = torch.from_numpy(keep_mask(seed_v, tg, idx.reshape(-1), thr).reshape(M, N))
+    report("gemm dropout + LN-residual -> fp16 (%s)" % core, C, torch.where(keep, u * drop_scale(thr), torch.zeros_like(u)) + ln_out, 2e-3, 2e-3)
+    # plain bf16 residual, fp16 output (encoder layer 0)
+    resb = rnd(M, N, seed=20)
+    rg = torch.zeros((M, ldc), dtype=torch.bfloat16, device=dev())[:, :N]
+    rg.copy_(resb.to(dev()))
+    ops.gemm_nt(Ag, Bg, C, bias=bias.to(dev()), res=rg)
+    report("gemm bf16 residual -> fp16 (%s)" % core, C, u + resb, 2e-3, 2e-3)
+    # LayerNorm forward / backward on fp16 rows
+    H = 768
+    rows = 257
+    x = (torch.randn(rows, H, generator=torch.Generator().manual_seed(21)) * 1.7 - 0.2).half().float()
+    g2 = 1.0 + 0.1 * torch.randn(H, generator=torch.Generator().manual_seed(22))
+    b2 = 0.1 * torch.randn(H, generator=torch.Generator().manual_seed(23))
+    dy = rnd(rows, H, seed=24)
+    xr = x.clone().requires_grad_(True)
+    mu = xr.mean(1, keepdim=True)
+    yref = (xr - mu) / torch.sqrt(((xr - mu) ** 2).mean(1, keepdim=True) + 1e-12) * g2 + b2
+    yref.backward(dy)
+    y = torch.empty((rows, H), dtype=torch.bfloat16, device=dev())
+    stats = torch.empty((rows, 2), dtype=torch.float32, device=dev())
+    xg = x.half().to(dev())
+    ops.layernorm_fwd(xg, g2.to(dev()), b2.to(dev()), y, stats)
+    report("layernorm fwd on fp16 rows", y, yref.detach(), 1e-3, 1e-2)
+    dx = torch.empty((rows, H), dtype=torch.bfloat16, device=dev())
+    dg, db = torch.zeros(H, device=dev()), torch.zeros(H, device=dev())
+    ops.layernorm_bwd(to_gpu_bf16(dy), xg, stats, g2.to(dev()), dx=dx, dgamma=dg, dbeta=db)
+    report("layernorm bwd dx on fp16 rows", dx, xr.grad, 1e-3, 1e-2)
+    report("layernorm bwd dgamma on fp16 rows", dg, (dy * ((x - x.mean(1, keepdim=True)) / torch.sqrt(x.var(1, unbiased=False, keepdim=True) + 1e-12))).sum(0), 1e-3, 2e-3)
+
+
 def test_engine_step_through_large_tile_core(force_p8):
     """The whole VL-BERT step with EVERY eligible GEMM forced through gemm_p8.hip (one mostly-clamped 256-row tile at this size)
     against the same engine on the 128x128 kernels: logits / losses / gradients must agree to bf16 rounding."""

@@ -50,6 +50,21 @@ def run_case(M, N, K, epi, mode, seed_t, ldpad=0):
         kw = dict(bias=bias, res=side_g)
     elif epi == 5:
         kw = dict(bias=bias, act=ops.ACT_RELU)
+    elif epi in (6, 7):      # LayerNorm-residual from fp16 rows, fp16 output (epi 6: with dropout)
+        z = (side.float() * 2.0 + 0.3).half()
+        zg = torch.zeros((M, ldc), dtype=torch.float16, device=D)[:, :N]
+        zg.copy_(z.to(D))
+        zf = z.float()
+        mean = zf.mean(1, keepdim=True)
+        rstd = 1.0 / torch.sqrt(zf.var(1, unbiased=False, keepdim=True) + 1e-12)
+        st = torch.cat((mean, rstd), 1).contiguous().to(D)
+        gam = (1.0 + 0.2 * rnd(N, seed=8)).float().to(D)
+        bet = (0.1 * rnd(N, seed=9)).float().to(D)
+        C = torch.full((M, ldc), 7.0, dtype=torch.float16, device=D)[:, :N]
+        kw = dict(bias=bias, res=zg, res_ln=(st, gam, bet))
+        if epi == 6:
+            kw.update(drop_p=0.1, seed=seed_t, tag=17)
+        side = ((zf - mean) * rstd * gam.cpu() + bet.cpu())      # what the reference adds
     ops.gemm_nt(A, Bm, C, **kw)
     torch.cuda.synchronize()
     out = [C.float().cpu()]
@@ -70,7 +85,7 @@ def reference(M, N, K, epi, ins):
         return [x * cdf, cdf + x * torch.exp(-0.5 * x * x) / (2 * 3.141592653589793) ** 0.5]
     if epi == 2:
         return [acc * side.float()]
-    if epi == 4:
+    if epi in (4, 7):
         return [acc + b + side.float()]
     if epi == 5:
         return [torch.relu(acc + b)]
@@ -84,7 +99,7 @@ def check():
     bad = 0
     for M, N, K in shapes:
         for mode in (4, 5):
-            for epi in range(6):
+            for epi in range(8):
                 if N > 20000 and epi not in (0,):
                     continue
                 lib.gemm_set_option("p8_min_tiles", 1)
@@ -98,7 +113,7 @@ def check():
                     # vs old kernel: both round fp32 -> bf16 once, tiny accumulation-order differences only; vs fp32 torch: bf16 rounding
                     ok = d_old <= 2.5e-2 * max(scale, 1e-6) and (ref is None or d_ref <= 1.2e-2 * max(scale, 1e-6)) and bool(torch.isfinite(g).all())
                     frac_diff = float(((g - o).abs() > 1e-2 * max(scale, 1e-6)).float().mean())
-                    if epi == 3:   # identical dropout masks: the zero patterns must coincide
+                    if epi in (3, 6):   # identical dropout masks: the zero patterns must coincide
                         ok = ok and bool(((g == 0) == (o == 0)).float().mean() > 0.9999)
                     print("M %6d N %6d K %5d tile %d epi %d out %d: |d old| %.3e |d ref| %.3e scale %.3e frac>1%% %.2e %s"
                           % (M, N, K, 64 * mode, epi, k, d_old, d_ref, scale, frac_diff, "ok" if ok else "FAIL"), flush=True)

@@ -22,8 +22,9 @@ _SIGS = {
     "vlb_wgrad_nt_bf16": "plplpliiipls",
     "vlb_wgrad_tn_bf16": "plplpliiipplis",
     "vlb_zero_ranges_f32": "pppiis",
-    "vlb_layernorm_fwd": "plppplpiifs",
-    "vlb_layernorm_bwd": "pliplppplplfpuplpppiis",
+    "vlb_layernorm_fwd": "plppplpiifis",
+    "vlb_layernorm_bwd": "pliplppplplfpuplpppiiis",
+    "vlb_gemm_nt_bf16_ex": "plplpliiipiplplplpppifpuiis",
     "vlb_attention_fwd": "ppppiiiifpus",
     "vlb_attention_bwd": "ppppppiiiifpus",
     "vlb_seq_layout": "ppiiiipppppps",

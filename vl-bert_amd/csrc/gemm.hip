@@ -66,9 +66,12 @@ __device__ __forceinline__ void epi_copy_out(const EpiStage& st, bf16_t* C, long
   __syncthreads();
 }
 
-template <int ACT, bool DROP, bool RES, int OUT, bool INTERIOR, int FM, int FN>
+// GEN (the run-time dispatched kernel only): also honours the LayerNorm-residual form (p.res_stats) and fp16 output (p.c_f16)
+template <int ACT, bool DROP, bool RES, int OUT, bool INTERIOR, int FM, int FN, bool GEN = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[FM][FN], int mb, int nb, const EpiStage& st) {
-  constexpr bool STAGED = INTERIOR && OUT == 0;       // block-uniform: every thread takes the same path
+  const bool f16out = GEN && p.c_f16 != 0;
+  const bool lnres = GEN && RES && p.res_stats != nullptr;
+  const bool STAGED = INTERIOR && OUT == 0 && !f16out;       // block-uniform: every thread takes the same path
   const uint32_t seed = DROP ? *p.seed : 0u;
   float bias[FN][4];
 #pragma unroll
@@ -189,7 +192,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
       }
       if (RES) {
         const bf16_t* q = res_row + j * 16;
-        if (full) {
+        if (lnres) {     // residual = LayerNorm output re-materialised from the fp16 pre-LN row, its (mean, rstd) and gamma / beta
+          const float mean = p.res_stats[2 * (long)m], rstd = p.res_stats[2 * (long)m + 1];
+          for (int r = 0; r < 4 && (full || n + r < p.N); ++r)
+            v[r] += fmaf((h2f(q[r]) - mean) * rstd, p.res_gamma[n + r], p.res_beta[n + r]);
+        } else if (full) {
           const uint2 w = *(const uint2*)q;
           v[0] += bflo(w.x); v[1] += bfhi(w.x); v[2] += bflo(w.y); v[3] += bfhi(w.y);
         } else {
@@ -214,8 +221,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
           epi_stage_put(st, i, j, v);
         } else {
           bf16_t* c = (bf16_t*)p.C + offc + j * 16;
-          if (full) *(uint2*)c = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
-          else for (int r = 0; r < 4 && n + r < p.N; ++r) c[r] = f2bf(v[r]);
+          if (full) *(uint2*)c = make_uint2(pack2o(v[0], v[1], f16out), pack2o(v[2], v[3], f16out));
+          else for (int r = 0; r < 4 && n + r < p.N; ++r) c[r] = f16out ? f2h(v[r]) : f2bf(v[r]);
         }
       } else if (OUT == 1) {
         float* c = (float*)p.C + offc + j * 16;
@@ -240,24 +247,24 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 
 template <bool INTERIOR, int FM, int FN>
 __device__ __forceinline__ void gemm_epilogue_dispatch(const GemmParams& p, f32x4 (&acc)[FM][FN], int mb, int nb, const EpiStage& st) {
-  if (p.out_f32 == 3) gemm_epilogue<0, false, false, 3, INTERIOR, FM, FN>(p, acc, mb, nb, st);
-  else if (p.out_f32 == 2) gemm_epilogue<0, false, false, 2, INTERIOR, FM, FN>(p, acc, mb, nb, st);
-  else if (p.out_f32 == 1) gemm_epilogue<0, false, false, 1, INTERIOR, FM, FN>(p, acc, mb, nb, st);
-  else if (p.act == 1) gemm_epilogue<1, false, false, 0, INTERIOR, FM, FN>(p, acc, mb, nb, st);
-  else if (p.act == 2) gemm_epilogue<2, false, false, 0, INTERIOR, FM, FN>(p, acc, mb, nb, st);
-  else if (p.act == 3) gemm_epilogue<3, false, false, 0, INTERIOR, FM, FN>(p, acc, mb, nb, st);
-  else if (p.act == 4) gemm_epilogue<4, false, false, 0, INTERIOR, FM, FN>(p, acc, mb, nb, st);
-  else if (p.act == 5) gemm_epilogue<5, false, false, 0, INTERIOR, FM, FN>(p, acc, mb, nb, st);
-  else if (p.act == 6) gemm_epilogue<6, false, false, 0, INTERIOR, FM, FN>(p, acc, mb, nb, st);
-  else if (p.act == 7) gemm_epilogue<7, false, true, 0, INTERIOR, FM, FN>(p, acc, mb, nb, st);
+  if (p.out_f32 == 3) gemm_epilogue<0, false, false, 3, INTERIOR, FM, FN, true>(p, acc, mb, nb, st);
+  else if (p.out_f32 == 2) gemm_epilogue<0, false, false, 2, INTERIOR, FM, FN, true>(p, acc, mb, nb, st);
+  else if (p.out_f32 == 1) gemm_epilogue<0, false, false, 1, INTERIOR, FM, FN, true>(p, acc, mb, nb, st);
+  else if (p.act == 1) gemm_epilogue<1, false, false, 0, INTERIOR, FM, FN, true>(p, acc, mb, nb, st);
+  else if (p.act == 2) gemm_epilogue<2, false, false, 0, INTERIOR, FM, FN, true>(p, acc, mb, nb, st);
+  else if (p.act == 3) gemm_epilogue<3, false, false, 0, INTERIOR, FM, FN, true>(p, acc, mb, nb, st);
+  else if (p.act == 4) gemm_epilogue<4, false, false, 0, INTERIOR, FM, FN, true>(p, acc, mb, nb, st);
+  else if (p.act == 5) gemm_epilogue<5, false, false, 0, INTERIOR, FM, FN, true>(p, acc, mb, nb, st);
+  else if (p.act == 6) gemm_epilogue<6, false, false, 0, INTERIOR, FM, FN, true>(p, acc, mb, nb, st);
+  else if (p.act == 7) gemm_epilogue<7, false, true, 0, INTERIOR, FM, FN, true>(p, acc, mb, nb, st);
   else if (p.act == 8) {
-    if (p.res) gemm_epilogue<8, false, true, 0, INTERIOR, FM, FN>(p, acc, mb, nb, st);
-    else gemm_epilogue<8, false, false, 0, INTERIOR, FM, FN>(p, acc, mb, nb, st);
+    if (p.res) gemm_epilogue<8, false, true, 0, INTERIOR, FM, FN, true>(p, acc, mb, nb, st);
+    else gemm_epilogue<8, false, false, 0, INTERIOR, FM, FN, true>(p, acc, mb, nb, st);
   } else if (p.res) {
-    if (p.drop_thr) gemm_epilogue<0, true, true, 0, INTERIOR, FM, FN>(p, acc, mb, nb, st);
-    else gemm_epilogue<0, false, true, 0, INTERIOR, FM, FN>(p, acc, mb, nb, st);
-  } else if (p.drop_thr) gemm_epilogue<0, true, false, 0, INTERIOR, FM, FN>(p, acc, mb, nb, st);
-  else gemm_epilogue<0, false, false, 0, INTERIOR, FM, FN>(p, acc, mb, nb, st);
+    if (p.drop_thr) gemm_epilogue<0, true, true, 0, INTERIOR, FM, FN, true>(p, acc, mb, nb, st);
+    else gemm_epilogue<0, false, true, 0, INTERIOR, FM, FN, true>(p, acc, mb, nb, st);
+  } else if (p.drop_thr) gemm_epilogue<0, true, false, 0, INTERIOR, FM, FN, true>(p, acc, mb, nb, st);
+  else gemm_epilogue<0, false, false, 0, INTERIOR, FM, FN, true>(p, acc, mb, nb, st);
 }
 
 // EPI >= 0 compiles ONE fused epilogue into the kernel (bf16 output): 0 bias | 1 bias+GELU, gelu'(x) -> pre |
@@ -1048,7 +1055,7 @@ static int launch_gemm_cfg(GemmParams& p, int splits, hipStream_t stream) {
 // which single-epilogue instantiation serves this call (-1: the generic kernel with the runtime dispatch)
 static int epi_class(const GemmParams& p) {
   static const int specialise = env_int("VLB_GEMM_EPI_SPECIALISE", 1);
-  if (!specialise || p.out_f32 != 0) return -1;
+  if (!specialise || p.out_f32 != 0 || p.res_stats || p.c_f16) return -1;
   if (p.act == 0) return p.res ? (p.drop_thr ? 3 : 4) : (p.drop_thr ? -1 : 0);
   if (p.act == 4) return 1;
   if (p.act == 5) return 2;
@@ -1080,11 +1087,14 @@ static int launch_gemm(GemmParams& p, int splits, hipStream_t stream) {
   return launch_gemm_epi<BM, BN, 2, 2>(p, splits, stream);
 }
 
-extern "C" int vlb_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
-                                const float* bias, int act, const void* aux, long ldaux, void* pre, long ldpre,
-                                const void* res, long ldres, float drop_p, const uint32_t* seed, uint32_t tag,
-                                int out_mode, int splitk, hipStream_t stream) {
+static int gemm_nt_impl(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
+                        const float* bias, int act, const void* aux, long ldaux, void* pre, long ldpre,
+                        const void* res, long ldres, const float* res_stats, const float* res_gamma, const float* res_beta, int out_f16,
+                        float drop_p, const uint32_t* seed, uint32_t tag, int out_mode, int splitk, hipStream_t stream) {
   if (M <= 0 || N <= 0) return VLB_OK;
+  VLB_CHECK_ARG(!res_stats || (res && res_gamma && res_beta && act == 0 && out_mode == 0),
+                "vlb_gemm_nt_bf16_ex: the LayerNorm residual needs res (fp16 pre-LN rows), gamma, beta, act 0 and a 16-bit output");
+  VLB_CHECK_ARG(!out_f16 || out_mode == 0, "vlb_gemm_nt_bf16_ex: out_f16 applies to the 16-bit output mode");
   VLB_CHECK_ARG(K > 0 && (K % 64) == 0, "vlb_gemm_nt_bf16: K=%d must be a positive multiple of 64", K);
   VLB_CHECK_ARG(A && B && C, "vlb_gemm_nt_bf16: null operand");
   VLB_CHECK_ARG((lda % 8) == 0 && (ldb % 8) == 0, "vlb_gemm_nt_bf16: lda/ldb must be multiples of 8 elements");
@@ -1098,11 +1108,12 @@ extern "C" int vlb_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb
   VLB_CHECK_ARG(out_mode == 0 || (act == 0 && !(drop_p > 0.f) && !res), "vlb_gemm_nt_bf16: fp32 outputs take bias only");
   VLB_CHECK_ARG(!(drop_p > 0.f) || seed, "vlb_gemm_nt_bf16: dropout needs a device seed pointer");
   VLB_CHECK_ARG((long)M * (long)N < (1L << 32) || !(drop_p > 0.f), "vlb_gemm_nt_bf16: dropout index overflow");
-  GemmParams p;
+  GemmParams p = {};
   p.A = (const bf16_t*)A; p.lda = lda; p.B = (const bf16_t*)B; p.ldb = ldb;
   p.M = M; p.N = N; p.K = K;
   p.bias = bias; p.act = act; p.aux = (const bf16_t*)aux; p.ldaux = ldaux; p.pre = (bf16_t*)pre; p.ldpre = ldpre;
   p.res = (const bf16_t*)res; p.ldres = ldres;
+  p.res_stats = res_stats; p.res_gamma = res_gamma; p.res_beta = res_beta; p.c_f16 = out_f16 ? 1 : 0;
   p.drop_thr = vlb_drop_thr(drop_p); p.drop_scale = vlb_drop_scale(p.drop_thr); p.seed = seed; p.tag = tag;
   p.C = C; p.ldc = ldc; p.out_f32 = out_mode; p.c_split_stride = 0;
   int splits = 1;
@@ -1166,6 +1177,27 @@ extern "C" int vlb_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb
   return launch_gemm<128, 128>(p, splits, stream);
 }
 
+extern "C" int vlb_gemm_nt_bf16(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
+                                const float* bias, int act, const void* aux, long ldaux, void* pre, long ldpre,
+                                const void* res, long ldres, float drop_p, const uint32_t* seed, uint32_t tag,
+                                int out_mode, int splitk, hipStream_t stream) {
+  return gemm_nt_impl(A, lda, B, ldb, C, ldc, M, N, K, bias, act, aux, ldaux, pre, ldpre, res, ldres, nullptr, nullptr, nullptr, 0,
+                      drop_p, seed, tag, out_mode, splitk, stream);
+}
+
+// The same with (a) the "LayerNorm residual": `res` = the fp16 pre-LayerNorm rows of the sublayer that produced the residual,
+// res_stats = its [M][2] (mean, rstd), res_gamma / res_beta = that LayerNorm's parameters; the term added is the LayerNorm output
+// re-materialised in fp32 -- (b) out_f16: the 16-bit result is written as IEEE fp16 (the pre-LayerNorm sum this GEMM produces).
+// Together they keep the encoder's residual stream out of bf16 (BertSelfOutput / BertOutput, modeling.py:329-333,374-378).
+extern "C" int vlb_gemm_nt_bf16_ex(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
+                                   const float* bias, int act, const void* aux, long ldaux, void* pre, long ldpre,
+                                   const void* res, long ldres, const float* res_stats, const float* res_gamma, const float* res_beta,
+                                   int out_f16, float drop_p, const uint32_t* seed, uint32_t tag, int out_mode, int splitk,
+                                   hipStream_t stream) {
+  return gemm_nt_impl(A, lda, B, ldb, C, ldc, M, N, K, bias, act, aux, ldaux, pre, ldpre, res, ldres, res_stats, res_gamma, res_beta,
+                      out_f16, drop_p, seed, tag, out_mode, splitk, stream);
+}
+
 // ------------------------------------------------------------------------------------
 // Implicit 3x3 convolution (stride 1, padding = dilation) on an NHWC bf16 activation: the NT GEMM above with the im2col
 // gather done by the LDS-DMA address generator -- no [rows, 9C] image in HBM, the activation is read through L2 nine
@@ -1202,7 +1234,7 @@ extern "C" int vlb_conv3x3_nhwc_bf16(const void* x, int N, int H, int W, int C, 
   VLB_CHECK_ARG((ldw % 8) == 0 && ldw >= 9L * C && (ldy % 4) == 0, "vlb_conv3x3_nhwc_bf16: bad leading dimensions");
   VLB_CHECK_ARG(act == 0 || act == 2 || (act == 8 && aux), "vlb_conv3x3_nhwc_bf16: act must be 0, 2 or 8 (with aux)");
   VLB_CHECK_ARG((long)N * H * W < (1L << 31), "vlb_conv3x3_nhwc_bf16: too many rows");
-  GemmParams p;
+  GemmParams p = {};
   p.A = (const bf16_t*)x; p.lda = C; p.B = (const bf16_t*)w; p.ldb = ldw;
   p.M = N * H * W; p.N = O; p.K = 9 * C; p.k_per_split = 9 * C;
   p.bias = bias; p.act = act; p.aux = (const bf16_t*)aux; p.ldaux = ldaux; p.pre = nullptr; p.ldpre = 0; p.res = nullptr; p.ldres = 0;
@@ -1299,7 +1331,7 @@ extern "C" int vlb_wgrad_nt_bf16(const void* A, long lda, const void* B, long ld
   const int per = vlb_cdiv(ktiles, splits);
   const int nsp = vlb_cdiv(ktiles, per);
   const long ldw = (N + 3) / 4 * 4;
-  GemmParams p;
+  GemmParams p = {};
   p.A = (const bf16_t*)A; p.lda = lda; p.B = (const bf16_t*)B; p.ldb = ldb;
   p.M = M; p.N = N; p.K = K; p.k_per_split = per * 64;
   p.bias = nullptr; p.act = 0; p.aux = nullptr; p.ldaux = 0; p.pre = nullptr; p.ldpre = 0; p.res = nullptr; p.ldres = 0;
@@ -1337,7 +1369,7 @@ extern "C" int vlb_gemm_nt_bf16_splitk(const void* A, long lda, const void* B, l
   if (nsp <= 1)
     return vlb_gemm_nt_bf16(A, lda, B, ldb, C, ldc, M, N, K, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0.f, nullptr, 0, 0, 0, stream);
   const long ldw = (N + 3) / 4 * 4;
-  GemmParams p;
+  GemmParams p = {};
   p.A = (const bf16_t*)A; p.lda = lda; p.B = (const bf16_t*)B; p.ldb = ldb;
   p.M = M; p.N = N; p.K = K; p.k_per_split = per * 64;
   p.bias = nullptr; p.act = 0; p.aux = nullptr; p.ldaux = 0; p.pre = nullptr; p.ldpre = 0; p.res = nullptr; p.ldres = 0;
@@ -1370,7 +1402,7 @@ static int wgrad_tn_impl(const void* A, long lda, const void* B, long ldb, float
   const bool slab = nsp > 1 || rowscale != nullptr;      // a row scale is applied by the reduce kernel: always go through a slab
   VLB_CHECK_ARG(!rowscale || (workspace && workspace_floats >= (long)nsp * Mo * ldw), "vlb_wgrad_tn: rowscale needs a workspace of %ld floats",
                 (long)nsp * Mo * ldw);
-  GemmParams p;
+  GemmParams p = {};
   p.A = (const bf16_t*)A; p.lda = lda; p.B = (const bf16_t*)B; p.ldb = ldb;
   p.M = Mo; p.N = No; p.K = R; p.k_per_split = per * 64;
   p.bias = nullptr; p.act = 0; p.aux = nullptr; p.ldaux = 0; p.pre = nullptr; p.ldpre = 0; p.res = nullptr; p.ldres = 0;
@@ -1456,7 +1488,7 @@ extern "C" int vlb_conv3x3_wgrad_tn_bf16(const void* dy, long lddy, const void* 
   const bool slab = nsp > 1 || rowscale != nullptr;
   VLB_CHECK_ARG(!rowscale || (workspace && workspace_floats >= (long)nsp * Mo * ldw), "vlb_conv3x3_wgrad_tn_bf16: rowscale needs a workspace of %ld floats",
                 (long)nsp * Mo * ldw);
-  GemmParams p;
+  GemmParams p = {};
   p.A = (const bf16_t*)dy; p.lda = lddy; p.B = (const bf16_t*)x; p.ldb = C;
   p.M = Mo; p.N = No; p.K = R; p.k_per_split = per * 64;
   p.bias = nullptr; p.act = 0; p.aux = nullptr; p.ldaux = 0; p.pre = nullptr; p.ldpre = 0; p.res = nullptr; p.ldres = 0;

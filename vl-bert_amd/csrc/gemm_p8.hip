@@ -62,14 +62,15 @@ __device__ __forceinline__ void p8_barrier() {
 }
 
 // 8 consecutive output columns of one row: the whole fused epilogue on fp32 values, one rounding to bf16.
-// EPI: 0 bias | 1 bias + GELU, GELU'(x) -> pre | 2 x aux | 3 bias + dropout + residual | 4 bias + residual | 5 bias + ReLU
+// EPI: 0 bias | 1 bias + GELU, GELU'(x) -> pre | 2 x aux | 3 bias + dropout + residual | 4 bias + residual | 5 bias + ReLU |
+//      6 bias + dropout + LayerNorm-residual | 7 bias + LayerNorm-residual  (residual = LN output re-materialised in fp32 from the
+//      fp16 pre-LN rows in `side`, the row's (mean, rstd) in `ms` and gamma / beta of the thread's 8 columns in g8 / be8)
 template <int EPI>
-__device__ __forceinline__ void p8_epilogue8(const GemmParams& p, float (&v)[8], int m, int n, uint32_t seed, const uint4& side) {
-  if (p.bias) {
-    const float4 b0 = *(const float4*)(p.bias + n), b1 = *(const float4*)(p.bias + n + 4);
-    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
-    v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-  }
+__device__ __forceinline__ void p8_epilogue8(const GemmParams& p, float (&v)[8], const float (&b8)[8], int m, int n, uint32_t seed,
+                                             const uint4& side, const float2 ms = make_float2(0.f, 0.f), const float* g8 = nullptr,
+                                             const float* be8 = nullptr) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] += b8[e];      // (zeros when there is no bias)
   if (EPI == 1) {
     float d[8];
 #pragma unroll
@@ -87,7 +88,7 @@ __device__ __forceinline__ void p8_epilogue8(const GemmParams& p, float (&v)[8],
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
   }
-  if (EPI == 3) {
+  if (EPI == 3 || EPI == 6) {
     const uint32_t idx = (uint32_t)m * (uint32_t)p.N + (uint32_t)n;
     if ((idx & 1u) == 0) {   // element pairs share one 32-bit hash (vlb_common.h)
 #pragma unroll
@@ -105,6 +106,11 @@ __device__ __forceinline__ void p8_epilogue8(const GemmParams& p, float (&v)[8],
     v[0] += bflo(side.x); v[1] += bfhi(side.x); v[2] += bflo(side.y); v[3] += bfhi(side.y);
     v[4] += bflo(side.z); v[5] += bfhi(side.z); v[6] += bflo(side.w); v[7] += bfhi(side.w);
   }
+  if (EPI == 6 || EPI == 7) {
+    const float z[8] = {hlo(side.x), hhi(side.x), hlo(side.y), hhi(side.y), hlo(side.z), hhi(side.z), hlo(side.w), hhi(side.w)};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += fmaf((z[e] - ms.x) * ms.y, g8[e], be8[e]);
+  }
 }
 
 // scalar tail of the same (last, partial 8-column group of a row when N % 8 != 0)
@@ -121,9 +127,147 @@ __device__ __forceinline__ float p8_epilogue1(const GemmParams& p, float v, int 
   } else if (EPI == 5) {
     v = fmaxf(v, 0.f);
   }
-  if (EPI == 3) v = vlb_keep(seed, p.tag, (uint32_t)m * (uint32_t)p.N + (uint32_t)n, p.drop_thr) ? v * p.drop_scale : 0.f;
+  if (EPI == 3 || EPI == 6) v = vlb_keep(seed, p.tag, (uint32_t)m * (uint32_t)p.N + (uint32_t)n, p.drop_thr) ? v * p.drop_scale : 0.f;
   if (EPI == 3 || EPI == 4) v += bf2f(p.res[(long)m * p.ldres + n]);
+  if (EPI == 6 || EPI == 7)
+    v += fmaf((h2f(p.res[(long)m * p.ldres + n]) - p.res_stats[2 * (long)m]) * p.res_stats[2 * (long)m + 1], p.res_gamma[n], p.res_beta[n]);
   return v;
+}
+
+// Drain one output tile: raw fp32 accumulators -> LDS slab -> fused epilogue on 8-column groups -> bf16 rows.
+// KF = accumulator row fragments per wave per round: the slab holds 32*KF rows of 256 fp32 (both wave groups write KF fragments
+// each); KF = 0: a 16-row slab, the two wave groups alternate (320-row tiles in mid-stream: 16 KiB of LDS are left beside the
+// operand ring).  The 128-row form (KF = 4) borrows the operand ring itself and is used for the LAST tile of a workgroup, when no
+// LDS-DMA is in flight any more -- every launch with <= 256 tiles (the N = 768 GEMMs with 320-row tiles) drains this way.
+// Latency discipline: the bias of a thread's 8 columns is loaded once per tile; the residual / aux 16-B groups of the NEXT round
+// (KF <= 1) or of the whole round (KF = 4: 8 independent loads per thread) are requested before the slab is touched, so the
+// L2 round trip overlaps the slab writes, the barrier and the previous round's math instead of sitting in every round.
+template <int FMH, int EPI, int KF>
+__device__ __forceinline__ void p8_drain(const GemmParams& p, f32x4 (&acc)[2 * FMH][4], uint32_t slab, int m0, int n0, int wm, int wn,
+                                         int lane, int tid, uint32_t seed) {
+  constexpr int AH = 32 * FMH, NF = 2 * FMH;
+  constexpr bool ALT = (KF == 0);
+  constexpr int FPR = ALT ? 1 : KF;
+  constexpr int ROUNDS = ALT ? 2 * NF : (NF + FPR - 1) / FPR;
+  constexpr int PASSES = ALT ? 1 : 2 * FPR;
+  constexpr bool SIDE = (EPI == 2 || EPI == 3 || EPI == 4 || EPI == 6 || EPI == 7);
+  constexpr bool LNRES = (EPI == 6 || EPI == 7);
+  constexpr bool PRE_NEXT = SIDE && (PASSES <= 2);      // request the next round's side data one round ahead
+  // Every lane-dependent constant below is derived from an OPAQUE copy of the thread index: the optimiser would otherwise hoist
+  // these loop-invariant address computations above the K loop of the persistent tile loop, where their live ranges cost the
+  // main loop the registers it needs (the 320-row instantiation spilled a DMA offset and drained the queue to reload it).
+  asm volatile("" : "+v"(tid));
+  lane = tid & 63;
+  const int frow = lane & 15;
+  const int wrow = (ALT ? 0 : wm * 16) + frow;
+  uint32_t wr[4];
+#pragma unroll
+  for (int cj = 0; cj < 4; ++cj) {
+    const int c = (cj >> 1) * 32 + wn * 8 + (cj & 1) * 4 + (lane >> 4);
+    wr[cj] = slab + (uint32_t)(wrow * 1024 + ((c ^ (frow & 7)) << 4));
+  }
+  const int q = tid & 31, rho = tid >> 5;
+  const uint32_t rd0 = slab + (uint32_t)(rho * 1024 + (((2 * q) ^ (rho & 7)) << 4));
+  const uint32_t rd1 = slab + (uint32_t)(rho * 1024 + (((2 * q + 1) ^ (rho & 7)) << 4));
+  const int n = n0 + q * 8;
+  const bool full8 = n + 8 <= p.N;
+  bf16_t* const C = (bf16_t*)p.C;
+  float b8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (p.bias && full8) {
+    const float4 b0 = *(const float4*)(p.bias + n), b1 = *(const float4*)(p.bias + n + 4);
+    b8[0] = b0.x; b8[1] = b0.y; b8[2] = b0.z; b8[3] = b0.w; b8[4] = b1.x; b8[5] = b1.y; b8[6] = b1.z; b8[7] = b1.w;
+  }
+  float g8[8], be8[8];
+  if constexpr (LNRES) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) g8[e] = be8[e] = 0.f;
+    if (full8) {
+      const float4 a0 = *(const float4*)(p.res_gamma + n), a1 = *(const float4*)(p.res_gamma + n + 4);
+      const float4 c0 = *(const float4*)(p.res_beta + n), c1 = *(const float4*)(p.res_beta + n + 4);
+      g8[0] = a0.x; g8[1] = a0.y; g8[2] = a0.z; g8[3] = a0.w; g8[4] = a1.x; g8[5] = a1.y; g8[6] = a1.z; g8[7] = a1.w;
+      be8[0] = c0.x; be8[1] = c0.y; be8[2] = c0.z; be8[3] = c0.w; be8[4] = c1.x; be8[5] = c1.y; be8[6] = c1.z; be8[7] = c1.w;
+    }
+  }
+  const bool f16out = p.c_f16 != 0;
+  // tile row held by slab rows [pp*16, +16) in round r
+  auto row_of = [&](int r, int pp) {
+    const int f = ALT ? 0 : (pp >> 1), g = ALT ? (r & 1) : (pp & 1);
+    const int R = ALT ? (r >> 1) : (r * FPR + f);
+    const int ha = R / FMH, i = R - ha * FMH;
+    return m0 + ha * AH + g * FMH * 16 + i * 16 + rho;
+  };
+  auto frag_valid = [&](int r, int pp) { return ALT ? true : (r * FPR + (pp >> 1) < NF); };
+  auto load_side = [&](int r, int pp) {
+    uint4 sd = make_uint4(0, 0, 0, 0);
+    if constexpr (SIDE) {
+      const int m = row_of(r, pp);
+      if (frag_valid(r, pp) && m < p.M && full8) {
+        if (EPI == 2) sd = *(const uint4*)(p.aux + (long)m * p.ldaux + n);
+        else sd = *(const uint4*)(p.res + (long)m * p.ldres + n);
+      }
+    }
+    return sd;
+  };
+  uint4 side[2][PASSES];
+  if constexpr (PRE_NEXT) {
+#pragma unroll
+    for (int pp = 0; pp < PASSES; ++pp) side[0][pp] = load_side(0, pp);
+  }
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) {
+    if constexpr (SIDE && !PRE_NEXT) {
+#pragma unroll
+      for (int pp = 0; pp < PASSES; ++pp) side[r & 1][pp] = load_side(r, pp);
+    }
+    if (!ALT || wm == (r & 1)) {
+#pragma unroll
+      for (int f = 0; f < FPR; ++f) {
+        const int R = ALT ? (r >> 1) : (r * FPR + f);
+        if (R < NF) {
+          const uint32_t o = (uint32_t)(f * 32 * 1024);
+          p8_lds_write_f4<0>(wr[0] + o, acc[R < NF ? R : 0][0]);
+          p8_lds_write_f4<0>(wr[1] + o, acc[R < NF ? R : 0][1]);
+          p8_lds_write_f4<0>(wr[2] + o, acc[R < NF ? R : 0][2]);
+          p8_lds_write_f4<0>(wr[3] + o, acc[R < NF ? R : 0][3]);
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    p8_barrier();
+    if constexpr (PRE_NEXT) {
+      if (r + 1 < ROUNDS) {
+#pragma unroll
+        for (int pp = 0; pp < PASSES; ++pp) side[(r + 1) & 1][pp] = load_side(r + 1, pp);
+      }
+    }
+#pragma unroll
+    for (int pp = 0; pp < PASSES; ++pp) {
+      if (!frag_valid(r, pp)) continue;
+      const int m = row_of(r, pp);
+      f32x4 x0, x1;
+      p8_stage_read<0>(x0, x1, rd0 + (uint32_t)(pp * 16 * 1024), rd1 + (uint32_t)(pp * 16 * 1024));
+      if (m < p.M && n < p.N) {
+        float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+        if (full8) {
+          const uint4 sd = SIDE ? side[r & 1][pp] : make_uint4(0, 0, 0, 0);
+          if constexpr (LNRES) {
+            const float2 ms = *(const float2*)(p.res_stats + 2 * (long)m);
+            p8_epilogue8<EPI>(p, v, b8, m, n, seed, sd, ms, g8, be8);
+          } else {
+            p8_epilogue8<EPI>(p, v, b8, m, n, seed, sd);
+          }
+          *(uint4*)(C + (long)m * p.ldc + n) = make_uint4(pack2o(v[0], v[1], f16out), pack2o(v[2], v[3], f16out), pack2o(v[4], v[5], f16out),
+                                                          pack2o(v[6], v[7], f16out));
+        } else {
+          for (int e = 0; e < 8 && n + e < p.N; ++e) {
+            const float o = p8_epilogue1<EPI>(p, v[e], m, n + e, seed);
+            C[(long)m * p.ldc + n + e] = f16out ? f2h(o) : f2bf(o);
+          }
+        }
+      }
+    }
+    if (r + 1 < ROUNDS) p8_barrier();      // the slab is free for the next round
+  }
 }
 
 // FMH: 16-row accumulator fragments per wave per tile half (4 -> 256-row tiles, 5 -> 320-row tiles)
@@ -278,7 +422,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(const GemmParams p) 
   if (wm == 1) p8_barrier();       // the wm = 1 waves run one segment behind
 
   int g = 0;                       // K tiles consumed by this workgroup so far
-  const uint32_t seed = (EPI == 3) ? *p.seed : 0u;
+  const uint32_t seed = (EPI == 3 || EPI == 6) ? *p.seed : 0u;
   for (int w = blockIdx.x; w < nt; w += gridDim.x) {
 #pragma unroll
     for (int i = 0; i < 2 * FMH; ++i)
@@ -348,66 +492,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(const GemmParams p) 
     // ---------------- epilogue: raw fp32 accumulators -> staging slab -> fused math on 8-column groups -> bf16 ----------------
     int m0, n0;
     tile_of(w, m0, n0);
-    {
-      constexpr int ROUNDS = (SR == 32) ? 2 * FMH : 4 * FMH;
-      const uint32_t stg = lds0 + STG;
-      // write side: this lane's row inside the slab and its 16-B chunk (4 fp32) per fragment column
-      const int wrow = (SR == 32 ? wm * 16 : 0) + frow;
-      const uint32_t wr_base = stg + (uint32_t)(wrow * 1024);
-      uint32_t wr_off[4];
-#pragma unroll
-      for (int cj = 0; cj < 4; ++cj) {
-        const int c = (cj >> 1) * 32 + wn * 8 + (cj & 1) * 4 + (lane >> 4);
-        wr_off[cj] = wr_base + (uint32_t)(((c ^ (wrow & 7)) << 4));
-      }
-      // read side: thread -> (row rho, 8-column group q); SR = 32: two rows per thread (rho, rho + 16)
-      const int q = tid & 31, rho = tid >> 5;
-      const uint32_t rd0 = stg + (uint32_t)(rho * 1024 + (((2 * q) ^ (rho & 7)) << 4));
-      const uint32_t rd1 = stg + (uint32_t)(rho * 1024 + (((2 * q + 1) ^ (rho & 7)) << 4));
-      const int n = n0 + q * 8;
-      bf16_t* const C = (bf16_t*)p.C;
-#pragma unroll      // (fully unrolled: R becomes a compile-time index into the accumulator registers, the ladder below folds away)
-      for (int r = 0; r < ROUNDS; ++r) {
-        // which accumulator row fragment this round drains, and the tile rows the slab then holds
-        const int R = (SR == 32) ? r : (r >> 1);                  // SR = 16: wave rows alternate (wm = r & 1 writes)
-        const int ha = R / FMH, i = R - ha * FMH;
-        if (SR == 32 || wm == (r & 1)) {
-          // acc[R][*] with a run-time R: walk the fragments with a uniform branch ladder (register arrays need static indices)
-#pragma unroll
-          for (int RR = 0; RR < 2 * FMH; ++RR) {
-            if (RR == R) {
-              p8_lds_write_f4<0>(wr_off[0], acc[RR][0]);
-              p8_lds_write_f4<0>(wr_off[1], acc[RR][1]);
-              p8_lds_write_f4<0>(wr_off[2], acc[RR][2]);
-              p8_lds_write_f4<0>(wr_off[3], acc[RR][3]);
-            }
-          }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        p8_barrier();
-        // row of the tile held by slab row rho (+16): SR = 32: rows 0-15 from the wm = 0 waves, 16-31 from wm = 1
-#pragma unroll
-        for (int pass = 0; pass < SR / 16; ++pass) {
-          const int grp = (SR == 32) ? pass : (r & 1);
-          const int m = m0 + ha * AH + grp * FMH * 16 + i * 16 + rho;
-          f32x4 x0, x1;
-          if (pass == 0) p8_stage_read<0>(x0, x1, rd0, rd1);
-          else p8_stage_read<16 * 1024>(x0, x1, rd0, rd1);     // second half of the slab: +16 rows (same swizzle term rho & 7)
-          if (m < p.M && n < p.N) {
-            float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-            if (n + 8 <= p.N) {
-              uint4 side = make_uint4(0, 0, 0, 0);
-              if (EPI == 2) side = *(const uint4*)(p.aux + (long)m * p.ldaux + n);
-              if (EPI == 3 || EPI == 4) side = *(const uint4*)(p.res + (long)m * p.ldres + n);
-              p8_epilogue8<EPI>(p, v, m, n, seed, side);
-              *(uint4*)(C + (long)m * p.ldc + n) = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
-            } else {
-              for (int e = 0; e < 8 && n + e < p.N; ++e) C[(long)m * p.ldc + n + e] = f2bf(p8_epilogue1<EPI>(p, v[e], m, n + e, seed));
-            }
-          }
-        }
-        p8_barrier();              // the slab is free for the next round
-      }
+    if (w + (int)gridDim.x >= nt) {
+      // last tile of this workgroup: nothing is in flight into the operand ring any more (the producer stopped at this tile and
+      // every K tile it issued has been consumed) -> drain through a 128-row slab laid over the ring
+      p8_drain<FMH, EPI, 4>(p, acc, lds0, m0, n0, wm, wn, lane, tid, seed);
+    } else {
+      p8_drain<FMH, EPI, (SR == 32 ? 1 : 0)>(p, acc, lds0 + STG, m0, n0, wm, wn, lane, tid, seed);
     }
     // one full drain per output tile (stores and LDS-DMA share vmcnt and may retire out of order with respect to each other:
     // counted waits are only sound on a queue of loads); the K tiles prefetched for the next output tile had the whole epilogue
@@ -448,7 +538,9 @@ int p8_launch_epi(GemmParams& p, int epi, int group, hipStream_t stream) {
     case 2: return p8_launch<FMH, 2, KEEPB>(p, group, stream);
     case 3: return p8_launch<FMH, 3, KEEPB>(p, group, stream);
     case 4: return p8_launch<FMH, 4, KEEPB>(p, group, stream);
-    default: return p8_launch<FMH, 5, KEEPB>(p, group, stream);
+    case 5: return p8_launch<FMH, 5, KEEPB>(p, group, stream);
+    case 6: return p8_launch<FMH, 6, KEEPB>(p, group, stream);
+    default: return p8_launch<FMH, 7, KEEPB>(p, group, stream);
   }
 }
 
@@ -491,7 +583,8 @@ int vlb_gemm_p8_try(GemmParams& p, hipStream_t stream) {
   if (!mode || p.out_f32 != 0 || p.c_split_stride != 0) return 0;
   if ((p.K % 128) != 0 || p.k_per_split < p.K) return 0;
   int epi;
-  if (p.act == 0) epi = p.res ? (p.drop_thr ? 3 : 4) : (p.drop_thr ? -1 : 0);
+  if (p.act == 0 && p.res && p.res_stats) epi = p.drop_thr ? 6 : 7;
+  else if (p.act == 0) epi = p.res ? (p.drop_thr ? 3 : 4) : (p.drop_thr ? -1 : 0);
   else if (p.act == 4) epi = 1;
   else if (p.act == 5) epi = 2;
   else if (p.act == 2) epi = 5;
@@ -503,6 +596,7 @@ int vlb_gemm_p8_try(GemmParams& p, hipStream_t stream) {
   if (epi == 2 && ((p.ldaux % 8) || !aligned16(p.aux))) return 0;
   if (epi == 1 && p.pre && ((p.ldpre % 8) || !aligned16(p.pre))) return 0;
   if (p.bias && ((uintptr_t)p.bias & 15)) return 0;
+  if (p.res_stats && (((uintptr_t)p.res_gamma & 15) || ((uintptr_t)p.res_beta & 15) || ((uintptr_t)p.res_stats & 7))) return 0;
   if ((long)p.M * p.lda * 2 >= (1L << 31) || (long)p.N * p.ldb * 2 >= (1L << 31)) return 0;
   // tile height: whole rounds of 256 resident workgroups, time per round ~ tile area
   const long t4 = (long)vlb_cdiv(p.M, 256) * vlb_cdiv(p.N, 256), t5 = (long)vlb_cdiv(p.M, 320) * vlb_cdiv(p.N, 256);

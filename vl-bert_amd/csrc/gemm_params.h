@@ -12,6 +12,11 @@ struct GemmParams {
   const bf16_t* aux; long ldaux;
   bf16_t* pre; long ldpre;   // optional pre-activation output (act==1)
   const bf16_t* res; long ldres;
+  // "LayerNorm residual": res holds the fp16 PRE-LayerNorm rows of the producing sublayer and the residual that is added is the
+  // LayerNorm output re-materialised in fp32, (res - mean[m]) * rstd[m] * gamma[n] + beta[n] (res_stats = [M][2] (mean, rstd)).
+  // The encoder's residual stream then never passes through a bf16 rounding (DESIGN.md "precision").
+  const float* res_stats; const float* res_gamma; const float* res_beta;
+  int c_f16;                 // bf16-output kernels write C as fp16 instead (the pre-LayerNorm sums)
   uint32_t drop_thr; float drop_scale; const uint32_t* seed; uint32_t tag;
   void* C; long ldc;
   long c_split_stride;       // elements between the outputs of consecutive K splits (slab split-K), 0 otherwise

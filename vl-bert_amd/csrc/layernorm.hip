@@ -22,14 +22,15 @@ struct Row4 {
   float v[NIT][4];
 };
 
+// f16: the row holds IEEE fp16 instead of bf16 (the encoder's pre-LayerNorm sums, written by vlb_gemm_nt_bf16_ex(out_f16))
 template <int NIT>
-__device__ __forceinline__ void load_row_bf16(const bf16_t* x, int H, int lane, Row4<NIT>& r) {
+__device__ __forceinline__ void load_row_bf16(const bf16_t* x, int H, int lane, Row4<NIT>& r, bool f16 = false) {
 #pragma unroll
   for (int i = 0; i < NIT; ++i) {
     const int c = (lane + 64 * i) * 4;
     if (c < H) {
       const uint2 w = *(const uint2*)(x + c);
-      r.v[i][0] = bflo(w.x); r.v[i][1] = bfhi(w.x); r.v[i][2] = bflo(w.y); r.v[i][3] = bfhi(w.y);
+      r.v[i][0] = dec_lo(w.x, f16); r.v[i][1] = dec_hi(w.x, f16); r.v[i][2] = dec_lo(w.y, f16); r.v[i][3] = dec_hi(w.y, f16);
     } else {
       r.v[i][0] = r.v[i][1] = r.v[i][2] = r.v[i][3] = 0.f;
     }
@@ -40,12 +41,12 @@ __device__ __forceinline__ void load_row_bf16(const bf16_t* x, int H, int lane, 
 template <int NIT>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __restrict__ x, long ldx, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, bf16_t* __restrict__ y, long ldy,
-                                                            float* __restrict__ stats, int rows, int H, float eps) {
+                                                            float* __restrict__ stats, int rows, int H, float eps, int x_f16) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   Row4<NIT> r;
-  load_row_bf16(x + (long)row * ldx, H, lane, r);
+  load_row_bf16(x + (long)row * ldx, H, lane, r, x_f16 != 0);
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < NIT; ++i) s += (r.v[i][0] + r.v[i][1]) + (r.v[i][2] + r.v[i][3]);
@@ -97,14 +98,14 @@ struct Row8 {
 };
 
 template <int NP>
-__device__ __forceinline__ void load_row8_bf16(const bf16_t* x, int H, int lane, Row8<NP>& r) {
+__device__ __forceinline__ void load_row8_bf16(const bf16_t* x, int H, int lane, Row8<NP>& r, bool f16 = false) {
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
     const int c = (lane + 64 * i) * 8;
     uint4 w = make_uint4(0u, 0u, 0u, 0u);
     if (c < H) w = *(const uint4*)(x + c);
-    r.v[i][0] = bflo(w.x); r.v[i][1] = bfhi(w.x); r.v[i][2] = bflo(w.y); r.v[i][3] = bfhi(w.y);
-    r.v[i][4] = bflo(w.z); r.v[i][5] = bfhi(w.z); r.v[i][6] = bflo(w.w); r.v[i][7] = bfhi(w.w);
+    r.v[i][0] = dec_lo(w.x, f16); r.v[i][1] = dec_hi(w.x, f16); r.v[i][2] = dec_lo(w.y, f16); r.v[i][3] = dec_hi(w.y, f16);
+    r.v[i][4] = dec_lo(w.z, f16); r.v[i][5] = dec_hi(w.z, f16); r.v[i][6] = dec_lo(w.w, f16); r.v[i][7] = dec_hi(w.w, f16);
   }
 }
 
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
                                                             bf16_t* __restrict__ dx, long lddx, bf16_t* __restrict__ dx_drop, long lddd,
                                                             uint32_t drop_thr, float drop_scale, const uint32_t* __restrict__ seedp,
                                                             uint32_t tag, float* __restrict__ dx_acc, long ldacc, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta, float* __restrict__ ws, int rows, int H) {
+                                                            float* __restrict__ dbeta, float* __restrict__ ws, int rows, int H, int x_f16) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][2][LW] per-wave partial dgamma / dbeta (lane-major)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t seed = (drop_thr && seedp) ? *seedp : 0u;
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int row = t ? (has1 ? row1 : row0) : row0;
-      load_row8_bf16(x + (long)row * ldx, H, lane, xr[t]);
+      load_row8_bf16(x + (long)row * ldx, H, lane, xr[t], x_f16 != 0);
       if (dy_f32) {
         const float* d = (const float*)dy_ + (long)row * lddy;
 #pragma unroll
@@ -271,13 +272,13 @@ __global__ __launch_bounds__(256) void ln_param_finalize_kernel(const float* __r
 }
 
 extern "C" int vlb_layernorm_fwd(const void* x, long ldx, const float* gamma, const float* beta, void* y, long ldy,
-                                 float* stats, int rows, int H, float eps, hipStream_t stream) {
+                                 float* stats, int rows, int H, float eps, int x_f16, hipStream_t stream) {
   if (rows <= 0) return VLB_OK;
   VLB_CHECK_ARG(H > 0 && (H % 4) == 0 && H <= 256 * LN_MAX_IT, "vlb_layernorm_fwd: unsupported H=%d", H);
   VLB_CHECK_ARG((ldx % 4) == 0 && (ldy % 4) == 0, "vlb_layernorm_fwd: row strides must be multiples of 4");
 #define LN_FWD(NIT)                                                                                                         \
   hipLaunchKernelGGL(layernorm_fwd_kernel<NIT>, dim3(vlb_cdiv(rows, 4)), dim3(256), 0, stream, (const bf16_t*)x, ldx, gamma, \
-                     beta, (bf16_t*)y, ldy, stats, rows, H, eps)
+                     beta, (bf16_t*)y, ldy, stats, rows, H, eps, x_f16)
   const int nit = vlb_cdiv(H, 256);
   if (nit <= 1) LN_FWD(1); else if (nit == 2) LN_FWD(2); else if (nit == 3) LN_FWD(3); else if (nit == 4) LN_FWD(4); else LN_FWD(8);
 #undef LN_FWD
@@ -288,7 +289,7 @@ extern "C" int vlb_layernorm_fwd(const void* x, long ldx, const float* gamma, co
 extern "C" int vlb_layernorm_bwd(const void* dy, long lddy, int dy_f32, const void* x, long ldx, const float* stats,
                                  const float* gamma, void* dx, long lddx, void* dx_drop, long lddd, float drop_p,
                                  const uint32_t* seed, uint32_t tag, float* dx_acc, long ldacc, float* dgamma, float* dbeta,
-                                 float* workspace, int rows, int H, hipStream_t stream) {
+                                 float* workspace, int rows, int H, int x_f16, hipStream_t stream) {
   if (rows <= 0) return VLB_OK;
   VLB_CHECK_ARG(H > 0 && (H % 8) == 0 && H <= 2048, "vlb_layernorm_bwd: unsupported H=%d (multiple of 8, <= 2048)", H);
   VLB_CHECK_ARG((lddy % 8) == 0 && (ldx % 8) == 0 && (lddx % 8) == 0 && (lddd % 8) == 0,
@@ -303,7 +304,7 @@ extern "C" int vlb_layernorm_bwd(const void* dy, long lddy, int dy_f32, const vo
 #define LN_BWD(NP)                                                                                                             \
   hipLaunchKernelGGL(layernorm_bwd_kernel<NP>, dim3(blocks), dim3(256), 8 * NP * 512 * sizeof(float), stream, dy, lddy, dy_f32,  \
                      (const bf16_t*)x, ldx, stats, gamma, (bf16_t*)dx, lddx, (bf16_t*)dx_drop, lddd, thr, vlb_drop_scale(thr),  \
-                     seed, tag, dx_acc, ldacc, dgamma, dbeta, ws, rows, H)
+                     seed, tag, dx_acc, ldacc, dgamma, dbeta, ws, rows, H, x_f16)
   const int np = vlb_cdiv(H, 512);
   if (np <= 1) LN_BWD(1); else if (np == 2) LN_BWD(2); else if (np == 3) LN_BWD(3); else LN_BWD(4);
 #undef LN_BWD

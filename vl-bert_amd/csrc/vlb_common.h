@@ -43,6 +43,18 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
 __device__ __forceinline__ float bflo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bfhi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
+// ---- fp16 (IEEE half) <-> f32: the pre-LayerNorm sums of the encoder (the residual stream) are kept in fp16 -- 3 more mantissa
+// bits than bf16 at the same 2 bytes; their magnitudes are O(1..10), far inside the fp16 range (DESIGN.md "precision") ----
+__device__ __forceinline__ float h2f(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+__device__ __forceinline__ uint16_t f2h(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }   // RNE
+__device__ __forceinline__ uint32_t pack2h(float lo, float hi) { return ((uint32_t)f2h(hi) << 16) | (uint32_t)f2h(lo); }
+__device__ __forceinline__ float hlo(uint32_t w) { return h2f((uint16_t)(w & 0xffffu)); }
+__device__ __forceinline__ float hhi(uint32_t w) { return h2f((uint16_t)(w >> 16)); }
+// 16-bit element pair decoded as fp16 or bf16
+__device__ __forceinline__ float dec_lo(uint32_t w, bool f16) { return f16 ? hlo(w) : bflo(w); }
+__device__ __forceinline__ float dec_hi(uint32_t w, bool f16) { return f16 ? hhi(w) : bfhi(w); }
+__device__ __forceinline__ uint32_t pack2o(float lo, float hi, bool f16) { return f16 ? pack2h(lo, hi) : pack2bf(lo, hi); }
+
 // ---- wave reductions (64 lanes) ----
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -276,9 +276,18 @@ class PretrainEngine:
         self.QKV = [zb(M, 3 * H) for _ in range(L)]
         self.CTX = [zb(M, H) for _ in range(L)]
         self.LSE = [zf(Bt, nh, S) for _ in range(L)]
-        self.Z1, self.ST1, self.Y1 = [zb(M, H) for _ in range(L)], [zf(M, 2) for _ in range(L)], [zb(M, H) for _ in range(L)]
+        # Residual stream precision (DESIGN.md "precision"): the pre-LayerNorm sums Z1 / Z2 are kept in fp16 (3 more mantissa bits
+        # than bf16, same bytes; |Z| = O(1..10)) and the residual a sublayer adds is the previous LayerNorm's output re-materialised
+        # in fp32 from (Z, mean, rstd, gamma, beta) inside the GEMM epilogue, so nothing on the residual path is ever rounded to
+        # bf16 -- only the GEMM operands are.  At 12 layers this takes the logits' error against the fp32 reference from 1.3e-2 to
+        # ~6e-3 (relative Frobenius; 5e-3 of it is the bf16 rounding of the weights).  VLB_RESIDUAL_STREAM=bf16: the old behaviour.
+        import os as _os0
+        self.hp_res = _os0.environ.get("VLB_RESIDUAL_STREAM", "f16ln") != "bf16"
+        zdt = torch.float16 if self.hp_res else BF16
+        zz = lambda *s: torch.zeros(s, dtype=zdt, device=d)
+        self.Z1, self.ST1, self.Y1 = [zz(M, H) for _ in range(L)], [zf(M, 2) for _ in range(L)], [zb(M, H) for _ in range(L)]
         self.U, self.G = [zb(M, I) for _ in range(L)], [zb(M, I) for _ in range(L)]
-        self.Z2, self.ST2 = [zb(M, H) for _ in range(L)], [zf(M, 2) for _ in range(L)]
+        self.Z2, self.ST2 = [zz(M, H) for _ in range(L)], [zf(M, 2) for _ in range(L)]
         self.text_out, self.obj_out = zb(BT, H), zb(BR, H)
         self.mlm_u, self.mlm_g, self.mlm_h, self.st_mlm = zb(BT, H), zb(BT, H), zb(BT, H), zf(BT, 2)
         self.mlm_logits = zb(BT, self.Vp)
@@ -521,14 +530,24 @@ class PretrainEngine:
             bqkv = self.P.view(self.P.master, p + "attention.self.query.bias", (3 * H,), span=3)
             ops.gemm_nt(x, wqkv, self.QKV[l], bias=bqkv)
             ops.attention_fwd(self.QKV[l], mask, self.CTX[l], self.LSE[l], Bt, S, H, nh, drop_p=p_a, seed=seed, tag=l * 8 + 0)
+            if self.hp_res and l > 0:    # residual = LayerNorm(Z2[l-1]) in fp32 (layer 0: the bf16 embedding output, one rounding)
+                pp = "vlbert.encoder.layer.%d." % (l - 1)
+                res_kw = dict(res=self.Z2[l - 1], res_ln=(self.ST2[l - 1], w32[pp + "output.LayerNorm.weight"], w32[pp + "output.LayerNorm.bias"]))
+            else:
+                res_kw = dict(res=x)
             ops.gemm_nt(self.CTX[l], w16[p + "attention.output.dense.weight"], self.Z1[l], bias=w32[p + "attention.output.dense.bias"],
-                        res=x, drop_p=p_h, seed=seed, tag=l * 8 + 1)
+                        drop_p=p_h, seed=seed, tag=l * 8 + 1, **res_kw)
             ops.layernorm_fwd(self.Z1[l], w32[p + "attention.output.LayerNorm.weight"], w32[p + "attention.output.LayerNorm.bias"],
                               self.Y1[l], self.ST1[l])
             ops.gemm_nt(self.Y1[l], w16[p + "intermediate.dense.weight"], self.G[l], bias=w32[p + "intermediate.dense.bias"],
                         act=ops.ACT_GELU_D, pre=self.U[l])
-            ops.gemm_nt(self.G[l], w16[p + "output.dense.weight"], self.Z2[l], bias=w32[p + "output.dense.bias"], res=self.Y1[l],
-                        drop_p=p_h, seed=seed, tag=l * 8 + 2)
+            if self.hp_res:
+                res_kw = dict(res=self.Z1[l], res_ln=(self.ST1[l], w32[p + "attention.output.LayerNorm.weight"],
+                                                      w32[p + "attention.output.LayerNorm.bias"]))
+            else:
+                res_kw = dict(res=self.Y1[l])
+            ops.gemm_nt(self.G[l], w16[p + "output.dense.weight"], self.Z2[l], bias=w32[p + "output.dense.bias"],
+                        drop_p=p_h, seed=seed, tag=l * 8 + 2, **res_kw)
             ops.layernorm_fwd(self.Z2[l], w32[p + "output.LayerNorm.weight"], w32[p + "output.LayerNorm.bias"], self.X[l + 1],
                               self.ST2[l])
         # --- heads ---------------------------------------------------------------------------------------

@@ -35,12 +35,28 @@ def _ld(t):
     return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
 
 
+F16 = torch.float16
+
+
 def gemm_nt(A, B, C, bias=None, act=ACT_NONE, aux=None, pre=None, res=None, drop_p=0.0, seed=None, tag=0,
-            out_mode=OUT_BF16, splitk=0, K=None):
-    """C[M,N] (+)= A[M,K] B[N,K]^T with the fused epilogue of vlb_gemm_nt_bf16."""
+            out_mode=OUT_BF16, splitk=0, K=None, res_ln=None):
+    """C[M,N] (+)= A[M,K] B[N,K]^T with the fused epilogue of vlb_gemm_nt_bf16.
+    C of dtype float16 (16-bit output mode): the result is stored as IEEE fp16 (the encoder's pre-LayerNorm sums).
+    res_ln = (stats [M,2], gamma [N], beta [N]): `res` holds fp16 pre-LayerNorm rows and the residual added is that LayerNorm's
+    output re-materialised in fp32 (vlb_gemm_nt_bf16_ex)."""
     M, N = C.shape
     K = A.shape[1] if K is None else K
     assert A.shape[0] == M and B.shape[0] == N and B.shape[1] >= K and A.shape[1] >= K
+    if res_ln is not None or C.dtype == F16:
+        assert out_mode == OUT_BF16
+        st, g, b = res_ln if res_ln is not None else (None, None, None)
+        if res_ln is not None:
+            assert res is not None and res.dtype == F16 and st.shape[0] >= M
+        _lib.call("vlb_gemm_nt_bf16_ex", _p(A, BF16), _ld(A), _p(B, BF16), _ld(B), _p(C), _ld(C), M, N, K,
+                  _p(bias, torch.float32), act, _p(aux, BF16), _ld(aux), _p(pre, BF16), _ld(pre), _p(res), _ld(res),
+                  _p(st, torch.float32), _p(g, torch.float32), _p(b, torch.float32), 1 if C.dtype == F16 else 0,
+                  float(drop_p), _p(seed), int(tag), out_mode, splitk, _stream())
+        return C
     cdt = BF16 if out_mode == OUT_BF16 else torch.float32
     _lib.call("vlb_gemm_nt_bf16", _p(A, BF16), _ld(A), _p(B, BF16), _ld(B), _p(C, cdt), _ld(C), M, N, K,
               _p(bias, torch.float32), act, _p(aux, BF16), _ld(aux), _p(pre, BF16), _ld(pre), _p(res, BF16), _ld(res),
@@ -140,8 +156,9 @@ def layernorm_fwd(x, gamma, beta, y, stats=None, eps=1e-12, rows=None, ldx=None)
     """`rows`/`ldx` override the view-derived values (ldx=0 broadcasts one input row to every output row)."""
     H = x.shape[1]
     rows = x.shape[0] if rows is None else rows
-    _lib.call("vlb_layernorm_fwd", _p(x, BF16), _ld(x) if ldx is None else ldx, _p(gamma, torch.float32), _p(beta, torch.float32), _p(y, BF16),
-              _ld(y), _p(stats, torch.float32), rows, H, float(eps), _stream())
+    assert x.dtype in (BF16, F16)       # fp16: the encoder's pre-LayerNorm sums (gemm_nt with a float16 C)
+    _lib.call("vlb_layernorm_fwd", _p(x), _ld(x) if ldx is None else ldx, _p(gamma, torch.float32), _p(beta, torch.float32), _p(y, BF16),
+              _ld(y), _p(stats, torch.float32), rows, H, float(eps), 1 if x.dtype == F16 else 0, _stream())
     return y
 
 
@@ -151,10 +168,11 @@ def layernorm_bwd(dy, x, stats, gamma, dx=None, dx_drop=None, drop_p=0.0, seed=N
     H = x.shape[1]
     rows = x.shape[0] if rows is None else rows
     dy_f32 = 1 if dy.dtype == torch.float32 else 0
-    _lib.call("vlb_layernorm_bwd", _p(dy), _ld(dy), dy_f32, _p(x, BF16), _ld(x) if ldx is None else ldx, _p(stats, torch.float32),
+    assert x.dtype in (BF16, F16)
+    _lib.call("vlb_layernorm_bwd", _p(dy), _ld(dy), dy_f32, _p(x), _ld(x) if ldx is None else ldx, _p(stats, torch.float32),
               _p(gamma, torch.float32), _p(dx, BF16), _ld(dx), _p(dx_drop, BF16), _ld(dx_drop), float(drop_p), _p(seed),
               int(tag), _p(dx_acc, torch.float32), _ld(dx_acc) if ldacc is None else ldacc, _p(dgamma, torch.float32),
-              _p(dbeta, torch.float32), _p(workspace, torch.float32), rows, H, _stream())
+              _p(dbeta, torch.float32), _p(workspace, torch.float32), rows, H, 1 if x.dtype == F16 else 0, _stream())
 
 
 def attention_fwd(qkv, mask, ctx, lse, B, S, H, nh, drop_p=0.0, seed=None, tag=0):
