@@ -169,6 +169,19 @@ int vlb_embed_bwd(const void* dy, const void* pre, const float* stats, const flo
 /* out[i] = src[idx[i]] (rows of H bf16; idx < 0 -> zero row): text/object split of
  * visual_linguistic_bert.py:146-166 */
 int vlb_gather_rows(const void* src, const int32_t* idx, void* out, int n, int H, vlb_stream_t stream);
+/* out[idx[i]] = src[i] for idx[i] >= 0: inverse of vlb_gather_rows through the same index list */
+int vlb_scatter_rows(const void* src, const int32_t* idx, void* out, int n, int H, vlb_stream_t stream);
+/* MLM head compaction (BertOnlyMLMHead, modeling.py:439-482 + F.cross_entropy(ignore_index=-1),
+ * resnet_vlbert_for_pretraining.py:176-178): the unlabelled text positions contribute nothing to the loss and get exactly zero
+ * d(logits) rows, so the head runs on the labelled rows only.  vlb_mlm_compact lists them (stable order): sel_pos[k] = position in
+ * [0, n), sel_src[k] = src_rows[position], labels_c[k] = label (all -1 beyond the count), count0 / count1 = labelled rows among
+ * positions < n_split / >= n_split; *overflow is set when more than `cap` rows carry a label (the excess is dropped: an error for
+ * the caller).  vlb_ce_fwd_bwd_compact = vlb_ce_fwd_bwd on such rows with the two group means (loss_out0 over count0 rows, then
+ * loss_out1 over count1 rows). */
+int vlb_mlm_compact(const int64_t* labels, const int32_t* src_rows, int n, int n_split, int V, int cap, int32_t* sel_pos,
+                    int32_t* sel_src, int64_t* labels_c, float* count0, float* count1, int32_t* overflow, vlb_stream_t stream);
+int vlb_ce_fwd_bwd_compact(void* logits, long ld, int rows, int V, const int64_t* labels_c, const float* count0, const float* count1,
+                           float gscale, float* loss_out0, float* loss_out1, vlb_stream_t stream);
 /* inverse of the split: dX[b,s] = (s<T ? d_text[b,s] : 0) + (row is object j ? d_obj[b,j] : 0) */
 int vlb_head_grad_combine(const void* d_text, const void* d_obj, const int32_t* code, void* dx, int B, int T, int R,
                           int S, int H, vlb_stream_t stream);

@@ -33,6 +33,9 @@ _SIGS = {
     "vlb_embed_fwd": "pppp" "pppp" "pll" "pll" "pll" "p" "pp" "ppp" "iiiiiii" "f" "fpu" "s",
     "vlb_embed_bwd": "pppp" "ppppp" "pppppp" "pll" "pll" "pll" "iiiiiii" "fpu" "i" "s",
     "vlb_gather_rows": "pppiis",
+    "vlb_scatter_rows": "pppiis",
+    "vlb_mlm_compact": "ppiiiipppppps",
+    "vlb_ce_fwd_bwd_compact": "pliipppfpps",
     "vlb_head_grad_combine": "ppppiiiiis",
     "vlb_relu_bwd_cast": "pppls",
     "vlb_dgelu_mul": "pppls",

@@ -469,6 +469,17 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const bf16_t* __restri
   }
 }
 
+// out[idx[i]] = src[i] for idx[i] >= 0 (rows of H bf16; rows of `out` that no index names keep their contents): the inverse of a
+// gather through the same index list (gradient of the compacted MLM rows back to their text positions).
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const bf16_t* __restrict__ src, const int32_t* __restrict__ idx, bf16_t* __restrict__ out,
+                                                           int n, int H) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= n) return;
+  const int r = idx[i];
+  if (r < 0) return;
+  for (int c = lane * 8; c < H; c += 512) *(uint4*)(out + (long)r * H + c) = *(const uint4*)(src + (long)i * H + c);
+}
+
 // dX[b,s] = (s<T ? d_text[b,s] : 0) + (row (b,s) is the j-th object ? d_obj[b,j] : 0)
 // (inverse of the text/object split at common/visual_linguistic_bert.py:146-166).
 __global__ __launch_bounds__(256) void head_grad_combine_kernel(const bf16_t* __restrict__ d_text, const bf16_t* __restrict__ d_obj,
@@ -652,6 +663,14 @@ extern "C" int vlb_gather_rows(const void* src, const int32_t* idx, void* out, i
   VLB_CHECK_ARG((H % 8) == 0, "vlb_gather_rows: H must be a multiple of 8");
   hipLaunchKernelGGL(gather_rows_kernel, dim3(vlb_cdiv(n, 4)), dim3(256), 0, stream, (const bf16_t*)src, idx, (bf16_t*)out, n, H);
   VLB_CHECK_LAUNCH("vlb_gather_rows");
+  return VLB_OK;
+}
+
+extern "C" int vlb_scatter_rows(const void* src, const int32_t* idx, void* out, int n, int H, hipStream_t stream) {
+  if (n <= 0) return VLB_OK;
+  VLB_CHECK_ARG(src && idx && out && (H % 8) == 0, "vlb_scatter_rows: bad argument (H must be a multiple of 8)");
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3(vlb_cdiv(n, 4)), dim3(256), 0, stream, (const bf16_t*)src, idx, (bf16_t*)out, n, H);
+  VLB_CHECK_LAUNCH("vlb_scatter_rows");
   return VLB_OK;
 }
 

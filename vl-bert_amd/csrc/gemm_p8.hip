@@ -55,6 +55,16 @@ __device__ __forceinline__ void p8_stage_read(f32x4& x0, f32x4& x1, uint32_t a0,
                : "=&v"(x0), "=&v"(x1) : "v"(a0), "v"(a1), "n"(OFF) : "memory");
 }
 
+// compile-time loop: f(integral_constant<int, I>) for I in [I0, N) -- `#pragma unroll` is a request the optimiser may decline
+// (it did, for the 20-round epilogues), and a run-time index into the accumulator array sends the whole array to scratch memory
+template <int I, int N, typename F>
+__device__ __forceinline__ void p8_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    p8_static_for<I + 1, N>(f);
+  }
+}
+
 __device__ __forceinline__ void p8_barrier() {
   asm volatile("" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -147,12 +157,14 @@ __device__ __forceinline__ void p8_drain(const GemmParams& p, f32x4 (&acc)[2 * F
                                          int lane, int tid, uint32_t seed) {
   constexpr int AH = 32 * FMH, NF = 2 * FMH;
   constexpr bool ALT = (KF == 0);
+  constexpr bool LNRES = (EPI == 6 || EPI == 7);
   constexpr int FPR = ALT ? 1 : KF;
   constexpr int ROUNDS = ALT ? 2 * NF : (NF + FPR - 1) / FPR;
   constexpr int PASSES = ALT ? 1 : 2 * FPR;
   constexpr bool SIDE = (EPI == 2 || EPI == 3 || EPI == 4 || EPI == 6 || EPI == 7);
-  constexpr bool LNRES = (EPI == 6 || EPI == 7);
   constexpr bool PRE_NEXT = SIDE && (PASSES <= 2);      // request the next round's side data one round ahead
+  // side rows requested at a time (register budget: 160 accumulators + gamma / beta / bias vectors leave room for 2-4 of them)
+  constexpr int SB = PRE_NEXT ? PASSES : (FMH == 5 ? 4 : PASSES);
   // Every lane-dependent constant below is derived from an OPAQUE copy of the thread index: the optimiser would otherwise hoist
   // these loop-invariant address computations above the K loop of the persistent tile loop, where their live ranges cost the
   // main loop the registers it needs (the 320-row instantiation spilled a DMA offset and drained the queue to reload it).
@@ -177,11 +189,14 @@ __device__ __forceinline__ void p8_drain(const GemmParams& p, f32x4 (&acc)[2 * F
     const float4 b0 = *(const float4*)(p.bias + n), b1 = *(const float4*)(p.bias + n + 4);
     b8[0] = b0.x; b8[1] = b0.y; b8[2] = b0.z; b8[3] = b0.w; b8[4] = b1.x; b8[5] = b1.y; b8[6] = b1.z; b8[7] = b1.w;
   }
+  // gamma / beta of the thread's 8 columns: resident for the whole tile, except in the instantiation with the least register
+  // headroom (320-row tile + dropout hash), which re-reads them per row group from L1
+  constexpr bool HOIST_GB = LNRES;
   float g8[8], be8[8];
   if constexpr (LNRES) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) g8[e] = be8[e] = 0.f;
-    if (full8) {
+    if (HOIST_GB && full8) {
       const float4 a0 = *(const float4*)(p.res_gamma + n), a1 = *(const float4*)(p.res_gamma + n + 4);
       const float4 c0 = *(const float4*)(p.res_beta + n), c1 = *(const float4*)(p.res_beta + n + 4);
       g8[0] = a0.x; g8[1] = a0.y; g8[2] = a0.z; g8[3] = a0.w; g8[4] = a1.x; g8[5] = a1.y; g8[6] = a1.z; g8[7] = a1.w;
@@ -208,29 +223,29 @@ __device__ __forceinline__ void p8_drain(const GemmParams& p, f32x4 (&acc)[2 * F
     }
     return sd;
   };
-  uint4 side[2][PASSES];
+  uint4 side[2][SB];
   if constexpr (PRE_NEXT) {
 #pragma unroll
     for (int pp = 0; pp < PASSES; ++pp) side[0][pp] = load_side(0, pp);
   }
+  p8_static_for<0, ROUNDS>([&](auto r_c) {
+    constexpr int r = decltype(r_c)::value;
+    if constexpr (SIDE && !PRE_NEXT) {      // first batch of this round: in flight under the slab writes and the barrier
 #pragma unroll
-  for (int r = 0; r < ROUNDS; ++r) {
-    if constexpr (SIDE && !PRE_NEXT) {
-#pragma unroll
-      for (int pp = 0; pp < PASSES; ++pp) side[r & 1][pp] = load_side(r, pp);
+      for (int pp = 0; pp < SB; ++pp) side[0][pp] = load_side(r, pp);
     }
     if (!ALT || wm == (r & 1)) {
-#pragma unroll
-      for (int f = 0; f < FPR; ++f) {
-        const int R = ALT ? (r >> 1) : (r * FPR + f);
-        if (R < NF) {
+      p8_static_for<0, FPR>([&](auto f_c) {
+        constexpr int f = decltype(f_c)::value;
+        constexpr int R = ALT ? (r >> 1) : (r * FPR + f);
+        if constexpr (R < NF) {
           const uint32_t o = (uint32_t)(f * 32 * 1024);
-          p8_lds_write_f4<0>(wr[0] + o, acc[R < NF ? R : 0][0]);
-          p8_lds_write_f4<0>(wr[1] + o, acc[R < NF ? R : 0][1]);
-          p8_lds_write_f4<0>(wr[2] + o, acc[R < NF ? R : 0][2]);
-          p8_lds_write_f4<0>(wr[3] + o, acc[R < NF ? R : 0][3]);
+          p8_lds_write_f4<0>(wr[0] + o, acc[R][0]);
+          p8_lds_write_f4<0>(wr[1] + o, acc[R][1]);
+          p8_lds_write_f4<0>(wr[2] + o, acc[R][2]);
+          p8_lds_write_f4<0>(wr[3] + o, acc[R][3]);
         }
-      }
+      });
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     p8_barrier();
@@ -242,6 +257,12 @@ __device__ __forceinline__ void p8_drain(const GemmParams& p, f32x4 (&acc)[2 * F
     }
 #pragma unroll
     for (int pp = 0; pp < PASSES; ++pp) {
+      if constexpr (SIDE && !PRE_NEXT) {
+        if (pp > 0 && pp % SB == 0) {       // next batch of side rows
+#pragma unroll
+          for (int k = 0; k < SB; ++k) side[0][k] = load_side(r, pp + k);
+        }
+      }
       if (!frag_valid(r, pp)) continue;
       const int m = row_of(r, pp);
       f32x4 x0, x1;
@@ -249,9 +270,15 @@ __device__ __forceinline__ void p8_drain(const GemmParams& p, f32x4 (&acc)[2 * F
       if (m < p.M && n < p.N) {
         float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
         if (full8) {
-          const uint4 sd = SIDE ? side[r & 1][pp] : make_uint4(0, 0, 0, 0);
+          const uint4 sd = SIDE ? (PRE_NEXT ? side[r & 1][pp] : side[0][pp % SB]) : make_uint4(0, 0, 0, 0);
           if constexpr (LNRES) {
             const float2 ms = *(const float2*)(p.res_stats + 2 * (long)m);
+            if constexpr (!HOIST_GB) {
+              const float4 a0 = *(const float4*)(p.res_gamma + n), a1 = *(const float4*)(p.res_gamma + n + 4);
+              const float4 c0 = *(const float4*)(p.res_beta + n), c1 = *(const float4*)(p.res_beta + n + 4);
+              g8[0] = a0.x; g8[1] = a0.y; g8[2] = a0.z; g8[3] = a0.w; g8[4] = a1.x; g8[5] = a1.y; g8[6] = a1.z; g8[7] = a1.w;
+              be8[0] = c0.x; be8[1] = c0.y; be8[2] = c0.z; be8[3] = c0.w; be8[4] = c1.x; be8[5] = c1.y; be8[6] = c1.z; be8[7] = c1.w;
+            }
             p8_epilogue8<EPI>(p, v, b8, m, n, seed, sd, ms, g8, be8);
           } else {
             p8_epilogue8<EPI>(p, v, b8, m, n, seed, sd);
@@ -267,7 +294,7 @@ __device__ __forceinline__ void p8_drain(const GemmParams& p, f32x4 (&acc)[2 * F
       }
     }
     if (r + 1 < ROUNDS) p8_barrier();      // the slab is free for the next round
-  }
+  });
 }
 
 // FMH: 16-row accumulator fragments per wave per tile half (4 -> 256-row tiles, 5 -> 320-row tiles)

@@ -56,11 +56,18 @@ __global__ void count_labels_kernel(const int64_t* __restrict__ labels, int n, f
 
 // One block per row.  logits: bf16 [rows, ld] (columns >= V are padding and are zeroed).
 // out: loss_sum += row_loss / n_valid ;  logits <- dlogits * (gscale / n_valid).
+// Two-group form (compacted MLM rows of the multitask wrapper): rows [0, *n_valid) belong to group 0 (mean over n_valid ->
+// loss_out), the rows behind them to group 1 (mean over *n_valid2 -> loss_out2); n_valid2 == nullptr: one group.
 __global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(bf16_t* __restrict__ logits, long ld, int V, const int64_t* __restrict__ labels,
                                                          const float* __restrict__ n_valid, float gscale, float* __restrict__ loss_out,
-                                                         bf16_t* __restrict__ logits_copy, long ldcopy) {
+                                                         bf16_t* __restrict__ logits_copy, long ldcopy,
+                                                         const float* __restrict__ n_valid2 = nullptr, float* __restrict__ loss_out2 = nullptr) {
   __shared__ float sh[16];
   const int row = blockIdx.x;
+  if (n_valid2 && (float)row >= *n_valid) {
+    n_valid = n_valid2;
+    loss_out = loss_out2;
+  }
   bf16_t* x = logits + (long)row * ld;
   const long label = labels[row];
   const int ldv = (int)ld;
@@ -107,6 +114,100 @@ __global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(bf16_t* __restrict__ lo
     }
     *(uint4*)(x + c) = make_uint4(o[0], o[1], o[2], o[3]);
   }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// MLM head compaction.  ~85 % of the text positions carry no label (ignore_index -1): their logits rows are never read by
+// the loss and their d(logits) rows are exactly zero, so transform -> LayerNorm -> decoder (modeling.py:439-472) and the whole
+// backward of the head only need the LABELLED rows.  This kernel builds the (stable, ascending) list of labelled positions:
+//   sel_pos[k]  = position i in [0, n) of the k-th labelled row (-1 beyond the count)
+//   sel_src[k]  = src_rows[i]: its row in the packed encoder output (-1 -> zero row)
+//   labels_c[k] = its label (-1 beyond the count)
+//   counts[0] = labelled rows among positions [0, n_split) (image-caption samples), counts[1] = among [n_split, n) (text-only
+//   auxiliary samples of the multitask wrapper); *overflow |= (count > cap): the rows that did not fit are NOT trained on, so the
+//   host treats the flag as an error (engine.loss_values) -- capacity is a contract with the data pipeline (masking probability).
+// One 1024-thread block: every thread owns a contiguous run of positions, block scan of the run counts.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void mlm_compact_kernel(const int64_t* __restrict__ labels, const int32_t* __restrict__ src_rows, int n,
+                                                           int n_split, int V, int cap, int32_t* __restrict__ sel_pos,
+                                                           int32_t* __restrict__ sel_src, int64_t* __restrict__ labels_c,
+                                                           float* __restrict__ count0, float* __restrict__ count1,
+                                                           int32_t* __restrict__ overflow) {
+  __shared__ int wsum[16];
+  __shared__ int total_s, n0_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per = (n + 1023) / 1024, lo = tid * per, hi = min(n, lo + per);
+  int c = 0, c0 = 0;
+  for (int i = lo; i < hi; ++i) {
+    const bool lab = labels[i] >= 0 && labels[i] < V;
+    c += lab;
+    c0 += lab && i < n_split;
+  }
+  // inclusive scan of c across the block
+  int incl = c;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  const float f0 = wave_sum((float)c0);
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int w = 0; w < 16; ++w) { const int t = wsum[w]; wsum[w] = run; run += t; }
+    total_s = run;
+    n0_s = 0;
+  }
+  __syncthreads();
+  if (lane == 0 && f0 != 0.f) atomicAdd(&n0_s, (int)f0);
+  __syncthreads();
+  int k = wsum[wave] + incl - c;      // exclusive prefix of this thread's run
+  for (int i = lo; i < hi; ++i) {
+    const long lb = labels[i];
+    if (lb >= 0 && lb < V) {
+      if (k < cap) {
+        sel_pos[k] = i;
+        sel_src[k] = src_rows[i];
+        labels_c[k] = lb;
+      }
+      ++k;
+    }
+  }
+  const int total = total_s;
+  for (int q = total + tid; q < cap; q += 1024) {   // padding behind the labelled rows
+    sel_pos[q] = -1;
+    sel_src[q] = -1;
+    labels_c[q] = -1;
+  }
+  if (tid == 0) {
+    const int kept = min(total, cap), n0 = min(n0_s, kept);
+    *count0 = (float)n0;
+    *count1 = (float)(kept - n0);
+    if (total > cap) *overflow = 1;
+  }
+}
+
+extern "C" int vlb_mlm_compact(const int64_t* labels, const int32_t* src_rows, int n, int n_split, int V, int cap, int32_t* sel_pos,
+                               int32_t* sel_src, int64_t* labels_c, float* count0, float* count1, int32_t* overflow, hipStream_t stream) {
+  VLB_CHECK_ARG(labels && src_rows && sel_pos && sel_src && labels_c && count0 && count1 && overflow, "vlb_mlm_compact: null argument");
+  VLB_CHECK_ARG(n > 0 && cap > 0 && n_split >= 0 && n_split <= n, "vlb_mlm_compact: bad sizes");
+  hipLaunchKernelGGL(mlm_compact_kernel, dim3(1), dim3(1024), 0, stream, labels, src_rows, n, n_split, V, cap, sel_pos, sel_src, labels_c,
+                     count0, count1, overflow);
+  VLB_CHECK_LAUNCH("vlb_mlm_compact");
+  return VLB_OK;
+}
+
+// CE forward + backward on COMPACTED rows: counts are given (vlb_mlm_compact wrote them), two groups with their own means.
+extern "C" int vlb_ce_fwd_bwd_compact(void* logits, long ld, int rows, int V, const int64_t* labels_c, const float* count0,
+                                      const float* count1, float gscale, float* loss_out0, float* loss_out1, hipStream_t stream) {
+  if (rows <= 0) return VLB_OK;
+  VLB_CHECK_ARG(logits && labels_c && count0 && count1 && loss_out0 && loss_out1, "vlb_ce_fwd_bwd_compact: null argument");
+  VLB_CHECK_ARG(ld >= V && (ld % 8) == 0, "vlb_ce_fwd_bwd_compact: ld=%ld must be >= V=%d and a multiple of 8", ld, V);
+  hipLaunchKernelGGL(ce_fwd_bwd_kernel, dim3(rows), dim3(256), 0, stream, (bf16_t*)logits, ld, V, labels_c, count0, gscale, loss_out0,
+                     (bf16_t*)nullptr, 0L, count1, loss_out1);
+  VLB_CHECK_LAUNCH("vlb_ce_fwd_bwd_compact");
+  return VLB_OK;
 }
 
 // row validity for the soft-label loss: valid[r] = |sum_c t[r,c] - 1| < 0.1 ; counts[0] += #valid

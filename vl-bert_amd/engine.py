@@ -300,6 +300,23 @@ class PretrainEngine:
             self.rel_logits = zb(B, 64)                   # 2 logits, row padded to 64 (pad columns stay zero)
             self.rel_logits_copy = zb(B, 64) if keep_logits else None
         self.mlm_logits_copy = zb(BT, self.Vp) if keep_logits else None
+        # MLM head compaction (DESIGN.md "MLM head"): ~85 % of the text positions carry no label -- their logits are never read by the
+        # loss and their d(logits) rows are exactly zero -- so transform -> LayerNorm -> decoder and the head's whole backward run on
+        # the labelled rows only, gathered into the first `mlm_cap` rows of the same buffers.  Capacity is a contract with the data
+        # pipeline (BERT masking labels 15 % of the valid tokens): 25 % of the B*T positions; a batch that exceeds it raises (the
+        # device flag is checked at loss_values(); labels handed over as CPU tensors are counted exactly and such a batch simply
+        # takes the full path).  Off with keep_logits (the module mirrors return every logit) and in module-API mode.
+        import os as _os1
+        cap = min(self.BTp, max(256, _ru(int(math.ceil(0.25 * BT)), 256)))
+        want = _os1.environ.get("VLB_MLM_COMPACT", "1") != "0" and not keep_logits and not core and cap < BT
+        self.mlm_cap = cap if want else None
+        self._mlm_compact_now = want
+        if want:
+            self.sel_pos = torch.full((cap,), -1, dtype=torch.int32, device=d)
+            self.sel_src = torch.full((cap,), -1, dtype=torch.int32, device=d)
+            self.labels_c = torch.full((cap,), -1, dtype=torch.int64, device=d)
+            self.mlm_overflow = torch.zeros((1,), dtype=torch.int32, device=d)
+            self.d_text_out_c = zb(cap, H)
         self.mvrc_logits_copy = zb(BR, self.Cp) if keep_logits else None
 
         # backward scratch
@@ -419,6 +436,11 @@ class PretrainEngine:
         (box_mask = boxes[:,:,0] > -1.5 ; text_mask = text > 0).  `relationship_label` is only read
         with ModelConfig(with_rel_loss=True) (WITH_REL_LOSS is false in the north-star configuration)."""
         B = self.B
+        if self.mlm_cap is not None:    # labels still on the host: count them exactly (no sync) and take the full path if they do not fit
+            self._mlm_compact_now = True
+            if not mlm_labels.is_cuda and (aux_mlm_labels is None or not aux_mlm_labels.is_cuda):
+                n_lab = int((mlm_labels >= 0).sum()) + (int((aux_mlm_labels >= 0).sum()) if aux_mlm_labels is not None else 0)
+                self._mlm_compact_now = n_lab <= self.mlm_cap
         if self.vision is not None:     # e2e: `image` [B,3,H,W] fp32 (mean-subtracted, collate_batch.py), boxes [B,R,4]; features come from the CNN
             if image is None:
                 raise ValueError("engine built with e2e=True needs image=")
@@ -552,7 +574,14 @@ class PretrainEngine:
                               self.ST2[l])
         # --- heads ---------------------------------------------------------------------------------------
         xl = self.X[L]
-        ops.gather_rows(xl, self.lay["text_rows"].view(-1), self.text_out)
+        compact = self._mlm_compact_now and self.with_heads
+        nr = self.mlm_cap if compact else self.BT          # rows the MLM head runs on
+        if compact:
+            ops.mlm_compact(self.in_mlm_labels.view(-1), self.lay["text_rows"].view(-1), self.B * self.T, V, self.sel_pos, self.sel_src,
+                            self.labels_c, self.counts[0:1], self.counts[2:3], self.mlm_overflow)
+            ops.gather_rows(xl, self.sel_src, self.text_out[:nr])
+        else:
+            ops.gather_rows(xl, self.lay["text_rows"].view(-1), self.text_out)
         ops.gather_rows(xl, self.lay["obj_rows"].view(-1)[:self.BR], self.obj_out)
         if cfg.with_pooler:       # BertPooler: tanh(dense(first token)) for the image-caption samples; A operand = strided view of X[L]
             x0 = xl.view(Bt, S * H)[:self.B, :H]
@@ -563,11 +592,11 @@ class PretrainEngine:
             pr = "vlbert.relationsip_head.caption_image_relationship."
             ops.gemm_nt(self.pooled, w16[pr + "weight"], self.rel_logits[:, :2], bias=w32[pr + "bias"])
         pm = "vlbert.mlm_head.predictions."
-        ops.gemm_nt(self.text_out, w16[pm + "transform.dense.weight"], self.mlm_g, bias=w32[pm + "transform.dense.bias"],
-                    act=ops.ACT_GELU_D, pre=self.mlm_u)
-        ops.layernorm_fwd(self.mlm_g, w32[pm + "transform.LayerNorm.weight"], w32[pm + "transform.LayerNorm.bias"], self.mlm_h,
-                          self.st_mlm)
-        ops.gemm_nt(self.mlm_h, w16["vlbert.word_embeddings.weight"], self.mlm_logits[:, :V], bias=w32[pm + "bias"])
+        ops.gemm_nt(self.text_out[:nr], w16[pm + "transform.dense.weight"], self.mlm_g[:nr], bias=w32[pm + "transform.dense.bias"],
+                    act=ops.ACT_GELU_D, pre=self.mlm_u[:nr])
+        ops.layernorm_fwd(self.mlm_g[:nr], w32[pm + "transform.LayerNorm.weight"], w32[pm + "transform.LayerNorm.bias"], self.mlm_h[:nr],
+                          self.st_mlm[:nr])
+        ops.gemm_nt(self.mlm_h[:nr], w16["vlbert.word_embeddings.weight"], self.mlm_logits[:nr, :V], bias=w32[pm + "bias"])
         ops.gemm_nt(self.obj_out, w16["vlbert.mvrc_head.transform.dense.weight"], self.mvrc_g,
                     bias=w32["vlbert.mvrc_head.transform.dense.bias"], act=ops.ACT_GELU_D, pre=self.mvrc_u)
         ops.gemm_nt(self.mvrc_g, w16["vlbert.mvrc_head.region_cls_pred.weight"], self.mvrc_logits[:, :C],
@@ -584,11 +613,15 @@ class PretrainEngine:
             self.mvrc_logits.copy_(self.mvrc_logits_copy)
             losses, mcopy, vcopy = torch.zeros_like(self.losses), None, None
         nw = B * T     # rows of the image-caption samples; the aux rows follow and get their own mean (multitask.py:224-246)
-        ops.ce_fwd_bwd(self.mlm_logits[:nw], V, self.in_mlm_labels.view(-1)[:nw], self.counts[0:1], losses[0:1], gscale=gscale,
-                       logits_copy=mcopy[:nw] if mcopy is not None else None)
-        if Ba:
-            ops.ce_fwd_bwd(self.mlm_logits[nw:], V, self.in_mlm_labels.view(-1)[nw:], self.counts[2:3], losses[2:3],
-                           gscale=gscale, logits_copy=mcopy[nw:] if mcopy is not None else None)
+        if self._mlm_compact_now:      # labelled rows only: caption rows first, then the aux rows, each group with its own mean
+            ops.ce_fwd_bwd_compact(self.mlm_logits[:self.mlm_cap], V, self.labels_c, self.counts[0:1], self.counts[2:3], losses[0:1],
+                                   losses[2:3], gscale=gscale)
+        else:
+            ops.ce_fwd_bwd(self.mlm_logits[:nw], V, self.in_mlm_labels.view(-1)[:nw], self.counts[0:1], losses[0:1], gscale=gscale,
+                           logits_copy=mcopy[:nw] if mcopy is not None else None)
+            if Ba:
+                ops.ce_fwd_bwd(self.mlm_logits[nw:], V, self.in_mlm_labels.view(-1)[nw:], self.counts[2:3], losses[2:3],
+                               gscale=gscale, logits_copy=mcopy[nw:] if mcopy is not None else None)
         ops.soft_ce_fwd_bwd(self.mvrc_logits, C, self.in_mvrc_labels.view(self.BR, C), self.mvrc_tsum, self.counts[1:2],
                             losses[1:2], gscale=gscale, logits_copy=vcopy)
         if self.cfg.with_rel_loss:     # F.cross_entropy(relationship_logits, relationship_label) (resnet_vlbert_for_pretraining.py:160-161)
@@ -647,16 +680,24 @@ class PretrainEngine:
         if self.with_heads:
             # --- MLM head ------------------------------------------------------------------------------------
             pm = "vlbert.mlm_head.predictions."
-            dlog = self.mlm_logits                       # [BT, Vp], pad columns zero
-            self._wgrad(dlog[:, :V], self.mlm_h, g32["vlbert.word_embeddings.weight"], g32[pm + "bias"], self.tG_bt, self.tA_bt, BTp)
-            ops.gemm_nt_splitk(dlog, wT["vlbert.word_embeddings.weight"], self.d_mlm_h, workspace=self.wg_ws_main)
-            ops.layernorm_bwd(self.d_mlm_h, self.mlm_g, self.st_mlm, w32[pm + "transform.LayerNorm.weight"], dx=self.d_mlm_g,
+            compact = self._mlm_compact_now and not self.core
+            nr = self.mlm_cap if compact else self.BT
+            nrp = _ru(nr, 64)
+            dlog = self.mlm_logits[:nr]                  # [rows, Vp], pad columns zero
+            self._wgrad(dlog[:, :V], self.mlm_h[:nr], g32["vlbert.word_embeddings.weight"], g32[pm + "bias"], self.tG_bt, self.tA_bt, nrp)
+            ops.gemm_nt_splitk(dlog, wT["vlbert.word_embeddings.weight"], self.d_mlm_h[:nr], workspace=self.wg_ws_main)
+            ops.layernorm_bwd(self.d_mlm_h[:nr], self.mlm_g[:nr], self.st_mlm[:nr], w32[pm + "transform.LayerNorm.weight"], dx=self.d_mlm_g[:nr],
                               dgamma=g32[pm + "transform.LayerNorm.weight"], dbeta=g32[pm + "transform.LayerNorm.bias"],
                               workspace=self.ln_ws)
-            ops.mul_bf16(self.d_mlm_g, self.mlm_u, self.d_mlm_u)
-            self._wgrad(self.d_mlm_u, self.text_out, g32[pm + "transform.dense.weight"], g32[pm + "transform.dense.bias"], self.tG_bt,
-                        self.tA_bt, BTp)
-            ops.gemm_nt(self.d_mlm_u, wT[pm + "transform.dense.weight"], self.d_text_out)
+            ops.mul_bf16(self.d_mlm_g[:nr], self.mlm_u[:nr], self.d_mlm_u[:nr])
+            self._wgrad(self.d_mlm_u[:nr], self.text_out[:nr], g32[pm + "transform.dense.weight"], g32[pm + "transform.dense.bias"], self.tG_bt,
+                        self.tA_bt, nrp)
+            if compact:      # gradient of the labelled rows back to their text positions; every other position gets exactly zero
+                ops.gemm_nt(self.d_mlm_u[:nr], wT[pm + "transform.dense.weight"], self.d_text_out_c)
+                self.d_text_out.zero_()
+                ops.scatter_rows(self.d_text_out_c, self.sel_pos, self.d_text_out)
+            else:
+                ops.gemm_nt(self.d_mlm_u, wT[pm + "transform.dense.weight"], self.d_text_out)
             # --- MVRC head -----------------------------------------------------------------------------------
             dlog2 = self.mvrc_logits                     # [BR, Cp]
             self._wgrad(dlog2[:, :C], self.mvrc_g, g32["vlbert.mvrc_head.region_cls_pred.weight"],
@@ -1000,6 +1041,10 @@ class PretrainEngine:
     # results (host side, sync) -- used by tests / API parity, not by the timed loop
     # ------------------------------------------------------------------------------------------
     def loss_values(self):
+        if self.mlm_cap is not None and int(self.mlm_overflow.cpu()) != 0:
+            raise RuntimeError("MLM head compaction: a batch carried more than mlm_cap = %d labelled text positions (the excess was "
+                               "not trained on).  Build the engine with VLB_MLM_COMPACT=0 or hand the labels over as CPU tensors "
+                               "(they are then counted exactly and oversize batches take the full path)." % self.mlm_cap)
         l = self.losses.cpu()
         out = dict(mlm_loss=float(l[0]), mvrc_loss=float(l[1]), relationship_loss=float(l[3]), loss=float(l[0] + l[1] + l[2] + l[3]))
         if self.Ba:

@@ -292,6 +292,24 @@ def ce_fwd_bwd(logits, V, labels, counts, loss_out, gscale=1.0, logits_copy=None
               float(gscale), _p(loss_out, torch.float32), _p(logits_copy, BF16), _ld(logits_copy), _stream())
 
 
+def mlm_compact(labels, src_rows, n_split, V, sel_pos, sel_src, labels_c, count0, count1, overflow):
+    """Lists the labelled positions (vlb_mlm_compact); capacity = sel_pos.numel()."""
+    _lib.call("vlb_mlm_compact", _p(labels, torch.int64), _p(src_rows, torch.int32), labels.numel(), int(n_split), int(V), sel_pos.numel(),
+              _p(sel_pos, torch.int32), _p(sel_src, torch.int32), _p(labels_c, torch.int64), _p(count0, torch.float32),
+              _p(count1, torch.float32), _p(overflow, torch.int32), _stream())
+
+
+def ce_fwd_bwd_compact(logits, V, labels_c, count0, count1, loss_out0, loss_out1, gscale=1.0):
+    _lib.call("vlb_ce_fwd_bwd_compact", _p(logits, BF16), _ld(logits), logits.shape[0], V, _p(labels_c, torch.int64),
+              _p(count0, torch.float32), _p(count1, torch.float32), float(gscale), _p(loss_out0, torch.float32),
+              _p(loss_out1, torch.float32), _stream())
+
+
+def scatter_rows(src, idx, out):
+    _lib.call("vlb_scatter_rows", _p(src, BF16), _p(idx, torch.int32), _p(out, BF16), idx.numel(), src.shape[1], _stream())
+    return out
+
+
 def soft_ce_fwd_bwd(logits, C, target, tsum, counts, loss_out, gscale=1.0, logits_copy=None):
     rows = logits.shape[0]
     _lib.call("vlb_soft_ce_fwd_bwd", _p(logits, BF16), _ld(logits), rows, C, _p(target, torch.float32), _ld(target),
