@@ -901,8 +901,10 @@ def test_mlm_head_compaction_matches_full_path():
         print("compaction %s: full %.7f compact %.7f" % (k, full[0][k], comp[0][k]))
         assert abs(full[0][k] - comp[0][k]) <= 1e-5 * max(1.0, abs(full[0][k])), k
     assert abs(full[1] - comp[1]) <= 1e-5 * full[1]
-    worst = max((rel_fro(comp[2][n], g), n) for n, g in full[2].items() if float(g.norm()) > 1e-7 * full[1])
-    print("compaction: worst per-tensor rel-fro gradient difference %.3e (%s)" % worst)
+    # per tensor: |difference| against max(|tensor|, 1e-3 of the global norm) -- gradients that are ~0 by construction (the key bias:
+    # softmax is invariant to it) consist of fp32 summation-order noise in BOTH paths and carry no signal
+    worst = max((float((comp[2][n].double() - g.double()).norm()) / max(float(g.double().norm()), 1e-3 * full[1]), n) for n, g in full[2].items())
+    print("compaction: worst per-tensor gradient difference %.3e (%s)" % worst)
     assert worst[0] < 2e-4, worst
     n_lab = int((batch[4] >= 0).sum()) + int((aux[1] >= 0).sum())
     assert int(comp[3].counts[0] + comp[3].counts[2]) == n_lab and n_lab < comp[3].mlm_cap

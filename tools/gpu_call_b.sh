@@ -1,7 +1,7 @@
 #!/bin/bash
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
-O=gpurun_out/r2c; mkdir -p $O
+O=gpurun_out/r2d; mkdir -p $O
 echo "== p8 check"; timeout 240 python tools/p8_check.py check > $O/p8_check.log 2>&1; RC=$?; echo "p8 check rc=$RC"; grep -v " ok$" $O/p8_check.log | tail -12
 [ $RC -eq 0 ] || exit 0
 echo "== p8 bench"; timeout 300 python tools/p8_check.py bench 256 > $O/p8_bench.log 2>&1; echo "rc=$?"; cat $O/p8_bench.log
