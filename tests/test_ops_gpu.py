@@ -331,8 +331,9 @@ def test_wgrad_slab_splitk(ops, M, N, K, ws):
         assert float(C[:, N:].abs().max()) == 0.0
 
 
+# (the last four shapes -- reduction a multiple of 128 rows, enough 256x256 tiles x K slices -- run on the large-tile core, gemm_tn8.hip)
 @pytest.mark.parametrize("R,Mo,No", [(1000, 192, 320), (2048, 768, 768), (300, 70, 200), (101, 1601, 128), (6464, 2304, 768),
-                                     (64, 128, 128), (4096, 30522, 64)])
+                                     (64, 128, 128), (4096, 30522, 64), (4096, 768, 768), (2560, 1000, 520), (12928, 768, 3072)])
 def test_wgrad_tn_lds_transpose_reads(ops, R, Mo, No):
     """dW += dY^T X and db += colsum(dY) straight from row-major operands (ds_read_b64_tr_b16 fragments)."""
     lda, ldb = (Mo + 63) // 64 * 64, (No + 7) // 8 * 8

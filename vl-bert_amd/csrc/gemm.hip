@@ -1316,7 +1316,11 @@ static int wgrad_pick_splits(int M, int N, int K, long workspace_floats) {
 
 extern "C" long vlb_wgrad_workspace_floats(int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
-  const int sp = wgrad_pick_splits(M, N, K, 1L << 40);
+  int sp = wgrad_pick_splits(M, N, K, 1L << 40);
+  if (K >= 256 && (K % 128) == 0) {     // the large-tile core may want more slices
+    const int sp8 = vlb_tn8_pick_splits(M, N, K);
+    if (sp8 > sp) sp = sp8;
+  }
   return sp > 1 ? (long)sp * M * ((N + 3) / 4 * 4) : 0;
 }
 
@@ -1393,6 +1397,24 @@ static int wgrad_tn_impl(const void* A, long lda, const void* B, long ldb, float
   VLB_CHECK_ARG(A && B && C, "vlb_wgrad_tn_bf16: null operand");
   VLB_CHECK_ARG((lda % 8) == 0 && (ldb % 8) == 0 && (ldc % 4) == 0 && lda >= 8 && ldb >= 8, "vlb_wgrad_tn_bf16: bad leading dimensions");
   VLB_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "vlb_wgrad_tn_bf16: operands must be 16-byte aligned");
+  {   // large-tile core (gemm_tn8.hip) when the reduction is a whole number of 128-row units and there is enough work for 256x256 tiles
+    GemmParams q = {};
+    q.A = (const bf16_t*)A; q.lda = lda; q.B = (const bf16_t*)B; q.ldb = ldb;
+    q.M = Mo; q.N = No; q.K = R;
+    const int used = vlb_gemm_tn8_try(q, C, ldc, colsum, workspace, workspace_floats, accumulate, rowscale != nullptr, stream);
+    if (used < 0) return used;
+    if (used > 0) {
+      if (used > 1 || rowscale) {
+        const long ldw8 = (No + 3) / 4 * 4;
+        long blocks = ((long)Mo * (ldw8 / 4) + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)blocks), dim3(256), 0, stream, workspace, (long)Mo * ldw8, used, C, ldc, Mo, No,
+                           (int)ldw8, (bf16_t*)nullptr, 0L, accumulate, rowscale);
+        VLB_CHECK_LAUNCH("vlb_wgrad_tn_bf16(tn8 reduce)");
+      }
+      return VLB_OK;
+    }
+  }
   const int Rp = vlb_cdiv(R, 64) * 64;
   const int splits = wgrad_pick_splits(Mo, No, Rp, workspace ? workspace_floats : 0);
   const int ktiles = Rp / 64;

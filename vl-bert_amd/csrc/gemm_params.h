@@ -35,3 +35,10 @@ struct GemmParams {
 // gemm_p8.hip: 256x256 / 320x256 tiles, 8-phase schedule.  Returns 1 when it took the call, 0 when the shape / epilogue /
 // alignment is outside what it covers (the caller then uses the 128x128 kernel), < 0 on error.
 int vlb_gemm_p8_try(GemmParams& p, hipStream_t stream);
+
+// gemm_tn8.hip: weight gradients C[Mo,No] (fp32) (+)= A[R,Mo]^T B[R,No] with 256x256 tiles, 8-phase schedule, slab split-K.
+// Returns the number of K slices it used (>= 1; > 1 or force_slab: the partial tiles are in `workspace`, slice stride Mo * round4(No),
+// and the caller runs the slab reduce), 0 when the shape is outside what it covers, < 0 on error.
+int vlb_gemm_tn8_try(GemmParams& p, float* C, long ldc, float* colsum, float* workspace, long workspace_floats, int accumulate,
+                     bool force_slab, hipStream_t stream);
+int vlb_tn8_pick_splits(int Mo, int No, int R);

@@ -1,0 +1,395 @@
+// bf16 "TN" GEMM for weight gradients on gfx950 (CDNA4), large-tile core:
+//     C[Mo, No] (fp32) (+)= A[R, Mo]^T . B[R, No]        (reduction over the R rows; autograd's grad_output.t().mm(input))
+// Same machine as gemm_p8.hip -- one persistent 8-wave workgroup per CU, 256 x 256 output tile, 64 reduction rows per K tile,
+// two K-tile buffers of four 16-KiB half-images [A0 | A1 | B0 | B1] filled by LDS-DMA one half-image per phase and retired by a
+// counted vmcnt, 4 quadrant phases per K tile with the two wave groups one segment apart -- with the two differences a
+// row-reduction needs:
+//   * operands are consumed as the forward / backward passes left them (row-major [R, cols]); a half-image is [64 rows][128
+//     columns] (256-B rows), and the MFMA fragments (8 consecutive REDUCTION rows of one column per lane) come out of it through
+//     the LDS transpose read ds_read_b64_tr_b16 (two per fragment), with the 32-B column blocks XOR-swizzled by
+//     f(row) = (row & 3) | ((row >> 3) & 1) << 2 on the DMA source address (layout and conflict analysis: gemm_tn_bf16_kernel);
+//   * few output tiles and a very long reduction: the work items of a launch are (tile, K slice) pairs, every slice writes its fp32
+//     partial tile to a slab (plain 16-B stores) and a streaming reduce adds the slabs (gemm.hip: splitk_reduce_kernel).  Items
+//     are ordered slice-major (all tiles of a slice are concurrent and share their operand rows in L2).
+// The column sums of A (bias gradients) are accumulated by the wn = 0 waves of the tile_n = 0 tiles from the A fragments with
+// v_dot2c_f32_bf16 behind the MFMAs of the phase that holds them.
+#include <math.h>
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "gemm_params.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+
+template <int OFF>
+__device__ __forceinline__ void tn8_tr_read(s16x4& dst, uint32_t vaddr) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(vaddr), "n"(OFF));
+}
+
+__device__ __forceinline__ void tn8_barrier() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+__device__ __forceinline__ bf16x8 tn8_frag(s16x4 lo, s16x4 hi) {
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+// OUT: 1 fp32 store (slab slice, or overwrite) | 3 fp32 accumulate into C
+template <int OUT>
+__global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(const GemmParams p, float* __restrict__ colsum, int nsplit, int kt_per_split) {
+  constexpr int HB = 64 * 256;                  // bytes of a half-image: 64 reduction rows x 128 columns
+  constexpr int OFF_A0 = 0, OFF_A1 = HB, OFF_B0 = 2 * HB, OFF_B1 = 3 * HB;
+  constexpr int BUF = 4 * HB;                   // one K tile = 64 KiB
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int ntile = p.ntm * p.ntn;
+  const int nitems = ntile * nsplit;
+  const int nk_all = p.K >> 6;                  // K tiles in the whole reduction (p.K = R, a multiple of 128)
+  if ((int)blockIdx.x >= nitems) return;
+
+  // item -> (tile_m, tile_n, K-tile range): slice-major; inside a slice the tiles are walked in groups of `tile_group` tile rows,
+  // column-major inside a group (near-square patches share operand panels in L2)
+  auto item_of = [&](int w, int& m0, int& n0, int& kt0, int& nk) {
+    const int sp = w / ntile, t = w - sp * ntile;
+    const int gm = p.tile_group, per_group = gm * p.ntn, gid = t / per_group, first = gid * gm;
+    const int gsz = min(p.ntm - first, gm), rem = t - gid * per_group;
+    m0 = (first + rem % gsz) * 256;
+    n0 = (rem / gsz) * 256;
+    kt0 = sp * kt_per_split;
+    nk = min(nk_all - kt0, kt_per_split);       // even, >= 2 (host guarantees)
+  };
+
+  // ---------------- producer ----------------
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7FFFFFFF, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, 0x7FFFFFFF, 0x00020000);
+  // chunk P = it*512 + tid of a half-image: row = P >> 4 = it*32 + (tid >> 4), physical 16-B chunk c = P & 15; physical 32-B block
+  // c >> 1 holds logical block (c >> 1) ^ f(row), f(row) = (row & 3) | ((row >> 3) & 1) << 2 -- independent of `it`
+  const int ldaB = (int)p.lda * 2, ldbB = (int)p.ldb * 2;
+  const int srow = tid >> 4, sc = tid & 15;
+  const int sf = (srow & 3) | (((srow >> 3) & 1) << 2);
+  const int lc = ((((sc >> 1) ^ sf) << 1) | (sc & 1)) * 8;      // logical column offset inside the 128-wide half-image
+  const int rowA = srow * ldaB, rowB = srow * ldbB;
+  int w_p = blockIdx.x, kt_p = 0, nk_p = 0, kt0_p = 0, tiles_issued = 0, pm0 = 0, pn0 = 0;
+  bool live = true;
+  auto setup = [&](int w) { item_of(w, pm0, pn0, kt0_p, nk_p); };
+  auto stage = [&](auto which_c, auto buf_c) {
+    constexpr int WHICH = decltype(which_c)::value, B_ = decltype(buf_c)::value;
+    if (!live) return;
+    const int kt = kt0_p + kt_p;
+    if constexpr (WHICH < 2) {
+      char* dst = smem + B_ * BUF + (WHICH == 0 ? OFF_A0 : OFF_A1);
+      // columns beyond the operand are clamped (their products land in output rows the epilogue masks)
+      const int vo = rowA + 2 * min(pm0 + WHICH * 128 + lc, (int)p.lda - 8);
+#pragma unroll
+      for (int it = 0; it < 2; ++it)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(dst + (it * 512 + wave * 64) * 16), 16, vo, (kt * 64 + it * 32) * ldaB, 0, 0);
+    } else {
+      char* dst = smem + B_ * BUF + (WHICH == 2 ? OFF_B0 : OFF_B1);
+      const int vo = rowB + 2 * min(pn0 + (WHICH - 2) * 128 + lc, (int)p.ldb - 8);
+#pragma unroll
+      for (int it = 0; it < 2; ++it)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(dst + (it * 512 + wave * 64) * 16), 16, vo, (kt * 64 + it * 32) * ldbB, 0, 0);
+    }
+  };
+  auto advance = [&]() {
+    if (!live) return;
+    if (++kt_p == nk_p) {
+      kt_p = 0;
+      w_p += gridDim.x;
+      if (w_p < nitems) setup(w_p);
+      else live = false;
+    }
+    if (live) ++tiles_issued;
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using W0 = std::integral_constant<int, 0>;      // staging order A0 B1 A1 B0 (B0 is re-read for the 4th quadrant)
+  using W1 = std::integral_constant<int, 3>;
+  using W2 = std::integral_constant<int, 1>;
+  using W3 = std::integral_constant<int, 2>;
+
+  // ---------------- consumer ----------------
+  f32x4 acc[8][4];
+  s16x4 alo[4][2], ahi[4][2], blo[2][2], bhi[2][2];
+  float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int L = lane & 15, g = lane >> 4;
+  const int fl = (L >> 2) | ((g & 1) << 2);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(smem);
+  const uint32_t lane_off = lds0 + (uint32_t)((8 * g + (L >> 2)) * 256 + (L & 3) * 8);   // + 32*256*ks, + 4*256 for the high half
+  uint32_t a_fo[4], b_fo[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a_fo[i] = lane_off + (uint32_t)(((wm * 4 + i) ^ fl) << 5);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) b_fo[j] = lane_off + (uint32_t)(OFF_B0 + (((wn * 2 + j) ^ fl) << 5));
+
+  auto read_a = [&](auto buf_c, auto half_c) {
+    constexpr int O = decltype(buf_c)::value * BUF + decltype(half_c)::value * HB;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t v = a_fo[i] + (uint32_t)O;
+      tn8_tr_read<0>(alo[i][0], v);
+      tn8_tr_read<4 * 256>(ahi[i][0], v);
+      tn8_tr_read<32 * 256>(alo[i][1], v);
+      tn8_tr_read<32 * 256 + 4 * 256>(ahi[i][1], v);
+    }
+  };
+  auto read_b = [&](auto buf_c, auto half_c) {
+    constexpr int O = decltype(buf_c)::value * BUF + decltype(half_c)::value * HB;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const uint32_t v = b_fo[j] + (uint32_t)O;
+      tn8_tr_read<0>(blo[j][0], v);
+      tn8_tr_read<4 * 256>(bhi[j][0], v);
+      tn8_tr_read<32 * 256>(blo[j][1], v);
+      tn8_tr_read<32 * 256 + 4 * 256>(bhi[j][1], v);
+    }
+  };
+  bool do_colsum = false;
+  auto compute = [&](auto ha_c, auto hb_c, auto cs_c) {
+    constexpr int HA = decltype(ha_c)::value, HB_ = decltype(hb_c)::value;
+    constexpr bool CS = decltype(cs_c)::value;      // this phase holds freshly read A fragments: column sums are taken here
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(alo[0][0]), "+v"(ahi[0][0]), "+v"(alo[0][1]), "+v"(ahi[0][1]), "+v"(alo[1][0]), "+v"(ahi[1][0]), "+v"(alo[1][1]),
+                   "+v"(ahi[1][1]), "+v"(alo[2][0]), "+v"(ahi[2][0]), "+v"(alo[2][1]), "+v"(ahi[2][1]), "+v"(alo[3][0]), "+v"(ahi[3][0]),
+                   "+v"(alo[3][1]), "+v"(ahi[3][1]), "+v"(blo[0][0]), "+v"(bhi[0][0]), "+v"(blo[0][1]), "+v"(bhi[0][1]), "+v"(blo[1][0]),
+                   "+v"(bhi[1][0]), "+v"(blo[1][1]), "+v"(bhi[1][1]));
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[HA * 4 + i][HB_ * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tn8_frag(blo[j][ks], bhi[j][ks]), tn8_frag(alo[i][ks], ahi[i][ks]),
+                                                                                acc[HA * 4 + i][HB_ * 2 + j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    if constexpr (CS) {
+      if (do_colsum) {      // wave-uniform; 32 v_dot2c behind the MFMAs of this quadrant
+        const bf16x2_t one = {(__bf16)1.0f, (__bf16)1.0f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            const uint2 l = __builtin_bit_cast(uint2, alo[i][ks]), h = __builtin_bit_cast(uint2, ahi[i][ks]);
+            float s = csum[HA * 4 + i];
+            s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, l.x), one, s, false);
+            s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, l.y), one, s, false);
+            s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, h.x), one, s, false);
+            s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, h.y), one, s, false);
+            csum[HA * 4 + i] = s;
+          }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using T = std::true_type;
+  using F = std::false_type;
+
+  // ---------------- prologue ----------------
+  setup(w_p);
+  tiles_issued = 1;
+  stage(W0{}, I0{}); stage(W1{}, I0{}); stage(W2{}, I0{}); stage(W3{}, I0{});
+  advance();
+  stage(W0{}, I1{}); stage(W1{}, I1{});
+  if (live) __builtin_amdgcn_s_waitcnt(0x0F70 | 4);
+  else __builtin_amdgcn_s_waitcnt(0x0F70);
+  tn8_barrier();
+  if (wm == 1) tn8_barrier();
+
+  int gk = 0;      // K tiles consumed by this workgroup so far
+  for (int w = blockIdx.x; w < nitems; w += gridDim.x) {
+    int m0, n0, kt0, nk;
+    item_of(w, m0, n0, kt0, nk);
+    do_colsum = (colsum != nullptr) && (n0 == 0) && (wn == 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      csum[i] = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    for (int kt = 0; kt < nk; kt += 2, gk += 2) {
+      // ======== K tile gk (buffer 0): quadrants (0,0) (0,1) (1,1) (1,0) ========
+      read_b(I0{}, I0{});
+      __builtin_amdgcn_sched_barrier(0);
+      read_a(I0{}, I0{});
+      stage(W2{}, I1{});
+      tn8_barrier();
+      compute(I0{}, I0{}, T{});
+      tn8_barrier();
+      read_b(I0{}, I1{});
+      stage(W3{}, I1{});
+      tn8_barrier();
+      compute(I0{}, I1{}, F{});
+      tn8_barrier();
+      read_a(I0{}, I1{});
+      advance();
+      stage(W0{}, I0{});
+      tn8_barrier();
+      compute(I1{}, I1{}, T{});
+      tn8_barrier();
+      read_b(I0{}, I0{});
+      stage(W1{}, I0{});
+      if (tiles_issued >= gk + 3) __builtin_amdgcn_s_waitcnt(0x0F70 | 4);
+      else __builtin_amdgcn_s_waitcnt(0x0F70);
+      tn8_barrier();
+      compute(I1{}, I0{}, F{});
+      tn8_barrier();
+      // ======== K tile gk+1 (buffer 1) ========
+      read_b(I1{}, I0{});
+      __builtin_amdgcn_sched_barrier(0);
+      read_a(I1{}, I0{});
+      stage(W2{}, I0{});
+      tn8_barrier();
+      compute(I0{}, I0{}, T{});
+      tn8_barrier();
+      read_b(I1{}, I1{});
+      stage(W3{}, I0{});
+      tn8_barrier();
+      compute(I0{}, I1{}, F{});
+      tn8_barrier();
+      read_a(I1{}, I1{});
+      advance();
+      stage(W0{}, I1{});
+      tn8_barrier();
+      compute(I1{}, I1{}, T{});
+      tn8_barrier();
+      read_b(I1{}, I0{});
+      stage(W1{}, I1{});
+      if (tiles_issued >= gk + 4) __builtin_amdgcn_s_waitcnt(0x0F70 | 4);
+      else __builtin_amdgcn_s_waitcnt(0x0F70);
+      tn8_barrier();
+      compute(I1{}, I0{}, F{});
+      tn8_barrier();
+    }
+    // ---------------- epilogue: fp32 fragments straight to the slab slice / C (16 B per lane) ----------------
+    // (no LDS involved: the operand stream of the next item keeps landing; the wave groups need no re-alignment)
+    {
+      const int sp = w / ntile;
+      float* const C = (float*)p.C + (long)sp * p.c_split_stride;
+#pragma unroll
+      for (int R_ = 0; R_ < 8; ++R_) {
+        const int m = m0 + (R_ >> 2) * 128 + wm * 64 + (R_ & 3) * 16 + L;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int cj = 0; cj < 4; ++cj) {
+          const int n = n0 + (cj >> 1) * 128 + wn * 32 + (cj & 1) * 16 + 4 * g;
+          if (n >= p.N) continue;
+          float* c = C + (long)m * p.ldc + n;
+          const f32x4 v = acc[R_][cj];
+          if (n + 3 < p.N) {
+            if (OUT == 3) {
+              const float4 o = *(const float4*)c;
+              *(float4*)c = make_float4(o.x + v[0], o.y + v[1], o.z + v[2], o.w + v[3]);
+            } else {
+              *(float4*)c = make_float4(v[0], v[1], v[2], v[3]);
+            }
+          } else {
+            for (int r = 0; r < 4 && n + r < p.N; ++r) c[r] = (OUT == 3) ? c[r] + v[r] : v[r];
+          }
+        }
+      }
+      if (do_colsum) {      // per-lane partial sums cover k = 8 g + [0, 8) of every k-step: reduce over the 4 lane groups
+#pragma unroll
+        for (int R_ = 0; R_ < 8; ++R_) {
+          float v = csum[R_];
+          v += __shfl_xor(v, 16, 64);
+          v += __shfl_xor(v, 32, 64);
+          const int m = m0 + (R_ >> 2) * 128 + wm * 64 + (R_ & 3) * 16 + L;
+          if (g == 0 && m < p.M) atomicAdd(colsum + m, v);
+        }
+      }
+    }
+    // stores / atomics and LDS-DMA share vmcnt: one full drain per item keeps the counted waits of the next item sound
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+  }
+  if (wm == 0) tn8_barrier();      // pairs with the extra barrier the lagging wave group took at the start
+}
+
+int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+
+}  // namespace
+
+// K slices for a [Mo, No] gradient over R rows: fill the 256 CUs (one workgroup each) in whole rounds; a slice is a whole number of
+// 128-row units.  Cost model: rounds x (slice length + fixed cost per item) + slab traffic.
+int vlb_tn8_pick_splits(int Mo, int No, int R) {
+  const long tiles = (long)vlb_cdiv(Mo, 256) * vlb_cdiv(No, 256);
+  const int pairs = R / 128;
+  const long ldw = (No + 3) / 4 * 4;
+  double best = -1.0;
+  int best_sp = 1;
+  for (int sp = 1; sp <= pairs && sp <= 64; ++sp) {
+    const long items = tiles * sp;
+    const long rounds = (items + 255) / 256;
+    const int per = vlb_cdiv(pairs, sp);
+    if ((long)vlb_cdiv(pairs, per) != sp) continue;               // (sp must be realisable with equal slices)
+    const double t = (double)rounds * (per * 2 * 1.6 + 6.0) + (sp > 1 ? 2.0 * sp * Mo * (double)ldw * 4.0 / 4.0e6 : 0.0);
+    if (best < 0 || t < best) { best = t; best_sp = sp; }
+  }
+  return best_sp;
+}
+
+// Weight gradient through the large-tile core.  Returns the number of K slices used (>= 1; the caller then runs the slab reduce when
+// it is > 1 or a row scale is pending), 0 when the shape is outside what this kernel covers, < 0 on error.
+// p: A = dY [R, Mo], B = X [R, No], M = Mo, N = No, K = R; p.C / ldc / c_split_stride / out_f32 are filled in here.
+int vlb_gemm_tn8_try(GemmParams& p, float* C, long ldc, float* colsum, float* workspace, long workspace_floats, int accumulate,
+                     bool force_slab, hipStream_t stream) {
+  static const int mode = env_int("VLB_GEMM_TN8", 1);
+  static const int group = env_int("VLB_GEMM_TN8_GROUP", 0);
+  if (!mode) return 0;
+  const int R = p.K, Mo = p.M, No = p.N;
+  if ((R % 128) != 0 || R < 256) return 0;
+  if ((p.lda % 8) || (p.ldb % 8) || p.lda < 8 || p.ldb < 8 || (ldc % 4)) return 0;
+  if ((long)R * p.lda * 2 >= (1L << 31) || (long)R * p.ldb * 2 >= (1L << 31)) return 0;
+  const int ntm = vlb_cdiv(Mo, 256), ntn = vlb_cdiv(No, 256);
+  const long tiles = (long)ntm * ntn;
+  const int pairs = R / 128;                       // 128-row units of the reduction
+  const long ldw = (No + 3) / 4 * 4;
+  int splits = vlb_tn8_pick_splits(Mo, No, R);
+  if (tiles * splits < 128) return 0;              // cannot fill the chip with 256x256 tiles: the 128x128 kernel covers it
+  int per = vlb_cdiv(pairs, splits);
+  splits = vlb_cdiv(pairs, per);
+  const bool slab = splits > 1 || force_slab;
+  if (slab && (!workspace || workspace_floats < (long)splits * Mo * ldw)) return 0;
+  if (slab) {
+    p.C = workspace; p.ldc = ldw; p.out_f32 = 1; p.c_split_stride = (long)Mo * ldw;
+  } else {
+    p.C = C; p.ldc = ldc; p.out_f32 = accumulate ? 3 : 1; p.c_split_stride = 0;
+  }
+  p.ntm = ntm; p.ntn = ntn;
+  int gm = group;
+  if (gm <= 0) {
+    gm = 1;
+    if (2 * ntn >= ntm) gm = (int)(sqrt((double)ntm * ntn / 8.0) + 0.5);
+  }
+  if (gm > ntm) gm = ntm;
+  if (gm < 1) gm = 1;
+  p.tile_group = gm;
+  constexpr int smem = 131072;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_tn8_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)gemm_tn8_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_set = true;
+  }
+  long items = tiles * splits;
+  int gx = items > 256 ? 256 : (int)items;
+  if (p.out_f32 == 3) hipLaunchKernelGGL(gemm_tn8_kernel<3>, dim3(gx), dim3(512), smem, stream, p, colsum, splits, per * 2);
+  else hipLaunchKernelGGL(gemm_tn8_kernel<1>, dim3(gx), dim3(512), smem, stream, p, colsum, splits, per * 2);
+  VLB_CHECK_LAUNCH("vlb_wgrad_tn_bf16(tn8)");
+  return splits;
+}
