@@ -71,7 +71,8 @@ int vlb_gemm_nt_bf16_ex(const void* A, long lda, const void* B, long ldb, void* 
 int vlb_gemm_nt_bf16_splitk(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
                             float* workspace, long workspace_floats, vlb_stream_t stream);
 /* Run-time tuning knob of the GEMM dispatcher (the environment variables VLB_GEMM_P8* give the defaults): name = "p8_mode"
- * (0: 128x128 kernels only | 1: cost model | 4 / 5: force 256- / 320-row tiles), "p8_keepb", "p8_group", "p8_min_tiles". */
+ * (0: 128x128 kernels only | 1: cost model | 4 / 5: force 256- / 320-row tiles), "p8_keepb", "p8_group", "p8_min_tiles",
+ * "tn8_mode" (weight gradients: 0 = 128x128 TN kernel only, 1 = large-tile core where it applies). */
 int vlb_gemm_set_option(const char* name, int value);
 
 

@@ -905,7 +905,10 @@ def test_mlm_head_compaction_matches_full_path():
     # softmax is invariant to it) consist of fp32 summation-order noise in BOTH paths and carry no signal
     worst = max((float((comp[2][n].double() - g.double()).norm()) / max(float(g.double().norm()), 1e-3 * full[1]), n) for n, g in full[2].items())
     print("compaction: worst per-tensor gradient difference %.3e (%s)" % worst)
-    assert worst[0] < 2e-4, worst
+    # not bit-identical: the split-K partition of the decoder dgrad / wgrad depends on the row count, so fp32 sums are taken in a
+    # different order and a few bf16 roundings of d(hidden) flip by one ulp (2^-8) -- the difference stays an order of magnitude
+    # below the engine-vs-fp32-oracle error (1e-2 class)
+    assert worst[0] < 5e-3, worst
     n_lab = int((batch[4] >= 0).sum()) + int((aux[1] >= 0).sum())
     assert int(comp[3].counts[0] + comp[3].counts[2]) == n_lab and n_lab < comp[3].mlm_cap
     # oracle agreement of the compact engine (multitask forward)

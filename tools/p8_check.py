@@ -188,7 +188,43 @@ def bench(batch):
     print("%-36s | " % "NT ms per step (12 layers + decoder fwd)" + " | ".join("%13.2f" % t for t in tot), flush=True)
 
 
+def bench_wgrad(batch):
+    """weight-gradient (TN) shapes of one step: 128x128 TN kernel vs the large-tile core"""
+    M = batch * 101
+    shapes = [("qkv wgrad", M, 2304, 768), ("out wgrad", M, 768, 768), ("ffn1 wgrad", M, 3072, 768), ("ffn2 wgrad", M, 768, 3072),
+              ("decoder wgrad (compact)", 4096, 30522, 768), ("decoder wgrad (full)", batch * 64, 30522, 768)]
+    print("%-26s %7s %6s %6s | %-16s | %-16s" % ("wgrad", "R", "Mo", "No", "128x128 TN", "tn8"))
+    tot = [0.0, 0.0]
+    for name, R, Mo, No in shapes:
+        dY = rnd(R, Mo, seed=1).to(BF).to(D)
+        X = rnd(R, No, seed=2).to(BF).to(D)
+        C = torch.zeros((Mo, No), dtype=torch.float32, device=D)
+        db = torch.zeros(Mo, dtype=torch.float32, device=D)
+        work = torch.empty(max(ops.wgrad_workspace_floats(Mo, No, R), 4), dtype=torch.float32, device=D)
+        row = []
+        for vi, mode in enumerate((0, 1)):
+            lib.gemm_set_option("tn8_mode", mode)
+            run = lambda: ops.wgrad_tn(dY, X, C, colsum=db, workspace=work, accumulate=False)
+            for _ in range(3):
+                run()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 10
+            row.append("%7.1fus %6.0f TF" % (ms * 1e3, 2.0 * R * Mo * No / ms / 1e9))
+            if not name.startswith("decoder wgrad (full"):
+                tot[vi] += ms * (1 if name.startswith("decoder") else 12)
+        print("%-26s %7d %6d %6d | " % (name, R, Mo, No) + " | ".join(row), flush=True)
+    print("TN ms per step (12 layers + compact decoder): %.2f | %.2f" % tuple(tot), flush=True)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "check":
         sys.exit(1 if check() else 0)
+    if len(sys.argv) > 1 and sys.argv[1] == "wgrad":
+        bench_wgrad(int(sys.argv[2]) if len(sys.argv) > 2 else 256)
+        sys.exit(0)
     bench(int(sys.argv[2]) if len(sys.argv) > 2 else 256)

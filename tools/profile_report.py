@@ -26,6 +26,7 @@ def db(name):
 
 
 def short(n):
+    n = n.replace("(anonymous namespace)::", "")
     n = re.sub(r"\(.*$", "", n)
     return re.sub(r"^void ", "", n)[:64]
 

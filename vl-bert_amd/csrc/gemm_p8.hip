@@ -595,6 +595,10 @@ static void p8_options_init() {
 extern "C" int vlb_gemm_set_option(const char* name, int value) {
   p8_options_init();
   VLB_CHECK_ARG(name && value >= 0, "vlb_gemm_set_option: null name / negative value");
+  if (!strcmp(name, "tn8_mode")) {
+    vlb_tn8_set_mode(value);
+    return VLB_OK;
+  }
   for (int i = 0; i < 4; ++i)
     if (!strcmp(name, g_opt_name[i])) {
       g_opt[i] = value;

@@ -42,3 +42,4 @@ int vlb_gemm_p8_try(GemmParams& p, hipStream_t stream);
 int vlb_gemm_tn8_try(GemmParams& p, float* C, long ldc, float* colsum, float* workspace, long workspace_floats, int accumulate,
                      bool force_slab, hipStream_t stream);
 int vlb_tn8_pick_splits(int Mo, int No, int R);
+void vlb_tn8_set_mode(int v);

@@ -324,6 +324,9 @@ int env_int(const char* name, int dflt) {
 
 }  // namespace
 
+static int g_tn8_mode = -1;      // VLB_GEMM_TN8 (0: 128x128 TN kernel only); run-time override: vlb_gemm_set_option("tn8_mode", v)
+void vlb_tn8_set_mode(int v) { g_tn8_mode = v; }
+
 // K slices for a [Mo, No] gradient over R rows: fill the 256 CUs (one workgroup each) in whole rounds; a slice is a whole number of
 // 128-row units.  Cost model: rounds x (slice length + fixed cost per item) + slab traffic.
 int vlb_tn8_pick_splits(int Mo, int No, int R) {
@@ -348,9 +351,9 @@ int vlb_tn8_pick_splits(int Mo, int No, int R) {
 // p: A = dY [R, Mo], B = X [R, No], M = Mo, N = No, K = R; p.C / ldc / c_split_stride / out_f32 are filled in here.
 int vlb_gemm_tn8_try(GemmParams& p, float* C, long ldc, float* colsum, float* workspace, long workspace_floats, int accumulate,
                      bool force_slab, hipStream_t stream) {
-  static const int mode = env_int("VLB_GEMM_TN8", 1);
   static const int group = env_int("VLB_GEMM_TN8_GROUP", 0);
-  if (!mode) return 0;
+  if (g_tn8_mode < 0) g_tn8_mode = env_int("VLB_GEMM_TN8", 1);
+  if (!g_tn8_mode) return 0;
   const int R = p.K, Mo = p.M, No = p.N;
   if ((R % 128) != 0 || R < 256) return 0;
   if ((p.lda % 8) || (p.ldb % 8) || p.lda < 8 || p.ldb < 8 || (ldc % 4)) return 0;
