@@ -282,6 +282,12 @@ int vlb_conv3x3_wgrad_tn_bf16(const void* dy, long lddy, const void* x, int N, i
 /* vlb_wgrad_tn_bf16 with output row m scaled by rowscale[m] (folded frozen-BatchNorm: dW_master = scale[o] * dW_folded) in the
  * slab reduce -- no separate finalize pass.  rowscale (also optional in vlb_conv3x3_wgrad_tn_bf16) needs
  * workspace >= splits * Mo * round4(No) floats, at least Mo * round4(No). */
+/* n <= 4 weight gradients over the SAME R rows in one launch (the four Linear layers of a transformer block): dW_i[Mo_i, No_i] (+)=
+ * A_i[R, Mo_i]^T B_i[R, No_i], colsum_i[Mo_i] += column sums of A_i (entries / the array may be NULL).  Arrays are HOST arrays of n
+ * entries.  workspace >= 2 * sum_i Mo_i * round4(No_i) floats lets the grouped large-tile kernel run (otherwise n single calls). */
+int vlb_wgrad_tn_group_bf16(int n, const void* const* A, const long* lda, const void* const* B, const long* ldb, float* const* C,
+                            const long* ldc, int R, const int* Mo, const int* No, float* const* colsum, float* workspace,
+                            long workspace_floats, int accumulate, vlb_stream_t stream);
 int vlb_wgrad_tn_rowscale_bf16(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int R, int Mo, int No,
                                const float* rowscale, float* workspace, long workspace_floats, int accumulate, vlb_stream_t stream);
 int vlb_im2col_nhwc_bf16(const void* x, void* col, long ldcol, int N, int H, int W, int C, int KH, int KW, int stride,

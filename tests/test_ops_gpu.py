@@ -369,6 +369,27 @@ def test_wgrad_tn_lds_transpose_reads(ops, R, Mo, No):
     assert torch.equal(buf.cpu(), ref)
 
 
+@pytest.mark.parametrize("R,accumulate", [(2560, True), (1024, False), (300, True)])
+def test_wgrad_tn_grouped_layer(ops, R, accumulate):
+    """vlb_wgrad_tn_group_bf16: the four weight gradients of a transformer block in one launch (large-tile core, 2 K slices; R = 300
+    takes the per-gradient fallback) against fp32 torch; bias column sums; accumulate and overwrite."""
+    H, I = 768, 3072
+    shapes = [(H, I), (I, H), (H, H), (3 * H, H)]          # (Mo, No): output.dense, intermediate.dense, attention.output, fused QKV
+    items, refs = [], []
+    for k, (Mo, No) in enumerate(shapes):
+        dY, X = rnd(R, Mo, seed=30 + k, scale=0.5), rnd(R, No, seed=40 + k, scale=0.2)
+        base = torch.randn(Mo, No, generator=torch.Generator().manual_seed(50 + k))
+        C = base.clone().to(dev())
+        db = torch.ones(Mo, dtype=torch.float32, device=dev())
+        items.append((to_gpu_bf16(dY), to_gpu_bf16(X), C, db))
+        refs.append(((base if accumulate else 0) + dY.t() @ X, 1 + dY.sum(0)))
+    work = torch.empty(2 * sum(a * b for a, b in shapes) + 64, dtype=torch.float32, device=dev())
+    ops.wgrad_tn_group(items, workspace=work, accumulate=accumulate)
+    for k, ((_, _, C, db), (rc, rb)) in enumerate(zip(items, refs)):
+        report("grouped wgrad %d (R=%d)" % (k, R), C, rc, 1e-3, 2e-5)
+        report("grouped wgrad %d colsum" % k, db, rb, 1e-3, 2e-5)
+
+
 def test_gemm_dropout_and_ln_mask_agree(ops):
     """The GEMM-epilogue dropout mask and the LayerNorm-backward dx_drop mask are the same function."""
     M, N, K = 200, 256, 64

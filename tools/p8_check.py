@@ -196,7 +196,8 @@ def bench_wgrad(batch):
     print("%-26s %7s %6s %6s | %-16s | %-16s" % ("wgrad", "R", "Mo", "No", "128x128 TN", "tn8"))
     tot = [0.0, 0.0]
     for name, R, Mo, No in shapes:
-        dY = rnd(R, Mo, seed=1).to(BF).to(D)
+        dY = torch.zeros((R, (Mo + 63) // 64 * 64), dtype=BF, device=D)[:, :Mo]
+        dY.copy_(rnd(R, Mo, seed=1).to(BF).to(D))
         X = rnd(R, No, seed=2).to(BF).to(D)
         C = torch.zeros((Mo, No), dtype=torch.float32, device=D)
         db = torch.zeros(Mo, dtype=torch.float32, device=D)

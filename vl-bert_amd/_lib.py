@@ -21,6 +21,7 @@ _SIGS = {
     "vlb_transpose_bf16": "plpliips",
     "vlb_wgrad_nt_bf16": "plplpliiipls",
     "vlb_wgrad_tn_bf16": "plplpliiipplis",
+    "vlb_wgrad_tn_group_bf16": "ippppppipppplis",
     "vlb_zero_ranges_f32": "pppiis",
     "vlb_layernorm_fwd": "plppplpiifis",
     "vlb_layernorm_bwd": "pliplppplplfpuplpppiiis",

@@ -1481,6 +1481,40 @@ extern "C" int vlb_wgrad_tn_bf16(const void* A, long lda, const void* B, long ld
   return wgrad_tn_impl(A, lda, B, ldb, C, ldc, R, Mo, No, colsum, nullptr, workspace, workspace_floats, accumulate, stream);
 }
 
+// Up to 4 weight gradients over the SAME rows in one launch (the four Linear layers of a transformer block: output.dense,
+// intermediate.dense, attention.output.dense, fused QKV): one item list of tiles x K slices on the large-tile core, so the slab
+// split-K needs 2 slices instead of 7-28 per gradient (4x less fp32 slab traffic) and 1 launch replaces 4.  Falls back to n
+// single calls when the group is outside what the grouped kernel covers.  Arrays are HOST arrays of n entries.
+extern "C" int vlb_wgrad_tn_group_bf16(int n, const void* const* A, const long* lda, const void* const* B, const long* ldb,
+                                       float* const* C, const long* ldc, int R, const int* Mo, const int* No, float* const* colsum,
+                                       float* workspace, long workspace_floats, int accumulate, hipStream_t stream) {
+  VLB_CHECK_ARG(n >= 1 && n <= 4 && A && lda && B && ldb && C && ldc && Mo && No, "vlb_wgrad_tn_group_bf16: bad arguments (1 <= n <= 4)");
+  for (int i = 0; i < n; ++i) VLB_CHECK_ARG(A[i] && B[i] && C[i], "vlb_wgrad_tn_group_bf16: null operand %d", i);
+  int slices[4];
+  long ws_off[4];
+  const int took = vlb_gemm_tn8_group(n, A, lda, B, ldb, C, ldc, R, Mo, No, colsum, workspace, workspace_floats, accumulate, slices, ws_off,
+                                      stream);
+  if (took < 0) return took;
+  if (took == 0) {
+    for (int i = 0; i < n; ++i) {
+      const int rc = wgrad_tn_impl(A[i], lda[i], B[i], ldb[i], C[i], ldc[i], R, Mo[i], No[i], colsum ? colsum[i] : nullptr, nullptr,
+                                   workspace, workspace_floats, accumulate, stream);
+      if (rc) return rc;
+    }
+    return VLB_OK;
+  }
+  for (int i = 0; i < n; ++i) {
+    if (slices[i] <= 1) continue;
+    const long ldw = (No[i] + 3) / 4 * 4;
+    long blocks = ((long)Mo[i] * (ldw / 4) + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)blocks), dim3(256), 0, stream, workspace + ws_off[i], (long)Mo[i] * ldw, slices[i], C[i],
+                       ldc[i], Mo[i], No[i], (int)ldw, (bf16_t*)nullptr, 0L, accumulate, (const float*)nullptr);
+    VLB_CHECK_LAUNCH("vlb_wgrad_tn_group_bf16(reduce)");
+  }
+  return VLB_OK;
+}
+
 // same product with every output ROW m multiplied by rowscale[m] before it is written / accumulated (the gradient of a weight
 // whose frozen-BatchNorm scale was folded into the bf16 operand); needs workspace >= splits * Mo * round4(No) floats.
 extern "C" int vlb_wgrad_tn_rowscale_bf16(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int R, int Mo, int No,

@@ -535,6 +535,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(const GemmParams p) 
   }
 }
 
+static int g_p8_wgs = 256;
+
 template <int FMH, int EPI, bool KEEPB>
 int p8_launch(GemmParams& p, int group, hipStream_t stream) {
   constexpr int smem = 163840;
@@ -551,7 +553,8 @@ int p8_launch(GemmParams& p, int group, hipStream_t stream) {
   p.ntn = vlb_cdiv(p.N, 256);
   p.tile_group = group;
   int gx = p.ntm * p.ntn;
-  if (gx > 256) gx = 256;          // one persistent workgroup per CU (a multiple of 8: work item w and block b share an XCD)
+  const int cap = (g_p8_wgs >= 8 && g_p8_wgs <= 256) ? (g_p8_wgs & ~7) : 256;
+  if (gx > cap) gx = cap;          // one persistent workgroup per CU (a multiple of 8: work item w and block b share an XCD)
   hipLaunchKernelGGL((gemm_nt_p8_kernel<FMH, EPI, KEEPB>), dim3(gx), dim3(512), smem, stream, p);
   VLB_CHECK_LAUNCH("vlb_gemm_nt_bf16(p8)");
   return 1;
@@ -582,14 +585,17 @@ inline bool aligned16(const void* q) { return ((uintptr_t)q & 15) == 0; }
 
 // tuning knobs (environment defaults, run-time override through vlb_gemm_set_option for A/B measurements inside one process)
 // p8_mode: 0 off | 1 cost model (default) | 4 / 5: force the 256- / 320-row tile wherever the kernel applies
-static int g_opt[4] = {-1, -1, -1, -1};
-static const char* const g_opt_name[4] = {"p8_mode", "p8_keepb", "p8_group", "p8_min_tiles"};
+// p8_wgs: persistent workgroups per launch (<= 256 = one per CU).  Fewer leave CUs to a kernel running on another stream (the
+// weight-gradient GEMMs of the side stream): an MFMA-bound kernel then fills the HBM-bound epilogue bursts of this one.
+static int g_opt[5] = {-1, -1, -1, -1, -1};
+static const char* const g_opt_name[5] = {"p8_mode", "p8_keepb", "p8_group", "p8_min_tiles", "p8_wgs"};
 static void p8_options_init() {
   if (g_opt[0] >= 0) return;
   g_opt[0] = env_int("VLB_GEMM_P8", 1);
   g_opt[1] = env_int("VLB_GEMM_P8_KEEPB", 1);
   g_opt[2] = env_int("VLB_GEMM_P8_GROUP", 2);
   g_opt[3] = env_int("VLB_GEMM_P8_MIN_TILES", 160);
+  g_opt[4] = env_int("VLB_GEMM_P8_WGS", 256);
 }
 
 extern "C" int vlb_gemm_set_option(const char* name, int value) {
@@ -599,7 +605,11 @@ extern "C" int vlb_gemm_set_option(const char* name, int value) {
     vlb_tn8_set_mode(value);
     return VLB_OK;
   }
-  for (int i = 0; i < 4; ++i)
+  if (!strcmp(name, "tn8_wgs")) {
+    vlb_tn8_set_wgs(value);
+    return VLB_OK;
+  }
+  for (int i = 0; i < 5; ++i)
     if (!strcmp(name, g_opt_name[i])) {
       g_opt[i] = value;
       return VLB_OK;
@@ -611,6 +621,7 @@ extern "C" int vlb_gemm_set_option(const char* name, int value) {
 int vlb_gemm_p8_try(GemmParams& p, hipStream_t stream) {
   p8_options_init();
   const int mode = g_opt[0], keepb = g_opt[1], group = g_opt[2], min_tiles = g_opt[3];
+  g_p8_wgs = g_opt[4];
   if (!mode || p.out_f32 != 0 || p.c_split_stride != 0) return 0;
   if ((p.K % 128) != 0 || p.k_per_split < p.K) return 0;
   int epi;

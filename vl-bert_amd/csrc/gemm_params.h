@@ -42,4 +42,8 @@ int vlb_gemm_p8_try(GemmParams& p, hipStream_t stream);
 int vlb_gemm_tn8_try(GemmParams& p, float* C, long ldc, float* colsum, float* workspace, long workspace_floats, int accumulate,
                      bool force_slab, hipStream_t stream);
 int vlb_tn8_pick_splits(int Mo, int No, int R);
+int vlb_gemm_tn8_group(int n, const void* const* A, const long* lda, const void* const* B, const long* ldb, float* const* C,
+                       const long* ldc, int R, const int* Mo, const int* No, float* const* colsum, float* workspace,
+                       long workspace_floats, int accumulate, int* slices, long* ws_off, hipStream_t stream);
 void vlb_tn8_set_mode(int v);
+void vlb_tn8_set_wgs(int v);

@@ -42,9 +42,28 @@ __device__ __forceinline__ bf16x8 tn8_frag(s16x4 lo, s16x4 hi) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
-// OUT: 1 fp32 store (slab slice, or overwrite) | 3 fp32 accumulate into C
-template <int OUT>
-__global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(const GemmParams p, float* __restrict__ colsum, int nsplit, int kt_per_split) {
+// One weight gradient of a grouped launch.  Up to TN8_MAX_GROUP gradients (the four Linear layers of a transformer block) share ONE
+// launch: their tiles x K slices form one item list, so the K slices can be few (2 for a block at batch 256: 108 tiles x 2 = 216
+// items for 256 CUs) -- the fp32 slab traffic of slab split-K shrinks by the same factor -- and one launch replaces four.
+struct Tn8Desc {
+  const bf16_t* A; const bf16_t* B;     // dY [R, Mo], X [R, No]
+  float* C;                             // output (direct, or the slab of slice 0)
+  float* colsum;                        // [Mo] += column sums of A, or null
+  long c_split_stride;                  // floats between consecutive slices' slabs
+  int lda, ldb, ldc;
+  int Mo, No, R;
+  int ntm, ntn, tile_group;
+  int nsplit, kt_per_split;             // K slices and 64-row K tiles per slice (even)
+  int item0, nitems;                    // position in the launch's item list
+  int accumulate;                       // direct output (nsplit == 1): C += instead of C =
+};
+constexpr int TN8_MAX_GROUP = 4;
+struct Tn8Group {
+  Tn8Desc d[TN8_MAX_GROUP];
+  int n, nitems;
+};
+
+__global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(const Tn8Group grp) {
   constexpr int HB = 64 * 256;                  // bytes of a half-image: 64 reduction rows x 128 columns
   constexpr int OFF_A0 = 0, OFF_A1 = HB, OFF_B0 = 2 * HB, OFF_B1 = 3 * HB;
   constexpr int BUF = 4 * HB;                   // one K tile = 64 KiB
@@ -53,36 +72,47 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(const GemmParams p, fl
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
-  const int ntile = p.ntm * p.ntn;
-  const int nitems = ntile * nsplit;
-  const int nk_all = p.K >> 6;                  // K tiles in the whole reduction (p.K = R, a multiple of 128)
+  const int nitems = grp.nitems;
   if ((int)blockIdx.x >= nitems) return;
 
-  // item -> (tile_m, tile_n, K-tile range): slice-major; inside a slice the tiles are walked in groups of `tile_group` tile rows,
-  // column-major inside a group (near-square patches share operand panels in L2)
-  auto item_of = [&](int w, int& m0, int& n0, int& kt0, int& nk) {
-    const int sp = w / ntile, t = w - sp * ntile;
-    const int gm = p.tile_group, per_group = gm * p.ntn, gid = t / per_group, first = gid * gm;
-    const int gsz = min(p.ntm - first, gm), rem = t - gid * per_group;
+  // item -> (gradient g, tile origin, K-tile range): per gradient slice-major (all tiles of a slice are concurrent and share their
+  // operand rows in L2); inside a slice the tiles are walked in groups of `tile_group` tile rows, column-major inside a group
+  auto item_of = [&](int w, int& gi, int& m0, int& n0, int& kt0, int& nk) {
+    gi = 0;
+#pragma unroll
+    for (int q = 1; q < TN8_MAX_GROUP; ++q)
+      if (q < grp.n && w >= grp.d[q].item0) gi = q;
+    const Tn8Desc& d = grp.d[gi];
+    const int wl = w - d.item0, ntile = d.ntm * d.ntn;
+    const int sp = wl / ntile, t = wl - sp * ntile;
+    const int gm = d.tile_group, per_group = gm * d.ntn, gid = t / per_group, first = gid * gm;
+    const int gsz = min(d.ntm - first, gm), rem = t - gid * per_group;
     m0 = (first + rem % gsz) * 256;
     n0 = (rem / gsz) * 256;
-    kt0 = sp * kt_per_split;
-    nk = min(nk_all - kt0, kt_per_split);       // even, >= 2 (host guarantees)
+    kt0 = sp * d.kt_per_split;
+    nk = min((d.R >> 6) - kt0, d.kt_per_split);       // even, >= 2 (host guarantees)
   };
 
   // ---------------- producer ----------------
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7FFFFFFF, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, 0x7FFFFFFF, 0x00020000);
   // chunk P = it*512 + tid of a half-image: row = P >> 4 = it*32 + (tid >> 4), physical 16-B chunk c = P & 15; physical 32-B block
   // c >> 1 holds logical block (c >> 1) ^ f(row), f(row) = (row & 3) | ((row >> 3) & 1) << 2 -- independent of `it`
-  const int ldaB = (int)p.lda * 2, ldbB = (int)p.ldb * 2;
   const int srow = tid >> 4, sc = tid & 15;
   const int sf = (srow & 3) | (((srow >> 3) & 1) << 2);
   const int lc = ((((sc >> 1) ^ sf) << 1) | (sc & 1)) * 8;      // logical column offset inside the 128-wide half-image
-  const int rowA = srow * ldaB, rowB = srow * ldbB;
+  __amdgpu_buffer_rsrc_t rsA, rsB;
+  int ldaB = 0, ldbB = 0, clampA = 0, clampB = 0, rowA = 0, rowB = 0;
   int w_p = blockIdx.x, kt_p = 0, nk_p = 0, kt0_p = 0, tiles_issued = 0, pm0 = 0, pn0 = 0;
   bool live = true;
-  auto setup = [&](int w) { item_of(w, pm0, pn0, kt0_p, nk_p); };
+  auto setup = [&](int w) {
+    int gi;
+    item_of(w, gi, pm0, pn0, kt0_p, nk_p);
+    const Tn8Desc& d = grp.d[gi];
+    rsA = __builtin_amdgcn_make_buffer_rsrc((void*)d.A, 0, 0x7FFFFFFF, 0x00020000);
+    rsB = __builtin_amdgcn_make_buffer_rsrc((void*)d.B, 0, 0x7FFFFFFF, 0x00020000);
+    ldaB = d.lda * 2; ldbB = d.ldb * 2;
+    clampA = d.lda - 8; clampB = d.ldb - 8;
+    rowA = srow * ldaB; rowB = srow * ldbB;
+  };
   auto stage = [&](auto which_c, auto buf_c) {
     constexpr int WHICH = decltype(which_c)::value, B_ = decltype(buf_c)::value;
     if (!live) return;
@@ -90,13 +120,13 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(const GemmParams p, fl
     if constexpr (WHICH < 2) {
       char* dst = smem + B_ * BUF + (WHICH == 0 ? OFF_A0 : OFF_A1);
       // columns beyond the operand are clamped (their products land in output rows the epilogue masks)
-      const int vo = rowA + 2 * min(pm0 + WHICH * 128 + lc, (int)p.lda - 8);
+      const int vo = rowA + 2 * min(pm0 + WHICH * 128 + lc, clampA);
 #pragma unroll
       for (int it = 0; it < 2; ++it)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(dst + (it * 512 + wave * 64) * 16), 16, vo, (kt * 64 + it * 32) * ldaB, 0, 0);
     } else {
       char* dst = smem + B_ * BUF + (WHICH == 2 ? OFF_B0 : OFF_B1);
-      const int vo = rowB + 2 * min(pn0 + (WHICH - 2) * 128 + lc, (int)p.ldb - 8);
+      const int vo = rowB + 2 * min(pn0 + (WHICH - 2) * 128 + lc, clampB);
 #pragma unroll
       for (int it = 0; it < 2; ++it)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(dst + (it * 512 + wave * 64) * 16), 16, vo, (kt * 64 + it * 32) * ldbB, 0, 0);
@@ -210,8 +240,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(const GemmParams p, fl
 
   int gk = 0;      // K tiles consumed by this workgroup so far
   for (int w = blockIdx.x; w < nitems; w += gridDim.x) {
-    int m0, n0, kt0, nk;
-    item_of(w, m0, n0, kt0, nk);
+    int gi, m0, n0, kt0, nk;
+    item_of(w, gi, m0, n0, kt0, nk);
+    float* const colsum = grp.d[gi].colsum;
     do_colsum = (colsum != nullptr) && (n0 == 0) && (wn == 0);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -276,27 +307,31 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(const GemmParams p, fl
     // ---------------- epilogue: fp32 fragments straight to the slab slice / C (16 B per lane) ----------------
     // (no LDS involved: the operand stream of the next item keeps landing; the wave groups need no re-alignment)
     {
-      const int sp = w / ntile;
-      float* const C = (float*)p.C + (long)sp * p.c_split_stride;
+      const Tn8Desc& d = grp.d[gi];
+      const int sp = (w - d.item0) / (d.ntm * d.ntn);
+      float* const C = d.C + (long)sp * d.c_split_stride;
+      const bool accum = d.accumulate != 0;
+      const int Mo = d.Mo, No = d.No;
+      const long ldc = d.ldc;
 #pragma unroll
       for (int R_ = 0; R_ < 8; ++R_) {
         const int m = m0 + (R_ >> 2) * 128 + wm * 64 + (R_ & 3) * 16 + L;
-        if (m >= p.M) continue;
+        if (m >= Mo) continue;
 #pragma unroll
         for (int cj = 0; cj < 4; ++cj) {
           const int n = n0 + (cj >> 1) * 128 + wn * 32 + (cj & 1) * 16 + 4 * g;
-          if (n >= p.N) continue;
-          float* c = C + (long)m * p.ldc + n;
+          if (n >= No) continue;
+          float* c = C + (long)m * ldc + n;
           const f32x4 v = acc[R_][cj];
-          if (n + 3 < p.N) {
-            if (OUT == 3) {
+          if (n + 3 < No) {
+            if (accum) {
               const float4 o = *(const float4*)c;
               *(float4*)c = make_float4(o.x + v[0], o.y + v[1], o.z + v[2], o.w + v[3]);
             } else {
               *(float4*)c = make_float4(v[0], v[1], v[2], v[3]);
             }
           } else {
-            for (int r = 0; r < 4 && n + r < p.N; ++r) c[r] = (OUT == 3) ? c[r] + v[r] : v[r];
+            for (int r = 0; r < 4 && n + r < No; ++r) c[r] = accum ? c[r] + v[r] : v[r];
           }
         }
       }
@@ -307,7 +342,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(const GemmParams p, fl
           v += __shfl_xor(v, 16, 64);
           v += __shfl_xor(v, 32, 64);
           const int m = m0 + (R_ >> 2) * 128 + wm * 64 + (R_ & 3) * 16 + L;
-          if (g == 0 && m < p.M) atomicAdd(colsum + m, v);
+          if (g == 0 && m < grp.d[gi].Mo) atomicAdd(colsum + m, v);
         }
       }
     }
@@ -326,6 +361,8 @@ int env_int(const char* name, int dflt) {
 
 static int g_tn8_mode = -1;      // VLB_GEMM_TN8 (0: 128x128 TN kernel only); run-time override: vlb_gemm_set_option("tn8_mode", v)
 void vlb_tn8_set_mode(int v) { g_tn8_mode = v; }
+static int g_tn8_wgs = -1;       // VLB_GEMM_TN8_WGS: persistent workgroups per launch (default 256 = one per CU)
+void vlb_tn8_set_wgs(int v) { g_tn8_wgs = v; }
 
 // K slices for a [Mo, No] gradient over R rows: fill the 256 CUs (one workgroup each) in whole rounds; a slice is a whole number of
 // 128-row units.  Cost model: rounds x (slice length + fixed cost per item) + slab traffic.
@@ -346,53 +383,121 @@ int vlb_tn8_pick_splits(int Mo, int No, int R) {
   return best_sp;
 }
 
-// Weight gradient through the large-tile core.  Returns the number of K slices used (>= 1; the caller then runs the slab reduce when
-// it is > 1 or a row scale is pending), 0 when the shape is outside what this kernel covers, < 0 on error.
-// p: A = dY [R, Mo], B = X [R, No], M = Mo, N = No, K = R; p.C / ldc / c_split_stride / out_f32 are filled in here.
-int vlb_gemm_tn8_try(GemmParams& p, float* C, long ldc, float* colsum, float* workspace, long workspace_floats, int accumulate,
-                     bool force_slab, hipStream_t stream) {
+static int tile_group_for(int ntm, int ntn) {
   static const int group = env_int("VLB_GEMM_TN8_GROUP", 0);
-  if (g_tn8_mode < 0) g_tn8_mode = env_int("VLB_GEMM_TN8", 1);
-  if (!g_tn8_mode) return 0;
-  const int R = p.K, Mo = p.M, No = p.N;
-  if ((R % 128) != 0 || R < 256) return 0;
-  if ((p.lda % 8) || (p.ldb % 8) || p.lda < 8 || p.ldb < 8 || (ldc % 4)) return 0;
-  if ((long)R * p.lda * 2 >= (1L << 31) || (long)R * p.ldb * 2 >= (1L << 31)) return 0;
-  const int ntm = vlb_cdiv(Mo, 256), ntn = vlb_cdiv(No, 256);
-  const long tiles = (long)ntm * ntn;
-  const int pairs = R / 128;                       // 128-row units of the reduction
-  const long ldw = (No + 3) / 4 * 4;
-  int splits = vlb_tn8_pick_splits(Mo, No, R);
-  if (tiles * splits < 128) return 0;              // cannot fill the chip with 256x256 tiles: the 128x128 kernel covers it
-  int per = vlb_cdiv(pairs, splits);
-  splits = vlb_cdiv(pairs, per);
-  const bool slab = splits > 1 || force_slab;
-  if (slab && (!workspace || workspace_floats < (long)splits * Mo * ldw)) return 0;
-  if (slab) {
-    p.C = workspace; p.ldc = ldw; p.out_f32 = 1; p.c_split_stride = (long)Mo * ldw;
-  } else {
-    p.C = C; p.ldc = ldc; p.out_f32 = accumulate ? 3 : 1; p.c_split_stride = 0;
-  }
-  p.ntm = ntm; p.ntn = ntn;
   int gm = group;
   if (gm <= 0) {
     gm = 1;
     if (2 * ntn >= ntm) gm = (int)(sqrt((double)ntm * ntn / 8.0) + 0.5);
   }
   if (gm > ntm) gm = ntm;
-  if (gm < 1) gm = 1;
-  p.tile_group = gm;
+  return gm < 1 ? 1 : gm;
+}
+
+static int tn8_launch(Tn8Group& grp, hipStream_t stream) {
   constexpr int smem = 131072;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_tn8_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    (void)hipFuncSetAttribute((const void*)gemm_tn8_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_tn8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) {
+      vlb_set_error("gemm_tn8: cannot reserve %d bytes of LDS: %s", smem, hipGetErrorString(e));
+      return VLB_ERR_HIP;
+    }
     attr_set = true;
   }
-  long items = tiles * splits;
-  int gx = items > 256 ? 256 : (int)items;
-  if (p.out_f32 == 3) hipLaunchKernelGGL(gemm_tn8_kernel<3>, dim3(gx), dim3(512), smem, stream, p, colsum, splits, per * 2);
-  else hipLaunchKernelGGL(gemm_tn8_kernel<1>, dim3(gx), dim3(512), smem, stream, p, colsum, splits, per * 2);
+  if (g_tn8_wgs < 0) g_tn8_wgs = env_int("VLB_GEMM_TN8_WGS", 256);
+  const int cap = (g_tn8_wgs >= 8 && g_tn8_wgs <= 256) ? g_tn8_wgs : 256;
+  const int gx = grp.nitems > cap ? cap : grp.nitems;
+  hipLaunchKernelGGL(gemm_tn8_kernel, dim3(gx), dim3(512), smem, stream, grp);
   VLB_CHECK_LAUNCH("vlb_wgrad_tn_bf16(tn8)");
-  return splits;
+  return VLB_OK;
+}
+
+static bool tn8_shape_ok(long lda, long ldb, long ldc, int R) {
+  if ((R % 128) != 0 || R < 256) return false;
+  if ((lda % 8) || (ldb % 8) || lda < 8 || ldb < 8 || (ldc % 4)) return false;
+  if ((long)R * lda * 2 >= (1L << 31) || (long)R * ldb * 2 >= (1L << 31)) return false;
+  return true;
+}
+
+// Weight gradient through the large-tile core.  Returns the number of K slices used (>= 1; the caller then runs the slab reduce when
+// it is > 1 or a row scale is pending), 0 when the shape is outside what this kernel covers, < 0 on error.
+// p: A = dY [R, Mo], B = X [R, No], M = Mo, N = No, K = R.
+int vlb_gemm_tn8_try(GemmParams& p, float* C, long ldc, float* colsum, float* workspace, long workspace_floats, int accumulate,
+                     bool force_slab, hipStream_t stream) {
+  if (g_tn8_mode < 0) g_tn8_mode = env_int("VLB_GEMM_TN8", 1);
+  if (!g_tn8_mode) return 0;
+  const int R = p.K, Mo = p.M, No = p.N;
+  if (!tn8_shape_ok(p.lda, p.ldb, ldc, R)) return 0;
+  const int ntm = vlb_cdiv(Mo, 256), ntn = vlb_cdiv(No, 256);
+  const long tiles = (long)ntm * ntn;
+  const int pairs = R / 128;                       // 128-row units of the reduction
+  const long ldw = (No + 3) / 4 * 4;
+  int splits = vlb_tn8_pick_splits(Mo, No, R);
+  if (tiles * splits < 128) return 0;              // cannot fill the chip with 256x256 tiles: the 128x128 kernel covers it
+  const int per = vlb_cdiv(pairs, splits);
+  splits = vlb_cdiv(pairs, per);
+  const bool slab = splits > 1 || force_slab;
+  if (slab && (!workspace || workspace_floats < (long)splits * Mo * ldw)) return 0;
+  Tn8Group grp = {};
+  Tn8Desc& d = grp.d[0];
+  d.A = p.A; d.B = p.B; d.colsum = colsum;
+  d.lda = (int)p.lda; d.ldb = (int)p.ldb; d.Mo = Mo; d.No = No; d.R = R;
+  d.ntm = ntm; d.ntn = ntn; d.tile_group = tile_group_for(ntm, ntn);
+  d.nsplit = splits; d.kt_per_split = per * 2; d.item0 = 0; d.nitems = (int)(tiles * splits);
+  if (slab) { d.C = workspace; d.ldc = (int)ldw; d.c_split_stride = (long)Mo * ldw; d.accumulate = 0; }
+  else { d.C = C; d.ldc = (int)ldc; d.c_split_stride = 0; d.accumulate = accumulate ? 1 : 0; }
+  grp.n = 1; grp.nitems = d.nitems;
+  const int rc = tn8_launch(grp, stream);
+  return rc < 0 ? rc : splits;
+}
+
+// Grouped form: n <= 4 gradients over the SAME number of rows R in one launch.  slices[i] (out) = K slices used for gradient i: when
+// > 1 its partial tiles lie in `workspace` at float offset ws_off[i] (slice stride Mo[i] * round4(No[i])) and the caller reduces
+// them; 1: written (or accumulated) straight into C[i].  Returns 1 when launched, 0 when the group is outside what the kernel covers
+// (nothing launched), < 0 on error.
+int vlb_gemm_tn8_group(int n, const void* const* A, const long* lda, const void* const* B, const long* ldb, float* const* C,
+                       const long* ldc, int R, const int* Mo, const int* No, float* const* colsum, float* workspace,
+                       long workspace_floats, int accumulate, int* slices, long* ws_off, hipStream_t stream) {
+  if (g_tn8_mode < 0) g_tn8_mode = env_int("VLB_GEMM_TN8", 1);
+  if (!g_tn8_mode || n < 1 || n > TN8_MAX_GROUP) return 0;
+  long tiles = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!tn8_shape_ok(lda[i], ldb[i], ldc[i], R)) return 0;
+    tiles += (long)vlb_cdiv(Mo[i], 256) * vlb_cdiv(No[i], 256);
+  }
+  const int pairs = R / 128;
+  // one slice count for the whole group (equal item lengths): as many slices as keep the item list within one round of 256 CUs
+  int splits = (int)(256 / tiles);
+  if (splits < 1) splits = 1;
+  if (splits > pairs) splits = pairs;
+  if (tiles * splits < 128) return 0;
+  const int per = vlb_cdiv(pairs, splits);
+  splits = vlb_cdiv(pairs, per);
+  Tn8Group grp = {};
+  long off = 0;
+  int item = 0;
+  for (int i = 0; i < n; ++i) {
+    Tn8Desc& d = grp.d[i];
+    const long ldw = (No[i] + 3) / 4 * 4;
+    d.A = (const bf16_t*)A[i]; d.B = (const bf16_t*)B[i]; d.colsum = colsum ? colsum[i] : nullptr;
+    d.lda = (int)lda[i]; d.ldb = (int)ldb[i]; d.Mo = Mo[i]; d.No = No[i]; d.R = R;
+    d.ntm = vlb_cdiv(Mo[i], 256); d.ntn = vlb_cdiv(No[i], 256); d.tile_group = tile_group_for(d.ntm, d.ntn);
+    d.nsplit = splits; d.kt_per_split = per * 2;
+    d.item0 = item; d.nitems = d.ntm * d.ntn * splits;
+    item += d.nitems;
+    if (splits > 1) {
+      d.C = workspace + off; d.ldc = (int)ldw; d.c_split_stride = (long)Mo[i] * ldw; d.accumulate = 0;
+      ws_off[i] = off;
+      off += (long)splits * Mo[i] * ldw;
+    } else {
+      d.C = C[i]; d.ldc = (int)ldc[i]; d.c_split_stride = 0; d.accumulate = accumulate ? 1 : 0;
+      ws_off[i] = 0;
+    }
+    slices[i] = splits;
+  }
+  if (splits > 1 && (!workspace || off > workspace_floats)) return 0;
+  grp.n = n; grp.nitems = item;
+  const int rc = tn8_launch(grp, stream);
+  return rc < 0 ? rc : 1;
 }

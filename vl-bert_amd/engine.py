@@ -321,9 +321,14 @@ class PretrainEngine:
 
         # backward scratch
         self.dXa, self.dXb = zb(M, H), zb(M, H)
-        self.dZ, self.dD, self.dDb = zb(M, H), zb(M, H), zb(M, H)     # dD / dDb: LN2 / LN1 outputs (a side-stream wgrad may still read one)
-        self.dU = zb(M, I)
-        self.dCTX, self.dQKV = zb(M, H), zb(M, 3 * H)
+        # The four weight gradients of a layer go out as ONE grouped launch at the end of the layer's backward (side stream), so their
+        # gradient operands (LN2 / LN1 outputs through dropout, dU, dQKV) stay alive until then and are double-buffered by layer
+        # parity: the next layer writes the other set while the group still reads this one.
+        self.dZ = zb(M, H)
+        self.dD2, self.dD1 = [zb(M, H), zb(M, H)], [zb(M, H), zb(M, H)]
+        self.dU2 = [zb(M, I), zb(M, I)]
+        self.dQKV2 = [zb(M, 3 * H), zb(M, 3 * H)]
+        self.dCTX = zb(M, H)
         self.tG = zb(max(3 * H, I), self.Mp)       # transposed gradients (zero padded columns persist)
         self.tA = zb(max(H, I), self.Mp)           # transposed activations
         self.tG_bt, self.tA_bt = zb(max(self.Vp, H), self.BTp), zb(H, self.BTp)
@@ -346,6 +351,7 @@ class PretrainEngine:
                 ((3 * H, H, self.Mp), (H, H, self.Mp), (I, H, self.Mp), (H, I, self.Mp), (V, H, self.BTp), (H, H, self.BTp),
                  (C, H, self.BRp), (H, H, self.BRp), (H, 2 * VIS_DIM, self.BRp))]
         need.append(ops.wgrad_workspace_floats(self.BT, H, self.Vp))     # tied-decoder dgrad (K = vocabulary) at small batch
+        need.append(2 * (3 * H * H + H * H + 2 * I * H) + 64)             # grouped launch of a layer's four gradients, 2 K slices
         self.wg_ws = zf(max(max(need), 4))
         # Weight gradients run on a second stream: they only feed the optimizer, while the dgrad chain is the critical
         # path, and at small per-GPU batch neither fills the chip (312 + 432 workgroups for 512 slots at B = 32).
@@ -654,6 +660,27 @@ class PretrainEngine:
         ops.transpose(x, ta)
         ops.wgrad_nt(tg, ta, gw, workspace=self.wg_ws)
 
+    def _wgrad_group(self, items):
+        """items: [(dy, x, gw, gb)] over the same rows -- the four Linear layers of an encoder layer -- as one grouped launch on the
+        side stream (ops.wgrad_tn_group); falls back to single calls without the TN path."""
+        if not self.use_tn_wgrad:
+            for dy, x, gw, gb in items:
+                self._wgrad(dy, x, gw, gb, self.tG, self.tA, self.Mp)
+            return
+        acc = not self._fresh_grads
+        if self.side is None:
+            ops.wgrad_tn_group(items, workspace=self.wg_ws, accumulate=acc)
+            return
+        ready = torch.cuda.Event()
+        ready.record()
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ready)
+            ops.wgrad_tn_group(items, workspace=self.wg_ws, accumulate=acc)
+            done = torch.cuda.Event()
+            done.record()
+        for dy, _, _, _ in items:
+            self._pending[dy.data_ptr()] = done              # whoever overwrites an operand next must wait for the group
+
     def _before_write(self, *bufs):
         """Main stream is about to overwrite these buffers: wait for side-stream weight gradients still reading them."""
         for b in bufs:
@@ -729,37 +756,36 @@ class PretrainEngine:
         for l in reversed(range(L)):
             p = "vlbert.encoder.layer.%d." % l
             dx_next = self.dXb if dx is self.dXa else self.dXa
-            drop = p_h > 0
-            # LN2: dZ2 (residual branch) and dD2 (into output.dense, through its dropout)
-            self._before_write(self.dZ, self.dD)
+            par = l & 1
+            dD2, dD1, dU, dQKV = self.dD2[par], self.dD1[par], self.dU2[par], self.dQKV2[par]
+            # LN2: dZ2 (residual branch) and dD2 (into output.dense, through its dropout; a plain copy when dropout is off --
+            # dZ is reused inside the layer, the grouped weight gradient at its end needs its own operand)
+            self._before_write(self.dZ, dD2)
             ops.layernorm_bwd(dx, self.Z2[l], self.ST2[l], w32[p + "output.LayerNorm.weight"], dx=self.dZ,
-                              dx_drop=self.dD if drop else None, drop_p=p_h, seed=seed, tag=l * 8 + 2,
+                              dx_drop=dD2, drop_p=p_h, seed=seed, tag=l * 8 + 2,
                               dgamma=g32[p + "output.LayerNorm.weight"], dbeta=g32[p + "output.LayerNorm.bias"],
                               workspace=self.ln_ws)
-            dD2 = self.dD if drop else self.dZ
-            self._wgrad(dD2, self.G[l], g32[p + "output.dense.weight"], g32[p + "output.dense.bias"], self.tG, self.tA, Mp)
-            self._before_write(self.dU)
-            ops.gemm_nt(dD2, wT[p + "output.dense.weight"], self.dU, act=ops.ACT_MULAUX, aux=self.U[l])
-            self._wgrad(self.dU, self.Y1[l], g32[p + "intermediate.dense.weight"], g32[p + "intermediate.dense.bias"], self.tG,
-                        self.tA, Mp)
-            ops.gemm_nt(self.dU, wT[p + "intermediate.dense.weight"], dx_next, res=self.dZ)            # dY1
+            self._before_write(dU)
+            ops.gemm_nt(dD2, wT[p + "output.dense.weight"], dU, act=ops.ACT_MULAUX, aux=self.U[l])
+            ops.gemm_nt(dU, wT[p + "intermediate.dense.weight"], dx_next, res=self.dZ)            # dY1
             # LN1
-            self._before_write(self.dZ, self.dDb)
+            self._before_write(self.dZ, dD1)
             ops.layernorm_bwd(dx_next, self.Z1[l], self.ST1[l], w32[p + "attention.output.LayerNorm.weight"], dx=self.dZ,
-                              dx_drop=self.dDb if drop else None, drop_p=p_h, seed=seed, tag=l * 8 + 1,
+                              dx_drop=dD1, drop_p=p_h, seed=seed, tag=l * 8 + 1,
                               dgamma=g32[p + "attention.output.LayerNorm.weight"], dbeta=g32[p + "attention.output.LayerNorm.bias"],
                               workspace=self.ln_ws)
-            dD1 = self.dDb if drop else self.dZ
-            self._wgrad(dD1, self.CTX[l], g32[p + "attention.output.dense.weight"], g32[p + "attention.output.dense.bias"],
-                        self.tG, self.tA, Mp)
             ops.gemm_nt(dD1, wT[p + "attention.output.dense.weight"], self.dCTX)
-            self._before_write(self.dQKV)
-            ops.attention_bwd(self.QKV[l], mask, self.CTX[l], self.LSE[l], self.dCTX, self.dQKV, Bt, S, H, nh, drop_p=p_a,
+            self._before_write(dQKV)
+            ops.attention_bwd(self.QKV[l], mask, self.CTX[l], self.LSE[l], self.dCTX, dQKV, Bt, S, H, nh, drop_p=p_a,
                               seed=seed, tag=l * 8 + 0)
             gwqkv = self.P.view(self.P.grad, p + "attention.self.query.weight", (3 * H, H), span=3)
             gbqkv = self.P.view(self.P.grad, p + "attention.self.query.bias", (3 * H,), span=3)
-            self._wgrad(self.dQKV, self.X[l], gwqkv, gbqkv, self.tG, self.tA, Mp)
-            ops.gemm_nt(self.dQKV, wT[p + "qkv"], dx_next, res=self.dZ)                                  # dX_l (overwrites dY1)
+            ops.gemm_nt(dQKV, wT[p + "qkv"], dx_next, res=self.dZ)                                  # dX_l (overwrites dY1)
+            # the layer's four weight gradients: one grouped launch (side stream), off the critical dgrad chain
+            self._wgrad_group([(dD2, self.G[l], g32[p + "output.dense.weight"], g32[p + "output.dense.bias"]),
+                               (dU, self.Y1[l], g32[p + "intermediate.dense.weight"], g32[p + "intermediate.dense.bias"]),
+                               (dD1, self.CTX[l], g32[p + "attention.output.dense.weight"], g32[p + "attention.output.dense.bias"]),
+                               (dQKV, self.X[l], gwqkv, gbqkv)])
             dx = dx_next
             if on_layer_done:
                 self._join_side()           # the bucket's weight gradients must be complete before its all-reduce reads them

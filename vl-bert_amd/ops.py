@@ -108,6 +108,24 @@ class ZeroRanges:
                       self.total, _stream())
 
 
+def wgrad_tn_group(items, workspace=None, accumulate=True):
+    """items: up to 4 (dy [R,Mo], x [R,No], C [Mo,No] fp32, colsum [Mo] | None) over the same R rows -> one grouped launch
+    (vlb_wgrad_tn_group_bf16)."""
+    import ctypes
+    n = len(items)
+    R = items[0][0].shape[0]
+    P, Lg, I = ctypes.c_void_p * n, ctypes.c_long * n, ctypes.c_int * n
+    for dy, x, C, cs in items:
+        assert dy.shape[0] == R and x.shape[0] == R and C.shape == (dy.shape[1], x.shape[1])
+    A = P(*[_p(t[0], BF16) for t in items]); lda = Lg(*[_ld(t[0]) for t in items])
+    B = P(*[_p(t[1], BF16) for t in items]); ldb = Lg(*[_ld(t[1]) for t in items])
+    Cs = P(*[_p(t[2], torch.float32) for t in items]); ldc = Lg(*[_ld(t[2]) for t in items])
+    Mo = I(*[t[0].shape[1] for t in items]); No = I(*[t[1].shape[1] for t in items])
+    cs = P(*[_p(t[3], torch.float32) for t in items])
+    _lib.call("vlb_wgrad_tn_group_bf16", n, A, lda, B, ldb, Cs, ldc, R, Mo, No, cs, _p(workspace, torch.float32),
+              workspace.numel() if workspace is not None else 0, 1 if accumulate else 0, _stream())
+
+
 def gemm_nt_splitk(A, B, C, workspace=None):
     """C (bf16) = A B^T with slab split-K when the output has too few tiles to fill the chip (long-K dgrad)."""
     M, K = A.shape
