@@ -171,10 +171,9 @@ def bench(batch):
               ("ffn2 fwd", M, 768, 3072, "dropres"), ("out dgrad", M, 768, 768, "plain"), ("qkv dgrad", M, 768, 2304, "res"),
               ("ffn1 dgrad", M, 768, 3072, "res"), ("ffn2 dgrad", M, 3072, 768, "mulaux"), ("decoder fwd", BT, 30522, 768, "bias"),
               ("square 4096", 4096, 4096, 4096, "plain"), ("square 8192", 8192, 8192, 8192, "plain")]
-    variants = [("128x128", dict(p8_mode=0)), ("p8 256 keepb", dict(p8_mode=4, p8_keepb=1, p8_group=2)),
-                ("p8 256 reread", dict(p8_mode=4, p8_keepb=0, p8_group=2)), ("p8 320", dict(p8_mode=5, p8_group=2)),
-                ("p8 256 g1", dict(p8_mode=4, p8_keepb=1, p8_group=1)), ("p8 256 g4", dict(p8_mode=4, p8_keepb=1, p8_group=4)),
-                ("p8 320 g4", dict(p8_mode=5, p8_group=4)), ("p8 model", dict(p8_mode=1, p8_keepb=1, p8_group=2))]
+    variants = [("128x128", dict(p8_mode=0)), ("p8 256", dict(p8_mode=4, p8_keepb=1, p8_group=2)),
+                ("p8 320", dict(p8_mode=5, p8_group=2)), ("p8 model", dict(p8_mode=1, p8_keepb=1, p8_group=2)),
+                ("p8 320 g4", dict(p8_mode=5, p8_group=4))]
     print("%-14s %7s %6s %6s | " % ("gemm", "M", "N", "K") + " | ".join("%-13s" % v[0] for v in variants))
     tot = [0.0] * len(variants)
     for name, m, n, k, kwm in shapes:
@@ -222,7 +221,28 @@ def bench_wgrad(batch):
     print("TN ms per step (12 layers + compact decoder): %.2f | %.2f" % tuple(tot), flush=True)
 
 
+def ablate(batch):
+    """where the time of a short-K GEMM goes: full kernel | no epilogue | epilogue without global stores"""
+    M = batch * 101
+    shapes = [("qkv fwd", M, 2304, 768, "bias"), ("ffn1 fwd", M, 3072, 768, "gelu"), ("ffn2 dgrad", M, 3072, 768, "mulaux"),
+              ("attn-out fwd", M, 768, 768, "dropres"), ("ffn2 fwd", M, 768, 3072, "dropres"), ("square 8192", 8192, 8192, 8192, "plain")]
+    print("%-14s | %-30s | %-30s" % ("gemm", "tile 256: full / no-epi / no-store (us)", "tile 320: full / no-epi / no-store (us)"))
+    for name, m, n, k, kwm in shapes:
+        row = []
+        for mode in (4, 5):
+            t = []
+            for ab in (0, 1, 2):
+                ms, tf = bench_one(m, n, k, kwm, dict(p8_mode=mode, p8_ablate=ab))
+                t.append(ms * 1e3)
+            row.append("%7.1f / %7.1f / %7.1f" % tuple(t))
+        lib.gemm_set_option("p8_ablate", 0)
+        print("%-14s | %-30s | %-30s" % (name, row[0], row[1]), flush=True)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "ablate":
+        ablate(int(sys.argv[2]) if len(sys.argv) > 2 else 256)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "check":
         sys.exit(1 if check() else 0)
     if len(sys.argv) > 1 and sys.argv[1] == "wgrad":

@@ -283,8 +283,9 @@ __device__ __forceinline__ void p8_drain(const GemmParams& p, f32x4 (&acc)[2 * F
           } else {
             p8_epilogue8<EPI>(p, v, b8, m, n, seed, sd);
           }
-          *(uint4*)(C + (long)m * p.ldc + n) = make_uint4(pack2o(v[0], v[1], f16out), pack2o(v[2], v[3], f16out), pack2o(v[4], v[5], f16out),
-                                                          pack2o(v[6], v[7], f16out));
+          const uint4 o4 = make_uint4(pack2o(v[0], v[1], f16out), pack2o(v[2], v[3], f16out), pack2o(v[4], v[5], f16out), pack2o(v[6], v[7], f16out));
+          if (p.ablate != 2) *(uint4*)(C + (long)m * p.ldc + n) = o4;
+          else if (o4.x == 0x12345678u && o4.y == 0x9abcdef0u) C[0] = 1;      // (timing ablation: keeps the math alive)
         } else {
           for (int e = 0; e < 8 && n + e < p.N; ++e) {
             const float o = p8_epilogue1<EPI>(p, v[e], m, n + e, seed);
@@ -519,7 +520,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(const GemmParams p) 
     // ---------------- epilogue: raw fp32 accumulators -> staging slab -> fused math on 8-column groups -> bf16 ----------------
     int m0, n0;
     tile_of(w, m0, n0);
-    if (w + (int)gridDim.x >= nt) {
+    if (p.ablate == 1) {
+      // (timing ablation: no epilogue at all)
+    } else if (w + (int)gridDim.x >= nt) {
       // last tile of this workgroup: nothing is in flight into the operand ring any more (the producer stopped at this tile and
       // every K tile it issued has been consumed) -> drain through a 128-row slab laid over the ring
       p8_drain<FMH, EPI, 4>(p, acc, lds0, m0, n0, wm, wn, lane, tid, seed);
@@ -587,8 +590,9 @@ inline bool aligned16(const void* q) { return ((uintptr_t)q & 15) == 0; }
 // p8_mode: 0 off | 1 cost model (default) | 4 / 5: force the 256- / 320-row tile wherever the kernel applies
 // p8_wgs: persistent workgroups per launch (<= 256 = one per CU).  Fewer leave CUs to a kernel running on another stream (the
 // weight-gradient GEMMs of the side stream): an MFMA-bound kernel then fills the HBM-bound epilogue bursts of this one.
-static int g_opt[5] = {-1, -1, -1, -1, -1};
-static const char* const g_opt_name[5] = {"p8_mode", "p8_keepb", "p8_group", "p8_min_tiles", "p8_wgs"};
+// p8_ablate (tools/p8_check.py ablate; results are WRONG when != 0): 1 no epilogue | 2 epilogue without its global stores
+static int g_opt[6] = {-1, -1, -1, -1, -1, -1};
+static const char* const g_opt_name[6] = {"p8_mode", "p8_keepb", "p8_group", "p8_min_tiles", "p8_wgs", "p8_ablate"};
 static void p8_options_init() {
   if (g_opt[0] >= 0) return;
   g_opt[0] = env_int("VLB_GEMM_P8", 1);
@@ -596,6 +600,7 @@ static void p8_options_init() {
   g_opt[2] = env_int("VLB_GEMM_P8_GROUP", 2);
   g_opt[3] = env_int("VLB_GEMM_P8_MIN_TILES", 160);
   g_opt[4] = env_int("VLB_GEMM_P8_WGS", 256);
+  g_opt[5] = 0;
 }
 
 extern "C" int vlb_gemm_set_option(const char* name, int value) {
@@ -609,7 +614,7 @@ extern "C" int vlb_gemm_set_option(const char* name, int value) {
     vlb_tn8_set_wgs(value);
     return VLB_OK;
   }
-  for (int i = 0; i < 5; ++i)
+  for (int i = 0; i < 6; ++i)
     if (!strcmp(name, g_opt_name[i])) {
       g_opt[i] = value;
       return VLB_OK;
@@ -647,6 +652,7 @@ int vlb_gemm_p8_try(GemmParams& p, hipStream_t stream) {
   int fmh = (c5 < 0.97 * c4) ? 5 : 4;
   if (mode == 4 || mode == 5) fmh = mode;
   const int g = group < 1 ? 1 : group;
+  p.ablate = g_opt[5];
   if (fmh == 5) return p8_launch_epi<5, false>(p, epi, g, stream);
   return keepb ? p8_launch_epi<4, true>(p, epi, g, stream) : p8_launch_epi<4, false>(p, epi, g, stream);
 }

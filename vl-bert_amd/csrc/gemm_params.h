@@ -17,6 +17,8 @@ struct GemmParams {
   // The encoder's residual stream then never passes through a bf16 rounding (DESIGN.md "precision").
   const float* res_stats; const float* res_gamma; const float* res_beta;
   int c_f16;                 // bf16-output kernels write C as fp16 instead (the pre-LayerNorm sums)
+  int ablate;                // gemm_p8 timing ablations (results are WRONG when != 0): 1 no epilogue | 2 epilogue without global stores |
+                             // 3 epilogue without the LDS slab round trip
   uint32_t drop_thr; float drop_scale; const uint32_t* seed; uint32_t tag;
   void* C; long ldc;
   long c_split_stride;       // elements between the outputs of consecutive K splits (slab split-K), 0 otherwise
