@@ -263,14 +263,27 @@ def main():
             return out
         return wrapper
 
+    def timed_group(items, *a, **kw):         # the grouped weight gradients of one encoder layer (one launch)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = orig_group(items, *a, **kw)
+        e1.record()
+        fl = sum(2.0 * dy.shape[0] * dy.shape[1] * x.shape[1] for dy, x, _, _ in items)
+        nb = sum(dy.numel() * 2 + x.numel() * 2 + C.numel() * 4 for dy, x, C, _ in items)
+        rec.append((e0, e1, fl, nb))
+        return out
+
     for n in names:
         setattr(ops, n, timed(n))
+    orig_group = ops.wgrad_tn_group
+    ops.wgrad_tn_group = timed_group
     side, eng.side = eng.side, None          # kernel efficiency is measured with the GEMMs serialised on one stream
     eng.train_step()
     torch.cuda.synchronize()
     eng.side = side
     for n in names:
         setattr(ops, n, orig[n])
+    ops.wgrad_tn_group = orig_group
     gemm_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in rec)
     gemm_flops = sum(f for _, _, f, _ in rec)
     gemm_alg_gb = sum(b for _, _, _, b in rec) / max(len(rec), 1) / 1e9      # operands read once + result written once
@@ -316,7 +329,8 @@ def main():
                        "collective_backend": (("RCCL (nccl)" if backend == "nccl" else backend) if world > 1 else None),
                        "grad_wire_dtype": (str(eng.buckets.reduced.dtype).replace("torch.", "") if eng.buckets is not None else None),
                        "ranks_share_devices": bool(shared)},
-            "roofline": {"bound": "mfma", "kernel": "gemm_nt_bf16_kernel + gemm_tn_bf16_kernel (all %d GEMM launches of one step)" % len(rec),
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt_p8_kernel + gemm_tn8_kernel (+ the 128x128 gemm_nt / gemm_tn kernels on the small head shapes): "
+                                                       "all %d GEMM launches of one step" % len(rec),
                          "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": traffic_unit,
                          "algorithmic_GB_per_launch": round(gemm_alg_gb, 4),

@@ -84,10 +84,11 @@ __device__ __forceinline__ void p8_epilogue8(const GemmParams& p, float (&v)[8],
   if (EPI == 1) {
     float d[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float g;
-      gelu_both(v[e], g, d[e]);
-      v[e] = g;
+    for (int e = 0; e < 8; e += 2) {      // packed fp32: two elements per VALU issue
+      vlb_f2 g2, d2;
+      gelu_both2((vlb_f2){v[e], v[e + 1]}, g2, d2);
+      v[e] = g2.x; v[e + 1] = g2.y;
+      d[e] = d2.x; d[e + 1] = d2.y;
     }
     if (p.pre)
       *(uint4*)(p.pre + (long)m * p.ldpre + n) = make_uint4(pack2bf(d[0], d[1]), pack2bf(d[2], d[3]), pack2bf(d[4], d[5]), pack2bf(d[6], d[7]));
