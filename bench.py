@@ -306,12 +306,12 @@ def main():
     # HBM bytes per GEMM launch come from PMC counters, which need their own rocprofv3 passes (tools/make_profiles.sh);
     # the committed summary of those passes is reported here when it was taken on this workload, else null.
     traffic, traffic_unit = None, None
-    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_gemm_traffic.json")
+    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_gemm_traffic.json")
     if world == 1 and args.global_batch == 256 and args.layers == 12 and os.path.isfile(tpath):
         with open(tpath) as f:
             tj = json.load(f)
         traffic = round(tj["gemm_hbm_GB_per_launch"], 4)
-        traffic_unit = "GB per GEMM launch (avg over %d launches/step; rocprofv3 2xFETCH_SIZE+WRITE_SIZE, profiles/r01_gemm_traffic.json)" \
+        traffic_unit = "GB per GEMM launch (avg over %d launches/step; rocprofv3 2xFETCH_SIZE+WRITE_SIZE, profiles/r02_gemm_traffic.json)" \
             % round(tj["gemm_launches_per_step"])
 
     if rank == 0:

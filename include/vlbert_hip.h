@@ -333,9 +333,6 @@ int vlb_roi_align_bwd(const float* grad_output, const float* rois, float* grad_i
                       int channels, int height, int width, int pooled_h, int pooled_w, float spatial_scale,
                       int sampling_ratio, vlb_stream_t stream);
 
-/* ---- debug probes (development only; not on the product path) ---------------------------------- */
-/* one ds_read_b64_tr_b16 per lane at LDS byte address addr[lane] over LDS[i] = in[i]; out[lane*4+j] */
-int vlb_debug_tr_read(const uint16_t* in, int n_elems, const int* addr, uint16_t* out, vlb_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,5 +1,7 @@
-// Debug / probe entry points (not on the product path): hardware-semantics probes used while developing kernels.
-#include "vlb_common.h"
+// Hardware-semantics probe used while developing the LDS-transpose-read kernels.  A development tool: built on the fly into its own
+// shared object by tools/probe_tr.py; NOT part of libvlbert_hip.so or of the product ABI (include/vlbert_hip.h).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
@@ -14,9 +16,8 @@ __global__ void probe_tr_read_kernel(const uint16_t* in, int n_elems, const int*
   for (int j = 0; j < 4; ++j) out[lane * 4 + j] = (uint16_t)v[j];
 }
 
-extern "C" int vlb_debug_tr_read(const uint16_t* in, int n_elems, const int* addr, uint16_t* out, hipStream_t stream) {
-  VLB_CHECK_ARG(in && addr && out && n_elems > 0 && n_elems <= 8192, "vlb_debug_tr_read: bad arguments");
+extern "C" int probe_tr_read(const uint16_t* in, int n_elems, const int* addr, uint16_t* out, hipStream_t stream) {
+  if (!in || !addr || !out || n_elems <= 0 || n_elems > 8192) return -1;
   hipLaunchKernelGGL(probe_tr_read_kernel, dim3(1), dim3(64), 0, stream, in, n_elems, addr, out);
-  VLB_CHECK_LAUNCH("vlb_debug_tr_read");
-  return VLB_OK;
+  return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -1,9 +1,13 @@
 #!/usr/bin/env python
 """Probe the lane/element semantics of ds_read_b64_tr_b16 on gfx950 (development tool)."""
-import importlib, os, sys
+import ctypes, os, subprocess, sys, tempfile
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-lib = importlib.import_module("vl-bert_amd._lib")
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+so = os.path.join(tempfile.gettempdir(), "probe_tr.so")
+subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-shared", "-fPIC", os.path.join(HERE, "probe_tr.hip"), "-o", so], check=True)
+probe = ctypes.CDLL(so)
+probe.probe_tr_read.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
 
 def run(addr):
     d = "cuda:0"
@@ -11,7 +15,7 @@ def run(addr):
     inp = torch.arange(n, dtype=torch.int32).to(torch.int16).to(d)
     a = torch.tensor(addr, dtype=torch.int32, device=d)
     out = torch.zeros(256, dtype=torch.int16, device=d)
-    lib.call("vlb_debug_tr_read", inp.data_ptr(), n, a.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert probe.probe_tr_read(inp.data_ptr(), n, a.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
     torch.cuda.synchronize()
     return out.cpu().numpy().astype(np.int64).reshape(64, 4) & 0xFFFF
 

@@ -32,6 +32,10 @@ def short(n):
 
 
 def family(n):
+    if "gemm_nt_p8" in n:
+        return "gemm_nt_p8_kernel"            # large-tile 8-phase NT core (gemm_p8.hip): every epilogue / tile height
+    if "gemm_tn8" in n:
+        return "gemm_tn8_kernel"              # large-tile TN core (weight gradients, grouped per layer)
     if "gemm_nt_bf16" in n or "gemm_nt_256" in n:
         return "gemm_nt_bf16_kernel"          # (incl. the 256x256-tile instantiation used by the decoder)
     if "gemm_tn_bf16" in n:
@@ -92,6 +96,10 @@ def pmc(name):
 
 def family_e2e(n):
     conv = ", true>" in n
+    if "gemm_nt_p8" in n:
+        return "gemm_nt_p8_kernel"
+    if "gemm_tn8" in n:
+        return "gemm_tn8_kernel"
     if "gemm_nt_bf16" in n or "gemm_nt_256" in n:
         return "gemm_nt_bf16_kernel<..,CONV>" if conv else "gemm_nt_bf16_kernel"
     if "gemm_tn_bf16" in n:
@@ -107,7 +115,7 @@ def write_sq(sq_dir, out_name, what, gemm_keys):
                 "# SQ_LDS_* count cycles summed over SIMDs / CUs (MI355X_MICROARCH.md, PMC slots).\n" % what)
         names = sorted({k for a in sq.values() for k in a["c"]})
         f.write("%-34s %6s %9s " % ("kernel family", "calls", "avg_us") + " ".join("%24s" % n for n in names) + "\n")
-        for k, a in sorted(sq.items(), key=lambda kv: -kv[1]["dur"])[:10]:
+        for k, a in sorted(sq.items(), key=lambda kv: -kv[1]["dur"])[:12]:
             f.write("%-34s %6d %9.1f " % (k[:34], a["n"], a["dur"] / a["n"] / 1e3) + " ".join("%24.4g" % (a["c"].get(n, 0) / a["n"]) for n in names) + "\n")
         for k in gemm_keys:
             if k in sq:
@@ -138,9 +146,10 @@ def write_traffic(fetch_dir, write_dir, out_name, what, top=14):
     return traffic
 
 
-write_sq("final_sq", tag + "_gemm_pmc.txt", "the same bench command", ("gemm_nt_bf16_kernel", "gemm_tn_bf16_kernel"))
+GEMM_FAMILIES = ("gemm_nt_p8_kernel", "gemm_tn8_kernel", "gemm_nt_bf16_kernel", "gemm_tn_bf16_kernel")
+write_sq("final_sq", tag + "_gemm_pmc.txt", "the same bench command", GEMM_FAMILIES)
 traffic = write_traffic("final_fetch", "final_write", tag + "_hbm_traffic.txt", "the same bench command")
-g = [traffic[k] for k in ("gemm_nt_bf16_kernel", "gemm_tn_bf16_kernel") if k in traffic]
+g = [traffic[k] for k in GEMM_FAMILIES if k in traffic]
 n = sum(t["launches_per_step"] for t in g)
 out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), tools/make_profiles.sh + tools/profile_report.py",
        "correction": "read = 2 x FETCH_SIZE (gfx950, 16 B/lane streaming reads); WRITE_SIZE as reported",
@@ -153,5 +162,6 @@ print("wrote", dst, tag, "GEMM GB/launch", out["gemm_hbm_GB_per_launch"])
 if glob.glob(os.path.join(src, "final_e2e_sq", "*.db")):        # the e2e configuration: convolution / ROIAlign kernels
     family = family_e2e
     write_sq("final_e2e_sq", tag + "_e2e_pmc.txt", "python bench.py --e2e (config C3)",
-             ("gemm_nt_bf16_kernel<..,CONV>", "gemm_tn_bf16_kernel<..,CONV>", "gemm_nt_bf16_kernel", "gemm_tn_bf16_kernel"))
+             ("gemm_nt_bf16_kernel<..,CONV>", "gemm_tn_bf16_kernel<..,CONV>", "gemm_nt_p8_kernel", "gemm_tn8_kernel", "gemm_nt_bf16_kernel",
+              "gemm_tn_bf16_kernel"))
     write_traffic("final_e2e_fetch", "final_e2e_write", tag + "_e2e_hbm_traffic.txt", "python bench.py --e2e (config C3)", top=18)

@@ -72,7 +72,6 @@ _SIGS = {
     "vlb_cast_f32_bf16": "ppls",
     "vlb_cast_bf16_f32": "ppls",
     "vlb_rng_advance": "ps",
-    "vlb_debug_tr_read": "pipps",
     "vlb_roi_align_fwd": "pppiiiiiifis",
     "vlb_roi_align_bwd": "pppiiiiiiifis",
 }

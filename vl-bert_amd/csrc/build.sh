@@ -7,7 +7,7 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -ffp-contract=fast"
 mkdir -p "$HERE/obj"
 pids=()
-for f in api gemm gemm_p8 gemm_tn8 layernorm embed loss attention optim roi_align vision debug; do
+for f in api gemm gemm_p8 gemm_tn8 layernorm embed loss attention optim roi_align vision; do
   [ -f "$HERE/$f.hip" ] || continue
   if [ ! -f "$HERE/obj/$f.o" ] || [ "$HERE/$f.hip" -nt "$HERE/obj/$f.o" ] || [ "$HERE/vlb_common.h" -nt "$HERE/obj/$f.o" ] || [ "$HERE/gemm_params.h" -nt "$HERE/obj/$f.o" ] \
      || [ "$HERE/../../include/vlbert_hip.h" -nt "$HERE/obj/$f.o" ]; then
