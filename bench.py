@@ -105,6 +105,8 @@ def main():
     ap.add_argument("--e2e", action="store_true", help="config C3 (cfgs/pretrain/base_e2e_16x16G_fp16.yaml): ResNet-101 trunk + ROIAlign + "
                     "layer4 head on 600x1000 images, 8 images per GPU, in front of the same VL-BERT step")
     ap.add_argument("--image-size", type=int, nargs=2, default=(600, 1000))
+    ap.add_argument("--aux-batch", type=int, default=None, help="text-only samples per GPU appended to the caption batch (MODULE "
+                    "ResNetVLBERTForPretrainingMultitask).  Default: 8 with --e2e (TRAIN.BATCH_IMAGES [8, 8] of the shipped yaml), else 0")
     ap.add_argument("--large", action="store_true", help="VL-BERT-large shape of BASELINE.json configs 4-5 through the same pretraining step: "
                     "24 layers, hidden 1024, 16 heads, FFN 4096, 128 text + 100 regions (S = 229); default global batch 64")
     ap.add_argument("--layers", type=int, default=12)
@@ -164,16 +166,23 @@ def main():
     if args.global_batch is None:
         args.global_batch = 8 * world if args.e2e else (64 if args.large else 256)
     per_gpu = args.global_batch // world
+    aux = args.aux_batch if args.aux_batch is not None else (8 if args.e2e else 0)
     if args.large:
         args.layers = 24
-        cfg = engine.ModelConfig(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096, e2e=args.e2e)
+        cfg = engine.ModelConfig(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096, e2e=args.e2e,
+                                 multitask=aux > 0)
     else:
-        cfg = engine.ModelConfig(num_hidden_layers=args.layers, e2e=args.e2e)
+        cfg = engine.ModelConfig(num_hidden_layers=args.layers, e2e=args.e2e, multitask=aux > 0)
     eng = engine.PretrainEngine(cfg, per_gpu, T, R, device="cuda:%d" % local_rank, train=True, lr=1e-4, weight_decay=1e-4,
-                                max_grad_norm=10.0, seed=1234 + rank, image_size=tuple(args.image_size) if args.e2e else None)
+                                max_grad_norm=10.0, seed=1234 + rank, image_size=tuple(args.image_size) if args.e2e else None,
+                                B_aux=aux)
     eng.init_random(seed=rank, visual_ln_init=1.0 if args.e2e else 0.0)
     eng.broadcast_parameters(src=0)      # rank 0's parameters everywhere (the DDP start-up broadcast, pretrain/function/train.py:331-334)
     batch = syn.make_batch(per_gpu, T, R, seed=100 + rank)
+    kw = {}
+    if aux:           # the text-only corpus batch of the multitask wrapper (general_corpus.py): SEQ_LEN 64, no regions
+        aux_text, aux_lab = syn.make_aux_text(aux, T, seed=300 + rank)
+        kw.update(aux_text=aux_text.cuda(non_blocking=True), aux_mlm_labels=aux_lab.cuda(non_blocking=True))
     if args.e2e:      # images as the dataset hands them over (mean-subtracted pixels), boxes inside the image
         gi = torch.Generator().manual_seed(200 + rank)
         Hi, Wi = args.image_size
@@ -185,9 +194,8 @@ def main():
         bx[:, :, 3] = torch.minimum(bx[:, :, 3], torch.full_like(bx[:, :, 3], Hi - 1.0))
         bx[:, 0, :4] = torch.tensor([0.0, 0.0, Wi - 1.0, Hi - 1.0])
         batch[1][:, 0], batch[1][:, 1] = Wi, Hi
-        eng.set_batch(*[t.cuda(non_blocking=True) for t in batch], image=image.cuda(non_blocking=True))
-    else:
-        eng.set_batch(*[t.cuda(non_blocking=True) for t in batch])
+        kw["image"] = image.cuda(non_blocking=True)
+    eng.set_batch(*[t.cuda(non_blocking=True) for t in batch], **kw)
     eng.sync_weights()
     torch.cuda.synchronize()
 
@@ -219,7 +227,8 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt)
     ms = elapsed / args.steps * 1e3
-    value = args.global_batch / (elapsed / args.steps)
+    total_samples = args.global_batch + aux * world          # caption samples + text-only samples of one step, all ranks
+    value = total_samples / (elapsed / args.steps)
     losses = eng.loss_values()
 
     # ---- forward-only and forward+backward times (SURVEY.md §8d asks for them next to the step time); outside the timed region
@@ -309,6 +318,9 @@ def main():
     by_op["host_launch_ms_whole_step"] = round(h_step * 1e3, 3)
     achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     fwd, fwdbwd = flops_per_sample(cfg, T, R)
+    if aux:           # sample-weighted mean: a text-only sample is T tokens + END, no regions, MLM head only
+        fa, fba = flops_per_sample(cfg, T, 0)
+        wc, wa = per_gpu / (per_gpu + aux), aux / (per_gpu + aux)
     if args.e2e:      # + convolution FLOPs of the vision path (forward of every conv; dgrad + wgrad of the trainable stages)
         vs = eng.vision
         need_dx = vs._dgrad_set()
@@ -323,6 +335,8 @@ def main():
             if b["trainable"]:
                 vb += sum(f * (2 if k + n in need_dx else 1) for n, f in per.items())
         fwd, fwdbwd = fwd + vf / per_gpu, fwdbwd + (vf + vb) / per_gpu
+    if aux:
+        fwd, fwdbwd = wc * fwd + wa * fa, wc * fwdbwd + wa * fba
     # HBM bytes per GEMM launch come from PMC counters, which need their own rocprofv3 passes (tools/make_profiles.sh);
     # the committed summary of those passes is reported here when it was taken on this workload, else null.
     traffic, traffic_unit = None, None
@@ -343,8 +357,14 @@ def main():
             "dtype": "bf16", "data": "synthetic (random-init weights, random tokens/boxes/features, resident in HBM)",
             "config": {"workload": "VL-BERT-%s %d-layer pretrain step (fwd+bwd+clip+AdamW), %d text + %d regions, "
                                    "%s, dropout on" % ("large" if args.large else "base", args.layers, T, R, "ResNet-101 trunk + ROIAlign + dilated layer4 head on the device "
-                                                       "(stages 1-2 and BatchNorm frozen)" if args.e2e else "precomputed 2048-d region features"),
-                       "global_batch": args.global_batch, "per_gpu_batch": per_gpu, "seq_len": T + R + 1,
+                                                       "(stages 1-2 and BatchNorm frozen)" if args.e2e else "precomputed 2048-d region features")
+                                   + ("; multitask: %d image-caption + %d text-only samples per GPU in one encoder pass" % (per_gpu, aux) if aux else ""),
+                       "global_batch": total_samples, "per_gpu_batch": per_gpu + aux, "per_gpu_caption_samples": per_gpu,
+                       "per_gpu_text_only_samples": aux,
+                       "module": "ResNetVLBERTForPretrainingMultitask" if aux else "ResNetVLBERTForPretraining",
+                       "reference_cfg": ("cfgs/pretrain/base_e2e_16x16G_fp16.yaml" if (args.e2e and aux == 8 and per_gpu == 8 and not args.large)
+                                         else None),
+                       "seq_len": T + R + 1,
                        "parallelism": "dp%d" % world, "hipgraph": bool(use_graph), "arch": arch, "cus": cus,
                        "collective_backend": (("RCCL (nccl)" if backend == "nccl" else backend) if world > 1 else None),
                        "grad_wire_dtype": (str(eng.buckets.reduced.dtype).replace("torch.", "") if eng.buckets is not None else None),

@@ -291,18 +291,25 @@ def pretrain_forward(p, cfg, boxes, im_info, text, relationship_label, mlm_label
 
 
 def pretrain_multitask_forward(p, cfg, boxes, im_info, text, relationship_label, mlm_labels, mvrc_ops, mvrc_labels,
-                               aux_text, aux_mlm_labels, train=False):
-    """pretrain/modules/resnet_vlbert_for_pretraining_multitask.py:96-290 (precomputed features, one auxiliary
-    text-only dataset): the aux captions are appended as extra samples without objects whose text-visual embedding is
-    the learned `aux_text_visual_embedding`; MLM loss is split into the with-visual-content and aux parts."""
+                               aux_text, aux_mlm_labels, train=False, image=None, vision_params=None, image_num_layers=101):
+    """pretrain/modules/resnet_vlbert_for_pretraining_multitask.py:96-290 (one auxiliary text-only dataset): the aux captions
+    are appended as extra samples without objects whose text-visual embedding is the learned `aux_text_visual_embedding`; MLM
+    loss is split into the with-visual-content and aux parts.  image=None: precomputed features (:132-135); image + vision_params:
+    the e2e configuration of cfgs/pretrain/base_e2e_16x16G_fp16.yaml (MASK_RAW_PIXELS default true => mask_visual_embed=None,
+    :137-146) -- only the caption samples carry an image, the text-only samples never touch the CNN."""
     boxes = boxes.clone()
     box_mask = boxes[:, :, 0] > -1.5
     origin_len = boxes.shape[1]
     max_len = int(box_mask.sum(1).max())
     box_mask, boxes = box_mask[:, :max_len], boxes[:, :max_len]
     mvrc_ops, mvrc_labels = mvrc_ops[:, :max_len], mvrc_labels[:, :max_len]
-    feats = boxes[:, :, 4:].clone()
-    feats[mvrc_ops == 1] = p["object_mask_visual_embedding.weight"][0]
+    if image is not None:
+        from . import vision_oracle as VO
+        valid, _ = VO.e2e_features(image, boxes[:, :, :4], vision_params, image_num_layers)
+        feats = valid.new_zeros((*box_mask.shape, valid.shape[1])).masked_scatter(box_mask[:, :, None], valid)
+    else:
+        feats = boxes[:, :, 4:].clone()
+        feats[mvrc_ops == 1] = p["object_mask_visual_embedding.weight"][0]
     boxes = torch.cat((boxes[:, :, :4], feats), -1)
     obj_reps = fast_rcnn_precomputed(p, cfg, boxes, box_mask, im_info, train)
     B, R = box_mask.shape

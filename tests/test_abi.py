@@ -99,6 +99,25 @@ def test_train_end2end_entry_point_dry_run(tmp_path):
         r3 = tr.main(["--cfg", ref3, "--dry-run"])
         assert r3["multitask"] and r3["e2e"] and r3["per_gpu_batch"] == 8 and r3["per_gpu_aux_batch"] == 8
         assert r3["global_batch"] == 16 and abs(r3["lr"] - 1.0e-7 * 16 * r3["accumulate"]) < 1e-15
+    # the repository's own cfgs/pretrain/base_e2e_16x16G_fp16.yaml (BASELINE config 3): resolves the same way and carries the
+    # reference file's value for every key it names
+    mine = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cfgs", "pretrain", "base_e2e_16x16G_fp16.yaml")
+    r4 = tr.main(["--cfg", mine, "--dry-run"])
+    assert r4["multitask"] and r4["e2e"] and (r4["per_gpu_batch"], r4["per_gpu_aux_batch"]) == (8, 8) and r4["image_size"] == (600, 1000)
+    assert abs(r4["lr"] - 1.6e-6) < 1e-15 and r4["warmup_steps"] == 16000 and r4["fp16_requested"] and r4["seed"] == 12345
+    if os.path.isfile(ref3):
+        import yaml
+        assert r4 == r3
+
+        def same(a, b, path=""):
+            for k, v in b.items():
+                assert k in a, path + k
+                if isinstance(v, dict):
+                    same(a[k], v, path + k + ".")
+                else:
+                    assert a[k] == v, (path + k, a[k], v)
+        with open(ref3) as f, open(mine) as g:
+            same(yaml.safe_load(f), yaml.safe_load(g))
     if not torch.cuda.is_available():
         with pytest.raises(RuntimeError, match="no CPU execution path"):
             tr.main(["--cfg", str(y), "--steps", "1"])

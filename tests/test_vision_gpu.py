@@ -346,6 +346,20 @@ def test_vision_stack_matches_reference_golden():
         assert e < (3e-2 if "roi_head" in short else 8e-2), short
 
 
+def _vision_grad_errors(eng, Po, names):
+    """per-tensor rel-Frobenius errors of the trainable convolution gradients, the rel-Frobenius error of their concatenation and
+    the relative difference of the global gradient norm over the vision parameters."""
+    errs, num, gn, rn = [], 0.0, 0.0, 0.0
+    for name, g in eng.vision.grads().items():
+        ref = Po[names[name[len("image_feature_extractor."):]]].grad
+        errs.append((rel_fro(g, ref), name))
+        a, b = g.double().cpu().reshape(-1), ref.double().cpu().reshape(-1)
+        num += float((a - b).pow(2).sum())
+        gn += float(a.pow(2).sum())
+        rn += float(b.pow(2).sum())
+    return errs, (num / rn) ** 0.5, abs(gn ** 0.5 - rn ** 0.5) / rn ** 0.5
+
+
 @pytest.mark.parametrize("empty_sample", [False, True])
 def test_engine_e2e_step_vs_oracle(empty_sample):
     """One e2e pretraining step (image -> CNN -> VL-BERT -> losses -> gradients) of the engine against the composed oracle.
@@ -386,12 +400,11 @@ def test_engine_e2e_step_vs_oracle(empty_sample):
     assert abs(lv["mlm_loss"] - float(out["mlm_loss"])) < 2e-2 * max(1.0, abs(float(out["mlm_loss"])))
     assert abs(lv["mvrc_loss"] - float(out["mvrc_loss"])) < 2e-2 * max(1.0, abs(float(out["mvrc_loss"].detach())))
     names = dict(zip(VO.split_state_dict(P).keys(), P.keys()))
-    errs = []
-    for name, g in eng.vision.grads().items():
-        ref = Po[names[name[len("image_feature_extractor."):]]].grad
-        errs.append((rel_fro(g, ref), name))
-    print("e2e engine: conv weight gradients median rel-fro %.3e worst %.3e (%s)" % (float(np.median([e for e, _ in errs])), *max(errs)))
+    errs, glob, dnorm = _vision_grad_errors(eng, Po, names)
+    print("e2e engine: conv weight gradients median rel-fro %.3e worst %.3e (%s); all vision parameters: rel-fro %.3e, grad-norm "
+          "difference %.3e" % (float(np.median([e for e, _ in errs])), *max(errs), glob, dnorm))
     assert np.median([e for e, _ in errs]) < 5e-2 and max(errs)[0] < 0.2
+    assert dnorm < 1e-2, dnorm          # global gradient norm over the vision parameters (what the clip and the step size see)
     assert leaves["object_mask_visual_embedding.weight"].grad is None or float(leaves["object_mask_visual_embedding.weight"].grad.abs().sum()) == 0.0
     assert float(eng.g32["object_mask_visual_embedding.weight"].abs().sum()) == 0.0
     for k in ("image_feature_extractor.obj_downsample.1.weight", "vlbert.encoder.layer.0.output.dense.weight"):
@@ -406,6 +419,75 @@ def test_engine_e2e_step_vs_oracle(empty_sample):
     moved = [k for k in before if not torch.equal(before[k], after[k])]
     trainable = set(eng.vision.grads())
     assert set(moved) == trainable, (set(moved) ^ trainable)
+
+
+def test_engine_multitask_e2e_step_vs_oracle():
+    """multitask x e2e (cfgs/pretrain/base_e2e_16x16G_fp16.yaml: MODULE ResNetVLBERTForPretrainingMultitask with
+    IMAGE_FEAT_PRECOMPUTED false): caption samples take their region features from the CNN, the text-only samples never touch it
+    and see aux_text_visual_embedding; three losses (mlm_wvc, mlm_aux, mvrc) and all gradients against the composed oracle
+    (resnet_vlbert_for_pretraining_multitask.py:96-290)."""
+    E, syn = pkg("engine"), pkg("synthetic")
+    z, nl, P = _vision_fixture()
+    img, boxes4 = torch.from_numpy(z["img"]), torch.from_numpy(z["boxes"]).clone()
+    B, R = boxes4.shape[:2]
+    T, Ba = 12, 3
+    cfg = O.VLBertConfig(num_hidden_layers=1)
+    cfg.multitask = True
+    params = O.init_params(cfg, seed=31)
+    batch = list(syn.make_batch(B, T, R, seed=32, ragged=False))
+    batch[0] = torch.cat((boxes4, torch.zeros(B, R, 2048)), -1)
+    batch[1] = torch.from_numpy(z["im_info"])
+    pad = boxes4[:, :, 0] <= -1.5
+    batch[5][pad] = 0
+    batch[6][pad] = 0
+    aux_text, aux_lab = syn.make_aux_text(Ba, T, seed=33)
+    mc = E.ModelConfig(num_hidden_layers=1, e2e=True, multitask=True, image_num_layers=nl)
+    eng = E.PretrainEngine(mc, B, T, R, device="cuda:0", train=False, keep_logits=True, image_size=tuple(img.shape[2:]), B_aux=Ba)
+    sd = {k: v.to(dev()) for k, v in params.items()}
+    sd.update({k: v.to(dev()) for k, v in _prefixed(P).items()})
+    eng.load_state_dict(sd)
+    eng.set_batch(*[t.to(dev()) for t in batch], aux_text=aux_text.to(dev()), aux_mlm_labels=aux_lab.to(dev()), image=img.to(dev()))
+    eng.zero_grad()
+    eng.forward(False)
+    eng.backward(False)
+    torch.cuda.synchronize()
+    frozen = VO.frozen_names(P)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    Po = {k: v.clone().requires_grad_(k not in frozen) for k, v in P.items()}
+    out, loss = O.pretrain_multitask_forward(leaves, cfg, *batch, aux_text, aux_lab, train=False, image=img, vision_params=Po,
+                                             image_num_layers=nl)
+    loss.backward()
+    lv = eng.loss_values()
+    for k in ("mlm_loss_wvc", "mlm_loss_aux", "mvrc_loss"):
+        print("multitask e2e %s: hip %.5f oracle %.5f" % (k, lv[k], float(out[k].detach())))
+        assert abs(lv[k] - float(out[k])) < 2e-2 * max(1.0, abs(float(out[k].detach()))), k
+    names = dict(zip(VO.split_state_dict(P).keys(), P.keys()))
+    errs, glob, dnorm = _vision_grad_errors(eng, Po, names)
+    print("multitask e2e: conv weight gradients median rel-fro %.3e worst %.3e (%s); all vision parameters: rel-fro %.3e, "
+          "grad-norm difference %.3e" % (float(np.median([e for e, _ in errs])), *max(errs), glob, dnorm))
+    assert np.median([e for e, _ in errs]) < 5e-2 and max(errs)[0] < 0.2
+    assert dnorm < 1e-2, dnorm
+    for k in ("aux_text_visual_embedding.weight", "image_feature_extractor.obj_downsample.1.weight",
+              "vlbert.encoder.layer.0.output.dense.weight", "vlbert.word_embeddings.weight"):
+        e = rel_fro(eng.g32[k], leaves[k].grad)
+        print("  %s rel-fro %.3e" % (k, e))
+        assert e < 5e-2, k
+
+
+def test_train_end2end_runs_the_shipped_e2e_multitask_config():
+    """cfgs/pretrain/base_e2e_16x16G_fp16.yaml (BASELINE config 3) unmodified through the reference-style entry point: MODULE
+    ResNetVLBERTForPretrainingMultitask, 8 image-caption samples (600x1000 images through ResNet-101 / ROIAlign / layer4) + 8
+    text-only samples per GPU, triangle schedule with 16000 warm-up steps -- two optimizer steps on synthetic batches."""
+    tr = pkg("pretrain.train_end2end")
+    cfg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cfgs", "pretrain", "base_e2e_16x16G_fp16.yaml")
+    eng = tr.main(["--cfg", cfg, "--steps", "2"])
+    torch.cuda.synchronize()
+    lv = eng.loss_values()
+    assert eng.B == 8 and eng.Ba == 8 and eng.vision is not None and eng.in_image.shape[2:] == (600, 1000)
+    assert np.isfinite(lv["loss"]) and lv["mlm_loss_wvc"] > 0 and lv["mlm_loss_aux"] > 0 and lv["mvrc_loss"] > 0
+    assert float(eng.adam[5]) == 2.0
+    base = 1.0e-7 * 16                                           # TRAIN.LR x (8 + 8) x world 1
+    assert abs(float(eng.adam[0]) - base * O.warmup_linear_lr(2, 16000, 100000)) < 1e-6 * base
 
 
 def test_dropin_module_e2e_training_loop_contract():

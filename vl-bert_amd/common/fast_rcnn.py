@@ -132,7 +132,7 @@ class FastRCNN(nn.Module):
         self._w16 = torch.zeros((final_dim, 2 * VIS_DIM), dtype=torch.bfloat16, device=dev)
         self._wT = torch.zeros((2 * VIS_DIM, final_dim), dtype=torch.bfloat16, device=dev)
         self._zero_embed = torch.zeros((VIS_DIM,), dtype=torch.float32, device=dev)
-        self._seed = torch.tensor([20011], dtype=torch.int32, device=dev)
+        self._seed = torch.tensor([ops.rank_seed(20011)], dtype=torch.int32, device=dev)
         self._version, self._states = None, {}
         self._stacks, self._conv_params, self._conv_grads, self._vbuffers, self._vversion = {}, {}, {}, {}, 0
         if self.e2e:

@@ -19,6 +19,7 @@ import torch
 import torch.nn as nn
 
 from .. import engine as _engine
+from .. import ops
 
 _PREFIX = "vlbert."
 
@@ -134,7 +135,8 @@ class VisualLinguisticBert(nn.Module):
         key = (B, T, R, sequence)
         if key not in self._engines:
             self._engines[key] = _engine.PretrainEngine(self.cfg, B, T, R, device=str(self.device_), flat=self.flat, core=True,
-                                                        core_heads=self.WITH_HEADS, core_sequence=sequence)
+                                                        core_heads=self.WITH_HEADS, core_sequence=sequence,
+                                                        seed=ops.rank_seed(1234) // 2)      # per-rank dropout stream
         eng = self._engines[key]
         version = self.flat.master._version
         if getattr(eng, "_synced_version", None) != version:

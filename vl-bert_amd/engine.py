@@ -164,8 +164,8 @@ class PretrainEngine:
                  B_aux=0, core=False, core_heads=True, core_sequence=False, lr_schedule=None, warmup_steps=0, t_total=0,
                  image_size=None):
         cfg.validate()
-        if cfg.e2e and (core or B_aux or image_size is None):
-            raise ValueError("e2e needs image_size=(H, W) and the plain pretraining wrapper (no core / multitask mode)")
+        if cfg.e2e and (core or image_size is None):
+            raise ValueError("e2e needs image_size=(H, W) and a pretraining wrapper (plain or multitask; not the core module mode)")
         # lr_schedule: None (host sets lr) | "constant" | "warmup_constant" | "triangle" (WarmupLinearSchedule,
         # pretrain/function/train.py:316-320) -- evaluated on the device from the step counter each optimizer step.
         kinds = {None: None, "constant": ops.LR_CONSTANT, "warmup_constant": ops.LR_WARMUP_CONSTANT,

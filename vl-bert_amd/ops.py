@@ -389,6 +389,13 @@ def cast_bf16_f32(src, dst):
     return dst
 
 
+def rank_seed(base):
+    """Odd per-rank dropout seed for the nn.Module mirrors: data-parallel replicas must not share dropout masks."""
+    import torch.distributed as dist
+    r = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+    return (int(base) | 1) + 2 * r
+
+
 def rng_advance(seed):
     _lib.call("vlb_rng_advance", _p(seed), _stream())
 

@@ -62,8 +62,6 @@ class ResNetVLBERTForPretraining(nn.Module):
         vl = _get(net, "VLBERT")
         self.e2e = not _get(net, "IMAGE_FEAT_PRECOMPUTED", False)
         if self.e2e:
-            if self.MULTITASK:
-                raise NotImplementedError("e2e image path in the multitask wrapper is not supported")
             if not (_get(net, "IMAGE_FROZEN_BN", True) and _get(net, "IMAGE_STRIDE_IN_1x1", True) and _get(net, "IMAGE_C5_DILATED", True)):
                 raise NotImplementedError("e2e path needs IMAGE_FROZEN_BN, IMAGE_STRIDE_IN_1x1 and IMAGE_C5_DILATED (the shipped e2e cfgs)")
             if _get(net, "OUTPUT_CONV5", False):
@@ -190,7 +188,7 @@ class ResNetVLBERTForPretraining(nn.Module):
         key = (B, T, R, B_aux, image_size)
         if key not in self._engines:
             eng = _engine.PretrainEngine(self.cfg, B, T, R, device=str(self.device_), keep_logits=True, flat=self.flat,
-                                         B_aux=B_aux, image_size=image_size)
+                                         B_aux=B_aux, image_size=image_size, seed=ops.rank_seed(1234) // 2)   # per-rank dropout stream
             self._engines[key] = eng
         eng = self._engines[key]
         if self.e2e and getattr(eng, "_buffers_version", None) != self._buffers_version:
@@ -211,7 +209,12 @@ class ResNetVLBERTForPretraining(nn.Module):
         ops.cast_bf16_f32(eng.mlm_logits_copy[:, :V].contiguous(), mlm_logits)
         mvrc = torch.empty((eng.B, eng.R, C), dtype=torch.float32, device=self.device_)
         ops.cast_bf16_f32(eng.mvrc_logits_copy[:, :C].contiguous(), mvrc)
-        mvrc[:, int(eng.lay["nobj"].max()):] = -10000.0
+        mvrc[:, int(eng.lay["nobj"][:eng.B].max()):] = -10000.0
+        # the reference's encoder runs on the batch trimmed to max(text_len + n_obj) + 1 packed positions
+        # (common/visual_linguistic_bert.py:202,152-153), so its text logits stop there and the wrapper pads the rest with -10000
+        seq_max = int((eng.lay["text_len"][:Bt] + eng.lay["nobj"][:Bt]).max()) + 1
+        if seq_max < eng.T:
+            mlm_logits[:, seq_max:] = -10000.0
         return mlm_logits, mvrc
 
     # -- forward ------------------------------------------------------------------------------------
@@ -248,8 +251,8 @@ class ResNetVLBERTForPretrainingMultitask(ResNetVLBERTForPretraining):
     MULTITASK = True
 
     def forward(self, image, boxes, im_info, text, relationship_label, mlm_labels, mvrc_ops, mvrc_labels, *aux):
-        if image is not None:
-            raise NotImplementedError("precomputed-feature configuration: pass image=None")
+        if (image is not None) != self.e2e:
+            raise NotImplementedError("IMAGE_FEAT_PRECOMPUTED configuration takes image=None, the e2e configuration an image batch")
         if len(aux) == 0 or len(aux) % 2:
             raise ValueError("aux must be (text, mlm_labels) pairs")
         texts, labels = aux[0::2], aux[1::2]
@@ -263,8 +266,13 @@ class ResNetVLBERTForPretrainingMultitask(ResNetVLBERTForPretraining):
             cur += t.shape[0]
         B, R = boxes.shape[0], boxes.shape[1]
         T = max(text.shape[1], Ta)
-        eng = self._engine_for(B, T, R, Ba)
-        eng.set_batch(boxes, im_info, text, relationship_label, mlm_labels, mvrc_ops, mvrc_labels, aux_text, aux_labels)
+        if self.e2e:      # only the caption samples carry an image (cfgs/pretrain/base_e2e_16x16G_fp16.yaml)
+            eng = self._engine_for(B, T, R, Ba, image_size=(int(image.shape[2]), int(image.shape[3])))
+            eng.set_batch(boxes, im_info, text, relationship_label, mlm_labels, mvrc_ops, mvrc_labels, aux_text, aux_labels,
+                          image=image.float())
+        else:
+            eng = self._engine_for(B, T, R, Ba)
+            eng.set_batch(boxes, im_info, text, relationship_label, mlm_labels, mvrc_ops, mvrc_labels, aux_text, aux_labels)
         eng.mirror_pre_forward(self.training)
         eng.forward(train=self.training)
         loss = _HipLoss.apply(self._pnames["vlbert.word_embeddings.weight"], self, eng)

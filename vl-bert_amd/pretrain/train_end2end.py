@@ -139,6 +139,7 @@ def main(argv=None):
     pkg = __package__.rsplit(".", 1)[0]
     engine = importlib.import_module(pkg + ".engine")
     syn = importlib.import_module(pkg + ".synthetic")
+    ops = importlib.import_module(pkg + ".ops")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -198,6 +199,8 @@ def main(argv=None):
                 eng.forward(True, gscale=1.0 / accum)
                 last = micro == accum - 1
                 eng.backward(True, on_layer_done=eng.buckets.on_done if (last and eng.buckets is not None) else None)
+                if not last:
+                    ops.rng_advance(eng.seed)      # fresh dropout masks per micro-batch (optimizer_step advances after the last one)
             if eng.buckets is not None:
                 eng.buckets.wait()
             eng.optimizer_step()

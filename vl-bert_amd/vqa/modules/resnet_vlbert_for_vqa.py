@@ -151,7 +151,7 @@ class ResNetVLBERT(nn.Module):
         zb = lambda *s: torch.zeros(s, dtype=BF16, device=dev)
         self._w1, self._w1T = zb(self.hc, H), zb(H, self.hcp)          # first Linear and its transpose (K padded to 64)
         self._w2, self._w2T = zb(self.answers, self.hcp), zb(self.hc, self.Ap)
-        self._seed = torch.tensor([30011], dtype=torch.int32, device=dev)
+        self._seed = torch.tensor([ops.rank_seed(30011)], dtype=torch.int32, device=dev)
         self._head_version, self._states = None, {}
         self.init_weight()
 
