@@ -648,3 +648,34 @@ def test_vision_stack_odd_image_sizes_vs_oracle(Hi, Wi):
         e = rel_fro(got["image_feature_extractor." + short], Po[ref_name].grad)
         print("   odd %dx%d d %s rel-fro %.3e" % (Hi, Wi, short, e))
         assert e < 0.15, short
+
+
+def test_resnet101_forward_at_headline_image_size_vs_oracle():
+    """The e2e configuration's real shape (BASELINE config 3): ONE 600x1000 image through the full ResNet-101 trunk (conv1 ... layer3,
+    stride 16 -> body4 38x63x1024), ROIAlign 14x14 and the dilated layer4 head, forward only, against oracle/vision_oracle.py
+    (torch fp32 on the host).  bf16 activations through 101 convolutions: rel-Frobenius bounds, measured values printed."""
+    V = pkg("vision")
+    nl, Hi, Wi = 101, 600, 1000
+    P = VO.init_vision_params(5, nl)
+    g = torch.Generator().manual_seed(6)
+    N, R = 1, 4
+    img = torch.randn(N, 3, Hi, Wi, generator=g) * 50
+    boxes4 = torch.tensor([[[0.0, 0.0, Wi - 1.0, Hi - 1.0], [120.5, 80.25, 431.0, 377.5], [700.0, 300.0, 990.0, 590.0],
+                            [-2.0, -2.0, -2.0, -2.0]]])
+    vs = V.VisionStack(N, Hi, Wi, R, device=dev(), num_layers=nl)
+    vs.load_state_dict({k: v.to(dev()) for k, v in _prefixed(P).items()})
+    boxes = torch.zeros((N, R, 4 + 2048), device=dev())
+    boxes[:, :, :4] = boxes4.to(dev())
+    vs.forward(img.to(dev()), boxes)
+    torch.cuda.synchronize()
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    with torch.no_grad():
+        feats, body4 = VO.e2e_features(img, boxes4, P, nl)
+    mask = boxes4[:, :, 0] > -1.5
+    assert (vs.H3, vs.W3) == tuple(body4.shape[2:]) == (38, 63)
+    e_body = rel_fro(vs.body4.float().cpu().view(N, vs.H3, vs.W3, -1).permute(0, 3, 1, 2), body4)
+    e_feat = rel_fro(boxes[:, :, 4:].cpu()[mask], feats)
+    print("ResNet-101 600x1000: body4 rel-fro %.3e, post-ROIAlign layer4 features rel-fro %.3e (|feats| max %.3f)" %
+          (e_body, e_feat, float(feats.abs().max())))
+    assert e_body < 3e-2 and e_feat < 3e-2
+    assert float(boxes[0, 3, 4:].abs().max()) == 0.0          # the padded box slot stays zero
