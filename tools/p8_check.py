@@ -171,9 +171,8 @@ def bench(batch):
               ("ffn2 fwd", M, 768, 3072, "dropres"), ("out dgrad", M, 768, 768, "plain"), ("qkv dgrad", M, 768, 2304, "res"),
               ("ffn1 dgrad", M, 768, 3072, "res"), ("ffn2 dgrad", M, 3072, 768, "mulaux"), ("decoder fwd", BT, 30522, 768, "bias"),
               ("square 4096", 4096, 4096, 4096, "plain"), ("square 8192", 8192, 8192, 8192, "plain")]
-    variants = [("128x128", dict(p8_mode=0)), ("p8 256", dict(p8_mode=4, p8_keepb=1, p8_group=2)),
-                ("p8 320", dict(p8_mode=5, p8_group=2)), ("p8 model", dict(p8_mode=1, p8_keepb=1, p8_group=2)),
-                ("p8 320 g4", dict(p8_mode=5, p8_group=4))]
+    variants = [("128x128", dict(p8_mode=0)), ("p8 256", dict(p8_mode=4, p8_keepb=1, p8_group=2, p8_min_tiles=1)),
+                ("p8 320", dict(p8_mode=5, p8_group=2, p8_min_tiles=1)), ("p8 model", dict(p8_mode=1, p8_keepb=1, p8_group=2, p8_min_tiles=160))]
     print("%-14s %7s %6s %6s | " % ("gemm", "M", "N", "K") + " | ".join("%-13s" % v[0] for v in variants))
     tot = [0.0] * len(variants)
     for name, m, n, k, kwm in shapes:
@@ -221,6 +220,75 @@ def bench_wgrad(batch):
     print("TN ms per step (12 layers + compact decoder): %.2f | %.2f" % tuple(tot), flush=True)
 
 
+def check_ring():
+    """ring kernels (nt_ring 2: 128x128 / 4 stages, 3: 128x64 / 3 stages) against the two-stage kernel and torch fp32"""
+    seed_t = torch.tensor([12345], dtype=torch.int32, device=D)
+    shapes = [(3232, 768, 768), (3232, 3072, 768), (3232, 768, 3072), (6464, 2304, 768), (1000, 1000, 256), (777, 130, 64),
+              (4100, 3000 + 2, 128), (128, 64, 64), (25856, 768, 768)]
+    bad = 0
+    lib.gemm_set_option("p8_mode", 0)
+    for M, N, K in shapes:
+        for ring in (2, 3):
+            for epi in range(8):
+                lib.gemm_set_option("nt_ring", ring)
+                got, ins = run_case(M, N, K, epi, 0, seed_t)
+                lib.gemm_set_option("nt_ring", 0)
+                old, _ = run_case(M, N, K, epi, 0, seed_t)
+                ref = reference(M, N, K, epi, ins)
+                for k, (g, o) in enumerate(zip(got, old)):
+                    scale = float(o.abs().max())
+                    d_old = float((g - o).abs().max())
+                    d_ref = float((g - ref[k]).abs().max()) if ref is not None else float("nan")
+                    ok = d_old <= 1e-6 * max(scale, 1e-6) and bool(torch.isfinite(g).all())      # same arithmetic, same order: bit-equal
+                    print("M %6d N %6d K %5d ring %d epi %d out %d: |d two-stage| %.3e |d ref| %.3e scale %.3e %s"
+                          % (M, N, K, ring, epi, k, d_old, d_ref, scale, "ok" if ok else "FAIL"), flush=True)
+                    bad += 0 if ok else 1
+    lib.gemm_set_option("nt_ring", 1)
+    print("RING CHECK %s (%d failures)" % ("PASSED" if bad == 0 else "FAILED", bad), flush=True)
+    return bad
+
+
+def bench_ring(batch):
+    M = batch * 101
+    BT = batch * 64
+    shapes = [("qkv fwd", M, 2304, 768, "bias"), ("attn-out fwd", M, 768, 768, "dropres"), ("ffn1 fwd", M, 3072, 768, "gelu"),
+              ("ffn2 fwd", M, 768, 3072, "dropres"), ("out dgrad", M, 768, 768, "plain"), ("qkv dgrad", M, 768, 2304, "res"),
+              ("ffn1 dgrad", M, 768, 3072, "res"), ("ffn2 dgrad", M, 3072, 768, "mulaux"), ("decoder fwd", BT, 30522, 768, "bias")]
+    variants = [("two-stage", dict(p8_mode=0, nt_ring=0)), ("ring 128x128", dict(p8_mode=0, nt_ring=2)), ("ring 128x64", dict(p8_mode=0, nt_ring=3)),
+                ("p8 model", dict(p8_mode=1, p8_keepb=1, p8_group=2, p8_min_tiles=160, nt_ring=0))]
+    print("%-14s %7s %6s %6s | " % ("gemm", "M", "N", "K") + " | ".join("%-13s" % v[0] for v in variants))
+    tot = [0.0] * len(variants)
+    best = 0.0
+    for name, m, n, k, kwm in shapes:
+        row, ts = [], []
+        for vi, (vn, opt) in enumerate(variants):
+            ms, tf = bench_one(m, n, k, kwm, opt)
+            row.append("%6.1fus %5.0f" % (ms * 1e3, tf))
+            tot[vi] += ms * (1 if name.startswith("decoder") else 12)
+            ts.append(ms * (1 if name.startswith("decoder") else 12))
+        best += min(ts)
+        print("%-14s %7d %6d %6d | " % (name, m, n, k) + " | ".join(row), flush=True)
+    print("%-36s | " % "NT ms per step (12 layers + decoder fwd)" + " | ".join("%13.2f" % t for t in tot) + " | best-of %.2f" % best, flush=True)
+    lib.gemm_set_option("nt_ring", 1)
+
+
+def stagger(batch):
+    """128x128 kernel (2 workgroups per CU): phase offset between the two residents of a CU"""
+    M = batch * 101
+    shapes = [("qkv fwd", M, 2304, 768, "bias"), ("attn-out fwd", M, 768, 768, "dropres"), ("ffn1 fwd", M, 3072, 768, "gelu"),
+              ("out dgrad", M, 768, 768, "plain"), ("ffn2 dgrad", M, 3072, 768, "mulaux"), ("ffn2 fwd", M, 768, 3072, "dropres"),
+              ("square 4096", 4096, 4096, 4096, "plain")]
+    sts = (0, 1, 2, 3, 4, 6, 8)
+    print("%-14s | " % "gemm" + " | ".join("stagger %-6d" % s for s in sts))
+    for name, m, n, k, kwm in shapes:
+        row = []
+        for st in sts:
+            ms, tf = bench_one(m, n, k, kwm, dict(p8_mode=0, nt_stagger=st))
+            row.append("%6.1fus %5.0f" % (ms * 1e3, tf))
+        print("%-14s | " % name + " | ".join(row), flush=True)
+    lib.gemm_set_option("nt_stagger", 0)
+
+
 def ablate(batch):
     """where the time of a short-K GEMM goes: full kernel | no epilogue | epilogue without global stores"""
     M = batch * 101
@@ -240,6 +308,14 @@ def ablate(batch):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "ringcheck":
+        sys.exit(1 if check_ring() else 0)
+    if len(sys.argv) > 1 and sys.argv[1] == "ring":
+        bench_ring(int(sys.argv[2]) if len(sys.argv) > 2 else 256)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "stagger":
+        stagger(int(sys.argv[2]) if len(sys.argv) > 2 else 256)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ablate":
         ablate(int(sys.argv[2]) if len(sys.argv) > 2 else 256)
         sys.exit(0)

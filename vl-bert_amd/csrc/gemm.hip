@@ -380,6 +380,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN >= 8) ? 4 : 2) void gemm
   const bf16_t* b_src[NB];
   uint32_t a_msk[NA];
   int w = blockIdx.x, m0, n0, buf = 0;
+  if (!CONV && p.stagger > 0 && ((blockIdx.x >> 3) & 63) >= 32) {      // second-resident workgroup of its CU: phase offset
+    for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+  }
   tile_of(w, m0, n0);
   setup(a_src, a_msk, b_src, m0, n0);
   stage(a_src, a_msk, b_src, 0, 0);
@@ -441,6 +444,179 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN >= 8) ? 4 : 2) void gemm
     w = w_next; m0 = m0n; n0 = n0n;
     __syncthreads();   // the prefetched first stage of the next tile has landed; everyone left the old buffers
     buf ^= 1;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// The same tiles (128x128 / 128x64, BK = 64, every fused epilogue) behind a RING of NS operand stages with counted waits.
+//
+// The kernel above has two stages and retires the whole LDS-DMA queue at every K tile (hipcc drains it in front of the
+// compiler-visible fragment reads), i.e. a prefetch distance of one K tile: fine when many workgroups share a CU and cover each
+// other's latency, but the per-GPU batches of a strong-scaling run (M = 3232 rows at 32 samples per GPU) give a launch only
+// 150-600 tiles -- one or two per CU -- and those GEMMs ran at the L2 -> LDS latency, 0.7 us per K tile against 0.1 us of MFMA
+// work.  Here stage g + NS - 1 is issued while stage g is consumed, the wait is `s_waitcnt vmcnt(stages still allowed in
+// flight)`, the fragment reads are inline asm (invisible to the compiler's own waitcnt insertion) released by an explicit
+// lgkmcnt wait, and the ring runs across output tiles (persistent workgroups; the next tile's first stages land under the
+// epilogue, which stages its bf16 rows through the slot consumed last).  One barrier per K tile, as before.
+// ------------------------------------------------------------------------------------
+template <int I, int N, typename F>
+__device__ __forceinline__ void vlb_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    vlb_static_for<I + 1, N>(f);
+  }
+}
+
+template <int OFF>
+__device__ __forceinline__ void ring_lds_read(bf16x8& dst, uint32_t vaddr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(vaddr), "n"(OFF));
+}
+
+template <int N>
+__device__ __forceinline__ void ring_wait_vm() {      // gfx9 s_waitcnt: vmcnt = imm[15:14]:imm[3:0]; expcnt 7 / lgkmcnt 15 = no wait
+  __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
+}
+
+template <int BM, int BN, int WGM, int WGN, int EPI, int NS>
+__global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_nt_ring_kernel(const GemmParams p) {
+  constexpr int BK = 64;
+  constexpr int NT = 64 * WGM * WGN;
+  constexpr int WM = BM / WGM, WN = BN / WGN;
+  constexpr int FM = WM / 16, FN = WN / 16;
+  constexpr int NA = BM * 8 / NT, NB = BN * 8 / NT;   // 16-B chunks per thread per stage
+  constexpr int NL = NA + NB;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+  static_assert(BM == 128, "the epilogue staging image is 128 rows");
+  static_assert((NS - 1) * NL < 64, "vmcnt is a 6-bit counter");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int nt = p.ntm * p.ntn;
+  const int ntk = p.K / BK;
+  if ((int)blockIdx.x >= nt || ntk <= 0) return;
+  auto tile_of = [&](int w, int& m0, int& n0) {      // XCD-aware grouped order, as in gemm_nt_bf16_kernel
+    const int xcd = w & 7, q = nt >> 3, r = nt & 7;
+    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (w >> 3);
+    const int gm = p.tile_group, per_group = gm * p.ntn, gid = t / per_group, first = gid * gm;
+    const int gsz = min(p.ntm - first, gm), rem = t - gid * per_group;
+    m0 = (first + rem % gsz) * BM;
+    n0 = (rem / gsz) * BN;
+  };
+  // ---- producer: (tile, K tile) of the next stage to issue; per-thread source pointers advance in place -------------
+  const bf16_t* a_src[NA];
+  const bf16_t* b_src[NB];
+  int w_p = blockIdx.x, kt_p = 0, issued = 0, slot_p = 0;
+  auto setup = [&](int w) {
+    int m0, n0;
+    tile_of(w, m0, n0);
+#pragma unroll
+    for (int it = 0; it < NA; ++it) {
+      const int P = it * NT + tid, r = P >> 3, kc = (P & 7) ^ ((r >> 1) & 7);
+      a_src[it] = p.A + (long)min(m0 + r, p.M - 1) * p.lda + kc * 8;
+    }
+#pragma unroll
+    for (int it = 0; it < NB; ++it) {
+      const int P = it * NT + tid, r = P >> 3, kc = (P & 7) ^ ((r >> 1) & 7);
+      b_src[it] = p.B + (long)min(n0 + r, p.N - 1) * p.ldb + kc * 8;
+    }
+  };
+  auto produce = [&]() {
+    if (w_p >= nt) return;
+    char* sa = smem + slot_p * STAGE;
+    char* sb = sa + A_BYTES;
+#pragma unroll
+    for (int it = 0; it < NA; ++it) {
+      __builtin_amdgcn_global_load_lds(GLDS_PTR(a_src[it]), LDS_PTR(sa + (it * NT + wave * 64) * 16), 16, 0, 0);
+      a_src[it] += BK;
+    }
+#pragma unroll
+    for (int it = 0; it < NB; ++it) {
+      __builtin_amdgcn_global_load_lds(GLDS_PTR(b_src[it]), LDS_PTR(sb + (it * NT + wave * 64) * 16), 16, 0, 0);
+      b_src[it] += BK;
+    }
+    ++issued;
+    slot_p = (slot_p + 1 == NS) ? 0 : slot_p + 1;
+    if (++kt_p == ntk) {
+      kt_p = 0;
+      w_p += gridDim.x;
+      if (w_p < nt) setup(w_p);
+    }
+  };
+
+  f32x4 acc[FM][FN];
+  const int frow = lane & 15;
+  const int c0 = (((lane >> 4) ^ (frow >> 1)) << 4);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(smem);
+  const uint32_t a_rel = (uint32_t)((wm * WM + frow) * 128 + c0);             // k-step 1 fragment: chunk index ^ 4 (byte 64)
+  const uint32_t b_rel = (uint32_t)(A_BYTES + (wn * WN + frow) * 128 + c0);
+
+  setup(w_p);
+#pragma unroll
+  for (int s_ = 0; s_ < NS - 1; ++s_) produce();
+  int g = 0, slot_c = 0;      // stages consumed so far, ring slot of stage g
+  for (int w = blockIdx.x; w < nt; w += gridDim.x) {
+    int m0, n0;
+    tile_of(w, m0, n0);
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < ntk; ++kt) {
+      // stage g has landed once only the loads of the stages issued after it can still be outstanding (in-order retirement;
+      // right after an epilogue the youngest operations are its stores, which only makes the wait conservative)
+      const int ahead = issued - g - 1;
+      if (NS >= 4 && ahead >= 3) ring_wait_vm<3 * NL>();
+      else if (NS >= 3 && ahead == 2) ring_wait_vm<2 * NL>();
+      else if (ahead == 1) ring_wait_vm<NL>();
+      else ring_wait_vm<0>();
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();     // every wave's part of stage g is in LDS; everyone is done reading stage g-1
+      asm volatile("" ::: "memory");
+      produce();                        // stage g + NS - 1 -> the slot stage g - 1 was read from
+      const uint32_t so = lds0 + (uint32_t)(slot_c * STAGE);
+      const uint32_t va0 = so + a_rel, vb0 = so + b_rel, va1 = so + (a_rel ^ 64u), vb1 = so + (b_rel ^ 64u);
+      bf16x8 af[2][FM], bfr[2][FN];
+      vlb_static_for<0, FN>([&](auto j_c) { constexpr int j = decltype(j_c)::value; ring_lds_read<j * 2048>(bfr[0][j], vb0); });
+      vlb_static_for<0, FM>([&](auto i_c) { constexpr int i = decltype(i_c)::value; ring_lds_read<i * 2048>(af[0][i], va0); });
+      vlb_static_for<0, FN>([&](auto j_c) { constexpr int j = decltype(j_c)::value; ring_lds_read<j * 2048>(bfr[1][j], vb1); });
+      vlb_static_for<0, FM>([&](auto i_c) { constexpr int i = decltype(i_c)::value; ring_lds_read<i * 2048>(af[1][i], va1); });
+      // k-step 0 starts under the LDS latency of the k-step 1 fragments (reads return in order)
+      __builtin_amdgcn_s_waitcnt(0xC07F | ((FM + FN) << 8));      // lgkmcnt(FM + FN); vmcnt / expcnt: no wait
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[0][j], af[0][i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_waitcnt(0xC07F);                         // lgkmcnt(0)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[1][j], af[1][i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      ++g;
+      slot_c = (slot_c + 1 == NS) ? 0 : slot_c + 1;
+    }
+    // ---- epilogue: lane holds C[m][n..n+3]; staging image = the slot consumed last (no stage in flight targets it) ----
+    const int last = (slot_c == 0) ? NS - 1 : slot_c - 1;
+    const int mb = m0 + wm * WM + (lane & 15), nb = n0 + wn * WN + 4 * (lane >> 4);
+    const EpiStage st = {smem + last * STAGE, m0, n0, wm * WM + (lane & 15), wn * WN + 4 * (lane >> 4), tid, NT, BN};
+    if (m0 + BM <= p.M && n0 + BN <= p.N) {
+      __syncthreads();   // every wave finished reading the K-loop operands of that slot
+      gemm_epilogue_select<EPI, true, FM, FN>(p, acc, mb, nb, st);
+    } else {
+      gemm_epilogue_select<EPI, false, FM, FN>(p, acc, mb, nb, st);
+    }
+    // one full drain per output tile, where the compiler can see it: with the epilogue's loads / stores still pending at the
+    // loop back-edge hipcc protects their registers with an `s_waitcnt vmcnt(0)` INSIDE the K loop, which would empty the ring at
+    // every K tile.  (The next tile's first NS - 1 stages were issued before the epilogue and have landed by now.)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
   }
 }
 
@@ -1021,6 +1197,9 @@ __global__ __launch_bounds__(256) void transpose_batched_kernel(const long* __re
 // ------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------
+static int g_nt_stagger = -1;
+void vlb_nt_set_stagger(int v) { g_nt_stagger = v; }
+
 static int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return v ? atoi(v) : dflt;
@@ -1081,6 +1260,59 @@ static int launch_gemm_epi(GemmParams& p, int splits, hipStream_t stream) {
   }
 }
 
+// ring kernels: 128x128 (8 waves, 4 stages = 128 KiB: one workgroup per CU) and 128x64 (4 waves, 3 stages = 72 KiB: two per CU)
+static int g_nt_ring = -1;        // VLB_GEMM_NT_RING: 0 off | 1 auto (default) | 2 force 128x128 | 3 force 128x64
+void vlb_nt_set_ring(int v) { g_nt_ring = v; }
+
+template <int BM, int BN, int WGM, int WGN, int EPI, int NS>
+static int launch_ring_cfg(GemmParams& p, hipStream_t stream) {
+  constexpr int smem = NS * (BM + BN) * 128;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<BM, BN, WGM, WGN, EPI, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_set = true;
+  }
+  static const int group = env_int("VLB_GEMM_TILE_GROUP", 4);
+  p.ntm = vlb_cdiv(p.M, BM);
+  p.ntn = vlb_cdiv(p.N, BN);
+  p.tile_group = group < 1 ? 1 : group;
+  const int cap = 256 * (163840 / smem);       // resident workgroups (a multiple of 8: work item w and block b share an XCD)
+  int gx = p.ntm * p.ntn;
+  if (gx > cap) gx = cap;
+  hipLaunchKernelGGL((gemm_nt_ring_kernel<BM, BN, WGM, WGN, EPI, NS>), dim3(gx), dim3(64 * WGM * WGN), smem, stream, p);
+  VLB_CHECK_LAUNCH("vlb_gemm_nt_bf16(ring)");
+  return VLB_OK;
+}
+
+template <int BM, int BN, int WGM, int WGN, int NS>
+static int launch_ring_epi(GemmParams& p, hipStream_t stream) {
+  switch (epi_class(p)) {
+    case 0: return launch_ring_cfg<BM, BN, WGM, WGN, 0, NS>(p, stream);
+    case 1: return launch_ring_cfg<BM, BN, WGM, WGN, 1, NS>(p, stream);
+    case 2: return launch_ring_cfg<BM, BN, WGM, WGN, 2, NS>(p, stream);
+    case 3: return launch_ring_cfg<BM, BN, WGM, WGN, 3, NS>(p, stream);
+    case 4: return launch_ring_cfg<BM, BN, WGM, WGN, 4, NS>(p, stream);
+    case 5: return launch_ring_cfg<BM, BN, WGM, WGN, 5, NS>(p, stream);
+    case -1: return launch_ring_cfg<BM, BN, WGM, WGN, -1, NS>(p, stream);
+    default: return 1;      // the Bottleneck-tail epilogues stay on the two-stage kernel
+  }
+}
+
+// > 0: not taken
+static int gemm_ring_try(GemmParams& p, int splits, bool want_narrow, hipStream_t stream) {
+  if (g_nt_ring < 0) g_nt_ring = env_int("VLB_GEMM_NT_RING", 1);
+  if (!g_nt_ring || splits != 1 || p.c_split_stride != 0 || p.k_per_split < p.K) return 1;
+  // auto: measured on MI355X (tools/p8_check.py ring) the deeper prefetch only pays where a launch has about one tile per CU and a
+  // long K loop -- the N = 768 GEMMs of a 32..64-sample per-GPU batch (M = 3232 / 6464: 70 -> 56 us for ffn2 fwd, 52 -> 42 us for
+  // the QKV dgrad at M = 6464); with several workgroups per CU the two-stage kernel's co-resident workgroups already cover the
+  // latency and its smaller LDS footprint wins (M >= 12928: 5-25 % slower with the ring)
+  if (g_nt_ring == 1 && !(p.N <= 1024 && p.M <= 8192 && p.M >= 1024 && p.K >= 512)) return 1;
+  const bool narrow = g_nt_ring == 3 || g_nt_ring == 1;
+  (void)want_narrow;
+  if (narrow) return launch_ring_epi<128, 64, 2, 2, 3>(p, stream);
+  return launch_ring_epi<128, 128, 2, 4, 4>(p, stream);
+}
+
 template <int BM, int BN>
 static int launch_gemm(GemmParams& p, int splits, hipStream_t stream) {
   if (BN == 128) return launch_gemm_epi<BM, 128, 2, 4>(p, splits, stream);   // 8 waves of 64x32: 16 waves/CU hide LDS/barrier latency
@@ -1116,6 +1348,8 @@ static int gemm_nt_impl(const void* A, long lda, const void* B, long ldb, void* 
   p.res_stats = res_stats; p.res_gamma = res_gamma; p.res_beta = res_beta; p.c_f16 = out_f16 ? 1 : 0;
   p.drop_thr = vlb_drop_thr(drop_p); p.drop_scale = vlb_drop_scale(p.drop_thr); p.seed = seed; p.tag = tag;
   p.C = C; p.ldc = ldc; p.out_f32 = out_mode; p.c_split_stride = 0;
+  if (g_nt_stagger < 0) g_nt_stagger = env_int("VLB_GEMM_NT_STAGGER", 0);
+  p.stagger = g_nt_stagger;
   int splits = 1;
   const int ktiles = K / 64;
   if (out_mode == 2) {
@@ -1173,7 +1407,12 @@ static int gemm_nt_impl(const void* A, long lda, const void* B, long ldb, void* 
   }
   // narrow-N tile when the 128x128 grid would leave most CUs idle
   const long tiles128 = (long)vlb_cdiv(M, 128) * vlb_cdiv(N, 128) * splits;
-  if (tiles128 < 384 || N <= 64) return launch_gemm<128, 64>(p, splits, stream);
+  const bool narrow = tiles128 < 384 || N <= 64;
+  {
+    const int took = gemm_ring_try(p, splits, narrow, stream);
+    if (took <= 0) return took;
+  }
+  if (narrow) return launch_gemm<128, 64>(p, splits, stream);
   return launch_gemm<128, 128>(p, splits, stream);
 }
 

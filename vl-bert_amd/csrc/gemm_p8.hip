@@ -611,6 +611,14 @@ extern "C" int vlb_gemm_set_option(const char* name, int value) {
     vlb_tn8_set_mode(value);
     return VLB_OK;
   }
+  if (!strcmp(name, "nt_ring")) {
+    vlb_nt_set_ring(value);
+    return VLB_OK;
+  }
+  if (!strcmp(name, "nt_stagger")) {
+    vlb_nt_set_stagger(value);
+    return VLB_OK;
+  }
   if (!strcmp(name, "tn8_wgs")) {
     vlb_tn8_set_wgs(value);
     return VLB_OK;

@@ -19,6 +19,8 @@ struct GemmParams {
   int c_f16;                 // bf16-output kernels write C as fp16 instead (the pre-LayerNorm sums)
   int ablate;                // gemm_p8 timing ablations (results are WRONG when != 0): 1 no epilogue | 2 epilogue without global stores |
                              // 3 epilogue without the LDS slab round trip
+  int stagger;               // 128x128 kernel: second-resident workgroups start `stagger` x ~3.4 us late (phase offset between the two
+                             // workgroups of a CU, so one runs its epilogue under the other's MFMA loop)
   uint32_t drop_thr; float drop_scale; const uint32_t* seed; uint32_t tag;
   void* C; long ldc;
   long c_split_stride;       // elements between the outputs of consecutive K splits (slab split-K), 0 otherwise
@@ -47,5 +49,7 @@ int vlb_tn8_pick_splits(int Mo, int No, int R);
 int vlb_gemm_tn8_group(int n, const void* const* A, const long* lda, const void* const* B, const long* ldb, float* const* C,
                        const long* ldc, int R, const int* Mo, const int* No, float* const* colsum, float* workspace,
                        long workspace_floats, int accumulate, int* slices, long* ws_off, hipStream_t stream);
+void vlb_nt_set_stagger(int v);
+void vlb_nt_set_ring(int v);
 void vlb_tn8_set_mode(int v);
 void vlb_tn8_set_wgs(int v);

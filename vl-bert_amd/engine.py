@@ -267,14 +267,25 @@ class PretrainEngine:
 
         # activations
         M, BT, BR, S, nh = self.M, self.BT, self.BR, self.S, cfg.num_attention_heads
+        # Operands of the per-layer weight gradients are allocated with their row count rounded up to 128 (the pad rows stay zero:
+        # every kernel writes M rows) and used through [:M] views; the grouped large-tile wgrad (gemm_tn8.hip, K tiles of 128 rows)
+        # gets the padded tensors, so it also serves the per-GPU batches of a strong-scaling run (M = 3232 at 32 samples).
+        self.Mp128 = _ru(M, 128)
+        self._row_padded = {}
+
+        def zbm(cols):
+            full = zb(self.Mp128, cols)
+            view = full[:M]
+            self._row_padded[view.data_ptr()] = full
+            return view
         self.a_ds = zb(BR, 2 * VIS_DIM)
         self.obj_reps = zb(BR, H)
         self.objvis, self.st_objvis = zb(BR, H), zf(BR, 2)
         self.textvis, self.st_textvis = zb(Bt, H), zf(Bt, 2)
         self.emb_pre, self.st_emb = zb(M, H), zf(M, 2)
-        self.X = [zb(M, H) for _ in range(L + 1)]
+        self.X = [zbm(H) for _ in range(L + 1)]
         self.QKV = [zb(M, 3 * H) for _ in range(L)]
-        self.CTX = [zb(M, H) for _ in range(L)]
+        self.CTX = [zbm(H) for _ in range(L)]
         self.LSE = [zf(Bt, nh, S) for _ in range(L)]
         # Residual stream precision (DESIGN.md "precision"): the pre-LayerNorm sums Z1 / Z2 are kept in fp16 (3 more mantissa bits
         # than bf16, same bytes; |Z| = O(1..10)) and the residual a sublayer adds is the previous LayerNorm's output re-materialised
@@ -285,8 +296,8 @@ class PretrainEngine:
         self.hp_res = _os0.environ.get("VLB_RESIDUAL_STREAM", "f16ln") != "bf16"
         zdt = torch.float16 if self.hp_res else BF16
         zz = lambda *s: torch.zeros(s, dtype=zdt, device=d)
-        self.Z1, self.ST1, self.Y1 = [zz(M, H) for _ in range(L)], [zf(M, 2) for _ in range(L)], [zb(M, H) for _ in range(L)]
-        self.U, self.G = [zb(M, I) for _ in range(L)], [zb(M, I) for _ in range(L)]
+        self.Z1, self.ST1, self.Y1 = [zz(M, H) for _ in range(L)], [zf(M, 2) for _ in range(L)], [zbm(H) for _ in range(L)]
+        self.U, self.G = [zb(M, I) for _ in range(L)], [zbm(I) for _ in range(L)]
         self.Z2, self.ST2 = [zz(M, H) for _ in range(L)], [zf(M, 2) for _ in range(L)]
         self.text_out, self.obj_out = zb(BT, H), zb(BR, H)
         self.mlm_u, self.mlm_g, self.mlm_h, self.st_mlm = zb(BT, H), zb(BT, H), zb(BT, H), zf(BT, 2)
@@ -325,9 +336,9 @@ class PretrainEngine:
         # gradient operands (LN2 / LN1 outputs through dropout, dU, dQKV) stay alive until then and are double-buffered by layer
         # parity: the next layer writes the other set while the group still reads this one.
         self.dZ = zb(M, H)
-        self.dD2, self.dD1 = [zb(M, H), zb(M, H)], [zb(M, H), zb(M, H)]
-        self.dU2 = [zb(M, I), zb(M, I)]
-        self.dQKV2 = [zb(M, 3 * H), zb(M, 3 * H)]
+        self.dD2, self.dD1 = [zbm(H), zbm(H)], [zbm(H), zbm(H)]
+        self.dU2 = [zbm(I), zbm(I)]
+        self.dQKV2 = [zbm(3 * H), zbm(3 * H)]
         self.dCTX = zb(M, H)
         self.tG = zb(max(3 * H, I), self.Mp)       # transposed gradients (zero padded columns persist)
         self.tA = zb(max(H, I), self.Mp)           # transposed activations
@@ -668,6 +679,10 @@ class PretrainEngine:
                 self._wgrad(dy, x, gw, gb, self.tG, self.tA, self.Mp)
             return
         acc = not self._fresh_grads
+        pad = self._row_padded       # row-padded operands (zero pad rows): K a multiple of 128 for the large-tile kernel
+        items = [(pad.get(dy.data_ptr(), dy), pad.get(x.data_ptr(), x), gw, gb) for dy, x, gw, gb in items]
+        if len({t.shape[0] for it in items for t in it[:2]}) != 1:
+            items = [(dy[:self.M], x[:self.M], gw, gb) for dy, x, gw, gb in items]
         if self.side is None:
             ops.wgrad_tn_group(items, workspace=self.wg_ws, accumulate=acc)
             return
