@@ -238,6 +238,12 @@ int vlb_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, l
 int vlb_sumsq_bf16_det(const void* g_bf16, long n, float* partials, int partials_len, float* out, vlb_stream_t stream);
 int vlb_adamw_step_gbf16(float* p, const void* g_bf16, float* m, float* v, void* p_bf16, long n, float* state, float grad_scale,
                          vlb_stream_t stream);
+/* SGD with momentum (torch.optim.SGD(lr, momentum, weight_decay), dampening 0, no Nesterov: the optimiser of
+ * vcr/function/train.py:124-128) in one pass:  d = coef * g + weight_decay * p ;  buf = momentum * buf + d ;  p -= lr * buf ;
+ * p_bf16 (optional) = bf16(p).  coef = grad_scale * min(1, max_norm / (sqrt(*sumsq) * grad_scale + 1e-6)) when `sumsq` (device,
+ * e.g. from vlb_sumsq_f32) is given and max_norm > 0 -- clip_grad_norm_ of common/trainer.py:139-145 -- else grad_scale. */
+int vlb_sgd_momentum_step(float* p, const float* g, float* momentum_buf, void* p_bf16, long n, float lr, float momentum,
+                          float weight_decay, const float* sumsq, float max_norm, float grad_scale, vlb_stream_t stream);
 /* lr schedule evaluated on the device from state[5] (steps taken): state[0] = base_lr * lambda(step + 1), matching the
  * reference's scheduler.step() -> optimizer.step() order (common/trainer.py:131-135).  kind 0 = ConstantLRSchedule,
  * 1 = WarmupConstantSchedule, 2 = WarmupLinearSchedule (common/nlp/bert/optimization.py:27-62).  Call before

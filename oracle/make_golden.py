@@ -343,6 +343,114 @@ def run_vqa_case(name="vqa_small"):
     print("%s -> %s (%.1f KB), %d gradient tensors" % (name, path, os.path.getsize(path) / 1024, len(keys)))
 
 
+def run_vcr_case(name="vcr_small", num_layers=50):
+    """VCR fixture: the reference's own vcr.modules.resnet_vlbert_for_vcr.ResNetVLBERT in the configuration of the shipped
+    cfgs/vcr/*.yaml (images through the FastRCNN image branch with object masks, 4 answer choices folded by TimeDistributed, pooler,
+    "1fc" classifier, sigmoid BCE, ENABLE_CNN_REG_LOSS + CNN_LOSS_TOP), every dropout at p = 0, parameters from
+    oracle/vcr_oracle.init_vcr_params + oracle/vision_oracle.init_vision_params; stores inputs, logits, losses and gradient norms;
+    checks the restatement (oracle/vcr_oracle.py) against it."""
+    from oracle import vcr_oracle as VC
+    from oracle import vision_oracle as VO
+    ref_import.import_reference()
+    ref_import.install_roi_align_oracle()
+    import common.lib.roi_pooling as rp
+    rp.C_ROIPooling = sys.modules["common.lib.roi_pooling.C_ROIPooling"]
+    import common.lib.roi_pooling.roi_align as ra_mod
+    ra_mod.C_ROIPooling = rp.C_ROIPooling
+    from vcr.modules.resnet_vlbert_for_vcr import ResNetVLBERT as RefVCR
+    cfg = VLBertConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                       vocab_size=512, max_position_embeddings=64, visual_region_classes=50, hidden_dropout_prob=0.0,
+                       attention_probs_dropout_prob=0.0, obj_downsample_dropout=0.0, with_pooler=True)
+    vocab_dir = ref_import.make_vocab_dir(os.path.join(tempfile.gettempdir(), "vlb_vocab_%s" % name), cfg.vocab_size)
+    rc = ref_import.make_reference_config(cfg, vocab_dir)
+    pos_w = 2.0
+    for k, v in dict(IMAGE_FEAT_PRECOMPUTED=False, IMAGE_SEMANTIC=False, IMAGE_STRIDE_IN_1x1=True, IMAGE_C5_DILATED=True,
+                     IMAGE_NUM_LAYERS=num_layers, IMAGE_PRETRAINED="oracle_init", IMAGE_PRETRAINED_EPOCH=0, OUTPUT_CONV5=False,
+                     IMAGE_FROZEN_BN=True, IMAGE_FROZEN_BACKBONE_STAGES=[1, 2], BLIND=False, NO_GROUNDING=False, NO_OBJ_ATTENTION=False,
+                     ANSWER_FIRST=False, QA_ONE_SENT=False, FOR_MASK_VL_MODELING_PRETRAIN=False, ENABLE_CNN_REG_LOSS=True,
+                     CNN_LOSS_TOP=True, CNN_REG_DROPOUT=0.0, CNN_LOSS_WEIGHT=1.0, ANS_LOSS_WEIGHT=1.0, CLASSIFIER_TYPE="1fc",
+                     CLASSIFIER_HIDDEN_SIZE=64, CLASSIFIER_DROPOUT=0.0, CLASSIFIER_SIGMOID=True,
+                     CLASSIFIER_SIGMOID_LOSS_POSITIVE_WEIGHT=pos_w, REPLACE_OBJECT_CHANGE_LABEL=False).items():
+        setattr(rc.NETWORK, k, v)
+        rc.NETWORK[k] = v
+    vseed, pseed = 17, 19
+    P = VO.init_vision_params(vseed, num_layers)
+    real_load = torch.load
+    torch.load = lambda path, *a, **k: dict(P) if str(path).startswith("oracle_init") else real_load(path, *a, **k)
+    try:
+        torch.manual_seed(0)
+        model = RefVCR(rc)
+    finally:
+        torch.load = real_load
+    params = VC.init_vcr_params(cfg, pseed, classifier="1fc", embed_mode=2, cnn_reg_top=True)
+    ref_sd = {}
+    for k, v in params.items():
+        ref_sd[("vlbert._module." + k[len("vlbert."):]) if k.startswith("vlbert.") else k] = v
+    for k, v in VO.split_state_dict(P).items():
+        ref_sd["image_feature_extractor." + k] = v
+    sd = model.state_dict()
+    # (`image_feature_extractor.head.0.*` are aliases: `head` = Sequential(roi_head_feature_extractor, pool, flatten), fast_rcnn.py:80-84)
+    missing = [k for k in sd if k not in ref_sd and not k.endswith("num_batches_tracked") and ".head.0." not in k]
+    assert not missing, missing
+    model.load_state_dict({k: ref_sd[k] for k in sd if k in ref_sd}, strict=False)
+    model.train()                                   # (ResNetVLBERT.train() puts the BatchNorms in eval mode, :100-104)
+    model.image_feature_extractor.obj_downsample[0].p = 0.0
+    g = torch.Generator().manual_seed(23)
+    B, C, R, Hi, Wi, Lq, La = 2, 4, 3, 96, 128, 6, 5
+    img = torch.randn(B, 3, Hi, Wi, generator=g) * 50.0
+    boxes = torch.tensor([[[0.0, 0.0, 127.0, 95.0, 0.0], [30.5, 10.25, 120.0, 60.0, 17.0], [4.0, 6.0, 90.0, 80.0, 80.0]],
+                          [[0.0, 0.0, 127.0, 95.0, 0.0], [64.0, 8.0, 100.0, 40.0, 3.0], [-1.0, -1.0, -1.0, -1.0, -1.0]]])
+    masks = (torch.rand(B, R, 14, 14, generator=g) < 0.7).float()
+    im_info = torch.tensor([[Wi, Hi, 1.0, 1.0, 0.0], [Wi, Hi, 1.0, 1.0, 1.0]])
+    nvalid = torch.tensor([3, 2])
+    qlen = torch.tensor([Lq, 4])
+    question = torch.zeros((B, Lq, 2), dtype=torch.int64)
+    question[:, :, 0] = torch.randint(200, cfg.vocab_size, (B, Lq), generator=g)
+    question[:, :, 1] = torch.randint(-1, 2, (B, Lq), generator=g)                  # -1: no object (clamped to 0 = the image box)
+    question[torch.arange(Lq)[None, :] >= qlen[:, None]] = 0
+    answers = torch.zeros((B, C, La, 2), dtype=torch.int64)
+    answers[..., 0] = torch.randint(200, cfg.vocab_size, (B, C, La), generator=g)
+    answers[..., 1] = torch.randint(-1, 2, (B, C, La), generator=g)
+    alen = torch.randint(2, La + 1, (B, C), generator=g)
+    alen[0, 1] = La
+    answers[torch.arange(La)[None, None, :] >= alen[:, :, None]] = 0
+    answers[..., 1] = torch.minimum(answers[..., 1], (nvalid - 1)[:, None, None])
+    question[:, :, 1] = torch.minimum(question[:, :, 1], (nvalid - 1)[:, None])
+    label = torch.tensor([2, 0])
+    outputs, loss = model(img, boxes.clone(), masks, question, None, answers, None, label, im_info)
+    loss.backward()
+    ref_grads = {}
+    for k, v in model.named_parameters():
+        if v.grad is not None and float(v.grad.abs().sum()) > 0:
+            ref_grads[k.replace("vlbert._module.", "vlbert.")] = v.grad.detach()
+    frozen = VO.frozen_names(P)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    Po = {k: v.clone().requires_grad_(k not in frozen) for k, v in P.items()}
+    out2, loss2 = VC.vcr_forward(leaves, cfg, img, boxes, masks, question, answers, label, im_info, Po, num_layers, classifier="1fc",
+                                 classifier_dropout=0.0, sigmoid=True, positive_weight=pos_w, cnn_reg_top=True, train=False)
+    loss2.backward()
+    err = float((out2["label_logits"] - outputs["label_logits"]).abs().max())
+    print("%s: restatement vs reference |d logits|max %.3e, loss %.6f vs %.6f, cnn reg %.6f vs %.6f" %
+          (name, err, float(loss2), float(loss), float(out2["cnn_regularization_loss"]), float(outputs["cnn_regularization_loss"])))
+    assert err < 1e-4 and abs(float(loss2) - float(loss)) < 1e-5
+    worst = 0.0
+    for k, gref in ref_grads.items():
+        if k in leaves:
+            worst = max(worst, float((leaves[k].grad - gref).norm() / max(float(gref.norm()), 1e-12)))
+    print("%s: restatement gradients, worst rel-fro vs reference %.3e" % (name, worst))
+    assert worst < 1e-3
+    keys = sorted(ref_grads)
+    path = os.path.join(ROOT, "tests", "golden", "vcr", name + ".npz")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    np.savez_compressed(path, pseed=pseed, vseed=vseed, num_layers=num_layers, positive_weight=pos_w, img=img.numpy(), boxes=boxes.numpy(),
+                        masks=masks.numpy(), im_info=im_info.numpy(), question=question.numpy(), answers=answers.numpy(),
+                        label=label.numpy(), logits=outputs["label_logits"].detach().numpy(), loss=float(loss),
+                        ans_loss=float(outputs["ans_loss"]), cnn_reg_loss=float(outputs["cnn_regularization_loss"]),
+                        grad_names=np.array(keys), grad_norms=np.array([float(ref_grads[k].double().norm()) for k in keys]),
+                        grad_total_norm=float(torch.sqrt(sum((g_.double() ** 2).sum() for g_ in ref_grads.values()))))
+    print("%s -> %s (%.1f KB), %d gradient tensors" % (name, path, os.path.getsize(path) / 1024, len(keys)))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     if len(sys.argv) > 1 and sys.argv[1] == "core":
@@ -351,6 +459,8 @@ if __name__ == "__main__":
         run_vision_case()
     elif len(sys.argv) > 1 and sys.argv[1] == "vqa":
         run_vqa_case()
+    elif len(sys.argv) > 1 and sys.argv[1] == "vcr":
+        run_vcr_case()
     else:
         for name, spec in CASES.items():
             run_case(name, spec)

@@ -195,3 +195,56 @@ def test_vqa_oracle_matches_reference_module():
         L = int((batch[2][b] > 0).sum())
         assert ids[b, 0] == 101 and ids[b, L + 1] == 102 and ids[b, L + 2] == 103 and ids[b, L + 3] == 102 and int(ans_pos[b]) == L + 2
         assert int(mask[b].sum()) == L + 4 and types[b, L + 2] == 1 and types[b, L + 1] == 0
+
+
+def load_vcr_case():
+    from oracle import vcr_oracle as VC
+    from oracle import vision_oracle as VO
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "vcr", "vcr_small.npz"), allow_pickle=False)
+    cfg = O.VLBertConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, vocab_size=512,
+                         max_position_embeddings=64, visual_region_classes=50, hidden_dropout_prob=0.0,
+                         attention_probs_dropout_prob=0.0, obj_downsample_dropout=0.0, with_pooler=True)
+    params = VC.init_vcr_params(cfg, int(z["pseed"]), classifier="1fc", embed_mode=2, cnn_reg_top=True)
+    P = VO.init_vision_params(int(z["vseed"]), int(z["num_layers"]))
+    batch = dict(image=torch.from_numpy(z["img"]), boxes=torch.from_numpy(z["boxes"]), masks=torch.from_numpy(z["masks"]),
+                 question=torch.from_numpy(z["question"]), answer_choices=torch.from_numpy(z["answers"]),
+                 answer_label=torch.from_numpy(z["label"]), im_info=torch.from_numpy(z["im_info"]))
+    return z, cfg, params, P, batch
+
+
+def test_vcr_oracle_matches_reference_module():
+    """oracle/vcr_oracle.py against the fixture produced by the reference's own vcr ResNetVLBERT.train_forward (images + object masks
+    through the FastRCNN image branch, 4 answer choices folded by TimeDistributed, pooler, "1fc" classifier, sigmoid BCE with a
+    positive weight, top-of-BERT CNN regulariser): logits, both losses, the gradient norm of every parameter that receives one."""
+    from oracle import vcr_oracle as VC
+    from oracle import vision_oracle as VO
+    z, cfg, params, P, batch = load_vcr_case()
+    frozen = VO.frozen_names(P)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    Po = {k: v.clone().requires_grad_(k not in frozen) for k, v in P.items()}
+    out, loss = VC.vcr_forward(leaves, cfg, vision_params=Po, image_num_layers=int(z["num_layers"]), classifier="1fc",
+                               classifier_dropout=0.0, sigmoid=True, positive_weight=float(z["positive_weight"]), cnn_reg_top=True,
+                               train=False, **batch)
+    assert np.allclose(out["label_logits"].detach().numpy(), z["logits"], atol=1e-5)
+    assert abs(float(loss) - float(z["loss"])) < 1e-5 and abs(float(out["ans_loss"]) - float(z["ans_loss"])) < 1e-5
+    assert abs(float(out["cnn_regularization_loss"]) - float(z["cnn_reg_loss"])) < 1e-5
+    loss.backward()
+    vis = dict(zip(("image_feature_extractor." + k for k in VO.split_state_dict(P)), P.keys()))
+    checked = 0
+    for k, n in zip(z["grad_names"], z["grad_norms"]):
+        k = str(k)
+        g = leaves[k].grad if k in leaves else (Po[vis[k]].grad if k in vis else None)
+        if k.startswith("image_feature_extractor.head.0."):
+            continue                                   # alias of roi_head_feature_extractor.* (common/fast_rcnn.py:80-84)
+        assert g is not None and abs(float(g.double().norm()) - n) <= 1e-4 * n + 1e-9, k
+        checked += 1
+    assert checked > 60
+    # text layout of one choice: [CLS] q [SEP] a [SEP], token types 0 / 1, tags of the plain words clamped to the image box
+    q, a = batch["question"], batch["answer_choices"]
+    ids, types, tags, mask = VC.prepare_text_from_qa(q[:, :, 0], q[:, :, 1][:, None].expand(-1, a.shape[1], -1), q[:, :, 0] > 0.5,
+                                                     a[..., 0], a[..., 1], a[..., 0] > 0.5)
+    for b in range(ids.shape[0]):
+        for c in range(ids.shape[1]):
+            lq, la = int((q[b, :, 0] > 0).sum()), int((a[b, c, :, 0] > 0).sum())
+            assert ids[b, c, 0] == 101 and ids[b, c, lq + 1] == 102 and ids[b, c, lq + la + 2] == 102
+            assert int(mask[b, c].sum()) == lq + la + 3 and int(types[b, c].sum()) == la + 1

@@ -51,6 +51,7 @@ _SIGS = {
     "vlb_sumsq_f32_det": "plpips",
     "vlb_adamw_step": "ppppplpfs",
     "vlb_adamw_step_gbf16": "ppppplpfs",
+    "vlb_sgd_momentum_step": "pppplfffpffs",
     "vlb_sumsq_bf16_det": "plpips",
     "vlb_lr_schedule_step": "pifffs",
     "vlb_conv_weight_prepare": "pppppfppppiiiis",

@@ -15,8 +15,8 @@ IMAGE_FEAT_PRECOMPUTED false (the image branch, :144-156): `forward(images [B,3,
 continues through the RoI head, ROIAlign and the trainable trunk stages.  Parameters / buffers carry the reference's names
 (`backbone.*`, `roi_head_feature_extractor.*`); trainable convolution weights are stored as [O,KH,KW,I] (state_dict /
 load_state_dict convert from / to the reference's [O,I,KH,KW]).  `segms` [B,R,14,14] (VCR's object masks) are multiplied into the
-RoI-head output before the pool (:152-156).  Not supported on this branch: `classes` / IMAGE_SEMANTIC, `mask_visual_embed`,
-cnn_reg_loss, OUTPUT_CONV5.
+RoI-head output before the pool (:152-156).  Not supported on this branch: IMAGE_SEMANTIC (`classes` is accepted and unused, as
+in the reference with that option off), `mask_visual_embed`, the bottom-of-CNN cnn_reg_loss, OUTPUT_CONV5.
 """
 import torch
 import torch.nn as nn
@@ -176,10 +176,14 @@ class FastRCNN(nn.Module):
         for name in self._conv_params:            # engine layout [O,KH,KW,I] -> reference layout [O,I,KH,KW]
             k = prefix + name[len("image_feature_extractor."):]
             sd[k] = sd[k].permute(0, 3, 1, 2).contiguous()
+        if self.e2e:      # the reference registers the RoI head twice: `head` = Sequential(roi_head_feature_extractor, pool, flatten)
+            alias = prefix + "roi_head_feature_extractor."      # (common/fast_rcnn.py:80-84), so its checkpoints carry `head.0.*` too
+            for k in [k for k in sd if k.startswith(alias)]:
+                sd[prefix + "head.0." + k[len(alias):]] = sd[k]
         return sd
 
     def load_state_dict(self, state_dict, strict=True):
-        state_dict = {k: v for k, v in state_dict.items() if not k.endswith("num_batches_tracked")}
+        state_dict = {k: v for k, v in state_dict.items() if not k.endswith("num_batches_tracked") and not k.startswith("head.0.")}
         for name in self._conv_params:
             k = name[len("image_feature_extractor."):]
             if k in state_dict:
@@ -236,8 +240,10 @@ class FastRCNN(nn.Module):
         return self._states[key]
 
     def _forward_e2e(self, images, boxes, box_mask, im_info, classes, segms, mvrc_ops, mask_visual_embed):
-        if classes is not None or mask_visual_embed is not None:
-            raise NotImplementedError("image branch: classes / mask_visual_embed are not supported")
+        # `classes` only feeds the IMAGE_SEMANTIC object-class embedding and the bottom-of-CNN regulariser (common/fast_rcnn.py:139,
+        # 158-163), both rejected by the constructor: accepted and unused here, as in the reference with those options off
+        if mask_visual_embed is not None:
+            raise NotImplementedError("image branch: mask_visual_embed is not supported")
         B, R = boxes.shape[0], boxes.shape[1]
         dev = boxes.device
         full = torch.zeros((B, R, 4 + VIS_DIM), dtype=torch.float32, device=dev)

@@ -130,6 +130,40 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   }
 }
 
+// SGD with momentum, the optimiser of the VCR fine-tuning runs (vcr/function/train.py:124-128: torch.optim.SGD(lr, momentum, weight_decay),
+// dampening 0, no Nesterov):  d = coef * g + wd * p ;  buf = momentum * buf + d ;  p -= lr * buf   -- one pass over (p, g, buf),
+// the bf16 working copy refreshed in the same pass.  coef = grad_scale x the clip_grad_norm_ factor from the device-resident
+// squared norm (common/trainer.py:139-145), so no host round trip sits between the gradient norm and the update.
+__global__ __launch_bounds__(256) void sgd_momentum_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                                                           bf16_t* __restrict__ p16, long n, float lr, float momentum, float wd,
+                                                           const float* __restrict__ sumsq, float max_norm, float grad_scale) {
+  float coef = grad_scale;
+  if (sumsq && max_norm > 0.f) coef *= fminf(max_norm / (sqrtf(*sumsq) * grad_scale + 1e-6f), 1.0f);
+  const long stride = (long)gridDim.x * 256 * 4;
+  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 3 < n) {
+      const float4 a = *(const float4*)(p + i), b = *(const float4*)(g + i), c = *(const float4*)(buf + i);
+      float pv[4] = {a.x, a.y, a.z, a.w}, mv[4] = {c.x, c.y, c.z, c.w};
+      const float gv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        mv[k] = momentum * mv[k] + fmaf(wd, pv[k], coef * gv[k]);
+        pv[k] -= lr * mv[k];
+      }
+      *(float4*)(p + i) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+      *(float4*)(buf + i) = make_float4(mv[0], mv[1], mv[2], mv[3]);
+      if (p16) *(uint2*)(p16 + i) = make_uint2(pack2bf(pv[0], pv[1]), pack2bf(pv[2], pv[3]));
+    } else {
+      for (long k = i; k < n; ++k) {
+        const float mv = momentum * buf[k] + fmaf(wd, p[k], coef * g[k]);
+        const float pv = p[k] - lr * mv;
+        buf[k] = mv; p[k] = pv;
+        if (p16) p16[k] = f2bf(pv);
+      }
+    }
+  }
+}
+
 // runs after adamw_kernel in the same stream: step += 1, sumsq = 0 (ready for the next step)
 __global__ void adam_advance_kernel(VlbAdamState* st) {
   st->step += 1.0f;
@@ -220,6 +254,17 @@ extern "C" int vlb_adamw_step(float* p, const float* g, float* m, float* v, void
                      (VlbAdamState*)state, grad_scale);
   hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(1), 0, stream, (VlbAdamState*)state);
   VLB_CHECK_LAUNCH("vlb_adamw_step");
+  return VLB_OK;
+}
+
+extern "C" int vlb_sgd_momentum_step(float* p, const float* g, float* momentum_buf, void* p_bf16, long n, float lr, float momentum,
+                                     float weight_decay, const float* sumsq, float max_norm, float grad_scale, hipStream_t stream) {
+  if (n <= 0) return VLB_OK;
+  VLB_CHECK_ARG(p && g && momentum_buf, "vlb_sgd_momentum_step: null argument");
+  VLB_CHECK_ARG(momentum >= 0.f && lr >= 0.f && weight_decay >= 0.f, "vlb_sgd_momentum_step: negative hyper-parameter");
+  hipLaunchKernelGGL(sgd_momentum_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, stream, p, g, momentum_buf, (bf16_t*)p_bf16, n, lr,
+                     momentum, weight_decay, sumsq, max_norm, grad_scale);
+  VLB_CHECK_LAUNCH("vlb_sgd_momentum_step");
   return VLB_OK;
 }
 

@@ -370,6 +370,12 @@ def adamw_step(p, g, m, v, p16, state, grad_scale=1.0):
               _p(p16, BF16), p.numel(), _p(state, torch.float32), float(grad_scale), _stream())
 
 
+def sgd_momentum_step(p, g, buf, lr, momentum=0.9, weight_decay=0.0, p16=None, sumsq=None, max_norm=0.0, grad_scale=1.0):
+    """torch.optim.SGD(lr, momentum, weight_decay) on flat fp32 tensors (vlb_sgd_momentum_step); sumsq: device scalar for the clip."""
+    _lib.call("vlb_sgd_momentum_step", _p(p, torch.float32), _p(g, torch.float32), _p(buf, torch.float32), _p(p16, BF16), p.numel(),
+              float(lr), float(momentum), float(weight_decay), _p(sumsq, torch.float32), float(max_norm), float(grad_scale), _stream())
+
+
 LR_CONSTANT, LR_WARMUP_CONSTANT, LR_WARMUP_LINEAR = 0, 1, 2
 
 

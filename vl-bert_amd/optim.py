@@ -1,0 +1,73 @@
+"""Optimisers of the reference's fine-tuning entry points over the HIP library.
+
+`FusedSGD` = torch.optim.SGD(lr, momentum, weight_decay) as the VCR trainer builds it (vcr/function/train.py:124-128; dampening 0, no
+Nesterov): same constructor arguments, same `param_groups` / `state_dict` layout (`momentum_buffer` per parameter), so the reference's
+LR schedulers and checkpoints work unchanged; `step()` runs vlb_sgd_momentum_step (optim.hip: weight decay, momentum and the update
+in ONE pass over each parameter, no temporaries).  Parameters that are consecutive slices of one flat allocation (the `FlatParams`
+storage behind the VisualLinguisticBert mirrors) are updated by a single launch over the whole range.
+"""
+import torch
+
+from . import ops
+
+
+class FusedSGD(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, momentum=0.0, dampening=0.0, weight_decay=0.0, nesterov=False):
+        if dampening != 0.0 or nesterov:
+            raise NotImplementedError("FusedSGD implements dampening = 0, nesterov = False (the reference's configuration)")
+        if lr < 0.0 or momentum < 0.0 or weight_decay < 0.0:
+            raise ValueError("negative hyper-parameter")
+        super().__init__(params, dict(lr=lr, momentum=momentum, dampening=dampening, weight_decay=weight_decay, nesterov=nesterov))
+        self._runs = {}
+
+    @staticmethod
+    def _flat_runs(params):
+        """[(first index, last index + 1)] of maximal runs whose parameter AND gradient tensors are consecutive in memory."""
+        runs, start = [], 0
+        for i in range(1, len(params) + 1):
+            if i < len(params):
+                a, b = params[i - 1], params[i]
+                same = (a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()
+                        and a.grad.untyped_storage().data_ptr() == b.grad.untyped_storage().data_ptr()
+                        and b.data_ptr() == a.data_ptr() + a.numel() * 4 and b.grad.data_ptr() == a.grad.data_ptr() + a.numel() * 4)
+                if same:
+                    continue
+            runs.append((start, i))
+            start = i
+        return runs
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for gi, group in enumerate(self.param_groups):
+            ps = [p for p in group["params"] if p.grad is not None]
+            for p in ps:
+                if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous() and p.grad.dtype == torch.float32):
+                    raise RuntimeError("FusedSGD needs contiguous fp32 GPU parameters and gradients; there is no CPU path")
+            key = (gi, tuple((p.data_ptr(), p.grad.data_ptr()) for p in ps))
+            if self._runs.get("key%d" % gi) != key:          # layout changed (first step / re-allocated gradients): re-derive the runs
+                self._runs["key%d" % gi] = key
+                self._runs[gi] = self._flat_runs(ps)
+            for a, b in self._runs[gi]:
+                first = ps[a]
+                n = sum(p.numel() for p in ps[a:b])
+                st = self.state[first]
+                if "flat_buffer" not in st or st["flat_buffer"].numel() != n:
+                    st["flat_buffer"] = torch.zeros(n, dtype=torch.float32, device=first.device)
+                    off = 0
+                    for p in ps[a:b]:                        # torch.optim.SGD's per-parameter state: views of the run's buffer
+                        old = self.state[p].get("momentum_buffer")
+                        view = st["flat_buffer"][off:off + p.numel()].view_as(p)
+                        if old is not None:
+                            view.copy_(old)
+                        self.state[p]["momentum_buffer"] = view
+                        off += p.numel()
+                pf = first.data.as_strided((n,), (1,), first.storage_offset())
+                gf = first.grad.as_strided((n,), (1,), first.grad.storage_offset())
+                ops.sgd_momentum_step(pf, gf, st["flat_buffer"], group["lr"], group["momentum"], group["weight_decay"])
+                for p in ps[a:b]:      # the kernel wrote through raw pointers: tell autograd (the module mirrors key their bf16 /
+                    torch.autograd.graph.increment_version(p)      # transposed weight copies on the parameters' version counters)
+        return loss

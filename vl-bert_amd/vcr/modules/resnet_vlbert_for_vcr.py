@@ -1,0 +1,340 @@
+"""Drop-in `ResNetVLBERT` for VCR fine-tuning (vcr/modules/resnet_vlbert_for_vcr.py:15-560) on the HIP library: same constructor
+argument (the config tree of vcr/function/config.py), same `train_forward(image, boxes, masks, question, question_align_matrix,
+answer_choices, answer_align_matrix, answer_label, im_info) -> (outputs, loss)` / `inference_forward(...) -> outputs`, same
+parameter names (`image_feature_extractor.*`, `object_linguistic_embeddings.weight`, `vlbert._module.*`, `final_mlp.*`,
+`cnn_loss_reg.*`), so the reference's trainer (vcr/function/train.py, SGD + gradient accumulation) and checkpoints work unchanged.
+
+Composition, as in the reference (:226-399):
+  FastRCNN mirror, image branch with the per-object masks (`segms`)                       -> obj_reps [B,R,H]
+  per answer choice `[CLS] q [SEP] a [SEP]`, each token's visual embedding = the object its tag points at (index plumbing in
+  torch, :116-167), object linguistic embedding = row clamp(class) of the 1-row / 81-row table (:303-308)
+  `TimeDistributed` (common/nlp/time_distributed.py): the C answer choices fold into the batch -- the SAME engine rows, B*C
+  sequences of up to 256 positions -- around the VisualLinguisticBert mirror with the pooler
+  `final_mlp` on the pooled [CLS] -> logits [B,C]; sigmoid BCE with the positive-class weight (:344-356) or softmax CE (:358)
+  ENABLE_CNN_REG_LOSS + CNN_LOSS_TOP (the shipped cfgs/vcr/*.yaml): every valid object's final hidden state -> transform
+  (Linear + GELU) -> Dropout -> Linear(H, 81) -> CE against its detector class, one autograd node on the library (bf16 GEMMs with
+  fused bias / GELU epilogues, vlb_ce_fwd_bwd, TN weight gradients).
+The [B*C, H] x [H, 1] classifier and its 16-element loss are plain torch fp32 (a dot product per sequence -- no kernel to write).
+Not built: BLIND, NO_GROUNDING, NO_OBJ_ATTENTION, ANSWER_FIRST, QA_ONE_SENT, object_word_embed_mode 3, IMAGE_SEMANTIC, the
+bottom-of-the-CNN form of the regulariser (CNN_LOSS_TOP false), mask_position / mask_label (asserted off in the reference too).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ... import ops
+from ...common.fast_rcnn import FastRCNN
+from ...common.visual_linguistic_bert import VisualLinguisticBert
+
+BF16, F32 = torch.bfloat16, torch.float32
+CLS, SEP = 101, 102          # ids of '[CLS]', '[SEP]' in the BERT vocabularies (tokenizer lookups in the reference)
+_TAG_REG = 3001
+NUM_OBJ_CLASSES = 81         # COCO detector classes of the VCR annotations (:26,38)
+
+
+def _get(obj, name, default=None):
+    return getattr(obj, name, default) if not isinstance(obj, dict) else obj.get(name, default)
+
+
+def _ru(x, m):
+    return (x + m - 1) // m * m
+
+
+class TimeDistributed(nn.Module):
+    """common/nlp/time_distributed.py:10-50: fold dimension 1 into dimension 0, apply, unfold every returned tensor."""
+
+    def __init__(self, module):
+        super().__init__()
+        self._module = module
+
+    def forward(self, *inputs, **kwargs):
+        folded = []
+        for t in inputs:
+            if t.dim() <= 2:
+                raise RuntimeError("No dimension to distribute: " + str(tuple(t.shape)))
+            folded.append(t.contiguous().view(-1, *t.shape[2:]))
+        lead = inputs[-1].shape[:2]
+        out = self._module(*folded, **kwargs)
+        unfold = lambda o: o.contiguous().view(*lead, *o.shape[1:])
+        if isinstance(out, torch.Tensor):
+            return unfold(out)
+        if isinstance(out, tuple):
+            return tuple(unfold(o) for o in out)
+        raise ValueError("Not support!")
+
+
+class _ObjClsFn(torch.autograd.Function):
+    """x [n,H] fp32 (final hidden states of the valid objects), labels [n] -> CE loss of Linear(GELU(Linear(x))) (`cnn_loss_reg`,
+    :33-37,391-394) on the device: two bf16 GEMMs with fused epilogues, vlb_ce_fwd_bwd (loss and d(logits) in one pass),
+    hand-scheduled backward."""
+
+    @staticmethod
+    def forward(ctx, x, labels, module, train, w1, b1, w2, b2):
+        n, H = x.shape
+        st = module._reg_state(n, x.device)
+        module._sync_reg()
+        p = module.reg_drop if train else 0.0
+        ops.cast_f32_bf16(x.detach().contiguous(), st["x0"])
+        ops.gemm_nt(st["x0"], module._rw1, st["u"], bias=b1.detach(), act=ops.ACT_GELU_D, pre=st["du_act"])
+        x1 = ops.dropout_bf16(st["u"], st["x1"], p, module._seed, _TAG_REG) if p > 0 else st["u"]
+        ops.gemm_nt(x1, module._rw2, st["logits"][:, :NUM_OBJ_CLASSES], bias=b2.detach())
+        st["loss"].zero_()
+        ops.ce_fwd_bwd(st["logits"], NUM_OBJ_CLASSES, labels.contiguous(), st["count"], st["loss"], logits_copy=st["logits_copy"])
+        ctx.module, ctx.st, ctx.p, ctx.x1, ctx.labels = module, st, p, x1, labels
+        return st["loss"][0].clone()
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        module, st, p = ctx.module, ctx.st, ctx.p
+        g = float(g_loss)
+        if g != 1.0:      # upstream scale (CNN_LOSS_WEIGHT, gradient accumulation): re-derive d(logits) from the kept logits
+            st["logits"].copy_(st["logits_copy"])
+            st["loss"].zero_()
+            ops.ce_fwd_bwd(st["logits"], NUM_OBJ_CLASSES, ctx.labels.contiguous(), st["count"], st["loss"], gscale=g)
+        w1, b1, w2, b2 = module._reg_params()
+        gw1, gb1, gw2, gb2 = (torch.zeros_like(q, dtype=F32) for q in (w1, b1, w2, b2))
+        ops.wgrad_tn(st["logits"][:, :NUM_OBJ_CLASSES], ctx.x1, gw2, colsum=gb2, workspace=None)
+        ops.gemm_nt(st["logits"], module._rw2T, st["dx1"])                     # K = the padded class dimension (zero columns)
+        dh = ops.dropout_bf16(st["dx1"], st["dh"], p, module._seed, _TAG_REG) if p > 0 else st["dx1"]
+        ops.mul_bf16(dh, st["du_act"], st["dpre"])
+        ops.wgrad_tn(st["dpre"], st["x0"], gw1, colsum=gb1, workspace=None)
+        ops.gemm_nt(st["dpre"], module._rw1T, st["dx0"])
+        dx = torch.empty(st["dx0"].shape, dtype=F32, device=st["dx0"].device)
+        ops.cast_bf16_f32(st["dx0"], dx)
+        if p > 0:
+            ops.rng_advance(module._seed)
+        return dx, None, None, None, gw1, gb1, gw2, gb2
+
+
+class ResNetVLBERT(nn.Module):
+    def __init__(self, config, device=None):
+        super().__init__()
+        self.config = config
+        net = _get(config, "NETWORK")
+        vl = _get(net, "VLBERT")
+        for flag in ("BLIND", "NO_GROUNDING", "NO_OBJ_ATTENTION", "ANSWER_FIRST", "QA_ONE_SENT", "FOR_MASK_VL_MODELING_PRETRAIN",
+                     "IMAGE_SEMANTIC"):
+            if _get(net, flag, False):
+                raise NotImplementedError("NETWORK.%s is not supported" % flag)
+        self.embed_mode = int(_get(vl, "object_word_embed_mode", 2))
+        if self.embed_mode not in (1, 2):
+            raise NotImplementedError("object_word_embed_mode must be 1 (81 class embeddings) or 2 (one shared embedding)")
+        self.enable_cnn_reg_loss = bool(_get(net, "ENABLE_CNN_REG_LOSS", False))
+        self.cnn_loss_top = bool(_get(net, "CNN_LOSS_TOP", False))
+        if self.enable_cnn_reg_loss and not self.cnn_loss_top:
+            raise NotImplementedError("ENABLE_CNN_REG_LOSS needs CNN_LOSS_TOP (the form of the shipped cfgs/vcr/*.yaml)")
+        self.classifier = _get(net, "CLASSIFIER_TYPE", "2fc")
+        if self.classifier not in ("1fc", "2fc"):
+            raise ValueError("Not support classifier type: {}!".format(self.classifier))
+        if not torch.cuda.is_available():
+            raise RuntimeError("ResNetVLBERT (HIP) needs an MI355X: there is no CPU fallback")
+        dev = torch.device(device or ("cuda:%d" % torch.cuda.current_device()))
+        self.device_ = dev
+        H = int(_get(vl, "hidden_size"))
+        self.H = H
+        self.sigmoid = bool(_get(net, "CLASSIFIER_SIGMOID", False))
+        self.pos_weight = float(_get(net, "CLASSIFIER_SIGMOID_LOSS_POSITIVE_WEIGHT", 1.0))
+        self.cls_drop = float(_get(net, "CLASSIFIER_DROPOUT", 0.1))
+        self.reg_drop = float(_get(net, "CNN_REG_DROPOUT", 0.0))
+        self.ans_loss_weight = float(_get(net, "ANS_LOSS_WEIGHT", 1.0))
+        self.cnn_loss_weight = float(_get(net, "CNN_LOSS_WEIGHT", 1.0))
+        self.image_feature_extractor = FastRCNN(config, average_pool=True, final_dim=_get(net, "IMAGE_FINAL_DIM", 768),
+                                                enable_cnn_reg_loss=False, device=dev)
+        self.object_linguistic_embeddings = nn.Embedding(NUM_OBJ_CLASSES if self.embed_mode == 1 else 1, H).to(dev)
+        self.vlbert = TimeDistributed(VisualLinguisticBert(vl, language_pretrained_model_path=None, device=dev))
+
+        def lin(o, i):
+            m = nn.Module()
+            m.register_parameter("weight", nn.Parameter(torch.empty((o, i), device=dev)))
+            m.register_parameter("bias", nn.Parameter(torch.zeros((o,), device=dev)))
+            return m
+        mlp = nn.Module()
+        if self.classifier == "1fc":
+            mlp.add_module("1", lin(1, H))
+        else:
+            hc = int(_get(net, "CLASSIFIER_HIDDEN_SIZE", 1024))
+            mlp.add_module("1", lin(hc, H))
+            mlp.add_module("4", lin(1, hc))
+        self.final_mlp = mlp
+        if self.enable_cnn_reg_loss:
+            reg = nn.Module()
+            tr = nn.Module()
+            tr.add_module("dense", lin(H, H))
+            reg.add_module("0", tr)
+            reg.add_module("2", lin(NUM_OBJ_CLASSES, H))
+            self.cnn_loss_reg = reg
+            zb = lambda *s: torch.zeros(s, dtype=BF16, device=dev)
+            self.Cp = _ru(NUM_OBJ_CLASSES, 64)
+            self._rw1, self._rw1T = zb(H, H), zb(H, H)
+            self._rw2, self._rw2T = zb(NUM_OBJ_CLASSES, H), zb(H, self.Cp)
+        self._seed = torch.tensor([ops.rank_seed(40011)], dtype=torch.int32, device=dev)
+        self._reg_version, self._states = None, {}
+        self.init_weight()
+
+    # -- parameters ---------------------------------------------------------------------------------
+    def _reg_params(self):
+        r = self.cnn_loss_reg
+        t, c = getattr(r, "0"), getattr(r, "2")
+        return [t.dense.weight, t.dense.bias, c.weight, c.bias]
+
+    def init_weight(self):
+        """:84-97: N(0, 0.02) object word embeddings and regulariser head, xavier-uniform classifier, zero biases."""
+        with torch.no_grad():
+            self.image_feature_extractor.init_weight()
+            self.object_linguistic_embeddings.weight.normal_(0.0, 0.02)
+            if self.enable_cnn_reg_loss:
+                for q in self._reg_params():
+                    if q.dim() == 2:
+                        q.normal_(0.0, 0.02)
+                    else:
+                        q.zero_()
+            for m in self.final_mlp.children():
+                nn.init.xavier_uniform_(m.weight)
+                m.bias.zero_()
+
+    def fix_params(self):
+        pass
+
+    def train(self, mode=True):
+        super().train(mode)
+        self.image_feature_extractor.bn_eval()            # frozen BatchNorm (:99-104); the HIP vision stack folds it anyway
+        return self
+
+    def state_dict(self, *args, **kwargs):
+        """the FastRCNN mirror converts its convolution layout ([O,KH,KW,I] <-> the reference's [O,I,KH,KW]) in its own
+        state_dict / load_state_dict, which nn.Module's recursion does not call for sub-modules"""
+        sd = super().state_dict(*args, **kwargs)
+        prefix = kwargs.get("prefix", args[1] if len(args) > 1 else "") + "image_feature_extractor."
+        for k in [k for k in sd if k.startswith(prefix)]:
+            del sd[k]
+        for k, v in self.image_feature_extractor.state_dict().items():
+            sd[prefix + k] = v
+        return sd
+
+    def load_state_dict(self, state_dict, strict=True):
+        pre = "image_feature_extractor."
+        self.image_feature_extractor.load_state_dict({k[len(pre):]: v for k, v in state_dict.items() if k.startswith(pre)}, strict=strict)
+        own = super().state_dict()
+        rest = {k: v for k, v in state_dict.items() if not k.startswith(pre)}
+        rest.update({k: v for k, v in own.items() if k.startswith(pre)})
+        return super().load_state_dict(rest, strict=strict)
+
+    def _sync_reg(self):
+        params = self._reg_params()
+        ver = tuple(q._version for q in params)
+        if ver == self._reg_version:
+            return
+        ops.cast_f32_bf16(params[0].detach().contiguous(), self._rw1)
+        ops.cast_f32_bf16(params[2].detach().contiguous(), self._rw2)
+        ops.transpose(self._rw1, self._rw1T)
+        ops.transpose(self._rw2, self._rw2T)          # [H, 81] into the zero-padded [H, Cp] image
+        self._reg_version = ver
+
+    def _reg_state(self, n, dev):
+        cap = _ru(n, 64)
+        if cap not in self._states:
+            zb = lambda *s: torch.zeros(s, dtype=BF16, device=dev)
+            H, Cp = self.H, self.Cp
+            self._states[cap] = dict(x0=zb(cap, H), u=zb(cap, H), du_act=zb(cap, H), x1=zb(cap, H), logits=zb(cap, Cp),
+                                     logits_copy=zb(cap, Cp), dx1=zb(cap, H), dh=zb(cap, H), dpre=zb(cap, H), dx0=zb(cap, H),
+                                     loss=torch.zeros((1,), dtype=F32, device=dev), count=torch.zeros((1,), dtype=F32, device=dev))
+        return {k: (v[:n] if v.dim() == 2 else v) for k, v in self._states[cap].items()}
+
+    # -- text preparation: index plumbing (prepare_text_from_qa, :136-167) -------------------------------------------
+    @staticmethod
+    def _prepare_text(question, question_tags, question_mask, answers, answers_tags, answers_mask):
+        B, Lq = question.shape
+        _, C, La = answers.shape
+        L = int((question_mask.sum(1) + answers_mask.sum(2).max(1)[0]).max()) + 3
+        d = question.device
+        question = question[:, None, :].expand(B, C, Lq)
+        qmask = question_mask[:, None, :].expand(B, C, Lq)
+        q_end = 1 + qmask.sum(2, keepdim=True)
+        a_end = q_end + 1 + answers_mask.sum(2, keepdim=True)
+        k = torch.arange(L, device=d)[None, None, :].expand(B, C, L)
+        ids = torch.zeros((B, C, L), dtype=question.dtype, device=d)
+        tags = torch.zeros((B, C, L), dtype=question.dtype, device=d)
+        mask = k <= a_end
+        types = ((k > q_end) & (k <= a_end)).to(question.dtype)
+        q_in, a_in = (k > 0) & (k < q_end), (k > q_end) & (k < a_end)
+        ids[:, :, 0] = CLS
+        ids[k == q_end] = SEP
+        ids[k == a_end] = SEP
+        ids[q_in] = question[qmask]
+        ids[a_in] = answers[answers_mask]
+        tags[q_in] = question_tags[qmask]
+        tags[a_in] = answers_tags[answers_mask]
+        return ids, types, tags, mask
+
+    def _encode(self, image, boxes, masks, question, answer_choices, im_info):
+        objects = boxes[:, :, -1]
+        boxes4 = boxes[:, :, :4]
+        box_mask = boxes4[:, :, -1] > -0.5
+        max_len = int(box_mask.sum(1).max())
+        objects, box_mask, boxes4, segms = objects[:, :max_len], box_mask[:, :max_len], boxes4[:, :max_len], masks[:, :max_len]
+        obj = self.image_feature_extractor(images=image, boxes=boxes4, box_mask=box_mask, im_info=im_info, classes=objects, segms=segms)
+        reps = obj["obj_reps"]
+        B, R = box_mask.shape
+        C = answer_choices.shape[1]
+        q_ids, q_tags = question[:, :, 0], question[:, :, 1]
+        q_tags = q_tags[:, None, :].expand(-1, C, -1)
+        q_mask = question[:, :, 0] > 0.5
+        a_ids, a_tags = answer_choices[:, :, :, 0], answer_choices[:, :, :, 1]
+        a_mask = answer_choices[:, :, :, 0] > 0.5
+        ids, types, tags, text_mask = self._prepare_text(q_ids, q_tags, q_mask, a_ids, a_tags, a_mask)
+        L = ids.shape[2]
+        rows = torch.arange(B, device=ids.device)[:, None, None].expand(B, C, L)
+        text_visual = reps[rows.reshape(-1), tags.clamp(min=0).reshape(-1)].view(B, C, L, -1)          # _collect_obj_reps (:116-134)
+        table = self.object_linguistic_embeddings.weight
+        ling = table[objects.long().clamp(min=0, max=table.shape[0] - 1)]
+        obj_vl = torch.cat((reps, ling), -1)[:, None].expand(B, C, R, -1)
+        text_out, obj_out, pooled = self.vlbert(ids, types, text_visual, text_mask, obj_vl, box_mask[:, None].expand(B, C, R),
+                                                output_all_encoded_layers=False, output_text_and_object_separately=True)
+        return pooled, obj_out, objects, box_mask
+
+    def _classify(self, pooled):
+        m = self.final_mlp
+        x = F.dropout(pooled.float(), self.cls_drop, self.training)
+        if self.classifier == "1fc":
+            lin = getattr(m, "1")
+            return F.linear(x, lin.weight, lin.bias).squeeze(2)
+        a, b = getattr(m, "1"), getattr(m, "4")
+        h = F.dropout(F.relu(F.linear(x, a.weight, a.bias)), self.cls_drop, self.training)
+        return F.linear(h, b.weight, b.bias).squeeze(2)
+
+    def train_forward(self, image, boxes, masks, question, question_align_matrix, answer_choices, answer_align_matrix, answer_label,
+                      im_info, mask_position=None, mask_type=None, mask_label=None):
+        if mask_position is not None:
+            raise NotImplementedError("mask_position (asserted off in the reference, :365)")
+        pooled, obj_out, objects, box_mask = self._encode(image, boxes, masks, question, answer_choices, im_info)
+        logits = self._classify(pooled)
+        B, C = logits.shape
+        outputs = {}
+        if self.sigmoid:
+            label_binary = torch.arange(C, device=logits.device)[None, :] == answer_label[:, None]
+            weight = torch.ones_like(logits)
+            weight[label_binary] = self.pos_weight
+            rescale = (self.pos_weight + 1.0) / (2.0 * self.pos_weight)
+            ans_loss = rescale * F.binary_cross_entropy_with_logits(logits, label_binary.to(logits.dtype), weight=weight)
+            outputs["positive_fraction"] = label_binary.to(logits.dtype).sum() / label_binary.numel()
+        else:
+            ans_loss = F.cross_entropy(logits, answer_label.long().view(-1))
+        outputs.update({"label_logits": logits, "label": answer_label.long().view(-1), "ans_loss": ans_loss})
+        loss = ans_loss.mean() * self.ans_loss_weight
+        if self.enable_cnn_reg_loss:
+            R = box_mask.shape[1]
+            sel = box_mask[:, None].expand(B, C, R)
+            labels = objects[:, None].expand(B, C, R)[sel].long()
+            reg_loss = _ObjClsFn.apply(obj_out[sel].float(), labels, self, self.training, *self._reg_params())
+            loss = loss + reg_loss * self.cnn_loss_weight
+            outputs["cnn_regularization_loss"] = reg_loss
+        return outputs, loss
+
+    def inference_forward(self, image, boxes, masks, question, question_align_matrix, answer_choices, answer_align_matrix, *args):
+        im_info = args[-1]
+        pooled, _, _, _ = self._encode(image, boxes, masks, question, answer_choices, im_info)
+        return {"label_logits": self._classify(pooled)}
+
+    def forward(self, *inputs, **kwargs):
+        """common/module.py:19-24"""
+        return self.train_forward(*inputs, **kwargs) if self.training else self.inference_forward(*inputs, **kwargs)
