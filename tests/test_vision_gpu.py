@@ -403,7 +403,7 @@ def test_engine_e2e_step_vs_oracle(empty_sample):
     errs, glob, dnorm = _vision_grad_errors(eng, Po, names)
     print("e2e engine: conv weight gradients median rel-fro %.3e worst %.3e (%s); all vision parameters: rel-fro %.3e, grad-norm "
           "difference %.3e" % (float(np.median([e for e, _ in errs])), *max(errs), glob, dnorm))
-    assert np.median([e for e, _ in errs]) < 5e-2 and max(errs)[0] < 0.2
+    assert np.median([e for e, _ in errs]) < 6e-2 and max(errs)[0] < 0.13      # measured: median 3.0-4.5e-2, worst 6.3-9.0e-2
     assert dnorm < 1e-2, dnorm          # global gradient norm over the vision parameters (what the clip and the step size see)
     assert leaves["object_mask_visual_embedding.weight"].grad is None or float(leaves["object_mask_visual_embedding.weight"].grad.abs().sum()) == 0.0
     assert float(eng.g32["object_mask_visual_embedding.weight"].abs().sum()) == 0.0
@@ -465,7 +465,7 @@ def test_engine_multitask_e2e_step_vs_oracle():
     errs, glob, dnorm = _vision_grad_errors(eng, Po, names)
     print("multitask e2e: conv weight gradients median rel-fro %.3e worst %.3e (%s); all vision parameters: rel-fro %.3e, "
           "grad-norm difference %.3e" % (float(np.median([e for e, _ in errs])), *max(errs), glob, dnorm))
-    assert np.median([e for e, _ in errs]) < 5e-2 and max(errs)[0] < 0.2
+    assert np.median([e for e, _ in errs]) < 6e-2 and max(errs)[0] < 0.13      # measured: median 3.0-4.5e-2, worst 6.3-9.0e-2
     assert dnorm < 1e-2, dnorm
     for k in ("aux_text_visual_embedding.weight", "image_feature_extractor.obj_downsample.1.weight",
               "vlbert.encoder.layer.0.output.dense.weight", "vlbert.word_embeddings.weight"):
@@ -677,5 +677,5 @@ def test_resnet101_forward_at_headline_image_size_vs_oracle():
     e_feat = rel_fro(boxes[:, :, 4:].cpu()[mask], feats)
     print("ResNet-101 600x1000: body4 rel-fro %.3e, post-ROIAlign layer4 features rel-fro %.3e (|feats| max %.3f)" %
           (e_body, e_feat, float(feats.abs().max())))
-    assert e_body < 3e-2 and e_feat < 3e-2
+    assert e_body < 2e-2 and e_feat < 1e-2          # measured on MI355X: 9.1e-3 / 3.0e-3
     assert float(boxes[0, 3, 4:].abs().max()) == 0.0          # the padded box slot stays zero

@@ -200,24 +200,18 @@ class ResNetVLBERT(nn.Module):
         self.image_feature_extractor.bn_eval()            # frozen BatchNorm (:99-104); the HIP vision stack folds it anyway
         return self
 
-    def state_dict(self, *args, **kwargs):
-        """the FastRCNN mirror converts its convolution layout ([O,KH,KW,I] <-> the reference's [O,I,KH,KW]) in its own
-        state_dict / load_state_dict, which nn.Module's recursion does not call for sub-modules"""
-        sd = super().state_dict(*args, **kwargs)
-        prefix = kwargs.get("prefix", args[1] if len(args) > 1 else "") + "image_feature_extractor."
-        for k in [k for k in sd if k.startswith(prefix)]:
-            del sd[k]
-        for k, v in self.image_feature_extractor.state_dict().items():
-            sd[prefix + k] = v
-        return sd
-
     def load_state_dict(self, state_dict, strict=True):
+        """the FastRCNN mirror converts its convolution layout ([O,KH,KW,I] <-> the reference's [O,I,KH,KW]) and drops the reference's
+        `head.0.*` alias keys in its own load_state_dict, which nn.Module's recursion does not call for sub-modules (state_dict's
+        recursion does): hand it its slice directly, load the rest here"""
         pre = "image_feature_extractor."
         self.image_feature_extractor.load_state_dict({k[len(pre):]: v for k, v in state_dict.items() if k.startswith(pre)}, strict=strict)
-        own = super().state_dict()
         rest = {k: v for k, v in state_dict.items() if not k.startswith(pre)}
-        rest.update({k: v for k, v in own.items() if k.startswith(pre)})
-        return super().load_state_dict(rest, strict=strict)
+        res = super().load_state_dict(rest, strict=False)
+        missing = [k for k in res.missing_keys if not k.startswith(pre)]
+        if strict and (missing or res.unexpected_keys):
+            raise RuntimeError("Error(s) in loading state_dict for ResNetVLBERT: missing %s, unexpected %s" % (missing, res.unexpected_keys))
+        return res
 
     def _sync_reg(self):
         params = self._reg_params()
