@@ -656,7 +656,10 @@ int vlb_gemm_p8_try(GemmParams& p, hipStream_t stream) {
   if ((long)p.M * p.lda * 2 >= (1L << 31) || (long)p.N * p.ldb * 2 >= (1L << 31)) return 0;
   // tile height: whole rounds of 256 resident workgroups, time per round ~ tile area
   const long t4 = (long)vlb_cdiv(p.M, 256) * vlb_cdiv(p.N, 256), t5 = (long)vlb_cdiv(p.M, 320) * vlb_cdiv(p.N, 256);
-  if (t4 < min_tiles) return 0;    // too few tiles for one workgroup per CU: the 128x128 kernel fills the chip better
+  // too few tiles for one workgroup per CU: the 128x128 kernel fills the chip better -- except for a long K loop, where the large
+  // tile's main loop still wins with 60 % of the CUs busy (M = 12928, N = 768: 153 tiles; K = 3072: 84.7 -> 78.2 us, K = 2304:
+  // 64.1 -> 58.7 us measured; at K = 768 the 128x128 kernel is faster: 24.9 vs 27.8 us)
+  if (t4 < min_tiles && !(t4 >= 128 && p.K >= 1536)) return 0;
   const double c4 = (double)((t4 + 255) / 256) * 256.0, c5 = (double)((t5 + 255) / 256) * 320.0;
   int fmh = (c5 < 0.97 * c4) ? 5 : 4;
   if (mode == 4 || mode == 5) fmh = mode;
