@@ -248,74 +248,6 @@ def check_ring():
     return bad
 
 
-def check_p4():
-    """256x128-tile two-workgroups-per-CU kernel (p4_mode 2) against the 128x128 two-stage kernel and torch fp32, every epilogue"""
-    seed_t = torch.tensor([12345], dtype=torch.int32, device=D)
-    shapes = [(4096, 2304, 768), (8192 + 256, 768, 768), (6464, 768, 3072), (25856, 768, 768), (5000, 1000, 256), (4100, 3000 + 2, 128),
-              (3232, 3072, 768), (300, 130, 128)]
-    bad = 0
-    for M, N, K in shapes:
-        for epi in range(8):
-            lib.gemm_set_option("p4_mode", 2)
-            lib.gemm_set_option("p8_min_tiles", 1)
-            got, ins = run_case(M, N, K, epi, 1, seed_t)
-            lib.gemm_set_option("p4_mode", 0)
-            lib.gemm_set_option("nt_ring", 0)
-            old, _ = run_case(M, N, K, epi, 0, seed_t)
-            ref = reference(M, N, K, epi, ins)
-            for k, (g, o) in enumerate(zip(got, old)):
-                scale = float(o.abs().max())
-                d_old = float((g - o).abs().max())
-                d_ref = float((g - ref[k]).abs().max()) if ref is not None else float("nan")
-                ok = d_old <= 2.5e-2 * max(scale, 1e-6) and (ref is None or d_ref <= 1.2e-2 * max(scale, 1e-6)) and bool(torch.isfinite(g).all())
-                if epi in (3, 6):
-                    ok = ok and bool(((g == 0) == (o == 0)).float().mean() > 0.9999)
-                print("M %6d N %6d K %5d p4 epi %d out %d: |d two-stage| %.3e |d ref| %.3e scale %.3e %s"
-                      % (M, N, K, epi, k, d_old, d_ref, scale, "ok" if ok else "FAIL"), flush=True)
-                bad += 0 if ok else 1
-    lib.gemm_set_option("p4_mode", 2)
-    A = rnd(3000, 256, seed=1).to(BF).to(D)
-    Bm = rnd(1000, 256, seed=2).to(BF).to(D)
-    Cfull = torch.full((3000 + 8, 1024), 7.0, dtype=BF, device=D)
-    ops.gemm_nt(A, Bm, Cfull[:3000, :1000])
-    torch.cuda.synchronize()
-    ok = bool((Cfull[:3000, 1000:] == 7.0).all()) and bool((Cfull[3000:] == 7.0).all())
-    print("padding columns / rows beyond M untouched: %s" % ("ok" if ok else "FAIL"))
-    bad += 0 if ok else 1
-    lib.gemm_set_option("p4_mode", 1)
-    lib.gemm_set_option("nt_ring", 1)
-    print("P4 CHECK %s (%d failures)" % ("PASSED" if bad == 0 else "FAILED", bad), flush=True)
-    return bad
-
-
-def bench_p4(batch):
-    M = batch * 101
-    BT = batch * 64
-    shapes = [("qkv fwd", M, 2304, 768, "bias"), ("attn-out fwd", M, 768, 768, "dropres"), ("ffn1 fwd", M, 3072, 768, "gelu"),
-              ("ffn2 fwd", M, 768, 3072, "dropres"), ("out dgrad", M, 768, 768, "plain"), ("qkv dgrad", M, 768, 2304, "res"),
-              ("ffn1 dgrad", M, 768, 3072, "res"), ("ffn2 dgrad", M, 3072, 768, "mulaux"), ("decoder fwd", BT, 30522, 768, "bias"),
-              ("square 4096", 4096, 4096, 4096, "plain"), ("square 8192", 8192, 8192, 8192, "plain")]
-    variants = [("p8 model", dict(p4_mode=0, p8_mode=1, p8_keepb=1, p8_group=2, p8_min_tiles=160, nt_stagger=0)),
-                ("p4", dict(p4_mode=2, p8_mode=1, p8_min_tiles=1, nt_stagger=0)),
-                ("p4 stagger 1", dict(p4_mode=2, p8_mode=1, p8_min_tiles=1, nt_stagger=1)),
-                ("p4 stagger 2", dict(p4_mode=2, p8_mode=1, p8_min_tiles=1, nt_stagger=2)),
-                ("p4 no epilogue", dict(p4_mode=2, p8_mode=1, p8_min_tiles=1, nt_stagger=0, p8_ablate=1))]
-    print("%-14s %7s %6s %6s | " % ("gemm", "M", "N", "K") + " | ".join("%-13s" % v[0] for v in variants))
-    tot = [0.0] * len(variants)
-    for name, m, n, k, kwm in shapes:
-        row = []
-        for vi, (vn, opt) in enumerate(variants):
-            lib.gemm_set_option("p8_ablate", 0)
-            ms, tf = bench_one(m, n, k, kwm, opt)
-            row.append("%6.1fus %5.0f" % (ms * 1e3, tf))
-            if not name.startswith("square"):
-                tot[vi] += ms * (1 if name.startswith("decoder") else 12)
-        print("%-14s %7d %6d %6d | " % (name, m, n, k) + " | ".join(row), flush=True)
-    print("%-36s | " % "NT ms per step (12 layers + decoder fwd)" + " | ".join("%13.2f" % t for t in tot), flush=True)
-    for k, v in dict(p4_mode=1, p8_ablate=0, nt_stagger=0, p8_min_tiles=160).items():
-        lib.gemm_set_option(k, v)
-
-
 def bench_ring(batch):
     M = batch * 101
     BT = batch * 64
@@ -376,11 +308,6 @@ def ablate(batch):
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "p4check":
-        sys.exit(1 if check_p4() else 0)
-    if len(sys.argv) > 1 and sys.argv[1] == "p4":
-        bench_p4(int(sys.argv[2]) if len(sys.argv) > 2 else 256)
-        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ringcheck":
         sys.exit(1 if check_ring() else 0)
     if len(sys.argv) > 1 and sys.argv[1] == "ring":

@@ -539,269 +539,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(const GemmParams p) 
   }
 }
 
-// =====================================================================================================================
-// gemm_nt_p4_kernel: 256 x 128 tiles, 4 waves, TWO workgroups per CU -- the short-K companion of the kernel above.
-//
-// With K = 768 the 256-accumulator kernel spends as long in its epilogue (VALU: GELU pair / dropout hash, slab round trips, a
-// bursty store stream) as in its main loop, and one workgroup per CU with the whole register file has nothing to overlap it with
-// (tools/p8_check.py ablate).  Here a wave tile is still 128 x 64 (the same LDS bytes per FLOP inside the wave), but a
-// workgroup is 4 waves / 128 accumulator registers / 72 KiB of LDS, so two of them share a CU: while one runs its epilogue the
-// other has the matrix pipe.  Main loop = the 3-stage BK = 32 ring of gemm_nt_256_kernel (LDS-DMA for stage g + 2 issued in
-// iteration g, counted vmcnt, inline-asm fragment reads, one barrier per K step, running across output tiles); epilogue = the
-// two-pass fp32 slab scheme above (32 rows per round through the ring slot consumed last, every thread 8 consecutive columns,
-// p8_epilogue8), side rows requested before the slab is written.
-// =====================================================================================================================
-template <int EPI>
-__device__ __forceinline__ void p4_drain(const GemmParams& p, f32x4 (&acc)[8][4], uint32_t slab, int m0, int n0, int wm, int wn,
-                                         int tid, uint32_t seed) {
-  constexpr bool LNRES = (EPI == 6 || EPI == 7);
-  constexpr bool SIDE = (EPI == 2 || EPI == 3 || EPI == 4 || EPI == 6 || EPI == 7);
-  asm volatile("" : "+v"(tid));       // (keeps these lane constants out of the K loop's live ranges)
-  const int lane = tid & 63, frow = lane & 15;
-  const int wrow = wm * 16 + frow;    // slab row this lane writes: rows [0,16) from the wm = 0 waves, [16,32) from wm = 1
-  uint32_t wr[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int c = wn * 16 + j * 4 + (lane >> 4);                       // 16-B chunk (4 floats) of the 128-column slab row
-    wr[j] = slab + (uint32_t)(wrow * 512 + ((c ^ (frow & 7)) << 4));
-  }
-  const int q = tid & 15, rho = tid >> 4;                                // reader: columns q*8 .. +8 of slab rows rho, rho + 16
-  const int n = n0 + q * 8;
-  const bool full8 = n + 8 <= p.N;
-  bf16_t* const C = (bf16_t*)p.C;
-  float b8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (p.bias && full8) {
-    const float4 b0 = *(const float4*)(p.bias + n), b1 = *(const float4*)(p.bias + n + 4);
-    b8[0] = b0.x; b8[1] = b0.y; b8[2] = b0.z; b8[3] = b0.w; b8[4] = b1.x; b8[5] = b1.y; b8[6] = b1.z; b8[7] = b1.w;
-  }
-  float g8[8], be8[8];
-  if constexpr (LNRES) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) g8[e] = be8[e] = 0.f;
-    if (full8) {
-      const float4 a0 = *(const float4*)(p.res_gamma + n), a1 = *(const float4*)(p.res_gamma + n + 4);
-      const float4 c0 = *(const float4*)(p.res_beta + n), c1 = *(const float4*)(p.res_beta + n + 4);
-      g8[0] = a0.x; g8[1] = a0.y; g8[2] = a0.z; g8[3] = a0.w; g8[4] = a1.x; g8[5] = a1.y; g8[6] = a1.z; g8[7] = a1.w;
-      be8[0] = c0.x; be8[1] = c0.y; be8[2] = c0.z; be8[3] = c0.w; be8[4] = c1.x; be8[5] = c1.y; be8[6] = c1.z; be8[7] = c1.w;
-    }
-  }
-  const bool f16out = p.c_f16 != 0;
-  p8_static_for<0, 8>([&](auto r_c) {
-    constexpr int r = decltype(r_c)::value;          // row fragment r of both wave rows: tile rows {0, 128} + 16 r + [0, 16)
-    uint4 side[2];
-    if constexpr (SIDE) {                            // requested before the slab is touched: in flight under the writes + barrier
-#pragma unroll
-      for (int pp = 0; pp < 2; ++pp) {
-        const int m = m0 + pp * 128 + r * 16 + rho;
-        side[pp] = make_uint4(0, 0, 0, 0);
-        if (m < p.M && full8) {
-          if (EPI == 2) side[pp] = *(const uint4*)(p.aux + (long)m * p.ldaux + n);
-          else side[pp] = *(const uint4*)(p.res + (long)m * p.ldres + n);
-        }
-      }
-    }
-    p8_lds_write_f4<0>(wr[0], acc[r][0]);
-    p8_lds_write_f4<0>(wr[1], acc[r][1]);
-    p8_lds_write_f4<0>(wr[2], acc[r][2]);
-    p8_lds_write_f4<0>(wr[3], acc[r][3]);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    p8_barrier();
-#pragma unroll
-    for (int pp = 0; pp < 2; ++pp) {
-      const int sr = pp * 16 + rho;
-      const int m = m0 + pp * 128 + r * 16 + rho;
-      f32x4 x0, x1;
-      p8_stage_read<0>(x0, x1, slab + (uint32_t)(sr * 512 + (((2 * q) ^ (sr & 7)) << 4)),
-                       slab + (uint32_t)(sr * 512 + (((2 * q + 1) ^ (sr & 7)) << 4)));
-      if (m < p.M && n < p.N) {
-        float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-        if (full8) {
-          const uint4 sd = SIDE ? side[pp] : make_uint4(0, 0, 0, 0);
-          if constexpr (LNRES) {
-            const float2 ms = *(const float2*)(p.res_stats + 2 * (long)m);
-            p8_epilogue8<EPI>(p, v, b8, m, n, seed, sd, ms, g8, be8);
-          } else {
-            p8_epilogue8<EPI>(p, v, b8, m, n, seed, sd);
-          }
-          *(uint4*)(C + (long)m * p.ldc + n) = make_uint4(pack2o(v[0], v[1], f16out), pack2o(v[2], v[3], f16out),
-                                                         pack2o(v[4], v[5], f16out), pack2o(v[6], v[7], f16out));
-        } else {
-          for (int e = 0; e < 8 && n + e < p.N; ++e) {
-            const float o = p8_epilogue1<EPI>(p, v[e], m, n + e, seed);
-            C[(long)m * p.ldc + n + e] = f16out ? f2h(o) : f2bf(o);
-          }
-        }
-      }
-    }
-    if (r + 1 < 8) p8_barrier();      // the slab is free for the next round
-  });
-}
-
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_nt_p4_kernel(const GemmParams p) {
-  constexpr int BM = 256, BN = 128, NT = 256, NS = 3;
-  constexpr int WM = 128, WN = 64, FM = 8, FN = 4;
-  constexpr int NA = BM * 4 / NT, NB = BN * 4 / NT;            // 16-B chunks per thread per stage (4 per 64-B row): 4 + 2
-  constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64, STAGE = A_BYTES + B_BYTES;      // 24 KiB
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int nt = p.ntm * p.ntn;
-  const int ntk = p.K / 32;
-  if ((int)blockIdx.x >= nt) return;
-  if (p.stagger > 0 && (((blockIdx.x >> 3) & 63) >= 32)) {      // (experiment: phase offset for the second resident of a CU)
-    for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
-  }
-  auto tile_of = [&](int w, int& m0, int& n0) {   // XCD-aware grouped order (as in gemm_nt_bf16_kernel)
-    const int xcd = w & 7, q = nt >> 3, r = nt & 7;
-    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (w >> 3);
-    const int gm = p.tile_group, per_group = gm * p.ntn, gid = t / per_group, first = gid * gm;
-    const int gsz = min(p.ntm - first, gm), rem = t - gid * per_group;
-    m0 = (first + rem % gsz) * BM;
-    n0 = (rem / gsz) * BN;
-  };
-  const bf16_t* a_src[NA];
-  const bf16_t* b_src[NB];
-  int w_p = blockIdx.x, kt_p = 0, issued = 0, slot_p = 0;
-  auto setup = [&](int w) {
-    int m0, n0;
-    tile_of(w, m0, n0);
-#pragma unroll
-    for (int it = 0; it < NA; ++it) {
-      const int P = it * NT + tid, r = P >> 2, kc = (P & 3) ^ ((4 - ((r >> 2) & 3)) & 3);
-      a_src[it] = p.A + (long)min(m0 + r, p.M - 1) * p.lda + kc * 8;
-    }
-#pragma unroll
-    for (int it = 0; it < NB; ++it) {
-      const int P = it * NT + tid, r = P >> 2, kc = (P & 3) ^ ((4 - ((r >> 2) & 3)) & 3);
-      b_src[it] = p.B + (long)min(n0 + r, p.N - 1) * p.ldb + kc * 8;
-    }
-  };
-  auto produce = [&]() {
-    if (w_p >= nt) return;
-    char* sa = smem + slot_p * STAGE;
-    char* sb = sa + A_BYTES;
-#pragma unroll
-    for (int it = 0; it < NA; ++it) {
-      __builtin_amdgcn_global_load_lds(GLDS_PTR(a_src[it]), LDS_PTR(sa + (it * NT + wave * 64) * 16), 16, 0, 0);
-      a_src[it] += 32;
-    }
-#pragma unroll
-    for (int it = 0; it < NB; ++it) {
-      __builtin_amdgcn_global_load_lds(GLDS_PTR(b_src[it]), LDS_PTR(sb + (it * NT + wave * 64) * 16), 16, 0, 0);
-      b_src[it] += 32;
-    }
-    ++issued;
-    slot_p = (slot_p + 1 == NS) ? 0 : slot_p + 1;
-    if (++kt_p == ntk) {
-      kt_p = 0;
-      w_p += gridDim.x;
-      if (w_p < nt) setup(w_p);
-    }
-  };
-
-  f32x4 acc[FM][FN];
-  const int frow = lane & 15;
-  const int pc = ((lane >> 4) ^ ((4 - (frow >> 2)) & 3)) << 4;
-  const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(smem);
-  const uint32_t a_off = lds0 + (uint32_t)((wm * WM + frow) * 64 + pc);
-  const uint32_t b_off = lds0 + (uint32_t)(A_BYTES + (wn * WN + frow) * 64 + pc);
-  const uint32_t seed = ((EPI == 3 || EPI == 6) && p.seed) ? *p.seed : 0u;
-
-  setup(w_p);
-  produce();
-  produce();
-  int g = 0, slot_c = 0;      // stages consumed so far, ring slot of stage g
-  for (int w = blockIdx.x; w < nt; w += gridDim.x) {
-    int m0, n0;
-    tile_of(w, m0, n0);
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-      for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int kt = 0; kt < ntk; ++kt) {
-      if (issued - g >= 2) __builtin_amdgcn_s_waitcnt(0x0F70 | (NA + NB));      // only stage g + 1 may still be in flight
-      else __builtin_amdgcn_s_waitcnt(0x0F70);
-      p8_barrier();                     // every wave's part of stage g is in LDS; everyone is done reading stage g - 1
-      produce();                        // stage g + 2 -> the slot stage g - 1 was read from
-      const uint32_t so = (uint32_t)(slot_c * STAGE);
-      const uint32_t va = so + a_off, vb = so + b_off;
-      bf16x8 af[FM], bfr[FN];
-      p8_lds_read<0 * 1024>(bfr[0], vb); p8_lds_read<1 * 1024>(bfr[1], vb);
-      p8_lds_read<2 * 1024>(bfr[2], vb); p8_lds_read<3 * 1024>(bfr[3], vb);
-      p8_lds_read<0 * 1024>(af[0], va); p8_lds_read<1 * 1024>(af[1], va);
-      p8_lds_read<2 * 1024>(af[2], va); p8_lds_read<3 * 1024>(af[3], va);
-      p8_lds_read<4 * 1024>(af[4], va); p8_lds_read<5 * 1024>(af[5], va);
-      p8_lds_read<6 * 1024>(af[6], va); p8_lds_read<7 * 1024>(af[7], va);
-      // the first half of the wave tile (A fragments 0-3) starts under the LDS latency of fragments 4-7
-      asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bfr[0]), "+v"(bfr[1]), "+v"(bfr[2]), "+v"(bfr[3]), "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]));
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[4]), "+v"(af[5]), "+v"(af[6]), "+v"(af[7]));
-#pragma unroll
-      for (int i = 4; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
-      __builtin_amdgcn_sched_barrier(0);
-      ++g;
-      slot_c = (slot_c + 1 == NS) ? 0 : slot_c + 1;
-    }
-    // ---- epilogue: fp32 slab = the ring slot consumed last (the other two hold the next tile's first stages) ----
-    const int last = (slot_c == 0) ? NS - 1 : slot_c - 1;
-    p8_barrier();                       // every wave's MFMAs have consumed their fragments of that slot
-    if (p.ablate != 1) p4_drain<EPI>(p, acc, lds0 + (uint32_t)(last * STAGE), m0, n0, wm, wn, tid, seed);
-    // one full drain per output tile, where the compiler can see it (otherwise hipcc protects the registers of the epilogue's
-    // pending loads / stores with an `s_waitcnt vmcnt(0)` inside the K loop); the other workgroup of the CU runs meanwhile
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    p8_barrier();                       // the slab slot is free again before produce() targets it
-  }
-}
-
-static int g_p4_mode = -1;      // VLB_GEMM_P4: 0 off | 1 auto | 2 force wherever it applies
-
-template <int EPI>
-int p4_launch(GemmParams& p, hipStream_t stream) {
-  constexpr int smem = 3 * (256 + 128) * 64;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_p4_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) {
-      vlb_set_error("gemm_p4: cannot reserve %d bytes of LDS: %s", smem, hipGetErrorString(e));
-      return VLB_ERR_HIP;
-    }
-    attr_set = true;
-  }
-  p.ntm = vlb_cdiv(p.M, 256);
-  p.ntn = vlb_cdiv(p.N, 128);
-  p.tile_group = 2;
-  int gx = p.ntm * p.ntn;
-  if (gx > 512) gx = 512;           // two persistent workgroups per CU (a multiple of 8: work item w and block b share an XCD)
-  hipLaunchKernelGGL((gemm_nt_p4_kernel<EPI>), dim3(gx), dim3(256), smem, stream, p);
-  VLB_CHECK_LAUNCH("vlb_gemm_nt_bf16(p4)");
-  return 1;
-}
-
-int p4_launch_epi(GemmParams& p, int epi, hipStream_t stream) {
-  switch (epi) {
-    case 0: return p4_launch<0>(p, stream);
-    case 1: return p4_launch<1>(p, stream);
-    case 2: return p4_launch<2>(p, stream);
-    case 3: return p4_launch<3>(p, stream);
-    case 4: return p4_launch<4>(p, stream);
-    case 5: return p4_launch<5>(p, stream);
-    case 6: return p4_launch<6>(p, stream);
-    default: return p4_launch<7>(p, stream);
-  }
-}
-
 static int g_p8_wgs = 256;
 
 template <int FMH, int EPI, bool KEEPB>
@@ -874,10 +611,6 @@ extern "C" int vlb_gemm_set_option(const char* name, int value) {
     vlb_tn8_set_mode(value);
     return VLB_OK;
   }
-  if (!strcmp(name, "p4_mode")) {
-    g_p4_mode = value;
-    return VLB_OK;
-  }
   if (!strcmp(name, "nt_ring")) {
     vlb_nt_set_ring(value);
     return VLB_OK;
@@ -921,12 +654,6 @@ int vlb_gemm_p8_try(GemmParams& p, hipStream_t stream) {
   if (p.bias && ((uintptr_t)p.bias & 15)) return 0;
   if (p.res_stats && (((uintptr_t)p.res_gamma & 15) || ((uintptr_t)p.res_beta & 15) || ((uintptr_t)p.res_stats & 7))) return 0;
   if ((long)p.M * p.lda * 2 >= (1L << 31) || (long)p.N * p.ldb * 2 >= (1L << 31)) return 0;
-  // short-K companion (256 x 128 tiles, two workgroups per CU): p4_mode 2 forces it wherever the large-tile kernels apply
-  if (g_p4_mode < 0) g_p4_mode = env_int("VLB_GEMM_P4", 1);
-  if (g_p4_mode == 2) {
-    p.ablate = g_opt[5];
-    return p4_launch_epi(p, epi, stream);
-  }
   // tile height: whole rounds of 256 resident workgroups, time per round ~ tile area
   const long t4 = (long)vlb_cdiv(p.M, 256) * vlb_cdiv(p.N, 256), t5 = (long)vlb_cdiv(p.M, 320) * vlb_cdiv(p.N, 256);
   // too few tiles for one workgroup per CU: the 128x128 kernel fills the chip better -- except for a long K loop, where the large
