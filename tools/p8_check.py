@@ -98,7 +98,7 @@ def check():
               (16384, 30522, 768)]
     bad = 0
     for M, N, K in shapes:
-        for mode in (4, 5):
+        for mode in (3, 4, 5):
             for epi in range(8):
                 if N > 20000 and epi not in (0,):
                     continue
@@ -171,7 +171,7 @@ def bench(batch):
               ("ffn2 fwd", M, 768, 3072, "dropres"), ("out dgrad", M, 768, 768, "plain"), ("qkv dgrad", M, 768, 2304, "res"),
               ("ffn1 dgrad", M, 768, 3072, "res"), ("ffn2 dgrad", M, 3072, 768, "mulaux"), ("decoder fwd", BT, 30522, 768, "bias"),
               ("square 4096", 4096, 4096, 4096, "plain"), ("square 8192", 8192, 8192, 8192, "plain")]
-    variants = [("128x128", dict(p8_mode=0)), ("p8 256", dict(p8_mode=4, p8_keepb=1, p8_group=2, p8_min_tiles=1)),
+    variants = [("128x128", dict(p8_mode=0)), ("p8 192", dict(p8_mode=3, p8_group=2, p8_min_tiles=1)), ("p8 256", dict(p8_mode=4, p8_keepb=1, p8_group=2, p8_min_tiles=1)),
                 ("p8 320", dict(p8_mode=5, p8_group=2, p8_min_tiles=1)), ("p8 model", dict(p8_mode=1, p8_keepb=1, p8_group=2, p8_min_tiles=160))]
     print("%-14s %7s %6s %6s | " % ("gemm", "M", "N", "K") + " | ".join("%-13s" % v[0] for v in variants))
     tot = [0.0] * len(variants)

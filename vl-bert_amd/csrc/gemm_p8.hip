@@ -299,7 +299,7 @@ __device__ __forceinline__ void p8_drain(const GemmParams& p, f32x4 (&acc)[2 * F
   });
 }
 
-// FMH: 16-row accumulator fragments per wave per tile half (4 -> 256-row tiles, 5 -> 320-row tiles)
+// FMH: 16-row accumulator fragments per wave per tile half (3 -> 192-row tiles, 4 -> 256-row tiles, 5 -> 320-row tiles)
 // KEEPB: keep the B0 fragments in registers for the 4th quadrant (16 more VGPRs) instead of re-reading them
 template <int FMH, int EPI, bool KEEPB>
 __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(const GemmParams p) {
@@ -309,8 +309,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(const GemmParams p) 
   constexpr int OFF_A0 = 0, OFF_A1 = AHB, OFF_B0 = 2 * AHB, OFF_B1 = 2 * AHB + BHB;
   constexpr int BUF = 2 * AHB + 2 * BHB;       // one K tile: 64 KiB (FMH 4) / 72 KiB (FMH 5)
   constexpr int STG = 2 * BUF;                 // epilogue staging slab
-  constexpr int SR = (163840 - STG) / 1024;    // its rows of 256 fp32: 32 / 16
-  constexpr int NLA = (AH * 8 + 511) / 512;    // LDS-DMA instructions per thread per A half-image: 2 / 3 (third: waves 0-3)
+  constexpr int SR = (163840 - STG) / 1024 >= 32 ? 32 : (163840 - STG) / 1024;    // its rows of 256 fp32: 32 / 16
+  constexpr int NLA = (AH * 8 + 511) / 512;    // LDS-DMA instructions per thread per A half-image: 2 / 3 (the last one: waves 0-3 only)
+  // loads of the NEXT K tile that may still be in flight when the current one is retired: its A0 half-image + one B half-image,
+  // counted for the waves that issue the fewest (the waves with one more in flight merely wait for their oldest a little early)
+  constexpr int VM_AHEAD = (AH * 8) / 512 + 2;
   static_assert(SR == 32 || SR == 16, "staging slab");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -402,7 +405,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(const GemmParams p) 
     p8_lds_read<O + 0 * 2048>(af[0][0], v0); p8_lds_read<O + 0 * 2048>(af[0][1], v1);
     p8_lds_read<O + 1 * 2048>(af[1][0], v0); p8_lds_read<O + 1 * 2048>(af[1][1], v1);
     p8_lds_read<O + 2 * 2048>(af[2][0], v0); p8_lds_read<O + 2 * 2048>(af[2][1], v1);
-    p8_lds_read<O + 3 * 2048>(af[3][0], v0); p8_lds_read<O + 3 * 2048>(af[3][1], v1);
+    if constexpr (FMH >= 4) {
+      p8_lds_read<O + 3 * 2048>(af[3][0], v0); p8_lds_read<O + 3 * 2048>(af[3][1], v1);
+    }
     if constexpr (FMH == 5) {
       p8_lds_read<O + 4 * 2048>(af[4][0], v0); p8_lds_read<O + 4 * 2048>(af[4][1], v1);
     }
@@ -417,7 +422,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(const GemmParams p) 
   // release the fragments of this phase to the MFMAs (every asm read above is retired), then the quadrant's 16 (20) MFMAs
   auto compute = [&](auto ha_c, auto hb_c, bf16x8 (&bq)[2][2]) {
     constexpr int HA = decltype(ha_c)::value, HB = decltype(hb_c)::value;
-    if constexpr (FMH == 4) {
+    if constexpr (FMH == 3) {
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[1][0]), "+v"(af[1][1]), "+v"(af[2][0]), "+v"(af[2][1]), "+v"(bq[0][0]),
+                     "+v"(bq[0][1]), "+v"(bq[1][0]), "+v"(bq[1][1]));
+    } else if constexpr (FMH == 4) {
       asm volatile("s_waitcnt lgkmcnt(0)"
                    : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[1][0]), "+v"(af[1][1]), "+v"(af[2][0]), "+v"(af[2][1]), "+v"(af[3][0]),
                      "+v"(af[3][1]), "+v"(bq[0][0]), "+v"(bq[0][1]), "+v"(bq[1][0]), "+v"(bq[1][1]));
@@ -445,7 +454,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(const GemmParams p) 
   stage(W0{}, I0{}); stage(W1{}, I0{}); stage(W2{}, I0{}); stage(W3{}, I0{});
   advance();
   stage(W0{}, I1{}); stage(W1{}, I1{});
-  if (live) __builtin_amdgcn_s_waitcnt(0x0F70 | 4);
+  if (live) __builtin_amdgcn_s_waitcnt(0x0F70 | VM_AHEAD);
   else __builtin_amdgcn_s_waitcnt(0x0F70);
   p8_barrier();
   if (wm == 1) p8_barrier();       // the wm = 1 waves run one segment behind
@@ -484,7 +493,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(const GemmParams p) 
       // phase 4: (B0 again) -> (1,0); K tile g+1 retired
       if constexpr (!KEEPB) read_b(I0{}, I0{}, bfr);
       stage(W1{}, I0{});
-      if (tiles_issued >= g + 3) __builtin_amdgcn_s_waitcnt(0x0F70 | 4);
+      if (tiles_issued >= g + 3) __builtin_amdgcn_s_waitcnt(0x0F70 | VM_AHEAD);
       else __builtin_amdgcn_s_waitcnt(0x0F70);
       p8_barrier();
       if constexpr (KEEPB) compute(I1{}, I0{}, bkeep); else compute(I1{}, I0{}, bfr);
@@ -510,7 +519,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(const GemmParams p) 
       p8_barrier();
       if constexpr (!KEEPB) read_b(I1{}, I0{}, bfr);
       stage(W1{}, I1{});
-      if (tiles_issued >= g + 4) __builtin_amdgcn_s_waitcnt(0x0F70 | 4);
+      if (tiles_issued >= g + 4) __builtin_amdgcn_s_waitcnt(0x0F70 | VM_AHEAD);
       else __builtin_amdgcn_s_waitcnt(0x0F70);
       p8_barrier();
       if constexpr (KEEPB) compute(I1{}, I0{}, bkeep); else compute(I1{}, I0{}, bfr);
@@ -526,7 +535,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(const GemmParams p) 
     } else if (w + (int)gridDim.x >= nt) {
       // last tile of this workgroup: nothing is in flight into the operand ring any more (the producer stopped at this tile and
       // every K tile it issued has been consumed) -> drain through a 128-row slab laid over the ring
-      p8_drain<FMH, EPI, 4>(p, acc, lds0, m0, n0, wm, wn, lane, tid, seed);
+      p8_drain<FMH, EPI, (STG >= 131072 ? 4 : 3)>(p, acc, lds0, m0, n0, wm, wn, lane, tid, seed);      // 128 (96) slab rows of 1 KiB
     } else {
       p8_drain<FMH, EPI, (SR == 32 ? 1 : 0)>(p, acc, lds0 + STG, m0, n0, wm, wn, lane, tid, seed);
     }
@@ -588,12 +597,12 @@ inline bool aligned16(const void* q) { return ((uintptr_t)q & 15) == 0; }
 }  // namespace
 
 // tuning knobs (environment defaults, run-time override through vlb_gemm_set_option for A/B measurements inside one process)
-// p8_mode: 0 off | 1 cost model (default) | 4 / 5: force the 256- / 320-row tile wherever the kernel applies
+// p8_mode: 0 off | 1 cost model (default) | 3 / 4 / 5: force the 192- / 256- / 320-row tile wherever the kernel applies
 // p8_wgs: persistent workgroups per launch (<= 256 = one per CU).  Fewer leave CUs to a kernel running on another stream (the
 // weight-gradient GEMMs of the side stream): an MFMA-bound kernel then fills the HBM-bound epilogue bursts of this one.
 // p8_ablate (tools/p8_check.py ablate; results are WRONG when != 0): 1 no epilogue | 2 epilogue without its global stores
-static int g_opt[6] = {-1, -1, -1, -1, -1, -1};
-static const char* const g_opt_name[6] = {"p8_mode", "p8_keepb", "p8_group", "p8_min_tiles", "p8_wgs", "p8_ablate"};
+static int g_opt[7] = {-1, -1, -1, -1, -1, -1, -1};
+static const char* const g_opt_name[7] = {"p8_mode", "p8_keepb", "p8_group", "p8_min_tiles", "p8_wgs", "p8_ablate", "p8_tile192"};
 static void p8_options_init() {
   if (g_opt[0] >= 0) return;
   g_opt[0] = env_int("VLB_GEMM_P8", 1);
@@ -602,6 +611,7 @@ static void p8_options_init() {
   g_opt[3] = env_int("VLB_GEMM_P8_MIN_TILES", 160);
   g_opt[4] = env_int("VLB_GEMM_P8_WGS", 256);
   g_opt[5] = 0;
+  g_opt[6] = env_int("VLB_GEMM_P8_192", 1);
 }
 
 extern "C" int vlb_gemm_set_option(const char* name, int value) {
@@ -623,7 +633,7 @@ extern "C" int vlb_gemm_set_option(const char* name, int value) {
     vlb_tn8_set_wgs(value);
     return VLB_OK;
   }
-  for (int i = 0; i < 6; ++i)
+  for (int i = 0; i < 7; ++i)
     if (!strcmp(name, g_opt_name[i])) {
       g_opt[i] = value;
       return VLB_OK;
@@ -654,17 +664,25 @@ int vlb_gemm_p8_try(GemmParams& p, hipStream_t stream) {
   if (p.bias && ((uintptr_t)p.bias & 15)) return 0;
   if (p.res_stats && (((uintptr_t)p.res_gamma & 15) || ((uintptr_t)p.res_beta & 15) || ((uintptr_t)p.res_stats & 7))) return 0;
   if ((long)p.M * p.lda * 2 >= (1L << 31) || (long)p.N * p.ldb * 2 >= (1L << 31)) return 0;
-  // tile height: whole rounds of 256 resident workgroups, time per round ~ tile area
-  const long t4 = (long)vlb_cdiv(p.M, 256) * vlb_cdiv(p.N, 256), t5 = (long)vlb_cdiv(p.M, 320) * vlb_cdiv(p.N, 256);
-  // too few tiles for one workgroup per CU: the 128x128 kernel fills the chip better -- except for a long K loop, where the large
-  // tile's main loop still wins with 60 % of the CUs busy (M = 12928, N = 768: 153 tiles; K = 3072: 84.7 -> 78.2 us, K = 2304:
-  // 64.1 -> 58.7 us measured; at K = 768 the 128x128 kernel is faster: 24.9 vs 27.8 us)
-  if (t4 < min_tiles && !(t4 >= 128 && p.K >= 1536)) return 0;
-  const double c4 = (double)((t4 + 255) / 256) * 256.0, c5 = (double)((t5 + 255) / 256) * 320.0;
-  int fmh = (c5 < 0.97 * c4) ? 5 : 4;
-  if (mode == 4 || mode == 5) fmh = mode;
+  // tile height: whole rounds of 256 resident workgroups, time per round ~ tile area (the 192-row tile pays ~15 % in the main loop -- 8192^3: 1006 vs 1216 TFLOP/s --:
+  // 12 instead of 16 MFMAs per phase behind the same barriers).  A height qualifies with enough tiles for one workgroup per CU --
+  // below that the 128x128 kernel fills the chip better -- except for a long K loop, where the 256-row tile's main loop still wins
+  // with 60 % of the CUs busy (M = 12928, N = 768: 153 tiles; K = 3072: 84.7 -> 78.2 us, K = 2304: 64.1 -> 58.7 us measured; at
+  // K = 768 the 128x128 kernel is faster: 24.9 vs 27.8 us)
+  const long nn = vlb_cdiv(p.N, 256);
+  const long t3 = (long)vlb_cdiv(p.M, 192) * nn, t4 = (long)vlb_cdiv(p.M, 256) * nn, t5 = (long)vlb_cdiv(p.M, 320) * nn;
+  const double c3 = (double)((t3 + 255) / 256) * 192.0 * 1.15, c4 = (double)((t4 + 255) / 256) * 256.0, c5 = (double)((t5 + 255) / 256) * 320.0;
+  const bool ok3 = t3 >= min_tiles, ok4 = t4 >= min_tiles || (t4 >= 128 && p.K >= 1536), ok5 = t5 >= min_tiles;
+  int fmh = 0;
+  double best = 1e30;
+  if (ok4) { fmh = 4; best = c4; }
+  if (ok5 && c5 < 0.97 * best) { fmh = 5; best = c5; }
+  if (ok3 && g_opt[6] && c3 < 0.97 * best) { fmh = 3; best = c3; }
+  if (mode == 3 || mode == 4 || mode == 5) fmh = mode;
+  if (!fmh) return 0;
   const int g = group < 1 ? 1 : group;
   p.ablate = g_opt[5];
+  if (fmh == 3) return p8_launch_epi<3, true>(p, epi, g, stream);
   if (fmh == 5) return p8_launch_epi<5, false>(p, epi, g, stream);
   return keepb ? p8_launch_epi<4, true>(p, epi, g, stream) : p8_launch_epi<4, false>(p, epi, g, stream);
 }
