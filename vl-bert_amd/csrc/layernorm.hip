@@ -14,7 +14,7 @@
 // The dgamma/dbeta flush of 768 workgroups x 2H fp32 atomics (~1.2 M) costs as much as the whole HBM-bound row pass
 // (atomic throughput, ~40 G/s).  With a workspace every workgroup stores its partial vector with plain 16-B stores
 // and a small second kernel column-sums the LN_MAX_BLOCKS x 2H slab (4.7 MB at H=768) into the gradients.
-#define LN_MAX_BLOCKS 768   // 3 workgroups per CU
+#define LN_MAX_BLOCKS 1024  // 4 workgroups per CU (the 4-column backward runs 4 waves per SIMD)
 
 // NIT = ceil(H / 256): per-lane register footprint follows the actual row width (H=768 -> 3)
 template <int NIT>
@@ -251,9 +251,147 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
   }
 }
 
+// The same backward with 4-column (8-B) lane chunks -- the forward's mapping: a lane owns columns (lane + 64 i) * 4 .. +3.
+// H = 768 is then three FULL passes (the 8-column form above runs one full and one half-wave pass and keeps 16 values per
+// array per lane: 192 VGPRs, 2 waves per SIMD -- too few bytes in flight for a kernel that only streams: 2.8 TB/s measured);
+// here the footprint is 12 values per array, two rows in flight, <= 128 VGPRs -> 4 waves per SIMD.
+// Partial dgamma / dbeta vectors are lane-major with LW = NIT * 256: element (i, k) of lane l at (i*4 + k)*64 + l.
+template <int NIT, int RIF>      // RIF rows in flight per wave iteration (2 while the registers allow it)
+__global__ __launch_bounds__(256) void layernorm_bwd4_kernel(const void* __restrict__ dy_, long lddy, int dy_f32, const bf16_t* __restrict__ x,
+                                                             long ldx, const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                             bf16_t* __restrict__ dx, long lddx, bf16_t* __restrict__ dx_drop, long lddd,
+                                                             uint32_t drop_thr, float drop_scale, const uint32_t* __restrict__ seedp,
+                                                             uint32_t tag, float* __restrict__ dx_acc, long ldacc, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta, float* __restrict__ ws, int rows, int H, int x_f16) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][2][LW]
+  constexpr int LW = NIT * 256;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t seed = (drop_thr && seedp) ? *seedp : 0u;
+  const bool want_gb = (dgamma != nullptr) || (dbeta != nullptr);
+  float gsum[NIT][4], bsum[NIT][4], gam[NIT][4];
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < H) g0 = *(const float4*)(gamma + c);
+    gam[i][0] = g0.x; gam[i][1] = g0.y; gam[i][2] = g0.z; gam[i][3] = g0.w;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) gsum[i][k] = bsum[i][k] = 0.f;
+  }
+  const int nw = blockDim.x >> 6, step = gridDim.x * nw;
+  for (int row0 = blockIdx.x * nw + wave; row0 < rows; row0 += RIF * step) {
+    Row4<NIT> xr[RIF], dyr[RIF];
+    float mean[RIF], rstd[RIF];
+    bool has[RIF];
+#pragma unroll
+    for (int t = 0; t < RIF; ++t) {
+      has[t] = row0 + t * step < rows;
+      const int row = has[t] ? row0 + t * step : row0;
+      load_row_bf16(x + (long)row * ldx, H, lane, xr[t], x_f16 != 0);
+      if (dy_f32) {
+        const float* d = (const float*)dy_ + (long)row * lddy;
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+          const int c = (lane + 64 * i) * 4;
+          float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (c < H) v0 = *(const float4*)(d + c);
+          dyr[t].v[i][0] = v0.x; dyr[t].v[i][1] = v0.y; dyr[t].v[i][2] = v0.z; dyr[t].v[i][3] = v0.w;
+        }
+      } else {
+        load_row_bf16((const bf16_t*)dy_ + (long)row * lddy, H, lane, dyr[t]);
+      }
+      const float2 ms = *(const float2*)(stats + 2 * (long)row);
+      mean[t] = ms.x;
+      rstd[t] = ms.y;
+    }
+    float s1[RIF], s2[RIF];
+#pragma unroll
+    for (int t = 0; t < RIF; ++t) {
+      s1[t] = s2[t] = 0.f;
+      const float live = has[t] ? 1.f : 0.f;            // the duplicate of row0 must not count
+#pragma unroll
+      for (int i = 0; i < NIT; ++i) {
+        const bool in = (lane + 64 * i) * 4 < H;         // out-of-range lanes hold zeros for dy: only xhat needs masking
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float xh = in ? (xr[t].v[i][k] - mean[t]) * rstd[t] : 0.f;
+          const float dyv = dyr[t].v[i][k] * live;
+          gsum[i][k] += dyv * xh;
+          bsum[i][k] += dyv;
+          const float gv = dyv * gam[i][k];
+          s1[t] += gv;
+          s2[t] += gv * xh;
+          xr[t].v[i][k] = xh;    // reuse storage: xhat
+          dyr[t].v[i][k] = gv;   // reuse storage: g
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {     // independent butterflies interleaved
+#pragma unroll
+      for (int t = 0; t < RIF; ++t) { s1[t] += __shfl_xor(s1[t], o, 64); s2[t] += __shfl_xor(s2[t], o, 64); }
+    }
+#pragma unroll
+    for (int t = 0; t < RIF; ++t) {
+      if (!has[t]) continue;
+      const int row = row0 + t * step;
+      const float m1 = s1[t] / (float)H, m2 = s2[t] / (float)H;
+#pragma unroll
+      for (int i = 0; i < NIT; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < H) {
+          float o[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) o[k] = rstd[t] * (dyr[t].v[i][k] - m1 - xr[t].v[i][k] * m2);
+          if (dx) *(uint2*)(dx + (long)row * lddx + c) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+          if (dx_drop) {
+            float d[4] = {o[0], o[1], o[2], o[3]};
+            if (drop_thr) {
+              const uint32_t idx = (uint32_t)row * (uint32_t)H + (uint32_t)c;      // H % 4 == 0 -> idx even
+              const uint32_t h0 = vlb_rng_pair(seed, tag, idx >> 1), h1 = vlb_rng_pair(seed, tag, (idx >> 1) + 1);
+              d[0] = ((h0 & 0xffffu) >= drop_thr) ? o[0] * drop_scale : 0.f;
+              d[1] = ((h0 >> 16) >= drop_thr) ? o[1] * drop_scale : 0.f;
+              d[2] = ((h1 & 0xffffu) >= drop_thr) ? o[2] * drop_scale : 0.f;
+              d[3] = ((h1 >> 16) >= drop_thr) ? o[3] * drop_scale : 0.f;
+            }
+            *(uint2*)(dx_drop + (long)row * lddd + c) = make_uint2(pack2bf(d[0], d[1]), pack2bf(d[2], d[3]));
+          }
+          if (dx_acc) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) atomicAdd(dx_acc + (long)row * ldacc + c + k, o[k]);
+          }
+        }
+      }
+    }
+  }
+  if (!want_gb) return;
+  float* mine = red + wave * 2 * LW;
+#pragma unroll
+  for (int i = 0; i < NIT; ++i)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      mine[(i * 4 + k) * 64 + lane] = gsum[i][k];
+      mine[LW + (i * 4 + k) * 64 + lane] = bsum[i][k];
+    }
+  __syncthreads();
+  for (int q = threadIdx.x; q < 2 * LW; q += 256) {
+    const float v = (red[q] + red[2 * LW + q]) + (red[4 * LW + q] + red[6 * LW + q]);
+    if (ws) ws[(long)blockIdx.x * 2 * LW + q] = v;
+    else red[q] = v;
+  }
+  if (ws) return;
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * H; c += 256) {    // no workspace: coalesced atomics in natural column order
+    const int which = c >= H, col = c - which * H, chunk = col >> 2;
+    const float v = red[which * LW + (((chunk >> 6) * 4 + (col & 3)) << 6) + (chunk & 63)];
+    float* dst = which ? dbeta : dgamma;
+    if (dst) atomicAdd(dst + col, v);
+  }
+}
+
 // dgamma/dbeta += column sums of the `nslab` lane-major partial vectors [2][LW]: grid (2 LW / 64, 8)
 __global__ __launch_bounds__(256) void ln_param_finalize_kernel(const float* __restrict__ ws, int nslab, int LW, float* __restrict__ dgamma,
-                                                                float* __restrict__ dbeta, int H) {
+                                                                float* __restrict__ dbeta, int H, int cpl_log2) {
   __shared__ float part[4][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int q = blockIdx.x * 64 + tx;
@@ -263,7 +401,8 @@ __global__ __launch_bounds__(256) void ln_param_finalize_kernel(const float* __r
   __syncthreads();
   if (ty == 0) {
     s = (part[0][tx] + part[1][tx]) + (part[2][tx] + part[3][tx]);
-    const int r = q % LW, col = ((r & 63) + 64 * (r >> 9)) * 8 + ((r >> 6) & 7);
+    const int r = q % LW, cpl = 1 << cpl_log2;      // columns per lane chunk: 8 (layernorm_bwd_kernel) or 4 (layernorm_bwd4_kernel)
+    const int col = ((r & 63) + 64 * (r >> (6 + cpl_log2))) * cpl + ((r >> 6) & (cpl - 1));
     if (col < H) {
       if (q < LW) { if (dgamma) atomicAdd(dgamma + col, s); }
       else if (dbeta) atomicAdd(dbeta + col, s);
@@ -286,6 +425,8 @@ extern "C" int vlb_layernorm_fwd(const void* x, long ldx, const float* gamma, co
   return VLB_OK;
 }
 
+static int g_ln_bwd4 = -1;      // VLB_LN_BWD4: 1 (default) the 4-column kernel; 0 the 8-column kernel
+
 extern "C" int vlb_layernorm_bwd(const void* dy, long lddy, int dy_f32, const void* x, long ldx, const float* stats,
                                  const float* gamma, void* dx, long lddx, void* dx_drop, long lddd, float drop_p,
                                  const uint32_t* seed, uint32_t tag, float* dx_acc, long ldacc, float* dgamma, float* dbeta,
@@ -296,22 +437,45 @@ extern "C" int vlb_layernorm_bwd(const void* dy, long lddy, int dy_f32, const vo
                 "vlb_layernorm_bwd: row strides must be multiples of 8");
   VLB_CHECK_ARG(!(drop_p > 0.f) || seed, "vlb_layernorm_bwd: dropout needs a device seed pointer");
   VLB_CHECK_ARG((long)rows * H < (1L << 32) || !(drop_p > 0.f), "vlb_layernorm_bwd: dropout index overflow");
-  int blocks = vlb_cdiv(rows, 8);      // a wave handles two rows per iteration
+  if (g_ln_bwd4 < 0) {
+    const char* v = getenv("VLB_LN_BWD4");
+    g_ln_bwd4 = v ? atoi(v) : 1;
+  }
+  int blocks = vlb_cdiv(rows, 8);      // 4 waves per workgroup, one or two rows per wave iteration
   if (blocks < 1) blocks = 1;
   if (blocks > LN_MAX_BLOCKS) blocks = LN_MAX_BLOCKS;
   float* ws = (workspace && (dgamma || dbeta) && blocks > 32) ? workspace : nullptr;
   const uint32_t thr = vlb_drop_thr(drop_p);
+  int LW, cpl_log2;
+  if (g_ln_bwd4) {
+    const int nit = vlb_cdiv(H, 256);
+    const int nitc = nit <= 4 ? nit : 8;
+    LW = nitc * 256;
+    cpl_log2 = 2;
+#define LN_BWD4(NIT, RIF)                                                                                                         \
+  hipLaunchKernelGGL((layernorm_bwd4_kernel<NIT, RIF>), dim3(blocks), dim3(256), 8 * NIT * 256 * sizeof(float), stream, dy, lddy,   \
+                     dy_f32, (const bf16_t*)x, ldx, stats, gamma, (bf16_t*)dx, lddx, (bf16_t*)dx_drop, lddd, thr,                   \
+                     vlb_drop_scale(thr), seed, tag, dx_acc, ldacc, dgamma, dbeta, ws, rows, H, x_f16)
+    // rows in flight per wave: 2 while the kernel stays near 128 VGPRs (4 waves per SIMD); g_ln_bwd4 == 2 forces 2 for H = 768 / 1024
+    if (nit <= 1) LN_BWD4(1, 2); else if (nit == 2) LN_BWD4(2, 2);
+    else if (nit == 3) { if (g_ln_bwd4 == 2) LN_BWD4(3, 2); else LN_BWD4(3, 1); }
+    else if (nit == 4) { if (g_ln_bwd4 == 2) LN_BWD4(4, 2); else LN_BWD4(4, 1); }
+    else LN_BWD4(8, 1);
+#undef LN_BWD4
+  } else {
 #define LN_BWD(NP)                                                                                                             \
   hipLaunchKernelGGL(layernorm_bwd_kernel<NP>, dim3(blocks), dim3(256), 8 * NP * 512 * sizeof(float), stream, dy, lddy, dy_f32,  \
                      (const bf16_t*)x, ldx, stats, gamma, (bf16_t*)dx, lddx, (bf16_t*)dx_drop, lddd, thr, vlb_drop_scale(thr),  \
                      seed, tag, dx_acc, ldacc, dgamma, dbeta, ws, rows, H, x_f16)
-  const int np = vlb_cdiv(H, 512);
-  if (np <= 1) LN_BWD(1); else if (np == 2) LN_BWD(2); else if (np == 3) LN_BWD(3); else LN_BWD(4);
+    const int np = vlb_cdiv(H, 512);
+    if (np <= 1) LN_BWD(1); else if (np == 2) LN_BWD(2); else if (np == 3) LN_BWD(3); else LN_BWD(4);
 #undef LN_BWD
+    LW = (np <= 3 ? np : 4) * 512;
+    cpl_log2 = 3;
+  }
   VLB_CHECK_LAUNCH("vlb_layernorm_bwd");
   if (ws) {
-    const int LW = (np <= 3 ? np : 4) * 512;
-    hipLaunchKernelGGL(ln_param_finalize_kernel, dim3(2 * LW / 64, 8), dim3(256), 0, stream, ws, blocks, LW, dgamma, dbeta, H);
+    hipLaunchKernelGGL(ln_param_finalize_kernel, dim3(2 * LW / 64, 8), dim3(256), 0, stream, ws, blocks, LW, dgamma, dbeta, H, cpl_log2);
     VLB_CHECK_LAUNCH("vlb_layernorm_bwd(finalize)");
   }
   return VLB_OK;
@@ -319,6 +483,7 @@ extern "C" int vlb_layernorm_bwd(const void* dy, long lddy, int dy_f32, const vo
 
 extern "C" long vlb_layernorm_bwd_workspace_floats(int H) {
   if (H <= 0) return 0;
-  const int np = vlb_cdiv(H, 512);
-  return (long)LN_MAX_BLOCKS * 2 * (np <= 3 ? np : 4) * 512;
+  const int np = vlb_cdiv(H, 512), nit = vlb_cdiv(H, 256);
+  const long lw8 = (np <= 3 ? np : 4) * 512, lw4 = (nit <= 4 ? nit : 8) * 256;      // either backward kernel may run
+  return (long)LN_MAX_BLOCKS * 2 * (lw8 > lw4 ? lw8 : lw4);
 }
