@@ -114,6 +114,18 @@ int vlb_layernorm_bwd(const void* dy, long lddy, int dy_f32, const void* x, long
                       const uint32_t* seed, uint32_t tag, float* dx_acc, long ldacc, float* dgamma, float* dbeta,
                       float* workspace, int rows, int H, int x_f16, vlb_stream_t stream);
 long vlb_layernorm_bwd_workspace_floats(int H);
+/* vlb_layernorm_bwd with the dgamma / dbeta finalize DEFERRED: the per-workgroup partial vectors stay in `workspace` (required, and
+ * not to be reused until consumed); vlb_ln_param_finalize_batch adds the column sums of up to 32 such workspaces (entry i: ws[i] with
+ * nslab[i] = vlb_layernorm_bwd_slabs(rows of that call) > 0 partial vectors) into dgamma[i] / dbeta[i] in ONE launch.  A training
+ * step runs 26 LayerNorm backwards whose parameter gradients are only read by the optimizer / a bucket's all-reduce.
+ * vlb_layernorm_bwd_slabs == 0: the call was small enough to add its sums directly (nothing to finalize). */
+int vlb_layernorm_bwd_deferred(const void* dy, long lddy, int dy_f32, const void* x, long ldx, const float* stats,
+                               const float* gamma, void* dx, long lddx, void* dx_drop, long lddd, float drop_p,
+                               const uint32_t* seed, uint32_t tag, float* dx_acc, long ldacc, float* dgamma, float* dbeta,
+                               float* workspace, int rows, int H, int x_f16, vlb_stream_t stream);
+int vlb_layernorm_bwd_slabs(int rows);
+int vlb_ln_param_finalize_batch(int n, const float* const* ws, const int* nslab, float* const* dgamma, float* const* dbeta, int H,
+                                vlb_stream_t stream);
 
 /* ---- BertSelfAttention core (modeling.py:300-316) --------------------------------------------
  * qkv [B*S, 3H] bf16 (q | k | v, head h at columns h*64), mask [B,S] fp32 (1 attend / 0 -> -10000),

@@ -896,3 +896,47 @@ def test_error_path_raises(ops):
         ops.gemm_nt(A[:, :96], A[:, :96], C, K=96)
     with pytest.raises(RuntimeError, match="no CPU path"):
         ops.cast_f32_bf16(torch.zeros(4), torch.zeros(4, dtype=torch.bfloat16))
+
+
+def test_layernorm_bwd_deferred_parameter_gradients_batched(ops):
+    """vlb_layernorm_bwd_deferred + vlb_ln_param_finalize_batch: three LayerNorm backwards leave their partial dgamma / dbeta vectors in
+    workspaces of their own and ONE launch adds them into the gradients -- equal (up to fp32 summation order) to the per-call finalize
+    of vlb_layernorm_bwd; dx is bit-identical; a small call (<= 32 workgroups) reports 0 partial vectors and adds its sums directly."""
+    H = 768
+    g = torch.Generator().manual_seed(7)
+    entries, ref = [], []
+    for k, rows in enumerate((1000, 4096, 700)):
+        x = (torch.randn(rows, H, generator=g) * 1.5).half().to(dev())
+        dy = to_gpu_bf16(torch.randn(rows, H, generator=g))
+        gamma = torch.randn(H, generator=g).to(dev())
+        y = torch.empty(rows, H, dtype=torch.bfloat16, device=dev())
+        stats = torch.empty(rows, 2, device=dev())
+        ops.layernorm_fwd(x, gamma, torch.zeros(H, device=dev()), y, stats)
+        dx0, dx1 = torch.empty_like(dy), torch.empty_like(dy)
+        dg0, db0 = torch.full((H,), 0.5, device=dev()), torch.full((H,), -0.25, device=dev())
+        dg1, db1 = dg0.clone(), db0.clone()
+        ws0 = torch.empty(ops.ln_bwd_workspace_floats(H), device=dev())
+        ws1 = torch.empty(ops.ln_bwd_workspace_floats(H), device=dev())
+        ops.layernorm_bwd(dy, x, stats, gamma, dx=dx0, dgamma=dg0, dbeta=db0, workspace=ws0)
+        slabs = ops.layernorm_bwd(dy, x, stats, gamma, dx=dx1, dgamma=dg1, dbeta=db1, workspace=ws1, defer=True)
+        assert torch.equal(dx0, dx1)
+        assert slabs == (rows + 7) // 8
+        entries.append((ws1, slabs, dg1, db1))
+        ref.append((dg0, db0))
+    ops.ln_param_finalize_batch(entries, H)
+    torch.cuda.synchronize()
+    for (ws, slabs, dg1, db1), (dg0, db0) in zip(entries, ref):
+        assert float((dg1 - dg0).abs().max()) < 1e-4 * max(1.0, float(dg0.abs().max()))
+        assert float((db1 - db0).abs().max()) < 1e-4 * max(1.0, float(db0.abs().max()))
+    # small call: direct atomics, nothing deferred
+    rows = 64
+    x = torch.randn(rows, H, generator=g).half().to(dev())
+    dy = to_gpu_bf16(torch.randn(rows, H, generator=g))
+    gamma = torch.ones(H, device=dev())
+    stats = torch.empty(rows, 2, device=dev())
+    ops.layernorm_fwd(x, gamma, torch.zeros(H, device=dev()), torch.empty(rows, H, dtype=torch.bfloat16, device=dev()), stats)
+    dg, db = torch.zeros(H, device=dev()), torch.zeros(H, device=dev())
+    ws = torch.empty(ops.ln_bwd_workspace_floats(H), device=dev())
+    assert ops.layernorm_bwd(dy, x, stats, gamma, dgamma=dg, dbeta=db, workspace=ws, defer=True) == 0
+    torch.cuda.synchronize()
+    assert float((db - dy.float().sum(0)).abs().max()) < 1e-2

@@ -25,6 +25,8 @@ _SIGS = {
     "vlb_zero_ranges_f32": "pppiis",
     "vlb_layernorm_fwd": "plppplpiifis",
     "vlb_layernorm_bwd": "pliplppplplfpuplpppiiis",
+    "vlb_layernorm_bwd_deferred": "pliplppplplfpuplpppiiis",
+    "vlb_ln_param_finalize_batch": "ippppis",
     "vlb_gemm_nt_bf16_ex": "plplpliiipiplplplpppifpuiis",
     "vlb_attention_fwd": "ppppiiiifpus",
     "vlb_attention_bwd": "ppppppiiiifpus",
@@ -104,6 +106,8 @@ def load():
     lib.vlb_wgrad_workspace_floats.argtypes = [_I, _I, _I]
     lib.vlb_layernorm_bwd_workspace_floats.restype = _L
     lib.vlb_layernorm_bwd_workspace_floats.argtypes = [_I]
+    lib.vlb_layernorm_bwd_slabs.restype = _I
+    lib.vlb_layernorm_bwd_slabs.argtypes = [_I]
     lib.vlb_gemm_set_option.restype = _I
     lib.vlb_gemm_set_option.argtypes = [ctypes.c_char_p, _I]
     for name, sig in _SIGS.items():
@@ -116,7 +120,7 @@ def load():
 
 def exported_names():
     return ["vlb_last_error", "vlb_version", "vlb_device_info", "vlb_wgrad_workspace_floats",
-            "vlb_layernorm_bwd_workspace_floats", "vlb_gemm_set_option"] + sorted(_SIGS)
+            "vlb_layernorm_bwd_workspace_floats", "vlb_layernorm_bwd_slabs", "vlb_gemm_set_option"] + sorted(_SIGS)
 
 
 def gemm_set_option(name, value):

@@ -425,12 +425,31 @@ extern "C" int vlb_layernorm_fwd(const void* x, long ldx, const float* gamma, co
   return VLB_OK;
 }
 
-static int g_ln_bwd4 = -1;      // VLB_LN_BWD4: 1 (default) the 4-column kernel; 0 the 8-column kernel
+static int g_ln_bwd4 = -1;      // VLB_LN_BWD4: 1 (default) the 4-column kernel (2: two rows in flight at H = 768 / 1024); 0 the 8-column kernel
 
-extern "C" int vlb_layernorm_bwd(const void* dy, long lddy, int dy_f32, const void* x, long ldx, const float* stats,
-                                 const float* gamma, void* dx, long lddx, void* dx_drop, long lddd, float drop_p,
-                                 const uint32_t* seed, uint32_t tag, float* dx_acc, long ldacc, float* dgamma, float* dbeta,
-                                 float* workspace, int rows, int H, int x_f16, hipStream_t stream) {
+static int ln_bwd_blocks(int rows) {
+  int blocks = vlb_cdiv(rows, 8);      // 4 waves per workgroup, one or two rows per wave iteration
+  if (blocks < 1) blocks = 1;
+  if (blocks > LN_MAX_BLOCKS) blocks = LN_MAX_BLOCKS;
+  return blocks;
+}
+
+static void ln_lw(int H, int& LW, int& cpl_log2) {
+  if (g_ln_bwd4) {
+    const int nit = vlb_cdiv(H, 256);
+    LW = (nit <= 4 ? nit : 8) * 256;
+    cpl_log2 = 2;
+  } else {
+    const int np = vlb_cdiv(H, 512);
+    LW = (np <= 3 ? np : 4) * 512;
+    cpl_log2 = 3;
+  }
+}
+
+static int ln_bwd_impl(const void* dy, long lddy, int dy_f32, const void* x, long ldx, const float* stats,
+                       const float* gamma, void* dx, long lddx, void* dx_drop, long lddd, float drop_p,
+                       const uint32_t* seed, uint32_t tag, float* dx_acc, long ldacc, float* dgamma, float* dbeta,
+                       float* workspace, int rows, int H, int x_f16, bool finalize, hipStream_t stream) {
   if (rows <= 0) return VLB_OK;
   VLB_CHECK_ARG(H > 0 && (H % 8) == 0 && H <= 2048, "vlb_layernorm_bwd: unsupported H=%d (multiple of 8, <= 2048)", H);
   VLB_CHECK_ARG((lddy % 8) == 0 && (ldx % 8) == 0 && (lddx % 8) == 0 && (lddd % 8) == 0,
@@ -441,17 +460,12 @@ extern "C" int vlb_layernorm_bwd(const void* dy, long lddy, int dy_f32, const vo
     const char* v = getenv("VLB_LN_BWD4");
     g_ln_bwd4 = v ? atoi(v) : 1;
   }
-  int blocks = vlb_cdiv(rows, 8);      // 4 waves per workgroup, one or two rows per wave iteration
-  if (blocks < 1) blocks = 1;
-  if (blocks > LN_MAX_BLOCKS) blocks = LN_MAX_BLOCKS;
+  const int blocks = ln_bwd_blocks(rows);
   float* ws = (workspace && (dgamma || dbeta) && blocks > 32) ? workspace : nullptr;
   const uint32_t thr = vlb_drop_thr(drop_p);
   int LW, cpl_log2;
   if (g_ln_bwd4) {
     const int nit = vlb_cdiv(H, 256);
-    const int nitc = nit <= 4 ? nit : 8;
-    LW = nitc * 256;
-    cpl_log2 = 2;
 #define LN_BWD4(NIT, RIF)                                                                                                         \
   hipLaunchKernelGGL((layernorm_bwd4_kernel<NIT, RIF>), dim3(blocks), dim3(256), 8 * NIT * 256 * sizeof(float), stream, dy, lddy,   \
                      dy_f32, (const bf16_t*)x, ldx, stats, gamma, (bf16_t*)dx, lddx, (bf16_t*)dx_drop, lddd, thr,                   \
@@ -470,14 +484,91 @@ extern "C" int vlb_layernorm_bwd(const void* dy, long lddy, int dy_f32, const vo
     const int np = vlb_cdiv(H, 512);
     if (np <= 1) LN_BWD(1); else if (np == 2) LN_BWD(2); else if (np == 3) LN_BWD(3); else LN_BWD(4);
 #undef LN_BWD
-    LW = (np <= 3 ? np : 4) * 512;
-    cpl_log2 = 3;
   }
+  ln_lw(H, LW, cpl_log2);
   VLB_CHECK_LAUNCH("vlb_layernorm_bwd");
-  if (ws) {
+  if (ws && finalize) {
     hipLaunchKernelGGL(ln_param_finalize_kernel, dim3(2 * LW / 64, 8), dim3(256), 0, stream, ws, blocks, LW, dgamma, dbeta, H, cpl_log2);
     VLB_CHECK_LAUNCH("vlb_layernorm_bwd(finalize)");
   }
+  return VLB_OK;
+}
+
+extern "C" int vlb_layernorm_bwd(const void* dy, long lddy, int dy_f32, const void* x, long ldx, const float* stats,
+                                 const float* gamma, void* dx, long lddx, void* dx_drop, long lddd, float drop_p,
+                                 const uint32_t* seed, uint32_t tag, float* dx_acc, long ldacc, float* dgamma, float* dbeta,
+                                 float* workspace, int rows, int H, int x_f16, hipStream_t stream) {
+  return ln_bwd_impl(dy, lddy, dy_f32, x, ldx, stats, gamma, dx, lddx, dx_drop, lddd, drop_p, seed, tag, dx_acc, ldacc, dgamma, dbeta,
+                     workspace, rows, H, x_f16, true, stream);
+}
+
+// The same with the parameter-gradient finalize DEFERRED: the per-workgroup partial dgamma / dbeta vectors stay in `workspace`
+// (which therefore must not be reused before they are consumed) and vlb_ln_param_finalize_batch adds the column sums of up to 32
+// such workspaces into their gradients in ONE launch -- a training step runs 26 LayerNorm backwards whose parameter gradients are
+// only needed by the optimizer (or a bucket's all-reduce).  vlb_layernorm_bwd_slabs(rows) = number of partial vectors the call
+// leaves (0: the call was small enough to add its sums directly; nothing to finalize).
+extern "C" int vlb_layernorm_bwd_deferred(const void* dy, long lddy, int dy_f32, const void* x, long ldx, const float* stats,
+                                          const float* gamma, void* dx, long lddx, void* dx_drop, long lddd, float drop_p,
+                                          const uint32_t* seed, uint32_t tag, float* dx_acc, long ldacc, float* dgamma, float* dbeta,
+                                          float* workspace, int rows, int H, int x_f16, hipStream_t stream) {
+  VLB_CHECK_ARG(workspace && (dgamma || dbeta), "vlb_layernorm_bwd_deferred: needs a workspace and a parameter gradient");
+  return ln_bwd_impl(dy, lddy, dy_f32, x, ldx, stats, gamma, dx, lddx, dx_drop, lddd, drop_p, seed, tag, dx_acc, ldacc, dgamma, dbeta,
+                     workspace, rows, H, x_f16, false, stream);
+}
+
+extern "C" int vlb_layernorm_bwd_slabs(int rows) {
+  if (rows <= 0) return 0;
+  const int blocks = ln_bwd_blocks(rows);
+  return blocks > 32 ? blocks : 0;
+}
+
+struct LnFinalizeBatch {
+  const float* ws[32];
+  float* dgamma[32];
+  float* dbeta[32];
+  int nslab[32];
+};
+
+__global__ __launch_bounds__(256) void ln_param_finalize_batch_kernel(const LnFinalizeBatch b, int LW, int H, int cpl_log2) {
+  __shared__ float part[4][64];
+  const int e = blockIdx.z;
+  const float* ws = b.ws[e];
+  const int nslab = b.nslab[e];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int q = blockIdx.x * 64 + tx;
+  float s = 0.f;
+  for (int r = blockIdx.y * 4 + ty; r < nslab; r += 4 * gridDim.y) s += ws[(long)r * 2 * LW + q];
+  part[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0) {
+    s = (part[0][tx] + part[1][tx]) + (part[2][tx] + part[3][tx]);
+    const int r = q % LW, cpl = 1 << cpl_log2;
+    const int col = ((r & 63) + 64 * (r >> (6 + cpl_log2))) * cpl + ((r >> 6) & (cpl - 1));
+    if (col < H) {
+      if (q < LW) { if (b.dgamma[e]) atomicAdd(b.dgamma[e] + col, s); }
+      else if (b.dbeta[e]) atomicAdd(b.dbeta[e] + col, s);
+    }
+  }
+}
+
+extern "C" int vlb_ln_param_finalize_batch(int n, const float* const* ws, const int* nslab, float* const* dgamma, float* const* dbeta,
+                                           int H, hipStream_t stream) {
+  if (n <= 0) return VLB_OK;
+  VLB_CHECK_ARG(n <= 32 && ws && nslab && dgamma && dbeta, "vlb_ln_param_finalize_batch: 1..32 entries");
+  VLB_CHECK_ARG(H > 0 && (H % 8) == 0 && H <= 2048, "vlb_ln_param_finalize_batch: unsupported H=%d", H);
+  if (g_ln_bwd4 < 0) {
+    const char* v = getenv("VLB_LN_BWD4");
+    g_ln_bwd4 = v ? atoi(v) : 1;
+  }
+  LnFinalizeBatch b;
+  for (int i = 0; i < n; ++i) {
+    VLB_CHECK_ARG(ws[i] && nslab[i] > 0, "vlb_ln_param_finalize_batch: entry %d has no partial vectors", i);
+    b.ws[i] = ws[i]; b.nslab[i] = nslab[i]; b.dgamma[i] = dgamma[i]; b.dbeta[i] = dbeta[i];
+  }
+  int LW, cpl_log2;
+  ln_lw(H, LW, cpl_log2);
+  hipLaunchKernelGGL(ln_param_finalize_batch_kernel, dim3(2 * LW / 64, 8, n), dim3(256), 0, stream, b, LW, H, cpl_log2);
+  VLB_CHECK_LAUNCH("vlb_ln_param_finalize_batch");
   return VLB_OK;
 }
 

@@ -374,6 +374,12 @@ class PretrainEngine:
         self.wg_ws_main = zf(max(need[-1], 4)) if self.side is not None else self.wg_ws    # decoder dgrad split-K (main stream)
         self._pending = {}
         self.ln_ws = zf(ops.ln_bwd_workspace_floats(H))     # per-workgroup partial dgamma/dbeta sums of the LayerNorm backward
+        # The encoder's LayerNorm backwards (2 per layer + the MLM head's) leave their partial sums in a workspace slice of their
+        # own; one batched launch (ops.ln_param_finalize_batch) adds them into the gradients when those are next needed -- a
+        # bucket's all-reduce, or the end of backward -- instead of a 7-10 us finalize launch behind each of the 25 calls.
+        n_slices = min(2 * L + 1, 32) if _os0.environ.get("VLB_LN_DEFER", "1") != "0" else 0
+        self._ln_slices = list(zf(n_slices, ops.ln_bwd_workspace_floats(H)).unbind(0)) if n_slices else []
+        self._ln_pending = []
         self.graph = None
         self._weights_dirty = True
         import os
@@ -711,7 +717,29 @@ class PretrainEngine:
             torch.cuda.current_stream().wait_event(ev)
             self._pending.clear()
 
+    def _ln_bwd(self, dy, x, stats, gamma, dgamma, dbeta, **kw):
+        if not self._ln_slices:             # VLB_LN_DEFER=0: finalize behind every call
+            ops.layernorm_bwd(dy, x, stats, gamma, dgamma=dgamma, dbeta=dbeta, workspace=self.ln_ws, **kw)
+            return
+        if len(self._ln_pending) == len(self._ln_slices):
+            self._flush_ln()                 # (more deferred calls than slices: the 24-layer model)
+        ws = self._ln_slices[len(self._ln_pending)]
+        slabs = ops.layernorm_bwd(dy, x, stats, gamma, dgamma=dgamma, dbeta=dbeta, workspace=ws, defer=True, **kw)
+        if slabs:
+            self._ln_pending.append((ws, slabs, dgamma, dbeta))
+
+    def _flush_ln(self):
+        if self._ln_pending:
+            ops.ln_param_finalize_batch(self._ln_pending, self.cfg.hidden_size)
+            self._ln_pending = []
+
     def backward(self, train=None, on_layer_done=None):
+        if on_layer_done is not None:       # a bucket is about to be reduced: the deferred LayerNorm parameter gradients first
+            user_hook = on_layer_done
+
+            def on_layer_done(what):
+                self._flush_ln()
+                user_hook(what)
         train = self.train if train is None else train
         cfg, B, T, R, S, Bt, Ba = self.cfg, self.B, self.T, self.R, self.S, self.Bt, self.Ba
         H, I, V, C, L, nh = cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size, cfg.visual_region_classes, \
@@ -728,9 +756,8 @@ class PretrainEngine:
             dlog = self.mlm_logits[:nr]                  # [rows, Vp], pad columns zero
             self._wgrad(dlog[:, :V], self.mlm_h[:nr], g32["vlbert.word_embeddings.weight"], g32[pm + "bias"], self.tG_bt, self.tA_bt, nrp)
             ops.gemm_nt_splitk(dlog, wT["vlbert.word_embeddings.weight"], self.d_mlm_h[:nr], workspace=self.wg_ws_main)
-            ops.layernorm_bwd(self.d_mlm_h[:nr], self.mlm_g[:nr], self.st_mlm[:nr], w32[pm + "transform.LayerNorm.weight"], dx=self.d_mlm_g[:nr],
-                              dgamma=g32[pm + "transform.LayerNorm.weight"], dbeta=g32[pm + "transform.LayerNorm.bias"],
-                              workspace=self.ln_ws)
+            self._ln_bwd(self.d_mlm_h[:nr], self.mlm_g[:nr], self.st_mlm[:nr], w32[pm + "transform.LayerNorm.weight"],
+                         g32[pm + "transform.LayerNorm.weight"], g32[pm + "transform.LayerNorm.bias"], dx=self.d_mlm_g[:nr])
             ops.mul_bf16(self.d_mlm_g[:nr], self.mlm_u[:nr], self.d_mlm_u[:nr])
             self._wgrad(self.d_mlm_u[:nr], self.text_out[:nr], g32[pm + "transform.dense.weight"], g32[pm + "transform.dense.bias"], self.tG_bt,
                         self.tA_bt, nrp)
@@ -776,19 +803,16 @@ class PretrainEngine:
             # LN2: dZ2 (residual branch) and dD2 (into output.dense, through its dropout; a plain copy when dropout is off --
             # dZ is reused inside the layer, the grouped weight gradient at its end needs its own operand)
             self._before_write(self.dZ, dD2)
-            ops.layernorm_bwd(dx, self.Z2[l], self.ST2[l], w32[p + "output.LayerNorm.weight"], dx=self.dZ,
-                              dx_drop=dD2, drop_p=p_h, seed=seed, tag=l * 8 + 2,
-                              dgamma=g32[p + "output.LayerNorm.weight"], dbeta=g32[p + "output.LayerNorm.bias"],
-                              workspace=self.ln_ws)
+            self._ln_bwd(dx, self.Z2[l], self.ST2[l], w32[p + "output.LayerNorm.weight"], g32[p + "output.LayerNorm.weight"],
+                         g32[p + "output.LayerNorm.bias"], dx=self.dZ, dx_drop=dD2, drop_p=p_h, seed=seed, tag=l * 8 + 2)
             self._before_write(dU)
             ops.gemm_nt(dD2, wT[p + "output.dense.weight"], dU, act=ops.ACT_MULAUX, aux=self.U[l])
             ops.gemm_nt(dU, wT[p + "intermediate.dense.weight"], dx_next, res=self.dZ)            # dY1
             # LN1
             self._before_write(self.dZ, dD1)
-            ops.layernorm_bwd(dx_next, self.Z1[l], self.ST1[l], w32[p + "attention.output.LayerNorm.weight"], dx=self.dZ,
-                              dx_drop=dD1, drop_p=p_h, seed=seed, tag=l * 8 + 1,
-                              dgamma=g32[p + "attention.output.LayerNorm.weight"], dbeta=g32[p + "attention.output.LayerNorm.bias"],
-                              workspace=self.ln_ws)
+            self._ln_bwd(dx_next, self.Z1[l], self.ST1[l], w32[p + "attention.output.LayerNorm.weight"],
+                         g32[p + "attention.output.LayerNorm.weight"], g32[p + "attention.output.LayerNorm.bias"], dx=self.dZ,
+                         dx_drop=dD1, drop_p=p_h, seed=seed, tag=l * 8 + 1)
             ops.gemm_nt(dD1, wT[p + "attention.output.dense.weight"], self.dCTX)
             self._before_write(dQKV)
             ops.attention_bwd(self.QKV[l], mask, self.CTX[l], self.LSE[l], self.dCTX, dQKV, Bt, S, H, nh, drop_p=p_a,
@@ -811,6 +835,7 @@ class PretrainEngine:
         else:
             self._front_pretrain_bwd(dx, p_h, p_ds, on_layer_done)
         self._join_side()
+        self._flush_ln()
         self._fresh_grads = False       # a further backward before the next zero_grad() accumulates
         if on_layer_done:
             on_layer_done("embed")

@@ -181,16 +181,31 @@ def layernorm_fwd(x, gamma, beta, y, stats=None, eps=1e-12, rows=None, ldx=None)
 
 
 def layernorm_bwd(dy, x, stats, gamma, dx=None, dx_drop=None, drop_p=0.0, seed=None, tag=0, dx_acc=None, dgamma=None,
-                  dbeta=None, rows=None, ldx=None, ldacc=None, workspace=None):
-    """workspace: fp32 scratch tensor of ln_bwd_workspace_floats(H) elements, or None (direct atomics)."""
+                  dbeta=None, rows=None, ldx=None, ldacc=None, workspace=None, defer=False):
+    """workspace: fp32 scratch tensor of ln_bwd_workspace_floats(H) elements, or None (direct atomics).
+    defer=True (vlb_layernorm_bwd_deferred): the parameter-gradient partial sums stay in `workspace`; returns the number of partial
+    vectors for ln_param_finalize_batch (0: they were added directly)."""
     H = x.shape[1]
     rows = x.shape[0] if rows is None else rows
     dy_f32 = 1 if dy.dtype == torch.float32 else 0
     assert x.dtype in (BF16, F16)
-    _lib.call("vlb_layernorm_bwd", _p(dy), _ld(dy), dy_f32, _p(x), _ld(x) if ldx is None else ldx, _p(stats, torch.float32),
+    _lib.call("vlb_layernorm_bwd_deferred" if defer else "vlb_layernorm_bwd", _p(dy), _ld(dy), dy_f32, _p(x),
+              _ld(x) if ldx is None else ldx, _p(stats, torch.float32),
               _p(gamma, torch.float32), _p(dx, BF16), _ld(dx), _p(dx_drop, BF16), _ld(dx_drop), float(drop_p), _p(seed),
               int(tag), _p(dx_acc, torch.float32), _ld(dx_acc) if ldacc is None else ldacc, _p(dgamma, torch.float32),
               _p(dbeta, torch.float32), _p(workspace, torch.float32), rows, H, 1 if x.dtype == F16 else 0, _stream())
+    return int(_lib.load().vlb_layernorm_bwd_slabs(rows)) if defer else None
+
+
+def ln_param_finalize_batch(entries, H):
+    """entries: [(workspace, n partial vectors, dgamma, dbeta)], at most 32 -> one launch (vlb_ln_param_finalize_batch)."""
+    import ctypes
+    n = len(entries)
+    if not n:
+        return
+    P, I = ctypes.c_void_p * n, ctypes.c_int * n
+    _lib.call("vlb_ln_param_finalize_batch", n, P(*[_p(e[0], torch.float32) for e in entries]), I(*[int(e[1]) for e in entries]),
+              P(*[_p(e[2], torch.float32) for e in entries]), P(*[_p(e[3], torch.float32) for e in entries]), int(H), _stream())
 
 
 def attention_fwd(qkv, mask, ctx, lse, B, S, H, nh, drop_p=0.0, seed=None, tag=0):
