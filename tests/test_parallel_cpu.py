@@ -46,6 +46,28 @@ def test_buckets_tile_the_flat_buffer():
         assert fired[0] == 0
 
 
+def test_will_launch_predicate_matches_on_done():
+    """engine.backward joins its side stream (and calls the hook) only for the events that start a collective: the predicate must be
+    true exactly where on_done() launches -- bucket boundaries, heads, word_emb / embed -- once per step, and never at world size 1."""
+    P = importlib.import_module("vl-bert_amd.parallel")
+    cfg, offsets, numel = _layout()
+    b = P.GradBuckets(torch.zeros(numel), offsets, numel, cfg.num_hidden_layers, bucket_bytes=200_000)
+    assert not any(b.will_launch(w) for w in list(range(cfg.num_hidden_layers)) + ["heads", "embed", "word_emb"])      # world 1
+    b.world = 2
+    launched = []
+    b._launch = lambda lo, hi: launched.append((lo, hi))
+    for what in ["heads"] + list(reversed(range(cfg.num_hidden_layers))) + ["word_emb", "embed"]:
+        before = len(launched)
+        expect = b.will_launch(what)
+        b.on_done(what)
+        assert (len(launched) > before) == expect, what
+        assert not b.will_launch(what)                    # once per step
+    cov = sorted(launched)
+    assert cov[0][0] == 0 and cov[-1][1] == numel and all(a[1] == c[0] for a, c in zip(cov[:-1], cov[1:]))
+    b.wait()
+    assert b.will_launch("heads")                         # re-armed
+
+
 def test_buckets_with_vision_tail_tile_the_flat_buffer():
     """e2e layout: the trainable convolution weights sit behind the heads and form their own (last) bucket."""
     E = importlib.import_module("vl-bert_amd.engine")

@@ -1628,6 +1628,45 @@ extern "C" int vlb_gemm_nt_bf16_splitk(const void* A, long lda, const void* B, l
   return VLB_OK;
 }
 
+struct SplitkReduceGroup {
+  const float* slabs[4];
+  long slab_stride[4];
+  float* C[4];
+  long ldc[4];
+  int splits[4], M[4], N[4], ldw[4];
+};
+
+// splitk_reduce_kernel (fp32 result) for up to four outputs in one launch: blockIdx.y selects the member
+__global__ __launch_bounds__(256) void splitk_reduce_group_kernel(const SplitkReduceGroup g, int accumulate) {
+  const int e = blockIdx.y;
+  const float* slabs = g.slabs[e];
+  const long slab_stride = g.slab_stride[e], ldc = g.ldc[e];
+  float* C = g.C[e];
+  const int splits = g.splits[e], M = g.M[e], N = g.N[e], ldw = g.ldw[e];
+  const int n4 = ldw >> 2;
+  const long total = (long)M * n4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int m = (int)(i / n4), n = (int)(i % n4) * 4;
+    const float* src = slabs + (long)m * ldw + n;
+    float4 a = *(const float4*)src;
+    for (int sp = 1; sp < splits; ++sp) {
+      const float4 b = *(const float4*)(src + sp * slab_stride);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    float* c = C + (long)m * ldc + n;
+    if (n + 3 < N) {
+      if (accumulate) {
+        const float4 o = *(const float4*)c;
+        a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+      }
+      *(float4*)c = a;
+    } else {
+      const float av[4] = {a.x, a.y, a.z, a.w};
+      for (int r = 0; r < 4 && n + r < N; ++r) c[r] = accumulate ? c[r] + av[r] : av[r];
+    }
+  }
+}
+
 // dW[Mo,No] (fp32) (+)= A[R,Mo]^T B[R,No]; optional colsum[Mo] += column sums of A (bias gradient).
 // accumulate == 0 overwrites dW (first micro-batch of an optimizer step: no zero fill and no read-modify-write).
 static int wgrad_tn_impl(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int R, int Mo, int No, float* colsum,
@@ -1742,13 +1781,22 @@ extern "C" int vlb_wgrad_tn_group_bf16(int n, const void* const* A, const long* 
     }
     return VLB_OK;
   }
+  // the members' slab reduces as ONE launch (blockIdx.y = member): 4 small launches per encoder layer were 48 of the step's launches
+  SplitkReduceGroup rg;
+  int nr = 0;
+  long max_blocks = 1;
   for (int i = 0; i < n; ++i) {
     if (slices[i] <= 1) continue;
     const long ldw = (No[i] + 3) / 4 * 4;
     long blocks = ((long)Mo[i] * (ldw / 4) + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)blocks), dim3(256), 0, stream, workspace + ws_off[i], (long)Mo[i] * ldw, slices[i], C[i],
-                       ldc[i], Mo[i], No[i], (int)ldw, (bf16_t*)nullptr, 0L, accumulate, (const float*)nullptr);
+    if (blocks > max_blocks) max_blocks = blocks;
+    rg.slabs[nr] = workspace + ws_off[i]; rg.slab_stride[nr] = (long)Mo[i] * ldw; rg.splits[nr] = slices[i];
+    rg.C[nr] = C[i]; rg.ldc[nr] = ldc[i]; rg.M[nr] = Mo[i]; rg.N[nr] = No[i]; rg.ldw[nr] = (int)ldw;
+    ++nr;
+  }
+  if (nr) {
+    hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3((int)max_blocks, nr), dim3(256), 0, stream, rg, accumulate);
     VLB_CHECK_LAUNCH("vlb_wgrad_tn_group_bf16(reduce)");
   }
   return VLB_OK;

@@ -734,8 +734,10 @@ class PretrainEngine:
             self._ln_pending = []
 
     def backward(self, train=None, on_layer_done=None):
+        will_launch = None
         if on_layer_done is not None:       # a bucket is about to be reduced: the deferred LayerNorm parameter gradients first
             user_hook = on_layer_done
+            will_launch = getattr(getattr(user_hook, "__self__", None), "will_launch", None)     # GradBuckets.on_done -> its predicate
 
             def on_layer_done(what):
                 self._flush_ln()
@@ -826,7 +828,7 @@ class PretrainEngine:
                                (dD1, self.CTX[l], g32[p + "attention.output.dense.weight"], g32[p + "attention.output.dense.bias"]),
                                (dQKV, self.X[l], gwqkv, gbqkv)])
             dx = dx_next
-            if on_layer_done:
+            if on_layer_done and (will_launch is None or will_launch(l)):
                 self._join_side()           # the bucket's weight gradients must be complete before its all-reduce reads them
                 on_layer_done(l)
         self._join_side()               # embed_bwd adds into the word-embedding gradient the decoder wgrad wrote

@@ -141,6 +141,12 @@ class GradBuckets:
         elif what in self.layer_bucket:
             self._launch(*self.layer_bucket[what])
 
+    def will_launch(self, what):
+        """True when on_done(what) would start a collective now (engine.backward joins its side stream only then)."""
+        if self.world == 1 or what in self.launched:
+            return False
+        return what in self.layer_bucket or what in self.ranges or what in ("vision", "embed")
+
     def wait(self):
         for work in self.pending:
             work.wait()
