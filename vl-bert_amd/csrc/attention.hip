@@ -390,6 +390,201 @@ __global__ __launch_bounds__(ATT_THREADS, NU <= 4 ? 4 : 2) void attn_bwd_kernel(
   }   // qs
 }
 
+// =============================================================================================
+// backward, S <= 128, one evaluation of the S x S tile (round 2).
+//
+// The kernel above computes P and dS TWICE -- once per orientation -- because the reduction over queries (dV, dK) needs them with
+// queries along the MFMA k index and the reduction over keys (dQ) with keys along it.  Measured, it is VALU-bound (80 % of the
+// SIMD cycles issuing: exp, the dropout hash -- one per ELEMENT in the key-major orientation --, dS), not MFMA- or LDS-bound.
+// Here every wave evaluates its 16 queries x all keys once (the query-major role: exp, one hash per element PAIR, dS, dQ), keeps
+// the two bf16 tiles in registers (32 VGPRs), and after a barrier hands them over through the LDS space K and V no longer need:
+// row-major [query][key] images, 16-B stores, XOR-swizzled 16-B chunks.  The key-major role then only runs the two products that
+// reduce over queries, reading its B operands (8 consecutive queries of one key) with the LDS transpose read ds_read_b64_tr_b16
+// -- no second exp / hash / dP.  The images share the 32 KiB of sK | sV, Pd first (dV), then dS (dK): LDS stays at 66 KiB, two
+// workgroups per CU.
+// =============================================================================================
+__device__ __forceinline__ int pt_addr(int row, int chunk16) { return row * 256 + ((chunk16 ^ (row & 15)) << 4); }
+
+// B operand of a product that reduces over QUERIES: lane (L = lane & 15, g) <- T[query 32 v + 8 g + j][key key0 + L], j = 0..7
+__device__ __forceinline__ bf16x8 frag_pt(const char* img, int v, int key0, int lane) {
+  const int L = lane & 15, g = lane >> 4;
+  const int r_lo = 32 * v + 8 * g + (L >> 2), r_hi = r_lo + 4;
+  const int cb = key0 * 2 + (L & 3) * 8;                       // byte offset of this lane's 4 keys inside the 256-B row
+  const int a_lo = pt_addr(r_lo, cb >> 4) | (cb & 15), a_hi = pt_addr(r_hi, cb >> 4) | (cb & 15);
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(img + a_lo));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(img + a_hi));
+  const s16x8 w = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, w);
+}
+
+__global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd2_kernel(const AttnParams p) {
+  constexpr int NU = 4, ATT_SP = 128, TILE_BYTES = ATT_SP * ATT_D * 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sQ = smem;
+  char* sK = smem + 1 * TILE_BYTES;
+  char* sV = smem + 2 * TILE_BYTES;
+  char* sdO = smem + 3 * TILE_BYTES;
+  char* sT = sK;                                   // [128 queries][128 keys] bf16 = sK | sV, after the query-major role
+  float* sMB = (float*)(smem + 4 * TILE_BYTES);
+  float* sLSE = sMB + ATT_SP;
+  float* sD = sLSE + ATT_SP;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x / p.nh, h = blockIdx.x % p.nh;
+  const int S = p.S;
+  const long ld = 3L * p.H;
+  const bf16_t* qbase = p.qkv + (long)b * S * ld + h * ATT_D;
+  const bf16_t* dobase = p.dctx + (long)b * S * p.H + h * ATT_D;
+  const bf16_t* obase = p.ctx + (long)b * S * p.H + h * ATT_D;
+  stage_tile<ATT_SP>(qbase, ld, S, sQ, tid);
+  stage_tile<ATT_SP>(qbase + p.H, ld, S, sK, tid);
+  stage_tile<ATT_SP>(qbase + 2 * p.H, ld, S, sV, tid);
+  stage_tile<ATT_SP>(dobase, p.H, S, sdO, tid);
+#pragma unroll
+  for (int it = 0; it < ATT_SP * 8 / ATT_THREADS; ++it) {      // D[q] = sum_d dO[q][d] * O[q][d]
+    const int P = it * ATT_THREADS + tid, row = P >> 3, ch = P & 7;
+    float d = 0.f;
+    if (row < S) {
+      const uint4 a = *(const uint4*)(dobase + (long)row * p.H + ch * 8);
+      const uint4 o = *(const uint4*)(obase + (long)row * p.H + ch * 8);
+      d = bflo(a.x) * bflo(o.x) + bfhi(a.x) * bfhi(o.x) + bflo(a.y) * bflo(o.y) + bfhi(a.y) * bfhi(o.y) +
+          bflo(a.z) * bflo(o.z) + bfhi(a.z) * bfhi(o.z) + bflo(a.w) * bflo(o.w) + bfhi(a.w) * bfhi(o.w);
+    }
+    d += __shfl_xor(d, 1, 64);
+    d += __shfl_xor(d, 2, 64);
+    d += __shfl_xor(d, 4, 64);
+    if (ch == 0) sD[row] = d;
+  }
+  if (tid < ATT_SP) {
+    sMB[tid] = (tid < S) ? (1.0f - p.mask[b * S + tid]) * -10000.0f : -INFINITY;
+    sLSE[tid] = (tid < S) ? p.lse[((long)b * p.nh + h) * S + tid] : 0.f;
+  }
+  __syncthreads();
+
+  const uint32_t seed = (p.drop_thr && p.seed) ? *p.seed : 0u;
+  const uint32_t key = vlb_hash32(seed ^ (p.tag * 0x85ebca6bu + 0x632be5abu));
+  const uint32_t bh = (uint32_t)(b * p.nh + h);
+  const int U = (S + 31) >> 5;
+  const int w16 = wave * 16;
+  const int pos = w16 + c;                          // this lane's query (first role) / key (second role)
+  const bool pos_ok = pos < S;
+  const bool active = w16 < 32 * U;                 // this wave's 16 rows lie inside the processed 32-blocks
+
+  // ------------------------------------------------------------------------------------------
+  // query-major role: S^T[key][q] tiles = K(perm rows) Q^T ;  P, Pd, dS ;  dQ^T = K^T dS^T
+  // ------------------------------------------------------------------------------------------
+  bf16x8 pd[NU], dsf[NU];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) pd[u] = dsf[u] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+  if (w16 < S) {
+    bf16x8 qf[2], dof[2];
+#pragma unroll
+    for (int ds = 0; ds < 2; ++ds) {
+      qf[ds] = frag_nat(sQ, w16, c, ds * 4 + g);
+      dof[ds] = frag_nat(sdO, w16, c, ds * 4 + g);
+    }
+    f32x4 dq[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float lse = sLSE[pos], dd = sD[pos];
+    const float rowf = pos_ok ? 1.f : 0.f;          // queries beyond S contribute nothing to the reductions over queries
+    const uint32_t qrow = (bh * (uint32_t)S + (uint32_t)min(pos, S - 1)) * (uint32_t)S;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      if (u < U) {
+        float pr[8], dpv[8], kv[8];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ds = 0; ds < 2; ++ds) {
+            sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_perm(sK, u, hf, c, ds * 4 + g), qf[ds], sc, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_perm(sV, u, hf, c, ds * 4 + g), dof[ds], dp, 0, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            pr[4 * hf + r] = __expf(sc[r] * p.scale + sMB[32 * u + 8 * g + 4 * hf + r] - lse) * rowf;
+            dpv[4 * hf + r] = dp[r];
+            kv[4 * hf + r] = 1.f;
+          }
+        }
+        if (p.drop_thr) drop8(kv, key, qrow + 32u * u + 8u * g, p.drop_thr, p.drop_scale);      // keep * 1/(1-p) per element
+        float pdv[8], dsv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          pdv[j] = pr[j] * kv[j];
+          dsv[j] = pr[j] * (dpv[j] * kv[j] - dd);
+        }
+        pd[u] = pack8(pdv);
+        dsf[u] = pack8(dsv);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+          dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(sK, u, dt * 16, lane), dsf[u], dq[dt], 0, 0, 0);
+      }
+    }
+    if (pos_ok) {
+      bf16_t* orow = p.dqkv + ((long)b * S + pos) * ld + h * ATT_D + 4 * g;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        *(uint2*)(orow + dt * 16) = make_uint2(pack2bf(dq[dt][0] * p.scale, dq[dt][1] * p.scale),
+                                               pack2bf(dq[dt][2] * p.scale, dq[dt][3] * p.scale));
+    }
+  }
+  __syncthreads();                                  // every wave is done with sK / sV
+
+  // ------------------------------------------------------------------------------------------
+  // key-major role: dV^T = dO^T Pd ,  dK^T = Q^T dS  -- operands from the [query][key] images
+  // ------------------------------------------------------------------------------------------
+  f32x4 dv[4], dk[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) dv[dt] = dk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (active) {                                     // lane (c, g): query row w16 + c, keys 32 u + 8 g + [0, 8)  (zeros beyond S)
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+      if (u < U) *(bf16x8*)(sT + pt_addr(w16 + c, 4 * u + g)) = pd[u];
+  }
+  __syncthreads();
+  if (w16 < S) {
+#pragma unroll
+    for (int v = 0; v < NU; ++v) {
+      if (v < U) {
+        const bf16x8 pt = frag_pt(sT, v, w16, lane);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+          dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(sdO, v, dt * 16, lane), pt, dv[dt], 0, 0, 0);
+      }
+    }
+  }
+  __syncthreads();                                  // Pd consumed: the image is reused for dS
+  if (active) {
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+      if (u < U) *(bf16x8*)(sT + pt_addr(w16 + c, 4 * u + g)) = dsf[u];
+  }
+  __syncthreads();
+  if (w16 < S) {
+#pragma unroll
+    for (int v = 0; v < NU; ++v) {
+      if (v < U) {
+        const bf16x8 st = frag_pt(sT, v, w16, lane);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+          dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(sQ, v, dt * 16, lane), st, dk[dt], 0, 0, 0);
+      }
+    }
+    if (pos_ok) {
+      bf16_t* orow = p.dqkv + ((long)b * S + pos) * ld + h * ATT_D + 4 * g;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        *(uint2*)(orow + p.H + dt * 16) = make_uint2(pack2bf(dk[dt][0] * p.scale, dk[dt][1] * p.scale),
+                                                     pack2bf(dk[dt][2] * p.scale, dk[dt][3] * p.scale));
+        *(uint2*)(orow + 2 * p.H + dt * 16) = make_uint2(pack2bf(dv[dt][0], dv[dt][1]), pack2bf(dv[dt][2], dv[dt][3]));
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------- C ABI
 static int check_attn(const char* name, int B, int S, int H, int nh) {
   VLB_CHECK_ARG(B > 0 && S > 0 && S <= ATT_SP_MAX, "%s: S=%d unsupported (1..%d)", name, S, ATT_SP_MAX);
@@ -439,10 +634,18 @@ extern "C" int vlb_attention_bwd(const void* qkv, const float* mask, const void*
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (128 * ATT_D * 2) + 3 * 128 * 4);
+    (void)hipFuncSetAttribute((const void*)attn_bwd2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (128 * ATT_D * 2) + 3 * 128 * 4);
     (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (256 * ATT_D * 2) + 3 * 256 * 4);
     attr_set = true;
   }
-  if (S <= 128)
+  static int bwd2 = -1;      // VLB_ATTN_BWD2: 1 (default) the single-evaluation backward for S <= 128; 0 the two-orientation kernel
+  if (bwd2 < 0) {
+    const char* v = getenv("VLB_ATTN_BWD2");
+    bwd2 = v ? atoi(v) : 1;
+  }
+  if (S <= 128 && bwd2)
+    hipLaunchKernelGGL(attn_bwd2_kernel, dim3(B * nh), dim3(ATT_THREADS), 4 * (128 * ATT_D * 2) + 3 * 128 * 4, stream, p);
+  else if (S <= 128)
     hipLaunchKernelGGL((attn_bwd_kernel<4, 1>), dim3(B * nh), dim3(ATT_THREADS), 4 * (128 * ATT_D * 2) + 3 * 128 * 4, stream, p);
   else
     hipLaunchKernelGGL((attn_bwd_kernel<8, 2>), dim3(B * nh), dim3(ATT_THREADS), 4 * (256 * ATT_D * 2) + 3 * 256 * 4, stream, p);
