@@ -160,6 +160,51 @@ def test_roi_align_nhwc(ops, sr, C, H, W):
     report("roi_align nhwc bwd sr%d C%d %dx%d" % (sr, C, H, W), dfeat, nhwc(refb), 1e-4, 1e-4)
 
 
+@pytest.mark.parametrize("C,H,W", [(32, 9, 12), (64, 38, 63)])
+def test_roi_align_nhwc_backward_is_the_jacobian_transpose_of_the_hip_forward(ops, C, H, W):
+    """The reference has no CPU ROIAlign backward (ROIAlign.h:44), so the backward oracle is only pinned through the adjoint of its own
+    forward.  This test closes the loop on the DEVICE kernels themselves: ROIAlign is linear in the feature map, so the forward of a
+    one-hot map IS a Jacobian column (exact finite difference), and the LDS-window backward (C % 32 == 0; 14x14 bins, the pre-training
+    geometry at 38x63) must return <dout, that column> at the hot element -- for hot elements inside, at the border of and outside the
+    RoI windows -- and the full adjoint identity <dout, fwd(x)> = <bwd(dout), x> must hold for a random map."""
+    N, R, ph = 2, 3, 14
+    X, Y = 16.0 * W - 1, 16.0 * H - 1
+    boxes = torch.tensor([[[10.0, 20.0, 0.45 * X, 0.8 * Y, 9.0], [0.0, 0.0, X, Y, 9.0], [60.5, 30.25, 70.0, 35.0, 9.0]],
+                          [[0.3 * X, 8.0, 0.9 * X, 0.9 * Y, 9.0], [-20.0, -10.0, 40.0, 50.0, 9.0], [-2.0, -2.0, -2.0, -2.0, 9.0]]])
+    bx = boxes.view(N * R, 5).contiguous().to(dev())
+    g = torch.Generator().manual_seed(21)
+    dout = torch.randn(N * R * ph * ph, C, generator=g)
+    dout_g = to_gpu_bf16(dout)
+    dout_r = dout_g.float().cpu()
+    dfeat = torch.zeros((N * H * W, C), device=dev())
+    ops.roi_align_nhwc_bwd(dout_g, bx, R, dfeat, N, H, W, C, pooled=ph, spatial_scale=1.0 / 16, sampling_ratio=1)
+    torch.cuda.synchronize()
+    dfeat_c = dfeat.cpu()
+    out = torch.zeros((N * R * ph * ph, C), dtype=torch.bfloat16, device=dev())
+    hot = [(0, 1, 1, 3), (0, H // 2, W // 3, 0), (0, H - 1, W - 1, C - 1), (1, 2, W // 2, 7), (1, H - 2, 1, C // 2), (1, 0, 0, 1),
+           (0, 2, 4, 5), (1, H // 2, W - 2, 9)]
+    worst = 0.0
+    for n, y, x, c in hot:
+        feat = torch.zeros((N * H * W, C))
+        feat[(n * H + y) * W + x, c] = 1.0
+        ops.roi_align_nhwc_fwd(to_gpu_bf16(feat), bx, R, out, N, H, W, C, pooled=ph, spatial_scale=1.0 / 16, sampling_ratio=1)
+        col = out.float().cpu()                                    # Jacobian column (bilinear weights / samples per bin, bf16)
+        want = float((col * dout_r).sum())
+        got = float(dfeat_c[(n * H + y) * W + x, c])
+        scale = float((col.abs() * dout_r.abs()).sum()) + 1e-6
+        worst = max(worst, abs(got - want) / scale)
+        assert abs(got - want) <= 1e-2 * scale, (n, y, x, c, got, want)
+    feat = torch.randn(N * H * W, C, generator=g)
+    feat_g = to_gpu_bf16(feat)
+    ops.roi_align_nhwc_fwd(feat_g, bx, R, out, N, H, W, C, pooled=ph, spatial_scale=1.0 / 16, sampling_ratio=1)
+    lhs = float((out.float().cpu().double() * dout_r.double()).sum())
+    rhs = float((dfeat_c.double() * feat_g.float().cpu().double()).sum())
+    print("roi_align nhwc %dx%dx%d: one-hot Jacobian columns worst rel %.2e; adjoint identity %.6f vs %.6f" % (H, W, C, worst, lhs, rhs))
+    # the forward output is rounded to bf16 (2^-9 relative per element): the identity holds up to that rounding noise on its terms
+    noise = float(((out.float().cpu().double() * dout_r.double()) ** 2).sum().sqrt()) * 2.0 ** -8
+    assert abs(lhs - rhs) <= 4.0 * noise + 1e-4 * abs(lhs), (lhs, rhs, noise)
+
+
 def test_avgpool_rows_and_relu_mask(ops):
     K, P, C, ld = 5, 9, 32, 4 + 32
     y = torch.relu(rnd(K * P, C, seed=13))
