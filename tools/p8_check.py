@@ -50,6 +50,10 @@ def run_case(M, N, K, epi, mode, seed_t, ldpad=0):
         kw = dict(bias=bias, res=side_g)
     elif epi == 5:
         kw = dict(bias=bias, act=ops.ACT_RELU)
+    elif epi == 8:       # relu(acc + bias + res): Bottleneck forward tail
+        kw = dict(bias=bias, res=side_g, act=ops.ACT_RES_RELU)
+    elif epi == 10:      # acc where aux > 0: ReLU backward
+        kw = dict(act=ops.ACT_RELU_MASK, aux=side_g)
     elif epi in (6, 7):      # LayerNorm-residual from fp16 rows, fp16 output (epi 6: with dropout)
         z = (side.float() * 2.0 + 0.3).half()
         zg = torch.zeros((M, ldc), dtype=torch.float16, device=D)[:, :N]
@@ -89,6 +93,10 @@ def reference(M, N, K, epi, ins):
         return [acc + b + side.float()]
     if epi == 5:
         return [torch.relu(acc + b)]
+    if epi == 8:
+        return [torch.relu(acc + b + side.float())]
+    if epi == 10:
+        return [acc * (side.float() > 0)]
     return None     # dropout: compared with the 128x128 kernel only (same counter RNG)
 
 
@@ -99,7 +107,7 @@ def check():
     bad = 0
     for M, N, K in shapes:
         for mode in (3, 4, 5):
-            for epi in range(8):
+            for epi in (0, 1, 2, 3, 4, 5, 6, 7, 8, 10):
                 if N > 20000 and epi not in (0,):
                     continue
                 lib.gemm_set_option("p8_min_tiles", 1)

@@ -73,7 +73,7 @@ __device__ __forceinline__ void p8_barrier() {
 
 // 8 consecutive output columns of one row: the whole fused epilogue on fp32 values, one rounding to bf16.
 // EPI: 0 bias | 1 bias + GELU, GELU'(x) -> pre | 2 x aux | 3 bias + dropout + residual | 4 bias + residual | 5 bias + ReLU |
-//      6 bias + dropout + LayerNorm-residual | 7 bias + LayerNorm-residual  (residual = LN output re-materialised in fp32 from the
+//      6 bias + dropout + LayerNorm-residual | 7 bias + LayerNorm-residual | 8 relu(bias + residual) | 10 acc where aux > 0  (residual = LN output re-materialised in fp32 from the
 //      fp16 pre-LN rows in `side`, the row's (mean, rstd) in `ms` and gamma / beta of the thread's 8 columns in g8 / be8)
 template <int EPI>
 __device__ __forceinline__ void p8_epilogue8(const GemmParams& p, float (&v)[8], const float (&b8)[8], int m, int n, uint32_t seed,
@@ -113,9 +113,18 @@ __device__ __forceinline__ void p8_epilogue8(const GemmParams& p, float (&v)[8],
       for (int e = 0; e < 8; ++e) v[e] = vlb_keep(seed, p.tag, idx + e, p.drop_thr) ? v[e] * p.drop_scale : 0.f;
     }
   }
-  if (EPI == 3 || EPI == 4) {
+  if (EPI == 3 || EPI == 4 || EPI == 8) {
     v[0] += bflo(side.x); v[1] += bfhi(side.x); v[2] += bflo(side.y); v[3] += bfhi(side.y);
     v[4] += bflo(side.z); v[5] += bfhi(side.z); v[6] += bflo(side.w); v[7] += bfhi(side.w);
+  }
+  if (EPI == 8) {            // Bottleneck tail (common/backbone/resnet/resnet.py:112-116): relu(conv + shift + residual)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+  }
+  if (EPI == 10) {           // ReLU backward on a gradient: acc where the saved activation aux > 0
+    const float a[8] = {bflo(side.x), bfhi(side.x), bflo(side.y), bfhi(side.y), bflo(side.z), bfhi(side.z), bflo(side.w), bfhi(side.w)};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = a[e] > 0.f ? v[e] : 0.f;
   }
   if (EPI == 6 || EPI == 7) {
     const float z[8] = {hlo(side.x), hhi(side.x), hlo(side.y), hhi(side.y), hlo(side.z), hhi(side.z), hlo(side.w), hhi(side.w)};
@@ -139,7 +148,9 @@ __device__ __forceinline__ float p8_epilogue1(const GemmParams& p, float v, int 
     v = fmaxf(v, 0.f);
   }
   if (EPI == 3 || EPI == 6) v = vlb_keep(seed, p.tag, (uint32_t)m * (uint32_t)p.N + (uint32_t)n, p.drop_thr) ? v * p.drop_scale : 0.f;
-  if (EPI == 3 || EPI == 4) v += bf2f(p.res[(long)m * p.ldres + n]);
+  if (EPI == 3 || EPI == 4 || EPI == 8) v += bf2f(p.res[(long)m * p.ldres + n]);
+  if (EPI == 8) v = fmaxf(v, 0.f);
+  if (EPI == 10) v = bf2f(p.aux[(long)m * p.ldaux + n]) > 0.f ? v : 0.f;
   if (EPI == 6 || EPI == 7)
     v += fmaf((h2f(p.res[(long)m * p.ldres + n]) - p.res_stats[2 * (long)m]) * p.res_stats[2 * (long)m + 1], p.res_gamma[n], p.res_beta[n]);
   return v;
@@ -162,7 +173,7 @@ __device__ __forceinline__ void p8_drain(const GemmParams& p, f32x4 (&acc)[2 * F
   constexpr int FPR = ALT ? 1 : KF;
   constexpr int ROUNDS = ALT ? 2 * NF : (NF + FPR - 1) / FPR;
   constexpr int PASSES = ALT ? 1 : 2 * FPR;
-  constexpr bool SIDE = (EPI == 2 || EPI == 3 || EPI == 4 || EPI == 6 || EPI == 7);
+  constexpr bool SIDE = (EPI == 2 || EPI == 3 || EPI == 4 || EPI == 6 || EPI == 7 || EPI == 8 || EPI == 10);
   constexpr bool PRE_NEXT = SIDE && (PASSES <= 2);      // request the next round's side data one round ahead
   // side rows requested at a time (register budget: 160 accumulators + gamma / beta / bias vectors leave room for 2-4 of them)
   constexpr int SB = PRE_NEXT ? PASSES : (FMH == 5 ? 4 : PASSES);
@@ -218,7 +229,7 @@ __device__ __forceinline__ void p8_drain(const GemmParams& p, f32x4 (&acc)[2 * F
     if constexpr (SIDE) {
       const int m = row_of(r, pp);
       if (frag_valid(r, pp) && m < p.M && full8) {
-        if (EPI == 2) sd = *(const uint4*)(p.aux + (long)m * p.ldaux + n);
+        if (EPI == 2 || EPI == 10) sd = *(const uint4*)(p.aux + (long)m * p.ldaux + n);
         else sd = *(const uint4*)(p.res + (long)m * p.ldres + n);
       }
     }
@@ -583,7 +594,9 @@ int p8_launch_epi(GemmParams& p, int epi, int group, hipStream_t stream) {
     case 4: return p8_launch<FMH, 4, KEEPB>(p, group, stream);
     case 5: return p8_launch<FMH, 5, KEEPB>(p, group, stream);
     case 6: return p8_launch<FMH, 6, KEEPB>(p, group, stream);
-    default: return p8_launch<FMH, 7, KEEPB>(p, group, stream);
+    case 7: return p8_launch<FMH, 7, KEEPB>(p, group, stream);
+    case 8: return p8_launch<FMH, 8, KEEPB>(p, group, stream);
+    default: return p8_launch<FMH, 10, KEEPB>(p, group, stream);
   }
 }
 
@@ -654,12 +667,14 @@ int vlb_gemm_p8_try(GemmParams& p, hipStream_t stream) {
   else if (p.act == 4) epi = 1;
   else if (p.act == 5) epi = 2;
   else if (p.act == 2) epi = 5;
+  else if (p.act == 7 && p.res && !p.drop_thr) epi = 8;        // relu(acc + bias + res): the Bottleneck forward tail (vision path)
+  else if (p.act == 8 && !p.res && !p.drop_thr) epi = 10;      // acc where aux > 0: ReLU backward in a dgrad epilogue
   else epi = -1;
   if (epi < 0) return 0;
   // 16-B vector accesses on every side tensor; 31-bit byte offsets inside A and B
   if ((p.ldc % 8) || !aligned16(p.C) || (p.lda % 8) || (p.ldb % 8) || !aligned16(p.A) || !aligned16(p.B)) return 0;
   if (p.res && ((p.ldres % 8) || !aligned16(p.res))) return 0;
-  if (epi == 2 && ((p.ldaux % 8) || !aligned16(p.aux))) return 0;
+  if ((epi == 2 || epi == 10) && ((p.ldaux % 8) || !aligned16(p.aux))) return 0;
   if (epi == 1 && p.pre && ((p.ldpre % 8) || !aligned16(p.pre))) return 0;
   if (p.bias && ((uintptr_t)p.bias & 15)) return 0;
   if (p.res_stats && (((uintptr_t)p.res_gamma & 15) || ((uintptr_t)p.res_beta & 15) || ((uintptr_t)p.res_stats & 7))) return 0;
