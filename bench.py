@@ -96,6 +96,178 @@ def cpu_baseline_e2e(cfg_kw, T, R, image_size, vlbert):
                       % (image_size[0], image_size[1], R, best, vlbert["sample"])}
 
 
+def vcr_config(large=True, num_layers=101):
+    """cfgs/vcr/large_q2a_4x16G_fp16.yaml as the attribute tree the module mirror reads (NETWORK.*)."""
+    class A(dict):
+        __getattr__ = dict.__getitem__
+    H, L, nh, I = (1024, 24, 16, 4096) if large else (768, 12, 12, 3072)
+    return A(NETWORK=A(IMAGE_FEAT_PRECOMPUTED=False, IMAGE_SEMANTIC=False, IMAGE_STRIDE_IN_1x1=True, IMAGE_C5_DILATED=True,
+                       IMAGE_NUM_LAYERS=num_layers, OUTPUT_CONV5=False, IMAGE_FROZEN_BN=True, IMAGE_FROZEN_BACKBONE_STAGES=[1, 2],
+                       IMAGE_FINAL_DIM=H, BLIND=False, NO_GROUNDING=False, NO_OBJ_ATTENTION=False, ANSWER_FIRST=False, QA_ONE_SENT=False,
+                       FOR_MASK_VL_MODELING_PRETRAIN=False, ENABLE_CNN_REG_LOSS=True, CNN_LOSS_TOP=True, CNN_REG_DROPOUT=0.0,
+                       CNN_LOSS_WEIGHT=1.0, ANS_LOSS_WEIGHT=1.0, CLASSIFIER_TYPE="1fc", CLASSIFIER_HIDDEN_SIZE=1024,
+                       CLASSIFIER_DROPOUT=0.1, CLASSIFIER_SIGMOID=True, CLASSIFIER_SIGMOID_LOSS_POSITIVE_WEIGHT=1.0,
+                       VLBERT=A(hidden_size=H, visual_size=H, num_hidden_layers=L, num_attention_heads=nh, intermediate_size=I,
+                                vocab_size=30522, max_position_embeddings=512, type_vocab_size=3, visual_ln=True, with_pooler=True,
+                                hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, initializer_range=0.02,
+                                visual_scale_text_init=0.0, visual_scale_object_init=0.0, object_word_embed_mode=2)))
+
+
+def vcr_batch(B, C, R, Lq, La, Hi, Wi, seed, device):
+    """One collated VCR micro-batch (vcr/data/collate_batch.py layout): image, boxes [B,R,5] (x1,y1,x2,y2,class; box 0 = the whole image),
+    object masks [B,R,14,14], question [B,Lq,2] / answer_choices [B,C,La,2] = (token id, object tag), answer_label [B], im_info."""
+    g = torch.Generator().manual_seed(seed)
+    image = torch.randn(B, 3, Hi, Wi, generator=g) * 50.0
+    x1 = torch.rand(B, R, generator=g) * (Wi - 200)
+    y1 = torch.rand(B, R, generator=g) * (Hi - 200)
+    w = 30 + torch.rand(B, R, generator=g) * 160
+    h = 30 + torch.rand(B, R, generator=g) * 160
+    boxes = torch.stack((x1, y1, x1 + w, y1 + h, torch.randint(1, 81, (B, R), generator=g).float()), -1)
+    boxes[:, 0] = torch.tensor([0.0, 0.0, Wi - 1.0, Hi - 1.0, 0.0])
+    masks = (torch.rand(B, R, 14, 14, generator=g) < 0.7).float()
+    question = torch.zeros((B, Lq, 2), dtype=torch.int64)
+    question[:, :, 0] = torch.randint(1000, 30522, (B, Lq), generator=g)
+    question[:, :, 1] = torch.randint(-1, R, (B, Lq), generator=g)
+    answers = torch.zeros((B, C, La, 2), dtype=torch.int64)
+    answers[..., 0] = torch.randint(1000, 30522, (B, C, La), generator=g)
+    answers[..., 1] = torch.randint(-1, R, (B, C, La), generator=g)
+    label = torch.randint(0, C, (B,), generator=g)
+    im_info = torch.tensor([[Wi, Hi, 1.0, 1.0, float(i)] for i in range(B)])
+    return [t.to(device) for t in (image, boxes, masks, question, answers, label, im_info)]
+
+
+def bench_vcr(args):
+    """BASELINE config 5: one optimizer step = 4 accumulated micro-batches of 4 samples x 4 answer choices (16 sequences of 256
+    positions through the 24 x 1024 encoder + 4 images of 600x1000 through the ResNet-101 path), clip_grad_norm_ 10, SGD momentum."""
+    ops = importlib.import_module("vl-bert_amd.ops")
+    lib = importlib.import_module("vl-bert_amd._lib")
+    M = importlib.import_module("vl-bert_amd.vcr.modules.resnet_vlbert_for_vcr")
+    OPT = importlib.import_module("vl-bert_amd.optim")
+    arch, cus = lib.device_info(0)
+    dev = torch.device("cuda:0")
+    B, C, R, Lq, La, accum = 4, 4, 55, 80, 117, 4                 # T = Lq + La + 3 = 200 text positions, S = T + R + 1 = 256
+    Hi, Wi = args.image_size
+    torch.manual_seed(0)
+    net = M.ResNetVLBERT(vcr_config(), device=dev)
+    with torch.no_grad():                                          # the shipped init leaves the visual LayerNorm gains at 0: open the visual path
+        for n, p in net.named_parameters():
+            if n.endswith("visual_ln_text.weight") or n.endswith("visual_ln_object.weight"):
+                p.fill_(1.0)
+    net.train()
+    opt = OPT.FusedSGD(net.parameters(), lr=7.0e-5 * B * accum, momentum=0.9, weight_decay=1e-4)
+    batches = [vcr_batch(B, C, R, Lq, La, Hi, Wi, 500 + i, dev) for i in range(accum)]
+
+    def step():
+        opt.zero_grad(set_to_none=False)
+        total = 0.0
+        for image, boxes, masks, question, answers, label, im_info in batches:
+            outputs, loss = net.train_forward(image, boxes, masks, question, None, answers, None, label, im_info)
+            (loss / accum).backward()
+            total = loss.detach()
+        torch.nn.utils.clip_grad_norm_(net.parameters(), 10.0)
+        opt.step()
+        return total
+
+    for _ in range(max(1, args.warmup)):
+        last = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ms = elapsed / args.steps * 1e3
+    value = B * accum / (elapsed / args.steps)
+
+    # roofline of the dominant kernels (the bf16 MFMA GEMM launches of one optimizer step), as in the pre-training bench
+    rec = []
+    names = ("gemm_nt", "gemm_nt_splitk", "wgrad_nt", "wgrad_tn")
+    orig = {n: getattr(ops, n) for n in names}
+
+    def timed(name):
+        fn = orig[name]
+
+        def wrapper(A, Bm, Cm, *a, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(A, Bm, Cm, *a, **kw)
+            e1.record()
+            K = A.shape[0] if name == "wgrad_tn" else A.shape[1]
+            rec.append((e0, e1, 2.0 * Cm.shape[0] * Cm.shape[1] * K))
+            return out
+        return wrapper
+    orig_group = ops.wgrad_tn_group
+
+    def timed_group(items, *a, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = orig_group(items, *a, **kw)
+        e1.record()
+        rec.append((e0, e1, sum(2.0 * dy.shape[0] * dy.shape[1] * x.shape[1] for dy, x, _, _ in items)))
+        return out
+    for n in names:
+        setattr(ops, n, timed(n))
+    ops.wgrad_tn_group = timed_group
+    hs_a = torch.zeros((8192, 4096), dtype=torch.bfloat16, device=dev)
+    hs_b = torch.zeros((4096, 8192), dtype=torch.bfloat16, device=dev)
+    hs_c = torch.empty((8192, 8192), dtype=torch.bfloat16, device=dev)
+    for _ in range(args.head_start * 4):
+        torch.mm(hs_a, hs_b, out=hs_c)
+    step()
+    torch.cuda.synchronize()
+    for n in names:
+        setattr(ops, n, orig[n])
+    ops.wgrad_tn_group = orig_group
+    gemm_ms = sum(r[0].elapsed_time(r[1]) for r in rec)
+    achieved = sum(r[2] for r in rec) / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    out = {
+        "metric": "samples/sec VL-BERT-large VCR Q->A fine-tuning step (4 answer choices, 256-position sequences, ResNet-101 image path, "
+                  "SGD, gradient accumulation 4)",
+        "value": round(value, 2), "unit": "samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+        "data": "synthetic (random-init weights, random images / boxes / masks / tokens / tags, resident in HBM)",
+        "config": {"workload": "BASELINE config 5 through the module mirror vl-bert_amd/vcr (cfgs/vcr/large_q2a_4x16G_fp16.yaml): 24 x 1024 encoder, "
+                               "%d samples x %d choices per micro-batch, %d text + %d regions + END = %d positions, %dx%d images, "
+                               "1fc sigmoid classifier + top-of-BERT CNN regulariser, clip 10, SGD momentum 0.9, %d micro-batches per "
+                               "optimizer step; a step = one optimizer step" % (B, C, Lq + La + 3, R, Lq + La + 3 + R + 1, Hi, Wi, accum),
+                   "global_batch": B * accum, "per_gpu_batch": B * accum, "seq_len": Lq + La + 3 + R + 1, "parallelism": "dp1",
+                   "arch": arch, "cus": cus},
+        "roofline": {"bound": "mfma", "kernel": "all %d bf16 GEMM launches of one optimizer step (encoder: large-tile NT / TN cores; vision path: "
+                                               "implicit-GEMM convolutions)" % len(rec),
+                     "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+                     "traffic": None, "gemm_ms_per_step": round(gemm_ms, 3), "gemm_share_of_step": round(gemm_ms / ms, 3)},
+        "loss": round(float(last), 4),
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_vcr(Lq, La, R, (Hi, Wi))
+    print(json.dumps(out), flush=True)
+
+
+def cpu_baseline_vcr(Lq, La, R, image_size):
+    """the pinned VCR oracle (oracle/vcr_oracle.py + vision_oracle.py: the restatement of the reference's own VCR module) on this box's
+    host cores: forward + backward of ONE sample (4 choices, same sequence length, one 600x1000 image), bounded sample."""
+    from oracle import vcr_oracle as VC
+    from oracle import vision_oracle as VO
+    from oracle import vlbert_oracle as O
+    cores = min(os.cpu_count() or 1, 64)
+    torch.set_num_threads(cores)
+    cfg = O.VLBertConfig(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096, with_pooler=True)
+    params = VC.init_vcr_params(cfg, 3, classifier="1fc", embed_mode=2, cnn_reg_top=True)
+    P = VO.init_vision_params(4, 101)
+    frozen = VO.frozen_names(P)
+    image, boxes, masks, question, answers, label, im_info = vcr_batch(1, 4, R, Lq, La, image_size[0], image_size[1], 600, "cpu")
+    leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    Po = {k: v.clone().requires_grad_(k not in frozen) for k, v in P.items()}
+    t0 = time.time()
+    out, loss = VC.vcr_forward(leaves, cfg, image, boxes, masks, question, answers, label, im_info, Po, 101, classifier="1fc",
+                               classifier_dropout=0.1, sigmoid=True, cnn_reg_top=True, train=True)
+    loss.backward()
+    t = time.time() - t0
+    return {"value": round(1.0 / t, 4), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": "VCR oracle fwd+bwd, 1 sample x 4 choices, 256 positions, one %dx%d image through ResNet-101, fp32, dropout on, 1 iteration"
+                      % image_size}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -109,6 +281,9 @@ def main():
                     "ResNetVLBERTForPretrainingMultitask).  Default: 8 with --e2e (TRAIN.BATCH_IMAGES [8, 8] of the shipped yaml), else 0")
     ap.add_argument("--large", action="store_true", help="VL-BERT-large shape of BASELINE.json configs 4-5 through the same pretraining step: "
                     "24 layers, hidden 1024, 16 heads, FFN 4096, 128 text + 100 regions (S = 229); default global batch 64")
+    ap.add_argument("--vcr", action="store_true", help="BASELINE config 5 through the module mirror (vl-bert_amd/vcr): VL-BERT-large VCR Q->A, 4 answer "
+                    "choices, sequences of 256 positions, ResNet-101 image path with object masks, SGD momentum 0.9, gradient accumulation 4 "
+                    "(cfgs/vcr/large_q2a_4x16G_fp16.yaml: 4 samples per GPU per micro-batch); one GPU; a step = one OPTIMIZER step")
     ap.add_argument("--layers", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--head-start", type=int, default=60, help="unrelated 0.55-TFLOP torch.mm launches queued ahead of the instrumented step (roofline)")
@@ -155,6 +330,11 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+
+    if args.vcr:
+        if world != 1:
+            raise SystemExit("--vcr runs the module mirror on one GPU (its data-parallel wrapper is the trainer's DDP, host glue that is not built)")
+        return bench_vcr(args)
 
     engine = importlib.import_module("vl-bert_amd.engine")
     syn = importlib.import_module("vl-bert_amd.synthetic")
