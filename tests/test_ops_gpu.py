@@ -390,6 +390,36 @@ def test_wgrad_tn_grouped_layer(ops, R, accumulate):
         report("grouped wgrad %d colsum" % k, db, rb, 1e-3, 2e-5)
 
 
+@pytest.mark.parametrize("R", [25856, 12928 + 128, 6528])
+def test_wgrad_tn_grouped_layer_uneven_cut(ops, R):
+    """The grouped launch at the encoder's row counts (batch 256 / 128 / 64): 108 tiles x 2 K slices leave 40 CUs idle, so the host cuts
+    every tile's K range in two long slices + a short remainder dealt to the spare workgroups (gemm_tn8.hip, Tn8Group).  Both cuts
+    against an fp32 torch.mm of the same bf16 operands, and against each other."""
+    from importlib import import_module
+    lib = import_module("vl-bert_amd._lib")
+    H, I = 768, 3072
+    shapes = [(H, I), (I, H), (H, H), (3 * H, H)]
+    ins = [(to_gpu_bf16(rnd(R, Mo, seed=60 + k, scale=0.5)), to_gpu_bf16(rnd(R, No, seed=70 + k, scale=0.2))) for k, (Mo, No) in enumerate(shapes)]
+    work = torch.empty(3 * sum(a * b for a, b in shapes) + 64, dtype=torch.float32, device=dev())
+    got = {}
+    try:
+        for uneven in (0, 1):
+            lib.gemm_set_option("tn8_uneven", uneven)
+            items = [(dY, X, torch.full((Mo, No), 0.5, dtype=torch.float32, device=dev()), torch.ones(Mo, dtype=torch.float32, device=dev()))
+                     for (dY, X), (Mo, No) in zip(ins, shapes)]
+            ops.wgrad_tn_group(items, workspace=work, accumulate=True)
+            got[uneven] = items
+    finally:
+        lib.gemm_set_option("tn8_uneven", 0)
+    for k, (dY, X) in enumerate(ins):
+        ref = 0.5 + dY.float().t() @ X.float()
+        refb = 1 + dY.float().sum(0)
+        for uneven in (0, 1):
+            report("grouped wgrad %d (R=%d, uneven=%d)" % (k, R, uneven), got[uneven][k][2], ref.cpu(), 1e-3, 2e-4)
+            report("grouped wgrad %d colsum (uneven=%d)" % (k, uneven), got[uneven][k][3], refb.cpu(), 1e-3, 2e-4)
+        report("grouped wgrad %d uneven vs equal cut" % k, got[1][k][2], got[0][k][2].cpu(), 1e-3, 2e-4)
+
+
 def test_gemm_dropout_and_ln_mask_agree(ops):
     """The GEMM-epilogue dropout mask and the LayerNorm-backward dx_drop mask are the same function."""
     M, N, K = 200, 256, 64

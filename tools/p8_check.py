@@ -228,6 +228,38 @@ def bench_wgrad(batch):
     print("TN ms per step (12 layers + compact decoder): %.2f | %.2f" % tuple(tot), flush=True)
 
 
+def bench_wgrad_group(batch):
+    """grouped per-layer weight gradient (4 gradients, one launch): equal 2-slice cut vs the uneven 3-slice cut"""
+    R = (batch * 101 + 127) // 128 * 128
+    H, I = 768, 3072
+    shapes = [(H, I), (I, H), (H, H), (3 * H, H)]
+    items = []
+    for k, (Mo, No) in enumerate(shapes):
+        items.append((rnd(R, Mo, seed=30 + k).to(BF).to(D), rnd(R, No, seed=40 + k).to(BF).to(D),
+                      torch.zeros((Mo, No), dtype=torch.float32, device=D), torch.zeros(Mo, dtype=torch.float32, device=D)))
+    work = torch.empty(3 * sum(a * b for a, b in shapes) + 64, dtype=torch.float32, device=D)
+    flops = 2.0 * R * sum(a * b for a, b in shapes)
+    outs = []
+    for uneven in (0, 1, 0, 1):
+        lib.gemm_set_option("tn8_uneven", uneven)
+        run = lambda: ops.wgrad_tn_group(items, workspace=work, accumulate=False)
+        for _ in range(3):
+            run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 20
+        outs.append([t[2].clone() for t in items])
+        print("grouped wgrad batch %d R %d uneven %d: %7.1f us %6.0f TFLOP/s (incl. slab reduce)" % (batch, R, uneven, ms * 1e3, flops / ms / 1e9),
+              flush=True)
+    for a, b in zip(outs[0], outs[1]):
+        print("  |uneven - equal| max %.3e scale %.3e" % (float((a - b).abs().max()), float(a.abs().max())))
+    lib.gemm_set_option("tn8_uneven", 0)
+
+
 def check_ring():
     """ring kernels (nt_ring 2: 128x128 / 4 stages, 3: 128x64 / 3 stages) against the two-stage kernel and torch fp32"""
     seed_t = torch.tensor([12345], dtype=torch.int32, device=D)
@@ -329,6 +361,10 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "check":
         sys.exit(1 if check() else 0)
+    if len(sys.argv) > 1 and sys.argv[1] == "wgradgroup":
+        for b in [int(x) for x in sys.argv[2:]] or [256]:
+            bench_wgrad_group(b)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "wgrad":
         bench_wgrad(int(sys.argv[2]) if len(sys.argv) > 2 else 256)
         sys.exit(0)

@@ -646,6 +646,10 @@ extern "C" int vlb_gemm_set_option(const char* name, int value) {
     vlb_tn8_set_wgs(value);
     return VLB_OK;
   }
+  if (!strcmp(name, "tn8_uneven")) {
+    vlb_tn8_set_uneven(value);
+    return VLB_OK;
+  }
   for (int i = 0; i < 7; ++i)
     if (!strcmp(name, g_opt_name[i])) {
       g_opt[i] = value;

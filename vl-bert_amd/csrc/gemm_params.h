@@ -53,3 +53,4 @@ void vlb_nt_set_stagger(int v);
 void vlb_nt_set_ring(int v);
 void vlb_tn8_set_mode(int v);
 void vlb_tn8_set_wgs(int v);
+void vlb_tn8_set_uneven(int v);

@@ -55,12 +55,20 @@ struct Tn8Desc {
   int ntm, ntn, tile_group;
   int nsplit, kt_per_split;             // K slices and 64-row K tiles per slice (even)
   int item0, nitems;                    // position in the launch's item list
+  int short0;                           // uneven mode: position of this gradient's remainder slices in the short list
   int accumulate;                       // direct output (nsplit == 1): C += instead of C =
 };
 constexpr int TN8_MAX_GROUP = 4;
+// Uneven mode (nlong > 0): with T tiles and 2 T <= 256 < 3 T, two equal K slices leave 256 - 2 T CUs idle (216 items for 256 CUs at
+// the encoder's shapes: 16 % of the chip).  Every tile's K range is then cut in THREE: two long slices of kt_per_split K tiles --
+// the first nlong = 2 T items, one per workgroup -- and a short remainder; the T remainders are shared by the other workgroups
+// (k = ceil(T / (grid - nlong)) each).  With L chosen so that L ~ k x remainder the makespan drops from 101 to 87 K-tile pairs at
+// batch 256 (-14 %) for one more slab per tile.  OFF by default: on the GPU the launch is not faster (the 40 idle CUs leave the
+// other 216 more fabric bandwidth and clock; the third slab costs 57 MB of extra traffic per layer) -- see DESIGN.md.
 struct Tn8Group {
   Tn8Desc d[TN8_MAX_GROUP];
   int n, nitems;
+  int nlong;
 };
 
 __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(const Tn8Group grp) {
@@ -81,18 +89,31 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(const Tn8Group grp) {
   // CONTIGUOUS run of the list, i.e. tiles of the same gradient and K slice that share operand panels in that XCD's L2.  (The plain
   // w -> t = w order spread neighbouring tiles over all 8 L2s: the profile showed 3.1x the algorithmic bytes on the fabric,
   // 6.6 TB/s -- the kernel was memory-bound.)
+  const int nlong = grp.nlong;
+  auto xcd_order = [](int w, int n) {      // position of work item w (w & 7 = its XCD) when every XCD owns a contiguous run of n items
+    const int xcd = w & 7, q = n >> 3, r = n & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (w >> 3);
+  };
   auto item_of = [&](int w, int& gi, int& m0, int& n0, int& kt0, int& nk) {
-    {
-      const int xcd = w & 7, q = nitems >> 3, r = nitems & 7;
-      w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (w >> 3);
-    }
+    int sp, t;
     gi = 0;
+    if (nlong > 0 && w >= nlong) {          // a remainder slice (uneven mode): short list, tile-major per gradient
+      const int vs = xcd_order(w - nlong, nitems - nlong);
 #pragma unroll
-    for (int q = 1; q < TN8_MAX_GROUP; ++q)
-      if (q < grp.n && w >= grp.d[q].item0) gi = q;
+      for (int q = 1; q < TN8_MAX_GROUP; ++q)
+        if (q < grp.n && vs >= grp.d[q].short0) gi = q;
+      sp = 2;
+      t = vs - grp.d[gi].short0;
+    } else {
+      w = xcd_order(w, nlong > 0 ? nlong : nitems);
+#pragma unroll
+      for (int q = 1; q < TN8_MAX_GROUP; ++q)
+        if (q < grp.n && w >= grp.d[q].item0) gi = q;
+      const int wl = w - grp.d[gi].item0, ntile = grp.d[gi].ntm * grp.d[gi].ntn;
+      sp = wl / ntile;
+      t = wl - sp * ntile;
+    }
     const Tn8Desc& d = grp.d[gi];
-    const int wl = w - d.item0, ntile = d.ntm * d.ntn;
-    const int sp = wl / ntile, t = wl - sp * ntile;
     const int gm = d.tile_group, per_group = gm * d.ntn, gid = t / per_group, first = gid * gm;
     const int gsz = min(d.ntm - first, gm), rem = t - gid * per_group;
     m0 = (first + rem % gsz) * 256;
@@ -100,6 +121,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(const Tn8Group grp) {
     kt0 = sp * d.kt_per_split;
     nk = min((d.R >> 6) - kt0, d.kt_per_split);       // even, >= 2 (host guarantees)
   };
+  // this workgroup's walk through the item list: w = b, b + step, ...  (uneven mode: a long item is the only one of its workgroup,
+  // the remainders are dealt round-robin to the workgroups behind the long ones)
+  const int step = (nlong > 0) ? ((int)blockIdx.x < nlong ? (1 << 30) : (int)gridDim.x - nlong) : (int)gridDim.x;
 
   // ---------------- producer ----------------
   // chunk P = it*512 + tid of a half-image: row = P >> 4 = it*32 + (tid >> 4), physical 16-B chunk c = P & 15; physical 32-B block
@@ -144,7 +168,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(const Tn8Group grp) {
     if (!live) return;
     if (++kt_p == nk_p) {
       kt_p = 0;
-      w_p += gridDim.x;
+      w_p = (step >= (1 << 30)) ? nitems : w_p + step;
       if (w_p < nitems) setup(w_p);
       else live = false;
     }
@@ -247,7 +271,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(const Tn8Group grp) {
   if (wm == 1) tn8_barrier();
 
   int gk = 0;      // K tiles consumed by this workgroup so far
-  for (int w = blockIdx.x; w < nitems; w += gridDim.x) {
+  for (int w = blockIdx.x; w < nitems; w = (step >= (1 << 30)) ? nitems : w + step) {
     int gi, m0, n0, kt0, nk;
     item_of(w, gi, m0, n0, kt0, nk);
     float* const colsum = grp.d[gi].colsum;
@@ -316,9 +340,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(const Tn8Group grp) {
     // (no LDS involved: the operand stream of the next item keeps landing; the wave groups need no re-alignment)
     {
       const Tn8Desc& d = grp.d[gi];
-      const int xcd_ = w & 7, q_ = nitems >> 3, r_ = nitems & 7;
-      const int t_ = (xcd_ < r_ ? xcd_ * (q_ + 1) : r_ * (q_ + 1) + (xcd_ - r_) * q_) + (w >> 3);
-      const int sp = (t_ - d.item0) / (d.ntm * d.ntn);
+      const int sp = kt0 / d.kt_per_split;      // kt0 = slice x kt_per_split in both item lists
       float* const C = d.C + (long)sp * d.c_split_stride;
       const bool accum = d.accumulate != 0;
       const int Mo = d.Mo, No = d.No;
@@ -371,8 +393,11 @@ int env_int(const char* name, int dflt) {
 
 static int g_tn8_mode = -1;      // VLB_GEMM_TN8 (0: 128x128 TN kernel only); run-time override: vlb_gemm_set_option("tn8_mode", v)
 void vlb_tn8_set_mode(int v) { g_tn8_mode = v; }
+static int g_tn8_uneven = -1;   // VLB_GEMM_TN8_UNEVEN: 1 = the uneven three-slice cut of grouped launches; 0 (default) equal slices --
+                                 // measured: no gain at batch 256 (21.07 vs 21.02 ms / step), 5-10 % slower launches at batch 64 / 32
 static int g_tn8_wgs = -1;       // VLB_GEMM_TN8_WGS: persistent workgroups per launch (default 256 = one per CU)
 void vlb_tn8_set_wgs(int v) { g_tn8_wgs = v; }
+void vlb_tn8_set_uneven(int v) { g_tn8_uneven = v; }
 
 // K slices for a [Mo, No] gradient over R rows: fill the 256 CUs (one workgroup each) in whole rounds; a slice is a whole number of
 // 128-row units.  Cost model: rounds x (slice length + fixed cost per item) + slab traffic.
@@ -482,11 +507,28 @@ int vlb_gemm_tn8_group(int n, const void* const* A, const long* lda, const void*
   if (splits < 1) splits = 1;
   if (splits > pairs) splits = pairs;
   if (tiles * splits < 128) return 0;
-  const int per = vlb_cdiv(pairs, splits);
+  int per = vlb_cdiv(pairs, splits);
   splits = vlb_cdiv(pairs, per);
+  // uneven three-way cut (see Tn8Group): two long slices of L pairs per tile, one workgroup each, and a remainder of pairs - 2 L
+  // shared by the 256 - 2 T spare workgroups, k = ceil(T / spare) remainders each; L minimises max(L, k x remainder)
+  if (g_tn8_uneven < 0) g_tn8_uneven = env_int("VLB_GEMM_TN8_UNEVEN", 0);
+  int nlong = 0;
+  long slab_floats = 0;
+  for (int i = 0; i < n; ++i) slab_floats += (long)Mo[i] * ((No[i] + 3) / 4 * 4);
+  if (g_tn8_wgs < 0) g_tn8_wgs = env_int("VLB_GEMM_TN8_WGS", 256);
+  if (g_tn8_uneven && splits == 2 && 2 * tiles < 256 && workspace && 3 * slab_floats <= workspace_floats && g_tn8_wgs == 256) {
+    const int spare = 256 - 2 * (int)tiles, k = vlb_cdiv((int)tiles, spare);
+    const int L = vlb_cdiv(k * pairs, 2 * k + 1), rem = pairs - 2 * L;
+    const int makespan = L > k * rem ? L : k * rem;
+    if (rem >= 1 && L >= 1 && makespan * 100 <= per * 95) {      // worth a third slab per tile only for >= 5 %
+      nlong = 2 * (int)tiles;
+      per = L;
+      splits = 3;
+    }
+  }
   Tn8Group grp = {};
   long off = 0;
-  int item = 0;
+  int item = 0, sitem = 0;
   for (int i = 0; i < n; ++i) {
     Tn8Desc& d = grp.d[i];
     const long ldw = (No[i] + 3) / 4 * 4;
@@ -494,8 +536,11 @@ int vlb_gemm_tn8_group(int n, const void* const* A, const long* lda, const void*
     d.lda = (int)lda[i]; d.ldb = (int)ldb[i]; d.Mo = Mo[i]; d.No = No[i]; d.R = R;
     d.ntm = vlb_cdiv(Mo[i], 256); d.ntn = vlb_cdiv(No[i], 256); d.tile_group = tile_group_for(d.ntm, d.ntn);
     d.nsplit = splits; d.kt_per_split = per * 2;
-    d.item0 = item; d.nitems = d.ntm * d.ntn * splits;
+    const int ntile = d.ntm * d.ntn;
+    d.item0 = item; d.nitems = ntile * (nlong ? 2 : splits);      // (uneven: the two long slices; the remainders follow all of them)
+    d.short0 = sitem;
     item += d.nitems;
+    sitem += ntile;
     if (splits > 1) {
       d.C = workspace + off; d.ldc = (int)ldw; d.c_split_stride = (long)Mo[i] * ldw; d.accumulate = 0;
       ws_off[i] = off;
@@ -506,6 +551,8 @@ int vlb_gemm_tn8_group(int n, const void* const* A, const long* lda, const void*
     }
     slices[i] = splits;
   }
+  if (nlong) item += sitem;
+  grp.nlong = nlong;
   if (splits > 1 && (!workspace || off > workspace_floats)) return 0;
   grp.n = n; grp.nitems = item;
   const int rc = tn8_launch(grp, stream);

@@ -361,8 +361,9 @@ class PretrainEngine:
         need = [ops.wgrad_workspace_floats(n, k, rp) for n, k, rp in
                 ((3 * H, H, self.Mp), (H, H, self.Mp), (I, H, self.Mp), (H, I, self.Mp), (V, H, self.BTp), (H, H, self.BTp),
                  (C, H, self.BRp), (H, H, self.BRp), (H, 2 * VIS_DIM, self.BRp))]
-        need.append(ops.wgrad_workspace_floats(self.BT, H, self.Vp))     # tied-decoder dgrad (K = vocabulary) at small batch
-        need.append(2 * (3 * H * H + H * H + 2 * I * H) + 64)             # grouped launch of a layer's four gradients, 2 K slices
+        need_dec = ops.wgrad_workspace_floats(self.BT, H, self.Vp)       # tied-decoder dgrad (K = vocabulary) at small batch
+        need.append(need_dec)
+        need.append(3 * (3 * H * H + H * H + 2 * I * H) + 64)             # grouped launch of a layer's four gradients, <= 3 K slices
         self.wg_ws = zf(max(max(need), 4))
         # Weight gradients run on a second stream: they only feed the optimizer, while the dgrad chain is the critical
         # path, and at small per-GPU batch neither fills the chip (312 + 432 workgroups for 512 slots at B = 32).
@@ -371,7 +372,7 @@ class PretrainEngine:
         # next writer -- a full layer later thanks to the dD / dDb double buffer).  VLB_WGRAD_STREAM=0 serialises.
         import os as _os
         self.side = torch.cuda.Stream(device=d) if (d.type == "cuda" and _os.environ.get("VLB_WGRAD_STREAM", "1") != "0") else None
-        self.wg_ws_main = zf(max(need[-1], 4)) if self.side is not None else self.wg_ws    # decoder dgrad split-K (main stream)
+        self.wg_ws_main = zf(max(need_dec, 4)) if self.side is not None else self.wg_ws    # decoder dgrad split-K (main stream)
         self._pending = {}
         self.ln_ws = zf(ops.ln_bwd_workspace_floats(H))     # per-workgroup partial dgamma/dbeta sums of the LayerNorm backward
         # The encoder's LayerNorm backwards (2 per layer + the MLM head's) leave their partial sums in a workspace slice of their
