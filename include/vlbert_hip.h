@@ -327,6 +327,15 @@ int vlb_roi_align_nhwc_fwd(const void* feat, const float* boxes, long ldbox, int
 int vlb_roi_align_nhwc_bwd(const void* dout, const float* boxes, long ldbox, int boxes_per_image, float* dfeat, int K, int N,
                            int C, int H, int W, int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio,
                            vlb_stream_t stream);
+/* The same backward as a gather over the feature map (the form the engine uses): the bilinear weights factorise into a per-RoI
+ * [bins_h, H] and [bins_w, W] matrix (built in `workspace` by a first kernel from the forward's sampling arithmetic), one workgroup
+ * per feature pixel sums its RoIs' contributions -- no atomics, no zero-fill; every element of dx_bf16 [N,H,W,C] and / or dx_f32 is
+ * written.  act (optional, bf16 [N,H,W,C]): dx_bf16 = 0 where act <= 0 (the ReLU in front of ROIAlign, i.e. vlb_relu_mask_cast
+ * folded in).  K = N * boxes_per_image; C % 4 == 0; workspace: 16-byte aligned, vlb_roi_align_gather_workspace_bytes(K, ...). */
+long vlb_roi_align_gather_workspace_bytes(int K, int H, int W, int pooled_h, int pooled_w);
+int vlb_roi_align_nhwc_bwd_gather(const void* dout, const float* boxes, long ldbox, int boxes_per_image, const void* act,
+                                  void* dx_bf16, float* dx_f32, void* workspace, long workspace_bytes, int N, int C, int H, int W,
+                                  int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio, vlb_stream_t stream);
 /* dz (bf16) = g (fp32) where y (bf16) > 0 else 0; n % 8 == 0 */
 int vlb_relu_mask_cast(const float* g, const void* y, void* dz, long n, vlb_stream_t stream);
 /* AvgPool2d(14)+Flattener (common/fast_rcnn.py:80-84): y [K,P,C] bf16 -> out[k*ld + col0 + c] fp32 (the feature slots of

@@ -158,10 +158,43 @@ def test_roi_align_nhwc(ops, sr, C, H, W):
                            spatial_scale=1.0 / 16, sampling_ratio=sr)
     refb = torch.from_numpy(RA.roi_align_backward(dout[mask.view(-1)].numpy(), rois, 1.0 / 16, ph, ph, N, C, H, W, sr).astype(np.float32))
     report("roi_align nhwc bwd sr%d C%d %dx%d" % (sr, C, H, W), dfeat, nhwc(refb), 1e-4, 1e-4)
+    # the gather form (per-RoI separable weight tables, one owner per output element): fp32 output, and the bf16 output with the
+    # ReLU mask of the producing activation folded in (what VisionStack consumes)
+    ws = ops.roi_align_gather_workspace(N * R, H, W, ph, dev())
+    dout_g = to_gpu_bf16(dout.permute(0, 2, 3, 1).reshape(-1, C))
+    g32 = torch.full((N * H * W, C), 7.0, device=dev())
+    gbf = torch.full((N * H * W, C), 7.0, dtype=torch.bfloat16, device=dev())
+    act = rnd(N * H * W, C, seed=13)
+    ops.roi_align_nhwc_bwd_gather(dout_g, bx, R, ws, N, H, W, C, act=to_gpu_bf16(act), dx_bf16=gbf, dx_f32=g32, pooled=ph,
+                                  spatial_scale=1.0 / 16, sampling_ratio=sr)
+    report("roi_align nhwc bwd gather sr%d C%d %dx%d" % (sr, C, H, W), g32, nhwc(refb), 1e-4, 1e-4)
+    report("roi_align nhwc bwd gather bf16 + relu mask", gbf, nhwc(refb) * (bf(act) > 0), 1e-4, 4e-3)
 
 
+def test_roi_align_nhwc_backward_gather_matches_scatter_many_boxes(ops):
+    """More than 64 box slots per image (the gather kernel walks them in chunks of a wave), ragged padding, C not a multiple of 256."""
+    N, R, C, H, W, ph = 2, 70, 40, 12, 16, 7
+    g = torch.Generator().manual_seed(5)
+    x1 = torch.rand(N, R, generator=g) * (16 * W - 40) - 10
+    y1 = torch.rand(N, R, generator=g) * (16 * H - 40) - 10
+    boxes = torch.stack((x1, y1, x1 + 4 + torch.rand(N, R, generator=g) * 150, y1 + 4 + torch.rand(N, R, generator=g) * 120,
+                         torch.zeros(N, R)), -1)
+    boxes[0, 50:] = -2.0
+    boxes[1, 67:] = -2.0
+    bx = boxes.view(N * R, 5).contiguous().to(dev())
+    dout = to_gpu_bf16(torch.randn(N * R * ph * ph, C, generator=g))
+    for sr in (1, 2, 0):
+        ref = torch.zeros((N * H * W, C), device=dev())
+        ops.roi_align_nhwc_bwd(dout, bx, R, ref, N, H, W, C, pooled=ph, spatial_scale=1.0 / 16, sampling_ratio=sr)
+        got = torch.full((N * H * W, C), 3.0, device=dev())
+        ops.roi_align_nhwc_bwd_gather(dout, bx, R, ops.roi_align_gather_workspace(N * R, H, W, ph, dev()), N, H, W, C, dx_f32=got,
+                                      pooled=ph, spatial_scale=1.0 / 16, sampling_ratio=sr)
+        report("roi_align bwd gather vs atomic scatter, 70 slots, sr %d" % sr, got, ref.cpu(), 1e-4, 1e-4)
+
+
+@pytest.mark.parametrize("form", ["atomic", "gather"])
 @pytest.mark.parametrize("C,H,W", [(32, 9, 12), (64, 38, 63)])
-def test_roi_align_nhwc_backward_is_the_jacobian_transpose_of_the_hip_forward(ops, C, H, W):
+def test_roi_align_nhwc_backward_is_the_jacobian_transpose_of_the_hip_forward(ops, C, H, W, form):
     """The reference has no CPU ROIAlign backward (ROIAlign.h:44), so the backward oracle is only pinned through the adjoint of its own
     forward.  This test closes the loop on the DEVICE kernels themselves: ROIAlign is linear in the feature map, so the forward of a
     one-hot map IS a Jacobian column (exact finite difference), and the LDS-window backward (C % 32 == 0; 14x14 bins, the pre-training
@@ -177,7 +210,11 @@ def test_roi_align_nhwc_backward_is_the_jacobian_transpose_of_the_hip_forward(op
     dout_g = to_gpu_bf16(dout)
     dout_r = dout_g.float().cpu()
     dfeat = torch.zeros((N * H * W, C), device=dev())
-    ops.roi_align_nhwc_bwd(dout_g, bx, R, dfeat, N, H, W, C, pooled=ph, spatial_scale=1.0 / 16, sampling_ratio=1)
+    if form == "atomic":
+        ops.roi_align_nhwc_bwd(dout_g, bx, R, dfeat, N, H, W, C, pooled=ph, spatial_scale=1.0 / 16, sampling_ratio=1)
+    else:
+        ops.roi_align_nhwc_bwd_gather(dout_g, bx, R, ops.roi_align_gather_workspace(N * R, H, W, ph, dev()), N, H, W, C, dx_f32=dfeat,
+                                      pooled=ph, spatial_scale=1.0 / 16, sampling_ratio=1)
     torch.cuda.synchronize()
     dfeat_c = dfeat.cpu()
     out = torch.zeros((N * R * ph * ph, C), dtype=torch.bfloat16, device=dev())

@@ -69,6 +69,7 @@ _SIGS = {
     "vlb_upsample2_zero_nhwc": "ppiiiis",
     "vlb_roi_align_nhwc_fwd": "pplipiiiiiifis",
     "vlb_roi_align_nhwc_bwd": "pplipiiiiiiifis",
+    "vlb_roi_align_nhwc_bwd_gather": "pplippppliiiiiifis",
     "vlb_relu_mask_cast": "pppls",
     "vlb_avgpool_rows_fwd": "ppliiiiips",
     "vlb_avgpool_rows_bwd": "plpplpiiifpuuups",
@@ -110,6 +111,8 @@ def load():
     lib.vlb_layernorm_bwd_slabs.argtypes = [_I]
     lib.vlb_gemm_set_option.restype = _I
     lib.vlb_gemm_set_option.argtypes = [ctypes.c_char_p, _I]
+    lib.vlb_roi_align_gather_workspace_bytes.restype = _L
+    lib.vlb_roi_align_gather_workspace_bytes.argtypes = [_I, _I, _I, _I, _I]
     for name, sig in _SIGS.items():
         fn = getattr(lib, name)
         fn.restype = _I
@@ -120,7 +123,8 @@ def load():
 
 def exported_names():
     return ["vlb_last_error", "vlb_version", "vlb_device_info", "vlb_wgrad_workspace_floats",
-            "vlb_layernorm_bwd_workspace_floats", "vlb_layernorm_bwd_slabs", "vlb_gemm_set_option"] + sorted(_SIGS)
+            "vlb_layernorm_bwd_workspace_floats", "vlb_layernorm_bwd_slabs", "vlb_gemm_set_option",
+            "vlb_roi_align_gather_workspace_bytes"] + sorted(_SIGS)
 
 
 def gemm_set_option(name, value):

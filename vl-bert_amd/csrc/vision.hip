@@ -520,6 +520,185 @@ __global__ __launch_bounds__(256) void roi_align_nhwc_bwd_lds_kernel(const bf16_
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Backward as a GATHER over the feature map (the path the engine takes).  The bilinear weight of sample (iy, ix) of bin (ph, pw) on
+// pixel (py, px) is a product of a y-factor and an x-factor, the out-of-range test is an OR of a y- and an x-test, and the sum over
+// the sampling grid factorises, so
+//     dfeat[n, py, px, c] = sum_k  sum_ph Wy_k[ph, py]  sum_pw Wx_k[pw, px]  dout[k, ph, pw, c]
+// with two small dense matrices per RoI (Wy: [bins_h, H], Wx: [bins_w, W], 1 / grid folded in).  Pass 1 (one workgroup per RoI)
+// builds them from the SAME sampling arithmetic as the forward, plus per (RoI, row) / (RoI, column) the contiguous range of bins
+// with a non-zero weight (sample coordinates are monotonic in the bin index).  Pass 2: one workgroup per feature pixel, lanes over
+// channels (8 B each); lane j first fetches the ranges of RoI j, a ballot gives the RoIs that touch the pixel, and the wave walks
+// only those, 4 independent 8-B loads per step.  Every output element has exactly one owner: no atomics, no memset, and the
+// consumer's ReLU mask + bf16 cast (vlb_relu_mask_cast) is folded into the store.  288 RoIs x 14 x 14 x 1024 onto 8 x 38 x 63:
+// 1.21 ms (LDS-window atomics + memset + mask pass) -> see DESIGN.md.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void roi_axis_sample(float v, int size, int& lo, int& hi, float& wl, float& wh) {
+  // one axis of nhwc_sample(): lo / hi pixel and their weights; out of range -> weights 0
+  if (v < -1.0f || v > (float)size) { lo = hi = 0; wl = wh = 0.f; return; }
+  if (v <= 0.f) v = 0.f;
+  lo = (int)v;
+  if (lo >= size - 1) { hi = lo = size - 1; v = (float)lo; } else { hi = lo + 1; }
+  wh = v - (float)lo;
+  wl = 1.f - wh;
+}
+
+__global__ __launch_bounds__(128) void roi_axis_tables_kernel(const float* __restrict__ boxes, long ldbox, int H, int W, int ph_n, int pw_n,
+                                                              float scale, int sampling_ratio, float* __restrict__ Wy,
+                                                              float* __restrict__ Wx, unsigned short* __restrict__ yr,
+                                                              unsigned short* __restrict__ xr) {
+  const int k = blockIdx.x, tid = threadIdx.x;
+  float* wy = Wy + (long)k * ph_n * H;
+  float* wx = Wx + (long)k * pw_n * W;
+  for (int i = tid; i < ph_n * H; i += 128) wy[i] = 0.f;
+  for (int i = tid; i < pw_n * W; i += 128) wx[i] = 0.f;
+  __syncthreads();
+  const float* bx = boxes + (long)k * ldbox;
+  if (bx[0] > -1.5f) {
+    const float start_w = bx[0] * scale, start_h = bx[1] * scale, end_w = bx[2] * scale, end_h = bx[3] * scale;
+    const float rw = fmaxf(end_w - start_w, 1.f), rh = fmaxf(end_h - start_h, 1.f);
+    const float bin_h = rh / (float)ph_n, bin_w = rw / (float)pw_n;
+    const int grid_h = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rh / (float)ph_n);
+    const int grid_w = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rw / (float)pw_n);
+    for (int t = tid; t < ph_n + pw_n; t += 128) {       // one thread per bin row / bin column: no races on its table row
+      const bool isy = t < ph_n;
+      const int p = isy ? t : t - ph_n, grid = isy ? grid_h : grid_w, size = isy ? H : W;
+      const float start = isy ? start_h : start_w, bin = isy ? bin_h : bin_w, inv = 1.0f / (float)grid;
+      float* row = isy ? wy + (long)p * H : wx + (long)p * W;
+      for (int i = 0; i < grid; ++i) {
+        const float v = start + p * bin + (i + .5f) * bin / (float)grid;
+        int lo, hi; float wl, wh;
+        roi_axis_sample(v, size, lo, hi, wl, wh);
+        row[lo] += wl * inv;
+        row[hi] += wh * inv;
+      }
+    }
+  }
+  __syncthreads();
+  for (int t = tid; t < H + W; t += 128) {
+    const bool isy = t < H;
+    const int q = isy ? t : t - H, nb = isy ? ph_n : pw_n, size = isy ? H : W;
+    const float* tab = isy ? wy : wx;
+    int lo = 1, hi = 0;
+    bool any = false;
+    for (int p = 0; p < nb; ++p)
+      if (tab[(long)p * size + q] != 0.f) { if (!any) lo = p; hi = p; any = true; }
+    (isy ? yr + (long)k * H : xr + (long)k * W)[q] = (unsigned short)(lo | (hi << 8));
+  }
+}
+
+__device__ __forceinline__ void fma4_bf16(float (&acc)[4], float w, const uint2& v) {
+  acc[0] += w * __uint_as_float(v.x << 16);
+  acc[1] += w * __uint_as_float(v.x & 0xFFFF0000u);
+  acc[2] += w * __uint_as_float(v.y << 16);
+  acc[3] += w * __uint_as_float(v.y & 0xFFFF0000u);
+}
+
+__global__ __launch_bounds__(256) void roi_align_nhwc_bwd_gather_kernel(const bf16_t* __restrict__ dout, const float* __restrict__ Wy,
+                                                                        const float* __restrict__ Wx,
+                                                                        const unsigned short* __restrict__ yr,
+                                                                        const unsigned short* __restrict__ xr,
+                                                                        const bf16_t* __restrict__ act, bf16_t* __restrict__ out_bf,
+                                                                        float* __restrict__ out_f32, int R, int C, int H, int W, int ph_n,
+                                                                        int pw_n) {
+  const int pix = blockIdx.x;                        // (n, py, px)
+  const int n = pix / (H * W), py = (pix / W) % H, px = pix % W;
+  const int lane = threadIdx.x & 63;
+  const int c4n = C >> 2;
+  const long bins = (long)ph_n * pw_n;
+  for (int c4b = (threadIdx.x & ~63); c4b < c4n; c4b += 256) {      // wave-uniform trip count: every lane takes part in the
+    const bool live = c4b + lane < c4n;                              // range loads / ballot below, also when C / 4 is not a
+    const int c4 = live ? c4b + lane : c4n - 1;                      // multiple of 64 (idle lanes shadow the last chunk)
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < R; k0 += 64) {
+      unsigned yv = 1u, xv = 1u;                     // (lo = 1, hi = 0): empty
+      if (k0 + lane < R) {
+        yv = yr[((long)n * R + k0 + lane) * H + py];
+        xv = xr[((long)n * R + k0 + lane) * W + px];
+      }
+      unsigned long long m = __ballot((yv & 255u) <= (yv >> 8) && (xv & 255u) <= (xv >> 8));
+      while (m) {
+        const int j = __builtin_ctzll(m);
+        m &= m - 1;
+        const unsigned ys = __builtin_amdgcn_readlane(yv, j), xs = __builtin_amdgcn_readlane(xv, j);
+        const int ylo = ys & 255u, yhi = ys >> 8, xlo = xs & 255u, xhi = xs >> 8;
+        const long k = (long)n * R + k0 + j;
+        const float* wyk = Wy + k * ph_n * H + py;
+        const float* wxk = Wx + k * pw_n * W + px;
+        const bf16_t* dk = dout + k * bins * C + (long)c4 * 4;
+        for (int ph = ylo; ph <= yhi; ph += 2) {
+          const int ph1 = min(ph + 1, yhi);
+          const float wy0 = wyk[(long)ph * H], wy1 = (ph + 1 <= yhi) ? wyk[(long)ph1 * H] : 0.f;
+          for (int pw = xlo; pw <= xhi; pw += 2) {
+            const int pw1 = min(pw + 1, xhi);
+            const float wx0 = wxk[(long)pw * W], wx1 = (pw + 1 <= xhi) ? wxk[(long)pw1 * W] : 0.f;
+            const uint2 v00 = *(const uint2*)(dk + ((long)ph * pw_n + pw) * C);
+            const uint2 v01 = *(const uint2*)(dk + ((long)ph * pw_n + pw1) * C);
+            const uint2 v10 = *(const uint2*)(dk + ((long)ph1 * pw_n + pw) * C);
+            const uint2 v11 = *(const uint2*)(dk + ((long)ph1 * pw_n + pw1) * C);
+            fma4_bf16(acc, wy0 * wx0, v00);
+            fma4_bf16(acc, wy0 * wx1, v01);
+            fma4_bf16(acc, wy1 * wx0, v10);
+            fma4_bf16(acc, wy1 * wx1, v11);
+          }
+        }
+      }
+    }
+    if (!live) continue;
+    const long o = (long)pix * C + (long)c4 * 4;
+    if (out_f32) *(float4*)(out_f32 + o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    if (out_bf) {
+      if (act) {                                      // gradient through the ReLU that produced `act` (vlb_relu_mask_cast)
+        const uint2 a = *(const uint2*)(act + o);
+        if (!(__uint_as_float(a.x << 16) > 0.f)) acc[0] = 0.f;
+        if (!(__uint_as_float(a.x & 0xFFFF0000u) > 0.f)) acc[1] = 0.f;
+        if (!(__uint_as_float(a.y << 16) > 0.f)) acc[2] = 0.f;
+        if (!(__uint_as_float(a.y & 0xFFFF0000u) > 0.f)) acc[3] = 0.f;
+      }
+      uint2 r;
+      r.x = (unsigned)f2bf(acc[0]) | ((unsigned)f2bf(acc[1]) << 16);
+      r.y = (unsigned)f2bf(acc[2]) | ((unsigned)f2bf(acc[3]) << 16);
+      *(uint2*)(out_bf + o) = r;
+    }
+  }
+}
+
+// bytes of table workspace vlb_roi_align_nhwc_bwd_gather needs for K RoIs
+extern "C" long vlb_roi_align_gather_workspace_bytes(int K, int H, int W, int pooled_h, int pooled_w) {
+  const long f = (long)K * ((long)pooled_h * H + (long)pooled_w * W) * 4;
+  const long r = (long)K * (H + W) * 2;
+  return (f + 15) / 16 * 16 + (r + 15) / 16 * 16;
+}
+
+// dx_bf16 [N,H,W,C] (and / or dx_f32) = ROIAlign backward of dout [K,ph,pw,C]; act (optional, bf16 [N,H,W,C]): dx_bf16 is zeroed
+// where act <= 0.  K = N * boxes_per_image box rows.  Every element of the outputs is written (no accumulation, no zero-fill needed).
+extern "C" int vlb_roi_align_nhwc_bwd_gather(const void* dout, const float* boxes, long ldbox, int boxes_per_image, const void* act,
+                                             void* dx_bf16, float* dx_f32, void* workspace, long workspace_bytes, int N, int C, int H,
+                                             int W, int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio,
+                                             hipStream_t stream) {
+  if ((long)N * C * H * W <= 0) return VLB_OK;
+  const int K = N * boxes_per_image;
+  VLB_CHECK_ARG(dout && boxes && (dx_bf16 || dx_f32) && workspace, "vlb_roi_align_nhwc_bwd_gather: null argument");
+  VLB_CHECK_ARG(C > 0 && (C % 4) == 0 && H > 0 && W > 0 && pooled_h > 0 && pooled_w > 0 && pooled_h < 256 && pooled_w < 256 &&
+                boxes_per_image > 0 && ldbox >= 4, "vlb_roi_align_nhwc_bwd_gather: bad geometry");
+  VLB_CHECK_ARG(workspace_bytes >= vlb_roi_align_gather_workspace_bytes(K, H, W, pooled_h, pooled_w),
+                "vlb_roi_align_nhwc_bwd_gather: workspace too small");
+  VLB_CHECK_ARG(((uintptr_t)workspace & 15) == 0, "vlb_roi_align_nhwc_bwd_gather: workspace must be 16-byte aligned");
+  float* Wy = (float*)workspace;
+  float* Wx = Wy + (long)K * pooled_h * H;
+  const long f = ((long)K * ((long)pooled_h * H + (long)pooled_w * W) * 4 + 15) / 16 * 16;
+  unsigned short* yr = (unsigned short*)((char*)workspace + f);
+  unsigned short* xr = yr + (long)K * H;
+  hipLaunchKernelGGL(roi_axis_tables_kernel, dim3(K), dim3(128), 0, stream, boxes, ldbox, H, W, pooled_h, pooled_w, spatial_scale,
+                     sampling_ratio, Wy, Wx, yr, xr);
+  VLB_CHECK_LAUNCH("vlb_roi_align_nhwc_bwd_gather(tables)");
+  hipLaunchKernelGGL(roi_align_nhwc_bwd_gather_kernel, dim3(N * H * W), dim3(256), 0, stream, (const bf16_t*)dout, Wy, Wx, yr, xr,
+                     (const bf16_t*)act, (bf16_t*)dx_bf16, dx_f32, boxes_per_image, C, H, W, pooled_h, pooled_w);
+  VLB_CHECK_LAUNCH("vlb_roi_align_nhwc_bwd_gather");
+  return VLB_OK;
+}
+
 extern "C" int vlb_roi_align_nhwc_fwd(const void* feat, const float* boxes, long ldbox, int boxes_per_image, void* out, int K, int C,
                                       int H, int W, int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio,
                                       hipStream_t stream) {

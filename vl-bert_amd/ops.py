@@ -563,6 +563,22 @@ def roi_align_nhwc_bwd(dout, boxes, boxes_per_image, dfeat, N, H, W, C, pooled=1
     return dfeat
 
 
+def roi_align_gather_workspace(K, H, W, pooled, device):
+    n = _lib.load().vlb_roi_align_gather_workspace_bytes(K, H, W, pooled, pooled)
+    return torch.empty(max(int(n), 16), dtype=torch.uint8, device=device)
+
+
+def roi_align_nhwc_bwd_gather(dout, boxes, boxes_per_image, workspace, N, H, W, C, act=None, dx_bf16=None, dx_f32=None, pooled=14,
+                              spatial_scale=1.0 / 16, sampling_ratio=1):
+    """ROIAlign backward as a gather per feature pixel (vlb_roi_align_nhwc_bwd_gather): dx_bf16 (masked by act > 0) and / or dx_f32."""
+    assert dx_bf16 is not None or dx_f32 is not None
+    _lib.call("vlb_roi_align_nhwc_bwd_gather", _p(dout, BF16), _p(boxes, torch.float32), _ld(boxes), boxes_per_image,
+              _p(act, BF16) if act is not None else None, _p(dx_bf16, BF16) if dx_bf16 is not None else None,
+              _p(dx_f32, torch.float32) if dx_f32 is not None else None, _p(workspace, torch.uint8), workspace.numel(), N, C, H, W,
+              pooled, pooled, float(spatial_scale), sampling_ratio, _stream())
+    return dx_bf16 if dx_bf16 is not None else dx_f32
+
+
 def relu_mask_cast(g, y, dz):
     _lib.call("vlb_relu_mask_cast", _p(g, torch.float32), _p(y, BF16), _p(dz, BF16), g.numel(), _stream())
     return dz

@@ -193,7 +193,10 @@ class VisionStack:
         if self.Cout != VIS_DIM:
             raise ValueError("RoI head width %d != %d" % (self.Cout, VIS_DIM))
         self.P_roi = self.blocks[-1]["h"] * self.blocks[-1]["w"]
-        self.dfeat32 = zf(self.M3, self.C3)
+        # ROIAlign backward: gather form (VLB_ROI_BWD_GATHER=0: the atomic scatter into an fp32 map + separate mask / cast pass)
+        self.roi_gather = os.environ.get("VLB_ROI_BWD_GATHER", "1") != "0" and self.C3 % 4 == 0 and pooled < 256
+        self.dfeat32 = None if self.roi_gather else zf(self.M3, self.C3)
+        self.roi_ws = ops.roi_align_gather_workspace(self.K, self.H3, self.W3, pooled, d) if self.roi_gather else None
         self.wg_ws = zf(max(max_wg, max_dwf, 4))         # split-K slabs (at least one slab of the largest weight)
 
     # ------------------------------------------------------------------------------------------------------------------
@@ -443,11 +446,16 @@ class VisionStack:
                     return
                 self._block_bwd(b, cur, g["dxs"], True, False)          # ROIAlign output: no ReLU in front, no mask
                 self._stage_done(hook, 4)
-                ops.roi_align_nhwc_bwd(g["dxs"], box_rows, self.R, self.dfeat32, self.N, self.H3, self.W3, self.C3, self.pooled,
-                                       self.scale, self.sr)
                 g3 = self.groups[3]
                 self._before_write(g3["dzA"])
-                cur = ops.relu_mask_cast(self.dfeat32, self.body4, g3["dzA"])
+                if self.roi_gather:      # gather per feature pixel: no atomics / memset, ReLU mask + bf16 cast in the store
+                    cur = ops.roi_align_nhwc_bwd_gather(g["dxs"], box_rows, self.R, self.roi_ws, self.N, self.H3, self.W3, self.C3,
+                                                        act=self.body4, dx_bf16=g3["dzA"], pooled=self.pooled,
+                                                        spatial_scale=self.scale, sampling_ratio=self.sr)
+                else:
+                    ops.roi_align_nhwc_bwd(g["dxs"], box_rows, self.R, self.dfeat32, self.N, self.H3, self.W3, self.C3, self.pooled,
+                                           self.scale, self.sr)
+                    cur = ops.relu_mask_cast(self.dfeat32, self.body4, g3["dzA"])
             elif b is first:
                 self._block_bwd(b, cur, None, False, False)
                 self._stage_done(hook, L)
