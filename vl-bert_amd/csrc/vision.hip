@@ -195,8 +195,12 @@ extern "C" int vlb_im2col_nhwc_bf16(const void* x, void* col, long ldcol, int N,
 }
 
 // stem: fp32 NCHW image, 7x7 stride 2 pad 3 (resnet.py:137-138); column k = (ky*7 + kx)*3 + c, zero from 147 up to ldcol
-__global__ __launch_bounds__(256) void im2col_image_kernel(const float* __restrict__ img, bf16_t* __restrict__ col, int N, int Cin, int H,
-                                                           int W, int KH, int KW, int stride, int pad, int OH, int OW, int ldcol) {
+// STEM = true: the ResNet stem's geometry (3 channels, 7 x 7, stride 2, pad 3) as compile-time constants -- the per-element index
+// arithmetic (k -> (ky, kx, c)) is then multiplies and shifts instead of five runtime integer divisions, which bound the kernel
+template <bool STEM>
+__global__ __launch_bounds__(256) void im2col_image_kernel(const float* __restrict__ img, bf16_t* __restrict__ col, int N, int Cin_, int H,
+                                                           int W, int KH_, int KW_, int stride_, int pad_, int OH, int OW, int ldcol) {
+  const int Cin = STEM ? 3 : Cin_, KH = STEM ? 7 : KH_, KW = STEM ? 7 : KW_, stride = STEM ? 2 : stride_, pad = STEM ? 3 : pad_;
   const int k8n = ldcol >> 3;
   const int kreal = KH * KW * Cin;
   const long total = (long)N * OH * OW * k8n;
@@ -231,8 +235,12 @@ extern "C" int vlb_im2col_image_f32(const float* img, void* col, int ldcol, int 
   const long total = (long)N * OH * OW * (ldcol / 8);
   long blocks = (total + 255) / 256;
   if (blocks > 65536) blocks = 65536;
-  hipLaunchKernelGGL(im2col_image_kernel, dim3((int)blocks), dim3(256), 0, stream, img, (bf16_t*)col, N, Cin, H, W, KH, KW, stride, pad,
-                     OH, OW, ldcol);
+  if (Cin == 3 && KH == 7 && KW == 7 && stride == 2 && pad == 3)
+    hipLaunchKernelGGL(im2col_image_kernel<true>, dim3((int)blocks), dim3(256), 0, stream, img, (bf16_t*)col, N, Cin, H, W, KH, KW, stride,
+                       pad, OH, OW, ldcol);
+  else
+    hipLaunchKernelGGL(im2col_image_kernel<false>, dim3((int)blocks), dim3(256), 0, stream, img, (bf16_t*)col, N, Cin, H, W, KH, KW, stride,
+                       pad, OH, OW, ldcol);
   VLB_CHECK_LAUNCH("vlb_im2col_image_f32");
   return VLB_OK;
 }
