@@ -65,11 +65,17 @@ def drop_scale(thr):
     return 65536.0 / (65536.0 - thr) if thr else 1.0
 
 
+def _pair_hash(pair_idx, key):
+    """vlb_pair_hash (vlb_common.h)"""
+    m = np.uint64(0xFFFFFFFF)
+    return _hash32(((pair_idx.astype(np.uint64) * np.uint64(0x9E3779B1)) + np.uint64(key)) & m)
+
+
 def keep_mask(seed, tag, idx, thr):
     """idx: numpy integer array of element indices -> bool keep mask."""
     m = np.uint64(0xFFFFFFFF)
     idx = idx.astype(np.uint64)
     key = _hash32(np.array([(seed ^ ((tag * 0x85EBCA6B + 0x632BE5AB) & 0xFFFFFFFF)) & 0xFFFFFFFF], dtype=np.uint64))[0]
-    h = _hash32((((idx >> np.uint64(1)) * np.uint64(0x9E3779B1)) + key) & m)
+    h = _pair_hash(idx >> np.uint64(1), key)
     bits = np.where((idx & np.uint64(1)) == 1, h >> np.uint64(16), h & np.uint64(0xFFFF))
     return bits >= np.uint64(thr)

@@ -228,6 +228,34 @@ def bench_wgrad(batch):
     print("TN ms per step (12 layers + compact decoder): %.2f | %.2f" % tuple(tot), flush=True)
 
 
+def bench_wgrad_vision():
+    """layer3 / layer4 1x1-convolution weight gradients of the e2e trunk (8 images): R = 19152 rows is not a multiple of 128, so the
+    large-tile core is out; would zero-padding the rows to 19200 pay?  128x128 TN kernel at R = 19152 vs both kernels at 19200"""
+    for name, R, Mo, No in (("layer3 conv1", 19152, 256, 1024), ("layer3 conv3", 19152, 1024, 256), ("layer3 down", 19152, 1024, 512),
+                            ("layer4 conv1", 56448, 512, 2048), ("layer4 conv3", 56448, 2048, 512)):
+        row = []
+        for Rp, mode in ((R, 0), ((R + 127) // 128 * 128, 0), ((R + 127) // 128 * 128, 1)):
+            dY = torch.zeros((Rp, Mo), dtype=BF, device=D); dY[:R].copy_(rnd(R, Mo, seed=1).to(BF).to(D))
+            X = torch.zeros((Rp, No), dtype=BF, device=D); X[:R].copy_(rnd(R, No, seed=2).to(BF).to(D))
+            C = torch.zeros((Mo, No), dtype=torch.float32, device=D)
+            sc = torch.ones(Mo, dtype=torch.float32, device=D)
+            work = torch.empty(64 * Mo * No + 64, dtype=torch.float32, device=D)
+            lib.gemm_set_option("tn8_mode", mode)
+            run = lambda: ops.wgrad_tn_rowscale(dY, X, C, sc, work, accumulate=True)
+            for _ in range(3):
+                run()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 20
+            row.append("R %5d tn8 %d: %6.1f us %4.0f TF" % (Rp, mode, ms * 1e3, 2.0 * R * Mo * No / ms / 1e9))
+        print("%-14s %5d x %5d | " % (name, Mo, No) + " | ".join(row), flush=True)
+    lib.gemm_set_option("tn8_mode", 1)
+
+
 def bench_wgrad_group(batch):
     """grouped per-layer weight gradient (4 gradients, one launch): equal 2-slice cut vs the uneven 3-slice cut"""
     R = (batch * 101 + 127) // 128 * 128
@@ -361,6 +389,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "check":
         sys.exit(1 if check() else 0)
+    if len(sys.argv) > 1 and sys.argv[1] == "wgradvision":
+        bench_wgrad_vision()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "wgradgroup":
         for b in [int(x) for x in sys.argv[2:]] or [256]:
             bench_wgrad_group(b)

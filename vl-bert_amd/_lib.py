@@ -9,7 +9,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvlbert_hip.so")
+# VLB_LIB_PATH: an alternative build of the same library (A/B measurements of compile-time variants on one GPU box)
+LIB_PATH = os.environ.get("VLB_LIB_PATH") or os.path.join(_HERE, "libvlbert_hip.so")
 
 _P, _L, _I, _F, _U = ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_float, ctypes.c_uint32
 

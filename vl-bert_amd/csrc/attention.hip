@@ -85,7 +85,7 @@ __device__ __forceinline__ void drop8(float* v, uint32_t key, uint32_t base, uin
   const uint32_t odd = base & 1u, p0 = base >> 1;
   uint32_t h[5];
 #pragma unroll
-  for (int k = 0; k < 5; ++k) h[k] = vlb_hash32((p0 + k) * 0x9E3779B1u + key);
+  for (int k = 0; k < 5; ++k) h[k] = vlb_pair_hash(p0 + k, key);
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const uint32_t hs = odd ? h[(j + 1) >> 1] : h[j >> 1];              // pair of element base+j
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(ATT_THREADS, NU <= 4 ? 4 : 2) void attn_fwd_kernel(
   if (tid < ATT_SP) sMB[tid] = (tid < S) ? (1.0f - p.mask[b * S + tid]) * -10000.0f : -INFINITY;
   __syncthreads();
   const uint32_t seed = (p.drop_thr && p.seed) ? *p.seed : 0u;
-  const uint32_t key = vlb_hash32(seed ^ (p.tag * 0x85ebca6bu + 0x632be5abu));
+  const uint32_t key = vlb_rng_key(seed, p.tag);
   const int U = (S + 31) >> 5;  // key blocks of 32 actually present
 
 #pragma unroll 1
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(ATT_THREADS, NU <= 4 ? 4 : 2) void attn_bwd_kernel(
   __syncthreads();
 
   const uint32_t seed = (p.drop_thr && p.seed) ? *p.seed : 0u;
-  const uint32_t key = vlb_hash32(seed ^ (p.tag * 0x85ebca6bu + 0x632be5abu));
+  const uint32_t key = vlb_rng_key(seed, p.tag);
   const uint32_t bh = (uint32_t)(b * p.nh + h);
   const int U = (S + 31) >> 5;
 #pragma unroll 1
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(ATT_THREADS, NU <= 4 ? 4 : 2) void attn_bwd_kernel(
             float keepf = 1.f;
             if (p.drop_thr) {
               const uint32_t idx = (bh * (uint32_t)S + (uint32_t)min(q, S - 1)) * (uint32_t)S + kcol;
-              const uint32_t hsh = vlb_hash32((idx >> 1) * 0x9E3779B1u + key);
+              const uint32_t hsh = vlb_pair_hash(idx >> 1, key);
               keepf = (((idx & 1u) ? (hsh >> 16) : (hsh & 0xffffu)) >= p.drop_thr) ? p.drop_scale : 0.f;
             }
             pv[4 * hf + r] = pr * keepf;
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd2_kernel(const AttnPar
   __syncthreads();
 
   const uint32_t seed = (p.drop_thr && p.seed) ? *p.seed : 0u;
-  const uint32_t key = vlb_hash32(seed ^ (p.tag * 0x85ebca6bu + 0x632be5abu));
+  const uint32_t key = vlb_rng_key(seed, p.tag);
   const uint32_t bh = (uint32_t)(b * p.nh + h);
   const int U = (S + 31) >> 5;
   const int w16 = wave * 16;

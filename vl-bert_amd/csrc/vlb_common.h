@@ -75,8 +75,15 @@ __device__ __forceinline__ uint32_t vlb_hash32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
   return x;
 }
+// 32 random bits for element PAIR pair_idx under a (wave-uniform) key: two 16-bit fields, one per element.
+// (Round 2 tried a version built only from 24-bit multiplies -- v_mad_u32_u24 / v_mul_u32_u24 + xorshifts, 11 issue slots, statistically
+// as good on the CPU study in tools/hash_quality.py -- on the theory that the three v_mul_lo_u32 here are quarter-rate.  Same-box A/B of
+// the whole step: 21.10 / 21.24 ms with this hash, 21.32 / 21.33 ms with the 24-bit one at batch 256, 5.79 vs 5.77 ms at batch 32:
+// no gain, so the simpler, bijective 32-bit form stays.)
+__device__ __forceinline__ uint32_t vlb_pair_hash(uint32_t pair_idx, uint32_t key) { return vlb_hash32(pair_idx * 0x9E3779B1u + key); }
+__device__ __forceinline__ uint32_t vlb_rng_key(uint32_t seed, uint32_t tag) { return vlb_hash32(seed ^ (tag * 0x85ebca6bu + 0x632be5abu)); }
 __device__ __forceinline__ uint32_t vlb_rng_pair(uint32_t seed, uint32_t tag, uint32_t pair_idx) {
-  return vlb_hash32(pair_idx * 0x9E3779B1u + vlb_hash32(seed ^ (tag * 0x85ebca6bu + 0x632be5abu)));
+  return vlb_pair_hash(pair_idx, vlb_rng_key(seed, tag));
 }
 __device__ __forceinline__ bool vlb_keep(uint32_t seed, uint32_t tag, uint32_t idx, uint32_t thr) {
   uint32_t h = vlb_rng_pair(seed, tag, idx >> 1);
