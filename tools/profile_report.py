@@ -44,7 +44,7 @@ def family(n):
 
 
 # ---------------------------------------------------------------- kernel time
-def kernel_stats(trace, out_name, cmd_note):
+def kernel_stats(trace, out_name, cmd_note, steps=steps):
     cur = db(trace).cursor()
     rows = cur.execute("select name, end - start from kernels").fetchall()
     agg = {}
@@ -71,12 +71,27 @@ def kernel_stats(trace, out_name, cmd_note):
         f.write("%-66s %7s %10.3f %10.3f\n" % ("TOTAL kernel time", "", total / 1e6, total / 1e6 / steps))
 
 
-kernel_stats("final_trace", tag + "_kernel_stats.txt",
-             "# VLB_WGRAD_STREAM=0 rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-phase-times\n")
+if glob.glob(os.path.join(src, "final_trace", "*.db")):
+    kernel_stats("final_trace", tag + "_kernel_stats.txt",
+                 "# VLB_WGRAD_STREAM=0 rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-phase-times\n")
 if glob.glob(os.path.join(src, "final_e2e_trace", "*.db")):
     kernel_stats("final_e2e_trace", tag + "_e2e_kernel_stats.txt",
                  "# VLB_WGRAD_STREAM=0 VLB_VISION_WGRAD_STREAM=0 rocprofv3 --kernel-trace --stats -- python bench.py --e2e --steps 3 --warmup 1 "
                  "--no-graph --no-cpu-baseline --no-phase-times\n# (config C3: 8 images of 600x1000, ResNet-101 trunk + ROIAlign + dilated layer4 head + the VL-BERT step)\n")
+
+
+if glob.glob(os.path.join(src, "final_large_trace", "*.db")):
+    kernel_stats("final_large_trace", tag + "_large_kernel_stats.txt",
+                 "# VLB_WGRAD_STREAM=0 rocprofv3 --kernel-trace --stats -- python bench.py --large --steps 3 --warmup 1 --no-graph --no-cpu-baseline "
+                 "--no-phase-times\n# (VL-BERT-large shape of BASELINE configs 4-5 through the pretraining step: 24 x 1024, 128 text + 100 regions, batch 64)\n")
+if glob.glob(os.path.join(src, "final_vcr_trace", "*.db")):
+    kernel_stats("final_vcr_trace", tag + "_vcr_kernel_stats.txt",
+                 "# rocprofv3 --kernel-trace --stats -- python bench.py --vcr --steps 2 --warmup 1 --no-cpu-baseline\n# (BASELINE config 5 through the "
+                 "module mirror: 24 x 1024 encoder, 4 samples x 4 answer choices x 256 positions + 4 images of 600x1000 per micro-batch,\n# 4 micro-batches "
+                 "per optimizer step; 1 warm-up + 2 timed + 1 instrumented optimizer step = 4 steps in the process; weight-gradient streams NOT serialised)\n",
+                 steps=4.0)
+if len(sys.argv) > 5 and sys.argv[5] == "extra-only":
+    sys.exit(0)
 
 
 # ---------------------------------------------------------------- PMC helpers
