@@ -136,6 +136,176 @@ def vcr_batch(B, C, R, Lq, La, Hi, Wi, seed, device):
     return [t.to(device) for t in (image, boxes, masks, question, answers, label, im_info)]
 
 
+def _mirror_gemm_roofline(ops, step, head_start, dev):
+    """roofline of the dominant kernels of a module-mirror step (the bf16 MFMA GEMM launches of one optimizer step): every GEMM entry of
+    `ops` is wrapped in a HIP event pair for ONE extra step, behind a head start of unrelated torch.mm work so that no pair contains a
+    wait for the host.  -> (records, total GEMM ms, achieved TFLOP/s)"""
+    rec = []
+    names = ("gemm_nt", "gemm_nt_splitk", "wgrad_nt", "wgrad_tn")
+    orig = {n: getattr(ops, n) for n in names}
+
+    def timed(name):
+        fn = orig[name]
+
+        def wrapper(A, Bm, Cm, *a, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(A, Bm, Cm, *a, **kw)
+            e1.record()
+            K = A.shape[0] if name == "wgrad_tn" else A.shape[1]
+            rec.append((e0, e1, 2.0 * Cm.shape[0] * Cm.shape[1] * K))
+            return out
+        return wrapper
+    orig_group = ops.wgrad_tn_group
+
+    def timed_group(items, *a, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = orig_group(items, *a, **kw)
+        e1.record()
+        rec.append((e0, e1, sum(2.0 * dy.shape[0] * dy.shape[1] * x.shape[1] for dy, x, _, _ in items)))
+        return out
+    for n in names:
+        setattr(ops, n, timed(n))
+    ops.wgrad_tn_group = timed_group
+    hs_a = torch.zeros((8192, 4096), dtype=torch.bfloat16, device=dev)
+    hs_b = torch.zeros((4096, 8192), dtype=torch.bfloat16, device=dev)
+    hs_c = torch.empty((8192, 8192), dtype=torch.bfloat16, device=dev)
+    for _ in range(head_start * 4):
+        torch.mm(hs_a, hs_b, out=hs_c)
+    step()
+    torch.cuda.synchronize()
+    for n in names:
+        setattr(ops, n, orig[n])
+    ops.wgrad_tn_group = orig_group
+    gemm_ms = sum(r[0].elapsed_time(r[1]) for r in rec)
+    achieved = sum(r[2] for r in rec) / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    return rec, gemm_ms, achieved
+
+
+def vqa_config(answers=3129):
+    """cfgs/vqa/large_4x16G_fp32.yaml as the attribute tree the module mirror reads."""
+    class A(dict):
+        __getattr__ = dict.__getitem__
+    H, L, nh, I = 1024, 24, 16, 4096
+    return A(DATASET=A(ANSWER_VOCAB_SIZE=answers),
+             NETWORK=A(IMAGE_FEAT_PRECOMPUTED=True, IMAGE_SEMANTIC=False, IMAGE_STRIDE_IN_1x1=True, IMAGE_C5_DILATED=True, IMAGE_NUM_LAYERS=101,
+                       OUTPUT_CONV5=False, IMAGE_FROZEN_BN=True, IMAGE_FROZEN_BACKBONE_STAGES=[1, 2], IMAGE_FINAL_DIM=H, BLIND=False,
+                       NO_GROUNDING=False, ENABLE_CNN_REG_LOSS=False, CLASSIFIER_TYPE="mlm", CLASSIFIER_HIDDEN_SIZE=1024, CLASSIFIER_DROPOUT=0.1,
+                       CLASSIFIER_SIGMOID=False,
+                       VLBERT=A(hidden_size=H, visual_size=H, num_hidden_layers=L, num_attention_heads=nh, intermediate_size=I,
+                                vocab_size=30522, max_position_embeddings=512, type_vocab_size=3, visual_ln=True, with_pooler=False,
+                                hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, initializer_range=0.02,
+                                visual_scale_text_init=0.0, visual_scale_object_init=0.0, object_word_embed_mode=2)))
+
+
+def vqa_batch(B, R, Lq, seed, device, answers=3129):
+    """One collated VQA micro-batch with precomputed region features (vqa/data/collate_batch.py layout): boxes [B,R,4+2048] (box 0 = the
+    whole image), im_info, question ids [B,Lq], soft answer scores [B,answers]."""
+    g = torch.Generator().manual_seed(seed)
+    Wi, Hi = 1000.0, 600.0
+    x1 = torch.rand(B, R, generator=g) * (Wi - 200)
+    y1 = torch.rand(B, R, generator=g) * (Hi - 200)
+    w = 30 + torch.rand(B, R, generator=g) * 160
+    h = 30 + torch.rand(B, R, generator=g) * 160
+    boxes = torch.cat((torch.stack((x1, y1, x1 + w, y1 + h), -1), torch.randn(B, R, 2048, generator=g).abs()), -1)
+    boxes[:, 0, :4] = torch.tensor([0.0, 0.0, Wi - 1.0, Hi - 1.0])
+    im_info = torch.tensor([[Wi, Hi, 1.0, 1.0]] * B)
+    question = torch.randint(1000, 30522, (B, Lq), generator=g)
+    label = torch.zeros(B, answers)
+    idx = torch.randint(0, answers, (B, 3), generator=g)
+    label.scatter_(1, idx, torch.tensor([[1.0, 0.6, 0.3]] * B))
+    return [t.to(device) for t in (boxes, im_info, question, label)]
+
+
+def bench_vqa(args):
+    """BASELINE config 4's workload through the module mirror: VL-BERT-large VQA fine-tuning, 128 text positions + 100 regions
+    (precomputed features), 16 samples per micro-batch, 4 micro-batches per optimizer step, clip_grad_norm_ 1.0, the reference's AdamW.
+    bf16 compute: the fp32 compute mode that config names is NOT built, which `dtype` and `config.note` say."""
+    ops = importlib.import_module("vl-bert_amd.ops")
+    lib = importlib.import_module("vl-bert_amd._lib")
+    M = importlib.import_module("vl-bert_amd.vqa.modules.resnet_vlbert_for_vqa")
+    OPT = importlib.import_module("vl-bert_amd.optim")
+    arch, cus = lib.device_info(0)
+    dev = torch.device("cuda:0")
+    B, R, Lq, accum = 16, 100, 124, 4                              # text = [CLS] q [SEP] [MASK] [SEP] = Lq + 4 = 128 positions
+    torch.manual_seed(0)
+    net = M.ResNetVLBERT(vqa_config(), device=dev)
+    with torch.no_grad():                                          # the shipped init leaves the visual LayerNorm gains at 0: open the visual path
+        for n, p in net.named_parameters():
+            if n.endswith("visual_ln_text.weight") or n.endswith("visual_ln_object.weight"):
+                p.fill_(1.0)
+    net.train()
+    opt = OPT.FusedAdamW(net.parameters(), lr=6.25e-7 * B * accum, betas=(0.9, 0.999), eps=1e-6, weight_decay=1e-4)
+    batches = [vqa_batch(B, R, Lq, 700 + i, dev) for i in range(accum)]
+
+    def step():
+        opt.zero_grad(set_to_none=False)
+        total = 0.0
+        for boxes, im_info, question, label in batches:
+            outputs, loss = net.train_forward(None, boxes, im_info, question, label)
+            (loss / accum).backward()
+            total = loss.detach()
+        torch.nn.utils.clip_grad_norm_(net.parameters(), 1.0)
+        opt.step()
+        return total
+
+    for _ in range(max(1, args.warmup)):
+        last = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ms = elapsed / args.steps * 1e3
+    value = B * accum / (elapsed / args.steps)
+    rec, gemm_ms, achieved = _mirror_gemm_roofline(ops, step, args.head_start, dev)
+    out = {
+        "metric": "samples/sec VL-BERT-large VQA fine-tuning step (128 text + 100 regions, precomputed features, AdamW, gradient accumulation 4)",
+        "value": round(value, 2), "unit": "samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+        "data": "synthetic (random-init weights, random boxes / features / tokens / answer scores, resident in HBM)",
+        "config": {"workload": "BASELINE config 4's shape through the module mirror vl-bert_amd/vqa (cfgs/vqa/large_4x16G_fp32.yaml): 24 x 1024 "
+                               "encoder, %d samples per micro-batch, %d text + %d regions + END = %d positions, 'mlm' classifier over %d answers + "
+                               "BCE, clip 1.0, AdamW, %d micro-batches per optimizer step; a step = one optimizer step"
+                               % (B, Lq + 4, R, Lq + 4 + R + 1, 3129, accum),
+                   "note": "bf16 compute with fp32 master weights; the fp32 COMPUTE mode the reference config runs in is not built, so this "
+                           "line is not a measurement of config 4 at its named precision",
+                   "global_batch": B * accum, "per_gpu_batch": B * accum, "seq_len": Lq + 4 + R + 1, "parallelism": "dp1", "arch": arch, "cus": cus},
+        "roofline": {"bound": "mfma", "kernel": "all %d bf16 GEMM launches of one optimizer step (large-tile NT / TN cores + the 128x128 kernels "
+                                               "on the classifier shapes)" % len(rec),
+                     "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+                     "traffic": None, "gemm_ms_per_step": round(gemm_ms, 3), "gemm_share_of_step": round(gemm_ms / ms, 3)},
+        "loss": round(float(last), 4),
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_vqa(B, R, Lq)
+    print(json.dumps(out), flush=True)
+
+
+def cpu_baseline_vqa(B, R, Lq):
+    """the pinned VQA oracle (oracle/vqa_oracle.py: the restatement of the reference's own VQA module) on this box's host cores: forward +
+    backward of ONE sample of the same shape, bounded sample."""
+    from oracle import vlbert_oracle as O
+    from oracle import vqa_oracle as VQ
+    cores = min(os.cpu_count() or 1, 64)
+    torch.set_num_threads(cores)
+    cfg = O.VLBertConfig(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096, with_pooler=False)
+    params = VQ.init_vqa_params(cfg, 3, 3129, "mlm")
+    batch = vqa_batch(1, R, Lq, 800, "cpu")
+    best = None
+    for _ in range(2):
+        leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+        t0 = time.time()
+        out, loss = VQ.vqa_forward(leaves, cfg, *batch, classifier="mlm", classifier_dropout=0.1, train=True)
+        loss.backward()
+        dt = time.time() - t0
+        best = dt if best is None else min(best, dt)
+    return {"value": round(1.0 / best, 3), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": "VQA oracle fwd+bwd of 1 sample (24 x 1024, %d text + %d regions, fp32, dropout on), best of 2: %.2f s" % (Lq + 4, R, best)}
+
+
 def bench_vcr(args):
     """BASELINE config 5: one optimizer step = 4 accumulated micro-batches of 4 samples x 4 answer choices (16 sequences of 256
     positions through the 24 x 1024 encoder + 4 images of 600x1000 through the ResNet-101 path), clip_grad_norm_ 10, SGD momentum."""
@@ -179,47 +349,7 @@ def bench_vcr(args):
     ms = elapsed / args.steps * 1e3
     value = B * accum / (elapsed / args.steps)
 
-    # roofline of the dominant kernels (the bf16 MFMA GEMM launches of one optimizer step), as in the pre-training bench
-    rec = []
-    names = ("gemm_nt", "gemm_nt_splitk", "wgrad_nt", "wgrad_tn")
-    orig = {n: getattr(ops, n) for n in names}
-
-    def timed(name):
-        fn = orig[name]
-
-        def wrapper(A, Bm, Cm, *a, **kw):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            out = fn(A, Bm, Cm, *a, **kw)
-            e1.record()
-            K = A.shape[0] if name == "wgrad_tn" else A.shape[1]
-            rec.append((e0, e1, 2.0 * Cm.shape[0] * Cm.shape[1] * K))
-            return out
-        return wrapper
-    orig_group = ops.wgrad_tn_group
-
-    def timed_group(items, *a, **kw):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        out = orig_group(items, *a, **kw)
-        e1.record()
-        rec.append((e0, e1, sum(2.0 * dy.shape[0] * dy.shape[1] * x.shape[1] for dy, x, _, _ in items)))
-        return out
-    for n in names:
-        setattr(ops, n, timed(n))
-    ops.wgrad_tn_group = timed_group
-    hs_a = torch.zeros((8192, 4096), dtype=torch.bfloat16, device=dev)
-    hs_b = torch.zeros((4096, 8192), dtype=torch.bfloat16, device=dev)
-    hs_c = torch.empty((8192, 8192), dtype=torch.bfloat16, device=dev)
-    for _ in range(args.head_start * 4):
-        torch.mm(hs_a, hs_b, out=hs_c)
-    step()
-    torch.cuda.synchronize()
-    for n in names:
-        setattr(ops, n, orig[n])
-    ops.wgrad_tn_group = orig_group
-    gemm_ms = sum(r[0].elapsed_time(r[1]) for r in rec)
-    achieved = sum(r[2] for r in rec) / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    rec, gemm_ms, achieved = _mirror_gemm_roofline(ops, step, args.head_start, dev)
     out = {
         "metric": "samples/sec VL-BERT-large VCR Q->A fine-tuning step (4 answer choices, 256-position sequences, ResNet-101 image path, "
                   "SGD, gradient accumulation 4)",
@@ -281,6 +411,8 @@ def main():
                     "ResNetVLBERTForPretrainingMultitask).  Default: 8 with --e2e (TRAIN.BATCH_IMAGES [8, 8] of the shipped yaml), else 0")
     ap.add_argument("--large", action="store_true", help="VL-BERT-large shape of BASELINE.json configs 4-5 through the same pretraining step: "
                     "24 layers, hidden 1024, 16 heads, FFN 4096, 128 text + 100 regions (S = 229); default global batch 64")
+    ap.add_argument("--vqa", action="store_true", help="BASELINE config 4's workload through the module mirror (vl-bert_amd/vqa): VL-BERT-large VQA "
+                    "fine-tuning, 128 text + 100 precomputed regions, AdamW, accumulation 4 -- in bf16 (the fp32 compute mode is not built)")
     ap.add_argument("--vcr", action="store_true", help="BASELINE config 5 through the module mirror (vl-bert_amd/vcr): VL-BERT-large VCR Q->A, 4 answer "
                     "choices, sequences of 256 positions, ResNet-101 image path with object masks, SGD momentum 0.9, gradient accumulation 4 "
                     "(cfgs/vcr/large_q2a_4x16G_fp16.yaml: 4 samples per GPU per micro-batch); one GPU; a step = one OPTIMIZER step")
@@ -331,6 +463,10 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    if args.vqa:
+        if world != 1:
+            raise SystemExit("--vqa runs the module mirror on one GPU (its data-parallel wrapper is the trainer's DDP, host glue that is not built)")
+        return bench_vqa(args)
     if args.vcr:
         if world != 1:
             raise SystemExit("--vcr runs the module mirror on one GPU (its data-parallel wrapper is the trainer's DDP, host glue that is not built)")

@@ -145,11 +145,12 @@ int vlb_attention_bwd(const void* qkv, const float* mask, const void* ctx, const
 int vlb_seq_layout(const uint8_t* text_mask, const uint8_t* obj_mask, int B, int T, int R, int S, int32_t* code,
                    int32_t* text_len, int32_t* nobj, int32_t* text_rows, int32_t* obj_rows, float* attn_mask,
                    vlb_stream_t stream);
-/* boxes [B*R, ldbox] fp32 (x1,y1,x2,y2, 2048 features; x1 <= -1.5 marks padding), im_info [B,5],
- * mvrc_ops int64 [B*R] (1 -> use mask_emb[2048] instead of the feature) -> out bf16 [B*R, 4096]
+/* boxes [B*R, ldbox] fp32 (x1,y1,x2,y2, 2048 features; x1 <= -1.5 marks padding), im_info [B, ldinfo >= 2] = (width, height, ...)
+ * per image -- the reference's datasets emit 5 columns for pre-training / VCR (conceptual_captions.py:138, vcr.py:377) and 4 for VQA
+ * (vqa/data/datasets/vqa.py:217), so the row stride is an argument; mvrc_ops int64 [B*R] (1 -> use mask_emb[2048] instead of the feature) -> out bf16 [B*R, 4096]
  * = dropout(coordinate_embeddings || feature)  (common/utils/bbox.py:33-65, fast_rcnn.py:165-175,
  * pretrain/modules/resnet_vlbert_for_pretraining.py:114-117). */
-int vlb_obj_prep_fwd(const float* boxes, long ldbox, const float* im_info, const int64_t* mvrc_ops,
+int vlb_obj_prep_fwd(const float* boxes, long ldbox, const float* im_info, long ldinfo, const int64_t* mvrc_ops,
                      const float* mask_emb, void* out, int B, int R, float drop_p, const uint32_t* seed, uint32_t tag,
                      vlb_stream_t stream);
 /* x[r, :] = 0 where boxes[r*ldbox] <= -1.5 (padded box): the zero rows pad_sequence leaves in obj_reps (common/fast_rcnn.py:176-186) */

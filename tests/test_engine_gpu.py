@@ -559,6 +559,34 @@ def test_module_api_vqa_style_composition_vs_oracle():
         assert e <= 5e-2, name
 
 
+def test_fast_rcnn_mirror_im_info_row_width():
+    """The datasets disagree on im_info's width: (w, h, 1, 1, index) for pre-training / VCR (conceptual_captions.py:138, vcr.py:377),
+    (w, h, 1, 1) for VQA (vqa/data/datasets/vqa.py:217).  The coordinate embedding divides by THAT image's (w, h)
+    (common/utils/bbox.py:33-65), so the row stride must be honoured: per-image sizes, 4 and 5 columns, against the oracle."""
+    FR, syn = pkg("common.fast_rcnn"), pkg("synthetic")
+    H, B, T, R = 128, 5, 6, 4
+    cfg = O.VLBertConfig(hidden_size=H, num_hidden_layers=1, num_attention_heads=2, intermediate_size=256, vocab_size=512,
+                         max_position_embeddings=64, visual_region_classes=50)
+    full = O.init_params(cfg, seed=23)
+    boxes, im_info, _, _, _, _, _ = syn.make_batch(B, T, R, vocab_size=512, region_classes=50, seed=11, ragged=True)
+    im_info = im_info.clone()
+    im_info[:, 0] = torch.tensor([1000.0, 640.0, 800.0, 1333.0, 500.0])      # a different size for every image
+    im_info[:, 1] = torch.tensor([600.0, 480.0, 800.0, 750.0, 375.0])
+    box_mask = boxes[:, :, 0] > -1.5
+
+    class A(dict):
+        __getattr__ = dict.__getitem__
+    fr = FR.FastRCNN(A(NETWORK=A(IMAGE_FEAT_PRECOMPUTED=True, IMAGE_SEMANTIC=False)), final_dim=H)
+    fr.load_state_dict({"obj_downsample.1.weight": full["image_feature_extractor.obj_downsample.1.weight"],
+                        "obj_downsample.1.bias": full["image_feature_extractor.obj_downsample.1.bias"]})
+    fr.eval()
+    ref = O.fast_rcnn_precomputed(full, cfg, boxes, box_mask, im_info, False)
+    for width in (5, 4, 2):
+        info = im_info[:, :width].contiguous() if width <= im_info.shape[1] else im_info
+        out = fr(None, boxes.to(dev()), box_mask.to(dev()), info.to(dev()))
+        report("FastRCNN mirror obj_reps, im_info [B,%d]" % width, out["obj_reps"], ref, 2e-3, 1e-2)
+
+
 def test_fast_rcnn_mirror_mask_embedding_gradient():
     """FastRCNN mirror with mvrc_ops / mask_visual_embed (common/fast_rcnn.py:170-172): output, obj_reps_raw and the
     gradient that flows back into the mask embedding."""

@@ -209,3 +209,58 @@ def test_fused_sgd_optimizer_on_a_module_mirror():
     l1 = run()
     assert abs(float(l1) - float(l0)) > 1e-4            # the next forward ran on the updated weights
     assert "momentum_buffer" in opt.state[params[0]] and opt.state_dict()["param_groups"][0]["momentum"] == 0.9
+
+
+def _reference_adamw_step(p, g, st, lr, betas, eps, wd):
+    """common/nlp/bert/optimization.py:150-185 restated on fp32 tensors (test-local, double-free: the same operation order)."""
+    st["step"] += 1
+    st["m"].mul_(betas[0]).add_(g, alpha=1.0 - betas[0])
+    st["v"].mul_(betas[1]).addcmul_(g, g, value=1.0 - betas[1])
+    denom = st["v"].sqrt().add_(eps)
+    step_size = lr * (1.0 - betas[1] ** st["step"]) ** 0.5 / (1.0 - betas[0] ** st["step"])
+    p.addcdiv_(st["m"], denom, value=-step_size)
+    if wd > 0.0:
+        p.add_(p, alpha=-lr * wd)
+
+
+def test_fused_adamw_optimizer_matches_the_reference_adamw():
+    """FusedAdamW (pre-training / VQA optimiser, common/nlp/bert/optimization.py:107-187) on the VisualLinguisticBert mirror's flat
+    parameter runs and on separately allocated tensors: three steps with a learning-rate change in between (an LR scheduler writing
+    param_groups[...]['lr']) against the reference's update rule restated in torch; state keys as the reference's."""
+    VL = pkg("common.visual_linguistic_bert")
+    OPT = pkg("optim")
+    cfg = O.VLBertConfig(hidden_size=128, num_hidden_layers=1, num_attention_heads=2, intermediate_size=256, vocab_size=300,
+                         max_position_embeddings=64, with_pooler=True)
+    core = VL.VisualLinguisticBert(_vcr_config(cfg, 50, 1.0)["NETWORK"]["VLBERT"], device="cuda:0")
+    g = torch.Generator().manual_seed(9)
+    core._prepare_grads()
+    extra = [torch.nn.Parameter(torch.randn(33, 7, generator=g).to(dev())), torch.nn.Parameter(torch.randn(5, generator=g).to(dev()))]
+    params = list(core.parameters()) + extra
+    for p in params:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+    betas, eps, wd = (0.9, 0.999), 1e-6, 1e-2
+    opt = OPT.FusedAdamW([{"params": list(core.parameters())}, {"params": extra, "weight_decay": 0.0}], lr=1e-2, betas=betas, eps=eps,
+                         weight_decay=wd)
+    ref = [(p.detach().clone(), {"step": 0, "m": torch.zeros_like(p), "v": torch.zeros_like(p)}) for p in params]
+    for it, lr in enumerate((1e-2, 1e-2, 3e-3)):
+        for group in opt.param_groups:
+            group["lr"] = lr
+        grads = []
+        for p in params:
+            gr = torch.randn(p.shape, generator=g).to(dev()) * 0.1
+            p.grad.copy_(gr)
+            grads.append(gr)
+        opt.step()
+        for (rp, st), gr, p in zip(ref, grads, params):
+            _reference_adamw_step(rp, gr, st, lr, betas, eps, wd if not any(p is e for e in extra) else 0.0)
+    torch.cuda.synchronize()
+    worst = max(float((p.detach() - rp).abs().max()) for p, (rp, _) in zip(params, ref))
+    worst_m = max(float((opt.state[p]["exp_avg"] - st["m"]).abs().max()) for p, (_, st) in zip(params, ref))
+    worst_v = max(float((opt.state[p]["exp_avg_sq"] - st["v"]).abs().max()) for p, (_, st) in zip(params, ref))
+    print("FusedAdamW: %d parameters in %d + %d launches; max |dp| %.2e |dm| %.2e |dv| %.2e"
+          % (len(params), len(opt._runs[0]), len(opt._runs[1]), worst, worst_m, worst_v))
+    assert worst < 1e-5 and worst_m < 1e-7 and worst_v < 1e-8, (worst, worst_m, worst_v)
+    assert len(opt._runs[0]) <= len(list(core.parameters())) // 3 and len(opt._runs[1]) == 2
+    assert all(opt.state[p]["step"] == 3 for p in params)
+    assert set(opt.state[extra[0]]) >= {"step", "exp_avg", "exp_avg_sq"}

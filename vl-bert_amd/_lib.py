@@ -32,7 +32,7 @@ _SIGS = {
     "vlb_attention_fwd": "ppppiiiifpus",
     "vlb_attention_bwd": "ppppppiiiifpus",
     "vlb_seq_layout": "ppiiiipppppps",
-    "vlb_obj_prep_fwd": "plppppiifpus",
+    "vlb_obj_prep_fwd": "plplpppiifpus",
     "vlb_masked_colsum": "plpiipfpuuus",
     "vlb_embed_fwd": "pppp" "pppp" "pll" "pll" "pll" "p" "pp" "ppp" "iiiiiii" "f" "fpu" "s",
     "vlb_embed_bwd": "pppp" "ppppp" "pppppp" "pll" "pll" "pll" "iiiiiii" "fpu" "i" "s",

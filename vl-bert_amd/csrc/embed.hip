@@ -52,7 +52,7 @@ __global__ void seq_layout_kernel(const uint8_t* __restrict__ text_mask, const u
 // (resnet_vlbert_for_pretraining.py:114-117); hard-coded Dropout(p) of obj_downsample.
 // One 256-thread block per region: 8 coord + 8 feature elements per thread, 16/32-B accesses.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void obj_prep_fwd_kernel(const float* __restrict__ boxes, long ldbox, const float* __restrict__ im_info,
+__global__ __launch_bounds__(256) void obj_prep_fwd_kernel(const float* __restrict__ boxes, long ldbox, const float* __restrict__ im_info, long ldinfo,
                                                            const int64_t* __restrict__ mvrc_ops, const float* __restrict__ mask_emb,
                                                            bf16_t* __restrict__ out, int B, int R, uint32_t drop_thr, float drop_scale,
                                                            const uint32_t* __restrict__ seedp, uint32_t tag) {
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void obj_prep_fwd_kernel(const float* __restri
     *(uint4*)(o + 2048 + tid * 8) = make_uint4(0, 0, 0, 0);
     return;
   }
-  const float W = im_info[b * 5 + 0], Hh = im_info[b * 5 + 1];
+  const float W = im_info[b * ldinfo + 0], Hh = im_info[b * ldinfo + 1];
   const float x1 = bx[0], y1 = bx[1], x2 = bx[2], y2 = bx[3];
   float pos[4];
   pos[0] = (x1 + x2) / 2 / W * 100;
@@ -564,14 +564,16 @@ extern "C" int vlb_seq_layout(const uint8_t* text_mask, const uint8_t* obj_mask,
   return VLB_OK;
 }
 
-extern "C" int vlb_obj_prep_fwd(const float* boxes, long ldbox, const float* im_info, const int64_t* mvrc_ops,
+extern "C" int vlb_obj_prep_fwd(const float* boxes, long ldbox, const float* im_info, long ldinfo, const int64_t* mvrc_ops,
                                 const float* mask_emb, void* out, int B, int R, float drop_p, const uint32_t* seed, uint32_t tag,
                                 hipStream_t stream) {
   if (B * R <= 0) return VLB_OK;
   VLB_CHECK_ARG(ldbox >= 4 + 2048 && (ldbox % 4) == 0, "vlb_obj_prep_fwd: ldbox=%ld must be >= 2052 and a multiple of 4", ldbox);
+  VLB_CHECK_ARG(boxes && im_info && out && ldinfo >= 2, "vlb_obj_prep_fwd: null argument or im_info rows narrower than (width, height): ldinfo=%ld",
+                ldinfo);
   VLB_CHECK_ARG(!(drop_p > 0.f) || seed, "vlb_obj_prep_fwd: dropout needs a device seed pointer");
   const uint32_t thr = vlb_drop_thr(drop_p);
-  hipLaunchKernelGGL(obj_prep_fwd_kernel, dim3(B * R), dim3(256), 0, stream, boxes, ldbox, im_info, mvrc_ops, mask_emb, (bf16_t*)out,
+  hipLaunchKernelGGL(obj_prep_fwd_kernel, dim3(B * R), dim3(256), 0, stream, boxes, ldbox, im_info, ldinfo, mvrc_ops, mask_emb, (bf16_t*)out,
                      B, R, thr, vlb_drop_scale(thr), seed, tag);
   VLB_CHECK_LAUNCH("vlb_obj_prep_fwd");
   return VLB_OK;

@@ -472,7 +472,7 @@ class PretrainEngine:
             self.in_boxes[:, :, :4].copy_(boxes[:, :, :4], non_blocking=True)
         else:
             self.in_boxes.copy_(boxes, non_blocking=True)
-        self.in_im_info.copy_(im_info, non_blocking=True)
+        self.in_im_info[:, :2].copy_(im_info[:, :2], non_blocking=True)      # (width, height); the datasets append 2-3 more columns
         if self.Ba or text.shape[1] != self.T:
             self.in_text.zero_()
             self.in_mlm_labels.fill_(-1)

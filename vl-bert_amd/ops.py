@@ -251,7 +251,9 @@ def seq_layout_into(tm, om, S, out):
 def obj_prep_fwd(boxes, im_info, mvrc_ops, mask_emb, out, drop_p=0.0, seed=None, tag=0):
     B, R, ldb = boxes.shape
     assert boxes.is_contiguous() and out.shape[-1] == 4096
-    _lib.call("vlb_obj_prep_fwd", _p(boxes, torch.float32), ldb, _p(im_info, torch.float32), _p(mvrc_ops, torch.int64),
+    # im_info rows are (width, height, ...): 5 columns from the pre-training / VCR datasets, 4 from VQA's (vqa/data/datasets/vqa.py:217)
+    assert im_info.dim() == 2 and im_info.shape[0] == B and im_info.shape[1] >= 2 and im_info.stride(1) == 1, tuple(im_info.shape)
+    _lib.call("vlb_obj_prep_fwd", _p(boxes, torch.float32), ldb, _p(im_info, torch.float32), im_info.stride(0), _p(mvrc_ops, torch.int64),
               _p(mask_emb, torch.float32), _p(out, BF16), B, R, float(drop_p), _p(seed), int(tag), _stream())
     return out
 

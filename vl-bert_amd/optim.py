@@ -5,10 +5,94 @@ Nesterov): same constructor arguments, same `param_groups` / `state_dict` layout
 LR schedulers and checkpoints work unchanged; `step()` runs vlb_sgd_momentum_step (optim.hip: weight decay, momentum and the update
 in ONE pass over each parameter, no temporaries).  Parameters that are consecutive slices of one flat allocation (the `FlatParams`
 storage behind the VisualLinguisticBert mirrors) are updated by a single launch over the whole range.
+
+`FusedAdamW` = the reference's own `AdamW` (common/nlp/bert/optimization.py:107-187, the optimiser of the pre-training and VQA entry
+points: Adam with bias correction, weight decay applied to the weights AFTER the Adam update with the un-corrected lr), same constructor
+arguments and per-parameter state keys (`step`, `exp_avg`, `exp_avg_sq`); `step()` runs vlb_adamw_step per flat run.
 """
 import torch
 
 from . import ops
+
+
+def _flat_runs(params):
+    """[(first index, last index + 1)] of maximal runs whose parameter AND gradient tensors are consecutive in memory."""
+    runs, start = [], 0
+    for i in range(1, len(params) + 1):
+        if i < len(params):
+            a, b = params[i - 1], params[i]
+            same = (a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()
+                    and a.grad.untyped_storage().data_ptr() == b.grad.untyped_storage().data_ptr()
+                    and b.data_ptr() == a.data_ptr() + a.numel() * 4 and b.grad.data_ptr() == a.grad.data_ptr() + a.numel() * 4)
+            if same:
+                continue
+        runs.append((start, i))
+        start = i
+    return runs
+
+
+def _check_fp32_gpu(ps, who):
+    for p in ps:
+        if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous() and p.grad.dtype == torch.float32):
+            raise RuntimeError("%s needs contiguous fp32 GPU parameters and gradients; there is no CPU path" % who)
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, correct_bias=True):
+        if lr < 0.0 or eps < 0.0 or not (0.0 <= betas[0] < 1.0) or not (0.0 <= betas[1] < 1.0):
+            raise ValueError("invalid hyper-parameter")          # the reference's checks (optimization.py:117-124)
+        if not correct_bias:
+            raise NotImplementedError("FusedAdamW implements correct_bias=True (every shipped configuration)")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, correct_bias=correct_bias))
+        self._runs = {}
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for gi, group in enumerate(self.param_groups):
+            ps = [p for p in group["params"] if p.grad is not None]
+            _check_fp32_gpu(ps, "FusedAdamW")
+            key = (gi, tuple((p.data_ptr(), p.grad.data_ptr()) for p in ps))
+            if self._runs.get("key%d" % gi) != key:
+                self._runs["key%d" % gi] = key
+                self._runs[gi] = _flat_runs(ps)
+            hyper = (float(group["lr"]), float(group["betas"][0]), float(group["betas"][1]), float(group["eps"]), float(group["weight_decay"]))
+            for a, b in self._runs[gi]:
+                first = ps[a]
+                n = sum(p.numel() for p in ps[a:b])
+                st = self.state[first]
+                if "flat_m" not in st or st["flat_m"].numel() != n:
+                    st["flat_m"] = torch.zeros(n, dtype=torch.float32, device=first.device)
+                    st["flat_v"] = torch.zeros(n, dtype=torch.float32, device=first.device)
+                    steps = [self.state[p].get("step", 0) for p in ps[a:b]]
+                    if len(set(steps)) != 1:
+                        raise RuntimeError("FusedAdamW: parameters of one flat run carry different step counts")
+                    # device-resident {lr, beta1, beta2, eps, weight_decay, step, max_norm (0: no clip), sumsq}: one per run
+                    st["dev"] = torch.tensor(list(hyper) + [float(steps[0]), 0.0, 0.0], dtype=torch.float32, device=first.device)
+                    st["hyper"] = hyper
+                    off = 0
+                    for p in ps[a:b]:                        # the reference's per-parameter state: views of the run's buffers
+                        for name, flat in (("exp_avg", st["flat_m"]), ("exp_avg_sq", st["flat_v"])):
+                            old = self.state[p].get(name)
+                            view = flat[off:off + p.numel()].view_as(p)
+                            if old is not None:
+                                view.copy_(old)
+                            self.state[p][name] = view
+                        self.state[p].setdefault("step", 0)
+                        off += p.numel()
+                if st["hyper"] != hyper:                     # an LR scheduler (or the user) changed the group's values
+                    st["dev"][0:5].copy_(torch.tensor(hyper, dtype=torch.float32), non_blocking=True)
+                    st["hyper"] = hyper
+                pf = first.data.as_strided((n,), (1,), first.storage_offset())
+                gf = first.grad.as_strided((n,), (1,), first.grad.storage_offset())
+                ops.adamw_step(pf, gf, st["flat_m"], st["flat_v"], None, st["dev"])      # (the kernel advances the run's step count)
+                for p in ps[a:b]:
+                    self.state[p]["step"] += 1
+                    torch.autograd.graph.increment_version(p)
+        return loss
 
 
 class FusedSGD(torch.optim.Optimizer):
@@ -20,22 +104,6 @@ class FusedSGD(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, momentum=momentum, dampening=dampening, weight_decay=weight_decay, nesterov=nesterov))
         self._runs = {}
 
-    @staticmethod
-    def _flat_runs(params):
-        """[(first index, last index + 1)] of maximal runs whose parameter AND gradient tensors are consecutive in memory."""
-        runs, start = [], 0
-        for i in range(1, len(params) + 1):
-            if i < len(params):
-                a, b = params[i - 1], params[i]
-                same = (a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()
-                        and a.grad.untyped_storage().data_ptr() == b.grad.untyped_storage().data_ptr()
-                        and b.data_ptr() == a.data_ptr() + a.numel() * 4 and b.grad.data_ptr() == a.grad.data_ptr() + a.numel() * 4)
-                if same:
-                    continue
-            runs.append((start, i))
-            start = i
-        return runs
-
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
@@ -44,13 +112,11 @@ class FusedSGD(torch.optim.Optimizer):
                 loss = closure()
         for gi, group in enumerate(self.param_groups):
             ps = [p for p in group["params"] if p.grad is not None]
-            for p in ps:
-                if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous() and p.grad.dtype == torch.float32):
-                    raise RuntimeError("FusedSGD needs contiguous fp32 GPU parameters and gradients; there is no CPU path")
+            _check_fp32_gpu(ps, "FusedSGD")
             key = (gi, tuple((p.data_ptr(), p.grad.data_ptr()) for p in ps))
             if self._runs.get("key%d" % gi) != key:          # layout changed (first step / re-allocated gradients): re-derive the runs
                 self._runs["key%d" % gi] = key
-                self._runs[gi] = self._flat_runs(ps)
+                self._runs[gi] = _flat_runs(ps)
             for a, b in self._runs[gi]:
                 first = ps[a]
                 n = sum(p.numel() for p in ps[a:b])
