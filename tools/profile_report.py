@@ -90,6 +90,12 @@ if glob.glob(os.path.join(src, "final_vcr_trace", "*.db")):
                  "module mirror: 24 x 1024 encoder, 4 samples x 4 answer choices x 256 positions + 4 images of 600x1000 per micro-batch,\n# 4 micro-batches "
                  "per optimizer step; 1 warm-up + 2 timed + 1 instrumented optimizer step = 4 steps in the process; weight-gradient streams NOT serialised)\n",
                  steps=4.0)
+if glob.glob(os.path.join(src, "final_vqa_trace", "*.db")):
+    kernel_stats("final_vqa_trace", tag + "_vqa_kernel_stats.txt",
+                 "# rocprofv3 --kernel-trace --stats -- python bench.py --vqa --steps 2 --warmup 1 --no-cpu-baseline\n# (BASELINE config 4's shape through "
+                 "the module mirror, bf16: 24 x 1024 encoder, 16 samples x 229 positions per micro-batch, precomputed region features,\n# 4 micro-batches "
+                 "per optimizer step, AdamW; 1 warm-up + 2 timed + 1 instrumented optimizer step = 4 steps in the process; weight-gradient streams NOT serialised)\n",
+                 steps=4.0)
 if len(sys.argv) > 5 and sys.argv[5] == "extra-only":
     sys.exit(0)
 
