@@ -375,12 +375,57 @@ def test_dropin_module_train_mode_backward_uses_forward_dropout_masks():
     eng.P.grad.zero_()
     eng._fresh_grads = False
     eng.forward_core(train=True)
-    eng.backward_core(c0, c1, None, train=True)
+    pad = torch.nn.functional.pad           # the mirror rounds (T, R) up to its shape buckets: cotangents of the extra positions are 0
+    eng.backward_core(pad(c0, (0, 0, 0, eng.T - c0.shape[1])), pad(c1, (0, 0, 0, eng.R - c1.shape[1])), None, train=True)
     torch.cuda.synchronize()
     named = eng.P.named(eng.P.grad)
     worst = max((rel_fro(got[n], named["vlbert." + n]), n) for n in got if float(named["vlbert." + n].norm()) > 0)
     print("train-mode module-API mirror vs engine (same seed): worst rel-fro %.3e (%s)" % worst)
     assert worst[0] < 1e-4, worst
+
+
+def test_mirror_shape_buckets_do_not_change_results(monkeypatch):
+    """The collators pad each batch to its own longest text / largest box count, so the mirrors see a new (T, R) almost every batch; they
+    round both up to a bucket (masked positions, outputs sliced back) and keep a bounded number of engines.  Exact shapes
+    (VLB_MIRROR_BUCKETS=1,1,8) and bucketed shapes (default 8,4,8 -> T 11 -> 16, R 6 -> 8) must agree: outputs, and gradients w.r.t.
+    parameters and both embedding inputs; the engine cache stays within its cap over many shapes."""
+    VL = pkg("common.visual_linguistic_bert")
+    z, ccfg, params, ins = _core_fixture()
+    res = {}
+    for mode in ("1,1,8", "8,4,8"):
+        monkeypatch.setenv("VLB_MIRROR_BUCKETS", mode)
+        core = VL.VisualLinguisticBertForPretraining(_module_config(ccfg)["NETWORK"]["VLBERT"], with_rel_head=False)
+        core.load_state_dict(params)
+        core.eval()
+        tv, ovl = ins[2].clone().requires_grad_(True), ins[4].clone().requires_grad_(True)
+        _, mlm, mvrc = core(ins[0], ins[1], tv, ins[3], ovl, ins[5], output_all_encoded_layers=False, output_text_and_object_separately=True)
+        g = torch.Generator().manual_seed(9)
+        c0 = torch.randn(mlm.shape, generator=g).to(dev()) * 1e-2
+        c1 = torch.randn(mvrc.shape, generator=g).to(dev()) * 1e-2
+        ((mlm * c0).sum() + (mvrc * c1).sum()).backward()
+        torch.cuda.synchronize()
+        key = next(iter(core._engines))
+        res[mode] = (mlm.detach(), mvrc.detach(), tv.grad.clone(), ovl.grad.clone(),
+                     {n: p.grad.detach().clone() for n, p in core.named_parameters()}, key)
+    exact, buck = res["1,1,8"], res["8,4,8"]
+    assert exact[5][1:3] == (11, 6) and buck[5][1:3] == (16, 8), (exact[5], buck[5])
+    report("bucketed vs exact mlm logits", buck[0], exact[0], 2e-2, 1e-2)
+    report("bucketed vs exact mvrc logits", buck[1], exact[1], 2e-2, 1e-2)
+    assert rel_fro(buck[2], exact[2]) < 2e-2 and rel_fro(buck[3], exact[3]) < 2e-2
+    worst = max((rel_fro(buck[4][n], exact[4][n]), n) for n in exact[4] if float(exact[4][n].norm()) > 0)
+    print("bucketed vs exact shapes: worst parameter-gradient rel-fro %.3e (%s)" % worst)
+    assert worst[0] < 2e-2, worst
+    # bounded cache: 12 distinct text lengths -> at most 8 engines (here even fewer buckets)
+    monkeypatch.setenv("VLB_MIRROR_BUCKETS", "1,1,3")
+    core = VL.VisualLinguisticBert(_module_config(ccfg)["NETWORK"]["VLBERT"])
+    core.eval()
+    H = ccfg.hidden_size
+    for T in range(4, 16):
+        ids = torch.randint(5, 100, (2, T), device=dev())
+        core(ids, torch.zeros_like(ids), torch.zeros(2, T, H, device=dev()), torch.ones(2, T, dtype=torch.bool, device=dev()),
+             torch.zeros(2, 3, 2 * H, device=dev()), torch.ones(2, 3, dtype=torch.bool, device=dev()), output_all_encoded_layers=False,
+             output_text_and_object_separately=True)
+    assert len(core._engines) == 3, len(core._engines)
 
 
 def _core_fixture():

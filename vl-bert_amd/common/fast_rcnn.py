@@ -18,6 +18,8 @@ load_state_dict convert from / to the reference's [O,I,KH,KW]).  `segms` [B,R,14
 RoI-head output before the pool (:152-156).  Not supported on this branch: IMAGE_SEMANTIC (`classes` is accepted and unused, as
 in the reference with that option off), `mask_visual_embed`, the bottom-of-CNN cnn_reg_loss, OUTPUT_CONV5.
 """
+from collections import OrderedDict
+
 import torch
 import torch.nn as nn
 
@@ -133,8 +135,8 @@ class FastRCNN(nn.Module):
         self._wT = torch.zeros((2 * VIS_DIM, final_dim), dtype=torch.bfloat16, device=dev)
         self._zero_embed = torch.zeros((VIS_DIM,), dtype=torch.float32, device=dev)
         self._seed = torch.tensor([ops.rank_seed(20011)], dtype=torch.int32, device=dev)
-        self._version, self._states = None, {}
-        self._stacks, self._conv_params, self._conv_grads, self._vbuffers, self._vversion = {}, {}, {}, {}, 0
+        self._version, self._states = None, OrderedDict()
+        self._stacks, self._conv_params, self._conv_grads, self._vbuffers, self._vversion = OrderedDict(), {}, {}, {}, 0
         if self.e2e:
             from .. import vision as _vision
             self._vision = _vision
@@ -192,12 +194,13 @@ class FastRCNN(nn.Module):
         return super().load_state_dict(state_dict, strict=strict)
 
     def _stack(self, B, R, Hi, Wi, dev):
-        key = (B, R, Hi, Wi)
-        if key not in self._stacks:
-            storage = lambda name, shape: (self._conv_params[name].data, self._conv_grads[name])
-            self._stacks[key] = self._vision.VisionStack(B, Hi, Wi, R, device=dev, num_layers=self._nl, frozen_stages=self._frozen_stages,
-                                                         storage=storage)
-        return self._stacks[key]
+        # the collators pad the images of a batch to that batch's largest one (clip_pad_images), so (Hi, Wi) varies: a stack owns every
+        # activation of the trunk for one geometry (6.4 GB at 8 x 600 x 1000) -- only the most recently used ones are kept
+        from .visual_linguistic_bert import lru_get
+        storage = lambda name, shape: (self._conv_params[name].data, self._conv_grads[name])
+        return lru_get(self._stacks, (B, R, Hi, Wi),
+                       lambda: self._vision.VisionStack(B, Hi, Wi, R, device=dev, num_layers=self._nl, frozen_stages=self._frozen_stages,
+                                                        storage=storage))
 
     def _sync_vision(self, vs):
         """BatchNorm tensors / frozen weights after construction or load_state_dict; folded bf16 operands after any weight update."""
@@ -231,13 +234,12 @@ class FastRCNN(nn.Module):
             self._version = w._version
 
     def _state(self, B, R, dev):
-        key = (B, R)
-        if key not in self._states:
+        def make():
             n, H = B * R, self.final_dim
             zb = lambda *s: torch.zeros(s, dtype=torch.bfloat16, device=dev)
-            self._states[key] = dict(a=zb(n, 2 * VIS_DIM), y=zb(n, H), out=zb(n, H), dy_all=zb(n, H), dy=zb(n, H),
-                                     dfeat=zb(n, VIS_DIM))
-        return self._states[key]
+            return dict(a=zb(n, 2 * VIS_DIM), y=zb(n, H), out=zb(n, H), dy_all=zb(n, H), dy=zb(n, H), dfeat=zb(n, VIS_DIM))
+        from .visual_linguistic_bert import lru_get       # (R follows each batch's largest box count: keep the recent shapes only)
+        return lru_get(self._states, (B, R), make)
 
     def _forward_e2e(self, images, boxes, box_mask, im_info, classes, segms, mvrc_ops, mask_visual_embed):
         # `classes` only feeds the IMAGE_SEMANTIC object-class embedding and the bottom-of-CNN regulariser (common/fast_rcnn.py:139,

@@ -15,13 +15,46 @@ backward).  Supported: visual_size == hidden_size, visual_ln, optional pooler / 
 text and objects returned separately; anything else raises NotImplementedError (no silent eager fallback).
 Parameters are views of the engine's flat fp32 master buffer, `.grad` views of its flat gradient buffer.
 """
+import os
+from collections import OrderedDict
+
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from .. import engine as _engine
 from .. import ops
 
 _PREFIX = "vlbert."
+_MAX_S = 256      # longest packed sequence the attention kernels cover (attention.hip: ATT_SP_MAX)
+
+
+def shape_buckets():
+    """(text multiple, region multiple, max cached engines).  The reference's collators pad every batch to ITS longest question and
+    ITS largest box count (vqa/data/collate_batch.py:20-21, pretrain/data/collate_batch.py), so (T, R) changes from batch to batch; an
+    engine owns static buffers for one (B, T, R), hence the mirrors round T and R up to a multiple (extra positions are masked out,
+    outputs are sliced back) and keep only the most recently used engines.  VLB_MIRROR_BUCKETS="8,4,8" (default); "1,1,N" = exact."""
+    v = os.environ.get("VLB_MIRROR_BUCKETS", "8,4,8").split(",")
+    return max(1, int(v[0])), max(1, int(v[1])), max(1, int(v[2]))
+
+
+def bucketed(T, R):
+    bt, br, _ = shape_buckets()
+    Tp, Rp = (T + bt - 1) // bt * bt, (R + br - 1) // br * br
+    if Tp + Rp + 1 > _MAX_S:          # rounding must not push a sequence that fits over the kernels' limit
+        Tp, Rp = T, R
+    return Tp, Rp
+
+
+def lru_get(cache, key, make):
+    """cache: OrderedDict; newest last; at most shape_buckets()[2] entries (an evicted engine is freed once no autograd graph holds it)"""
+    if key in cache:
+        cache.move_to_end(key)
+        return cache[key]
+    cache[key] = make()
+    while len(cache) > shape_buckets()[2]:
+        cache.popitem(last=False)
+    return cache[key]
 
 
 def _get(obj, name, default=None):
@@ -89,7 +122,7 @@ class VisualLinguisticBert(nn.Module):
             raise RuntimeError("VisualLinguisticBert (HIP) needs an MI355X: there is no CPU fallback")
         self.device_ = torch.device(device or ("cuda:%d" % torch.cuda.current_device()))
         self.flat = _engine.FlatParams(self.cfg, self.device_)
-        self._engines = {}
+        self._engines = OrderedDict()
         self._pnames = {}
         heads = ("mlm_head.", "mvrc_head.", "relationsip_head.")
         for name, t in self.flat.named(self.flat.master).items():
@@ -132,12 +165,10 @@ class VisualLinguisticBert(nn.Module):
                 p.grad = named[_PREFIX + name]
 
     def _engine_for(self, B, T, R, sequence=False):
-        key = (B, T, R, sequence)
-        if key not in self._engines:
-            self._engines[key] = _engine.PretrainEngine(self.cfg, B, T, R, device=str(self.device_), flat=self.flat, core=True,
-                                                        core_heads=self.WITH_HEADS, core_sequence=sequence,
-                                                        seed=ops.rank_seed(1234) // 2)      # per-rank dropout stream
-        eng = self._engines[key]
+        eng = lru_get(self._engines, (B, T, R, sequence),
+                      lambda: _engine.PretrainEngine(self.cfg, B, T, R, device=str(self.device_), flat=self.flat, core=True,
+                                                     core_heads=self.WITH_HEADS, core_sequence=sequence,
+                                                     seed=ops.rank_seed(1234) // 2))        # per-rank dropout stream
         version = self.flat.master._version
         if getattr(eng, "_synced_version", None) != version:
             eng.sync_weights()
@@ -149,10 +180,20 @@ class VisualLinguisticBert(nn.Module):
              sequence=False):
         B, T = text_input_ids.shape
         R = object_vl_embeddings.shape[1]
-        eng = self._engine_for(B, T, R, sequence)
+        Tp, Rp = bucketed(T, R)
+        if Tp != T:       # masked-out extra text positions (autograd slices the gradient of the padded embeddings back)
+            text_input_ids, text_token_type_ids = F.pad(text_input_ids, (0, Tp - T)), F.pad(text_token_type_ids, (0, Tp - T))
+            text_visual_embeddings = F.pad(text_visual_embeddings, (0, 0, 0, Tp - T))
+            text_mask = F.pad(text_mask, (0, Tp - T))
+        if Rp != R:
+            object_vl_embeddings, object_mask = F.pad(object_vl_embeddings, (0, 0, 0, Rp - R)), F.pad(object_mask, (0, Rp - R))
+        eng = self._engine_for(B, Tp, Rp, sequence)
         eng.set_core_inputs(text_input_ids, text_token_type_ids, text_visual_embeddings, text_mask, object_vl_embeddings, object_mask)
         anchor = next(iter(self._pnames.values()))
-        return _CoreFn.apply(text_visual_embeddings, object_vl_embeddings, anchor, self, eng)
+        a, b, third = _CoreFn.apply(text_visual_embeddings, object_vl_embeddings, anchor, self, eng)
+        if not sequence:  # [B, Tp, .] / [B, Rp, .] -> the caller's T and R (the packed sequence output is trimmed to its own length)
+            a, b = a[:, :T], b[:, :R]
+        return a, b, third
 
     def forward(self, text_input_ids, text_token_type_ids, text_visual_embeddings, text_mask, object_vl_embeddings, object_mask,
                 output_all_encoded_layers=True, output_text_and_object_separately=False, output_attention_probs=False):

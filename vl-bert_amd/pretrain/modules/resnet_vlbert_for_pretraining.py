@@ -20,11 +20,15 @@ flat buffer in the engine's [O,KH,KW,I] layout (state_dict / load_state_dict con
 BatchNorm tensors and the frozen stages are buffers under the reference's names.  One image size per module (static shapes).
 Anything else raises NotImplementedError (nothing silently falls back to PyTorch eager).
 """
+from collections import OrderedDict
+
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from ... import engine as _engine
 from ... import ops
+from ...common.visual_linguistic_bert import bucketed, lru_get
 
 
 def _get(obj, name, default=None):
@@ -91,7 +95,7 @@ class ResNetVLBERTForPretraining(nn.Module):
         if not torch.cuda.is_available():
             raise RuntimeError("ResNetVLBERTForPretraining (HIP) needs an MI355X: there is no CPU fallback")
         self.device_ = torch.device(device or ("cuda:%d" % torch.cuda.current_device()))
-        self._engines = {}
+        self._engines = OrderedDict()
         self.flat = _engine.FlatParams(self.cfg, self.device_)
         self._init_scale = (_get(vl, "visual_scale_text_init", 0.0), _get(vl, "visual_scale_object_init", 0.0),
                             _get(vl, "initializer_range", 0.02))
@@ -185,12 +189,9 @@ class ResNetVLBERTForPretraining(nn.Module):
                 self._pnames[name].grad = t
 
     def _engine_for(self, B, T, R, B_aux=0, image_size=None):
-        key = (B, T, R, B_aux, image_size)
-        if key not in self._engines:
-            eng = _engine.PretrainEngine(self.cfg, B, T, R, device=str(self.device_), keep_logits=True, flat=self.flat,
-                                         B_aux=B_aux, image_size=image_size, seed=ops.rank_seed(1234) // 2)   # per-rank dropout stream
-            self._engines[key] = eng
-        eng = self._engines[key]
+        eng = lru_get(self._engines, (B, T, R, B_aux, image_size),
+                      lambda: _engine.PretrainEngine(self.cfg, B, T, R, device=str(self.device_), keep_logits=True, flat=self.flat,
+                                                     B_aux=B_aux, image_size=image_size, seed=ops.rank_seed(1234) // 2))   # per-rank dropout stream
         if self.e2e and getattr(eng, "_buffers_version", None) != self._buffers_version:
             eng.vision.load_state_dict(self._vision_buffers, strict=False)      # BatchNorm tensors + frozen stages (trainables live in flat)
             eng._buffers_version = self._buffers_version
@@ -217,22 +218,33 @@ class ResNetVLBERTForPretraining(nn.Module):
             mlm_logits[:, seq_max:] = -10000.0
         return mlm_logits, mvrc
 
+    @staticmethod
+    def _bucket_regions(R, Rp, boxes, mvrc_ops, mvrc_labels):
+        """R box slots -> Rp: padded rows carry the collator's markers (boxes -2, mvrc_ops 0, labels 0: pretrain/data/collate_batch.py:39-55).
+        (The text side needs no copy: the engine accepts text / labels narrower than its T and pads them itself.)"""
+        if Rp == R:
+            return boxes, mvrc_ops, mvrc_labels
+        return F.pad(boxes, (0, 0, 0, Rp - R), value=-2.0), F.pad(mvrc_ops, (0, Rp - R)), F.pad(mvrc_labels, (0, 0, 0, Rp - R))
+
     # -- forward ------------------------------------------------------------------------------------
     def forward(self, image, boxes, im_info, text, relationship_label, mlm_labels, mvrc_ops, mvrc_labels):
         if (image is not None) != self.e2e:
             raise NotImplementedError("IMAGE_FEAT_PRECOMPUTED configuration takes image=None, the e2e configuration an image batch")
         B, R = boxes.shape[0], boxes.shape[1]
         T = text.shape[1]
+        Tp, Rp = bucketed(T, R)        # (T, R) follow each batch's longest caption / largest box count: engines exist per bucket
+        boxes_p, ops_p, labels_p = self._bucket_regions(R, Rp, boxes, mvrc_ops, mvrc_labels)
         if self.e2e:
-            eng = self._engine_for(B, T, R, image_size=(int(image.shape[2]), int(image.shape[3])))
-            eng.set_batch(boxes, im_info, text, relationship_label, mlm_labels, mvrc_ops, mvrc_labels, image=image.float())
+            eng = self._engine_for(B, Tp, Rp, image_size=(int(image.shape[2]), int(image.shape[3])))
+            eng.set_batch(boxes_p, im_info, text, relationship_label, mlm_labels, ops_p, labels_p, image=image.float())
         else:
-            eng = self._engine_for(B, T, R)
-            eng.set_batch(boxes, im_info, text, relationship_label, mlm_labels, mvrc_ops, mvrc_labels)
+            eng = self._engine_for(B, Tp, Rp)
+            eng.set_batch(boxes_p, im_info, text, relationship_label, mlm_labels, ops_p, labels_p)
         eng.mirror_pre_forward(self.training)      # fresh dropout masks for this forward AND its backward
         eng.forward(train=self.training)
         loss = _HipLoss.apply(self._pnames["vlbert.word_embeddings.weight"], self, eng)
         mlm_logits, mvrc = self._padded_logits(eng, B)
+        mlm_logits, mvrc = mlm_logits[:, :T], mvrc[:, :R]
         outputs = {
             "relationship_logits": eng.rel_logits_copy[:, :2].float() if self.with_rel else None,
             "relationship_label": relationship_label if self.with_rel else None,
@@ -266,18 +278,21 @@ class ResNetVLBERTForPretrainingMultitask(ResNetVLBERTForPretraining):
             cur += t.shape[0]
         B, R = boxes.shape[0], boxes.shape[1]
         T = max(text.shape[1], Ta)
+        Tp, Rp = bucketed(T, R)
+        boxes_p, ops_p, labels_p = self._bucket_regions(R, Rp, boxes, mvrc_ops, mvrc_labels)
         if self.e2e:      # only the caption samples carry an image (cfgs/pretrain/base_e2e_16x16G_fp16.yaml)
-            eng = self._engine_for(B, T, R, Ba, image_size=(int(image.shape[2]), int(image.shape[3])))
-            eng.set_batch(boxes, im_info, text, relationship_label, mlm_labels, mvrc_ops, mvrc_labels, aux_text, aux_labels,
+            eng = self._engine_for(B, Tp, Rp, Ba, image_size=(int(image.shape[2]), int(image.shape[3])))
+            eng.set_batch(boxes_p, im_info, text, relationship_label, mlm_labels, ops_p, labels_p, aux_text, aux_labels,
                           image=image.float())
         else:
-            eng = self._engine_for(B, T, R, Ba)
-            eng.set_batch(boxes, im_info, text, relationship_label, mlm_labels, mvrc_ops, mvrc_labels, aux_text, aux_labels)
+            eng = self._engine_for(B, Tp, Rp, Ba)
+            eng.set_batch(boxes_p, im_info, text, relationship_label, mlm_labels, ops_p, labels_p, aux_text, aux_labels)
         eng.mirror_pre_forward(self.training)
         eng.forward(train=self.training)
         loss = _HipLoss.apply(self._pnames["vlbert.word_embeddings.weight"], self, eng)
         mlm_logits, mvrc = self._padded_logits(eng, B + Ba)
-        lab = eng.in_mlm_labels
+        mlm_logits, mvrc = mlm_logits[:, :T], mvrc[:, :R]
+        lab = eng.in_mlm_labels[:, :T]
         outputs = {
             "relationship_logits": None, "relationship_label": None,
             "mlm_logits_wvc": mlm_logits[:B], "mlm_label_wvc": lab[:B].clone(),
