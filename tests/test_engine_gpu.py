@@ -384,6 +384,35 @@ def test_dropin_module_train_mode_backward_uses_forward_dropout_masks():
     assert worst[0] < 1e-4, worst
 
 
+def test_engine_accepts_batches_narrower_than_its_buffers():
+    """set_batch with a collated batch that has fewer text columns and fewer box slots than the engine was built for (the collator
+    pads to each batch's own maxima): the engine completes them with the collator's padding markers; losses and every gradient equal
+    those of an engine built for the batch's exact shape."""
+    syn = pkg("synthetic")
+    cfg = O.VLBertConfig(num_hidden_layers=2)
+    params = O.init_params(cfg, seed=61)
+    B, T, R = 3, 24, 9
+    batch = [t.to(dev()) for t in syn.make_batch(B, T, R, seed=62, ragged=True)]
+    res = []
+    for Te, Re in ((T, R), (T + 8, R + 3)):
+        eng = make_engine(cfg, B, Te, Re, train=False)
+        eng.load_state_dict({k: v.to(dev()) for k, v in params.items()})
+        if (Te, Re) != (T, R):        # stale content in the extra slots must not leak: fill them with a full-width batch first
+            eng.set_batch(*[t.to(dev()) for t in syn.make_batch(B, Te, Re, seed=63)])
+        eng.set_batch(*batch)
+        eng.zero_grad()
+        eng.forward(train=False)
+        eng.backward(train=False)
+        torch.cuda.synchronize()
+        res.append((eng.loss_values(), {k: v.detach().clone() for k, v in eng.g32.items()}))
+    (l0, g0), (l1, g1) = res
+    for k in ("loss", "mlm_loss", "mvrc_loss"):
+        assert abs(l0[k] - l1[k]) <= 1e-3 * max(1.0, abs(l0[k])), (k, l0[k], l1[k])
+    worst = max((rel_fro(g1[n], g0[n]), n) for n in g0 if float(g0[n].norm()) > 0)
+    print("wider engine vs exact-shape engine: worst gradient rel-fro %.3e (%s)" % worst)
+    assert worst[0] < 2e-2, worst
+
+
 def test_mirror_shape_buckets_do_not_change_results(monkeypatch):
     """The collators pad each batch to its own longest text / largest box count, so the mirrors see a new (T, R) almost every batch; they
     round both up to a bucket (masked positions, outputs sliced back) and keep a bounded number of engines.  Exact shapes

@@ -469,9 +469,19 @@ class PretrainEngine:
             if image is None:
                 raise ValueError("engine built with e2e=True needs image=")
             self.in_image.copy_(image, non_blocking=True)
-            self.in_boxes[:, :, :4].copy_(boxes[:, :, :4], non_blocking=True)
+        # the collator pads to the batch's own largest box count (pretrain/data/collate_batch.py:21,39): fewer slots than this engine's R
+        # are completed with its padding markers (boxes -2, mvrc_ops 0, soft labels 0)
+        Rb = boxes.shape[1]
+        if Rb > self.R:
+            raise ValueError("batch has %d box slots, engine was built for %d" % (Rb, self.R))
+        if Rb < self.R:
+            self.in_boxes[:, Rb:].fill_(-2.0)
+            self.in_mvrc_ops[:, Rb:].zero_()
+            self.in_mvrc_labels[:, Rb:].zero_()
+        if self.vision is not None:
+            self.in_boxes[:, :Rb, :4].copy_(boxes[:, :, :4], non_blocking=True)
         else:
-            self.in_boxes.copy_(boxes, non_blocking=True)
+            self.in_boxes[:, :Rb].copy_(boxes, non_blocking=True)
         self.in_im_info[:, :2].copy_(im_info[:, :2], non_blocking=True)      # (width, height); the datasets append 2-3 more columns
         if self.Ba or text.shape[1] != self.T:
             self.in_text.zero_()
@@ -483,8 +493,8 @@ class PretrainEngine:
                 raise ValueError("engine built with B_aux=%d needs aux_text of that many rows" % self.Ba)
             self.in_text[B:, :aux_text.shape[1]].copy_(aux_text, non_blocking=True)
             self.in_mlm_labels[B:, :aux_mlm_labels.shape[1]].copy_(aux_mlm_labels, non_blocking=True)
-        self.in_mvrc_ops.copy_(mvrc_ops, non_blocking=True)
-        self.in_mvrc_labels.copy_(mvrc_labels, non_blocking=True)
+        self.in_mvrc_ops[:, :Rb].copy_(mvrc_ops, non_blocking=True)
+        self.in_mvrc_labels[:, :Rb].copy_(mvrc_labels, non_blocking=True)
         if self.cfg.with_rel_loss:
             self.in_rel_label.copy_(relationship_label, non_blocking=True)
         torch.gt(self.in_text, 0, out=self.text_mask.view(torch.bool))
