@@ -1,7 +1,6 @@
 """VCR fine-tuning wrapper (BASELINE config 5) on the GPU (-m gpu): the `ResNetVLBERT` mirror of
 vcr/modules/resnet_vlbert_for_vcr.py against the fixture produced by the reference's own module and against oracle/vcr_oracle.py, and
 the fused SGD-momentum step (vcr/function/train.py:124-128) against torch.optim.SGD semantics."""
-import numpy as np
 import pytest
 import torch
 
