@@ -919,6 +919,47 @@ def test_roi_align_debug_fixture(ops):
     report("roi_align debug.py fixture", out[0, 0], torch.tensor([[15., 18, 21], [42, 45, 48], [69, 72, 75]]), 1e-5, 0)
 
 
+def test_roi_align_module_api_drop_in(ops):
+    """The seam the reference itself exposes: `common.lib.roi_pooling.roi_align.ROIAlign` / `roi_align` and the
+    `C_ROIPooling` functions behind them -- the reference's debug.py fixture through the MODULE, autograd backward against the numpy
+    oracle, non-contiguous / non-fp32 inputs (the module casts, like the reference), an empty RoI list, and the error contract."""
+    from oracle import roi_align_oracle as R
+    RA = pkg("common.lib.roi_pooling.roi_align")
+    C = pkg("common.lib.roi_pooling.C_ROIPooling")
+    feature = torch.arange(81 * 2 * 3).view(2, 3, 9, 9).float().to(dev())
+    rois = torch.tensor([[0, 0, 0, 9, 9], [1, 0, 0, 9, 9], [1, 0, 0, 7, 7]], dtype=torch.float32, device=dev())
+    layer = RA.ROIAlign((3, 3), 1.0, 1)
+    assert "output_size=(3, 3)" in repr(layer)
+    out = layer(feature, rois)
+    report("ROIAlign module, debug.py fixture", out[0, 0], torch.tensor([[15., 18, 21], [42, 45, 48], [69, 72, 75]]), 1e-5, 0)
+    # autograd through the Function; half input + non-contiguous rois are cast / made contiguous by the wrapper chain
+    rng = np.random.RandomState(3)
+    x = torch.from_numpy(rng.randn(2, 6, 12, 17).astype(np.float32))
+    rois_np = np.array([[0, 3.2, 2.1, 40.5, 30.0], [1, 0, 0, 60, 44], [1, 10, 5, 12, 9], [0, -4, -4, 20, 20]], dtype=np.float32)
+    xg = x.to(dev()).requires_grad_(True)
+    wide = torch.zeros((4, 7), device=dev())
+    wide[:, :5] = torch.from_numpy(rois_np).to(dev())
+    y = RA.roi_align(xg, wide[:, :5], (4, 5), 0.25, 2)
+    ref = R.roi_align_forward(x.numpy(), rois_np, 0.25, 4, 5, 2)
+    report("roi_align function fwd", y, torch.from_numpy(ref).float(), 1e-5, 1e-5)
+    dy = rng.randn(*ref.shape).astype(np.float32)
+    y.backward(torch.from_numpy(dy).to(dev()))
+    gref = R.roi_align_backward(dy, rois_np, 0.25, 4, 5, 2, 6, 12, 17, 2)
+    report("roi_align function bwd (autograd)", xg.grad, torch.from_numpy(gref).float(), 1e-5, 1e-5)
+    yh = RA.ROIAlign((4, 5), 0.25, 2)(x.to(dev()).half(), torch.from_numpy(rois_np).to(dev()).double())
+    assert yh.dtype == torch.float32
+    report("ROIAlign module on half features / double rois", yh, torch.from_numpy(R.roi_align_forward(x.half().float().numpy(), rois_np, 0.25, 4, 5,
+                                                                                                      2)).float(), 1e-5, 1e-5)
+    empty = RA.ROIAlign((4, 5), 0.25, 2)(x.to(dev()), torch.zeros((0, 5), device=dev()))
+    assert tuple(empty.shape) == (0, 6, 4, 5)
+    with pytest.raises(RuntimeError, match="GPU tensor"):
+        C.roi_align_forward(x, torch.from_numpy(rois_np), 0.25, 4, 5, 2)
+    with pytest.raises(RuntimeError, match="float32"):
+        C.roi_align_forward(x.to(dev()).half(), torch.from_numpy(rois_np).to(dev()), 0.25, 4, 5, 2)
+    with pytest.raises(RuntimeError, match="dead code"):
+        C.roi_pool_forward(x, rois_np)
+
+
 def test_error_path_raises(ops):
     A = torch.zeros((64, 100), dtype=torch.bfloat16, device=dev())
     C = torch.zeros((64, 64), dtype=torch.bfloat16, device=dev())
