@@ -1,3 +1,4 @@
+"""GEMM launches of a rocprofv3 --kernel-trace run grouped by (kind, grid): python tools/gemm_shapes_from_trace.py <rocpd .db file>"""
 import sqlite3, sys
 con = sqlite3.connect(sys.argv[1])
 cur = con.cursor()

@@ -1,4 +1,6 @@
 #!/bin/bash
+# Runs ON THE GPU BOX: the round-end checks in one call -- full `-m gpu` suite, smoke(), default bench (JSON kept in gpurun_out/),
+# plain-wrapper e2e bench, and `--gpus 2` (two ranks sharing the box's one GPU over gloo: a functional check of the self-launch + DP path).
 O=gpurun_out; mkdir -p $O
 timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
 timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE OK')" 2>&1 | tail -2
