@@ -107,6 +107,11 @@ int vlb_transpose_batched_bf16(const int64_t* desc, const int32_t* tile_start, i
  *      x_f16 != 0: the rows of x are IEEE fp16 (the pre-LayerNorm sums written by vlb_gemm_nt_bf16_ex(out_f16)), else bf16.
  *      workspace: NULL (dgamma/dbeta by direct fp32 atomics) or vlb_layernorm_bwd_workspace_floats(H) floats of
  *      scratch (per-workgroup partial sums stored without atomics, column-summed by a 2nd kernel). */
+/* Overflow guard of the fp16 residual stream: every vlb_layernorm_fwd raises a sticky per-device flag when a row's statistics are not
+ * finite (an fp16 pre-LayerNorm sum beyond 65504 became inf in the producing GEMM's epilogue; bit 0 = fp16 rows, bit 1 = bf16 rows).
+ * vlb_nonfinite_status returns the flag (>= 0; clears it when reset != 0), negative on error; it synchronises the device.  The
+ * reference has no counterpart (fp32 activations; its fp16 path relies on apex loss scaling, common/trainer.py:119-127). */
+int vlb_nonfinite_status(int reset);
 int vlb_layernorm_fwd(const void* x, long ldx, const float* gamma, const float* beta, void* y, long ldy, float* stats,
                       int rows, int H, float eps, int x_f16, vlb_stream_t stream);
 int vlb_layernorm_bwd(const void* dy, long lddy, int dy_f32, const void* x, long ldx, const float* stats,
@@ -251,6 +256,18 @@ int vlb_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, l
 int vlb_sumsq_bf16_det(const void* g_bf16, long n, float* partials, int partials_len, float* out, vlb_stream_t stream);
 int vlb_adamw_step_gbf16(float* p, const void* g_bf16, float* m, float* v, void* p_bf16, long n, float* state, float grad_scale,
                          vlb_stream_t stream);
+/* Sharded optimizer of the data-parallel path (replaces the REPLICATED clip + AdamW that DDP implies, common/trainer.py:139-153 after
+ * pretrain/function/train.py:89-90): a rank owns one slice of every gradient bucket, the reduce-scatter leaves the reduced slices in a
+ * compact image `g` (fp32, or bf16 when g_is_bf16), and clip + AdamW run over those slices only.  ranges: DEVICE int64 [n][3] =
+ * {offset into p / m / v, offset into the compact images, length}; block_start: DEVICE int32 [n + 1] = running count of
+ * `chunk`-element blocks (chunk a multiple of 1024, total_blocks <= partials_len).  vlb_sumsq_ranges_det adds the slices' sum of
+ * squares into *out in a fixed order (the caller all-reduces it over the ranks); vlb_adamw_step_ranges is vlb_adamw_step over the
+ * slices, the bf16 copy of the updated parameters written to p_bf16_compact (nullable) at the compact offsets -- the image the
+ * weight all-gather distributes -- then step += 1, sumsq = 0. */
+int vlb_sumsq_ranges_det(const void* g, int g_is_bf16, const int64_t* ranges, const int32_t* block_start, int n, int total_blocks, int chunk,
+                         float* partials, int partials_len, float* out, vlb_stream_t stream);
+int vlb_adamw_step_ranges(float* p, const void* g, int g_is_bf16, float* m, float* v, void* p_bf16_compact, const int64_t* ranges,
+                          const int32_t* block_start, int n, int total_blocks, int chunk, float* state, float grad_scale, vlb_stream_t stream);
 /* SGD with momentum (torch.optim.SGD(lr, momentum, weight_decay), dampening 0, no Nesterov: the optimiser of
  * vcr/function/train.py:124-128) in one pass:  d = coef * g + weight_decay * p ;  buf = momentum * buf + d ;  p -= lr * buf ;
  * p_bf16 (optional) = bf16(p).  coef = grad_scale * min(1, max_norm / (sqrt(*sumsq) * grad_scale + 1e-6)) when `sumsq` (device,

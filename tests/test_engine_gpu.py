@@ -35,8 +35,10 @@ def rel_fro(a, b):
     return float((a - b).norm() / max(b.norm(), 1e-12))
 
 
-def check_against_oracle(tag, cfg, params, batch, grad_tol=5e-2, logit_rtol=1e-2, logit_fro_tol=None):
-    """logit_rtol: bound on max|err| / max|ref| (+ 2e-3 absolute); logit_fro_tol: additional bound on the relative Frobenius error."""
+def check_against_oracle(tag, cfg, params, batch, grad_tol=5e-2, logit_rtol=1e-2, logit_fro_tol=None, oracle=None):
+    """logit_rtol: bound on max|err| / max|ref| (+ 2e-3 absolute); logit_fro_tol: additional bound on the relative Frobenius error.
+    oracle: a precomputed O.loss_and_grads(params, cfg, batch, train=False) result (several engine configurations against one
+    oracle evaluation); the result used is left in eng.oracle_result."""
     B, T, R = batch[2].shape[0], batch[2].shape[1], batch[0].shape[1]
     eng = make_engine(cfg, B, T, R, train=False)
     eng.load_state_dict({k: v.to(dev()) for k, v in params.items()})
@@ -45,7 +47,10 @@ def check_against_oracle(tag, cfg, params, batch, grad_tol=5e-2, logit_rtol=1e-2
     eng.forward(train=False)
     eng.backward(train=False)
     torch.cuda.synchronize()
-    outputs, loss, grads, norm = O.loss_and_grads(params, cfg, batch, train=False)
+    if oracle is None:
+        oracle = O.loss_and_grads(params, cfg, batch, train=False)
+    outputs, loss, grads, norm = oracle
+    eng.oracle_result = oracle
     lv = eng.loss_values()
     V, C = cfg.vocab_size, cfg.visual_region_classes
     if logit_fro_tol is not None:
@@ -948,7 +953,7 @@ def test_engine_headline_c2_12_layers_vs_oracle():
     params = O.init_params(cfg, seed=71)
     batch = syn.make_batch(6, 64, 36, seed=72, ragged=True)
     eng = check_against_oracle("C2 12-layer", cfg, params, batch, grad_tol=6e-2, logit_rtol=1e-2, logit_fro_tol=1e-2)
-    _, _, grads, norm = O.loss_and_grads(params, cfg, batch, train=False)
+    _, _, grads, norm = eng.oracle_result
     rows = _per_layer_report("C2 12-layer", eng, grads, norm, 12)
     assert max(e for _, e in rows) <= 4e-2, rows
 
@@ -970,9 +975,67 @@ def test_engine_large_4_layers_s229_vs_oracle():
     params = O.init_params(cfg, seed=75)
     batch = syn.make_batch(2, 128, 100, seed=76, ragged=True)
     eng = check_against_oracle("large 4-layer S=229", cfg, params, batch, grad_tol=0.12, logit_rtol=1e-2, logit_fro_tol=1e-2)
-    _, _, grads, norm = O.loss_and_grads(params, cfg, batch, train=False)
+    _, _, grads, norm = eng.oracle_result
     rows = _per_layer_report("large 4-layer S=229", eng, grads, norm, 4)
     assert max(e for _, e in rows) <= 4e-2, rows
+
+
+def test_engine_large_24_layers_s229_vs_oracle():
+    """BASELINE.json configs 4-5 at their FULL depth: VL-BERT-large, 24 layers x 1024, 16 heads, FFN 4096, 128 text + 100 regions
+    (S = 229), full vocabulary, ragged batch of 2 -- what `bench.py --large / --vqa / --vcr` time.  Same bars as the 12-layer
+    headline test (north_star's bf16 bound): losses and global gradient norm within 1e-2, logits within 1e-2 of the tensor scale in
+    the max norm and in relative Frobenius norm; per-layer gradient error printed (depth growth is visible in the log)."""
+    syn = pkg("synthetic")
+    cfg = O.VLBertConfig(hidden_size=1024, num_attention_heads=16, intermediate_size=4096, num_hidden_layers=24)
+    params = O.init_params(cfg, seed=77)
+    batch = syn.make_batch(2, 128, 100, seed=78, ragged=True)
+    eng = check_against_oracle("large 24-layer S=229", cfg, params, batch, grad_tol=0.12, logit_rtol=1e-2, logit_fro_tol=1e-2)
+    _, _, grads, norm = eng.oracle_result
+    rows = _per_layer_report("large 24-layer S=229", eng, grads, norm, 24)
+    assert max(e for _, e in rows) <= 5e-2, rows
+
+
+@pytest.fixture
+def gemm_options():
+    """Run-time GEMM kernel selection (vlb_gemm_set_option), restored to the library defaults afterwards."""
+    lib = pkg("_lib")
+    yield lib
+    lib.gemm_set_option("p8_min_tiles", 160)
+    lib.gemm_set_option("p8_mode", 1)
+    lib.gemm_set_option("nt_ring", 1)
+
+
+@pytest.mark.parametrize("tile", [3, 4, 5])
+def test_engine_headline_c2_12_layers_through_large_tile_kernels(gemm_options, tile):
+    """The headline configuration (12 layers, 64 + 36, V = 30522) with every eligible GEMM FORCED onto the kernels bench.py times
+    at batch 256 -- `gemm_nt_p8_kernel<FMH, EPI>` with 192- / 256- / 320-row tiles (all fused epilogues incl. the LayerNorm-residual
+    fp16 stream) and the grouped large-tile weight gradient `gemm_tn8_kernel` (the engine's row-padded operands reach it at any
+    batch) -- against the fp32 oracle, same 1e-2 bars as the default-selection test.  At B = 6 the launcher's own choice would be
+    the 128x128 kernels, so without this test the benched kernels were only compared per-op and engine-vs-engine at 2 layers."""
+    syn = pkg("synthetic")
+    cfg = O.VLBertConfig(num_hidden_layers=12)
+    params = O.init_params(cfg, seed=71)
+    batch = syn.make_batch(6, 64, 36, seed=72, ragged=True)
+    cache = test_engine_headline_c2_12_layers_through_large_tile_kernels.__dict__.setdefault("oracle", {})
+    if "r" not in cache:
+        cache["r"] = O.loss_and_grads(params, cfg, batch, train=False)
+    gemm_options.gemm_set_option("p8_min_tiles", 1)
+    gemm_options.gemm_set_option("p8_mode", tile)
+    eng = check_against_oracle("C2 12-layer via p8<%d>" % tile, cfg, params, batch, grad_tol=6e-2, logit_rtol=1e-2, logit_fro_tol=1e-2,
+                               oracle=cache["r"])
+    rows = _per_layer_report("C2 12-layer via p8<%d>" % tile, eng, cache["r"][2], cache["r"][3], 12)
+    assert max(e for _, e in rows) <= 4e-2, rows
+
+
+def test_engine_c2_per_gpu_batch_32_step_vs_oracle():
+    """One rank of the 8-GPU strong-scaling run: 12 layers, 32 full-length samples (M = 3232 rows) with the launcher's OWN kernel
+    selection at that size -- the 192-row large tile for the N = 3072 GEMMs, `gemm_nt_ring_kernel` (EPI -1 / 4 / 0) for the N = 768
+    ones, the grouped weight gradient at R = 3328 -- against the oracle (1e-2 bars)."""
+    syn = pkg("synthetic")
+    cfg = O.VLBertConfig(num_hidden_layers=12)
+    params = O.init_params(cfg, seed=79)
+    batch = syn.make_batch(32, 64, 36, seed=80, ragged=False)
+    check_against_oracle("C2 12-layer B=32", cfg, params, batch, grad_tol=6e-2, logit_rtol=1e-2, logit_fro_tol=1e-2)
 
 
 def test_mlm_head_compaction_matches_full_path():

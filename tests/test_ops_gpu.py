@@ -147,14 +147,35 @@ def force_p8():
     lib.gemm_set_option("p8_mode", 1)
 
 
-@pytest.mark.parametrize("tile", [4, 5])
+@pytest.mark.parametrize("tile", [3, 4, 5])
 @pytest.mark.parametrize("M,N,K", [(2048, 1024, 256), (1000, 520, 128), (2600, 768, 768), (700, 2306, 384)])
 def test_gemm_large_tile_core_epilogues(ops, force_p8, tile, M, N, K):
-    """vl-bert_amd/csrc/gemm_p8.hip (256- and 320-row tiles, 8-phase schedule, fp32-staged epilogue): every fused epilogue of the
+    """vl-bert_amd/csrc/gemm_p8.hip (192-, 256- and 320-row tiles, 8-phase schedule, fp32-staged epilogue): every fused epilogue of the
     training step against the fp32 statement of the same op, interior and edge tiles (M, N not multiples of the tile, N % 8 != 0),
     the shortest K the pipeline accepts (two K tiles), several output tiles per workgroup; dropout against the numpy restatement of
-    the counter RNG.  Padding columns of C must stay untouched."""
+    the counter RNG.  Padding columns of C must stay untouched.  (The 192-row tile is what the launcher picks for the N = 3072
+    GEMMs of a 32-sample per-GPU batch -- the 8-GPU strong-scaling regime.)"""
     force_p8.gemm_set_option("p8_mode", tile)
+    _epilogue_battery(ops, "p8/%d %dx%dx%d " % (64 * tile, M, N, K), M, N, K)
+
+
+@pytest.mark.parametrize("ring", [2, 3], ids=["ring-128x128", "ring-128x64"])
+@pytest.mark.parametrize("M,N,K", [(3232, 768, 768), (1000, 520, 512), (1300, 776, 3072)])
+def test_gemm_ring_kernel_epilogues(ops, force_p8, ring, M, N, K):
+    """`gemm_nt_ring_kernel` (gemm.hip: the 128x128 / 128x64 tiles behind a 4- / 3-stage operand ring with counted waits) -- the
+    kernel the launcher picks for the N = 768 GEMMs at M = 1024..8192 (per-GPU batches 32-64 of a 4-8-GPU strong-scaling run).
+    Every fused epilogue instantiation (EPI 0 bias, 1 GELU + GELU', 2 x aux, 3 dropout + residual, 4 bias + residual, 5 ReLU) against
+    the fp32 statement; the generic instantiation (EPI -1: LayerNorm-residual / fp16 output) is covered by
+    test_gemm_layernorm_residual_fp16_stream[ring-*]."""
+    force_p8.gemm_set_option("p8_mode", 0)
+    force_p8.gemm_set_option("nt_ring", ring)
+    try:
+        _epilogue_battery(ops, "ring/%s %dx%dx%d " % ("128x128" if ring == 2 else "128x64", M, N, K), M, N, K)
+    finally:
+        force_p8.gemm_set_option("nt_ring", 1)
+
+
+def _epilogue_battery(ops, tag, M, N, K):
     A, B = rnd(M, K, seed=4), rnd(N, K, seed=5, scale=0.08)
     bias = 0.3 * torch.randn(N, generator=torch.Generator().manual_seed(6))
     res, aux = rnd(M, N, seed=7), rnd(M, N, seed=8)
@@ -167,7 +188,6 @@ def test_gemm_large_tile_core_epilogues(ops, force_p8, tile, M, N, K):
     Cf = torch.full((M, ldc), 3.0, dtype=torch.bfloat16, device=dev())
     C = Cf[:, :N]
     pre = torch.full((M, ldc), 3.0, dtype=torch.bfloat16, device=dev())[:, :N]
-    tag = "p8/%d %dx%dx%d " % (64 * tile, M, N, K)
     ops.gemm_nt(Ag, Bg, C, bias=bg)
     report(tag + "bias", C, u, 1e-3, 1e-2)
     assert bool((Cf[:, N:] == 3.0).all())
@@ -200,13 +220,21 @@ def test_gemm_large_tile_core_epilogues(ops, force_p8, tile, M, N, K):
     assert bool((Cf[:, N:] == 3.0).all())
 
 
-@pytest.mark.parametrize("core", ["128x128", "p8-256", "p8-320"])
+@pytest.mark.parametrize("core", ["128x128", "p8-192", "p8-256", "p8-320", "ring-128x128", "ring-128x64"])
 def test_gemm_layernorm_residual_fp16_stream(ops, force_p8, core):
     """vlb_gemm_nt_bf16_ex: residual = LayerNorm output re-materialised in fp32 from fp16 pre-LN rows + (mean, rstd) + gamma / beta,
     result stored as fp16 (the encoder's residual stream, BertSelfOutput / BertOutput); with and without dropout; and the LayerNorm
     kernels reading fp16 rows.  Reference: fp32 torch on the same (fp16 / bf16 rounded) inputs."""
     lib = force_p8
-    lib.gemm_set_option("p8_mode", {"128x128": 0, "p8-256": 4, "p8-320": 5}[core])
+    lib.gemm_set_option("p8_mode", {"128x128": 0, "p8-192": 3, "p8-256": 4, "p8-320": 5}.get(core, 0))
+    lib.gemm_set_option("nt_ring", {"ring-128x128": 2, "ring-128x64": 3}.get(core, 0))
+    try:
+        _ln_residual_checks(ops, core)
+    finally:
+        lib.gemm_set_option("nt_ring", 1)
+
+
+def _ln_residual_checks(ops, core):
     M, N, K = 1300, 776, 256
     A, B = rnd(M, K, seed=14), rnd(N, K, seed=15, scale=0.08)
     bias = 0.3 * torch.randn(N, generator=torch.Generator().manual_seed(16))
@@ -807,6 +835,76 @@ def test_adamw_and_sumsq_on_bf16_wire_gradient(ops):
     coef = O.clip_coef(float(g.double().norm()) * scale, max_norm) * scale
     O.adamw_step(pr, g * coef, mr, vr, 1, lr, eps=1e-6, weight_decay=wd)
     report("adamw (bf16 wire gradient) p", res[1][1], pr, 1e-6, 1e-5)
+
+
+def test_sharded_optimizer_kernels_match_flat_adamw(ops):
+    """vlb_sumsq_ranges_det / vlb_adamw_step_ranges (the data-parallel SHARDED optimizer: a rank updates its slice of every bucket from
+    a compact reduced-gradient image and emits the bf16 copy into a compact image): the union of two 'ranks' owned slices must
+    reproduce vlb_sumsq_*_det + vlb_adamw_step over the whole buffer bit for bit (sum of squares: to fp32 summation order)."""
+    n, world = 64 * 2 * 531, 2
+    g0 = torch.Generator().manual_seed(52)
+    p = torch.randn(n, generator=g0)
+    lr, wd, max_norm, scale = 1e-3, 1e-2, 1.0, 0.5
+    mk = lambda: torch.tensor([lr, 0.9, 0.999, 1e-6, wd, 3.0, max_norm, 0.0], dtype=torch.float32, device=dev())
+    part = torch.zeros(2048, device=dev())
+    cuts = [0, 128 * 40, 128 * 300, n]                       # three buckets, each split evenly over the two ranks
+    for wire in (torch.float32, torch.bfloat16):
+        g = (torch.randn(n, generator=g0) * 2).to(wire).to(dev())
+        state = mk()
+        pf, m, v = p.clone().to(dev()), torch.full((n,), 0.01, device=dev()), torch.full((n,), 0.02, device=dev())
+        p16 = torch.empty(n, dtype=torch.bfloat16, device=dev())
+        ops.sumsq_det(g, part, state[7:8])
+        ss = float(state[7])
+        ops.adamw_step(pf, g, m, v, p16, state, grad_scale=scale)
+        ps, ms, vs = p.clone().to(dev()), torch.full((n,), 0.01, device=dev()), torch.full((n,), 0.02, device=dev())
+        w16 = torch.zeros(n, dtype=torch.bfloat16, device=dev())
+        sq = torch.zeros(1, device=dev())
+        shards = []
+        for r in range(world):
+            rows, comp = [], []
+            for lo, hi in zip(cuts[:-1], cuts[1:]):
+                k = (hi - lo) // world
+                rows.append((lo + r * k, lo // world, k))
+                comp.append(g[lo + r * k:lo + (r + 1) * k])
+            tbl = ops.ShardRanges(rows, dev())
+            gs = torch.cat(comp).contiguous()                # the compact image a reduce-scatter leaves
+            st = mk()
+            tbl.sumsq(gs, part, st[7:8])
+            sq += st[7:8]
+            shards.append((tbl, gs, rows))
+        assert abs(float(sq) - ss) <= 1e-5 * ss
+        for tbl, gs, rows in shards:
+            st = mk()
+            st[7] = ss                                       # the all-reduced norm
+            ws = torch.zeros(n // world, dtype=torch.bfloat16, device=dev())
+            tbl.adamw(ps, gs, ms, vs, ws, st, grad_scale=scale)
+            assert float(st[5]) == 4.0 and float(st[7]) == 0.0        # one step advance per call, norm cleared
+            for p0, c0, k in rows:
+                w16[p0:p0 + k] = ws[c0:c0 + k]
+        assert torch.equal(ps, pf) and torch.equal(ms, m) and torch.equal(vs, v) and torch.equal(w16, p16), str(wire)
+
+
+def test_fp16_residual_stream_overflow_is_flagged(ops):
+    """A pre-LayerNorm sum beyond the fp16 range (65504) becomes inf in the GEMM epilogue's conversion; the LayerNorm forward that
+    reads the row raises the sticky device flag (vlb_nonfinite_status) instead of training on silently -- random-init tests never
+    reach it, pretrained BERT's outlier channels could."""
+    lib = pkg("_lib")
+    lib.nonfinite_status(reset=True)
+    M, N, K = 256, 128, 64
+    A, B = to_gpu_bf16(rnd(M, K, seed=1)), to_gpu_bf16(rnd(N, K, seed=2))
+    bias = torch.zeros(N, device=dev())
+    Z = torch.zeros((M, N), dtype=torch.float16, device=dev())
+    g, b = torch.ones(N, device=dev()), torch.zeros(N, device=dev())
+    y, st = torch.zeros((M, N), dtype=torch.bfloat16, device=dev()), torch.zeros((M, 2), device=dev())
+    ops.gemm_nt(A, B, Z, bias=bias)
+    ops.layernorm_fwd(Z, g, b, y, st)
+    assert lib.nonfinite_status() == 0
+    bias[5] = 7.0e4                                      # > 65504: the fp16 store overflows
+    ops.gemm_nt(A, B, Z, bias=bias)
+    assert bool(torch.isinf(Z[:, 5]).all())
+    ops.layernorm_fwd(Z, g, b, y, st)
+    assert lib.nonfinite_status(reset=False) == 1        # bit 0: an fp16 row
+    assert lib.nonfinite_status(reset=True) == 1 and lib.nonfinite_status() == 0      # sticky until reset
 
 
 def test_bce_logits_and_dropout(ops):

@@ -110,7 +110,11 @@ def _worker(rank, world, port, numel_holder):
     g = torch.Generator().manual_seed(rank)
     grad = torch.randn(numel, generator=g)
     mine = grad.clone()
-    b = P.GradBuckets(grad, offsets, numel, cfg.num_hidden_layers, bucket_bytes=300_000, wire_dtype=None)
+    b = P.GradBuckets(grad, offsets, numel, cfg.num_hidden_layers, bucket_bytes=300_000, wire_dtype=None, mode="allreduce")
+    with pytest.raises(RuntimeError, match="incomplete"):
+        b.invalidate()
+        b.reduced                                    # nothing exchanged yet: the optimizer must not read a stale image
+    b._complete = True
     assert b.reduced is grad
     # replay the engine's completion order
     b.on_done("heads")
@@ -125,8 +129,8 @@ def _worker(rank, world, port, numel_holder):
     # bf16 wire format (the default): the reduced gradient stays in the persistent bf16 image the optimizer reads; the word-embedding
     # table goes as its own bucket in front of the rest of the front end
     grad2 = mine.clone()
-    b2 = P.GradBuckets(grad2, offsets, numel, cfg.num_hidden_layers)
-    assert b2.wire_dtype == torch.bfloat16 and b2.reduced.dtype == torch.bfloat16 and b2.reduced.numel() == numel
+    b2 = P.GradBuckets(grad2, offsets, numel, cfg.num_hidden_layers, mode="allreduce")
+    assert b2.wire_dtype == torch.bfloat16 and b2.wire.dtype == torch.bfloat16 and b2.wire.numel() == numel
     launched = []
     orig = b2._launch
     b2._launch = lambda lo, hi: (launched.append((lo, hi)), orig(lo, hi))[1]
@@ -139,6 +143,11 @@ def _worker(rank, world, port, numel_holder):
     same = b2.reduced.clone()
     dist.broadcast(same, src=0)
     assert torch.equal(same, b2.reduced)                               # every rank holds the same reduced bits
+    # a step that skipped a range (backward without the hook for it) must not hand the optimizer a stale slice
+    b2.on_done("heads")
+    b2.wait()
+    with pytest.raises(RuntimeError, match="incomplete"):
+        b2.reduced
     dist.barrier()
     dist.destroy_process_group()
 
@@ -146,3 +155,179 @@ def _worker(rank, world, port, numel_holder):
 def test_bucketed_allreduce_gloo_world2():
     port = _free_port()
     mp.spawn(_worker, args=(2, port, None), nprocs=2, join=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# sharded optimizer exchange (reduce-scatter -> owned slices -> all-gather of the updated weights)
+# ---------------------------------------------------------------------------------------------------------------
+def _padded_layout(world, e2e=False):
+    E = importlib.import_module("vl-bert_amd.engine")
+    P = importlib.import_module("vl-bert_amd.parallel")
+    import math
+    cfg = E.ModelConfig(hidden_size=64, num_hidden_layers=5, num_attention_heads=1, intermediate_size=128, vocab_size=300,
+                        max_position_embeddings=32, visual_region_classes=20, e2e=e2e, image_num_layers=50)
+    shapes = E.param_layout(cfg)
+    offsets, off = {}, 0
+    for n, s in shapes.items():
+        offsets[n] = off
+        off = E._ru(off + math.prod(s), 64)
+    numel = E._ru(off, P.shard_alignment(world))
+    vis = [n for n in shapes if n.startswith("image_feature_extractor.") and "obj_downsample" not in n]
+    return cfg, offsets, numel, (min(offsets[n] for n in vis) if vis else None), shapes
+
+
+@pytest.mark.parametrize("world", [2, 8])
+@pytest.mark.parametrize("e2e", [False, True])
+def test_sharded_buckets_split_evenly_and_absorb_into_the_later_bucket(world, e2e):
+    """Sharded mode moves every bucket boundary onto the 64 x world grid.  Invariants: the buckets still tile the buffer; each
+    splits into `world` equal slices; and every PARAMETER lies in buckets that fire no earlier than the bucket the un-aligned layout
+    puts it in (a slice must not leave before its last producer ran)."""
+    P = importlib.import_module("vl-bert_amd.parallel")
+    import math
+    cfg, offsets, numel, vstart, shapes = _padded_layout(world, e2e)
+    ref = P.GradBuckets(torch.zeros(numel), offsets, numel, cfg.num_hidden_layers, bucket_bytes=200_000, mode="allreduce", vision_start=vstart)
+    b = P.GradBuckets(torch.zeros(numel), offsets, numel, cfg.num_hidden_layers, bucket_bytes=200_000, mode="sharded", vision_start=vstart)
+    b.world = ref.world = world                              # (not initialised: the layout logic only)
+    G = P.shard_alignment(world)
+    bs = P.GradBuckets.__new__(P.GradBuckets)                # rebuild with the real world size for the cut computation
+    orig = P.dist.get_world_size, P.dist.is_initialized, P.dist.get_rank, P.dist.get_backend
+    P.dist.get_world_size, P.dist.is_initialized, P.dist.get_rank, P.dist.get_backend = (lambda g=None: world), (lambda: True), (lambda g=None: world - 1), (lambda g=None: "gloo")
+    try:
+        bs.__init__(torch.zeros(numel), offsets, numel, cfg.num_hidden_layers, bucket_bytes=200_000, mode="sharded", vision_start=vstart)
+    finally:
+        P.dist.get_world_size, P.dist.is_initialized, P.dist.get_rank, P.dist.get_backend = orig
+    assert bs.sharded and bs.world == world
+    cov = bs.coverage()
+    assert cov[0][0] == 0 and cov[-1][1] == numel
+    for (lo, hi), (lo2, _) in zip(cov[:-1], cov[1:]):
+        assert hi == lo2 and lo < hi
+    assert all(lo % G == 0 and hi % G == 0 for lo, hi in cov)
+    order = ["heads"] + sorted(ref.layer_bucket, reverse=True) + ["word_emb", "embed"] + list(reversed(ref.vision_keys))
+    fire = {k: i for i, k in enumerate(order)}
+    assert [k for k, _, _ in bs.buckets] == [k for k, _, _ in ref.buckets]
+    for name, off in offsets.items():
+        end = off + math.prod(shapes[name])
+        home = max(fire[k] for k, lo, hi in ref.buckets if lo < end and off < hi)
+        for k, lo, hi in bs.buckets:
+            if lo < end and off < hi:
+                assert fire[k] >= home, (name, k)
+    rows = bs.owned_rows()
+    assert sum(r[2] for r in rows) == numel // world
+    assert [r[1] for r in rows] == [sum(q[2] for q in rows[:i]) for i in range(len(rows))]        # compact image: slices back to back
+    assert all(r[0] % 64 == 0 and r[1] % 64 == 0 and r[2] % 64 == 0 for r in rows)
+
+
+def _adamw_ref(p, g, m, v, step, lr, b1=0.9, b2=0.999, eps=1e-6, wd=1e-4):
+    m.mul_(b1).add_(g, alpha=1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    p.sub_(m / (v.sqrt() + eps) * (lr * (1 - b2 ** step) ** 0.5 / (1 - b1 ** step)))
+    p.sub_(p * (lr * wd))
+
+
+def _sharded_worker(rank, world, port, emulate, wire):
+    """Two optimizer steps through the sharded exchange on CPU (gloo) with a torch statement of the owned-slice AdamW standing in for
+    the HIP kernel: parameters after the weight gather equal the replicated all-reduce + AdamW on every rank."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    P = importlib.import_module("vl-bert_amd.parallel")
+    cfg, offsets, numel, vstart, _ = _padded_layout(world)
+    torch.manual_seed(0)
+    p0 = torch.randn(numel) * 0.02
+    master, m, v = p0.clone(), torch.zeros(numel), torch.zeros(numel)
+    w16 = master.to(torch.bfloat16)
+    ref_p, ref_m, ref_v = p0.clone(), torch.zeros(numel), torch.zeros(numel)
+    grad = torch.zeros(numel)
+    b = P.GradBuckets(grad, offsets, numel, cfg.num_hidden_layers, bucket_bytes=300_000, mode="sharded", wire_dtype=wire,
+                      emulate_collectives=emulate)
+    assert b.sharded and b.emulate == emulate
+    wshard = torch.zeros(numel // world, dtype=torch.bfloat16)
+    for step in (1, 2):
+        locals_ = [torch.randn(numel, generator=torch.Generator().manual_seed(100 * step + r)) for r in range(world)]
+        grad.copy_(locals_[rank])
+        for what in ["heads"] + list(reversed(range(cfg.num_hidden_layers))) + ["word_emb", "embed"]:
+            b.on_done(what)
+        b.wait()
+        if wire is None:
+            total = sum(locals_)
+        else:           # the bf16 image: each addend rounded, summed in the collective's order (2 ranks: one addition, rounded)
+            total = sum(l.to(torch.bfloat16) for l in locals_[1:]) + locals_[0].to(torch.bfloat16) if world == 2 else None
+            total = (locals_[0].to(torch.bfloat16) + locals_[1].to(torch.bfloat16)).float()
+        g = b.grad_shard
+        sq = torch.zeros(1)
+        for p_off, c_off, n in b.owned_rows():
+            assert torch.equal(g[c_off:c_off + n].float(), total[p_off:p_off + n].float()), "reduce-scatter slice"
+            sq += g[c_off:c_off + n].float().pow(2).sum()
+        b.all_reduce_scalar(sq)
+        assert abs(float(sq) - float(total.float().pow(2).sum())) <= 1e-4 * float(sq)
+        coef = (1.0 / world) * min(1.0, 10.0 / (float(sq) ** 0.5 / world + 1e-6))
+        for p_off, c_off, n in b.owned_rows():
+            sl = slice(p_off, p_off + n)
+            _adamw_ref(master[sl], g[c_off:c_off + n].float() * coef, m[sl], v[sl], step, 1e-3)
+            wshard[c_off:c_off + n] = master[sl].to(torch.bfloat16)
+        b.gather_params(w16, wshard)
+        b.wait_params("front")
+        b.wait_params(2)
+        b.wait_params("all")
+        _adamw_ref(ref_p, total.float() * coef, ref_m, ref_v, step, 1e-3)
+        assert torch.equal(w16, ref_p.to(torch.bfloat16)), "gathered bf16 weights differ from the replicated update"
+    b.gather_master(master)
+    assert torch.equal(master, ref_p)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("emulate", [False, True], ids=["native", "emulated"])
+@pytest.mark.parametrize("wire", [None, torch.bfloat16], ids=["fp32", "bf16"])
+def test_sharded_exchange_equals_replicated_update_gloo_world2(emulate, wire):
+    mp.spawn(_sharded_worker, args=(2, _free_port(), emulate, wire), nprocs=2, join=True)
+
+
+def _wire8_worker(rank, world, port):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    P = importlib.import_module("vl-bert_amd.parallel")
+    cfg, offsets, numel, _, _ = _padded_layout(world)
+    # gradients of data-parallel replicas: a shared component (the true gradient) + per-rank mini-batch noise of comparable size,
+    # log-normal magnitudes over several decades (per-tensor scales differ by orders of magnitude in the real model)
+    g0 = torch.Generator().manual_seed(7)
+    scale = torch.exp(torch.randn(numel, generator=g0) * 2.0) * 1e-3
+    common = torch.randn(numel, generator=g0)
+    locals_ = [(common + torch.randn(numel, generator=torch.Generator().manual_seed(50 + r))) * scale for r in range(world)]
+    exact = torch.stack([l.double() for l in locals_]).sum(0)
+    for mode in ("allreduce", "sharded"):
+        grad = locals_[rank].clone()
+        b = P.GradBuckets(grad, offsets, numel, cfg.num_hidden_layers, bucket_bytes=300_000, mode=mode)
+        assert b.wire_dtype == torch.bfloat16                     # the default at 8 ranks
+        for what in ["heads"] + list(reversed(range(cfg.num_hidden_layers))) + ["word_emb", "embed"]:
+            b.on_done(what)
+        b.wait()
+        if mode == "allreduce":
+            got = b.reduced.double()
+            ref = exact
+        else:
+            rows = b.owned_rows()
+            got = torch.cat([b.grad_shard[c:c + n].double() for _, c, n in rows])
+            ref = torch.cat([exact[p:p + n] for p, _, n in rows])
+        # global quantities: in sharded mode a rank holds 1/8 of the reduced gradient -> sum the squared norms over the ranks
+        t = torch.tensor([float((got - ref).pow(2).sum()), float(got.pow(2).sum()), float(ref.pow(2).sum())], dtype=torch.float64)
+        if mode == "sharded":
+            dist.all_reduce(t)
+        t = torch.tensor([(t[0] / t[2]) ** 0.5, abs(t[1] ** 0.5 - t[2] ** 0.5) / t[2] ** 0.5], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            print("bf16 wire, world 8, %s: rel-Frobenius error of the reduced gradient %.3e, gradient-norm error %.3e" % (mode, t[0], t[1]))
+        # bars: the gradient norm (what the clip coefficient is made of) within 1e-3 -- 10x inside north_star's 1e-2 bf16 bound -- and
+        # the reduced gradient within 1e-2 in relative Frobenius norm (measured: ~4e-3 = bf16 rounding of addends and partial sums)
+        assert t[1] <= 1e-3 and t[0] <= 1e-2, (mode, t)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bf16_wire_error_world8():
+    """The default wire format is a bf16 running sum up to 8 ranks (parallel.BF16_WIRE_MAX_WORLD; fp32 above): bound its error against
+    the exact (fp64) sum of the ranks' fp32 gradients at world size 8, for both exchange modes."""
+    P = importlib.import_module("vl-bert_amd.parallel")
+    assert P.default_wire_dtype(8) == torch.bfloat16 and P.default_wire_dtype(9) is None and P.default_wire_dtype(256) is None
+    mp.spawn(_wire8_worker, args=(8, _free_port()), nprocs=8, join=True)

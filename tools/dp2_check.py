@@ -1,9 +1,11 @@
 """Two data-parallel ranks of the engine on ONE MI355X (gloo over CUDA tensors): the first real execution of
 train_step() with world_size > 1 -- bucketed all-reduce hooks inside backward, side-stream joins, 1/world folded into AdamW.
-Launch:  python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 tools/dp2_check.py [--e2e]
-Checks: (1) after 2 optimizer steps both ranks hold bit-identical parameters; (2) the reduced flat gradient equals the sum of
-the two ranks' local gradients (recomputed without buckets); (3) the step differs from a purely local one.
-(RCCL cannot put two ranks on one device, so the backend here is gloo; the engine's calls are the same.)"""
+Launch:  python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 tools/dp2_check.py [--e2e] [--mode sharded|allreduce]
+Checks: (1) after 2 optimizer steps both ranks hold bit-identical parameters; (2) the reduced gradient (flat image, or this rank's
+slices in sharded mode) equals the sum of the two ranks' local gradients (recomputed without buckets); (3) the step differs from a
+purely local one; (4) sharded mode: the bf16 working copy every rank computes with equals the bf16 rounding of the gathered master.
+(RCCL cannot put two ranks on one device, so the backend here is gloo -- reduce-scatter / all-gather are then carried as all-reduces,
+parallel.GradBuckets(emulate_collectives) --; the engine's calls are the same.)"""
 import importlib
 import os
 import sys
@@ -16,6 +18,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def main():
     e2e = "--e2e" in sys.argv
+    mode = sys.argv[sys.argv.index("--mode") + 1] if "--mode" in sys.argv else "default"
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -24,8 +27,10 @@ def main():
     B, T, R = 4, 16, 6
     cfg = E.ModelConfig(num_hidden_layers=3, e2e=e2e, image_num_layers=50)
     kw = dict(image_size=(96, 128)) if e2e else {}
-    eng = E.PretrainEngine(cfg, B, T, R, device="cuda:0", train=True, lr=1e-3, seed=7 + rank, **kw)
+    eng = E.PretrainEngine(cfg, B, T, R, device="cuda:0", train=True, lr=1e-3, seed=7 + rank, dp_mode=mode, **kw)
     assert eng.buckets is not None and eng.buckets.world == 2
+    sharded = eng.buckets.sharded
+    assert sharded == (mode != "allreduce"), (mode, sharded)
     eng.init_random(seed=0, visual_ln_init=1.0)
     batch = list(syn.make_batch(B, T, R, seed=50 + rank))
     if e2e:
@@ -47,12 +52,18 @@ def main():
     eng.backward(True, on_layer_done=eng.buckets.on_done)
     eng.buckets.wait()
     torch.cuda.synchronize()
-    red = eng.buckets.reduced              # fp32 flat gradient, or the bf16 wire image (default) the optimizer reads
+    if sharded:        # this rank's slices of the reduced gradient (compact image) against the same slices of the summed gradient
+        rows = eng.buckets.owned_rows()
+        red = torch.cat([eng.buckets.grad_shard[c:c + n] for _, c, n in rows])
+        total = torch.cat([total[p:p + n] for p, _, n in rows])
+        local = torch.cat([local[p:p + n] for p, _, n in rows])
+    else:
+        red = eng.buckets.reduced          # fp32 flat gradient, or the bf16 wire image (default) the optimizer reads
     wire16 = red.dtype == torch.bfloat16
     err = float((red.float() - total).abs().max()) / max(float(total.abs().max()), 1e-30)
     cov = eng.buckets.coverage()
-    print("rank %d: reduced-vs-summed gradient max rel err %.2e over %d buckets (vision buckets: %s)" %
-          (rank, err, len(cov), eng.buckets.vision_keys), flush=True)
+    print("rank %d [%s]: reduced-vs-summed gradient max rel err %.2e over %d buckets (vision buckets: %s)" %
+          (rank, "sharded" if sharded else "allreduce", err, len(cov), eng.buckets.vision_keys), flush=True)
     # two backward passes of one rank are not bit-identical (fp32 atomics: LayerNorm / embedding sums; e2e: ROIAlign backward, whose
     # rounding to bf16 then propagates through the trunk), so this compares to a tolerance; check (1) below is exact
     assert err < (1e-2 if wire16 else (1e-3 if e2e else 1e-6)), err
@@ -61,6 +72,15 @@ def main():
     for _ in range(2):
         eng.train_step()
     torch.cuda.synchronize()
+    if sharded:      # the master is authoritative on the owner only: gather it (state_dict() does the same), and the working copy every
+        # rank computes the next forward with must be its bf16 rounding
+        eng.forward(True)                  # drains the weight gathers still in flight
+        torch.cuda.synchronize()
+        eng.buckets.gather_master(eng.P.master)
+        end = eng.buckets.ranges["heads"][1]       # (the vision stages travel as fp32 master slices: no bf16 copy of theirs is used)
+        ok16 = bool(torch.equal(eng.P.w16[:end], eng.P.master[:end].to(torch.bfloat16)))
+        print("rank %d: gathered bf16 working copy == bf16(master): %s" % (rank, ok16), flush=True)
+        assert ok16
     mine = eng.P.master.clone()
     other = mine.clone()
     dist.broadcast(other, src=0)

@@ -56,6 +56,8 @@ _SIGS = {
     "vlb_adamw_step_gbf16": "ppppplpfs",
     "vlb_sgd_momentum_step": "pppplfffpffs",
     "vlb_sumsq_bf16_det": "plpips",
+    "vlb_sumsq_ranges_det": "pippiiipips",
+    "vlb_adamw_step_ranges": "ppipppppiiipfs",
     "vlb_lr_schedule_step": "pifffs",
     "vlb_conv_weight_prepare": "pppppfppppiiiis",
     "vlb_conv_weight_prepare_batched": "ppiifs",
@@ -112,6 +114,8 @@ def load():
     lib.vlb_layernorm_bwd_slabs.argtypes = [_I]
     lib.vlb_gemm_set_option.restype = _I
     lib.vlb_gemm_set_option.argtypes = [ctypes.c_char_p, _I]
+    lib.vlb_nonfinite_status.restype = _I
+    lib.vlb_nonfinite_status.argtypes = [_I]
     lib.vlb_roi_align_gather_workspace_bytes.restype = _L
     lib.vlb_roi_align_gather_workspace_bytes.argtypes = [_I, _I, _I, _I, _I]
     for name, sig in _SIGS.items():
@@ -125,7 +129,17 @@ def load():
 def exported_names():
     return ["vlb_last_error", "vlb_version", "vlb_device_info", "vlb_wgrad_workspace_floats",
             "vlb_layernorm_bwd_workspace_floats", "vlb_layernorm_bwd_slabs", "vlb_gemm_set_option",
-            "vlb_roi_align_gather_workspace_bytes"] + sorted(_SIGS)
+            "vlb_roi_align_gather_workspace_bytes", "vlb_nonfinite_status"] + sorted(_SIGS)
+
+
+def nonfinite_status(reset=True):
+    """Sticky flag of the LayerNorm forwards on the current device (vlb_nonfinite_status): 0 clean | bit 0 an fp16 pre-LayerNorm row
+    overflowed | bit 1 a bf16 row held inf / NaN."""
+    lib = load()
+    v = lib.vlb_nonfinite_status(1 if reset else 0)
+    if v < 0:
+        raise RuntimeError("vlb_nonfinite_status: %s" % lib.vlb_last_error().decode())
+    return v
 
 
 def gemm_set_option(name, value):

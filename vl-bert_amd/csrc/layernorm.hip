@@ -16,6 +16,12 @@
 // and a small second kernel column-sums the LN_MAX_BLOCKS x 2H slab (4.7 MB at H=768) into the gradients.
 #define LN_MAX_BLOCKS 1024  // 4 workgroups per CU (the 4-column backward runs 4 waves per SIMD)
 
+// Overflow guard of the fp16 residual stream (DESIGN.md "precision"): the pre-LayerNorm sums are stored as IEEE fp16, |Z| > 65504
+// becomes inf in the GEMM epilogue's conversion.  Random-init tests cannot see that; pretrained BERT has outlier channels.  Every
+// LayerNorm forward notices (a row with a non-finite element has a non-finite mean / rstd) and raises a sticky per-device flag:
+// bit 0 = an fp16 row, bit 1 = a bf16 row.  vlb_nonfinite_status() reads (and optionally clears) it; engine.loss_values() raises.
+__device__ unsigned int g_vlb_ln_nonfinite = 0u;
+
 // NIT = ceil(H / 256): per-lane register footprint follows the actual row width (H=768 -> 3)
 template <int NIT>
 struct Row4 {
@@ -64,6 +70,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __rest
     }
   }
   const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)H + eps);
+  if (lane == 0 && !(fabsf(mean) <= 3.0e38f && rstd <= 3.0e38f)) atomicOr(&g_vlb_ln_nonfinite, x_f16 ? 1u : 2u);     // (NaN compares false)
   if (lane == 0 && stats) {
     stats[2 * (long)row] = mean;
     stats[2 * (long)row + 1] = rstd;
@@ -423,6 +430,23 @@ extern "C" int vlb_layernorm_fwd(const void* x, long ldx, const float* gamma, co
 #undef LN_FWD
   VLB_CHECK_LAUNCH("vlb_layernorm_fwd");
   return VLB_OK;
+}
+
+// Sticky non-finite flag of the LayerNorm forwards on the CURRENT device (see g_vlb_ln_nonfinite): returns its value (0 = clean;
+// bit 0: an fp16 pre-LayerNorm row overflowed, bit 1: a bf16 row held inf / NaN), negative on a HIP error.  Synchronises the device.
+extern "C" int vlb_nonfinite_status(int reset) {
+  unsigned int v = 0u;
+  hipError_t e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_vlb_ln_nonfinite), sizeof(v), 0, hipMemcpyDeviceToHost);
+  if (e == hipSuccess && reset && v) {
+    const unsigned int z = 0u;
+    e = hipMemcpyToSymbol(HIP_SYMBOL(g_vlb_ln_nonfinite), &z, sizeof(z), 0, hipMemcpyHostToDevice);
+  }
+  if (e != hipSuccess) {
+    vlb_set_error("vlb_nonfinite_status: %s", hipGetErrorString(e));
+    return VLB_ERR_HIP;
+  }
+  return (int)(v & 3u);
 }
 
 static int g_ln_bwd4 = -1;      // VLB_LN_BWD4: 1 (default) the 4-column kernel (2: two rows in flight at H = 768 / 1024); 0 the 8-column kernel

@@ -281,6 +281,145 @@ extern "C" int vlb_adamw_step_gbf16(float* p, const void* g_bf16, float* m, floa
   return VLB_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Sharded optimizer (data parallel, parallel.GradBuckets mode "sharded"): a rank owns one slice of every gradient bucket; the
+// reduce-scatter leaves the reduced slices in a COMPACT gradient image, the clip norm is the all-reduced sum of the ranks'
+// partial sums, AdamW touches the owned slices only (1/world of the 3.4 GB the replicated update streams) and writes the bf16
+// working copy into a compact image that the all-gather distributes.  One launch each over a table of ranges.
+// ranges (device int64): n x {p_start, g_start, length} (element offsets: into p / m / v, into the compact images g / p16c);
+// block_start (device int32, n + 1): running count of `chunk`-element blocks.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int range_of_block(const int* __restrict__ block_start, int n, int b) {
+  int lo = 0, hi = n;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (b >= block_start[mid]) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+template <typename GT>
+__global__ __launch_bounds__(256) void sumsq_ranges_partial_kernel(const GT* __restrict__ g, const long* __restrict__ ranges,
+                                                                   const int* __restrict__ block_start, int n, int chunk,
+                                                                   float* __restrict__ partials) {
+  __shared__ float sh[4];
+  const int r = range_of_block(block_start, n, blockIdx.x);
+  const long g0 = ranges[3 * r + 1], len = ranges[3 * r + 2];
+  const long base = (long)(blockIdx.x - block_start[r]) * chunk;
+  const long end = min(base + (long)chunk, len);
+  float s = 0.f;
+  for (long i = base + threadIdx.x * 4; i < end; i += 1024) {
+    if (i + 3 < end) {
+      const float4 v = load_grad4(g + g0, i);
+      s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    } else {
+      for (long k = i; k < end; ++k) { const float x = load_grad1(g + g0, k); s += x * x; }
+    }
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+template <typename GT>
+__global__ __launch_bounds__(256) void adamw_ranges_kernel(float* __restrict__ p, const GT* __restrict__ g, float* __restrict__ m,
+                                                           float* __restrict__ v, bf16_t* __restrict__ p16c,
+                                                           const long* __restrict__ ranges, const int* __restrict__ block_start, int n,
+                                                           int chunk, const VlbAdamState* __restrict__ st, float grad_scale) {
+  const float lr = st->lr, b1 = st->beta1, b2 = st->beta2, eps = st->eps, wd = st->weight_decay;
+  const float step = st->step + 1.0f;
+  float coef = grad_scale;
+  if (st->max_norm > 0.f) {
+    const float total = sqrtf(st->sumsq) * grad_scale;
+    coef *= fminf(st->max_norm / (total + 1e-6f), 1.0f);
+  }
+  const float step_size = lr * sqrtf(1.0f - powf(b2, step)) / (1.0f - powf(b1, step));
+  const int r = range_of_block(block_start, n, blockIdx.x);
+  const long p0 = ranges[3 * r], g0 = ranges[3 * r + 1], len = ranges[3 * r + 2];
+  const long base = (long)(blockIdx.x - block_start[r]) * chunk;
+  const long end = min(base + (long)chunk, len);
+  for (long i = base + threadIdx.x * 4; i < end; i += 1024) {
+    const int cnt = (int)min(4L, end - i);      // (range starts / lengths are multiples of 4: cnt == 4 except for a ragged last range)
+    float pv[4], gv[4], mv[4], vv[4];
+    if (cnt == 4) {
+      const float4 a = *(const float4*)(p + p0 + i), b = load_grad4(g + g0, i), c = *(const float4*)(m + p0 + i), d = *(const float4*)(v + p0 + i);
+      pv[0] = a.x; pv[1] = a.y; pv[2] = a.z; pv[3] = a.w;
+      gv[0] = b.x; gv[1] = b.y; gv[2] = b.z; gv[3] = b.w;
+      mv[0] = c.x; mv[1] = c.y; mv[2] = c.z; mv[3] = c.w;
+      vv[0] = d.x; vv[1] = d.y; vv[2] = d.z; vv[3] = d.w;
+    } else {
+      for (int k = 0; k < 4; ++k) {
+        const bool ok = k < cnt;
+        pv[k] = ok ? p[p0 + i + k] : 0.f; gv[k] = ok ? load_grad1(g + g0, i + k) : 0.f;
+        mv[k] = ok ? m[p0 + i + k] : 0.f; vv[k] = ok ? v[p0 + i + k] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gg = gv[k] * coef;
+      mv[k] = mv[k] * b1 + (1.0f - b1) * gg;
+      vv[k] = vv[k] * b2 + (1.0f - b2) * gg * gg;
+      const float denom = sqrtf(vv[k]) + eps;
+      pv[k] -= step_size * (mv[k] / denom);
+      if (wd > 0.f) pv[k] -= lr * wd * pv[k];
+    }
+    if (cnt == 4) {
+      *(float4*)(p + p0 + i) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+      *(float4*)(m + p0 + i) = make_float4(mv[0], mv[1], mv[2], mv[3]);
+      *(float4*)(v + p0 + i) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+      if (p16c) *(uint2*)(p16c + g0 + i) = make_uint2(pack2bf(pv[0], pv[1]), pack2bf(pv[2], pv[3]));
+    } else {
+      for (int k = 0; k < cnt; ++k) {
+        p[p0 + i + k] = pv[k]; m[p0 + i + k] = mv[k]; v[p0 + i + k] = vv[k];
+        if (p16c) p16c[g0 + i + k] = f2bf(pv[k]);
+      }
+    }
+  }
+}
+
+// out += sum over the ranges of g^2 (fixed summation order; g = the compact reduced-gradient image, fp32 or bf16)
+extern "C" int vlb_sumsq_ranges_det(const void* g, int g_is_bf16, const int64_t* ranges, const int32_t* block_start, int n, int total_blocks,
+                                    int chunk, float* partials, int partials_len, float* out, hipStream_t stream) {
+  if (n <= 0 || total_blocks <= 0) return VLB_OK;
+  VLB_CHECK_ARG(g && ranges && block_start && partials && out, "vlb_sumsq_ranges_det: null argument");
+  VLB_CHECK_ARG(chunk >= 1024 && (chunk % 1024) == 0, "vlb_sumsq_ranges_det: chunk must be a positive multiple of 1024");
+  VLB_CHECK_ARG(total_blocks <= partials_len, "vlb_sumsq_ranges_det: %d blocks need %d partial sums (workspace holds %d)", total_blocks,
+                total_blocks, partials_len);
+  VLB_CHECK_ARG(((uintptr_t)g % 16) == 0, "vlb_sumsq_ranges_det: gradient image must be 16-byte aligned");
+  if (g_is_bf16)
+    hipLaunchKernelGGL(sumsq_ranges_partial_kernel<bf16_t>, dim3(total_blocks), dim3(256), 0, stream, (const bf16_t*)g, (const long*)ranges,
+                       (const int*)block_start, n, chunk, partials);
+  else
+    hipLaunchKernelGGL(sumsq_ranges_partial_kernel<float>, dim3(total_blocks), dim3(256), 0, stream, (const float*)g, (const long*)ranges,
+                       (const int*)block_start, n, chunk, partials);
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, stream, partials, total_blocks, out);
+  VLB_CHECK_LAUNCH("vlb_sumsq_ranges_det");
+  return VLB_OK;
+}
+
+// AdamW over the ranges (see vlb_adamw_step for the arithmetic); p_bf16_compact (nullable) receives the bf16 copy of the updated
+// parameters at the ranges' g_start offsets; then step += 1 and sumsq = 0.
+extern "C" int vlb_adamw_step_ranges(float* p, const void* g, int g_is_bf16, float* m, float* v, void* p_bf16_compact,
+                                     const int64_t* ranges, const int32_t* block_start, int n, int total_blocks, int chunk, float* state,
+                                     float grad_scale, hipStream_t stream) {
+  VLB_CHECK_ARG(state, "vlb_adamw_step_ranges: null state");
+  if (n > 0 && total_blocks > 0) {
+    VLB_CHECK_ARG(p && g && m && v && ranges && block_start, "vlb_adamw_step_ranges: null argument");
+    VLB_CHECK_ARG(chunk >= 1024 && (chunk % 1024) == 0, "vlb_adamw_step_ranges: chunk must be a positive multiple of 1024");
+    VLB_CHECK_ARG(((uintptr_t)g % 16) == 0 && ((uintptr_t)p % 16) == 0, "vlb_adamw_step_ranges: buffers must be 16-byte aligned");
+    if (g_is_bf16)
+      hipLaunchKernelGGL(adamw_ranges_kernel<bf16_t>, dim3(total_blocks), dim3(256), 0, stream, p, (const bf16_t*)g, m, v,
+                         (bf16_t*)p_bf16_compact, (const long*)ranges, (const int*)block_start, n, chunk, (const VlbAdamState*)state, grad_scale);
+    else
+      hipLaunchKernelGGL(adamw_ranges_kernel<float>, dim3(total_blocks), dim3(256), 0, stream, p, (const float*)g, m, v,
+                         (bf16_t*)p_bf16_compact, (const long*)ranges, (const int*)block_start, n, chunk, (const VlbAdamState*)state, grad_scale);
+  }
+  hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(1), 0, stream, (VlbAdamState*)state);
+  VLB_CHECK_LAUNCH("vlb_adamw_step_ranges");
+  return VLB_OK;
+}
+
 extern "C" int vlb_lr_schedule_step(float* state, int kind, float base_lr, float warmup_steps, float t_total, hipStream_t stream) {
   VLB_CHECK_ARG(state, "vlb_lr_schedule_step: null state");
   VLB_CHECK_ARG(kind >= 0 && kind <= 2, "vlb_lr_schedule_step: kind must be 0 (constant), 1 (warmup-constant) or 2 (warmup-linear)");

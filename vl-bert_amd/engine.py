@@ -130,13 +130,16 @@ class FlatParams:
     """One contiguous buffer per role (fp32 master / fp32 grad / Adam m / Adam v / bf16 copy); every
     tensor starts on a 64-element boundary (256 B fp32, 128 B bf16)."""
 
-    def __init__(self, cfg, device):
+    def __init__(self, cfg, device, align=64):
+        """align: the buffers' length is rounded up to it (parallel.shard_alignment(world): every data-parallel bucket then splits
+        evenly over the ranks; the zero tail belongs to no parameter)."""
         self.shapes = param_layout(cfg)
         self.offsets = OrderedDict()
         off = 0
         for name, shape in self.shapes.items():
             self.offsets[name] = off
             off = _ru(off + math.prod(shape), 64)
+        off = _ru(off, max(64, int(align)))
         self.numel = off
         self.master = torch.zeros(off, dtype=F32, device=device)
         self.grad = torch.zeros(off, dtype=F32, device=device)
@@ -162,7 +165,7 @@ class PretrainEngine:
     def __init__(self, cfg, B, T, R, device="cuda:0", train=True, lr=1e-4, weight_decay=1e-4, max_grad_norm=10.0,
                  betas=(0.9, 0.999), eps=1e-6, seed=1234, grad_accum=1, process_group=None, keep_logits=False, flat=None,
                  B_aux=0, core=False, core_heads=True, core_sequence=False, lr_schedule=None, warmup_steps=0, t_total=0,
-                 image_size=None):
+                 image_size=None, dp_mode="default", dp_wire="default"):
         cfg.validate()
         if cfg.e2e and (core or image_size is None):
             raise ValueError("e2e needs image_size=(H, W) and a pretraining wrapper (plain or multitask; not the core module mode)")
@@ -203,7 +206,12 @@ class PretrainEngine:
         self.Mp, self.BTp, self.BRp = _ru(self.M, 64), _ru(self.BT, 64), _ru(self.BR, 64)
         self.Vp, self.Cp = _ru(V, 64), _ru(C, 64)
         d = self.dev
-        self.P = flat if flat is not None else FlatParams(cfg, d)   # `flat`: share storage with an nn.Module mirror
+        import torch.distributed as dist
+        world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        if flat is None:
+            from .parallel import shard_alignment
+            flat = FlatParams(cfg, d, align=shard_alignment(world))
+        self.P = flat                                                # (`flat` given: storage shared with an nn.Module mirror)
         P = self.P
         self.w16 = P.named(P.w16)
         self.w32 = P.named(P.master)
@@ -386,12 +394,20 @@ class PretrainEngine:
         import os
         self.use_tn_wgrad = os.environ.get("VLB_WGRAD_TN", "1") != "0"
         self.buckets = None
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1:
+        # sharded optimizer: the weight gather of the last update may still be in flight (forward waits per bucket); the transposed /
+        # folded weight copies are refreshed once it has landed (backward / the next forward of the vision path)
+        self._wT_stale = self._gather_pending = self._vision_stale = False
+        if world > 1:
             from .parallel import GradBuckets
             vstart = min((o for n, o in self.P.offsets.items() if n.startswith("image_feature_extractor.") and
                           not n.startswith("image_feature_extractor.obj_downsample")), default=None)
-            self.buckets = GradBuckets(self.P.grad, self.P.offsets, self.P.numel, L, group=process_group, vision_start=vstart)
+            self.buckets = GradBuckets(self.P.grad, self.P.offsets, self.P.numel, L, group=process_group, vision_start=vstart,
+                                       wire_dtype=dp_wire, mode=dp_mode)
+            if self.buckets.sharded:
+                # this rank's slice of every bucket: clip-norm partial + AdamW run on those only, one launch each (ops.ShardRanges);
+                # wshard = the compact bf16 image of the updated slices the weight all-gather distributes (parallel.py)
+                self.shard_tbl = ops.ShardRanges(self.buckets.owned_rows(), d)
+                self.wshard = torch.zeros(self.P.numel // world, dtype=BF16, device=d)
 
     # ------------------------------------------------------------------------------------------
     # parameters
@@ -415,6 +431,10 @@ class PretrainEngine:
         return {"image_feature_extractor." + k + ".weight" for k, c in self.vision.convs.items() if c.trainable}
 
     def state_dict(self):
+        """With the sharded data-parallel optimizer the fp32 master is authoritative on the owning rank only: the slices are gathered
+        first, so this is a COLLECTIVE there (call it on every rank, save on one)."""
+        if self.buckets is not None and self.buckets.sharded:
+            self.buckets.gather_master(self.P.master)
         vis = self._vision_names()
         sd = OrderedDict((k, v.detach().clone()) for k, v in self.w32.items() if k not in vis)
         sd[TIED_DECODER_KEY] = sd["vlbert.word_embeddings.weight"]
@@ -424,6 +444,9 @@ class PretrainEngine:
 
     def sync_weights(self):
         """fp32 master -> bf16 working copy + transposed copies (after load / external modification)."""
+        if self.buckets is not None:
+            self.buckets.wait_params("all")
+        self._wT_stale = self._gather_pending = self._vision_stale = False
         ops.cast_f32_bf16(self.P.master, self.P.w16)
         self._refresh_transposes()
         if self.vision is not None:
@@ -520,6 +543,13 @@ class PretrainEngine:
         w16, w32, seed = self.w16, self.w32, self.seed
         self.losses.zero_()
         ops.seq_layout_into(self.text_mask, self.box_mask, S, self.lay)
+        if self._gather_pending:    # sharded optimizer: the bf16 weights of the last update arrive bucket by bucket (parallel.gather_params)
+            if self.vision is not None:
+                self.buckets.wait_params("vision")
+                if self._vision_stale:
+                    self.vision.refresh_weights(trainable_only=True)
+                    self._vision_stale = False
+            self.buckets.wait_params("front")
         if self.core:
             self._front_core_fwd(p_h)
         else:
@@ -579,9 +609,12 @@ class PretrainEngine:
         w16, w32, seed = self.w16, self.w32, self.seed
         # --- encoder -------------------------------------------------------------------------------------
         mask = self.lay["attn_mask"]
+        stale = self._gather_pending
         for l in range(L):
             p = "vlbert.encoder.layer.%d." % l
             x = self.X[l]
+            if stale:
+                self.buckets.wait_params(l)
             wqkv = self.P.view(self.P.w16, p + "attention.self.query.weight", (3 * H, H), span=3)
             bqkv = self.P.view(self.P.master, p + "attention.self.query.bias", (3 * H,), span=3)
             ops.gemm_nt(x, wqkv, self.QKV[l], bias=bqkv)
@@ -607,6 +640,9 @@ class PretrainEngine:
             ops.layernorm_fwd(self.Z2[l], w32[p + "output.LayerNorm.weight"], w32[p + "output.LayerNorm.bias"], self.X[l + 1],
                               self.ST2[l])
         # --- heads ---------------------------------------------------------------------------------------
+        if stale:
+            self.buckets.wait_params("heads")
+            self._gather_pending = False
         xl = self.X[L]
         compact = self._mlm_compact_now and self.with_heads
         nr = self.mlm_cap if compact else self.BT          # rows the MLM head runs on
@@ -760,6 +796,12 @@ class PretrainEngine:
         p_h, p_a, p_ds = self._p(train)
         w16, w32, g32, wT, seed = self.w16, self.w32, self.g32, self.wT, self.seed
         Mp, BTp, BRp = self.Mp, self.BTp, self.BRp
+        if self._wT_stale:           # sharded optimizer: every gathered weight has landed by now -> the dgrad operands W^T
+            self.buckets.wait_params("all")
+            self._refresh_transposes()
+            self._wT_stale = False
+        if self.buckets is not None and on_layer_done is None:
+            self.buckets.invalidate()      # (a micro-step without the exchange: the reduced images are stale until a hooked backward)
         if self.with_heads:
             # --- MLM head ------------------------------------------------------------------------------------
             pm = "vlbert.mlm_head.predictions."
@@ -1054,6 +1096,21 @@ class PretrainEngine:
         if self.lr_kind is not None:
             ops.lr_schedule_step(self.adam, self.lr_kind, self.base_lr, self.warmup_steps, self.t_total)
         scale = self.buckets.grad_scale if self.buckets is not None else 1.0
+        self._check_mlm_overflow_now_and_then()
+        if self.buckets is not None and self.buckets.pending:
+            self.buckets.wait()
+        if self.buckets is not None and self.buckets.sharded:
+            # sharded optimizer (parallel.py): this rank holds the reduced slices it owns; partial clip norm -> sum over ranks ->
+            # AdamW on the owned slices -> the updated bf16 slices are all-gathered bucket by bucket under the next forward
+            g = self.buckets.grad_shard
+            self.shard_tbl.sumsq(g, self.sumsq_ws, self.adam[7:8])
+            self.buckets.all_reduce_scalar(self.adam[7:8])
+            self.shard_tbl.adamw(self.P.master, g, self.P.m, self.P.v, self.wshard, self.adam, grad_scale=scale)
+            self.buckets.gather_params(self.P.w16, self.wshard, master=self.P.master if self.vision is not None else None)
+            self._wT_stale = self._gather_pending = True
+            self._vision_stale = self.vision is not None
+            ops.rng_advance(self.seed)
+            return
         # data parallel: the reduced gradient is read where the exchange left it (the bf16 wire image by default, parallel.py)
         grad = self.buckets.reduced if self.buckets is not None else self.P.grad
         ops.sumsq_det(grad, self.sumsq_ws, self.adam[7:8])     # fixed summation order: replicas stay bit-identical
@@ -1062,6 +1119,23 @@ class PretrainEngine:
         if self.vision is not None:
             self.vision.refresh_weights(trainable_only=True)
         ops.rng_advance(self.seed)
+
+    def _check_mlm_overflow_now_and_then(self, every=64):
+        """MLM head compaction with device-resident labels: the overflow flag (a batch with more labelled positions than mlm_cap ran
+        truncated) is otherwise only read by loss_values(); loops that never call it get the check every `every` optimizer steps
+        (one 4-byte readback)."""
+        if self.mlm_cap is None:
+            return
+        self._opt_steps = getattr(self, "_opt_steps", 0) + 1
+        if self._opt_steps % every == 0 and not torch.cuda.is_current_stream_capturing():
+            self._raise_on_mlm_overflow()
+
+    def _raise_on_mlm_overflow(self):
+        if int(self.mlm_overflow.cpu()) != 0:
+            self.mlm_overflow.zero_()
+            raise RuntimeError("MLM head compaction: a batch carried more than mlm_cap = %d labelled text positions (the excess was "
+                               "not trained on).  Build the engine with VLB_MLM_COMPACT=0 or hand the labels over as CPU tensors "
+                               "(they are then counted exactly and oversize batches take the full path)." % self.mlm_cap)
 
     # -- dropout seed discipline of the nn.Module mirrors (reference-style loop: net.train(); loss.backward(); optimizer.step()) --
     # Masks are never stored: forward and backward regenerate them from the device-resident seed, so the seed a backward sees must
@@ -1120,11 +1194,16 @@ class PretrainEngine:
     # results (host side, sync) -- used by tests / API parity, not by the timed loop
     # ------------------------------------------------------------------------------------------
     def loss_values(self):
-        if self.mlm_cap is not None and int(self.mlm_overflow.cpu()) != 0:
-            raise RuntimeError("MLM head compaction: a batch carried more than mlm_cap = %d labelled text positions (the excess was "
-                               "not trained on).  Build the engine with VLB_MLM_COMPACT=0 or hand the labels over as CPU tensors "
-                               "(they are then counted exactly and oversize batches take the full path)." % self.mlm_cap)
+        if self.mlm_cap is not None:
+            self._raise_on_mlm_overflow()
         l = self.losses.cpu()
+        from . import _lib
+        bad = _lib.nonfinite_status(reset=True)
+        if bad:
+            raise FloatingPointError("non-finite LayerNorm input (%s): %s" % (
+                "fp16 residual stream" if bad & 1 else "bf16 rows",
+                "a pre-LayerNorm sum exceeded the fp16 range (65504); run with VLB_RESIDUAL_STREAM=bf16" if bad & 1
+                else "the activations already held inf / NaN"))
         out = dict(mlm_loss=float(l[0]), mvrc_loss=float(l[1]), relationship_loss=float(l[3]), loss=float(l[0] + l[1] + l[2] + l[3]))
         if self.Ba:
             out.update(mlm_loss_wvc=float(l[0]), mlm_loss_aux=float(l[2]))

@@ -595,3 +595,32 @@ def avgpool_rows_bwd(dfeat, y, boxes, dz, K, P, C, drop_p=0.0, seed=None, tag=0,
     _lib.call("vlb_avgpool_rows_bwd", _p(dfeat, BF16), _ld(dfeat), _p(y, BF16), _p(boxes, torch.float32), _ld(boxes) if boxes is not None else 0,
               _p(dz, BF16), K, P, C, float(drop_p), _p(seed), int(tag), int(drop_row_elems), int(drop_col0), _p(segm, torch.float32), _stream())
     return dz
+
+
+class ShardRanges:
+    """Device table of the slices one data-parallel rank owns (parallel.GradBuckets, mode "sharded"): rows (offset into the flat
+    parameter buffers, offset into the compact reduced-gradient / bf16-weight images, length).  Built once; sumsq() and adamw() are one
+    launch each over all slices (vlb_sumsq_ranges_det / vlb_adamw_step_ranges)."""
+
+    def __init__(self, rows, device, max_blocks=2048):
+        rows = [r for r in rows if r[2] > 0]
+        total = sum(r[2] for r in rows)
+        chunk = 4096
+        while sum((r[2] + chunk - 1) // chunk for r in rows) > max_blocks:
+            chunk *= 2
+        starts, nb = [0], 0
+        for r in rows:
+            nb += (r[2] + chunk - 1) // chunk
+            starts.append(nb)
+        self.rows, self.n, self.total_blocks, self.chunk, self.total = rows, len(rows), nb, chunk, total
+        self.ranges = torch.tensor(rows, dtype=torch.int64).reshape(-1, 3).to(device)
+        self.starts = torch.tensor(starts, dtype=torch.int32).to(device)
+
+    def sumsq(self, g, partials, out):
+        _lib.call("vlb_sumsq_ranges_det", _p(g), 1 if g.dtype == BF16 else 0, self.ranges.data_ptr(), self.starts.data_ptr(), self.n,
+                  self.total_blocks, self.chunk, _p(partials, torch.float32), partials.numel(), _p(out, torch.float32), _stream())
+
+    def adamw(self, p, g, m, v, p16c, state, grad_scale=1.0):
+        _lib.call("vlb_adamw_step_ranges", _p(p, torch.float32), _p(g), 1 if g.dtype == BF16 else 0, _p(m, torch.float32),
+                  _p(v, torch.float32), _p(p16c, BF16), self.ranges.data_ptr(), self.starts.data_ptr(), self.n, self.total_blocks,
+                  self.chunk, _p(state, torch.float32), float(grad_scale), _stream())

@@ -31,13 +31,35 @@ def _flat_runs(params):
     return runs
 
 
+_FLAT_KEYS = ("flat_m", "flat_v", "flat_buffer", "dev", "hyper")
+
+
+class _FlatStateMixin:
+    """The per-run flat buffers (`flat_*`, `dev`) are an implementation detail: state_dict() exports the reference's per-parameter
+    entries only (they are views of the flat buffers), and load_state_dict() drops the flat buffers so that the next step() re-creates
+    them FROM the loaded per-parameter tensors and re-binds the views -- otherwise a reloaded checkpoint would leave the kernels
+    updating buffers the exported state no longer aliases."""
+
+    def state_dict(self):
+        sd = super().state_dict()
+        sd["state"] = {k: {n: v for n, v in st.items() if n not in _FLAT_KEYS} for k, st in sd["state"].items()}
+        return sd
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        for st in self.state.values():
+            for n in _FLAT_KEYS:
+                st.pop(n, None)
+        self._runs = {}
+
+
 def _check_fp32_gpu(ps, who):
     for p in ps:
         if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous() and p.grad.dtype == torch.float32):
             raise RuntimeError("%s needs contiguous fp32 GPU parameters and gradients; there is no CPU path" % who)
 
 
-class FusedAdamW(torch.optim.Optimizer):
+class FusedAdamW(_FlatStateMixin, torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, correct_bias=True):
         if lr < 0.0 or eps < 0.0 or not (0.0 <= betas[0] < 1.0) or not (0.0 <= betas[1] < 1.0):
             raise ValueError("invalid hyper-parameter")          # the reference's checks (optimization.py:117-124)
@@ -79,7 +101,7 @@ class FusedAdamW(torch.optim.Optimizer):
                             old = self.state[p].get(name)
                             view = flat[off:off + p.numel()].view_as(p)
                             if old is not None:
-                                view.copy_(old)
+                                view.copy_(old.to(view.device, view.dtype).view_as(view))
                             self.state[p][name] = view
                         self.state[p].setdefault("step", 0)
                         off += p.numel()
@@ -95,7 +117,7 @@ class FusedAdamW(torch.optim.Optimizer):
         return loss
 
 
-class FusedSGD(torch.optim.Optimizer):
+class FusedSGD(_FlatStateMixin, torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, momentum=0.0, dampening=0.0, weight_decay=0.0, nesterov=False):
         if dampening != 0.0 or nesterov:
             raise NotImplementedError("FusedSGD implements dampening = 0, nesterov = False (the reference's configuration)")
@@ -128,7 +150,7 @@ class FusedSGD(torch.optim.Optimizer):
                         old = self.state[p].get("momentum_buffer")
                         view = st["flat_buffer"][off:off + p.numel()].view_as(p)
                         if old is not None:
-                            view.copy_(old)
+                            view.copy_(old.to(view.device, view.dtype).view_as(view))
                         self.state[p]["momentum_buffer"] = view
                         off += p.numel()
                 pf = first.data.as_strided((n,), (1,), first.storage_offset())

@@ -237,7 +237,10 @@ class VisionStack:
         """fp32 tensors that are NOT in the engine's flat parameter buffer (BatchNorm tensors, weights of the frozen stages):
         what a start-up parameter broadcast has to cover besides the flat buffer (engine.broadcast_parameters)."""
         self._dirty = True
-        return [t for t in self.frozen.values() if t.is_contiguous()]
+        bad = [n for n, t in self.frozen.items() if not t.is_contiguous()]
+        if bad:      # a view would be broadcast into a temporary and the replica left unsynchronised
+            raise RuntimeError("vision.broadcast_tensors: non-contiguous frozen tensors %s" % bad[:4])
+        return list(self.frozen.values())
 
     def state_dict(self):
         sd = OrderedDict()
