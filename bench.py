@@ -38,9 +38,10 @@ def flops_per_sample(cfg, T, R):
     return fwd, 3 * fwd
 
 
-def cpu_baseline(cfg_kw, T, R, budget_s=25.0):
+def cpu_baseline(cfg_kw, T, R, budget_s=25.0, full=False):
     """The oracle ("port" of the reference modules, oracle/vlbert_oracle.py) timed on this box's host cores:
-    forward + backward + AdamW of the same 12-layer model on a bounded sample (small batch, few iterations)."""
+    forward + backward + AdamW of the same 12-layer model on a bounded sample (small batch, few iterations).
+    full=True (--cpu-baseline-full): SURVEY.md 8d's form -- batch 32, 3 warm-up + 5 timed iterations, median (minutes of CPU time)."""
     from oracle import vlbert_oracle as O
     syn = importlib.import_module("vl-bert_amd.synthetic")
     # 256 torch threads on the GPU box's host oversubscribe badly (measured: 0.02 samples/s); cap the pool and
@@ -49,24 +50,29 @@ def cpu_baseline(cfg_kw, T, R, budget_s=25.0):
     torch.set_num_threads(cores)
     cfg = O.VLBertConfig(**cfg_kw)
     params = O.init_params(cfg, seed=0, randomize_all=False)
-    Bc = 8
+    Bc = 32 if full else 8
     batch = syn.make_batch(Bc, T, R, seed=0)
     m = {k: torch.zeros_like(v) for k, v in params.items()}
     v = {k: torch.zeros_like(v) for k, v in params.items()}
     times = []
     t_start = time.time()
     it = 0
-    while it < 4 and (time.time() - t_start) < budget_s:
+    while it < (8 if full else 4) and (full or (time.time() - t_start) < budget_s):
         t0 = time.time()
         _, _, grads, _ = O.loss_and_grads(params, cfg, batch, train=True)
         for k in params:
             O.adamw_step(params[k], grads[k], m[k], v[k], it + 1, 1e-4, eps=1e-6, weight_decay=1e-4)
         times.append(time.time() - t0)
         it += 1
-    t = min(times[1:]) if len(times) > 1 else times[0]
+    if full:
+        t = sorted(times[3:])[len(times[3:]) // 2]
+        how = "3 warm-up + %d timed iterations, median %.2f s" % (len(times) - 3, t)
+    else:
+        t = min(times[1:]) if len(times) > 1 else times[0]
+        how = "%d iterations (best of last %d)" % (len(times), max(1, len(times) - 1))
     return {"value": round(Bc / t, 3), "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": "oracle fwd+bwd+AdamW, %d-layer hidden %d, batch %d x (%d+%d), fp32, dropout on, %d iterations (best of last %d)"
-                      % (cfg.num_hidden_layers, cfg.hidden_size, Bc, T, R, len(times), max(1, len(times) - 1))}
+            "sample": "oracle fwd+bwd+AdamW, %d-layer hidden %d, batch %d x (%d+%d), fp32, dropout on, %s"
+                      % (cfg.num_hidden_layers, cfg.hidden_size, Bc, T, R, how)}
 
 
 def cpu_baseline_e2e(cfg_kw, T, R, image_size, vlbert):
@@ -417,14 +423,27 @@ def main():
                     "choices, sequences of 256 positions, ResNet-101 image path with object masks, SGD momentum 0.9, gradient accumulation 4 "
                     "(cfgs/vcr/large_q2a_4x16G_fp16.yaml: 4 samples per GPU per micro-batch); one GPU; a step = one OPTIMIZER step")
     ap.add_argument("--layers", type=int, default=12)
+    ap.add_argument("--precision", default=None, choices=["bf16", "f16"], help="16-bit type of the library build (vl-bert_amd/_lib.py): bf16 "
+                    "(default; BASELINE.json's headline precision) or f16 = IEEE fp16 activations / working weights / gradients + a static loss "
+                    "scale (the reference's Apex fp16 mode, TRAIN.FP16: true; same MFMA rate, 3 more mantissa bits per operand)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-full", action="store_true", help="time the CPU port at SURVEY 8d's size (batch 32, 3 warm-up + 5 timed "
+                    "iterations, median) instead of the quick bounded leg (batch 8, <= 25 s)")
+    ap.add_argument("--dp-mode", default="default", choices=["default", "sharded", "allreduce"], help="data-parallel exchange "
+                    "(vl-bert_amd/parallel.py): sharded optimizer (reduce-scatter + weight all-gather; default) or all-reduce")
     ap.add_argument("--head-start", type=int, default=60, help="unrelated 0.55-TFLOP torch.mm launches queued ahead of the instrumented step (roofline)")
     ap.add_argument("--no-phase-times", action="store_true", help="skip the separate forward / forward+backward timing loops (profiling runs)")
     ap.add_argument("--graph", action="store_true", help="replay the step as one hipGraph (single GPU).  Off by default: the step is "
                     "GPU-bound, not launch-bound -- measured on MI355X the eager stream launches are 3-5 %% FASTER than the graph replay "
                     "(26.97 vs 27.84 ms at batch 256, 6.72 vs 7.11 ms at batch 32)")
-    ap.add_argument("--no-graph", action="store_true", help="(default behaviour; kept for older command lines)")
+    ap.add_argument("--no-graph", action="store_true", help="never replay graphs.  With more than one rank the default IS graph replay in "
+                    "segments cut at the collectives (engine.make_step_graph): the eager launch loop (~5 ms of host time per step) would "
+                    "bound the 32-sample-per-GPU step")
     args = ap.parse_args()
+    if args.precision:
+        os.environ["VLB_PRECISION"] = args.precision        # read by vl-bert_amd/_lib.py at import (the imports below are lazy)
+    prec = os.environ.get("VLB_PRECISION", "bf16").lower()
+    dtype_name = "fp16 (fp32 accumulation, fp32 master weights, static loss scale)" if prec in ("f16", "fp16", "half", "float16") else "bf16"
 
     if "RANK" not in os.environ and args.gpus > 1:
         # plain `python bench.py --gpus N`: re-launch ourselves as N ranks (one per GPU) under torch.distributed.run, exactly the
@@ -491,7 +510,7 @@ def main():
         cfg = engine.ModelConfig(num_hidden_layers=args.layers, e2e=args.e2e, multitask=aux > 0)
     eng = engine.PretrainEngine(cfg, per_gpu, T, R, device="cuda:%d" % local_rank, train=True, lr=1e-4, weight_decay=1e-4,
                                 max_grad_norm=10.0, seed=1234 + rank, image_size=tuple(args.image_size) if args.e2e else None,
-                                B_aux=aux)
+                                B_aux=aux, dp_mode=args.dp_mode)
     eng.init_random(seed=rank, visual_ln_init=1.0 if args.e2e else 0.0)
     eng.broadcast_parameters(src=0)      # rank 0's parameters everywhere (the DDP start-up broadcast, pretrain/function/train.py:331-334)
     batch = syn.make_batch(per_gpu, T, R, seed=100 + rank)
@@ -520,15 +539,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    use_graph = args.graph and not args.no_graph and world == 1
+    use_graph = (args.graph or world > 1) and not args.no_graph
     step = eng.train_step
+    graph_info = None
     if use_graph:
-        eng.train_step()                            # lazy one-time setup outside capture
+        eng.train_step()                            # lazy one-time setup + steady-state flags outside capture
         torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            eng.train_step()
-        step = g.replay
+        step = eng.make_step_graph()                # one graph (1 rank) / segments cut at the collectives (data parallel)
+        graph_info = "%d graph segment(s) + %d host-side collective calls per step" % (step.n_graphs, step.n_calls)
 
     for _ in range(args.warmup):
         step()
@@ -545,6 +563,8 @@ def main():
     ms = elapsed / args.steps * 1e3
     total_samples = args.global_batch + aux * world          # caption samples + text-only samples of one step, all ranks
     value = total_samples / (elapsed / args.steps)
+    if eng.buckets is not None and eng.buckets.sharded:     # drain the weight gathers of the last timed step before anything else runs
+        eng.forward(True)
     losses = eng.loss_values()
 
     # ---- forward-only and forward+backward times (SURVEY.md §8d asks for them next to the step time); outside the timed region
@@ -658,13 +678,20 @@ def main():
     # HBM bytes per GEMM launch come from PMC counters, which need their own rocprofv3 passes (tools/make_profiles.sh);
     # the committed summary of those passes is reported here when it was taken on this workload, else null.
     traffic, traffic_unit = None, None
-    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_gemm_traffic.json")
-    if world == 1 and args.global_batch == 256 and args.layers == 12 and os.path.isfile(tpath):
-        with open(tpath) as f:
+    pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    tname = next((n for n in ("r03_gemm_traffic.json", "r02_gemm_traffic.json") if os.path.isfile(os.path.join(pdir, n))), None)
+    if world == 1 and args.global_batch == 256 and args.layers == 12 and not args.e2e and not args.large and tname:
+        with open(os.path.join(pdir, tname)) as f:
             tj = json.load(f)
         traffic = round(tj["gemm_hbm_GB_per_launch"], 4)
-        traffic_unit = "GB per GEMM launch (avg over %d launches/step; rocprofv3 2xFETCH_SIZE+WRITE_SIZE, profiles/r02_gemm_traffic.json)" \
-            % round(tj["gemm_launches_per_step"])
+        traffic_unit = "GB per GEMM launch (avg over %d launches/step; rocprofv3 2xFETCH_SIZE+WRITE_SIZE, separate --pmc passes of this " \
+                       "workload: profiles/%s%s)" % (round(tj["gemm_launches_per_step"]), tname,
+                                                     ", commit " + tj["commit"] if "commit" in tj else "")
+    # FLOPs the step EXECUTES (the MLM head runs on the labelled rows only -- engine mlm_cap -- so less than SURVEY 8d's algorithmic
+    # count, which the north star's `step_frac_of_peak` is defined on): the timed GEMM launches + the attention matmuls
+    H_, L_ = cfg.hidden_size, cfg.num_hidden_layers
+    attn_flops = 3.0 * 4.0 * (T + R + 1) ** 2 * H_ * L_ * (per_gpu + aux)          # fwd + 2x bwd of QK^T and PV
+    exec_tflop = (gemm_flops + attn_flops) / 1e12
 
     if rank == 0:
         out = {
@@ -672,7 +699,7 @@ def main():
             if args.e2e else "samples/sec VL-BERT-base pretrain (seq 64+36 regions) at 1/2/4/8 MI355X",
             "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak" if args.e2e else "strong", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic (random-init weights, random tokens/boxes/features, resident in HBM)",
+            "dtype": dtype_name, "data": "synthetic (random-init weights, random tokens/boxes/features, resident in HBM)",
             "config": {"workload": "VL-BERT-%s %d-layer pretrain step (fwd+bwd+clip+AdamW), %d text + %d regions, "
                                    "%s, dropout on" % ("large" if args.large else "base", args.layers, T, R, "ResNet-101 trunk + ROIAlign + dilated layer4 head on the device "
                                                        "(stages 1-2 and BatchNorm frozen)" if args.e2e else "precomputed 2048-d region features")
@@ -683,9 +710,13 @@ def main():
                        "reference_cfg": ("cfgs/pretrain/base_e2e_16x16G_fp16.yaml" if (args.e2e and aux == 8 and per_gpu == 8 and not args.large)
                                          else None),
                        "seq_len": T + R + 1,
-                       "parallelism": "dp%d" % world, "hipgraph": bool(use_graph), "arch": arch, "cus": cus,
+                       "parallelism": "dp%d" % world, "hipgraph": graph_info if use_graph else False, "arch": arch, "cus": cus,
                        "collective_backend": (("RCCL (nccl)" if backend == "nccl" else backend) if world > 1 else None),
-                       "grad_wire_dtype": (str(eng.buckets.reduced.dtype).replace("torch.", "") if eng.buckets is not None else None),
+                       "ranks": world,
+                       "dp_exchange": (("sharded optimizer: reduce-scatter -> clip + AdamW on the owned 1/%d -> bf16 weight all-gather under "
+                                        "the next forward" % world) if eng.buckets.sharded else "bucketed all-reduce, replicated AdamW")
+                       if eng.buckets is not None else None,
+                       "grad_wire_dtype": (str(eng.buckets.wire_dtype or torch.float32).replace("torch.", "") if eng.buckets is not None else None),
                        "ranks_share_devices": bool(shared)},
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_p8_kernel + gemm_tn8_kernel (+ the 128x128 gemm_nt / gemm_tn kernels on the small head shapes): "
                                                        "all %d GEMM launches of one step" % len(rec),
@@ -694,7 +725,9 @@ def main():
                          "algorithmic_GB_per_launch": round(gemm_alg_gb, 4),
                          "gemm_ms_per_step": round(gemm_ms, 3), "gemm_share_of_step": round(gemm_ms / ms, 3), "by_op": by_op,
                          "step_algorithmic_tflops": round(value * fwdbwd / 1e12, 2),
-                         "step_frac_of_peak": round(value * fwdbwd / 1e12 / (world * PEAK_BF16_TFLOPS), 4)},
+                         "step_frac_of_peak": round(value * fwdbwd / 1e12 / (world * PEAK_BF16_TFLOPS), 4),
+                         "step_executed_tflop_per_gpu": round(exec_tflop, 3),
+                         "step_frac_of_peak_executed": round(exec_tflop / (ms * 1e-3) / PEAK_BF16_TFLOPS, 4)},
             "fwd_ms": round(fwd_ms, 3) if fwd_ms is not None else None,
             "fwd_bwd_ms": round(fwd_bwd_ms, 3) if fwd_bwd_ms is not None else None,
             "loss": round(losses["loss"], 4),
@@ -702,7 +735,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             ckw = dict(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096) if args.large \
                 else dict(num_hidden_layers=args.layers)
-            out["cpu_baseline"] = cpu_baseline(ckw, T, R, budget_s=12.0 if args.e2e else 25.0)
+            out["cpu_baseline"] = cpu_baseline(ckw, T, R, budget_s=12.0 if args.e2e else 25.0, full=args.cpu_baseline_full)
             if args.e2e:
                 out["cpu_baseline"] = cpu_baseline_e2e(dict(num_hidden_layers=args.layers), T, R, tuple(args.image_size), out["cpu_baseline"])
         print(json.dumps(out), flush=True)

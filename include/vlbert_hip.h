@@ -34,6 +34,10 @@ typedef struct ihipStream_t* vlb_stream_t; /* == hipStream_t */
 
 const char* vlb_last_error(void);
 int vlb_version(void);
+/* 16-bit storage type of this build: 0 = bfloat16 (libvlbert_hip.so, the default), 1 = IEEE fp16 (libvlbert_hip_f16.so: every
+ * "bf16" in the names below then means fp16 -- the reference's own mixed precision, Apex O2 with a static loss scale,
+ * pretrain/function/train.py:345-352; the host scales the loss and passes 1/scale as grad_scale to the optimizer entry points). */
+int vlb_act_dtype(void);
 /* returns the CU count of `device` and copies its gcnArchName ("gfx950:...") into name */
 int vlb_device_info(int device, char* name, int cap);
 

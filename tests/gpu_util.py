@@ -17,13 +17,18 @@ def dev():
     return torch.device("cuda:0")
 
 
+def act_dtype():
+    """The library's 16-bit type: torch.bfloat16, or torch.float16 when the suite runs against the fp16 build (VLB_PRECISION=f16)."""
+    return pkg("ops").BF16
+
+
 def bf(t):
-    """Round an fp32 CPU tensor to bf16 values (kept in fp32)."""
-    return t.to(torch.bfloat16).float()
+    """Round an fp32 CPU tensor to the library's 16-bit type (kept in fp32)."""
+    return t.to(act_dtype()).float()
 
 
 def to_gpu_bf16(t):
-    return t.to(torch.bfloat16).to(dev())
+    return t.to(act_dtype()).to(dev())
 
 
 def report(name, got, ref, atol, rtol):

@@ -52,7 +52,7 @@ def test_ctypes_signatures_match_header():
         assert name in protos, "binding %s has no prototype in include/vlbert_hip.h" % name
         assert protos[name] == sig, "%s: header %s vs binding %s" % (name, protos[name], sig)
     for name in protos:
-        assert name in lib._SIGS or name in ("vlb_last_error", "vlb_version", "vlb_device_info", "vlb_wgrad_workspace_floats",
+        assert name in lib._SIGS or name in ("vlb_last_error", "vlb_version", "vlb_act_dtype", "vlb_device_info", "vlb_wgrad_workspace_floats",
                                             "vlb_layernorm_bwd_workspace_floats", "vlb_layernorm_bwd_slabs", "vlb_gemm_set_option",
                                                 "vlb_roi_align_gather_workspace_bytes", "vlb_nonfinite_status"), name
 
@@ -67,6 +67,21 @@ def test_library_loads_and_exports_every_symbol():
         assert hasattr(h, name), "libvlbert_hip.so does not export %s" % name
     assert h.vlb_version() >= 100
     assert isinstance(h.vlb_last_error(), bytes)
+    assert h.vlb_act_dtype() == 0                      # the default build computes in bfloat16
+
+
+def test_fp16_build_of_the_library_exports_the_same_abi():
+    """libvlbert_hip_f16.so = the same sources with IEEE fp16 as the 16-bit type (the reference's Apex fp16 mode): same symbols."""
+    import ctypes
+    lib = importlib.import_module("vl-bert_amd._lib")
+    path = lib._default_path("f16")
+    if not os.path.isfile(path):
+        import __graft_entry__
+        __graft_entry__.build()
+    h = ctypes.CDLL(path)
+    for name in header_prototypes():
+        assert hasattr(h, name), "libvlbert_hip_f16.so does not export %s" % name
+    assert h.vlb_act_dtype() == 1
 
 
 def test_missing_library_fails_loudly(monkeypatch):

@@ -26,6 +26,12 @@ def _run(extra):
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     print(r.stdout[-3000:])
     print(r.stderr[-3000:])
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "dp_test_%s.log" % "_".join(a.strip("-") for a in extra)), "w") as f:
+            f.write(r.stdout + "\n---- stderr ----\n" + r.stderr)
+    except OSError:
+        pass
     assert r.returncode == 0, r.stderr[-2000:]
     assert r.stdout.count("parameters identical to rank 0 after 2 DP steps: True") == 2
 

@@ -88,6 +88,47 @@ def main():
     print("rank %d: parameters identical to rank 0 after 2 DP steps: %s (max |diff| %.3e) ; loss %.4f" %
           (rank, same, float((mine - other).abs().max()), eng.loss_values()["loss"]), flush=True)
     assert same
+    # (5) the same step replayed as hipGraph segments cut at the collectives (engine.make_step_graph): replicas stay identical and the
+    # replayed step computes what the eager one does (same dropout seed sequence: compare the loss of replay k with eager step k)
+    snap = dict(master=eng.P.master.clone(), m=eng.P.m.clone(), v=eng.P.v.clone(), adam=eng.adam.clone(), seed=eng.seed.clone(),
+                w16=eng.P.w16.clone())
+    eager_losses = []
+    for _ in range(2):
+        eng.train_step()
+        eager_losses.append(eng.loss_values()["loss"])
+    torch.cuda.synchronize()
+    if sharded:
+        eng.forward(True)                  # drain the weight gathers in flight before the copy is read / the state is rewound
+        torch.cuda.synchronize()
+    after_eager = eng.P.w16.clone()
+    eng.P.master.copy_(snap["master"]); eng.P.m.copy_(snap["m"]); eng.P.v.copy_(snap["v"]); eng.adam.copy_(snap["adam"])
+    eng.seed.copy_(snap["seed"]); eng.P.w16.copy_(snap["w16"])
+    eng._refresh_transposes()
+    if eng.vision is not None:
+        eng.vision.refresh_weights(trainable_only=True)
+    eng._wT_stale = eng._gather_pending = eng._vision_stale = False
+    eng.train_step()                       # one eager step puts the engine into its steady state (flags as at the end of a step) ...
+    first = eng.loss_values()["loss"]
+    step = eng.make_step_graph()           # ... which is what the capture assumes
+    step()
+    second = eng.loss_values()["loss"]
+    torch.cuda.synchronize()
+    if sharded:
+        eng.forward(True)
+        torch.cuda.synchronize()
+    print("rank %d: graph replay: %d segments + %d host calls per step; losses eager %.5f %.5f | eager+replay %.5f %.5f" %
+          (rank, step.n_graphs, step.n_calls, eager_losses[0], eager_losses[1], first, second), flush=True)
+    assert abs(first - eager_losses[0]) <= 2e-3 * abs(first) and abs(second - eager_losses[1]) <= 2e-3 * abs(second)
+    end = eng.buckets.ranges["heads"][1]
+    d16 = float((eng.P.w16[:end].float() - after_eager[:end].float()).abs().max())
+    print("rank %d: bf16 weights after eager+replay vs eager+eager: max |diff| %.3e" % (rank, d16), flush=True)
+    # two runs of one step differ in fp32-atomic summation order (LayerNorm / embedding sums; e2e: ROIAlign backward), so a weight may
+    # land on the neighbouring 16-bit value: one ulp = 2^-7 relative in bf16 (7.8e-3 on a LayerNorm gain of 1, 1.2e-4 on a 0.02 weight)
+    assert bool(torch.allclose(eng.P.w16[:end].float(), after_eager[:end].float(), rtol=2.0 ** -6, atol=2e-3)), d16
+    mine = eng.P.w16.clone()
+    other = mine.clone()
+    dist.broadcast(other, src=0)
+    assert bool(torch.equal(mine, other)), "replicas diverged under graph replay"
     dist.barrier()
     dist.destroy_process_group()
 

@@ -9,8 +9,22 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+# The 16-bit type is a build-time choice of the library (csrc/vlb_common.h): "bf16" -> libvlbert_hip.so (default), "f16" ->
+# libvlbert_hip_f16.so (IEEE fp16 activations / working weights / gradients + a static loss scale: the reference's Apex fp16 mode).
+# One precision per process: VLB_PRECISION at start-up, or set_precision() before the first engine / module is built.
+PRECISION = os.environ.get("VLB_PRECISION", "bf16").lower()
+if PRECISION in ("fp16", "half", "float16"):
+    PRECISION = "f16"
+if PRECISION not in ("bf16", "f16"):
+    raise ValueError("VLB_PRECISION must be bf16 or f16 (got %r)" % PRECISION)
+
+
+def _default_path(precision):
+    return os.path.join(_HERE, "libvlbert_hip.so" if precision == "bf16" else "libvlbert_hip_f16.so")
+
+
 # VLB_LIB_PATH: an alternative build of the same library (A/B measurements of compile-time variants on one GPU box)
-LIB_PATH = os.environ.get("VLB_LIB_PATH") or os.path.join(_HERE, "libvlbert_hip.so")
+LIB_PATH = os.environ.get("VLB_LIB_PATH") or _default_path(PRECISION)
 
 _P, _L, _I, _F, _U = ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_float, ctypes.c_uint32
 
@@ -101,6 +115,10 @@ def load():
             "libvlbert_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or vl-bert_amd/csrc/build.sh).  There is no CPU / eager fallback." % LIB_PATH)
     lib = ctypes.CDLL(LIB_PATH)
+    lib.vlb_act_dtype.restype = _I
+    lib.vlb_act_dtype.argtypes = []
+    if lib.vlb_act_dtype() != (1 if PRECISION == "f16" else 0):
+        raise RuntimeError("%s was built for %s but VLB_PRECISION is %s" % (LIB_PATH, "f16" if lib.vlb_act_dtype() else "bf16", PRECISION))
     lib.vlb_last_error.restype = ctypes.c_char_p
     lib.vlb_last_error.argtypes = []
     lib.vlb_version.restype = _I
@@ -126,8 +144,27 @@ def load():
     return lib
 
 
+def set_precision(precision):
+    """Switch the process to the other build of the library (tests; A/B runs).  Tensors of engines built before the switch keep
+    their dtype: do not interleave engines of two precisions."""
+    global PRECISION, LIB_PATH, _lib
+    precision = {"fp16": "f16", "half": "f16", "float16": "f16"}.get(precision, precision)
+    if precision not in ("bf16", "f16"):
+        raise ValueError("precision must be bf16 or f16")
+    if precision != PRECISION:
+        PRECISION, LIB_PATH, _lib = precision, _default_path(precision), None
+        from . import ops
+        ops.BF16 = act_torch_dtype()
+    return load()
+
+
+def act_torch_dtype():
+    import torch
+    return torch.float16 if PRECISION == "f16" else torch.bfloat16
+
+
 def exported_names():
-    return ["vlb_last_error", "vlb_version", "vlb_device_info", "vlb_wgrad_workspace_floats",
+    return ["vlb_last_error", "vlb_version", "vlb_act_dtype", "vlb_device_info", "vlb_wgrad_workspace_floats",
             "vlb_layernorm_bwd_workspace_floats", "vlb_layernorm_bwd_slabs", "vlb_gemm_set_option",
             "vlb_roi_align_gather_workspace_bytes", "vlb_nonfinite_status"] + sorted(_SIGS)
 

@@ -131,8 +131,8 @@ class FastRCNN(nn.Module):
         down.register_parameter("bias", nn.Parameter(torch.zeros((final_dim,), device=dev)))
         self.obj_downsample = nn.Module()
         self.obj_downsample.add_module("1", down)              # Sequential(Dropout, Linear, ReLU): the Linear is entry "1"
-        self._w16 = torch.zeros((final_dim, 2 * VIS_DIM), dtype=torch.bfloat16, device=dev)
-        self._wT = torch.zeros((2 * VIS_DIM, final_dim), dtype=torch.bfloat16, device=dev)
+        self._w16 = torch.zeros((final_dim, 2 * VIS_DIM), dtype=ops.BF16, device=dev)
+        self._wT = torch.zeros((2 * VIS_DIM, final_dim), dtype=ops.BF16, device=dev)
         self._zero_embed = torch.zeros((VIS_DIM,), dtype=torch.float32, device=dev)
         self._seed = torch.tensor([ops.rank_seed(20011)], dtype=torch.int32, device=dev)
         self._version, self._states = None, OrderedDict()
@@ -236,7 +236,7 @@ class FastRCNN(nn.Module):
     def _state(self, B, R, dev):
         def make():
             n, H = B * R, self.final_dim
-            zb = lambda *s: torch.zeros(s, dtype=torch.bfloat16, device=dev)
+            zb = lambda *s: torch.zeros(s, dtype=ops.BF16, device=dev)
             return dict(a=zb(n, 2 * VIS_DIM), y=zb(n, H), out=zb(n, H), dy_all=zb(n, H), dy=zb(n, H), dfeat=zb(n, VIS_DIM))
         from .visual_linguistic_bert import lru_get       # (R follows each batch's largest box count: keep the recent shapes only)
         return lru_get(self._states, (B, R), make)

@@ -17,6 +17,10 @@ extern "C" const char* vlb_last_error(void) { return g_err; }
 
 extern "C" int vlb_version(void) { return 100; }  // 0.1.0
 
+// 16-bit storage type this build of the library computes in (vlb_common.h): 0 = bfloat16 (libvlbert_hip.so), 1 = IEEE fp16
+// (libvlbert_hip_f16.so, -DVLB_ACT_F16).  Same entry points, same layouts; the host allocates its tensors accordingly.
+extern "C" int vlb_act_dtype(void) { return VLB_ACT_IS_F16; }
+
 // Fills name (<= cap bytes) with the device's gcnArchName; returns the number of compute units,
 // or a negative code.  Used by the host to fail loudly when not running on gfx950.
 extern "C" int vlb_device_info(int device, char* name, int cap) {

@@ -153,7 +153,7 @@ __global__ __launch_bounds__(ATT_THREADS, NU <= 4 ? 4 : 2) void attn_fwd_kernel(
       if (u < U) {
 #pragma unroll
         for (int ds = 0; ds < 2; ++ds)
-          sc[u][hf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_perm(sK, u, hf, c, ds * 4 + g), qf[ds], sc[u][hf], 0, 0, 0);
+          sc[u][hf] = VLB_MFMA_16x16x32(frag_perm(sK, u, hf, c, ds * 4 + g), qf[ds], sc[u][hf], 0, 0, 0);
       }
     }
 
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(ATT_THREADS, NU <= 4 ? 4 : 2) void attn_fwd_kernel(
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < NU; ++u)
-      if (u < U) o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(sV, u, dt * 16, lane), pf[u], o, 0, 0, 0);
+      if (u < U) o = VLB_MFMA_16x16x32(frag_tr(sV, u, dt * 16, lane), pf[u], o, 0, 0, 0);
     if (q < S) *(uint2*)(orow + dt * 16) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));   // rows d = dt*16 + 4g + r
   }
   }   // qs
@@ -300,8 +300,8 @@ __global__ __launch_bounds__(ATT_THREADS, NU <= 4 ? 4 : 2) void attn_bwd_kernel(
           f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int ds = 0; ds < 2; ++ds) {
-            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_perm(sQ, v, hf, c, ds * 4 + g), kf[ds], s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_perm(sdO, v, hf, c, ds * 4 + g), vf[ds], dp, 0, 0, 0);
+            s = VLB_MFMA_16x16x32(frag_perm(sQ, v, hf, c, ds * 4 + g), kf[ds], s, 0, 0, 0);
+            dp = VLB_MFMA_16x16x32(frag_perm(sdO, v, hf, c, ds * 4 + g), vf[ds], dp, 0, 0, 0);
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -320,8 +320,8 @@ __global__ __launch_bounds__(ATT_THREADS, NU <= 4 ? 4 : 2) void attn_bwd_kernel(
         const bf16x8 pd = pack8(pv), dsf = pack8(dsv);   // operands: col = key c, k = query 32v + 8g + j
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-          dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(sdO, v, dt * 16, lane), pd, dv[dt], 0, 0, 0);
-          dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(sQ, v, dt * 16, lane), dsf, dk[dt], 0, 0, 0);
+          dv[dt] = VLB_MFMA_16x16x32(frag_tr(sdO, v, dt * 16, lane), pd, dv[dt], 0, 0, 0);
+          dk[dt] = VLB_MFMA_16x16x32(frag_tr(sQ, v, dt * 16, lane), dsf, dk[dt], 0, 0, 0);
         }
       }
     }
@@ -360,8 +360,8 @@ __global__ __launch_bounds__(ATT_THREADS, NU <= 4 ? 4 : 2) void attn_bwd_kernel(
           f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int ds = 0; ds < 2; ++ds) {
-            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_perm(sK, u, hf, c, ds * 4 + g), qf[ds], s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_perm(sV, u, hf, c, ds * 4 + g), dof[ds], dp, 0, 0, 0);
+            s = VLB_MFMA_16x16x32(frag_perm(sK, u, hf, c, ds * 4 + g), qf[ds], s, 0, 0, 0);
+            dp = VLB_MFMA_16x16x32(frag_perm(sV, u, hf, c, ds * 4 + g), dof[ds], dp, 0, 0, 0);
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(ATT_THREADS, NU <= 4 ? 4 : 2) void attn_bwd_kernel(
         const bf16x8 dsf = pack8(dsv);
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
-          dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(sK, u, dt * 16, lane), dsf, dq[dt], 0, 0, 0);
+          dq[dt] = VLB_MFMA_16x16x32(frag_tr(sK, u, dt * 16, lane), dsf, dq[dt], 0, 0, 0);
       }
     }
     if (pos_ok) {
@@ -499,8 +499,8 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd2_kernel(const AttnPar
           f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int ds = 0; ds < 2; ++ds) {
-            sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_perm(sK, u, hf, c, ds * 4 + g), qf[ds], sc, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_perm(sV, u, hf, c, ds * 4 + g), dof[ds], dp, 0, 0, 0);
+            sc = VLB_MFMA_16x16x32(frag_perm(sK, u, hf, c, ds * 4 + g), qf[ds], sc, 0, 0, 0);
+            dp = VLB_MFMA_16x16x32(frag_perm(sV, u, hf, c, ds * 4 + g), dof[ds], dp, 0, 0, 0);
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd2_kernel(const AttnPar
         dsf[u] = pack8(dsv);
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
-          dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(sK, u, dt * 16, lane), dsf[u], dq[dt], 0, 0, 0);
+          dq[dt] = VLB_MFMA_16x16x32(frag_tr(sK, u, dt * 16, lane), dsf[u], dq[dt], 0, 0, 0);
       }
     }
     if (pos_ok) {
@@ -552,7 +552,7 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd2_kernel(const AttnPar
         const bf16x8 pt = frag_pt(sT, v, w16, lane);
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
-          dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(sdO, v, dt * 16, lane), pt, dv[dt], 0, 0, 0);
+          dv[dt] = VLB_MFMA_16x16x32(frag_tr(sdO, v, dt * 16, lane), pt, dv[dt], 0, 0, 0);
       }
     }
   }
@@ -570,7 +570,7 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd2_kernel(const AttnPar
         const bf16x8 st = frag_pt(sT, v, w16, lane);
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
-          dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(sQ, v, dt * 16, lane), st, dk[dt], 0, 0, 0);
+          dk[dt] = VLB_MFMA_16x16x32(frag_tr(sQ, v, dt * 16, lane), st, dk[dt], 0, 0, 0);
       }
     }
     if (pos_ok) {

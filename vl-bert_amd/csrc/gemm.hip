@@ -415,7 +415,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN >= 8) ? 4 : 2) void gemm
         for (int i = 0; i < FM; ++i)
 #pragma unroll
           for (int j = 0; j < FN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+            acc[i][j] = VLB_MFMA_16x16x32(bfr[j], af[i], acc[i][j], 0, 0, 0);
       }
       if (kt + 1 < ntk) {
         __syncthreads();  // next stage landed (hipcc drains the LDS-DMA queue here) + WAR on the buffer just read
@@ -590,7 +590,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_nt_ring_kernel(const G
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[0][j], af[0][i], acc[i][j], 0, 0, 0);
+          acc[i][j] = VLB_MFMA_16x16x32(bfr[0][j], af[0][i], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_waitcnt(0xC07F);                         // lgkmcnt(0)
       __builtin_amdgcn_sched_barrier(0);
@@ -598,7 +598,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_nt_ring_kernel(const G
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[1][j], af[1][i], acc[i][j], 0, 0, 0);
+          acc[i][j] = VLB_MFMA_16x16x32(bfr[1][j], af[1][i], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       ++g;
       slot_c = (slot_c + 1 == NS) ? 0 : slot_c + 1;
@@ -746,14 +746,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256_kernel(const GemmParams p)
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = VLB_MFMA_16x16x32(bfr[j], af[i], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[4]), "+v"(af[5]), "+v"(af[6]), "+v"(af[7]));
 #pragma unroll
       for (int i = 4; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = VLB_MFMA_16x16x32(bfr[j], af[i], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
     // ---- epilogue (+bias, bf16): lane holds C[m][n..n+3], m = .. + (lane&15) + 16 i, n = .. + 4 (lane>>4) + 16 j
@@ -906,7 +906,7 @@ __device__ __forceinline__ void tn_mfma_step(s16x4 (&alo)[4], s16x4 (&ahi)[4], s
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < FN; ++j)
-      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+      acc[i][j] = VLB_MFMA_16x16x32(bfr[j], af[i], acc[i][j], 0, 0, 0);
 }
 
 // one stage = 64 reduction rows = 2 k-steps; va / vb: per-fragment LDS byte addresses inside the stage's A image

@@ -454,7 +454,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(const GemmParams p) 
       for (int i = 0; i < FMH; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[HA * FMH + i][HB * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[j][ks], af[i][ks], acc[HA * FMH + i][HB * 2 + j], 0, 0, 0);
+          acc[HA * FMH + i][HB * 2 + j] = VLB_MFMA_16x16x32(bq[j][ks], af[i][ks], acc[HA * FMH + i][HB * 2 + j], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
   };

@@ -23,7 +23,12 @@
 namespace {
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) vlb_h16 bf16x2_t;
+#ifdef VLB_ACT_F16
+#define VLB_FDOT2 __builtin_amdgcn_fdot2
+#else
+#define VLB_FDOT2 __builtin_amdgcn_fdot2_f32_bf16
+#endif
 
 template <int OFF>
 __device__ __forceinline__ void tn8_tr_read(s16x4& dst, uint32_t vaddr) {
@@ -234,22 +239,22 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(const Tn8Group grp) {
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[HA * 4 + i][HB_ * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tn8_frag(blo[j][ks], bhi[j][ks]), tn8_frag(alo[i][ks], ahi[i][ks]),
+          acc[HA * 4 + i][HB_ * 2 + j] = VLB_MFMA_16x16x32(tn8_frag(blo[j][ks], bhi[j][ks]), tn8_frag(alo[i][ks], ahi[i][ks]),
                                                                                 acc[HA * 4 + i][HB_ * 2 + j], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
     if constexpr (CS) {
       if (do_colsum) {      // wave-uniform; 32 v_dot2c behind the MFMAs of this quadrant
-        const bf16x2_t one = {(__bf16)1.0f, (__bf16)1.0f};
+        const bf16x2_t one = {(vlb_h16)1.0f, (vlb_h16)1.0f};
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks) {
             const uint2 l = __builtin_bit_cast(uint2, alo[i][ks]), h = __builtin_bit_cast(uint2, ahi[i][ks]);
             float s = csum[HA * 4 + i];
-            s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, l.x), one, s, false);
-            s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, l.y), one, s, false);
-            s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, h.x), one, s, false);
-            s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, h.y), one, s, false);
+            s = VLB_FDOT2(__builtin_bit_cast(bf16x2_t, l.x), one, s, false);
+            s = VLB_FDOT2(__builtin_bit_cast(bf16x2_t, l.y), one, s, false);
+            s = VLB_FDOT2(__builtin_bit_cast(bf16x2_t, h.x), one, s, false);
+            s = VLB_FDOT2(__builtin_bit_cast(bf16x2_t, h.y), one, s, false);
             csum[HA * 4 + i] = s;
           }
       }

@@ -6,8 +6,23 @@
 
 #include "../../include/vlbert_hip.h"  // every extern "C" definition is checked against the public prototypes
 
-typedef uint16_t bf16_t;  // raw bfloat16 bits in memory
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+// The 16-bit activation / working-weight / gradient type is a BUILD-TIME choice of the whole library:
+//   default            bfloat16  -> libvlbert_hip.so      (BASELINE.json's headline precision; no loss scaling needed)
+//   -DVLB_ACT_F16      IEEE fp16 -> libvlbert_hip_f16.so  (the reference's own mixed precision: Apex O2 fp16 + a static loss scale,
+//                      pretrain/function/train.py:345-352; 3 more mantissa bits on every GEMM operand, same MFMA rate on gfx950)
+// Every kernel converts through the helpers below and issues its matrix instruction through VLB_MFMA_16x16x32, so the sources
+// are shared; names keep the "bf16" of the default build (bf16_t = "the 16-bit storage type").
+typedef uint16_t bf16_t;  // raw 16-bit element in memory (bfloat16, or IEEE fp16 in the VLB_ACT_F16 build)
+#ifdef VLB_ACT_F16
+typedef _Float16 vlb_h16;
+#define VLB_MFMA_16x16x32 __builtin_amdgcn_mfma_f32_16x16x32_f16
+#define VLB_ACT_IS_F16 1
+#else
+typedef __bf16 vlb_h16;
+#define VLB_MFMA_16x16x32 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#define VLB_ACT_IS_F16 0
+#endif
+typedef __attribute__((ext_vector_type(8))) vlb_h16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 #define VLB_WAVE 64
@@ -34,7 +49,18 @@ void vlb_set_error(const char* fmt, ...);
     }                                                                       \
   } while (0)
 
-// ---- bf16 <-> f32 ----
+// ---- 16-bit storage type <-> f32 ----
+#ifdef VLB_ACT_F16
+__device__ __forceinline__ float bf2f(bf16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (_Float16)f); }   // RNE
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+  typedef __attribute__((ext_vector_type(2))) _Float16 h2_t;
+  const h2_t v = {(_Float16)lo, (_Float16)hi};                                                        // v_cvt_pk / two v_cvt_f16_f32
+  return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float bflo(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xffffu)); }
+__device__ __forceinline__ float bfhi(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16)); }
+#else
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 __device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }  // RNE (v_cvt_pk_bf16_f32)
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
@@ -42,6 +68,7 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
 }
 __device__ __forceinline__ float bflo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bfhi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+#endif
 
 // ---- fp16 (IEEE half) <-> f32: the pre-LayerNorm sums of the encoder (the residual stream) are kept in fp16 -- 3 more mantissa
 // bits than bf16 at the same 2 bytes; their magnitudes are O(1..10), far inside the fp16 range (DESIGN.md "precision") ----

@@ -24,7 +24,6 @@ import torch
 
 from . import ops
 
-BF16 = torch.bfloat16
 F32 = torch.float32
 VIS_DIM = 2048            # hard-coded in the reference (common/fast_rcnn.py:107, resnet_vlbert_for_pretraining.py:25)
 TAG_EMBED, TAG_DOWNSAMPLE = 1000, 1001
@@ -145,7 +144,7 @@ class FlatParams:
         self.grad = torch.zeros(off, dtype=F32, device=device)
         self.m = torch.zeros(off, dtype=F32, device=device)
         self.v = torch.zeros(off, dtype=F32, device=device)
-        self.w16 = torch.zeros(off, dtype=BF16, device=device)
+        self.w16 = torch.zeros(off, dtype=ops.BF16, device=device)
 
     def view(self, buf, name, shape=None, span=1):
         """View of `name` in `buf`; span>1 extends over the following adjacent tensors."""
@@ -165,7 +164,7 @@ class PretrainEngine:
     def __init__(self, cfg, B, T, R, device="cuda:0", train=True, lr=1e-4, weight_decay=1e-4, max_grad_norm=10.0,
                  betas=(0.9, 0.999), eps=1e-6, seed=1234, grad_accum=1, process_group=None, keep_logits=False, flat=None,
                  B_aux=0, core=False, core_heads=True, core_sequence=False, lr_schedule=None, warmup_steps=0, t_total=0,
-                 image_size=None, dp_mode="default", dp_wire="default"):
+                 image_size=None, dp_mode="default", dp_wire="default", loss_scale=None):
         cfg.validate()
         if cfg.e2e and (core or image_size is None):
             raise ValueError("e2e needs image_size=(H, W) and a pretraining wrapper (plain or multitask; not the core module mode)")
@@ -179,6 +178,14 @@ class PretrainEngine:
             raise ValueError("triangle schedule needs t_total > warmup_steps")
         self.lr_kind, self.base_lr, self.warmup_steps, self.t_total = kinds[lr_schedule], lr, warmup_steps, t_total
         self.cfg, self.B, self.T, self.R = cfg, B, T, R
+        # Static loss scale (the reference's TRAIN.FP16_LOSS_SCALE, pretrain/function/train.py:345-352): d(loss)/d(logits) leaves the
+        # loss kernels multiplied by it, every 16-bit gradient tensor and the flat fp32 gradient carry it, and the optimizer's
+        # grad_scale divides it out (clip norm included).  1 in the bf16 build (fp32 exponent range); 4096 by default in the fp16
+        # build (VLB_PRECISION=f16): d(logits) ~ 1/n_valid ~ 4e-4 at batch 256 would sit in fp16's subnormals otherwise.  Engines behind
+        # the autograd mirrors (flat=... / core=True) hand their parameter gradients to torch unscaled, so they default to 1.
+        if loss_scale is None:
+            loss_scale = 4096.0 if (ops.BF16 == torch.float16 and flat is None and not core) else 1.0
+        self.loss_scale = float(loss_scale)
         # multitask: B_aux text-only samples are appended after the B image-caption samples; they have no
         # objects, their text-visual embedding is the learned aux_text_visual_embedding and their MLM loss is
         # accounted separately (resnet_vlbert_for_pretraining_multitask.py:96-290).  T = max(caption, aux) length.
@@ -224,7 +231,7 @@ class PretrainEngine:
             self.in_image = torch.zeros((B, 3, image_size[0], image_size[1]), dtype=F32, device=d)
 
         def zb(*s):
-            return torch.zeros(s, dtype=BF16, device=d)
+            return torch.zeros(s, dtype=ops.BF16, device=d)
 
         def zf(*s):
             return torch.zeros(s, dtype=F32, device=d)
@@ -302,7 +309,7 @@ class PretrainEngine:
         # ~6e-3 (relative Frobenius; 5e-3 of it is the bf16 rounding of the weights).  VLB_RESIDUAL_STREAM=bf16: the old behaviour.
         import os as _os0
         self.hp_res = _os0.environ.get("VLB_RESIDUAL_STREAM", "f16ln") != "bf16"
-        zdt = torch.float16 if self.hp_res else BF16
+        zdt = torch.float16 if self.hp_res else ops.BF16
         zz = lambda *s: torch.zeros(s, dtype=zdt, device=d)
         self.Z1, self.ST1, self.Y1 = [zz(M, H) for _ in range(L)], [zf(M, 2) for _ in range(L)], [zbm(H) for _ in range(L)]
         self.U, self.G = [zb(M, I) for _ in range(L)], [zbm(I) for _ in range(L)]
@@ -407,7 +414,7 @@ class PretrainEngine:
                 # this rank's slice of every bucket: clip-norm partial + AdamW run on those only, one launch each (ops.ShardRanges);
                 # wshard = the compact bf16 image of the updated slices the weight all-gather distributes (parallel.py)
                 self.shard_tbl = ops.ShardRanges(self.buckets.owned_rows(), d)
-                self.wshard = torch.zeros(self.P.numel // world, dtype=BF16, device=d)
+                self.wshard = torch.zeros(self.P.numel // world, dtype=ops.BF16, device=d)
 
     # ------------------------------------------------------------------------------------------
     # parameters
@@ -556,7 +563,7 @@ class PretrainEngine:
             self._front_pretrain_fwd(p_h, p_ds)
         self._encoder_heads_fwd(p_h, p_a)
         if not self.core:
-            self._losses_fwd_bwd(gscale, True)
+            self._losses_fwd_bwd(gscale * self.loss_scale, True)
 
     def _front_core_fwd(self, p_h):
         """VisualLinguisticBert.embedding (common/visual_linguistic_bert.py:173-241) on caller-provided embeddings."""
@@ -1095,7 +1102,7 @@ class PretrainEngine:
             self.adam[0:1].fill_(lr)
         if self.lr_kind is not None:
             ops.lr_schedule_step(self.adam, self.lr_kind, self.base_lr, self.warmup_steps, self.t_total)
-        scale = self.buckets.grad_scale if self.buckets is not None else 1.0
+        scale = (self.buckets.grad_scale if self.buckets is not None else 1.0) / self.loss_scale
         self._check_mlm_overflow_now_and_then()
         if self.buckets is not None and self.buckets.pending:
             self.buckets.wait()
@@ -1190,6 +1197,17 @@ class PretrainEngine:
             self.buckets.wait()
         self.optimizer_step(lr)
 
+    def make_step_graph(self, lr=None):
+        """train_step() captured as hipGraph SEGMENTS -> a callable that replays one optimizer step.  A captured graph cannot contain
+        the RCCL calls of the data-parallel exchange (work handles, the communicator's own stream), so with more than one rank the
+        step is cut at every collective: [graph] bucket launch [graph] ... wait [graph] norm all-reduce [graph] weight gather, and in
+        the forward at every per-bucket wait of the sharded optimizer's weight gather -- ~2 x (buckets + 2) graph launches + as many
+        collective calls per step instead of ~350 kernel launches from Python (host side ~5 ms -> ~1 ms; at 32 samples per GPU the
+        device step is 5-6 ms, so the eager launch loop is the bound there).  One rank: a single graph.
+        Call it in steady state (after at least one eager train_step on this engine); the batch is read from the static input
+        buffers (set_batch between replays is fine), lr / step count / dropout seed live on the device."""
+        return _SegmentedStep(self, lr)
+
     # ------------------------------------------------------------------------------------------
     # results (host side, sync) -- used by tests / API parity, not by the timed loop
     # ------------------------------------------------------------------------------------------
@@ -1210,10 +1228,12 @@ class PretrainEngine:
         return out
 
     def grads(self):
-        return OrderedDict((k, v.detach().clone()) for k, v in self.g32.items())
+        """Parameter gradients of the local batch (the loss scale divided out)."""
+        inv = 1.0 / self.loss_scale
+        return OrderedDict((k, v.detach().clone() * inv if inv != 1.0 else v.detach().clone()) for k, v in self.g32.items())
 
     def grad_norm(self):
-        return float(self.P.grad.double().norm())
+        return float(self.P.grad.double().norm()) / self.loss_scale
 
     def init_random(self, seed=0, visual_ln_init=0.0):
         """Reference initialisation statistics on the device (BaseModel.init_weights,
@@ -1236,3 +1256,76 @@ class PretrainEngine:
             else:
                 t.normal_(0.0, 0.02, generator=g)
         self._weights_dirty = True
+
+
+class _SegmentedStep:
+    """Capture of PretrainEngine.train_step as alternating [hipGraph segment] / [host call] items (PretrainEngine.make_step_graph)."""
+
+    class _Recorder:
+        """Stands in for engine.buckets during capture: the calls that start or wait for a collective END the current segment, are
+        recorded (not executed: nothing runs during capture) and a new segment begins; everything else is delegated."""
+        BREAKS = ("on_done", "wait", "all_reduce_scalar", "gather_params", "wait_params", "gather_master")
+
+        def __init__(self, real, owner):
+            self._real, self._owner = real, owner
+
+        def __getattr__(self, name):
+            attr = getattr(self._real, name)
+            if name not in self.BREAKS:
+                return attr
+            owner = self._owner
+
+            def recorded(*a, **kw):
+                if name == "wait_params":       # only where a wait can block: gathers pending, and an encoder layer that opens a bucket
+                    if not owner.eng._gather_pending or (isinstance(a[0], int) and self._real.layer_key[a[0]] != a[0]):
+                        return None
+                if name == "on_done" and not self._real.will_launch(a[0]):
+                    return None
+                owner.cut(lambda: attr(*a, **kw))
+            recorded.__self__ = self             # (engine.backward looks up the hook owner's will_launch predicate)
+            return recorded
+
+    def __init__(self, eng, lr):
+        if not eng.dev.type == "cuda":
+            raise RuntimeError("make_step_graph needs a GPU engine")
+        self.eng, self.items = eng, []
+        self.pool = torch.cuda.graph_pool_handle()
+        self.stream = torch.cuda.Stream(device=eng.dev)
+        self._g = None
+        torch.cuda.synchronize()
+        real = eng.buckets
+        if real is not None:
+            if real.pending or real.launched:
+                raise RuntimeError("make_step_graph: a data-parallel exchange is in flight")
+            eng.buckets = self._Recorder(real, self)
+        try:
+            self._begin()
+            eng.train_step(lr)
+            self._end()
+        finally:
+            eng.buckets = real
+        torch.cuda.synchronize()
+        self.n_graphs = sum(1 for k, _ in self.items if k == "graph")
+        self.n_calls = len(self.items) - self.n_graphs
+
+    def _begin(self):
+        self._g = torch.cuda.CUDAGraph()
+        self._ctx = torch.cuda.graph(self._g, pool=self.pool, stream=self.stream)
+        self._ctx.__enter__()
+
+    def _end(self):
+        self._ctx.__exit__(None, None, None)
+        self.items.append(("graph", self._g))
+        self._g = None
+
+    def cut(self, fn):
+        self._end()
+        self.items.append(("call", fn))
+        self._begin()
+
+    def __call__(self):
+        for kind, x in self.items:
+            if kind == "graph":
+                x.replay()
+            else:
+                x()

@@ -8,7 +8,7 @@ import torch
 
 from . import _lib
 
-BF16 = torch.bfloat16
+BF16 = _lib.act_torch_dtype()      # the library's 16-bit type: torch.bfloat16, or torch.float16 for the VLB_PRECISION=f16 build (_lib.py)
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_DGELU, ACT_GELU_D, ACT_MULAUX, ACT_TANH = 0, 1, 2, 3, 4, 5, 6
 OUT_BF16, OUT_F32, OUT_F32_ATOMIC = 0, 1, 2
 

@@ -43,17 +43,23 @@ import os
 import torch
 import torch.distributed as dist
 
-_WIRE = {"bf16": torch.bfloat16, "fp32": None, "f32": None}
+def _wire16():
+    """The 16-bit wire type = the library's 16-bit type (bfloat16; IEEE fp16 in the VLB_PRECISION=f16 build, whose cast kernel emits fp16)."""
+    from . import _lib
+    return _lib.act_torch_dtype()
+
+
+_WIRE = {"bf16": "16", "f16": "16", "fp16": "16", "16": "16", "fp32": None, "f32": None}
 BF16_WIRE_MAX_WORLD = 8      # validated bound of the bf16 running sum (tests/test_parallel_cpu.py::test_bf16_wire_error_world8)
 
 
 def default_wire_dtype(world=1):
     v = os.environ.get("VLB_DP_WIRE", "").lower()
     if not v:
-        return torch.bfloat16 if world <= BF16_WIRE_MAX_WORLD else None
+        return _wire16() if world <= BF16_WIRE_MAX_WORLD else None
     if v not in _WIRE:
-        raise ValueError("VLB_DP_WIRE must be bf16 or fp32 (got %r)" % v)
-    return _WIRE[v]
+        raise ValueError("VLB_DP_WIRE must be bf16 (the library's 16-bit type) or fp32 (got %r)" % v)
+    return _wire16() if _WIRE[v] else None
 
 
 def default_mode():

@@ -49,7 +49,7 @@ def run_e2e():
     dilated layer4 head on 2 images of 96x128): forward features + one backward, against the fixture / the vision oracle."""
     import numpy as np
     from oracle import vision_oracle as VO         # test infrastructure: the checker
-    from . import vision
+    from . import ops, vision
     z = np.load(os.path.join(ROOT, "tests", "golden", "vision", "vision_small.npz"), allow_pickle=False)
     nl = int(z["num_layers"])
     P = VO.init_vision_params(int(z["seed"]), nl)
@@ -61,7 +61,7 @@ def run_e2e():
     boxes[:, :, :4] = boxes4.cuda()
     vs.forward(img.cuda(), boxes)
     vs.zero_grad()
-    vs.backward(torch.from_numpy(z["Wr"]).view(N * R, -1).to(torch.bfloat16).cuda(), boxes)
+    vs.backward(torch.from_numpy(z["Wr"]).view(N * R, -1).to(ops.BF16).cuda(), boxes)
     torch.cuda.synchronize()
     raw = torch.from_numpy(z["obj_reps_raw"])
     err = float((boxes[:, :, 4:].cpu() - raw).abs().max()) / float(raw.abs().max())

@@ -26,7 +26,7 @@ from ... import ops
 from ...common.fast_rcnn import FastRCNN
 from ...common.visual_linguistic_bert import VisualLinguisticBert
 
-BF16, F32 = torch.bfloat16, torch.float32
+F32 = torch.float32
 CLS, SEP = 101, 102          # ids of '[CLS]', '[SEP]' in the BERT vocabularies (tokenizer lookups in the reference)
 _TAG_REG = 3001
 NUM_OBJ_CLASSES = 81         # COCO detector classes of the VCR annotations (:26,38)
@@ -163,7 +163,7 @@ class ResNetVLBERT(nn.Module):
             reg.add_module("0", tr)
             reg.add_module("2", lin(NUM_OBJ_CLASSES, H))
             self.cnn_loss_reg = reg
-            zb = lambda *s: torch.zeros(s, dtype=BF16, device=dev)
+            zb = lambda *s: torch.zeros(s, dtype=ops.BF16, device=dev)
             self.Cp = _ru(NUM_OBJ_CLASSES, 64)
             self._rw1, self._rw1T = zb(H, H), zb(H, H)
             self._rw2, self._rw2T = zb(NUM_OBJ_CLASSES, H), zb(H, self.Cp)
@@ -227,7 +227,7 @@ class ResNetVLBERT(nn.Module):
     def _reg_state(self, n, dev):
         cap = _ru(n, 64)
         if cap not in self._states:
-            zb = lambda *s: torch.zeros(s, dtype=BF16, device=dev)
+            zb = lambda *s: torch.zeros(s, dtype=ops.BF16, device=dev)
             H, Cp = self.H, self.Cp
             self._states[cap] = dict(x0=zb(cap, H), u=zb(cap, H), du_act=zb(cap, H), x1=zb(cap, H), logits=zb(cap, Cp),
                                      logits_copy=zb(cap, Cp), dx1=zb(cap, H), dh=zb(cap, H), dpre=zb(cap, H), dx0=zb(cap, H),

@@ -30,7 +30,7 @@ import torch
 
 from . import ops
 
-BF16, F32 = torch.bfloat16, torch.float32
+F32 = torch.float32
 MODEL_LAYERS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}    # resnet.py model_layers
 PREFIX = "image_feature_extractor."
 VIS_DIM = 2048
@@ -95,13 +95,13 @@ class VisionStack:
         self.num_layers, self.frozen_stages = num_layers, tuple(frozen_stages)
         self.pooled, self.scale, self.sr = pooled, spatial_scale, sampling_ratio
         d = self.dev
-        zb = lambda *s: torch.zeros(s, dtype=BF16, device=d)
+        zb = lambda *s: torch.zeros(s, dtype=ops.BF16, device=d)
         zf = lambda *s: torch.zeros(s, dtype=F32, device=d)
         self.blocks = block_table(num_layers, True, c5_dilated)
         # 3x3 convolutions: implicit GEMM (gather in the GEMM's LDS-DMA address generator) for forward and data gradient; the
         # im2col image is only materialised in backward, for the TN weight gradient.  VLB_CONV_IMPLICIT=0: explicit im2col + GEMM.
         self.implicit = os.environ.get("VLB_CONV_IMPLICIT", "1") != "0"
-        self.zero16 = torch.zeros(64, dtype=BF16, device=d)
+        self.zero16 = torch.zeros(64, dtype=ops.BF16, device=d)
         # Weight gradients run on a second stream (they only feed the optimizer; the dgrad chain is the critical path and these
         # GEMMs are too small to fill 256 CUs one at a time).  Hazards are tracked per buffer: a wgrad starts after the event
         # recorded behind its producers, and whoever overwrites one of its inputs first waits for the event recorded behind it

@@ -17,7 +17,7 @@ from ... import ops
 from ...common.fast_rcnn import FastRCNN
 from ...common.visual_linguistic_bert import VisualLinguisticBert
 
-BF16, F32 = torch.bfloat16, torch.float32
+F32 = torch.float32
 CLS, SEP, MASK = 101, 102, 103          # ids of '[CLS]', '[SEP]', '[MASK]' in the BERT vocabularies (tokenizer lookups in the reference)
 _TAG0, _TAG1 = 2001, 2002
 
@@ -148,7 +148,7 @@ class ResNetVLBERT(nn.Module):
             mlp.add_module("2", lin(self.answers, H))
         self.final_mlp = mlp
         self.hcp = _ru(self.hc, 64)
-        zb = lambda *s: torch.zeros(s, dtype=BF16, device=dev)
+        zb = lambda *s: torch.zeros(s, dtype=ops.BF16, device=dev)
         self._w1, self._w1T = zb(self.hc, H), zb(H, self.hcp)          # first Linear and its transpose (K padded to 64)
         self._w2, self._w2T = zb(self.answers, self.hcp), zb(self.hc, self.Ap)
         self._seed = torch.tensor([ops.rank_seed(30011)], dtype=torch.int32, device=dev)
@@ -186,7 +186,7 @@ class ResNetVLBERT(nn.Module):
             return
         w1, w2 = (params[0], params[2]) if self.classifier == "2fc" else (params[0], params[4])
         ops.cast_f32_bf16(w1.detach().contiguous(), self._w1)
-        tmp = torch.zeros((self.answers, self.hc), dtype=BF16, device=self.device_)
+        tmp = torch.zeros((self.answers, self.hc), dtype=ops.BF16, device=self.device_)
         ops.cast_f32_bf16(w2.detach().contiguous(), tmp)
         self._w2.zero_()
         self._w2[:, :self.hc].copy_(tmp)
@@ -196,7 +196,7 @@ class ResNetVLBERT(nn.Module):
 
     def _head_state(self, B, dev):
         if B not in self._states:
-            zb = lambda *s: torch.zeros(s, dtype=BF16, device=dev)
+            zb = lambda *s: torch.zeros(s, dtype=ops.BF16, device=dev)
             H, hcp, Ap = self.H, self.hcp, self.Ap
             self._states[B] = dict(x_in=zb(B, H), x0=zb(B, H), u=zb(B, hcp), x1=zb(B, hcp), h=zb(B, hcp), du_act=zb(B, hcp),
                                    logits=zb(B, Ap), logits_copy=zb(B, Ap), dx1=zb(B, hcp), du=zb(B, hcp), dln=zb(B, hcp), dpre=zb(B, hcp),
