@@ -436,12 +436,16 @@ def run_vcr_case(name="vcr_small", num_layers=50):
     print("%s: restatement vs reference |d logits|max %.3e, loss %.6f vs %.6f, cnn reg %.6f vs %.6f" %
           (name, err, float(loss2), float(loss), float(out2["cnn_regularization_loss"]), float(outputs["cnn_regularization_loss"])))
     assert err < 1e-4 and abs(float(loss2) - float(loss)) < 1e-5
-    worst = 0.0
+    # per tensor, against max(|tensor|, 1e-6 of the global norm): tensors whose gradient is zero by construction (the key bias: softmax
+    # is invariant to it) hold rounding noise on both sides -- the reference side now runs the reference's COMPILED ROIAlign forward,
+    # whose last-bit differences from the restatement re-draw that noise
+    total = float(torch.sqrt(sum((g_.double() ** 2).sum() for g_ in ref_grads.values())))
+    worst = (0.0, "")
     for k, gref in ref_grads.items():
         if k in leaves:
-            worst = max(worst, float((leaves[k].grad - gref).norm() / max(float(gref.norm()), 1e-12)))
-    print("%s: restatement gradients, worst rel-fro vs reference %.3e" % (name, worst))
-    assert worst < 1e-3
+            worst = max(worst, (float((leaves[k].grad - gref).norm() / max(float(gref.norm()), 1e-6 * total)), k))
+    print("%s: restatement gradients, worst rel-fro vs reference %.3e (%s)" % (name, worst[0], worst[1]))
+    assert worst[0] < 1e-3
     keys = sorted(ref_grads)
     path = os.path.join(ROOT, "tests", "golden", "vcr", name + ".npz")
     os.makedirs(os.path.dirname(path), exist_ok=True)

@@ -68,18 +68,27 @@ def install_stubs():
 
 
 def install_roi_align_oracle():
-    """Route the reference's `_ROIAlign` autograd function (common/lib/roi_pooling/roi_align.py:11-44) to
-    oracle/roi_align_oracle.py: the reference's compiled op has no CPU backward (ROIAlign.h:44) and is not built here.
-    Used only to drive the reference's own FastRCNN e2e module for the vision golden fixture."""
+    """Give the reference's `_ROIAlign` autograd function (common/lib/roi_pooling/roi_align.py:11-44) a C_ROIPooling to call when its
+    own FastRCNN e2e module is driven for the vision / VCR golden fixtures.  FORWARD: the reference's OWN compiled CPU kernel
+    (oracle/_ref/libroi_align_ref.so = cpu/ROIAlign_cpu.cpp built unmodified by oracle/build_ref.sh) -- the fixture's forward
+    arithmetic is the reference binary's, not a restatement.  BACKWARD: the reference has no CPU backward (ROIAlign.h:44 raises), so
+    the restatement of its CUDA backward (oracle/roi_align_oracle.py, pinned to the forward as its exact adjoint) stays."""
     import numpy as np
     import torch
+    from . import ref_roi_align as REF
     from . import roi_align_oracle as RA
     install_stubs()
     m = sys.modules["common.lib.roi_pooling.C_ROIPooling"]
+    if not REF.available():
+        raise RuntimeError("oracle/_ref/libroi_align_ref.so is missing: run oracle/build_ref.sh (the fixtures' ROIAlign forward is the "
+                           "reference's compiled kernel)")
 
     def fwd(inp, rois, scale, ph, pw, sr):
-        return torch.from_numpy(np.ascontiguousarray(RA.roi_align_forward(inp.detach().numpy().astype(np.float32),
-                                                                          rois.numpy().astype(np.float32), scale, ph, pw, sr), dtype=np.float32))
+        if os.environ.get("VLB_FIXTURE_ROI") == "numpy":      # (debug: the restatement instead of the reference binary)
+            return torch.from_numpy(np.ascontiguousarray(RA.roi_align_forward(inp.detach().numpy().astype(np.float32),
+                                                                              rois.numpy().astype(np.float32), scale, ph, pw, sr), dtype=np.float32))
+        return torch.from_numpy(REF.roi_align_forward(inp.detach().numpy().astype(np.float32), rois.numpy().astype(np.float32),
+                                                      float(scale), int(ph), int(pw), int(sr)))
 
     def bwd(grad, rois, scale, ph, pw, b, c, h, w, sr):
         return torch.from_numpy(np.ascontiguousarray(RA.roi_align_backward(grad.contiguous().numpy().astype(np.float32),
