@@ -252,7 +252,7 @@ def bench_vqa(args):
             outputs, loss = net.train_forward(None, boxes, im_info, question, label)
             (loss / accum).backward()
             total = loss.detach()
-        torch.nn.utils.clip_grad_norm_(net.parameters(), 1.0)
+        OPT.clip_grad_norm_(net.parameters(), 1.0, opt)          # fused into the step kernel (device-side norm, no rescale pass)
         opt.step()
         return total
 
@@ -340,7 +340,7 @@ def bench_vcr(args):
             outputs, loss = net.train_forward(image, boxes, masks, question, None, answers, None, label, im_info)
             (loss / accum).backward()
             total = loss.detach()
-        torch.nn.utils.clip_grad_norm_(net.parameters(), 10.0)
+        OPT.clip_grad_norm_(net.parameters(), 10.0, opt)         # fused into the step kernel (device-side norm, no rescale pass)
         opt.step()
         return total
 

@@ -231,9 +231,10 @@ int vlb_soft_ce_fwd_bwd(void* logits, long ld, int rows, int C, const float* tar
 
 /* VQA answer loss (vqa/modules/resnet_vlbert_for_vqa.py:226): binary_cross_entropy_with_logits(logits[rows,A], label) * A =
  * (1/rows) sum of the element losses; logits (bf16, row stride ld, columns >= A zeroed) are overwritten IN PLACE by
- * gscale * d(loss)/d(logits) = gscale * (sigmoid(x) - y) / rows; loss_out is accumulated (+=); logits_copy (optional) keeps the logits. */
-int vlb_bce_logits_fwd_bwd(void* logits, long ld, int rows, int A, const float* label, long ldl, float gscale, float* loss_out,
-                           void* logits_copy, long ldcopy, vlb_stream_t stream);
+ * gscale * d(loss)/d(logits) = gscale * w * (sigmoid(x) - y) / rows; loss_out is accumulated (+=); logits_copy (optional) keeps the logits.
+ * w = pos_weight where y > 0.5, else 1: the element `weight` of the VCR answer loss (vcr/modules/resnet_vlbert_for_vcr.py:333-341; 1 = VQA). */
+int vlb_bce_logits_fwd_bwd(void* logits, long ld, int rows, int A, const float* label, long ldl, float gscale, float pos_weight,
+                           float* loss_out, void* logits_copy, long ldcopy, vlb_stream_t stream);
 /* y[i] = x[i] * keep(seed, tag, i) / (1 - p): elementwise dropout with the library's counter RNG (the classifier dropouts of the
  * VQA head, resnet_vlbert_for_vqa.py:57-77); the same call on the gradient is its backward. */
 int vlb_dropout_bf16(const void* x, void* y, long n, float drop_p, const uint32_t* seed, uint32_t tag, vlb_stream_t stream);

@@ -1,6 +1,7 @@
 """VCR fine-tuning wrapper (BASELINE config 5) on the GPU (-m gpu): the `ResNetVLBERT` mirror of
 vcr/modules/resnet_vlbert_for_vcr.py against the fixture produced by the reference's own module and against oracle/vcr_oracle.py, and
 the fused SGD-momentum step (vcr/function/train.py:124-128) against torch.optim.SGD semantics."""
+import numpy as np
 import pytest
 import torch
 
@@ -157,6 +158,68 @@ def test_sgd_momentum_kernel_matches_torch_sgd(n):
         print("sgd n %d clip %s: max |p - torch| %.3e" % (n, clip, err))
         assert err < 2e-6 * max(1.0, float(ref.detach().abs().max()))
         assert torch.equal(p16.float().cpu(), p.cpu().to(torch.bfloat16).float())
+
+
+@pytest.mark.parametrize("kind", ["sgd", "adamw"])
+def test_fused_clip_grad_norm_matches_torch_clip_then_step(kind):
+    """optim.clip_grad_norm_(params, max_norm, optimizer) -- the trainer's clip (common/trainer.py:139-145) fused into the NEXT step's
+    kernel (device-side norm, coefficient applied as the gradients are read) -- against torch.nn.utils.clip_grad_norm_ followed by the
+    torch statement of the same optimizer, two steps (one clipping, one not), several flat runs; also with an fp16-style loss scale
+    folded out through grad_scale.  The gradients themselves must stay untouched."""
+    OPT = pkg("optim")
+    g0 = torch.Generator().manual_seed(11)
+    shapes = [(300, 64), (64,), (1000,), (17, 5)]
+    for scale in (1.0, 128.0):
+        flat = torch.zeros(sum(int(np.prod(sh)) for sh in shapes) + 64, device=dev())
+        ps, off = [], 0
+        for i, sh in enumerate(shapes):
+            n = int(np.prod(sh))
+            if i == 2:
+                off += 64                                    # a gap: two flat runs
+            q = torch.nn.Parameter(flat[off:off + n].view(sh))
+            q.data.copy_(torch.randn(sh, generator=g0))
+            ps.append(q)
+            off += n
+        gflat = torch.zeros_like(flat)
+        off = 0
+        for i, (q, sh) in enumerate(zip(ps, shapes)):
+            n = int(np.prod(sh))
+            if i == 2:
+                off += 64
+            q.grad = gflat[off:off + n].view(sh)
+            off += n
+        ref = [torch.nn.Parameter(q.detach().cpu().clone()) for q in ps]
+        if kind == "sgd":
+            opt = OPT.FusedSGD(ps, lr=0.05, momentum=0.9, weight_decay=1e-2)
+            ropt = torch.optim.SGD(ref, lr=0.05, momentum=0.9, weight_decay=1e-2)
+        else:
+            opt = OPT.FusedAdamW(ps, lr=1e-2, eps=1e-6, weight_decay=1e-2)
+            m = [torch.zeros_like(r) for r in ref]
+            v = [torch.zeros_like(r) for r in ref]
+        max_norm = 1.0
+        for step, mag in ((1, 3.0), (2, 0.01)):               # step 1 clips (norm ~ 100), step 2 does not
+            grads = [torch.randn(sh, generator=g0) * mag for sh in shapes]
+            for q, g in zip(ps, grads):
+                q.grad.copy_(g * scale)
+            kept = [q.grad.clone() for q in ps]
+            total = OPT.clip_grad_norm_(ps, max_norm, opt, grad_scale=1.0 / scale)
+            for r, g in zip(ref, grads):
+                r.grad = g.clone()
+            tnorm = torch.nn.utils.clip_grad_norm_(ref, max_norm)
+            assert abs(float(total) - float(tnorm)) <= 1e-5 * float(tnorm)
+            opt.step()
+            assert all(torch.equal(q.grad, k) for q, k in zip(ps, kept))           # fused: nothing rescaled in place
+            if kind == "sgd":
+                ropt.step()
+            else:
+                for r, mm, vv in zip(ref, m, v):
+                    O.adamw_step(r.data, r.grad, mm, vv, step, 1e-2, eps=1e-6, weight_decay=1e-2)
+            torch.cuda.synchronize()
+            err = max(float((q.detach().cpu() - r.detach()).abs().max()) for q, r in zip(ps, ref))
+            print("fused clip + %s, loss scale %g, step %d: norm %.4f, max |p - torch| %.3e" % (kind, scale, step, float(total), err))
+            assert err < 5e-6
+        opt.step()                                             # a step without a clip call: no stale coefficient
+        assert opt._clip is None
 
 
 def test_fused_sgd_optimizer_on_a_module_mirror():

@@ -408,7 +408,9 @@ def test_vision_stack_matches_reference_golden():
     for k in by_layer:       # the error grows with the number of bf16 Bottlenecks the gradient has crossed (head -> layer2)
         print("   %-22s max rel-fro %.3e" % (k, max(by_layer[k])))
     assert set(n[len("image_feature_extractor."):] for n in got) == set(want_norm)
-    assert np.median(errs) < 6e-2 and worst[0] < 0.15, worst
+    # measured on MI355X (bf16 build): median 3.9e-2, worst 8.1e-2 (layer2.0.conv1: the gradient that crossed the most bf16 Bottlenecks) --
+    # bounds = measured + ~25 %; the global gradient norm is within 2e-3 (asserted by the engine-level e2e tests)
+    assert np.median(errs) < 5e-2 and worst[0] < 0.10, worst
     # VCR call form: object masks inside the RoI head -- forward against the reference fixture, masked-pool backward against the oracle
     segms = torch.from_numpy(z["segms"])
     vs.forward(img.to(dev()), boxes, segms.to(dev()))
@@ -485,7 +487,7 @@ def test_engine_e2e_step_vs_oracle(empty_sample):
     errs, glob, dnorm = _vision_grad_errors(eng, Po, names)
     print("e2e engine: conv weight gradients median rel-fro %.3e worst %.3e (%s); all vision parameters: rel-fro %.3e, grad-norm "
           "difference %.3e" % (float(np.median([e for e, _ in errs])), *max(errs), glob, dnorm))
-    assert np.median([e for e, _ in errs]) < 6e-2 and max(errs)[0] < 0.13      # measured: median 3.0-4.5e-2, worst 6.3-9.0e-2
+    assert np.median([e for e, _ in errs]) < 5.5e-2 and max(errs)[0] < 0.11      # measured: median 3.0-4.5e-2, worst 6.3-9.0e-2 (+ ~20 %)
     assert dnorm < 1e-2, dnorm          # global gradient norm over the vision parameters (what the clip and the step size see)
     assert leaves["object_mask_visual_embedding.weight"].grad is None or float(leaves["object_mask_visual_embedding.weight"].grad.abs().sum()) == 0.0
     assert float(eng.g32["object_mask_visual_embedding.weight"].abs().sum()) == 0.0
@@ -547,7 +549,7 @@ def test_engine_multitask_e2e_step_vs_oracle():
     errs, glob, dnorm = _vision_grad_errors(eng, Po, names)
     print("multitask e2e: conv weight gradients median rel-fro %.3e worst %.3e (%s); all vision parameters: rel-fro %.3e, "
           "grad-norm difference %.3e" % (float(np.median([e for e, _ in errs])), *max(errs), glob, dnorm))
-    assert np.median([e for e, _ in errs]) < 6e-2 and max(errs)[0] < 0.13      # measured: median 3.0-4.5e-2, worst 6.3-9.0e-2
+    assert np.median([e for e, _ in errs]) < 5.5e-2 and max(errs)[0] < 0.11      # measured: median 3.0-4.5e-2, worst 6.3-9.0e-2 (+ ~20 %)
     assert dnorm < 1e-2, dnorm
     for k in ("aux_text_visual_embedding.weight", "image_feature_extractor.obj_downsample.1.weight",
               "vlbert.encoder.layer.0.output.dense.weight", "vlbert.word_embeddings.weight"):

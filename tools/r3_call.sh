@@ -12,6 +12,8 @@ for what in "$@"; do
     dptests) timeout 900 python -m pytest tests/test_dp_gpu.py -m gpu -q 2>&1 | tail -30 > $OUT/dptests.log; tail -6 $OUT/dptests.log ;;
     f16)     timeout 1200 python -m pytest tests/test_f16_build_gpu.py -m gpu -q 2>&1 | tail -30 > $OUT/f16.log; tail -8 $OUT/f16.log; grep -E "Frobenius|passed|failed|FAILED|Error" gpurun_out/f16_suite.log | tail -30 ;;
     t24)     timeout 600 python -m pytest tests/test_engine_gpu.py -m gpu -q -s -k "24_layers" > $OUT/t24.log 2>&1; grep -E "Frobenius|passed|failed|per-layer|grad_norm|rel-fro|Error|assert" $OUT/t24.log | tail -25 ;;
+    vcrtests) timeout 900 python -m pytest tests/test_vcr_gpu.py -m gpu -q -x -s > $OUT/vcrtests.log 2>&1; grep -E "passed|failed|FAILED|Error|fused clip|vcr " $OUT/vcrtests.log | tail -20 ;;
+    vistests) timeout 900 python -m pytest tests/test_vision_gpu.py -m gpu -q -s > $OUT/vistests.log 2>&1; grep -E "passed|failed|FAILED|median|max rel-fro|grad-norm|gradient norm" $OUT/vistests.log | tail -30 ;;
     bench)   python bench.py --no-cpu-baseline > $OUT/bench256.json 2> $OUT/bench256.err; cut -c1-400 $OUT/bench256.json ;;
     small)   for b in 128 64 32; do python bench.py --no-cpu-baseline --global-batch $b --no-phase-times > $OUT/bench$b.json 2> $OUT/bench$b.err; python -c "import json;d=json.load(open('$OUT/bench$b.json'));print($b, d['ms_per_step'], d['roofline']['frac'], d['roofline']['by_op']['host_launch_ms_whole_step'])"; done ;;
     graph)   for b in 256 32; do python bench.py --no-cpu-baseline --global-batch $b --no-phase-times --graph > $OUT/benchg$b.json 2> $OUT/benchg$b.err; python -c "import json;d=json.load(open('$OUT/benchg$b.json'));print('graph',$b, d['ms_per_step'])"; done ;;

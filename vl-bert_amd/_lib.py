@@ -63,7 +63,7 @@ _SIGS = {
     "vlb_soft_ce_fwd_bwd": "pliiplppfppls",
     "vlb_sumsq_f32": "plps",
     "vlb_zero_padded_rows_bf16": "plpliis",
-    "vlb_bce_logits_fwd_bwd": "pliiplfppls",
+    "vlb_bce_logits_fwd_bwd": "pliiplffppls",
     "vlb_dropout_bf16": "pplfpus",
     "vlb_sumsq_f32_det": "plpips",
     "vlb_adamw_step": "ppppplpfs",

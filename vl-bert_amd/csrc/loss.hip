@@ -299,8 +299,8 @@ extern "C" int vlb_soft_ce_fwd_bwd(void* logits, long ld, int rows, int C, const
 // untouched logits are copied out when asked for (label_logits of the reference's outputs dict).  One block per row.
 // ------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void bce_logits_fwd_bwd_kernel(bf16_t* __restrict__ logits, long ld, int A, const float* __restrict__ label,
-                                                                 long ldl, int rows, float gscale, float* __restrict__ loss_out,
-                                                                 bf16_t* __restrict__ logits_copy, long ldcopy) {
+                                                                 long ldl, int rows, float gscale, float pos_weight,
+                                                                 float* __restrict__ loss_out, bf16_t* __restrict__ logits_copy, long ldcopy) {
   __shared__ float sh[4];
   const int row = blockIdx.x;
   bf16_t* x = logits + (long)row * ld;
@@ -312,9 +312,10 @@ __global__ __launch_bounds__(256) void bce_logits_fwd_bwd_kernel(bf16_t* __restr
       const float v = bf2f(x[a]), t = y[a];
       if (logits_copy) logits_copy[(long)row * ldcopy + a] = x[a];
       const float e = __expf(-fabsf(v));
-      acc += fmaxf(v, 0.f) - v * t + log1pf(e);
+      const float w = t > 0.5f ? pos_weight : 1.0f;       // element weight (the `weight=` tensor of vcr/modules/resnet_vlbert_for_vcr.py:336-339)
+      acc += w * (fmaxf(v, 0.f) - v * t + log1pf(e));
       const float sig = v >= 0.f ? 1.0f / (1.0f + e) : e / (1.0f + e);
-      x[a] = f2bf((sig - t) * inv_rows * gscale);
+      x[a] = f2bf(w * (sig - t) * inv_rows * gscale);
     } else {
       x[a] = 0;
       if (logits_copy && a < (int)ldcopy) logits_copy[(long)row * ldcopy + a] = 0;
@@ -324,13 +325,13 @@ __global__ __launch_bounds__(256) void bce_logits_fwd_bwd_kernel(bf16_t* __restr
   if (threadIdx.x == 0) atomicAdd(loss_out, s * inv_rows);
 }
 
-extern "C" int vlb_bce_logits_fwd_bwd(void* logits, long ld, int rows, int A, const float* label, long ldl, float gscale, float* loss_out,
-                                      void* logits_copy, long ldcopy, hipStream_t stream) {
+extern "C" int vlb_bce_logits_fwd_bwd(void* logits, long ld, int rows, int A, const float* label, long ldl, float gscale, float pos_weight,
+                                      float* loss_out, void* logits_copy, long ldcopy, hipStream_t stream) {
   if (rows <= 0) return VLB_OK;
   VLB_CHECK_ARG(logits && label && loss_out && A > 0 && ld >= A && ldl >= A, "vlb_bce_logits_fwd_bwd: bad argument");
   VLB_CHECK_ARG(!logits_copy || ldcopy >= A, "vlb_bce_logits_fwd_bwd: ldcopy too small");
   hipLaunchKernelGGL(bce_logits_fwd_bwd_kernel, dim3(rows), dim3(256), 0, stream, (bf16_t*)logits, ld, A, label, ldl, rows, gscale,
-                     loss_out, (bf16_t*)logits_copy, ldcopy);
+                     pos_weight, loss_out, (bf16_t*)logits_copy, ldcopy);
   VLB_CHECK_LAUNCH("vlb_bce_logits_fwd_bwd");
   return VLB_OK;
 }

@@ -359,11 +359,12 @@ def soft_ce_fwd_bwd(logits, C, target, tsum, counts, loss_out, gscale=1.0, logit
               _p(logits_copy, BF16), _ld(logits_copy), _stream())
 
 
-def bce_logits_fwd_bwd(logits, A, label, loss_out, gscale=1.0, logits_copy=None):
-    """logits bf16 [rows, >=A] <- gscale * (sigmoid(x) - y) / rows in place; loss_out += BCE-with-logits * A (reference convention)."""
+def bce_logits_fwd_bwd(logits, A, label, loss_out, gscale=1.0, logits_copy=None, pos_weight=1.0):
+    """logits bf16 [rows, >=A] <- gscale * w * (sigmoid(x) - y) / rows in place; loss_out += BCE-with-logits * A (reference convention);
+    w = pos_weight on the positive labels (VCR), 1 elsewhere."""
     rows = logits.shape[0]
     _lib.call("vlb_bce_logits_fwd_bwd", _p(logits, BF16), _ld(logits), rows, A, _p(label, torch.float32), _ld(label), float(gscale),
-              _p(loss_out, torch.float32), _p(logits_copy, BF16), _ld(logits_copy), _stream())
+              float(pos_weight), _p(loss_out, torch.float32), _p(logits_copy, BF16), _ld(logits_copy), _stream())
 
 
 def dropout_bf16(x, y, drop_p, seed, tag):

@@ -31,7 +31,23 @@ def _flat_runs(params):
     return runs
 
 
-_FLAT_KEYS = ("flat_m", "flat_v", "flat_buffer", "dev", "hyper")
+_FLAT_KEYS = ("flat_m", "flat_v", "flat_buffer", "dev", "hyper", "hyper_clip")
+
+
+def clip_grad_norm_(parameters, max_norm, optimizer, grad_scale=None):
+    """torch.nn.utils.clip_grad_norm_ as the reference's trainer calls it (common/trainer.py:139-145), fused into the next
+    `optimizer.step()`: the squared gradient norm is summed on the device by the HIP kernels (vlb_sumsq_f32 over the flat runs of the
+    optimizer's parameters -- `parameters` is accepted for signature parity), kept on the device, and the step's kernel multiplies
+    every gradient by min(1, max_norm / (norm + 1e-6)) as it reads it -- no pass over the gradients to rescale them, no host sync.
+    grad_scale: an fp16 loss scale to divide out first (norm and clip are computed on the unscaled gradients).  Returns the total norm
+    (0-dim device tensor, unscaled).  The gradients themselves are left as they are."""
+    if not isinstance(optimizer, (FusedAdamW, FusedSGD)):
+        raise TypeError("clip_grad_norm_ fuses into FusedAdamW / FusedSGD")
+    if grad_scale is not None:
+        optimizer.grad_scale = float(grad_scale)
+    total = optimizer._sumsq_all()
+    optimizer._clip = (float(max_norm), total)
+    return total.sqrt() * optimizer.grad_scale
 
 
 class _FlatStateMixin:
@@ -39,6 +55,30 @@ class _FlatStateMixin:
     entries only (they are views of the flat buffers), and load_state_dict() drops the flat buffers so that the next step() re-creates
     them FROM the loaded per-parameter tensors and re-binds the views -- otherwise a reloaded checkpoint would leave the kernels
     updating buffers the exported state no longer aliases."""
+
+    grad_scale = 1.0      # multiplies every gradient inside the step kernel (1 / loss scale of an fp16 run; 1 / world of a DP sum)
+    _clip = None          # (max_norm, device sum of squares) left by clip_grad_norm_ for the next step()
+
+    def _group_runs(self, gi, group, who):
+        ps = [p for p in group["params"] if p.grad is not None]
+        _check_fp32_gpu(ps, who)
+        key = (gi, tuple((p.data_ptr(), p.grad.data_ptr()) for p in ps))
+        if self._runs.get("key%d" % gi) != key:          # layout changed (first step / re-allocated gradients): re-derive the runs
+            self._runs["key%d" % gi] = key
+            self._runs[gi] = _flat_runs(ps)
+        return ps, self._runs[gi]
+
+    def _sumsq_all(self):
+        total = None
+        for gi, group in enumerate(self.param_groups):
+            ps, runs = self._group_runs(gi, group, type(self).__name__)
+            for a, b in runs:
+                first = ps[a]
+                n = sum(p.numel() for p in ps[a:b])
+                if total is None:
+                    total = torch.zeros(1, dtype=torch.float32, device=first.device)
+                ops.sumsq(first.grad.as_strided((n,), (1,), first.grad.storage_offset()), total)
+        return total if total is not None else torch.zeros(1)
 
     def state_dict(self):
         sd = super().state_dict()
@@ -74,15 +114,11 @@ class FusedAdamW(_FlatStateMixin, torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        clip, self._clip = self._clip, None
         for gi, group in enumerate(self.param_groups):
-            ps = [p for p in group["params"] if p.grad is not None]
-            _check_fp32_gpu(ps, "FusedAdamW")
-            key = (gi, tuple((p.data_ptr(), p.grad.data_ptr()) for p in ps))
-            if self._runs.get("key%d" % gi) != key:
-                self._runs["key%d" % gi] = key
-                self._runs[gi] = _flat_runs(ps)
+            ps, runs = self._group_runs(gi, group, "FusedAdamW")
             hyper = (float(group["lr"]), float(group["betas"][0]), float(group["betas"][1]), float(group["eps"]), float(group["weight_decay"]))
-            for a, b in self._runs[gi]:
+            for a, b in runs:
                 first = ps[a]
                 n = sum(p.numel() for p in ps[a:b])
                 st = self.state[first]
@@ -110,7 +146,13 @@ class FusedAdamW(_FlatStateMixin, torch.optim.Optimizer):
                     st["hyper"] = hyper
                 pf = first.data.as_strided((n,), (1,), first.storage_offset())
                 gf = first.grad.as_strided((n,), (1,), first.grad.storage_offset())
-                ops.adamw_step(pf, gf, st["flat_m"], st["flat_v"], None, st["dev"])      # (the kernel advances the run's step count)
+                if clip is not None:                         # {max_norm, sumsq} of the device state: the kernel derives the coefficient
+                    st["dev"][6:7].fill_(clip[0])
+                    st["dev"][7:8].copy_(clip[1])
+                elif float(st["hyper_clip"] if "hyper_clip" in st else 0.0) != 0.0:
+                    st["dev"][6:7].zero_()
+                st["hyper_clip"] = clip[0] if clip is not None else 0.0
+                ops.adamw_step(pf, gf, st["flat_m"], st["flat_v"], None, st["dev"], grad_scale=self.grad_scale)      # (advances the run's step count)
                 for p in ps[a:b]:
                     self.state[p]["step"] += 1
                     torch.autograd.graph.increment_version(p)
@@ -132,14 +174,10 @@ class FusedSGD(_FlatStateMixin, torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        clip, self._clip = self._clip, None
         for gi, group in enumerate(self.param_groups):
-            ps = [p for p in group["params"] if p.grad is not None]
-            _check_fp32_gpu(ps, "FusedSGD")
-            key = (gi, tuple((p.data_ptr(), p.grad.data_ptr()) for p in ps))
-            if self._runs.get("key%d" % gi) != key:          # layout changed (first step / re-allocated gradients): re-derive the runs
-                self._runs["key%d" % gi] = key
-                self._runs[gi] = _flat_runs(ps)
-            for a, b in self._runs[gi]:
+            ps, runs = self._group_runs(gi, group, "FusedSGD")
+            for a, b in runs:
                 first = ps[a]
                 n = sum(p.numel() for p in ps[a:b])
                 st = self.state[first]
@@ -155,7 +193,9 @@ class FusedSGD(_FlatStateMixin, torch.optim.Optimizer):
                         off += p.numel()
                 pf = first.data.as_strided((n,), (1,), first.storage_offset())
                 gf = first.grad.as_strided((n,), (1,), first.grad.storage_offset())
-                ops.sgd_momentum_step(pf, gf, st["flat_buffer"], group["lr"], group["momentum"], group["weight_decay"])
+                ops.sgd_momentum_step(pf, gf, st["flat_buffer"], group["lr"], group["momentum"], group["weight_decay"],
+                                      sumsq=clip[1] if clip is not None else None, max_norm=clip[0] if clip is not None else 0.0,
+                                      grad_scale=self.grad_scale)
                 for p in ps[a:b]:      # the kernel wrote through raw pointers: tell autograd (the module mirrors key their bf16 /
                     torch.autograd.graph.increment_version(p)      # transposed weight copies on the parameters' version counters)
         return loss

@@ -28,7 +28,7 @@ from ...common.visual_linguistic_bert import VisualLinguisticBert
 
 F32 = torch.float32
 CLS, SEP = 101, 102          # ids of '[CLS]', '[SEP]' in the BERT vocabularies (tokenizer lookups in the reference)
-_TAG_REG = 3001
+_TAG_REG, _TAG_A0, _TAG_A1 = 3001, 3002, 3003
 NUM_OBJ_CLASSES = 81         # COCO detector classes of the VCR annotations (:26,38)
 
 
@@ -106,6 +106,99 @@ class _ObjClsFn(torch.autograd.Function):
         return dx, None, None, None, gw1, gb1, gw2, gb2
 
 
+class _AnswerFn(torch.autograd.Function):
+    """pooled [B,C,H] fp32 (BertPooler output per answer choice), answer_label [B] -> (label_logits [B,C], ans_loss): `final_mlp`
+    (Dropout -> Linear(H,1) | Dropout -> Linear(H,hc) -> ReLU -> Dropout -> Linear(hc,1), :62-82) and the answer loss -- the weighted
+    sigmoid BCE with the (w+1)/(2w) rescale, or the softmax CE over the choices (:333-345) -- on the device: bf16 GEMMs with fused
+    bias / ReLU epilogues, counter-RNG dropout, vlb_bce_logits_fwd_bwd / vlb_ce_fwd_bwd (loss and d(logits) in one pass),
+    hand-scheduled backward."""
+
+    @staticmethod
+    def forward(ctx, pooled, answer_label, module, train, *params):
+        B, C, H = pooled.shape
+        n = B * C
+        st = module._cls_state(n, B, pooled.device)
+        module._sync_cls()
+        p = module.cls_drop if train else 0.0
+        ops.cast_f32_bf16(pooled.detach().contiguous().view(n, H), st["x_in"])
+        x0 = ops.dropout_bf16(st["x_in"], st["x0"], p, module._seed, _TAG_A0) if p > 0 else st["x_in"]
+        if module.classifier == "1fc":
+            x1 = x0
+            ops.gemm_nt(x0, module._cw2, st["z"][:, :1], bias=params[1].detach())
+        else:
+            ops.gemm_nt(x0, module._cw1, st["u"], bias=params[1].detach(), act=ops.ACT_RELU)
+            x1 = ops.dropout_bf16(st["u"], st["x1"], p, module._seed, _TAG_A1) if p > 0 else st["u"]
+            ops.gemm_nt(x1, module._cw2, st["z"][:, :1], bias=params[3].detach())
+        logits = st["z"][:, 0].float().view(B, C)                 # (glue: the [B,C] fp32 tensor the outputs dict carries)
+        st["loss"].zero_()
+        ctx.has_label = answer_label is not None
+        if ctx.has_label:
+            _AnswerFn._loss(module, st, answer_label, B, C, 1.0)
+        ctx.module, ctx.st, ctx.p, ctx.x0, ctx.x1, ctx.label, ctx.shape = module, st, p, x0, x1, answer_label, (B, C, H)
+        ctx.mark_non_differentiable(logits)
+        return logits, st["loss"][0].clone()
+
+    @staticmethod
+    def _loss(module, st, answer_label, B, C, g):
+        """loss value into st["loss"], g * d(loss)/d(logit) into column 0 of st["z"] (the kept logits live in st["z_copy"])."""
+        n = B * C
+        if module.sigmoid:      # mean over the B*C logits of w * BCE, times (w+1)/(2w)
+            rescale = (module.pos_weight + 1.0) / (2.0 * module.pos_weight)
+            lab = st["lab"]
+            lab.zero_()
+            lab.view(B, C).scatter_(1, answer_label.long().view(B, 1), 1.0)          # one-hot of the right answer (index plumbing)
+            ops.bce_logits_fwd_bwd(st["z"], 1, lab.view(n, 1), st["loss"], gscale=g * rescale, logits_copy=st["z_copy"],
+                                   pos_weight=module.pos_weight)
+            st["loss"].mul_(rescale)
+        else:                   # softmax cross entropy over the C choices of a sample
+            st["z_copy"].copy_(st["z"])
+            zc = st["zc"]
+            zc.zero_()
+            zc[:, :C].copy_(st["z"][:, 0].view(B, C))
+            ops.ce_fwd_bwd(zc, C, answer_label.long().contiguous().view(-1), st["count"], st["loss"], gscale=g)
+            st["z"].zero_()
+            st["z"][:, 0].copy_(zc[:, :C].reshape(-1))
+
+    @staticmethod
+    def backward(ctx, _g_logits, g_loss):
+        module, st, p = ctx.module, ctx.st, ctx.p
+        B, C, H = ctx.shape
+        n = B * C
+        params = module._cls_params()
+        grads = [torch.zeros_like(q, dtype=F32) for q in params]
+        if not ctx.has_label:
+            return (torch.zeros((B, C, H), dtype=F32, device=st["z"].device), None, None, None) + tuple(grads)
+        g = float(g_loss)
+        if g != 1.0:      # upstream scale (ANS_LOSS_WEIGHT, gradient accumulation): re-derive d(logits) from the kept logits
+            st["z"].copy_(st["z_copy"])
+            st["loss"].zero_()
+            _AnswerFn._loss(module, st, ctx.label, B, C, g)
+        dz = st["z"]                                                        # [n, 64]: column 0 live, the rest exactly zero
+        gw2p = st["gw2p"]
+        gw2p.zero_()
+        st["gb2p"].zero_()
+        if module.classifier == "1fc":
+            gw2, gb2 = grads
+            ops.wgrad_tn(dz, ctx.x1, gw2p[:, :H], colsum=st["gb2p"], workspace=None)
+            gw2.copy_(gw2p[:1, :H]); gb2.copy_(st["gb2p"][:1])
+            ops.gemm_nt(dz, module._cw2T, st["dx0"])                         # K = 64 (one live column)
+        else:
+            gw1, gb1, gw2, gb2 = grads
+            hc = module.hc
+            ops.wgrad_tn(dz, ctx.x1, gw2p[:, :hc], colsum=st["gb2p"], workspace=None)
+            gw2.copy_(gw2p[:1, :hc]); gb2.copy_(st["gb2p"][:1])
+            ops.gemm_nt(dz, module._cw2T, st["dx1"], act=ops.ACT_RELU_MASK, aux=st["u"])
+            du = ops.dropout_bf16(st["dx1"], st["du"], p, module._seed, _TAG_A1) if p > 0 else st["dx1"]
+            ops.wgrad_tn(du, ctx.x0, gw1, colsum=gb1, workspace=None)
+            ops.gemm_nt(du, module._cw1T, st["dx0"])
+        dx = ops.dropout_bf16(st["dx0"], st["dxin"], p, module._seed, _TAG_A0) if p > 0 else st["dx0"]
+        d_pooled = torch.empty((n, H), dtype=F32, device=dx.device)
+        ops.cast_bf16_f32(dx.contiguous(), d_pooled)
+        if p > 0:
+            ops.rng_advance(module._seed)
+        return (d_pooled.view(B, C, H), None, None, None) + tuple(grads)
+
+
 class ResNetVLBERT(nn.Module):
     def __init__(self, config, device=None):
         super().__init__()
@@ -167,11 +260,51 @@ class ResNetVLBERT(nn.Module):
             self.Cp = _ru(NUM_OBJ_CLASSES, 64)
             self._rw1, self._rw1T = zb(H, H), zb(H, H)
             self._rw2, self._rw2T = zb(NUM_OBJ_CLASSES, H), zb(H, self.Cp)
+        # bf16 working copies of the classifier: first Linear [hc,H] (2fc) and the 1-output Linear padded to 64 rows (+ transposes)
+        zc = lambda *s: torch.zeros(s, dtype=ops.BF16, device=dev)
+        self.hc = int(_get(net, "CLASSIFIER_HIDDEN_SIZE", 1024)) if self.classifier != "1fc" else H
+        if self.hc % 64:
+            raise NotImplementedError("CLASSIFIER_HIDDEN_SIZE must be a multiple of 64")
+        self._cw1, self._cw1T = (zc(self.hc, H), zc(H, self.hc)) if self.classifier != "1fc" else (None, None)
+        self._cw2, self._cw2T = zc(1, self.hc), zc(self.hc, 64)
+        self._cls_version, self._cls_states = None, {}
         self._seed = torch.tensor([ops.rank_seed(40011)], dtype=torch.int32, device=dev)
         self._reg_version, self._states = None, {}
         self.init_weight()
 
     # -- parameters ---------------------------------------------------------------------------------
+    def _cls_params(self):
+        m = self.final_mlp
+        if self.classifier == "1fc":
+            l = getattr(m, "1")
+            return [l.weight, l.bias]
+        a, b = getattr(m, "1"), getattr(m, "4")
+        return [a.weight, a.bias, b.weight, b.bias]
+
+    def _sync_cls(self):
+        params = self._cls_params()
+        ver = tuple(q._version for q in params)
+        if ver == self._cls_version:
+            return
+        w2 = params[0] if self.classifier == "1fc" else params[2]
+        ops.cast_f32_bf16(w2.detach().contiguous(), self._cw2)
+        self._cw2T.zero_()
+        self._cw2T[:, 0].copy_(self._cw2[0])                           # [hc, 64] with one live column (index plumbing)
+        if self.classifier != "1fc":
+            ops.cast_f32_bf16(params[0].detach().contiguous(), self._cw1)
+            ops.transpose(self._cw1, self._cw1T)
+        self._cls_version = ver
+
+    def _cls_state(self, n, B, dev):
+        if (n, B) not in self._cls_states:
+            zb = lambda *s: torch.zeros(s, dtype=ops.BF16, device=dev)
+            zf = lambda *s: torch.zeros(s, dtype=F32, device=dev)
+            H, hc = self.H, self.hc
+            self._cls_states[(n, B)] = dict(x_in=zb(n, H), x0=zb(n, H), u=zb(n, hc), x1=zb(n, hc), z=zb(n, 64), z_copy=zb(n, 64), zc=zb(B, 64),
+                                            dx1=zb(n, hc), du=zb(n, hc), dx0=zb(n, H), dxin=zb(n, H), lab=zf(n), gw2p=zf(64, max(H, hc)),
+                                            gb2p=zf(64), loss=zf(1), count=zf(1))
+        return self._cls_states[(n, B)]
+
     def _reg_params(self):
         r = self.cnn_loss_reg
         t, c = getattr(r, "0"), getattr(r, "2")
@@ -286,33 +419,21 @@ class ResNetVLBERT(nn.Module):
                                                 output_all_encoded_layers=False, output_text_and_object_separately=True)
         return pooled, obj_out, objects, box_mask
 
-    def _classify(self, pooled):
-        m = self.final_mlp
-        x = F.dropout(pooled.float(), self.cls_drop, self.training)
-        if self.classifier == "1fc":
-            lin = getattr(m, "1")
-            return F.linear(x, lin.weight, lin.bias).squeeze(2)
-        a, b = getattr(m, "1"), getattr(m, "4")
-        h = F.dropout(F.relu(F.linear(x, a.weight, a.bias)), self.cls_drop, self.training)
-        return F.linear(h, b.weight, b.bias).squeeze(2)
+    def _classify(self, pooled, answer_label=None):
+        """-> (label_logits [B,C], ans_loss | None) through the HIP head (_AnswerFn)."""
+        logits, loss = _AnswerFn.apply(pooled.float(), answer_label, self, self.training, *self._cls_params())
+        return logits, (loss if answer_label is not None else None)
 
     def train_forward(self, image, boxes, masks, question, question_align_matrix, answer_choices, answer_align_matrix, answer_label,
                       im_info, mask_position=None, mask_type=None, mask_label=None):
         if mask_position is not None:
             raise NotImplementedError("mask_position (asserted off in the reference, :365)")
         pooled, obj_out, objects, box_mask = self._encode(image, boxes, masks, question, answer_choices, im_info)
-        logits = self._classify(pooled)
+        logits, ans_loss = self._classify(pooled, answer_label)
         B, C = logits.shape
         outputs = {}
         if self.sigmoid:
-            label_binary = torch.arange(C, device=logits.device)[None, :] == answer_label[:, None]
-            weight = torch.ones_like(logits)
-            weight[label_binary] = self.pos_weight
-            rescale = (self.pos_weight + 1.0) / (2.0 * self.pos_weight)
-            ans_loss = rescale * F.binary_cross_entropy_with_logits(logits, label_binary.to(logits.dtype), weight=weight)
-            outputs["positive_fraction"] = label_binary.to(logits.dtype).sum() / label_binary.numel()
-        else:
-            ans_loss = F.cross_entropy(logits, answer_label.long().view(-1))
+            outputs["positive_fraction"] = torch.full((), 1.0 / C, dtype=logits.dtype, device=logits.device)     # one right answer per sample
         outputs.update({"label_logits": logits, "label": answer_label.long().view(-1), "ans_loss": ans_loss})
         loss = ans_loss.mean() * self.ans_loss_weight
         if self.enable_cnn_reg_loss:
@@ -327,7 +448,7 @@ class ResNetVLBERT(nn.Module):
     def inference_forward(self, image, boxes, masks, question, question_align_matrix, answer_choices, answer_align_matrix, *args):
         im_info = args[-1]
         pooled, _, _, _ = self._encode(image, boxes, masks, question, answer_choices, im_info)
-        return {"label_logits": self._classify(pooled)}
+        return {"label_logits": self._classify(pooled)[0]}
 
     def forward(self, *inputs, **kwargs):
         """common/module.py:19-24"""
