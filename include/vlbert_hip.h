@@ -384,6 +384,40 @@ int vlb_roi_align_bwd(const float* grad_output, const float* rois, float* grad_i
                       int sampling_ratio, vlb_stream_t stream);
 
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * fp32 compute path of the encoder (csrc/f32_path.hip; host side vl-bert_amd/encoder_f32.py): the reference's fp32 configurations
+ * (TRAIN.FP16: false, cfgs/pretrain/base_prec_4x16G_fp32.yaml:112, cfgs/vqa/large_4x16G_fp32.yaml:108) -- per layer
+ * external/pytorch_pretrained_bert/modeling.py:268-397 with every tensor in fp32.  The fp32 products run on the bf16 matrix cores
+ * by operand splitting (x = h + m, 3 MFMAs per product, fp32 accumulation: ~2^-16 relative per product).
+ *
+ * vlb_gemm_nt_f32: C[M,N] (+)= epilogue(alpha * A[M,K] . B[N,K]^T), batched over nb1 x nb2 (element strides s?1 / s?2).
+ *   epilogue: + bias[n] (row i1 * sBias1: a Linear bias, or the per-sample additive attention mask), activation epi (0 none |
+ *   1 erf-GELU with GELU' -> pre | 2 ReLU | 3 x aux | 4 tanh | 5 keep where aux > 0), dropout(drop_p, counter RNG, element m*N+n),
+ *   + res.  atomic != 0: C += by atomicAdd over splitk K slices (weight gradients), no epilogue.  K % 32 == 0 (zero-pad),
+ *   N % 4 == 0, leading dimensions / strides % 4 == 0, 16-byte aligned pointers.
+ * vlb_transpose_f32: dst[c][r] = src[r][c], rows R..Rp of the result zero (the padded reduction dimension of the GEMM above);
+ *   colsum += column sums of src (bias gradients; unbatched).
+ * vlb_layernorm_f32_fwd / _bwd: BertLayerNorm (modeling.py:222-235) on fp32 rows; bwd writes dx and / or the dropout-masked dx_drop
+ *   (element row*H+col, the mask of the GEMM that produced the row) and accumulates dgamma / dbeta.
+ * vlb_softmax_f32_fwd / _bwd: softmax over the first S of Sp <= 256 columns; scores carry 1/sqrt(d); mask01 (nullable, [samples][S],
+ *   1 = attend) adds the reference's (1 - mask) * -10000 to the keys of sample row / rows_per_sample; p = the
+ *   probabilities (0 in the padding), pd = dropout(p); bwd: dpd <- p * (dp - sum dp p) in place, dp = dropout mask applied to dpd. */
+int vlb_gemm_nt_f32(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N, int K, int nb1, int nb2,
+                    long sA1, long sA2, long sB1, long sB2, long sC1, long sC2, const float* bias, long sBias1, float alpha, int epi,
+                    const float* aux, long ldaux, float* pre, long ldpre, const float* res, long ldres, float drop_p,
+                    const uint32_t* seed, uint32_t tag, int atomic, int splitk, vlb_stream_t stream);
+int vlb_transpose_f32(const float* src, long lds, float* dst, long ldd, int R, int C, int Rp, int nb1, int nb2, long sS1, long sS2,
+                      long sD1, long sD2, float* colsum, vlb_stream_t stream);
+int vlb_layernorm_f32_fwd(const float* x, long ldx, const float* gamma, const float* beta, float* y, long ldy, float* stats, int rows,
+                          int H, float eps, vlb_stream_t stream);
+int vlb_layernorm_f32_bwd(const float* dy, long lddy, const float* x, long ldx, const float* stats, const float* gamma, float* dx,
+                          long lddx, float* dx_drop, long lddd, float drop_p, const uint32_t* seed, uint32_t tag, float* dgamma,
+                          float* dbeta, int rows, int H, vlb_stream_t stream);
+int vlb_softmax_f32_fwd(const float* s, const float* mask01, int rows_per_sample, float* p, float* pd, int rows, int S, int Sp, float drop_p,
+                        const uint32_t* seed, uint32_t tag, vlb_stream_t stream);
+int vlb_softmax_f32_bwd(const float* p, float* dpd, int rows, int S, int Sp, float drop_p, const uint32_t* seed, uint32_t tag,
+                        vlb_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

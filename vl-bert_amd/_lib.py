@@ -90,6 +90,12 @@ _SIGS = {
     "vlb_relu_mask_cast": "pppls",
     "vlb_avgpool_rows_fwd": "ppliiiiips",
     "vlb_avgpool_rows_bwd": "plpplpiiifpuuups",
+    "vlb_gemm_nt_f32": "plplpliiiiillllllplfiplplplfpuiis",
+    "vlb_transpose_f32": "plpliiiiillllps",
+    "vlb_layernorm_f32_fwd": "plppplpiifs",
+    "vlb_layernorm_f32_bwd": "plplppplplfpuppiis",
+    "vlb_softmax_f32_fwd": "ppippiiifpus",
+    "vlb_softmax_f32_bwd": "ppiiifpus",
     "vlb_cast_f32_bf16": "ppls",
     "vlb_cast_bf16_f32": "ppls",
     "vlb_rng_advance": "ps",

@@ -164,7 +164,7 @@ class PretrainEngine:
     def __init__(self, cfg, B, T, R, device="cuda:0", train=True, lr=1e-4, weight_decay=1e-4, max_grad_norm=10.0,
                  betas=(0.9, 0.999), eps=1e-6, seed=1234, grad_accum=1, process_group=None, keep_logits=False, flat=None,
                  B_aux=0, core=False, core_heads=True, core_sequence=False, lr_schedule=None, warmup_steps=0, t_total=0,
-                 image_size=None, dp_mode="default", dp_wire="default", loss_scale=None):
+                 image_size=None, dp_mode="default", dp_wire="default", loss_scale=None, encoder_fp32=False):
         cfg.validate()
         if cfg.e2e and (core or image_size is None):
             raise ValueError("e2e needs image_size=(H, W) and a pretraining wrapper (plain or multitask; not the core module mode)")
@@ -415,6 +415,15 @@ class PretrainEngine:
                 # wshard = the compact bf16 image of the updated slices the weight all-gather distributes (parallel.py)
                 self.shard_tbl = ops.ShardRanges(self.buckets.owned_rows(), d)
                 self.wshard = torch.zeros(self.P.numel // world, dtype=ops.BF16, device=d)
+        # fp32 compute mode of the encoder (the reference's TRAIN.FP16: false configurations; encoder_f32.py): the layers run on fp32
+        # tensors and the fp32 MASTER weights, the embedding side and the heads stay on the 16-bit kernels (use the fp16 build)
+        self.enc32 = None
+        if encoder_fp32:
+            if self.buckets is not None and self.buckets.sharded:
+                raise ValueError("encoder_fp32 reads the fp32 master weights on every rank: use dp_mode='allreduce' (the sharded optimizer "
+                                 "keeps them authoritative on the owner only)")
+            from .encoder_f32 import EncoderF32
+            self.enc32 = EncoderF32(self)
 
     # ------------------------------------------------------------------------------------------
     # parameters
@@ -479,6 +488,8 @@ class PretrainEngine:
                 pairs.append((self.w16[n], self.wT[n]))
             self._tbatch = ops.TransposeBatch(pairs, self.dev)
         self._tbatch.run()
+        if self.enc32 is not None:
+            self.enc32.refresh()
 
     # ------------------------------------------------------------------------------------------
     # batch
@@ -617,7 +628,9 @@ class PretrainEngine:
         # --- encoder -------------------------------------------------------------------------------------
         mask = self.lay["attn_mask"]
         stale = self._gather_pending
-        for l in range(L):
+        if self.enc32 is not None:
+            self.enc32.forward(p_h, p_a)
+        for l in range(L if self.enc32 is None else 0):
             p = "vlbert.encoder.layer.%d." % l
             x = self.X[l]
             if stale:
@@ -857,7 +870,9 @@ class PretrainEngine:
             on_layer_done("heads")
         # --- encoder, last layer first -------------------------------------------------------------------
         mask = self.lay["attn_mask"]
-        for l in reversed(range(L)):
+        if self.enc32 is not None:
+            dx = self.enc32.backward(dx, p_h, p_a, on_layer_done, will_launch)
+        for l in reversed(range(L if self.enc32 is None else 0)):
             p = "vlbert.encoder.layer.%d." % l
             dx_next = self.dXb if dx is self.dXa else self.dXa
             par = l & 1
@@ -1063,7 +1078,8 @@ class PretrainEngine:
     def zero_grad(self):
         """Start of an optimizer step.  With the TN weight-gradient path the Linear weight gradients (97 % of the buffer)
         are OVERWRITTEN by the first backward, so only the ranges that are accumulated with atomics are cleared."""
-        if not self.use_tn_wgrad or self.core:      # (module-API mode may run without the heads: nothing overwrites their gradients)
+        if not self.use_tn_wgrad or self.core or self.enc32 is not None:      # (module-API mode may run without the heads: nothing overwrites
+            # their gradients; the fp32 encoder ACCUMULATES its weight gradients with atomics)
             self.P.grad.zero_()
             self._fresh_grads = False
             return

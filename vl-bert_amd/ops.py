@@ -625,3 +625,54 @@ class ShardRanges:
         _lib.call("vlb_adamw_step_ranges", _p(p, torch.float32), _p(g), 1 if g.dtype == BF16 else 0, _p(m, torch.float32),
                   _p(v, torch.float32), _p(p16c, BF16), self.ranges.data_ptr(), self.starts.data_ptr(), self.n, self.total_blocks,
                   self.chunk, _p(state, torch.float32), float(grad_scale), _stream())
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# fp32 encoder path (csrc/f32_path.hip): raw-pointer wrappers -- operands are sub-matrices of larger fp32 buffers addressed by
+# (tensor, element offset), batched with two stride levels
+# ---------------------------------------------------------------------------------------------------------------
+F32 = torch.float32
+
+
+def _pf(t, off=0):
+    if t is None:
+        return None
+    if isinstance(t, tuple):
+        t, off = t
+    if not t.is_cuda or t.dtype != F32:
+        raise RuntimeError("fp32 path: expected a float32 GPU tensor (got %s on %s)" % (t.dtype, t.device))
+    return t.data_ptr() + 4 * int(off)
+
+
+def gemm_nt_f32(A, lda, B, ldb, C, ldc, M, N, K, batch=(1, 1), sA=(0, 0), sB=(0, 0), sC=(0, 0), bias=None, sBias1=0, alpha=1.0, epi=0,
+                aux=None, ldaux=0, pre=None, ldpre=0, res=None, ldres=0, drop_p=0.0, seed=None, tag=0, atomic=False, splitk=1):
+    """C (+)= epilogue(alpha * A . B^T) in fp32 (vlb_gemm_nt_f32).  A / B / C / bias / aux / pre / res: tensor or (tensor, element offset)."""
+    _lib.call("vlb_gemm_nt_f32", _pf(A), int(lda), _pf(B), int(ldb), _pf(C), int(ldc), int(M), int(N), int(K), int(batch[0]), int(batch[1]),
+              int(sA[0]), int(sA[1]), int(sB[0]), int(sB[1]), int(sC[0]), int(sC[1]), _pf(bias), int(sBias1), float(alpha), int(epi),
+              _pf(aux), int(ldaux), _pf(pre), int(ldpre), _pf(res), int(ldres), float(drop_p), _p(seed), int(tag), 1 if atomic else 0,
+              int(splitk), _stream())
+
+
+def transpose_f32(src, lds, dst, ldd, R, C, Rp, batch=(1, 1), sS=(0, 0), sD=(0, 0), colsum=None):
+    _lib.call("vlb_transpose_f32", _pf(src), int(lds), _pf(dst), int(ldd), int(R), int(C), int(Rp), int(batch[0]), int(batch[1]), int(sS[0]),
+              int(sS[1]), int(sD[0]), int(sD[1]), _pf(colsum), _stream())
+
+
+def layernorm_f32_fwd(x, gamma, beta, y, stats, eps=1e-12):
+    rows, H = x.shape
+    _lib.call("vlb_layernorm_f32_fwd", _pf(x), _ld(x), _pf(gamma), _pf(beta), _pf(y), _ld(y), _pf(stats), rows, H, float(eps), _stream())
+
+
+def layernorm_f32_bwd(dy, x, stats, gamma, dx=None, dx_drop=None, drop_p=0.0, seed=None, tag=0, dgamma=None, dbeta=None):
+    rows, H = x.shape
+    _lib.call("vlb_layernorm_f32_bwd", _pf(dy), _ld(dy), _pf(x), _ld(x), _pf(stats), _pf(gamma), _pf(dx), _ld(dx), _pf(dx_drop), _ld(dx_drop),
+              float(drop_p), _p(seed), int(tag), _pf(dgamma), _pf(dbeta), rows, H, _stream())
+
+
+def softmax_f32_fwd(s, mask01, rows_per_sample, p, pd, rows, S, Sp, drop_p=0.0, seed=None, tag=0):
+    _lib.call("vlb_softmax_f32_fwd", _pf(s), _pf(mask01), int(rows_per_sample), _pf(p), _pf(pd), int(rows), int(S), int(Sp), float(drop_p),
+              _p(seed), int(tag), _stream())
+
+
+def softmax_f32_bwd(p, dpd, rows, S, Sp, drop_p=0.0, seed=None, tag=0):
+    _lib.call("vlb_softmax_f32_bwd", _pf(p), _pf(dpd), int(rows), int(S), int(Sp), float(drop_p), _p(seed), int(tag), _stream())
