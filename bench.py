@@ -171,6 +171,17 @@ def _mirror_gemm_roofline(ops, step, head_start, dev):
         e1.record()
         rec.append((e0, e1, sum(2.0 * dy.shape[0] * dy.shape[1] * x.shape[1] for dy, x, _, _ in items)))
         return out
+    orig_f32 = ops.gemm_nt_f32
+
+    def timed_f32(A, lda, B, ldb, C, ldc, M, N, K, *a, **kw):      # the fp32 encoder's GEMMs (linear layers, attention products, weight gradients)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = orig_f32(A, lda, B, ldb, C, ldc, M, N, K, *a, **kw)
+        e1.record()
+        nb = kw.get("batch", (1, 1))
+        rec.append((e0, e1, 2.0 * M * N * K * nb[0] * nb[1], "f32"))
+        return out
+    ops.gemm_nt_f32 = timed_f32
     for n in names:
         setattr(ops, n, timed(n))
     ops.wgrad_tn_group = timed_group
@@ -184,6 +195,7 @@ def _mirror_gemm_roofline(ops, step, head_start, dev):
     for n in names:
         setattr(ops, n, orig[n])
     ops.wgrad_tn_group = orig_group
+    ops.gemm_nt_f32 = orig_f32
     gemm_ms = sum(r[0].elapsed_time(r[1]) for r in rec)
     achieved = sum(r[2] for r in rec) / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     return rec, gemm_ms, achieved
@@ -270,24 +282,42 @@ def bench_vqa(args):
     out = {
         "metric": "samples/sec VL-BERT-large VQA fine-tuning step (128 text + 100 regions, precomputed features, AdamW, gradient accumulation 4)",
         "value": round(value, 2), "unit": "samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype_name,
         "data": "synthetic (random-init weights, random boxes / features / tokens / answer scores, resident in HBM)",
         "config": {"workload": "BASELINE config 4's shape through the module mirror vl-bert_amd/vqa (cfgs/vqa/large_4x16G_fp32.yaml): 24 x 1024 "
                                "encoder, %d samples per micro-batch, %d text + %d regions + END = %d positions, 'mlm' classifier over %d answers + "
                                "BCE, clip 1.0, AdamW, %d micro-batches per optimizer step; a step = one optimizer step"
                                % (B, Lq + 4, R, Lq + 4 + R + 1, 3129, accum),
-                   "note": "bf16 compute with fp32 master weights; the fp32 COMPUTE mode the reference config runs in is not built, so this "
-                           "line is not a measurement of config 4 at its named precision",
+                   "note": ("config 4 at its named precision: fp32 encoder (24 layers: GEMMs, LayerNorm, softmax, residual stream, weights, "
+                            "gradients in fp32; parity 6.9e-4 on logits at 24 layers, tests/test_f32_encoder_gpu.py), fp16 kernels for the "
+                            "embedding side and the classifier" if args.fp32 else
+                            "16-bit compute with fp32 master weights -- run with --precision fp32 for config 4's named precision"),
                    "global_batch": B * accum, "per_gpu_batch": B * accum, "seq_len": Lq + 4 + R + 1, "parallelism": "dp1", "arch": arch, "cus": cus},
-        "roofline": {"bound": "mfma", "kernel": "all %d bf16 GEMM launches of one optimizer step (large-tile NT / TN cores + the 128x128 kernels "
-                                               "on the classifier shapes)" % len(rec),
-                     "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-                     "traffic": None, "gemm_ms_per_step": round(gemm_ms, 3), "gemm_share_of_step": round(gemm_ms / ms, 3)},
+        "roofline": _vqa_roofline(rec, achieved, gemm_ms, ms, args),
         "loss": round(float(last), 4),
     }
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_vqa(B, R, Lq)
     print(json.dumps(out), flush=True)
+
+
+def _vqa_roofline(rec, achieved, gemm_ms, ms, args):
+    if not args.fp32:
+        return {"bound": "mfma", "kernel": "all %d 16-bit GEMM launches of one optimizer step (large-tile NT / TN cores + the 128x128 kernels "
+                                           "on the classifier shapes)" % len(rec),
+                "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+                "traffic": None, "gemm_ms_per_step": round(gemm_ms, 3), "gemm_share_of_step": round(gemm_ms / ms, 3)}
+    f32 = [r for r in rec if len(r) > 3]
+    ms32 = sum(r[0].elapsed_time(r[1]) for r in f32)
+    a32 = sum(r[2] for r in f32) / (ms32 * 1e-3) / 1e12 if ms32 > 0 else 0.0
+    # an fp32 product = 3 bf16 MFMAs in gemm_f32_split_kernel: its ceiling is a third of the dense bf16 MFMA peak; gfx950's NATIVE fp32
+    # MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md) is given beside it
+    return {"bound": "mfma", "kernel": "gemm_f32_split_kernel: the %d fp32 GEMM launches of one optimizer step (encoder linear layers, attention "
+                                       "products, weight gradients); fp32 FLOPs = 2 M N K" % len(f32),
+            "achieved": round(a32, 2), "peak": round(PEAK_BF16_TFLOPS / 3.0, 1), "unit": "TFLOP/s (fp32-equivalent)",
+            "frac": round(a32 / (PEAK_BF16_TFLOPS / 3.0), 4), "native_fp32_mfma_peak": 157.3, "vs_native_fp32_mfma_peak": round(a32 / 157.3, 3),
+            "traffic": None, "gemm_ms_per_step": round(ms32, 3), "gemm_share_of_step": round(ms32 / ms, 3),
+            "all_gemm_launches": len(rec), "all_gemm_tflops": round(achieved, 2)}
 
 
 def cpu_baseline_vqa(B, R, Lq):
@@ -360,7 +390,7 @@ def bench_vcr(args):
         "metric": "samples/sec VL-BERT-large VCR Q->A fine-tuning step (4 answer choices, 256-position sequences, ResNet-101 image path, "
                   "SGD, gradient accumulation 4)",
         "value": round(value, 2), "unit": "samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype_name,
         "data": "synthetic (random-init weights, random images / boxes / masks / tokens / tags, resident in HBM)",
         "config": {"workload": "BASELINE config 5 through the module mirror vl-bert_amd/vcr (cfgs/vcr/large_q2a_4x16G_fp16.yaml): 24 x 1024 encoder, "
                                "%d samples x %d choices per micro-batch, %d text + %d regions + END = %d positions, %dx%d images, "
@@ -423,9 +453,11 @@ def main():
                     "choices, sequences of 256 positions, ResNet-101 image path with object masks, SGD momentum 0.9, gradient accumulation 4 "
                     "(cfgs/vcr/large_q2a_4x16G_fp16.yaml: 4 samples per GPU per micro-batch); one GPU; a step = one OPTIMIZER step")
     ap.add_argument("--layers", type=int, default=12)
-    ap.add_argument("--precision", default=None, choices=["bf16", "f16"], help="16-bit type of the library build (vl-bert_amd/_lib.py): bf16 "
-                    "(default; BASELINE.json's headline precision) or f16 = IEEE fp16 activations / working weights / gradients + a static loss "
-                    "scale (the reference's Apex fp16 mode, TRAIN.FP16: true; same MFMA rate, 3 more mantissa bits per operand)")
+    ap.add_argument("--precision", default=None, choices=["bf16", "f16", "fp32"], help="bf16 (default; BASELINE.json's headline precision) | "
+                    "f16 = the fp16 build of the library: IEEE fp16 activations / working weights / gradients + a static loss scale (the "
+                    "reference's Apex fp16 mode, TRAIN.FP16: true; same MFMA rate, 3 more mantissa bits per operand) | fp32 = every encoder "
+                    "tensor in fp32 (vl-bert_amd/encoder_f32.py: fp32 products on the bf16 matrix cores by operand splitting), the fp16 build "
+                    "around it -- the reference's TRAIN.FP16: false configurations (BASELINE config 4: --vqa --precision fp32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-full", action="store_true", help="time the CPU port at SURVEY 8d's size (batch 32, 3 warm-up + 5 timed "
                     "iterations, median) instead of the quick bounded leg (batch 8, <= 25 s)")
@@ -440,10 +472,15 @@ def main():
                     "segments cut at the collectives (engine.make_step_graph): the eager launch loop (~5 ms of host time per step) would "
                     "bound the 32-sample-per-GPU step")
     args = ap.parse_args()
-    if args.precision:
-        os.environ["VLB_PRECISION"] = args.precision        # read by vl-bert_amd/_lib.py at import (the imports below are lazy)
+    if args.precision:      # read by vl-bert_amd/_lib.py / common/visual_linguistic_bert.py at import / construction (the imports below are lazy)
+        os.environ["VLB_PRECISION"] = "f16" if args.precision == "fp32" else args.precision
+        os.environ["VLB_ENCODER_FP32"] = "1" if args.precision == "fp32" else "0"
     prec = os.environ.get("VLB_PRECISION", "bf16").lower()
+    args.fp32 = os.environ.get("VLB_ENCODER_FP32", "0") == "1"
     dtype_name = "fp16 (fp32 accumulation, fp32 master weights, static loss scale)" if prec in ("f16", "fp16", "half", "float16") else "bf16"
+    if args.fp32:
+        dtype_name = "fp32 (encoder: fp32 tensors, fp32 products by bf16 operand splitting with fp32 accumulation; embedding / head kernels fp16)"
+    args.dtype_name = dtype_name
 
     if "RANK" not in os.environ and args.gpus > 1:
         # plain `python bench.py --gpus N`: re-launch ourselves as N ranks (one per GPU) under torch.distributed.run, exactly the

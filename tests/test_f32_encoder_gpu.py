@@ -219,3 +219,22 @@ def test_engine_fp32_encoder_large_4_and_24_layers_on_the_fp16_build():
 @pytest.mark.parametrize("layers", [4, 24])
 def test_child_case_large(layers):
     _engine_case(layers, True, 2, 128, 100, 310 + layers, "fp32-encoder large %d-layer" % layers)
+
+
+def test_vqa_and_module_api_mirrors_on_the_fp32_encoder():
+    """The module API mirrors (common.visual_linguistic_bert, the VQA wrapper of BASELINE config 4) with VLB_ENCODER_FP32=1 on the fp16
+    build: the same reference-fixture / oracle tests as the 16-bit builds run, through the fp32 encoder (child process)."""
+    env = dict(os.environ, VLB_PRECISION="f16", VLB_ENCODER_FP32="1")
+    cmd = [sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_engine_gpu.py"), "-m", "gpu", "-q", "-x", "-s", "-k",
+           "vqa_module_mirror or module_api_hidden_states or module_api_pooler or module_api_pretraining_heads"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    try:
+        with open(os.path.join(ROOT, "gpurun_out", "f32_encoder_mirrors.log"), "w") as f:
+            f.write(r.stdout + "\n---- stderr ----\n" + r.stderr)
+    except OSError:
+        pass
+    print(r.stdout[-4000:])
+    print(r.stderr[-1500:])
+    assert r.returncode == 0, r.stdout[-3000:]
+    m = re.search(r"(\d+) passed", r.stdout)
+    assert m and int(m.group(1)) >= 5

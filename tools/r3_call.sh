@@ -15,6 +15,8 @@ for what in "$@"; do
     vcrtests) timeout 900 python -m pytest tests/test_vcr_gpu.py -m gpu -q -x -s > $OUT/vcrtests.log 2>&1; grep -E "passed|failed|FAILED|Error|fused clip|vcr " $OUT/vcrtests.log | tail -20 ;;
     vistests) timeout 900 python -m pytest tests/test_vision_gpu.py -m gpu -q -s > $OUT/vistests.log 2>&1; grep -E "passed|failed|FAILED|median|max rel-fro|grad-norm|gradient norm" $OUT/vistests.log | tail -30 ;;
     f32tests) timeout 1500 python -m pytest tests/test_f32_encoder_gpu.py -m gpu -q -x -s > $OUT/f32tests.log 2>&1; grep -E "passed|failed|FAILED|Error|error|max rel err|Frobenius|fp32 encoder|assert" $OUT/f32tests.log | tail -40 ;;
+    vqa32)   python bench.py --vqa --precision fp32 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/vqa_fp32.json 2> $OUT/vqa_fp32.err; cut -c1-2500 $OUT/vqa_fp32.json; tail -3 $OUT/vqa_fp32.err
+             python bench.py --vqa --precision f16 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/vqa_f16.json 2> $OUT/vqa_f16.err; cut -c1-300 $OUT/vqa_f16.json; tail -3 $OUT/vqa_f16.err ;;
     bench)   python bench.py --no-cpu-baseline > $OUT/bench256.json 2> $OUT/bench256.err; cut -c1-400 $OUT/bench256.json ;;
     small)   for b in 128 64 32; do python bench.py --no-cpu-baseline --global-batch $b --no-phase-times > $OUT/bench$b.json 2> $OUT/bench$b.err; python -c "import json;d=json.load(open('$OUT/bench$b.json'));print($b, d['ms_per_step'], d['roofline']['frac'], d['roofline']['by_op']['host_launch_ms_whole_step'])"; done ;;
     graph)   for b in 256 32; do python bench.py --no-cpu-baseline --global-batch $b --no-phase-times --graph > $OUT/benchg$b.json 2> $OUT/benchg$b.err; python -c "import json;d=json.load(open('$OUT/benchg$b.json'));print('graph',$b, d['ms_per_step'])"; done ;;

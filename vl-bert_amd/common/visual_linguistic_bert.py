@@ -109,6 +109,10 @@ class VisualLinguisticBert(nn.Module):
         if _get(config, "word_embedding_frozen", False) or _get(config, "pos_embedding_frozen", False):
             raise NotImplementedError("frozen embeddings are not supported")
         self.config = config
+        # fp32 compute mode of the encoder (the reference's TRAIN.FP16: false configurations; ../encoder_f32.py): `fp32_encoder` in the
+        # VLBERT config node, or VLB_ENCODER_FP32=1 -- run it on the fp16 build (VLB_PRECISION=f16) for the 1e-3 class
+        import os as _os
+        self.fp32_encoder = bool(_get(config, "fp32_encoder", False)) or _os.environ.get("VLB_ENCODER_FP32", "0") == "1"
         self.cfg = _engine.ModelConfig(
             hidden_size=_get(config, "hidden_size"), num_hidden_layers=_get(config, "num_hidden_layers"),
             num_attention_heads=_get(config, "num_attention_heads"), intermediate_size=_get(config, "intermediate_size"),
@@ -168,7 +172,8 @@ class VisualLinguisticBert(nn.Module):
         eng = lru_get(self._engines, (B, T, R, sequence),
                       lambda: _engine.PretrainEngine(self.cfg, B, T, R, device=str(self.device_), flat=self.flat, core=True,
                                                      core_heads=self.WITH_HEADS, core_sequence=sequence,
-                                                     seed=ops.rank_seed(1234) // 2))        # per-rank dropout stream
+                                                     seed=ops.rank_seed(1234) // 2,         # per-rank dropout stream
+                                                     encoder_fp32=self.fp32_encoder))
         version = self.flat.master._version
         if getattr(eng, "_synced_version", None) != version:
             eng.sync_weights()

@@ -97,7 +97,9 @@ def resolve(config, world, args):
                 lr_schedule=sched, warmup_steps=int(tr.WARMUP_STEPS) if tr.WARMUP else 0,
                 t_total=int(int(tr.END_EPOCH) * steps_per_epoch / accum), steps_per_epoch=steps_per_epoch,
                 e2e=not config.NETWORK.IMAGE_FEAT_PRECOMPUTED, image_size=tuple(config.SCALES), multitask=multitask,
-                fp16_requested=bool(tr.FP16), seed=int(config.RNG_SEED))
+                fp16_requested=bool(tr.FP16), seed=int(config.RNG_SEED),
+                compute=(("fp16" if tr.FP16 else "fp32") if args.compute == "cfg" else args.compute),
+                loss_scale=(float(tr.FP16_LOSS_SCALE) if isinstance(tr.get("FP16_LOSS_SCALE", None), (int, float)) else None))
 
 
 def parse_args(argv=None):
@@ -114,6 +116,11 @@ def parse_args(argv=None):
     ap.add_argument("--batch-images", type=int, default=0, help="override TRAIN.BATCH_IMAGES (per GPU)")
     ap.add_argument("--text-len", type=int, default=64)
     ap.add_argument("--regions", type=int, default=36)
+    ap.add_argument("--compute", default="bf16", choices=["bf16", "fp16", "fp32", "cfg"],
+                    help="arithmetic of the step.  bf16 (default): bf16 operands, fp32 accumulation / master weights, no loss scaling.  "
+                         "fp16: the fp16 build of the library + static loss scale TRAIN.FP16_LOSS_SCALE (the reference's Apex mode, "
+                         "pretrain/function/train.py:345-352; 'dynamic' -> 4096).  fp32: every encoder tensor in fp32 (encoder_f32.py), fp16 "
+                         "embedding / head kernels around it.  cfg: what the YAML names -- TRAIN.FP16 true -> fp16, false -> fp32")
     ap.add_argument("--dry-run", action="store_true", help="resolve and print the configuration, touch no GPU")
     return ap.parse_args(argv)
 
@@ -137,6 +144,8 @@ def main(argv=None):
         raise RuntimeError("train_end2end: no GPU visible.  The MI355X engine has no CPU execution path (use --dry-run to check a "
                            "configuration without a GPU)")
     pkg = __package__.rsplit(".", 1)[0]
+    if r["compute"] != "bf16":      # fp16 and fp32 modes run on the fp16 build of the library (vl-bert_amd/_lib.py: one build per process)
+        importlib.import_module(pkg + "._lib").set_precision("f16")
     engine = importlib.import_module(pkg + ".engine")
     syn = importlib.import_module(pkg + ".synthetic")
     ops = importlib.import_module(pkg + ".ops")
@@ -162,13 +171,15 @@ def main(argv=None):
     eng = engine.PretrainEngine(mc, B, T, R, device="cuda:%d" % local_rank, train=True, lr=r["lr"], weight_decay=r["weight_decay"],
                                 max_grad_norm=r["clip_grad_norm"], seed=r["seed"] + rank, B_aux=B_aux,
                                 lr_schedule=r["lr_schedule"], warmup_steps=r["warmup_steps"], t_total=max(r["t_total"], r["warmup_steps"] + 1),
-                                image_size=r["image_size"] if r["e2e"] else None, grad_accum=r["accumulate"])
+                                image_size=r["image_size"] if r["e2e"] else None, grad_accum=r["accumulate"],
+                                encoder_fp32=r["compute"] == "fp32", dp_mode="allreduce" if r["compute"] == "fp32" else "default",
+                                loss_scale=r["loss_scale"] if r["compute"] == "fp16" else None)
     eng.init_random(seed=r["seed"], visual_ln_init=float(g("visual_scale_object_init", 0.0)))
     eng.broadcast_parameters(src=0)       # rank 0's parameters / optimizer state everywhere (pretrain/function/train.py:331-334)
     if rank == 0:
         print("train_end2end: %s | %d GPU(s) x batch %d | lr %.3e wd %.1e clip %.1f | schedule %s warmup %d t_total %d%s" %
               (config.MODULE, world, B + B_aux, r["lr"], r["weight_decay"], r["clip_grad_norm"], r["lr_schedule"], r["warmup_steps"], r["t_total"],
-               " | fp16 requested -> bf16 compute (no loss scaling needed)" if r["fp16_requested"] else ""), flush=True)
+               " | compute %s%s" % (r["compute"], " (loss scale %g)" % eng.loss_scale if eng.loss_scale != 1.0 else "")), flush=True)
     t0, seen = time.time(), 0
     def load_batch(seed_off):
         batch = list(syn.make_batch(B, T, R, seed=1000 * rank + seed_off))
