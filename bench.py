@@ -201,6 +201,30 @@ def _mirror_gemm_roofline(ops, step, head_start, dev):
     return rec, gemm_ms, achieved
 
 
+def _timed_mirror_steps(step, args, per_gpu_samples):
+    """warm-up, then args.steps optimizer steps between barriers; MAX over the ranks -> (ms per step, whole-job samples/s, last loss)"""
+    dist, world = args.dist, args.world
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+    last = None
+    for _ in range(max(1, args.warmup)):
+        last = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt)
+    return elapsed / args.steps * 1e3, per_gpu_samples * world / (elapsed / args.steps), last
+
+
 def vqa_config(answers=3129):
     """cfgs/vqa/large_4x16G_fp32.yaml as the attribute tree the module mirror reads."""
     class A(dict):
@@ -254,34 +278,30 @@ def bench_vqa(args):
             if n.endswith("visual_ln_text.weight") or n.endswith("visual_ln_object.weight"):
                 p.fill_(1.0)
     net.train()
-    opt = OPT.FusedAdamW(net.parameters(), lr=6.25e-7 * B * accum, betas=(0.9, 0.999), eps=1e-6, weight_decay=1e-4)
-    batches = [vqa_batch(B, R, Lq, 700 + i, dev) for i in range(accum)]
+    world, rank = args.world, args.rank
+    if world > 1:      # vqa/function/train.py:327 wraps the model in DistributedDataParallel: 16 samples per GPU per micro-batch (weak scaling)
+        net = importlib.import_module("vl-bert_amd.parallel").DistributedDataParallel(net)
+    opt = OPT.FusedAdamW(net.parameters(), lr=6.25e-7 * B * accum * world, betas=(0.9, 0.999), eps=1e-6, weight_decay=1e-4)
+    batches = [vqa_batch(B, R, Lq, 700 + i + 100 * rank, dev) for i in range(accum)]
 
     def step():
         opt.zero_grad(set_to_none=False)
         total = 0.0
         for boxes, im_info, question, label in batches:
-            outputs, loss = net.train_forward(None, boxes, im_info, question, label)
+            outputs, loss = net(None, boxes, im_info, question, label)
             (loss / accum).backward()
             total = loss.detach()
         OPT.clip_grad_norm_(net.parameters(), 1.0, opt)          # fused into the step kernel (device-side norm, no rescale pass)
         opt.step()
         return total
 
-    for _ in range(max(1, args.warmup)):
-        last = step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        last = step()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    ms = elapsed / args.steps * 1e3
-    value = B * accum / (elapsed / args.steps)
+    ms, value, last = _timed_mirror_steps(step, args, B * accum)
     rec, gemm_ms, achieved = _mirror_gemm_roofline(ops, step, args.head_start, dev)
+    if rank != 0:
+        return
     out = {
         "metric": "samples/sec VL-BERT-large VQA fine-tuning step (128 text + 100 regions, precomputed features, AdamW, gradient accumulation 4)",
-        "value": round(value, 2), "unit": "samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+        "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype_name,
         "data": "synthetic (random-init weights, random boxes / features / tokens / answer scores, resident in HBM)",
         "config": {"workload": "BASELINE config 4's shape through the module mirror vl-bert_amd/vqa (cfgs/vqa/large_4x16G_fp32.yaml): 24 x 1024 "
@@ -292,7 +312,9 @@ def bench_vqa(args):
                             "gradients in fp32; parity 6.9e-4 on logits at 24 layers, tests/test_f32_encoder_gpu.py), fp16 kernels for the "
                             "embedding side and the classifier" if args.fp32 else
                             "16-bit compute with fp32 master weights -- run with --precision fp32 for config 4's named precision"),
-                   "global_batch": B * accum, "per_gpu_batch": B * accum, "seq_len": Lq + 4 + R + 1, "parallelism": "dp1", "arch": arch, "cus": cus},
+                   "global_batch": B * accum * world, "per_gpu_batch": B * accum, "seq_len": Lq + 4 + R + 1, "parallelism": "dp%d" % world,
+                   "dp_exchange": "parallel.DistributedDataParallel: flat-gradient buckets from the engine's backward hooks + one coalesced "
+                                  "all-reduce of the remaining parameters" if world > 1 else None, "arch": arch, "cus": cus},
         "roofline": _vqa_roofline(rec, achieved, gemm_ms, ms, args),
         "loss": round(float(last), 4),
     }
@@ -360,43 +382,38 @@ def bench_vcr(args):
             if n.endswith("visual_ln_text.weight") or n.endswith("visual_ln_object.weight"):
                 p.fill_(1.0)
     net.train()
-    opt = OPT.FusedSGD(net.parameters(), lr=7.0e-5 * B * accum, momentum=0.9, weight_decay=1e-4)
-    batches = [vcr_batch(B, C, R, Lq, La, Hi, Wi, 500 + i, dev) for i in range(accum)]
+    world, rank = args.world, args.rank
+    if world > 1:      # vcr/function/train.py:330 wraps the model in DistributedDataParallel: 4 samples per GPU per micro-batch (weak scaling)
+        net = importlib.import_module("vl-bert_amd.parallel").DistributedDataParallel(net)
+    opt = OPT.FusedSGD(net.parameters(), lr=7.0e-5 * B * accum * world, momentum=0.9, weight_decay=1e-4)
+    batches = [vcr_batch(B, C, R, Lq, La, Hi, Wi, 500 + i + 100 * rank, dev) for i in range(accum)]
 
     def step():
         opt.zero_grad(set_to_none=False)
         total = 0.0
         for image, boxes, masks, question, answers, label, im_info in batches:
-            outputs, loss = net.train_forward(image, boxes, masks, question, None, answers, None, label, im_info)
+            outputs, loss = net(image, boxes, masks, question, None, answers, None, label, im_info)
             (loss / accum).backward()
             total = loss.detach()
         OPT.clip_grad_norm_(net.parameters(), 10.0, opt)         # fused into the step kernel (device-side norm, no rescale pass)
         opt.step()
         return total
 
-    for _ in range(max(1, args.warmup)):
-        last = step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        last = step()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    ms = elapsed / args.steps * 1e3
-    value = B * accum / (elapsed / args.steps)
-
+    ms, value, last = _timed_mirror_steps(step, args, B * accum)
     rec, gemm_ms, achieved = _mirror_gemm_roofline(ops, step, args.head_start, dev)
+    if rank != 0:
+        return
     out = {
         "metric": "samples/sec VL-BERT-large VCR Q->A fine-tuning step (4 answer choices, 256-position sequences, ResNet-101 image path, "
                   "SGD, gradient accumulation 4)",
-        "value": round(value, 2), "unit": "samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+        "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype_name,
         "data": "synthetic (random-init weights, random images / boxes / masks / tokens / tags, resident in HBM)",
         "config": {"workload": "BASELINE config 5 through the module mirror vl-bert_amd/vcr (cfgs/vcr/large_q2a_4x16G_fp16.yaml): 24 x 1024 encoder, "
                                "%d samples x %d choices per micro-batch, %d text + %d regions + END = %d positions, %dx%d images, "
                                "1fc sigmoid classifier + top-of-BERT CNN regulariser, clip 10, SGD momentum 0.9, %d micro-batches per "
                                "optimizer step; a step = one optimizer step" % (B, C, Lq + La + 3, R, Lq + La + 3 + R + 1, Hi, Wi, accum),
-                   "global_batch": B * accum, "per_gpu_batch": B * accum, "seq_len": Lq + La + 3 + R + 1, "parallelism": "dp1",
+                   "global_batch": B * accum * world, "per_gpu_batch": B * accum, "seq_len": Lq + La + 3 + R + 1, "parallelism": "dp%d" % world,
                    "arch": arch, "cus": cus},
         "roofline": {"bound": "mfma", "kernel": "all %d bf16 GEMM launches of one optimizer step (encoder: large-tile NT / TN cores; vision path: "
                                                "implicit-GEMM convolutions)" % len(rec),
@@ -519,14 +536,13 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    if args.vqa:
-        if world != 1:
-            raise SystemExit("--vqa runs the module mirror on one GPU (its data-parallel wrapper is the trainer's DDP, host glue that is not built)")
-        return bench_vqa(args)
-    if args.vcr:
-        if world != 1:
-            raise SystemExit("--vcr runs the module mirror on one GPU (its data-parallel wrapper is the trainer's DDP, host glue that is not built)")
-        return bench_vcr(args)
+    args.world, args.rank, args.dist = world, rank, dist
+    if args.vqa or args.vcr:
+        (bench_vqa if args.vqa else bench_vcr)(args)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     engine = importlib.import_module("vl-bert_amd.engine")
     syn = importlib.import_module("vl-bert_amd.synthetic")

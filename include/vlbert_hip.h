@@ -248,6 +248,8 @@ int vlb_dropout_bf16(const void* x, void* y, long n, float drop_p, const uint32_
 /* zero n ranges of one fp32 buffer in one launch: ranges (device) = n x {start, length} int64, block_start (device, n+1
  * int32) = running count of 1024-float blocks, block_start[n] == total_blocks.  Used for the gradients that are accumulated by
  * atomics (biases, LayerNorm parameters, small tables) when the GEMM weight gradients are written with accumulate = 0. */
+/* x[0..n) *= alpha: the 1 / world average of an all-reduced gradient handed back through autograd (parallel.DistributedDataParallel) */
+int vlb_scale_f32(float* x, long n, float alpha, vlb_stream_t stream);
 int vlb_zero_ranges_f32(float* base, const int64_t* ranges, const int32_t* block_start, int n, int total_blocks, vlb_stream_t stream);
 
 int vlb_sumsq_f32(const float* g, long n, float* out, vlb_stream_t stream);

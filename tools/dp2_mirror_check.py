@@ -1,0 +1,114 @@
+"""Two data-parallel ranks of a MODULE MIRROR (the VQA wrapper, BASELINE config 4's model class) on ONE MI355X over gloo:
+parallel.DistributedDataParallel against a hand-made all-reduce.
+Launch:  python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29512 tools/dp2_mirror_check.py
+Checks: (1) after a DDP backward every parameter gradient equals the average over the ranks of the gradients a local (no_sync)
+backward of the same forward produces, (2) both ranks hold identical parameters after two FusedAdamW steps with the fused clip,
+(3) no_sync() leaves the local gradients untouched."""
+import importlib
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+class A(dict):
+    __getattr__ = dict.__getitem__
+
+
+def config(H=128, L=2, nh=2, I=256, answers=50):
+    return A(DATASET=A(ANSWER_VOCAB_SIZE=answers),
+             NETWORK=A(IMAGE_FEAT_PRECOMPUTED=True, IMAGE_SEMANTIC=False, IMAGE_STRIDE_IN_1x1=True, IMAGE_C5_DILATED=True, IMAGE_NUM_LAYERS=101,
+                       OUTPUT_CONV5=False, IMAGE_FROZEN_BN=True, IMAGE_FROZEN_BACKBONE_STAGES=[1, 2], IMAGE_FINAL_DIM=H, BLIND=False,
+                       NO_GROUNDING=False, ENABLE_CNN_REG_LOSS=False, CLASSIFIER_TYPE="2fc", CLASSIFIER_HIDDEN_SIZE=128, CLASSIFIER_DROPOUT=0.0,
+                       CLASSIFIER_SIGMOID=False,
+                       VLBERT=A(hidden_size=H, visual_size=H, num_hidden_layers=L, num_attention_heads=nh, intermediate_size=I, vocab_size=400,
+                                max_position_embeddings=64, type_vocab_size=3, visual_ln=True, with_pooler=False, hidden_dropout_prob=0.0,
+                                attention_probs_dropout_prob=0.0, initializer_range=0.02, visual_scale_text_init=1.0,
+                                visual_scale_object_init=1.0, object_word_embed_mode=2)))
+
+
+def batch(B, R, Lq, seed, answers=50):
+    g = torch.Generator().manual_seed(seed)
+    x1, y1 = torch.rand(B, R, generator=g) * 300, torch.rand(B, R, generator=g) * 300
+    boxes = torch.cat((torch.stack((x1, y1, x1 + 50, y1 + 60), -1), torch.randn(B, R, 2048, generator=g).abs()), -1)
+    im_info = torch.tensor([[600.0, 500.0, 1.0, 1.0]] * B)
+    question = torch.randint(5, 400, (B, Lq), generator=g)
+    label = torch.zeros(B, answers)
+    label.scatter_(1, torch.randint(0, answers, (B, 2), generator=g), 1.0)
+    return [t.cuda() for t in (boxes, im_info, question, label)]
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    M = importlib.import_module("vl-bert_amd.vqa.modules.resnet_vlbert_for_vqa")
+    P = importlib.import_module("vl-bert_amd.parallel")
+    OPT = importlib.import_module("vl-bert_amd.optim")
+    torch.manual_seed(100 + rank)                      # different initial weights per rank: the wrapper must broadcast rank 0's
+    net = M.ResNetVLBERT(config(), device="cuda:0")
+    net.train()
+    net.image_feature_extractor.drop_p = 0.0           # (the hard-coded Dropout(0.1) of obj_downsample: the two passes compared below must
+    ddp = P.DistributedDataParallel(net)               #  compute the same function)
+    first = next(iter(net.parameters())).detach().clone()
+    other = first.clone()
+    dist.broadcast(other, src=0)
+    assert torch.equal(first, other), "start-up broadcast"
+    b = batch(4, 5, 9, 40 + rank)
+    params = [p for p in net.parameters() if p.requires_grad]
+    # local gradients (no exchange), then their average over the ranks by hand
+    for p in params:
+        p.grad = None
+    with ddp.no_sync():
+        _, loss = ddp(None, *b)
+        loss.backward()
+    torch.cuda.synchronize()
+    local = [p.grad.detach().clone() for p in params]
+    avg = []
+    for g in local:
+        t = g.clone()
+        dist.all_reduce(t)
+        avg.append(t / world)
+    # the same forward through the wrapper with the exchange on
+    for p in params:
+        p.grad.zero_()
+    _, loss = ddp(None, *b)
+    loss.backward()
+    torch.cuda.synchronize()
+    worst, names = (0.0, ""), [n for n, p in net.named_parameters() if p.requires_grad]
+    gmax = max(float(a.abs().max()) for a in avg)
+    for n, p, a, l in zip(names, params, avg, local):
+        # tensors that are zero by construction (the key bias: softmax is invariant to it) hold summation-order noise in both passes
+        scale = max(float(a.abs().max()), 1e-4 * gmax)
+        worst = max(worst, (float((p.grad - a).abs().max()) / scale, n))
+    print("rank %d: worst tensor %s" % (rank, worst[1]), flush=True)
+    worst = worst[0]
+    moved = max(float((p.grad - l).abs().max()) for p, l in zip(params, local))
+    print("rank %d: DDP gradient vs hand-averaged local gradients: worst max-rel difference %.2e over %d tensors (differs from the local "
+          "gradient by up to %.2e)" % (rank, worst, len(params), moved), flush=True)
+    # (two backward passes of one rank differ in fp32-atomic summation order)
+    assert worst < 2e-3 and moved > 0
+    opt = OPT.FusedAdamW(ddp.parameters(), lr=1e-3, eps=1e-6, weight_decay=1e-4)
+    for step in range(2):
+        opt.zero_grad(set_to_none=False)
+        _, loss = ddp(None, *batch(4, 5, 9, 60 + 10 * step + rank))
+        loss.backward()
+        OPT.clip_grad_norm_(ddp.parameters(), 1.0, opt)
+        opt.step()
+    torch.cuda.synchronize()
+    same = True
+    for p in params:
+        o = p.detach().clone()
+        dist.broadcast(o, src=0)
+        same = same and bool(torch.equal(o, p.detach()))
+    print("rank %d: parameters identical to rank 0 after 2 DDP steps: %s ; loss %.4f" % (rank, same, float(loss)), flush=True)
+    assert same
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

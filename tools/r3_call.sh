@@ -9,7 +9,8 @@ for what in "$@"; do
   case $what in
     tests)   timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -40 > $OUT/tests.log; tail -5 $OUT/tests.log ;;
     newtests) timeout 1500 python -m pytest tests -m gpu -q -k "24_layers or large_tile_kernels or batch_32 or ring or large_tile_core or layernorm_residual or sharded or overflow or two_ranks" 2>&1 | tail -60 > $OUT/newtests.log; tail -15 $OUT/newtests.log ;;
-    dptests) timeout 900 python -m pytest tests/test_dp_gpu.py -m gpu -q 2>&1 | tail -30 > $OUT/dptests.log; tail -6 $OUT/dptests.log ;;
+    dptests) timeout 900 python -m pytest tests/test_dp_gpu.py -m gpu -q 2>&1 | tail -30 > $OUT/dptests.log; tail -6 $OUT/dptests.log; grep -h "^rank" gpurun_out/dp_test_dp2_mirror*.log | tail -6; grep -h "Error\|assert" gpurun_out/dp_test_dp2_mirror*.log | head -8 ;;
+    vqadp)   python bench.py --vqa --gpus 2 --steps 2 --warmup 1 --no-cpu-baseline > $OUT/vqa_dp2.json 2> $OUT/vqa_dp2.err; cut -c1-400 $OUT/vqa_dp2.json; grep -v Gloo $OUT/vqa_dp2.err | tail -5 ;;
     f16)     timeout 1200 python -m pytest tests/test_f16_build_gpu.py -m gpu -q 2>&1 | tail -30 > $OUT/f16.log; tail -8 $OUT/f16.log; grep -E "Frobenius|passed|failed|FAILED|Error" gpurun_out/f16_suite.log | tail -30 ;;
     t24)     timeout 600 python -m pytest tests/test_engine_gpu.py -m gpu -q -s -k "24_layers" > $OUT/t24.log 2>&1; grep -E "Frobenius|passed|failed|per-layer|grad_norm|rel-fro|Error|assert" $OUT/t24.log | tail -25 ;;
     vcrtests) timeout 900 python -m pytest tests/test_vcr_gpu.py -m gpu -q -x -s > $OUT/vcrtests.log 2>&1; grep -E "passed|failed|FAILED|Error|fused clip|vcr " $OUT/vcrtests.log | tail -20 ;;

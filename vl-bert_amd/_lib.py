@@ -96,6 +96,7 @@ _SIGS = {
     "vlb_layernorm_f32_bwd": "plplppplplfpuppiis",
     "vlb_softmax_f32_fwd": "ppippiiifpus",
     "vlb_softmax_f32_bwd": "ppiiifpus",
+    "vlb_scale_f32": "plfs",
     "vlb_cast_f32_bf16": "ppls",
     "vlb_cast_bf16_f32": "ppls",
     "vlb_rng_advance": "ps",

@@ -174,6 +174,7 @@ class VisualLinguisticBert(nn.Module):
                                                      core_heads=self.WITH_HEADS, core_sequence=sequence,
                                                      seed=ops.rank_seed(1234) // 2,         # per-rank dropout stream
                                                      encoder_fp32=self.fp32_encoder))
+        eng._dp_hook = getattr(self, "_dp_hook", None)          # parallel.DistributedDataParallel: gradient buckets leave from backward
         version = self.flat.master._version
         if getattr(eng, "_synced_version", None) != version:
             eng.sync_weights()

@@ -443,6 +443,29 @@ extern "C" int vlb_cast_bf16_f32(const void* in, float* out, long n, hipStream_t
   return VLB_OK;
 }
 
+// x *= alpha (the 1 / world average of an all-reduced gradient that leaves through autograd's .grad tensors: the DistributedDataParallel
+// mirror of parallel.py; the engine's own data-parallel step folds the factor into the AdamW kernel instead)
+__global__ __launch_bounds__(256) void scale_f32_kernel(float* __restrict__ x, long n, float alpha) {
+  const long stride = (long)gridDim.x * 256 * 4;
+  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 3 < n && ((uintptr_t)(x + i) % 16) == 0) {
+      float4 v = *(float4*)(x + i);
+      v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha;
+      *(float4*)(x + i) = v;
+    } else {
+      for (long k = i; k < n && k < i + 4; ++k) x[k] *= alpha;
+    }
+  }
+}
+
+extern "C" int vlb_scale_f32(float* x, long n, float alpha, hipStream_t stream) {
+  if (n <= 0) return VLB_OK;
+  VLB_CHECK_ARG(x, "vlb_scale_f32: null argument");
+  hipLaunchKernelGGL(scale_f32_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, stream, x, n, alpha);
+  VLB_CHECK_LAUNCH("vlb_scale_f32");
+  return VLB_OK;
+}
+
 extern "C" int vlb_rng_advance(uint32_t* seed, hipStream_t stream) {
   VLB_CHECK_ARG(seed, "vlb_rng_advance: null seed");
   hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, stream, seed);

@@ -215,6 +215,7 @@ class PretrainEngine:
         d = self.dev
         import torch.distributed as dist
         world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self._own_flat = flat is None
         if flat is None:
             from .parallel import shard_alignment
             flat = FlatParams(cfg, d, align=shard_alignment(world))
@@ -404,7 +405,8 @@ class PretrainEngine:
         # sharded optimizer: the weight gather of the last update may still be in flight (forward waits per bucket); the transposed /
         # folded weight copies are refreshed once it has landed (backward / the next forward of the vision path)
         self._wT_stale = self._gather_pending = self._vision_stale = False
-        if world > 1:
+        self._dp_hook = None         # set by parallel.DistributedDataParallel on the engines of a module mirror (shared flat buffers)
+        if world > 1 and self._own_flat:
             from .parallel import GradBuckets
             vstart = min((o for n, o in self.P.offsets.items() if n.startswith("image_feature_extractor.") and
                           not n.startswith("image_feature_extractor.obj_downsample")), default=None)
@@ -802,6 +804,8 @@ class PretrainEngine:
 
     def backward(self, train=None, on_layer_done=None):
         will_launch = None
+        if on_layer_done is None and self._dp_hook is not None:
+            on_layer_done = self._dp_hook       # module mirror under parallel.DistributedDataParallel: exchange the flat gradient's buckets
         if on_layer_done is not None:       # a bucket is about to be reduced: the deferred LayerNorm parameter gradients first
             user_hook = on_layer_done
             will_launch = getattr(getattr(user_hook, "__self__", None), "will_launch", None)     # GradBuckets.on_done -> its predicate
@@ -1313,6 +1317,8 @@ class _SegmentedStep:
         if real is not None:
             if real.pending or real.launched:
                 raise RuntimeError("make_step_graph: a data-parallel exchange is in flight")
+            real.wait_params("all")          # weight gathers of the last eager step: let them land before anything is captured
+            torch.cuda.synchronize()
             eng.buckets = self._Recorder(real, self)
         try:
             self._begin()
@@ -1326,7 +1332,9 @@ class _SegmentedStep:
 
     def _begin(self):
         self._g = torch.cuda.CUDAGraph()
-        self._ctx = torch.cuda.graph(self._g, pool=self.pool, stream=self.stream)
+        # thread_local: the collective backend's helper threads (gloo's host copies, RCCL's proxy) keep making runtime calls while this
+        # thread captures; under the default "global" mode any of them invalidates the capture
+        self._ctx = torch.cuda.graph(self._g, pool=self.pool, stream=self.stream, capture_error_mode="thread_local")
         self._ctx.__enter__()
 
     def _end(self):

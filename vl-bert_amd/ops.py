@@ -410,6 +410,11 @@ def lr_schedule_step(state, kind, base_lr, warmup_steps=0, t_total=0):
               _stream())
 
 
+def scale_f32(x, alpha):
+    _lib.call("vlb_scale_f32", _p(x, torch.float32), x.numel(), float(alpha), _stream())
+    return x
+
+
 def cast_f32_bf16(src, dst):
     _lib.call("vlb_cast_f32_bf16", _p(src, torch.float32), _p(dst, BF16), src.numel(), _stream())
     return dst

@@ -77,7 +77,10 @@ class _FlatStateMixin:
                 n = sum(p.numel() for p in ps[a:b])
                 if total is None:
                     total = torch.zeros(1, dtype=torch.float32, device=first.device)
-                ops.sumsq(first.grad.as_strided((n,), (1,), first.grad.storage_offset()), total)
+                    if getattr(self, "_sumsq_ws", None) is None or self._sumsq_ws.device != first.device:
+                        self._sumsq_ws = torch.zeros(2048, dtype=torch.float32, device=first.device)
+                # fixed summation order: data-parallel replicas hold identical gradients and must derive the identical clip coefficient
+                ops.sumsq_det(first.grad.as_strided((n,), (1,), first.grad.storage_offset()), self._sumsq_ws, total)
         return total if total is not None else torch.zeros(1)
 
     def state_dict(self):

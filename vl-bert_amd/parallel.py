@@ -360,3 +360,104 @@ class GradBuckets:
             upto = self._gather_idx[self.layer_key[key]]
         while self._gathers and self._gathers[0][0] <= upto:
             self._gathers.pop(0)[1].wait()
+
+
+class DistributedDataParallel(torch.nn.Module):
+    """torch.nn.parallel.DistributedDataParallel for the module mirrors (vqa / vcr `ResNetVLBERT`, `VisualLinguisticBert*`): what the
+    reference's fine-tuning trainers wrap their model in (vqa/function/train.py:327, vcr/function/train.py:330).  After every backward
+    the gradients of all parameters are averaged over the ranks.
+
+    How, MI355X-first: the VL-BERT core's parameters live in ONE flat buffer whose backward is hand-scheduled (engine.backward), so its
+    gradient goes out in the same contiguous buckets as the pre-training engine's -- `GradBuckets` launched from the engine's layer
+    hooks, overlapped with the rest of the backward (fp32 all-reduce in place on the .grad storage).  The remaining parameters (region
+    feature projection, classifier, the ResNet path of the VCR model) are coalesced into one staging buffer when the backward pass
+    ends (autograd engine callback), all-reduced once and copied back.  The 1/world average is one HIP pass (vlb_scale_f32).
+    `no_sync()` skips the exchange for gradient-accumulation micro-steps, as torch's does."""
+
+    def __init__(self, module, device_ids=None, output_device=None, process_group=None, bucket_bytes=64 << 20):
+        super().__init__()
+        self.module = module
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.require_backward_grad_sync = True
+        self._cores = [m for m in module.modules() if hasattr(m, "flat") and hasattr(m, "_engine_for")]
+        self._buckets = []
+        self._flat_ids = set()
+        for core in self._cores:
+            core._prepare_grads()
+            fl = core.flat
+            self._buckets.append(GradBuckets(fl.grad, fl.offsets, fl.numel, core.cfg.num_hidden_layers, group=process_group,
+                                             bucket_bytes=bucket_bytes, wire_dtype=None, mode="allreduce"))
+            for p in core._pnames.values():
+                self._flat_ids.add(id(p))
+        self._rest = [p for p in module.parameters() if id(p) not in self._flat_ids and p.requires_grad]
+        self._stage = None
+        self._armed = False
+        # rank 0's parameters and buffers everywhere (DDP's start-up broadcast)
+        if self.world > 1:
+            with torch.no_grad():
+                for core in self._cores:
+                    dist.broadcast(core.flat.master, src=0, group=process_group)
+                    torch.autograd.graph.increment_version(core.flat.master)
+                for t in list(self._rest) + [b for b in module.buffers() if b.is_floating_point()]:
+                    dist.broadcast(t.data if t.is_contiguous() else t.data.contiguous(), src=0, group=process_group)
+
+    def no_sync(self):
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            old, self.require_backward_grad_sync = self.require_backward_grad_sync, False
+            try:
+                yield
+            finally:
+                self.require_backward_grad_sync = old
+        return ctx()
+
+    def _hook(self, k):
+        b = self._buckets[k]
+
+        def on_done(what):
+            if not self._armed:          # first hook of this backward: the finalizer runs when the autograd pass ends
+                self._armed = True
+                torch.autograd.Variable._execution_engine.queue_callback(self._finalize)
+            b.on_done(what)
+        on_done.__self__ = b             # engine.backward asks the hook's owner for its will_launch predicate
+        return on_done
+
+    def forward(self, *inputs, **kwargs):
+        sync = self.world > 1 and self.require_backward_grad_sync and torch.is_grad_enabled()
+        for k, core in enumerate(self._cores):
+            hook = self._hook(k) if sync else None
+            core._dp_hook = hook
+            for eng in core._engines.values():
+                eng._dp_hook = hook
+        return self.module(*inputs, **kwargs)
+
+    def _finalize(self):
+        from . import ops
+        self._armed = False
+        for b in self._buckets:
+            for key, _, _ in b.buckets:          # ranges the backward did not reach (a head that was not used) still take part
+                b.on_done(key)
+            b.wait()
+            ops.scale_f32(b.flat, 1.0 / self.world)
+        ps = [p for p in self._rest if p.grad is not None]
+        if ps:
+            n = sum(p.numel() for p in ps)
+            if self._stage is None or self._stage.numel() != n:
+                self._stage = torch.empty(n, dtype=torch.float32, device=ps[0].device)
+            views, off = [], 0
+            for p in ps:
+                views.append(self._stage[off:off + p.numel()].view_as(p.grad))
+                off += p.numel()
+            torch._foreach_copy_(views, [p.grad for p in ps])
+            dist.all_reduce(self._stage, group=self.group)
+            ops.scale_f32(self._stage, 1.0 / self.world)
+            torch._foreach_copy_([p.grad for p in ps], views)
+
+    def state_dict(self, *a, **k):
+        return self.module.state_dict(*a, **k)
+
+    def load_state_dict(self, *a, **k):
+        return self.module.load_state_dict(*a, **k)
