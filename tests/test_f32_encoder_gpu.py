@@ -238,3 +238,51 @@ def test_vqa_and_module_api_mirrors_on_the_fp32_encoder():
     assert r.returncode == 0, r.stdout[-3000:]
     m = re.search(r"(\d+) passed", r.stdout)
     assert m and int(m.group(1)) >= 5
+
+
+def test_module_api_inspection_forms_all_layers_and_attention_probs():
+    """VisualLinguisticBert.forward(output_all_encoded_layers=True / output_attention_probs=True) (reference :131-171, its viz/ scripts):
+    every layer's output and every layer's attention probabilities through the fp32 encoder path.  Checks: the last layer agrees with
+    the default call form and with the oracle; probabilities are a masked softmax (rows sum to 1, padded keys get 0); layer 0's
+    probabilities equal softmax(Q K^T / 8 + mask) recomputed in fp64 from the layer's own input and weights; the separate
+    text / object form places the objects as the reference's masked scatter does."""
+    from tests.test_engine_gpu import _core_fixture, _module_config
+    VL = pkg("common.visual_linguistic_bert")
+    z, cfg, params, ins = _core_fixture()
+    net = VL.VisualLinguisticBert(_module_config(cfg)["NETWORK"]["VLBERT"])
+    net.load_state_dict({k: v for k, v in params.items() if not k.startswith(("mlm_head.", "mvrc_head."))})
+    net.eval()
+    layers, pooled, probs = net(*ins, output_all_encoded_layers=True, output_attention_probs=True)
+    L, nh, H = cfg.num_hidden_layers, cfg.num_attention_heads, cfg.hidden_size
+    assert len(layers) == L and len(probs) == L and pooled is None
+    B, n = layers[0].shape[0], layers[0].shape[1]
+    assert probs[0].shape == (B, nh, n, n)
+    seq, _ = net(*ins, output_all_encoded_layers=False)
+    report("inspection: last layer vs the default call form", layers[-1], seq[:, :n], 2e-3, 1.5e-2)
+    p = O.init_params(cfg, seed=int(z["pseed"]))
+    rt, ro, _, _ = O.vlbert_forward(p, cfg, *[t.cpu() for t in ins], False)
+    T = ins[0].shape[1]
+    tm = ins[3].cpu().unsqueeze(-1).float()
+    report("inspection: last layer (text part) vs oracle", layers[-1][:, :T].cpu() * tm[:, :min(T, n)], (rt * tm)[:, :n], 2e-3, 1.5e-2)
+    # masked softmax properties
+    eng = net._engines[("inspect", B, T, ins[4].shape[1])]
+    valid = eng.lay["attn_mask"].view(B, eng.S)[:, :n].bool()                       # [B, n] keys that may be attended
+    for l in range(L):
+        pr = probs[l]
+        assert float((pr.sum(-1) - 1.0).abs().max()) < 1e-5
+        assert float((pr * (~valid)[:, None, None, :]).abs().max()) == 0.0
+    # layer 0 recomputed from its input
+    x0 = eng.enc32.X[0].double().view(B, eng.S, H)[:, :n]
+    wq, wk = p["vlbert.encoder.layer.0.attention.self.query.weight"].double().to(dev()), p["vlbert.encoder.layer.0.attention.self.key.weight"].double().to(dev())
+    bq, bk = p["vlbert.encoder.layer.0.attention.self.query.bias"].double().to(dev()), p["vlbert.encoder.layer.0.attention.self.key.bias"].double().to(dev())
+    q = (x0 @ wq.t() + bq).view(B, n, nh, 64).transpose(1, 2)
+    k = (x0 @ wk.t() + bk).view(B, n, nh, 64).transpose(1, 2)
+    sc = q @ k.transpose(-1, -2) / 8.0 + ((~valid).double() * -10000.0)[:, None, None, :]
+    ref = torch.softmax(sc, -1)
+    err = float((probs[0].double() - ref).abs().max())
+    print("inspection: layer-0 attention probabilities vs fp64 recomputation: max abs err %.2e" % err)
+    assert err < 2e-5
+    # separate text / object form, last layer only + pooled None
+    t_out, o_out, pooled = net(*ins, output_all_encoded_layers=True, output_text_and_object_separately=True)
+    assert len(t_out) == L and t_out[-1].shape[1] == T and o_out[-1].shape[1] == ins[4].shape[1]
+    report("inspection: object rows vs oracle", o_out[-1], ro, 2e-3, 1.5e-2)

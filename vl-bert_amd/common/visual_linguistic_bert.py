@@ -204,7 +204,8 @@ class VisualLinguisticBert(nn.Module):
     def forward(self, text_input_ids, text_token_type_ids, text_visual_embeddings, text_mask, object_vl_embeddings, object_mask,
                 output_all_encoded_layers=True, output_text_and_object_separately=False, output_attention_probs=False):
         if output_all_encoded_layers or output_attention_probs:
-            raise NotImplementedError("supported call forms: output_all_encoded_layers=False, output_attention_probs=False")
+            return self._inspect(text_input_ids, text_token_type_ids, text_visual_embeddings, text_mask, object_vl_embeddings, object_mask,
+                                 output_all_encoded_layers, output_text_and_object_separately, output_attention_probs)
         if not output_text_and_object_separately:     # VQA / VCR callers: (sequence_output, pooled_output)  (:139-171)
             seq, _, pooled = self._run(text_input_ids, text_token_type_ids, text_visual_embeddings, text_mask,
                                        object_vl_embeddings, object_mask, sequence=True)
@@ -212,6 +213,49 @@ class VisualLinguisticBert(nn.Module):
         text_out, obj_out, pooled = self._run(text_input_ids, text_token_type_ids, text_visual_embeddings, text_mask,
                                               object_vl_embeddings, object_mask)
         return text_out, obj_out, (pooled if self.with_pooler else None)
+
+    @torch.no_grad()
+    def _inspect(self, text_input_ids, text_token_type_ids, text_visual_embeddings, text_mask, object_vl_embeddings, object_mask,
+                 all_layers, separately, probs):
+        """The inspection call forms of the reference (:131-171; its viz/ scripts): every encoder layer's output and / or the attention
+        probabilities [B, heads, S, S] of every layer.  The fused 16-bit attention kernel never materialises the probabilities; the fp32
+        encoder path (../encoder_f32.py) keeps them per layer for its backward, so these forms run through it -- forward only, fp32,
+        returned WITHOUT autograd history (train with the default call forms)."""
+        B, T = text_input_ids.shape
+        R = object_vl_embeddings.shape[1]
+        key = ("inspect", B, T, R)
+        eng = lru_get(self._engines, key, lambda: _engine.PretrainEngine(self.cfg, B, T, R, device=str(self.device_), flat=self.flat, core=True,
+                                                                         core_heads=False, core_sequence=True,
+                                                                         seed=ops.rank_seed(1234) // 2, encoder_fp32=True))
+        version = self.flat.master._version
+        if getattr(eng, "_synced_version", None) != version:
+            eng.sync_weights()
+            eng._synced_version = version
+        eng._weights_dirty = False
+        eng.set_core_inputs(text_input_ids, text_token_type_ids, text_visual_embeddings, text_mask, object_vl_embeddings, object_mask)
+        eng.mirror_pre_forward(self.training)
+        eng.forward_core(train=self.training)
+        enc, H, S, L, nh = eng.enc32, self.cfg.hidden_size, eng.S, self.cfg.num_hidden_layers, self.cfg.num_attention_heads
+        n = int((eng.lay["text_len"] + eng.lay["nobj"]).max()) + 1          # the batch's longest packed sequence (:202)
+        layers = [enc.X[l + 1].view(B, S, H)[:, :n].clone() for l in (range(L) if all_layers else [L - 1])]
+        pooled = eng.pooled.float().clone() if self.with_pooler else None
+        out_probs = None
+        if probs:
+            p_a = self.cfg.attention_probs_dropout_prob if self.training else 0.0
+            src = enc.Pd if (p_a > 0 and enc.Pd is not None) else enc.P      # the reference returns them after their dropout
+            out_probs = [src[l].view(B, nh, S, enc.Sp)[:, :, :n, :n].clone() for l in range(L)]
+        if separately:
+            rows = eng.lay["obj_rows"][:B].long()                            # packed row of object r of sample b, -1 = no object
+            texts, objs = [], []
+            for l in (range(L) if all_layers else [L - 1]):
+                full = enc.X[l + 1]
+                texts.append(full.view(B, S, H)[:, :T].clone())
+                objs.append(full[rows.clamp(min=0).view(-1)].view(B, R, H) * (rows >= 0).unsqueeze(-1))
+            if not all_layers:
+                texts, objs = texts[0], objs[0]
+            return (texts, objs, pooled, out_probs) if probs else (texts, objs, pooled)
+        enc_out = layers if all_layers else layers[0]
+        return (enc_out, pooled, out_probs) if probs else (enc_out, pooled)
 
 
 class VisualLinguisticBertForPretraining(VisualLinguisticBert):

@@ -330,11 +330,12 @@ class PretrainEngine:
         # MLM head compaction (DESIGN.md "MLM head"): ~85 % of the text positions carry no label -- their logits are never read by the
         # loss and their d(logits) rows are exactly zero -- so transform -> LayerNorm -> decoder and the head's whole backward run on
         # the labelled rows only, gathered into the first `mlm_cap` rows of the same buffers.  Capacity is a contract with the data
-        # pipeline (BERT masking labels 15 % of the valid tokens): 25 % of the B*T positions; a batch that exceeds it raises (the
+        # pipeline (BERT masking labels 15 % of the valid tokens; at 16384 positions 20 % is 17 standard deviations away): 20 % of the B*T
+        # positions rounded up to 256; a batch that exceeds it raises (the
         # device flag is checked at loss_values(); labels handed over as CPU tensors are counted exactly and such a batch simply
         # takes the full path).  Off with keep_logits (the module mirrors return every logit) and in module-API mode.
         import os as _os1
-        cap = min(self.BTp, max(256, _ru(int(math.ceil(0.25 * BT)), 256)))
+        cap = min(self.BTp, max(256, _ru(int(math.ceil(0.20 * BT)), 256)))
         want = _os1.environ.get("VLB_MLM_COMPACT", "1") != "0" and not keep_logits and not core and cap < BT
         self.mlm_cap = cap if want else None
         self._mlm_compact_now = want
