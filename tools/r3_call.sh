@@ -18,6 +18,7 @@ for what in "$@"; do
     f32tests) timeout 1500 python -m pytest tests/test_f32_encoder_gpu.py -m gpu -q -x -s > $OUT/f32tests.log 2>&1; grep -E "passed|failed|FAILED|Error|error|max rel err|Frobenius|fp32 encoder|assert" $OUT/f32tests.log | tail -40 ;;
     vqa32)   python bench.py --vqa --precision fp32 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/vqa_fp32.json 2> $OUT/vqa_fp32.err; cut -c1-2500 $OUT/vqa_fp32.json; tail -3 $OUT/vqa_fp32.err
              python bench.py --vqa --precision f16 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/vqa_f16.json 2> $OUT/vqa_f16.err; cut -c1-300 $OUT/vqa_f16.json; tail -3 $OUT/vqa_f16.err ;;
+    prof32)  cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/prof32 -o r -- python $GRAFT_REPO_ROOT/bench.py --vqa --precision fp32 --steps 2 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/prof32.log 2>&1; cd $GRAFT_REPO_ROOT; python tools/kstats.py $OUT/prof32 4 30 | tee $OUT/prof32_kstats.txt; rm -rf $OUT/prof32 ;;
     bench)   python bench.py --no-cpu-baseline > $OUT/bench256.json 2> $OUT/bench256.err; cut -c1-400 $OUT/bench256.json ;;
     small)   for b in 128 64 32; do python bench.py --no-cpu-baseline --global-batch $b --no-phase-times > $OUT/bench$b.json 2> $OUT/bench$b.err; python -c "import json;d=json.load(open('$OUT/bench$b.json'));print($b, d['ms_per_step'], d['roofline']['frac'], d['roofline']['by_op']['host_launch_ms_whole_step'])"; done ;;
     graph)   for b in 256 32; do python bench.py --no-cpu-baseline --global-batch $b --no-phase-times --graph > $OUT/benchg$b.json 2> $OUT/benchg$b.err; python -c "import json;d=json.load(open('$OUT/benchg$b.json'));print('graph',$b, d['ms_per_step'])"; done ;;

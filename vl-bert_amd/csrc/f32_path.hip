@@ -21,6 +21,8 @@
 // register-staged double buffering): this path exists for precision; the bf16 / fp16 builds are the fast ones.
 #include <math.h>
 
+#include <type_traits>
+
 #include "vlb_common.h"
 
 namespace {
@@ -51,7 +53,7 @@ struct F32Gemm {
   int k_per_split;
 };
 
-constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int BN = 128, BK = 32;      // BM = 32 * FM rows (FM = 4: 128-row tiles; FM = 2: 64-row tiles for launches that would leave CUs idle)
 
 // fp32 tile rows -> (h, m) bf16 planes in LDS.  Row image: 128 B = 8 chunks of 16 B: logical chunks 0-3 = h of k [8c, 8c+8),
 // 4-7 = m of the same k; physical slot = logical ^ ((row >> 1) & 7) (conflict-free ds_read_b128 of 16 rows, as in gemm.hip).
@@ -64,10 +66,12 @@ __device__ __forceinline__ void split_store(char* tile, int row, int kc, const f
   *(uint4*)(tile + row * 128 + (((kc + 4) ^ sw) << 4)) = make_uint4(m0, m1, m2, m3);
 }
 
+template <int FM>
 __global__ __launch_bounds__(256, 2) void gemm_f32_split_kernel(const F32Gemm p) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * (BM + BN) * 128];      // 2 stages x (A 16 KiB + B 16 KiB)
+  constexpr int BM = 32 * FM, NA = FM / 2;                                       // NA staging items of A per thread
+  __shared__ __attribute__((aligned(16))) char smem[2 * (BM + BN) * 128];      // 2 stages x (A 16 / 8 KiB + B 16 KiB)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;                                       // 2 x 2 waves of 64 x 64
+  const int wm = wave >> 1, wn = wave & 1;                                       // 2 x 2 waves of (16 FM) x 64
   const int ntm = (p.M + BM - 1) / BM;
   const int tm = blockIdx.x % ntm, tn = blockIdx.x / ntm;                        // consecutive blocks share the B panel
   const int m0 = tm * BM, n0 = tn * BN;
@@ -89,50 +93,54 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_kernel(const F32Gemm p)
     const int P = it * 256 + tid;
     s_row[it] = P >> 2;
     s_kc[it] = P & 3;
-    a_src[it] = A + (long)min(m0 + s_row[it], p.M - 1) * p.lda + k_begin + s_kc[it] * 8;
+    a_src[it] = A + (long)min(m0 + (s_row[it] & (BM - 1)), p.M - 1) * p.lda + k_begin + s_kc[it] * 8;
     b_src[it] = B + (long)min(n0 + s_row[it], p.N - 1) * p.ldb + k_begin + s_kc[it] * 8;
   }
-  float4 ra[2][2], rb[2][2];
-  auto fetch = [&](int kt) {
+  // register staging, TWO K tiles deep: tile kt+2 is requested while tile kt is multiplied and tile kt+1 (already in registers) waits
+  // to be split into the other LDS buffer -- with one tile in flight the kernel was bound by memory-level parallelism (64 B per thread
+  // outstanding against ~2 us of L2 latency)
+  float4 ra[2][2][2], rb[2][2][2];
+  auto fetch = [&](auto set_c, int kt) {
+    constexpr int SET = decltype(set_c)::value;
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
-      ra[it][0] = *(const float4*)(a_src[it] + kt * BK);
-      ra[it][1] = *(const float4*)(a_src[it] + kt * BK + 4);
-      rb[it][0] = *(const float4*)(b_src[it] + kt * BK);
-      rb[it][1] = *(const float4*)(b_src[it] + kt * BK + 4);
+      if (it < NA) {
+        ra[SET][it][0] = *(const float4*)(a_src[it] + kt * BK);
+        ra[SET][it][1] = *(const float4*)(a_src[it] + kt * BK + 4);
+      }
+      rb[SET][it][0] = *(const float4*)(b_src[it] + kt * BK);
+      rb[SET][it][1] = *(const float4*)(b_src[it] + kt * BK + 4);
     }
   };
-  auto store = [&](int buf) {
+  auto store = [&](auto set_c, int buf) {
+    constexpr int SET = decltype(set_c)::value;
     char* sa = smem + buf * (BM + BN) * 128;
     char* sb = sa + BM * 128;
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
-      split_store(sa, s_row[it], s_kc[it], ra[it][0], ra[it][1]);
-      split_store(sb, s_row[it], s_kc[it], rb[it][0], rb[it][1]);
+      if (it < NA) split_store(sa, s_row[it], s_kc[it], ra[SET][it][0], ra[SET][it][1]);
+      split_store(sb, s_row[it], s_kc[it], rb[SET][it][0], rb[SET][it][1]);
     }
   };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
 
-  f32x4 acc[4][4];
+  f32x4 acc[FM][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < FM; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int frow = lane & 15;
   const int c0 = (((lane >> 4) ^ (frow >> 1)) << 4);          // h plane of this lane's k group; the m plane is c0 ^ 64
-  const int a_off = (wm * 64 + frow) * 128 + c0;
+  const int a_off = (wm * 16 * FM + frow) * 128 + c0;
   const int b_off = (wn * 64 + frow) * 128 + c0;
 
-  fetch(0);
-  store(0);
-  __syncthreads();
-  int buf = 0;
-  for (int kt = 0; kt < ntk; ++kt) {
-    if (kt + 1 < ntk) fetch(kt + 1);                            // next tile's global loads fly under this tile's MFMAs
+  auto compute = [&](int buf) {
     const char* sa = smem + buf * (BM + BN) * 128;
     const char* sb = sa + BM * 128;
-    tbf16x8 ah[4], am[4], bh[4], bm[4];
+    tbf16x8 ah[FM], am[FM], bh[4], bm[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < FM; ++i) {
       ah[i] = *(const tbf16x8*)(sa + a_off + i * 16 * 128);
       am[i] = *(const tbf16x8*)(sa + ((a_off + i * 16 * 128) ^ 64));
     }
@@ -142,17 +150,33 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_kernel(const F32Gemm p)
       bm[j] = *(const tbf16x8*)(sb + ((b_off + j * 16 * 128) ^ 64));
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < FM; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {        // small terms first, then the leading one
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm[j], ah[i], acc[i][j], 0, 0, 0);
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], am[i], acc[i][j], 0, 0, 0);
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah[i], acc[i][j], 0, 0, 0);
       }
+  };
+  // tile kt lives in LDS buffer kt & 1 and came through register set kt & 1
+  fetch(S0{}, 0);
+  if (ntk > 1) fetch(S1{}, 1);
+  store(S0{}, 0);
+  __syncthreads();
+  for (int kt = 0; kt < ntk; kt += 2) {
+    // even tile kt: buffer 0; registers: set 1 holds tile kt+1, set 0 is free for tile kt+2
+    if (kt + 2 < ntk) fetch(S0{}, kt + 2);
+    compute(0);
     if (kt + 1 < ntk) {
-      store(buf ^ 1);
+      store(S1{}, 1);
       __syncthreads();
-      buf ^= 1;
+      // odd tile kt+1: buffer 1; set 0 holds tile kt+2, set 1 is free for tile kt+3
+      if (kt + 3 < ntk) fetch(S1{}, kt + 3);
+      compute(1);
+      if (kt + 2 < ntk) {
+        store(S0{}, 0);
+        __syncthreads();
+      }
     }
   }
 
@@ -160,8 +184,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_kernel(const F32Gemm p)
   const uint32_t seed = p.drop_thr ? *p.seed : 0u;
   const float* bias = p.bias ? p.bias + i1 * p.sBias1 : nullptr;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+  for (int i = 0; i < FM; ++i) {
+    const int m = m0 + wm * 16 * FM + i * 16 + (lane & 15);
     if (m >= p.M) continue;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -170,8 +194,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_kernel(const F32Gemm p)
       float v[4] = {acc[i][j][0] * p.alpha, acc[i][j][1] * p.alpha, acc[i][j][2] * p.alpha, acc[i][j][3] * p.alpha};
       if (p.atomic) {
         float* c = C + (long)m * p.ldc + n;
+        if (gridDim.y == 1) {                 // a single K slice owns the element: plain read-modify-write
+          float4 o = *(float4*)c;
+          o.x += v[0]; o.y += v[1]; o.z += v[2]; o.w += v[3];
+          *(float4*)c = o;
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) atomicAdd(c + e, v[e]);
+          for (int e = 0; e < 4; ++e) atomicAdd(c + e, v[e]);
+        }
         continue;
       }
       if (bias) {
@@ -337,13 +367,27 @@ __global__ __launch_bounds__(256) void ln_f32_bwd_kernel(const float* __restrict
       }
     }
   }
+  // the four waves' partial sums -> LDS -> one atomic per column per WORKGROUP (a flush per wave made the atomics, not the row pass,
+  // the cost of this kernel: 82 us for 3664 x 1024 rows)
+  __shared__ float red[4][2][256 * LN_IT / 2];      // [wave][gamma | beta][column], H <= 1024 per pass
+  const int wv = threadIdx.x >> 6;
+  for (int base = 0; base < H; base += 1024) {
 #pragma unroll
-  for (int i = 0; i < LN_IT; ++i) {
-    const int c = (lane + 64 * i) * 4;
-    if (c < H) {
-      if (dgamma) { atomicAdd(dgamma + c, pg[i].x); atomicAdd(dgamma + c + 1, pg[i].y); atomicAdd(dgamma + c + 2, pg[i].z); atomicAdd(dgamma + c + 3, pg[i].w); }
-      if (dbeta) { atomicAdd(dbeta + c, pb[i].x); atomicAdd(dbeta + c + 1, pb[i].y); atomicAdd(dbeta + c + 2, pb[i].z); atomicAdd(dbeta + c + 3, pb[i].w); }
+    for (int i = 0; i < LN_IT; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      if (c >= base && c < base + 1024 && c < H) {
+        *(float4*)&red[wv][0][c - base] = pg[i];
+        *(float4*)&red[wv][1][c - base] = pb[i];
+      }
     }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 1024 && base + c < H; c += 256) {
+      const float sg = (red[0][0][c] + red[1][0][c]) + (red[2][0][c] + red[3][0][c]);
+      const float sb = (red[0][1][c] + red[1][1][c]) + (red[2][1][c] + red[3][1][c]);
+      if (dgamma) atomicAdd(dgamma + base + c, sg);
+      if (dbeta) atomicAdd(dbeta + base + c, sb);
+    }
+    __syncthreads();
   }
 }
 
@@ -456,8 +500,14 @@ extern "C" int vlb_gemm_nt_f32(const float* A, long lda, const float* B, long ld
   const int per = vlb_cdiv(ktiles, splits);
   splits = vlb_cdiv(ktiles, per);
   p.k_per_split = per * 32;
-  const int tiles = vlb_cdiv(M, 128) * vlb_cdiv(N, 128);
-  hipLaunchKernelGGL(gemm_f32_split_kernel, dim3(tiles, splits, nb1 * nb2), dim3(256), 0, stream, p);
+  // tile height: 128 rows, or 64 when the launch would not give the 512 resident workgroups (2 per CU) a full round -- the N = 1024
+  // GEMMs of a 16-sample micro-batch (M = 3664): 232 tiles of 128 rows vs 464 of 64
+  const long wgs128 = (long)vlb_cdiv(M, 128) * vlb_cdiv(N, 128) * splits * nb1 * nb2;
+  if (wgs128 < 460 && M > 64) {
+    hipLaunchKernelGGL(gemm_f32_split_kernel<2>, dim3(vlb_cdiv(M, 64) * vlb_cdiv(N, 128), splits, nb1 * nb2), dim3(256), 0, stream, p);
+  } else {
+    hipLaunchKernelGGL(gemm_f32_split_kernel<4>, dim3(vlb_cdiv(M, 128) * vlb_cdiv(N, 128), splits, nb1 * nb2), dim3(256), 0, stream, p);
+  }
   VLB_CHECK_LAUNCH("vlb_gemm_nt_f32");
   return VLB_OK;
 }
@@ -494,7 +544,7 @@ extern "C" int vlb_layernorm_f32_bwd(const float* dy, long lddy, const float* x,
                 "vlb_layernorm_f32_bwd: unsupported H=%d / strides", H);
   VLB_CHECK_ARG(!(drop_p > 0.f) || seed, "vlb_layernorm_f32_bwd: dropout needs a device seed pointer");
   VLB_CHECK_ARG((long)rows * H < (1L << 32), "vlb_layernorm_f32_bwd: dropout index overflow");
-  int blocks = vlb_cdiv(rows, 32);
+  int blocks = vlb_cdiv(rows, 8);           // >= 2 rows per wave, at most two workgroups per CU
   if (blocks > 512) blocks = 512;
   if (blocks < 1) blocks = 1;
   const uint32_t thr = vlb_drop_thr(drop_p);

@@ -15,8 +15,9 @@ roundings per layer in a 16-bit build -- see none.  Measured: tests/test_f32_enc
 Attention is composed from the batched GEMM: scores = Q.K^T / 8 per (sample, head) -> softmax (+ key mask, + dropout) -> P.V with V
 transposed per head; the backward is the five products of the same shapes.  The probabilities are kept per layer ([B, h, S, Sp] fp32:
 54 MB per layer at 16 x 229 -- 1.3 GB for 24 layers, nothing against 288 GB).
-Weight gradients: dW += dY^T.X as an NT product of the two transposed operands (zero-padded to a multiple of 32 rows), split over K and
-accumulated with fp32 atomics into the engine's flat gradient; bias gradients are the column sums taken by the transpose of dY.
+Weight gradients: dW += dY^T.X as an NT product of the two transposed operands (zero-padded to a multiple of 32 rows), accumulated into
+the engine's flat gradient by a plain read-modify-write (one K slice; two slices with fp32 atomics only for the 1024 x 1024 outputs
+that would otherwise occupy a quarter of the chip); bias gradients are the column sums taken by the transpose of dY.
 """
 import torch
 
@@ -117,9 +118,10 @@ class EncoderF32:
         M, Mp = self.M, self.Mp
         ops.transpose_f32(dy, N, self.tG, Mp, M, N, Mp, colsum=gb)
         ops.transpose_f32(x, K, self.tA, Mp, M, K, Mp)
+        # K slices only where the output has too few tiles to occupy the chip: fp32 atomics cost more than idle CUs (measured,
+        # tools/f32_gemm_bench.py: 4096 x 1024 x 3680 -- 131 us with one slice (plain read-modify-write), 186 / 226 / 268 us with 2 / 3 / 4)
         tiles = ((N + 127) // 128) * ((K + 127) // 128)
-        splitk = max(1, min(Mp // 128, (768 + tiles - 1) // tiles))
-        ops.gemm_nt_f32(self.tG, Mp, self.tA, Mp, gw, K, N, K, Mp, atomic=True, splitk=splitk)
+        ops.gemm_nt_f32(self.tG, Mp, self.tA, Mp, gw, K, N, K, Mp, atomic=True, splitk=1 if tiles >= 128 else 2)
 
     # -- forward ------------------------------------------------------------------------------------------------------
     def forward(self, p_h, p_a):
