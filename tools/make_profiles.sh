@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (through gpurun): rocprofv3 passes over the default bench workload; summaries -> gpurun_out/summary/<tag>_*
-# (copy them into profiles/), logs -> gpurun_out/final_*.log.  Usage: tools/make_profiles.sh [tag]
+# (copy them into profiles/), logs -> gpurun_out/final_*.log.  Usage: VLB_COMMIT=<hash> tools/make_profiles.sh [tag]   (the hash stamps <tag>_gemm_traffic.json)
 #   1. --kernel-trace --stats            : per-kernel time
 #   2. --kernel-trace --pmc <SQ set>     : wave / MFMA / LDS counters          (separate pass, kernel-trace only)
 #   3. --kernel-trace --pmc FETCH_SIZE   : HBM-side read bytes                 (separate pass)
@@ -26,7 +26,7 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/final_e2e_fetch" -o r -- $CMD
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/final_e2e_write" -o r -- $CMD --e2e > "$OUT/final_e2e_write.log" 2>&1
 # summarise on the box and drop the raw rocpd databases (five of them exceed the 64 MiB that gpurun copies back)
 mkdir -p "$OUT/summary"
-python "$ROOT/tools/profile_report.py" "$OUT" "$OUT/summary" "${1:-r02}"
+python "$ROOT/tools/profile_report.py" "$OUT" "$OUT/summary" "${1:-r03}"
 rm -rf "$OUT"/final_trace "$OUT"/final_sq "$OUT"/final_fetch "$OUT"/final_write "$OUT"/final_e2e_trace "$OUT"/final_e2e_sq "$OUT"/final_e2e_fetch "$OUT"/final_e2e_write
 grep '"metric"' "$OUT/final_trace.log" | tail -1 | cut -c1-200
 grep '"metric"' "$OUT/final_e2e_trace.log" | tail -1 | cut -c1-200

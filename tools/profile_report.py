@@ -177,6 +177,7 @@ n = sum(t["launches_per_step"] for t in g)
 out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), tools/make_profiles.sh + tools/profile_report.py",
        "correction": "read = 2 x FETCH_SIZE (gfx950, 16 B/lane streaming reads); WRITE_SIZE as reported",
        "workload": "bench.py default (global batch 256, 1 GPU)",
+       "commit": os.environ.get("VLB_COMMIT", "unknown"),
        "gemm_launches_per_step": n,
        "gemm_hbm_GB_per_launch": sum((t["read_MB_per_launch"] + t["write_MB_per_launch"]) * t["launches_per_step"] for t in g) / n / 1e3,
        "families": traffic}
