@@ -1659,7 +1659,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_group_kernel(const SplitkRe
         const float4 o = *(const float4*)c;
         a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
       }
-      *(float4*)c = a;
+      vlb_store_nt((float4*)c, a);          // weight gradients are next read by the optimizer: keep them out of the caches
     } else {
       const float av[4] = {a.x, a.y, a.z, a.w};
       for (int r = 0; r < 4 && n + r < N; ++r) c[r] = accumulate ? c[r] + av[r] : av[r];

@@ -90,8 +90,10 @@ __device__ __forceinline__ void p8_epilogue8(const GemmParams& p, float (&v)[8],
       v[e] = g2.x; v[e + 1] = g2.y;
       d[e] = d2.x; d[e + 1] = d2.y;
     }
-    if (p.pre)
-      *(uint4*)(p.pre + (long)m * p.ldpre + n) = make_uint4(pack2bf(d[0], d[1]), pack2bf(d[2], d[3]), pack2bf(d[4], d[5]), pack2bf(d[6], d[7]));
+    if (p.pre) {
+      const uint4 dv = make_uint4(pack2bf(d[0], d[1]), pack2bf(d[2], d[3]), pack2bf(d[4], d[5]), pack2bf(d[6], d[7]));
+      vlb_store_nt((uint4*)(p.pre + (long)m * p.ldpre + n), dv);      // GELU' is next read in the backward pass
+    }
   } else if (EPI == 2) {
     v[0] *= bflo(side.x); v[1] *= bfhi(side.x); v[2] *= bflo(side.y); v[3] *= bfhi(side.y);
     v[4] *= bflo(side.z); v[5] *= bfhi(side.z); v[6] *= bflo(side.w); v[7] *= bfhi(side.w);
@@ -229,7 +231,7 @@ __device__ __forceinline__ void p8_drain(const GemmParams& p, f32x4 (&acc)[2 * F
     if constexpr (SIDE) {
       const int m = row_of(r, pp);
       if (frag_valid(r, pp) && m < p.M && full8) {
-        if (EPI == 2 || EPI == 10) sd = *(const uint4*)(p.aux + (long)m * p.ldaux + n);
+        if (EPI == 2 || EPI == 10) sd = vlb_load_nt((const uint4*)(p.aux + (long)m * p.ldaux + n));      // read exactly once
         else sd = *(const uint4*)(p.res + (long)m * p.ldres + n);
       }
     }

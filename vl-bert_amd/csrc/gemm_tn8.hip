@@ -361,12 +361,13 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(const Tn8Group grp) {
           float* c = C + (long)m * ldc + n;
           const f32x4 v = acc[R_][cj];
           if (n + 3 < No) {
+            float4 o4 = make_float4(v[0], v[1], v[2], v[3]);
             if (accum) {
               const float4 o = *(const float4*)c;
-              *(float4*)c = make_float4(o.x + v[0], o.y + v[1], o.z + v[2], o.w + v[3]);
-            } else {
-              *(float4*)c = make_float4(v[0], v[1], v[2], v[3]);
+              o4 = make_float4(o.x + v[0], o.y + v[1], o.z + v[2], o.w + v[3]);
             }
+            if (d.c_split_stride == 0) vlb_store_nt((float4*)c, o4);      // the gradient itself (next read by the optimizer): streaming store
+            else *(float4*)c = o4;                                          // a K-slice slab: re-read by the reduce kernel right away
           } else {
             for (int r = 0; r < 4 && n + r < No; ++r) c[r] = accum ? c[r] + v[r] : v[r];
           }

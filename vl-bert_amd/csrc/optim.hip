@@ -95,8 +95,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
     float pv[4], gv[4], mv[4], vv[4];
     const bool full = (i + 3 < n);
-    if (full) {
-      const float4 a = *(const float4*)(p + i), b = load_grad4(g, i), c = *(const float4*)(m + i), d = *(const float4*)(v + i);
+    if (full) {      // p, m, v are touched once per step: streaming accesses (they would only evict the weights the next forward reads)
+      const float4 a = vlb_load_nt((const float4*)(p + i)), b = load_grad4(g, i), c = vlb_load_nt((const float4*)(m + i)),
+                   d = vlb_load_nt((const float4*)(v + i));
       pv[0] = a.x; pv[1] = a.y; pv[2] = a.z; pv[3] = a.w;
       gv[0] = b.x; gv[1] = b.y; gv[2] = b.z; gv[3] = b.w;
       mv[0] = c.x; mv[1] = c.y; mv[2] = c.z; mv[3] = c.w;
@@ -117,9 +118,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
       if (wd > 0.f) pv[k] -= lr * wd * pv[k];
     }
     if (full) {
-      *(float4*)(p + i) = make_float4(pv[0], pv[1], pv[2], pv[3]);
-      *(float4*)(m + i) = make_float4(mv[0], mv[1], mv[2], mv[3]);
-      *(float4*)(v + i) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+      vlb_store_nt((float4*)(p + i), make_float4(pv[0], pv[1], pv[2], pv[3]));
+      vlb_store_nt((float4*)(m + i), make_float4(mv[0], mv[1], mv[2], mv[3]));
+      vlb_store_nt((float4*)(v + i), make_float4(vv[0], vv[1], vv[2], vv[3]));
       if (p16) *(uint2*)(p16 + i) = make_uint2(pack2bf(pv[0], pv[1]), pack2bf(pv[2], pv[3]));
     } else {
       for (int k = 0; k < 4 && i + k < n; ++k) {
