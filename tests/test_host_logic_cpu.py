@@ -85,3 +85,61 @@ def test_module_mirrors_fail_loudly_without_a_gpu():
     ops = pkg("ops")
     with pytest.raises(RuntimeError, match="no CPU path"):
         ops.cast_f32_bf16(torch.zeros(8), torch.zeros(8, dtype=torch.bfloat16))
+
+
+def _vcr_text_case():
+    import torch
+    q = torch.tensor([[11, 12, 13, 0], [21, 22, 0, 0]])
+    qt = torch.tensor([[1, -1, 2, 0], [0, 3, 0, 0]])
+    a = torch.tensor([[[31, 32, 0], [33, 0, 0]], [[41, 42, 43], [44, 45, 0]]])
+    at = torch.tensor([[[2, -1, 0], [1, 0, 0]], [[-1, 0, 1], [2, 2, 0]]])
+    return q, qt, q > 0, a, at, a > 0
+
+
+def test_vcr_text_layouts_of_the_ablation_switches():
+    """ResNetVLBERT._prepare_text (vcr mirror): the three token layouts of the reference's forward -- prepare_text_from_qa,
+    _qa_onesent (QA_ONE_SENT) and _aq (ANSWER_FIRST), vcr/modules/resnet_vlbert_for_vcr.py:136-224 -- on a hand-checked case."""
+    import importlib
+    import torch
+    M = importlib.import_module("vl-bert_amd.vcr.modules.resnet_vlbert_for_vcr")
+    q, qt, qm, a, at, am = _vcr_text_case()
+    C = a.shape[1]
+    f = M.ResNetVLBERT._prepare_text
+    ids, types, tags, mask = f(q, qt[:, None].expand(-1, C, -1), qm, a, at, am, order="qa")
+    assert ids[0, 0].tolist() == [101, 11, 12, 13, 102, 31, 32, 102] and types[0, 0].tolist() == [0, 0, 0, 0, 0, 1, 1, 1]
+    assert tags[0, 0].tolist() == [0, 1, -1, 2, 0, 2, -1, 0] and mask[0, 0].tolist() == [True] * 8
+    assert ids[1, 1].tolist() == [101, 21, 22, 102, 44, 45, 102, 0] and mask[1, 1].tolist() == [True] * 7 + [False]
+    ids, types, tags, mask = f(q, qt[:, None].expand(-1, C, -1), qm, a, at, am, order="qa_onesent")
+    assert ids[0, 0].tolist() == [101, 11, 12, 13, 31, 32, 102] and int(types.sum()) == 0
+    assert ids[1, 0].tolist() == [101, 21, 22, 41, 42, 43, 102] and tags[1, 0].tolist() == [0, 0, 3, -1, 0, 1, 0]
+    ids, types, tags, mask = f(q, qt[:, None].expand(-1, C, -1), qm, a, at, am, order="aq")
+    assert ids[0, 0].tolist() == [101, 31, 32, 102, 11, 12, 13, 102] and types[0, 0].tolist() == [0, 0, 0, 0, 1, 1, 1, 1]
+    assert ids[0, 1].tolist() == [101, 33, 102, 11, 12, 13, 102, 0] and mask[0, 1].tolist() == [True] * 7 + [False]
+
+
+def test_vcr_text_layouts_match_the_reference_functions():
+    """... and against the reference's own three functions where the reference tree is present (this container)."""
+    import importlib
+    import os
+    import pytest
+    import torch
+    if not os.path.isdir(os.environ.get("VLBERT_REFERENCE_ROOT", "/root/reference")):
+        pytest.skip("reference tree not present")
+    from oracle import ref_import
+    ref_import.import_reference()
+    ref_import.install_roi_align_oracle()
+    from vcr.modules.resnet_vlbert_for_vcr import ResNetVLBERT as Ref
+    M = importlib.import_module("vl-bert_amd.vcr.modules.resnet_vlbert_for_vcr")
+
+    class Stub:
+        class tokenizer:
+            @staticmethod
+            def convert_tokens_to_ids(toks):
+                return [101, 102]
+    q, qt, qm, a, at, am = _vcr_text_case()
+    C = a.shape[1]
+    qtr = qt.repeat(1, C).view(qt.shape[0], C, -1)
+    for order, fn in (("qa", Ref.prepare_text_from_qa), ("qa_onesent", Ref.prepare_text_from_qa_onesent), ("aq", Ref.prepare_text_from_aq)):
+        r_ids, r_types, r_tags, r_mask = fn(Stub(), q, qtr, qm, a, at, am)
+        ids, types, tags, mask = M.ResNetVLBERT._prepare_text(q, qtr, qm, a, at, am, order=order)
+        assert torch.equal(ids, r_ids) and torch.equal(types, r_types) and torch.equal(tags, r_tags) and torch.equal(mask, r_mask.bool()), order

@@ -326,3 +326,54 @@ def test_fused_adamw_optimizer_matches_the_reference_adamw():
     assert len(opt._runs[0]) <= len(list(core.parameters())) // 3 and len(opt._runs[1]) == 2
     assert all(opt.state[p]["step"] == 3 for p in params)
     assert set(opt.state[extra[0]]) >= {"step", "exp_avg", "exp_avg_sq"}
+
+
+@pytest.mark.parametrize("flag", ["BLIND", "NO_GROUNDING", "NO_OBJ_ATTENTION", "ANSWER_FIRST", "QA_ONE_SENT"])
+def test_vcr_ablation_switches_run_and_change_what_they_should(flag):
+    """The ablation switches of the reference's VCR forward (vcr/modules/resnet_vlbert_for_vcr.py:253-330) through the mirror: each is
+    input plumbing in front of the same encoder (token layouts pinned on CPU against the reference's functions,
+    tests/test_host_logic_cpu.py).  Here: the step runs (finite loss, gradients), the logits DIFFER from the default configuration, and
+    the visual switches act as specified -- BLIND is independent of the image and of the boxes' classes, NO_OBJ_ATTENTION / BLIND hand
+    the encoder an empty object mask."""
+    from tests.test_oracle_golden import load_vcr_case
+    from oracle import vision_oracle as VO
+    M = pkg("vcr.modules.resnet_vlbert_for_vcr")
+    z, cfg, params, P, batch = load_vcr_case()
+    nl, pos_w = int(z["num_layers"]), float(z["positive_weight"])
+    sd = {("vlbert._module." + k[len("vlbert."):]) if k.startswith("vlbert.") else k: v for k, v in params.items()}
+    sd.update({"image_feature_extractor." + k: v for k, v in VO.split_state_dict(P).items()})
+    gb = {k: v.to(dev()) for k, v in batch.items()}
+    args = lambda b: (b["image"], b["boxes"], b["masks"], b["question"], None, b["answer_choices"], None, b["answer_label"], b["im_info"])
+
+    def build(**kw):
+        c = _vcr_config(cfg, nl, pos_w)
+        c["NETWORK"].update(kw)
+        if kw.get("BLIND"):
+            c["NETWORK"]["ENABLE_CNN_REG_LOSS"] = False
+        net = M.ResNetVLBERT(c, device="cuda:0")
+        net.load_state_dict(sd, strict=False)
+        net.train()
+        for m in (net.vlbert, net.image_feature_extractor):
+            m.eval()
+        net.cls_drop = 0.0
+        return net
+    base = build()
+    ref_logits = base.train_forward(*args(gb))[0]["label_logits"].detach().clone()
+    net = build(**{flag: True})
+    outputs, loss = net.train_forward(*args(gb))
+    loss.backward()
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(loss)) and bool(torch.isfinite(outputs["label_logits"]).all())
+    gsum = sum(float(p.grad.abs().sum()) for p in net.parameters() if p.grad is not None)
+    assert gsum > 0 and gsum == gsum
+    diff = float((outputs["label_logits"].detach() - ref_logits).abs().max())
+    print("vcr %s: loss %.4f, max |logits - default| %.3e" % (flag, float(loss), diff))
+    assert diff > 1e-4
+    if flag == "BLIND":                       # no pixel and no detector class reaches the logits
+        b2 = dict(gb)
+        b2["image"] = gb["image"] * 0.0 + 7.0
+        boxes = gb["boxes"].clone()
+        boxes[:, :, -1] = (boxes[:, :, -1] + 3).clamp(max=80) * (boxes[:, :, -1] >= 0) + boxes[:, :, -1] * (boxes[:, :, -1] < 0)
+        b2["boxes"] = boxes
+        again = net.train_forward(*args(b2))[0]["label_logits"].detach()
+        assert torch.equal(again, outputs["label_logits"].detach())

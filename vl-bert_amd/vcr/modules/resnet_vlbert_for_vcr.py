@@ -14,8 +14,9 @@ Composition, as in the reference (:226-399):
   ENABLE_CNN_REG_LOSS + CNN_LOSS_TOP (the shipped cfgs/vcr/*.yaml): every valid object's final hidden state -> transform
   (Linear + GELU) -> Dropout -> Linear(H, 81) -> CE against its detector class, one autograd node on the library (bf16 GEMMs with
   fused bias / GELU epilogues, vlb_ce_fwd_bwd, TN weight gradients).
-The [B*C, H] x [H, 1] classifier and its 16-element loss are plain torch fp32 (a dot product per sequence -- no kernel to write).
-Not built: BLIND, NO_GROUNDING, NO_OBJ_ATTENTION, ANSWER_FIRST, QA_ONE_SENT, object_word_embed_mode 3, IMAGE_SEMANTIC, the
+The answer classifier (Dropout -> Linear(H,1) | 2fc) and the answer loss (weighted sigmoid BCE with the (w+1)/(2w) rescale, or softmax CE
+over the choices) are one autograd node on the library as well (`_AnswerFn`).
+Built as input plumbing: BLIND, NO_GROUNDING, NO_OBJ_ATTENTION, ANSWER_FIRST, QA_ONE_SENT.  Not built: object_word_embed_mode 3, IMAGE_SEMANTIC, the
 bottom-of-the-CNN form of the regulariser (CNN_LOSS_TOP false), mask_position / mask_label (asserted off in the reference too).
 """
 import torch
@@ -205,10 +206,19 @@ class ResNetVLBERT(nn.Module):
         self.config = config
         net = _get(config, "NETWORK")
         vl = _get(net, "VLBERT")
-        for flag in ("BLIND", "NO_GROUNDING", "NO_OBJ_ATTENTION", "ANSWER_FIRST", "QA_ONE_SENT", "FOR_MASK_VL_MODELING_PRETRAIN",
-                     "IMAGE_SEMANTIC"):
+        for flag in ("FOR_MASK_VL_MODELING_PRETRAIN", "IMAGE_SEMANTIC"):
             if _get(net, flag, False):
                 raise NotImplementedError("NETWORK.%s is not supported" % flag)
+        # ablation switches of the reference's forward (:253-330): all of them are input plumbing in front of the same encoder
+        self.blind = bool(_get(net, "BLIND", False))                      # no visual input at all: zero features, no object positions
+        self.no_grounding = bool(_get(net, "NO_GROUNDING", False))        # every token tagged with box 0 (the whole image)
+        self.no_obj_attention = bool(_get(net, "NO_OBJ_ATTENTION", False))      # objects feed the token embeddings but are not attended
+        self.answer_first = bool(_get(net, "ANSWER_FIRST", False))        # [CLS] answer [SEP] question [SEP]
+        self.qa_one_sent = bool(_get(net, "QA_ONE_SENT", False))          # [CLS] question answer [SEP], one segment
+        if self.answer_first and self.qa_one_sent:
+            raise NotImplementedError("ANSWER_FIRST with QA_ONE_SENT (the reference raises as well, :276-277)")
+        if self.blind and _get(net, "ENABLE_CNN_REG_LOSS", False):
+            raise NotImplementedError("BLIND with ENABLE_CNN_REG_LOSS: there are no object positions to classify")
         self.embed_mode = int(_get(vl, "object_word_embed_mode", 2))
         if self.embed_mode not in (1, 2):
             raise NotImplementedError("object_word_embed_mode must be 1 (81 class embeddings) or 2 (one shared embedding)")
@@ -367,26 +377,37 @@ class ResNetVLBERT(nn.Module):
                                      loss=torch.zeros((1,), dtype=F32, device=dev), count=torch.zeros((1,), dtype=F32, device=dev))
         return {k: (v[:n] if v.dim() == 2 else v) for k, v in self._states[cap].items()}
 
-    # -- text preparation: index plumbing (prepare_text_from_qa, :136-167) -------------------------------------------
+    # -- text preparation: index plumbing (prepare_text_from_qa / _qa_onesent / _aq, :136-224) ------------------------
     @staticmethod
-    def _prepare_text(question, question_tags, question_mask, answers, answers_tags, answers_mask):
+    def _prepare_text(question, question_tags, question_mask, answers, answers_tags, answers_mask, order="qa"):
+        """order: "qa"  [CLS] q [SEP] a [SEP] (segment 1 = answer + its [SEP]) | "qa_onesent"  [CLS] q a [SEP] (one segment) |
+        "aq"  [CLS] a [SEP] q [SEP] (segment 1 = question + its [SEP])"""
         B, Lq = question.shape
         _, C, La = answers.shape
-        L = int((question_mask.sum(1) + answers_mask.sum(2).max(1)[0]).max()) + 3
+        n_sep = 1 if order == "qa_onesent" else 2
+        L = int((question_mask.sum(1) + answers_mask.sum(2).max(1)[0]).max()) + 1 + n_sep
         d = question.device
         question = question[:, None, :].expand(B, C, Lq)
         qmask = question_mask[:, None, :].expand(B, C, Lq)
-        q_end = 1 + qmask.sum(2, keepdim=True)
-        a_end = q_end + 1 + answers_mask.sum(2, keepdim=True)
+        nq, na = qmask.sum(2, keepdim=True), answers_mask.sum(2, keepdim=True)
         k = torch.arange(L, device=d)[None, None, :].expand(B, C, L)
         ids = torch.zeros((B, C, L), dtype=question.dtype, device=d)
         tags = torch.zeros((B, C, L), dtype=question.dtype, device=d)
-        mask = k <= a_end
-        types = ((k > q_end) & (k <= a_end)).to(question.dtype)
-        q_in, a_in = (k > 0) & (k < q_end), (k > q_end) & (k < a_end)
+        if order == "qa":
+            first_end, last_end = 1 + nq, 2 + nq + na                 # positions of the two [SEP]
+            q_in, a_in = (k > 0) & (k < first_end), (k > first_end) & (k < last_end)
+        elif order == "aq":
+            first_end, last_end = 1 + na, 2 + na + nq
+            a_in, q_in = (k > 0) & (k < first_end), (k > first_end) & (k < last_end)
+        else:
+            first_end, last_end = 1 + nq, 1 + nq + na                 # no separator between question and answer
+            q_in, a_in = (k > 0) & (k < first_end), (k >= first_end) & (k < last_end)
+        mask = k <= last_end
+        types = ((k > first_end) & (k <= last_end)).to(question.dtype) if order != "qa_onesent" else torch.zeros_like(ids)
         ids[:, :, 0] = CLS
-        ids[k == q_end] = SEP
-        ids[k == a_end] = SEP
+        if order != "qa_onesent":
+            ids[k == first_end] = SEP
+        ids[k == last_end] = SEP
         ids[q_in] = question[qmask]
         ids[a_in] = answers[answers_mask]
         tags[q_in] = question_tags[qmask]
@@ -399,23 +420,33 @@ class ResNetVLBERT(nn.Module):
         box_mask = boxes4[:, :, -1] > -0.5
         max_len = int(box_mask.sum(1).max())
         objects, box_mask, boxes4, segms = objects[:, :max_len], box_mask[:, :max_len], boxes4[:, :max_len], masks[:, :max_len]
-        obj = self.image_feature_extractor(images=image, boxes=boxes4, box_mask=box_mask, im_info=im_info, classes=objects, segms=segms)
-        reps = obj["obj_reps"]
         B, R = box_mask.shape
+        if self.blind:
+            reps = torch.zeros((B, R, self.H), dtype=F32, device=boxes4.device)
+        else:
+            reps = self.image_feature_extractor(images=image, boxes=boxes4, box_mask=box_mask, im_info=im_info, classes=objects,
+                                                segms=segms)["obj_reps"]
         C = answer_choices.shape[1]
         q_ids, q_tags = question[:, :, 0], question[:, :, 1]
         q_tags = q_tags[:, None, :].expand(-1, C, -1)
         q_mask = question[:, :, 0] > 0.5
         a_ids, a_tags = answer_choices[:, :, :, 0], answer_choices[:, :, :, 1]
         a_mask = answer_choices[:, :, :, 0] > 0.5
-        ids, types, tags, text_mask = self._prepare_text(q_ids, q_tags, q_mask, a_ids, a_tags, a_mask)
+        order = "aq" if self.answer_first else ("qa_onesent" if self.qa_one_sent else "qa")
+        ids, types, tags, text_mask = self._prepare_text(q_ids, q_tags, q_mask, a_ids, a_tags, a_mask, order=order)
+        if self.no_grounding:
+            tags = torch.zeros_like(tags)
         L = ids.shape[2]
         rows = torch.arange(B, device=ids.device)[:, None, None].expand(B, C, L)
         text_visual = reps[rows.reshape(-1), tags.clamp(min=0).reshape(-1)].view(B, C, L, -1)          # _collect_obj_reps (:116-134)
-        table = self.object_linguistic_embeddings.weight
-        ling = table[objects.long().clamp(min=0, max=table.shape[0] - 1)]
+        if self.blind:
+            ling = torch.zeros_like(reps)
+        else:
+            table = self.object_linguistic_embeddings.weight
+            ling = table[objects.long().clamp(min=0, max=table.shape[0] - 1)]
         obj_vl = torch.cat((reps, ling), -1)[:, None].expand(B, C, R, -1)
-        text_out, obj_out, pooled = self.vlbert(ids, types, text_visual, text_mask, obj_vl, box_mask[:, None].expand(B, C, R),
+        attend = torch.zeros_like(box_mask) if (self.no_obj_attention or self.blind) else box_mask
+        text_out, obj_out, pooled = self.vlbert(ids, types, text_visual, text_mask, obj_vl, attend[:, None].expand(B, C, R),
                                                 output_all_encoded_layers=False, output_text_and_object_separately=True)
         return pooled, obj_out, objects, box_mask
 
