@@ -829,7 +829,7 @@ def _vqa_config(cfg, classifier, answers, hidden):
     return conf
 
 
-@pytest.mark.parametrize("classifier", ["2fc", "mlm"])
+@pytest.mark.parametrize("classifier", ["2fc", "mlm", "1fc"])
 def test_vqa_module_mirror_vs_reference_fixture_and_oracle(classifier):
     """vqa ResNetVLBERT mirror (FastRCNN + VisualLinguisticBert mirrors + the HIP classifier / BCE node): "2fc" against the fixture
     produced by the reference's own VQA module, "mlm" (the shipped cfgs/vqa classifier) against the oracle; logits, loss, gradients
@@ -839,8 +839,8 @@ def test_vqa_module_mirror_vs_reference_fixture_and_oracle(classifier):
     M = pkg("vqa.modules.resnet_vlbert_for_vqa")
     z, cfg, params, batch = load_vqa_case()
     A, hidden = int(z["answer_vocab"]), int(z["classifier_hidden"])
-    if classifier == "mlm":
-        params = VQ.init_vqa_params(cfg, int(z["pseed"]), A, "mlm")
+    if classifier != "2fc":
+        params = VQ.init_vqa_params(cfg, int(z["pseed"]), A, classifier)
     net = M.ResNetVLBERT(_vqa_config(cfg, classifier, A, hidden), device="cuda:0")
     assert set(net.state_dict()) == set(params), set(net.state_dict()) ^ set(params)
     net.load_state_dict({k: v for k, v in params.items()})
@@ -862,8 +862,8 @@ def test_vqa_module_mirror_vs_reference_fixture_and_oracle(classifier):
     got = dict(net.named_parameters())
     names = ["vlbert.encoder.layer.1.output.dense.weight", "image_feature_extractor.obj_downsample.1.weight", "vlbert.word_embeddings.weight",
              "object_linguistic_embeddings.weight"]
-    names += ["final_mlp.1.weight", "final_mlp.4.weight", "final_mlp.4.bias"] if classifier == "2fc" else \
-        ["final_mlp.0.dense.weight", "final_mlp.0.LayerNorm.weight", "final_mlp.2.weight", "final_mlp.2.bias"]
+    names += {"2fc": ["final_mlp.1.weight", "final_mlp.4.weight", "final_mlp.4.bias"], "1fc": ["final_mlp.1.weight", "final_mlp.1.bias"],
+              "mlm": ["final_mlp.0.dense.weight", "final_mlp.0.LayerNorm.weight", "final_mlp.2.weight", "final_mlp.2.bias"]}[classifier]
     for k in names:
         e = rel_fro(got[k].grad, leaves[k].grad)
         print("  vqa %s d %s rel-fro %.3e" % (classifier, k, e))

@@ -41,7 +41,11 @@ class _HeadFn(torch.autograd.Function):
         A, Ap = module.answers, module.Ap
         p = module.cls_drop if train else 0.0
         ops.cast_f32_bf16(hm.detach().contiguous(), st["x_in"])
-        if module.classifier == "2fc":
+        if module.classifier == "1fc":
+            x0 = ops.dropout_bf16(st["x_in"], st["x0"], p, module._seed, _TAG0) if p > 0 else st["x_in"]
+            x1 = x0
+            ops.gemm_nt(x0, module._w2, st["logits"][:, :A], bias=params[1].detach())
+        elif module.classifier == "2fc":
             x0 = ops.dropout_bf16(st["x_in"], st["x0"], p, module._seed, _TAG0) if p > 0 else st["x_in"]
             ops.gemm_nt(x0, module._w1, st["u"][:, :module.hc], bias=params[1].detach(), act=ops.ACT_RELU)
             x1 = ops.dropout_bf16(st["u"], st["x1"], p, module._seed, _TAG1) if p > 0 else st["u"]
@@ -75,7 +79,12 @@ class _HeadFn(torch.autograd.Function):
             ops.bce_logits_fwd_bwd(st["logits"], A, ctx.label.detach().float().contiguous(), st["loss"], gscale=g)
         dlog = st["logits"][:, :A]
         grads = [torch.zeros_like(q, dtype=F32) for q in params]
-        if module.classifier == "2fc":
+        if module.classifier == "1fc":
+            gw2, gb2 = grads
+            ops.wgrad_tn(dlog, ctx.x1, gw2, colsum=gb2, workspace=None)
+            ops.gemm_nt(st["logits"], module._w2T, st["dx0"])                                # K = padded answers (zero columns)
+            dx = ops.dropout_bf16(st["dx0"], st["dxin"], p, module._seed, _TAG0) if p > 0 else st["dx0"]
+        elif module.classifier == "2fc":
             gw1, gb1, gw2, gb2 = grads
             ops.wgrad_tn(dlog, ctx.x1[:, :module.hc], gw2, colsum=gb2, workspace=None)
             ops.gemm_nt(st["logits"], module._w2T, st["dx1"][:, :module.hc], act=ops.ACT_RELU_MASK, aux=st["u"][:, :module.hc])   # K = padded answers (zero columns)
@@ -105,14 +114,15 @@ class ResNetVLBERT(nn.Module):
         self.config = config
         net = _get(config, "NETWORK")
         vl = _get(net, "VLBERT")
-        if _get(net, "BLIND", False) or _get(net, "NO_GROUNDING", False) or _get(net, "ENABLE_CNN_REG_LOSS", False) or \
-                _get(net, "CLASSIFIER_SIGMOID", False):
-            raise NotImplementedError("BLIND / NO_GROUNDING / ENABLE_CNN_REG_LOSS / CLASSIFIER_SIGMOID are not supported")
+        if _get(net, "BLIND", False) or _get(net, "NO_GROUNDING", False) or _get(net, "ENABLE_CNN_REG_LOSS", False):
+            raise NotImplementedError("BLIND / NO_GROUNDING / ENABLE_CNN_REG_LOSS are not supported")
+        # (CLASSIFIER_SIGMOID is a key of the shared config schema that the reference's VQA module never reads: the answer loss is
+        #  always the sigmoid BCE of :226)
         if _get(vl, "object_word_embed_mode", 2) != 2:
             raise NotImplementedError("object_word_embed_mode must be 2 (one shared object word embedding)")
         self.classifier = _get(net, "CLASSIFIER_TYPE", "2fc")
-        if self.classifier not in ("2fc", "mlm"):
-            raise NotImplementedError("CLASSIFIER_TYPE %s (built: 2fc, mlm)" % self.classifier)
+        if self.classifier not in ("2fc", "1fc", "mlm"):
+            raise ValueError("Not support classifier type: %s!" % self.classifier)       # (the reference's message, :75-76)
         if not torch.cuda.is_available():
             raise RuntimeError("ResNetVLBERT (HIP) needs an MI355X: there is no CPU fallback")
         dev = torch.device(device or ("cuda:%d" % torch.cuda.current_device()))
@@ -136,6 +146,9 @@ class ResNetVLBERT(nn.Module):
             self.hc = int(_get(net, "CLASSIFIER_HIDDEN_SIZE", 1024))
             mlp.add_module("1", lin(self.hc, H))
             mlp.add_module("4", lin(self.answers, self.hc))
+        elif self.classifier == "1fc":            # Dropout -> Linear(H, answers)  (:64-68)
+            self.hc = H
+            mlp.add_module("1", lin(self.answers, H))
         else:
             self.hc = H
             tr = nn.Module()
@@ -149,7 +162,7 @@ class ResNetVLBERT(nn.Module):
         self.final_mlp = mlp
         self.hcp = _ru(self.hc, 64)
         zb = lambda *s: torch.zeros(s, dtype=ops.BF16, device=dev)
-        self._w1, self._w1T = zb(self.hc, H), zb(H, self.hcp)          # first Linear and its transpose (K padded to 64)
+        self._w1, self._w1T = zb(self.hc, H), zb(H, self.hcp)          # first Linear and its transpose (K padded to 64; unused by "1fc")
         self._w2, self._w2T = zb(self.answers, self.hcp), zb(self.hc, self.Ap)
         self._seed = torch.tensor([ops.rank_seed(30011)], dtype=torch.int32, device=dev)
         self._head_version, self._states = None, {}
@@ -161,6 +174,9 @@ class ResNetVLBERT(nn.Module):
         if self.classifier == "2fc":
             a, b = getattr(m, "1"), getattr(m, "4")
             return [a.weight, a.bias, b.weight, b.bias]
+        if self.classifier == "1fc":
+            a = getattr(m, "1")
+            return [a.weight, a.bias]
         t, b = getattr(m, "0"), getattr(m, "2")
         return [t.dense.weight, t.dense.bias, t.LayerNorm.weight, t.LayerNorm.bias, b.weight, b.bias]
 
@@ -184,13 +200,15 @@ class ResNetVLBERT(nn.Module):
         ver = tuple(q._version for q in params)
         if ver == self._head_version:
             return
-        w1, w2 = (params[0], params[2]) if self.classifier == "2fc" else (params[0], params[4])
-        ops.cast_f32_bf16(w1.detach().contiguous(), self._w1)
+        w1, w2 = (params[0], params[2]) if self.classifier == "2fc" else ((None, params[0]) if self.classifier == "1fc" else (params[0], params[4]))
+        if w1 is not None:
+            ops.cast_f32_bf16(w1.detach().contiguous(), self._w1)
         tmp = torch.zeros((self.answers, self.hc), dtype=ops.BF16, device=self.device_)
         ops.cast_f32_bf16(w2.detach().contiguous(), tmp)
         self._w2.zero_()
         self._w2[:, :self.hc].copy_(tmp)
-        ops.transpose(self._w1, self._w1T)
+        if w1 is not None:
+            ops.transpose(self._w1, self._w1T)
         ops.transpose(tmp, self._w2T)
         self._head_version = ver
 
