@@ -53,10 +53,18 @@ def test_flat_runs_group_parameters_that_are_consecutive_in_memory():
     lone = torch.nn.Parameter(torch.zeros(7))
     lone.grad = torch.zeros(7)
     params.append(lone)
-    assert OPT._flat_runs(params) == [(0, 3), (3, 5), (5, 6)]
+    # (first, last + 1, elements spanned): the zero padding is part of the run
+    assert OPT._flat_runs(params) == [(0, 5, 100), (5, 6, 7)]
+    # a gap that holds somebody else's data is not padding: the run stops there (parameter side and gradient side alike)
+    flat_p[36] = 1.0
+    assert OPT._flat_runs(params) == [(0, 3, 34), (3, 5, 60), (5, 6, 7)]
+    flat_p[36] = 0.0
+    flat_g[35] = 1.0
+    assert OPT._flat_runs(params) == [(0, 3, 34), (3, 5, 60), (5, 6, 7)]
+    flat_g[35] = 0.0
     # a gradient that is NOT consecutive splits the run even when the parameters are
     params[1].grad = torch.zeros(20)
-    assert OPT._flat_runs(params) == [(0, 1), (1, 2), (2, 3), (3, 5), (5, 6)]
+    assert OPT._flat_runs(params) == [(0, 1, 10), (1, 2, 20), (2, 5, 70), (5, 6, 7)]
 
 
 def test_fused_optimisers_refuse_cpu_tensors_and_unsupported_modes():
