@@ -37,6 +37,10 @@
 
 #include "gemm_params.h"
 
+#ifndef VLB_P8_WDRAIN
+#define VLB_P8_WDRAIN 1      // wave-private epilogue drain (p8_drain_w); 0: the shared-slab drain with workgroup barriers (p8_drain)
+#endif
+
 namespace {
 
 template <int OFF>
@@ -47,6 +51,11 @@ __device__ __forceinline__ void p8_lds_read(bf16x8& dst, uint32_t vaddr) {
 template <int OFF>
 __device__ __forceinline__ void p8_lds_write_f4(uint32_t vaddr, const f32x4& v) {
   asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(vaddr), "v"(v), "n"(OFF) : "memory");
+}
+
+template <int OFF>
+__device__ __forceinline__ void p8_lds_read_f4(f32x4& dst, uint32_t vaddr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(vaddr), "n"(OFF));
 }
 
 template <int OFF>   // two 16-B reads of the staging slab (8 consecutive fp32 of one row), waited for in the same statement
@@ -189,7 +198,11 @@ __device__ __forceinline__ void p8_drain(const GemmParams& p, f32x4 (&acc)[2 * F
   uint32_t wr[4];
 #pragma unroll
   for (int cj = 0; cj < 4; ++cj) {
+#if VLB_P8_WDRAIN
+    const int c = wn * 16 + (cj >> 1) * 8 + (cj & 1) * 4 + (lane >> 4);      // a wave's two 32-column halves are neighbours (see p8_drain_w)
+#else
     const int c = (cj >> 1) * 32 + wn * 8 + (cj & 1) * 4 + (lane >> 4);
+#endif
     wr[cj] = slab + (uint32_t)(wrow * 1024 + ((c ^ (frow & 7)) << 4));
   }
   const int q = tid & 31, rho = tid >> 5;
@@ -312,6 +325,119 @@ __device__ __forceinline__ void p8_drain(const GemmParams& p, f32x4 (&acc)[2 * F
   });
 }
 
+// Drain WITHOUT workgroup barriers (default; -DVLB_P8_WDRAIN=0 selects the shared-slab drain above): every wave transposes its own
+// accumulators through a PRIVATE 2-KiB region of the slab, one unit = (fragment row R, row half hf) = 8 rows x 64 columns of fp32 at a
+// time -- the lanes that hold those rows in the MFMA layout (lane: row lane & 15, 4 consecutive columns per fragment) write their four
+// fragments (ds_write_b128), then every lane reads 8 consecutive columns of one row back (lane = (row lane >> 3, columns (lane & 7) * 8)),
+// runs the fused epilogue on them and stores 16 B: 8 lanes per row = whole 128-B lines for C and for the side tensors.  LDS operations
+// of one wave execute in issue order, so the region needs no second buffer: the writes of unit u + 1 are issued right after the
+// reads of unit u have returned and land under the math of unit u.  Measured on the FFN shape (tools/epi_probe.py): the shared
+// slab's 16 barriers per tile cost 7 of the 8 us of a tile's "bias only" epilogue.  The B half-images are staged with the rows of
+// a wave's two halves ADJACENT (tile column = wn * 64 + h * 32 + ...), so that a wave owns 64 consecutive columns of C.
+// EDGE = false: the tile lies inside C (every row < M, every 8-column group whole): straight-line code without per-lane conditions, so
+// that the side loads issued one unit ahead are retired by COUNTED vmcnt waits (a load or store under a lane condition makes hipcc
+// drain the queue -- including the previous unit's store -- in front of every use).
+template <int FMH, int EPI, bool EDGE>
+__device__ __forceinline__ void p8_drain_w(const GemmParams& p, f32x4 (&acc)[2 * FMH][4], uint32_t slab, int m0, int n0, int wm, int wn,
+                                           int tid, uint32_t seed) {
+  constexpr int AH = 32 * FMH, NF = 2 * FMH, NU = 2 * NF;
+  constexpr bool LNRES = (EPI == 6 || EPI == 7);
+  constexpr bool SIDE = (EPI == 2 || EPI == 3 || EPI == 4 || EPI == 6 || EPI == 7 || EPI == 8 || EPI == 10);
+  asm volatile("" : "+v"(tid));      // (see p8_drain: keeps the address arithmetic below out of the K loop's live ranges)
+  const int lane = tid & 63, frow = lane & 15;
+  const uint32_t mine = slab + (uint32_t)((tid >> 6) * 2048);
+  uint32_t wr[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) wr[j] = mine + (uint32_t)((frow & 7) * 256 + (((j * 4 + (lane >> 4)) ^ (frow & 7)) << 4));
+  const bool upper = (frow >> 3) != 0;
+  const int rr = lane >> 3, cq = lane & 7;
+  const uint32_t rd0 = mine + (uint32_t)(rr * 256 + (((2 * cq) ^ rr) << 4));
+  const uint32_t rd1 = mine + (uint32_t)(rr * 256 + (((2 * cq + 1) ^ rr) << 4));
+  const bool f16out = p.c_f16 != 0;
+  const int n = n0 + wn * 64 + cq * 8;
+  const bool full8 = EDGE ? (n + 8 <= p.N) : true;
+  const int mw = m0 + wm * FMH * 16 + rr;           // + ha * AH + i * 16 + hf * 8
+  auto uoff = [](int u) { return ((u >> 1) / FMH) * AH + ((u >> 1) % FMH) * 16 + (u & 1) * 8; };      // tile row of unit u, lane row 0
+  // per-lane element offsets of unit 0; a unit adds a wave-uniform multiple of the row stride
+  bf16_t* const Cl = (bf16_t*)p.C + (long)mw * p.ldc + n;
+  const bf16_t* const Sl = !SIDE ? nullptr : ((EPI == 2 || EPI == 10) ? p.aux + (long)mw * p.ldaux + n : p.res + (long)mw * p.ldres + n);
+  const long lds_ = (EPI == 2 || EPI == 10) ? p.ldaux : p.ldres;
+  const float* const Ml = LNRES ? p.res_stats + 2 * (long)mw : nullptr;
+  // bias / gamma / beta of the lane's 8 columns: resident for the whole tile
+  float b8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, g8[8], be8[8];
+  auto consts = [&]() {
+    if (p.bias && full8) {
+      const float4 b0 = *(const float4*)(p.bias + n), b1 = *(const float4*)(p.bias + n + 4);
+      b8[0] = b0.x; b8[1] = b0.y; b8[2] = b0.z; b8[3] = b0.w; b8[4] = b1.x; b8[5] = b1.y; b8[6] = b1.z; b8[7] = b1.w;
+    }
+    if constexpr (LNRES) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) g8[e] = be8[e] = 0.f;
+      if (full8) {
+        const float4 a0 = *(const float4*)(p.res_gamma + n), a1 = *(const float4*)(p.res_gamma + n + 4);
+        const float4 c0 = *(const float4*)(p.res_beta + n), c1 = *(const float4*)(p.res_beta + n + 4);
+        g8[0] = a0.x; g8[1] = a0.y; g8[2] = a0.z; g8[3] = a0.w; g8[4] = a1.x; g8[5] = a1.y; g8[6] = a1.z; g8[7] = a1.w;
+        be8[0] = c0.x; be8[1] = c0.y; be8[2] = c0.z; be8[3] = c0.w; be8[4] = c1.x; be8[5] = c1.y; be8[6] = c1.z; be8[7] = c1.w;
+      }
+    }
+  };
+  auto load_side = [&](int u, uint4& sd, float2& ms) {
+    if constexpr (SIDE) {
+      if (!EDGE || (mw + uoff(u) < p.M && full8)) {
+        const uint4* src = (const uint4*)(Sl + uoff(u) * lds_);
+        if (EPI == 2 || EPI == 10) sd = vlb_load_nt(src);      // read exactly once
+        else sd = *src;
+        if constexpr (LNRES) ms = *(const float2*)(Ml + 2 * uoff(u));
+      }
+    }
+  };
+  auto put = [&](auto u_c) {      // the lanes holding rows [hf * 8, +8) of fragment row R write their 64 columns
+    constexpr int u = decltype(u_c)::value, R = u >> 1, hf = u & 1;
+    if (upper == (hf != 0)) {
+      p8_lds_write_f4<0>(wr[0], acc[R][0]);
+      p8_lds_write_f4<0>(wr[1], acc[R][1]);
+      p8_lds_write_f4<0>(wr[2], acc[R][2]);
+      p8_lds_write_f4<0>(wr[3], acc[R][3]);
+    }
+  };
+  auto finish = [&](int u, const f32x4& x0, const f32x4& x1, const uint4& sd, const float2& ms) {
+    const int m = mw + uoff(u);
+    if (!EDGE || (m < p.M && n < p.N)) {
+      float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+      if (full8) {
+        if constexpr (LNRES) p8_epilogue8<EPI>(p, v, b8, m, n, seed, sd, ms, g8, be8);
+        else p8_epilogue8<EPI>(p, v, b8, m, n, seed, sd);
+        uint4 o4;
+        if (f16out) o4 = make_uint4(pack2h(v[0], v[1]), pack2h(v[2], v[3]), pack2h(v[4], v[5]), pack2h(v[6], v[7]));
+        else o4 = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+        // (timing ablation 2: every unit overwrites the lane's first 16 B -- the store stays, its HBM traffic goes; no branch here:
+        // a store under a condition would make the counted waits conservative)
+        *(uint4*)(Cl + (p.ablate != 2 ? uoff(u) * (long)p.ldc : 0L)) = o4;
+      } else {
+        for (int e = 0; e < 8 && n + e < p.N; ++e) {
+          const float o = p8_epilogue1<EPI>(p, v[e], m, n + e, seed);
+          Cl[uoff(u) * (long)p.ldc + e] = f16out ? f2h(o) : f2bf(o);
+        }
+      }
+    }
+  };
+  uint4 side[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+  float2 mst[2] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
+  consts();
+  load_side(0, side[0], mst[0]);
+  put(std::integral_constant<int, 0>{});
+  p8_static_for<0, NU>([&](auto u_c) {
+    constexpr int u = decltype(u_c)::value;
+    f32x4 x0, x1;
+    p8_stage_read<0>(x0, x1, rd0, rd1);      // (waits for this wave's LDS queue: the writes of unit u and these reads)
+    if constexpr (u + 1 < NU) {
+      load_side(u + 1, side[(u + 1) & 1], mst[(u + 1) & 1]);
+      put(std::integral_constant<int, u + 1>{});
+    }
+    finish(u, x0, x1, side[u & 1], mst[u & 1]);
+  });
+}
+
 // FMH: 16-row accumulator fragments per wave per tile half (3 -> 192-row tiles, 4 -> 256-row tiles, 5 -> 320-row tiles)
 // KEEPB: keep the B0 fragments in registers for the 4th quadrant (16 more VGPRs) instead of re-reading them
 template <int FMH, int EPI, bool KEEPB>
@@ -356,7 +482,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(const GemmParams p) 
   const int ldaB = (int)p.lda * 2, ldbB = (int)p.ldb * 2;
   const int kcb = (((tid & 7) ^ ((tid >> 4) & 7)) << 4);
   const int rowA = (tid >> 3) * ldaB + kcb, maxA = (p.M - 1) * ldaB + kcb;
+#if VLB_P8_WDRAIN
+  // B half-image h, LDS row r  <-  tile column (r >> 5) * 64 + h * 32 + (r & 31): the 32-column groups a wave owns in the two halves are
+  // neighbours in C (p8_drain_w)
+  const int rowB = ((tid >> 8) * 64 + ((tid >> 3) & 31)) * ldbB + kcb, maxB = (p.N - 1) * ldbB + kcb;
+#else
   const int rowB = (tid >> 3) * ldbB + kcb, maxB = (p.N - 1) * ldbB + kcb;
+#endif
   int w_p = blockIdx.x, kt_p = 0, tiles_issued = 0, pm0 = 0, pn0 = 0;
   bool live = true;
   auto setup = [&](int w) { tile_of(w, pm0, pn0); };
@@ -378,7 +510,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(const GemmParams p) 
       char* dst = smem + B_ * BUF + (WHICH == 2 ? OFF_B0 : OFF_B1);
 #pragma unroll
       for (int it = 0; it < 2; ++it) {
+#if VLB_P8_WDRAIN
+        const int vo = min((pn0 + (WHICH - 2) * 32 + it * 128) * ldbB + rowB, maxB);
+#else
         const int vo = min((pn0 + (WHICH - 2) * 128 + it * 64) * ldbB + rowB, maxB);
+#endif
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(dst + (it * 512 + wave * 64) * 16), 16, vo, koff, 0, 0);
       }
     }
@@ -545,6 +681,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(const GemmParams p) 
     tile_of(w, m0, n0);
     if (p.ablate == 1) {
       // (timing ablation: no epilogue at all)
+#if VLB_P8_WDRAIN
+    } else if (w + (int)gridDim.x < nt && !(FMH == 5 && (EPI == 6 || EPI == 7))) {
+      // mid-stream tile: wave-private drain beside the operand ring (not in the one instantiation without the registers for it: its
+      // spills land in the K loop; that one keeps the shared slab)
+      if (m0 + BM <= p.M && n0 + BN <= p.N) p8_drain_w<FMH, EPI, false>(p, acc, lds0 + STG, m0, n0, wm, wn, tid, seed);
+      else p8_drain_w<FMH, EPI, true>(p, acc, lds0 + STG, m0, n0, wm, wn, tid, seed);
+#endif
     } else if (w + (int)gridDim.x >= nt) {
       // last tile of this workgroup: nothing is in flight into the operand ring any more (the producer stopped at this tile and
       // every K tile it issued has been consumed) -> drain through a 128-row slab laid over the ring
