@@ -408,8 +408,12 @@ __device__ __forceinline__ void p8_drain_w(const GemmParams& p, f32x4 (&acc)[2 *
         if constexpr (LNRES) p8_epilogue8<EPI>(p, v, b8, m, n, seed, sd, ms, g8, be8);
         else p8_epilogue8<EPI>(p, v, b8, m, n, seed, sd);
         uint4 o4;
-        if (f16out) o4 = make_uint4(pack2h(v[0], v[1]), pack2h(v[2], v[3]), pack2h(v[4], v[5]), pack2h(v[6], v[7]));
-        else o4 = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+        if (f16out) {
+          asm volatile("" ::: "memory");      // a real (wave-uniform) branch: if-converted, BOTH roundings ran in every unit (+40 VALU instructions)
+          o4 = make_uint4(pack2h(v[0], v[1]), pack2h(v[2], v[3]), pack2h(v[4], v[5]), pack2h(v[6], v[7]));
+        } else {
+          o4 = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+        }
         // (timing ablation 2: every unit overwrites the lane's first 16 B -- the store stays, its HBM traffic goes; no branch here:
         // a store under a condition would make the counted waits conservative)
         *(uint4*)(Cl + (p.ablate != 2 ? uoff(u) * (long)p.ldc : 0L)) = o4;

@@ -63,8 +63,10 @@ __device__ __forceinline__ float bfhi(uint32_t w) { return (float)__builtin_bit_
 #else
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 __device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }  // RNE (v_cvt_pk_bf16_f32)
-__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-  return ((uint32_t)f2bf(hi) << 16) | (uint32_t)f2bf(lo);
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {      // ONE v_cvt_pk_bf16_f32 (two scalar conversions + shift + or otherwise)
+  typedef __attribute__((ext_vector_type(2))) __bf16 vlb_bf2_t;
+  typedef __attribute__((ext_vector_type(2))) float vlb_fl2_t;
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector((vlb_fl2_t){lo, hi}, vlb_bf2_t));
 }
 __device__ __forceinline__ float bflo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bfhi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
@@ -74,7 +76,11 @@ __device__ __forceinline__ float bfhi(uint32_t w) { return __uint_as_float(w & 0
 // bits than bf16 at the same 2 bytes; their magnitudes are O(1..10), far inside the fp16 range (DESIGN.md "precision") ----
 __device__ __forceinline__ float h2f(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
 __device__ __forceinline__ uint16_t f2h(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }   // RNE
-__device__ __forceinline__ uint32_t pack2h(float lo, float hi) { return ((uint32_t)f2h(hi) << 16) | (uint32_t)f2h(lo); }
+__device__ __forceinline__ uint32_t pack2h(float lo, float hi) {        // ONE v_cvt_pk_f16_f32
+  typedef __attribute__((ext_vector_type(2))) _Float16 vlb_h2_t;
+  typedef __attribute__((ext_vector_type(2))) float vlb_fl2h_t;
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector((vlb_fl2h_t){lo, hi}, vlb_h2_t));
+}
 __device__ __forceinline__ float hlo(uint32_t w) { return h2f((uint16_t)(w & 0xffffu)); }
 __device__ __forceinline__ float hhi(uint32_t w) { return h2f((uint16_t)(w >> 16)); }
 // 16-bit element pair decoded as fp16 or bf16
