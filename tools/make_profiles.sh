@@ -18,12 +18,14 @@ rocprofv3 --kernel-trace --stats -d "$OUT/final_trace" -o r -- $CMD > "$OUT/fina
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY -d "$OUT/final_sq" -o r -- $CMD > "$OUT/final_sq.log" 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/final_fetch" -o r -- $CMD > "$OUT/final_fetch.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/final_write" -o r -- $CMD > "$OUT/final_write.log" 2>&1
-# e2e configuration (C3: ResNet-101 trunk + ROIAlign + layer4 head in front of the same step), kernel trace only
+# e2e configuration (C3: ResNet-101 trunk + ROIAlign + layer4 head in front of the same step); VLB_PROFILE_SKIP_E2E=1 skips these four passes
 export VLB_VISION_WGRAD_STREAM=0
+if [ "${VLB_PROFILE_SKIP_E2E:-0}" != 1 ]; then
 rocprofv3 --kernel-trace --stats -d "$OUT/final_e2e_trace" -o r -- $CMD --e2e > "$OUT/final_e2e_trace.log" 2>&1
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY -d "$OUT/final_e2e_sq" -o r -- $CMD --e2e > "$OUT/final_e2e_sq.log" 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/final_e2e_fetch" -o r -- $CMD --e2e > "$OUT/final_e2e_fetch.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/final_e2e_write" -o r -- $CMD --e2e > "$OUT/final_e2e_write.log" 2>&1
+fi
 # summarise on the box and drop the raw rocpd databases (five of them exceed the 64 MiB that gpurun copies back)
 mkdir -p "$OUT/summary"
 python "$ROOT/tools/profile_report.py" "$OUT" "$OUT/summary" "${1:-r03}"
