@@ -420,6 +420,27 @@ int vlb_softmax_f32_fwd(const float* s, const float* mask01, int rows_per_sample
 int vlb_softmax_f32_bwd(const float* p, float* dpd, int rows, int S, int Sp, float drop_p, const uint32_t* seed, uint32_t tag,
                         vlb_stream_t stream);
 
+/* ---- data-parallel gradient exchange for a C / C++ host: RCCL over xGMI (csrc/comm.hip) ---------------------------------------
+ * Replaces the gradient all-reduce that torch DistributedDataParallel / apex DDP issue for the reference
+ * (pretrain/function/train.py:89-90,353-354; vqa/function/train.py:327; vcr/function/train.py:330): one SUM over the ranks of every
+ * gradient bucket per optimizer step; the 1/world average is `grad_scale` of the optimizer entry points.  One communicator = one rank
+ * = one GPU (hipSetDevice first).  RCCL is bound at run time (dlopen; the copy a torch process already holds is reused, VLB_RCCL_PATH
+ * overrides), so the library loads without it.  Collectives are enqueued on `stream` and never synchronise.
+ * dtype: 0 = fp32, 1 = the library's 16-bit type (the wire image written by vlb_cast_f32_bf16).
+ *   vlb_comm_unique_id     : rank 0 fills 128 opaque bytes and distributes them through the host's own channel
+ *   vlb_comm_init          : collective over `world` ranks -> *comm
+ *   vlb_comm_allreduce_bucket      : buf[count] <- SUM over ranks, in place (the all-reduce exchange)
+ *   vlb_comm_reduce_scatter_bucket : out[count / world] <- this rank's slice of the SUM of buf[count]   } the two halves of the sharded
+ *   vlb_comm_allgather_bucket      : out[count] <- the ranks' in[count / world], rank order             } optimizer (ZeRO-1 style)
+ *   vlb_comm_finalize      : destroys the communicator (NULL is a no-op)
+ * The Python host of this repo issues the same collectives through torch.distributed on the same slices (vl-bert_amd/parallel.py). */
+int vlb_comm_unique_id(void* id128);
+int vlb_comm_init(int rank, int world, const void* id128, void** comm);
+int vlb_comm_allreduce_bucket(void* comm, void* buf, long count, int dtype, vlb_stream_t stream);
+int vlb_comm_reduce_scatter_bucket(void* comm, const void* buf, void* out, long count, int dtype, vlb_stream_t stream);
+int vlb_comm_allgather_bucket(void* comm, const void* in, void* out, long count, int dtype, vlb_stream_t stream);
+int vlb_comm_finalize(void* comm);
+
 #ifdef __cplusplus
 }
 #endif

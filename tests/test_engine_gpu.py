@@ -540,6 +540,69 @@ def test_module_api_hidden_states_match_oracle():
     assert rel_fro(gw, p["vlbert.encoder.layer.0.intermediate.dense.weight"].grad) <= 5e-2
 
 
+def _language_checkpoint(params, heads):
+    """`params` (the mirror's names) re-keyed the way a language-only BERT checkpoint names them (TF-style gamma / beta)."""
+    tf = lambda k: k.replace("LayerNorm.weight", "LayerNorm.gamma").replace("LayerNorm.bias", "LayerNorm.beta")
+    ck = {"optimizer.state": torch.zeros(1)}
+    for k, v in params.items():
+        if k.startswith(("encoder.", "pooler.")):
+            ck["bert." + tf(k)] = v.clone()
+        elif k in ("word_embeddings.weight", "position_embeddings.weight"):
+            ck["bert.embeddings." + k] = v.clone()
+        elif k == "token_type_embeddings.weight":
+            ck["bert.embeddings." + k] = v[:2].clone()
+        elif k.startswith("embedding_LayerNorm."):
+            ck["bert.embeddings." + tf(k[len("embedding_"):])] = v.clone()
+        elif heads and k.startswith("mlm_head.predictions."):
+            ck["cls.predictions." + tf(k[len("mlm_head.predictions."):])] = v.clone()
+    if heads:
+        ck["cls.predictions.decoder.weight"] = params["word_embeddings.weight"].clone()
+    return ck
+
+
+def test_module_api_language_pretrained_initialisation(tmp_path, capsys):
+    """language_pretrained_model_path of the mirrors (common/visual_linguistic_bert.py:76-78,243-309,382-469; key mapping pinned
+    against the reference's loader on CPU, tests/test_host_logic_cpu.py): the checkpoint's tensors land in the flat master buffer, the
+    rest keeps its initialisation, and the engine computes with them; the pre-training wrapper picks BERT_PRETRAINED-<epoch>.model."""
+    VL = pkg("common.visual_linguistic_bert")
+    z, cfg, params, ins = _core_fixture()
+    vcfg = _module_config(cfg)["NETWORK"]["VLBERT"]
+    for heads in (False, True):
+        ck = _language_checkpoint(params, heads)
+        path = str(tmp_path / ("lang%d.bin" % heads))
+        torch.save(ck, path)
+        torch.manual_seed(3)
+        net = (VL.VisualLinguisticBertForPretraining(vcfg, path, with_rel_head=False) if heads else VL.VisualLinguisticBert(vcfg, path))
+        assert "Unexpected keys: ['optimizer.state']" in capsys.readouterr().out
+        named = dict(net.named_parameters())
+        loaded = [k for k in params if k.startswith(("encoder.", "embedding_LayerNorm.")) or k in ("word_embeddings.weight", "position_embeddings.weight")
+                  or (heads and k.startswith("mlm_head.predictions."))]
+        assert len(loaded) > 30
+        for k in loaded:
+            assert torch.equal(named[k].detach().cpu(), params[k]), k
+        assert torch.equal(named["token_type_embeddings.weight"][:2].detach().cpu(), params["token_type_embeddings.weight"][:2])
+        assert float(named["visual_ln_text.weight"].abs().max()) == 0.0            # visual_scale_text_init: untouched by the checkpoint
+        twin = (VL.VisualLinguisticBertForPretraining(vcfg, with_rel_head=False) if heads else VL.VisualLinguisticBert(vcfg))
+        twin.load_state_dict(net.state_dict())
+        net.eval(), twin.eval()
+        a = net(*ins) if heads else net(*ins, output_all_encoded_layers=False, output_text_and_object_separately=True)
+        b = twin(*ins) if heads else twin(*ins, output_all_encoded_layers=False, output_text_and_object_separately=True)
+        for x, y in zip(a, b):
+            assert (x is None and y is None) or torch.equal(x, y)
+    # the wrapper's checkpoint choice + from_scratch
+    M = pkg("pretrain.modules")
+    mc = _module_config(cfg)
+    os.replace(str(tmp_path / "lang1.bin"), str(tmp_path / "bert-0003.model"))
+    mc["NETWORK"].update(BERT_PRETRAINED=str(tmp_path / "bert"), BERT_PRETRAINED_EPOCH=3, BERT_MODEL_NAME="bert-base-uncased")
+    wrap = M.ResNetVLBERTForPretraining(mc)
+    wn = dict(wrap.named_parameters())
+    for k in ("encoder.layer.1.output.dense.weight", "word_embeddings.weight", "mlm_head.predictions.transform.LayerNorm.bias"):
+        assert torch.equal(wn["vlbert." + k].detach().cpu(), params[k]), k
+    mc["NETWORK"]["VLBERT"]["from_scratch"] = True
+    wrap2 = M.ResNetVLBERTForPretraining(mc)
+    assert not torch.equal(dict(wrap2.named_parameters())["vlbert.word_embeddings.weight"].detach().cpu(), params["word_embeddings.weight"])
+
+
 def test_module_api_pooler_and_relationship_head_vs_oracle():
     """with_pooler + with_rel_head through the module API: pooled output (base class) and relationship logits
     (pretraining class) and their gradients against the oracle (whose pooler / relationship head are pinned by the

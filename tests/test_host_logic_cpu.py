@@ -151,3 +151,113 @@ def test_vcr_text_layouts_match_the_reference_functions():
         r_ids, r_types, r_tags, r_mask = fn(Stub(), q, qtr, qm, a, at, am)
         ids, types, tags, mask = M.ResNetVLBERT._prepare_text(q, qtr, qm, a, at, am, order=order)
         assert torch.equal(ids, r_ids) and torch.equal(types, r_types) and torch.equal(tags, r_tags) and torch.equal(mask, r_mask.bool()), order
+
+
+# ---- language-only BERT / RoBERTa initialisation (common/language_pretrained.py) ---------------------------------------------
+def _fake_language_checkpoint(ref_sd, style, with_heads, seed=0):
+    """A checkpoint in the naming of a language-only model, with tensors of the shapes `ref_sd` (a reference VisualLinguisticBert*
+    state dict) expects: `bert.` + TF-style gamma / beta LayerNorm names, or `roberta.` + a one-row token-type table + `lm_head.*`."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    rnd = lambda t: torch.randn(t.shape, generator=g)
+    prefix = "bert." if style == "bert" else "roberta."
+    ck = {}
+    for k, v in ref_sd.items():
+        if k.startswith("encoder.") or k.startswith("pooler."):
+            kk = k
+            if style == "bert" and "LayerNorm" in k:
+                kk = k.replace("LayerNorm.weight", "LayerNorm.gamma").replace("LayerNorm.bias", "LayerNorm.beta")
+            ck[prefix + kk] = rnd(v)
+        elif k in ("word_embeddings.weight", "position_embeddings.weight"):
+            ck[prefix + "embeddings." + k] = rnd(v)
+        elif k == "token_type_embeddings.weight":
+            ck[prefix + "embeddings." + k] = rnd(v[:2] if style == "bert" else v[:1])
+        elif k.startswith("embedding_LayerNorm."):
+            ck[prefix + "embeddings.LayerNorm." + ("gamma" if k.endswith("weight") else "beta")] = rnd(v)
+    ck[prefix + "embeddings.bogus.weight"] = torch.zeros(3)            # unexpected under embeddings.
+    ck[prefix + "something.else"] = torch.zeros(2)                     # base class: unexpected; pretraining class: silently dropped
+    ck["optimizer.step"] = torch.zeros(1)                              # no bert. / roberta. prefix
+    if with_heads:
+        for k, v in ref_sd.items():
+            if k.startswith("mlm_head.predictions."):
+                k_ = k[len("mlm_head.predictions."):]
+                if style == "bert":
+                    ck["cls.predictions." + k_.replace("LayerNorm.weight", "LayerNorm.gamma").replace("LayerNorm.bias", "LayerNorm.beta")] = rnd(v)
+                else:
+                    ck["lm_head." + k_.replace("transform.", "").replace("LayerNorm", "layer_norm")] = rnd(v)
+            elif k.startswith("relationsip_head.caption_image_relationship."):
+                ck["cls.seq_relationship." + k[len("relationsip_head.caption_image_relationship."):]] = rnd(v)
+    return ck
+
+
+def test_language_pretrained_plan_matches_the_reference_loader(tmp_path):
+    """common/language_pretrained.plan + apply against the reference's own load_language_pretrained_model (both classes, BERT- and
+    RoBERTa-style checkpoints) run on CPU in this container: same final parameters, same 'unexpected keys' list."""
+    import importlib
+    import os
+    import pytest
+    import torch
+    if not os.path.isdir(os.environ.get("VLBERT_REFERENCE_ROOT", "/root/reference")):
+        pytest.skip("reference tree not present")
+    from oracle import ref_import
+    ref_import.import_reference()
+    from common.visual_linguistic_bert import VisualLinguisticBert as RefBase, VisualLinguisticBertForPretraining as RefPre
+    lp = importlib.import_module("vl-bert_amd.common.language_pretrained")
+    E = ref_import._EasyDict
+    for with_heads in (False, True):
+        for style in ("bert", "roberta"):
+            for with_pooler in (False, True):
+                cfg = E(dict(hidden_size=32, visual_size=32, num_hidden_layers=2, num_attention_heads=4, intermediate_size=64, hidden_act="gelu",
+                             hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, max_position_embeddings=40, type_vocab_size=3,
+                             vocab_size=50, initializer_range=0.02, visual_scale_text_init=0.0, visual_scale_object_init=0.0, visual_ln=True,
+                             with_pooler=with_pooler, visual_region_classes=7, position_padding_idx=-1, obj_pos_id_relative=True,
+                             word_embedding_frozen=False, pos_embedding_frozen=False))
+                torch.manual_seed(1)
+                kw = dict(with_rel_head=with_pooler) if with_heads else {}
+                ref = (RefPre if with_heads else RefBase)(cfg, **kw)
+                before = {k: v.clone() for k, v in ref.state_dict().items()}
+                ck = _fake_language_checkpoint(before, style, with_heads, seed=3)
+                path = str(tmp_path / ("ck_%d_%s_%d.bin" % (with_heads, style, with_pooler)))
+                torch.save(ck, path)
+                import io
+                import contextlib
+                buf = io.StringIO()
+                with contextlib.redirect_stdout(buf):
+                    ref.load_language_pretrained_model(path)
+                after = ref.state_dict()
+                mine = {k: v.clone() for k, v in before.items()}
+                assign, unexpected = lp.plan(torch.load(path), list(mine), with_pooler, pretraining=with_heads,
+                                             with_rel_head=bool(kw.get("with_rel_head", False)), with_mlm_head=True)
+                lp.apply(assign, mine)
+                if with_heads:          # the reference's decoder is the tied word-embedding Parameter
+                    mine["mlm_head.predictions.decoder.weight"] = mine["word_embeddings.weight"]
+                for k in after:
+                    assert torch.equal(after[k], mine[k]), (with_heads, style, with_pooler, k)
+                assert any(not torch.equal(after[k], before[k]) for k in after)
+                assert buf.getvalue().strip() == "Warnings: Unexpected keys: {}.".format(unexpected), (buf.getvalue(), unexpected)
+
+
+def test_language_pretrained_strict_parts_and_path_resolution(tmp_path):
+    import importlib
+    import pytest
+    import torch
+    lp = importlib.import_module("vl-bert_amd.common.language_pretrained")
+    own = ["word_embeddings.weight", "embedding_LayerNorm.weight", "embedding_LayerNorm.bias", "encoder.layer.0.a.weight", "encoder.layer.0.a.bias"]
+    ck = {"bert.embeddings.LayerNorm.gamma": torch.ones(4), "bert.embeddings.LayerNorm.beta": torch.zeros(4),
+          "bert.encoder.layer.0.a.weight": torch.ones(2, 2)}
+    with pytest.raises(RuntimeError, match="Missing key"):           # the encoder is loaded strictly: its bias is absent
+        lp.plan(ck, own, with_pooler=False)
+    ck["bert.encoder.layer.0.a.bias"] = torch.zeros(2)
+    assign, unexpected = lp.plan(ck, own, with_pooler=False)
+    assert unexpected == [] and [a[0] for a in assign] == ["embedding_LayerNorm.weight", "embedding_LayerNorm.bias", "encoder.layer.0.a.weight",
+                                                            "encoder.layer.0.a.bias"]
+    with pytest.raises(RuntimeError, match="expects"):               # a table of another size cannot replace a flat-buffer view
+        lp.apply([("word_embeddings.weight", torch.zeros(5, 4), None)], {"word_embeddings.weight": torch.zeros(6, 4)})
+    # the wrappers' checkpoint choice
+    assert lp.resolve_path({"BERT_PRETRAINED": "", "BERT_MODEL_NAME": "bert-base-uncased"}) is None
+    assert lp.resolve_path({"BERT_PRETRAINED": "/x/bert", "BERT_PRETRAINED_EPOCH": 7, "BERT_MODEL_NAME": str(tmp_path)}) == "/x/bert-0007.model"
+    assert lp.resolve_path({"BERT_PRETRAINED": "", "BERT_MODEL_NAME": str(tmp_path)}) is None
+    (tmp_path / "pytorch_model.bin").write_bytes(b"")
+    assert lp.resolve_path({"BERT_PRETRAINED": "", "BERT_MODEL_NAME": str(tmp_path)}) == str(tmp_path / "pytorch_model.bin")
+    sd, keys = lp.mlm_transform_state_dict({"cls.predictions.transform.LayerNorm.gamma": 1, "cls.predictions.bias": 2, "bert.x": 3})
+    assert sd == {"LayerNorm.weight": 1} and keys == ["cls.predictions.transform.LayerNorm.gamma"]

@@ -99,8 +99,6 @@ class VisualLinguisticBert(nn.Module):
 
     def __init__(self, config, language_pretrained_model_path=None, device=None):
         super().__init__()
-        if language_pretrained_model_path is not None:
-            raise NotImplementedError("loading a language-only BERT checkpoint is host glue that is not mirrored; use load_state_dict")
         if _get(config, "visual_size", _get(config, "hidden_size")) != _get(config, "hidden_size"):
             raise NotImplementedError("visual_size != hidden_size (visual_1x1 projections) is not supported")
         if not _get(config, "visual_ln", True):
@@ -150,6 +148,24 @@ class VisualLinguisticBert(nn.Module):
                     p.zero_()
                 else:
                     p.normal_(0.0, std)
+        if language_pretrained_model_path is not None:         # (:76-78; the pretraining class loads after its heads exist, :335-336)
+            self.load_language_pretrained_model(language_pretrained_model_path)
+
+    def load_language_pretrained_model(self, language_pretrained_model_path):
+        """Initialise embeddings / encoder / pooler (and, for the pretraining class, the MLM and relationship heads) from a language-only
+        BERT or RoBERTa checkpoint (:243-309, :382-469): the key mapping lives in language_pretrained.py (checked against the
+        reference's method on CPU); here the assignments land in the flat fp32 master buffer."""
+        from . import language_pretrained as lp
+        pretrained_state_dict = torch.load(language_pretrained_model_path, map_location=lambda storage, loc: storage)
+        own = list(self._pnames)
+        if self.WITH_HEADS:
+            own.append("mlm_head.predictions.decoder.weight")                    # tied to word_embeddings.weight
+        assign, unexpected = lp.plan(pretrained_state_dict, own, self.with_pooler, pretraining=self.WITH_HEADS,
+                                     with_rel_head=bool(getattr(self, "with_rel_head", False)), with_mlm_head=True)
+        if len(unexpected) > 0:
+            print("Warnings: Unexpected keys: {}.".format(unexpected))
+        lp.apply(assign, self._pnames)
+        torch.autograd.graph.increment_version(self.flat.master)                # cached engines refresh their 16-bit working copies
 
     def _register(self, dotted, param):
         mod = self

@@ -6,7 +6,7 @@ HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 OUT="${1:-$HERE/..}"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -ffp-contract=fast"
-SRCS="api gemm gemm_p8 gemm_tn8 layernorm embed loss attention optim roi_align vision f32_path"
+SRCS="api gemm gemm_p8 gemm_tn8 layernorm embed loss attention optim roi_align vision f32_path comm"
 JOBS="${VLB_BUILD_JOBS:-$(nproc)}"
 mkdir -p "$HERE/obj" "$HERE/obj_f16"
 todo=()

@@ -22,6 +22,8 @@ Anything else raises NotImplementedError (nothing silently falls back to PyTorch
 """
 from collections import OrderedDict
 
+import sys
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -114,6 +116,28 @@ class ResNetVLBERTForPretraining(nn.Module):
             self._vision_names = set(_vision.vision_param_layout(self.cfg.image_num_layers, self.cfg.image_frozen_stages))
             self._image_size = None
         self.init_weight()
+        # language-only BERT initialisation of the vlbert.* parameters (:28-47): BERT_PRETRAINED-<epoch>.model, else
+        # BERT_MODEL_NAME/pytorch_model.bin; `from_scratch` skips it.  (The reference loads inside the VLBERT constructor and then
+        # re-draws only the wrapper-level embeddings in init_weight, :55-63 -- same end state.)
+        from ...common import language_pretrained as _lp
+        path = _lp.resolve_path(net)
+        if path is None:
+            print("Warning: no pretrained language model found, training from scratch!!!", file=sys.stderr)   # (the reference prints to stdout; bench.py owns stdout)
+        elif not _get(vl, "from_scratch", False):
+            self.load_language_pretrained_model(path)
+
+    def load_language_pretrained_model(self, language_pretrained_model_path):
+        """VisualLinguisticBertForPretraining.load_language_pretrained_model (common/visual_linguistic_bert.py:382-469) on this
+        wrapper's `vlbert.*` parameters (key mapping: common/language_pretrained.py)."""
+        from ...common import language_pretrained as _lp
+        sd = torch.load(language_pretrained_model_path, map_location=lambda storage, loc: storage)
+        own = {n[len("vlbert."):]: p for n, p in self._pnames.items() if n.startswith("vlbert.")}
+        assign, unexpected = _lp.plan(sd, list(own) + ["mlm_head.predictions.decoder.weight"], self.cfg.with_pooler, pretraining=True,
+                                      with_rel_head=self.with_rel, with_mlm_head=True)
+        if len(unexpected) > 0:
+            print("Warnings: Unexpected keys: {}.".format(unexpected))
+        _lp.apply(assign, own)
+        torch.autograd.graph.increment_version(self.flat.master)
 
     # -- parameter plumbing -----------------------------------------------------------------------
     def _register(self, dotted, param):

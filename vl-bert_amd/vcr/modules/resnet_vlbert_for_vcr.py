@@ -19,6 +19,8 @@ over the choices) are one autograd node on the library as well (`_AnswerFn`).
 Built as input plumbing: BLIND, NO_GROUNDING, NO_OBJ_ATTENTION, ANSWER_FIRST, QA_ONE_SENT.  Not built: object_word_embed_mode 3, IMAGE_SEMANTIC, the
 bottom-of-the-CNN form of the regulariser (CNN_LOSS_TOP false), mask_position / mask_label (asserted off in the reference too).
 """
+import sys
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -244,7 +246,11 @@ class ResNetVLBERT(nn.Module):
         self.image_feature_extractor = FastRCNN(config, average_pool=True, final_dim=_get(net, "IMAGE_FINAL_DIM", 768),
                                                 enable_cnn_reg_loss=False, device=dev)
         self.object_linguistic_embeddings = nn.Embedding(NUM_OBJ_CLASSES if self.embed_mode == 1 else 1, H).to(dev)
-        self.vlbert = TimeDistributed(VisualLinguisticBert(vl, language_pretrained_model_path=None, device=dev))
+        from ...common import language_pretrained as _lp
+        self.language_pretrained_model_path = _lp.resolve_path(net)                    # (vcr/modules/resnet_vlbert_for_vcr.py:49-58)
+        if self.language_pretrained_model_path is None:
+            print("Warning: no pretrained language model found, training from scratch!!!", file=sys.stderr)   # (the reference prints to stdout; bench.py owns stdout)
+        self.vlbert = TimeDistributed(VisualLinguisticBert(vl, language_pretrained_model_path=self.language_pretrained_model_path, device=dev))
 
         def lin(o, i):
             m = nn.Module()

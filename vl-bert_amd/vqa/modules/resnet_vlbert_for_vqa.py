@@ -10,6 +10,8 @@ with fused bias / ReLU / GELU epilogues, LayerNorm, counter-RNG dropout (vlb_dro
 gradient in one pass), TN weight-gradient GEMMs.  CLASSIFIER_TYPE "2fc" (config default) and "mlm" (the shipped cfgs/vqa/*.yaml)
 are built; "1fc", BLIND, NO_GROUNDING, CLASSIFIER_SIGMOID, cnn_reg_loss raise NotImplementedError.
 """
+import sys
+
 import torch
 import torch.nn as nn
 
@@ -134,7 +136,11 @@ class ResNetVLBERT(nn.Module):
         self.cls_drop = float(_get(net, "CLASSIFIER_DROPOUT", 0.1))
         self.image_feature_extractor = FastRCNN(config, average_pool=True, final_dim=_get(net, "IMAGE_FINAL_DIM", 768), device=dev)
         self.object_linguistic_embeddings = nn.Embedding(1, H).to(dev)
-        self.vlbert = VisualLinguisticBert(vl, language_pretrained_model_path=None, device=dev)
+        from ...common import language_pretrained as _lp
+        self.language_pretrained_model_path = _lp.resolve_path(net)                    # (:37-47)
+        if self.language_pretrained_model_path is None:
+            print("Warning: no pretrained language model found, training from scratch!!!", file=sys.stderr)   # (the reference prints to stdout; bench.py owns stdout)
+        self.vlbert = VisualLinguisticBert(vl, language_pretrained_model_path=self.language_pretrained_model_path, device=dev)
         mlp = nn.Module()
 
         def lin(o, i):
@@ -191,6 +197,16 @@ class ResNetVLBERT(nn.Module):
             if self.classifier == "mlm":
                 t = getattr(self.final_mlp, "0")
                 t.dense.bias.zero_()
+                if self.language_pretrained_model_path is not None:
+                    # the classifier's transform starts from the language model's MLM transform (:97-110).  (Without a checkpoint the
+                    # reference dies in torch.load(None); the mirror keeps the random init so that synthetic benches can run.)
+                    from ...common import language_pretrained as _lp
+                    sd = torch.load(self.language_pretrained_model_path, map_location="cpu")
+                    tsd, keys = _lp.mlm_transform_state_dict(sd)
+                    print("loading pretrained classifier transform keys: {}.".format(keys))
+                    _lp.apply([(k, v, None) for k, v in tsd.items()],
+                              {"dense.weight": t.dense.weight, "dense.bias": t.dense.bias, "LayerNorm.weight": t.LayerNorm.weight,
+                               "LayerNorm.bias": t.LayerNorm.bias}, strict_keys=True)
 
     def fix_params(self):
         pass
