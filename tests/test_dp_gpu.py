@@ -50,3 +50,50 @@ def test_module_mirror_under_distributed_data_parallel():
     """parallel.DistributedDataParallel around the VQA module mirror (vqa/function/train.py:327): gradients = the hand-averaged local
     gradients, identical replicas after two FusedAdamW steps with the fused clip, no_sync() semantics."""
     _run([], tool="dp2_mirror_check.py")
+
+
+_COMM_SCRIPT = r"""
+import ctypes, importlib, sys
+import torch
+sys.path.insert(0, %r)
+L = importlib.import_module("vl-bert_amd._lib")
+ops = importlib.import_module("vl-bert_amd.ops")
+lib = L.load()
+torch.cuda.set_device(0)
+uid = ctypes.create_string_buffer(128)
+assert lib.vlb_comm_unique_id(uid) == 0, lib.vlb_last_error()
+comm = ctypes.c_void_p()
+assert lib.vlb_comm_init(0, 1, uid, ctypes.byref(comm)) == 0, lib.vlb_last_error()
+st = torch.cuda.current_stream().cuda_stream
+g = torch.randn(1 << 20, device="cuda")
+ref = g.clone()
+assert lib.vlb_comm_allreduce_bucket(comm, g.data_ptr(), g.numel(), 0, st) == 0, lib.vlb_last_error()
+w = torch.empty(g.numel(), dtype=ops.BF16, device="cuda")
+ops.cast_f32_bf16(g, w)                                   # the 16-bit wire image of the bucket
+wref = w.clone()
+assert lib.vlb_comm_allreduce_bucket(comm, w.data_ptr(), w.numel(), 1, st) == 0, lib.vlb_last_error()
+shard = torch.empty_like(w)
+assert lib.vlb_comm_reduce_scatter_bucket(comm, w.data_ptr(), shard.data_ptr(), w.numel(), 1, st) == 0, lib.vlb_last_error()
+full = torch.empty_like(w)
+assert lib.vlb_comm_allgather_bucket(comm, shard.data_ptr(), full.data_ptr(), w.numel(), 1, st) == 0, lib.vlb_last_error()
+torch.cuda.synchronize()
+assert torch.equal(g, ref) and torch.equal(w, wref) and torch.equal(shard, wref) and torch.equal(full, wref)
+assert lib.vlb_comm_allreduce_bucket(comm, g.data_ptr(), -1, 0, st) == -1 and b"bad count" in lib.vlb_last_error()
+assert lib.vlb_comm_allreduce_bucket(None, g.data_ptr(), 4, 0, st) == -1
+assert lib.vlb_comm_finalize(comm) == 0, lib.vlb_last_error()
+assert lib.vlb_comm_finalize(None) == 0
+print("VLB_COMM_OK")
+"""
+
+
+def test_c_abi_rccl_exchange_single_rank():
+    """vlb_comm_* (include/vlbert_hip.h): the C host's RCCL binding -- unique id, communicator, in-place all-reduce of an
+    fp32 bucket and of its 16-bit wire image, the reduce-scatter / all-gather halves of the sharded optimizer, argument errors,
+    finalize -- with the one rank a 1-GPU box allows (a world of one is the identity; RCCL refuses two ranks on one device).  Runs in
+    its own process: a communicator bound to the RCCL copy torch loaded."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, "-c", _COMM_SCRIPT % ROOT], env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    print(r.stdout[-2000:])
+    print(r.stderr[-3000:])
+    assert r.returncode == 0 and "VLB_COMM_OK" in r.stdout, r.stderr[-2000:]

@@ -102,6 +102,13 @@ _SIGS = {
     "vlb_rng_advance": "ps",
     "vlb_roi_align_fwd": "pppiiiiiifis",
     "vlb_roi_align_bwd": "pppiiiiiiifis",
+    # RCCL exchange for a C / C++ host (csrc/comm.hip; this Python host issues its collectives through torch.distributed)
+    "vlb_comm_unique_id": "p",
+    "vlb_comm_init": "iipp",
+    "vlb_comm_allreduce_bucket": "pplis",
+    "vlb_comm_reduce_scatter_bucket": "ppplis",
+    "vlb_comm_allgather_bucket": "ppplis",
+    "vlb_comm_finalize": "p",
 }
 _CT = {"p": _P, "l": _L, "i": _I, "f": _F, "u": _U, "s": _P}
 
