@@ -62,15 +62,50 @@ __device__ __forceinline__ bf16x8 frag_tr(const char* img, int blk, int d0, int 
   return __builtin_bit_cast(bf16x8, v);
 }
 
-// Stage one [S][64] head slice (row stride ld elements) into a row-major image at permuted rows; rows >= S zero.
+// Staging of [S][64] head slices (row stride ld elements) into row-major LDS images at permuted rows, rows >= S zero -- in TWO steps,
+// so that a kernel issues the global loads of ALL its tiles (and whatever else its prologue reads) before the first wait.  The loads
+// are unconditional: a row index beyond the sequence is clamped to the last row and the value replaced by zeros afterwards.  (With a
+// load under `if (s < S)` hipcc branches around every single load and waits vmcnt(0) behind it: the prologue of the backward kernel
+// was ten dependent HBM round trips, 65 % of its wave cycles parked -- profiles/r03_gemm_pmc.txt, attn_bwd2_kernel.)
 template <int SP>
-__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, long ld, int S, char* img, int tid) {
+struct TileRegs {
+  uint4 v[SP * 8 / ATT_THREADS];
+};
+
+template <int SP>
+__device__ __forceinline__ void tile_load(const bf16_t* __restrict__ g, long ld, int S, int tid, TileRegs<SP>& r) {
+#pragma unroll
+  for (int it = 0; it < SP * 8 / ATT_THREADS; ++it) {
+    const int P = it * ATT_THREADS + tid, s = min(P >> 3, S - 1), ch = P & 7;
+    r.v[it] = *(const uint4*)(g + (long)s * ld + ch * 8);
+  }
+}
+
+template <int SP>
+__device__ __forceinline__ void tile_store(const TileRegs<SP>& r, int S, char* img, int tid) {
 #pragma unroll
   for (int it = 0; it < SP * 8 / ATT_THREADS; ++it) {
     const int P = it * ATT_THREADS + tid, s = P >> 3, ch = P & 7;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (s < S) v = *(const uint4*)(g + (long)s * ld + ch * 8);
+    const bool in = s < S;
+    const uint4 v = make_uint4(in ? r.v[it].x : 0u, in ? r.v[it].y : 0u, in ? r.v[it].z : 0u, in ? r.v[it].w : 0u);
     *(uint4*)(img + rm_addr(rho(s), ch)) = v;
+  }
+}
+
+// D[q] = sum_d dO[q][d] * O[q][d] from the staged dO chunks and the matching O chunks (8 lanes per row, 8 elements each)
+template <int SP>
+__device__ __forceinline__ void rowdot_store(const TileRegs<SP>& a_, const TileRegs<SP>& o_, int S, float* sD, int tid) {
+#pragma unroll
+  for (int it = 0; it < SP * 8 / ATT_THREADS; ++it) {
+    const int P = it * ATT_THREADS + tid, row = P >> 3, ch = P & 7;
+    const uint4 a = a_.v[it], o = o_.v[it];
+    float d = bflo(a.x) * bflo(o.x) + bfhi(a.x) * bfhi(o.x) + bflo(a.y) * bflo(o.y) + bfhi(a.y) * bfhi(o.y) +
+              bflo(a.z) * bflo(o.z) + bfhi(a.z) * bfhi(o.z) + bflo(a.w) * bflo(o.w) + bfhi(a.w) * bfhi(o.w);
+    d = row < S ? d : 0.f;
+    d += __shfl_xor(d, 1, 64);
+    d += __shfl_xor(d, 2, 64);
+    d += __shfl_xor(d, 4, 64);
+    if (ch == 0) sD[row] = d;
   }
 }
 
@@ -124,11 +159,24 @@ __global__ __launch_bounds__(ATT_THREADS, NU <= 4 ? 4 : 2) void attn_fwd_kernel(
   const int S = p.S;
   const long ld = 3L * p.H;
   const bf16_t* qbase = p.qkv + (long)b * S * ld + h * ATT_D;
-  stage_tile<ATT_SP>(qbase + p.H, ld, S, sK, tid);
-  stage_tile<ATT_SP>(qbase + 2 * p.H, ld, S, sV, tid);
-  if (tid < ATT_SP) sMB[tid] = (tid < S) ? (1.0f - p.mask[b * S + tid]) * -10000.0f : -INFINITY;
-  __syncthreads();
+  // every global read of the prologue is issued before the first wait: K and V tiles, the first Q fragment, the mask row
+  TileRegs<ATT_SP> rk, rv;
+  tile_load<ATT_SP>(qbase + p.H, ld, S, tid, rk);
+  tile_load<ATT_SP>(qbase + 2 * p.H, ld, S, tid, rv);
+  // Q fragment straight from global in B-operand layout: lane (c, g) <- Q[q0+c][32ds+8g ..+8)
+  bf16x8 qf[2];
+  auto load_q = [&](int q0) {
+    const int q = min(q0 + c, S - 1);
+#pragma unroll
+    for (int ds = 0; ds < 2; ++ds) qf[ds] = *(const bf16x8*)(qbase + (long)q * ld + ds * 32 + g * 8);
+  };
+  load_q(wave * 16);
+  const float mrow = p.mask[b * S + min(tid, S - 1)];
   const uint32_t seed = (p.drop_thr && p.seed) ? *p.seed : 0u;
+  tile_store<ATT_SP>(rk, S, sK, tid);
+  tile_store<ATT_SP>(rv, S, sV, tid);
+  if (tid < ATT_SP) sMB[tid] = (tid < S) ? (1.0f - mrow) * -10000.0f : -INFINITY;
+  __syncthreads();
   const uint32_t key = vlb_rng_key(seed, p.tag);
   const int U = (S + 31) >> 5;  // key blocks of 32 actually present
 
@@ -136,13 +184,7 @@ __global__ __launch_bounds__(ATT_THREADS, NU <= 4 ? 4 : 2) void attn_fwd_kernel(
   for (int qs = 0; qs < QS; ++qs) {
   const int q0 = (wave + 8 * qs) * 16;
   if (q0 >= S) break;
-  // Q fragment straight from global in B-operand layout: lane (c, g) <- Q[q0+c][32ds+8g ..+8)
-  bf16x8 qf[2];
-  {
-    const int q = min(q0 + c, S - 1);
-#pragma unroll
-    for (int ds = 0; ds < 2; ++ds) qf[ds] = *(const bf16x8*)(qbase + (long)q * ld + ds * 32 + g * 8);
-  }
+  if (qs > 0) load_q(q0);
 
   f32x4 sc[NU][2];              // [u][half] : S^T tiles (keys x this wave's 16 queries)
 #pragma unroll
@@ -238,33 +280,27 @@ __global__ __launch_bounds__(ATT_THREADS, NU <= 4 ? 4 : 2) void attn_bwd_kernel(
   const bf16_t* qbase = p.qkv + (long)b * S * ld + h * ATT_D;
   const bf16_t* dobase = p.dctx + (long)b * S * p.H + h * ATT_D;
   const bf16_t* obase = p.ctx + (long)b * S * p.H + h * ATT_D;
-  stage_tile<ATT_SP>(qbase, ld, S, sQ, tid);
-  stage_tile<ATT_SP>(qbase + p.H, ld, S, sK, tid);
-  stage_tile<ATT_SP>(qbase + 2 * p.H, ld, S, sV, tid);
-  stage_tile<ATT_SP>(dobase, p.H, S, sdO, tid);
-  // D[q] = sum_d dO[q][d] * O[q][d]   (8 lanes per row, 8 elements each)
-#pragma unroll
-  for (int it = 0; it < ATT_SP * 8 / ATT_THREADS; ++it) {
-    const int P = it * ATT_THREADS + tid, row = P >> 3, ch = P & 7;
-    float d = 0.f;
-    if (row < S) {
-      const uint4 a = *(const uint4*)(dobase + (long)row * p.H + ch * 8);
-      const uint4 o = *(const uint4*)(obase + (long)row * p.H + ch * 8);
-      d = bflo(a.x) * bflo(o.x) + bfhi(a.x) * bfhi(o.x) + bflo(a.y) * bflo(o.y) + bfhi(a.y) * bfhi(o.y) +
-          bflo(a.z) * bflo(o.z) + bfhi(a.z) * bfhi(o.z) + bflo(a.w) * bflo(o.w) + bfhi(a.w) * bfhi(o.w);
-    }
-    d += __shfl_xor(d, 1, 64);
-    d += __shfl_xor(d, 2, 64);
-    d += __shfl_xor(d, 4, 64);
-    if (ch == 0) sD[row] = d;
-  }
+  // every global read of the prologue is issued before the first wait (see tile_load): the four tiles, O for the row dots, mask, lse
+  TileRegs<ATT_SP> rq, rk, rv, rdo, ro;
+  tile_load<ATT_SP>(qbase, ld, S, tid, rq);
+  tile_load<ATT_SP>(qbase + p.H, ld, S, tid, rk);
+  tile_load<ATT_SP>(qbase + 2 * p.H, ld, S, tid, rv);
+  tile_load<ATT_SP>(dobase, p.H, S, tid, rdo);
+  tile_load<ATT_SP>(obase, p.H, S, tid, ro);
+  const float mrow = p.mask[b * S + min(tid, S - 1)];
+  const float lrow = p.lse[((long)b * p.nh + h) * S + min(tid, S - 1)];
+  const uint32_t seed = (p.drop_thr && p.seed) ? *p.seed : 0u;
+  tile_store<ATT_SP>(rq, S, sQ, tid);
+  tile_store<ATT_SP>(rk, S, sK, tid);
+  tile_store<ATT_SP>(rv, S, sV, tid);
+  tile_store<ATT_SP>(rdo, S, sdO, tid);
+  rowdot_store<ATT_SP>(rdo, ro, S, sD, tid);      // D[q] = sum_d dO[q][d] * O[q][d]
   if (tid < ATT_SP) {
-    sMB[tid] = (tid < S) ? (1.0f - p.mask[b * S + tid]) * -10000.0f : -INFINITY;
-    sLSE[tid] = (tid < S) ? p.lse[((long)b * p.nh + h) * S + tid] : 0.f;
+    sMB[tid] = (tid < S) ? (1.0f - mrow) * -10000.0f : -INFINITY;
+    sLSE[tid] = (tid < S) ? lrow : 0.f;
   }
   __syncthreads();
 
-  const uint32_t seed = (p.drop_thr && p.seed) ? *p.seed : 0u;
   const uint32_t key = vlb_rng_key(seed, p.tag);
   const uint32_t bh = (uint32_t)(b * p.nh + h);
   const int U = (S + 31) >> 5;
@@ -437,32 +473,27 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd2_kernel(const AttnPar
   const bf16_t* qbase = p.qkv + (long)b * S * ld + h * ATT_D;
   const bf16_t* dobase = p.dctx + (long)b * S * p.H + h * ATT_D;
   const bf16_t* obase = p.ctx + (long)b * S * p.H + h * ATT_D;
-  stage_tile<ATT_SP>(qbase, ld, S, sQ, tid);
-  stage_tile<ATT_SP>(qbase + p.H, ld, S, sK, tid);
-  stage_tile<ATT_SP>(qbase + 2 * p.H, ld, S, sV, tid);
-  stage_tile<ATT_SP>(dobase, p.H, S, sdO, tid);
-#pragma unroll
-  for (int it = 0; it < ATT_SP * 8 / ATT_THREADS; ++it) {      // D[q] = sum_d dO[q][d] * O[q][d]
-    const int P = it * ATT_THREADS + tid, row = P >> 3, ch = P & 7;
-    float d = 0.f;
-    if (row < S) {
-      const uint4 a = *(const uint4*)(dobase + (long)row * p.H + ch * 8);
-      const uint4 o = *(const uint4*)(obase + (long)row * p.H + ch * 8);
-      d = bflo(a.x) * bflo(o.x) + bfhi(a.x) * bfhi(o.x) + bflo(a.y) * bflo(o.y) + bfhi(a.y) * bfhi(o.y) +
-          bflo(a.z) * bflo(o.z) + bfhi(a.z) * bfhi(o.z) + bflo(a.w) * bflo(o.w) + bfhi(a.w) * bfhi(o.w);
-    }
-    d += __shfl_xor(d, 1, 64);
-    d += __shfl_xor(d, 2, 64);
-    d += __shfl_xor(d, 4, 64);
-    if (ch == 0) sD[row] = d;
-  }
+  // every global read of the prologue is issued before the first wait (see tile_load): the four tiles, O for the row dots, mask, lse
+  TileRegs<ATT_SP> rq, rk, rv, rdo, ro;
+  tile_load<ATT_SP>(qbase, ld, S, tid, rq);
+  tile_load<ATT_SP>(qbase + p.H, ld, S, tid, rk);
+  tile_load<ATT_SP>(qbase + 2 * p.H, ld, S, tid, rv);
+  tile_load<ATT_SP>(dobase, p.H, S, tid, rdo);
+  tile_load<ATT_SP>(obase, p.H, S, tid, ro);
+  const float mrow = p.mask[b * S + min(tid, S - 1)];
+  const float lrow = p.lse[((long)b * p.nh + h) * S + min(tid, S - 1)];
+  const uint32_t seed = (p.drop_thr && p.seed) ? *p.seed : 0u;
+  tile_store<ATT_SP>(rq, S, sQ, tid);
+  tile_store<ATT_SP>(rk, S, sK, tid);
+  tile_store<ATT_SP>(rv, S, sV, tid);
+  tile_store<ATT_SP>(rdo, S, sdO, tid);
+  rowdot_store<ATT_SP>(rdo, ro, S, sD, tid);      // D[q] = sum_d dO[q][d] * O[q][d]
   if (tid < ATT_SP) {
-    sMB[tid] = (tid < S) ? (1.0f - p.mask[b * S + tid]) * -10000.0f : -INFINITY;
-    sLSE[tid] = (tid < S) ? p.lse[((long)b * p.nh + h) * S + tid] : 0.f;
+    sMB[tid] = (tid < S) ? (1.0f - mrow) * -10000.0f : -INFINITY;
+    sLSE[tid] = (tid < S) ? lrow : 0.f;
   }
   __syncthreads();
 
-  const uint32_t seed = (p.drop_thr && p.seed) ? *p.seed : 0u;
   const uint32_t key = vlb_rng_key(seed, p.tag);
   const uint32_t bh = (uint32_t)(b * p.nh + h);
   const int U = (S + 31) >> 5;

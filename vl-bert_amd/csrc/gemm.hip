@@ -193,9 +193,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
       if (RES) {
         const bf16_t* q = res_row + j * 16;
         if (lnres) {     // residual = LayerNorm output re-materialised from the fp16 pre-LN row, its (mean, rstd) and gamma / beta
-          const float mean = p.res_stats[2 * (long)m], rstd = p.res_stats[2 * (long)m + 1];
-          for (int r = 0; r < 4 && (full || n + r < p.N); ++r)
-            v[r] += fmaf((h2f(q[r]) - mean) * rstd, p.res_gamma[n + r], p.res_beta[n + r]);
+          const float2 ms = *(const float2*)(p.res_stats + 2 * (long)m);
+          if (full) {    // whole 4-column group: one 8-B row load, two 16-B parameter loads (the scalar form below is 13 loads)
+            const uint2 w = *(const uint2*)q;
+            const float4 g4 = *(const float4*)(p.res_gamma + n), b4 = *(const float4*)(p.res_beta + n);
+            v[0] += fmaf((hlo(w.x) - ms.x) * ms.y, g4.x, b4.x);
+            v[1] += fmaf((hhi(w.x) - ms.x) * ms.y, g4.y, b4.y);
+            v[2] += fmaf((hlo(w.y) - ms.x) * ms.y, g4.z, b4.z);
+            v[3] += fmaf((hhi(w.y) - ms.x) * ms.y, g4.w, b4.w);
+          } else {
+            for (int r = 0; r < 4 && n + r < p.N; ++r) v[r] += fmaf((h2f(q[r]) - ms.x) * ms.y, p.res_gamma[n + r], p.res_beta[n + r]);
+          }
         } else if (full) {
           const uint2 w = *(const uint2*)q;
           v[0] += bflo(w.x); v[1] += bfhi(w.x); v[2] += bflo(w.y); v[3] += bfhi(w.y);

@@ -29,17 +29,55 @@ struct Row4 {
 };
 
 // f16: the row holds IEEE fp16 instead of bf16 (the encoder's pre-LayerNorm sums, written by vlb_gemm_nt_bf16_ex(out_f16))
+// Loads are UNCONDITIONAL (a column beyond H is clamped to the row's last chunk and its values replaced by zeros) and all of a row's
+// loads are issued before the first decode: with `if (c < H) load` hipcc branches around every load and waits vmcnt(0) behind it
+// (three dependent HBM round trips per 1.5-KB row; the runtime fp16 / bf16 choice added a branch per element pair on top: it is now
+// ONE wave-uniform branch around the decode of the whole row).
+template <int NIT>
+struct Raw4 {
+  uint2 w[NIT];
+};
+
+template <int NIT>
+__device__ __forceinline__ void raw_load_row(const bf16_t* x, int H, int lane, Raw4<NIT>& q) {
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) q.w[i] = *(const uint2*)(x + min((lane + 64 * i) * 4, H - 4));
+}
+
+template <int NIT>
+__device__ __forceinline__ void decode_row(const Raw4<NIT>& q, int H, int lane, Row4<NIT>& r, bool f16) {
+  if (f16) {      // (wave-uniform; both arms are pure VALU, the loads are already in flight)
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const bool in = (lane + 64 * i) * 4 < H;
+      r.v[i][0] = in ? hlo(q.w[i].x) : 0.f; r.v[i][1] = in ? hhi(q.w[i].x) : 0.f; r.v[i][2] = in ? hlo(q.w[i].y) : 0.f; r.v[i][3] = in ? hhi(q.w[i].y) : 0.f;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const bool in = (lane + 64 * i) * 4 < H;
+      r.v[i][0] = in ? bflo(q.w[i].x) : 0.f; r.v[i][1] = in ? bfhi(q.w[i].x) : 0.f; r.v[i][2] = in ? bflo(q.w[i].y) : 0.f; r.v[i][3] = in ? bfhi(q.w[i].y) : 0.f;
+    }
+  }
+}
+
 template <int NIT>
 __device__ __forceinline__ void load_row_bf16(const bf16_t* x, int H, int lane, Row4<NIT>& r, bool f16 = false) {
+  Raw4<NIT> q;
+  raw_load_row(x, H, lane, q);
+  decode_row(q, H, lane, r, f16);
+}
+
+// the same for an fp32 row (LayerNorm backward with an fp32 upstream gradient)
+template <int NIT>
+__device__ __forceinline__ void load_row_f32(const float* x, int H, int lane, Row4<NIT>& r) {
+  float4 w[NIT];
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) w[i] = *(const float4*)(x + min((lane + 64 * i) * 4, H - 4));
 #pragma unroll
   for (int i = 0; i < NIT; ++i) {
-    const int c = (lane + 64 * i) * 4;
-    if (c < H) {
-      const uint2 w = *(const uint2*)(x + c);
-      r.v[i][0] = dec_lo(w.x, f16); r.v[i][1] = dec_hi(w.x, f16); r.v[i][2] = dec_lo(w.y, f16); r.v[i][3] = dec_hi(w.y, f16);
-    } else {
-      r.v[i][0] = r.v[i][1] = r.v[i][2] = r.v[i][3] = 0.f;
-    }
+    const bool in = (lane + 64 * i) * 4 < H;
+    r.v[i][0] = in ? w[i].x : 0.f; r.v[i][1] = in ? w[i].y : 0.f; r.v[i][2] = in ? w[i].z : 0.f; r.v[i][3] = in ? w[i].w : 0.f;
   }
 }
 
@@ -51,8 +89,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __rest
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
-  Row4<NIT> r;
+  Row4<NIT> r, gm, bt;
   load_row_bf16(x + (long)row * ldx, H, lane, r, x_f16 != 0);
+  load_row_f32(gamma, H, lane, gm);          // (issued with the row: nothing below waits for a second round trip)
+  load_row_f32(beta, H, lane, bt);
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < NIT; ++i) s += (r.v[i][0] + r.v[i][1]) + (r.v[i][2] + r.v[i][3]);
@@ -80,11 +120,9 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __rest
   for (int i = 0; i < NIT; ++i) {
     const int c = (lane + 64 * i) * 4;
     if (c < H) {
-      const float4 g = *(const float4*)(gamma + c);
-      const float4 b = *(const float4*)(beta + c);
       uint2 w;
-      w.x = pack2bf((r.v[i][0] - mean) * rstd * g.x + b.x, (r.v[i][1] - mean) * rstd * g.y + b.y);
-      w.y = pack2bf((r.v[i][2] - mean) * rstd * g.z + b.z, (r.v[i][3] - mean) * rstd * g.w + b.w);
+      w.x = pack2bf((r.v[i][0] - mean) * rstd * gm.v[i][0] + bt.v[i][0], (r.v[i][1] - mean) * rstd * gm.v[i][1] + bt.v[i][1]);
+      w.y = pack2bf((r.v[i][2] - mean) * rstd * gm.v[i][2] + bt.v[i][2], (r.v[i][3] - mean) * rstd * gm.v[i][3] + bt.v[i][3]);
       *(uint2*)(yr + c) = w;
     }
   }
@@ -106,13 +144,25 @@ struct Row8 {
 
 template <int NP>
 __device__ __forceinline__ void load_row8_bf16(const bf16_t* x, int H, int lane, Row8<NP>& r, bool f16 = false) {
+  uint4 w[NP];
 #pragma unroll
-  for (int i = 0; i < NP; ++i) {
-    const int c = (lane + 64 * i) * 8;
-    uint4 w = make_uint4(0u, 0u, 0u, 0u);
-    if (c < H) w = *(const uint4*)(x + c);
-    r.v[i][0] = dec_lo(w.x, f16); r.v[i][1] = dec_hi(w.x, f16); r.v[i][2] = dec_lo(w.y, f16); r.v[i][3] = dec_hi(w.y, f16);
-    r.v[i][4] = dec_lo(w.z, f16); r.v[i][5] = dec_hi(w.z, f16); r.v[i][6] = dec_lo(w.w, f16); r.v[i][7] = dec_hi(w.w, f16);
+  for (int i = 0; i < NP; ++i) w[i] = *(const uint4*)(x + min((lane + 64 * i) * 8, H - 8));      // unconditional (see load_row_bf16)
+  if (f16) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const bool in = (lane + 64 * i) * 8 < H;
+      const uint32_t u[4] = {w[i].x, w[i].y, w[i].z, w[i].w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { r.v[i][2 * k] = in ? hlo(u[k]) : 0.f; r.v[i][2 * k + 1] = in ? hhi(u[k]) : 0.f; }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const bool in = (lane + 64 * i) * 8 < H;
+      const uint32_t u[4] = {w[i].x, w[i].y, w[i].z, w[i].w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { r.v[i][2 * k] = in ? bflo(u[k]) : 0.f; r.v[i][2 * k + 1] = in ? bfhi(u[k]) : 0.f; }
+    }
   }
 }
 
@@ -264,54 +314,68 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
 // here the footprint is 12 values per array, two rows in flight, <= 128 VGPRs -> 4 waves per SIMD.
 // Partial dgamma / dbeta vectors are lane-major with LW = NIT * 256: element (i, k) of lane l at (i*4 + k)*64 + l.
 template <int NIT, int RIF>      // RIF rows in flight per wave iteration (2 while the registers allow it)
-__global__ __launch_bounds__(256) void layernorm_bwd4_kernel(const void* __restrict__ dy_, long lddy, int dy_f32, const bf16_t* __restrict__ x,
+__global__ __launch_bounds__(256, (NIT * RIF <= 3 ? 4 : 1)) void layernorm_bwd4_kernel(const void* __restrict__ dy_, long lddy, int dy_f32, const bf16_t* __restrict__ x,
                                                              long ldx, const float* __restrict__ stats, const float* __restrict__ gamma,
                                                              bf16_t* __restrict__ dx, long lddx, bf16_t* __restrict__ dx_drop, long lddd,
                                                              uint32_t drop_thr, float drop_scale, const uint32_t* __restrict__ seedp,
                                                              uint32_t tag, float* __restrict__ dx_acc, long ldacc, float* __restrict__ dgamma,
                                                              float* __restrict__ dbeta, float* __restrict__ ws, int rows, int H, int x_f16) {
-  extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][2][LW]
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][2][LW] + gamma [4 waves][NIT][64] float4
   constexpr int LW = NIT * 256;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t seed = (drop_thr && seedp) ? *seedp : 0u;
   const bool want_gb = (dgamma != nullptr) || (dbeta != nullptr);
-  float gsum[NIT][4], bsum[NIT][4], gam[NIT][4];
+  float gsum[NIT][4], bsum[NIT][4];
+  // gamma of the lane's columns lives in LDS (behind the reduction area, one float4 per (pass, lane), written and read by the SAME
+  // lane: no barrier), not in 4 NIT registers for the whole row loop: with every load of an iteration in flight at once the kernel
+  // would not fit the 128 registers of 4 waves per SIMD otherwise.  The opaque copy of the address keeps the reads inside the loop.
+  float4* const gam_l = (float4*)(red + 8 * LW) + wave * NIT * 64 + lane;
+  {
+    Row4<NIT> g0;
+    load_row_f32(gamma, H, lane, g0);
 #pragma unroll
-  for (int i = 0; i < NIT; ++i) {
-    const int c = (lane + 64 * i) * 4;
-    float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (c < H) g0 = *(const float4*)(gamma + c);
-    gam[i][0] = g0.x; gam[i][1] = g0.y; gam[i][2] = g0.z; gam[i][3] = g0.w;
+    for (int i = 0; i < NIT; ++i) {
+      gam_l[i * 64] = make_float4(g0.v[i][0], g0.v[i][1], g0.v[i][2], g0.v[i][3]);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) gsum[i][k] = bsum[i][k] = 0.f;
+      for (int k = 0; k < 4; ++k) gsum[i][k] = bsum[i][k] = 0.f;
+    }
   }
   const int nw = blockDim.x >> 6, step = gridDim.x * nw;
   for (int row0 = blockIdx.x * nw + wave; row0 < rows; row0 += RIF * step) {
     Row4<NIT> xr[RIF], dyr[RIF];
     float mean[RIF], rstd[RIF];
     bool has[RIF];
+    // every load of the iteration (x rows, dy rows, row statistics) is issued before the first decode waits for one
+    Raw4<NIT> qx[RIF], qd[RIF];
+    float2 ms[RIF];
 #pragma unroll
     for (int t = 0; t < RIF; ++t) {
       has[t] = row0 + t * step < rows;
       const int row = has[t] ? row0 + t * step : row0;
-      load_row_bf16(x + (long)row * ldx, H, lane, xr[t], x_f16 != 0);
-      if (dy_f32) {
-        const float* d = (const float*)dy_ + (long)row * lddy;
+      raw_load_row(x + (long)row * ldx, H, lane, qx[t]);
+      if (!dy_f32) raw_load_row((const bf16_t*)dy_ + (long)row * lddy, H, lane, qd[t]);
+      ms[t] = *(const float2*)(stats + 2 * (long)row);
+    }
 #pragma unroll
-        for (int i = 0; i < NIT; ++i) {
-          const int c = (lane + 64 * i) * 4;
-          float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (c < H) v0 = *(const float4*)(d + c);
-          dyr[t].v[i][0] = v0.x; dyr[t].v[i][1] = v0.y; dyr[t].v[i][2] = v0.z; dyr[t].v[i][3] = v0.w;
-        }
-      } else {
-        load_row_bf16((const bf16_t*)dy_ + (long)row * lddy, H, lane, dyr[t]);
-      }
-      const float2 ms = *(const float2*)(stats + 2 * (long)row);
-      mean[t] = ms.x;
-      rstd[t] = ms.y;
+    for (int t = 0; t < RIF; ++t) {
+      const int row = has[t] ? row0 + t * step : row0;
+      if (dy_f32) load_row_f32((const float*)dy_ + (long)row * lddy, H, lane, dyr[t]);
+      else decode_row(qd[t], H, lane, dyr[t], false);
+      decode_row(qx[t], H, lane, xr[t], x_f16 != 0);
+      mean[t] = ms[t].x;
+      rstd[t] = ms[t].y;
     }
     float s1[RIF], s2[RIF];
+    float gam[NIT][4];
+    {
+      const float4* gp = gam_l;
+      asm volatile("" : "+v"(gp));
+#pragma unroll
+      for (int i = 0; i < NIT; ++i) {
+        const float4 g4 = gp[i * 64];
+        gam[i][0] = g4.x; gam[i][1] = g4.y; gam[i][2] = g4.z; gam[i][3] = g4.w;
+      }
+    }
 #pragma unroll
     for (int t = 0; t < RIF; ++t) {
       s1[t] = s2[t] = 0.f;
@@ -490,10 +554,15 @@ static int ln_bwd_impl(const void* dy, long lddy, int dy_f32, const void* x, lon
   int LW, cpl_log2;
   if (g_ln_bwd4) {
     const int nit = vlb_cdiv(H, 256);
-#define LN_BWD4(NIT, RIF)                                                                                                         \
-  hipLaunchKernelGGL((layernorm_bwd4_kernel<NIT, RIF>), dim3(blocks), dim3(256), 8 * NIT * 256 * sizeof(float), stream, dy, lddy,   \
-                     dy_f32, (const bf16_t*)x, ldx, stats, gamma, (bf16_t*)dx, lddx, (bf16_t*)dx_drop, lddd, thr,                   \
-                     vlb_drop_scale(thr), seed, tag, dx_acc, ldacc, dgamma, dbeta, ws, rows, H, x_f16)
+#define LN_BWD4(NIT, RIF)                                                                                                      \
+  do {                                                                                                                          \
+    constexpr size_t smem = (8 * NIT * 256 + 4 * NIT * 256) * sizeof(float);      /* reduction area + the lanes' gamma */          \
+    if (smem > 65536)                                                                                                           \
+      (void)hipFuncSetAttribute((const void*)layernorm_bwd4_kernel<NIT, RIF>, hipFuncAttributeMaxDynamicSharedMemorySize, smem); \
+    hipLaunchKernelGGL((layernorm_bwd4_kernel<NIT, RIF>), dim3(blocks), dim3(256), smem, stream, dy, lddy, dy_f32,               \
+                       (const bf16_t*)x, ldx, stats, gamma, (bf16_t*)dx, lddx, (bf16_t*)dx_drop, lddd, thr, vlb_drop_scale(thr), \
+                       seed, tag, dx_acc, ldacc, dgamma, dbeta, ws, rows, H, x_f16);                                             \
+  } while (0)
     // rows in flight per wave: 2 while the kernel stays near 128 VGPRs (4 waves per SIMD); g_ln_bwd4 == 2 forces 2 for H = 768 / 1024
     if (nit <= 1) LN_BWD4(1, 2); else if (nit == 2) LN_BWD4(2, 2);
     else if (nit == 3) { if (g_ln_bwd4 == 2) LN_BWD4(3, 2); else LN_BWD4(3, 1); }
