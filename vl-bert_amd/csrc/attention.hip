@@ -121,12 +121,13 @@ __device__ __forceinline__ void drop8(float* v, uint32_t key, uint32_t base, uin
   uint32_t h[5];
 #pragma unroll
   for (int k = 0; k < 5; ++k) h[k] = vlb_pair_hash(p0 + k, key);
+  // the 16-bit fields of the run, in element order, are the 160-bit string h[0..4] read from bit 16 * odd: one funnel shift per
+  // pair (v_alignbit_b32) instead of two selects per element
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const uint32_t hs = odd ? h[(j + 1) >> 1] : h[j >> 1];              // pair of element base+j
-    const uint32_t member = (j & 1) ^ odd;                               // (base + j) & 1
-    const uint32_t bits = member ? (hs >> 16) : (hs & 0xffffu);
-    v[j] = (bits >= thr) ? v[j] * scale : 0.f;
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t w = __builtin_amdgcn_alignbit(h[k + 1], h[k], odd << 4);
+    v[2 * k] = ((w & 0xffffu) >= thr) ? v[2 * k] * scale : 0.f;
+    v[2 * k + 1] = ((w >> 16) >= thr) ? v[2 * k + 1] * scale : 0.f;
   }
 }
 

@@ -326,11 +326,30 @@ __global__ __launch_bounds__(512) void embed_bwd_kernel(const EmbedBwdParams p) 
 
   // gridDim.y workgroups share one sample: each takes a contiguous chunk of its S rows
   const int rows_per = (p.S + gridDim.y - 1) / gridDim.y, s_lo = blockIdx.y * rows_per, s_hi = min(p.S, s_lo + rows_per);
+  // gamma of the lane's columns is loop-invariant (columns beyond H: clamped load, masked use)
+  float gam[NIT][4];
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const float4 gm = *(const float4*)(p.gamma + min((lane + 64 * i) * 4, H - 4));
+    gam[i][0] = gm.x; gam[i][1] = gm.y; gam[i][2] = gm.z; gam[i][3] = gm.w;
+  }
   for (int s = s_lo + wave; s < s_hi; s += nwave) {
     const long row = (long)b * p.S + s;
-    const int code = p.code[row], kind = code >> 16, idx = code & 0xffff;
+    // every load of the row -- its code, its statistics, the saved pre-LN row, the gradient row -- is issued before the first use
+    // (unconditional, clamped columns: with loads under `if (c < H)` hipcc waited vmcnt(0) behind each of them, ~8 dependent round
+    // trips per row)
+    const int code = p.code[row];
+    const float2 st = *(const float2*)(p.stats + 2 * row);
+    uint2 wxr[NIT], wdr[NIT];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int cc = min((lane + 64 * i) * 4, H - 4);
+      wxr[i] = *(const uint2*)(p.pre + row * H + cc);
+      wdr[i] = *(const uint2*)(p.dy + row * H + cc);
+    }
+    const int kind = code >> 16, idx = code & 0xffff;
     if (kind == KIND_PAD) continue;  // pad rows never reach a loss; their dy is exactly zero
-    const float mean = p.stats[2 * row], rstd = p.stats[2 * row + 1];
+    const float mean = st.x, rstd = st.y;
     float xh[NIT][4], g[NIT][4];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -339,8 +358,7 @@ __global__ __launch_bounds__(512) void embed_bwd_kernel(const EmbedBwdParams p) 
 #pragma unroll
       for (int k = 0; k < 4; ++k) xh[i][k] = g[i][k] = 0.f;
       if (c < H) {
-        const uint2 wx = *(const uint2*)(p.pre + row * H + c);
-        const uint2 wd = *(const uint2*)(p.dy + row * H + c);
+        const uint2 wx = wxr[i], wd = wdr[i];
         float x[4] = {bflo(wx.x), bfhi(wx.x), bflo(wx.y), bfhi(wx.y)};
         float d[4] = {bflo(wd.x), bfhi(wd.x), bflo(wd.y), bfhi(wd.y)};
         if (p.drop_thr) {
@@ -351,14 +369,12 @@ __global__ __launch_bounds__(512) void embed_bwd_kernel(const EmbedBwdParams p) 
           d[2] = ((h1 & 0xffffu) >= p.drop_thr) ? d[2] * p.drop_scale : 0.f;
           d[3] = ((h1 >> 16) >= p.drop_thr) ? d[3] * p.drop_scale : 0.f;
         }
-        const float4 gm = *(const float4*)(p.gamma + c);
-        const float gg[4] = {gm.x, gm.y, gm.z, gm.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           xh[i][k] = (x[k] - mean) * rstd;
           gs[i][k] += d[k] * xh[i][k];
           bs[i][k] += d[k];
-          g[i][k] = d[k] * gg[k];
+          g[i][k] = d[k] * gam[i][k];
           s1 += g[i][k];
           s2 += g[i][k] * xh[i][k];
         }
