@@ -26,3 +26,25 @@ for M, N, K in ((25856, 2304, 768), (25856, 768, 768), (25856, 3072, 768), (2585
     fl = 2.0 * M * N * K
     print("%6d x %5d x %5d : vendor %7.1f us = %6.1f TF/s (zero-filled A: %6.1f TF/s) | vlb_gemm_nt_bf16 %7.1f us = %6.1f TF/s" %
           (M, N, K, us_v, fl / us_v / 1e6, fl / us_z / 1e6, us_o, fl / us_o / 1e6))
+
+# ---- weight gradient (TN): dW[N_out, K_in] = dY^T X over M = 25856 rows; the library runs the four of a layer as one grouped launch
+if "--more" in sys.argv:
+    M = 25856
+    X = (torch.rand((M, 768), device=d) * 2 - 1).to(torch.bfloat16)
+    for n_out, k_in in ((2304, 768), (768, 768), (3072, 768), (768, 3072)):
+        dY = (torch.rand((M, n_out), device=d) * 2 - 1).to(torch.bfloat16)
+        Xk = X if k_in == 768 else (torch.rand((M, k_in), device=d) * 2 - 1).to(torch.bfloat16)
+        out = torch.empty((n_out, k_in), dtype=torch.float32, device=d)
+        us_v = t(lambda: torch.matmul(dY.t(), Xk))                 # bf16 output (the vendor call cannot accumulate to fp32 from bf16 inputs here)
+        fl = 2.0 * M * n_out * k_in
+        print("wgrad %5d x %5d over %d rows : vendor (bf16 out) %7.1f us = %6.1f TF/s" % (n_out, k_in, M, us_v, fl / us_v / 1e6))
+    # ---- attention: torch's fused SDPA (flash / CK backend) at the model shape, forward and forward + backward
+    import torch.nn.functional as F
+    B, nh, S, dh = 256, 12, 101, 64
+    q, k, v = [(torch.randn((B, nh, S, dh), device=d)).to(torch.bfloat16).requires_grad_(True) for _ in range(3)]
+    us_f = t(lambda: F.scaled_dot_product_attention(q, k, v, dropout_p=0.1))
+    def fb():
+        o = F.scaled_dot_product_attention(q, k, v, dropout_p=0.1)
+        o.backward(torch.ones_like(o))
+    us_fb = t(fb)
+    print("attention B=256 h=12 S=101 d=64 p=0.1: torch SDPA fwd %.1f us, fwd+bwd %.1f us (vlb: fwd 41, bwd 93 -> 134)" % (us_f, us_fb))
