@@ -1,0 +1,82 @@
+"""Compile-outcome contracts of the hot non-GEMM kernels, checked on the ISA hipcc emits (no GPU: hipcc cross-compiles gfx950 here).
+
+The kernels' speed depends on things the source does not guarantee: that all loads of a prologue / loop iteration are issued as ONE
+burst with counted waits (a load under a lane condition becomes `branch + load + s_waitcnt vmcnt(0)`: ten dependent HBM round trips
+in the attention backward before round 3's fix -- DESIGN.md §3, "Serialised prologue loads"), that the register count stays under the
+occupancy step the launch geometry assumes, and that nothing spills.  tools/isa_lint.py extracts those facts; this test pins them."""
+import importlib.util
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+spec = importlib.util.spec_from_file_location("isa_lint", os.path.join(ROOT, "tools", "isa_lint.py"))
+L = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(L)
+
+pytestmark = pytest.mark.skipif(not L.available(), reason="hipcc not installed")
+CSRC = os.path.join(ROOT, "vl-bert_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def attention():
+    return L.kernels(L.compile_isa(os.path.join(CSRC, "attention.hip")))
+
+
+@pytest.fixture(scope="module")
+def layernorm():
+    return L.kernels(L.compile_isa(os.path.join(CSRC, "layernorm.hip")))
+
+
+def test_attention_prologues_issue_their_loads_in_one_burst(attention):
+    fwd = L.find(attention, r"attn_fwd_kernelILi4ELi1E")
+    bwd2 = L.find(attention, r"attn_bwd2_kernel")
+    bwd = L.find(attention, r"attn_bwd_kernelILi4ELi1E")
+    # forward: K and V tiles (4 x 16 B per thread), the first Q fragment (2) and the mask row before the first wait
+    assert L.loads_before_first_wait(fwd["body"]) >= 7
+    # backward: Q, K, V, dO tiles (8), O for the row dots (2), mask and lse rows (2)
+    assert L.loads_before_first_wait(bwd2["body"]) >= 12
+    assert L.loads_before_first_wait(bwd["body"]) >= 12
+    for k in (fwd, bwd2, bwd):
+        assert L.serialized_loads(k["body"]) == 0
+        assert k["spill"] == 0 and k["scratch"] == 0
+    # the first wait of the backward is a COUNTED one (the oldest load of the burst, not the whole queue)
+    body = bwd2["body"]
+    first = next(l for l in body if "s_waitcnt" in l and "vmcnt(" in l)
+    assert "vmcnt(0)" not in first, first
+
+
+def test_attention_register_budgets(attention):
+    # launch geometry: forward 4 workgroups of 8 waves per CU (<= 64 VGPRs), backward 2 (<= 128)
+    assert L.find(attention, r"attn_fwd_kernelILi4ELi1E")["vgpr"] <= 64
+    assert L.find(attention, r"attn_bwd2_kernel")["vgpr"] <= 128
+    assert L.find(attention, r"attn_bwd_kernelILi4ELi1E")["vgpr"] <= 128
+    assert L.find(attention, r"attn_fwd_kernelILi8ELi2E")["vgpr"] <= 128
+    assert L.find(attention, r"attn_bwd_kernelILi8ELi2E")["vgpr"] <= 128
+
+
+def test_layernorm_rows_are_loaded_in_one_burst(layernorm):
+    fwd = L.find(layernorm, r"layernorm_fwd_kernelILi3E")            # H = 768: three 8-B chunks per lane + gamma / beta
+    assert L.loads_before_first_wait(fwd["body"]) >= 3 and L.serialized_loads(fwd["body"]) == 0
+    assert fwd["vgpr"] <= 64 and fwd["spill"] == 0
+    fwd4 = L.find(layernorm, r"layernorm_fwd_kernelILi4E")           # H = 1024
+    assert L.serialized_loads(fwd4["body"]) == 0 and fwd4["vgpr"] <= 72
+    bwd = L.find(layernorm, r"layernorm_bwd4_kernelILi3ELi1E")        # the encoder's backward at H = 768
+    assert bwd["vgpr"] <= 128 and bwd["spill"] == 0 and bwd["scratch"] == 0       # 4 waves per SIMD: LN_MAX_BLOCKS = 4 workgroups per CU
+    assert L.serialized_loads(bwd["body"]) == 0
+    # inside the row loop: x (3), dy (3) and the row statistics are in flight together -- find the loop's first row load
+    body = bwd["body"]
+    loop = next(i for i, l in enumerate(body) if "global_load_dwordx2" in l)
+    assert L.loads_before_first_wait(body, loop) >= 7
+    bwd1024 = L.find(layernorm, r"layernorm_bwd4_kernelILi4ELi1E")    # H = 1024 (VL-BERT-large): 3 waves per SIMD, no spill
+    assert bwd1024["vgpr"] <= 168 and bwd1024["spill"] == 0 and L.serialized_loads(bwd1024["body"]) == 0
+
+
+def test_grouped_weight_gradient_main_loop_is_clean():
+    ks = L.kernels(L.compile_isa(os.path.join(CSRC, "gemm_tn8.hip")))
+    k = L.find(ks, r"gemm_tn8_kernel")
+    lo, hi = L.mfma_region(k["body"])
+    inner = L.region_counts(k["body"], lo, hi)
+    assert inner["mfma"] == 128 and inner["scratch"] == 0           # two K tiles x four phases x 16 MFMAs, no spill traffic in the loop
+    assert inner["vmcnt0"] <= 1                                      # (the end-of-stream drain; the steady state uses counted waits)
+    assert k["spill"] == 0 and k["vgpr"] <= 256
