@@ -261,3 +261,40 @@ def test_language_pretrained_strict_parts_and_path_resolution(tmp_path):
     assert lp.resolve_path({"BERT_PRETRAINED": "", "BERT_MODEL_NAME": str(tmp_path)}) == str(tmp_path / "pytorch_model.bin")
     sd, keys = lp.mlm_transform_state_dict({"cls.predictions.transform.LayerNorm.gamma": 1, "cls.predictions.bias": 2, "bert.x": 3})
     assert sd == {"LayerNorm.weight": 1} and keys == ["cls.predictions.transform.LayerNorm.gamma"]
+
+
+def test_bench_other_configs_summarises_children_and_survives_failures(monkeypatch):
+    """bench.other_configs(): the child bench lines of BASELINE configs 3 / 4 are condensed into the default line; a failing or
+    hanging child becomes an {"error": ...} entry and never an exception (the headline line must still print)."""
+    import importlib.util
+    import json
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("vlb_bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    calls = []
+
+    class R:
+        def __init__(self, rc, out, err=""):
+            self.returncode, self.stdout, self.stderr = rc, out, err
+
+    def fake_run(cmd, **kw):
+        calls.append(cmd)
+        assert kw.get("timeout") and kw.get("capture_output")
+        if "--e2e" in cmd:
+            line = json.dumps({"metric": "samples/sec e2e", "value": 740.0, "unit": "samples/s", "ms_per_step": 21.6, "dtype": "bf16",
+                               "config": {"workload": "C3"}, "roofline": {"achieved": 320.4, "frac": 0.128, "peak": 2500.0}})
+            return R(0, "some warning on stdout\n" + line + "\n")
+        raise subprocess.TimeoutExpired(cmd, kw["timeout"])
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    out = bench.other_configs()
+    assert set(out) == {"config3_e2e", "config4_vqa_fp32"} and len(calls) == 2
+    c3 = out["config3_e2e"]
+    assert c3["value"] == 740.0 and c3["ms_per_step"] == 21.6 and c3["gemm_frac_of_peak"] == 0.128 and c3["workload"] == "C3"
+    assert c3["cmd"].startswith("python bench.py --e2e") and "--no-cpu-baseline" in c3["cmd"]
+    assert "error" in out["config4_vqa_fp32"] and "TimeoutExpired" in out["config4_vqa_fp32"]["error"]
+    monkeypatch.setattr(subprocess, "run", lambda cmd, **kw: R(1, "", "boom"))
+    out = bench.other_configs()
+    assert all("error" in v and "boom" in v["error"] for v in out.values())
