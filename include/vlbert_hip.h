@@ -251,6 +251,12 @@ int vlb_dropout_bf16(const void* x, void* y, long n, float drop_p, const uint32_
 /* x[0..n) *= alpha: the 1 / world average of an all-reduced gradient handed back through autograd (parallel.DistributedDataParallel) */
 int vlb_scale_f32(float* x, long n, float alpha, vlb_stream_t stream);
 int vlb_zero_ranges_f32(float* base, const int64_t* ranges, const int32_t* block_start, int n, int total_blocks, vlb_stream_t stream);
+/* dst[dst_start + i] = src[src_start + i] over n ranges {src_start, dst_start, length} in one launch (block_start: running count of
+ * 1024-float blocks, n + 1 entries): pack / unpack of the fp32-read parameters (biases, LayerNorm gamma / beta) that the sharded
+ * data-parallel optimizer replicates after its owner-only AdamW -- replaces the implicit "every rank updates everything" of DDP,
+ * pretrain/function/train.py:89-90 */
+int vlb_copy_ranges_f32(const float* src, float* dst, const int64_t* ranges, const int32_t* block_start, int n, int total_blocks,
+                        vlb_stream_t stream);
 
 int vlb_sumsq_f32(const float* g, long n, float* out, vlb_stream_t stream);
 /* same sum with a fixed summation order (per-block partials in `partials[partials_len]`, then one block): bit-identical on every

@@ -35,11 +35,17 @@ def _run(extra, tool="dp2_check.py"):
     assert r.returncode == 0, r.stderr[-2000:]
     assert r.stdout.count("parameters identical to rank 0 after 2 D") == 2 and "identical to rank 0 after 2 DP steps: False" not in r.stdout \
         and "after 2 DDP steps: False" not in r.stdout
+    return r.stdout
 
 
 @pytest.mark.parametrize("mode", ["sharded", "allreduce"])
 def test_two_ranks_on_one_gpu_precomputed(mode):
-    _run(["--mode", mode])
+    out = _run(["--mode", mode])
+    if mode == "sharded":
+        # the fp32-read tensors (biases, LayerNorm parameters) are replicated with the weight gather, checked BEFORE any master gather,
+        # and a 5-step sharded trajectory equals the all-reduce one (round-3 ADVICE: stale biases on the non-owner ranks)
+        assert out.count("fp32-read tensors identical to rank 0 before the master gather: True") == 2, out[-2000:]
+        assert out.count("steps sharded vs allreduce") == 2, out[-2000:]
 
 
 def test_two_ranks_on_one_gpu_e2e_sharded():

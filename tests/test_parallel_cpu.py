@@ -331,3 +331,108 @@ def test_bf16_wire_error_world8():
     P = importlib.import_module("vl-bert_amd.parallel")
     assert P.default_wire_dtype(8) == torch.bfloat16 and P.default_wire_dtype(9) is None and P.default_wire_dtype(256) is None
     mp.spawn(_wire8_worker, args=(8, _free_port()), nprocs=8, join=True)
+
+
+def _replicated_worker(rank, world, port):
+    """Sharded optimizer: the fp32-read tensors (biases, LayerNorm parameters) are updated on the owner only -- gather_params must hand
+    every rank the owner's fp32 values bit for bit, while the rest of the master stays rank-local (stale biases on the
+    non-owners)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    E = importlib.import_module("vl-bert_amd.engine")
+    P = importlib.import_module("vl-bert_amd.parallel")
+    import math
+    cfg, offsets, numel, vstart, _ = _padded_layout(world)
+    shapes = E.param_layout(cfg)
+    small = [(offsets[n], offsets[n] + math.prod(sh)) for n, sh in shapes.items()
+             if len(sh) == 1 or n == "object_mask_visual_embedding.weight"]
+    assert len(small) > 10 * cfg.num_hidden_layers
+    grad = torch.zeros(numel)
+    b = P.GradBuckets(grad, offsets, numel, cfg.num_hidden_layers, bucket_bytes=300_000, mode="sharded", wire_dtype=None)
+    b.set_replicated_fp32(small)
+    # the "owner's update": every rank writes rank-specific values into the slices it owns, garbage elsewhere
+    truth = torch.randn(numel, generator=torch.Generator().manual_seed(3))
+    master = torch.full((numel,), float("nan"))
+    for p_off, _, n in b.owned_rows():
+        master[p_off:p_off + n] = truth[p_off:p_off + n]
+    own_mask = torch.zeros(numel, dtype=torch.bool)
+    for p_off, _, n in b.owned_rows():
+        own_mask[p_off:p_off + n] = True
+    w16 = torch.zeros(numel, dtype=torch.bfloat16)
+    wshard = torch.zeros(numel // world, dtype=torch.bfloat16)
+    for p_off, c_off, n in b.owned_rows():
+        wshard[c_off:c_off + n] = master[p_off:p_off + n].to(torch.bfloat16)
+    b.gather_params(w16, wshard, master=master, vision_master=False)
+    b.wait_params("front")          # the first wait of a forward unpacks the replicated image
+    small_mask = torch.zeros(numel, dtype=torch.bool)
+    for lo, hi in small:
+        small_mask[lo:hi] = True
+    assert torch.equal(master[small_mask], truth[small_mask]), "fp32-read tensors are not the owners' values on rank %d" % rank
+    rest = ~small_mask & ~own_mask
+    assert bool(torch.isnan(master[rest]).all()), "non-replicated master slices must stay rank-local"
+    b.wait_params("all")
+    assert torch.equal(w16, truth.to(torch.bfloat16))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_replicates_fp32_read_tensors(world):
+    mp.spawn(_replicated_worker, args=(world, _free_port()), nprocs=world, join=True)
+
+
+def _ddp_rest_worker(rank, world, port):
+    """parallel.DistributedDataParallel on a module without a VL-BERT core: the coalesced all-reduce covers every parameter even when a
+    rank's backward did not reach one, the finalizer is armed from the output, non-contiguous parameters are broadcast."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    P = importlib.import_module("vl-bert_amd.parallel")
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = torch.nn.Linear(4, 4)
+            self.b = torch.nn.Linear(4, 4)
+            self.c = torch.nn.Linear(4, 4)          # used by nobody
+            self.t = torch.nn.Parameter(torch.randn(4, 6).t())     # non-contiguous
+
+        def forward(self, x, use_b):
+            y = self.a(x) + (x @ self.t.t()[:, :4].t() if False else 0)
+            y = y + (self.t[:4, :4] * 0).sum()
+            return self.b(y).sum() if use_b else y.sum()
+
+    torch.manual_seed(10 + rank)
+    net = Net()
+    ddp = P.DistributedDataParallel(net)
+    ref = [p.detach().clone() for p in net.parameters()]
+    for p in ref:
+        q = p.clone()
+        dist.broadcast(q, src=0)
+        assert torch.equal(p, q), "start-up broadcast left the replicas different"
+    x = torch.randn(3, 4, generator=torch.Generator().manual_seed(20 + rank))
+    loss = ddp(x, use_b=(rank == 0))
+    loss.backward()
+    # expected: the average of the ranks' local gradients, parameters no rank used keep grad None
+    net2 = Net()
+    net2.load_state_dict(net.state_dict())
+    want = {}
+    for r in range(world):
+        net2.zero_grad()
+        xr = torch.randn(3, 4, generator=torch.Generator().manual_seed(20 + r))
+        net2(xr, use_b=(r == 0)).backward()
+        for n, p in net2.named_parameters():
+            if p.grad is not None:
+                want[n] = want.get(n, 0) + p.grad / world
+    for n, p in net.named_parameters():
+        if n in want:
+            assert p.grad is not None and torch.allclose(p.grad, want[n], atol=1e-6), n
+        else:
+            assert p.grad is None, n
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ddp_wrapper_reduces_every_parameter_gloo_world2():
+    mp.spawn(_ddp_rest_worker, args=(2, _free_port()), nprocs=2, join=True)

@@ -69,6 +69,7 @@ def main():
     assert err < (1e-2 if wire16 else (1e-3 if e2e else 1e-6)), err
     assert float((red.float() - local).abs().max()) > 0
     # (1) two full steps -> identical parameters on both ranks
+    start_master = eng.P.master.clone()
     for _ in range(2):
         eng.train_step()
     torch.cuda.synchronize()
@@ -76,6 +77,16 @@ def main():
         # rank computes the next forward with must be its bf16 rounding
         eng.forward(True)                  # drains the weight gathers still in flight
         torch.cuda.synchronize()
+        # (4b) BEFORE any master gather: the tensors the kernels read from the fp32 master (biases, LayerNorm gamma / beta, the mask
+        # embedding) must already be the owner's values on every rank -- they are replicated with the weight gather
+        # (GradBuckets.set_replicated_fp32); a non-owner computing with its start-up biases is the round-3 ADVICE bug
+        small = torch.cat([eng.P.master[lo:hi] for lo, hi in eng._fp32_read_ranges()])
+        other = small.clone()
+        dist.broadcast(other, src=0)
+        moved = float((small - torch.cat([start_master[lo:hi] for lo, hi in eng._fp32_read_ranges()])).abs().max())
+        print("rank %d: fp32-read tensors identical to rank 0 before the master gather: %s (%d values, moved %.2e since start)" %
+              (rank, bool(torch.equal(small, other)), small.numel(), moved), flush=True)
+        assert bool(torch.equal(small, other)) and moved > 0
         eng.buckets.gather_master(eng.P.master)
         end = eng.buckets.ranges["heads"][1]       # (the vision stages travel as fp32 master slices: no bf16 copy of theirs is used)
         ok16 = bool(torch.equal(eng.P.w16[:end], eng.P.master[:end].to(torch.bfloat16)))
@@ -129,6 +140,31 @@ def main():
     other = mine.clone()
     dist.broadcast(other, src=0)
     assert bool(torch.equal(mine, other)), "replicas diverged under graph replay"
+    # (6) trajectory: a sharded engine and an all-reduce engine started from the same weights, fed the same batches, must produce the
+    # same losses and the same parameters over several optimizer steps (the two modes differ only in who computes which slice of the
+    # update and in the summation order of the clip norm)
+    if sharded and not e2e:
+        engs = {}
+        for m in ("sharded", "allreduce"):
+            e = E.PretrainEngine(cfg, B, T, R, device="cuda:0", train=True, lr=1e-3, seed=7 + rank, dp_mode=m)
+            e.init_random(seed=0, visual_ln_init=1.0)
+            e.set_batch(*[t.cuda() for t in batch])
+            e.sync_weights()
+            engs[m] = e
+        steps = 5
+        losses = {m: [] for m in engs}
+        for _ in range(steps):
+            for m, e in engs.items():
+                e.train_step()
+                losses[m].append(e.loss_values()["loss"])
+        torch.cuda.synchronize()
+        sd = {m: e.state_dict() for m, e in engs.items()}          # (a collective in sharded mode: gathers the master)
+        worst = max(float((sd["sharded"][k].float() - sd["allreduce"][k].float()).abs().max()) for k in sd["sharded"])
+        lrel = max(abs(a - b) / abs(b) for a, b in zip(losses["sharded"], losses["allreduce"]))
+        print("rank %d: %d steps sharded vs allreduce: losses %s | %s (max rel diff %.2e), parameters max |diff| %.3e" %
+              (rank, steps, ["%.5f" % x for x in losses["sharded"]], ["%.5f" % x for x in losses["allreduce"]], lrel, worst), flush=True)
+        # each AdamW step moves a parameter by ~lr = 1e-3: a stale bias would show up as a difference of that order
+        assert lrel < 5e-4 and worst < 2e-4, (lrel, worst)
     dist.barrier()
     dist.destroy_process_group()
 

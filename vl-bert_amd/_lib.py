@@ -38,6 +38,7 @@ _SIGS = {
     "vlb_wgrad_tn_bf16": "plplpliiipplis",
     "vlb_wgrad_tn_group_bf16": "ippppppipppplis",
     "vlb_zero_ranges_f32": "pppiis",
+    "vlb_copy_ranges_f32": "ppppiis",
     "vlb_layernorm_fwd": "plppplpiifis",
     "vlb_layernorm_bwd": "pliplppplplfpuplpppiiis",
     "vlb_layernorm_bwd_deferred": "pliplppplplfpuplpppiiis",

@@ -502,3 +502,35 @@ extern "C" int vlb_zero_ranges_f32(float* base, const int64_t* ranges, const int
   VLB_CHECK_LAUNCH("vlb_zero_ranges_f32");
   return VLB_OK;
 }
+
+// Copy several ranges between two fp32 buffers in a single launch: dst[dst_start + i] = src[src_start + i].
+// Sharded data-parallel optimizer (parallel.GradBuckets.gather_params): the tensors the compute path reads as fp32 on EVERY rank -- Linear
+// biases, LayerNorm gamma / beta, the mask embedding: ~0.15 % of the flat buffer -- are packed from the owner's master slices into one
+// compact image, summed over the ranks (exactly one rank contributes a non-zero value per element) and unpacked into every rank's master.
+// ranges (device int64): n x {src_start, dst_start, length}; block_start (device int32, n+1): running count of 1024-float blocks.
+__global__ __launch_bounds__(256) void copy_ranges_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                          const long* __restrict__ ranges, const int* __restrict__ block_start, int n) {
+  int lo = 0, hi = n;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if ((int)blockIdx.x >= block_start[mid]) lo = mid; else hi = mid;
+  }
+  const long s0 = ranges[3 * lo], d0 = ranges[3 * lo + 1], len = ranges[3 * lo + 2];
+  const long i = (long)(blockIdx.x - block_start[lo]) * 1024 + threadIdx.x * 4;
+  const float* q = src + s0 + i;
+  float* w = dst + d0 + i;
+  if (i + 3 < len && ((uintptr_t)q % 16) == 0 && ((uintptr_t)w % 16) == 0) {
+    *(float4*)w = *(const float4*)q;
+  } else {
+    for (int k = 0; k < 4 && i + k < len; ++k) w[k] = q[k];
+  }
+}
+
+extern "C" int vlb_copy_ranges_f32(const float* src, float* dst, const int64_t* ranges, const int32_t* block_start, int n,
+                                   int total_blocks, hipStream_t stream) {
+  if (n <= 0 || total_blocks <= 0) return VLB_OK;
+  VLB_CHECK_ARG(src && dst && ranges && block_start, "vlb_copy_ranges_f32: null argument");
+  hipLaunchKernelGGL(copy_ranges_kernel, dim3(total_blocks), dim3(256), 0, stream, src, dst, (const long*)ranges, (const int*)block_start, n);
+  VLB_CHECK_LAUNCH("vlb_copy_ranges_f32");
+  return VLB_OK;
+}

@@ -418,6 +418,9 @@ class PretrainEngine:
                 # wshard = the compact bf16 image of the updated slices the weight all-gather distributes (parallel.py)
                 self.shard_tbl = ops.ShardRanges(self.buckets.owned_rows(), d)
                 self.wshard = torch.zeros(self.P.numel // world, dtype=ops.BF16, device=d)
+                # the tensors forward / backward read from the fp32 MASTER (not from the gathered 16-bit copy) are replicated after
+                # every owner-only update (parallel.GradBuckets.set_replicated_fp32)
+                self.buckets.set_replicated_fp32(self._fp32_read_ranges())
         # fp32 compute mode of the encoder (the reference's TRAIN.FP16: false configurations; encoder_f32.py): the layers run on fp32
         # tensors and the fp32 MASTER weights, the embedding side and the heads stay on the 16-bit kernels (use the fp16 build)
         self.enc32 = None
@@ -443,6 +446,14 @@ class PretrainEngine:
         if self.vision is not None:     # conv weights ([O,I,KH,KW] in the reference) + BatchNorm tensors + frozen stages
             self.vision.load_state_dict(sd)
         self._weights_dirty = True
+
+    def _fp32_read_ranges(self):
+        """[(lo, hi)] of the flat buffer for every parameter the kernels read from the fp32 master: all 1-D tensors (Linear biases,
+        LayerNorm gamma / beta, the decoder bias) and the mask visual embedding (obj_prep reads it as fp32).  Matrices and embedding
+        tables are read through the 16-bit working copy; the e2e convolution weights travel as master slices with their buckets."""
+        vis = self._vision_names()
+        return [(self.P.offsets[n], self.P.offsets[n] + math.prod(sh)) for n, sh in self.P.shapes.items()
+                if n not in vis and (len(sh) == 1 or n == "object_mask_visual_embedding.weight")]
 
     def _vision_names(self):
         if self.vision is None:
@@ -1134,7 +1145,7 @@ class PretrainEngine:
             self.shard_tbl.sumsq(g, self.sumsq_ws, self.adam[7:8])
             self.buckets.all_reduce_scalar(self.adam[7:8])
             self.shard_tbl.adamw(self.P.master, g, self.P.m, self.P.v, self.wshard, self.adam, grad_scale=scale)
-            self.buckets.gather_params(self.P.w16, self.wshard, master=self.P.master if self.vision is not None else None)
+            self.buckets.gather_params(self.P.w16, self.wshard, master=self.P.master, vision_master=self.vision is not None)
             self._wT_stale = self._gather_pending = True
             self._vision_stale = self.vision is not None
             ops.rng_advance(self.seed)
@@ -1306,10 +1317,13 @@ class _SegmentedStep:
             recorded.__self__ = self             # (engine.backward looks up the hook owner's will_launch predicate)
             return recorded
 
+    CHECK_EVERY = 64
+
     def __init__(self, eng, lr):
         if not eng.dev.type == "cuda":
             raise RuntimeError("make_step_graph needs a GPU engine")
         self.eng, self.items = eng, []
+        self.replays = 0
         self.pool = torch.cuda.graph_pool_handle()
         self.stream = torch.cuda.Stream(device=eng.dev)
         self._g = None
@@ -1354,3 +1368,8 @@ class _SegmentedStep:
                 x.replay()
             else:
                 x()
+        # optimizer_step's periodic host-side checks ran once, at capture: the replay loop carries them itself (MLM head compaction
+        # overflow flag, one 4-byte readback every CHECK_EVERY replays -- never a silent truncation of the labelled positions)
+        self.replays += 1
+        if self.eng.mlm_cap is not None and self.replays % self.CHECK_EVERY == 0:
+            self.eng._raise_on_mlm_overflow()

@@ -115,6 +115,26 @@ class ZeroRanges:
                       self.total, _stream())
 
 
+class CopyRanges:
+    """dst[dst_start + i] = src[src_start + i] over a fixed table of (src_start, dst_start, length) rows in one launch
+    (vlb_copy_ranges_f32): pack / unpack of the fp32-read parameters the sharded data-parallel optimizer replicates."""
+
+    def __init__(self, rows, device):
+        rows = [[int(a), int(b), int(n)] for a, b, n in rows if n > 0]
+        starts, total = [0], 0
+        for _, _, n in rows:
+            total += (n + 1023) // 1024
+            starts.append(total)
+        self.rows, self.n, self.total = rows, len(rows), total
+        self.ranges = torch.tensor(rows, dtype=torch.int64).reshape(-1, 3).to(device) if rows else None
+        self.starts = torch.tensor(starts, dtype=torch.int32).to(device)
+
+    def run(self, src, dst):
+        if self.n:
+            _lib.call("vlb_copy_ranges_f32", _p(src, torch.float32), _p(dst, torch.float32), self.ranges.data_ptr(), self.starts.data_ptr(),
+                      self.n, self.total, _stream())
+
+
 def wgrad_tn_group(items, workspace=None, accumulate=True):
     """items: up to 4 (dy [R,Mo], x [R,No], C [Mo,No] fp32, colsum [Mo] | None) over the same R rows -> one grouped launch
     (vlb_wgrad_tn_group_bf16)."""

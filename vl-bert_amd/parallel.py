@@ -175,6 +175,7 @@ class GradBuckets:
             self._gather_idx = {k: i for i, k in enumerate(self.gather_order)}
             self._gathers = []                    # [(index in gather_order, work, post)] still in flight
             self._stage32 = None
+        self._repl = None                         # set_replicated_fp32()
         assert names[0] in offsets
 
     # ------------------------------------------------------------------------------------------------------------------
@@ -314,13 +315,65 @@ class GradBuckets:
             w = dist.all_gather_into_tensor(out, inp, group=self.group, async_op=async_op)
         return w
 
-    def gather_params(self, w16, wshard, master=None):
+    def set_replicated_fp32(self, ranges):
+        """ranges: [(lo, hi)] element ranges of the flat fp32 master that the compute path reads AS FP32 on every rank (Linear biases,
+        LayerNorm gamma / beta, the mask embedding -- engine.PretrainEngine._fp32_read_ranges; ~0.15 % of the buffer).  The sharded
+        AdamW updates the master on the owner only and the weight gather distributes the 16-bit copy, so these would stay frozen at
+        their start-up values on the non-owners (replicas computing with different biases).  gather_params therefore replicates them:
+        each rank packs the parts it owns into a zeroed compact image, one fp32 all-reduce (SUM; exactly one rank contributes a
+        non-zero term per element, so the sum is that rank's value bit for bit) distributes them, and the first wait_params of the
+        next forward unpacks the image into the master -- in front of the first kernel that reads a bias."""
+        self._repl = None
+        if not self.sharded or self.world == 1:
+            return
+        own, full, off = [], [], 0
+        for lo, hi in sorted((int(a), int(b)) for a, b in ranges if b > a):
+            full.append((off, lo, hi - lo))                       # unpack: compact -> master
+            for key, _, _ in self.buckets:
+                p0, _, n = self.piece(key)
+                a, b = max(lo, p0), min(hi, p0 + n)
+                if b > a:
+                    own.append((a, off + (a - lo), b - a))        # pack: master -> compact
+            off += (hi - lo + 3) // 4 * 4
+        self._repl = dict(numel=off, own=own, full=full, buf=None, pack=None, unpack=None)
+
+    def _copy_rows(self, which, src, dst):
+        r = self._repl
+        if src.is_cuda:
+            from . import ops
+            if r[which] is None:
+                r[which] = ops.CopyRanges(r["own" if which == "pack" else "full"], src.device)
+            r[which].run(src, dst)
+        else:                                                     # (gloo CPU tests)
+            for a, b, n in r["own" if which == "pack" else "full"]:
+                dst[b:b + n].copy_(src[a:a + n])
+
+    def _exchange_replicated(self, master):
+        r = self._repl
+        if r["buf"] is None:
+            r["buf"] = torch.zeros(max(r["numel"], 4), dtype=master.dtype, device=master.device)
+        buf = r["buf"]
+        buf.zero_()
+        self._copy_rows("pack", master, buf)
+        work = dist.all_reduce(buf, group=self.group, async_op=True)
+        self._gathers.append((-1, work, lambda: self._copy_rows("unpack", buf, master)))
+
+    def gather_params(self, w16, wshard, master=None, vision_master=None):
         """After the sharded AdamW: distribute the updated bf16 working copy (compact image `wshard` -> flat `w16`), one async
         all-gather per bucket in FORWARD order; wait_params(key) blocks the compute stream right before the first use.  The vision
         stages' convolution weights are folded from the fp32 master (vision.py), so for those buckets the fp32 master slices travel
-        instead (`master`)."""
+        instead (`vision_master`, default: when `master` is given and there are vision buckets -- the older calling form).  `master` +
+        set_replicated_fp32(): the fp32-read tensors are replicated first (see there)."""
         if self.world == 1:
             return
+        if vision_master is None:
+            vision_master = master is not None
+        if getattr(self, "_repl", None) is not None:
+            if master is None:
+                raise RuntimeError("gather_params: the replicated fp32 tensors (set_replicated_fp32) need master=")
+            self._exchange_replicated(master)
+        if not vision_master:
+            master = None
         for i, key in enumerate(self.gather_order):
             lo, hi = self._range(key)
             p0, c0, n = self.piece(key)
@@ -332,7 +385,7 @@ class GradBuckets:
                 work = self._all_gather(master[lo:hi], st)
             else:
                 work = self._all_gather(w16[lo:hi], wshard[c0:c0 + n])
-            self._gathers.append((i, work))
+            self._gathers.append((i, work, None))
 
     def gather_master(self, master):
         """Blocking: every rank's authoritative fp32 master slices into the full flat `master` (checkpoints; a collective)."""
@@ -359,7 +412,10 @@ class GradBuckets:
         else:
             upto = self._gather_idx[self.layer_key[key]]
         while self._gathers and self._gathers[0][0] <= upto:
-            self._gathers.pop(0)[1].wait()
+            _, work, post = self._gathers.pop(0)
+            work.wait()
+            if post is not None:
+                post()
 
 
 class DistributedDataParallel(torch.nn.Module):
@@ -400,7 +456,12 @@ class DistributedDataParallel(torch.nn.Module):
                     dist.broadcast(core.flat.master, src=0, group=process_group)
                     torch.autograd.graph.increment_version(core.flat.master)
                 for t in list(self._rest) + [b for b in module.buffers() if b.is_floating_point()]:
-                    dist.broadcast(t.data if t.is_contiguous() else t.data.contiguous(), src=0, group=process_group)
+                    if t.is_contiguous():
+                        dist.broadcast(t.data, src=0, group=process_group)
+                    else:                 # a broadcast into a temporary copy would be discarded: copy the received values back
+                        tmp = t.data.contiguous()
+                        dist.broadcast(tmp, src=0, group=process_group)
+                        t.data.copy_(tmp)
 
     def no_sync(self):
         import contextlib
@@ -432,7 +493,31 @@ class DistributedDataParallel(torch.nn.Module):
             core._dp_hook = hook
             for eng in core._engines.values():
                 eng._dp_hook = hook
-        return self.module(*inputs, **kwargs)
+        out = self.module(*inputs, **kwargs)
+        if sync:
+            # the finalizer must run after EVERY synchronised backward, also one in which no core hook fires (a loss that does not
+            # reach a VL-BERT core): any output that carries a graph arms it when its gradient arrives
+            for t in self._tensors(out):
+                if t.requires_grad:
+                    t.register_hook(self._arm)
+        return out
+
+    @staticmethod
+    def _tensors(x):
+        if torch.is_tensor(x):
+            yield x
+        elif isinstance(x, dict):
+            for v in x.values():
+                yield from DistributedDataParallel._tensors(v)
+        elif isinstance(x, (list, tuple)):
+            for v in x:
+                yield from DistributedDataParallel._tensors(v)
+
+    def _arm(self, grad):
+        if not self._armed:
+            self._armed = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._finalize)
+        return None
 
     def _finalize(self):
         from . import ops
@@ -442,19 +527,47 @@ class DistributedDataParallel(torch.nn.Module):
                 b.on_done(key)
             b.wait()
             ops.scale_f32(b.flat, 1.0 / self.world)
-        ps = [p for p in self._rest if p.grad is not None]
-        if ps:
-            n = sum(p.numel() for p in ps)
-            if self._stage is None or self._stage.numel() != n:
-                self._stage = torch.empty(n, dtype=torch.float32, device=ps[0].device)
-            views, off = [], 0
-            for p in ps:
-                views.append(self._stage[off:off + p.numel()].view_as(p.grad))
-                off += p.numel()
-            torch._foreach_copy_(views, [p.grad for p in ps])
-            dist.all_reduce(self._stage, group=self.group)
-            ops.scale_f32(self._stage, 1.0 / self.world)
-            torch._foreach_copy_([p.grad for p in ps], views)
+        self._reduce_rest()
+
+    def _reduce_rest(self):
+        """The parameters outside the flat cores, one coalesced all-reduce.  The staging layout covers EVERY such parameter, whether or
+        not this rank's backward reached it (a parameter used on one rank only -- a conditional branch, an unused head -- would
+        otherwise give the ranks staging buffers of different sizes: a hang or a silent mix-up); missing gradients take part as zeros
+        and a parameter receives a gradient as soon as ANY rank produced one (its flag is reduced with the data)."""
+        from . import ops
+        rest = self._rest
+        if not rest or self.world == 1:
+            return
+        n = sum(p.numel() for p in rest)
+        if self._stage is None or self._stage.numel() != n + len(rest):
+            self._stage = torch.zeros(n + len(rest), dtype=torch.float32, device=rest[0].device)
+        st = self._stage
+        st.zero_()
+        views, off = [], 0
+        for p in rest:
+            views.append(st[off:off + p.numel()].view(p.shape))
+            off += p.numel()
+        have = [i for i, p in enumerate(rest) if p.grad is not None]
+        if have:
+            torch._foreach_copy_([views[i] for i in have], [rest[i].grad for i in have])
+            st[n:][torch.tensor(have, device=st.device)] = 1.0
+        dist.all_reduce(st, group=self.group)
+        if st.is_cuda:
+            ops.scale_f32(st[:n], 1.0 / self.world)
+        else:
+            st[:n].mul_(1.0 / self.world)
+        # (the flags are read back -- a host sync -- only when this rank is missing a gradient; otherwise every parameter is copied)
+        used = (st[n:] > 0).tolist() if len(have) < len(rest) else [True] * len(rest)
+        dst, src = [], []
+        for i, p in enumerate(rest):
+            if not used[i]:
+                continue
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+            dst.append(p.grad)
+            src.append(views[i])
+        if dst:
+            torch._foreach_copy_(dst, src)
 
     def state_dict(self, *a, **k):
         return self.module.state_dict(*a, **k)
