@@ -1113,6 +1113,55 @@ def test_engine_c2_per_gpu_batch_32_step_vs_oracle():
     check_against_oracle("C2 12-layer B=32", cfg, params, batch, grad_tol=6e-2, logit_rtol=1e-2, logit_fro_tol=1e-2)
 
 
+def test_engine_headline_c2_batch_256_as_benched_vs_oracle():
+    """The headline configuration AT THE BATCH bench.py TIMES: 12 layers, 256 full-length samples of 64 text + 36 regions (M = 25856
+    rows), the engine built as bench.py builds it (MLM head on the labelled rows only, no logits copy), the library's OWN kernel
+    selection at that size -- 243-1212-tile launches of `gemm_nt_p8_kernel` with mid-stream wave-private drains, the grouped
+    `gemm_tn8_kernel` weight gradients with K = 25856 -- one forward + backward against the fp32 oracle (eval mode: the oracle cannot
+    regenerate the counter-RNG masks; the dropout instantiations at this shape are compared per op in
+    tests/test_ops_gpu.py::test_gemm_headline_shapes_with_the_launchers_own_selection).  Bars: north_star's bf16 bound 1e-2 on the
+    losses, the global gradient norm and the encoder output; per-tensor / per-layer gradient errors as in the batch-6 test.
+    (The oracle's forward + backward of 256 samples takes ~1-2 min on the box's host cores.)"""
+    syn = pkg("synthetic")
+    E = pkg("engine")
+    cfg = O.VLBertConfig(num_hidden_layers=12)
+    params = O.init_params(cfg, seed=81)
+    B, T, R = 256, 64, 36
+    batch = syn.make_batch(B, T, R, seed=82, ragged=False)
+    eng = E.PretrainEngine(E.ModelConfig(num_hidden_layers=12), B, T, R, device="cuda:0", train=False)
+    assert eng.mlm_cap is not None, "bench.py's engine runs the MLM head on the labelled rows"
+    eng.load_state_dict({k: v.to(dev()) for k, v in params.items()})
+    eng.set_batch(*[t.to(dev()) for t in batch])
+    eng.zero_grad()
+    eng.forward(train=False)
+    eng.backward(train=False)
+    torch.cuda.synchronize()
+    lv = eng.loss_values()
+    outputs, loss, grads, norm = O.loss_and_grads(params, cfg, batch, train=False)
+    tag = "C2 12-layer B=256"
+    S = eng.S
+    seq = outputs["sequence_output"].detach()
+    got = eng.X[-1].view(B, S, -1)[:, :seq.shape[1]]
+    fro = rel_fro(got, seq)
+    print("%s encoder output relative Frobenius error %.3e" % (tag, fro))
+    assert fro <= 1e-2, fro
+    report(tag + " encoder output", got, seq, 2e-3, 1.5e-2)
+    for k in ("mlm_loss", "mvrc_loss"):
+        ref = float(outputs[k])
+        print("%s %s: hip %.6f oracle %.6f" % (tag, k, lv[k], ref))
+        assert abs(lv[k] - ref) <= 1e-2 * max(1.0, abs(ref)), (k, lv[k], ref)
+    gn = eng.grad_norm()
+    print("%s grad_norm: hip %.6f oracle %.6f rel %.3e" % (tag, gn, norm, abs(gn - norm) / norm))
+    assert abs(gn - norm) <= 1e-2 * norm
+    worst = sorted(((rel_fro(g, grads[name]), name) for name, g in eng.grads().items() if float(grads[name].norm()) >= 1e-6 * norm),
+                   reverse=True)
+    for e, n in worst[:8]:
+        print("   rel-fro grad err %.3e  %s" % (e, n))
+    assert worst[0][0] <= 6e-2, worst[:5]
+    rows = _per_layer_report(tag, eng, grads, norm, 12)
+    assert max(e for _, e in rows) <= 4e-2, rows
+
+
 def test_mlm_head_compaction_matches_full_path():
     """MLM head on the labelled rows only (engine default) vs the full head (keep_logits engine): identical losses, gradients equal
     up to fp32 summation order; multitask layout (caption + text-only groups with their own means); capacity overflow is loud."""

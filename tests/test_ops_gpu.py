@@ -12,7 +12,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from tests.gpu_util import bf, dev, drop_scale, drop_thr, keep_mask, pkg, report, to_gpu_bf16
+from tests.gpu_util import act_dtype, bf, dev, drop_scale, drop_thr, keep_mask, pkg, report, to_gpu_bf16
 
 pytestmark = pytest.mark.gpu
 
@@ -145,18 +145,32 @@ def force_p8():
     yield lib
     lib.gemm_set_option("p8_min_tiles", 160)
     lib.gemm_set_option("p8_mode", 1)
+    lib.gemm_set_option("p8_wgs", 256)
+    lib.gemm_set_option("p8_keepb", 1)
 
 
-@pytest.mark.parametrize("tile", [3, 4, 5])
+# wgs = persistent workgroups per launch.  256 (one per CU, the default): these shapes have <= 36 tiles, so every workgroup owns ONE
+# tile and drains it through the "last tile" path (shared slab over the idle operand ring).  8: every workgroup owns SEVERAL tiles and
+# drains all but its last one MID-STREAM, beside the live operand ring -- `p8_drain_w<FMH, EPI, EDGE>` (wave-private, round 3), the path
+# ~10 of the 15.9 GEMM ms of the headline bench spend their epilogues in (M = 25856: 303-1212 tiles on 256 workgroups), interior and
+# edge tiles; tile "4k0" = the 256-row tile without the kept B fragments (KEEPB = false instantiations).
+@pytest.mark.parametrize("wgs", [256, 8], ids=["one-tile-per-wg", "mid-stream-drain"])
+@pytest.mark.parametrize("tile", [3, 4, "4k0", 5])
 @pytest.mark.parametrize("M,N,K", [(2048, 1024, 256), (1000, 520, 128), (2600, 768, 768), (700, 2306, 384)])
-def test_gemm_large_tile_core_epilogues(ops, force_p8, tile, M, N, K):
+def test_gemm_large_tile_core_epilogues(ops, force_p8, tile, M, N, K, wgs):
     """vl-bert_amd/csrc/gemm_p8.hip (192-, 256- and 320-row tiles, 8-phase schedule, fp32-staged epilogue): every fused epilogue of the
     training step against the fp32 statement of the same op, interior and edge tiles (M, N not multiples of the tile, N % 8 != 0),
     the shortest K the pipeline accepts (two K tiles), several output tiles per workgroup; dropout against the numpy restatement of
     the counter RNG.  Padding columns of C must stay untouched.  (The 192-row tile is what the launcher picks for the N = 3072
     GEMMs of a 32-sample per-GPU batch -- the 8-GPU strong-scaling regime.)"""
+    if tile == "4k0":
+        if wgs == 256 and (M, N, K) != (2600, 768, 768):
+            pytest.skip("KEEPB = false: the mid-stream cases + one single-tile shape")
+        force_p8.gemm_set_option("p8_keepb", 0)
+        tile = 4
     force_p8.gemm_set_option("p8_mode", tile)
-    _epilogue_battery(ops, "p8/%d %dx%dx%d " % (64 * tile, M, N, K), M, N, K)
+    force_p8.gemm_set_option("p8_wgs", wgs)
+    _epilogue_battery(ops, "p8/%d%s %dx%dx%d " % (64 * tile, " wgs8" if wgs == 8 else "", M, N, K), M, N, K, vision=True)
 
 
 @pytest.mark.parametrize("ring", [2, 3], ids=["ring-128x128", "ring-128x64"])
@@ -175,7 +189,7 @@ def test_gemm_ring_kernel_epilogues(ops, force_p8, ring, M, N, K):
         force_p8.gemm_set_option("nt_ring", 1)
 
 
-def _epilogue_battery(ops, tag, M, N, K):
+def _epilogue_battery(ops, tag, M, N, K, vision=False):
     A, B = rnd(M, K, seed=4), rnd(N, K, seed=5, scale=0.08)
     bias = 0.3 * torch.randn(N, generator=torch.Generator().manual_seed(6))
     res, aux = rnd(M, N, seed=7), rnd(M, N, seed=8)
@@ -218,14 +232,24 @@ def _epilogue_battery(ops, tag, M, N, K):
     keep = torch.from_numpy(keep_mask(seed_v, tg, idx.reshape(-1), thr).reshape(M, N))
     report(tag + "dropout+res", C, torch.where(keep, u * drop_scale(thr), torch.zeros_like(u)) + res, 1e-3, 1e-2)
     assert bool((Cf[:, N:] == 3.0).all())
+    if vision:      # the two epilogues of the e2e trunk that run on this core (EPI 8 / 10): Bottleneck tail, ReLU backward in a dgrad
+        ops.gemm_nt(Ag, Bg, C, bias=bg, res=resg, act=ops.ACT_RES_RELU)
+        report(tag + "relu(bias+res)", C, torch.relu(u + res), 1e-3, 1e-2)
+        ops.gemm_nt(Ag, Bg, C, act=ops.ACT_RELU_MASK, aux=auxg)
+        report(tag + "acc where aux>0", C, acc * (aux > 0), 1e-3, 1e-2)
+        assert bool((Cf[:, N:] == 3.0).all())
 
 
-@pytest.mark.parametrize("core", ["128x128", "p8-192", "p8-256", "p8-320", "ring-128x128", "ring-128x64"])
+@pytest.mark.parametrize("core", ["128x128", "p8-192", "p8-256", "p8-320", "p8-192-midstream", "p8-256-midstream", "p8-320-midstream",
+                                  "ring-128x128", "ring-128x64"])
 def test_gemm_layernorm_residual_fp16_stream(ops, force_p8, core):
     """vlb_gemm_nt_bf16_ex: residual = LayerNorm output re-materialised in fp32 from fp16 pre-LN rows + (mean, rstd) + gamma / beta,
     result stored as fp16 (the encoder's residual stream, BertSelfOutput / BertOutput); with and without dropout; and the LayerNorm
     kernels reading fp16 rows.  Reference: fp32 torch on the same (fp16 / bf16 rounded) inputs."""
     lib = force_p8
+    if core.endswith("-midstream"):      # several tiles per workgroup: EPI 6 / 7 through the mid-stream drain (see the epilogue test)
+        core = core[:-len("-midstream")]
+        lib.gemm_set_option("p8_wgs", 8)
     lib.gemm_set_option("p8_mode", {"128x128": 0, "p8-192": 3, "p8-256": 4, "p8-320": 5}.get(core, 0))
     lib.gemm_set_option("nt_ring", {"ring-128x128": 2, "ring-128x64": 3}.get(core, 0))
     try:
@@ -290,6 +314,68 @@ def _ln_residual_checks(ops, core):
     ops.layernorm_bwd(to_gpu_bf16(dy), xg, stats, g2.to(dev()), dx=dx, dgamma=dg, dbeta=db)
     report("layernorm bwd dx on fp16 rows", dx, xr.grad, 1e-3, 1e-2)
     report("layernorm bwd dgamma on fp16 rows", dg, (dy * ((x - x.mean(1, keepdim=True)) / torch.sqrt(x.var(1, unbiased=False, keepdim=True) + 1e-12))).sum(0), 1e-3, 2e-3)
+
+
+HEADLINE_GEMMS = [      # (name, N, K, epilogue) of one encoder layer at the headline batch: M = 256 x 101 = 25856 rows
+    ("qkv fwd", 2304, 768, "bias"), ("attn-out fwd", 768, 768, "drop_lnres"), ("ffn1 fwd", 3072, 768, "gelu_d"),
+    ("ffn2 fwd", 768, 3072, "drop_lnres"), ("attn-out dgrad", 768, 768, "plain"), ("qkv dgrad", 768, 2304, "res"),
+    ("ffn1 dgrad", 768, 3072, "res"), ("ffn2 dgrad", 3072, 768, "mulaux")]
+
+
+@pytest.mark.parametrize("name,N,K,epi", HEADLINE_GEMMS, ids=[g[0].replace(" ", "-") for g in HEADLINE_GEMMS])
+def test_gemm_headline_shapes_with_the_launchers_own_selection(ops, name, N, K, epi):
+    """The eight NT GEMMs of an encoder layer EXACTLY as bench.py times them -- M = 25856 rows (batch 256 x 101 positions), the library's
+    default kernel selection (no option forced: 243-1212 tiles of the large-tile core, mid-stream wave-private drains, the
+    last-tile slab drain, 320- / 256-row tiles as the cost model picks), the epilogue each one carries in the step -- against an fp32
+    CPU statement of the same op on the same 16-bit inputs.  (tools/p8_check.py check covered these shapes as a tool only; the
+    round-3 review found no suite test with more than 204 tiles and a fused epilogue.)"""
+    M = 256 * 101
+    g = torch.Generator().manual_seed(500 + N + K)
+    A = bf((torch.rand((M, K), generator=g) * 2 - 1))
+    B = bf((torch.rand((N, K), generator=g) * 2 - 1) * 0.06)
+    bias = 0.3 * torch.randn(N, generator=g)
+    Ag, Bg, bg = to_gpu_bf16(A), to_gpu_bf16(B), bias.to(dev())
+    acc = A @ B.t()
+    tag = "headline %s %dx%dx%d " % (name, M, N, K)
+    C = torch.full((M, N), 3.0, dtype=act_dtype(), device=dev())
+    if epi == "bias":
+        ops.gemm_nt(Ag, Bg, C, bias=bg)
+        report(tag + "bias", C, acc + bias, 1e-3, 1e-2)
+    elif epi == "plain":
+        ops.gemm_nt(Ag, Bg, C)
+        report(tag + "plain", C, acc, 1e-3, 1e-2)
+    elif epi == "gelu_d":
+        pre = torch.full((M, N), 3.0, dtype=act_dtype(), device=dev())
+        ops.gemm_nt(Ag, Bg, C, bias=bg, act=ops.ACT_GELU_D, pre=pre)
+        u = acc + bias
+        cdf = 0.5 * (1 + torch.erf(u / math.sqrt(2)))
+        report(tag + "gelu out", C, u * cdf, 1e-3, 1e-2)
+        report(tag + "gelu' saved", pre, cdf + u * torch.exp(-0.5 * u * u) / math.sqrt(2 * math.pi), 1e-3, 1e-2)
+    elif epi == "res":
+        res = bf(torch.randn((M, N), generator=g))
+        ops.gemm_nt(Ag, Bg, C, bias=bg, res=to_gpu_bf16(res))
+        report(tag + "bias+res", C, acc + bias + res, 1e-3, 1e-2)
+    elif epi == "mulaux":
+        aux = bf(torch.rand((M, N), generator=g) * 1.2 - 0.1)
+        ops.gemm_nt(Ag, Bg, C, act=ops.ACT_MULAUX, aux=to_gpu_bf16(aux))
+        report(tag + "x aux", C, acc * aux, 1e-3, 1e-2)
+    else:       # dropout + LayerNorm-residual from fp16 rows, fp16 output: BertSelfOutput / BertOutput as the engine runs them
+        gam = 1.0 + 0.2 * torch.randn(N, generator=g)
+        bet = 0.1 * torch.randn(N, generator=g)
+        z = (torch.randn((M, N), generator=g) * 2.0 + 0.3).half()
+        zf = z.float()
+        mean = zf.mean(1, keepdim=True)
+        rstd = 1.0 / torch.sqrt(zf.var(1, unbiased=False, keepdim=True) + 1e-12)
+        st = torch.cat((mean, rstd), 1).contiguous().to(dev())
+        Ch = torch.full((M, N), 3.0, dtype=torch.float16, device=dev())
+        p, seed_v, tg = 0.1, 991, 21
+        seed = torch.tensor([seed_v], dtype=torch.int32, device=dev())
+        ops.gemm_nt(Ag, Bg, Ch, bias=bg, res=z.to(dev()), res_ln=(st, gam.to(dev()), bet.to(dev())), drop_p=p, seed=seed, tag=tg)
+        thr = drop_thr(p)
+        keep = torch.from_numpy(keep_mask(seed_v, tg, np.arange(M * N, dtype=np.int64), thr).reshape(M, N))
+        u = acc + bias
+        report(tag + "dropout + LN-residual -> fp16", Ch, torch.where(keep, u * drop_scale(thr), torch.zeros_like(u)) +
+               ((zf - mean) * rstd * gam + bet), 2e-3, 2e-3 if act_dtype() == torch.float16 else 4e-3)
 
 
 def test_engine_step_through_large_tile_core(force_p8):
