@@ -452,13 +452,16 @@ def cpu_baseline_vcr(Lq, La, R, image_size):
 
 
 def other_configs():
-    """BASELINE.json configs 3 (e2e: ResNet-101 + ROIAlign in front of the step, the shipped multitask yaml) and 4 (VL-BERT-large VQA at its
-    named precision, fp32) on this GPU, each as its own `bench.py` process (fresh engine, same flags a user would type); failures and
+    """BASELINE.json configs 3 (e2e: ResNet-101 + ROIAlign in front of the step, the shipped multitask yaml), 4 (VL-BERT-large VQA at its
+    named precision, fp32) and 5 (VL-BERT-large VCR Q->A, mixed precision = the fp16 build) on this GPU, each as its own `bench.py` process (fresh engine, same flags a user would type); failures and
     time-outs are reported as such, never raised: the headline line must still print."""
     import subprocess
     here = os.path.abspath(__file__)
+    # each config at the precision BASELINE.json names for it: config 3 bf16, config 4 fp32, config 5 "mixed precision" = the reference's
+    # Apex fp16 mode = the fp16 build (the bf16 build's 24-layer numbers are an aside: its parity at that depth is 1.1e-2, DESIGN.md §2)
     runs = {"config3_e2e": ["--e2e", "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-phase-times"],
-            "config4_vqa_fp32": ["--vqa", "--precision", "fp32", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]}
+            "config4_vqa_fp32": ["--vqa", "--precision", "fp32", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+            "config5_vcr_fp16": ["--vcr", "--precision", "f16", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]}
     res = {}
     for name, flags in runs.items():
         cmd = [sys.executable, here] + flags
@@ -478,6 +481,26 @@ def other_configs():
     return res
 
 
+def _fail(reason, code=1):
+    """One line with the reason on stderr, non-zero exit code, no clean-up that could block (a hung collective cannot be joined)."""
+    print("bench.py: FAILED: " + reason.replace("\n", " "), file=sys.stderr, flush=True)
+    os._exit(code)
+
+
+def _watchdog(seconds):
+    """bench.py must never hang a multi-GPU run: after `seconds` of wall clock the process reports why it is stuck and exits 3."""
+    import threading
+    state = {"phase": "start-up"}
+
+    def run():
+        time.sleep(seconds)
+        _fail("watchdog: still in phase '%s' after %d s (VLB_BENCH_WATCHDOG_S) -- a collective or a graph segment never completed"
+              % (state["phase"], seconds), code=3)
+    t = threading.Thread(target=run, daemon=True)
+    t.start()
+    return state
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -492,7 +515,7 @@ def main():
     ap.add_argument("--large", action="store_true", help="VL-BERT-large shape of BASELINE.json configs 4-5 through the same pretraining step: "
                     "24 layers, hidden 1024, 16 heads, FFN 4096, 128 text + 100 regions (S = 229); default global batch 64")
     ap.add_argument("--vqa", action="store_true", help="BASELINE config 4's workload through the module mirror (vl-bert_amd/vqa): VL-BERT-large VQA "
-                    "fine-tuning, 128 text + 100 precomputed regions, AdamW, accumulation 4 -- in bf16 (the fp32 compute mode is not built)")
+                    "fine-tuning, 128 text + 100 precomputed regions, AdamW, accumulation 4; config 4's named precision is `--precision fp32`")
     ap.add_argument("--vcr", action="store_true", help="BASELINE config 5 through the module mirror (vl-bert_amd/vcr): VL-BERT-large VCR Q->A, 4 answer "
                     "choices, sequences of 256 positions, ResNet-101 image path with object masks, SGD momentum 0.9, gradient accumulation 4 "
                     "(cfgs/vcr/large_q2a_4x16G_fp16.yaml: 4 samples per GPU per micro-batch); one GPU; a step = one OPTIMIZER step")
@@ -507,7 +530,8 @@ def main():
                     "(--vqa --precision fp32), each from a child bench.py process, under \"other_configs\"; this switch (or any of "
                     "--no-cpu-baseline / --e2e / --large / --vqa / --vcr / --precision / --global-batch / --gpus N) skips them")
     ap.add_argument("--cpu-baseline-full", action="store_true", help="time the CPU port at SURVEY 8d's size (batch 32, 3 warm-up + 5 timed "
-                    "iterations, median) instead of the quick bounded leg (batch 8, <= 25 s)")
+                    "iterations, median; ~1 min of host time) -- the DEFAULT of the plain headline invocation (1 GPU, no mode flag)")
+    ap.add_argument("--cpu-baseline-quick", action="store_true", help="the quick bounded leg (batch 8, <= 25 s) also on the plain invocation")
     ap.add_argument("--dp-mode", default="default", choices=["default", "sharded", "allreduce"], help="data-parallel exchange "
                     "(vl-bert_amd/parallel.py): sharded optimizer (reduce-scatter + weight all-gather; default) or all-reduce")
     ap.add_argument("--head-start", type=int, default=60, help="unrelated 0.55-TFLOP torch.mm launches queued ahead of the instrumented step (roofline)")
@@ -561,12 +585,26 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        import datetime
+        # a collective that cannot complete (a rank that died, a communicator that never formed) must end the run with a reason, not
+        # hang it: bounded time-out on every collective (RCCL's watchdog aborts the process group) + the wall-clock watchdog below
+        tmo = datetime.timedelta(seconds=int(os.environ.get("VLB_BENCH_COLLECTIVE_TIMEOUT_S", "180")))
+        try:
+            if backend == "nccl":
+                os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank), timeout=tmo)
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world, timeout=tmo)
+            probe = torch.ones(1, device="cuda")
+            dist.all_reduce(probe)           # first contact with the communicator: fail here, with the reason, rather than mid-step
+            torch.cuda.synchronize()
+            if int(probe.item()) != world:
+                raise RuntimeError("probe all-reduce returned %s for %d ranks" % (probe.item(), world))
+        except Exception as e:
+            _fail("rank %d: %s communicator over %d ranks could not be formed: %s: %s" % (rank, backend, world, type(e).__name__, str(e)[:300]))
 
     args.world, args.rank, args.dist = world, rank, dist
+    wd = _watchdog(int(os.environ.get("VLB_BENCH_WATCHDOG_S", "1500"))) if world > 1 else {"phase": ""}
     if args.vqa or args.vcr:
         (bench_vqa if args.vqa else bench_vcr)(args)
         if dist is not None:
@@ -632,18 +670,24 @@ def main():
             step = eng.make_step_graph()            # one graph (1 rank) / segments cut at the collectives (data parallel)
             graph_info = "%d graph segment(s) + %d host-side collective calls per step" % (step.n_graphs, step.n_calls)
         except Exception as e:                      # (a capture restriction of the installed runtime: the eager step is the same arithmetic)
-            print("bench.py: graph capture failed (%s: %s) -- running the step eagerly" % (type(e).__name__, str(e)[:200]), file=sys.stderr, flush=True)
+            print("bench.py: rank %d: graph capture failed (%s: %s) -- running the step eagerly" % (rank, type(e).__name__, str(e)[:200]),
+                  file=sys.stderr, flush=True)
             torch.cuda.synchronize()
             step, use_graph = eng.train_step, False
+            if eng.buckets is not None and (eng.buckets.pending or eng.buckets.launched):
+                _fail("rank %d: graph capture failed with a gradient exchange half recorded (%s: %s)" % (rank, type(e).__name__, str(e)[:200]))
+    wd["phase"] = "warm-up steps"
 
     for _ in range(args.warmup):
         step()
     barrier()
+    wd["phase"] = "timed steps"
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
+    wd["phase"] = "post-processing"
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -654,6 +698,46 @@ def main():
     if eng.buckets is not None and eng.buckets.sharded:     # drain the weight gathers of the last timed step before anything else runs
         eng.forward(True)
     losses = eng.loss_values()
+
+    # ---- exposed communication per rank = step time - the same step with every collective call skipped (GradBuckets.null_collectives:
+    # identical kernels, graph segments and host calls at the same per-GPU batch; the numbers computed there are meaningless, the
+    # parameters are re-broadcast afterwards).  Per-rank wall time between device syncs, no barrier inside.
+    comm = None
+    if world > 1 and eng.buckets is not None:
+        def rank_loop(n):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(n):
+                step()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t) / n * 1e3
+        wd["phase"] = "exposed-communication measurement"
+        n_c = max(3, min(args.steps, 10))
+        barrier()
+        with_ms = rank_loop(n_c)
+        if eng.buckets.sharded:
+            eng.forward(True)
+        barrier()
+        eng.buckets.null_collectives(True)
+        step()
+        only_ms = rank_loop(n_c)
+        eng.buckets.null_collectives(False)
+        barrier()
+        both = torch.tensor([with_ms, only_ms], dtype=torch.float64, device="cuda")
+        allr = [torch.zeros_like(both) for _ in range(world)]
+        dist.all_gather(allr, both)
+        # back to consistent replicas (the null steps updated every rank from un-reduced gradients): the owners' master slices in
+        # sharded mode (moments stay with their owners), rank 0's state otherwise
+        if eng.buckets.sharded:
+            eng.buckets.gather_master(eng.P.master)
+        else:
+            eng.broadcast_parameters(src=0)
+        eng.sync_weights()
+        torch.cuda.synchronize()
+        comm = {"step_ms_per_rank": [round(float(t[0]), 3) for t in allr], "compute_only_ms_per_rank": [round(float(t[1]), 3) for t in allr],
+                "exposed_comm_ms_per_rank": [round(float(t[0] - t[1]), 3) for t in allr], "steps": n_c,
+                "how": "same step with every collective call skipped (parallel.GradBuckets.null_collectives), per-rank wall time"}
+    wd["phase"] = "post-processing"
 
     # ---- forward-only and forward+backward times (SURVEY.md §8d asks for them next to the step time); outside the timed region
     def timed_loop(fn, n=5):
@@ -695,6 +779,14 @@ def main():
             e1.record()
             K = A.shape[0] if name == "wgrad_tn" else A.shape[1]      # TN form reduces over the rows
             nbytes = A.shape[0] * A.shape[1] * 2 + B.shape[0] * B.shape[1] * 2 + C.shape[0] * C.shape[1] * C.element_size()
+            # + every side tensor the fused epilogue has to touch once: bias, the GELU' store, residual / aux rows, the LayerNorm
+            # statistics and gamma / beta of a re-materialised residual (all "algorithmic": the fusion needs them)
+            for key in ("bias", "pre", "aux", "res"):
+                t = kw.get(key)
+                if t is not None:
+                    nbytes += t.shape[0] * (t.shape[1] if t.dim() > 1 else 1) * t.element_size()
+            if kw.get("res_ln") is not None:
+                nbytes += C.shape[0] * 8 + 2 * C.shape[1] * 4
             rec.append((e0, e1, 2.0 * C.shape[0] * C.shape[1] * K, nbytes, name))
             return out
         return wrapper
@@ -707,7 +799,7 @@ def main():
         host["wgrad_tn_group"] = host.get("wgrad_tn_group", 0.0) + time.perf_counter() - h0
         e1.record()
         fl = sum(2.0 * dy.shape[0] * dy.shape[1] * x.shape[1] for dy, x, _, _ in items)
-        nb = sum(dy.numel() * 2 + x.numel() * 2 + C.numel() * 4 for dy, x, C, _ in items)
+        nb = sum(dy.numel() * 2 + x.numel() * 2 + C.numel() * 4 + (cs.numel() * 4 if cs is not None else 0) for dy, x, C, cs in items)
         rec.append((e0, e1, fl, nb, "wgrad_tn_group"))
         return out
 
@@ -734,7 +826,7 @@ def main():
     ops.wgrad_tn_group = orig_group
     gemm_ms = sum(r[0].elapsed_time(r[1]) for r in rec)
     gemm_flops = sum(r[2] for r in rec)
-    gemm_alg_gb = sum(r[3] for r in rec) / max(len(rec), 1) / 1e9      # operands read once + result written once
+    gemm_alg_gb = sum(r[3] for r in rec) / max(len(rec), 1) / 1e9      # operands + epilogue side tensors read once, results written once
     by_op = {}
     for r in rec:
         a = by_op.setdefault(r[4], [0, 0.0, 0.0])
@@ -767,7 +859,7 @@ def main():
     # the committed summary of those passes is reported here when it was taken on this workload, else null.
     traffic, traffic_unit = None, None
     pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    tname = next((n for n in ("r03_gemm_traffic.json", "r02_gemm_traffic.json") if os.path.isfile(os.path.join(pdir, n))), None)
+    tname = next((n for n in ("r04_gemm_traffic.json", "r03_gemm_traffic.json", "r02_gemm_traffic.json") if os.path.isfile(os.path.join(pdir, n))), None)
     if world == 1 and args.global_batch == 256 and args.layers == 12 and not args.e2e and not args.large and tname:
         with open(os.path.join(pdir, tname)) as f:
             tj = json.load(f)
@@ -816,6 +908,7 @@ def main():
                          "step_frac_of_peak": round(value * fwdbwd / 1e12 / (world * PEAK_BF16_TFLOPS), 4),
                          "step_executed_tflop_per_gpu": round(exec_tflop, 3),
                          "step_frac_of_peak_executed": round(exec_tflop / (ms * 1e-3) / PEAK_BF16_TFLOPS, 4)},
+            "comm": comm,
             "fwd_ms": round(fwd_ms, 3) if fwd_ms is not None else None,
             "fwd_bwd_ms": round(fwd_bwd_ms, 3) if fwd_bwd_ms is not None else None,
             "loss": round(losses["loss"], 4),
@@ -823,7 +916,9 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             ckw = dict(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096) if args.large \
                 else dict(num_hidden_layers=args.layers)
-            out["cpu_baseline"] = cpu_baseline(ckw, T, R, budget_s=12.0 if args.e2e else 25.0, full=args.cpu_baseline_full)
+            plain = (args.global_batch == 256 and args.layers == 12 and not args.e2e and not args.large and not args.precision)
+            full = args.cpu_baseline_full or (plain and not args.cpu_baseline_quick)      # SURVEY 8d's form on the driver-visible line
+            out["cpu_baseline"] = cpu_baseline(ckw, T, R, budget_s=12.0 if args.e2e else 25.0, full=full)
             if args.e2e:
                 out["cpu_baseline"] = cpu_baseline_e2e(dict(num_hidden_layers=args.layers), T, R, tuple(args.image_size), out["cpu_baseline"])
         if (not args.no_cpu_baseline and not args.no_other_configs and world == 1 and args.global_batch == 256 and args.layers == 12

@@ -103,3 +103,59 @@ def test_c_abi_rccl_exchange_single_rank():
     print(r.stdout[-2000:])
     print(r.stderr[-3000:])
     assert r.returncode == 0 and "VLB_COMM_OK" in r.stdout, r.stderr[-2000:]
+
+
+def _gpus():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.skipif(_gpus() < 2, reason="needs >= 2 GPUs: the N > 1 RCCL path (this box has %d)" % _gpus())
+@pytest.mark.parametrize("mode", ["sharded", "allreduce"])
+def test_two_ranks_over_rccl_one_gpu_each(mode):
+    """First contact with RCCL at N > 1 wherever the suite runs on a multi-GPU box (auto-skipped on the 1-GPU boxes): one rank per
+    GPU over `nccl`, native reduce-scatter / all-gather, the same checks as the shared-GPU gloo run -- reduced slices = summed local
+    gradients, fp32-read tensors replicated, bit-identical replicas, sharded trajectory = all-reduce trajectory, graph replay."""
+    out = _run(["--mode", mode, "--backend", "nccl"])
+    assert out.count("backend nccl") == 2 and "collectives native" in out
+
+
+@pytest.mark.skipif(_gpus() < 2, reason="needs >= 2 GPUs")
+def test_bench_two_gpus_over_rccl_reports_the_exchange():
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one rank per GPU): finishes with rc 0 and a JSON line that
+    names RCCL, 2 ranks and the per-rank exposed-communication figures."""
+    import json
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["OMP_NUM_THREADS"] = "4"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    print(r.stdout[-3000:])
+    print(r.stderr[-2000:])
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(next(l for l in reversed(r.stdout.splitlines()) if l.startswith("{")))
+    assert d["n_gpus"] == 2 and d["config"]["ranks"] == 2 and d["config"]["collective_backend"] == "RCCL (nccl)"
+    assert not d["config"]["ranks_share_devices"]
+    assert d["comm"] is not None and len(d["comm"]["exposed_comm_ms_per_rank"]) == 2
+    assert d["value"] > 0 and d["config"]["global_batch"] == 256
+
+
+def test_bench_fails_loudly_when_the_communicator_cannot_form():
+    """A rank whose peers never show up must end with a non-zero exit code and ONE line saying why -- not hang the driver's SCALE run:
+    WORLD_SIZE = 2 with a single process, short rendezvous time-out."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               VLB_BENCH_COLLECTIVE_TIMEOUT_S="8", VLB_BENCH_BACKEND="gloo", OMP_NUM_THREADS="4")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=300)
+    print(r.stderr[-1500:])
+    assert r.returncode != 0
+    assert "bench.py: FAILED:" in r.stderr and "communicator" in r.stderr

@@ -883,6 +883,81 @@ def test_train_end2end_entry_point_runs_reference_style_config():
     assert abs(float(eng.adam[0]) - base * O.warmup_linear_lr(3, 4, 10)) < 1e-6 * base
 
 
+def test_checkpoint_written_by_the_reference_resumes_on_the_engine(tmp_path):
+    """tests/golden/checkpoint/ref_small-0000.model was written by the REFERENCE's `Checkpoint` callback after 2 steps of the reference's
+    AdamW (oracle/make_checkpoint_golden.py).  The engine must (a) load it -- weights by name, Adam moments by the reference's parameter
+    index order, step counter --, (b) continue the trajectory the reference itself continued after reloading that file (its next two
+    losses, stored with the fixture), and (c) write a file with the same structure (keys, index order, shapes, group fields), which
+    (d) it reads back to the identical state.  Replaces common/callbacks/epoch_end_callbacks/checkpoint.py:12-21 +
+    common/utils/load.py:20-54."""
+    E, C = pkg("engine"), pkg("common.checkpoint")
+    gold = os.path.join(os.path.dirname(__file__), "golden", "checkpoint")
+    z = np.load(os.path.join(gold, "ref_small_batch.npz"))
+    kw = {k: (int(v) if float(v).is_integer() else float(v)) for k, v in zip(z["cfg_keys"], z["cfg_vals"])}
+    batch = [torch.from_numpy(z["in_%d" % i]) for i in range(7)]
+    B, T, R = batch[2].shape[0], batch[2].shape[1], batch[0].shape[1]
+    eng = E.PretrainEngine(E.ModelConfig(**kw), B, T, R, device="cuda:0", train=False, lr=2e-3, weight_decay=1e-4, max_grad_norm=10.0)
+    path = os.path.join(gold, "ref_small-0000.model")
+    ck = C.load_checkpoint(eng, path)
+    assert float(eng.adam[5]) == 2.0
+    names = C.reference_param_order(eng.P.shapes)
+    m = eng.P.named(eng.P.m)
+    for i in (0, 5, len(names) - 1):
+        assert torch.equal(m[names[i]].cpu(), ck["optimizer"]["state"][i]["exp_avg"]), names[i]
+    eng.set_batch(*[t.to(dev()) for t in batch])
+    got = []
+    for _ in range(2):
+        eng.zero_grad(); eng.forward(train=False); eng.backward(train=False); eng.optimizer_step()
+        got.append(eng.loss_values()["loss"])
+    ref = [float(x) for x in z["losses_after"]]
+    print("resumed trajectory: engine %s | reference %s (before the checkpoint: %s)" % (got, ref, list(z["losses_before"])))
+    for a, b in zip(got, ref):
+        assert abs(a - b) <= 1e-2 * abs(b), (got, ref)
+    probe = str(z["probe_name"])
+    torch.cuda.synchronize()
+    report("resumed AdamW: %s after 2 more steps" % probe, eng.w32[probe], torch.from_numpy(z["probe_after"]), 3e-4, 2e-3)
+    # (c) + (d)
+    out = C.save_checkpoint(eng, str(tmp_path / "mine"), 1)
+    assert out.endswith("mine-0001.model")
+    mine = torch.load(out, map_location="cpu", weights_only=False)
+    assert list(mine.keys())[:2] == ["state_dict", "optimizer"] and set(mine["state_dict"]) == set(ck["state_dict"])
+    for k, t in ck["state_dict"].items():
+        assert tuple(mine["state_dict"][k].shape) == tuple(t.shape) and mine["state_dict"][k].dtype == t.dtype, k
+    g0, g1 = ck["optimizer"]["param_groups"][0], mine["optimizer"]["param_groups"][0]
+    assert g1["params"] == g0["params"] and set(g0) <= set(g1) and g1["betas"] == g0["betas"] and g1["correct_bias"] is True
+    assert abs(g1["eps"] - g0["eps"]) < 1e-12 and abs(g1["weight_decay"] - g0["weight_decay"]) < 1e-9
+    for i, st in ck["optimizer"]["state"].items():
+        assert set(mine["optimizer"]["state"][i]) == set(st) and mine["optimizer"]["state"][i]["step"] == 4
+        assert tuple(mine["optimizer"]["state"][i]["exp_avg_sq"].shape) == tuple(st["exp_avg_sq"].shape)
+    eng2 = E.PretrainEngine(E.ModelConfig(**kw), B, T, R, device="cuda:0", train=False, lr=2e-3, weight_decay=1e-4, max_grad_norm=10.0)
+    C.load_checkpoint(eng2, out)
+    assert torch.equal(eng2.P.master, eng.P.master) and torch.equal(eng2.P.m, eng.P.m) and torch.equal(eng2.P.v, eng.P.v)
+    assert torch.equal(eng2.adam[1:6], eng.adam[1:6])
+
+
+def test_train_end2end_writes_epoch_checkpoints_and_auto_resumes(tmp_path):
+    """--model-dir: `{prefix}-{epoch:04d}.model` after every epoch, TRAIN.AUTO_RESUME picks the newest one up and the run continues at
+    the right optimizer step (the LR schedule follows the restored step counter)."""
+    tr = pkg("pretrain.train_end2end")
+    with open(os.path.join(os.path.dirname(__file__), "fixtures", "pretrain_small.yaml")) as f:
+        text = f.read().replace("END_EPOCH: 1", "END_EPOCH: 10")
+    cfg = str(tmp_path / "pretrain_small_10_epochs.yaml")
+    with open(cfg, "w") as f:
+        f.write(text)
+    common = ["--cfg", cfg, "--steps-per-epoch", "4", "--text-len", "32", "--regions", "10", "--model-dir", str(tmp_path / "ckpt")]
+    eng = tr.main(common + ["--steps", "4"])            # accumulate 2 -> 2 optimizer steps per epoch -> epochs 0 and 1
+    torch.cuda.synchronize()
+    files = sorted(f for _, _, fs in os.walk(tmp_path / "ckpt") for f in fs)
+    assert [f[-11:] for f in files] == ["-0000.model", "-0001.model"], files
+    w_end = eng.P.master.clone()
+    eng2 = tr.main(common + ["--steps", "1"])           # resumes from epoch 2 = optimizer step 4
+    torch.cuda.synchronize()
+    assert float(eng2.adam[5]) == 5.0
+    assert not torch.equal(eng2.P.master, w_end)
+    base = 1.0e-5 * 4 * 2
+    assert abs(float(eng2.adam[0]) - base * O.warmup_linear_lr(5, 4, 20)) < 1e-6 * base
+
+
 def _vqa_config(cfg, classifier, answers, hidden):
     conf = _module_config(cfg)
     conf["NETWORK"].update(BLIND=False, NO_GROUNDING=False, ENABLE_CNN_REG_LOSS=False, CLASSIFIER_TYPE=classifier, CLASSIFIER_DROPOUT=0.1,

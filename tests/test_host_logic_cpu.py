@@ -298,3 +298,30 @@ def test_bench_other_configs_summarises_children_and_survives_failures(monkeypat
     monkeypatch.setattr(subprocess, "run", lambda cmd, **kw: R(1, "", "boom"))
     out = bench.other_configs()
     assert all("error" in v and "boom" in v["error"] for v in out.values())
+
+
+def test_checkpoint_parameter_order_is_the_reference_models():
+    """The index order of the optimizer state in a checkpoint (common/checkpoint.reference_param_order) against the reference's own
+    `named_parameters()` order, recorded from the reference's modules by oracle/make_checkpoint_golden.py (plain, pooler + relationship
+    head, multitask), and against the parameter order inside the checkpoint file the reference's Checkpoint callback wrote."""
+    import json
+    import os
+    E = importlib.import_module("vl-bert_amd.engine")
+    C = importlib.import_module("vl-bert_amd.common.checkpoint")
+    gold = os.path.join(os.path.dirname(__file__), "golden", "checkpoint")
+    with open(os.path.join(gold, "param_order.json")) as f:
+        order = json.load(f)
+    small = dict(hidden_size=64, num_hidden_layers=2, num_attention_heads=1, intermediate_size=128, vocab_size=300,
+                 max_position_embeddings=64, visual_region_classes=50)
+    for tag, kw in (("plain", {}), ("pooler_rel", dict(with_pooler=True, with_rel_loss=True)), ("multitask", dict(multitask=True))):
+        shapes = E.param_layout(E.ModelConfig(**small, **kw))
+        assert C.reference_param_order(shapes) == order[tag], tag
+        assert C.reference_param_order(reversed(list(shapes))) == order[tag], tag          # independent of the input order
+    ck = torch.load(os.path.join(gold, "ref_small-0000.model"), map_location="cpu", weights_only=False)
+    shapes = E.param_layout(E.ModelConfig(**small))
+    names = C.reference_param_order(shapes)
+    assert ck["optimizer"]["param_groups"][0]["params"] == list(range(len(names)))
+    for i, n in enumerate(names):
+        assert tuple(ck["optimizer"]["state"][i]["exp_avg"].shape) == tuple(shapes[n]), n
+    assert set(ck["state_dict"]) == set(shapes) | {E.TIED_DECODER_KEY}
+    assert C.checkpoint_path("out/vl-bert", 3) == "out/vl-bert-0003.model"

@@ -20,15 +20,25 @@ def main():
     e2e = "--e2e" in sys.argv
     mode = sys.argv[sys.argv.index("--mode") + 1] if "--mode" in sys.argv else "default"
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # --backend nccl: one rank per GPU over RCCL (needs >= world GPUs; tests/test_dp_gpu.py runs it where the box has them) -- native
+    # reduce-scatter / all-gather instead of the gloo emulation, same checks
+    backend = sys.argv[sys.argv.index("--backend") + 1] if "--backend" in sys.argv else "gloo"
+    DEV = "cuda:%d" % (int(os.environ.get("LOCAL_RANK", "0")) if backend == "nccl" else 0)
+    torch.cuda.set_device(DEV)
+    if backend == "nccl":
+        import datetime
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(DEV), timeout=datetime.timedelta(seconds=180))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     E = importlib.import_module("vl-bert_amd.engine")
     syn = importlib.import_module("vl-bert_amd.synthetic")
     B, T, R = 4, 16, 6
     cfg = E.ModelConfig(num_hidden_layers=3, e2e=e2e, image_num_layers=50)
     kw = dict(image_size=(96, 128)) if e2e else {}
-    eng = E.PretrainEngine(cfg, B, T, R, device="cuda:0", train=True, lr=1e-3, seed=7 + rank, dp_mode=mode, **kw)
-    assert eng.buckets is not None and eng.buckets.world == 2
+    eng = E.PretrainEngine(cfg, B, T, R, device=DEV, train=True, lr=1e-3, seed=7 + rank, dp_mode=mode, **kw)
+    assert eng.buckets is not None and eng.buckets.world == world
+    assert eng.buckets.emulate == (backend == "gloo"), "native reduce-scatter / all-gather expected over RCCL"
+    print("rank %d: backend %s on %s, collectives %s" % (rank, backend, DEV, "emulated (all-reduce)" if eng.buckets.emulate else "native"), flush=True)
     sharded = eng.buckets.sharded
     assert sharded == (mode != "allreduce"), (mode, sharded)
     eng.init_random(seed=0, visual_ln_init=1.0)
@@ -38,9 +48,9 @@ def main():
         batch[0][:, :, :4] = batch[0][:, :, :4].clamp(0, 90)
         batch[0][:, :, 2:4] += 20
         batch[1][:, 0], batch[1][:, 1] = 128, 96
-        eng.set_batch(*[t.cuda() for t in batch], image=img.cuda())
+        eng.set_batch(*[t.to(DEV) for t in batch], image=img.to(DEV))
     else:
-        eng.set_batch(*[t.cuda() for t in batch])
+        eng.set_batch(*[t.to(DEV) for t in batch])
     eng.sync_weights()
     # (2) local gradients without the hooks, then the engine's reduced gradient for the same forward (dropout masks: same seed)
     eng.zero_grad(); eng.forward(True); eng.backward(True)
@@ -146,9 +156,9 @@ def main():
     if sharded and not e2e:
         engs = {}
         for m in ("sharded", "allreduce"):
-            e = E.PretrainEngine(cfg, B, T, R, device="cuda:0", train=True, lr=1e-3, seed=7 + rank, dp_mode=m)
+            e = E.PretrainEngine(cfg, B, T, R, device=DEV, train=True, lr=1e-3, seed=7 + rank, dp_mode=m)
             e.init_random(seed=0, visual_ln_init=1.0)
-            e.set_batch(*[t.cuda() for t in batch])
+            e.set_batch(*[t.to(DEV) for t in batch])
             e.sync_weights()
             engs[m] = e
         steps = 5

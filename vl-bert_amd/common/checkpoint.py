@@ -1,0 +1,177 @@
+"""Checkpoint files in the reference's on-disk format, for the fused engine.
+
+What it replaces: `Checkpoint.__call__` (common/callbacks/epoch_end_callbacks/checkpoint.py:12-21) -- after every epoch rank 0 writes
+`{prefix}-{epoch:04d}.model` = torch.save({'state_dict': net.state_dict(), 'optimizer': optimizer.state_dict()}) -- and `smart_resume`
+(common/utils/load.py:20-54): TRAIN.RESUME loads `{prefix}-{BEGIN_EPOCH-1:04d}.model`, TRAIN.AUTO_RESUME the newest existing epoch file,
+model weights through the 'module.' prefix tolerant loader, the optimizer through `optimizer.load_state_dict`.
+
+The engine keeps parameters, gradients and Adam moments in flat buffers; here they are presented in the layout the reference's files
+have, so either side reads the other's checkpoints:
+  * 'state_dict': the reference's key names (engine.state_dict(), tied decoder key included), CPU fp32 tensors;
+  * 'optimizer': torch.optim's state-dict form of the reference's AdamW (common/nlp/bert/optimization.py:107-187): 'state' = {index:
+    {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups' = [one group: lr, betas, eps, weight_decay, correct_bias, params = indices] with
+    the indices in the order of the reference model's `named_parameters()` (pretrain/function/train.py:140-160 builds the group in that
+    order; pinned by tests/golden/checkpoint/param_order.json, produced from the reference's own modules).  An extra top-level key
+    'param_names' (ignored by torch's loader) records the name of every index, so a resume never depends on ordering conventions.
+With the sharded data-parallel optimizer the master weights and moments are authoritative on the owning rank: saving is a COLLECTIVE
+(every rank calls save_checkpoint, rank 0 writes).  Host glue: no arithmetic here.
+"""
+import os
+from collections import OrderedDict
+
+import torch
+
+
+def reference_param_order(names):
+    """`names`: the engine's parameter names (any order) -> the order of the reference model's named_parameters()."""
+    names = list(names)
+    have = set(names)
+    order = []
+
+    def take(n):
+        if n in have and n not in order:
+            order.append(n)
+
+    # (e2e) the FastRCNN convolution weights are registered first (self.image_feature_extractor is the first sub-module); among
+    # themselves they keep the engine's state-dict order (backbone stem .. layer3, then the RoI head)
+    for n in names:
+        if n.startswith("image_feature_extractor.") and not n.startswith("image_feature_extractor.obj_downsample"):
+            take(n)
+    for n in ("image_feature_extractor.obj_downsample.1.weight", "image_feature_extractor.obj_downsample.1.bias",
+              "object_linguistic_embeddings.weight", "object_mask_visual_embedding.weight", "object_mask_word_embedding.weight",
+              "aux_text_visual_embedding.weight", "vlbert.word_embeddings.weight", "vlbert.end_embedding.weight",
+              "vlbert.position_embeddings.weight", "vlbert.token_type_embeddings.weight", "vlbert.embedding_LayerNorm.weight",
+              "vlbert.embedding_LayerNorm.bias", "vlbert.visual_ln_text.weight", "vlbert.visual_ln_text.bias",
+              "vlbert.visual_ln_object.weight", "vlbert.visual_ln_object.bias"):
+        take(n)
+    layer = 0
+    while "vlbert.encoder.layer.%d.attention.self.query.weight" % layer in have:
+        p = "vlbert.encoder.layer.%d." % layer
+        for n in ("attention.self.query", "attention.self.key", "attention.self.value", "attention.output.dense", "attention.output.LayerNorm",
+                  "intermediate.dense", "output.dense", "output.LayerNorm"):
+            take(p + n + ".weight")
+            take(p + n + ".bias")
+        layer += 1
+    for n in ("vlbert.pooler.dense.weight", "vlbert.pooler.dense.bias", "vlbert.relationsip_head.caption_image_relationship.weight",
+              "vlbert.relationsip_head.caption_image_relationship.bias", "vlbert.mlm_head.predictions.bias",
+              "vlbert.mlm_head.predictions.transform.dense.weight", "vlbert.mlm_head.predictions.transform.dense.bias",
+              "vlbert.mlm_head.predictions.transform.LayerNorm.weight", "vlbert.mlm_head.predictions.transform.LayerNorm.bias",
+              "vlbert.mvrc_head.transform.dense.weight", "vlbert.mvrc_head.transform.dense.bias", "vlbert.mvrc_head.region_cls_pred.weight",
+              "vlbert.mvrc_head.region_cls_pred.bias"):
+        take(n)
+    for n in names:          # anything this table does not know keeps its place at the end (never dropped)
+        take(n)
+    return order
+
+
+def checkpoint_path(prefix, epoch):
+    return "{}-{:04d}.model".format(prefix, epoch)
+
+
+def optimizer_state_dict(eng):
+    """The engine's AdamW state in torch.optim's state-dict form (see the module docstring).  A collective with the sharded optimizer."""
+    if eng.buckets is not None and eng.buckets.sharded:       # moments live on the owner: gather them like the master weights
+        eng.buckets.gather_master(eng.P.m)
+        eng.buckets.gather_master(eng.P.v)
+    adam = eng.adam.detach().cpu()
+    step = int(round(float(adam[5])))
+    shapes = eng.P.shapes
+    order = reference_param_order(shapes)
+    m, v = eng.P.named(eng.P.m), eng.P.named(eng.P.v)
+    vis = eng.vision
+    state = {}
+    for i, n in enumerate(order):
+        em, ev = m[n].detach().cpu().clone(), v[n].detach().cpu().clone()
+        if vis is not None and n in eng._vision_names():       # the engine keeps conv weights as [O, KH, KW, I]; the reference as [O, I, KH, KW]
+            em, ev = em.permute(0, 3, 1, 2).contiguous(), ev.permute(0, 3, 1, 2).contiguous()
+        state[i] = {"step": step, "exp_avg": em, "exp_avg_sq": ev}
+    lr = float(adam[0])
+    group = {"lr": lr, "betas": (float(adam[1]), float(adam[2])), "eps": float(adam[3]), "weight_decay": float(adam[4]),
+             "correct_bias": True, "params": list(range(len(order)))}
+    if eng.lr_kind is not None:      # what the reference's LambdaLR scheduler leaves in the group (train.py:283-285 sets it before resuming)
+        group["initial_lr"] = float(eng.base_lr)
+    return {"state": state, "param_groups": [group], "param_names": order}
+
+
+def load_optimizer_state_dict(eng, osd):
+    """Inverse of optimizer_state_dict; accepts files written by the reference (no 'param_names': indices follow its named_parameters()
+    order) and by this module."""
+    shapes = eng.P.shapes
+    order = osd.get("param_names") or reference_param_order(shapes)
+    idx = [i for g in osd["param_groups"] for i in g["params"]]
+    if len(idx) != len(order):
+        raise ValueError("optimizer state has %d parameters, the engine %d" % (len(idx), len(order)))
+    m, v = eng.P.named(eng.P.m), eng.P.named(eng.P.v)
+    steps = set()
+    visn = eng._vision_names() if eng.vision is not None else ()
+    for i, n in zip(idx, order):
+        if n not in shapes:
+            raise KeyError("optimizer state names a parameter the engine does not have: %s" % n)
+        st = osd["state"].get(i)
+        if st is None:            # a parameter that never received a gradient has no state in torch's optimizers
+            m[n].zero_()
+            v[n].zero_()
+            continue
+        em, ev = st["exp_avg"], st["exp_avg_sq"]
+        if n in visn:
+            em, ev = em.permute(0, 2, 3, 1), ev.permute(0, 2, 3, 1)
+        if tuple(em.shape) != tuple(shapes[n]):
+            raise ValueError("optimizer state of %s has shape %s, expected %s (is the file's parameter order the reference's?)"
+                             % (n, tuple(em.shape), tuple(shapes[n])))
+        m[n].copy_(em.to(torch.float32))
+        v[n].copy_(ev.to(torch.float32))
+        steps.add(int(st["step"]))
+    if len(steps) > 1:
+        raise ValueError("per-parameter step counts differ (%s): the fused AdamW keeps one counter" % sorted(steps))
+    g = osd["param_groups"][0]
+    eng.adam[1:5].copy_(torch.tensor([g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"]], dtype=torch.float32))
+    eng.adam[5:6].fill_(float(steps.pop()) if steps else 0.0)
+    if eng.lr_kind is None:
+        eng.adam[0:1].fill_(float(g["lr"]))       # (with a device-side schedule the lr is recomputed from the step counter each step)
+
+
+def save_checkpoint(eng, prefix, epoch, rank=0, extra=None):
+    """`Checkpoint(prefix, frequent)(epoch, net, optimizer, ...)`: writes `{prefix}-{epoch:04d}.model` on rank 0.  Call on EVERY rank."""
+    sd = eng.state_dict()                 # (gathers the master slices first with the sharded optimizer)
+    osd = optimizer_state_dict(eng)
+    path = checkpoint_path(prefix, epoch)
+    if rank == 0:
+        ck = OrderedDict(state_dict=OrderedDict((k, t.detach().cpu()) for k, t in sd.items()), optimizer=osd)
+        if extra:
+            ck.update(extra)
+        d = os.path.dirname(os.path.abspath(path))
+        os.makedirs(d, exist_ok=True)
+        tmp = path + ".tmp"
+        torch.save(ck, tmp)
+        os.replace(tmp, path)             # never leave a half-written epoch file for AUTO_RESUME to find
+    return path
+
+
+def load_checkpoint(eng, path, with_optimizer=True):
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    sd = ck["state_dict"]
+    # smart_load_model_state_dict (common/utils/load.py:84-104): tolerate the 'module.' prefix of a DistributedDataParallel wrapper
+    sd = OrderedDict((k[len("module."):] if k.startswith("module.") else k, t) for k, t in sd.items())
+    eng.load_state_dict({k: t.to(eng.dev) for k, t in sd.items()})
+    if with_optimizer and "optimizer" in ck:
+        load_optimizer_state_dict(eng, ck["optimizer"])
+    eng.sync_weights()
+    return ck
+
+
+def smart_resume(eng, prefix, begin_epoch, end_epoch, resume=False, auto_resume=True, log=print):
+    """common/utils/load.py:20-54 -> the epoch to begin with.  RESUME: `{prefix}-{begin_epoch-1:04d}.model` must exist; AUTO_RESUME: the
+    newest `{prefix}-{e-1:04d}.model` for e in (begin_epoch, end_epoch]."""
+    if resume:
+        path = checkpoint_path(prefix, begin_epoch - 1)
+        log("continue training from %d (%s)" % (begin_epoch, path))
+        load_checkpoint(eng, path)
+        return begin_epoch
+    if auto_resume:
+        for epoch in range(end_epoch, begin_epoch, -1):
+            path = checkpoint_path(prefix, epoch - 1)
+            if os.path.exists(path):
+                load_checkpoint(eng, path)
+                log("Auto continue training from {0}".format(path))
+                return epoch
+    return begin_epoch

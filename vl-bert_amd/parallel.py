@@ -166,6 +166,7 @@ class GradBuckets:
         self.launched = set()
         self.pending = []
         self._complete = self.world == 1
+        self._null = False                        # null_collectives(): timing mode, every collective call skipped
         # ---- sharded mode: compact images + the forward-order weight gather --------------------------------------------------
         if self.sharded:
             wdt = self.wire_dtype if self.wire_dtype is not None else flat_grad.dtype
@@ -205,10 +206,20 @@ class GradBuckets:
             w.copy_(t)                        # (gloo CPU tests)
         return w
 
+    def null_collectives(self, on=True):
+        """Measurement mode (bench.py's exposed-communication figure): every collective call of the exchange -- bucket reduce(-scatter),
+        norm all-reduce, weight gather, fp32 replication -- is SKIPPED while the local work around it (wire casts, sharded clip + AdamW,
+        graph segments, host calls) runs unchanged: the step time that remains is this rank's compute-only time at the same per-GPU
+        batch and launch structure.  The numbers computed in this mode are meaningless (stale slices); switch it off again and
+        re-broadcast before training on."""
+        self._null = bool(on)
+
     def _launch(self, lo, hi):
         if self.world == 1:
             return
         src = self._cast_to_wire(lo, hi) if self.wire is not None else self.flat[lo:hi]
+        if self._null:
+            return
         if not self.sharded:
             self.pending.append((dist.all_reduce(src, group=self.group, async_op=True), None))
             return
@@ -301,7 +312,7 @@ class GradBuckets:
     # ------------------------------------------------------------------------------------------------------------------
     def all_reduce_scalar(self, t):
         """Sum of the ranks' partial squared gradient norms (every rank receives the same bits)."""
-        if self.world > 1:
+        if self.world > 1 and not self._null:
             dist.all_reduce(t, group=self.group)
 
     def _all_gather(self, out, inp, async_op=True):
@@ -364,7 +375,7 @@ class GradBuckets:
         stages' convolution weights are folded from the fp32 master (vision.py), so for those buckets the fp32 master slices travel
         instead (`vision_master`, default: when `master` is given and there are vision buckets -- the older calling form).  `master` +
         set_replicated_fp32(): the fp32-read tensors are replicated first (see there)."""
-        if self.world == 1:
+        if self.world == 1 or self._null:
             return
         if vision_master is None:
             vision_master = master is not None

@@ -11,8 +11,9 @@ hyper-parameter conventions:
   * 'triangle' = WarmupLinearSchedule(WARMUP_STEPS, t_total = END_EPOCH x steps/epoch / accumulate)     (:316-320)
   * clip_grad_norm_(CLIP_GRAD_NORM), AdamW(betas 0.9/0.999, eps 1e-6, WD, bias-corrected)               (:146-160)
   * one process per GPU with --dist (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* from the launcher; backend nccl = RCCL).
-What it does NOT reproduce is the data side (pretrain/data/: datasets, tokeniser, image decoding -- out of scope):
-batches are synthetic, in the collated layout of pretrain/data/collate_batch.py.  There is no CPU execution path: without a GPU
+Checkpoints: with --model-dir the reference's epoch files `{prefix}-{epoch:04d}.model` are written and TRAIN.RESUME / AUTO_RESUME
+honoured (vl-bert_amd/common/checkpoint.py).  What it does NOT reproduce is the data side (pretrain/data/: datasets, tokeniser,
+image decoding -- out of scope): batches are synthetic, in the collated layout of pretrain/data/collate_batch.py.  There is no CPU execution path: without a GPU
 the program stops with an error unless --dry-run is given, which only resolves and prints the configuration (the "plumbing"
 check of the reference's scripts/nondist_run.sh case).
 """
@@ -38,11 +39,13 @@ class AttrDict(dict):
 
 DEFAULTS = {
     "RNG_SEED": 12345, "MODULE": "ResNetVLBERTForPretraining", "LOG_FREQUENT": 100, "SCALES": (600, 1000),
+    "OUTPUT_PATH": "", "MODEL_PREFIX": "", "CHECKPOINT_FREQUENT": 1,
     "NETWORK": {"IMAGE_FEAT_PRECOMPUTED": True, "IMAGE_NUM_LAYERS": 101, "IMAGE_C5_DILATED": True, "IMAGE_STRIDE_IN_1x1": True,
                 "IMAGE_FROZEN_BACKBONE_STAGES": [1, 2], "IMAGE_FROZEN_BN": True, "IMAGE_SEMANTIC": False, "OUTPUT_CONV5": False,
                 "WITH_REL_LOSS": False, "WITH_MLM_LOSS": True, "WITH_MVRC_LOSS": True, "VLBERT": {}},
     "TRAIN": {"BATCH_IMAGES": 64, "LR": 1.0e-7, "WD": 1.0e-4, "CLIP_GRAD_NORM": 10, "LR_SCHEDULE": "triangle", "WARMUP": True,
-              "WARMUP_STEPS": 8000, "BEGIN_EPOCH": 0, "END_EPOCH": 10, "GRAD_ACCUMULATE_STEPS": 1, "OPTIMIZER": "AdamW", "FP16": False},
+              "WARMUP_STEPS": 8000, "BEGIN_EPOCH": 0, "END_EPOCH": 10, "GRAD_ACCUMULATE_STEPS": 1, "OPTIMIZER": "AdamW", "FP16": False,
+              "RESUME": False, "AUTO_RESUME": True},
 }
 
 
@@ -105,7 +108,10 @@ def resolve(config, world, args):
 def parse_args(argv=None):
     ap = argparse.ArgumentParser("Train VL-BERT on the MI355X engine")
     ap.add_argument("--cfg", type=str, help="path to a reference-style config file (cfgs/pretrain/*.yaml)")
-    ap.add_argument("--model-dir", type=str, help="accepted for command-line compatibility (checkpoint I/O is host glue, not built)")
+    ap.add_argument("--model-dir", type=str, help="root of the checkpoint directory (pretrain/train_end2end.py:21,39-40): epoch files "
+                    "`<model-dir>/<OUTPUT_PATH>/<cfg name>/<MODEL_PREFIX>-<epoch:04d>.model` in the reference's format are written every "
+                    "CHECKPOINT_FREQUENT epochs (an epoch = --steps-per-epoch optimizer steps) and TRAIN.RESUME / TRAIN.AUTO_RESUME are "
+                    "honoured (vl-bert_amd/common/checkpoint.py).  Without it nothing is written")
     ap.add_argument("--log-dir", type=str, help="accepted for command-line compatibility")
     ap.add_argument("--dist", action="store_true", help="one process per GPU (torch.distributed.run / SLURM environment)")
     ap.add_argument("--slurm", action="store_true")
@@ -180,6 +186,18 @@ def main(argv=None):
         print("train_end2end: %s | %d GPU(s) x batch %d | lr %.3e wd %.1e clip %.1f | schedule %s warmup %d t_total %d%s" %
               (config.MODULE, world, B + B_aux, r["lr"], r["weight_decay"], r["clip_grad_norm"], r["lr_schedule"], r["warmup_steps"], r["t_total"],
                " | compute %s%s" % (r["compute"], " (loss scale %g)" % eng.loss_scale if eng.loss_scale != 1.0 else "")), flush=True)
+    # checkpoints in the reference's format + resume (common/callbacks/epoch_end_callbacks/checkpoint.py, common/utils/load.py:20-54)
+    ckpt = importlib.import_module(pkg + ".common.checkpoint")
+    spe = max(1, int(r["steps_per_epoch"] // r["accumulate"]))           # optimizer steps per epoch
+    begin_epoch, prefix = int(config.TRAIN.BEGIN_EPOCH), None
+    if args.model_dir:
+        cfg_name = os.path.splitext(os.path.basename(args.cfg))[0] if args.cfg else "default"
+        prefix = os.path.join(args.model_dir, str(config.OUTPUT_PATH).lstrip("./"), cfg_name, str(config.MODEL_PREFIX) or "vl-bert")
+        begin_epoch = ckpt.smart_resume(eng, prefix, begin_epoch, int(config.TRAIN.END_EPOCH), resume=bool(config.TRAIN.RESUME),
+                                        auto_resume=bool(config.TRAIN.AUTO_RESUME), log=(print if rank == 0 else (lambda *a: None)))
+        if begin_epoch > int(config.TRAIN.BEGIN_EPOCH) or config.TRAIN.RESUME:
+            eng.broadcast_parameters(src=0)
+    first_step = begin_epoch * spe
     t0, seen = time.time(), 0
     def load_batch(seed_off):
         batch = list(syn.make_batch(B, T, R, seed=1000 * rank + seed_off))
@@ -199,7 +217,7 @@ def main(argv=None):
         eng.set_batch(*[t.cuda(non_blocking=True) for t in batch], **kw)
 
     accum = r["accumulate"]
-    for step in range(args.steps):
+    for step in range(first_step, first_step + args.steps):
         if accum == 1:
             load_batch(step)
             eng.train_step()
@@ -216,7 +234,13 @@ def main(argv=None):
                 eng.buckets.wait()
             eng.optimizer_step()
         seen += (B + B_aux) * world * accum
-        if (step + 1) % max(1, min(int(config.LOG_FREQUENT), args.steps)) == 0 or step + 1 == args.steps:
+        if prefix is not None and (step + 1) % spe == 0:          # epoch end: Checkpoint(model_prefix, CHECKPOINT_FREQUENT) on rank 0
+            epoch = (step + 1) // spe - 1
+            if (epoch + 1) % max(1, int(config.CHECKPOINT_FREQUENT)) == 0:
+                path = ckpt.save_checkpoint(eng, prefix, epoch, rank=rank)       # (a collective with the sharded optimizer)
+                if rank == 0:
+                    print("epoch %d done: checkpoint %s" % (epoch, path), flush=True)
+        if (step + 1 - first_step) % max(1, min(int(config.LOG_FREQUENT), args.steps)) == 0 or step + 1 == first_step + args.steps:
             lv = eng.loss_values()          # host sync, like the reference's Speedometer + metric readout
             if rank == 0:
                 print("step %d  lr %.3e  loss %.4f (mlm %.4f mvrc %.4f)  %.1f samples/s" %
