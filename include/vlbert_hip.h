@@ -344,6 +344,10 @@ int vlb_im2col_nhwc_bf16(const void* x, void* col, long ldcol, int N, int H, int
 /* stem (resnet.py:137-141): fp32 NCHW image -> [N*OH*OW, ldcol] bf16, column (ky*KW+kx)*Cin + c, zero padded to ldcol */
 int vlb_im2col_image_f32(const float* img, void* col, int ldcol, int N, int Cin, int H, int W, int KH, int KW, int stride,
                          int pad, vlb_stream_t stream);
+/* raw-pixel masking of the masked regions of an e2e batch (pretrain/data/datasets/conceptual_captions.py:201-206): for every box slot
+ * with mvrc_ops == 1, img[n, :, int(y1):int(y2)+1, int(x1):int(x2)+1] = 0; img fp32 NCHW, boxes [N, R, ldb] (x1, y1, x2, y2, ...) */
+int vlb_mask_image_boxes_f32(float* img, int N, int C, int H, int W, const float* boxes, long ldb, int R, const int64_t* mvrc_ops,
+                             vlb_stream_t stream);
 int vlb_maxpool3x3s2_nhwc(const void* x, void* y, int N, int H, int W, int C, vlb_stream_t stream);
 /* stride-2 1x1 convolutions (caffe-style stride_in_1x1, resnet.py:79): y = x[:, ::2, ::2, :]; its adjoint writes all of dx */
 int vlb_subsample2_nhwc(const void* x, void* y, int N, int H, int W, int C, vlb_stream_t stream);

@@ -167,6 +167,23 @@ def roi_align(feat, rois, out_size=14, scale=1.0 / 16, sampling_ratio=1):
     return _RoiAlign.apply(feat, rois, out_size, scale, sampling_ratio)
 
 
+def mask_raw_pixels(image, boxes, mvrc_ops):
+    """pretrain/data/datasets/conceptual_captions.py:201-206 (= coco_captions.py:240-244), per sample of a collated batch:
+        for mvrc_op, box in zip(mvrc_ops, boxes):
+            if mvrc_op == 1:
+                x1, y1, x2, y2 = box
+                image[:, int(y1):(int(y2)+1), int(x1):(int(x2)+1)] = 0
+    image [B,3,H,W] (modified in place, returned), boxes [B,R,>=4], mvrc_ops [B,R].  The fragment sits inside the dataset's
+    __getitem__ (which needs the image / box archives), so there is no way to execute the reference for it here: this restatement is
+    the five lines above, statement for statement ("parity unpinned" for this fragment alone)."""
+    for b in range(image.shape[0]):
+        for mvrc_op, box in zip(mvrc_ops[b].tolist(), boxes[b]):
+            if mvrc_op == 1:
+                x1, y1, x2, y2 = [float(v) for v in box[:4]]
+                image[b, :, int(y1):(int(y2) + 1), int(x1):(int(x2) + 1)] = 0
+    return image
+
+
 def rois_from_boxes(boxes):
     """common/fast_rcnn.py:136,145-149: (batch index, x1, y1, x2, y2) of every valid box, batch-major."""
     box_mask = boxes[:, :, 0] > -1.5

@@ -325,3 +325,43 @@ def test_checkpoint_parameter_order_is_the_reference_models():
         assert tuple(ck["optimizer"]["state"][i]["exp_avg"].shape) == tuple(shapes[n]), n
     assert set(ck["state_dict"]) == set(shapes) | {E.TIED_DECODER_KEY}
     assert C.checkpoint_path("out/vl-bert", 3) == "out/vl-bert-0003.model"
+
+
+def test_finetune_entry_points_resolve_reference_style_configs_and_schedules():
+    """vqa / vcr train_end2end --dry-run on reference-style YAMLs (lr = LR x world x batch x accumulate, optimiser, clip, compute from
+    TRAIN.FP16) and the two LR schedules against torch LambdaLR-free restatements -- and against the reference's own scheduler classes
+    where the reference tree is present (build container)."""
+    import os
+    import sys
+    F = importlib.import_module("vl-bert_amd.common.finetune_entry")
+    fx = os.path.join(os.path.dirname(__file__), "fixtures")
+    r = F.main("vqa", ["--cfg", os.path.join(fx, "vqa_small.yaml"), "--dry-run", "--compute", "cfg"])
+    assert r["optimizer"] == "AdamW" and abs(r["lr"] - 1.0e-5 * 2 * 2) < 1e-12 and r["compute"] == "fp32" and r["clip_grad_norm"] == 1.0
+    r = F.main("vcr", ["--cfg", os.path.join(fx, "vcr_small.yaml"), "--dry-run", "--compute", "cfg"])
+    assert r["optimizer"] == "SGD" and abs(r["lr"] - 7.0e-5 * 2 * 2) < 1e-12 and r["compute"] == "fp16" and r["loss_scale"] == 128.0
+    cfg = F.load_config("vcr", os.path.join(fx, "vcr_small.yaml"))
+    assert cfg.NETWORK.VLBERT.with_pooler is True and cfg.NETWORK.CNN_LOSS_TOP is True
+    f = F.lr_lambda(cfg, 10)          # 10 micro-batches per epoch / accumulate 2 -> milestones at optimizer steps 70 and 90
+    assert [round(f(k), 6) for k in range(6)] == [0.0, 0.25, 0.5, 0.75, 1.0, 1.0] and f(69) == 1.0 and abs(f(70) - 0.1) < 1e-12 \
+        and abs(f(90) - 0.01) < 1e-12
+    cfg = F.load_config("vqa", os.path.join(fx, "vqa_small.yaml"))
+    g = F.lr_lambda(cfg, 8)           # t_total = 5 x 8 / 2 = 20, warm-up 3
+    assert [round(g(k), 6) for k in range(5)] == [0.0, round(1 / 3, 6), round(2 / 3, 6), 1.0, round(16 / 17, 6)] and g(20) == 0.0
+    ref = os.environ.get("VLBERT_REFERENCE_ROOT", "/root/reference")
+    if os.path.isdir(ref):            # the reference's own classes (not available on the GPU box; this is a CPU test)
+        sys.path.insert(0, ref)
+        try:
+            from common.lr_scheduler import WarmupMultiStepLR
+            from common.nlp.bert.optimization import WarmupLinearSchedule
+        finally:
+            sys.path.remove(ref)
+        for sched, fn in ((lambda o: WarmupMultiStepLR(o, milestones=[70, 90], gamma=0.1, warmup_factor=0.0, warmup_iters=4,
+                                                       warmup_method="linear"), f),
+                          (lambda o: WarmupLinearSchedule(o, 3, t_total=20), g)):
+            p = torch.nn.Parameter(torch.zeros(1))
+            opt = torch.optim.SGD([p], lr=1.0)
+            s = sched(opt)
+            for k in range(95):
+                assert abs(opt.param_groups[0]["lr"] - fn(k)) < 1e-9, (k, opt.param_groups[0]["lr"], fn(k))
+                opt.step()
+                s.step()

@@ -505,6 +505,83 @@ def test_engine_e2e_step_vs_oracle(empty_sample):
     assert set(moved) == trainable, (set(moved) ^ trainable)
 
 
+def test_raw_pixel_masking_of_masked_regions_vs_oracle(ops):
+    """vlb_mask_image_boxes_f32 = the dataset's MASK_RAW_PIXELS step (pretrain/data/datasets/conceptual_captions.py:201-206) on a
+    collated batch: bit-exact against oracle.vision_oracle.mask_raw_pixels -- fractional corners (int() truncation), boxes touching
+    and leaving the image, degenerate and padded (-2) boxes, ops other than 1 -- and through engine.set_batch(mask_raw_pixels=True),
+    whose e2e step then matches the oracle fed the masked image."""
+    g = torch.Generator().manual_seed(5)
+    B, R, H, W = 3, 7, 37, 53
+    img = torch.randn(B, 3, H, W, generator=g) * 40 + 3
+    boxes = torch.zeros(B, R, 6)
+    x1 = torch.rand(B, R, generator=g) * (W - 10)
+    y1 = torch.rand(B, R, generator=g) * (H - 10)
+    boxes[..., 0], boxes[..., 1] = x1, y1
+    boxes[..., 2] = x1 + torch.rand(B, R, generator=g) * 20
+    boxes[..., 3] = y1 + torch.rand(B, R, generator=g) * 20
+    boxes[0, 0, :4] = torch.tensor([0.0, 0.0, W - 1.0, H - 1.0])          # the whole image
+    boxes[0, 1, :4] = torch.tensor([W - 3.5, H - 2.2, W + 9.0, H + 4.0])    # leaves the image
+    boxes[1, 0, :4] = torch.tensor([4.9, 5.9, 4.1, 5.2])                    # x2 < x1 after int(): still one pixel column (stop = int()+1)
+    boxes[1, 1, :4] = torch.tensor([-2.0, -2.0, -2.0, -2.0])                # a padded slot that (wrongly) carries op 1: python slice semantics
+    boxes[2, 2, :4] = torch.tensor([10.0, 8.0, 10.0, 8.0])                  # one pixel
+    opsm = (torch.rand(B, R, generator=g) < 0.5).long()
+    opsm[0, 0], opsm[0, 1], opsm[1, 0], opsm[1, 1], opsm[2, 2], opsm[2, 3] = 0, 1, 1, 1, 1, 2
+    ref = VO.mask_raw_pixels(img.clone(), boxes, opsm)
+    got = img.clone().to(dev())
+    ops.mask_image_boxes(got, boxes.to(dev()), opsm.to(dev()))
+    torch.cuda.synchronize()
+    assert torch.equal(got.cpu(), ref), "masked image differs from conceptual_captions.py:201-206"
+    assert int((ref == 0).sum()) > 0 and not torch.equal(ref, img)
+    opsm[0, 0] = 1                                                           # the whole image masked
+    got = img.clone().to(dev())
+    ops.mask_image_boxes(got, boxes.to(dev()), opsm.to(dev()))
+    assert float(got[0].abs().sum()) == 0.0 and torch.equal(got.cpu(), VO.mask_raw_pixels(img.clone(), boxes, opsm))
+
+
+def test_engine_e2e_step_with_raw_pixel_masking_vs_oracle():
+    """The e2e step on a batch whose masked regions (mvrc_op 1) have their PIXELS zeroed by set_batch(mask_raw_pixels=True) -- what the
+    reference trains on with MASK_RAW_PIXELS -- against the composed oracle on the image masked by the oracle's own statement."""
+    E, syn = pkg("engine"), pkg("synthetic")
+    z, nl, P = _vision_fixture()
+    img, boxes4 = torch.from_numpy(z["img"]), torch.from_numpy(z["boxes"]).clone()
+    B, R = boxes4.shape[:2]
+    T = 12
+    cfg = O.VLBertConfig(num_hidden_layers=1)
+    params = O.init_params(cfg, seed=23)
+    batch = list(syn.make_batch(B, T, R, seed=24, ragged=False))
+    batch[0] = torch.cat((boxes4, torch.zeros(B, R, 2048)), -1)
+    batch[1] = torch.from_numpy(z["im_info"])
+    pad = boxes4[:, :, 0] <= -1.5
+    batch[5][pad] = 0
+    batch[6][pad] = 0
+    assert int((batch[5] == 1).sum()) >= 2
+    mc = E.ModelConfig(num_hidden_layers=1, e2e=True, image_num_layers=nl)
+    eng = E.PretrainEngine(mc, B, T, R, device="cuda:0", train=False, keep_logits=True, image_size=tuple(img.shape[2:]))
+    sd = {k: v.to(dev()) for k, v in params.items()}
+    sd.update({k: v.to(dev()) for k, v in _prefixed(P).items()})
+    eng.load_state_dict(sd)
+    eng.set_batch(*[t.to(dev()) for t in batch], image=img.to(dev()), mask_raw_pixels=True)
+    masked = VO.mask_raw_pixels(img.clone(), boxes4, batch[5])
+    assert torch.equal(eng.in_image.cpu(), masked) and not torch.equal(masked, img)
+    eng.zero_grad()
+    eng.forward(False)
+    eng.backward(False)
+    torch.cuda.synchronize()
+    frozen = VO.frozen_names(P)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    Po = {k: v.clone().requires_grad_(k not in frozen) for k, v in P.items()}
+    out, loss = O.pretrain_forward(leaves, cfg, *batch, train=False, image=masked, vision_params=Po, image_num_layers=nl)
+    _, loss_unmasked = O.pretrain_forward(params, cfg, *batch, train=False, image=img, vision_params=P, image_num_layers=nl)
+    lv = eng.loss_values()
+    print("e2e masked pixels: hip mlm %.5f mvrc %.5f | oracle mlm %.5f mvrc %.5f (oracle loss on the unmasked image %.5f)" %
+          (lv["mlm_loss"], lv["mvrc_loss"], float(out["mlm_loss"]), float(out["mvrc_loss"]), float(loss_unmasked)))
+    assert abs(lv["mlm_loss"] - float(out["mlm_loss"])) < 2e-2 * max(1.0, abs(float(out["mlm_loss"])))
+    assert abs(lv["mvrc_loss"] - float(out["mvrc_loss"])) < 2e-2 * max(1.0, abs(float(out["mvrc_loss"])))
+    with pytest.raises(ValueError):
+        pre = E.PretrainEngine(E.ModelConfig(num_hidden_layers=1), B, T, R, device="cuda:0", train=False)
+        pre.set_batch(*[t.to(dev()) for t in batch], mask_raw_pixels=True)
+
+
 def test_engine_multitask_e2e_step_vs_oracle():
     """multitask x e2e (cfgs/pretrain/base_e2e_16x16G_fp16.yaml: MODULE ResNetVLBERTForPretrainingMultitask with
     IMAGE_FEAT_PRECOMPUTED false): caption samples take their region features from the CNN, the text-only samples never touch it

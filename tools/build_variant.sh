@@ -8,7 +8,7 @@ OUT="$SRC/${VLB_AB_DIR:-ab}"
 mkdir -p "$OUT/obj"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -ffp-contract=fast $*"
 pids=()
-for f in api gemm gemm_p8 gemm_tn8 layernorm embed loss attention optim roi_align vision f32_path; do
+for f in api gemm gemm_p8 gemm_tn8 layernorm embed loss attention optim roi_align vision f32_path comm; do
   /opt/rocm/bin/hipcc $FLAGS -I"$ROOT/include" -c "$SRC/$f.hip" -o "$OUT/obj/$f.o" 2>/dev/null &
   pids+=($!)
 done

@@ -82,6 +82,7 @@ _SIGS = {
     "vlb_wgrad_tn_rowscale_bf16": "plplpliiipplis",
     "vlb_im2col_nhwc_bf16": "ppliiiiiiiiis",
     "vlb_im2col_image_f32": "ppiiiiiiiiis",
+    "vlb_mask_image_boxes_f32": "piiiiplips",
     "vlb_maxpool3x3s2_nhwc": "ppiiiis",
     "vlb_subsample2_nhwc": "ppiiiis",
     "vlb_upsample2_zero_nhwc": "ppiiiis",

@@ -37,6 +37,9 @@
 
 #include "gemm_params.h"
 
+#ifndef VLB_P8_SIDE_DEPTH
+#define VLB_P8_SIDE_DEPTH 1  // units of lead of the aux loads in the wave-private drain (EPI 2 / 10)
+#endif
 #ifndef VLB_P8_WDRAIN
 #define VLB_P8_WDRAIN 1      // wave-private epilogue drain (p8_drain_w); 0: the shared-slab drain with workgroup barriers (p8_drain)
 #endif
@@ -425,20 +428,30 @@ __device__ __forceinline__ void p8_drain_w(const GemmParams& p, f32x4 (&acc)[2 *
       }
     }
   };
-  uint4 side[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
-  float2 mst[2] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
+  // side rows are requested DEPTH units ahead of their use.  The aux tensor of the x-aux / ReLU-mask epilogues (GELU' of the FFN2 data
+  // gradient: 159 MB per launch, written in the forward pass, i.e. read from HBM, 16 B per lane per unit) is the one side tensor that
+  // is as large as the output: one unit of lead keeps 8 KiB per CU in flight, which caps the read stream by latency, not bandwidth
+  constexpr int DEPTH = (EPI == 2 || EPI == 10) ? VLB_P8_SIDE_DEPTH : 1, RING = DEPTH + 1;
+  uint4 side[RING];
+  float2 mst[RING];
+#pragma unroll
+  for (int d = 0; d < RING; ++d) {
+    side[d] = make_uint4(0, 0, 0, 0);
+    mst[d] = make_float2(0.f, 0.f);
+  }
   consts();
-  load_side(0, side[0], mst[0]);
+  p8_static_for<0, (DEPTH < NU ? DEPTH : NU)>([&](auto d_c) {
+    constexpr int d = decltype(d_c)::value;
+    load_side(d, side[d % RING], mst[d % RING]);
+  });
   put(std::integral_constant<int, 0>{});
   p8_static_for<0, NU>([&](auto u_c) {
     constexpr int u = decltype(u_c)::value;
     f32x4 x0, x1;
     p8_stage_read<0>(x0, x1, rd0, rd1);      // (waits for this wave's LDS queue: the writes of unit u and these reads)
-    if constexpr (u + 1 < NU) {
-      load_side(u + 1, side[(u + 1) & 1], mst[(u + 1) & 1]);
-      put(std::integral_constant<int, u + 1>{});
-    }
-    finish(u, x0, x1, side[u & 1], mst[u & 1]);
+    if constexpr (u + DEPTH < NU) load_side(u + DEPTH, side[(u + DEPTH) % RING], mst[(u + DEPTH) % RING]);
+    if constexpr (u + 1 < NU) put(std::integral_constant<int, u + 1>{});
+    finish(u, x0, x1, side[u % RING], mst[u % RING]);
   });
 }
 
@@ -699,10 +712,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(const GemmParams p) 
     } else {
       p8_drain<FMH, EPI, (SR == 32 ? 1 : 0)>(p, acc, lds0 + STG, m0, n0, wm, wn, lane, tid, seed);
     }
-    // one full drain per output tile (stores and LDS-DMA share vmcnt and may retire out of order with respect to each other:
-    // counted waits are only sound on a queue of loads); the K tiles prefetched for the next output tile had the whole epilogue
-    // to land, so this waits for the last stores only
-    __builtin_amdgcn_s_waitcnt(0x0F70);
+    // No drain of the epilogue's stores (round 4; p8_flags bit 0 restores the vmcnt(0) of round 3).  The next output tile's K tile 0
+    // was retired by the last in-loop wait, BEFORE the epilogue; its K tile 1 is retired by the next in-loop vmcnt(VM_AHEAD), which
+    // stays sound with stores in the queue: vmcnt counts stores too, LDS-DMA loads retire in order among themselves, so "at most
+    // VM_AHEAD operations outstanding" still implies that every load older than the VM_AHEAD youngest ones (all loads: the
+    // stores are older) has landed -- whatever order stores and loads retire in relative to each other.  What changes: a wave no
+    // longer sits out the L2 / HBM acknowledgement of its last stores behind every tile (all 256 CUs end their epilogues
+    // together: 119-318 MB of stores per launch in bursts); they drain under the first three phases of the next tile instead.
+    if (p.p8_flags & 1) __builtin_amdgcn_s_waitcnt(0x0F70);
     p8_barrier();
     if (wm == 1 && w + (int)gridDim.x < nt) p8_barrier();   // re-establish the one-segment lag for the next output tile
   }
@@ -763,8 +780,8 @@ inline bool aligned16(const void* q) { return ((uintptr_t)q & 15) == 0; }
 // p8_wgs: persistent workgroups per launch (<= 256 = one per CU).  Fewer leave CUs to a kernel running on another stream (the
 // weight-gradient GEMMs of the side stream): an MFMA-bound kernel then fills the HBM-bound epilogue bursts of this one.
 // p8_ablate (tools/p8_check.py ablate; results are WRONG when != 0): 1 no epilogue | 2 epilogue without its global stores
-static int g_opt[7] = {-1, -1, -1, -1, -1, -1, -1};
-static const char* const g_opt_name[7] = {"p8_mode", "p8_keepb", "p8_group", "p8_min_tiles", "p8_wgs", "p8_ablate", "p8_tile192"};
+static int g_opt[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+static const char* const g_opt_name[8] = {"p8_mode", "p8_keepb", "p8_group", "p8_min_tiles", "p8_wgs", "p8_ablate", "p8_tile192", "p8_drain"};
 static void p8_options_init() {
   if (g_opt[0] >= 0) return;
   g_opt[0] = env_int("VLB_GEMM_P8", 1);
@@ -774,6 +791,7 @@ static void p8_options_init() {
   g_opt[4] = env_int("VLB_GEMM_P8_WGS", 256);
   g_opt[5] = 0;
   g_opt[6] = env_int("VLB_GEMM_P8_192", 1);
+  g_opt[7] = env_int("VLB_GEMM_P8_DRAIN", 0);      // 1: vmcnt(0) behind every output tile (round-3 behaviour, A/B)
 }
 
 extern "C" int vlb_gemm_set_option(const char* name, int value) {
@@ -799,7 +817,7 @@ extern "C" int vlb_gemm_set_option(const char* name, int value) {
     vlb_tn8_set_uneven(value);
     return VLB_OK;
   }
-  for (int i = 0; i < 7; ++i)
+  for (int i = 0; i < 8; ++i)
     if (!strcmp(name, g_opt_name[i])) {
       g_opt[i] = value;
       return VLB_OK;
@@ -850,6 +868,7 @@ int vlb_gemm_p8_try(GemmParams& p, hipStream_t stream) {
   if (!fmh) return 0;
   const int g = group < 1 ? 1 : group;
   p.ablate = g_opt[5];
+  p.p8_flags = g_opt[7] ? 1 : 0;
   if (fmh == 3) return p8_launch_epi<3, true>(p, epi, g, stream);
   if (fmh == 5) return p8_launch_epi<5, false>(p, epi, g, stream);
   return keepb ? p8_launch_epi<4, true>(p, epi, g, stream) : p8_launch_epi<4, false>(p, epi, g, stream);

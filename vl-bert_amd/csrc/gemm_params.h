@@ -19,6 +19,7 @@ struct GemmParams {
   int c_f16;                 // bf16-output kernels write C as fp16 instead (the pre-LayerNorm sums)
   int ablate;                // gemm_p8 timing ablations (results are WRONG when != 0): 1 no epilogue | 2 epilogue without global stores |
                              // 3 epilogue without the LDS slab round trip
+  int p8_flags;              // gemm_p8 run-time variants: bit 0 = keep the vmcnt(0) drain behind every output tile's epilogue (round-3 behaviour)
   int stagger;               // 128x128 kernel: second-resident workgroups start `stagger` x ~3.4 us late (phase offset between the two
                              // workgroups of a CU, so one runs its epilogue under the other's MFMA loop)
   uint32_t drop_thr; float drop_scale; const uint32_t* seed; uint32_t tag;

@@ -284,6 +284,38 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const bf16_t* __restr
   }
 }
 
+// Raw-pixel masking of the masked regions (pretrain/data/datasets/conceptual_captions.py:201-206, coco_captions.py:240-244; e2e only,
+// NETWORK.MASK_RAW_PIXELS): for every box with mvrc_op == 1,  image[:, int(y1):(int(y2)+1), int(x1):(int(x2)+1)] = 0  on the
+// transformed (mean-subtracted) fp32 NCHW image, boxes in that image's pixel coordinates.  The reference does it per sample on the data
+// worker; here one launch over the collated batch on the device (the image is already in HBM).  One workgroup per (box slot, sample),
+// python slice semantics: negative starts count from the end, stops clamp to the extent.
+__global__ __launch_bounds__(256) void mask_image_boxes_kernel(float* __restrict__ img, int C, int H, int W, const float* __restrict__ boxes,
+                                                                long ldb, int R, const int64_t* __restrict__ ops) {
+  const int r = blockIdx.x, b = blockIdx.y;
+  if (ops[(long)b * R + r] != 1) return;
+  const float* bx = boxes + ((long)b * R + r) * ldb;
+  auto lo = [](float v, int n) { int i = (int)v; if (i < 0) i += n; return min(max(i, 0), n); };      // int(): truncation toward zero
+  auto hi = [](float v, int n) { int i = (int)v + 1; if (i < 0) i += n; return min(max(i, 0), n); };
+  const int x0 = lo(bx[0], W), y0 = lo(bx[1], H), x1 = hi(bx[2], W), y1 = hi(bx[3], H);
+  const int w = x1 - x0, h = y1 - y0;
+  if (w <= 0 || h <= 0) return;
+  float* base = img + (long)b * C * H * W;
+  const long n = (long)C * h * w;
+  for (long i = threadIdx.x; i < n; i += 256) {
+    const int x = (int)(i % w), y = (int)((i / w) % h), c = (int)(i / ((long)w * h));
+    base[((long)c * H + y0 + y) * W + x0 + x] = 0.f;
+  }
+}
+
+extern "C" int vlb_mask_image_boxes_f32(float* img, int N, int C, int H, int W, const float* boxes, long ldb, int R, const int64_t* mvrc_ops,
+                                        hipStream_t stream) {
+  if (N <= 0 || R <= 0) return VLB_OK;
+  VLB_CHECK_ARG(img && boxes && mvrc_ops && C > 0 && H > 0 && W > 0 && ldb >= 4, "vlb_mask_image_boxes_f32: bad argument");
+  hipLaunchKernelGGL(mask_image_boxes_kernel, dim3(R, N), dim3(256), 0, stream, img, C, H, W, boxes, ldb, R, mvrc_ops);
+  VLB_CHECK_LAUNCH("vlb_mask_image_boxes_f32");
+  return VLB_OK;
+}
+
 extern "C" int vlb_maxpool3x3s2_nhwc(const void* x, void* y, int N, int H, int W, int C, hipStream_t stream) {
   if (N <= 0) return VLB_OK;
   VLB_CHECK_ARG(x && y && C > 0 && (C % 8) == 0 && H > 0 && W > 0, "vlb_maxpool3x3s2_nhwc: bad argument");

@@ -509,11 +509,13 @@ class PretrainEngine:
     # batch
     # ------------------------------------------------------------------------------------------
     def set_batch(self, boxes, im_info, text, relationship_label, mlm_labels, mvrc_ops, mvrc_labels, aux_text=None,
-                  aux_mlm_labels=None, image=None):
+                  aux_mlm_labels=None, image=None, mask_raw_pixels=False):
         """Copies a collated batch (pretrain/data/collate_batch.py layout) into the static device buffers
         and derives the masks exactly as resnet_vlbert_for_pretraining.py:106,134 does
         (box_mask = boxes[:,:,0] > -1.5 ; text_mask = text > 0).  `relationship_label` is only read
-        with ModelConfig(with_rel_loss=True) (WITH_REL_LOSS is false in the north-star configuration)."""
+        with ModelConfig(with_rel_loss=True) (WITH_REL_LOSS is false in the north-star configuration).
+        mask_raw_pixels (e2e): the image arrives UNMASKED and the pixels of the regions with mvrc_op == 1 are zeroed here, on the
+        device copy -- the step the reference's dataset does per sample (conceptual_captions.py:201-206, MASK_RAW_PIXELS)."""
         B = self.B
         if self.mlm_cap is not None:    # labels still on the host: count them exactly (no sync) and take the full path if they do not fit
             self._mlm_compact_now = True
@@ -554,6 +556,11 @@ class PretrainEngine:
             self.in_rel_label.copy_(relationship_label, non_blocking=True)
         torch.gt(self.in_text, 0, out=self.text_mask.view(torch.bool))
         torch.gt(self.in_boxes[:, :, 0], -1.5, out=self.box_mask[:B].view(torch.bool))
+        if mask_raw_pixels:
+            if self.vision is None:
+                raise ValueError("mask_raw_pixels applies to the e2e configuration (precomputed features are masked by the "
+                                 "object_mask_visual_embedding overwrite, resnet_vlbert_for_pretraining.py:114-117)")
+            ops.mask_image_boxes(self.in_image, self.in_boxes, self.in_mvrc_ops)
 
     # ------------------------------------------------------------------------------------------
     # forward

@@ -561,6 +561,15 @@ def im2col_image(img, col, k=7, stride=2, pad=3):
     return col
 
 
+def mask_image_boxes(image, boxes, mvrc_ops):
+    """image [N,3,H,W] fp32 (in place): zero the pixels of every box whose mvrc_op is 1 (conceptual_captions.py:201-206)."""
+    N, C, H, W = image.shape
+    assert boxes.shape[0] == N and mvrc_ops.shape == boxes.shape[:2] and mvrc_ops.dtype == torch.int64 and image.is_contiguous()
+    assert boxes.stride(2) == 1 and boxes.stride(0) == boxes.shape[1] * boxes.stride(1) and mvrc_ops.is_contiguous()
+    _lib.call("vlb_mask_image_boxes_f32", _p(image, torch.float32), N, C, H, W, _p(boxes, torch.float32), boxes.stride(1), boxes.shape[1],
+              mvrc_ops.data_ptr(), _stream())
+
+
 def maxpool3x3s2_nhwc(x, y, N, H, W, C):
     _lib.call("vlb_maxpool3x3s2_nhwc", _p(x, BF16), _p(y, BF16), N, H, W, C, _stream())
     return y

@@ -214,6 +214,7 @@ def main(argv=None):
             batch[0][:, :, 2] = torch.minimum(batch[0][:, :, 2], torch.full_like(batch[0][:, :, 2], Wi - 1.0))
             batch[0][:, :, 3] = torch.minimum(batch[0][:, :, 3], torch.full_like(batch[0][:, :, 3], Hi - 1.0))
             batch[1][:, 0], batch[1][:, 1] = Wi, Hi
+            kw["mask_raw_pixels"] = bool(config.NETWORK.get("MASK_RAW_PIXELS", True))      # conceptual_captions.py:201-206
         eng.set_batch(*[t.cuda(non_blocking=True) for t in batch], **kw)
 
     accum = r["accumulate"]

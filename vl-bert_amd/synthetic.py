@@ -79,3 +79,45 @@ def make_aux_text(Ba, Ta, vocab_size=30522, seed=0, ragged=True, mlm_prob=0.15):
     labels[pick] = text[pick]
     text[pick] = MASK % vocab_size
     return text, labels
+
+
+def make_vqa_batch(B, R, Lq, seed, device, answers=3129):
+    """One collated VQA micro-batch with precomputed region features (vqa/data/collate_batch.py layout): boxes [B,R,4+2048] (box 0 = the
+    whole image), im_info, question ids [B,Lq], soft answer scores [B,answers]."""
+    g = torch.Generator().manual_seed(seed)
+    Wi, Hi = 1000.0, 600.0
+    x1 = torch.rand(B, R, generator=g) * (Wi - 200)
+    y1 = torch.rand(B, R, generator=g) * (Hi - 200)
+    w = 30 + torch.rand(B, R, generator=g) * 160
+    h = 30 + torch.rand(B, R, generator=g) * 160
+    boxes = torch.cat((torch.stack((x1, y1, x1 + w, y1 + h), -1), torch.randn(B, R, 2048, generator=g).abs()), -1)
+    boxes[:, 0, :4] = torch.tensor([0.0, 0.0, Wi - 1.0, Hi - 1.0])
+    im_info = torch.tensor([[Wi, Hi, 1.0, 1.0]] * B)
+    question = torch.randint(1000, 30522, (B, Lq), generator=g)
+    label = torch.zeros(B, answers)
+    idx = torch.randint(0, answers, (B, 3), generator=g)
+    label.scatter_(1, idx, torch.tensor([[1.0, 0.6, 0.3]] * B))
+    return [t.to(device) for t in (boxes, im_info, question, label)]
+
+
+def make_vcr_batch(B, C, R, Lq, La, Hi, Wi, seed, device):
+    """One collated VCR micro-batch (vcr/data/collate_batch.py layout): image, boxes [B,R,5] (x1,y1,x2,y2,class; box 0 = the whole image),
+    object masks [B,R,14,14], question [B,Lq,2] / answer_choices [B,C,La,2] = (token id, object tag), answer_label [B], im_info."""
+    g = torch.Generator().manual_seed(seed)
+    image = torch.randn(B, 3, Hi, Wi, generator=g) * 50.0
+    x1 = torch.rand(B, R, generator=g) * (Wi - 200)
+    y1 = torch.rand(B, R, generator=g) * (Hi - 200)
+    w = 30 + torch.rand(B, R, generator=g) * 160
+    h = 30 + torch.rand(B, R, generator=g) * 160
+    boxes = torch.stack((x1, y1, x1 + w, y1 + h, torch.randint(1, 81, (B, R), generator=g).float()), -1)
+    boxes[:, 0] = torch.tensor([0.0, 0.0, Wi - 1.0, Hi - 1.0, 0.0])
+    masks = (torch.rand(B, R, 14, 14, generator=g) < 0.7).float()
+    question = torch.zeros((B, Lq, 2), dtype=torch.int64)
+    question[:, :, 0] = torch.randint(1000, 30522, (B, Lq), generator=g)
+    question[:, :, 1] = torch.randint(-1, R, (B, Lq), generator=g)
+    answers = torch.zeros((B, C, La, 2), dtype=torch.int64)
+    answers[..., 0] = torch.randint(1000, 30522, (B, C, La), generator=g)
+    answers[..., 1] = torch.randint(-1, R, (B, C, La), generator=g)
+    label = torch.randint(0, C, (B,), generator=g)
+    im_info = torch.tensor([[Wi, Hi, 1.0, 1.0, float(i)] for i in range(B)])
+    return [t.to(device) for t in (image, boxes, masks, question, answers, label, im_info)]
