@@ -1,6 +1,8 @@
 """VCR fine-tuning wrapper (BASELINE config 5) on the GPU (-m gpu): the `ResNetVLBERT` mirror of
 vcr/modules/resnet_vlbert_for_vcr.py against the fixture produced by the reference's own module and against oracle/vcr_oracle.py, and
 the fused SGD-momentum step (vcr/function/train.py:124-128) against torch.optim.SGD semantics."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -377,3 +379,25 @@ def test_vcr_ablation_switches_run_and_change_what_they_should(flag):
         b2["boxes"] = boxes
         again = net.train_forward(*args(b2))[0]["label_logits"].detach()
         assert torch.equal(again, outputs["label_logits"].detach())
+
+
+def test_finetune_entry_points_run_reference_style_configs():
+    """`python -m vl-bert_amd.vqa.train_end2end` / `vcr.train_end2end` (the reference's vqa/train_end2end.py, vcr/train_end2end.py command
+    lines) on reference-style YAMLs at test size: 3 optimizer steps of 2 accumulated micro-batches each through the module mirrors --
+    VQA: FusedAdamW + triangle schedule + clip 1.0 in bf16; VCR: FusedSGD + warm-up multi-step schedule + clip 10 with TRAIN.FP16 ->
+    the fp16 build and its static loss scale (run in a child process: one build of the library per process)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fx = os.path.join(root, "tests", "fixtures")
+    for task, extra, lr3 in (("vqa", [], 1.0e-5 * 2 * 2 * (2.0 / 3.0)), ("vcr", ["--compute", "cfg"], 7.0e-5 * 2 * 2 * 0.5)):
+        cmd = [sys.executable, "-c", "import importlib,sys; sys.path.insert(0, %r); m = importlib.import_module('vl-bert_amd.%s.train_end2end'); "
+               "net, opt, loss = m.main(%r); import math; assert math.isfinite(loss), loss; print('LR %%.9e LOSS %%.5f' %% (opt.param_groups[0]['lr'], loss))"
+               % (root, task, ["--cfg", os.path.join(fx, task + "_small.yaml"), "--steps", "3"] + extra)]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+        print(r.stdout[-1500:])
+        print(r.stderr[-1500:])
+        assert r.returncode == 0, r.stderr[-1500:]
+        line = next(l for l in r.stdout.splitlines() if l.startswith("LR "))
+        assert abs(float(line.split()[1]) - lr3) < 1e-6 * lr3, (line, lr3)      # the schedule's value at the LAST step run (k = 2)
+        assert "step 3" in r.stdout

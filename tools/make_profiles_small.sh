@@ -5,7 +5,7 @@
 set -u
 ROOT="${GRAFT_REPO_ROOT:-/root/repo}"
 OUT="$ROOT/gpurun_out"
-TAG="${1:-r03}"
+TAG="${1:-r04}"
 cd /tmp && export TMPDIR=/tmp
 mkdir -p "$OUT/summary"
 one() {   # name, steps-in-process, note, command...

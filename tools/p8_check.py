@@ -194,6 +194,24 @@ def bench(batch):
     print("%-36s | " % "NT ms per step (12 layers + decoder fwd)" + " | ".join("%13.2f" % t for t in tot), flush=True)
 
 
+def bench_model(batch):
+    """the step's NT GEMM shapes with the library's OWN selection and current options (environment / VLB_LIB_PATH decide the variant):
+    one column, more iterations -- for A/B runs of compile-time or env-switched variants (tools/gpu_call.sh gemm:<variants>)"""
+    M = batch * 101
+    shapes = [("qkv fwd", M, 2304, 768, "bias"), ("attn-out fwd", M, 768, 768, "dropres"), ("ffn1 fwd", M, 3072, 768, "gelu"),
+              ("ffn2 fwd", M, 768, 3072, "dropres"), ("out dgrad", M, 768, 768, "plain"), ("qkv dgrad", M, 768, 2304, "res"),
+              ("ffn1 dgrad", M, 768, 3072, "res"), ("ffn2 dgrad", M, 3072, 768, "mulaux")]
+    tot = 0.0
+    for rep in range(2):
+        tot = 0.0
+        for name, m, n, k, kwm in shapes:
+            ms, tf = bench_one(m, n, k, kwm, {}, iters=40)
+            tot += ms
+            if rep == 1:
+                print("%-14s %7d %6d %6d | %7.1f us %6.0f TFLOP/s" % (name, m, n, k, ms * 1e3, tf), flush=True)
+    print("NT us per layer (8 GEMMs): %.1f" % (tot * 1e3), flush=True)
+
+
 def bench_wgrad(batch):
     """weight-gradient (TN) shapes of one step: 128x128 TN kernel vs the large-tile core"""
     M = batch * 101
@@ -386,6 +404,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ablate":
         ablate(int(sys.argv[2]) if len(sys.argv) > 2 else 256)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "model":
+        bench_model(int(sys.argv[2]) if len(sys.argv) > 2 else 256)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "check":
         sys.exit(1 if check() else 0)
