@@ -169,12 +169,25 @@ def main():
                 losses[m].append(e.loss_values()["loss"])
         torch.cuda.synchronize()
         sd = {m: e.state_dict() for m, e in engs.items()}          # (a collective in sharded mode: gathers the master)
-        worst = max(float((sd["sharded"][k].float() - sd["allreduce"][k].float()).abs().max()) for k in sd["sharded"])
         lrel = max(abs(a - b) / abs(b) for a, b in zip(losses["sharded"], losses["allreduce"]))
-        print("rank %d: %d steps sharded vs allreduce: losses %s | %s (max rel diff %.2e), parameters max |diff| %.3e" %
-              (rank, steps, ["%.5f" % x for x in losses["sharded"]], ["%.5f" % x for x in losses["allreduce"]], lrel, worst), flush=True)
-        # each AdamW step moves a parameter by ~lr = 1e-3: a stale bias would show up as a difference of that order
-        assert lrel < 5e-4 and worst < 2e-4, (lrel, worst)
+        # Two backward passes of one rank are not bit-identical (fp32 atomics), and AdamW turns a gradient element that is pure rounding
+        # noise into a +-lr step, so single elements may differ by a few lr between ANY two runs: compare the parameter difference with
+        # the distance the parameters MOVED (relative Frobenius), over all tensors and over the fp32-read tensors alone (biases,
+        # LayerNorm gamma / beta: a rank computing with stale ones would make that ratio ~1 -- the round-3 ADVICE bug)
+        e0 = E.PretrainEngine(cfg, B, T, R, device=DEV, train=True, lr=1e-3, seed=7 + rank, dp_mode="allreduce")
+        e0.init_random(seed=0, visual_ln_init=1.0)
+        p0 = e0.state_dict()
+        small = [k for k, t in p0.items() if t.dim() == 1 or k == "object_mask_visual_embedding.weight"]
+
+        def ratio(keys):
+            num = sum(float((sd["sharded"][k].double() - sd["allreduce"][k].double()).pow(2).sum()) for k in keys)
+            den = sum(float((sd["allreduce"][k].double() - p0[k].double()).pow(2).sum()) for k in keys)
+            return (num / max(den, 1e-300)) ** 0.5
+        r_all, r_small = ratio(list(p0)), ratio(small)
+        print("rank %d: %d steps sharded vs allreduce: losses %s | %s (max rel diff %.2e); parameter difference / distance moved: all "
+              "%.3e, fp32-read tensors %.3e" % (rank, steps, ["%.5f" % x for x in losses["sharded"]], ["%.5f" % x for x in losses["allreduce"]],
+                                                 lrel, r_all, r_small), flush=True)
+        assert lrel < 2e-3 and r_all < 0.1 and r_small < 0.1, (lrel, r_all, r_small)
     dist.barrier()
     dist.destroy_process_group()
 

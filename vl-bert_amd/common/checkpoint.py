@@ -86,8 +86,13 @@ def optimizer_state_dict(eng):
             em, ev = em.permute(0, 3, 1, 2).contiguous(), ev.permute(0, 3, 1, 2).contiguous()
         state[i] = {"step": step, "exp_avg": em, "exp_avg_sq": ev}
     lr = float(adam[0])
-    group = {"lr": lr, "betas": (float(adam[1]), float(adam[2])), "eps": float(adam[3]), "weight_decay": float(adam[4]),
-             "correct_bias": True, "params": list(range(len(order)))}
+
+    def exact(dev_value, given):      # the hyper-parameter as the caller gave it (a Python float) while the device copy still is its fp32 image
+        return given if abs(float(dev_value) - given) <= 1e-6 * max(abs(given), 1e-30) else float(dev_value)
+    hy = eng.hyper
+    group = {"lr": exact(adam[0], float(eng.base_lr)) if eng.lr_kind is None else lr,
+             "betas": (exact(adam[1], hy["betas"][0]), exact(adam[2], hy["betas"][1])), "eps": exact(adam[3], hy["eps"]),
+             "weight_decay": exact(adam[4], hy["weight_decay"]), "correct_bias": True, "params": list(range(len(order)))}
     if eng.lr_kind is not None:      # what the reference's LambdaLR scheduler leaves in the group (train.py:283-285 sets it before resuming)
         group["initial_lr"] = float(eng.base_lr)
     return {"state": state, "param_groups": [group], "param_names": order}
@@ -125,6 +130,7 @@ def load_optimizer_state_dict(eng, osd):
         raise ValueError("per-parameter step counts differ (%s): the fused AdamW keeps one counter" % sorted(steps))
     g = osd["param_groups"][0]
     eng.adam[1:5].copy_(torch.tensor([g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"]], dtype=torch.float32))
+    eng.hyper = dict(betas=(float(g["betas"][0]), float(g["betas"][1])), eps=float(g["eps"]), weight_decay=float(g["weight_decay"]))
     eng.adam[5:6].fill_(float(steps.pop()) if steps else 0.0)
     if eng.lr_kind is None:
         eng.adam[0:1].fill_(float(g["lr"]))       # (with a device-side schedule the lr is recomputed from the step counter each step)

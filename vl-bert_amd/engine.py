@@ -262,6 +262,7 @@ class PretrainEngine:
         # seed = RNG_SEED + rank launch onto one dropout stream
         self.seed = torch.tensor([((seed * 2 + 1) & 0x7FFFFFFF)], dtype=torch.int32, device=d)
         self.adam = torch.tensor([lr, betas[0], betas[1], eps, weight_decay, 0.0, max_grad_norm, 0.0], dtype=F32, device=d)
+        self.hyper = dict(betas=(float(betas[0]), float(betas[1])), eps=float(eps), weight_decay=float(weight_decay))   # as given (checkpoints)
         self.sumsq_ws = zf(2048)  # per-block partial sums of the gradient norm
         self.losses = zf(4)       # mlm (with visual content), mvrc, mlm (aux text), relationship
         self.counts = zf(4)       # n_valid mlm, n_valid mvrc, n_valid mlm aux

@@ -107,6 +107,12 @@ class VisionStack:
         # recorded behind its producers, and whoever overwrites one of its inputs first waits for the event recorded behind it
         # (da / db are double-buffered by block parity so that wait is two blocks old).  VLB_VISION_WGRAD_STREAM=0 serialises.
         self.side = torch.cuda.Stream(device=d) if (d.type == "cuda" and os.environ.get("VLB_VISION_WGRAD_STREAM", "1") != "0") else None
+        # Round 4: the three / four weight gradients of a Bottleneck are independent of each other, and each of them is a 100-300-tile
+        # launch (+ its slab reduce) that leaves CUs idle: they rotate over VLB_VISION_WGRAD_STREAMS side streams (default 3), each with
+        # its own split-K slab workspace, so that they overlap each other as well as the data-gradient chain.
+        n_side = max(1, int(os.environ.get("VLB_VISION_WGRAD_STREAMS", "3"))) if self.side is not None else 0
+        self.sides = [self.side] + [torch.cuda.Stream(device=d) for _ in range(n_side - 1)] if self.side is not None else []
+        self._side_rr = 0
         self._pending = {}
         min_train = min(b["stage"] for b in self.blocks if b["stage"] not in self.frozen_stages)
         if any(b["stage"] in self.frozen_stages and b["stage"] > min_train for b in self.blocks):
@@ -198,6 +204,7 @@ class VisionStack:
         self.dfeat32 = None if self.roi_gather else zf(self.M3, self.C3)
         self.roi_ws = ops.roi_align_gather_workspace(self.K, self.H3, self.W3, pooled, d) if self.roi_gather else None
         self.wg_ws = zf(max(max_wg, max_dwf, 4))         # split-K slabs (at least one slab of the largest weight)
+        self.wg_wss = [self.wg_ws] + [zf(self.wg_ws.numel()) for _ in range(len(self.sides) - 1)]       # one per side stream
 
     # ------------------------------------------------------------------------------------------------------------------
     def _dgrad_set(self):
@@ -331,42 +338,46 @@ class VisionStack:
 
     # ------------------------------------------------------------------------------------------------------------------
     def _side_run(self, fn, *reads):
-        """Run fn on the weight-gradient stream after everything enqueued so far; `reads` are the transient buffers it reads."""
+        """Run fn(workspace) on the next weight-gradient stream after everything enqueued so far; `reads` are the transient buffers it
+        reads."""
         if self.side is None:
-            fn()
+            fn(self.wg_ws)
             return
+        i = self._side_rr
+        self._side_rr = (i + 1) % len(self.sides)
+        side = self.sides[i]
         ready = torch.cuda.Event()
         ready.record()
-        with torch.cuda.stream(self.side):
-            self.side.wait_event(ready)
-            fn()
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            fn(self.wg_wss[i])
             done = torch.cuda.Event()
             done.record()
-        for t in reads:
-            self._pending[t.data_ptr()] = done
+        for t in reads:          # a buffer read by several pending weight gradients: the next writer waits for all of them
+            self._pending.setdefault(t.data_ptr(), []).append(done)
 
     def _before_write(self, *bufs):
         for t in bufs:
-            ev = self._pending.pop(t.data_ptr(), None) if t is not None else None
-            if ev is not None:
+            evs = self._pending.pop(t.data_ptr(), None) if t is not None else None
+            for ev in evs or ():
                 torch.cuda.current_stream().wait_event(ev)
 
     def _join_side(self):
-        if self.side is not None:
+        for side in self.sides:
             ev = torch.cuda.Event()
-            ev.record(self.side)
+            ev.record(side)
             torch.cuda.current_stream().wait_event(ev)
-            self._pending.clear()
+        self._pending.clear()
 
     def _wgrad(self, c, dy, x, conv=None):
         """g32 += scale[o] * (dy^T x) for the folded operand; conv = (n, h, w, C, dil): x is the NHWC activation and the im2col
         gather happens inside the TN GEMM."""
-        def run():   # the BatchNorm scale is applied by the split-K slab reduce (no separate finalize pass)
+        def run(ws):   # the BatchNorm scale is applied by the split-K slab reduce (no separate finalize pass)
             if conv is None:
-                ops.wgrad_tn_rowscale(dy, x, c.g32, c.scale, self.wg_ws, accumulate=True)
+                ops.wgrad_tn_rowscale(dy, x, c.g32, c.scale, ws, accumulate=True)
             else:
-                ops.conv3x3_wgrad_tn(dy, x, c.g32, *conv, workspace=self.wg_ws, accumulate=True, rowscale=c.scale)
-        self._side_run(run, dy)
+                ops.conv3x3_wgrad_tn(dy, x, c.g32, *conv, workspace=ws, accumulate=True, rowscale=c.scale)
+        self._side_run(run, dy, x)
 
     def _block_bwd(self, b, dz, dx_out, need_dx, mask_input):
         """dz: masked gradient of this block's pre-ReLU output [M, 4P].  Writes the (masked) gradient of the block input into
