@@ -11,6 +11,7 @@
 #   gemm             tools/p8_check.py bench 256 (per-shape GEMM table, tile heights + model)
 #   small            per-GPU batches 128 / 64 / 32 (strong-scaling columns, no communication)
 #   modes            every secondary bench mode quoted in DESIGN.md §6 (f16, e2e, large, vqa, vqa fp32, vcr f16)
+#   e2e              config 3 eager / --graph / one vs three weight-gradient side streams     | clock   tools/clock_probe.py
 #   dp2              bench.py --gpus 2 on this box (2 ranks sharing the GPU over gloo; over RCCL where the box has 2 GPUs)
 #   trace            rocprofv3 --kernel-trace --stats of the headline workload -> kernel table (tools/kstats.py)
 #   profiles[:tag]   tools/make_profiles.sh (kernel stats, SQ PMC, FETCH / WRITE passes; summaries in gpurun_out/summary)
@@ -48,6 +49,11 @@ for what in "$@"; do
               run large_f16 --large --precision f16 --no-cpu-baseline; run vqa --vqa --steps 5 --warmup 2 --no-cpu-baseline
               run vqa_fp32 --vqa --precision fp32 --steps 3 --warmup 1 --no-cpu-baseline; run vcr_f16 --vcr --precision f16 --steps 3 --warmup 1 --no-cpu-baseline
               run vcr --vcr --steps 3 --warmup 1 --no-cpu-baseline ;;
+    e2e)      for v in "" "--graph" ; do timeout 400 python bench.py --e2e --no-cpu-baseline --no-phase-times $v 2>/dev/null | line "e2e $v"; done | tee $OUT/e2e.log
+              VLB_VISION_WGRAD_STREAMS=1 timeout 400 python bench.py --e2e --no-cpu-baseline --no-phase-times 2>/dev/null | line "e2e 1 side stream" | tee -a $OUT/e2e.log
+              VLB_VISION_WGRAD_STREAMS=1 timeout 400 python bench.py --e2e --no-cpu-baseline --no-phase-times --graph 2>/dev/null | line "e2e 1 side stream --graph" | tee -a $OUT/e2e.log ;;
+    clock)    timeout 300 python tools/clock_probe.py 4 2>&1 | grep -v amdgpu.ids | tee $OUT/clock_probe.txt ;;
+    graphsmall) for b in 64 32; do timeout 300 python bench.py --no-cpu-baseline --global-batch $b --no-phase-times --graph 2>/dev/null | line "batch $b --graph"; done | tee $OUT/graphsmall.log ;;
     dp2)      timeout 600 python bench.py --gpus 2 --no-cpu-baseline --steps 10 > $OUT/dp2.json 2> $OUT/dp2.err; cut -c1-1500 $OUT/dp2.json; grep -v Gloo $OUT/dp2.err | tail -3
               python -c "import json; d=json.load(open('$OUT/dp2.json')); print('comm', d.get('comm'))" ;;
     trace)    ( cd /tmp && export TMPDIR=/tmp && VLB_WGRAD_STREAM=0 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/tr -o r -- python $ROOT/bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-phase-times > $OUT/tr.log 2>&1 )

@@ -37,9 +37,6 @@
 
 #include "gemm_params.h"
 
-#ifndef VLB_P8_PP
-#define VLB_P8_PP 0          // 1: ping-pong schedule of the K loop (one barrier per phase, per-phase counted waits)
-#endif
 #ifndef VLB_P8_SIDE_DEPTH
 #define VLB_P8_SIDE_DEPTH 1  // units of lead of the aux loads in the wave-private drain (EPI 2 / 10)
 #endif
@@ -473,9 +470,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(const GemmParams p) 
   // loads of the NEXT K tile that may still be in flight when the current one is retired: its A0 half-image + one B half-image,
   // counted for the waves that issue the fewest (the waves with one more in flight merely wait for their oldest a little early)
   constexpr int VM_AHEAD = (AH * 8) / 512 + 2;
-  // ping-pong schedule: loads of the three youngest half-images, counted for the waves and the phase that have the fewest: two A
-  // half-images ((AH * 8) / 512 loads each on the waves that issue the fewest) + one B half-image (2 loads)
-  constexpr int VM_3H = 2 * ((AH * 8) / 512) + 2;      // (the youngest three always hold at most one B pair more than two A half-images)
   static_assert(SR == 32 || SR == 16, "staging slab");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -640,95 +634,62 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(const GemmParams p) 
       for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     for (int kt = 0; kt < nk; kt += 2, g += 2) {
-      // P8_BAR_L / P8_BAR_C: the barriers behind a LOAD / a COMPUTE segment; P8_WAIT_L: the counted wait that ends every LOAD segment
-      // (ping-pong schedule only); P8_WAIT_TILE(n): the once-per-K-tile wait of the lock-step schedule.
-#if VLB_P8_PP
-      // Ping-pong schedule (round 4): ONE barrier per phase.  The wm = 0 waves take only the barrier behind their LOAD segment, the
-      // wm = 1 waves (one barrier behind, as before) only the one behind their COMPUTE segment, so a barrier interval is
-      // {COMPUTE(p), LOAD(p+1)} for wm = 0 and {LOAD(p), COMPUTE(p)} for wm = 1: on every SIMD one wave multiplies while its partner
-      // reads fragments / issues DMA, and they swap roles in mid-interval WITHOUT meeting at a barrier (half the barriers of the
-      // lock-step schedule, no wave parked waiting for the slower role).  Soundness: a half-image staged in LOAD(s) is first read
-      // in LOAD(s + 5) or later and last read in LOAD(s - 2) or earlier (same table as before); the wm = 1 waves run their LOAD(p)
-      // one interval after the wm = 0 waves, which costs one interval on either side, so every wave must have retired the DMA of
-      // a half-image by ITS LOAD(s + 3): each LOAD segment ends with vmcnt(3 half-images) -- the three youngest stay in flight --
-      // instead of one wait per K tile; re-staging keeps its two-phase distance: LOAD(s - 2) of wm = 1 and LOAD(s) of wm = 0 are
-      // separated by the barrier that ends interval s - 2.
-#define P8_BAR_L() do { if (wm == 0) p8_barrier(); } while (0)
-#define P8_BAR_C() do { if (wm == 1) p8_barrier(); } while (0)
-#define P8_WAIT_L() do { if (live) __builtin_amdgcn_s_waitcnt(0x0F70 | VM_3H); else __builtin_amdgcn_s_waitcnt(0x0F70); } while (0)
-#define P8_WAIT_TILE(n) ((void)0)
-#else
-#define P8_BAR_L() p8_barrier()
-#define P8_BAR_C() p8_barrier()
-#define P8_WAIT_L() ((void)0)
-#define P8_WAIT_TILE(n) do { if (tiles_issued >= g + (n)) __builtin_amdgcn_s_waitcnt(0x0F70 | VM_AHEAD); else __builtin_amdgcn_s_waitcnt(0x0F70); } while (0)
-#endif
       // ======== K tile g (buffer 0) ========
       // phase 1: A0 + B0 -> quadrant (0,0)
       if constexpr (KEEPB) read_b(I0{}, I0{}, bkeep); else read_b(I0{}, I0{}, bfr);
       __builtin_amdgcn_sched_barrier(0);
       read_a(I0{}, I0{});
       stage(W2{}, I1{});
-      P8_WAIT_L();
-      P8_BAR_L();
+      p8_barrier();
       if constexpr (KEEPB) compute(I0{}, I0{}, bkeep); else compute(I0{}, I0{}, bfr);
-      P8_BAR_C();
+      p8_barrier();
       // phase 2: B1 -> (0,1)
       read_b(I0{}, I1{}, bfr);
       stage(W3{}, I1{});
-      P8_WAIT_L();
-      P8_BAR_L();
+      p8_barrier();
       compute(I0{}, I1{}, bfr);
-      P8_BAR_C();
+      p8_barrier();
       // phase 3: A1 -> (1,1)
       read_a(I0{}, I1{});
       advance();
       stage(W0{}, I0{});
-      P8_WAIT_L();
-      P8_BAR_L();
+      p8_barrier();
       compute(I1{}, I1{}, bfr);
-      P8_BAR_C();
+      p8_barrier();
       // phase 4: (B0 again) -> (1,0); K tile g+1 retired
       if constexpr (!KEEPB) read_b(I0{}, I0{}, bfr);
       stage(W1{}, I0{});
-      P8_WAIT_TILE(3);
-      P8_WAIT_L();
-      P8_BAR_L();
+      if (tiles_issued >= g + 3) __builtin_amdgcn_s_waitcnt(0x0F70 | VM_AHEAD);
+      else __builtin_amdgcn_s_waitcnt(0x0F70);
+      p8_barrier();
       if constexpr (KEEPB) compute(I1{}, I0{}, bkeep); else compute(I1{}, I0{}, bfr);
-      P8_BAR_C();
+      p8_barrier();
       // ======== K tile g+1 (buffer 1) ========
       if constexpr (KEEPB) read_b(I1{}, I0{}, bkeep); else read_b(I1{}, I0{}, bfr);
       __builtin_amdgcn_sched_barrier(0);
       read_a(I1{}, I0{});
       stage(W2{}, I0{});
-      P8_WAIT_L();
-      P8_BAR_L();
+      p8_barrier();
       if constexpr (KEEPB) compute(I0{}, I0{}, bkeep); else compute(I0{}, I0{}, bfr);
-      P8_BAR_C();
+      p8_barrier();
       read_b(I1{}, I1{}, bfr);
       stage(W3{}, I0{});
-      P8_WAIT_L();
-      P8_BAR_L();
+      p8_barrier();
       compute(I0{}, I1{}, bfr);
-      P8_BAR_C();
+      p8_barrier();
       read_a(I1{}, I1{});
       advance();
       stage(W0{}, I1{});
-      P8_WAIT_L();
-      P8_BAR_L();
+      p8_barrier();
       compute(I1{}, I1{}, bfr);
-      P8_BAR_C();
+      p8_barrier();
       if constexpr (!KEEPB) read_b(I1{}, I0{}, bfr);
       stage(W1{}, I1{});
-      P8_WAIT_TILE(4);
-      P8_WAIT_L();
-      P8_BAR_L();
+      if (tiles_issued >= g + 4) __builtin_amdgcn_s_waitcnt(0x0F70 | VM_AHEAD);
+      else __builtin_amdgcn_s_waitcnt(0x0F70);
+      p8_barrier();
       if constexpr (KEEPB) compute(I1{}, I0{}, bkeep); else compute(I1{}, I0{}, bfr);
-      P8_BAR_C();
-#undef P8_BAR_L
-#undef P8_BAR_C
-#undef P8_WAIT_L
-#undef P8_WAIT_TILE
+      p8_barrier();
     }
     if (wm == 0) p8_barrier();     // let the lagging wave group finish its last quadrant: the epilogue runs aligned
 
