@@ -54,8 +54,8 @@ for what in "$@"; do
               VLB_VISION_WGRAD_STREAMS=1 timeout 400 python bench.py --e2e --no-cpu-baseline --no-phase-times --graph 2>/dev/null | line "e2e 1 side stream --graph" | tee -a $OUT/e2e.log ;;
     clock)    timeout 300 python tools/clock_probe.py 4 2>&1 | grep -v amdgpu.ids | tee $OUT/clock_probe.txt ;;
     graphsmall) for b in 64 32; do timeout 300 python bench.py --no-cpu-baseline --global-batch $b --no-phase-times --graph 2>/dev/null | line "batch $b --graph"; done | tee $OUT/graphsmall.log ;;
-    dp2)      timeout 600 python bench.py --gpus 2 --no-cpu-baseline --steps 10 > $OUT/dp2.json 2> $OUT/dp2.err; cut -c1-1500 $OUT/dp2.json; grep -v Gloo $OUT/dp2.err | tail -3
-              python -c "import json; d=json.load(open('$OUT/dp2.json')); print('comm', d.get('comm'))" ;;
+    dp2)      timeout 600 python bench.py --gpus 2 --no-cpu-baseline --steps 10 > $OUT/dp2.json 2> $OUT/dp2.err; grep '^{' $OUT/dp2.json | cut -c1-1200; grep -v Gloo $OUT/dp2.err | tail -3
+              grep -o '"comm": {[^}]*}' $OUT/dp2.json ;;
     trace)    ( cd /tmp && export TMPDIR=/tmp && VLB_WGRAD_STREAM=0 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/tr -o r -- python $ROOT/bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-phase-times > $OUT/tr.log 2>&1 )
               python tools/kstats.py $OUT/tr 5 24 | tee $OUT/kstats.txt; rm -rf $OUT/tr ;;
     profiles*) t="${what#profiles}"; t="${t#:}"; VLB_COMMIT=$(cat $ROOT/.commit_stamp 2>/dev/null || echo unknown) timeout 1500 bash tools/make_profiles.sh "${t:-r04}"; ls $ROOT/gpurun_out/summary ;;
