@@ -339,6 +339,17 @@ int vlb_wgrad_tn_group_bf16(int n, const void* const* A, const long* lda, const 
                             long workspace_floats, int accumulate, vlb_stream_t stream);
 int vlb_wgrad_tn_rowscale_bf16(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int R, int Mo, int No,
                                const float* rowscale, float* workspace, long workspace_floats, int accumulate, vlb_stream_t stream);
+/* Table-driven weight gradients (round 4): n products  C_i[Mo_i, No_i] (+)= rowscale_i[m] * (A_i[R_i, Mo_i]^T B_i[R_i, No_i])  (+ colsum_i),
+ * each with its own row count R_i (a multiple of 128, >= 256; operands zero-padded to it), as ONE launch of full-K 256 x 256 work
+ * items on the large-tile core: no K slices, no slabs, no reduce pass.  The descriptor table is built once on the HOST for a fixed
+ * set of device buffers (_pack: returns the number of work items, 0 when a product is outside what the kernel covers), copied to the
+ * device by the caller and replayed every step (_launch).  Replaces the per-convolution dW = dY^T X products of autograd in a ResNet
+ * stage (common/backbone/resnet/resnet.py:98-118) -- vision.VisionStack defers the 1x1-convolution gradients of a stage into one. */
+long vlb_wgrad_tn_table_desc_bytes(void);
+int vlb_wgrad_tn_table_pack(int n, const void* const* A, const long* lda, const void* const* B, const long* ldb, float* const* C,
+                            const long* ldc, const int* R, const int* Mo, const int* No, float* const* colsum,
+                            const float* const* rowscale, int accumulate, void* host_out, long host_bytes);
+int vlb_wgrad_tn_table_launch(const void* desc_dev, int n, int nitems, vlb_stream_t stream);
 int vlb_im2col_nhwc_bf16(const void* x, void* col, long ldcol, int N, int H, int W, int C, int KH, int KW, int stride,
                          int pad, int dil, vlb_stream_t stream);
 /* stem (resnet.py:137-141): fp32 NCHW image -> [N*OH*OW, ldcol] bf16, column (ky*KW+kx)*Cin + c, zero padded to ldcol */

@@ -534,6 +534,46 @@ def test_wgrad_tn_grouped_layer_uneven_cut(ops, R):
         report("grouped wgrad %d uneven vs equal cut" % k, got[1][k][2], got[0][k][2].cpu(), 1e-3, 2e-4)
 
 
+@pytest.mark.parametrize("accumulate", [True, False])
+def test_wgrad_tn_table_many_products_one_launch(ops, accumulate):
+    """vlb_wgrad_tn_table_*: weight gradients with DIFFERENT row counts, ragged output shapes (Mo / No below, at and beyond one
+    256 x 256 tile, not multiples of 8 allowed only where the leading dimension still is), per-output-row scale (the frozen-BatchNorm
+    fold of the vision path), optional column sums, accumulate / overwrite -- one launch, against fp32 torch on the same bf16 operands.
+    A product whose row count is not a multiple of 128 makes the table refuse (ok = False) instead of computing garbage."""
+    specs = [(19200, 256, 1024, True, False), (19200, 1024, 256, True, True), (384, 40, 264, False, True), (1280, 520, 72, True, False),
+             (2560, 256, 512, False, False)]          # (R, Mo, No, rowscale?, colsum?)
+    items, refs = [], []
+    for k, (R, Mo, No, with_rs, with_cs) in enumerate(specs):
+        g = torch.Generator().manual_seed(900 + k)
+        valid = R - (48 if k < 2 else 0)                # the vision path's operands: M = 19152 rows + zero rows up to 19200
+        dY = bf(torch.randn((R, Mo), generator=g) * 0.5)
+        X = bf(torch.randn((R, No), generator=g) * 0.2)
+        dY[valid:] = 0
+        X[valid:] = 0
+        base = torch.randn((Mo, No), generator=g)
+        C = base.clone().to(dev())
+        rs = (0.5 + torch.rand(Mo, generator=g)) if with_rs else None
+        cs = torch.ones(Mo, dtype=torch.float32, device=dev()) if with_cs else None
+        items.append((to_gpu_bf16(dY), to_gpu_bf16(X), C, cs, rs.to(dev()) if with_rs else None))
+        prod = dY.t() @ X
+        if with_rs:
+            prod = prod * rs[:, None]
+        refs.append(((base if accumulate else 0) + prod, (1 + dY.sum(0)) if with_cs else None))
+    tab = ops.WgradTable(items, dev(), accumulate=accumulate)
+    assert tab.ok and tab.n == len(specs) and tab.nitems == 4 + 4 + 2 + 3 + 2
+    tab.run()
+    tab.run() if accumulate is False else None          # overwrite mode is idempotent
+    torch.cuda.synchronize()
+    for k, ((_, _, C, cs, _), (rc, rb)) in enumerate(zip(items, refs)):
+        report("table wgrad %d R=%d %dx%d" % (k, specs[k][0], specs[k][1], specs[k][2]), C, rc, 2e-3, 2e-4)
+        if cs is not None:
+            report("table wgrad %d colsum" % k, cs, (rb if accumulate else 1 + 2 * (rb - 1)), 1e-3, 2e-4)
+    bad = ops.WgradTable([(items[2][0][:300], items[2][1][:300], items[2][2], None, None)], dev())
+    assert not bad.ok
+    with pytest.raises(RuntimeError):
+        bad.run()
+
+
 def test_gemm_dropout_and_ln_mask_agree(ops):
     """The GEMM-epilogue dropout mask and the LayerNorm-backward dx_drop mask are the same function."""
     M, N, K = 200, 256, 64

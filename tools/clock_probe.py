@@ -103,6 +103,23 @@ def main():
     if clk:
         print("   -> %.0f TFLOP/s incl. launch gaps = %.3f of the 2.5 PFLOP/s boost-clock peak, %.3f of the peak at the sustained %.0f MHz"
               % (tf, tf / 2500.0, tf / (2500.0 * clk / 2400.0), clk))
+    # in-kernel evidence, independent of what sysfs reports: every workgroup of the large-tile kernel stamps the shader-clock counter
+    # (s_memtime) and the constant 100 MHz real-time counter (s_memrealtime) at entry and exit (p8_ablate = 4, table passed as `pre`)
+    lib = importlib.import_module("vl-bert_amd._lib")
+    table = torch.zeros((256, 16), dtype=torch.bfloat16, device=D)           # 256 workgroups x 4 x int64 (a 2-D bf16 view: the `pre` argument)
+    for _ in range(200):                                                      # bring the device to its sustained state first
+        ops.gemm_nt(A, B, C, bias=bias)
+    lib.gemm_set_option("p8_ablate", 4)
+    ops.gemm_nt(A, B, C, bias=bias, pre=table)
+    lib.gemm_set_option("p8_ablate", 0)
+    torch.cuda.synchronize()
+    t = table.view(torch.int64).view(256, 4).cpu()
+    t = t[t[:, 3] > 0]
+    if t.numel():
+        cyc, rt = (t[:, 2] - t[:, 0]).double(), (t[:, 3] - t[:, 1]).double()
+        mhz = cyc / rt * 100.0
+        print("in-kernel (FFN2 shape, %d workgroups): kernel residency %.1f us, effective shader clock = d(s_memtime) / d(s_memrealtime) x 100 MHz: "
+              "min %.0f median %.0f max %.0f MHz" % (t.shape[0], float(rt.median()) / 100.0, float(mhz.min()), float(mhz.median()), float(mhz.max())), flush=True)
     A2 = (torch.rand((8192, 8192), generator=g) * 2 - 1).to(torch.bfloat16).to(D)
     C2 = torch.empty((8192, 8192), dtype=torch.bfloat16, device=D)
     n, el, clk = sample_while(lambda: ops.gemm_nt(A2, A2, C2), secs, "p8 GEMM 8192^3")

@@ -37,6 +37,8 @@ _SIGS = {
     "vlb_wgrad_nt_bf16": "plplpliiipls",
     "vlb_wgrad_tn_bf16": "plplpliiipplis",
     "vlb_wgrad_tn_group_bf16": "ippppppipppplis",
+    "vlb_wgrad_tn_table_launch": "piis",
+    "vlb_wgrad_tn_table_pack": "i" + "p" * 11 + "ipl",      # (returns the item count: called directly, not through call())
     "vlb_zero_ranges_f32": "pppiis",
     "vlb_copy_ranges_f32": "ppppiis",
     "vlb_layernorm_fwd": "plppplpiifis",
@@ -146,6 +148,8 @@ def load():
     lib.vlb_layernorm_bwd_workspace_floats.argtypes = [_I]
     lib.vlb_layernorm_bwd_slabs.restype = _I
     lib.vlb_layernorm_bwd_slabs.argtypes = [_I]
+    lib.vlb_wgrad_tn_table_desc_bytes.restype = _L
+    lib.vlb_wgrad_tn_table_desc_bytes.argtypes = []
     lib.vlb_gemm_set_option.restype = _I
     lib.vlb_gemm_set_option.argtypes = [ctypes.c_char_p, _I]
     lib.vlb_nonfinite_status.restype = _I
@@ -182,7 +186,7 @@ def act_torch_dtype():
 def exported_names():
     return ["vlb_last_error", "vlb_version", "vlb_act_dtype", "vlb_device_info", "vlb_wgrad_workspace_floats",
             "vlb_layernorm_bwd_workspace_floats", "vlb_layernorm_bwd_slabs", "vlb_gemm_set_option",
-            "vlb_roi_align_gather_workspace_bytes", "vlb_nonfinite_status"] + sorted(_SIGS)
+            "vlb_roi_align_gather_workspace_bytes", "vlb_nonfinite_status", "vlb_wgrad_tn_table_desc_bytes"] + sorted(_SIGS)
 
 
 def nonfinite_status(reset=True):

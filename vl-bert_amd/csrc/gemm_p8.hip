@@ -479,6 +479,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(const GemmParams p) 
   const int nt = p.ntm * p.ntn;
   const int nk = p.K >> 6;                      // K tiles per output tile (even: K % 128 == 0)
   if ((int)blockIdx.x >= nt) return;
+  // (measurement ablation 4, tools/clock_probe.py: workgroup b leaves {shader-clock counter, 100 MHz real-time counter} at entry and at
+  // exit in the int64 table the caller passes through `pre` -- the effective shader clock UNDER this kernel = d(cycles) / d(real time))
+  if (p.ablate == 4 && tid == 0 && p.pre) {
+    unsigned long long* t = (unsigned long long*)p.pre + 4 * blockIdx.x;
+    t[0] = __builtin_readcyclecounter();
+    t[1] = __builtin_amdgcn_s_memrealtime();
+  }
 
   auto tile_of = [&](int w, int& m0, int& n0) {   // XCD-aware grouped order (see gemm_nt_bf16_kernel)
     const int xcd = w & 7, q = nt >> 3, r = nt & 7;
@@ -723,6 +730,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(const GemmParams p) 
     p8_barrier();
     if (wm == 1 && w + (int)gridDim.x < nt) p8_barrier();   // re-establish the one-segment lag for the next output tile
   }
+  if (p.ablate == 4 && tid == 0 && p.pre) {
+    unsigned long long* t = (unsigned long long*)p.pre + 4 * blockIdx.x;
+    t[2] = __builtin_readcyclecounter();
+    t[3] = __builtin_amdgcn_s_memrealtime();
+  }
 }
 
 static int g_p8_wgs = 256;
@@ -779,7 +791,8 @@ inline bool aligned16(const void* q) { return ((uintptr_t)q & 15) == 0; }
 // p8_mode: 0 off | 1 cost model (default) | 3 / 4 / 5: force the 192- / 256- / 320-row tile wherever the kernel applies
 // p8_wgs: persistent workgroups per launch (<= 256 = one per CU).  Fewer leave CUs to a kernel running on another stream (the
 // weight-gradient GEMMs of the side stream): an MFMA-bound kernel then fills the HBM-bound epilogue bursts of this one.
-// p8_ablate (tools/p8_check.py ablate; results are WRONG when != 0): 1 no epilogue | 2 epilogue without its global stores
+// p8_ablate (tools/p8_check.py ablate; results are WRONG when != 0): 1 no epilogue | 2 epilogue without its global stores | 4 (results
+// correct) per-workgroup clock stamps into the table passed as `pre` (tools/clock_probe.py)
 static int g_opt[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
 static const char* const g_opt_name[8] = {"p8_mode", "p8_keepb", "p8_group", "p8_min_tiles", "p8_wgs", "p8_ablate", "p8_tile192", "p8_drain"};
 static void p8_options_init() {

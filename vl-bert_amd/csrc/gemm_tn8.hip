@@ -62,6 +62,7 @@ struct Tn8Desc {
   int item0, nitems;                    // position in the launch's item list
   int short0;                           // uneven mode: position of this gradient's remainder slices in the short list
   int accumulate;                       // direct output (nsplit == 1): C += instead of C =
+  const float* rowscale;                // direct output: row m of the product is multiplied by rowscale[m] first (frozen-BN fold), or null
 };
 constexpr int TN8_MAX_GROUP = 4;
 // Uneven mode (nlong > 0): with T tiles and 2 T <= 256 < 3 T, two equal K slices leave 256 - 2 T CUs idle (216 items for 256 CUs at
@@ -76,7 +77,16 @@ struct Tn8Group {
   int nlong;
 };
 
-__global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(const Tn8Group grp) {
+// TABLE = false: up to TN8_MAX_GROUP descriptors travel in the kernel argument (the encoder's per-layer group).  TABLE = true (round 4):
+// any number of descriptors in a device table `tab` (grp.n / grp.nitems valid, grp.d unused) -- the deferred weight gradients of a
+// whole ResNet stage (vision.py): ~46 small products that would each be a 100-300-tile launch + a slab reduce become one launch of
+// full-K 256 x 256 items; the descriptor of an item is found by binary search over item0.
+template <bool TABLE>
+__global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(const Tn8Group grp, const Tn8Desc* __restrict__ tab) {
+  auto D = [&](int gi) -> Tn8Desc {
+    if constexpr (TABLE) return tab[gi];
+    else return grp.d[gi];
+  };
   constexpr int HB = 64 * 256;                  // bytes of a half-image: 64 reduction rows x 128 columns
   constexpr int OFF_A0 = 0, OFF_A1 = HB, OFF_B0 = 2 * HB, OFF_B1 = 3 * HB;
   constexpr int BUF = 4 * HB;                   // one K tile = 64 KiB
@@ -111,14 +121,24 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(const Tn8Group grp) {
       t = vs - grp.d[gi].short0;
     } else {
       w = xcd_order(w, nlong > 0 ? nlong : nitems);
+      if constexpr (TABLE) {
+        int lo = 0, hi = grp.n;
+        while (hi - lo > 1) {
+          const int mid = (lo + hi) >> 1;
+          if (w >= tab[mid].item0) lo = mid; else hi = mid;
+        }
+        gi = lo;
+      } else {
 #pragma unroll
-      for (int q = 1; q < TN8_MAX_GROUP; ++q)
-        if (q < grp.n && w >= grp.d[q].item0) gi = q;
-      const int wl = w - grp.d[gi].item0, ntile = grp.d[gi].ntm * grp.d[gi].ntn;
+        for (int q = 1; q < TN8_MAX_GROUP; ++q)
+          if (q < grp.n && w >= grp.d[q].item0) gi = q;
+      }
+      const Tn8Desc dd = D(gi);
+      const int wl = w - dd.item0, ntile = dd.ntm * dd.ntn;
       sp = wl / ntile;
       t = wl - sp * ntile;
     }
-    const Tn8Desc& d = grp.d[gi];
+    const Tn8Desc d = D(gi);
     const int gm = d.tile_group, per_group = gm * d.ntn, gid = t / per_group, first = gid * gm;
     const int gsz = min(d.ntm - first, gm), rem = t - gid * per_group;
     m0 = (first + rem % gsz) * 256;
@@ -143,7 +163,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(const Tn8Group grp) {
   auto setup = [&](int w) {
     int gi;
     item_of(w, gi, pm0, pn0, kt0_p, nk_p);
-    const Tn8Desc& d = grp.d[gi];
+    const Tn8Desc d = D(gi);
     rsA = __builtin_amdgcn_make_buffer_rsrc((void*)d.A, 0, 0x7FFFFFFF, 0x00020000);
     rsB = __builtin_amdgcn_make_buffer_rsrc((void*)d.B, 0, 0x7FFFFFFF, 0x00020000);
     ldaB = d.lda * 2; ldbB = d.ldb * 2;
@@ -279,7 +299,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(const Tn8Group grp) {
   for (int w = blockIdx.x; w < nitems; w = (step >= (1 << 30)) ? nitems : w + step) {
     int gi, m0, n0, kt0, nk;
     item_of(w, gi, m0, n0, kt0, nk);
-    float* const colsum = grp.d[gi].colsum;
+    float* const colsum = D(gi).colsum;
     do_colsum = (colsum != nullptr) && (n0 == 0) && (wn == 0);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -344,22 +364,25 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(const Tn8Group grp) {
     // ---------------- epilogue: fp32 fragments straight to the slab slice / C (16 B per lane) ----------------
     // (no LDS involved: the operand stream of the next item keeps landing; the wave groups need no re-alignment)
     {
-      const Tn8Desc& d = grp.d[gi];
+      const Tn8Desc d = D(gi);
       const int sp = kt0 / d.kt_per_split;      // kt0 = slice x kt_per_split in both item lists
       float* const C = d.C + (long)sp * d.c_split_stride;
       const bool accum = d.accumulate != 0;
       const int Mo = d.Mo, No = d.No;
       const long ldc = d.ldc;
+      const float* const rowscale = d.rowscale;
 #pragma unroll
       for (int R_ = 0; R_ < 8; ++R_) {
         const int m = m0 + (R_ >> 2) * 128 + wm * 64 + (R_ & 3) * 16 + L;
         if (m >= Mo) continue;
+        const float rs = rowscale ? rowscale[m] : 1.0f;
 #pragma unroll
         for (int cj = 0; cj < 4; ++cj) {
           const int n = n0 + (cj >> 1) * 128 + wn * 32 + (cj & 1) * 16 + 4 * g;
           if (n >= No) continue;
           float* c = C + (long)m * ldc + n;
-          const f32x4 v = acc[R_][cj];
+          f32x4 v = acc[R_][cj];
+          if (rowscale) v = (f32x4){v[0] * rs, v[1] * rs, v[2] * rs, v[3] * rs};
           if (n + 3 < No) {
             float4 o4 = make_float4(v[0], v[1], v[2], v[3]);
             if (accum) {
@@ -380,7 +403,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(const Tn8Group grp) {
           v += __shfl_xor(v, 16, 64);
           v += __shfl_xor(v, 32, 64);
           const int m = m0 + (R_ >> 2) * 128 + wm * 64 + (R_ & 3) * 16 + L;
-          if (g == 0 && m < grp.d[gi].Mo) atomicAdd(colsum + m, v);
+          if (g == 0 && m < D(gi).Mo) atomicAdd(colsum + m, v);
         }
       }
     }
@@ -435,11 +458,12 @@ static int tile_group_for(int ntm, int ntn) {
   return gm < 1 ? 1 : gm;
 }
 
-static int tn8_launch(Tn8Group& grp, hipStream_t stream) {
+template <bool TABLE>
+static int tn8_launch_t(Tn8Group& grp, const Tn8Desc* tab, hipStream_t stream) {
   constexpr int smem = 131072;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_tn8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_tn8_kernel<TABLE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) {
       vlb_set_error("gemm_tn8: cannot reserve %d bytes of LDS: %s", smem, hipGetErrorString(e));
       return VLB_ERR_HIP;
@@ -449,10 +473,12 @@ static int tn8_launch(Tn8Group& grp, hipStream_t stream) {
   if (g_tn8_wgs < 0) g_tn8_wgs = env_int("VLB_GEMM_TN8_WGS", 256);
   const int cap = (g_tn8_wgs >= 8 && g_tn8_wgs <= 256) ? g_tn8_wgs : 256;
   const int gx = grp.nitems > cap ? cap : grp.nitems;
-  hipLaunchKernelGGL(gemm_tn8_kernel, dim3(gx), dim3(512), smem, stream, grp);
+  hipLaunchKernelGGL(gemm_tn8_kernel<TABLE>, dim3(gx), dim3(512), smem, stream, grp, tab);
   VLB_CHECK_LAUNCH("vlb_wgrad_tn_bf16(tn8)");
   return VLB_OK;
 }
+
+static int tn8_launch(Tn8Group& grp, hipStream_t stream) { return tn8_launch_t<false>(grp, nullptr, stream); }
 
 static bool tn8_shape_ok(long lda, long ldb, long ldc, int R) {
   if ((R % 128) != 0 || R < 256) return false;
@@ -563,4 +589,47 @@ int vlb_gemm_tn8_group(int n, const void* const* A, const long* lda, const void*
   grp.n = n; grp.nitems = item;
   const int rc = tn8_launch(grp, stream);
   return rc < 0 ? rc : 1;
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Table-driven form (round 4): n weight gradients  C[i] (+)= rowscale[i] . (A[i]^T B[i])  with their own row counts, in ONE launch of
+// full-K 256 x 256 items (no K slices, no slabs, no reduce pass).  The descriptor table is built once on the host for a fixed set of
+// buffers (vlb_wgrad_tn_table_pack), uploaded by the caller, and replayed every step (vlb_wgrad_tn_table_launch).
+// Replaces the per-convolution `dW = dY^T X` products of torch's autograd in the ResNet stages (common/backbone/resnet/resnet.py:98-118).
+extern "C" long vlb_wgrad_tn_table_desc_bytes(void) { return (long)sizeof(Tn8Desc); }
+
+// host_out: n * vlb_wgrad_tn_table_desc_bytes() bytes.  Returns the number of work items (> 0), 0 when a product is outside what the
+// kernel covers (R % 128, R < 256, unaligned leading dimensions), < 0 on error.
+extern "C" int vlb_wgrad_tn_table_pack(int n, const void* const* A, const long* lda, const void* const* B, const long* ldb, float* const* C,
+                                       const long* ldc, const int* R, const int* Mo, const int* No, float* const* colsum,
+                                       const float* const* rowscale, int accumulate, void* host_out, long host_bytes) {
+  VLB_CHECK_ARG(n >= 1 && A && B && C && lda && ldb && ldc && R && Mo && No && host_out, "vlb_wgrad_tn_table_pack: null argument");
+  VLB_CHECK_ARG(host_bytes >= (long)n * (long)sizeof(Tn8Desc), "vlb_wgrad_tn_table_pack: output buffer too small");
+  Tn8Desc* out = (Tn8Desc*)host_out;
+  int item = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!A[i] || !B[i] || !C[i] || Mo[i] < 1 || No[i] < 1) {
+      vlb_set_error("vlb_wgrad_tn_table_pack: bad product %d", i);
+      return VLB_ERR_ARG;
+    }
+    if (!tn8_shape_ok(lda[i], ldb[i], ldc[i], R[i])) return 0;
+    Tn8Desc d = {};
+    d.A = (const bf16_t*)A[i]; d.B = (const bf16_t*)B[i]; d.C = C[i]; d.colsum = colsum ? colsum[i] : nullptr;
+    d.rowscale = rowscale ? rowscale[i] : nullptr;
+    d.lda = (int)lda[i]; d.ldb = (int)ldb[i]; d.ldc = (int)ldc[i]; d.Mo = Mo[i]; d.No = No[i]; d.R = R[i];
+    d.ntm = vlb_cdiv(Mo[i], 256); d.ntn = vlb_cdiv(No[i], 256); d.tile_group = tile_group_for(d.ntm, d.ntn);
+    d.nsplit = 1; d.kt_per_split = R[i] / 64; d.c_split_stride = 0; d.accumulate = accumulate ? 1 : 0;
+    d.item0 = item; d.nitems = d.ntm * d.ntn; d.short0 = 0;
+    item += d.nitems;
+    out[i] = d;
+  }
+  return item;
+}
+
+extern "C" int vlb_wgrad_tn_table_launch(const void* desc_dev, int n, int nitems, hipStream_t stream) {
+  VLB_CHECK_ARG(desc_dev && n >= 1 && nitems >= 1, "vlb_wgrad_tn_table_launch: bad argument");
+  Tn8Group grp = {};
+  grp.n = n; grp.nitems = nitems; grp.nlong = 0;
+  return tn8_launch_t<true>(grp, (const Tn8Desc*)desc_dev, stream);
 }

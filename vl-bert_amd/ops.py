@@ -153,6 +153,41 @@ def wgrad_tn_group(items, workspace=None, accumulate=True):
               workspace.numel() if workspace is not None else 0, 1 if accumulate else 0, _stream())
 
 
+class WgradTable:
+    """Any number of weight gradients  C_i (+)= rowscale_i . (dy_i^T x_i)  in ONE launch of the large-tile core (vlb_wgrad_tn_table_*):
+    items = [(dy [R_i, Mo] bf16, x [R_i, No] bf16, C [Mo, No] fp32, colsum [Mo] | None, rowscale [Mo] | None)], R_i % 128 == 0 (the
+    operands' zero pad rows included).  Built once for fixed buffers; .ok is False when a product is outside what the kernel covers."""
+
+    def __init__(self, items, device, accumulate=True):
+        import ctypes
+        lib = _lib.load()
+        n = len(items)
+        self.keep = list(items)
+        P, Lg, I = ctypes.c_void_p * n, ctypes.c_long * n, ctypes.c_int * n
+        for dy, x, C, cs, rs in items:
+            assert dy.shape[0] == x.shape[0] and C.shape == (dy.shape[1], x.shape[1]) and dy.dtype == BF16 and x.dtype == BF16
+        A = P(*[_p(t[0], BF16) for t in items]); lda = Lg(*[_ld(t[0]) for t in items])
+        B = P(*[_p(t[1], BF16) for t in items]); ldb = Lg(*[_ld(t[1]) for t in items])
+        Cs = P(*[_p(t[2], torch.float32) for t in items]); ldc = Lg(*[_ld(t[2]) for t in items])
+        R = I(*[t[0].shape[0] for t in items])
+        Mo = I(*[t[0].shape[1] for t in items]); No = I(*[t[1].shape[1] for t in items])
+        cs = P(*[_p(t[3], torch.float32) for t in items]); rs = P(*[_p(t[4], torch.float32) for t in items])
+        nbytes = int(lib.vlb_wgrad_tn_table_desc_bytes()) * n
+        host = ctypes.create_string_buffer(nbytes)
+        rc = lib.vlb_wgrad_tn_table_pack(n, A, lda, B, ldb, Cs, ldc, R, Mo, No, cs, rs, 1 if accumulate else 0, host, nbytes)
+        if rc < 0:
+            raise RuntimeError("vlb_wgrad_tn_table_pack failed (%d): %s" % (rc, lib.vlb_last_error().decode()))
+        self.ok, self.n, self.nitems = rc > 0, n, rc
+        self.flops = sum(2.0 * t[0].shape[0] * t[0].shape[1] * t[1].shape[1] for t in items)
+        self.nbytes = sum(t[0].numel() * 2 + t[1].numel() * 2 + t[2].numel() * 4 for t in items)
+        self.desc = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(device) if self.ok else None
+
+    def run(self):
+        if not self.ok:
+            raise RuntimeError("WgradTable: a product is outside what the table kernel covers (row counts must be multiples of 128)")
+        _lib.call("vlb_wgrad_tn_table_launch", self.desc.data_ptr(), self.n, self.nitems, _stream())
+
+
 def gemm_nt_splitk(A, B, C, workspace=None):
     """C (bf16) = A B^T with slab split-K when the output has too few tiles to fill the chip (long-K dgrad)."""
     M, K = A.shape

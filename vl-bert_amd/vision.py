@@ -158,6 +158,21 @@ class VisionStack:
         h, w, n = self.Hp, self.Wp, N
         self.groups = OrderedDict()              # per layer: geometry + backward scratch
         shared_col = {}
+        # Round 4: the 1x1-convolution weight gradients of layer3 (22 identical Bottlenecks + the first: 46-47 products of 256 x 1024 /
+        # 1024 x 256 outputs over 19 152 rows, each a 100-300-tile launch of the 128 x 128 TN kernel + a slab reduce) are DEFERRED: every
+        # block keeps its dz / da gradient tensors, and when the stage's data-gradient chain is through, ONE table-driven launch of the
+        # large-tile core computes all of them as full-K 256 x 256 items with the BatchNorm scale in the epilogue (ops.WgradTable: no K
+        # slices, no slabs, no reduce launches).  Its operands are allocated with their row count rounded up to 128 (zero pad rows:
+        # every kernel writes M rows).  +1.1 GB of gradient tensors at 8 images of 600 x 1000.  VLB_VISION_WGRAD_DEFER=0 switches it off.
+        want_defer = os.environ.get("VLB_VISION_WGRAD_DEFER", "1") != "0" and self.implicit
+        self.defer_layers = {3} if want_defer else set()
+        self._row_parent = {}
+
+        def zbp(M, C):                           # [M, C] view of a zero [round128(M), C] allocation
+            full = zb(_ru(M, 128), C)
+            view = full[:M]
+            self._row_parent[view.data_ptr()] = full
+            return view
         max_wg, max_dwf = 0, 0
         for b in self.blocks:
             L, P, C = b["layer"], b["planes"], b["inplanes"]
@@ -173,8 +188,13 @@ class VisionStack:
             b["M"] = M
             tr = b["stage"] not in self.frozen_stages
             b["trainable"] = tr
-            b["xs"] = zb(M, C) if b["stride"] == 2 else None
-            b["a"], b["b"], b["y"] = zb(M, P), zb(M, P), zb(M, 4 * P)
+            # (a first block without stride reads the previous stage's output; the table kernel needs >= 256 reduction rows)
+            dfr = tr and L in self.defer_layers and (b["index"] > 0 or b["stride"] == 2) and _ru(M, 128) >= 256
+            if tr and L in self.defer_layers and not dfr:
+                self.defer_layers.discard(L)
+            za = zbp if dfr else zb
+            b["xs"] = za(M, C) if b["stride"] == 2 else None
+            b["a"], b["b"], b["y"] = zb(M, P), za(M, P), za(M, 4 * P)
             b["r"] = zb(M, 4 * P) if b["downsample"] else None
             if tr and not self.implicit:
                 b["col"] = zb(M, 9 * P)                      # kept for the weight gradient
@@ -204,6 +224,31 @@ class VisionStack:
         self.dfeat32 = None if self.roi_gather else zf(self.M3, self.C3)
         self.roi_ws = ops.roi_align_gather_workspace(self.K, self.H3, self.W3, pooled, d) if self.roi_gather else None
         self.wg_ws = zf(max(max_wg, max_dwf, 4))         # split-K slabs (at least one slab of the largest weight)
+        # ---- deferred 1x1 weight gradients: per-block gradient tensors + one descriptor table per stage ----------------
+        self._tables = {}
+        for L in sorted(self.defer_layers):
+            g = self.groups[L]
+            blks = [b for b in self.blocks if b["layer"] == L]
+            M, P = g["M"], g["P"]
+            g["dz"] = [zbp(M, 4 * P) for _ in blks]          # dz[i]: gradient of block i's pre-ReLU output
+            g["da_list"] = [zbp(M, P) for _ in blks]
+            g["dzA"], g["dzB"] = g["dz"][-1], None           # the stage's entry buffer (written by the next stage's backward)
+            par = lambda t: self._row_parent[t.data_ptr()]
+            items = []
+            for i, b in enumerate(blks):
+                k = b["key"]
+                c1, c3 = self.convs[k + "conv1"], self.convs[k + "conv3"]
+                xin = b["xs"] if b["stride"] == 2 else blks[i - 1]["y"]
+                items.append((par(g["dz"][i]), par(b["b"]), c3.g32, None, c3.scale))
+                items.append((par(g["da_list"][i]), par(xin), c1.g32, None, c1.scale))
+                if b["downsample"]:
+                    cd = self.convs[k + "downsample.0"]
+                    items.append((par(g["dz"][i]), par(xin), cd.g32, None, cd.scale))
+            tab = ops.WgradTable(items, d, accumulate=True) if d.type == "cuda" else None
+            if tab is not None and tab.ok:
+                self._tables[L] = tab
+            else:
+                raise RuntimeError("deferred weight gradients of layer%d: the table kernel refused the shapes" % L)
         self.wg_wss = [self.wg_ws] + [zf(self.wg_ws.numel()) for _ in range(len(self.sides) - 1)]       # one per side stream
 
     # ------------------------------------------------------------------------------------------------------------------
@@ -388,8 +433,10 @@ class VisionStack:
         c1, c2, c3 = cv[k + "conv1"], cv[k + "conv2"], cv[k + "conv3"]
         x = b["x"]
         xs = b["xs"] if b["stride"] == 2 else x
-        da, db = g["da"][b["index"] & 1], g["db"][b["index"] & 1]
-        self._wgrad(c3, dz, b["b"])
+        defer = b["layer"] in self._tables       # this stage's 1x1 weight gradients go out as ONE table launch when the stage is through
+        da, db = (g["da_list"][b["index"]] if defer else g["da"][b["index"] & 1]), g["db"][b["index"] & 1]
+        if not defer:
+            self._wgrad(c3, dz, b["b"])
         self._before_write(db)
         ops.gemm_nt(dz, c3.wb, db, act=ops.ACT_RELU_MASK, aux=b["b"])
         self._before_write(da)
@@ -405,10 +452,11 @@ class VisionStack:
             self._wgrad(c2, db, b["col"])
             ops.im2col_nhwc(db, g["dcol"], n, h, w, P, 3, 1, b["dil"], b["dil"])
             ops.gemm_nt(g["dcol"], c2.wb, da, act=ops.ACT_RELU_MASK, aux=b["a"])
-        self._wgrad(c1, da, xs)
         cd = cv[k + "downsample.0"] if b["downsample"] else None
-        if cd is not None:
-            self._wgrad(cd, dz, xs)
+        if not defer:
+            self._wgrad(c1, da, xs)
+            if cd is not None:
+                self._wgrad(cd, dz, xs)
         if not need_dx:
             return
         res = dz
@@ -430,6 +478,12 @@ class VisionStack:
         self._backward(d_feat, boxes, drop_p, seed, tag, drop_row_elems, drop_col0, on_stage_done)
         self._join_side()        # every weight gradient is complete for whatever the caller enqueues next
 
+    def _deferred_wgrads(self, L):
+        """The stage's deferred 1x1 weight gradients: one table launch on a side stream, behind everything enqueued so far."""
+        tab = self._tables.get(L)
+        if tab is not None:
+            self._side_run(lambda ws: tab.run())
+
     def _stage_done(self, hook, layer):
         if hook is not None:
             self._join_side()
@@ -448,7 +502,10 @@ class VisionStack:
         for b in reversed(blocks):
             L, g = b["layer"], self.groups[b["layer"]]
             if b["index"] > 0:
-                other = g["dzB"] if cur is g["dzA"] else g["dzA"]
+                if L in self._tables:
+                    other = g["dz"][b["index"] - 1]
+                else:
+                    other = g["dzB"] if cur is g["dzA"] else g["dzA"]
                 self._block_bwd(b, cur, other, True, True)
                 cur = other
                 continue
@@ -472,9 +529,11 @@ class VisionStack:
                     cur = ops.relu_mask_cast(self.dfeat32, self.body4, g3["dzA"])
             elif b is first:
                 self._block_bwd(b, cur, None, False, False)
+                self._deferred_wgrads(L)
                 self._stage_done(hook, L)
             else:
                 prev = self.groups[L - 1]
                 self._block_bwd(b, cur, prev["dzA"], True, True)
                 cur = prev["dzA"]
+                self._deferred_wgrads(L)
                 self._stage_done(hook, L)
