@@ -264,7 +264,7 @@ def test_language_pretrained_strict_parts_and_path_resolution(tmp_path):
 
 
 def test_bench_other_configs_summarises_children_and_survives_failures(monkeypatch):
-    """bench.other_configs(): the child bench lines of BASELINE configs 3 / 4 are condensed into the default line; a failing or
+    """bench.other_configs(): the child bench lines of BASELINE configs 3 / 4 / 5 are condensed into the default line; a failing or
     hanging child becomes an {"error": ...} entry and never an exception (the headline line must still print)."""
     import importlib.util
     import json
@@ -290,7 +290,8 @@ def test_bench_other_configs_summarises_children_and_survives_failures(monkeypat
         raise subprocess.TimeoutExpired(cmd, kw["timeout"])
     monkeypatch.setattr(subprocess, "run", fake_run)
     out = bench.other_configs()
-    assert set(out) == {"config3_e2e", "config4_vqa_fp32"} and len(calls) == 2
+    assert set(out) == {"config3_e2e", "config4_vqa_fp32", "config5_vcr_fp16"} and len(calls) == 3
+    assert "--precision" in calls[2] and "f16" in calls[2] and "--vcr" in calls[2]          # config 5 at its named ("mixed") precision
     c3 = out["config3_e2e"]
     assert c3["value"] == 740.0 and c3["ms_per_step"] == 21.6 and c3["gemm_frac_of_peak"] == 0.128 and c3["workload"] == "C3"
     assert c3["cmd"].startswith("python bench.py --e2e") and "--no-cpu-baseline" in c3["cmd"]

@@ -74,9 +74,10 @@ def test_layernorm_rows_are_loaded_in_one_burst(layernorm):
 
 def test_grouped_weight_gradient_main_loop_is_clean():
     ks = L.kernels(L.compile_isa(os.path.join(CSRC, "gemm_tn8.hip")))
-    k = L.find(ks, r"gemm_tn8_kernel")
-    lo, hi = L.mfma_region(k["body"])
-    inner = L.region_counts(k["body"], lo, hi)
-    assert inner["mfma"] == 128 and inner["scratch"] == 0           # two K tiles x four phases x 16 MFMAs, no spill traffic in the loop
-    assert inner["vmcnt0"] <= 1                                      # (the end-of-stream drain; the steady state uses counted waits)
-    assert k["spill"] == 0 and k["vgpr"] <= 256
+    for inst in (r"gemm_tn8_kernelILb0E", r"gemm_tn8_kernelILb1E"):     # descriptors in the kernel argument | in a device table (round 4)
+        k = L.find(ks, inst)
+        lo, hi = L.mfma_region(k["body"])
+        inner = L.region_counts(k["body"], lo, hi)
+        assert inner["mfma"] == 128 and inner["scratch"] == 0       # two K tiles x four phases x 16 MFMAs, no spill traffic in the loop
+        assert inner["vmcnt0"] <= 1                                  # (the end-of-stream drain; the steady state uses counted waits)
+        assert k["spill"] == 0 and k["vgpr"] <= 256, inst

@@ -164,7 +164,7 @@ class VisionStack:
         # large-tile core computes all of them as full-K 256 x 256 items with the BatchNorm scale in the epilogue (ops.WgradTable: no K
         # slices, no slabs, no reduce launches).  Its operands are allocated with their row count rounded up to 128 (zero pad rows:
         # every kernel writes M rows).  +1.1 GB of gradient tensors at 8 images of 600 x 1000.  VLB_VISION_WGRAD_DEFER=0 switches it off.
-        want_defer = os.environ.get("VLB_VISION_WGRAD_DEFER", "1") != "0" and self.implicit
+        want_defer = os.environ.get("VLB_VISION_WGRAD_DEFER", "1") != "0" and self.implicit and d.type == "cuda"
         self.defer_layers = {3} if want_defer else set()
         self._row_parent = {}
 
@@ -244,11 +244,10 @@ class VisionStack:
                 if b["downsample"]:
                     cd = self.convs[k + "downsample.0"]
                     items.append((par(g["dz"][i]), par(xin), cd.g32, None, cd.scale))
-            tab = ops.WgradTable(items, d, accumulate=True) if d.type == "cuda" else None
-            if tab is not None and tab.ok:
-                self._tables[L] = tab
-            else:
+            tab = ops.WgradTable(items, d, accumulate=True)
+            if not tab.ok:       # (eligibility was decided above from the row count; the leading dimensions are multiples of 8)
                 raise RuntimeError("deferred weight gradients of layer%d: the table kernel refused the shapes" % L)
+            self._tables[L] = tab
         self.wg_wss = [self.wg_ws] + [zf(self.wg_ws.numel()) for _ in range(len(self.sides) - 1)]       # one per side stream
 
     # ------------------------------------------------------------------------------------------------------------------
