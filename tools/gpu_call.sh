@@ -29,6 +29,8 @@ for what in "$@"; do
     tests:*)  ( time timeout 1500 python -m pytest tests -m gpu -q -k "${what#tests:}" 2>&1 | tail -40 ) > $OUT/tests_subset.log 2>&1; tail -25 $OUT/tests_subset.log ;;
     libtests:*) spec="${what#libtests:}"; d="${spec%%:*}"; k="${spec#*:}"      # libtests:<variant dir>:<-k expr>: parity tests against a saved build
               ( time VLB_LIB_PATH=$ROOT/vl-bert_amd/csrc/$d/libvlbert_hip.so timeout 900 python -m pytest tests -m gpu -q -x -k "$k" 2>&1 | tail -15 ) > $OUT/libtests_$d.log 2>&1; tail -8 $OUT/libtests_$d.log ;;
+    envtests:*) spec="${what#envtests:}"; e="${spec%%:*}"; k="${spec#*:}"       # envtests:<NAME=VALUE>:<-k expr>: a subset under an environment switch
+              ( time env "$e" timeout 900 python -m pytest tests -m gpu -q -x -k "$k" 2>&1 | tail -12 ) > $OUT/envtests.log 2>&1; tail -6 $OUT/envtests.log ;;
     smoke)    timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE OK')" 2>&1 | tail -3 | tee $OUT/smoke.log ;;
     bench)    timeout 900 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; cut -c1-900 $OUT/bench_default.json; tail -2 $OUT/bench_default.err
               python -c "import json; d=json.load(open('$OUT/bench_default.json')); print('cpu_baseline', d.get('cpu_baseline')); print('other_configs', json.dumps(d.get('other_configs'))[:1500])" ;;

@@ -706,7 +706,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(const GemmParams p) 
     if (p.ablate == 1) {
       // (timing ablation: no epilogue at all)
 #if VLB_P8_WDRAIN
-    } else if (w + (int)gridDim.x < nt && !(FMH == 5 && (EPI == 6 || EPI == 7))) {
+    } else if ((w + (int)gridDim.x < nt || (p.p8_flags & 2)) && !(FMH == 5 && (EPI == 6 || EPI == 7))) {      // (bit 1: also a workgroup's LAST tile, A/B)
       // mid-stream tile: wave-private drain beside the operand ring (not in the one instantiation without the registers for it: its
       // spills land in the K loop; that one keeps the shared slab)
       if (m0 + BM <= p.M && n0 + BN <= p.N) p8_drain_w<FMH, EPI, false>(p, acc, lds0 + STG, m0, n0, wm, wn, tid, seed);
@@ -881,7 +881,7 @@ int vlb_gemm_p8_try(GemmParams& p, hipStream_t stream) {
   if (!fmh) return 0;
   const int g = group < 1 ? 1 : group;
   p.ablate = g_opt[5];
-  p.p8_flags = g_opt[7] ? 1 : 0;
+  p.p8_flags = (g_opt[7] & 1) | (env_int("VLB_GEMM_P8_LASTW", 0) ? 2 : 0);      // p8_drain bit 0; VLB_GEMM_P8_LASTW: wave-private drain for last tiles too
   if (fmh == 3) return p8_launch_epi<3, true>(p, epi, g, stream);
   if (fmh == 5) return p8_launch_epi<5, false>(p, epi, g, stream);
   return keepb ? p8_launch_epi<4, true>(p, epi, g, stream) : p8_launch_epi<4, false>(p, epi, g, stream);
