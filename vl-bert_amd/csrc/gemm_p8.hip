@@ -487,19 +487,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(const GemmParams p) 
     t[1] = __builtin_amdgcn_s_memrealtime();
   }
 
-  // Free stagger (round 4, p8_flags bit 2): when the tile count is not a multiple of the grid, the workgroups that own one tile
-  // less would sit idle at the END of the launch.  They idle at the START instead, for `stagger_ticks` of the 100 MHz real-time
-  // counter (about half a tile: set by the host from K and the epilogue kind), so that their epilogues -- bursts of 128-256 KiB of
-  // loads / stores per CU that all CUs otherwise issue in the same microseconds (FFN2 data gradient: 318 MB in the 46 us the CUs spend
-  // in their epilogues, i.e. HBM-bound windows between compute-bound main loops) -- fall into the other workgroups' main loops.
-  if ((p.p8_flags & 4) && nt > (int)gridDim.x) {
-    const int rem = nt % (int)gridDim.x;
-    if (rem != 0 && (int)blockIdx.x >= rem) {
-      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-      const unsigned long long d = (unsigned long long)(p.p8_flags >> 8);
-      while (__builtin_amdgcn_s_memrealtime() - t0 < d) __builtin_amdgcn_s_sleep(32);
-    }
-  }
   auto tile_of = [&](int w, int& m0, int& n0) {   // XCD-aware grouped order (see gemm_nt_bf16_kernel)
     const int xcd = w & 7, q = nt >> 3, r = nt & 7;
     const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (w >> 3);
@@ -898,15 +885,6 @@ int vlb_gemm_p8_try(GemmParams& p, hipStream_t stream) {
   const int g = group < 1 ? 1 : group;
   p.ablate = g_opt[5];
   p.p8_flags = (g_opt[7] & 1) | (env_int("VLB_GEMM_P8_LASTW", 0) ? 2 : 0);      // p8_drain bit 0; VLB_GEMM_P8_LASTW: wave-private drain for last tiles too
-  {      // free stagger of the workgroups that own one tile less: VLB_GEMM_P8_STAGGER = percent of one tile's main loop (0 = off)
-    static int stagger_pct = -1;
-    if (stagger_pct < 0) stagger_pct = env_int("VLB_GEMM_P8_STAGGER", 0);
-    if (stagger_pct > 0) {
-      // one K tile of a 256-row tile ~ 1.7 us = 170 ticks of the 100 MHz counter (scaled with the tile height)
-      const long ticks = (long)(p.K >> 6) * 170L * fmh / 4 * stagger_pct / 100;
-      p.p8_flags |= 4 | (int)((ticks > 0x7fffff ? 0x7fffff : ticks) << 8);
-    }
-  }
   if (fmh == 3) return p8_launch_epi<3, true>(p, epi, g, stream);
   if (fmh == 5) return p8_launch_epi<5, false>(p, epi, g, stream);
   return keepb ? p8_launch_epi<4, true>(p, epi, g, stream) : p8_launch_epi<4, false>(p, epi, g, stream);
