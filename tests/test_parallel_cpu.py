@@ -436,3 +436,40 @@ def _ddp_rest_worker(rank, world, port):
 
 def test_ddp_wrapper_reduces_every_parameter_gloo_world2():
     mp.spawn(_ddp_rest_worker, args=(2, _free_port()), nprocs=2, join=True)
+
+
+def _null_worker(rank, world, port):
+    """GradBuckets.null_collectives (bench.py's compute-only leg): with the switch on, rank 0 runs a whole exchange -- bucket launches,
+    wait, norm all-reduce, weight gather incl. the replicated fp32 tensors -- while rank 1 issues NOTHING; any collective that still
+    went out would have no partner and time out."""
+    import datetime
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=20))
+    P = importlib.import_module("vl-bert_amd.parallel")
+    cfg, offsets, numel, vstart, _ = _padded_layout(world)
+    if rank == 0:
+        for mode in ("sharded", "allreduce"):
+            grad = torch.randn(numel)
+            b = P.GradBuckets(grad, offsets, numel, cfg.num_hidden_layers, bucket_bytes=300_000, mode=mode, wire_dtype=None)
+            if mode == "sharded":
+                b.set_replicated_fp32([(0, 64), (1000, 1100)])
+            b.null_collectives(True)
+            for what in ["heads"] + list(reversed(range(cfg.num_hidden_layers))) + ["word_emb", "embed"]:
+                b.on_done(what)
+            b.wait()
+            b.all_reduce_scalar(torch.zeros(1))
+            if mode == "sharded":
+                _ = b.grad_shard
+                b.gather_params(torch.zeros(numel, dtype=torch.bfloat16), torch.zeros(numel // world, dtype=torch.bfloat16),
+                                master=torch.zeros(numel), vision_master=False)
+                b.wait_params("all")
+            else:
+                _ = b.reduced
+            b.null_collectives(False)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_null_collectives_issue_no_communication():
+    mp.spawn(_null_worker, args=(2, _free_port()), nprocs=2, join=True)
