@@ -349,6 +349,15 @@ def bench_vcr(args):
         for n, p in net.named_parameters():
             if n.endswith("visual_ln_text.weight") or n.endswith("visual_ln_object.weight"):
                 p.fill_(1.0)
+        # No checkpoints exist offline: the ResNet runs on its random initialisation, where identity BatchNorms let the residual stream
+        # double per block (33 blocks: beyond fp16's 65504 -- `--precision f16` gave loss = nan -- harmless in bf16).  The same 0.2 gain
+        # on the BatchNorm that closes each residual branch (and the stem) as engine.init_random / vision.VisionStack.init_random use
+        # keeps random-init activations O(1); timing does not depend on it.
+        sd = net.state_dict()
+        gains = {k: torch.full_like(v, 0.2) for k, v in sd.items() if k.endswith(".bn3.weight") or k.endswith("backbone.bn1.weight")}
+        if gains:
+            sd.update(gains)
+            net.load_state_dict(sd)
     net.train()
     world, rank = args.world, args.rank
     if world > 1:      # vcr/function/train.py:330 wraps the model in DistributedDataParallel: 4 samples per GPU per micro-batch (weak scaling)
@@ -535,6 +544,8 @@ def main():
     ap.add_argument("--dp-mode", default="default", choices=["default", "sharded", "allreduce"], help="data-parallel exchange "
                     "(vl-bert_amd/parallel.py): sharded optimizer (reduce-scatter + weight all-gather; default) or all-reduce")
     ap.add_argument("--head-start", type=int, default=60, help="unrelated 0.55-TFLOP torch.mm launches queued ahead of the instrumented step (roofline)")
+    ap.add_argument("--no-clock-probe", action="store_true", help="skip the in-kernel sustained-clock measurement (201 extra launches of the FFN2 "
+                    "shape after the timed region): profiling runs, so that the kernel tables hold the step's launches only")
     ap.add_argument("--no-phase-times", action="store_true", help="skip the separate forward / forward+backward timing loops (profiling runs)")
     ap.add_argument("--graph", action="store_true", help="replay the step as one hipGraph (single GPU).  Off by default: the step is "
                     "GPU-bound, not launch-bound -- measured on MI355X the eager stream launches are 3-5 %% FASTER than the graph replay "
@@ -881,7 +892,7 @@ def main():
                  "host_ms": round(host.get(k, 0.0) * 1e3, 3)} for k, v in by_op.items()}
     by_op["host_launch_ms_whole_step"] = round(h_step * 1e3, 3)
     achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-    clock_mhz = sustained_clock_mhz(ops, lib, eng.dev) if (rank == 0 and prec == "bf16") else None
+    clock_mhz = sustained_clock_mhz(ops, lib, eng.dev) if (rank == 0 and prec == "bf16" and not args.no_clock_probe) else None
     fwd, fwdbwd = flops_per_sample(cfg, T, R)
     if aux:           # sample-weighted mean: a text-only sample is T tokens + END, no regions, MLM head only
         fa, fba = flops_per_sample(cfg, T, 0)

@@ -36,10 +36,10 @@ for what in "$@"; do
               python -c "import json; d=json.load(open('$OUT/bench_default.json')); print('cpu_baseline', d.get('cpu_baseline')); print('other_configs', json.dumps(d.get('other_configs'))[:1500])" ;;
     ab:*)     IFS=, read -ra V <<< "${what#ab:}"
               for i in 1 2; do
-                unset VLB_LIB_PATH; timeout 300 python bench.py --no-cpu-baseline --no-phase-times 2>/dev/null | line tree
+                unset VLB_LIB_PATH; timeout 300 python bench.py --no-cpu-baseline --no-phase-times --no-clock-probe 2>/dev/null | line tree
                 for v in "${V[@]}"; do
-                  if [[ $v == *=* ]]; then env "$v" timeout 300 python bench.py --no-cpu-baseline --no-phase-times 2>/dev/null | line "$v"
-                  else VLB_LIB_PATH=$ROOT/vl-bert_amd/csrc/$v/libvlbert_hip.so timeout 300 python bench.py --no-cpu-baseline --no-phase-times 2>/dev/null | line "$v"; fi
+                  if [[ $v == *=* ]]; then env "$v" timeout 300 python bench.py --no-cpu-baseline --no-phase-times --no-clock-probe 2>/dev/null | line "$v"
+                  else VLB_LIB_PATH=$ROOT/vl-bert_amd/csrc/$v/libvlbert_hip.so timeout 300 python bench.py --no-cpu-baseline --no-phase-times --no-clock-probe 2>/dev/null | line "$v"; fi
                 done
               done 2>&1 | tee $OUT/ab.log ;;
     gemm)     timeout 600 python tools/p8_check.py bench 256 2>&1 | tee $OUT/gemm_table.txt | tail -16 ;;
@@ -51,14 +51,14 @@ for what in "$@"; do
               run large_f16 --large --precision f16 --no-cpu-baseline; run vqa --vqa --steps 5 --warmup 2 --no-cpu-baseline
               run vqa_fp32 --vqa --precision fp32 --steps 3 --warmup 1 --no-cpu-baseline; run vcr_f16 --vcr --precision f16 --steps 3 --warmup 1 --no-cpu-baseline
               run vcr --vcr --steps 3 --warmup 1 --no-cpu-baseline ;;
-    e2e)      for v in "" "--graph" ; do timeout 400 python bench.py --e2e --no-cpu-baseline --no-phase-times $v 2>/dev/null | line "e2e $v"; done | tee $OUT/e2e.log
-              VLB_VISION_WGRAD_STREAMS=1 timeout 400 python bench.py --e2e --no-cpu-baseline --no-phase-times 2>/dev/null | line "e2e 1 side stream" | tee -a $OUT/e2e.log
-              VLB_VISION_WGRAD_STREAMS=1 timeout 400 python bench.py --e2e --no-cpu-baseline --no-phase-times --graph 2>/dev/null | line "e2e 1 side stream --graph" | tee -a $OUT/e2e.log ;;
+    e2e)      for v in "" "--graph" ; do timeout 400 python bench.py --e2e --no-cpu-baseline --no-phase-times --no-clock-probe $v 2>/dev/null | line "e2e $v"; done | tee $OUT/e2e.log
+              VLB_VISION_WGRAD_STREAMS=1 timeout 400 python bench.py --e2e --no-cpu-baseline --no-phase-times --no-clock-probe 2>/dev/null | line "e2e 1 side stream" | tee -a $OUT/e2e.log
+              VLB_VISION_WGRAD_STREAMS=1 timeout 400 python bench.py --e2e --no-cpu-baseline --no-phase-times --no-clock-probe --graph 2>/dev/null | line "e2e 1 side stream --graph" | tee -a $OUT/e2e.log ;;
     clock)    timeout 300 python tools/clock_probe.py 4 2>&1 | grep -v amdgpu.ids | tee $OUT/clock_probe.txt ;;
     graphsmall) for b in 64 32; do timeout 300 python bench.py --no-cpu-baseline --global-batch $b --no-phase-times --graph 2>/dev/null | line "batch $b --graph"; done | tee $OUT/graphsmall.log ;;
     dp2)      timeout 600 python bench.py --gpus 2 --no-cpu-baseline --steps 10 > $OUT/dp2.json 2> $OUT/dp2.err; grep '^{' $OUT/dp2.json | cut -c1-1200; grep -v Gloo $OUT/dp2.err | tail -3
               grep -o '"comm": {[^}]*}' $OUT/dp2.json ;;
-    trace)    ( cd /tmp && export TMPDIR=/tmp && VLB_WGRAD_STREAM=0 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/tr -o r -- python $ROOT/bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-phase-times > $OUT/tr.log 2>&1 )
+    trace)    ( cd /tmp && export TMPDIR=/tmp && VLB_WGRAD_STREAM=0 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/tr -o r -- python $ROOT/bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-phase-times --no-clock-probe > $OUT/tr.log 2>&1 )
               python tools/kstats.py $OUT/tr 5 24 | tee $OUT/kstats.txt; rm -rf $OUT/tr ;;
     profiles*) t="${what#profiles}"; t="${t#:}"; VLB_COMMIT=$(cat $ROOT/.commit_stamp 2>/dev/null || echo unknown) timeout 1500 bash tools/make_profiles.sh "${t:-r04}"; ls $ROOT/gpurun_out/summary ;;
     *) echo "unknown step: $what" ;;

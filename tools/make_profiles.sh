@@ -13,7 +13,7 @@ cd /tmp && export TMPDIR=/tmp
 # per-kernel duration in a trace; the kernel-efficiency profile (like the instrumented step inside bench.py that produces
 # roofline.achieved) serialises them.  `value` in the default bench run is measured WITH the overlap.
 export VLB_WGRAD_STREAM=0
-CMD="python $ROOT/bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-phase-times"
+CMD="python $ROOT/bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-phase-times --no-clock-probe"
 rocprofv3 --kernel-trace --stats -d "$OUT/final_trace" -o r -- $CMD > "$OUT/final_trace.log" 2>&1
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY -d "$OUT/final_sq" -o r -- $CMD > "$OUT/final_sq.log" 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/final_fetch" -o r -- $CMD > "$OUT/final_fetch.log" 2>&1

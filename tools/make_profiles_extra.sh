@@ -4,7 +4,7 @@ set -u
 ROOT="${GRAFT_REPO_ROOT:-/root/repo}"
 OUT="$ROOT/gpurun_out"
 cd /tmp && export TMPDIR=/tmp
-VLB_WGRAD_STREAM=0 rocprofv3 --kernel-trace --stats -d "$OUT/final_large_trace" -o r -- python $ROOT/bench.py --large --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-phase-times > "$OUT/final_large_trace.log" 2>&1
+VLB_WGRAD_STREAM=0 rocprofv3 --kernel-trace --stats -d "$OUT/final_large_trace" -o r -- python $ROOT/bench.py --large --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-phase-times --no-clock-probe > "$OUT/final_large_trace.log" 2>&1
 rocprofv3 --kernel-trace --stats -d "$OUT/final_vcr_trace" -o r -- python $ROOT/bench.py --vcr --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/final_vcr_trace.log" 2>&1
 rocprofv3 --kernel-trace --stats -d "$OUT/final_vqa_trace" -o r -- python $ROOT/bench.py --vqa --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/final_vqa_trace.log" 2>&1
 mkdir -p "$OUT/summary"

@@ -17,9 +17,9 @@ one() {   # name, steps-in-process, note, command...
 }
 for b in 64 32; do
   VLB_WGRAD_STREAM=0 one kernel_stats_batch$b 5 "per-GPU batch $b of the global-256 strong-scaling run on ONE MI355X (no communication), weight-gradient stream serialised; 1 warm-up + 3 timed + 1 instrumented step" \
-    python "$ROOT/bench.py" --global-batch $b --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-phase-times
+    python "$ROOT/bench.py" --global-batch $b --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-phase-times --no-clock-probe
 done
 one vqa_fp32_kernel_stats 4 "BASELINE config 4 at its named precision: bench.py --vqa --precision fp32 (fp32 encoder, fp16 build around it); 1 warm-up + 2 timed + 1 instrumented optimizer step" \
   python "$ROOT/bench.py" --vqa --precision fp32 --steps 2 --warmup 1 --no-cpu-baseline
 VLB_WGRAD_STREAM=0 one f16_kernel_stats 5 "headline workload on the fp16 build of the library (VLB_PRECISION=f16): same kernels, IEEE fp16 as the 16-bit type" \
-  python "$ROOT/bench.py" --precision f16 --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-phase-times
+  python "$ROOT/bench.py" --precision f16 --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-phase-times --no-clock-probe
