@@ -28,7 +28,35 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/final_e2e_write" -o r -- $CMD
 fi
 # summarise on the box and drop the raw rocpd databases (five of them exceed the 64 MiB that gpurun copies back)
 mkdir -p "$OUT/summary"
-python "$ROOT/tools/profile_report.py" "$OUT" "$OUT/summary" "${1:-r04}"
+TAG="${1:-r04}"
+python "$ROOT/tools/profile_report.py" "$OUT" "$OUT/summary" "$TAG"
 rm -rf "$OUT"/final_trace "$OUT"/final_sq "$OUT"/final_fetch "$OUT"/final_write "$OUT"/final_e2e_trace "$OUT"/final_e2e_sq "$OUT"/final_e2e_fetch "$OUT"/final_e2e_write
 grep '"metric"' "$OUT/final_trace.log" | tail -1 | cut -c1-200
 grep '"metric"' "$OUT/final_e2e_trace.log" | tail -1 | cut -c1-200
+
+# ---- optional sets ------------------------------------------------------------------------------------------------------------
+one() {   # name, steps-in-process, note, command...
+  local name=$1 steps=$2 note=$3; shift 3
+  rocprofv3 --kernel-trace --stats -d "$OUT/tr_$name" -o r -- "$@" > "$OUT/tr_$name.log" 2>&1
+  { echo "# $note"; echo "# $*"; grep '"metric"' "$OUT/tr_$name.log" | tail -1 | sed 's/^/# bench line of the traced run: /'; python "$ROOT/tools/kstats.py" "$OUT/tr_$name" "$steps" 45; } > "$OUT/summary/${TAG}_$name.txt"
+  rm -rf "$OUT/tr_$name"
+  head -6 "$OUT/summary/${TAG}_$name.txt" | cut -c1-160 | tail -3
+}
+for set in "${@:2}"; do
+  case $set in
+    small)
+      for b in 64 32; do
+        VLB_WGRAD_STREAM=0 one kernel_stats_batch$b 5 "per-GPU batch $b of the global-256 strong-scaling run on ONE MI355X (no communication), weight-gradient stream serialised; 1 warm-up + 3 timed + 1 instrumented step" \
+          python "$ROOT/bench.py" --global-batch $b --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-phase-times --no-clock-probe
+      done
+      one vqa_fp32_kernel_stats 4 "BASELINE config 4 at its named precision: bench.py --vqa --precision fp32 (fp32 encoder, fp16 build around it); 1 warm-up + 2 timed + 1 instrumented optimizer step" \
+        python "$ROOT/bench.py" --vqa --precision fp32 --steps 2 --warmup 1 --no-cpu-baseline
+      VLB_WGRAD_STREAM=0 one f16_kernel_stats 5 "headline workload on the fp16 build of the library (VLB_PRECISION=f16): same kernels, IEEE fp16 as the 16-bit type" \
+        python "$ROOT/bench.py" --precision f16 --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-phase-times --no-clock-probe ;;
+    extra)
+      VLB_WGRAD_STREAM=0 one large_kernel_stats 5 "bench.py --large (24 x 1024, S = 229, batch 64), weight-gradient stream serialised" \
+        python "$ROOT/bench.py" --large --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-phase-times --no-clock-probe
+      one vcr_kernel_stats 4 "bench.py --vcr (BASELINE config 5 through the module mirror)" python "$ROOT/bench.py" --vcr --steps 2 --warmup 1 --no-cpu-baseline
+      one vqa_kernel_stats 4 "bench.py --vqa (config 4's workload, 16-bit build)" python "$ROOT/bench.py" --vqa --steps 2 --warmup 1 --no-cpu-baseline ;;
+  esac
+done
