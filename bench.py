@@ -471,7 +471,7 @@ def sustained_clock_mhz(ops, lib, dev):
         B = ((torch.rand((N, K), generator=g) * 2 - 1) * 0.05).to(torch.bfloat16).to(dev)
         C = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
         bias = torch.zeros(N, device=dev)
-        table = torch.zeros((256, 16), dtype=torch.bfloat16, device=dev)           # 256 workgroups x 4 x int64
+        table = torch.zeros((256, 32), dtype=torch.bfloat16, device=dev)           # 256 workgroups x 8 x int64
         for _ in range(200):
             ops.gemm_nt(A, B, C, bias=bias)
         lib.gemm_set_option("p8_ablate", 4)
@@ -480,7 +480,7 @@ def sustained_clock_mhz(ops, lib, dev):
         finally:
             lib.gemm_set_option("p8_ablate", 0)
         torch.cuda.synchronize()
-        t = table.view(torch.int64).view(256, 4).cpu()
+        t = table.view(torch.int64).view(256, 8).cpu()
         t = t[t[:, 3] > 0]
         if t.shape[0] < 8:
             return None

@@ -106,14 +106,14 @@ def main():
     # in-kernel evidence, independent of what sysfs reports: every workgroup of the large-tile kernel stamps the shader-clock counter
     # (s_memtime) and the constant 100 MHz real-time counter (s_memrealtime) at entry and exit (p8_ablate = 4, table passed as `pre`)
     lib = importlib.import_module("vl-bert_amd._lib")
-    table = torch.zeros((256, 16), dtype=torch.bfloat16, device=D)           # 256 workgroups x 4 x int64 (a 2-D bf16 view: the `pre` argument)
+    table = torch.zeros((256, 32), dtype=torch.bfloat16, device=D)           # 256 workgroups x 8 x int64 (a 2-D bf16 view: the `pre` argument)
     for _ in range(200):                                                      # bring the device to its sustained state first
         ops.gemm_nt(A, B, C, bias=bias)
     lib.gemm_set_option("p8_ablate", 4)
     ops.gemm_nt(A, B, C, bias=bias, pre=table)
     lib.gemm_set_option("p8_ablate", 0)
     torch.cuda.synchronize()
-    t = table.view(torch.int64).view(256, 4).cpu()
+    t = table.view(torch.int64).view(256, 8).cpu()
     t = t[t[:, 3] > 0]
     if t.numel():
         cyc, rt = (t[:, 2] - t[:, 0]).double(), (t[:, 3] - t[:, 1]).double()

@@ -481,8 +481,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(const GemmParams p) 
   if ((int)blockIdx.x >= nt) return;
   // (measurement ablation 4, tools/clock_probe.py: workgroup b leaves {shader-clock counter, 100 MHz real-time counter} at entry and at
   // exit in the int64 table the caller passes through `pre` -- the effective shader clock UNDER this kernel = d(cycles) / d(real time))
-  if (p.ablate == 4 && tid == 0 && p.pre) {
-    unsigned long long* t = (unsigned long long*)p.pre + 4 * blockIdx.x;
+  // (the GELU epilogue writes GELU' through `pre`: its stamps travel through `aux`, which that epilogue does not read)
+  unsigned long long* const stamps = (unsigned long long*)(EPI == 1 ? (void*)p.aux : (void*)p.pre);
+  const bool stamp = (p.ablate == 4) && stamps;      // wave-uniform
+  unsigned long long t_main = 0, t_epi = 0, t_mark = 0;
+  if (stamp && tid == 0) {
+    unsigned long long* t = stamps + 8 * blockIdx.x;
     t[0] = __builtin_readcyclecounter();
     t[1] = __builtin_amdgcn_s_memrealtime();
   }
@@ -640,6 +644,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(const GemmParams p) 
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    if (stamp) t_mark = __builtin_readcyclecounter();
     for (int kt = 0; kt < nk; kt += 2, g += 2) {
       // ======== K tile g (buffer 0) ========
       // phase 1: A0 + B0 -> quadrant (0,0)
@@ -699,6 +704,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(const GemmParams p) 
       p8_barrier();
     }
     if (wm == 0) p8_barrier();     // let the lagging wave group finish its last quadrant: the epilogue runs aligned
+    if (stamp) {
+      const unsigned long long now = __builtin_readcyclecounter();
+      t_main += now - t_mark;
+      t_mark = now;
+    }
 
     // ---------------- epilogue: raw fp32 accumulators -> staging slab -> fused math on 8-column groups -> bf16 ----------------
     int m0, n0;
@@ -732,11 +742,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(const GemmParams p) 
     if (p.p8_flags & 1) __builtin_amdgcn_s_waitcnt(0x0F70);
     p8_barrier();
     if (wm == 1 && w + (int)gridDim.x < nt) p8_barrier();   // re-establish the one-segment lag for the next output tile
+    if (stamp) t_epi += __builtin_readcyclecounter() - t_mark;
   }
-  if (p.ablate == 4 && tid == 0 && p.pre) {
-    unsigned long long* t = (unsigned long long*)p.pre + 4 * blockIdx.x;
+  if (stamp && tid == 0) {      // + the shader cycles this workgroup's wave 0 spent in K loops / in epilogues (incl. the tile-end barriers), tiles done
+    unsigned long long* t = stamps + 8 * blockIdx.x;
     t[2] = __builtin_readcyclecounter();
     t[3] = __builtin_amdgcn_s_memrealtime();
+    t[4] = t_main;
+    t[5] = t_epi;
+    t[6] = (unsigned long long)((nt - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x);
   }
 }
 
