@@ -37,6 +37,9 @@
 
 #include "gemm_params.h"
 
+#ifndef VLB_P8_LN_SB
+#define VLB_P8_LN_SB 2       // side rows (+ their LayerNorm statistics) requested at a time by the slab drain of the 320-row LayerNorm-residual forms
+#endif
 #ifndef VLB_P8_SIDE_DEPTH
 #define VLB_P8_SIDE_DEPTH 1  // units of lead of the aux loads in the wave-private drain (EPI 2 / 10)
 #endif
@@ -190,7 +193,7 @@ __device__ __forceinline__ void p8_drain(const GemmParams& p, f32x4 (&acc)[2 * F
   constexpr bool SIDE = (EPI == 2 || EPI == 3 || EPI == 4 || EPI == 6 || EPI == 7 || EPI == 8 || EPI == 10);
   constexpr bool PRE_NEXT = SIDE && (PASSES <= 2);      // request the next round's side data one round ahead
   // side rows requested at a time (register budget: 160 accumulators + gamma / beta / bias vectors leave room for 2-4 of them)
-  constexpr int SB = PRE_NEXT ? PASSES : (FMH == 5 ? 4 : PASSES);
+  constexpr int SB = PRE_NEXT ? PASSES : (FMH == 5 ? (LNRES ? VLB_P8_LN_SB : 4) : PASSES);      // (320-row tile + LayerNorm residual: 2 rows + their statistics)
   // Every lane-dependent constant below is derived from an OPAQUE copy of the thread index: the optimiser would otherwise hoist
   // these loop-invariant address computations above the K loop of the persistent tile loop, where their live ranges cost the
   // main loop the registers it needs (the 320-row instantiation spilled a DMA offset and drained the queue to reload it).
@@ -253,16 +256,34 @@ __device__ __forceinline__ void p8_drain(const GemmParams& p, f32x4 (&acc)[2 * F
     }
     return sd;
   };
+  // the row's LayerNorm statistics (mean, rstd) travel with its side row: loaded at the point of use (round 3) they were a dependent
+  // L2 round trip in EVERY pass -- measured in-kernel (tools/p8_phase_probe.py): 24 us of epilogue per 320 x 256 tile for the dropout +
+  // LayerNorm-residual form against 13.5 us for bias + residual through the same slab
+  auto load_ms = [&](int r, int pp) {
+    float2 ms = make_float2(0.f, 0.f);
+    if constexpr (LNRES) {
+      const int m = min(max(row_of(r, pp), 0), p.M - 1);      // unconditional load from a clamped row: no branch, no drained queue
+      ms = *(const float2*)(p.res_stats + 2 * (long)m);
+    }
+    return ms;
+  };
   uint4 side[2][SB];
+  float2 mss[2][SB];
   if constexpr (PRE_NEXT) {
 #pragma unroll
-    for (int pp = 0; pp < PASSES; ++pp) side[0][pp] = load_side(0, pp);
+    for (int pp = 0; pp < PASSES; ++pp) {
+      side[0][pp] = load_side(0, pp);
+      mss[0][pp] = load_ms(0, pp);
+    }
   }
   p8_static_for<0, ROUNDS>([&](auto r_c) {
     constexpr int r = decltype(r_c)::value;
     if constexpr (SIDE && !PRE_NEXT) {      // first batch of this round: in flight under the slab writes and the barrier
 #pragma unroll
-      for (int pp = 0; pp < SB; ++pp) side[0][pp] = load_side(r, pp);
+      for (int pp = 0; pp < SB; ++pp) {
+        side[0][pp] = load_side(r, pp);
+        mss[0][pp] = load_ms(r, pp);
+      }
     }
     if (!ALT || wm == (r & 1)) {
       p8_static_for<0, FPR>([&](auto f_c) {
@@ -282,7 +303,10 @@ __device__ __forceinline__ void p8_drain(const GemmParams& p, f32x4 (&acc)[2 * F
     if constexpr (PRE_NEXT) {
       if (r + 1 < ROUNDS) {
 #pragma unroll
-        for (int pp = 0; pp < PASSES; ++pp) side[(r + 1) & 1][pp] = load_side(r + 1, pp);
+        for (int pp = 0; pp < PASSES; ++pp) {
+          side[(r + 1) & 1][pp] = load_side(r + 1, pp);
+          mss[(r + 1) & 1][pp] = load_ms(r + 1, pp);
+        }
       }
     }
 #pragma unroll
@@ -290,7 +314,10 @@ __device__ __forceinline__ void p8_drain(const GemmParams& p, f32x4 (&acc)[2 * F
       if constexpr (SIDE && !PRE_NEXT) {
         if (pp > 0 && pp % SB == 0) {       // next batch of side rows
 #pragma unroll
-          for (int k = 0; k < SB; ++k) side[0][k] = load_side(r, pp + k);
+          for (int k = 0; k < SB; ++k) {
+            side[0][k] = load_side(r, pp + k);
+            mss[0][k] = load_ms(r, pp + k);
+          }
         }
       }
       if (!frag_valid(r, pp)) continue;
@@ -302,7 +329,7 @@ __device__ __forceinline__ void p8_drain(const GemmParams& p, f32x4 (&acc)[2 * F
         if (full8) {
           const uint4 sd = SIDE ? (PRE_NEXT ? side[r & 1][pp] : side[0][pp % SB]) : make_uint4(0, 0, 0, 0);
           if constexpr (LNRES) {
-            const float2 ms = *(const float2*)(p.res_stats + 2 * (long)m);
+            const float2 ms = PRE_NEXT ? mss[r & 1][pp] : mss[0][pp % SB];
             if constexpr (!HOIST_GB) {
               const float4 a0 = *(const float4*)(p.res_gamma + n), a1 = *(const float4*)(p.res_gamma + n + 4);
               const float4 c0 = *(const float4*)(p.res_beta + n), c1 = *(const float4*)(p.res_beta + n + 4);
