@@ -1,0 +1,188 @@
+"""The pre-training data readers (vl-bert_amd/pretrain/data) against samples and batches produced by the reference's OWN dataset classes
+from the same miniature on-disk data set (tests/fixtures/cc_tiny, tests/golden/data/cc_tiny.npz: oracle/make_data_golden.py).
+Bit-exact: ids, labels, ops are integers; boxes / features / images go through the same float32 operations in the same order."""
+import importlib
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FIX = os.path.join(HERE, "fixtures", "cc_tiny")
+D = importlib.import_module("vl-bert_amd.pretrain.data")
+T = importlib.import_module("vl-bert_amd.pretrain.data.transforms")
+R = importlib.import_module("vl-bert_amd.pretrain.data.records")
+
+
+@pytest.fixture(scope="module")
+def golden():
+    with open(os.path.join(HERE, "golden", "data", "cc_tiny_meta.json")) as f:
+        meta = json.load(f)
+    return dict(np.load(os.path.join(HERE, "golden", "data", "cc_tiny.npz"))), meta
+
+
+@pytest.fixture(scope="module")
+def tok():
+    return D.default_tokenizer(os.path.join(FIX, "vocab"))
+
+
+def chain(meta):
+    return T.Compose([T.Resize(60, 100), T.RandomHorizontalFlip(0.5), T.ToTensor(), T.Normalize(meta["pixel_means"], meta["pixel_stds"], True)])
+
+
+def check_pass(tag, ds, golden, meta):
+    g, info = golden, meta["passes"][tag]
+    coll = D.BatchCollator(ds)
+    assert len(ds) == info["n"]
+    for seed in info["seeds"]:
+        random.seed(seed)
+        samples = [ds[i] for i in range(len(ds))]
+        for i, s in enumerate(samples):
+            for name, v in zip(ds.data_names, s):
+                key = "%s/s%d/%d/%s" % (tag, seed, i, name)
+                if v is None:
+                    assert key not in g
+                    continue
+                got = np.asarray(v.numpy() if isinstance(v, torch.Tensor) else v)
+                assert got.shape == g[key].shape, (key, got.shape, g[key].shape)
+                assert np.array_equal(got, g[key]), key
+        for b0 in range(0, len(samples), info["batch"]):
+            batch = coll(samples[b0:b0 + info["batch"]])
+            for name, v in zip(ds.data_names, batch):
+                key = "%s/s%d/batch%d/%s" % (tag, seed, b0, name)
+                if v is None:
+                    assert key not in g
+                    continue
+                assert v.dtype == torch.from_numpy(g[key]).dtype, (key, v.dtype)
+                assert np.array_equal(v.numpy(), g[key]), key
+
+
+def test_precomputed_feature_samples_and_batches_match_the_reference(golden, tok):
+    g, meta = golden
+    ds = D.ConceptualCaptionsDataset("", "train", FIX, FIX, seq_len=20, with_precomputed_visual_feat=True, tokenizer=tok,
+                                     add_image_as_a_box=True, transform=chain(meta))
+    check_pass("prec", ds, g, meta)
+
+
+def test_image_samples_with_raw_pixel_masking_match_the_reference(golden, tok):
+    g, meta = golden
+    ds = D.ConceptualCaptionsDataset("", "train", FIX, FIX, seq_len=64, with_precomputed_visual_feat=False, mask_raw_pixels=True,
+                                     tokenizer=tok, add_image_as_a_box=True, transform=chain(meta))
+    check_pass("image", ds, g, meta)
+
+
+def test_plain_samples_without_text_tasks_match_the_reference(golden, tok):
+    g, meta = golden
+    ds = D.ConceptualCaptionsDataset("", "train", FIX, FIX, seq_len=64, with_precomputed_visual_feat=True, with_rel_task=False,
+                                     with_mlm_task=False, tokenizer=tok, add_image_as_a_box=False, transform=None)
+    check_pass("plain", ds, g, meta)
+
+
+def test_text_corpus_samples_match_the_reference(golden, tok):
+    g, meta = golden
+    ds = D.GeneralCorpus(os.path.join(FIX, "corpus.doc"), tokenizer=tok, seq_len=16, min_seq_len=12)
+    check_pass("corpus", ds, g, meta)
+
+
+def test_detector_record_round_trip_and_zip_member():
+    rng = np.random.RandomState(0)
+    boxes, scores, feats = rng.rand(5, 4).astype(np.float32), rng.rand(5, 7).astype(np.float32), rng.rand(5, 3).astype(np.float32)
+    rec = json.loads(json.dumps(R.encode_detector_record(boxes, scores, feats, 30, 20)))
+    det = R.decode_detector_record(rec)
+    order = np.argsort(scores.max(1))[::-1]
+    assert np.array_equal(det["boxes"], boxes[order]) and np.array_equal(det["features"], feats[order]) and (det["width"], det["height"]) == (30, 20)
+    assert np.all(np.diff(det["scores"].max(1)) <= 0)
+    # zip_mode: the annotation's `archive.zip@/member` spelling is read from the archive itself
+    ds = D.ConceptualCaptionsDataset.__new__(D.ConceptualCaptionsDataset)
+    ds.archives = importlib.import_module("vl-bert_amd.pretrain.data.datasets")._Archives()
+    raw = ds._bytes(os.path.join(FIX, "train_frcnn.0.zip@/0000.json"))
+    with open(os.path.join(FIX, "train_frcnn", "0000.json"), "rb") as f:
+        assert raw == f.read()
+
+
+def test_sequence_budget_rule():
+    assert R.sequence_budget(10, 30, 20) == (10, 10)
+    assert R.sequence_budget(30, 5, 20) == (15, 5)
+    assert R.sequence_budget(40, 40, 3) == (2, 2)      # ([CLS], [SEP] and one box always stay: the floor may exceed a tiny budget)
+
+
+def test_loaders_from_a_reference_style_config(tok):
+    te = importlib.import_module("vl-bert_amd.pretrain.train_end2end")
+    cfg = te.load_config(os.path.join(HERE, "fixtures", "pretrain_small.yaml"))
+    cfg["DATASET"] = te.AttrDict.wrap(dict(DATASET="conceptual_captions", DATASET_PATH=FIX, ROOT_PATH=FIX, TRAIN_IMAGE_SET="train",
+                                           ADD_IMAGE_AS_A_BOX=True, SEQ_LEN=24))
+    cfg.NETWORK["PIXEL_MEANS"], cfg.NETWORK["PIXEL_STDS"] = (102.9801, 115.9465, 122.7717), (1.0, 1.0, 1.0)
+    cfg.TRAIN["BATCH_IMAGES"] = 4
+    loader = D.make_dataloader(cfg, mode="train", tokenizer=tok)
+    random.seed(0)
+    torch.manual_seed(0)
+    batches = list(loader)
+    assert [b[1].shape[0] for b in batches] == [4, 2]
+    image, boxes, im_info, text, rel, mlm, ops, soft = batches[0]
+    assert image is None and boxes.shape[2] == 4 + 8 and text.dtype == torch.int64 and soft.shape[:2] == ops.shape
+    assert ((boxes[:, :, 0] > -1.5).sum(1) + (text > 0).sum(1) <= 24).all()
+    # distributed: the ranks' contiguous slices cover the epoch's permutation once (padded by wrap-around)
+    seen = []
+    for r in range(4):
+        s = D.DistributedSampler(loader.dataset, num_replicas=4, rank=r, shuffle=True)
+        s.set_epoch(3)
+        seen += list(s)
+    assert len(seen) == 8 and set(seen) == set(range(6))
+    # multitask: image-caption batches side by side with text-only ones; the short loader restarts
+    corpus = D.GeneralCorpus(os.path.join(FIX, "corpus.doc"), tokenizer=tok, seq_len=16, min_seq_len=12)
+    text_loader = torch.utils.data.DataLoader(corpus, batch_size=5, collate_fn=D.BatchCollator(corpus))
+    multi = D.MultiTaskDataLoader([loader, text_loader])
+    got = list(multi) + list(multi)
+    assert len(got) == 4 and all(len(b) == 10 for b in got) and got[0][8].shape[0] == 5
+
+
+def test_wordpiece_tokenizer_matches_the_reference_tokenizer(golden, tok):
+    _, meta = golden
+    assert len(meta["tokenizer_cases"]) >= 10
+    for text, basic, full in meta["tokenizer_cases"]:
+        assert tok.basic_tokenizer.tokenize(text) == basic, text
+        assert tok.tokenize(text) == full, text
+    assert tok.convert_ids_to_tokens(tok.convert_tokens_to_ids(["[CLS]", "dog", "##s", "[SEP]"])) == ["[CLS]", "dog", "##s", "[SEP]"]
+
+
+def write_dataset(root, n_images=6, feat_dim=2048, classes=1601, seed=3):
+    """A data set in the reference's on-disk layout with full-width detector records (shared with the GPU entry-point test)."""
+    rng = np.random.RandomState(seed)
+    os.makedirs(os.path.join(root, "train_frcnn"), exist_ok=True)
+    with open(os.path.join(FIX, "train_frcnn.json")) as f:
+        captions = [json.loads(line)["caption"] for line in f if line.strip()]
+    with open(os.path.join(root, "train_frcnn.json"), "w") as f:
+        for i in range(n_images):
+            n = 4 + i % 5
+            x1, y1 = rng.uniform(0, 300, n), rng.uniform(0, 200, n)
+            boxes = np.stack((x1, y1, x1 + rng.uniform(20, 200, n), y1 + rng.uniform(20, 150, n)), 1)
+            rec = R.encode_detector_record(boxes, rng.dirichlet(np.ones(classes) * 0.05, n), rng.rand(n, feat_dim), 500, 375)
+            with open(os.path.join(root, "train_frcnn", "%04d.json" % i), "w") as g:
+                json.dump(rec, g)
+            f.write(json.dumps(dict(caption=captions[i % len(captions)], image="train_image.zip@/%04d.jpg" % i,
+                                    frcnn="train_frcnn.zip@/%04d.json" % i)) + "\n")
+    return root
+
+
+def write_config(path, data_root, batch=2, seq_len=32):
+    import yaml
+    with open(os.path.join(HERE, "fixtures", "pretrain_small.yaml")) as f:
+        cfg = yaml.safe_load(f)
+    cfg["DATASET"] = dict(DATASET="conceptual_captions", DATASET_PATH=data_root, ROOT_PATH=data_root, TRAIN_IMAGE_SET="train",
+                          ADD_IMAGE_AS_A_BOX=True, SEQ_LEN=seq_len)
+    cfg["NETWORK"].update(BERT_MODEL_NAME=os.path.join(FIX, "vocab"), PIXEL_MEANS=[102.9801, 115.9465, 122.7717], PIXEL_STDS=[1.0, 1.0, 1.0])
+    cfg["TRAIN"].update(BATCH_IMAGES=batch, GRAD_ACCUMULATE_STEPS=1, SHUFFLE=True)
+    with open(path, "w") as f:
+        yaml.safe_dump(cfg, f)
+    return path
+
+
+def test_train_end2end_resolves_the_data_loaders_of_the_config(tmp_path):
+    te = importlib.import_module("vl-bert_amd.pretrain.train_end2end")
+    root = write_dataset(str(tmp_path / "cc"), feat_dim=16, classes=9)
+    cfg = write_config(str(tmp_path / "cfg.yaml"), root, batch=2)
+    r = te.main(["--cfg", cfg, "--data", "--dry-run"])
+    assert r["steps_per_epoch"] == 3 and r["per_gpu_batch"] == 2 and r["t_total"] == 3

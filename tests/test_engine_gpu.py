@@ -958,6 +958,35 @@ def test_train_end2end_writes_epoch_checkpoints_and_auto_resumes(tmp_path):
     assert abs(float(eng2.adam[0]) - base * O.warmup_linear_lr(5, 4, 20)) < 1e-6 * base
 
 
+def test_train_end2end_reads_the_reference_data_formats(tmp_path):
+    """--data: annotation jsonl + base64 detector records -> dataset -> sampler -> collator -> engine.set_batch -> fused step, through the
+    entry point.  (The readers themselves are pinned bit-exactly to the reference's dataset classes on the CPU: tests/test_data_cpu.py.)"""
+    import json
+    from tests.test_data_cpu import write_config, write_dataset
+    tr = pkg("pretrain.train_end2end")
+    R = pkg("pretrain.data.records")
+    root = write_dataset(str(tmp_path / "cc"))
+    cfg = write_config(str(tmp_path / "cfg.yaml"), root, batch=2, seq_len=32)
+    eng = tr.main(["--cfg", cfg, "--data", "--steps", "4"])        # 3 batches per epoch: the 4th step opens the next epoch
+    torch.cuda.synchronize()
+    lv = eng.loss_values()
+    assert float(eng.adam[5]) == 4.0 and np.isfinite(lv["loss"]) and lv["mlm_loss"] >= 0 and (eng.T, eng.R) == (32, 32)
+    rows = []
+    for i in range(6):
+        with open(os.path.join(root, "train_frcnn", "%04d.json" % i)) as f:
+            rows.append(R.decode_detector_record(json.load(f))["features"])
+    rows = torch.from_numpy(np.concatenate(rows)).to(eng.in_boxes.device)
+    boxes, ops_ = eng.in_boxes.float(), eng.in_mvrc_ops
+    valid = boxes[:, :, 0] > -1.5
+    assert valid[:, 0].all() and int(valid.sum()) >= 2 * 5 and bool((eng.in_text[:, 0] == 5).all())      # whole-image slot; [CLS] = id 5 of the fixture vocabulary
+    assert (boxes[:, 0, :4] == torch.tensor([0.0, 0.0, 799.0, 599.0], device=boxes.device)).all()        # 500 x 375 -> Resize(600, 1000) = 800 x 600
+    for b in range(boxes.shape[0]):
+        for k in range(1, boxes.shape[1]):
+            if valid[b, k]:
+                assert bool((rows == boxes[b, k, 4:]).all(dim=1).any()), (b, k)
+    assert ((valid.sum(1) + (eng.in_text > 0).sum(1)) <= 32).all()
+
+
 def _vqa_config(cfg, classifier, answers, hidden):
     conf = _module_config(cfg)
     conf["NETWORK"].update(BLIND=False, NO_GROUNDING=False, ENABLE_CNN_REG_LOSS=False, CLASSIFIER_TYPE=classifier, CLASSIFIER_DROPOUT=0.1,

@@ -1,7 +1,7 @@
 """Entry point with the reference's command line (pretrain/train_end2end.py:11-48) over the HIP engine:
 
     python -m vl-bert_amd.pretrain.train_end2end --cfg cfgs/pretrain/base_prec_withouttextonly_4x16G_fp32.yaml [--dist]
-           [--steps N] [--steps-per-epoch M] [--batch-images B] [--dry-run]
+           [--steps N] [--steps-per-epoch M] [--batch-images B] [--data] [--dry-run]
 
 It reads the reference's YAML files as they are (the keys of pretrain/function/config.py that the hot path consumes: NETWORK.*,
 TRAIN.{BATCH_IMAGES, LR, WD, CLIP_GRAD_NORM, LR_SCHEDULE, WARMUP, WARMUP_STEPS, END_EPOCH, BEGIN_EPOCH, GRAD_ACCUMULATE_STEPS},
@@ -12,8 +12,9 @@ hyper-parameter conventions:
   * clip_grad_norm_(CLIP_GRAD_NORM), AdamW(betas 0.9/0.999, eps 1e-6, WD, bias-corrected)               (:146-160)
   * one process per GPU with --dist (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* from the launcher; backend nccl = RCCL).
 Checkpoints: with --model-dir the reference's epoch files `{prefix}-{epoch:04d}.model` are written and TRAIN.RESUME / AUTO_RESUME
-honoured (vl-bert_amd/common/checkpoint.py).  What it does NOT reproduce is the data side (pretrain/data/: datasets, tokeniser,
-image decoding -- out of scope): batches are synthetic, in the collated layout of pretrain/data/collate_batch.py.  There is no CPU execution path: without a GPU
+honoured (vl-bert_amd/common/checkpoint.py).  Batches are synthetic by default (the collated layout of pretrain/data/collate_batch.py);
+with --data they come from the data sets the YAML names, read by vl-bert_amd/pretrain/data (the reference's annotation / detector-record /
+corpus formats, its sampling and collation).  There is no CPU execution path: without a GPU
 the program stops with an error unless --dry-run is given, which only resolves and prints the configuration (the "plumbing"
 check of the reference's scripts/nondist_run.sh case).
 """
@@ -83,7 +84,7 @@ def resolve(config, world, args):
         per_gpu_aux = args.batch_images if per_gpu_aux else 0
         per_gpu = args.batch_images
     accum = int(tr.GRAD_ACCUMULATE_STEPS)
-    steps_per_epoch = args.steps_per_epoch
+    steps_per_epoch = args.steps_per_epoch or 10000
     if tr.OPTIMIZER != "AdamW":
         raise NotImplementedError("TRAIN.OPTIMIZER %s: the fused step implements AdamW (every shipped pretrain cfg)" % tr.OPTIMIZER)
     sched = {"triangle": "triangle", "constant": "constant"}.get(tr.LR_SCHEDULE)
@@ -118,15 +119,20 @@ def parse_args(argv=None):
     ap.add_argument("--do-test", action="store_true")
     ap.add_argument("--cudnn-off", action="store_true", help="accepted and ignored (no cuDNN / MIOpen on this path)")
     ap.add_argument("--steps", type=int, default=20, help="optimizer steps to run on synthetic batches")
-    ap.add_argument("--steps-per-epoch", type=int, default=10000, help="stands in for len(train_loader) in the LR schedule")
+    ap.add_argument("--steps-per-epoch", type=int, default=0, help="stands in for len(train_loader) in the LR schedule (default: 10000 "
+                    "with synthetic batches, len(loader) with --data)")
     ap.add_argument("--batch-images", type=int, default=0, help="override TRAIN.BATCH_IMAGES (per GPU)")
-    ap.add_argument("--text-len", type=int, default=64)
-    ap.add_argument("--regions", type=int, default=36)
+    ap.add_argument("--text-len", type=int, default=0, help="text capacity of the step's static buffers (default 64; DATASET.SEQ_LEN with --data)")
+    ap.add_argument("--regions", type=int, default=0, help="box capacity (default 36; DATASET.SEQ_LEN with --data)")
     ap.add_argument("--compute", default="bf16", choices=["bf16", "fp16", "fp32", "cfg"],
                     help="arithmetic of the step.  bf16 (default): bf16 operands, fp32 accumulation / master weights, no loss scaling.  "
                          "fp16: the fp16 build of the library + static loss scale TRAIN.FP16_LOSS_SCALE (the reference's Apex mode, "
                          "pretrain/function/train.py:345-352; 'dynamic' -> 4096).  fp32: every encoder tensor in fp32 (encoder_f32.py), fp16 "
                          "embedding / head kernels around it.  cfg: what the YAML names -- TRAIN.FP16 true -> fp16, false -> fp32")
+    ap.add_argument("--data", action="store_true",
+                    help="read the data sets the YAML names (DATASET.*: annotation jsonl, detector records with base64 boxes / class scores / "
+                         "features, images, text corpora -- vl-bert_amd/pretrain/data) instead of synthetic batches; steps per epoch = "
+                         "len(loader) unless --steps-per-epoch is given; the engine's text / box capacities default to DATASET.SEQ_LEN")
     ap.add_argument("--dry-run", action="store_true", help="resolve and print the configuration, touch no GPU")
     return ap.parse_args(argv)
 
@@ -140,6 +146,28 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1")) if args.dist else 1
     rank = int(os.environ.get("RANK", "0")) if args.dist else 0
     local_rank = int(os.environ.get("LOCAL_RANK", "0")) if args.dist else 0
+    loader = None
+    if args.data:        # the reference's make_dataloader(s) + MultiTaskDataLoader (pretrain/function/train.py:60-66,113-118), one process per GPU
+        data = importlib.import_module(__package__ + ".data")
+        if "DATASET" not in config:
+            raise ValueError("--data: the configuration has no DATASET section")
+        kw = dict(mode="train", distributed=world > 1, num_replicas=world, rank=rank, drop_last=True)      # (static batch: the tail is dropped)
+        if isinstance(config.DATASET, (list, tuple)):
+            if args.batch_images:
+                raise ValueError("--batch-images with a multitask DATASET list: edit TRAIN.BATCH_IMAGES instead")
+            loaders = data.make_dataloaders(config, **kw)
+            loader = data.MultiTaskDataLoader(loaders) if len(loaders) > 1 else loaders[0]
+            seq_len = max(int(d.get("SEQ_LEN", 64)) for d in config.DATASET)
+        else:
+            if args.batch_images:
+                config.TRAIN["BATCH_IMAGES"] = args.batch_images
+            loader = data.make_dataloader(config, **kw)
+            seq_len = int(config.DATASET.get("SEQ_LEN", 64))
+        if len(loader) == 0:
+            raise ValueError("--data: fewer samples than one batch per rank")
+        args.steps_per_epoch = args.steps_per_epoch or len(loader)
+        args.text_len, args.regions = args.text_len or seq_len, args.regions or seq_len
+    args.text_len, args.regions = args.text_len or 64, args.regions or 36
     r = resolve(config, world, args)
     if args.dry_run:
         if rank == 0:
@@ -199,7 +227,42 @@ def main(argv=None):
             eng.broadcast_parameters(src=0)
     first_step = begin_epoch * spe
     t0, seen = time.time(), 0
+    stream = {"it": None, "epoch": begin_epoch}
+
+    def next_real_batch():
+        while True:
+            if stream["it"] is None:
+                for ld in (getattr(loader, "loaders", None) or [loader])[:1]:      # the master loader's sampler follows the epoch (train.py:335)
+                    smp = getattr(getattr(ld, "batch_sampler", None), "sampler", None)
+                    if hasattr(smp, "set_epoch"):
+                        smp.set_epoch(stream["epoch"])
+                stream["it"] = iter(loader)
+            try:
+                return next(stream["it"])
+            except StopIteration:
+                stream["it"], stream["epoch"] = None, stream["epoch"] + 1
+
+    def load_real_batch():
+        batch = next_real_batch()
+        image, boxes, im_info, text, rel, mlm, ops_, soft = batch[:8]
+        if text.shape[1] > T or boxes.shape[1] > R:
+            raise ValueError("batch of %d tokens / %d boxes exceeds the step's capacities (--text-len %d, --regions %d)" % (text.shape[1], boxes.shape[1], T, R))
+        kw = {}
+        if r["multitask"]:
+            kw.update(aux_text=batch[8].cuda(non_blocking=True), aux_mlm_labels=batch[9].cuda(non_blocking=True))
+        if r["e2e"]:
+            Hi, Wi = r["image_size"]
+            if image.shape[2] > Hi or image.shape[3] > Wi:
+                raise ValueError("image batch %dx%d does not fit the step's static %dx%d image buffer (SCALES; portrait images need their own engine)"
+                                 % (image.shape[2], image.shape[3], Hi, Wi))
+            full = torch.zeros((image.shape[0], 3, Hi, Wi), dtype=torch.float32)
+            full[:, :, :image.shape[2], :image.shape[3]] = image
+            kw["image"] = full.cuda(non_blocking=True)      # (raw-pixel masking was done by the dataset, as in the reference)
+        eng.set_batch(*[t.cuda(non_blocking=True) for t in (boxes, im_info, text, rel, mlm, ops_, soft)], **kw)
+
     def load_batch(seed_off):
+        if loader is not None:
+            return load_real_batch()
         batch = list(syn.make_batch(B, T, R, seed=1000 * rank + seed_off))
         kw = {}
         if r["multitask"]:
