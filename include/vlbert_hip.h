@@ -76,7 +76,9 @@ int vlb_gemm_nt_bf16_splitk(const void* A, long lda, const void* B, long ldb, vo
                             float* workspace, long workspace_floats, vlb_stream_t stream);
 /* Run-time tuning knob of the GEMM dispatcher (the environment variables VLB_GEMM_P8* give the defaults): name = "p8_mode"
  * (0: 128x128 kernels only | 1: cost model | 4 / 5: force 256- / 320-row tiles), "p8_keepb", "p8_group", "p8_min_tiles",
- * "tn8_mode" (weight gradients: 0 = 128x128 TN kernel only, 1 = large-tile core where it applies). */
+ * "tn8_mode" (weight gradients: 0 = 128x128 TN kernel only, 1 = large-tile core where it applies); "ln_fwd_rows" (rows per wave of
+ * vlb_layernorm_fwd: 1 / 2 / 4, 0 = by size), "ln_bwd4" (vlb_layernorm_bwd: 0 8-column kernel, 1 4-column, 2 two rows in flight,
+ * 3 software-pipelined for H = 768 / 1024). */
 int vlb_gemm_set_option(const char* name, int value);
 
 

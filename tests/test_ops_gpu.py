@@ -1193,6 +1193,54 @@ def test_error_path_raises(ops):
         ops.cast_f32_bf16(torch.zeros(4), torch.zeros(4, dtype=torch.bfloat16))
 
 
+@pytest.mark.parametrize("rows,H,f16", [(7001, 768, True), (4099, 1024, False), (25856, 768, True), (5, 768, False)])
+def test_layernorm_kernel_variants_agree(ops, rows, H, f16):
+    """The forward with 1 / 2 / 4 rows per wave and the backward in its plain (1), two-rows-in-flight (2) and software-pipelined (3) forms
+    (vlb_gemm_set_option "ln_fwd_rows" / "ln_bwd4"): same arithmetic in the same order per row -> BIT-IDENTICAL y, statistics, dx and
+    dropout-masked dx; the parameter-gradient sums agree to fp32 summation order.  Variant 1 is what test_layernorm_fwd_bwd pins to torch."""
+    lib = pkg("_lib")
+    g = torch.Generator().manual_seed(rows + H)
+    x = (torch.randn(rows, H, generator=g) * 1.5 + 0.3)
+    x = (x.half() if f16 else x.bfloat16()).to(dev())
+    dy = to_gpu_bf16(torch.randn(rows, H, generator=g))
+    gamma, beta = (1 + 0.2 * torch.randn(H, generator=g)).to(dev()), (0.1 * torch.randn(H, generator=g)).to(dev())
+    seed = torch.tensor([777], dtype=torch.int32, device=dev())
+    outs = {}
+    try:
+        for rpw in (1, 2, 4):
+            lib.gemm_set_option("ln_fwd_rows", rpw)
+            y = torch.full((rows, H), 9.0, dtype=torch.bfloat16, device=dev())
+            st = torch.full((rows, 2), 9.0, device=dev())
+            ops.layernorm_fwd(x, gamma, beta, y, st)
+            outs["f%d" % rpw] = (y, st)
+        for k in (2, 4):
+            assert torch.equal(outs["f%d" % k][0], outs["f1"][0]) and torch.equal(outs["f%d" % k][1], outs["f1"][1]), k
+        stats = outs["f1"][1]
+        for mode in (1, 2, 3):
+            lib.gemm_set_option("ln_bwd4", mode)
+            for form in ("both", "dx", "drop"):
+                dx = torch.full((rows, H), 9.0, dtype=torch.bfloat16, device=dev()) if form != "drop" else None
+                dd = torch.full((rows, H), 9.0, dtype=torch.bfloat16, device=dev()) if form != "dx" else None
+                dg, db = torch.zeros(H, device=dev()), torch.zeros(H, device=dev())
+                ws = torch.zeros(ops.ln_bwd_workspace_floats(H), device=dev())
+                ops.layernorm_bwd(dy, x, stats, gamma, dx=dx, dx_drop=dd, drop_p=0.1 if dd is not None else 0.0, seed=seed, tag=3,
+                                  dgamma=dg, dbeta=db, workspace=ws)
+                outs[(mode, form)] = (dx, dd, dg, db)
+        torch.cuda.synchronize()
+        for mode in (2, 3):
+            for form in ("both", "dx", "drop"):
+                a, b = outs[(mode, form)], outs[(1, form)]
+                for t, u in zip(a[:2], b[:2]):
+                    assert (t is None) == (u is None) and (t is None or torch.equal(t, u)), (mode, form)
+                for t, u in zip(a[2:], b[2:]):
+                    assert float((t - u).abs().max()) <= 1e-4 * max(1.0, float(u.abs().max())), (mode, form)
+        d = outs[(3, "both")]
+        assert float((d[1] == 0).float().mean()) > 0.05 and not torch.equal(d[0], d[1])
+    finally:
+        lib.gemm_set_option("ln_fwd_rows", 0)
+        lib.gemm_set_option("ln_bwd4", 1)
+
+
 def test_layernorm_bwd_deferred_parameter_gradients_batched(ops):
     """vlb_layernorm_bwd_deferred + vlb_ln_param_finalize_batch: three LayerNorm backwards leave their partial dgamma / dbeta vectors in
     workspaces of their own and ONE launch adds them into the gradients -- equal (up to fp32 summation order) to the per-call finalize

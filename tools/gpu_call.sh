@@ -12,6 +12,7 @@
 #   small            per-GPU batches 128 / 64 / 32 (strong-scaling columns, no communication)
 #   modes            every secondary bench mode quoted in DESIGN.md §6 (f16, e2e, large, vqa, vqa fp32, vcr f16)
 #   phase            tools/p8_phase_probe.py (in-kernel main-loop / epilogue split of the layer's NT GEMMs)
+#   stream           tools/ln_bench.py: LayerNorm forward / backward variants, squared norm, AdamW, wire cast (the HBM-bound kernels of the step)
 #   hbm              tools/hbm_stream_probe.hip (attainable streaming rates by access pattern: copy / read / fill / the AdamW stream mix)
 #   e2e              config 3 eager / --graph / one vs three weight-gradient side streams     | clock   tools/clock_probe.py
 #   dp2              bench.py --gpus 2 on this box (2 ranks sharing the GPU over gloo; over RCCL where the box has 2 GPUs)
@@ -31,8 +32,8 @@ for what in "$@"; do
     tests:*)  ( time timeout 1500 python -m pytest tests -m gpu -q -k "${what#tests:}" 2>&1 | tail -40 ) > $OUT/tests_subset.log 2>&1; tail -25 $OUT/tests_subset.log ;;
     libtests:*) spec="${what#libtests:}"; d="${spec%%:*}"; k="${spec#*:}"      # libtests:<variant dir>:<-k expr>: parity tests against a saved build
               ( time VLB_LIB_PATH=$ROOT/vl-bert_amd/csrc/$d/libvlbert_hip.so timeout 900 python -m pytest tests -m gpu -q -x -k "$k" 2>&1 | tail -15 ) > $OUT/libtests_$d.log 2>&1; tail -8 $OUT/libtests_$d.log ;;
-    envtests:*) spec="${what#envtests:}"; e="${spec%%:*}"; k="${spec#*:}"       # envtests:<NAME=VALUE>:<-k expr>: a subset under an environment switch
-              ( time env "$e" timeout 900 python -m pytest tests -m gpu -q -x -k "$k" 2>&1 | tail -12 ) > $OUT/envtests.log 2>&1; tail -6 $OUT/envtests.log ;;
+    envtests:*) spec="${what#envtests:}"; e="${spec%%:*}"; k="${spec#*:}"       # envtests:<NAME=VALUE[,NAME=VALUE...]>:<-k expr>: a subset under environment switches
+              ( time env ${e//,/ } timeout 900 python -m pytest tests -m gpu -q -x -k "$k" 2>&1 | tail -12 ) > $OUT/envtests.log 2>&1; tail -6 $OUT/envtests.log ;;
     smoke)    timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE OK')" 2>&1 | tail -3 | tee $OUT/smoke.log ;;
     bench)    timeout 900 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; cut -c1-900 $OUT/bench_default.json; tail -2 $OUT/bench_default.err
               python -c "import json; d=json.load(open('$OUT/bench_default.json')); print('cpu_baseline', d.get('cpu_baseline')); print('other_configs', json.dumps(d.get('other_configs'))[:1500])" ;;
@@ -57,6 +58,7 @@ for what in "$@"; do
               VLB_VISION_WGRAD_STREAMS=1 timeout 400 python bench.py --e2e --no-cpu-baseline --no-phase-times --no-clock-probe 2>/dev/null | line "e2e 1 side stream" | tee -a $OUT/e2e.log
               VLB_VISION_WGRAD_STREAMS=1 timeout 400 python bench.py --e2e --no-cpu-baseline --no-phase-times --no-clock-probe --graph 2>/dev/null | line "e2e 1 side stream --graph" | tee -a $OUT/e2e.log ;;
     phase)    { timeout 200 python tools/p8_phase_probe.py 256; timeout 200 python tools/p8_phase_probe.py 32; } 2>&1 | grep -v amdgpu.ids | tee $OUT/p8_phase_probe.txt ;;
+    stream)   for v in "VLB_LN_BWD4=1 VLB_LN_FWD_ROWS=1" "VLB_LN_BWD4=2 VLB_LN_FWD_ROWS=2" "VLB_LN_BWD4=3 VLB_LN_FWD_ROWS=4"; do env $v timeout 200 python tools/ln_bench.py 25856 768 $( [ "$v" = "VLB_LN_BWD4=1 VLB_LN_FWD_ROWS=1" ] || echo noopt ) 2>&1 | grep -v amdgpu.ids; done | tee $OUT/stream_bench.txt ;;
     hbm)      { hipcc --offload-arch=gfx950 -O3 tools/hbm_stream_probe.hip -o /tmp/hbm_probe && timeout 200 /tmp/hbm_probe; } 2>&1 | tee $OUT/hbm_stream_probe.txt | awk '/GB\/s/ { if ($(NF-1) > best[$1]) { best[$1] = $(NF-1); line[$1] = $0 } } END { for (k in line) print "best", line[k] }' ;;
     clock)    timeout 300 python tools/clock_probe.py 4 2>&1 | grep -v amdgpu.ids | tee $OUT/clock_probe.txt ;;
     graphsmall) for b in 64 32; do timeout 300 python bench.py --no-cpu-baseline --global-batch $b --no-phase-times --graph 2>/dev/null | line "batch $b --graph"; done | tee $OUT/graphsmall.log ;;

@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""LayerNorm backward micro-benchmark (run on the GPU box):  VLB_LN_BWD4=0|1|2 python tools/ln_bench.py [rows] [H]"""
+"""LayerNorm forward / backward micro-benchmark (run on the GPU box):
+VLB_LN_BWD4=0|1|2|3 VLB_LN_FWD_ROWS=1|2|4 python tools/ln_bench.py [rows] [H]      (3 = the software-pipelined backward)"""
 import importlib
 import os
 import sys
@@ -36,3 +37,40 @@ torch.cuda.synchronize()
 us = e0.elapsed_time(e1) / 20 * 1e3
 print("VLB_LN_BWD4=%s rows %d H %d: %.1f us per call (incl. finalize), %.2f TB/s on %d MB" %
       (os.environ.get("VLB_LN_BWD4", "default"), rows, H, us, rows * H * 8 / us / 1e6, rows * H * 8 >> 20))
+runf = lambda: ops.layernorm_fwd(x, gamma, beta, y, stats)
+for _ in range(3):
+    runf()
+e0.record()
+for _ in range(20):
+    runf()
+e1.record()
+torch.cuda.synchronize()
+us = e0.elapsed_time(e1) / 20 * 1e3
+print("VLB_LN_FWD_ROWS=%s rows %d H %d: forward %.1f us per call, %.2f TB/s on %d MB" %
+      (os.environ.get("VLB_LN_FWD_ROWS", "default"), rows, H, us, rows * H * 4 / us / 1e6, rows * H * 4 >> 20))
+
+# the optimizer's streams at the model's size (115 M parameters): squared norm (1 read) and AdamW (4 reads + 3.5 writes per element)
+if len(sys.argv) <= 3 or sys.argv[3] != "noopt":
+    n = 115_000_000
+    P, G, M, V = (torch.zeros(n, device=d) for _ in range(4))
+    G.normal_(generator=torch.Generator(device=d).manual_seed(1))
+    P16 = torch.zeros(n, dtype=torch.bfloat16, device=d)
+    state = torch.tensor([1e-4, 0.9, 0.999, 1e-6, 1e-4, 0.0, 1.0, 0.0], device=d)
+    partials = torch.zeros(4096, device=d)
+
+    def timed(fn, k=10):
+        for _ in range(2):
+            fn()
+        e0.record()
+        for _ in range(k):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / k * 1e3
+    us = timed(lambda: ops.sumsq_det(G, partials, state[7:8]))
+    print("sumsq_det   %d M elements: %.1f us, %.2f TB/s" % (n // 10**6, us, n * 4 / us / 1e6))
+    us = timed(lambda: ops.adamw_step(P, G, M, V, P16, state))
+    print("adamw_step  %d M elements: %.1f us, %.2f TB/s of the 30 B per element" % (n // 10**6, us, n * 30 / us / 1e6))
+    W = torch.zeros(n, dtype=torch.bfloat16, device=d)
+    us = timed(lambda: ops.cast_f32_bf16(G, W))
+    print("cast f32->16 %d M elements: %.1f us, %.2f TB/s" % (n // 10**6, us, n * 6 / us / 1e6))

@@ -851,6 +851,9 @@ static void p8_options_init() {
   g_opt[7] = env_int("VLB_GEMM_P8_DRAIN", 0);      // 1: vmcnt(0) behind every output tile (round-3 behaviour, A/B)
 }
 
+void vlb_ln_set_fwd_rows(int v);      // layernorm.hip
+void vlb_ln_set_bwd4(int v);
+
 extern "C" int vlb_gemm_set_option(const char* name, int value) {
   p8_options_init();
   VLB_CHECK_ARG(name && value >= 0, "vlb_gemm_set_option: null name / negative value");
@@ -868,6 +871,14 @@ extern "C" int vlb_gemm_set_option(const char* name, int value) {
   }
   if (!strcmp(name, "tn8_wgs")) {
     vlb_tn8_set_wgs(value);
+    return VLB_OK;
+  }
+  if (!strcmp(name, "ln_fwd_rows")) {      // (the LayerNorm kernels' variants ride on the same knob)
+    vlb_ln_set_fwd_rows(value);
+    return VLB_OK;
+  }
+  if (!strcmp(name, "ln_bwd4")) {
+    vlb_ln_set_bwd4(value);
     return VLB_OK;
   }
   if (!strcmp(name, "tn8_uneven")) {
