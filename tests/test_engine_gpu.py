@@ -979,7 +979,9 @@ def test_train_end2end_reads_the_reference_data_formats(tmp_path):
     boxes, ops_ = eng.in_boxes.float(), eng.in_mvrc_ops
     valid = boxes[:, :, 0] > -1.5
     assert valid[:, 0].all() and int(valid.sum()) >= 2 * 5 and bool((eng.in_text[:, 0] == 5).all())      # whole-image slot; [CLS] = id 5 of the fixture vocabulary
-    assert (boxes[:, 0, :4] == torch.tensor([0.0, 0.0, 799.0, 599.0], device=boxes.device)).all()        # 500 x 375 -> Resize(600, 1000) = 800 x 600
+    whole = boxes[:, 0, :4].cpu()          # the whole-image box [0, 0, 499, 374] of a 500 x 375 image after Resize(600, 1000) = x 1.6 (flipped or not)
+    assert torch.allclose(whole[:, 2] - whole[:, 0], torch.full((2,), 499 * 1.6), atol=1e-3) and torch.allclose(whole[:, 3], torch.full((2,), 374 * 1.6), atol=1e-3)
+    assert bool((whole[:, 1] == 0).all()) and bool(((whole[:, 0] == 0) | ((whole[:, 0] - 0.6).abs() < 1e-3)).all())
     for b in range(boxes.shape[0]):
         for k in range(1, boxes.shape[1]):
             if valid[b, k]:

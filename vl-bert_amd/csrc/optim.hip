@@ -95,6 +95,30 @@ __global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restric
   if (threadIdx.x == 0) *out += (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
+// One element of the update, with every rounding spelled out: the flat kernel and the ranges kernel of the sharded optimizer must give
+// the SAME BITS for the same element (a rank count must not change the trajectory), and under -ffp-contract=fast two differently shaped
+// loops around the same expression were contracted into different FMA patterns.
+//   g' = coef g ; m = b1 m + (1 - b1) g' ; v = b2 v + (1 - b2) g'^2 ; p -= step_size m / (sqrt(v) + eps) ; p -= lr wd p
+__device__ __forceinline__ void adamw_scalars(const VlbAdamState* st, float grad_scale, float& coef, float& step_size) {
+  const float step = st->step + 1.0f;
+  coef = grad_scale;
+  if (st->max_norm > 0.f) {      // clip_grad_norm_: min(max_norm / (total + 1e-6), 1)
+    const float total = __fmul_rn(__fsqrt_rn(st->sumsq), grad_scale);
+    coef = __fmul_rn(coef, fminf(__fdiv_rn(st->max_norm, __fadd_rn(total, 1e-6f)), 1.0f));
+  }
+  step_size = __fdiv_rn(__fmul_rn(st->lr, __fsqrt_rn(1.0f - powf(st->beta2, step))), 1.0f - powf(st->beta1, step));      // bias correction
+}
+
+__device__ __forceinline__ void adamw_update(float& p, float g, float& m, float& v, float coef, float b1, float b2, float eps,
+                                             float step_size, float lr_wd) {
+  const float gg = __fmul_rn(g, coef);
+  m = __fmaf_rn(m, b1, __fmul_rn(1.0f - b1, gg));
+  v = __fmaf_rn(v, b2, __fmul_rn(__fmul_rn(1.0f - b2, gg), gg));
+  const float denom = __fadd_rn(__fsqrt_rn(v), eps);
+  p = __fmaf_rn(-step_size, __fdiv_rn(m, denom), p);
+  if (lr_wd > 0.f) p = __fmaf_rn(-lr_wd, p, p);
+}
+
 // One-shot grid: every lane owns ADAMW_UNITS 16-B units per stream (units 4 KiB apart, so a block touches ADAMW_UNITS consecutive 4-KiB
 // lines of every stream) and all its loads are in flight before the first use.  Measured on MI355X (tools/hbm_stream_probe.hip, the same
 // stream mix on 115 M elements): 6.43 TB/s in this form against 5.88 for the 2048-block grid-stride loop this kernel used to be (writes
@@ -106,13 +130,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
                                                     float* __restrict__ v, bf16_t* __restrict__ p16, long n, VlbAdamState* __restrict__ st,
                                                     float grad_scale) {
   const float lr = st->lr, b1 = st->beta1, b2 = st->beta2, eps = st->eps, wd = st->weight_decay;
-  const float step = st->step + 1.0f;
-  float coef = grad_scale;
-  if (st->max_norm > 0.f) {
-    const float total = sqrtf(st->sumsq) * grad_scale;
-    coef *= fminf(st->max_norm / (total + 1e-6f), 1.0f);
-  }
-  const float step_size = lr * sqrtf(1.0f - powf(b2, step)) / (1.0f - powf(b1, step));
+  float coef, step_size;
+  adamw_scalars(st, grad_scale, coef, step_size);
   const long i0 = ((long)blockIdx.x * (256 * ADAMW_UNITS) + threadIdx.x) * 4;
   float pv[ADAMW_UNITS][4], gv[ADAMW_UNITS][4], mv[ADAMW_UNITS][4], vv[ADAMW_UNITS][4];
 #pragma unroll
@@ -136,14 +155,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   for (int u = 0; u < ADAMW_UNITS; ++u) {
     const long i = i0 + (long)u * 1024;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float gg = gv[u][k] * coef;
-      mv[u][k] = mv[u][k] * b1 + (1.0f - b1) * gg;
-      vv[u][k] = vv[u][k] * b2 + (1.0f - b2) * gg * gg;
-      const float denom = sqrtf(vv[u][k]) + eps;
-      pv[u][k] -= step_size * (mv[u][k] / denom);
-      if (wd > 0.f) pv[u][k] -= lr * wd * pv[u][k];
-    }
+    for (int k = 0; k < 4; ++k) adamw_update(pv[u][k], gv[u][k], mv[u][k], vv[u][k], coef, b1, b2, eps, step_size, lr * wd);
     if (i + 3 < n) {
       vlb_store_nt((float4*)(p + i), make_float4(pv[u][0], pv[u][1], pv[u][2], pv[u][3]));
       vlb_store_nt((float4*)(m + i), make_float4(mv[u][0], mv[u][1], mv[u][2], mv[u][3]));
@@ -213,12 +225,20 @@ __global__ void lr_schedule_kernel(VlbAdamState* st, int kind, float base_lr, fl
   st->lr = base_lr * f;
 }
 
+// (one-shot grid, two 16-B units per lane in flight: see adamw_kernel)
 __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, long n) {
-  const long stride = (long)gridDim.x * 256 * 4;
-  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+  const long i0 = ((long)blockIdx.x * 512 + threadIdx.x) * 4;
+  float4 a[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const long i = i0 + u * 1024;
+    a[u] = i + 3 < n ? *(const float4*)(in + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const long i = i0 + u * 1024;
     if (i + 3 < n) {
-      const float4 a = *(const float4*)(in + i);
-      *(uint2*)(out + i) = make_uint2(pack2bf(a.x, a.y), pack2bf(a.z, a.w));
+      *(uint2*)(out + i) = make_uint2(pack2bf(a[u].x, a[u].y), pack2bf(a[u].z, a[u].w));
     } else {
       for (long k = i; k < n; ++k) out[k] = f2bf(in[k]);
     }
@@ -358,13 +378,8 @@ __global__ __launch_bounds__(256) void adamw_ranges_kernel(float* __restrict__ p
                                                            const long* __restrict__ ranges, const int* __restrict__ block_start, int n,
                                                            int chunk, const VlbAdamState* __restrict__ st, float grad_scale) {
   const float lr = st->lr, b1 = st->beta1, b2 = st->beta2, eps = st->eps, wd = st->weight_decay;
-  const float step = st->step + 1.0f;
-  float coef = grad_scale;
-  if (st->max_norm > 0.f) {
-    const float total = sqrtf(st->sumsq) * grad_scale;
-    coef *= fminf(st->max_norm / (total + 1e-6f), 1.0f);
-  }
-  const float step_size = lr * sqrtf(1.0f - powf(b2, step)) / (1.0f - powf(b1, step));
+  float coef, step_size;
+  adamw_scalars(st, grad_scale, coef, step_size);
   const int r = range_of_block(block_start, n, blockIdx.x);
   const long p0 = ranges[3 * r], g0 = ranges[3 * r + 1], len = ranges[3 * r + 2];
   const long base = (long)(blockIdx.x - block_start[r]) * chunk;
@@ -387,14 +402,7 @@ __global__ __launch_bounds__(256) void adamw_ranges_kernel(float* __restrict__ p
       }
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float gg = gv[k] * coef;
-      mv[k] = mv[k] * b1 + (1.0f - b1) * gg;
-      vv[k] = vv[k] * b2 + (1.0f - b2) * gg * gg;
-      const float denom = sqrtf(vv[k]) + eps;
-      pv[k] -= step_size * (mv[k] / denom);
-      if (wd > 0.f) pv[k] -= lr * wd * pv[k];
-    }
+    for (int k = 0; k < 4; ++k) adamw_update(pv[k], gv[k], mv[k], vv[k], coef, b1, b2, eps, step_size, lr * wd);
     if (cnt == 4) {
       vlb_store_nt((float4*)(p + p0 + i), make_float4(pv[0], pv[1], pv[2], pv[3]));
       vlb_store_nt((float4*)(m + p0 + i), make_float4(mv[0], mv[1], mv[2], mv[3]));
@@ -462,7 +470,7 @@ extern "C" int vlb_lr_schedule_step(float* state, int kind, float base_lr, float
 
 extern "C" int vlb_cast_f32_bf16(const float* in, void* out, long n, hipStream_t stream) {
   if (n <= 0) return VLB_OK;
-  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, stream, in, (bf16_t*)out, n);
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)((n + 2047) / 2048)), dim3(256), 0, stream, in, (bf16_t*)out, n);
   VLB_CHECK_LAUNCH("vlb_cast_f32_bf16");
   return VLB_OK;
 }
