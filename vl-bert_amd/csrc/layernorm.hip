@@ -492,13 +492,20 @@ __device__ __forceinline__ void ln_raw_load_row_asm(const bf16_t* x, int lane, R
 #pragma unroll
   for (int i = 0; i < NIT; ++i) ln_gload2(q.w[i], x + (lane + 64 * i) * 4);
 }
-// every 8-B register pair loaded above is an in / out operand of the wait: their uses cannot be scheduled in front of it
+// The wait that retires them.  The row registers are in / out operands (their uses -- the decode right behind -- cannot be scheduled in
+// front of it).  The row statistics live until the end of the iteration, i.e. beyond the point where the NEXT prefetch reuses their
+// landing registers: they are MOVED out inside the same asm statement, behind the wait (as a tied in / out operand hipcc copied them to
+// other registers IN FRONT of the wait -- stale values from the second iteration on).
 template <int AHEAD, int NIT>
-__device__ __forceinline__ void ln_wait_rows(Raw4<NIT>& a, Raw4<NIT>& b, uint2& c) {
+__device__ __forceinline__ void ln_wait_rows(Raw4<NIT>& a, Raw4<NIT>& b, const uint2& c, float& mean, float& rstd) {
   if constexpr (NIT == 3)
-    asm volatile("s_waitcnt vmcnt(%7)" : "+v"(a.w[0]), "+v"(a.w[1]), "+v"(a.w[2]), "+v"(b.w[0]), "+v"(b.w[1]), "+v"(b.w[2]), "+v"(c) : "n"(AHEAD) : "memory");
+    asm volatile("s_waitcnt vmcnt(%10)\n\tv_mov_b32 %6, %8\n\tv_mov_b32 %7, %9"
+                 : "+v"(a.w[0]), "+v"(a.w[1]), "+v"(a.w[2]), "+v"(b.w[0]), "+v"(b.w[1]), "+v"(b.w[2]), "=&v"(mean), "=&v"(rstd)
+                 : "v"(c.x), "v"(c.y), "n"(AHEAD) : "memory");
   else if constexpr (NIT == 4)
-    asm volatile("s_waitcnt vmcnt(%9)" : "+v"(a.w[0]), "+v"(a.w[1]), "+v"(a.w[2]), "+v"(a.w[3]), "+v"(b.w[0]), "+v"(b.w[1]), "+v"(b.w[2]), "+v"(b.w[3]), "+v"(c) : "n"(AHEAD) : "memory");
+    asm volatile("s_waitcnt vmcnt(%12)\n\tv_mov_b32 %8, %10\n\tv_mov_b32 %9, %11"
+                 : "+v"(a.w[0]), "+v"(a.w[1]), "+v"(a.w[2]), "+v"(a.w[3]), "+v"(b.w[0]), "+v"(b.w[1]), "+v"(b.w[2]), "+v"(b.w[3]), "=&v"(mean), "=&v"(rstd)
+                 : "v"(c.x), "v"(c.y), "n"(AHEAD) : "memory");
   else
     static_assert(NIT == 3 || NIT == 4, "pipelined LayerNorm backward: H = 768 / 1024");
 }
@@ -554,11 +561,11 @@ __global__ __launch_bounds__(256, (NIT <= 3 ? 4 : 3)) void layernorm_bwd4p_kerne
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // first row: nothing was issued behind these loads (the loop's wait counts the stores)
   }
   for (; row < rows; row += step) {
-    ln_wait_rows<STORES, NIT>(qx, qd, msw);      // the row prefetched by the previous iteration has landed; that iteration's stores may still be in flight
+    float mean, rstd;
+    ln_wait_rows<STORES, NIT>(qx, qd, msw, mean, rstd);      // the row prefetched by the previous iteration has landed; that iteration's stores may still be in flight
     Row4<NIT> xr, dyr;
     decode_row_full(qd, dyr, false);
     decode_row_full(qx, xr, x_f16 != 0);
-    const float mean = __uint_as_float(msw.x), rstd = __uint_as_float(msw.y);
     {      // the next row of this wave (clamped: the last iteration re-reads the last row of the tensor)
       const int rn = min(row + step, rows - 1);
       ln_raw_load_row_asm(x + (long)rn * ldx, lane, qx);

@@ -50,9 +50,8 @@ __device__ __forceinline__ float4 load_grad4(const bf16_t* g, long i) {
 __device__ __forceinline__ float load_grad1(const float* g, long i) { return g[i]; }
 __device__ __forceinline__ float load_grad1(const bf16_t* g, long i) { return bf2f(g[i]); }
 
-// (four 16-B units per lane and iteration in flight, streaming loads: 7.0 TB/s against 6.3 for one plain load per iteration,
-// tools/hbm_stream_probe.hip "read")
-__device__ __forceinline__ float4 load_grad4_stream(const float* g, long i) { return vlb_load_nt((const float4*)(g + i)); }
+// (four 16-B units per lane and iteration in flight; plain loads: the gradient was written a moment ago and is read again by AdamW)
+__device__ __forceinline__ float4 load_grad4_stream(const float* g, long i) { return load_grad4(g, i); }
 __device__ __forceinline__ float4 load_grad4_stream(const bf16_t* g, long i) { return load_grad4(g, i); }
 
 template <typename GT>
