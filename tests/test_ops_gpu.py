@@ -1247,7 +1247,7 @@ def test_layernorm_kernel_variants_agree(ops, rows, H, f16):
         assert float((d[1] == 0).float().mean()) > 0.05 and not torch.equal(d[0], d[1])
     finally:
         lib.gemm_set_option("ln_fwd_rows", 0)
-        lib.gemm_set_option("ln_bwd4", 1)
+        lib.gemm_set_option("ln_bwd4", 3)
 
 
 def test_layernorm_bwd_deferred_parameter_gradients_batched(ops):

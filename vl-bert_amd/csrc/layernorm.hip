@@ -673,7 +673,7 @@ __global__ __launch_bounds__(256) void ln_param_finalize_kernel(const float* __r
 // rows per wave of the forward: VLB_LN_FWD_ROWS = 1 | 2 | 4 (0 / unset: 2 where at least two full rounds of single-row waves exist);
 // run-time override for A/B measurements and tests: vlb_gemm_set_option("ln_fwd_rows", v) / ("ln_bwd4", v)
 static int g_ln_fwd_rows = -1;
-static int g_ln_bwd4 = -1;      // VLB_LN_BWD4: 1 (default) the 4-column kernel (2: two rows in flight at H = 768 / 1024; 3: software-pipelined); 0 the 8-column kernel
+static int g_ln_bwd4 = -1;      // VLB_LN_BWD4: 3 (default) = 1 + the software-pipelined form where it applies (H = 768 / 1024, 16-bit dy, no dx_acc); 1 the 4-column kernel; 2: two rows in flight at H = 768 / 1024; 0 the 8-column kernel
 void vlb_ln_set_fwd_rows(int v) { g_ln_fwd_rows = v; }
 void vlb_ln_set_bwd4(int v) { g_ln_bwd4 = v; }
 
@@ -752,7 +752,7 @@ static int ln_bwd_impl(const void* dy, long lddy, int dy_f32, const void* x, lon
   VLB_CHECK_ARG((long)rows * H < (1L << 32) || !(drop_p > 0.f), "vlb_layernorm_bwd: dropout index overflow");
   if (g_ln_bwd4 < 0) {
     const char* v = getenv("VLB_LN_BWD4");
-    g_ln_bwd4 = v ? atoi(v) : 1;
+    g_ln_bwd4 = v ? atoi(v) : 3;
   }
   const int blocks = ln_bwd_blocks(rows);
   float* ws = (workspace && (dgamma || dbeta) && blocks > 32) ? workspace : nullptr;
@@ -872,7 +872,7 @@ extern "C" int vlb_ln_param_finalize_batch(int n, const float* const* ws, const 
   VLB_CHECK_ARG(H > 0 && (H % 8) == 0 && H <= 2048, "vlb_ln_param_finalize_batch: unsupported H=%d", H);
   if (g_ln_bwd4 < 0) {
     const char* v = getenv("VLB_LN_BWD4");
-    g_ln_bwd4 = v ? atoi(v) : 1;
+    g_ln_bwd4 = v ? atoi(v) : 3;
   }
   LnFinalizeBatch b;
   for (int i = 0; i < n; ++i) {
