@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """The grouped weight-gradient launch of one encoder layer (vlb_wgrad_tn_group_bf16: QKV, attention output, FFN1, FFN2 over the same
-R rows) with and without the bias-gradient column sums, and per member: does the column-sum work that only some waves of some tiles
-do set the launch's makespan?   python tools/wgrad_group_bench.py [batch]"""
+R rows) with and without the bias-gradient column sums, and per member.  Measured in BOTH orders: the first timed loops of a fresh process
+run 10-20 % slow (clock / power ramp), which once read as "the column sums cost 16 %" -- in steady state they cost ~3 %.
+python tools/wgrad_group_bench.py [batch]"""
 import importlib, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -33,7 +34,8 @@ shapes = [("qkv", 2304, 768), ("out", 768, 768), ("ffn1", 3072, 768), ("ffn2", 7
 M = [member(mo, no) for _, mo, no in shapes]
 ws = torch.empty(2 * sum(mo * no for _, mo, no in shapes) + 1024, device=d)
 flops = 2.0 * R * sum(mo * no for _, mo, no in shapes)
-for label, items in (("with column sums", [(a, b, c, s) for a, b, c, s in M]), ("without", [(a, b, c, None) for a, b, c, s in M])):
+with_cs, without = [(a, b, c, s) for a, b, c, s in M], [(a, b, c, None) for a, b, c, s in M]
+for label, items in (("without", without), ("with column sums", with_cs), ("without", without), ("with column sums", with_cs)):      # (both orders)
     us = t(lambda: ops.wgrad_tn_group(items, workspace=ws, accumulate=False))
     print("layer group, batch %d, %-17s: %7.1f us  %7.1f TFLOP/s" % (B, label, us, flops / us / 1e6))
 for (name, mo, no), (a, b, c, s) in zip(shapes, M):

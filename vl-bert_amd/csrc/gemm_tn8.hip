@@ -11,12 +11,8 @@
 //   * few output tiles and a very long reduction: the work items of a launch are (tile, K slice) pairs, every slice writes its fp32
 //     partial tile to a slab (plain 16-B stores) and a streaming reduce adds the slabs (gemm.hip: splitk_reduce_kernel).  Items
 //     are ordered slice-major (all tiles of a slice are concurrent and share their operand rows in L2).
-// The column sums of A (bias gradients) are taken from the A fragments with v_dot2c_f32_bf16 behind the MFMAs of the phase that holds
-// them -- by EVERY wave of EVERY tile, each for a share: the four waves of a wave row hold the same A fragments and take one 16-column
-// sub-fragment each, and the ntn tiles of a tile row (same A columns) take every ntn-th K tile each; fp32 atomics add the shares.
-// (Round 3 had the wn = 0 waves of the tile_n = 0 tiles do all of it: 32 dependent v_dot2c per phase on two waves of a quarter of the
-// workgroups -- and since one launch is one round of concurrent items, those workgroups set its duration: 438 vs 367 us per layer
-// with / without bias gradients, tools/wgrad_group_bench.py.)
+// The column sums of A (bias gradients) are accumulated by the wn = 0 waves of the tile_n = 0 tiles from the A fragments with
+// v_dot2c_f32_bf16 behind the MFMAs of the phase that holds them.
 #include <math.h>
 #include <stdlib.h>
 
@@ -213,7 +209,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(const Tn8Group grp, co
   // ---------------- consumer ----------------
   f32x4 acc[8][4];
   s16x4 alo[4][2], ahi[4][2], blo[2][2], bhi[2][2];
-  float csum[2] = {0.f, 0.f};      // column sums of this wave's share: A half h, sub-fragment wn
+  float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const int L = lane & 15, g = lane >> 4;
   const int fl = (L >> 2) | ((g & 1) << 2);
   const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(smem);
@@ -267,21 +263,19 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(const Tn8Group grp, co
                                                                                 acc[HA * 4 + i][HB_ * 2 + j], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
     if constexpr (CS) {
-      if (do_colsum) {      // wave-uniform; this wave's sub-fragment i == wn: 8 v_dot2c behind the MFMAs of this quadrant
+      if (do_colsum) {      // wave-uniform; 32 v_dot2c behind the MFMAs of this quadrant
         const bf16x2_t one = {(vlb_h16)1.0f, (vlb_h16)1.0f};
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-          if (wn == i) {
-            float s = csum[HA];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-              const uint2 l = __builtin_bit_cast(uint2, alo[i][ks]), h = __builtin_bit_cast(uint2, ahi[i][ks]);
-              s = VLB_FDOT2(__builtin_bit_cast(bf16x2_t, l.x), one, s, false);
-              s = VLB_FDOT2(__builtin_bit_cast(bf16x2_t, l.y), one, s, false);
-              s = VLB_FDOT2(__builtin_bit_cast(bf16x2_t, h.x), one, s, false);
-              s = VLB_FDOT2(__builtin_bit_cast(bf16x2_t, h.y), one, s, false);
-            }
-            csum[HA] = s;
+          for (int ks = 0; ks < 2; ++ks) {
+            const uint2 l = __builtin_bit_cast(uint2, alo[i][ks]), h = __builtin_bit_cast(uint2, ahi[i][ks]);
+            float s = csum[HA * 4 + i];
+            s = VLB_FDOT2(__builtin_bit_cast(bf16x2_t, l.x), one, s, false);
+            s = VLB_FDOT2(__builtin_bit_cast(bf16x2_t, l.y), one, s, false);
+            s = VLB_FDOT2(__builtin_bit_cast(bf16x2_t, h.x), one, s, false);
+            s = VLB_FDOT2(__builtin_bit_cast(bf16x2_t, h.y), one, s, false);
+            csum[HA * 4 + i] = s;
           }
       }
     }
@@ -306,19 +300,15 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(const Tn8Group grp, co
     int gi, m0, n0, kt0, nk;
     item_of(w, gi, m0, n0, kt0, nk);
     float* const colsum = D(gi).colsum;
-    // K tile k of this item's range belongs to the tile with (k mod ntn) == its tile column: cs_turn counts up to that tile's turn
-    const int cs_ntn = D(gi).ntn;
-    int cs_turn = colsum ? ((kt0 % cs_ntn) + cs_ntn - (n0 >> 8) % cs_ntn) % cs_ntn : -1;      // 0: the K tile at hand is this tile's; -1: no column sums
-    csum[0] = csum[1] = 0.f;
+    do_colsum = (colsum != nullptr) && (n0 == 0) && (wn == 0);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
+      csum[i] = 0.f;
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     for (int kt = 0; kt < nk; kt += 2, gk += 2) {
       // ======== K tile gk (buffer 0): quadrants (0,0) (0,1) (1,1) (1,0) ========
-      do_colsum = cs_turn == 0;
-      if (cs_turn >= 0 && ++cs_turn == cs_ntn) cs_turn = 0;
       read_b(I0{}, I0{});
       __builtin_amdgcn_sched_barrier(0);
       read_a(I0{}, I0{});
@@ -345,8 +335,6 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(const Tn8Group grp, co
       compute(I1{}, I0{}, F{});
       tn8_barrier();
       // ======== K tile gk+1 (buffer 1) ========
-      do_colsum = cs_turn == 0;
-      if (cs_turn >= 0 && ++cs_turn == cs_ntn) cs_turn = 0;
       read_b(I1{}, I0{});
       __builtin_amdgcn_sched_barrier(0);
       read_a(I1{}, I0{});
@@ -408,13 +396,13 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(const Tn8Group grp, co
           }
         }
       }
-      if (colsum) {      // per-lane partial sums cover k = 8 g + [0, 8) of every k-step: reduce over the 4 lane groups
+      if (do_colsum) {      // per-lane partial sums cover k = 8 g + [0, 8) of every k-step: reduce over the 4 lane groups
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          float v = csum[h];
+        for (int R_ = 0; R_ < 8; ++R_) {
+          float v = csum[R_];
           v += __shfl_xor(v, 16, 64);
           v += __shfl_xor(v, 32, 64);
-          const int m = m0 + h * 128 + wm * 64 + wn * 16 + L;
+          const int m = m0 + (R_ >> 2) * 128 + wm * 64 + (R_ & 3) * 16 + L;
           if (g == 0 && m < D(gi).Mo) atomicAdd(colsum + m, v);
         }
       }
