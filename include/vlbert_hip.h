@@ -77,8 +77,7 @@ int vlb_gemm_nt_bf16_splitk(const void* A, long lda, const void* B, long ldb, vo
 /* Run-time tuning knob of the GEMM dispatcher (the environment variables VLB_GEMM_P8* give the defaults): name = "p8_mode"
  * (0: 128x128 kernels only | 1: cost model | 4 / 5: force 256- / 320-row tiles), "p8_keepb", "p8_group", "p8_min_tiles",
  * "tn8_mode" (weight gradients: 0 = 128x128 TN kernel only, 1 = large-tile core where it applies); "ln_fwd_rows" (rows per wave of
- * vlb_layernorm_fwd: 1 / 2 / 4, 0 = by size), "ln_bwd4" (vlb_layernorm_bwd: 0 8-column kernel, 1 4-column, 2 two rows in flight,
- * 3 software-pipelined for H = 768 / 1024). */
+ * vlb_layernorm_fwd: 1 / 2 / 4, 0 = by size), "ln_bwd4" (vlb_layernorm_bwd: 0 8-column kernel, 1 4-column, 2 two rows in flight). */
 int vlb_gemm_set_option(const char* name, int value);
 
 
@@ -431,6 +430,13 @@ int vlb_gemm_nt_f32(const float* A, long lda, const float* B, long ldb, float* C
                     long sA1, long sA2, long sB1, long sB2, long sC1, long sC2, const float* bias, long sBias1, float alpha, int epi,
                     const float* aux, long ldaux, float* pre, long ldpre, const float* res, long ldres, float drop_p,
                     const uint32_t* seed, uint32_t tag, int atomic, int splitk, vlb_stream_t stream);
+/* C[Mo,No] (+)= alpha * A[R,Mo]^T . B[R,No]: the same split products with the reduction over the ROWS of two row-major fp32 operands --
+ * weight gradients dW = dY^T X (autograd's grad_output.t().mm(input) behind every nn.Linear, external/pytorch_pretrained_bert/modeling.py:
+ * 268-397 in fp32) and the attention products P^T dO / dS^T Q without transposed copies.  No % 4 == 0; operand rows are read in whole 8-column chunks (lda >= Mo rounded up to 8, ldb likewise);
+ * atomic: accumulate into C (splitk K slices allowed), colsum (nullable, unbatched): += column sums of A (the bias gradient). */
+int vlb_gemm_tn_f32(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int R, int Mo, int No, int nb1, int nb2,
+                    long sA1, long sA2, long sB1, long sB2, long sC1, long sC2, float alpha, int atomic, int splitk, float* colsum,
+                    vlb_stream_t stream);
 int vlb_transpose_f32(const float* src, long lds, float* dst, long ldd, int R, int C, int Rp, int nb1, int nb2, long sS1, long sS2,
                       long sD1, long sD2, float* colsum, vlb_stream_t stream);
 int vlb_layernorm_f32_fwd(const float* x, long ldx, const float* gamma, const float* beta, float* y, long ldy, float* stats, int rows,

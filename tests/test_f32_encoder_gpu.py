@@ -100,6 +100,81 @@ def test_gemm_f32_batched_strided_heads_and_transpose():
     assert _rel(cs, x.double().sum(0) + 1.0) < 1e-6
 
 
+@pytest.mark.parametrize("R,Mo,No", [(64, 128, 128), (229, 229, 64), (3664, 1024, 256), (1000, 200, 136), (33, 8, 4)])
+def test_gemm_tn_f32_row_reduction_products(R, Mo, No):
+    """vlb_gemm_tn_f32: C = alpha A^T B with the reduction over the ROWS of two row-major fp32 operands (weight gradients, P^T dO, dS^T Q):
+    fp32-class against fp64 torch -- overwrite, accumulate with one and several K slices, column sums of A, R not a multiple of 32,
+    Mo not a multiple of 8 (operand columns beyond Mo hold garbage that must only reach masked outputs)."""
+    ops = pkg("ops")
+    g = torch.Generator().manual_seed(R + Mo + No)
+    lda, ldb = (Mo + 7) // 8 * 8 + 8, (No + 7) // 8 * 8
+    A = torch.randn(R, lda, generator=g) * 3.0            # (columns >= Mo: garbage the kernel may read)
+    B = torch.randn(R, ldb, generator=g) * 0.05
+    A[:, Mo:] = 1e30
+    Ag, Bg = A.to(dev()), B.to(dev())
+    ref = A[:, :Mo].double().t() @ B[:, :No].double()
+    ldc = No + 4
+    C = torch.full((Mo + 3, ldc), 7.0, device=dev())
+    ops.gemm_tn_f32(Ag, lda, Bg, ldb, C, ldc, R, Mo, No)
+    e = _rel(C[:Mo, :No], ref)
+    print("gemm_tn_f32 R=%d %dx%d plain: max rel err %.2e" % (R, Mo, No, e))
+    assert e < 2e-5
+    assert float((C[Mo:] - 7.0).abs().max()) == 0.0 and float((C[:, No:] - 7.0).abs().max()) == 0.0      # nothing outside the product is touched
+    e16 = _rel(A[:, :Mo].bfloat16().double().t() @ B[:, :No].bfloat16().double(), ref)
+    assert e16 > 20 * e or R < 64
+    cs = torch.ones(Mo, device=dev())
+    C.fill_(1.0)
+    ops.gemm_tn_f32(Ag, lda, Bg, ldb, C, ldc, R, Mo, No, alpha=0.5, atomic=True, colsum=cs)
+    assert _rel(C[:Mo, :No], 0.5 * ref + 1.0) < 2e-5
+    assert _rel(cs, A[:, :Mo].double().sum(0) + 1.0) < 1e-5
+    C.fill_(-2.0)
+    cs.zero_()
+    ops.gemm_tn_f32(Ag, lda, Bg, ldb, C, ldc, R, Mo, No, atomic=True, splitk=3, colsum=cs)
+    assert _rel(C[:Mo, :No], ref - 2.0) < 2e-5 and _rel(cs, A[:, :Mo].double().sum(0)) < 1e-5
+
+
+def test_gemm_tn_f32_batched_attention_products():
+    """dV = Pd^T dO and dK = dS^T Q / 8 per (sample, head) straight from the [S, Sp] probability matrices and the [B*S, 3H] / [B*S, H] buffers."""
+    ops = pkg("ops")
+    Bt, nh, S, Sp, H = 2, 3, 45, 64, 192
+    g = torch.Generator().manual_seed(5)
+    pd = torch.randn(Bt * nh * S, Sp, generator=g)
+    do = torch.randn(Bt * S, H, generator=g)
+    qkv = torch.randn(Bt * S + Sp, 3 * H, generator=g)
+    dqkv = torch.full((Bt * S + Sp, 3 * H), 5.0, device=dev())
+    ops.gemm_tn_f32(pd.to(dev()), Sp, do.to(dev()), H, (dqkv, 2 * H), 3 * H, S, S, 64, batch=(Bt, nh), sA=(nh * S * Sp, S * Sp), sB=(S * H, 64),
+                    sC=(S * 3 * H, 64))
+    ops.gemm_tn_f32(pd.to(dev()), Sp, qkv.to(dev()), 3 * H, (dqkv, H), 3 * H, S, S, 64, batch=(Bt, nh), sA=(nh * S * Sp, S * Sp),
+                    sB=(S * 3 * H, 64), sC=(S * 3 * H, 64), alpha=0.125)
+    for b in range(Bt):
+        for h in range(nh):
+            P = pd[(b * nh + h) * S:(b * nh + h + 1) * S, :S].double()
+            dv = P.t() @ do[b * S:(b + 1) * S, h * 64:(h + 1) * 64].double()
+            dk = 0.125 * P.t() @ qkv[b * S:(b + 1) * S, h * 64:(h + 1) * 64].double()
+            assert _rel(dqkv[b * S:(b + 1) * S, 2 * H + h * 64:2 * H + (h + 1) * 64], dv) < 2e-5, (b, h)
+            assert _rel(dqkv[b * S:(b + 1) * S, H + h * 64:H + (h + 1) * 64], dk) < 2e-5, (b, h)
+    assert float((dqkv[:, :H] - 5.0).abs().max()) == 0.0 and float((dqkv[Bt * S:] - 5.0).abs().max()) == 0.0
+
+
+def test_fp32_encoder_row_reduction_form_matches_the_transposed_form():
+    """The backward with vlb_gemm_tn_f32 (default) against round 3's transposes + NT products: same gradients to fp32 summation order."""
+    E, syn = pkg("engine"), pkg("synthetic")
+    grads = []
+    for tn in (True, False):
+        mc = E.ModelConfig(num_hidden_layers=2)
+        eng = E.PretrainEngine(mc, 3, 32, 10, device="cuda:0", train=False, seed=5, encoder_fp32=True)
+        eng.enc32.tn = tn
+        eng.init_random(seed=1, visual_ln_init=1.0)
+        eng.set_batch(*[t.to(dev()) for t in syn.make_batch(3, 32, 10, seed=9, ragged=True)])
+        eng.zero_grad()
+        eng.forward(False)
+        eng.backward(False)
+        torch.cuda.synchronize()
+        grads.append(eng.P.grad.clone())
+    scale = float(grads[1].abs().max())
+    assert scale > 0 and float((grads[0] - grads[1]).abs().max()) <= 2e-5 * scale
+
+
 @pytest.mark.parametrize("rows,H", [(37, 768), (200, 1024), (9, 64)])
 def test_layernorm_f32_fwd_bwd(rows, H):
     ops = pkg("ops")

@@ -72,39 +72,6 @@ def test_layernorm_rows_are_loaded_in_one_burst(layernorm):
     assert bwd1024["vgpr"] <= 168 and bwd1024["spill"] == 0 and L.serialized_loads(bwd1024["body"]) == 0
 
 
-def test_pipelined_layernorm_backward_never_touches_a_row_in_flight(layernorm):
-    """layernorm_bwd4p_kernel prefetches the next row with loads the compiler does not track (inline asm) and retires them with ONE explicit
-    counted wait at the loop header.  That is only sound if (a) the loop's loads land in the SAME registers as the prologue's (otherwise
-    hipcc shuffles them with v_mov on the back edge -- before the data has arrived), (b) nothing reads a landing register between its load
-    and the wait: the only moves out of landing registers are the two inside the wait's own asm statement, BEHIND the s_waitcnt (the row
-    statistics; as a tied operand they were copied in front of it once: stale statistics from the second row on), (c) the loop waits
-    with the number of stores an iteration issues behind its prefetch, and never with vmcnt(0)."""
-    import re
-    for nit, out, stores in ((3, 3, 6), (3, 1, 3), (3, 2, 3), (4, 3, 8), (4, 1, 4), (4, 2, 4)):
-        k = L.find(layernorm, r"layernorm_bwd4p_kernelILi%dELi%dE" % (nit, out))
-        body = k["body"]
-        assert k["spill"] == 0 and k["scratch"] == 0 and k["vgpr"] <= (128 if nit == 3 else 168)
-        loads = [(i, re.search(r"global_load_dwordx2 (v\[\d+:\d+\])", l).group(1)) for i, l in enumerate(body) if "global_load_dwordx2" in l]
-        assert len(loads) == 2 * (2 * nit + 1), (nit, out, len(loads))
-        pro, loop = loads[:2 * nit + 1], loads[2 * nit + 1:]
-        assert sorted(r for _, r in pro) == sorted(r for _, r in loop), (nit, out)                       # (a)
-        landing = set()
-        for _, r in pro:
-            a, b = map(int, re.match(r"v\[(\d+):(\d+)\]", r).groups())
-            landing.update("v%d" % x for x in range(a, b + 1))
-        after = [(i, int(re.search(r"vmcnt\((\d+)\)", l).group(1))) for i, l in enumerate(body) if "s_waitcnt" in l and "vmcnt(" in l and i > pro[-1][0]]
-        # behind the prologue's loads: their drain, the loop's ONE counted wait (hipcc may rotate the loop: anywhere in the text), the drain behind the loop
-        assert sorted(c for _, c in after) == [0, 0, stores], (nit, out, after)                           # (c)
-        header_wait = next(i for i, c in after if c == stores)
-        for i, l in enumerate(body):                                                                      # (b)
-            m = re.match(r"\s*v_mov_b(?:32|64)(?:_e32|_e64)?\s+\S+,\s*(v\d+|v\[(\d+):(\d+)\])", l)
-            if not m:
-                continue
-            src = {m.group(1)} if m.group(2) is None else {"v%d" % x for x in range(int(m.group(2)), int(m.group(3)) + 1)}
-            if src & landing and pro[-1][0] < i:
-                assert i in (header_wait + 1, header_wait + 2), (nit, out, i, l)
-
-
 def test_grouped_weight_gradient_main_loop_is_clean():
     ks = L.kernels(L.compile_isa(os.path.join(CSRC, "gemm_tn8.hip")))
     for inst in (r"gemm_tn8_kernelILb0E", r"gemm_tn8_kernelILb1E"):     # descriptors in the kernel argument | in a device table (round 4)

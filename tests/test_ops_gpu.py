@@ -1195,7 +1195,7 @@ def test_error_path_raises(ops):
 
 @pytest.mark.parametrize("rows,H,f16", [(7001, 768, True), (4099, 1024, False), (25856, 768, True), (5, 768, False)])
 def test_layernorm_kernel_variants_agree(ops, rows, H, f16):
-    """The forward with 1 / 2 / 4 rows per wave and the backward in its plain (1), two-rows-in-flight (2) and software-pipelined (3) forms
+    """The forward with 1 / 2 / 4 rows per wave and the backward in its plain (1) and two-rows-in-flight (2) forms
     (vlb_gemm_set_option "ln_fwd_rows" / "ln_bwd4"): the same arithmetic per row.  The forward variants are one template and agree bit
     for bit; the backward variants are separate kernels whose fp32 expressions the compiler contracts into different FMA patterns, so
     they agree to one 16-bit rounding step, with IDENTICAL dropout masks; the parameter-gradient sums agree to fp32 summation order.
@@ -1218,7 +1218,7 @@ def test_layernorm_kernel_variants_agree(ops, rows, H, f16):
         for k in (2, 4):
             assert torch.equal(outs["f%d" % k][0], outs["f1"][0]) and torch.equal(outs["f%d" % k][1], outs["f1"][1]), k
         stats = outs["f1"][1]
-        for mode in (1, 2, 3):
+        for mode in (1, 2):
             lib.gemm_set_option("ln_bwd4", mode)
             for form in ("both", "dx", "drop"):
                 dx = torch.full((rows, H), 9.0, dtype=torch.bfloat16, device=dev()) if form != "drop" else None
@@ -1229,7 +1229,7 @@ def test_layernorm_kernel_variants_agree(ops, rows, H, f16):
                                   dgamma=dg, dbeta=db, workspace=ws)
                 outs[(mode, form)] = (dx, dd, dg, db)
         torch.cuda.synchronize()
-        for mode in (2, 3):
+        for mode in (2,):
             for form in ("both", "dx", "drop"):
                 a, b = outs[(mode, form)], outs[(1, form)]
                 for t, u in zip(a[:2], b[:2]):
@@ -1243,11 +1243,11 @@ def test_layernorm_kernel_variants_agree(ops, rows, H, f16):
                                                     int(bad.any(dim=1).nonzero()[0]) if bool(bad.any()) else None))
                 for t, u in zip(a[2:], b[2:]):
                     assert float((t - u).abs().max()) <= 1e-4 * max(1.0, float(u.abs().max())), (mode, form)
-        d = outs[(3, "both")]
+        d = outs[(2, "both")]
         assert float((d[1] == 0).float().mean()) > 0.05 and not torch.equal(d[0], d[1])
     finally:
         lib.gemm_set_option("ln_fwd_rows", 0)
-        lib.gemm_set_option("ln_bwd4", 3)
+        lib.gemm_set_option("ln_bwd4", 1)
 
 
 def test_layernorm_bwd_deferred_parameter_gradients_batched(ops):

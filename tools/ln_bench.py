@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """LayerNorm forward / backward micro-benchmark (run on the GPU box):
-VLB_LN_BWD4=0|1|2|3 VLB_LN_FWD_ROWS=1|2|4 python tools/ln_bench.py [rows] [H]      (3 = the software-pipelined backward)"""
+VLB_LN_BWD4=0|1|2 VLB_LN_FWD_ROWS=1|2|4 python tools/ln_bench.py [rows] [H]"""
 import importlib
 import os
 import sys

@@ -95,6 +95,7 @@ _SIGS = {
     "vlb_avgpool_rows_fwd": "ppliiiiips",
     "vlb_avgpool_rows_bwd": "plpplpiiifpuuups",
     "vlb_gemm_nt_f32": "plplpliiiiillllllplfiplplplfpuiis",
+    "vlb_gemm_tn_f32": "plplpliiiiillllllfiips",
     "vlb_transpose_f32": "plpliiiiillllps",
     "vlb_layernorm_f32_fwd": "plppplpiifs",
     "vlb_layernorm_f32_bwd": "plplppplplfpuppiis",

@@ -512,6 +512,234 @@ extern "C" int vlb_gemm_nt_f32(const float* A, long lda, const float* B, long ld
   return VLB_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// "TN" form of the split GEMM:  C[Mo, No] (+)= alpha * A[R, Mo]^T . B[R, No]  -- the reduction runs over the R ROWS of two row-major fp32
+// operands, i.e. over tensors exactly as the forward / backward passes left them: weight gradients dW = dY^T X (autograd's
+// grad_output.t().mm(input)) and the attention products dV = P^T dO, dK = dS^T Q, without the transposed fp32 copies the NT kernel
+// needed (1440 transpose launches and 23 ms of a VQA-large step, profiles/r04_vqa_fp32_kernel_stats.txt).
+//   * a stage = 32 reduction rows; per operand two bf16 images [32 rows][128 columns] (h plane, m plane; 256-B rows), written from
+//     registers after the split (16 B = 8 columns per plane and lane), the 32-B column blocks XOR-swizzled by
+//     f(row) = (row & 3) | ((row >> 3) & 1) << 2 exactly as in gemm_tn_bf16_kernel (gemm.hip) -- here on the LDS write address;
+//   * MFMA fragments (8 consecutive reduction rows of one column per lane) come out through the LDS transpose read
+//     ds_read_b64_tr_b16, two per fragment and plane (compiler-visible builtin: no LDS-DMA in this kernel, so hipcc's own waits are exact);
+//   * 128 x 128 output tile, 2 x 2 waves of 64 x 64, three MFMAs per fragment pair (bm.ah + bh.am + bh.ah), register staging two stages
+//     deep, K slices over blockIdx.y with fp32 atomics (as the NT kernel);
+//   * optional column sums of A (bias gradients), taken from the fp32 registers on their way to LDS by the tile_n == 0 workgroups.
+// Rows >= R and columns >= Mo / No are loaded clamped and replaced by zeros.
+// ---------------------------------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) short tn_s16x4;
+typedef __attribute__((address_space(3))) tn_s16x4 tn_lds_s16x4;
+
+__device__ __forceinline__ tbf16x8 tn_f32_frag(const char* img, int off) {      // rows +0..3 and +4..7 of the lane's column
+  const tn_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tn_lds_s16x4*)(img + off));
+  const tn_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tn_lds_s16x4*)(img + off + 4 * 256));
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(tbf16x8, v);
+}
+
+// 8 consecutive columns of one reduction row -> the two planes (16 B each) at the row's swizzled chunk
+__device__ __forceinline__ void split_store_tn(char* img_h, int row, int chunk, const float4& x0, const float4& x1) {
+  const uint32_t h0 = pack2_true_bf16(x0.x, x0.y), h1 = pack2_true_bf16(x0.z, x0.w), h2 = pack2_true_bf16(x1.x, x1.y), h3 = pack2_true_bf16(x1.z, x1.w);
+  const uint32_t m0 = pack2_true_bf16(x0.x - true_bf_lo(h0), x0.y - true_bf_hi(h0)), m1 = pack2_true_bf16(x0.z - true_bf_lo(h1), x0.w - true_bf_hi(h1));
+  const uint32_t m2 = pack2_true_bf16(x1.x - true_bf_lo(h2), x1.y - true_bf_hi(h2)), m3 = pack2_true_bf16(x1.z - true_bf_lo(h3), x1.w - true_bf_hi(h3));
+  const int f = (row & 3) | (((row >> 3) & 1) << 2);
+  const int pc = ((((chunk >> 1) ^ f) << 1) | (chunk & 1));
+  *(uint4*)(img_h + row * 256 + pc * 16) = make_uint4(h0, h1, h2, h3);
+  *(uint4*)(img_h + 32 * 256 + row * 256 + pc * 16) = make_uint4(m0, m1, m2, m3);
+}
+
+template <bool COLSUM>
+__global__ __launch_bounds__(256, 2) void gemm_f32_split_tn_kernel(const F32Gemm p, float* __restrict__ colsum) {
+  constexpr int BR = 32, IMG = BR * 256, STAGE = 4 * IMG;      // A_h | A_m | B_h | B_m : 32 KiB per stage
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;                     // 2 x 2 waves of 64 x 64
+  const int ntm = (p.M + 127) / 128;
+  const int tm = blockIdx.x % ntm, tn = blockIdx.x / ntm;
+  const int m0 = tm * 128, n0 = tn * 128;
+  const int z = blockIdx.z, i1 = z / p.nb2, i2 = z - i1 * p.nb2;
+  const float* A = p.A + i1 * p.sA1 + i2 * p.sA2;
+  const float* B = p.B + i1 * p.sB1 + i2 * p.sB2;
+  float* C = p.C + i1 * p.sC1 + i2 * p.sC2;
+  const int r_begin = blockIdx.y * p.k_per_split;
+  const int r_end = min(p.K, r_begin + p.k_per_split);         // p.K = number of reduction rows R
+  const int ntk = (r_end - r_begin + BR - 1) / BR;
+  if (ntk <= 0) return;
+
+  // staging: item P = it * 256 + tid (it = 0, 1): row = P >> 4 (0..31), 8-column chunk c = P & 15
+  int s_row[2], s_c[2];
+  bool a_ok[2], b_ok[2];
+  const float* a_src[2];
+  const float* b_src[2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int P = it * 256 + tid;
+    s_row[it] = P >> 4;
+    s_c[it] = P & 15;
+    // a chunk that STARTS inside the operand is loaded whole: its columns beyond Mo / No are real memory (lda >= round8(Mo)) and only
+    // reach output rows / columns the epilogue masks; chunks that start outside are clamped in bounds and replaced by zeros
+    a_ok[it] = m0 + s_c[it] * 8 < p.M;
+    b_ok[it] = n0 + s_c[it] * 8 < p.N;
+    a_src[it] = A + min(m0 + s_c[it] * 8, ((p.M + 7) & ~7) - 8);
+    b_src[it] = B + min(n0 + s_c[it] * 8, ((p.N + 7) & ~7) - 8);
+  }
+  float4 ra[2][2][2], rb[2][2][2];
+  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  auto fetch = [&](auto set_c, int kt) {
+    constexpr int SET = decltype(set_c)::value;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int r = r_begin + kt * BR + s_row[it];
+      const long rr = min(r, r_end - 1);                        // unconditional, clamped loads (a load under a condition serialises)
+      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 a0 = *(const float4*)(a_src[it] + rr * p.lda), a1 = *(const float4*)(a_src[it] + rr * p.lda + 4);
+      const float4 b0 = *(const float4*)(b_src[it] + rr * p.ldb), b1 = *(const float4*)(b_src[it] + rr * p.ldb + 4);
+      const bool in = r < r_end;
+      ra[SET][it][0] = (in && a_ok[it]) ? a0 : z4; ra[SET][it][1] = (in && a_ok[it]) ? a1 : z4;
+      rb[SET][it][0] = (in && b_ok[it]) ? b0 : z4; rb[SET][it][1] = (in && b_ok[it]) ? b1 : z4;
+    }
+  };
+  auto store = [&](auto set_c, int buf) {
+    constexpr int SET = decltype(set_c)::value;
+    char* sa = smem + buf * STAGE;
+    char* sb = sa + 2 * IMG;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      split_store_tn(sa, s_row[it], s_c[it], ra[SET][it][0], ra[SET][it][1]);
+      split_store_tn(sb, s_row[it], s_c[it], rb[SET][it][0], rb[SET][it][1]);
+      if (COLSUM) {      // (both items of a thread cover the same 8 columns: c = tid & 15)
+        cs[0] += ra[SET][it][0].x; cs[1] += ra[SET][it][0].y; cs[2] += ra[SET][it][0].z; cs[3] += ra[SET][it][0].w;
+        cs[4] += ra[SET][it][1].x; cs[5] += ra[SET][it][1].y; cs[6] += ra[SET][it][1].z; cs[7] += ra[SET][it][1].w;
+      }
+    }
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // fragment addressing (gemm.hip, "TN GEMM for weight gradients"): L = lane & 15 supplies (row L >> 2, 4 columns (L & 3) * 4) of a 4 x 16
+  // block and receives the block's column L; lane group g = lane >> 4 takes reduction rows 8 g .. 8 g + 7
+  const int L = lane & 15, g = lane >> 4;
+  const int fl = (L >> 2) | ((g & 1) << 2);
+  const int lane_off = (8 * g + (L >> 2)) * 256 + (L & 3) * 8;
+  int a_fo[4], b_fo[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    a_fo[i] = lane_off + (((wm * 4 + i) ^ fl) << 5);
+    b_fo[i] = lane_off + (((wn * 4 + i) ^ fl) << 5);
+  }
+  auto compute = [&](int buf) {
+    const char* sa = smem + buf * STAGE;
+    const char* sb = sa + 2 * IMG;
+    tbf16x8 ah[4], am[4], bh[4], bm[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ah[i] = tn_f32_frag(sa, a_fo[i]);
+      am[i] = tn_f32_frag(sa + IMG, a_fo[i]);
+      bh[i] = tn_f32_frag(sb, b_fo[i]);
+      bm[i] = tn_f32_frag(sb + IMG, b_fo[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {        // small terms first, then the leading one
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm[j], ah[i], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], am[i], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+      }
+  };
+  // stage kt lives in LDS buffer kt & 1 and came through register set kt & 1 (see gemm_f32_split_kernel)
+  fetch(S0{}, 0);
+  if (ntk > 1) fetch(S1{}, 1);
+  store(S0{}, 0);
+  __syncthreads();
+  for (int kt = 0; kt < ntk; kt += 2) {
+    if (kt + 2 < ntk) fetch(S0{}, kt + 2);
+    compute(0);
+    if (kt + 1 < ntk) {
+      store(S1{}, 1);
+      __syncthreads();
+      if (kt + 3 < ntk) fetch(S1{}, kt + 3);
+      compute(1);
+      if (kt + 2 < ntk) {
+        store(S0{}, 0);
+        __syncthreads();
+      }
+    }
+  }
+  if (COLSUM) {      // lanes l, l ^ 16, l ^ 32, l ^ 48 of a wave hold the same 8 columns (c = tid & 15)
+    if (tn == 0 && z == 0) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float v = cs[e];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        const int m = m0 + (lane & 15) * 8 + e;
+        if (lane < 16 && m < p.M) atomicAdd(colsum + m, v);
+      }
+    }
+  }
+  // ---- epilogue: lane holds C[m][n .. n+3], m = .. + (lane & 15), n = .. + 4 * (lane >> 4) ----
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + L;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + 4 * g;
+      if (n >= p.N) continue;                                   // (No % 4 == 0)
+      const float v[4] = {acc[i][j][0] * p.alpha, acc[i][j][1] * p.alpha, acc[i][j][2] * p.alpha, acc[i][j][3] * p.alpha};
+      float* c = C + (long)m * p.ldc + n;
+      if (!p.atomic) {
+        *(float4*)c = make_float4(v[0], v[1], v[2], v[3]);
+      } else if (gridDim.y == 1) {            // a single K slice owns the element: plain read-modify-write
+        float4 o = *(float4*)c;
+        o.x += v[0]; o.y += v[1]; o.z += v[2]; o.w += v[3];
+        *(float4*)c = o;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(c + e, v[e]);
+      }
+    }
+  }
+}
+
+// C[Mo, No] (+)= alpha * A[R, Mo]^T . B[R, No] in fp32 (split products), batched over nb1 x nb2; atomic: accumulate (K slices allowed);
+// colsum (nullable, unbatched): += column sums of A.
+extern "C" int vlb_gemm_tn_f32(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int R, int Mo, int No, int nb1, int nb2,
+                               long sA1, long sA2, long sB1, long sB2, long sC1, long sC2, float alpha, int atomic, int splitk, float* colsum,
+                               hipStream_t stream) {
+  if (R <= 0 || Mo <= 0 || No <= 0 || nb1 <= 0 || nb2 <= 0) return VLB_OK;
+  VLB_CHECK_ARG(A && B && C, "vlb_gemm_tn_f32: null operand");
+  VLB_CHECK_ARG((No % 4) == 0 && (lda % 4) == 0 && (ldb % 4) == 0 && (ldc % 4) == 0 && lda >= ((Mo + 7) & ~7) && ldb >= ((No + 7) & ~7),
+                "vlb_gemm_tn_f32: No must be a multiple of 4, the leading dimensions multiples of 4 and at least Mo / No rounded up to 8 "
+                "(operand rows are read in whole 8-column chunks)");
+  VLB_CHECK_ARG(al16(A) && al16(B) && al16(C), "vlb_gemm_tn_f32: pointers must be 16-byte aligned");
+  VLB_CHECK_ARG((sA1 % 4) == 0 && (sA2 % 4) == 0 && (sB1 % 4) == 0 && (sB2 % 4) == 0 && (sC1 % 4) == 0 && (sC2 % 4) == 0,
+                "vlb_gemm_tn_f32: batch strides must be multiples of 4 elements");
+  VLB_CHECK_ARG(!colsum || nb1 * nb2 == 1, "vlb_gemm_tn_f32: column sums are for the unbatched form");
+  VLB_CHECK_ARG((long)nb1 * nb2 <= 65535, "vlb_gemm_tn_f32: too many batches");
+  F32Gemm p = {};
+  p.A = A; p.B = B; p.C = C; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.M = Mo; p.N = No; p.K = R;
+  p.nb2 = nb2; p.sA1 = sA1; p.sA2 = sA2; p.sB1 = sB1; p.sB2 = sB2; p.sC1 = sC1; p.sC2 = sC2;
+  p.alpha = alpha; p.atomic = atomic ? 1 : 0;
+  const int stages = vlb_cdiv(R, 32);
+  int splits = (atomic && splitk > 1) ? (splitk > stages ? stages : splitk) : 1;
+  const int per = vlb_cdiv(stages, splits);
+  splits = vlb_cdiv(stages, per);
+  p.k_per_split = per * 32;
+  const dim3 grid(vlb_cdiv(Mo, 128) * vlb_cdiv(No, 128), splits, nb1 * nb2);
+  if (colsum) hipLaunchKernelGGL(gemm_f32_split_tn_kernel<true>, grid, dim3(256), 0, stream, p, colsum);
+  else hipLaunchKernelGGL(gemm_f32_split_tn_kernel<false>, grid, dim3(256), 0, stream, p, (float*)nullptr);
+  VLB_CHECK_LAUNCH("vlb_gemm_tn_f32");
+  return VLB_OK;
+}
+
 // dst[c][r] = src[r][c] (r < R; zero for R <= r < Rp), batched with two stride levels; colsum (nullable, unbatched use) += column sums.
 extern "C" int vlb_transpose_f32(const float* src, long lds, float* dst, long ldd, int R, int C, int Rp, int nb1, int nb2, long sS1, long sS2,
                                  long sD1, long sD2, float* colsum, hipStream_t stream) {

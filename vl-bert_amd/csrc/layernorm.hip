@@ -473,181 +473,12 @@ __global__ __launch_bounds__(256, (NIT * RIF <= 3 ? 4 : 1)) void layernorm_bwd4_
   }
 }
 
-// Software-pipelined form of layernorm_bwd4_kernel (one row per wave iteration) for FULL rows (H == 256 NIT: every lane owns NIT whole
-// chunks) with the outputs fixed at compile time (OUT bit 0: dx, bit 1: dx_drop): the loop body is straight-line code.  The loads of
-// the wave's NEXT row are issued right after the current row has been decoded, in front of its arithmetic and its stores.  gfx9's
-// vmcnt retires in issue order: in the plain loop the wait for row i + 1's loads also waits for the write acknowledgements of row i's
-// stores (issued before them), and any store under a run-time or per-lane condition makes hipcc's counted waits conservative (it must
-// assume the store was NOT issued, i.e. wait for more).  Here the loads are older than the stores, every memory instruction of the
-// loop is unconditional, the waits are exact and leave the stores outstanding, and a wave has a row in flight all the time instead of
-// only while it waits.  108 VGPRs at H = 768: still 4 waves per SIMD.  16-bit dy, no dx_acc (the other forms use layernorm_bwd4_kernel).
-// Loads the compiler does not track (and the explicit counted wait that retires them): hipcc's own wait for a load issued in the
-// previous loop iteration is computed at the loop header as the merge of the entry path (nothing issued behind the loads) and the back
-// edge (the iteration's stores issued behind them) -- it takes the conservative one, vmcnt(0), which drains the stores.
-__device__ __forceinline__ void ln_gload2(uint2& dst, const void* ptr) {
-  asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory");
-}
-template <int NIT>
-__device__ __forceinline__ void ln_raw_load_row_asm(const bf16_t* x, int lane, Raw4<NIT>& q) {
-#pragma unroll
-  for (int i = 0; i < NIT; ++i) ln_gload2(q.w[i], x + (lane + 64 * i) * 4);
-}
-// The wait that retires them.  The row registers are in / out operands (their uses -- the decode right behind -- cannot be scheduled in
-// front of it).  The row statistics live until the end of the iteration, i.e. beyond the point where the NEXT prefetch reuses their
-// landing registers: they are MOVED out inside the same asm statement, behind the wait (as a tied in / out operand hipcc copied them to
-// other registers IN FRONT of the wait -- stale values from the second iteration on).
-template <int AHEAD, int NIT>
-__device__ __forceinline__ void ln_wait_rows(Raw4<NIT>& a, Raw4<NIT>& b, const uint2& c, float& mean, float& rstd) {
-  if constexpr (NIT == 3)
-    asm volatile("s_waitcnt vmcnt(%10)\n\tv_mov_b32 %6, %8\n\tv_mov_b32 %7, %9"
-                 : "+v"(a.w[0]), "+v"(a.w[1]), "+v"(a.w[2]), "+v"(b.w[0]), "+v"(b.w[1]), "+v"(b.w[2]), "=&v"(mean), "=&v"(rstd)
-                 : "v"(c.x), "v"(c.y), "n"(AHEAD) : "memory");
-  else if constexpr (NIT == 4)
-    asm volatile("s_waitcnt vmcnt(%12)\n\tv_mov_b32 %8, %10\n\tv_mov_b32 %9, %11"
-                 : "+v"(a.w[0]), "+v"(a.w[1]), "+v"(a.w[2]), "+v"(a.w[3]), "+v"(b.w[0]), "+v"(b.w[1]), "+v"(b.w[2]), "+v"(b.w[3]), "=&v"(mean), "=&v"(rstd)
-                 : "v"(c.x), "v"(c.y), "n"(AHEAD) : "memory");
-  else
-    static_assert(NIT == 3 || NIT == 4, "pipelined LayerNorm backward: H = 768 / 1024");
-}
-
-template <int NIT>
-__device__ __forceinline__ void decode_row_full(const Raw4<NIT>& q, Row4<NIT>& r, bool f16) {
-  if (f16) {
-#pragma unroll
-    for (int i = 0; i < NIT; ++i) { r.v[i][0] = hlo(q.w[i].x); r.v[i][1] = hhi(q.w[i].x); r.v[i][2] = hlo(q.w[i].y); r.v[i][3] = hhi(q.w[i].y); }
-  } else {
-#pragma unroll
-    for (int i = 0; i < NIT; ++i) { r.v[i][0] = bflo(q.w[i].x); r.v[i][1] = bfhi(q.w[i].x); r.v[i][2] = bflo(q.w[i].y); r.v[i][3] = bfhi(q.w[i].y); }
-  }
-}
-
-template <int NIT, int OUT>
-__global__ __launch_bounds__(256, (NIT <= 3 ? 4 : 3)) void layernorm_bwd4p_kernel(const bf16_t* __restrict__ dy, long lddy, const bf16_t* __restrict__ x,
-                                                             long ldx, const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                             bf16_t* __restrict__ dx, long lddx, bf16_t* __restrict__ dx_drop, long lddd,
-                                                             uint32_t drop_thr, float drop_scale, const uint32_t* __restrict__ seedp,
-                                                             uint32_t tag, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                             float* __restrict__ ws, int rows, int x_f16) {
-  extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][2][LW] + gamma [4 waves][NIT][64] float4
-  constexpr int LW = NIT * 256, H = NIT * 256;
-  typedef __attribute__((address_space(3))) vlb_f32x4 lds_f4;      // (a plain vector type: HIP's float4 class has no address-space-qualified operators)
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t seed = (drop_thr && seedp) ? *seedp : 0u;
-  const bool want_gb = (dgamma != nullptr) || (dbeta != nullptr);
-  float gsum[NIT][4], bsum[NIT][4];
-  // gamma of the lane's columns lives in LDS (see layernorm_bwd4_kernel); read back through an explicit LDS pointer: a generic pointer
-  // that went through the optimisation barrier below becomes a FLAT load, whose wait is vmcnt(0) -- it would drain the prefetched row
-  lds_f4* const gam_l = (lds_f4*)(red + 8 * LW) + wave * NIT * 64 + lane;
-  {
-    Row4<NIT> g0;
-    load_row_f32(gamma, H, lane, g0);
-#pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-      gam_l[i * 64] = (vlb_f32x4){g0.v[i][0], g0.v[i][1], g0.v[i][2], g0.v[i][3]};
-#pragma unroll
-      for (int k = 0; k < 4; ++k) gsum[i][k] = bsum[i][k] = 0.f;
-    }
-  }
-  const int step = gridDim.x * 4;
-  int row = blockIdx.x * 4 + wave;
-  constexpr int STORES = NIT * ((OUT & 1) + ((OUT >> 1) & 1));      // vector-memory operations an iteration issues BEHIND its prefetch
-  Raw4<NIT> qx, qd;
-  uint2 msw;
-  {
-    const int r0 = min(row, rows - 1);      // (a wave without rows loads the last row and never uses it)
-    ln_raw_load_row_asm(x + (long)r0 * ldx, lane, qx);
-    ln_raw_load_row_asm(dy + (long)r0 * lddy, lane, qd);
-    ln_gload2(msw, stats + 2 * (long)r0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // first row: nothing was issued behind these loads (the loop's wait counts the stores)
-  }
-  for (; row < rows; row += step) {
-    float mean, rstd;
-    ln_wait_rows<STORES, NIT>(qx, qd, msw, mean, rstd);      // the row prefetched by the previous iteration has landed; that iteration's stores may still be in flight
-    Row4<NIT> xr, dyr;
-    decode_row_full(qd, dyr, false);
-    decode_row_full(qx, xr, x_f16 != 0);
-    {      // the next row of this wave (clamped: the last iteration re-reads the last row of the tensor)
-      const int rn = min(row + step, rows - 1);
-      ln_raw_load_row_asm(x + (long)rn * ldx, lane, qx);
-      ln_raw_load_row_asm(dy + (long)rn * lddy, lane, qd);
-      ln_gload2(msw, stats + 2 * (long)rn);
-    }
-    float gam[NIT][4];
-    {
-      uint32_t goff = (uint32_t)(uintptr_t)gam_l;
-      asm volatile("" : "+v"(goff));      // (keeps the reads inside the loop: 4 NIT registers less across the iteration)
-      const lds_f4* gp = (const lds_f4*)(uintptr_t)goff;
-#pragma unroll
-      for (int i = 0; i < NIT; ++i) {
-        const vlb_f32x4 g4 = gp[i * 64];
-        gam[i][0] = g4[0]; gam[i][1] = g4[1]; gam[i][2] = g4[2]; gam[i][3] = g4[3];
-      }
-    }
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float xh = (xr.v[i][k] - mean) * rstd;
-        const float dyv = dyr.v[i][k];
-        gsum[i][k] += dyv * xh;
-        bsum[i][k] += dyv;
-        const float gv = dyv * gam[i][k];
-        s1 += gv;
-        s2 += gv * xh;
-        xr.v[i][k] = xh;    // reuse storage: xhat
-        dyr.v[i][k] = gv;   // reuse storage: g
-      }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-    const float m1 = s1 / (float)H, m2 = s2 / (float)H;
-#pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-      const int c = (lane + 64 * i) * 4;
-      float o[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) o[k] = rstd * (dyr.v[i][k] - m1 - xr.v[i][k] * m2);
-      if (OUT & 1) *(uint2*)(dx + (long)row * lddx + c) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
-      if (OUT & 2) {
-        float d[4] = {o[0], o[1], o[2], o[3]};
-        if (drop_thr) {
-          const uint32_t idx = (uint32_t)row * (uint32_t)H + (uint32_t)c;      // H % 4 == 0 -> idx even
-          const uint32_t h0 = vlb_rng_pair(seed, tag, idx >> 1), h1 = vlb_rng_pair(seed, tag, (idx >> 1) + 1);
-          d[0] = ((h0 & 0xffffu) >= drop_thr) ? o[0] * drop_scale : 0.f;
-          d[1] = ((h0 >> 16) >= drop_thr) ? o[1] * drop_scale : 0.f;
-          d[2] = ((h1 & 0xffffu) >= drop_thr) ? o[2] * drop_scale : 0.f;
-          d[3] = ((h1 >> 16) >= drop_thr) ? o[3] * drop_scale : 0.f;
-        }
-        *(uint2*)(dx_drop + (long)row * lddd + c) = make_uint2(pack2bf(d[0], d[1]), pack2bf(d[2], d[3]));
-      }
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the last prefetch (a clamped re-read) targets registers that are reused below
-  if (!want_gb) return;
-  float* mine = red + wave * 2 * LW;
-#pragma unroll
-  for (int i = 0; i < NIT; ++i)
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      mine[(i * 4 + k) * 64 + lane] = gsum[i][k];
-      mine[LW + (i * 4 + k) * 64 + lane] = bsum[i][k];
-    }
-  __syncthreads();
-  for (int q = threadIdx.x; q < 2 * LW; q += 256) {
-    const float v = (red[q] + red[2 * LW + q]) + (red[4 * LW + q] + red[6 * LW + q]);
-    if (ws) ws[(long)blockIdx.x * 2 * LW + q] = v;
-    else red[q] = v;
-  }
-  if (ws) return;
-  __syncthreads();
-  for (int c = threadIdx.x; c < 2 * H; c += 256) {    // no workspace: coalesced atomics in natural column order
-    const int which = c >= H, col = c - which * H, chunk = col >> 2;
-    const float v = red[which * LW + (((chunk >> 6) * 4 + (col & 3)) << 6) + (chunk & 63)];
-    float* dst = which ? dbeta : dgamma;
-    if (dst) atomicAdd(dst + col, v);
-  }
-}
+// (Round 4 built and REMOVED a software-pipelined form of the kernel above: next row's loads issued in front of the current row's stores
+// through untracked inline-asm loads and one explicit `s_waitcnt vmcnt(stores per iteration)`.  5-7 % faster -- and unsound: vector-memory
+// loads retire in order among themselves, stores among themselves, but NOT with respect to each other, so "at most 6 operations
+// outstanding" did not prove the 7 older loads had landed once the 6 younger stores completed first.  It passed every test on warm data and
+// produced NaN gradients after other tests had cooled the caches.  That is also why hipcc waits with vmcnt(0) wherever loads and stores are
+// pending together -- it is not being conservative.  DESIGN.md §3, "HBM-bound kernels".)
 
 // dgamma/dbeta += column sums of the `nslab` lane-major partial vectors [2][LW]: grid (2 LW / 64, 8)
 __global__ __launch_bounds__(256) void ln_param_finalize_kernel(const float* __restrict__ ws, int nslab, int LW, float* __restrict__ dgamma,
@@ -673,7 +504,7 @@ __global__ __launch_bounds__(256) void ln_param_finalize_kernel(const float* __r
 // rows per wave of the forward: VLB_LN_FWD_ROWS = 1 | 2 | 4 (0 / unset: 2 where at least two full rounds of single-row waves exist);
 // run-time override for A/B measurements and tests: vlb_gemm_set_option("ln_fwd_rows", v) / ("ln_bwd4", v)
 static int g_ln_fwd_rows = -1;
-static int g_ln_bwd4 = -1;      // VLB_LN_BWD4: 3 (default) = 1 + the software-pipelined form where it applies (H = 768 / 1024, 16-bit dy, no dx_acc); 1 the 4-column kernel; 2: two rows in flight at H = 768 / 1024; 0 the 8-column kernel
+static int g_ln_bwd4 = -1;      // VLB_LN_BWD4: 1 (default) the 4-column kernel (2: two rows in flight at H = 768 / 1024); 0 the 8-column kernel
 void vlb_ln_set_fwd_rows(int v) { g_ln_fwd_rows = v; }
 void vlb_ln_set_bwd4(int v) { g_ln_bwd4 = v; }
 
@@ -752,7 +583,7 @@ static int ln_bwd_impl(const void* dy, long lddy, int dy_f32, const void* x, lon
   VLB_CHECK_ARG((long)rows * H < (1L << 32) || !(drop_p > 0.f), "vlb_layernorm_bwd: dropout index overflow");
   if (g_ln_bwd4 < 0) {
     const char* v = getenv("VLB_LN_BWD4");
-    g_ln_bwd4 = v ? atoi(v) : 3;
+    g_ln_bwd4 = v ? atoi(v) : 1;
   }
   const int blocks = ln_bwd_blocks(rows);
   float* ws = (workspace && (dgamma || dbeta) && blocks > 32) ? workspace : nullptr;
@@ -769,27 +600,12 @@ static int ln_bwd_impl(const void* dy, long lddy, int dy_f32, const void* x, lon
                        (const bf16_t*)x, ldx, stats, gamma, (bf16_t*)dx, lddx, (bf16_t*)dx_drop, lddd, thr, vlb_drop_scale(thr), \
                        seed, tag, dx_acc, ldacc, dgamma, dbeta, ws, rows, H, x_f16);                                             \
   } while (0)
-#define LN_BWD4P(NIT, OUT)                                                                                                     \
-  do {                                                                                                                          \
-    constexpr size_t smem = (8 * NIT * 256 + 4 * NIT * 256) * sizeof(float);                                                    \
-    hipLaunchKernelGGL((layernorm_bwd4p_kernel<NIT, OUT>), dim3(blocks), dim3(256), smem, stream, (const bf16_t*)dy, lddy,       \
-                       (const bf16_t*)x, ldx, stats, gamma, (bf16_t*)dx, lddx, (bf16_t*)dx_drop, lddd, thr, vlb_drop_scale(thr), \
-                       seed, tag, dgamma, dbeta, ws, rows, x_f16);                                                               \
-  } while (0)
-#define LN_BWD4P_OUT(NIT)                                                                                              \
-  do {                                                                                                                  \
-    if (dx && dx_drop) LN_BWD4P(NIT, 3); else if (dx) LN_BWD4P(NIT, 1); else LN_BWD4P(NIT, 2);                           \
-  } while (0)
-    // rows in flight per wave: 2 while the kernel stays near 128 VGPRs (4 waves per SIMD); g_ln_bwd4 == 2 forces 2 for H = 768 / 1024;
-    // g_ln_bwd4 == 3: the software-pipelined one-row form for H = 768 / 1024 with a 16-bit dy
-    const bool pipelined = g_ln_bwd4 == 3 && !dy_f32 && !dx_acc && (dx || dx_drop) && H == 256 * nit;
+    // rows in flight per wave: 2 while the kernel stays near 128 VGPRs (4 waves per SIMD); g_ln_bwd4 == 2 forces 2 for H = 768 / 1024
     if (nit <= 1) LN_BWD4(1, 2); else if (nit == 2) LN_BWD4(2, 2);
-    else if (nit == 3) { if (pipelined) LN_BWD4P_OUT(3); else if (g_ln_bwd4 == 2) LN_BWD4(3, 2); else LN_BWD4(3, 1); }
-    else if (nit == 4) { if (pipelined) LN_BWD4P_OUT(4); else if (g_ln_bwd4 == 2) LN_BWD4(4, 2); else LN_BWD4(4, 1); }
+    else if (nit == 3) { if (g_ln_bwd4 == 2) LN_BWD4(3, 2); else LN_BWD4(3, 1); }
+    else if (nit == 4) { if (g_ln_bwd4 == 2) LN_BWD4(4, 2); else LN_BWD4(4, 1); }
     else LN_BWD4(8, 1);
 #undef LN_BWD4
-#undef LN_BWD4P
-#undef LN_BWD4P_OUT
   } else {
 #define LN_BWD(NP)                                                                                                             \
   hipLaunchKernelGGL(layernorm_bwd_kernel<NP>, dim3(blocks), dim3(256), 8 * NP * 512 * sizeof(float), stream, dy, lddy, dy_f32,  \
@@ -872,7 +688,7 @@ extern "C" int vlb_ln_param_finalize_batch(int n, const float* const* ws, const 
   VLB_CHECK_ARG(H > 0 && (H % 8) == 0 && H <= 2048, "vlb_ln_param_finalize_batch: unsupported H=%d", H);
   if (g_ln_bwd4 < 0) {
     const char* v = getenv("VLB_LN_BWD4");
-    g_ln_bwd4 = v ? atoi(v) : 3;
+    g_ln_bwd4 = v ? atoi(v) : 1;
   }
   LnFinalizeBatch b;
   for (int i = 0; i < n; ++i) {

@@ -15,10 +15,13 @@ roundings per layer in a 16-bit build -- see none.  Measured: tests/test_f32_enc
 Attention is composed from the batched GEMM: scores = Q.K^T / 8 per (sample, head) -> softmax (+ key mask, + dropout) -> P.V with V
 transposed per head; the backward is the five products of the same shapes.  The probabilities are kept per layer ([B, h, S, Sp] fp32:
 54 MB per layer at 16 x 229 -- 1.3 GB for 24 layers, nothing against 288 GB).
-Weight gradients: dW += dY^T.X as an NT product of the two transposed operands (zero-padded to a multiple of 32 rows), accumulated into
-the engine's flat gradient by a plain read-modify-write (one K slice; two slices with fp32 atomics only for the 1024 x 1024 outputs
-that would otherwise occupy a quarter of the chip); bias gradients are the column sums taken by the transpose of dY.
+Weight gradients: dW += dY^T.X as a row-reduction product straight from the two row-major tensors (vlb_gemm_tn_f32: LDS transpose reads;
+round 3 transposed both operands in HBM first), accumulated into the engine's flat gradient by a plain read-modify-write (one K slice;
+two slices with fp32 atomics only for the 1024 x 1024 outputs that would otherwise occupy a quarter of the chip); bias gradients are
+column sums taken by the same kernel.  dV = Pd^T.dO and dK = dS^T.Q use the same form.
 """
+import os
+
 import torch
 
 from . import ops
@@ -67,6 +70,9 @@ class EncoderF32:
         for l in range(L):
             self.wT.append(dict(qkv=z(H, 3 * H), ao=z(H, H), f1=z(H, I), f2=z(I, H)))
         self._fresh = False
+        # row-reduction ("TN") products straight from the row-major tensors (vlb_gemm_tn_f32): weight gradients, dV = Pd^T dO, dK = dS^T Q.
+        # VLB_F32_TN=0: the round-3 form (transposed fp32 copies + the NT kernel)
+        self.tn = os.environ.get("VLB_F32_TN", "1") != "0"
 
     # -- parameters ---------------------------------------------------------------------------------------------------
     def _w(self, l):
@@ -116,11 +122,14 @@ class EncoderF32:
     def _wgrad(self, dy, N, x, K, gw, gb):
         """gw[N, K] += dy[M, N]^T . x[M, K] ; gb[N] += column sums of dy."""
         M, Mp = self.M, self.Mp
+        tiles = ((N + 127) // 128) * ((K + 127) // 128)
+        if self.tn:      # K slices only where the output has too few tiles to occupy the chip (fp32 atomics cost more than idle CUs)
+            ops.gemm_tn_f32(dy, N, x, K, gw, K, M, N, K, atomic=True, splitk=1 if tiles >= 128 else 2, colsum=gb)
+            return
         ops.transpose_f32(dy, N, self.tG, Mp, M, N, Mp, colsum=gb)
         ops.transpose_f32(x, K, self.tA, Mp, M, K, Mp)
         # K slices only where the output has too few tiles to occupy the chip: fp32 atomics cost more than idle CUs (measured,
         # tools/f32_gemm_bench.py: 4096 x 1024 x 3680 -- 131 us with one slice (plain read-modify-write), 186 / 226 / 268 us with 2 / 3 / 4)
-        tiles = ((N + 127) // 128) * ((K + 127) // 128)
         ops.gemm_nt_f32(self.tG, Mp, self.tA, Mp, gw, K, N, K, Mp, atomic=True, splitk=1 if tiles >= 128 else 2)
 
     # -- forward ------------------------------------------------------------------------------------------------------
@@ -184,18 +193,26 @@ class EncoderF32:
             pd = self.Pd[l] if p_a > 0 else self.P[l]
             ops.gemm_nt_f32(self.dCTX, H, (qkv, 2 * H), 3 * H, self.Sbuf, Sp, S, Sp, 64, batch=bh, sA=(S * H, 64), sB=(S * 3 * H, 64),
                             sC=(nh * S * Sp, S * Sp))
-            self._ss_T(pd, self.Tt)
-            self._head_T(self.dCTX, 0, H, self.hT[0])                                                   # dO^T per head
-            ops.gemm_nt_f32(self.Tt, Sp, self.hT[0], Sp, (self.dQKV, 2 * H), 3 * H, S, 64, Sp, batch=bh, sA=(nh * S * Sp, S * Sp),
-                            sB=(nh * 64 * Sp, 64 * Sp), sC=(S * 3 * H, 64))
+            if self.tn:      # dV = Pd^T . dO per (sample, head): the rows of Pd and of dO are the reduction
+                ops.gemm_tn_f32(pd, Sp, self.dCTX, H, (self.dQKV, 2 * H), 3 * H, S, S, 64, batch=bh, sA=(nh * S * Sp, S * Sp), sB=(S * H, 64),
+                                sC=(S * 3 * H, 64))
+            else:
+                self._ss_T(pd, self.Tt)
+                self._head_T(self.dCTX, 0, H, self.hT[0])                                               # dO^T per head
+                ops.gemm_nt_f32(self.Tt, Sp, self.hT[0], Sp, (self.dQKV, 2 * H), 3 * H, S, 64, Sp, batch=bh, sA=(nh * S * Sp, S * Sp),
+                                sB=(nh * 64 * Sp, 64 * Sp), sC=(S * 3 * H, 64))
             ops.softmax_f32_bwd(self.P[l], self.Sbuf, Bt * nh * S, S, Sp, drop_p=p_a, seed=seed, tag=l * 8 + 0)
             self._head_T(qkv, H, 3 * H, self.hT[0])                                                     # K^T per head
             ops.gemm_nt_f32(self.Sbuf, Sp, self.hT[0], Sp, self.dQKV, 3 * H, S, 64, Sp, batch=bh, sA=(nh * S * Sp, S * Sp),
                             sB=(nh * 64 * Sp, 64 * Sp), sC=(S * 3 * H, 64), alpha=0.125)
-            self._ss_T(self.Sbuf, self.Tt)
-            self._head_T(qkv, 0, 3 * H, self.hT[1])                                                     # Q^T per head
-            ops.gemm_nt_f32(self.Tt, Sp, self.hT[1], Sp, (self.dQKV, H), 3 * H, S, 64, Sp, batch=bh, sA=(nh * S * Sp, S * Sp),
-                            sB=(nh * 64 * Sp, 64 * Sp), sC=(S * 3 * H, 64), alpha=0.125)
+            if self.tn:      # dK = dS^T . Q / 8
+                ops.gemm_tn_f32(self.Sbuf, Sp, qkv, 3 * H, (self.dQKV, H), 3 * H, S, S, 64, batch=bh, sA=(nh * S * Sp, S * Sp),
+                                sB=(S * 3 * H, 64), sC=(S * 3 * H, 64), alpha=0.125)
+            else:
+                self._ss_T(self.Sbuf, self.Tt)
+                self._head_T(qkv, 0, 3 * H, self.hT[1])                                                 # Q^T per head
+                ops.gemm_nt_f32(self.Tt, Sp, self.hT[1], Sp, (self.dQKV, H), 3 * H, S, 64, Sp, batch=bh, sA=(nh * S * Sp, S * Sp),
+                                sB=(nh * 64 * Sp, 64 * Sp), sC=(S * 3 * H, 64), alpha=0.125)
             self._wgrad(self.dQKV, 3 * H, self.X[l], H, w["gwqkv"], w["gbqkv"])
             self._linear(self.dQKV, 3 * H, t["qkv"], H, dx_next, res=self.dZ, ldres=H)                   # dX_l = dQKV . Wqkv + dZ1
             dx = dx_next

@@ -722,6 +722,14 @@ def gemm_nt_f32(A, lda, B, ldb, C, ldc, M, N, K, batch=(1, 1), sA=(0, 0), sB=(0,
               int(splitk), _stream())
 
 
+def gemm_tn_f32(A, lda, B, ldb, C, ldc, R, Mo, No, batch=(1, 1), sA=(0, 0), sB=(0, 0), sC=(0, 0), alpha=1.0, atomic=False, splitk=1, colsum=None):
+    """C[Mo, No] (+)= alpha * A[R, Mo]^T . B[R, No] in fp32 (vlb_gemm_tn_f32: reduction over the rows of two row-major operands).
+    A / B / C: tensor or (tensor, element offset); colsum [Mo] += column sums of A (unbatched)."""
+    _lib.call("vlb_gemm_tn_f32", _pf(A), int(lda), _pf(B), int(ldb), _pf(C), int(ldc), int(R), int(Mo), int(No), int(batch[0]), int(batch[1]),
+              int(sA[0]), int(sA[1]), int(sB[0]), int(sB[1]), int(sC[0]), int(sC[1]), float(alpha), 1 if atomic else 0, int(splitk), _pf(colsum),
+              _stream())
+
+
 def transpose_f32(src, lds, dst, ldd, R, C, Rp, batch=(1, 1), sS=(0, 0), sD=(0, 0), colsum=None):
     _lib.call("vlb_transpose_f32", _pf(src), int(lds), _pf(dst), int(ldd), int(R), int(C), int(Rp), int(batch[0]), int(batch[1]), int(sS[0]),
               int(sS[1]), int(sD[0]), int(sD[1]), _pf(colsum), _stream())
