@@ -157,7 +157,7 @@ def test_gemm_tn_f32_batched_attention_products():
 
 
 def test_fp32_encoder_row_reduction_form_matches_the_transposed_form():
-    """The backward with vlb_gemm_tn_f32 (default) against round 3's transposes + NT products: same gradients to fp32 summation order."""
+    """The backward with vlb_gemm_tn_f32 (VLB_F32_TN=1) against the default transposes + NT products: same gradients to fp32 summation order."""
     E, syn = pkg("engine"), pkg("synthetic")
     grads = []
     for tn in (True, False):

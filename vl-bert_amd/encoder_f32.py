@@ -15,10 +15,10 @@ roundings per layer in a 16-bit build -- see none.  Measured: tests/test_f32_enc
 Attention is composed from the batched GEMM: scores = Q.K^T / 8 per (sample, head) -> softmax (+ key mask, + dropout) -> P.V with V
 transposed per head; the backward is the five products of the same shapes.  The probabilities are kept per layer ([B, h, S, Sp] fp32:
 54 MB per layer at 16 x 229 -- 1.3 GB for 24 layers, nothing against 288 GB).
-Weight gradients: dW += dY^T.X as a row-reduction product straight from the two row-major tensors (vlb_gemm_tn_f32: LDS transpose reads;
-round 3 transposed both operands in HBM first), accumulated into the engine's flat gradient by a plain read-modify-write (one K slice;
-two slices with fp32 atomics only for the 1024 x 1024 outputs that would otherwise occupy a quarter of the chip); bias gradients are
-column sums taken by the same kernel.  dV = Pd^T.dO and dK = dS^T.Q use the same form.
+Weight gradients: dW += dY^T.X as an NT product of the two transposed operands (zero-padded to a multiple of 32 rows), accumulated into
+the engine's flat gradient by a plain read-modify-write (one K slice; two slices with fp32 atomics only for the 1024 x 1024 outputs
+that would otherwise occupy a quarter of the chip); bias gradients are the column sums taken by the transpose of dY.  (VLB_F32_TN=1: the
+same products, and dV = Pd^T.dO / dK = dS^T.Q, straight from the row-major tensors through vlb_gemm_tn_f32 -- correct, not faster yet.)
 """
 import os
 
@@ -70,9 +70,11 @@ class EncoderF32:
         for l in range(L):
             self.wT.append(dict(qkv=z(H, 3 * H), ao=z(H, H), f1=z(H, I), f2=z(I, H)))
         self._fresh = False
-        # row-reduction ("TN") products straight from the row-major tensors (vlb_gemm_tn_f32): weight gradients, dV = Pd^T dO, dK = dS^T Q.
-        # VLB_F32_TN=0: the round-3 form (transposed fp32 copies + the NT kernel)
-        self.tn = os.environ.get("VLB_F32_TN", "1") != "0"
+        # VLB_F32_TN=1: row-reduction ("TN") products straight from the row-major tensors (vlb_gemm_tn_f32) for the weight gradients,
+        # dV = Pd^T dO and dK = dS^T Q instead of transposed fp32 copies + the NT kernel.  Same gradients (tested); OFF by default: at the
+        # VQA-large micro-batch (3 664 rows) the step is 193.7 ms with it and 190.9 without -- the 128 x 128-only TN kernel loses more
+        # on the under-filled 1024 x 1024 outputs than the 23 ms of transposes it removes (DESIGN.md, fp32 path)
+        self.tn = os.environ.get("VLB_F32_TN", "0") == "1"
 
     # -- parameters ---------------------------------------------------------------------------------------------------
     def _w(self, l):
