@@ -136,8 +136,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 #pragma unroll
   for (int u = 0; u < ADAMW_UNITS; ++u) {
     const long i = i0 + (long)u * 1024;
-    if (i + 3 < n) {      // p, m, v are touched once per step: streaming accesses (they would only evict the weights the next forward reads)
-      const float4 a = vlb_load_nt((const float4*)(p + i)), b = load_grad4(g, i), c = vlb_load_nt((const float4*)(m + i)),
+    if (i + 3 < n) {      // p, m, v are touched once per step: streaming accesses (they would only evict the weights the next forward reads).
+      // The master weights are loaded PLAIN: broadcasts, checkpoint loads and the replicated-fp32 exchange also write them, and a
+      // non-temporal load has once returned stale data behind a writer that was not one of this library's kernels
+      const float4 a = *(const float4*)(p + i), b = load_grad4(g, i), c = vlb_load_nt((const float4*)(m + i)),
                    d = vlb_load_nt((const float4*)(v + i));
       pv[u][0] = a.x; pv[u][1] = a.y; pv[u][2] = a.z; pv[u][3] = a.w;
       gv[u][0] = b.x; gv[u][1] = b.y; gv[u][2] = b.z; gv[u][3] = b.w;
@@ -387,8 +389,8 @@ __global__ __launch_bounds__(256) void adamw_ranges_kernel(float* __restrict__ p
     const int cnt = (int)min(4L, end - i);      // (range starts / lengths are multiples of 4: cnt == 4 except for a ragged last range)
     float pv[4], gv[4], mv[4], vv[4];
     if (cnt == 4) {
-      const float4 a = vlb_load_nt((const float4*)(p + p0 + i)), b = load_grad4(g + g0, i), c = vlb_load_nt((const float4*)(m + p0 + i)),
-                   d = vlb_load_nt((const float4*)(v + p0 + i));      // (streaming accesses, as in adamw_kernel)
+      const float4 a = *(const float4*)(p + p0 + i), b = load_grad4(g + g0, i), c = vlb_load_nt((const float4*)(m + p0 + i)),
+                   d = vlb_load_nt((const float4*)(v + p0 + i));      // (streaming accesses for the moments, plain for the master: as in adamw_kernel)
       pv[0] = a.x; pv[1] = a.y; pv[2] = a.z; pv[3] = a.w;
       gv[0] = b.x; gv[1] = b.y; gv[2] = b.z; gv[3] = b.w;
       mv[0] = c.x; mv[1] = c.y; mv[2] = c.z; mv[3] = c.w;
