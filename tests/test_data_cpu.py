@@ -180,6 +180,29 @@ def write_config(path, data_root, batch=2, seq_len=32):
     return path
 
 
+def write_multitask_config(path, data_root, batches=(2, 3), seq_len=32):
+    """conceptual_captions + general_corpus under ResNetVLBERTForPretrainingMultitask (the layout of cfgs/pretrain/base_e2e_16x16G_fp16.yaml)."""
+    import yaml
+    write_config(path, data_root, batch=batches[0], seq_len=seq_len)
+    with open(path) as f:
+        cfg = yaml.safe_load(f)
+    cfg["MODULE"] = "ResNetVLBERTForPretrainingMultitask"
+    cfg["DATASET"] = [cfg["DATASET"], dict(DATASET="general_corpus", TRAIN_ANNOTATION_FILE=os.path.join(FIX, "corpus.doc"), SEQ_LEN=16, MIN_SEQ_LEN=12)]
+    cfg["TRAIN"]["BATCH_IMAGES"] = list(batches)
+    with open(path, "w") as f:
+        yaml.safe_dump(cfg, f)
+    return path
+
+
+def test_train_end2end_resolves_a_multitask_data_set_list(tmp_path):
+    te = importlib.import_module("vl-bert_amd.pretrain.train_end2end")
+    root = write_dataset(str(tmp_path / "cc"), feat_dim=16, classes=9)
+    cfg = write_multitask_config(str(tmp_path / "cfg.yaml"), root)
+    r = te.main(["--cfg", cfg, "--data", "--dry-run"])
+    assert r["multitask"] and r["per_gpu_batch"] == 2 and r["per_gpu_aux_batch"] == 3 and r["steps_per_epoch"] == 3
+    assert abs(r["lr"] - 1.0e-5 * 5) < 1e-12            # LR x (sum of the per-GPU batches) x world x accumulate
+
+
 def test_train_end2end_resolves_the_data_loaders_of_the_config(tmp_path):
     te = importlib.import_module("vl-bert_amd.pretrain.train_end2end")
     root = write_dataset(str(tmp_path / "cc"), feat_dim=16, classes=9)

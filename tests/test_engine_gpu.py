@@ -989,6 +989,21 @@ def test_train_end2end_reads_the_reference_data_formats(tmp_path):
     assert ((valid.sum(1) + (eng.in_text > 0).sum(1)) <= 32).all()
 
 
+def test_train_end2end_multitask_reads_both_data_sets(tmp_path):
+    """--data with a DATASET list: image-caption batches from the detector records side by side with text-only batches from the corpus
+    (MultiTaskDataLoader), through the multitask engine."""
+    from tests.test_data_cpu import write_dataset, write_multitask_config
+    tr = pkg("pretrain.train_end2end")
+    root = write_dataset(str(tmp_path / "cc"))
+    cfg = write_multitask_config(str(tmp_path / "cfg.yaml"), root, batches=(2, 3), seq_len=32)
+    eng = tr.main(["--cfg", cfg, "--data", "--steps", "4"])
+    torch.cuda.synchronize()
+    lv = eng.loss_values()
+    assert float(eng.adam[5]) == 4.0 and np.isfinite(lv["loss"]) and (eng.B, eng.Ba) == (2, 3)
+    assert bool((eng.in_text[:, 0] > 0).all()) and bool((eng.in_text[2:, :12] > 0).all())      # text-only rows: at least MIN_SEQ_LEN tokens
+    assert int((eng.in_mlm_labels[2:] >= 0).sum()) >= 0 and bool((eng.in_boxes[:, 0, 0] > -1.5).all())
+
+
 def _vqa_config(cfg, classifier, answers, hidden):
     conf = _module_config(cfg)
     conf["NETWORK"].update(BLIND=False, NO_GROUNDING=False, ENABLE_CNN_REG_LOSS=False, CLASSIFIER_TYPE=classifier, CLASSIFIER_DROPOUT=0.1,
