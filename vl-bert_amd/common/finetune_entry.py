@@ -26,7 +26,11 @@ import time
 
 
 class AttrDict(dict):
-    __getattr__ = dict.__getitem__
+    def __getattr__(self, key):          # (AttributeError, not KeyError: copy / pickle probe for dunder attributes)
+        try:
+            return self[key]
+        except KeyError:
+            raise AttributeError(key) from None
 
     @staticmethod
     def wrap(x):
