@@ -173,9 +173,9 @@ def mask_raw_pixels(image, boxes, mvrc_ops):
             if mvrc_op == 1:
                 x1, y1, x2, y2 = box
                 image[:, int(y1):(int(y2)+1), int(x1):(int(x2)+1)] = 0
-    image [B,3,H,W] (modified in place, returned), boxes [B,R,>=4], mvrc_ops [B,R].  The fragment sits inside the dataset's
-    __getitem__ (which needs the image / box archives), so there is no way to execute the reference for it here: this restatement is
-    the five lines above, statement for statement ("parity unpinned" for this fragment alone)."""
+    image [B,3,H,W] (modified in place, returned), boxes [B,R,>=4], mvrc_ops [B,R].  Pinned: tests/test_data_cpu.py applies it to the
+    unmasked samples of tests/fixtures/cc_tiny and compares with the images the reference's own ConceptualCaptionsDataset produced with
+    MASK_RAW_PIXELS (tests/golden/data/cc_tiny.npz, oracle/make_data_golden.py) -- bit for bit."""
     for b in range(image.shape[0]):
         for mvrc_op, box in zip(mvrc_ops[b].tolist(), boxes[b]):
             if mvrc_op == 1:

@@ -209,3 +209,25 @@ def test_train_end2end_resolves_the_data_loaders_of_the_config(tmp_path):
     cfg = write_config(str(tmp_path / "cfg.yaml"), root, batch=2)
     r = te.main(["--cfg", cfg, "--data", "--dry-run"])
     assert r["steps_per_epoch"] == 3 and r["per_gpu_batch"] == 2 and r["t_total"] == 3
+
+
+def test_oracle_raw_pixel_masking_is_pinned_to_the_reference_dataset(golden, tok):
+    """oracle/vision_oracle.mask_raw_pixels (the checker of vlb_mask_image_boxes_f32) against the images the REFERENCE's dataset class
+    produced with NETWORK.MASK_RAW_PIXELS: the same samples read without masking (bit-identical otherwise, see above) + the oracle's
+    masking of their masked regions == the reference's masked images.  This pins the fragment that had no executable reference before."""
+    from oracle import vision_oracle as VO
+    g, meta = golden
+    info = meta["passes"]["image"]
+    ds = D.ConceptualCaptionsDataset("", "train", FIX, FIX, seq_len=64, with_precomputed_visual_feat=False, mask_raw_pixels=False,
+                                     tokenizer=tok, add_image_as_a_box=True, transform=chain(meta))
+    masked_any = 0
+    for seed in info["seeds"]:
+        random.seed(seed)
+        for i in range(len(ds)):
+            image, boxes, _, _, _, _, ops, _ = ds[i]
+            ref = g["image/s%d/%d/image" % (seed, i)]
+            assert np.array_equal(np.asarray(ops), g["image/s%d/%d/mvrc_ops" % (seed, i)])
+            got = VO.mask_raw_pixels(image.clone()[None], boxes[None], torch.as_tensor(ops)[None])[0]
+            assert np.array_equal(got.numpy(), ref), (seed, i)
+            masked_any += int(not np.array_equal(image.numpy(), ref))
+    assert masked_any >= 3          # the fixture really masks pixels in several samples
