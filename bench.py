@@ -19,6 +19,8 @@ import os
 import sys
 import time
 
+import os as _os
+_os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # (multi-process GPU work: the host driver only supports dmabuf IPC; before the HIP runtime loads)
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

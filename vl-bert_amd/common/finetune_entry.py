@@ -157,6 +157,7 @@ def main(task, argv=None):
         if rank == 0:
             print(json.dumps({"resolved": r, "NETWORK.VLBERT": dict(config.NETWORK.VLBERT)}, indent=1, default=str))
         return r
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # (one process per GPU: the host driver only supports dmabuf IPC)
     import torch
     if not torch.cuda.is_available():
         raise RuntimeError("%s/train_end2end: no GPU visible.  The MI355X mirrors have no CPU execution path (--dry-run checks a "
