@@ -81,3 +81,24 @@ def test_grouped_weight_gradient_main_loop_is_clean():
         assert inner["mfma"] == 128 and inner["scratch"] == 0       # two K tiles x four phases x 16 MFMAs, no spill traffic in the loop
         assert inner["vmcnt0"] <= 1                                  # (the end-of-stream drain; the steady state uses counted waits)
         assert k["spill"] == 0 and k["vgpr"] <= 256, inst
+
+
+def test_no_instruction_touches_an_lds_read_still_in_flight():
+    """The GEMM / attention cores issue their fragment reads from inline asm and retire them with explicit lgkmcnt waits: hipcc does not know
+    the destination registers are still in flight.  tools/isa_lint.landing_register_violations replays every kernel's instruction stream
+    (LDS reads complete in issue order; a counted wait retires all but the N youngest) and reports any instruction that reads or writes a
+    register whose read has not been waited for -- the class of defect found (on global loads) in round 4's LayerNorm experiment."""
+    synthetic = ["\t;;#ASMSTART", "\tds_read_b128 v[10:13], v1", "\t;;#ASMEND", "\t;;#ASMSTART", "\tds_read_b128 v[14:17], v1 offset:64", "\t;;#ASMEND",
+                 "\tv_add_f32_e32 v20, v21, v22", "\t;;#ASMSTART", "\ts_waitcnt lgkmcnt(1)", "\t;;#ASMEND", "\tv_mov_b32_e32 v30, v11",
+                 "\tv_mov_b32_e32 v31, v15", "\t;;#ASMSTART", "\ts_waitcnt lgkmcnt(0)", "\t;;#ASMEND", "\tv_mov_b32_e32 v32, v15"]
+    bad = L.landing_register_violations(synthetic)
+    assert [(i, r) for i, _, r in bad] == [(11, 15)]          # v11 was released by the counted wait, v15 was not
+    total = 0
+    for src in ("gemm_p8.hip", "gemm_tn8.hip", "gemm.hip", "attention.hip"):
+        ks = L.kernels(L.compile_isa(os.path.join(CSRC, src)))
+        assert ks, src
+        for name, k in ks.items():
+            v = L.landing_register_violations(k["body"])
+            assert not v, (src, name, v[:3])
+            total += 1
+    assert total >= 100

@@ -60,6 +60,50 @@ def kernels(isa):
     return out
 
 
+def _vregs(text):
+    out = set()
+    for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", text):
+        out.update(range(int(a), int(b) + 1))
+    out.update(int(a) for a in re.findall(r"\bv(\d+)\b", text))
+    return out
+
+
+def landing_register_violations(body):
+    """Asynchronous LDS reads issued from inline asm WITHOUT a wait in the same statement (`ds_read*` inside an ASMSTART / ASMEND block)
+    land in their destination registers some time later; the kernel retires them with an explicit `s_waitcnt lgkmcnt(..)` asm statement
+    that lists those registers as in / out operands.  hipcc believes the values are there at once: if it copies, spills or reuses a
+    landing register between the read and the wait, the copy holds stale data (seen once: a tied operand copied IN FRONT of the wait).
+    Returns [(line index, instruction, register)] for every instruction outside asm blocks that touches a landing register while its
+    read is in flight; [] is the contract."""
+    queue, bad, in_asm = [], [], False      # in-flight asm reads in issue order: [set of destination registers]
+    for i, l in enumerate(body):
+        t = l.strip()
+        if "ASMSTART" in t:
+            in_asm = True
+            continue
+        if "ASMEND" in t:
+            in_asm = False
+            continue
+        if not t or t.startswith(";") or t.startswith("."):
+            continue
+        m = re.search(r"lgkmcnt\((\d+)\)", t) if t.startswith("s_waitcnt") else None
+        if m:      # LDS operations complete in issue order: all but the N youngest reads have landed (other lgkm operations in flight can
+            n = int(m.group(1))      # only make the real wait longer than this model assumes -- never shorter)
+            queue = queue[len(queue) - n:] if n else []
+            continue
+        if in_asm:
+            m = re.match(r"ds_read\w*\s+(v\[\d+:\d+\]|v\d+)", t)
+            if m:
+                queue.append(_vregs(m.group(1)))
+            continue
+        touched = _vregs(t)
+        for regs in queue:
+            if touched & regs:
+                bad.append((i, t, min(touched & regs)))
+                break
+    return bad
+
+
 def find(ks, pattern):
     """The one kernel whose mangled name matches `pattern` (regex)."""
     hits = [n for n in ks if re.search(pattern, n)]
