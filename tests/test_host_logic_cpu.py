@@ -366,3 +366,62 @@ def test_finetune_entry_points_resolve_reference_style_configs_and_schedules():
                 assert abs(opt.param_groups[0]["lr"] - fn(k)) < 1e-9, (k, opt.param_groups[0]["lr"], fn(k))
                 opt.step()
                 s.step()
+
+
+def test_partial_pretrain_renaming_and_partial_load():
+    """NETWORK.PARTIAL_PRETRAIN of the fine-tuning entry points: key renaming by the first matching prefix rule, the VCR extras (relationship
+    head -> 1-logit classifier, segment-embedding init), then the tolerant partial load -- against the reference's own
+    smart_partial_load_model_state_dict where the reference tree is present, and against hand-checked expectations everywhere."""
+    import importlib
+    import torch
+    C = importlib.import_module("vl-bert_amd.common.checkpoint")
+    g = torch.Generator().manual_seed(0)
+    pre = {
+        "module.vlbert.mlm_head.predictions.transform.dense.weight": torch.randn(4, 4, generator=g),
+        "module.vlbert.word_embeddings.weight": torch.randn(6, 4, generator=g),
+        "module.vlbert.token_type_embeddings.weight": torch.randn(3, 4, generator=g).half(),
+        "module.vlbert.relationsip_head.caption_image_relationship.weight": torch.randn(2, 4, generator=g),
+        "module.vlbert.relationsip_head.caption_image_relationship.bias": torch.randn(2, generator=g),
+        "module.unrelated.weight": torch.randn(2, generator=g),
+    }
+    rules = ["module.vlbert.mlm_head.predictions.transform->module.final_mlp.0", "module.vlbert->module.vlbert._module", "vlbert->vlbert._module"]
+    out = C.partial_pretrain_state_dict(pre, rules, load_rel_head=True, segmb_init=True)
+    assert set(out) == {"module.final_mlp.0.dense.weight", "module.vlbert._module.word_embeddings.weight", "module.vlbert._module.token_type_embeddings.weight",
+                        "module.vlbert._module.relationsip_head.caption_image_relationship.weight",
+                        "module.vlbert._module.relationsip_head.caption_image_relationship.bias", "module.unrelated.weight",
+                        "module.final_mlp.1.weight", "module.final_mlp.1.bias"}
+    w = pre["module.vlbert.relationsip_head.caption_image_relationship.weight"]
+    assert torch.equal(out["module.final_mlp.1.weight"], w[1:2] - w[0:1]) and out["module.final_mlp.1.weight"].shape == (1, 4)
+    tt = out["module.vlbert._module.token_type_embeddings.weight"]
+    assert tt.dtype == torch.float32 and torch.equal(tt[1], tt[0]) and torch.equal(tt[2], pre["module.vlbert.token_type_embeddings.weight"][2].float())
+    assert pre["module.vlbert.token_type_embeddings.weight"].dtype == torch.float16          # the caller's dict is not modified
+    assert C.partial_pretrain_state_dict(pre, []) == pre
+
+    class Toy(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.final_mlp = torch.nn.Sequential(torch.nn.Sequential(), torch.nn.Linear(4, 1))
+            self.final_mlp[0].add_module("dense", torch.nn.Linear(4, 4, bias=False))
+            self.other = torch.nn.Linear(2, 2)
+
+    def fresh():
+        torch.manual_seed(3)
+        return Toy()
+    mine = fresh()
+    before = {k: v.clone() for k, v in mine.state_dict().items()}
+    lines = []
+    taken, unmatched = C.smart_partial_load(mine, out, log=lines.append)
+    assert sorted(taken) == ["final_mlp.0.dense.weight", "final_mlp.1.bias", "final_mlp.1.weight"] and len(unmatched) == 5 and len(lines) == 3
+    after = mine.state_dict()
+    assert torch.equal(after["final_mlp.0.dense.weight"], pre["module.vlbert.mlm_head.predictions.transform.dense.weight"])
+    assert torch.equal(after["final_mlp.1.weight"], w[1:2] - w[0:1]) and torch.equal(after["other.weight"], before["other.weight"])
+    import os
+    ref_root = os.environ.get("VLBERT_REFERENCE_ROOT", "/root/reference")
+    if os.path.isdir(ref_root):
+        from oracle import ref_import
+        ref_import.import_reference()
+        from common.utils.load import smart_partial_load_model_state_dict
+        theirs = fresh()
+        smart_partial_load_model_state_dict(theirs, out)
+        for k, v in theirs.state_dict().items():
+            assert torch.equal(v, after[k]), k

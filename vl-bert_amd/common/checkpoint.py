@@ -181,3 +181,55 @@ def smart_resume(eng, prefix, begin_epoch, end_epoch, resume=False, auto_resume=
                 log("Auto continue training from {0}".format(path))
                 return epoch
     return begin_epoch
+
+
+def partial_pretrain_state_dict(pretrain_state_dict, prefix_changes=(), load_rel_head=False, segmb_init=False):
+    """The `NETWORK.PARTIAL_PRETRAIN` preparation of the fine-tuning entry points (vqa/function/train.py:198-213, vcr/function/train.py:
+    200-230): every key is renamed by the FIRST matching 'old_prefix->new_prefix' rule of PARTIAL_PRETRAIN_PREFIX_CHANGES (keys without a
+    matching rule stay); VCR extras: LOAD_REL_HEAD seeds the 1-logit answer classifier with (row 1 - row 0) of the pre-trained
+    caption-image relationship head, PARTIAL_PRETRAIN_SEGMB_INIT copies the segment embedding of type 0 over type 1 (VCR uses types 0 / 1
+    for question / answer where pre-training only ever saw type 0 for text).  Returns a new dict; tensors are not copied unless changed."""
+    rules = [tuple(r.split("->")) if isinstance(r, str) else tuple(r) for r in prefix_changes]
+    out = {}
+    for key, value in pretrain_state_dict.items():
+        for old, new in rules:
+            if key.startswith(old):
+                key = new + key[len(old):]
+                break
+        out[key] = value
+    rel_w = "module.vlbert.relationsip_head.caption_image_relationship.weight"
+    rel_b = "module.vlbert.relationsip_head.caption_image_relationship.bias"
+    if load_rel_head and rel_w in pretrain_state_dict:
+        out["module.final_mlp.1.weight"] = pretrain_state_dict[rel_w][1:2].float() - pretrain_state_dict[rel_w][0:1].float()
+        out["module.final_mlp.1.bias"] = pretrain_state_dict[rel_b][1:2].float() - pretrain_state_dict[rel_b][0:1].float()
+    if segmb_init:
+        k = "module.vlbert._module.token_type_embeddings.weight"
+        if k not in out:
+            raise KeyError("PARTIAL_PRETRAIN_SEGMB_INIT: %s is not among the renamed keys (the reference indexes it unconditionally)" % k)
+        t = out[k].float().clone()
+        t[1] = t[0]
+        out[k] = t
+    return out
+
+
+def smart_partial_load(model, state_dict, log=print):
+    """smart_partial_load_model_state_dict (common/utils/load.py:57-81): take every tensor whose key -- as it is, or with a 'module.' prefix
+    added / removed -- names a tensor of the model, leave the rest of the model as it is; report what matched and what did not.
+    `model`: anything with state_dict() / load_state_dict() (the module mirrors, PretrainEngine).  Returns (loaded keys, unmatched keys)."""
+    own = model.state_dict()
+    take, unmatched = {}, []
+    for key, value in state_dict.items():
+        if key not in own:
+            key = key[len("module."):] if key.startswith("module.") else "module." + key
+        if key in own:
+            take[key] = value
+        else:
+            unmatched.append(key)
+    untouched = [k for k in own if k not in take]
+    log("[Partial Load] partial load state dict of keys: {}".format(list(take)))
+    log("[Partial Load] non matched keys: {}".format(unmatched))
+    log("[Partial Load] non pretrain keys: {}".format(untouched))
+    merged = dict(own)
+    merged.update(take)
+    model.load_state_dict(merged)
+    return list(take), unmatched

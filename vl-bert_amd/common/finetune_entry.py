@@ -178,16 +178,27 @@ def main(task, argv=None):
     M = importlib.import_module(pkg + ".%s.modules.resnet_vlbert_for_%s" % (task, task))
     torch.manual_seed(r["seed"])
     net = getattr(M, config.MODULE)(config, device=dev)
-    if args.partial_pretrain:       # common/utils/load.py:57-81: load what matches, report the rest
-        sd = torch.load(args.partial_pretrain, map_location="cpu", weights_only=False)
-        sd = sd.get("state_dict", sd)
-        own = net.state_dict()
-        hit = {k[len("module."):] if k.startswith("module.") else k: v for k, v in sd.items()}
-        hit = {k: v for k, v in hit.items() if k in own and tuple(own[k].shape) == tuple(v.shape)}
-        own.update(hit)
-        net.load_state_dict(own)
+    # NETWORK.PARTIAL_PRETRAIN (+ _PREFIX_CHANGES, LOAD_REL_HEAD, PARTIAL_PRETRAIN_SEGMB_INIT) -- vqa/function/train.py:198-214,
+    # vcr/function/train.py:200-232; --partial-pretrain overrides the path.  A configured file that does not exist is reported and
+    # skipped (the shipped YAMLs name ./model/pretrained_model/...: the reference would stop there; the bench-style runs start from random weights)
+    ckpt_path = args.partial_pretrain or str(config.NETWORK.get("PARTIAL_PRETRAIN", "") or "")
+    if ckpt_path and not os.path.isfile(ckpt_path):
+        if args.partial_pretrain:
+            raise FileNotFoundError(ckpt_path)
         if rank == 0:
-            print("[Partial Load] %d of %d tensors taken from %s" % (len(hit), len(own), args.partial_pretrain), flush=True)
+            print("[Partial Load] NETWORK.PARTIAL_PRETRAIN %s not found: starting from the module's own initialisation" % ckpt_path, flush=True)
+        ckpt_path = ""
+    if ckpt_path:
+        C = importlib.import_module(pkg + ".common.checkpoint")
+        sd = torch.load(ckpt_path, map_location="cpu", weights_only=False)
+        sd = sd.get("state_dict", sd)
+        sd = C.partial_pretrain_state_dict(sd, config.NETWORK.get("PARTIAL_PRETRAIN_PREFIX_CHANGES", []) or [],
+                                           load_rel_head=bool(config.NETWORK.get("LOAD_REL_HEAD", False)),
+                                           segmb_init=bool(config.NETWORK.get("PARTIAL_PRETRAIN_SEGMB_INIT", False)))
+        own = net.state_dict()      # (shape mismatches -- another answer vocabulary -- are left to the module's initialisation)
+        sd = {k: v for k, v in sd.items() if not any(kk in own and tuple(own[kk].shape) != tuple(v.shape)
+                                                      for kk in (k, k[len("module."):] if k.startswith("module.") else "module." + k))}
+        C.smart_partial_load(net, sd, log=(print if rank == 0 else (lambda *a: None)))      # (load_state_dict copies across devices)
     net.train()
     if world > 1:
         net = importlib.import_module(pkg + ".parallel").DistributedDataParallel(net)

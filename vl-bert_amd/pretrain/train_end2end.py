@@ -214,6 +214,22 @@ def main(argv=None):
                                 encoder_fp32=r["compute"] == "fp32", dp_mode="allreduce" if r["compute"] == "fp32" else "default",
                                 loss_scale=r["loss_scale"] if r["compute"] == "fp16" else None)
     eng.init_random(seed=r["seed"], visual_ln_init=float(g("visual_scale_object_init", 0.0)))
+    # NETWORK.PARTIAL_PRETRAIN (+ _PREFIX_CHANGES): start from a pre-trained checkpoint's matching tensors (pretrain/function/train.py:297-313,
+    # common/utils/load.py:57-81).  Empty in every shipped pre-training YAML; a configured file that does not exist is reported and skipped
+    pp = str(config.NETWORK.get("PARTIAL_PRETRAIN", "") or "")
+    if pp and not os.path.isfile(pp):
+        if rank == 0:
+            print("[Partial Load] NETWORK.PARTIAL_PRETRAIN %s not found: starting from the random initialisation" % pp, flush=True)
+        pp = ""
+    if pp:
+        ckpt_mod = importlib.import_module(pkg + ".common.checkpoint")
+        sd = torch.load(pp, map_location="cpu", weights_only=False)
+        sd = ckpt_mod.partial_pretrain_state_dict(sd.get("state_dict", sd), config.NETWORK.get("PARTIAL_PRETRAIN_PREFIX_CHANGES", []) or [])
+        own = eng.state_dict()
+        sd = {k: v.to(eng.dev) for k, v in sd.items()
+              if not any(kk in own and tuple(own[kk].shape) != tuple(v.shape) for kk in (k, k[len("module."):] if k.startswith("module.") else "module." + k))}
+        ckpt_mod.smart_partial_load(eng, sd, log=(print if rank == 0 else (lambda *a: None)))
+        eng.sync_weights()
     eng.broadcast_parameters(src=0)       # rank 0's parameters / optimizer state everywhere (pretrain/function/train.py:331-334)
     if rank == 0:
         print("train_end2end: %s | %d GPU(s) x batch %d | lr %.3e wd %.1e clip %.1f | schedule %s warmup %d t_total %d%s" %
