@@ -1,0 +1,157 @@
+"""ORACLE-anchored data-parallel step (test infrastructure; launched by tests/test_dp_gpu.py, never imported by the package).
+
+The other multi-rank checks compare the replicas with each other; "bit-identical replicas" would also hold if both were wrong in the same
+way.  Here two engine ranks (sharing the one MI355X over gloo, or one GPU each over RCCL with --backend nccl) take two optimizer steps on
+DIFFERENT per-rank batches and every stage is compared with the CPU oracle (oracle/vlbert_oracle.py, which restates the reference):
+
+  (1) exchange:   the reduced gradient / world  ==  mean over ranks of the oracle's per-rank gradients (each rank's loss is a mean
+                  over ITS valid tokens, then the cross-rank mean -- what DDP computes at pretrain/function/train.py:89-90), per tensor
+                  in relative Frobenius norm (the bound of the single-rank engine tests) and in the global norm (north_star: 1e-2);
+  (2) optimizer:  the weights after the engine's clip + AdamW (sharded or replicated)  ==  the oracle's clip_coef + adamw_step
+                  (common/trainer.py:139-145, common/nlp/bert/optimization.py:155-185) applied to that reduced gradient, to 2e-6 per
+                  step -- the trajectory the engine's own gradients imply;
+  (3) trajectory: the weights against the PURE oracle trajectory (oracle gradients all the way).  Adam's first steps are sign-like
+                  (update = lr g / |g|), so an element whose gradient is rounding noise lands 2 lr away: reported as
+                  |difference| / |distance moved| and bounded loosely.
+
+Launch: python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P tests/dp2_oracle_check.py
+        [--mode sharded|allreduce] [--backend gloo|nccl] [--wire fp32]"""
+import importlib
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import vlbert_oracle as O      # noqa: E402  (the checker)
+
+
+def arg(name, default):
+    return sys.argv[sys.argv.index(name) + 1] if name in sys.argv else default
+
+
+def rel_fro(a, b):
+    a, b = a.double().reshape(-1), b.double().reshape(-1)
+    return float((a - b).norm() / max(float(b.norm()), 1e-300))
+
+
+def main():
+    mode, backend, wire = arg("--mode", "sharded"), arg("--backend", "gloo"), arg("--wire", "default")
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    DEV = "cuda:%d" % (int(os.environ.get("LOCAL_RANK", "0")) if backend == "nccl" else 0)
+    torch.cuda.set_device(DEV)
+    if backend == "nccl":
+        import datetime
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(DEV), timeout=datetime.timedelta(seconds=180))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    E = importlib.import_module("vl-bert_amd.engine")
+    syn = importlib.import_module("vl-bert_amd.synthetic")
+    ops = importlib.import_module("vl-bert_amd.ops")
+    B, T, R, STEPS = 2, 16, 6, 2
+    lr, wd, max_norm = 1e-3, 1e-2, 1.0
+    cfg = O.VLBertConfig(num_hidden_layers=2)
+    params = O.init_params(cfg, seed=4)
+    mc = E.ModelConfig(hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers, num_attention_heads=cfg.num_attention_heads,
+                       intermediate_size=cfg.intermediate_size, vocab_size=cfg.vocab_size,
+                       max_position_embeddings=cfg.max_position_embeddings, visual_region_classes=cfg.visual_region_classes,
+                       hidden_dropout_prob=cfg.hidden_dropout_prob, attention_probs_dropout_prob=cfg.attention_probs_dropout_prob,
+                       obj_downsample_dropout=cfg.obj_downsample_dropout, with_pooler=cfg.with_pooler, with_rel_loss=cfg.with_rel_loss)
+    eng = E.PretrainEngine(mc, B, T, R, device=DEV, train=False, lr=lr, weight_decay=wd, max_grad_norm=max_norm, dp_mode=mode,
+                           dp_wire=(None if wire == "fp32" else "default"))
+    bk = eng.buckets
+    assert bk is not None and (bk.world == world) and bk.sharded == (mode == "sharded"), (mode, bk and bk.sharded)
+    wire16 = bk.wire_dtype is not None
+    print("rank %d: backend %s, %s exchange, wire %s, collectives %s" %
+          (rank, backend, mode, "16-bit" if wire16 else "fp32", "emulated (all-reduce)" if bk.emulate else "native"), flush=True)
+    eng.load_state_dict({k: v.to(DEV) for k, v in params.items()})
+    eng.sync_weights()
+    names = [n for n in params if n in eng.P.shapes]
+    # every rank evaluates the oracle for EVERY rank's batch (tiny model, CPU): no oracle numbers travel over the backend under test
+    batches = [[syn.make_batch(B, T, R, seed=100 + 10 * s + r, ragged=True) for r in range(world)] for s in range(STEPS)]
+
+    def oracle_mean_grads(weights, step):
+        per = [O.loss_and_grads(weights, cfg, batches[step][r], train=False) for r in range(world)]
+        g = {n: sum(p[2][n] for p in per) / world for n in names}
+        return g, [float(p[1]) for p in per]
+
+    # trajectory (2): oracle optimizer arithmetic on the ENGINE's reduced gradient; trajectory (3): oracle all the way
+    ref2 = {n: params[n].clone() for n in names}
+    ref3 = {n: params[n].clone() for n in names}
+    st2 = {n: (torch.zeros_like(params[n]), torch.zeros_like(params[n])) for n in names}
+    st3 = {n: (torch.zeros_like(params[n]), torch.zeros_like(params[n])) for n in names}
+    worst_all = dict(grad=0.0, norm=0.0, opt=0.0, traj=0.0)
+    for step in range(STEPS):
+        eng.set_batch(*[t.to(DEV) for t in batches[step][rank]])
+        eng.zero_grad()
+        eng.forward(False)                                   # dropout off: the oracle's eval-mode forward (SURVEY 8c pitfall ii)
+        eng.backward(False, on_layer_done=bk.on_done)
+        bk.wait()
+        torch.cuda.synchronize()
+        # the reduced gradient (SUM over ranks) as the optimizer will read it, assembled on every rank
+        if bk.sharded:
+            full = torch.zeros(eng.P.numel, dtype=torch.float32, device=DEV)
+            for p0, c0, n in bk.owned_rows():
+                full[p0:p0 + n] = bk.grad_shard[c0:c0 + n].float()
+            if world > 1:
+                dist.all_reduce(full)
+        else:
+            full = bk.reduced.float().clone()
+        red = {n: (t.cpu() / world) for n, t in eng.P.named(full).items() if n in params}
+        loss_hip = eng.loss_values()["loss"]
+        # (1) against the oracle's mean gradient at the weights the engine computed with (= trajectory 2, to 1e-6)
+        og, olosses = oracle_mean_grads(ref2, step)
+        onorm = float(torch.sqrt(sum((g.double() ** 2).sum() for g in og.values())))
+        rnorm = float(torch.sqrt(sum((g.double() ** 2).sum() for g in red.values())))
+        worst = max((rel_fro(red[n], og[n]), n) for n in names if float(og[n].norm()) >= 1e-6 * onorm)
+        print("rank %d step %d: loss hip %.5f oracle %.5f | reduced-gradient norm hip %.5f oracle %.5f (rel %.2e) | worst tensor rel-Fro "
+              "%.3e (%s)" % (rank, step + 1, loss_hip, olosses[rank], rnorm, onorm, abs(rnorm - onorm) / onorm, worst[0], worst[1]), flush=True)
+        assert abs(loss_hip - olosses[rank]) <= 1e-2 * max(1.0, abs(olosses[rank])), (loss_hip, olosses[rank])
+        assert abs(rnorm - onorm) <= 1e-2 * onorm, (rnorm, onorm)
+        assert worst[0] <= 5e-2, worst
+        worst_all["grad"], worst_all["norm"] = max(worst_all["grad"], worst[0]), max(worst_all["norm"], abs(rnorm - onorm) / onorm)
+        # the engine's optimizer step, then the two oracle trajectories
+        eng.optimizer_step()
+        torch.cuda.synchronize()
+        sd = {n: t.cpu() for n, t in eng.state_dict().items() if n in params}        # (sharded: gathers the master -- a collective)
+        coef2 = O.clip_coef(rnorm, max_norm)
+        for n in names:
+            O.adamw_step(ref2[n], red[n] * coef2, st2[n][0], st2[n][1], step + 1, lr, eps=1e-6, weight_decay=wd)
+        og3, _ = oracle_mean_grads(ref3, step)
+        n3 = float(torch.sqrt(sum((g.double() ** 2).sum() for g in og3.values())))
+        coef3 = O.clip_coef(n3, max_norm)
+        for n in names:
+            O.adamw_step(ref3[n], og3[n] * coef3, st3[n][0], st3[n][1], step + 1, lr, eps=1e-6, weight_decay=wd)
+        opt_err = max((float((sd[n] - ref2[n]).abs().max()), n) for n in names)
+        num = sum(float((sd[n].double() - ref3[n].double()).pow(2).sum()) for n in names)
+        den = sum(float((ref3[n].double() - params[n].double()).pow(2).sum()) for n in names)
+        traj = (num / max(den, 1e-300)) ** 0.5
+        print("rank %d step %d: clip coefficient %.5f | weights vs oracle clip+AdamW on the reduced gradient: max |diff| %.3e (%s) | vs the "
+              "pure oracle trajectory: |diff| / |moved| = %.3e" % (rank, step + 1, coef2, opt_err[0], opt_err[1], traj), flush=True)
+        assert coef2 < 1.0, "the clip must be active in this check"
+        assert opt_err[0] <= 2e-6 * (step + 1), opt_err
+        assert traj <= 0.5, traj
+        worst_all["opt"], worst_all["traj"] = max(worst_all["opt"], opt_err[0]), max(worst_all["traj"], traj)
+        # the 16-bit working copy every rank computes the next forward with is the rounding of those weights
+        eng.forward(False)
+        torch.cuda.synchronize()
+        w16 = eng.P.named(eng.P.w16)
+        for n in ("vlbert.encoder.layer.0.intermediate.dense.weight", "vlbert.word_embeddings.weight"):
+            assert torch.equal(w16[n].cpu(), sd[n].to(ops.BF16)), n
+    mine = eng.P.master.clone()
+    other = mine.clone()
+    dist.broadcast(other, src=0)
+    same = bool(torch.equal(mine, other))
+    print("rank %d: ORACLE-ANCHORED DP OK=%s after %d steps (%s, world %d): gradient rel-Fro <= %.3e, norm rel <= %.2e, optimizer max |diff| "
+          "%.2e, trajectory ratio %.3f ; replicas identical: %s" % (rank, same, STEPS, mode, world, worst_all["grad"], worst_all["norm"],
+                                                                   worst_all["opt"], worst_all["traj"], same), flush=True)
+    assert same
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

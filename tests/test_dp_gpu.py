@@ -13,7 +13,33 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(extra, tool="dp2_check.py"):
+def _rank_report(stdout, stderr, limit=70):
+    """What the ranks themselves said: every `[rankN]:` traceback line torchrun relays (the failing rank's exception, not the
+    launcher's boilerplate that follows it) and the last result lines of the tool -- this is what goes into the assertion message."""
+    import re
+    tb = [l for l in stderr.splitlines() if re.match(r"^\[rank\d+\]:", l)]
+    # the rank that failed FIRST is the one whose error is not a consequence of a peer going away
+    own = [l for l in tb if "Connection closed by peer" not in l and "SIGTERM" not in l]
+    said = [l for l in stdout.splitlines() if re.match(r"^rank \d+", l)]
+    return "\n".join(["---- rank tracebacks ----"] + (own or tb)[:limit] + ["---- rank output (tail) ----"] + said[-24:])
+
+
+def _launch(cmd, env, tag, timeout=600):
+    """Run one multi-process tool; full per-run log under gpurun_out/ (merged back from the GPU box), rank-level report on failure."""
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "dp_test_%s.log" % tag), "w") as f:
+            f.write(r.stdout + "\n---- stderr ----\n" + r.stderr)
+    except OSError:
+        pass
+    report = _rank_report(r.stdout, r.stderr)
+    print(report)
+    assert r.returncode == 0, "%s exited %d\n%s" % (tag, r.returncode, report)
+    return r
+
+
+def _run(extra, tool="dp2_check.py", nproc=2, env_extra=None, marker="parameters identical to rank 0 after 2 D"):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -21,20 +47,14 @@ def _run(extra, tool="dp2_check.py"):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env["OMP_NUM_THREADS"] = "4"
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "tools", tool)] + extra
-    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
-    print(r.stdout[-3000:])
-    print(r.stderr[-3000:])
-    try:
-        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-        with open(os.path.join(ROOT, "gpurun_out", "dp_test_%s.log" % "_".join([tool[:-3]] + [a.strip("-") for a in extra])), "w") as f:
-            f.write(r.stdout + "\n---- stderr ----\n" + r.stderr)
-    except OSError:
-        pass
-    assert r.returncode == 0, r.stderr[-2000:]
-    assert r.stdout.count("parameters identical to rank 0 after 2 D") == 2 and "identical to rank 0 after 2 DP steps: False" not in r.stdout \
-        and "after 2 DDP steps: False" not in r.stdout
+    env.update(env_extra or {})
+    path = os.path.join(ROOT, tool) if os.sep in tool else os.path.join(ROOT, "tools", tool)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), path] + extra
+    r = _launch(cmd, env, "_".join([os.path.basename(tool)[:-3]] + [a.strip("-") for a in extra] + ["n%d" % nproc]))
+    report = _rank_report(r.stdout, r.stderr)
+    assert r.stdout.count(marker) == nproc and "identical to rank 0 after 2 DP steps: False" not in r.stdout \
+        and "after 2 DDP steps: False" not in r.stdout, report
     return r.stdout
 
 
@@ -56,6 +76,29 @@ def test_module_mirror_under_distributed_data_parallel():
     """parallel.DistributedDataParallel around the VQA module mirror (vqa/function/train.py:327): gradients = the hand-averaged local
     gradients, identical replicas after two FusedAdamW steps with the fused clip, no_sync() semantics."""
     _run([], tool="dp2_mirror_check.py")
+
+
+@pytest.mark.parametrize("mode", ["sharded", "allreduce"])
+def test_two_ranks_against_the_oracle(mode):
+    """The oracle anchor of the multi-rank path (tests/dp2_oracle_check.py): two ranks, different batches, two optimizer steps --
+    the reduced gradient against the mean of the oracle's per-rank gradients (pretrain/function/train.py:89-90), the weights against
+    the oracle's clip + AdamW (common/trainer.py:139-145, common/nlp/bert/optimization.py:155-185), replicas identical."""
+    out = _run(["--mode", mode], tool=os.path.join("tests", "dp2_oracle_check.py"), marker="ORACLE-ANCHORED DP OK=True")
+    assert out.count("collectives emulated") == 2
+
+
+@pytest.mark.parametrize("mode", ["sharded", "allreduce"])
+def test_rccl_world_of_one_runs_the_native_exchange(mode):
+    """RCCL on the 1-GPU box: one rank over `nccl` with VLB_DP_FORCE_EXCHANGE=1 -- every collective is the identity, but the code the
+    8-GPU run depends on EXECUTES: native reduce_scatter_tensor / all_gather_into_tensor / all_reduce on the communicator's stream,
+    the wire casts, the sharded clip + AdamW, the weight gather under the next forward, and engine.make_step_graph()'s hipGraph
+    segments cut around the RCCL calls -- the same checks as the two-rank gloo run, plus the oracle anchor."""
+    env = {"VLB_DP_FORCE_EXCHANGE": "1"}
+    out = _run(["--mode", mode, "--backend", "nccl"], nproc=1, env_extra=env)
+    assert out.count("backend nccl") == 1 and "collectives native" in out and "graph replay:" in out
+    out = _run(["--mode", mode, "--backend", "nccl"], tool=os.path.join("tests", "dp2_oracle_check.py"), nproc=1, env_extra=env,
+               marker="ORACLE-ANCHORED DP OK=True")
+    assert "collectives native" in out
 
 
 _COMM_SCRIPT = r"""

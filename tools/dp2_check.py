@@ -77,7 +77,7 @@ def main():
     # two backward passes of one rank are not bit-identical (fp32 atomics: LayerNorm / embedding sums; e2e: ROIAlign backward, whose
     # rounding to bf16 then propagates through the trunk), so this compares to a tolerance; check (1) below is exact
     assert err < (1e-2 if wire16 else (1e-3 if e2e else 1e-6)), err
-    assert float((red.float() - local).abs().max()) > 0
+    assert world == 1 or float((red.float() - local).abs().max()) > 0
     # (1) two full steps -> identical parameters on both ranks
     start_master = eng.P.master.clone()
     for _ in range(2):

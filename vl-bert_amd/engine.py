@@ -408,7 +408,8 @@ class PretrainEngine:
         # folded weight copies are refreshed once it has landed (backward / the next forward of the vision path)
         self._wT_stale = self._gather_pending = self._vision_stale = False
         self._dp_hook = None         # set by parallel.DistributedDataParallel on the engines of a module mirror (shared flat buffers)
-        if world > 1 and self._own_flat:
+        from .parallel import force_exchange
+        if (world > 1 or force_exchange()) and self._own_flat:      # (VLB_DP_FORCE_EXCHANGE: the exchange as identities in a world of one)
             from .parallel import GradBuckets
             vstart = min((o for n, o in self.P.offsets.items() if n.startswith("image_feature_extractor.") and
                           not n.startswith("image_feature_extractor.obj_downsample")), default=None)

@@ -84,7 +84,12 @@ class _FlatStateMixin:
         key = (gi, tuple((p.data_ptr(), p.grad.data_ptr()) for p in ps))
         if self._runs.get("key%d" % gi) != key:          # layout changed (first step / re-allocated gradients): re-derive the runs
             self._runs["key%d" % gi] = key
-            self._runs[gi] = _flat_runs(ps)
+            # The runs are FOUND in address order but VISITED in the order of the group's parameter list: which of two separate
+            # allocations lies lower is the allocator's business and differs between the processes of a data-parallel job, and the
+            # squared norm is accumulated run by run (fp32, not associative) -- in address order two replicas holding bit-identical
+            # gradients derived clip coefficients one ulp apart and drifted (round-4 GPUTEST: dp2_mirror_check `assert same`).
+            where = {id(p): i for i, p in enumerate(group["params"])}
+            self._runs[gi] = sorted(_flat_runs(ps), key=lambda r: min(where[id(p)] for p in ps[r[0]:r[1]]))
         return ps, self._runs[gi]
 
     def _sumsq_all(self):

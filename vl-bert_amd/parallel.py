@@ -69,6 +69,11 @@ def default_mode():
     return v
 
 
+def force_exchange():
+    """VLB_DP_FORCE_EXCHANGE=1 and an initialised process group: run the data-parallel exchange even in a world of one."""
+    return os.environ.get("VLB_DP_FORCE_EXCHANGE", "0") == "1" and dist.is_available() and dist.is_initialized()
+
+
 def shard_alignment(world):
     """Element grid every bucket boundary (and the flat buffer's length) lies on in sharded mode: a bucket then splits into `world`
     slices of whole 64-element (256-B fp32 / 128-B bf16) units."""
@@ -89,6 +94,10 @@ class GradBuckets:
         self.numel = numel
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        # single: nothing to exchange (a world of one).  VLB_DP_FORCE_EXCHANGE=1 keeps the whole exchange ON in a world of one -- every
+        # collective is then the identity, but the communicator's reduce-scatter / all-gather / all-reduce calls, their stream
+        # ordering and the graph segments cut around them all execute: the way a 1-GPU box runs the RCCL code path (tests/test_dp_gpu.py)
+        self.single = self.world == 1 and not force_exchange()
         self.wire_dtype = default_wire_dtype(self.world) if wire_dtype == "default" else wire_dtype
         if self.wire_dtype == flat_grad.dtype:
             self.wire_dtype = None
@@ -165,7 +174,7 @@ class GradBuckets:
         self.vision_keys = [k for k, _, _ in vis]
         self.launched = set()
         self.pending = []
-        self._complete = self.world == 1
+        self._complete = self.single
         self._null = False                        # null_collectives(): timing mode, every collective call skipped
         # ---- sharded mode: compact images + the forward-order weight gather --------------------------------------------------
         if self.sharded:
@@ -215,7 +224,7 @@ class GradBuckets:
         self._null = bool(on)
 
     def _launch(self, lo, hi):
-        if self.world == 1:
+        if self.single:
             return
         src = self._cast_to_wire(lo, hi) if self.wire is not None else self.flat[lo:hi]
         if self._null:
@@ -257,7 +266,7 @@ class GradBuckets:
 
     def will_launch(self, what):
         """True when on_done(what) would start a collective now (engine.backward joins its side stream only then)."""
-        if self.world == 1 or what in self.launched:
+        if self.single or what in self.launched:
             return False
         return what in self.layer_bucket or what in self.ranges or what in ("vision", "embed")
 
@@ -270,14 +279,14 @@ class GradBuckets:
         # every range must have gone out this step: the optimizer reads the wire / compact image, and a slice that was not launched
         # would silently hold the previous step's gradient (a backward() without the on_done hook on a data-parallel engine)
         keys = {k for k, _, _ in self.buckets}
-        self._complete = self.world == 1 or keys <= self.launched
+        self._complete = self.single or keys <= self.launched
         self._missing = sorted(map(str, keys - self.launched))
         self.launched = set()
 
     def invalidate(self):
         """A backward ran without the exchange hooks (a gradient-accumulation micro-step): the images are stale until the next
         hooked backward + wait()."""
-        if self.world > 1:
+        if not self.single:
             self._complete = False
             self._missing = ["all (the last backward ran without the exchange hook)"]
 
@@ -292,7 +301,7 @@ class GradBuckets:
         fp32 buffer (always the flat buffer at world size 1, where nothing is exchanged)."""
         if self.sharded:
             raise RuntimeError("sharded exchange: the reduced gradient exists as this rank's slices only (grad_shard / owned_rows)")
-        if self.world == 1:
+        if self.single:
             return self.flat
         self._check_complete()
         return self.wire if self.wire is not None else self.flat
@@ -312,7 +321,7 @@ class GradBuckets:
     # ------------------------------------------------------------------------------------------------------------------
     def all_reduce_scalar(self, t):
         """Sum of the ranks' partial squared gradient norms (every rank receives the same bits)."""
-        if self.world > 1 and not self._null:
+        if not self.single and not self._null:
             dist.all_reduce(t, group=self.group)
 
     def _all_gather(self, out, inp, async_op=True):
@@ -335,7 +344,7 @@ class GradBuckets:
         non-zero term per element, so the sum is that rank's value bit for bit) distributes them, and the first wait_params of the
         next forward unpacks the image into the master -- in front of the first kernel that reads a bias."""
         self._repl = None
-        if not self.sharded or self.world == 1:
+        if not self.sharded or self.single:
             return
         own, full, off = [], [], 0
         for lo, hi in sorted((int(a), int(b)) for a, b in ranges if b > a):
@@ -375,7 +384,7 @@ class GradBuckets:
         stages' convolution weights are folded from the fp32 master (vision.py), so for those buckets the fp32 master slices travel
         instead (`vision_master`, default: when `master` is given and there are vision buckets -- the older calling form).  `master` +
         set_replicated_fp32(): the fp32-read tensors are replicated first (see there)."""
-        if self.world == 1 or self._null:
+        if self.single or self._null:
             return
         if vision_master is None:
             vision_master = master is not None
@@ -400,7 +409,7 @@ class GradBuckets:
 
     def gather_master(self, master):
         """Blocking: every rank's authoritative fp32 master slices into the full flat `master` (checkpoints; a collective)."""
-        if self.world == 1 or not self.sharded:
+        if self.single or not self.sharded:
             return
         self.wait_params("all")
         stage = torch.empty(max(self.piece(k)[2] for k, _, _ in self.buckets), dtype=master.dtype, device=master.device)
