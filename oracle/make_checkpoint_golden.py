@@ -44,7 +44,45 @@ def build(cfg, tag):
     return RefModel(ref_import.make_reference_config(cfg, vocab_dir)), RefAdamW
 
 
+def e2e_fastrcnn_names(num_layers):
+    """named_parameters() of the reference's FastRCNN with IMAGE_FEAT_PRECOMPUTED false (common/fast_rcnn.py:54-109): the head of the
+    e2e models' optimizer index order (image_feature_extractor is the wrappers' first sub-module)."""
+    from oracle import vision_oracle as VO
+    ref_import.import_reference()
+    ref_import.install_roi_align_oracle()
+    import common.lib.roi_pooling as rp
+    rp.C_ROIPooling = sys.modules["common.lib.roi_pooling.C_ROIPooling"]
+    import common.lib.roi_pooling.roi_align as ra_mod
+    ra_mod.C_ROIPooling = rp.C_ROIPooling
+    from common.fast_rcnn import FastRCNN as RefFastRCNN
+    P = VO.init_vision_params(7, num_layers)
+    E = ref_import._EasyDict
+    cfg = E(dict(NETWORK=dict(IMAGE_FEAT_PRECOMPUTED=False, IMAGE_SEMANTIC=False, IMAGE_STRIDE_IN_1x1=True, IMAGE_C5_DILATED=True,
+                              IMAGE_NUM_LAYERS=num_layers, IMAGE_PRETRAINED="oracle_init", IMAGE_PRETRAINED_EPOCH=0,
+                              OUTPUT_CONV5=False, IMAGE_FROZEN_BN=True, IMAGE_FROZEN_BACKBONE_STAGES=[1, 2])))
+    real_load = torch.load
+    torch.load = lambda path, *a, **k: dict(P) if str(path).startswith("oracle_init") else real_load(path, *a, **k)
+    try:
+        model = RefFastRCNN(cfg, average_pool=True, final_dim=768, enable_cnn_reg_loss=False)
+    finally:
+        torch.load = real_load
+    return [n for n, _ in model.named_parameters()], [n for n, p in model.named_parameters() if p.requires_grad]
+
+
+def add_e2e_order():
+    """param_order.json += e2e_fastrcnn_{50,101} (all parameters) and e2e_fastrcnn_{50,101}_trainable (requires_grad) -- ADVICE r4."""
+    path = os.path.join(OUT, "param_order.json")
+    order = json.load(open(path))
+    for nl in (50, 101):
+        order["e2e_fastrcnn_%d" % nl], order["e2e_fastrcnn_%d_trainable" % nl] = e2e_fastrcnn_names(nl)
+    with open(path, "w") as f:
+        json.dump(order, f, indent=0)
+
+
 def main():
+    if "--e2e-order-only" in sys.argv:
+        add_e2e_order()
+        return
     os.makedirs(OUT, exist_ok=True)
     order = {}
     for tag, kw in (("plain", {}), ("pooler_rel", dict(with_pooler=True, with_rel_loss=True)), ("multitask", dict(multitask=True))):
@@ -99,6 +137,7 @@ def main():
                         **{"in_%d" % i: t.numpy() for i, t in enumerate(batch)})
     print("wrote", OUT, "losses", losses, after, "optimizer keys", list(ck["optimizer"].keys()),
           "group keys", list(ck["optimizer"]["param_groups"][0].keys()), "state[0] keys", list(ck["optimizer"]["state"][0].keys()))
+    add_e2e_order()
 
 
 if __name__ == "__main__":

@@ -106,12 +106,16 @@ def main():
         og, olosses = oracle_mean_grads(ref2, step)
         onorm = float(torch.sqrt(sum((g.double() ** 2).sum() for g in og.values())))
         rnorm = float(torch.sqrt(sum((g.double() ** 2).sum() for g in red.values())))
-        worst = max((rel_fro(red[n], og[n]), n) for n in names if float(og[n].norm()) >= 1e-6 * onorm)
+        # per-tensor bound: 5e-2 (the single-rank engine tests' grad_tol) for every tensor that carries >= 1 % of the global norm; a small
+        # tensor (the mask embedding's gradient is a sum over the few masked regions of 2 x 6 boxes) sits nearer the 16-bit noise: 1.5e-1
+        errs = [(rel_fro(red[n], og[n]), n, float(og[n].norm()) / onorm) for n in names if float(og[n].norm()) >= 1e-6 * onorm]
+        bad = [e for e in errs if e[0] > (5e-2 if e[2] >= 1e-2 else 1.5e-1)]
+        worst = max(errs)
         print("rank %d step %d: loss hip %.5f oracle %.5f | reduced-gradient norm hip %.5f oracle %.5f (rel %.2e) | worst tensor rel-Fro "
               "%.3e (%s)" % (rank, step + 1, loss_hip, olosses[rank], rnorm, onorm, abs(rnorm - onorm) / onorm, worst[0], worst[1]), flush=True)
         assert abs(loss_hip - olosses[rank]) <= 1e-2 * max(1.0, abs(olosses[rank])), (loss_hip, olosses[rank])
         assert abs(rnorm - onorm) <= 1e-2 * onorm, (rnorm, onorm)
-        assert worst[0] <= 5e-2, worst
+        assert not bad, bad
         worst_all["grad"], worst_all["norm"] = max(worst_all["grad"], worst[0]), max(worst_all["norm"], abs(rnorm - onorm) / onorm)
         # the engine's optimizer step, then the two oracle trajectories
         eng.optimizer_step()
@@ -133,7 +137,7 @@ def main():
               "pure oracle trajectory: |diff| / |moved| = %.3e" % (rank, step + 1, coef2, opt_err[0], opt_err[1], traj), flush=True)
         assert coef2 < 1.0, "the clip must be active in this check"
         assert opt_err[0] <= 2e-6 * (step + 1), opt_err
-        assert traj <= 0.5, traj
+        assert traj <= 0.1, traj          # (measured 0.022: ~1e-4 of the elements land on the other side of a sign-like Adam step)
         worst_all["opt"], worst_all["traj"] = max(worst_all["opt"], opt_err[0]), max(worst_all["traj"], traj)
         # the 16-bit working copy every rank computes the next forward with is the rounding of those weights
         eng.forward(False)

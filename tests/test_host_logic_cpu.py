@@ -326,6 +326,20 @@ def test_checkpoint_parameter_order_is_the_reference_models():
         assert tuple(ck["optimizer"]["state"][i]["exp_avg"].shape) == tuple(shapes[n]), n
     assert set(ck["state_dict"]) == set(shapes) | {E.TIED_DECODER_KEY}
     assert C.checkpoint_path("out/vl-bert", 3) == "out/vl-bert-0003.model"
+    # e2e (IMAGE_FEAT_PRECOMPUTED false): the reference indexes EVERY parameter of the image branch, frozen stages and frozen BatchNorm
+    # weights / biases included (round-4 ADVICE: the engine only knew its trainable convolutions) -- the structural table against the
+    # real FastRCNN module's named_parameters(), and the engine's trainable set against the module's requires_grad set
+    V = importlib.import_module("vl-bert_amd.vision")
+    for nl in (50, 101):
+        vis = C.reference_vision_param_names(nl)
+        assert vis == order["e2e_fastrcnn_%d" % nl], nl
+        shapes = E.param_layout(E.ModelConfig(**small, e2e=True, image_num_layers=nl))
+        full = C.reference_param_order(shapes, e2e_num_layers=nl)
+        assert full[:len(vis)] == ["image_feature_extractor." + n for n in vis]
+        assert full[len(vis):] == [n for n in order["plain"] if not n.startswith("image_feature_extractor.")]
+        assert set(shapes) <= set(full) and len(set(full)) == len(full)
+        trainable = {"image_feature_extractor." + n for n in order["e2e_fastrcnn_%d_trainable" % nl]}
+        assert {n for n in shapes if n.startswith("image_feature_extractor.")} == trainable, nl
 
 
 def test_finetune_entry_points_resolve_reference_style_configs_and_schedules():
@@ -425,3 +439,19 @@ def test_partial_pretrain_renaming_and_partial_load():
         smart_partial_load_model_state_dict(theirs, out)
         for k, v in theirs.state_dict().items():
             assert torch.equal(v, after[k]), k
+
+
+def test_partial_pretrain_reports_and_bounds_shape_mismatches():
+    """Round-4 ADVICE: tensors dropped for a shape mismatch in front of smart_partial_load are logged with both shapes, and a
+    checkpoint of a different architecture (most name-matching tensors with another shape) is refused instead of silently leaving the
+    network at its random initialisation (the reference raises in load_state_dict, common/utils/load.py:57-81)."""
+    C = importlib.import_module("vl-bert_amd.common.checkpoint")
+    own = {"vlbert.a.weight": torch.zeros(3, 4), "vlbert.b.weight": torch.zeros(5), "final_mlp.weight": torch.zeros(2, 4)}
+    logs = []
+    kept, dropped = C.drop_shape_mismatches({"module.vlbert.a.weight": torch.ones(3, 4), "vlbert.b.weight": torch.ones(5),
+                                             "final_mlp.weight": torch.ones(7, 4), "unknown": torch.ones(1)}, own, log=logs.append)
+    assert sorted(kept) == ["module.vlbert.a.weight", "unknown", "vlbert.b.weight"]
+    assert dropped == [("final_mlp.weight", (7, 4), (2, 4))] and "final_mlp.weight: file (7, 4) vs model (2, 4)" in logs[0]
+    with pytest.raises(ValueError, match="different architecture"):
+        C.drop_shape_mismatches({"vlbert.a.weight": torch.ones(6, 8), "vlbert.b.weight": torch.ones(10), "final_mlp.weight": torch.ones(2, 4)},
+                                own, log=logs.append)

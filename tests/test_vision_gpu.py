@@ -840,3 +840,67 @@ def test_resnet101_forward_at_headline_image_size_vs_oracle():
           (e_body, e_feat, float(feats.abs().max())))
     assert e_body < 2e-2 and e_feat < 1e-2          # measured on MI355X: 9.1e-3 / 3.0e-3
     assert float(boxes[0, 3, 4:].abs().max()) == 0.0          # the padded box slot stays zero
+
+
+def test_e2e_checkpoint_optimizer_state_in_the_reference_index_order(tmp_path):
+    """Round-4 ADVICE (medium): for the e2e model the reference's optimizer indexes EVERY named parameter -- frozen backbone stages and
+    frozen BatchNorm weights / biases too (pretrain/function/train.py:139-142), with no state entry for them.  The engine's checkpoint
+    (a) writes that index table (len = the reference module's parameter count, golden e2e_fastrcnn_50 + the VL-BERT part), state only
+    on the trainable tensors, moments of the convolutions in [O,I,KH,KW]; (b) a file in the REFERENCE's form (no 'param_names', one
+    group) loads into a fresh engine and gives back the identical Adam state and step count; (c) a several-group file without names is
+    refused instead of being zipped against the wrong tensors."""
+    import json
+    E, C, syn = pkg("engine"), pkg("common.checkpoint"), pkg("synthetic")
+    z, nl, P = _vision_fixture()
+    img, boxes4 = torch.from_numpy(z["img"]), torch.from_numpy(z["boxes"]).clone()
+    B, R, T = boxes4.shape[0], boxes4.shape[1], 12
+    cfg = O.VLBertConfig(num_hidden_layers=1)
+    params = O.init_params(cfg, seed=21)
+    batch = list(syn.make_batch(B, T, R, seed=22, ragged=False))
+    batch[0] = torch.cat((boxes4, torch.zeros(B, R, 2048)), -1)
+    batch[1] = torch.from_numpy(z["im_info"])
+    pad = boxes4[:, :, 0] <= -1.5
+    batch[5][pad] = 0
+    batch[6][pad] = 0
+    mc = E.ModelConfig(num_hidden_layers=1, e2e=True, image_num_layers=nl)
+
+    def fresh():
+        eng = E.PretrainEngine(mc, B, T, R, device="cuda:0", train=False, lr=1e-3, image_size=tuple(img.shape[2:]))
+        sd = {k: v.to(dev()) for k, v in params.items()}
+        sd.update({k: v.to(dev()) for k, v in _prefixed(P).items()})
+        eng.load_state_dict(sd)
+        eng.set_batch(*[t.to(dev()) for t in batch], image=img.to(dev()))
+        eng.sync_weights()
+        return eng
+    eng = fresh()
+    for _ in range(2):
+        eng.zero_grad(); eng.forward(False); eng.backward(False); eng.optimizer_step()
+    torch.cuda.synchronize()
+    path = C.save_checkpoint(eng, str(tmp_path / "e2e"), 0)
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    osd = ck["optimizer"]
+    with open(os.path.join(os.path.dirname(__file__), "golden", "checkpoint", "param_order.json")) as f:
+        gold = json.load(f)
+    vis = ["image_feature_extractor." + n for n in gold["e2e_fastrcnn_%d" % nl]]
+    names = osd["param_names"]
+    assert names[:len(vis)] == vis and osd["param_groups"][0]["params"] == list(range(len(names)))
+    trainable = {"image_feature_extractor." + n for n in gold["e2e_fastrcnn_%d_trainable" % nl]}
+    for i, n in enumerate(names):
+        if n.startswith("image_feature_extractor."):
+            assert (i in osd["state"]) == (n in trainable), n
+    i = names.index("image_feature_extractor.roi_head_feature_extractor.0.conv2.weight")
+    assert tuple(osd["state"][i]["exp_avg"].shape) == tuple(ck["state_dict"][names[i]].shape) and osd["state"][i]["exp_avg"].shape[2:] == (3, 3)
+    assert float(osd["state"][i]["exp_avg"].abs().max()) > 0 and int(osd["state"][i]["step"]) == 2
+    # (b) the reference's form of the same file
+    ref_form = dict(ck)
+    ref_form["optimizer"] = {"state": osd["state"], "param_groups": osd["param_groups"]}
+    torch.save(ref_form, str(tmp_path / "ref-0000.model"))
+    eng2 = fresh()
+    C.load_checkpoint(eng2, str(tmp_path / "ref-0000.model"))
+    torch.cuda.synchronize()
+    assert torch.equal(eng2.P.m, eng.P.m) and torch.equal(eng2.P.v, eng.P.v) and torch.equal(eng2.P.master, eng.P.master)
+    assert float(eng2.adam[5]) == 2.0
+    # (c) several groups, no names: refused
+    bad = {"state": osd["state"], "param_groups": [dict(osd["param_groups"][0], params=[0]), dict(osd["param_groups"][0], params=list(range(1, len(names))))]}
+    with pytest.raises(ValueError, match="param_groups"):
+        C.load_optimizer_state_dict(eng2, bad)

@@ -22,9 +22,47 @@ from collections import OrderedDict
 import torch
 
 
-def reference_param_order(names):
-    """`names`: the engine's parameter names (any order) -> the order of the reference model's named_parameters()."""
+_RESNET_BLOCKS = {18: None, 34: None, 50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
+
+
+def reference_vision_param_names(num_layers):
+    """`[n for n, _ in FastRCNN(...).named_parameters()]` of the reference's e2e image branch (common/fast_rcnn.py:54-109 over
+    common/backbone/resnet/resnet.py:62-118,121-199: Bottleneck registers conv1, bn1, conv2, bn2, conv3, bn3, downsample in that order;
+    the module registers backbone, roi_head_feature_extractor (= layer4's blocks), obj_downsample), WITHOUT the wrapper's
+    'image_feature_extractor.' prefix.  Every tensor is listed whether it trains or not: frozen stages and the frozen BatchNorm
+    weights / biases are nn.Parameters with requires_grad False, the reference's optimizer indexes them like any other and simply
+    never creates state for them.  Pinned against the real module by tests/golden/checkpoint/param_order.json (e2e_fastrcnn_*)."""
+    blocks = _RESNET_BLOCKS.get(int(num_layers))
+    if blocks is None:
+        raise ValueError("the e2e image branch is built for ResNet-50 / 101 / 152 (got %r)" % (num_layers,))
+    names = ["backbone.conv1.weight", "backbone.bn1.weight", "backbone.bn1.bias"]
+
+    def bottleneck(prefix, downsample):
+        for i in (1, 2, 3):
+            names.extend([prefix + "conv%d.weight" % i, prefix + "bn%d.weight" % i, prefix + "bn%d.bias" % i])
+        if downsample:
+            names.extend([prefix + "downsample.0.weight", prefix + "downsample.1.weight", prefix + "downsample.1.bias"])
+    for stage in (1, 2, 3):
+        for b in range(blocks[stage - 1]):
+            bottleneck("backbone.layer%d.%d." % (stage, b), b == 0)
+    for b in range(blocks[3]):
+        bottleneck("roi_head_feature_extractor.%d." % b, b == 0)
+    names.extend(["obj_downsample.1.weight", "obj_downsample.1.bias"])
+    return names
+
+
+def reference_param_order(names, e2e_num_layers=None):
+    """`names`: the engine's parameter names (any order) -> the order of the reference model's named_parameters().
+    e2e_num_layers (the e2e engine: cfg.image_num_layers): the list then holds EVERY parameter of the reference's image branch --
+    frozen convolutions and BatchNorm weights / biases included, which the engine does not keep as optimizer tensors (`names` lacks
+    them) -- because the reference's optimizer indexes them (pretrain/function/train.py:139-142 builds its group from
+    model.named_parameters(), frozen or not); callers skip the names the engine has no optimizer tensors for."""
     names = list(names)
+    if e2e_num_layers is not None:
+        vis = ["image_feature_extractor." + n for n in reference_vision_param_names(e2e_num_layers)]
+        seen = set(vis)
+        rest = reference_param_order([n for n in names if n not in seen])
+        return vis + rest
     have = set(names)
     order = []
 
@@ -68,6 +106,16 @@ def checkpoint_path(prefix, epoch):
     return "{}-{:04d}.model".format(prefix, epoch)
 
 
+def _engine_order(eng):
+    """Index -> name table of the optimizer state this engine reads and writes (the reference model's named_parameters() order)."""
+    e2e = eng.cfg.image_num_layers if eng.vision is not None else None
+    order = reference_param_order(eng.P.shapes, e2e_num_layers=e2e)
+    missing = [n for n in eng.P.shapes if n not in set(order)]
+    if missing:
+        raise RuntimeError("checkpoint: engine parameters missing from the reference order: %s" % missing[:4])
+    return order
+
+
 def optimizer_state_dict(eng):
     """The engine's AdamW state in torch.optim's state-dict form (see the module docstring).  A collective with the sharded optimizer."""
     if eng.buckets is not None and eng.buckets.sharded:       # moments live on the owner: gather them like the master weights
@@ -76,11 +124,13 @@ def optimizer_state_dict(eng):
     adam = eng.adam.detach().cpu()
     step = int(round(float(adam[5])))
     shapes = eng.P.shapes
-    order = reference_param_order(shapes)
+    order = _engine_order(eng)
     m, v = eng.P.named(eng.P.m), eng.P.named(eng.P.v)
     vis = eng.vision
     state = {}
     for i, n in enumerate(order):
+        if n not in shapes:       # (e2e) a frozen tensor of the image branch: indexed, no state -- as torch's optimizers leave parameters
+            continue              # that never received a gradient
         em, ev = m[n].detach().cpu().clone(), v[n].detach().cpu().clone()
         if vis is not None and n in eng._vision_names():       # the engine keeps conv weights as [O, KH, KW, I]; the reference as [O, I, KH, KW]
             em, ev = em.permute(0, 3, 1, 2).contiguous(), ev.permute(0, 3, 1, 2).contiguous()
@@ -102,14 +152,31 @@ def load_optimizer_state_dict(eng, osd):
     """Inverse of optimizer_state_dict; accepts files written by the reference (no 'param_names': indices follow its named_parameters()
     order) and by this module."""
     shapes = eng.P.shapes
-    order = osd.get("param_names") or reference_param_order(shapes)
+    own = _engine_order(eng)
+    order = osd.get("param_names")
+    if order is None:
+        # a file written by the reference: indices follow named_parameters() -- but only when there is ONE group.  With a non-empty
+        # TRAIN.LR_MULT the reference builds several groups (pretrain/function/train.py:139-142) and the indices run in GROUP order;
+        # zipping them with named_parameters() would hand moments to the wrong tensors wherever shapes happen to agree.
+        if len(osd["param_groups"]) != 1:
+            raise ValueError("optimizer state with %d param_groups and no 'param_names' (a reference run with TRAIN.LR_MULT): the index "
+                             "-> parameter mapping cannot be recovered; load the weights only (with_optimizer=False)" % len(osd["param_groups"]))
+        order = own
     idx = [i for g in osd["param_groups"] for i in g["params"]]
     if len(idx) != len(order):
-        raise ValueError("optimizer state has %d parameters, the engine %d" % (len(idx), len(order)))
+        raise ValueError("optimizer state has %d parameters, the engine's table %d%s" %
+                         (len(idx), len(order), " (e2e: the reference indexes the frozen image-branch tensors too; is IMAGE_NUM_LAYERS the "
+                                                "same?)" if eng.vision is not None else ""))
     m, v = eng.P.named(eng.P.m), eng.P.named(eng.P.v)
     steps = set()
     visn = eng._vision_names() if eng.vision is not None else ()
+    frozen = set(own) - set(shapes)
     for i, n in zip(idx, order):
+        if n in frozen:           # (e2e) frozen image-branch tensor: the engine keeps no moments for it; a reference file has no state either
+            if osd["state"].get(i) is not None and float(torch.as_tensor(osd["state"][i]["exp_avg"]).abs().sum()) != 0.0:
+                raise ValueError("optimizer state holds moments for %s, which this engine keeps frozen (IMAGE_FROZEN_BACKBONE_STAGES / "
+                                 "IMAGE_FROZEN_BN differ from the run that wrote the file)" % n)
+            continue
         if n not in shapes:
             raise KeyError("optimizer state names a parameter the engine does not have: %s" % n)
         st = osd["state"].get(i)
@@ -210,6 +277,32 @@ def partial_pretrain_state_dict(pretrain_state_dict, prefix_changes=(), load_rel
         t[1] = t[0]
         out[k] = t
     return out
+
+
+def drop_shape_mismatches(state_dict, own, log=print, max_fraction=0.5):
+    """Tensors of `state_dict` whose key (as it is, or with 'module.' added / removed) names a tensor of `own` with ANOTHER shape are
+    taken out before smart_partial_load (an answer classifier for another vocabulary; the reference would raise in load_state_dict).
+    Every dropped key is logged with both shapes (round-4 ADVICE: they used to vanish from both the 'non matched' and the 'non
+    pretrain' report), and a file in which more than `max_fraction` of the matching keys have the wrong shape is refused: that is a
+    checkpoint of another model (base weights against a large model), not a head to re-initialise.  -> (kept dict, [(key, shape in
+    file, shape in model)])."""
+    kept, dropped, matched = {}, [], 0
+    for k, v in state_dict.items():
+        alt = k[len("module."):] if k.startswith("module.") else "module." + k
+        kk = k if k in own else (alt if alt in own else None)
+        if kk is not None:
+            matched += 1
+            if tuple(own[kk].shape) != tuple(v.shape):
+                dropped.append((k, tuple(v.shape), tuple(own[kk].shape)))
+                continue
+        kept[k] = v
+    if dropped:
+        log("[Partial Load] dropped for shape mismatch (left at the model's initialisation): {}".format(
+            ["%s: file %s vs model %s" % d for d in dropped]))
+        if matched and len(dropped) > max_fraction * matched:
+            raise ValueError("PARTIAL_PRETRAIN: %d of the %d tensors that match this model by name have another shape (first: %s: file %s "
+                             "vs model %s) -- this is a checkpoint of a different architecture" % ((len(dropped), matched) + dropped[0]))
+    return kept, dropped
 
 
 def smart_partial_load(model, state_dict, log=print):

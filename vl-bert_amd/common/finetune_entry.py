@@ -195,9 +195,8 @@ def main(task, argv=None):
         sd = C.partial_pretrain_state_dict(sd, config.NETWORK.get("PARTIAL_PRETRAIN_PREFIX_CHANGES", []) or [],
                                            load_rel_head=bool(config.NETWORK.get("LOAD_REL_HEAD", False)),
                                            segmb_init=bool(config.NETWORK.get("PARTIAL_PRETRAIN_SEGMB_INIT", False)))
-        own = net.state_dict()      # (shape mismatches -- another answer vocabulary -- are left to the module's initialisation)
-        sd = {k: v for k, v in sd.items() if not any(kk in own and tuple(own[kk].shape) != tuple(v.shape)
-                                                      for kk in (k, k[len("module."):] if k.startswith("module.") else "module." + k))}
+        own = net.state_dict()      # (shape mismatches -- another answer vocabulary -- are left to the module's initialisation, and SAID)
+        sd, _ = C.drop_shape_mismatches(sd, own, log=(print if rank == 0 else (lambda *a: None)))
         C.smart_partial_load(net, sd, log=(print if rank == 0 else (lambda *a: None)))      # (load_state_dict copies across devices)
     net.train()
     if world > 1:

@@ -760,12 +760,19 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(const GemmParams p) 
       p8_drain<FMH, EPI, (SR == 32 ? 1 : 0)>(p, acc, lds0 + STG, m0, n0, wm, wn, lane, tid, seed);
     }
     // No drain of the epilogue's stores (round 4; p8_flags bit 0 restores the vmcnt(0) of round 3).  The next output tile's K tile 0
-    // was retired by the last in-loop wait, BEFORE the epilogue; its K tile 1 is retired by the next in-loop vmcnt(VM_AHEAD), which
-    // stays sound with stores in the queue: vmcnt counts stores too, LDS-DMA loads retire in order among themselves, so "at most
-    // VM_AHEAD operations outstanding" still implies that every load older than the VM_AHEAD youngest ones (all loads: the
-    // stores are older) has landed -- whatever order stores and loads retire in relative to each other.  What changes: a wave no
-    // longer sits out the L2 / HBM acknowledgement of its last stores behind every tile (all 256 CUs end their epilogues
-    // together: 119-318 MB of stores per launch in bursts); they drain under the first three phases of the next tile instead.
+    // was retired by the last in-loop wait, BEFORE the epilogue.  Its K tile 1 -- whose first half-images were staged in phases 3 / 4
+    // of the last K iteration, i.e. they are OLDER than the epilogue's stores -- is retired by the next in-loop vmcnt(VM_AHEAD).
+    // Loads and stores retire out of order RELATIVE TO EACH OTHER (only loads among loads and stores among stores are ordered), so
+    // "the stores are older" proves nothing.  The invariant that makes the counted wait sound is this one: between the loads a wait
+    // retires and the wait itself, at least VM_AHEAD YOUNGER LOADS are issued (here: K tile 2's W0 and W1 half-images, phases 1-2 of
+    // the next tile).  Then, if a load L being retired were still outstanding at a point where vmcnt <= VM_AHEAD, the VM_AHEAD
+    // younger loads would be outstanding as well (loads retire in order among themselves): VM_AHEAD + 1 operations outstanding, a
+    // contradiction -- however many stores are in the queue and whenever they are acknowledged.  Every counted wait of this file
+    // satisfies it by construction (one stage() per phase, VM_AHEAD of them between a K tile's last load and its wait); a wait that
+    // leans on anything else -- the software-pipelined LayerNorm backward of round 4 relied on load/store order and produced NaN
+    // gradients -- is unsound.  VLB_GEMM_P8_DRAIN=1 stays available for a cold-cache A/B.  What the missing drain buys: a wave no
+    // longer sits out the L2 / HBM acknowledgement of its last stores behind every tile (all 256 CUs end their epilogues together:
+    // 119-318 MB of stores per launch in bursts); they drain under the first three phases of the next tile instead.
     if (p.p8_flags & 1) __builtin_amdgcn_s_waitcnt(0x0F70);
     p8_barrier();
     if (wm == 1 && w + (int)gridDim.x < nt) p8_barrier();   // re-establish the one-segment lag for the next output tile

@@ -226,8 +226,8 @@ def main(argv=None):
         sd = torch.load(pp, map_location="cpu", weights_only=False)
         sd = ckpt_mod.partial_pretrain_state_dict(sd.get("state_dict", sd), config.NETWORK.get("PARTIAL_PRETRAIN_PREFIX_CHANGES", []) or [])
         own = eng.state_dict()
-        sd = {k: v.to(eng.dev) for k, v in sd.items()
-              if not any(kk in own and tuple(own[kk].shape) != tuple(v.shape) for kk in (k, k[len("module."):] if k.startswith("module.") else "module." + k))}
+        sd, dropped = ckpt_mod.drop_shape_mismatches(sd, own, log=(print if rank == 0 else (lambda *a: None)))
+        sd = {k: v.to(eng.dev) for k, v in sd.items()}
         ckpt_mod.smart_partial_load(eng, sd, log=(print if rank == 0 else (lambda *a: None)))
         eng.sync_weights()
     eng.broadcast_parameters(src=0)       # rank 0's parameters / optimizer state everywhere (pretrain/function/train.py:331-334)
@@ -241,7 +241,15 @@ def main(argv=None):
     begin_epoch, prefix = int(config.TRAIN.BEGIN_EPOCH), None
     if args.model_dir:
         cfg_name = os.path.splitext(os.path.basename(args.cfg))[0] if args.cfg else "default"
-        prefix = os.path.join(args.model_dir, str(config.OUTPUT_PATH).lstrip("./"), cfg_name, str(config.MODEL_PREFIX) or "vl-bert")
+        # the reference's layout (pretrain/train_end2end.py:26-27 + common/utils/create_logger.py:24-48 + pretrain/function/train.py:41-46):
+        # <model_dir>/<OUTPUT_PATH>/<cfg name>/<TRAIN_IMAGE_SET of the first data set>_train/<MODEL_PREFIX>-NNNN.model, so that RESUME /
+        # AUTO_RESUME pick up a run directory the reference wrote and the reverse (round-4 ADVICE: the <image set>_train level was
+        # missing, and lstrip("./") strips CHARACTERS -- '../out' became 'out', '/abs/out' became 'abs/out')
+        ds = config.get("DATASET", None)
+        ds = ds[0] if isinstance(ds, (list, tuple)) and len(ds) else ds
+        image_set = str(ds.get("TRAIN_IMAGE_SET", "train")) if ds is not None and hasattr(ds, "get") else "train"
+        prefix = os.path.normpath(os.path.join(args.model_dir, str(config.OUTPUT_PATH), cfg_name, image_set + "_train",
+                                               str(config.MODEL_PREFIX) or "vl-bert"))
         begin_epoch = ckpt.smart_resume(eng, prefix, begin_epoch, int(config.TRAIN.END_EPOCH), resume=bool(config.TRAIN.RESUME),
                                         auto_resume=bool(config.TRAIN.AUTO_RESUME), log=(print if rank == 0 else (lambda *a: None)))
         if begin_epoch > int(config.TRAIN.BEGIN_EPOCH) or config.TRAIN.RESUME:
