@@ -23,6 +23,7 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <mutex>
 #include <type_traits>
 
 #include "vlb_common.h"
@@ -625,6 +626,239 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_nt_ring_kernel(const G
     // loop back-edge hipcc protects their registers with an `s_waitcnt vmcnt(0)` INSIDE the K loop, which would empty the ring at
     // every K tile.  (The next tile's first NS - 1 stages were issued before the epilogue and have landed by now.)
     __builtin_amdgcn_s_waitcnt(0x0F70);
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// STREAM-K form of the ring kernel (round 5): 128x128 tiles, 8 waves, 4-stage ring, ONE workgroup per CU, and the K loop of a
+// launch cut into EQUAL SHARES per workgroup instead of whole tiles per workgroup.
+//
+// Why: the strong-scaling columns of the headline metric run 32-128 samples per GPU.  At M = 3232 the N = 768 GEMMs with a long K
+// (FFN2 forward, FFN1 / QKV data gradients: K = 3072 / 2304) are 156 tiles of 128x128 -- 0.6 of a round of 256 CUs, or, as 128x64
+// tiles, 312 workgroups whose operand stream (43 FLOP per L2 byte) is bound by the 64 B/clk L2 -> LDS path of the CUs that got two
+// of them: 25-34 us per launch for 11-15 GFLOP (450 TFLOP/s; profiles/r04_kernel_stats_batch32.txt), 48 launches per step.  Cut
+// by K every CU gets the same 29 K tiles of a 128x128 tile (64 FLOP per byte): one round at 100 %.
+//
+// Decomposition (XCD-local): block b runs on XCD b % 8 (MI355X_MICROARCH.md, observed placement -- a SPEED assumption only).  Each
+// XCD owns a contiguous run of whole tiles (the grouped tile order of the kernels above); its gridDim.x / 8 blocks cut that run's
+// tiles x K-tiles "units" into equal contiguous shares.  A block therefore walks: [the tail of a tile an earlier block began]
+// [whole tiles] [the head of a tile a later block finishes].  The block that reaches a tile's LAST K tile is its finisher: it adds
+// the partial accumulators the earlier blocks of that tile published (at most a few; all on its own XCD, so the slabs are read
+// from the shared L2) and runs the fused epilogue.  Every block publishes at most ONE partial (its last segment), into its own
+// 64 KiB fp32 slab, lane-linear (16 B per lane and fragment: coalesced both ways).
+//
+// Hand-off (cdna_hip_programming.md "in-launch split-K reduction", MI355X_MICROARCH.md "inter-workgroup visibility"): plain 16-B
+// slab stores -> every wave s_waitcnt vmcnt(0) -> barrier -> lane 0: agent-scope RELEASE fence -> asm s_waitcnt vmcnt(0) (the
+// wait the compiler may drop behind buffer_wbl2) -> relaxed agent-scope flag store.  Finisher: lane 0 polls the flags RELAXED
+// (bounded), ONE agent-scope ACQUIRE fence, barrier, plain 16-B loads; then it clears the flags it consumed (each flag has exactly
+// one consumer), so the flags are all zero again when the launch ends: no per-launch host state, hipGraph replay safe.  Correct for
+// any block -> XCD placement; the same-XCD grouping only makes the slab reads L2 hits.  Contributors always have LOWER block
+// indices than their finisher and never wait for anybody, so a finisher can only wait for blocks dispatched before it.
+// Summation order is fixed (contributors in block order, then the finisher's own segment): deterministic.
+// ------------------------------------------------------------------------------------
+constexpr int SK_SLAB_FLOATS = 128 * 128;        // one partial tile
+constexpr unsigned SK_SPIN_LIMIT = 1u << 20;     // polls (~0.5-1 us each with the sleep) before a finisher gives up and flags an error
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_nt_sk_kernel(const GemmParams p, float* __restrict__ slabs, unsigned* __restrict__ flags) {
+  constexpr int BM = 128, BN = 128, WGM = 2, WGN = 4, NS = 4;
+  constexpr int BK = 64;
+  constexpr int NT = 64 * WGM * WGN;
+  constexpr int WM = BM / WGM, WN = BN / WGN;
+  constexpr int FM = WM / 16, FN = WN / 16;
+  constexpr int NA = BM * 8 / NT, NB = BN * 8 / NT;
+  constexpr int NL = NA + NB;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int nt = p.ntm * p.ntn;
+  const int ntk = p.K / BK;
+  // ---- this block's share: XCD x owns tiles [t_lo, t_lo + ntx) of the grouped order; its P blocks cut ntx * ntk units evenly ----
+  const int P = (int)gridDim.x >> 3;                       // blocks per XCD (gridDim.x is a multiple of 8)
+  const int xcd = (int)blockIdx.x & 7, rx = (int)blockIdx.x >> 3;
+  const int q = nt >> 3, rem = nt & 7;
+  const int t_lo = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
+  const int ntx = q + (xcd < rem ? 1 : 0);
+  const long U = (long)ntx * ntk;
+  auto share_begin = [&](int r) { return (U * r) / P; };   // first unit of block r of this XCD (r = P: one past the end)
+  const long ub = share_begin(rx), ue = share_begin(rx + 1);
+  if (ub >= ue) return;                                    // (fewer units than blocks: nothing to do, nobody waits for this block)
+  auto tile_origin = [&](int t, int& m0, int& n0) {        // grouped order, as in gemm_nt_bf16_kernel (t = position in the order)
+    const int gm = p.tile_group, per_group = gm * p.ntn, gid = t / per_group, first = gid * gm;
+    const int gsz = min(p.ntm - first, gm), r2 = t - gid * per_group;
+    m0 = (first + r2 % gsz) * BM;
+    n0 = (r2 / gsz) * BN;
+  };
+  // ---- producer: walks the units ub .. ue-1 in order, NS - 1 stages ahead of the consumer --------------------------------------
+  const bf16_t* a_src[NA];
+  const bf16_t* b_src[NB];
+  long u_p = ub;
+  int kt_p = 0, issued = 0, slot_p = 0;
+  auto setup = [&](long u) {
+    const int tl = (int)(u / ntk);
+    kt_p = (int)(u - (long)tl * ntk);
+    int m0, n0;
+    tile_origin(t_lo + tl, m0, n0);
+#pragma unroll
+    for (int it = 0; it < NA; ++it) {
+      const int Pc = it * NT + tid, r = Pc >> 3, kc = (Pc & 7) ^ ((r >> 1) & 7);
+      a_src[it] = p.A + (long)min(m0 + r, p.M - 1) * p.lda + kc * 8 + (long)kt_p * BK;
+    }
+#pragma unroll
+    for (int it = 0; it < NB; ++it) {
+      const int Pc = it * NT + tid, r = Pc >> 3, kc = (Pc & 7) ^ ((r >> 1) & 7);
+      b_src[it] = p.B + (long)min(n0 + r, p.N - 1) * p.ldb + kc * 8 + (long)kt_p * BK;
+    }
+  };
+  auto produce = [&]() {
+    if (u_p >= ue) return;
+    char* sa = smem + slot_p * STAGE;
+    char* sb = sa + A_BYTES;
+#pragma unroll
+    for (int it = 0; it < NA; ++it) {
+      __builtin_amdgcn_global_load_lds(GLDS_PTR(a_src[it]), LDS_PTR(sa + (it * NT + wave * 64) * 16), 16, 0, 0);
+      a_src[it] += BK;
+    }
+#pragma unroll
+    for (int it = 0; it < NB; ++it) {
+      __builtin_amdgcn_global_load_lds(GLDS_PTR(b_src[it]), LDS_PTR(sb + (it * NT + wave * 64) * 16), 16, 0, 0);
+      b_src[it] += BK;
+    }
+    ++issued;
+    slot_p = (slot_p + 1 == NS) ? 0 : slot_p + 1;
+    ++u_p;
+    if (++kt_p == ntk && u_p < ue) setup(u_p);             // next tile of this share
+  };
+
+  f32x4 acc[FM][FN];
+  const int frow = lane & 15;
+  const int c0 = (((lane >> 4) ^ (frow >> 1)) << 4);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(smem);
+  const uint32_t a_rel = (uint32_t)((wm * WM + frow) * 128 + c0);
+  const uint32_t b_rel = (uint32_t)(A_BYTES + (wn * WN + frow) * 128 + c0);
+
+  setup(u_p);
+#pragma unroll
+  for (int s_ = 0; s_ < NS - 1; ++s_) produce();
+  int g = 0, slot_c = 0;
+  long u = ub;
+  while (u < ue) {
+    const int tl = (int)(u / ntk);
+    const int k0 = (int)(u - (long)tl * ntk);
+    const int k1 = (int)min((long)ntk, (long)k0 + (ue - u));
+    int m0, n0;
+    tile_origin(t_lo + tl, m0, n0);
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kt = k0; kt < k1; ++kt) {
+      const int ahead = issued - g - 1;
+      if (ahead >= 3) ring_wait_vm<3 * NL>();
+      else if (ahead == 2) ring_wait_vm<2 * NL>();
+      else if (ahead == 1) ring_wait_vm<NL>();
+      else ring_wait_vm<0>();
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      produce();
+      const uint32_t so = lds0 + (uint32_t)(slot_c * STAGE);
+      const uint32_t va0 = so + a_rel, vb0 = so + b_rel, va1 = so + (a_rel ^ 64u), vb1 = so + (b_rel ^ 64u);
+      bf16x8 af[2][FM], bfr[2][FN];
+      vlb_static_for<0, FN>([&](auto j_c) { constexpr int j = decltype(j_c)::value; ring_lds_read<j * 2048>(bfr[0][j], vb0); });
+      vlb_static_for<0, FM>([&](auto i_c) { constexpr int i = decltype(i_c)::value; ring_lds_read<i * 2048>(af[0][i], va0); });
+      vlb_static_for<0, FN>([&](auto j_c) { constexpr int j = decltype(j_c)::value; ring_lds_read<j * 2048>(bfr[1][j], vb1); });
+      vlb_static_for<0, FM>([&](auto i_c) { constexpr int i = decltype(i_c)::value; ring_lds_read<i * 2048>(af[1][i], va1); });
+      __builtin_amdgcn_s_waitcnt(0xC07F | ((FM + FN) << 8));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = VLB_MFMA_16x16x32(bfr[0][j], af[0][i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = VLB_MFMA_16x16x32(bfr[1][j], af[1][i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      ++g;
+      slot_c = (slot_c + 1 == NS) ? 0 : slot_c + 1;
+    }
+    const bool ends = (k1 == ntk);
+    if (!ends) {
+      // ---- this block's last segment stops inside the tile: publish the partial accumulators (see the header) -----------------
+      float* slab = slabs + (long)blockIdx.x * SK_SLAB_FLOATS;
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) *(f32x4*)(slab + ((i * FN + j) * NT + tid) * 4) = acc[i][j];
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(flags + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    } else {
+      if (k0 != 0) {
+        // ---- finisher of a tile earlier blocks began: blocks r_first .. rx-1 of this XCD each hold one partial of it -----------
+        const long v = (long)tl * ntk;                     // first unit of the tile
+        int r_first = (int)((v * P) / U);
+        while (r_first + 1 < P && share_begin(r_first + 1) <= v) ++r_first;
+        while (r_first > 0 && share_begin(r_first) > v) --r_first;
+        if (tid == 0) {
+          for (int c = r_first; c < rx; ++c) {
+            if (share_begin(c) >= share_begin(c + 1)) continue;      // (an empty share publishes nothing)
+            unsigned* f = flags + (c * 8 + xcd);
+            unsigned spins = 0;
+            while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+              __builtin_amdgcn_s_sleep(4);
+              if (++spins > SK_SPIN_LIMIT) {               // never hang the chip: record the failure, take what is there
+                atomicAdd(flags + gridDim.x, 1u);
+                break;
+              }
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+        for (int c = r_first; c < rx; ++c) {
+          if (share_begin(c) >= share_begin(c + 1)) continue;   // (an empty share published nothing)
+          const float* slab = slabs + (long)(c * 8 + xcd) * SK_SLAB_FLOATS;
+#pragma unroll
+          for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+              const f32x4 t4 = *(const f32x4*)(slab + ((i * FN + j) * NT + tid) * 4);
+              acc[i][j] += t4;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                   // every lane has read every slab: the flags may be cleared
+        if (tid == 0)
+          for (int c = r_first; c < rx; ++c)
+            if (share_begin(c) < share_begin(c + 1)) __hip_atomic_store(flags + (c * 8 + xcd), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      const int last = (slot_c == 0) ? NS - 1 : slot_c - 1;
+      const int mb = m0 + wm * WM + (lane & 15), nb = n0 + wn * WN + 4 * (lane >> 4);
+      const EpiStage st = {smem + last * STAGE, m0, n0, wm * WM + (lane & 15), wn * WN + 4 * (lane >> 4), tid, NT, BN};
+      if (m0 + BM <= p.M && n0 + BN <= p.N) {
+        __syncthreads();
+        gemm_epilogue_select<EPI, true, FM, FN>(p, acc, mb, nb, st);
+      } else {
+        gemm_epilogue_select<EPI, false, FM, FN>(p, acc, mb, nb, st);
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                    // one full drain per segment, where the compiler can see it (ring kernel note)
+    u += (k1 - k0);
   }
 }
 
@@ -1321,6 +1555,107 @@ static int gemm_ring_try(GemmParams& p, int splits, bool want_narrow, hipStream_
   return launch_ring_epi<128, 128, 2, 4, 4>(p, stream);
 }
 
+// ---- stream-K launcher (gemm_nt_sk_kernel) ------------------------------------------------------------------------------------
+// Workspace: one 64-KiB fp32 slab + one flag per block, owned by the library (the C ABI of vlb_gemm_nt_bf16 has no scratch
+// argument and the slabs never leave the launch).  Launches on ONE stream are ordered, so they share a workspace; up to SK_STREAMS
+// streams get their own (all allocated on the first use, which is never inside a stream capture: a call that would have to
+// allocate while its stream is capturing is simply not taken and runs on the ring kernel).
+static int g_nt_sk = -1;          // VLB_GEMM_SK: 0 off | 1 auto (default) | 2 every shape the kernel covers
+static int g_sk_min_k = -1, g_sk_max_m = -1;
+void vlb_nt_set_sk(int v) { g_nt_sk = v; }
+constexpr int SK_STREAMS = 4;
+static struct { hipStream_t stream; float* slabs; unsigned* flags; } g_sk_ws[SK_STREAMS];
+static int g_sk_used = 0, g_sk_grid = 0;
+static bool g_sk_ready = false, g_sk_failed = false;
+static std::mutex g_sk_mutex;
+
+static int sk_workspace(hipStream_t stream, float** slabs, unsigned** flags) {      // 0: ok | 1: not available (caller falls back)
+  std::lock_guard<std::mutex> lock(g_sk_mutex);
+  if (g_sk_failed) return 1;
+  if (!g_sk_ready) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return 1; }
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) {
+      g_sk_failed = true;
+      return 1;
+    }
+    g_sk_grid = cus / 8 * 8;
+    const size_t slab_bytes = (size_t)g_sk_grid * SK_SLAB_FLOATS * sizeof(float), flag_bytes = (size_t)(g_sk_grid + 8) * sizeof(unsigned);
+    for (int i = 0; i < SK_STREAMS; ++i) {
+      if (hipMalloc((void**)&g_sk_ws[i].slabs, slab_bytes) != hipSuccess || hipMalloc((void**)&g_sk_ws[i].flags, flag_bytes) != hipSuccess ||
+          hipMemset(g_sk_ws[i].flags, 0, flag_bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        g_sk_failed = true;
+        return 1;
+      }
+    }
+    if (hipDeviceSynchronize() != hipSuccess) { g_sk_failed = true; return 1; }
+    g_sk_ready = true;
+  }
+  for (int i = 0; i < g_sk_used; ++i)
+    if (g_sk_ws[i].stream == stream) { *slabs = g_sk_ws[i].slabs; *flags = g_sk_ws[i].flags; return 0; }
+  if (g_sk_used == SK_STREAMS) return 1;
+  g_sk_ws[g_sk_used].stream = stream;
+  *slabs = g_sk_ws[g_sk_used].slabs;
+  *flags = g_sk_ws[g_sk_used].flags;
+  ++g_sk_used;
+  return 0;
+}
+
+// finishers that gave up waiting for a partial since the library was loaded (0 = every hand-off completed); synchronises the device
+extern "C" long vlb_gemm_sk_timeouts(void) {
+  std::lock_guard<std::mutex> lock(g_sk_mutex);
+  if (!g_sk_ready) return 0;
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  long total = 0;
+  for (int i = 0; i < SK_STREAMS; ++i) {
+    unsigned v = 0;
+    if (hipMemcpy(&v, g_sk_ws[i].flags + g_sk_grid, sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    total += v;
+  }
+  return total;
+}
+
+template <int EPI>
+static int launch_sk_cfg(GemmParams& p, float* slabs, unsigned* flags, hipStream_t stream) {
+  constexpr int smem = 4 * (128 + 128) * 128;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_nt_sk_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_set = true;
+  }
+  static const int group = env_int("VLB_GEMM_TILE_GROUP", 4);
+  p.ntm = vlb_cdiv(p.M, 128);
+  p.ntn = vlb_cdiv(p.N, 128);
+  p.tile_group = group < 1 ? 1 : group;
+  hipLaunchKernelGGL((gemm_nt_sk_kernel<EPI>), dim3(g_sk_grid), dim3(512), smem, stream, p, slabs, flags);
+  VLB_CHECK_LAUNCH("vlb_gemm_nt_bf16(stream-K)");
+  return VLB_OK;
+}
+
+// > 0: not taken
+static int gemm_sk_try(GemmParams& p, int splits, hipStream_t stream) {
+  if (g_nt_sk < 0) g_nt_sk = env_int("VLB_GEMM_SK", 1);
+  if (!g_nt_sk || splits != 1 || p.c_split_stride != 0 || p.k_per_split < p.K || p.out_f32 != 0) return 1;
+  if (g_sk_min_k < 0) { g_sk_min_k = env_int("VLB_GEMM_SK_MIN_K", 1536); g_sk_max_m = env_int("VLB_GEMM_SK_MAX_M", 8192); }
+  // auto: the launches whose whole-tile decomposition leaves most of the chip idle or lopsided and whose K loop is long enough
+  // to carry the ~4 us of a partial hand-off: N <= 1024 (6-8 column tiles), K >= 1536, 1024 <= M <= 8192 -- FFN2 forward and
+  // the FFN1 / QKV data gradients of a 32-64-sample per-GPU batch.  (Thresholds: VLB_GEMM_SK_MIN_K / VLB_GEMM_SK_MAX_M.)
+  if (g_nt_sk == 1 && !(p.N <= 1024 && p.K >= g_sk_min_k && p.M >= 1024 && p.M <= g_sk_max_m)) return 1;
+  const int ec = epi_class(p);
+  if (ec != 0 && ec != 3 && ec != 4 && ec != -1) return 1;
+  float* slabs = nullptr;
+  unsigned* flags = nullptr;
+  if (sk_workspace(stream, &slabs, &flags)) return 1;
+  switch (ec) {
+    case 0: return launch_sk_cfg<0>(p, slabs, flags, stream);
+    case 3: return launch_sk_cfg<3>(p, slabs, flags, stream);
+    case 4: return launch_sk_cfg<4>(p, slabs, flags, stream);
+    default: return launch_sk_cfg<-1>(p, slabs, flags, stream);
+  }
+}
+
 template <int BM, int BN>
 static int launch_gemm(GemmParams& p, int splits, hipStream_t stream) {
   if (BN == 128) return launch_gemm_epi<BM, 128, 2, 4>(p, splits, stream);   // 8 waves of 64x32: 16 waves/CU hide LDS/barrier latency
@@ -1384,6 +1719,10 @@ static int gemm_nt_impl(const void* A, long lda, const void* B, long ldb, void* 
   p.k_per_split = per * 64;
   // large-tile 8-phase core (gemm_p8.hip): bf16 outputs with the fused epilogues of the training step, enough tiles to give
   // every CU a 256-row tile
+  if (splits == 1 && out_mode == 0) {      // stream-K first: its auto rule only claims launches the large-tile core cannot fill
+    const int took = gemm_sk_try(p, splits, stream);
+    if (took <= 0) return took;
+  }
   if (splits == 1 && out_mode == 0) {
     const int took = vlb_gemm_p8_try(p, stream);
     if (took != 0) return took < 0 ? took : VLB_OK;
