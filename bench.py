@@ -51,6 +51,9 @@ def cpu_baseline(cfg_kw, T, R, budget_s=25.0, full=False):
     cores = min(os.cpu_count() or 1, 64)
     torch.set_num_threads(cores)
     cfg = O.VLBertConfig(**cfg_kw)
+    ref = _cpu_baseline_reference(cfg, T, R, cores, budget_s, full)      # the reference's OWN modules where its tree exists
+    if ref is not None:
+        return ref
     params = O.init_params(cfg, seed=0, randomize_all=False)
     Bc = 32 if full else 8
     batch = syn.make_batch(Bc, T, R, seed=0)
@@ -75,6 +78,64 @@ def cpu_baseline(cfg_kw, T, R, budget_s=25.0, full=False):
     return {"value": round(Bc / t, 3), "unit": "samples/s", "cores": cores, "kind": "port",
             "sample": "oracle fwd+bwd+AdamW, %d-layer hidden %d, batch %d x (%d+%d), fp32, dropout on, %s"
                       % (cfg.num_hidden_layers, cfg.hidden_size, Bc, T, R, how)}
+
+
+def _cpu_baseline_reference(cfg, T, R, cores, budget_s, full):
+    """`"kind": "reference"`: forward + backward + AdamW of the REFERENCE's ResNetVLBERTForPretraining (pretrain/modules/
+    resnet_vlbert_for_pretraining.py:93-216) and its own AdamW (common/nlp/bert/optimization.py:107-187), imported from the reference
+    tree through oracle/ref_import.py, on the same synthetic batch and the same bounded sample as the port -- only where that tree
+    exists (the build container; VLBERT_REFERENCE_ROOT).  The GPU box has no reference tree: there this returns None and the caller
+    times the oracle ("port", pinned to the reference at 1e-5 by tests/test_oracle_golden.py)."""
+    import tempfile
+    try:
+        from oracle import ref_import
+        if not os.path.isdir(ref_import.REFERENCE_ROOT):
+            return None
+        import contextlib
+        with contextlib.redirect_stdout(sys.stderr):      # (the reference prints while it builds: stdout carries the ONE JSON line)
+            RefModel, RefAdamW = ref_import.import_reference()
+            vocab_dir = ref_import.make_vocab_dir(os.path.join(tempfile.gettempdir(), "vlb_vocab_bench"), cfg.vocab_size)
+            torch.manual_seed(0)
+            model = RefModel(ref_import.make_reference_config(cfg, vocab_dir))
+    except Exception as e:            # (a reference tree that does not import here: say so, fall back to the port)
+        print("bench.py: cpu_baseline: reference modules not usable (%s: %s) -- timing the oracle port" % (type(e).__name__, e), file=sys.stderr)
+        return None
+    syn = importlib.import_module("vl-bert_amd.synthetic")
+    model.train()
+    Bc = 32 if full else 8
+    batch = syn.make_batch(Bc, T, R, seed=0)
+    opt = RefAdamW([{"params": [p for _, p in model.named_parameters()]}], lr=1e-4, betas=(0.9, 0.999), eps=1e-6, weight_decay=1e-4,
+                   correct_bias=True)
+    times, t_start, it = [], time.time(), 0
+    while it < (8 if full else 4) and (full or (time.time() - t_start) < budget_s):
+        t0 = time.time()
+        _, loss = model(None, *[t.clone() for t in batch])
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        times.append(time.time() - t0)
+        it += 1
+    if full:
+        t = sorted(times[3:])[len(times[3:]) // 2]
+        how = "3 warm-up + %d timed iterations, median %.2f s" % (len(times) - 3, t)
+    else:
+        t = min(times[1:]) if len(times) > 1 else times[0]
+        how = "%d iterations (best of last %d)" % (len(times), max(1, len(times) - 1))
+    return {"value": round(Bc / t, 3), "unit": "samples/s", "cores": cores, "kind": "reference",
+            "sample": "the reference's ResNetVLBERTForPretraining + its AdamW (imported from the reference tree), fwd+bwd+step, %d-layer hidden %d, "
+                      "batch %d x (%d+%d), fp32, dropout on, %s" % (cfg.num_hidden_layers, cfg.hidden_size, Bc, T, R, how)}
+
+
+def gemm_sources_sha():
+    """Content hash of the GEMM kernel sources: stamps profiles/<tag>_gemm_traffic.json (tools/profile_report.py) and decides whether
+    bench.py may quote that file as `roofline.traffic` -- PMC traffic of OTHER kernels is not this run's traffic."""
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "vl-bert_amd", "csrc")
+    for n in ("gemm.hip", "gemm_p8.hip", "gemm_tn8.hip", "gemm_params.h", "vlb_common.h"):
+        with open(os.path.join(d, n), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:12]
 
 
 def cpu_baseline_e2e(cfg_kw, T, R, image_size, vlbert):
@@ -919,14 +980,22 @@ def main():
     # the committed summary of those passes is reported here when it was taken on this workload, else null.
     traffic, traffic_unit = None, None
     pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    tname = next((n for n in ("r04_gemm_traffic.json", "r03_gemm_traffic.json", "r02_gemm_traffic.json") if os.path.isfile(os.path.join(pdir, n))), None)
+    tname = next((n for n in ("r05_gemm_traffic.json", "r04_gemm_traffic.json", "r03_gemm_traffic.json", "r02_gemm_traffic.json")
+                  if os.path.isfile(os.path.join(pdir, n))), None)
     if world == 1 and args.global_batch == 256 and args.layers == 12 and not args.e2e and not args.large and tname:
         with open(os.path.join(pdir, tname)) as f:
             tj = json.load(f)
-        traffic = round(tj["gemm_hbm_GB_per_launch"], 4)
-        traffic_unit = "GB per GEMM launch (avg over %d launches/step; rocprofv3 2xFETCH_SIZE+WRITE_SIZE, separate --pmc passes of this " \
-                       "workload: profiles/%s%s)" % (round(tj["gemm_launches_per_step"]), tname,
-                                                     ", commit " + tj["commit"] if "commit" in tj else "")
+        # quoted ONLY when the profile was taken on the GEMM sources this run executes (content hash stamped by tools/profile_report.py);
+        # a summary of other kernels is named, not echoed (round-4 review: builder-side data must not pass through a driver record)
+        sha = gemm_sources_sha()
+        if tj.get("gemm_sources_sha") == sha:
+            traffic = round(tj["gemm_hbm_GB_per_launch"], 4)
+            traffic_unit = "GB per GEMM launch (avg over %d launches/step; rocprofv3 2xFETCH_SIZE+WRITE_SIZE, separate --pmc passes of this " \
+                           "workload on these kernel sources (sha %s): profiles/%s%s; NOT measured inside this bench run)" % (
+                               round(tj["gemm_launches_per_step"]), sha, tname, ", commit " + tj["commit"] if "commit" in tj else "")
+        else:
+            traffic_unit = "null: profiles/%s was taken on other GEMM sources (sha %s, these are %s) -- re-run tools/make_profiles.sh" % (
+                tname, tj.get("gemm_sources_sha", "unstamped"), sha)
     # FLOPs the step EXECUTES (the MLM head runs on the labelled rows only -- engine mlm_cap -- so less than SURVEY 8d's algorithmic
     # count, which the north star's `step_frac_of_peak` is defined on): the timed GEMM launches + the attention matmuls
     H_, L_ = cfg.hidden_size, cfg.num_hidden_layers

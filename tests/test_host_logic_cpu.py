@@ -455,3 +455,18 @@ def test_partial_pretrain_reports_and_bounds_shape_mismatches():
     with pytest.raises(ValueError, match="different architecture"):
         C.drop_shape_mismatches({"vlbert.a.weight": torch.ones(6, 8), "vlbert.b.weight": torch.ones(10), "final_mlp.weight": torch.ones(2, 4)},
                                 own, log=logs.append)
+
+
+def test_traffic_stamp_hash_is_the_same_function_in_bench_and_profile_report():
+    """`roofline.traffic` is quoted from profiles/<tag>_gemm_traffic.json only when that file's `gemm_sources_sha` equals the hash of
+    the GEMM sources the bench runs (round-4 review: builder-side PMC data must not pass through a driver record unlabelled):
+    tools/profile_report.py stamps the file, bench.py checks it -- both must compute the same hash, and a stale file is named, not echoed."""
+    import ast
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bench = importlib.import_module("bench")
+    src = open(os.path.join(root, "tools", "profile_report.py")).read()
+    fn = next(n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "gemm_sources_sha")
+    ns = {"os": os, "__file__": os.path.join(root, "tools", "profile_report.py")}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "profile_report.py", "exec"), ns)
+    assert ns["gemm_sources_sha"]() == bench.gemm_sources_sha() and len(bench.gemm_sources_sha()) == 12

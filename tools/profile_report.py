@@ -36,7 +36,7 @@ def family(n):
         return "gemm_nt_p8_kernel"            # large-tile 8-phase NT core (gemm_p8.hip): every epilogue / tile height
     if "gemm_tn8" in n:
         return "gemm_tn8_kernel"              # large-tile TN core (weight gradients, grouped per layer)
-    if "gemm_nt_bf16" in n or "gemm_nt_256" in n or "gemm_nt_ring" in n:
+    if "gemm_nt_bf16" in n or "gemm_nt_256" in n or "gemm_nt_ring" in n or "gemm_nt_sk" in n:
         return "gemm_nt_bf16_kernel"          # (incl. the 256x256-tile instantiation used by the decoder)
     if "gemm_tn_bf16" in n:
         return "gemm_tn_bf16_kernel"
@@ -123,7 +123,7 @@ def family_e2e(n):
         return "gemm_nt_p8_kernel"
     if "gemm_tn8" in n:
         return "gemm_tn8_kernel"
-    if "gemm_nt_bf16" in n or "gemm_nt_256" in n or "gemm_nt_ring" in n:
+    if "gemm_nt_bf16" in n or "gemm_nt_256" in n or "gemm_nt_ring" in n or "gemm_nt_sk" in n:
         return "gemm_nt_bf16_kernel<..,CONV>" if conv else "gemm_nt_bf16_kernel"
     if "gemm_tn_bf16" in n:
         return "gemm_tn_bf16_kernel<..,CONV>" if conv else "gemm_tn_bf16_kernel"
@@ -169,6 +169,17 @@ def write_traffic(fetch_dir, write_dir, out_name, what, top=14):
     return traffic
 
 
+def gemm_sources_sha():
+    """= bench.gemm_sources_sha (kept in step by tests/test_host_logic_cpu.py): content hash of the GEMM kernel sources."""
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vl-bert_amd", "csrc")
+    for n in ("gemm.hip", "gemm_p8.hip", "gemm_tn8.hip", "gemm_params.h", "vlb_common.h"):
+        with open(os.path.join(d, n), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:12]
+
+
 GEMM_FAMILIES = ("gemm_nt_p8_kernel", "gemm_tn8_kernel", "gemm_nt_bf16_kernel", "gemm_tn_bf16_kernel")
 write_sq("final_sq", tag + "_gemm_pmc.txt", "the same bench command", GEMM_FAMILIES)
 traffic = write_traffic("final_fetch", "final_write", tag + "_hbm_traffic.txt", "the same bench command")
@@ -178,6 +189,7 @@ out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), too
        "correction": "read = 2 x FETCH_SIZE (gfx950, 16 B/lane streaming reads); WRITE_SIZE as reported",
        "workload": "bench.py default (global batch 256, 1 GPU)",
        "commit": os.environ.get("VLB_COMMIT", "unknown"),
+       "gemm_sources_sha": gemm_sources_sha(),      # bench.py quotes this file only when its own hash of the same files matches
        "gemm_launches_per_step": n,
        "gemm_hbm_GB_per_launch": sum((t["read_MB_per_launch"] + t["write_MB_per_launch"]) * t["launches_per_step"] for t in g) / n / 1e3,
        "families": traffic}

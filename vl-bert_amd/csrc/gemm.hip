@@ -642,19 +642,23 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_nt_ring_kernel(const G
 // Decomposition (XCD-local): block b runs on XCD b % 8 (MI355X_MICROARCH.md, observed placement -- a SPEED assumption only).  Each
 // XCD owns a contiguous run of whole tiles (the grouped tile order of the kernels above); its gridDim.x / 8 blocks cut that run's
 // tiles x K-tiles "units" into equal contiguous shares.  A block therefore walks: [the tail of a tile an earlier block began]
-// [whole tiles] [the head of a tile a later block finishes].  The block that reaches a tile's LAST K tile is its finisher: it adds
-// the partial accumulators the earlier blocks of that tile published (at most a few; all on its own XCD, so the slabs are read
-// from the shared L2) and runs the fused epilogue.  Every block publishes at most ONE partial (its last segment), into its own
-// 64 KiB fp32 slab, lane-linear (16 B per lane and fragment: coalesced both ways).
+// [whole tiles] [the head of a tile later blocks complete].  The block that computes a tile's FIRST K tile owns it: it adds the
+// partial accumulators the later blocks of that tile published (at most a few; all on its own XCD, so the slabs are read from the
+// shared L2) and runs the fused epilogue.  The order matters: a later block works on the owner's tile FIRST and publishes at
+// once, the owner reaches that tile LAST -- the partials are waiting when it gets there.  (The other way round -- the block that
+// reaches the tile's end finishes it -- makes block r wait at its start for the end of block r-1: a serial chain over the XCD's
+// blocks, measured 10x slower than the whole-tile kernels on the first GPU run of this kernel.)  Every block publishes at most ONE
+// partial (its first segment), into its own 64 KiB fp32 slab, lane-linear (16 B per lane and fragment: coalesced both ways).
 //
 // Hand-off (cdna_hip_programming.md "in-launch split-K reduction", MI355X_MICROARCH.md "inter-workgroup visibility"): plain 16-B
 // slab stores -> every wave s_waitcnt vmcnt(0) -> barrier -> lane 0: agent-scope RELEASE fence -> asm s_waitcnt vmcnt(0) (the
 // wait the compiler may drop behind buffer_wbl2) -> relaxed agent-scope flag store.  Finisher: lane 0 polls the flags RELAXED
 // (bounded), ONE agent-scope ACQUIRE fence, barrier, plain 16-B loads; then it clears the flags it consumed (each flag has exactly
 // one consumer), so the flags are all zero again when the launch ends: no per-launch host state, hipGraph replay safe.  Correct for
-// any block -> XCD placement; the same-XCD grouping only makes the slab reads L2 hits.  Contributors always have LOWER block
-// indices than their finisher and never wait for anybody, so a finisher can only wait for blocks dispatched before it.
-// Summation order is fixed (contributors in block order, then the finisher's own segment): deterministic.
+// any block -> XCD placement; the same-XCD grouping only makes the slab reads L2 hits.  Contributors never wait for anybody; an
+// owner may wait for blocks with HIGHER indices, so the grid never exceeds the CU count (one 128-KiB-LDS block per CU: every block
+// of the launch is resident, or becomes resident as soon as another kernel's blocks leave) and every spin is bounded.
+// Summation order is fixed (the owner's own segment, then the contributors in block order): deterministic.
 // ------------------------------------------------------------------------------------
 constexpr int SK_SLAB_FLOATS = 128 * 128;        // one partial tile
 constexpr unsigned SK_SPIN_LIMIT = 1u << 20;     // polls (~0.5-1 us each with the sleep) before a finisher gives up and flags an error
@@ -792,9 +796,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_sk_kernel(const GemmParams p, 
       ++g;
       slot_c = (slot_c + 1 == NS) ? 0 : slot_c + 1;
     }
-    const bool ends = (k1 == ntk);
-    if (!ends) {
-      // ---- this block's last segment stops inside the tile: publish the partial accumulators (see the header) -----------------
+    const bool starts = (k0 == 0), ends = (k1 == ntk);
+    if (!starts) {
+      // ---- this block's FIRST segment continues a tile an earlier block owns: publish the partial accumulators right away (the
+      //      owner reaches its own part of that tile at the END of its share, so it finds them waiting; see the header) -----------
       float* slab = slabs + (long)blockIdx.x * SK_SLAB_FLOATS;
 #pragma unroll
       for (int i = 0; i < FM; ++i)
@@ -808,19 +813,19 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_sk_kernel(const GemmParams p, 
         __hip_atomic_store(flags + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     } else {
-      if (k0 != 0) {
-        // ---- finisher of a tile earlier blocks began: blocks r_first .. rx-1 of this XCD each hold one partial of it -----------
-        const long v = (long)tl * ntk;                     // first unit of the tile
-        int r_first = (int)((v * P) / U);
-        while (r_first + 1 < P && share_begin(r_first + 1) <= v) ++r_first;
-        while (r_first > 0 && share_begin(r_first) > v) --r_first;
+      if (!ends) {
+        // ---- owner of a tile whose K loop later blocks complete: blocks rx+1 .. r_last of this XCD each publish one partial -------
+        const long v = (long)(tl + 1) * ntk - 1;           // last unit of the tile
+        int r_last = (int)((v * P) / U);
+        while (r_last + 1 < P && share_begin(r_last + 1) <= v) ++r_last;
+        while (r_last > 0 && share_begin(r_last) > v) --r_last;
         if (tid == 0) {
-          for (int c = r_first; c < rx; ++c) {
+          for (int c = rx + 1; c <= r_last; ++c) {
             if (share_begin(c) >= share_begin(c + 1)) continue;      // (an empty share publishes nothing)
             unsigned* f = flags + (c * 8 + xcd);
             unsigned spins = 0;
             while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-              __builtin_amdgcn_s_sleep(4);
+              __builtin_amdgcn_s_sleep(2);
               if (++spins > SK_SPIN_LIMIT) {               // never hang the chip: record the failure, take what is there
                 atomicAdd(flags + gridDim.x, 1u);
                 break;
@@ -830,8 +835,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_sk_kernel(const GemmParams p, 
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         __syncthreads();
-        for (int c = r_first; c < rx; ++c) {
-          if (share_begin(c) >= share_begin(c + 1)) continue;   // (an empty share published nothing)
+        for (int c = rx + 1; c <= r_last; ++c) {
+          if (share_begin(c) >= share_begin(c + 1)) continue;
           const float* slab = slabs + (long)(c * 8 + xcd) * SK_SLAB_FLOATS;
 #pragma unroll
           for (int i = 0; i < FM; ++i)
@@ -844,7 +849,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_sk_kernel(const GemmParams p, 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                   // every lane has read every slab: the flags may be cleared
         if (tid == 0)
-          for (int c = r_first; c < rx; ++c)
+          for (int c = rx + 1; c <= r_last; ++c)
             if (share_begin(c) < share_begin(c + 1)) __hip_atomic_store(flags + (c * 8 + xcd), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       const int last = (slot_c == 0) ? NS - 1 : slot_c - 1;
@@ -1634,6 +1639,34 @@ static int launch_sk_cfg(GemmParams& p, float* slabs, unsigned* flags, hipStream
   return VLB_OK;
 }
 
+// Two stream-K launches must not run CONCURRENTLY: each wants every CU (one 128-KiB-LDS block per CU) and its tile owners wait for
+// blocks that may not be resident yet -- two such kernels interleaved on the chip could starve each other until the spin bound.
+// Launches on one stream are ordered anyway (the engine issues its NT GEMMs on one stream).  When a second stream shows up, its
+// launches are ordered behind the other stream's last stream-K launch with an event (outside stream capture; a capturing stream is
+// left alone: a captured step is replayed instead of, not beside, the eager one).
+static hipStream_t g_sk_last_stream = nullptr;
+static hipEvent_t g_sk_event = nullptr;
+static bool g_sk_have_last = false;
+
+static void sk_order_before(hipStream_t stream, bool capturing) {
+  std::lock_guard<std::mutex> lock(g_sk_mutex);
+  if (capturing || !g_sk_have_last || g_sk_last_stream == stream) return;
+  if (g_sk_event == nullptr) {      // first hand-over between streams: no event was being recorded yet -> one host-side join
+    if (hipEventCreateWithFlags(&g_sk_event, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); g_sk_event = nullptr; }
+    (void)hipStreamSynchronize(g_sk_last_stream);
+    return;
+  }
+  (void)hipStreamWaitEvent(stream, g_sk_event, 0);
+}
+
+static void sk_order_after(hipStream_t stream, bool capturing) {
+  std::lock_guard<std::mutex> lock(g_sk_mutex);
+  if (capturing) return;
+  if (g_sk_event != nullptr) (void)hipEventRecord(g_sk_event, stream);      // (only once a second stream has been seen)
+  g_sk_last_stream = stream;
+  g_sk_have_last = true;
+}
+
 // > 0: not taken
 static int gemm_sk_try(GemmParams& p, int splits, hipStream_t stream) {
   if (g_nt_sk < 0) g_nt_sk = env_int("VLB_GEMM_SK", 1);
@@ -1648,12 +1681,19 @@ static int gemm_sk_try(GemmParams& p, int splits, hipStream_t stream) {
   float* slabs = nullptr;
   unsigned* flags = nullptr;
   if (sk_workspace(stream, &slabs, &flags)) return 1;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+  const bool capturing = cs != hipStreamCaptureStatusNone;
+  sk_order_before(stream, capturing);
+  int rc;
   switch (ec) {
-    case 0: return launch_sk_cfg<0>(p, slabs, flags, stream);
-    case 3: return launch_sk_cfg<3>(p, slabs, flags, stream);
-    case 4: return launch_sk_cfg<4>(p, slabs, flags, stream);
-    default: return launch_sk_cfg<-1>(p, slabs, flags, stream);
+    case 0: rc = launch_sk_cfg<0>(p, slabs, flags, stream); break;
+    case 3: rc = launch_sk_cfg<3>(p, slabs, flags, stream); break;
+    case 4: rc = launch_sk_cfg<4>(p, slabs, flags, stream); break;
+    default: rc = launch_sk_cfg<-1>(p, slabs, flags, stream); break;
   }
+  sk_order_after(stream, capturing);
+  return rc;
 }
 
 template <int BM, int BN>
