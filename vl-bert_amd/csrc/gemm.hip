@@ -660,12 +660,19 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_nt_ring_kernel(const G
 // of the launch is resident, or becomes resident as soon as another kernel's blocks leave) and every spin is bounded.
 // Summation order is fixed (the owner's own segment, then the contributors in block order): deterministic.
 // ------------------------------------------------------------------------------------
-constexpr int SK_SLAB_FLOATS = 128 * 128;        // one partial tile
+constexpr int SK_SLAB_BYTES = 128 * 128 * 4;      // workspace per CU: one 128x128 partial tile, or two 128x64 ones (two blocks per CU)
+typedef unsigned int sk_v4u __attribute__((ext_vector_type(4)));
+constexpr int SK_ERR_INDEX = 1024;                // flags[0 .. grid) hand-off flags (grid <= 1024), flags[SK_ERR_INDEX] = timed-out hand-offs
 constexpr unsigned SK_SPIN_LIMIT = 1u << 20;     // polls (~0.5-1 us each with the sleep) before a finisher gives up and flags an error
 
-template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_nt_sk_kernel(const GemmParams p, float* __restrict__ slabs, unsigned* __restrict__ flags) {
-  constexpr int BM = 128, BN = 128, WGM = 2, WGN = 4, NS = 4;
+// <BN, WGM, WGN, NS>: <128, 2, 4, 4> = 8 waves, 128 KiB of LDS, one block per CU | <64, 2, 2, 3> = 4 waves, 72 KiB, TWO blocks per CU
+// (the launcher's default: the 8-wave form runs its K tile in lockstep -- wait, barrier, fragment reads, MFMAs -- at 1.16 us per
+// 128x128x64 unit on the first measurement, 5x the MFMA time; two independent 4-wave blocks per CU cover each other's latency, which
+// is also why the whole-tile launcher prefers the 128x64 ring at these sizes)
+template <int BN, int WGM, int WGN, int NS, int EPI>
+__global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_nt_sk_kernel(const GemmParams p, float* __restrict__ slabs, unsigned* __restrict__ flags) {
+  constexpr int BM = 128;
+  constexpr int SK_SLAB_FLOATS = BM * BN;
   constexpr int BK = 64;
   constexpr int NT = 64 * WGM * WGN;
   constexpr int WM = BM / WGM, WN = BN / WGN;
@@ -762,8 +769,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_sk_kernel(const GemmParams p, 
       for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int kt = k0; kt < k1; ++kt) {
       const int ahead = issued - g - 1;
-      if (ahead >= 3) ring_wait_vm<3 * NL>();
-      else if (ahead == 2) ring_wait_vm<2 * NL>();
+      if (NS >= 4 && ahead >= 3) ring_wait_vm<3 * NL>();
+      else if (NS >= 3 && ahead == 2) ring_wait_vm<2 * NL>();
       else if (ahead == 1) ring_wait_vm<NL>();
       else ring_wait_vm<0>();
       asm volatile("" ::: "memory");
@@ -800,18 +807,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_sk_kernel(const GemmParams p, 
     if (!starts) {
       // ---- this block's FIRST segment continues a tile an earlier block owns: publish the partial accumulators right away (the
       //      owner reaches its own part of that tile at the END of its share, so it finds them waiting; see the header) -----------
-      float* slab = slabs + (long)blockIdx.x * SK_SLAB_FLOATS;
+      // write-through (sc1) 16-B stores: the payload is at the coherence point when the stores retire, so no release fence (no
+      // buffer_wbl2 walk over the XCD's dirty L2 lines: 3.0 vs 8.2 us per 64 KiB publish, MI355X_MICROARCH.md "publish-large")
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(slabs + (long)blockIdx.x * SK_SLAB_FLOATS), 0, 0x7FFFFFFF, 0x00020000);
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < FN; ++j) *(f32x4*)(slab + ((i * FN + j) * NT + tid) * 4) = acc[i][j];
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(flags + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
+        for (int j = 0; j < FN; ++j)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(sk_v4u, acc[i][j]), rs, ((i * FN + j) * NT + tid) * 16, 0, 16);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // EVERY storing wave drains its stores ...
+      __syncthreads();                                       // ... before ONE lane raises the flag
+      if (tid == 0) __hip_atomic_store(flags + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
       if (!ends) {
         // ---- owner of a tile whose K loop later blocks complete: blocks rx+1 .. r_last of this XCD each publish one partial -------
@@ -827,7 +833,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_sk_kernel(const GemmParams p, 
             while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
               __builtin_amdgcn_s_sleep(2);
               if (++spins > SK_SPIN_LIMIT) {               // never hang the chip: record the failure, take what is there
-                atomicAdd(flags + gridDim.x, 1u);
+                atomicAdd(flags + SK_ERR_INDEX, 1u);
                 break;
               }
             }
@@ -1585,8 +1591,9 @@ static int sk_workspace(hipStream_t stream, float** slabs, unsigned** flags) {  
       g_sk_failed = true;
       return 1;
     }
-    g_sk_grid = cus / 8 * 8;
-    const size_t slab_bytes = (size_t)g_sk_grid * SK_SLAB_FLOATS * sizeof(float), flag_bytes = (size_t)(g_sk_grid + 8) * sizeof(unsigned);
+    g_sk_grid = cus / 8 * 8;                 // CUs used (a multiple of 8: equal blocks per XCD); <= 512
+    if (2 * g_sk_grid > SK_ERR_INDEX) { g_sk_failed = true; return 1; }
+    const size_t slab_bytes = (size_t)g_sk_grid * SK_SLAB_BYTES, flag_bytes = (size_t)(SK_ERR_INDEX + 8) * sizeof(unsigned);
     for (int i = 0; i < SK_STREAMS; ++i) {
       if (hipMalloc((void**)&g_sk_ws[i].slabs, slab_bytes) != hipSuccess || hipMalloc((void**)&g_sk_ws[i].flags, flag_bytes) != hipSuccess ||
           hipMemset(g_sk_ws[i].flags, 0, flag_bytes) != hipSuccess) {
@@ -1616,27 +1623,35 @@ extern "C" long vlb_gemm_sk_timeouts(void) {
   long total = 0;
   for (int i = 0; i < SK_STREAMS; ++i) {
     unsigned v = 0;
-    if (hipMemcpy(&v, g_sk_ws[i].flags + g_sk_grid, sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (hipMemcpy(&v, g_sk_ws[i].flags + SK_ERR_INDEX, sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) return -1;
     total += v;
   }
   return total;
 }
 
-template <int EPI>
+template <int BN, int WGM, int WGN, int NS, int EPI>
 static int launch_sk_cfg(GemmParams& p, float* slabs, unsigned* flags, hipStream_t stream) {
-  constexpr int smem = 4 * (128 + 128) * 128;
+  constexpr int smem = NS * (128 + BN) * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_nt_sk_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_sk_kernel<BN, WGM, WGN, NS, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
   static const int group = env_int("VLB_GEMM_TILE_GROUP", 4);
   p.ntm = vlb_cdiv(p.M, 128);
-  p.ntn = vlb_cdiv(p.N, 128);
+  p.ntn = vlb_cdiv(p.N, BN);
   p.tile_group = group < 1 ? 1 : group;
-  hipLaunchKernelGGL((gemm_nt_sk_kernel<EPI>), dim3(g_sk_grid), dim3(512), smem, stream, p, slabs, flags);
+  const int grid = g_sk_grid * (163840 / smem);      // one block per CU (128 KiB of LDS) or two (72 KiB): every block resident
+  hipLaunchKernelGGL((gemm_nt_sk_kernel<BN, WGM, WGN, NS, EPI>), dim3(grid), dim3(64 * WGM * WGN), smem, stream, p, slabs, flags);
   VLB_CHECK_LAUNCH("vlb_gemm_nt_bf16(stream-K)");
   return VLB_OK;
+}
+
+template <int EPI>
+static int launch_sk_tile(GemmParams& p, float* slabs, unsigned* flags, hipStream_t stream) {
+  static const int tile = env_int("VLB_GEMM_SK_TILE", 64);      // 64: 128x64 tiles, two 4-wave blocks per CU (default) | 128: 128x128, one 8-wave block
+  if (tile == 128) return launch_sk_cfg<128, 2, 4, 4, EPI>(p, slabs, flags, stream);
+  return launch_sk_cfg<64, 2, 2, 3, EPI>(p, slabs, flags, stream);
 }
 
 // Two stream-K launches must not run CONCURRENTLY: each wants every CU (one 128-KiB-LDS block per CU) and its tile owners wait for
@@ -1687,10 +1702,10 @@ static int gemm_sk_try(GemmParams& p, int splits, hipStream_t stream) {
   sk_order_before(stream, capturing);
   int rc;
   switch (ec) {
-    case 0: rc = launch_sk_cfg<0>(p, slabs, flags, stream); break;
-    case 3: rc = launch_sk_cfg<3>(p, slabs, flags, stream); break;
-    case 4: rc = launch_sk_cfg<4>(p, slabs, flags, stream); break;
-    default: rc = launch_sk_cfg<-1>(p, slabs, flags, stream); break;
+    case 0: rc = launch_sk_tile<0>(p, slabs, flags, stream); break;
+    case 3: rc = launch_sk_tile<3>(p, slabs, flags, stream); break;
+    case 4: rc = launch_sk_tile<4>(p, slabs, flags, stream); break;
+    default: rc = launch_sk_tile<-1>(p, slabs, flags, stream); break;
   }
   sk_order_after(stream, capturing);
   return rc;
