@@ -221,7 +221,7 @@ def test_gemm_stream_k_epilogues(ops, force_p8, M, N, K):
         report("stream-K vs ring %dx%dx%d" % (M, N, K), outs[0], Cr.float(), 1e-3, 8e-3)
         assert force_p8.gemm_sk_timeouts() == 0
     finally:
-        force_p8.gemm_set_option("nt_sk", 1)
+        force_p8.gemm_set_option("nt_sk", 0)
 
 
 def test_gemm_stream_k_handoff_under_uneven_load(ops, force_p8):
@@ -255,7 +255,7 @@ def test_gemm_stream_k_handoff_under_uneven_load(ops, force_p8):
         assert not bad, "stream-K outputs differ from the idle-chip result in launches %s" % bad[:10]
         assert force_p8.gemm_sk_timeouts() == 0
     finally:
-        force_p8.gemm_set_option("nt_sk", 1)
+        force_p8.gemm_set_option("nt_sk", 0)
 
 
 def _epilogue_battery(ops, tag, M, N, K, vision=False):
@@ -327,7 +327,7 @@ def test_gemm_layernorm_residual_fp16_stream(ops, force_p8, core):
         assert lib.gemm_sk_timeouts() == 0
     finally:
         lib.gemm_set_option("nt_ring", 1)
-        lib.gemm_set_option("nt_sk", 1)
+        lib.gemm_set_option("nt_sk", 0)
 
 
 def _ln_residual_checks(ops, core):

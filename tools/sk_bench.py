@@ -59,7 +59,7 @@ def main():
                 L.gemm_set_option("nt_sk", mode)
                 t = timed(fn)
                 out[mode] = (t, C.float().clone())
-            L.gemm_set_option("nt_sk", 1)
+            L.gemm_set_option("nt_sk", 0)
             fl = 2.0 * M * H * K
             d = float((out[0][1] - out[2][1]).abs().max())
             print("%-22s %6d %5d %5d | %9.1f %8.1f | %9.1f %8.1f | %6.2fx %.3e" %

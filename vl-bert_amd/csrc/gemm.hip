@@ -659,6 +659,22 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_nt_ring_kernel(const G
 // owner may wait for blocks with HIGHER indices, so the grid never exceeds the CU count (one 128-KiB-LDS block per CU: every block
 // of the launch is resident, or becomes resident as soon as another kernel's blocks leave) and every spin is bounded.
 // Summation order is fixed (the owner's own segment, then the contributors in block order): deterministic.
+//
+// MEASURED (MI355X, gpurun_out/r5c + r5d, tools/sk_bench.py; us per launch, whole-tile launcher vs this kernel):
+//                         M = 3232 (32 samples)      M = 6464 (64)            M = 12928 (128)
+//   FFN2 fwd   K = 3072   34.9  vs 49.3 (128x64)     56.0 vs 92.3             66.7 vs 183.7
+//   FFN1 dgrad K = 3072   31.3  vs 46.0              50.5 vs 87.8             62.9 vs 180.7
+//   QKV dgrad  K = 2304   24.7  vs 33.3              39.8 vs 59.5             49.7 vs 130.5
+// (128x128 / one block per CU: 52.1 / 48.7 / 36.6 at M = 3232.)  Bit-checked, deterministic, no hand-off ever timed out -- and
+// 0.6-0.7x the speed of the kernels it was meant to replace, in the whole step 5.39 -> 5.92 ms at 32 samples.  Why: the balance is
+// perfect, the LOCALITY is gone.  In the whole-tile kernels the ~64 blocks an XCD runs at a time sit on neighbouring tiles at the
+// SAME K offset, so an A or B slab is fetched from HBM / the memory-side cache once and shared through the XCD's 4 MB L2; here
+// block r starts at unit r * U / P, i.e. every co-resident block is at a DIFFERENT K offset of its tile, nothing is shared in time,
+// and the launch streams ~360 MB of operands (units x 24 KB) instead of ~25 MB -- HBM-bound at the rate measured.  The load
+// balance stream-K buys (29 equal units per block instead of 48 on the CUs that hold two tiles) is worth less than the L2 reuse
+// it destroys when the operands (A 20 MB + B 4.7 MB) are 6x the L2.  Kept as an OPTION (VLB_GEMM_SK=1 / option "nt_sk"), off by
+// default; what would make it pay is a K-aligned decomposition (all blocks of an XCD inside the same K window), which for 312 tiles
+// on 512 block slots is plain split-K with a fractional split count -- not built.
 // ------------------------------------------------------------------------------------
 constexpr int SK_SLAB_BYTES = 128 * 128 * 4;      // workspace per CU: one 128x128 partial tile, or two 128x64 ones (two blocks per CU)
 typedef unsigned int sk_v4u __attribute__((ext_vector_type(4)));
@@ -1571,7 +1587,7 @@ static int gemm_ring_try(GemmParams& p, int splits, bool want_narrow, hipStream_
 // argument and the slabs never leave the launch).  Launches on ONE stream are ordered, so they share a workspace; up to SK_STREAMS
 // streams get their own (all allocated on the first use, which is never inside a stream capture: a call that would have to
 // allocate while its stream is capturing is simply not taken and runs on the ring kernel).
-static int g_nt_sk = -1;          // VLB_GEMM_SK: 0 off | 1 auto (default) | 2 every shape the kernel covers
+static int g_nt_sk = -1;          // VLB_GEMM_SK: 0 off (default: see the kernel's header -- measured slower) | 1 auto | 2 every shape the kernel covers
 static int g_sk_min_k = -1, g_sk_max_m = -1;
 void vlb_nt_set_sk(int v) { g_nt_sk = v; }
 constexpr int SK_STREAMS = 4;
@@ -1684,7 +1700,7 @@ static void sk_order_after(hipStream_t stream, bool capturing) {
 
 // > 0: not taken
 static int gemm_sk_try(GemmParams& p, int splits, hipStream_t stream) {
-  if (g_nt_sk < 0) g_nt_sk = env_int("VLB_GEMM_SK", 1);
+  if (g_nt_sk < 0) g_nt_sk = env_int("VLB_GEMM_SK", 0);
   if (!g_nt_sk || splits != 1 || p.c_split_stride != 0 || p.k_per_split < p.K || p.out_f32 != 0) return 1;
   if (g_sk_min_k < 0) { g_sk_min_k = env_int("VLB_GEMM_SK_MIN_K", 1536); g_sk_max_m = env_int("VLB_GEMM_SK_MAX_M", 8192); }
   // auto: the launches whose whole-tile decomposition leaves most of the chip idle or lopsided and whose K loop is long enough
