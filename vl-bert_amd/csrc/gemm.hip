@@ -686,8 +686,10 @@ constexpr unsigned SK_SPIN_LIMIT = 1u << 20;     // polls (~0.5-1 us each with t
 // 128x128x64 unit on the first measurement, 5x the MFMA time; two independent 4-wave blocks per CU cover each other's latency, which
 // is also why the whole-tile launcher prefers the 128x64 ring at these sizes)
 template <int BN, int WGM, int WGN, int NS, int EPI>
-__global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_nt_sk_kernel(const GemmParams p, float* __restrict__ slabs, unsigned* __restrict__ flags) {
+__global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_nt_sk_kernel(const GemmParams p, float* __restrict__ slabs, unsigned* __restrict__ flags,
+                                                                       const int pure_sk) {
   constexpr int BM = 128;
+  constexpr bool TWO_PER_CU = NS * (BM + BN) * 128 <= 81920;      // two blocks of this configuration fit a CU's 160 KiB of LDS
   constexpr int SK_SLAB_FLOATS = BM * BN;
   constexpr int BK = 64;
   constexpr int NT = 64 * WGM * WGN;
@@ -704,45 +706,102 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_nt_sk_kernel(const Gem
   const int wm = wave / WGN, wn = wave % WGN;
   const int nt = p.ntm * p.ntn;
   const int ntk = p.K / BK;
-  // ---- this block's share: XCD x owns tiles [t_lo, t_lo + ntx) of the grouped order; its P blocks cut ntx * ntk units evenly ----
+  // ---- this block's work: XCD x owns tiles [t_lo, t_lo + ntx) of the grouped order; its P blocks take ---------------------------
+  //   (1) WHOLE tiles, data-parallel, as long as there are full rounds of them: tile j * P + rx for j < dpr = ntx / P -- and, when the
+  //       remainder is at least half a round (>= P / 2 tiles: one per CU with two blocks per CU), one more whole tile for the first
+  //       P / 2 blocks ("half round").  Whole tiles of co-resident blocks sit at the SAME K offset, so operand slabs are shared
+  //       through the XCD's L2 (the locality the pure stream-K form of this kernel lost: header, "MEASURED");
+  //   (2) an equal share of the K tiles ("units") of the REMAINING tiles, stream-K: over all P blocks, or over the second P / 2 blocks
+  //       when the first half took a half-round tile (a CU then carries one whole tile + one share either way).
+  //   Order inside a block: its stream-K share's first segment first if that segment CONTINUES a tile (publish early), then the whole
+  //   tiles, then the rest of the share (an owner segment, if any, comes last: its partials are waiting).
   const int P = (int)gridDim.x >> 3;                       // blocks per XCD (gridDim.x is a multiple of 8)
+  const int Ph = P >> 1;
   const int xcd = (int)blockIdx.x & 7, rx = (int)blockIdx.x >> 3;
-  const int q = nt >> 3, rem = nt & 7;
-  const int t_lo = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
-  const int ntx = q + (xcd < rem ? 1 : 0);
-  const long U = (long)ntx * ntk;
-  auto share_begin = [&](int r) { return (U * r) / P; };   // first unit of block r of this XCD (r = P: one past the end)
-  const long ub = share_begin(rx), ue = share_begin(rx + 1);
-  if (ub >= ue) return;                                    // (fewer units than blocks: nothing to do, nobody waits for this block)
+  const int q = nt >> 3, rem8 = nt & 7;
+  const int t_lo = xcd < rem8 ? xcd * (q + 1) : rem8 * (q + 1) + (xcd - rem8) * q;
+  const int ntx = q + (xcd < rem8 ? 1 : 0);
+  // (pure_sk: measurement switch, option nt_sk = 3 -- no whole tiles, every K tile of the launch in the equal shares)
+  const int dpr = pure_sk ? 0 : ntx / P;                   // full data-parallel rounds
+  const int remt = ntx - dpr * P;                          // tiles left after them
+  const bool half = TWO_PER_CU && !pure_sk && Ph > 0 && remt >= Ph;
+  const int ndp = dpr + ((half && rx < Ph) ? 1 : 0);       // whole tiles of this block
+  const int sk_base = dpr * P + (half ? Ph : 0);           // first stream-K tile (position in this XCD's run)
+  const int sk_tiles = ntx - sk_base;
+  const int Ps = half ? (P - Ph) : P;                      // blocks that share the stream-K units
+  const int rs = half ? rx - Ph : rx;                      // this block's index among them (< 0: takes no share)
+  const int U = sk_tiles * ntk;
+  auto share_begin = [&](int r) { return (int)(((long)U * r) / Ps); };   // first unit of stream-K block r (r = Ps: one past the end)
+  const int ub = (rs >= 0 && U > 0) ? share_begin(rs) : 0, ue = (rs >= 0 && U > 0) ? share_begin(rs + 1) : 0;
+  if (ndp == 0 && ub >= ue) return;                        // nothing to do; nobody waits for this block
   auto tile_origin = [&](int t, int& m0, int& n0) {        // grouped order, as in gemm_nt_bf16_kernel (t = position in the order)
     const int gm = p.tile_group, per_group = gm * p.ntn, gid = t / per_group, first = gid * gm;
     const int gsz = min(p.ntm - first, gm), r2 = t - gid * per_group;
     m0 = (first + r2 % gsz) * BM;
     n0 = (r2 / gsz) * BN;
   };
-  // ---- producer: walks the units ub .. ue-1 in order, NS - 1 stages ahead of the consumer --------------------------------------
+  // segment enumerator: (tile position in the XCD's run, K tiles [k0, k1)); the producer and the consumer each walk it with a cursor
+  struct Cur { int phase, j, u; };
+  auto seg_next = [&](Cur& c, int& t, int& k0, int& k1) -> bool {
+    for (;;) {
+      if (c.phase == 0) {
+        c.phase = 1;
+        c.u = ub;
+        if (ub < ue) {
+          const int tl = ub / ntk, kk = ub - tl * ntk;
+          if (kk != 0) {                                   // continues a tile an earlier block owns: first, so that it is published early
+            t = sk_base + tl; k0 = kk; k1 = min(ntk, kk + (ue - ub));
+            c.u = ub + (k1 - k0);
+            return true;
+          }
+        }
+      } else if (c.phase == 1) {
+        if (c.j < ndp) {
+          t = (c.j < dpr) ? c.j * P + rx : dpr * P + rx;
+          k0 = 0; k1 = ntk;
+          ++c.j;
+          return true;
+        }
+        c.phase = 2;
+      } else if (c.phase == 2) {
+        if (c.u < ue) {
+          const int tl = c.u / ntk;
+          t = sk_base + tl; k0 = c.u - tl * ntk; k1 = min(ntk, k0 + (ue - c.u));
+          c.u += k1 - k0;
+          return true;
+        }
+        c.phase = 3;
+      } else {
+        return false;
+      }
+    }
+  };
+  // ---- producer: walks the segments in order, NS - 1 stages ahead of the consumer ----------------------------------------------
   const bf16_t* a_src[NA];
   const bf16_t* b_src[NB];
-  long u_p = ub;
-  int kt_p = 0, issued = 0, slot_p = 0;
-  auto setup = [&](long u) {
-    const int tl = (int)(u / ntk);
-    kt_p = (int)(u - (long)tl * ntk);
+  Cur pc = {0, 0, 0};
+  int kt_p = 0, kend_p = 0, issued = 0, slot_p = 0;
+  bool more_p = true;
+  auto setup = [&]() {                                     // next segment of the producer (more_p = false: none left)
+    int t, k0, k1;
+    more_p = seg_next(pc, t, k0, k1);
+    if (!more_p) return;
+    kt_p = k0; kend_p = k1;
     int m0, n0;
-    tile_origin(t_lo + tl, m0, n0);
+    tile_origin(t_lo + t, m0, n0);
 #pragma unroll
     for (int it = 0; it < NA; ++it) {
       const int Pc = it * NT + tid, r = Pc >> 3, kc = (Pc & 7) ^ ((r >> 1) & 7);
-      a_src[it] = p.A + (long)min(m0 + r, p.M - 1) * p.lda + kc * 8 + (long)kt_p * BK;
+      a_src[it] = p.A + (long)min(m0 + r, p.M - 1) * p.lda + kc * 8 + (long)k0 * BK;
     }
 #pragma unroll
     for (int it = 0; it < NB; ++it) {
       const int Pc = it * NT + tid, r = Pc >> 3, kc = (Pc & 7) ^ ((r >> 1) & 7);
-      b_src[it] = p.B + (long)min(n0 + r, p.N - 1) * p.ldb + kc * 8 + (long)kt_p * BK;
+      b_src[it] = p.B + (long)min(n0 + r, p.N - 1) * p.ldb + kc * 8 + (long)k0 * BK;
     }
   };
   auto produce = [&]() {
-    if (u_p >= ue) return;
+    if (!more_p) return;
     char* sa = smem + slot_p * STAGE;
     char* sb = sa + A_BYTES;
 #pragma unroll
@@ -757,8 +816,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_nt_sk_kernel(const Gem
     }
     ++issued;
     slot_p = (slot_p + 1 == NS) ? 0 : slot_p + 1;
-    ++u_p;
-    if (++kt_p == ntk && u_p < ue) setup(u_p);             // next tile of this share
+    if (++kt_p == kend_p) setup();                         // next segment of this block
   };
 
   f32x4 acc[FM][FN];
@@ -768,17 +826,16 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_nt_sk_kernel(const Gem
   const uint32_t a_rel = (uint32_t)((wm * WM + frow) * 128 + c0);
   const uint32_t b_rel = (uint32_t)(A_BYTES + (wn * WN + frow) * 128 + c0);
 
-  setup(u_p);
+  setup();
 #pragma unroll
   for (int s_ = 0; s_ < NS - 1; ++s_) produce();
   int g = 0, slot_c = 0;
-  long u = ub;
-  while (u < ue) {
-    const int tl = (int)(u / ntk);
-    const int k0 = (int)(u - (long)tl * ntk);
-    const int k1 = (int)min((long)ntk, (long)k0 + (ue - u));
+  Cur cc = {0, 0, 0};
+  int tseg, k0, k1;
+  while (seg_next(cc, tseg, k0, k1)) {
+    const int tl = tseg - sk_base;                         // (stream-K segments: the tile's index among the stream-K tiles)
     int m0, n0;
-    tile_origin(t_lo + tl, m0, n0);
+    tile_origin(t_lo + tseg, m0, n0);
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -837,14 +894,15 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_nt_sk_kernel(const Gem
     } else {
       if (!ends) {
         // ---- owner of a tile whose K loop later blocks complete: blocks rx+1 .. r_last of this XCD each publish one partial -------
-        const long v = (long)(tl + 1) * ntk - 1;           // last unit of the tile
-        int r_last = (int)((v * P) / U);
-        while (r_last + 1 < P && share_begin(r_last + 1) <= v) ++r_last;
+        const int v = (tl + 1) * ntk - 1;                  // last unit of the tile (stream-K unit space)
+        int r_last = (int)(((long)v * Ps) / U);
+        while (r_last + 1 < Ps && share_begin(r_last + 1) <= v) ++r_last;
         while (r_last > 0 && share_begin(r_last) > v) --r_last;
+        const int boff = half ? Ph : 0;                    // stream-K block index -> block index inside the XCD
         if (tid == 0) {
-          for (int c = rx + 1; c <= r_last; ++c) {
+          for (int c = rs + 1; c <= r_last; ++c) {
             if (share_begin(c) >= share_begin(c + 1)) continue;      // (an empty share publishes nothing)
-            unsigned* f = flags + (c * 8 + xcd);
+            unsigned* f = flags + ((c + boff) * 8 + xcd);
             unsigned spins = 0;
             while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
               __builtin_amdgcn_s_sleep(2);
@@ -857,9 +915,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_nt_sk_kernel(const Gem
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         __syncthreads();
-        for (int c = rx + 1; c <= r_last; ++c) {
+        for (int c = rs + 1; c <= r_last; ++c) {
           if (share_begin(c) >= share_begin(c + 1)) continue;
-          const float* slab = slabs + (long)(c * 8 + xcd) * SK_SLAB_FLOATS;
+          const float* slab = slabs + (long)((c + boff) * 8 + xcd) * SK_SLAB_FLOATS;
 #pragma unroll
           for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -871,8 +929,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_nt_sk_kernel(const Gem
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                   // every lane has read every slab: the flags may be cleared
         if (tid == 0)
-          for (int c = rx + 1; c <= r_last; ++c)
-            if (share_begin(c) < share_begin(c + 1)) __hip_atomic_store(flags + (c * 8 + xcd), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          for (int c = rs + 1; c <= r_last; ++c)
+            if (share_begin(c) < share_begin(c + 1))
+              __hip_atomic_store(flags + ((c + boff) * 8 + xcd), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       const int last = (slot_c == 0) ? NS - 1 : slot_c - 1;
       const int mb = m0 + wm * WM + (lane & 15), nb = n0 + wn * WN + 4 * (lane >> 4);
@@ -885,7 +944,6 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_nt_sk_kernel(const Gem
       }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);                    // one full drain per segment, where the compiler can see it (ring kernel note)
-    u += (k1 - k0);
   }
 }
 
@@ -1587,7 +1645,7 @@ static int gemm_ring_try(GemmParams& p, int splits, bool want_narrow, hipStream_
 // argument and the slabs never leave the launch).  Launches on ONE stream are ordered, so they share a workspace; up to SK_STREAMS
 // streams get their own (all allocated on the first use, which is never inside a stream capture: a call that would have to
 // allocate while its stream is capturing is simply not taken and runs on the ring kernel).
-static int g_nt_sk = -1;          // VLB_GEMM_SK: 0 off (default: see the kernel's header -- measured slower) | 1 auto | 2 every shape the kernel covers
+static int g_nt_sk = -1;          // VLB_GEMM_SK: 0 off | 1 auto | 2 every shape the kernel covers | 3 the same, PURE stream-K (no whole tiles: the measured-slower form)
 static int g_sk_min_k = -1, g_sk_max_m = -1;
 void vlb_nt_set_sk(int v) { g_nt_sk = v; }
 constexpr int SK_STREAMS = 4;
@@ -1658,7 +1716,8 @@ static int launch_sk_cfg(GemmParams& p, float* slabs, unsigned* flags, hipStream
   p.ntn = vlb_cdiv(p.N, BN);
   p.tile_group = group < 1 ? 1 : group;
   const int grid = g_sk_grid * (163840 / smem);      // one block per CU (128 KiB of LDS) or two (72 KiB): every block resident
-  hipLaunchKernelGGL((gemm_nt_sk_kernel<BN, WGM, WGN, NS, EPI>), dim3(grid), dim3(64 * WGM * WGN), smem, stream, p, slabs, flags);
+  hipLaunchKernelGGL((gemm_nt_sk_kernel<BN, WGM, WGN, NS, EPI>), dim3(grid), dim3(64 * WGM * WGN), smem, stream, p, slabs, flags,
+                     g_nt_sk == 3 ? 1 : 0);
   VLB_CHECK_LAUNCH("vlb_gemm_nt_bf16(stream-K)");
   return VLB_OK;
 }
