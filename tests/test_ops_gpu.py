@@ -194,17 +194,19 @@ def test_gemm_ring_kernel_epilogues(ops, force_p8, ring, M, N, K):
 # two tiles x 16 K tiles on 256 workgroups: every unit its own workgroup, 15 partial slabs per finisher
 @pytest.mark.parametrize("M,N,K", [(3232, 768, 3072), (6464, 768, 2304), (1000, 520, 512), (1300, 776, 3072), (130, 96, 64),
                                    (200, 128, 1024), (12928, 768, 3072)])
-def test_gemm_stream_k_epilogues(ops, force_p8, M, N, K):
+@pytest.mark.parametrize("mode", [2, 3], ids=["hybrid", "pure"])
+def test_gemm_stream_k_epilogues(ops, force_p8, M, N, K, mode):
     """`gemm_nt_sk_kernel` (gemm.hip, round 5): the 128x128 ring kernel with the launch's K loop cut into equal shares per CU
     (stream-K) -- a tile's finisher adds the partial tiles earlier workgroups published through the library's slabs (agent-scope
     release / acquire hand-off) and runs the fused epilogue.  Every epilogue it instantiates (0 bias, 3 dropout + residual, 4 bias +
     residual; the generic LayerNorm-residual form is in test_gemm_layernorm_residual_fp16_stream[stream-k]) against the fp32
     statement; the other epilogues of the battery fall through to the kernels they ran on before.  Two runs give identical bits
-    (fixed summation order), and no finisher ever timed out."""
+    (fixed summation order), and no finisher ever timed out.  mode 2 = the hybrid decomposition (whole tiles data-parallel, the
+    remainder round cut by K), 3 = pure stream-K (every K tile of the launch in equal shares)."""
     force_p8.gemm_set_option("p8_mode", 0)
-    force_p8.gemm_set_option("nt_sk", 2)
+    force_p8.gemm_set_option("nt_sk", mode)
     try:
-        _epilogue_battery(ops, "stream-K %dx%dx%d " % (M, N, K), M, N, K)
+        _epilogue_battery(ops, "stream-K[%d] %dx%dx%d " % (mode, M, N, K), M, N, K)
         A, B = to_gpu_bf16(rnd(M, K, seed=31)), to_gpu_bf16(rnd(N, K, seed=32, scale=0.08))
         bias = (0.3 * torch.randn(N, generator=torch.Generator().manual_seed(33))).to(dev())
         ldc = (N + 63) // 64 * 64

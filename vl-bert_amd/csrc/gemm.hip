@@ -660,21 +660,30 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_nt_ring_kernel(const G
 // of the launch is resident, or becomes resident as soon as another kernel's blocks leave) and every spin is bounded.
 // Summation order is fixed (the owner's own segment, then the contributors in block order): deterministic.
 //
-// MEASURED (MI355X, gpurun_out/r5c + r5d, tools/sk_bench.py; us per launch, whole-tile launcher vs this kernel):
-//                         M = 3232 (32 samples)      M = 6464 (64)            M = 12928 (128)
-//   FFN2 fwd   K = 3072   34.9  vs 49.3 (128x64)     56.0 vs 92.3             66.7 vs 183.7
-//   FFN1 dgrad K = 3072   31.3  vs 46.0              50.5 vs 87.8             62.9 vs 180.7
-//   QKV dgrad  K = 2304   24.7  vs 33.3              39.8 vs 59.5             49.7 vs 130.5
-// (128x128 / one block per CU: 52.1 / 48.7 / 36.6 at M = 3232.)  Bit-checked, deterministic, no hand-off ever timed out -- and
-// 0.6-0.7x the speed of the kernels it was meant to replace, in the whole step 5.39 -> 5.92 ms at 32 samples.  Why: the balance is
-// perfect, the LOCALITY is gone.  In the whole-tile kernels the ~64 blocks an XCD runs at a time sit on neighbouring tiles at the
-// SAME K offset, so an A or B slab is fetched from HBM / the memory-side cache once and shared through the XCD's 4 MB L2; here
-// block r starts at unit r * U / P, i.e. every co-resident block is at a DIFFERENT K offset of its tile, nothing is shared in time,
-// and the launch streams ~360 MB of operands (units x 24 KB) instead of ~25 MB -- HBM-bound at the rate measured.  The load
-// balance stream-K buys (29 equal units per block instead of 48 on the CUs that hold two tiles) is worth less than the L2 reuse
-// it destroys when the operands (A 20 MB + B 4.7 MB) are 6x the L2.  Kept as an OPTION (VLB_GEMM_SK=1 / option "nt_sk"), off by
-// default; what would make it pay is a K-aligned decomposition (all blocks of an XCD inside the same K window), which for 312 tiles
-// on 512 block slots is plain split-K with a fractional split count -- not built.
+// MEASURED (MI355X, gpurun_out/r5c .. r5f, tools/sk_bench.py; us per launch: whole-tile launcher | PURE stream-K | HYBRID):
+//                         M = 3232 (32 samples)       M = 6464 (64)              M = 12928 (128)
+//   FFN2 fwd   K = 3072   34.9 | 49.3 | 33.6          58.0 | 92.3 | 61.9         68.8 | 183.7 | 100.5
+//   FFN1 dgrad K = 3072   31.4 | 46.0 | 29.3          51.8 | 87.8 | 55.1         66.5 | 180.7 |  92.4
+//   QKV dgrad  K = 2304   24.6 | 33.3 | 25.8          40.6 | 59.5 | 46.7         51.7 | 130.5 |  74.2
+//   attn-out   K =  768   14.5 | 21.5 | 23.8          25.3 | 30.8 | 36.5         (hand-off cost > the K loop: never)
+// Bit-checked against the fp32 statement on every epilogue, deterministic, no hand-off ever timed out -- and not faster: the
+// hybrid is 0.94-1.07x at 32 samples, 0.87-0.94x at 64, the pure form 0.6-0.7x; whole step at 32 samples 5.45 (off) vs 5.51 ms.
+// Why, in the order the measurements taught it:
+//  1. PURE stream-K loses the L2.  In the whole-tile kernels the ~64 blocks an XCD runs at a time sit on neighbouring tiles at
+//     the SAME K offset, so an operand slab comes from HBM / the memory-side cache once and is shared through the XCD's 4 MB L2;
+//     with equal unit shares block r starts at unit r * U / P -- every co-resident block at a DIFFERENT K offset, nothing shared in
+//     time, ~360 MB of operands streamed per launch instead of ~25 MB.  (The first version also made the block that reaches a
+//     tile's END its finisher: block r then waits at its start for the end of block r - 1, a serial chain -- 10x slower.)
+//  2. The HYBRID keeps whole tiles in step (they must also come FIRST in every block: a continuation segment in front of them
+//     staggers the K offsets by up to 5 us of streaming and the L2 has turned over before a neighbour reuses a slab: 57.5 -> 55.1
+//     us), so only the remainder round is cut by K.  It then matches the whole-tile kernels but cannot beat them: under full load a
+//     128x64x64 unit takes 0.73 us per block (two blocks per CU: 66 GB/s of operands per CU, ~17 TB/s over the chip -- the
+//     L2 -> LDS path is the bound, not the MFMA pipe and not the balance), while the lopsided TAIL of the whole-tile launch -- 56
+//     or 100 second tiles on a nearly idle chip -- runs at 0.33 us per unit.  Perfect balance saves ~8 us of that tail and the
+//     hand-off costs ~8 us (32 KiB write-through publish, flag, one acquire, 3-4 slab reads per owner).
+//  3. What would pay at these sizes is fewer operand bytes per FLOP, i.e. 256x128 tiles (half the L2 traffic) on the 8-phase
+//     schedule of gemm_p8.hip, K cut in 3 to fill the chip, with this file's hand-off -- a new large-tile core, not built.
+// Kept as an OPTION (VLB_GEMM_SK=1 auto / option "nt_sk": 2 hybrid, 3 pure), OFF by default.
 // ------------------------------------------------------------------------------------
 constexpr int SK_SLAB_BYTES = 128 * 128 * 4;      // workspace per CU: one 128x128 partial tile, or two 128x64 ones (two blocks per CU)
 typedef unsigned int sk_v4u __attribute__((ext_vector_type(4)));
