@@ -60,19 +60,19 @@ def main():
                 t = timed(fn)
                 out[mode] = (t, C.float().clone())
             L.gemm_set_option("nt_sk", 0)
-            # the whole-tile ring kernel forced to its variants (p8 off so that the ring is what runs): 3 = 128x64 / 4 waves, 4 = 128x128 / 4 waves
+            # the whole-tile ring kernel forced to its variants (p8 off so that the ring is what runs): 3 = 128x64 / 4 waves, 2 = 128x128 / 8 waves
             ring = {}
             L.gemm_set_option("p8_mode", 0)
-            for rm in (3, 4, 2):
+            for rm in (3, 2):
                 L.gemm_set_option("nt_ring", rm)
                 ring[rm] = timed(fn)
             L.gemm_set_option("nt_ring", 1)
             L.gemm_set_option("p8_mode", 1)
             fl = 2.0 * M * H * K
             d = float((out[0][1] - out[2][1]).abs().max())
-            print("%-22s %6d %5d %5d | %9.1f %8.1f | %9.1f %8.1f | %6.2fx %.3e | ring 128x64 %6.1f  128x128/4w %6.1f  128x128/8w %6.1f" %
+            print("%-22s %6d %5d %5d | %9.1f %8.1f | %9.1f %8.1f | %6.2fx %.3e | ring 128x64 %6.1f  128x128/8w %6.1f" %
                   ("b%d %s" % (Bt, name), M, H, K, out[0][0], fl / out[0][0] * 1e-6, out[2][0], fl / out[2][0] * 1e-6, out[0][0] / out[2][0], d,
-                   ring[3], ring[4], ring[2]))
+                   ring[3], ring[2]))
     print("stream-K hand-off timeouts:", L.gemm_sk_timeouts())
 
 

@@ -1589,7 +1589,7 @@ static int launch_gemm_epi(GemmParams& p, int splits, hipStream_t stream) {
 }
 
 // ring kernels: 128x128 (8 waves, 4 stages = 128 KiB: one workgroup per CU) and 128x64 (4 waves, 3 stages = 72 KiB: two per CU)
-static int g_nt_ring = -1;        // VLB_GEMM_NT_RING: 0 off | 1 auto (default) | 2 force 128x128 (8 waves) | 3 force 128x64 | 4 force 128x128 on 4 waves
+static int g_nt_ring = -1;        // VLB_GEMM_NT_RING: 0 off | 1 auto (default) | 2 force 128x128 | 3 force 128x64
 void vlb_nt_set_ring(int v) { g_nt_ring = v; }
 
 template <int BM, int BN, int WGM, int WGN, int EPI, int NS>
@@ -1637,9 +1637,10 @@ static int gemm_ring_try(GemmParams& p, int splits, bool want_narrow, hipStream_
   if (g_nt_ring == 1 && !(p.N <= 1024 && p.M <= 8192 && p.M >= 1024 && p.K >= 512)) return 1;
   const bool narrow = g_nt_ring == 3 || g_nt_ring == 1;
   (void)want_narrow;
-  // 4 (round 5): 128x128 tiles on FOUR waves (64x64 per wave: 0.5 fragment reads per MFMA instead of 0.75, 64 FLOP per operand byte
-  // instead of 43), three stages = 96 KiB, one block per CU -- the N = 768 launches of a 32-sample batch are 156 such tiles
-  if (g_nt_ring == 4) return launch_ring_epi<128, 128, 2, 2, 3>(p, stream);
+  // (round 5, measured and removed: 128x128 tiles on FOUR waves -- 64x64 per wave, 0.5 fragment reads per MFMA instead of 0.75, 64
+  // FLOP per operand byte instead of 43, three stages = 96 KiB, one block per CU; the N = 768 launches of a 32-sample batch are 156
+  // such tiles.  us per launch at M = 3232 / 6464, K = 3072: 39.5 / 75.6 against 34.2 / 55.3 for the 128x64 form: one wave per SIMD
+  // has nobody to hide its fragment-read latency behind.  gpurun_out/r5g/sk_bench.txt)
   if (narrow) return launch_ring_epi<128, 64, 2, 2, 3>(p, stream);
   return launch_ring_epi<128, 128, 2, 4, 4>(p, stream);
 }
