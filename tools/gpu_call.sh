@@ -68,7 +68,7 @@ for what in "$@"; do
               grep -o '"comm": {[^}]*}' $OUT/dp2.json ;;
     trace)    ( cd /tmp && export TMPDIR=/tmp && VLB_WGRAD_STREAM=0 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/tr -o r -- python $ROOT/bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-phase-times --no-clock-probe > $OUT/tr.log 2>&1 )
               python tools/kstats.py $OUT/tr 5 24 | tee $OUT/kstats.txt; rm -rf $OUT/tr ;;
-    profiles*) t="${what#profiles}"; t="${t#:}"; VLB_COMMIT=$(cat $ROOT/.commit_stamp 2>/dev/null || echo unknown) timeout 2000 bash tools/make_profiles.sh "${t:-r04}" small; ls $ROOT/gpurun_out/summary ;;
+    profiles*) t="${what#profiles}"; t="${t#:}"; VLB_COMMIT=$(cat $ROOT/.commit_stamp 2>/dev/null || echo unknown) timeout 2000 bash tools/make_profiles.sh "${t:-r05}" small; ls $ROOT/gpurun_out/summary ;;
     *) echo "unknown step: $what" ;;
   esac
 done

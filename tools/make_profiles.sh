@@ -28,7 +28,7 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/final_e2e_write" -o r -- $CMD
 fi
 # summarise on the box and drop the raw rocpd databases (five of them exceed the 64 MiB that gpurun copies back)
 mkdir -p "$OUT/summary"
-TAG="${1:-r04}"
+TAG="${1:-r05}"
 python "$ROOT/tools/profile_report.py" "$OUT" "$OUT/summary" "$TAG"
 rm -rf "$OUT"/final_trace "$OUT"/final_sq "$OUT"/final_fetch "$OUT"/final_write "$OUT"/final_e2e_trace "$OUT"/final_e2e_sq "$OUT"/final_e2e_fetch "$OUT"/final_e2e_write
 grep '"metric"' "$OUT/final_trace.log" | tail -1 | cut -c1-200

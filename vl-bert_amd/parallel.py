@@ -97,7 +97,7 @@ class GradBuckets:
         # single: nothing to exchange (a world of one).  VLB_DP_FORCE_EXCHANGE=1 keeps the whole exchange ON in a world of one -- every
         # collective is then the identity, but the communicator's reduce-scatter / all-gather / all-reduce calls, their stream
         # ordering and the graph segments cut around them all execute: the way a 1-GPU box runs the RCCL code path (tests/test_dp_gpu.py)
-        self.single = self.world == 1 and not force_exchange()
+        self._force = force_exchange()
         self.wire_dtype = default_wire_dtype(self.world) if wire_dtype == "default" else wire_dtype
         if self.wire_dtype == flat_grad.dtype:
             self.wire_dtype = None
@@ -187,6 +187,11 @@ class GradBuckets:
             self._stage32 = None
         self._repl = None                         # set_replicated_fp32()
         assert names[0] in offsets
+
+    @property
+    def single(self):
+        """Nothing to exchange: a world of one without VLB_DP_FORCE_EXCHANGE (derived, so that `world` stays the one source of truth)."""
+        return self.world == 1 and not self._force
 
     # ------------------------------------------------------------------------------------------------------------------
     def coverage(self):
