@@ -656,7 +656,19 @@ def main():
     torch.cuda.set_device(local_rank)
     dist = None
     backend = os.environ.get("VLB_BENCH_BACKEND", "gloo" if shared else "nccl")
-    if world > 1:
+    # VLB_DP_FORCE_EXCHANGE=1 (parallel.force_exchange): the whole multi-rank path of this file -- communicator, gradient buckets, sharded
+    # optimizer, graph segments cut at the collectives, the exposed-communication measurement -- in a world of ONE, every collective the
+    # identity: how a 1-GPU box executes what `--gpus 8` will run (tests/test_dp_gpu.py).  The line it prints is a functional record,
+    # not a throughput claim (config.forced_exchange = true).
+    forced = os.environ.get("VLB_DP_FORCE_EXCHANGE", "0") == "1" and world == 1
+    multi = world > 1 or forced
+    if forced and "MASTER_PORT" not in os.environ:
+        import socket
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+        s.close()
+    if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import datetime
@@ -678,7 +690,7 @@ def main():
             _fail("rank %d: %s communicator over %d ranks could not be formed: %s: %s" % (rank, backend, world, type(e).__name__, str(e)[:300]))
 
     args.world, args.rank, args.dist = world, rank, dist
-    wd = _watchdog(int(os.environ.get("VLB_BENCH_WATCHDOG_S", "1500"))) if world > 1 else {"phase": ""}
+    wd = _watchdog(int(os.environ.get("VLB_BENCH_WATCHDOG_S", "1500"))) if multi else {"phase": ""}
     if args.vqa or args.vcr:
         (bench_vqa if args.vqa else bench_vcr)(args)
         if dist is not None:
@@ -735,7 +747,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    use_graph = (args.graph or world > 1) and not args.no_graph
+    use_graph = (args.graph or multi) and not args.no_graph
     step = eng.train_step
     graph_info = None
     if use_graph:
@@ -778,7 +790,7 @@ def main():
     # identical kernels, graph segments and host calls at the same per-GPU batch; the numbers computed there are meaningless, the
     # parameters are re-broadcast afterwards).  Per-rank wall time between device syncs, no barrier inside.
     comm = None
-    if world > 1 and eng.buckets is not None:
+    if multi and eng.buckets is not None:
         def rank_loop(n):
             torch.cuda.synchronize()
             t = time.perf_counter()
@@ -827,7 +839,7 @@ def main():
         return e0.elapsed_time(e1) / n
 
     fwd_ms = fwd_bwd_ms = None
-    if world == 1 and not args.no_phase_times:
+    if world == 1 and not forced and not args.no_phase_times:
         fwd_ms = timed_loop(lambda: eng.forward(True))
 
         def fwd_bwd():
@@ -1020,7 +1032,8 @@ def main():
                                          else None),
                        "seq_len": T + R + 1,
                        "parallelism": "dp%d" % world, "hipgraph": graph_info if use_graph else False, "arch": arch, "cus": cus,
-                       "collective_backend": (("RCCL (nccl)" if backend == "nccl" else backend) if world > 1 else None),
+                       "collective_backend": (("RCCL (nccl)" if backend == "nccl" else backend) if multi else None),
+                       "forced_exchange": bool(forced),
                        "ranks": world,
                        "dp_exchange": (("sharded optimizer: reduce-scatter -> clip + AdamW on the owned 1/%d -> bf16 weight all-gather under "
                                         "the next forward" % world) if eng.buckets.sharded else "bucketed all-reduce, replicated AdamW")

@@ -188,6 +188,31 @@ def test_bench_two_gpus_over_rccl_reports_the_exchange():
     assert d["value"] > 0 and d["config"]["global_batch"] == 256
 
 
+def test_bench_multi_gpu_path_runs_over_rccl_in_a_world_of_one():
+    """The code `bench.py --gpus N` will run on the 8-GPU node, executed here: VLB_DP_FORCE_EXCHANGE=1 makes a single rank form the RCCL
+    communicator (probe all-reduce included), build the gradient buckets and the sharded optimizer, capture the step as hipGraph segments
+    cut at the collectives, time it, and run the exposed-communication measurement -- every collective the identity.  rc 0, one JSON
+    line that names RCCL, the segmented graph and the per-rank communication figures; the loss is finite."""
+    import json
+    import math
+    env = dict(os.environ, VLB_DP_FORCE_EXCHANGE="1", OMP_NUM_THREADS="4")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--global-batch", "32",
+                        "--no-cpu-baseline", "--no-clock-probe"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    print(r.stdout[-2500:])
+    print(r.stderr[-2500:])
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(next(l for l in reversed(r.stdout.splitlines()) if l.startswith("{")))
+    c = d["config"]
+    assert c["forced_exchange"] is True and c["ranks"] == 1 and c["collective_backend"] == "RCCL (nccl)" and not c["ranks_share_devices"]
+    assert c["dp_exchange"].startswith("sharded optimizer") and c["grad_wire_dtype"] == "bfloat16"
+    assert isinstance(c["hipgraph"], str) and "graph segment" in c["hipgraph"], c["hipgraph"]
+    assert d["comm"] is not None and len(d["comm"]["exposed_comm_ms_per_rank"]) == 1
+    assert d["value"] > 0 and math.isfinite(d["loss"]) and d["roofline"]["achieved"] > 0
+
+
 def test_bench_fails_loudly_when_the_communicator_cannot_form():
     """A rank whose peers never show up must end with a non-zero exit code and ONE line saying why -- not hang the driver's SCALE run:
     WORLD_SIZE = 2 with a single process, short rendezvous time-out."""
