@@ -672,8 +672,11 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_nt_ring_kernel(const G
 //  1. PURE stream-K loses the L2.  In the whole-tile kernels the ~64 blocks an XCD runs at a time sit on neighbouring tiles at
 //     the SAME K offset, so an operand slab comes from HBM / the memory-side cache once and is shared through the XCD's 4 MB L2;
 //     with equal unit shares block r starts at unit r * U / P -- every co-resident block at a DIFFERENT K offset, nothing shared in
-//     time, ~360 MB of operands streamed per launch instead of ~25 MB.  (The first version also made the block that reaches a
-//     tile's END its finisher: block r then waits at its start for the end of block r - 1, a serial chain -- 10x slower.)
+//     time.  Measured (rocprofv3 --pmc FETCH_SIZE, tools/sk_traffic.py -> profiles/r05_sk_traffic.txt), HBM reads per launch at
+//     K = 3072: M = 3232: whole tiles 78 MB | hybrid 106 MB | pure 242 MB;  M = 6464: 138 | 167 | 504 MB (5.6 TB/s over its 90 us:
+//     the pure form is HBM-bound).  (Operands are 24.6 / 44.4 MB; with eight private L2s the whole-tile floor is W once per XCD +
+//     A once = 57.6 / 77.5 MB.)  (The first version also made the block that reaches a tile's END its finisher: block r then waits
+//     at its start for the end of block r - 1, a serial chain -- 10x slower.)
 //  2. The HYBRID keeps whole tiles in step (they must also come FIRST in every block: a continuation segment in front of them
 //     staggers the K offsets by up to 5 us of streaming and the L2 has turned over before a neighbour reuses a slab: 57.5 -> 55.1
 //     us), so only the remainder round is cut by K.  It then matches the whole-tile kernels but cannot beat them: under full load a
