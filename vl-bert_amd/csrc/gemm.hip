@@ -630,34 +630,38 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_nt_ring_kernel(const G
 }
 
 // ------------------------------------------------------------------------------------
-// STREAM-K form of the ring kernel (round 5): 128x128 tiles, 8 waves, 4-stage ring, ONE workgroup per CU, and the K loop of a
-// launch cut into EQUAL SHARES per workgroup instead of whole tiles per workgroup.
+// STREAM-K form of the ring kernel (round 5; an OPTION, off by default -- see "MEASURED" below): the ring kernel's tiles and K loop
+// (128x64 tiles on four waves, 3-stage ring, TWO blocks per CU by default; 128x128 on eight waves, one block per CU, as the other
+// instantiation), with the K tiles of a launch's REMAINDER round -- or, in the pure form, of the whole launch -- cut into EQUAL
+// SHARES per block instead of whole tiles per block.
 //
-// Why: the strong-scaling columns of the headline metric run 32-128 samples per GPU.  At M = 3232 the N = 768 GEMMs with a long K
-// (FFN2 forward, FFN1 / QKV data gradients: K = 3072 / 2304) are 156 tiles of 128x128 -- 0.6 of a round of 256 CUs, or, as 128x64
-// tiles, 312 workgroups whose operand stream (43 FLOP per L2 byte) is bound by the 64 B/clk L2 -> LDS path of the CUs that got two
-// of them: 25-34 us per launch for 11-15 GFLOP (450 TFLOP/s; profiles/r04_kernel_stats_batch32.txt), 48 launches per step.  Cut
-// by K every CU gets the same 29 K tiles of a 128x128 tile (64 FLOP per byte): one round at 100 %.
+// Why it was built: the strong-scaling columns of the headline metric run 32-128 samples per GPU.  At M = 3232 the N = 768 GEMMs
+// with a long K (FFN2 forward, FFN1 / QKV data gradients: K = 3072 / 2304) are 312 tiles of 128x64 for 512 block slots: the 56 CUs
+// that hold two tiles set the launch time (25-34 us for 11-15 GFLOP, 450 TFLOP/s; profiles/r04_kernel_stats_batch32.txt), 48
+// launches per step.  Cut by K, every block gets the same number of K tiles.
 //
-// Decomposition (XCD-local): block b runs on XCD b % 8 (MI355X_MICROARCH.md, observed placement -- a SPEED assumption only).  Each
-// XCD owns a contiguous run of whole tiles (the grouped tile order of the kernels above); its gridDim.x / 8 blocks cut that run's
-// tiles x K-tiles "units" into equal contiguous shares.  A block therefore walks: [the tail of a tile an earlier block began]
+// Decomposition (XCD-local; the kernel body has the details): block b runs on XCD b % 8 (MI355X_MICROARCH.md, observed placement --
+// a SPEED assumption only).  Each XCD owns a contiguous run of whole tiles (the grouped tile order of the kernels above).  HYBRID
+// (default): its blocks first take whole tiles, data-parallel, for as many full rounds as there are (+ a half round), all starting
+// at k = 0 together; only the tiles of the remaining partial round are cut into "units" (one K tile of one tile) and shared out
+// equally.  PURE (option nt_sk = 3): every tile is cut.  Inside its share a block walks [the tail of a tile an earlier block began]
 // [whole tiles] [the head of a tile later blocks complete].  The block that computes a tile's FIRST K tile owns it: it adds the
-// partial accumulators the later blocks of that tile published (at most a few; all on its own XCD, so the slabs are read from the
-// shared L2) and runs the fused epilogue.  The order matters: a later block works on the owner's tile FIRST and publishes at
-// once, the owner reaches that tile LAST -- the partials are waiting when it gets there.  (The other way round -- the block that
-// reaches the tile's end finishes it -- makes block r wait at its start for the end of block r-1: a serial chain over the XCD's
-// blocks, measured 10x slower than the whole-tile kernels on the first GPU run of this kernel.)  Every block publishes at most ONE
-// partial (its first segment), into its own 64 KiB fp32 slab, lane-linear (16 B per lane and fragment: coalesced both ways).
+// partial accumulators the later blocks of that tile published (at most a few; all on its own XCD) and runs the fused epilogue.  The
+// order matters: a later block works on the owner's tile at the START of its share and publishes at once, the owner reaches that
+// tile at the END of its own -- the partials are waiting when it gets there.  (The other way round -- the block that reaches the
+// tile's end finishes it -- makes block r wait at its start for the end of block r-1: a serial chain over the XCD's blocks,
+// measured 10x slower on the first GPU run of this kernel.)  Every block publishes at most ONE partial (the first segment of its
+// share), into its own fp32 slab (32 KiB for a 128x64 tile), lane-linear: 16 B per lane and fragment, coalesced both ways.
 //
-// Hand-off (cdna_hip_programming.md "in-launch split-K reduction", MI355X_MICROARCH.md "inter-workgroup visibility"): plain 16-B
-// slab stores -> every wave s_waitcnt vmcnt(0) -> barrier -> lane 0: agent-scope RELEASE fence -> asm s_waitcnt vmcnt(0) (the
-// wait the compiler may drop behind buffer_wbl2) -> relaxed agent-scope flag store.  Finisher: lane 0 polls the flags RELAXED
-// (bounded), ONE agent-scope ACQUIRE fence, barrier, plain 16-B loads; then it clears the flags it consumed (each flag has exactly
-// one consumer), so the flags are all zero again when the launch ends: no per-launch host state, hipGraph replay safe.  Correct for
-// any block -> XCD placement; the same-XCD grouping only makes the slab reads L2 hits.  Contributors never wait for anybody; an
-// owner may wait for blocks with HIGHER indices, so the grid never exceeds the CU count (one 128-KiB-LDS block per CU: every block
-// of the launch is resident, or becomes resident as soon as another kernel's blocks leave) and every spin is bounded.
+// Hand-off (cdna_hip_programming.md Guideline 16 / "in-launch split-K reduction", MI355X_MICROARCH.md "inter-workgroup
+// visibility"): WRITE-THROUGH (sc1) 16-B slab stores, so no release fence -> every storing wave s_waitcnt vmcnt(0) -> barrier ->
+// ONE lane's relaxed agent-scope flag store.  Owner: one lane polls the flags RELAXED with a sleep (bounded), ONE agent-scope
+// ACQUIRE fence, barrier, plain 16-B loads; then it clears the flags it consumed (each flag has exactly one consumer), so the flags
+// are all zero again when the launch ends: no per-launch host state, hipGraph replay safe.  Correct for any block -> XCD placement
+// (tests/test_isa_cpu.py pins the instruction sequence, tests/test_ops_gpu.py the results under uneven load).  Contributors never
+// wait for anybody; an owner may wait for blocks with HIGHER indices, so the grid never exceeds what is resident at once (one
+// 128-KiB or two 72-KiB blocks per CU: every block of the launch is resident, or becomes resident as soon as another kernel's
+// blocks leave), every spin is bounded, and two stream-K launches are never left to run concurrently (launcher, sk_order_*).
 // Summation order is fixed (the owner's own segment, then the contributors in block order): deterministic.
 //
 // MEASURED (MI355X, gpurun_out/r5c .. r5f, tools/sk_bench.py; us per launch: whole-tile launcher | PURE stream-K | HYBRID):
