@@ -74,11 +74,13 @@ def test_layernorm_rows_are_loaded_in_one_burst(layernorm):
 
 def test_grouped_weight_gradient_main_loop_is_clean():
     ks = L.kernels(L.compile_isa(os.path.join(CSRC, "gemm_tn8.hip")))
-    for inst in (r"gemm_tn8_kernelILb0E", r"gemm_tn8_kernelILb1E"):     # descriptors in the kernel argument | in a device table (round 4)
+    # descriptors in the kernel argument | in a device table (round 4)  x  16x16x32 | 32x32x16 matrix instructions (round 6)
+    for inst, mfmas in ((r"gemm_tn8_kernelILb0ELb0E", 128), (r"gemm_tn8_kernelILb1ELb0E", 128), (r"gemm_tn8_kernelILb0ELb1E", 64),
+                        (r"gemm_tn8_kernelILb1ELb1E", 64)):
         k = L.find(ks, inst)
         lo, hi = L.mfma_region(k["body"])
         inner = L.region_counts(k["body"], lo, hi)
-        assert inner["mfma"] == 128 and inner["scratch"] == 0       # two K tiles x four phases x 16 MFMAs, no spill traffic in the loop
+        assert inner["mfma"] == mfmas and inner["scratch"] == 0     # two K tiles x four phases x 16 (8) MFMAs, no spill traffic in the loop
         assert inner["vmcnt0"] <= 1                                  # (the end-of-stream drain; the steady state uses counted waits)
         assert k["spill"] == 0 and k["vgpr"] <= 256, inst
 

@@ -896,6 +896,14 @@ extern "C" int vlb_gemm_set_option(const char* name, int value) {
     vlb_tn8_set_uneven(value);
     return VLB_OK;
   }
+  if (!strcmp(name, "tn8_m32")) {          // weight-gradient core: 1 = 32x32x16 matrix instructions (default), 0 = 16x16x32
+    vlb_tn8_set_m32(value);
+    return VLB_OK;
+  }
+  if (!strcmp(name, "tn8_ablate")) {       // measurement builds only (-DVLB_TN8_PROBE)
+    vlb_tn8_set_ablate(value);
+    return VLB_OK;
+  }
   for (int i = 0; i < 8; ++i)
     if (!strcmp(name, g_opt_name[i])) {
       g_opt[i] = value;

@@ -56,3 +56,5 @@ void vlb_nt_set_sk(int v);
 void vlb_tn8_set_mode(int v);
 void vlb_tn8_set_wgs(int v);
 void vlb_tn8_set_uneven(int v);
+void vlb_tn8_set_m32(int v);
+void vlb_tn8_set_ablate(int v);

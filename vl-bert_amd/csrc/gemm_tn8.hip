@@ -75,13 +75,21 @@ struct Tn8Group {
   Tn8Desc d[TN8_MAX_GROUP];
   int n, nitems;
   int nlong;
+  unsigned long long* stamps;           // measurement only (tools/tn8_probe.py): workgroup b leaves {cycles, 100 MHz ticks} x {entry, exit}
 };
 
 // TABLE = false: up to TN8_MAX_GROUP descriptors travel in the kernel argument (the encoder's per-layer group).  TABLE = true (round 4):
 // any number of descriptors in a device table `tab` (grp.n / grp.nitems valid, grp.d unused) -- the deferred weight gradients of a
 // whole ResNet stage (vision.py): ~46 small products that would each be a 100-300-tile launch + a slab reduce become one launch of
 // full-K 256 x 256 items; the descriptor of an item is found by binary search over item0.
-template <bool TABLE>
+// M32 (round 6): the quadrant's products as 8 x v_mfma_f32_32x32x16 instead of 16 x v_mfma_f32_16x16x32 -- half the matrix
+// instructions and half the operand-register reads per FLOP (the chip is power-limited under these kernels), and the 32x32 form's
+// issue ceiling is 15 % above the 16x16 form's (2382 vs 2075 TFLOP/s micro-benchmarked).  A wave's 64 x 32 share of a quadrant is two
+// 32 x 32 blocks; a fragment of k-step s (16 reduction rows) is rows 16 s + 8 (lane >> 5) + [0, 8) of column lane & 31, i.e. the
+// 16-lane groups of a transpose read take (k half, 16-column half) = (lane >> 5, (lane >> 4) & 1); the 32-B column units are swizzled
+// by f(row) = (row & 3) << 1, which spreads the 4 rows x 2 units of a 32-lane read group over all 64 banks.
+// ABL (measurement builds only, -DVLB_TN8_PROBE): bit 0 no LDS-DMA, bit 1 no fragment reads, bit 2 no MFMAs (results WRONG).
+template <bool TABLE, bool M32, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(const Tn8Group grp, const Tn8Desc* __restrict__ tab) {
   auto D = [&](int gi) -> Tn8Desc {
     if constexpr (TABLE) return tab[gi];
@@ -97,6 +105,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(const Tn8Group grp, co
   const int wm = wave >> 2, wn = wave & 3;
   const int nitems = grp.nitems;
   if ((int)blockIdx.x >= nitems) return;
+  if (grp.stamps && tid == 0) {
+    unsigned long long* t = grp.stamps + 4 * blockIdx.x;
+    t[0] = __builtin_readcyclecounter();
+    t[1] = __builtin_amdgcn_s_memrealtime();
+  }
 
   // item -> (gradient g, tile origin, K-tile range): per gradient slice-major (all tiles of a slice are concurrent and share their
   // operand rows in L2); inside a slice the tiles are walked in groups of `tile_group` tile rows, column-major inside a group
@@ -154,7 +167,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(const Tn8Group grp, co
   // chunk P = it*512 + tid of a half-image: row = P >> 4 = it*32 + (tid >> 4), physical 16-B chunk c = P & 15; physical 32-B block
   // c >> 1 holds logical block (c >> 1) ^ f(row), f(row) = (row & 3) | ((row >> 3) & 1) << 2 -- independent of `it`
   const int srow = tid >> 4, sc = tid & 15;
-  const int sf = (srow & 3) | (((srow >> 3) & 1) << 2);
+  const int sf = M32 ? ((srow & 3) << 1) : ((srow & 3) | (((srow >> 3) & 1) << 2));
   const int lc = ((((sc >> 1) ^ sf) << 1) | (sc & 1)) * 8;      // logical column offset inside the 128-wide half-image
   __amdgpu_buffer_rsrc_t rsA, rsB;
   int ldaB = 0, ldbB = 0, clampA = 0, clampB = 0, rowA = 0, rowB = 0;
@@ -173,6 +186,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(const Tn8Group grp, co
   auto stage = [&](auto which_c, auto buf_c) {
     constexpr int WHICH = decltype(which_c)::value, B_ = decltype(buf_c)::value;
     if (!live) return;
+    if constexpr ((ABL & 1) != 0) return;
     const int kt = kt0_p + kt_p;
     if constexpr (WHICH < 2) {
       char* dst = smem + B_ * BUF + (WHICH == 0 ? OFF_A0 : OFF_A1);
@@ -207,75 +221,104 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(const Tn8Group grp, co
   using W3 = std::integral_constant<int, 2>;
 
   // ---------------- consumer ----------------
-  f32x4 acc[8][4];
-  s16x4 alo[4][2], ahi[4][2], blo[2][2], bhi[2][2];
-  float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  // fragments: A index i * KS + s (i: 16- / 32-column block of the wave's 64 A columns, s: k-step), B index j * KS + s
+  constexpr int NI = M32 ? 2 : 4, NJ = M32 ? 1 : 2, KS = M32 ? 4 : 2, KROWS = M32 ? 16 : 32;
+  typedef __attribute__((ext_vector_type(16))) float f32x16;
+  typedef typename std::conditional<M32, f32x16, f32x4>::type acc_t;
+  acc_t acc[2 * NI][2 * NJ];
+  s16x4 alo[NI * KS], ahi[NI * KS], blo[NJ * KS], bhi[NJ * KS];
+  float csum[2 * NI];
   const int L = lane & 15, g = lane >> 4;
-  const int fl = (L >> 2) | ((g & 1) << 2);
+  const int kh = M32 ? (g >> 1) : g;           // which 8-row group of a k-step this lane's fragment elements come from
+  const int e16 = M32 ? (g & 1) : 0;           // M32: which 16-column half of the 32-column block
+  const int fl = M32 ? ((L >> 2) << 1) : ((L >> 2) | ((g & 1) << 2));
   const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(smem);
-  const uint32_t lane_off = lds0 + (uint32_t)((8 * g + (L >> 2)) * 256 + (L & 3) * 8);   // + 32*256*ks, + 4*256 for the high half
-  uint32_t a_fo[4], b_fo[2];
+  const uint32_t lane_off = lds0 + (uint32_t)((8 * kh + (L >> 2)) * 256 + (L & 3) * 8);   // + KROWS*256*s, + 4*256 for the high half
+  uint32_t a_fo[NI], b_fo[NJ];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) a_fo[i] = lane_off + (uint32_t)(((wm * 4 + i) ^ fl) << 5);
+  for (int i = 0; i < NI; ++i)
+    a_fo[i] = lane_off + (uint32_t)(((M32 ? 2 * (wm * 2 + i) + e16 : wm * 4 + i) ^ fl) << 5);
 #pragma unroll
-  for (int j = 0; j < 2; ++j) b_fo[j] = lane_off + (uint32_t)(OFF_B0 + (((wn * 2 + j) ^ fl) << 5));
+  for (int j = 0; j < NJ; ++j)
+    b_fo[j] = lane_off + (uint32_t)(OFF_B0 + (((M32 ? 2 * wn + e16 : wn * 2 + j) ^ fl) << 5));
 
   auto read_a = [&](auto buf_c, auto half_c) {
+    if constexpr ((ABL & 2) != 0) return;
     constexpr int O = decltype(buf_c)::value * BUF + decltype(half_c)::value * HB;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NI; ++i) {
       const uint32_t v = a_fo[i] + (uint32_t)O;
-      tn8_tr_read<0>(alo[i][0], v);
-      tn8_tr_read<4 * 256>(ahi[i][0], v);
-      tn8_tr_read<32 * 256>(alo[i][1], v);
-      tn8_tr_read<32 * 256 + 4 * 256>(ahi[i][1], v);
+      tn8_tr_read<0>(alo[i * KS + 0], v);
+      tn8_tr_read<4 * 256>(ahi[i * KS + 0], v);
+      tn8_tr_read<KROWS * 256>(alo[i * KS + 1], v);
+      tn8_tr_read<KROWS * 256 + 4 * 256>(ahi[i * KS + 1], v);
+      if constexpr (M32) {
+        tn8_tr_read<2 * KROWS * 256>(alo[i * KS + 2], v);
+        tn8_tr_read<2 * KROWS * 256 + 4 * 256>(ahi[i * KS + 2], v);
+        tn8_tr_read<3 * KROWS * 256>(alo[i * KS + 3], v);
+        tn8_tr_read<3 * KROWS * 256 + 4 * 256>(ahi[i * KS + 3], v);
+      }
     }
   };
   auto read_b = [&](auto buf_c, auto half_c) {
+    if constexpr ((ABL & 2) != 0) return;
     constexpr int O = decltype(buf_c)::value * BUF + decltype(half_c)::value * HB;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NJ; ++j) {
       const uint32_t v = b_fo[j] + (uint32_t)O;
-      tn8_tr_read<0>(blo[j][0], v);
-      tn8_tr_read<4 * 256>(bhi[j][0], v);
-      tn8_tr_read<32 * 256>(blo[j][1], v);
-      tn8_tr_read<32 * 256 + 4 * 256>(bhi[j][1], v);
+      tn8_tr_read<0>(blo[j * KS + 0], v);
+      tn8_tr_read<4 * 256>(bhi[j * KS + 0], v);
+      tn8_tr_read<KROWS * 256>(blo[j * KS + 1], v);
+      tn8_tr_read<KROWS * 256 + 4 * 256>(bhi[j * KS + 1], v);
+      if constexpr (M32) {
+        tn8_tr_read<2 * KROWS * 256>(blo[j * KS + 2], v);
+        tn8_tr_read<2 * KROWS * 256 + 4 * 256>(bhi[j * KS + 2], v);
+        tn8_tr_read<3 * KROWS * 256>(blo[j * KS + 3], v);
+        tn8_tr_read<3 * KROWS * 256 + 4 * 256>(bhi[j * KS + 3], v);
+      }
     }
   };
   bool do_colsum = false;
   auto compute = [&](auto ha_c, auto hb_c, auto cs_c) {
     constexpr int HA = decltype(ha_c)::value, HB_ = decltype(hb_c)::value;
     constexpr bool CS = decltype(cs_c)::value;      // this phase holds freshly read A fragments: column sums are taken here
+    // (both forms hold 8 A and 4 B fragment register pairs x {lo, hi})
     asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(alo[0][0]), "+v"(ahi[0][0]), "+v"(alo[0][1]), "+v"(ahi[0][1]), "+v"(alo[1][0]), "+v"(ahi[1][0]), "+v"(alo[1][1]),
-                   "+v"(ahi[1][1]), "+v"(alo[2][0]), "+v"(ahi[2][0]), "+v"(alo[2][1]), "+v"(ahi[2][1]), "+v"(alo[3][0]), "+v"(ahi[3][0]),
-                   "+v"(alo[3][1]), "+v"(ahi[3][1]), "+v"(blo[0][0]), "+v"(bhi[0][0]), "+v"(blo[0][1]), "+v"(bhi[0][1]), "+v"(blo[1][0]),
-                   "+v"(bhi[1][0]), "+v"(blo[1][1]), "+v"(bhi[1][1]));
+                 : "+v"(alo[0]), "+v"(ahi[0]), "+v"(alo[1]), "+v"(ahi[1]), "+v"(alo[2]), "+v"(ahi[2]), "+v"(alo[3]), "+v"(ahi[3]),
+                   "+v"(alo[4]), "+v"(ahi[4]), "+v"(alo[5]), "+v"(ahi[5]), "+v"(alo[6]), "+v"(ahi[6]), "+v"(alo[7]), "+v"(ahi[7]),
+                   "+v"(blo[0]), "+v"(bhi[0]), "+v"(blo[1]), "+v"(bhi[1]), "+v"(blo[2]), "+v"(bhi[2]), "+v"(blo[3]), "+v"(bhi[3]));
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
+    if constexpr ((ABL & 4) == 0) {
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+      for (int s = 0; s < KS; ++s)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[HA * 4 + i][HB_ * 2 + j] = VLB_MFMA_16x16x32(tn8_frag(blo[j][ks], bhi[j][ks]), tn8_frag(alo[i][ks], ahi[i][ks]),
-                                                                                acc[HA * 4 + i][HB_ * 2 + j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
+          for (int j = 0; j < NJ; ++j) {
+            if constexpr (M32)
+              acc[HA * NI + i][HB_ * NJ + j] = VLB_MFMA_32x32x16(tn8_frag(blo[j * KS + s], bhi[j * KS + s]), tn8_frag(alo[i * KS + s], ahi[i * KS + s]),
+                                                                 acc[HA * NI + i][HB_ * NJ + j], 0, 0, 0);
+            else
+              acc[HA * NI + i][HB_ * NJ + j] = VLB_MFMA_16x16x32(tn8_frag(blo[j * KS + s], bhi[j * KS + s]), tn8_frag(alo[i * KS + s], ahi[i * KS + s]),
+                                                                 acc[HA * NI + i][HB_ * NJ + j], 0, 0, 0);
+          }
+      __builtin_amdgcn_s_setprio(0);
+    }
     if constexpr (CS) {
       if (do_colsum) {      // wave-uniform; 32 v_dot2c behind the MFMAs of this quadrant
         const bf16x2_t one = {(vlb_h16)1.0f, (vlb_h16)1.0f};
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
-          for (int ks = 0; ks < 2; ++ks) {
-            const uint2 l = __builtin_bit_cast(uint2, alo[i][ks]), h = __builtin_bit_cast(uint2, ahi[i][ks]);
-            float s = csum[HA * 4 + i];
+          for (int ks = 0; ks < KS; ++ks) {
+            const uint2 l = __builtin_bit_cast(uint2, alo[i * KS + ks]), h = __builtin_bit_cast(uint2, ahi[i * KS + ks]);
+            float s = csum[HA * NI + i];
             s = VLB_FDOT2(__builtin_bit_cast(bf16x2_t, l.x), one, s, false);
             s = VLB_FDOT2(__builtin_bit_cast(bf16x2_t, l.y), one, s, false);
             s = VLB_FDOT2(__builtin_bit_cast(bf16x2_t, h.x), one, s, false);
             s = VLB_FDOT2(__builtin_bit_cast(bf16x2_t, h.y), one, s, false);
-            csum[HA * 4 + i] = s;
+            csum[HA * NI + i] = s;
           }
       }
     }
@@ -302,10 +345,18 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(const Tn8Group grp, co
     float* const colsum = D(gi).colsum;
     do_colsum = (colsum != nullptr) && (n0 == 0) && (wn == 0);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < 2 * NI; ++i) {
       csum[i] = 0.f;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < 2 * NJ; ++j) {
+        if constexpr (M32) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+        }
+      }
     }
     for (int kt = 0; kt < nk; kt += 2, gk += 2) {
       // ======== K tile gk (buffer 0): quadrants (0,0) (0,1) (1,1) (1,0) ========
@@ -371,39 +422,50 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(const Tn8Group grp, co
       const int Mo = d.Mo, No = d.No;
       const long ldc = d.ldc;
       const float* const rowscale = d.rowscale;
+      // output fragment (fi, cj, q): row m (one per lane), 4 consecutive columns from n
+      //   16x16 form: fi < 8 (tile half x 16-row fragment), cj < 4, q = 0:      m = .. + (fi & 3) * 16 + L,       n = .. + (cj & 1) * 16 + 4 g
+      //   32x32 form: fi < 4 (tile half x 32-row block),    cj < 2, q < 4:      m = .. + (fi & 1) * 32 + lane&31, n = .. + 8 q + 4 (lane >> 5)
+      constexpr int NQ = M32 ? 4 : 1;
 #pragma unroll
-      for (int R_ = 0; R_ < 8; ++R_) {
-        const int m = m0 + (R_ >> 2) * 128 + wm * 64 + (R_ & 3) * 16 + L;
+      for (int fi = 0; fi < 2 * NI; ++fi) {
+        const int m = M32 ? m0 + (fi >> 1) * 128 + wm * 64 + (fi & 1) * 32 + (lane & 31) : m0 + (fi >> 2) * 128 + wm * 64 + (fi & 3) * 16 + L;
         if (m >= Mo) continue;
         const float rs = rowscale ? rowscale[m] : 1.0f;
 #pragma unroll
-        for (int cj = 0; cj < 4; ++cj) {
-          const int n = n0 + (cj >> 1) * 128 + wn * 32 + (cj & 1) * 16 + 4 * g;
-          if (n >= No) continue;
-          float* c = C + (long)m * ldc + n;
-          f32x4 v = acc[R_][cj];
-          if (rowscale) v = (f32x4){v[0] * rs, v[1] * rs, v[2] * rs, v[3] * rs};
-          if (n + 3 < No) {
-            float4 o4 = make_float4(v[0], v[1], v[2], v[3]);
-            if (accum) {
-              const float4 o = *(const float4*)c;
-              o4 = make_float4(o.x + v[0], o.y + v[1], o.z + v[2], o.w + v[3]);
+        for (int cj = 0; cj < 2 * NJ; ++cj) {
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) {
+            const int n = M32 ? n0 + cj * 128 + wn * 32 + 8 * q + 4 * (lane >> 5) : n0 + (cj >> 1) * 128 + wn * 32 + (cj & 1) * 16 + 4 * g;
+            if (n >= No) continue;
+            float* c = C + (long)m * ldc + n;
+            f32x4 v = (f32x4){acc[fi][cj][4 * q + 0], acc[fi][cj][4 * q + 1], acc[fi][cj][4 * q + 2], acc[fi][cj][4 * q + 3]};
+            if (rowscale) v = (f32x4){v[0] * rs, v[1] * rs, v[2] * rs, v[3] * rs};
+            if (n + 3 < No) {
+              float4 o4 = make_float4(v[0], v[1], v[2], v[3]);
+              if (accum) {
+                const float4 o = *(const float4*)c;
+                o4 = make_float4(o.x + v[0], o.y + v[1], o.z + v[2], o.w + v[3]);
+              }
+              if (d.c_split_stride == 0) vlb_store_nt((float4*)c, o4);      // the gradient itself (next read by the optimizer): streaming store
+              else *(float4*)c = o4;                                          // a K-slice slab: re-read by the reduce kernel right away
+            } else {
+              for (int r = 0; r < 4 && n + r < No; ++r) c[r] = accum ? c[r] + v[r] : v[r];
             }
-            if (d.c_split_stride == 0) vlb_store_nt((float4*)c, o4);      // the gradient itself (next read by the optimizer): streaming store
-            else *(float4*)c = o4;                                          // a K-slice slab: re-read by the reduce kernel right away
-          } else {
-            for (int r = 0; r < 4 && n + r < No; ++r) c[r] = accum ? c[r] + v[r] : v[r];
           }
         }
       }
-      if (do_colsum) {      // per-lane partial sums cover k = 8 g + [0, 8) of every k-step: reduce over the 4 lane groups
+      if (do_colsum) {      // per-lane partial sums cover 8 of a k-step's rows: reduce over the lanes that hold the other rows of the same column
 #pragma unroll
-        for (int R_ = 0; R_ < 8; ++R_) {
-          float v = csum[R_];
-          v += __shfl_xor(v, 16, 64);
-          v += __shfl_xor(v, 32, 64);
-          const int m = m0 + (R_ >> 2) * 128 + wm * 64 + (R_ & 3) * 16 + L;
-          if (g == 0 && m < D(gi).Mo) atomicAdd(colsum + m, v);
+        for (int fi = 0; fi < 2 * NI; ++fi) {
+          float v = csum[fi];
+          if constexpr (M32) {
+            v += __shfl_xor(v, 32, 64);
+          } else {
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+          }
+          const int m = M32 ? m0 + (fi >> 1) * 128 + wm * 64 + (fi & 1) * 32 + (lane & 31) : m0 + (fi >> 2) * 128 + wm * 64 + (fi & 3) * 16 + L;
+          if (kh == 0 && m < D(gi).Mo) atomicAdd(colsum + m, v);
         }
       }
     }
@@ -411,6 +473,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(const Tn8Group grp, co
     __builtin_amdgcn_s_waitcnt(0x0F70);
   }
   if (wm == 0) tn8_barrier();      // pairs with the extra barrier the lagging wave group took at the start
+  if (grp.stamps && tid == 0) {
+    unsigned long long* t = grp.stamps + 4 * blockIdx.x;
+    t[2] = __builtin_readcyclecounter();
+    t[3] = __builtin_amdgcn_s_memrealtime();
+  }
 }
 
 int env_int(const char* name, int dflt) {
@@ -427,6 +494,15 @@ static int g_tn8_uneven = -1;   // VLB_GEMM_TN8_UNEVEN: 1 = the uneven three-sli
 static int g_tn8_wgs = -1;       // VLB_GEMM_TN8_WGS: persistent workgroups per launch (default 256 = one per CU)
 void vlb_tn8_set_wgs(int v) { g_tn8_wgs = v; }
 void vlb_tn8_set_uneven(int v) { g_tn8_uneven = v; }
+static int g_tn8_m32 = -1;       // VLB_GEMM_TN8_M32: 1 = v_mfma_f32_32x32x16 form of the quadrant products (run-time: "tn8_m32")
+void vlb_tn8_set_m32(int v) { g_tn8_m32 = v; }
+static int g_tn8_ablate = 0;     // measurement builds (-DVLB_TN8_PROBE) only: see the kernel's ABL parameter
+void vlb_tn8_set_ablate(int v) { g_tn8_ablate = v; }
+static unsigned long long* g_tn8_stamps = nullptr;      // tools/tn8_probe.py: 4 x uint64 per workgroup, or null
+extern "C" int vlb_tn8_set_stamps(void* dev) {
+  g_tn8_stamps = (unsigned long long*)dev;
+  return VLB_OK;
+}
 
 // K slices for a [Mo, No] gradient over R rows: fill the 256 CUs (one workgroup each) in whole rounds; a slice is a whole number of
 // 128-row units.  Cost model: rounds x (slice length + fixed cost per item) + slab traffic.
@@ -458,24 +534,50 @@ static int tile_group_for(int ntm, int ntn) {
   return gm < 1 ? 1 : gm;
 }
 
-template <bool TABLE>
-static int tn8_launch_t(Tn8Group& grp, const Tn8Desc* tab, hipStream_t stream) {
+template <bool TABLE, bool M32, int ABL>
+static int tn8_launch_k(Tn8Group& grp, const Tn8Desc* tab, int gx, hipStream_t stream) {
   constexpr int smem = 131072;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_tn8_kernel<TABLE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_tn8_kernel<TABLE, M32, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) {
       vlb_set_error("gemm_tn8: cannot reserve %d bytes of LDS: %s", smem, hipGetErrorString(e));
       return VLB_ERR_HIP;
     }
     attr_set = true;
   }
-  if (g_tn8_wgs < 0) g_tn8_wgs = env_int("VLB_GEMM_TN8_WGS", 256);
-  const int cap = (g_tn8_wgs >= 8 && g_tn8_wgs <= 256) ? g_tn8_wgs : 256;
-  const int gx = grp.nitems > cap ? cap : grp.nitems;
-  hipLaunchKernelGGL(gemm_tn8_kernel<TABLE>, dim3(gx), dim3(512), smem, stream, grp, tab);
+  hipLaunchKernelGGL((gemm_tn8_kernel<TABLE, M32, ABL>), dim3(gx), dim3(512), smem, stream, grp, tab);
   VLB_CHECK_LAUNCH("vlb_wgrad_tn_bf16(tn8)");
   return VLB_OK;
+}
+
+template <bool TABLE>
+static int tn8_launch_t(Tn8Group& grp, const Tn8Desc* tab, hipStream_t stream) {
+  if (g_tn8_wgs < 0) g_tn8_wgs = env_int("VLB_GEMM_TN8_WGS", 256);
+  if (g_tn8_m32 < 0) g_tn8_m32 = env_int("VLB_GEMM_TN8_M32", 1);
+  const int cap = (g_tn8_wgs >= 8 && g_tn8_wgs <= 256) ? g_tn8_wgs : 256;
+  const int gx = grp.nitems > cap ? cap : grp.nitems;
+  grp.stamps = g_tn8_stamps;
+#ifdef VLB_TN8_PROBE
+  if (!TABLE && g_tn8_ablate) {
+    switch ((g_tn8_m32 ? 8 : 0) | (g_tn8_ablate & 7)) {
+      case 1: return tn8_launch_k<false, false, 1>(grp, tab, gx, stream);
+      case 2: return tn8_launch_k<false, false, 2>(grp, tab, gx, stream);
+      case 3: return tn8_launch_k<false, false, 3>(grp, tab, gx, stream);
+      case 4: return tn8_launch_k<false, false, 4>(grp, tab, gx, stream);
+      case 5: return tn8_launch_k<false, false, 5>(grp, tab, gx, stream);
+      case 6: return tn8_launch_k<false, false, 6>(grp, tab, gx, stream);
+      case 9: return tn8_launch_k<false, true, 1>(grp, tab, gx, stream);
+      case 10: return tn8_launch_k<false, true, 2>(grp, tab, gx, stream);
+      case 11: return tn8_launch_k<false, true, 3>(grp, tab, gx, stream);
+      case 12: return tn8_launch_k<false, true, 4>(grp, tab, gx, stream);
+      case 13: return tn8_launch_k<false, true, 5>(grp, tab, gx, stream);
+      case 14: return tn8_launch_k<false, true, 6>(grp, tab, gx, stream);
+      default: break;
+    }
+  }
+#endif
+  return g_tn8_m32 ? tn8_launch_k<TABLE, true, 0>(grp, tab, gx, stream) : tn8_launch_k<TABLE, false, 0>(grp, tab, gx, stream);
 }
 
 static int tn8_launch(Tn8Group& grp, hipStream_t stream) { return tn8_launch_t<false>(grp, nullptr, stream); }

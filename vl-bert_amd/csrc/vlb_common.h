@@ -16,10 +16,12 @@ typedef uint16_t bf16_t;  // raw 16-bit element in memory (bfloat16, or IEEE fp1
 #ifdef VLB_ACT_F16
 typedef _Float16 vlb_h16;
 #define VLB_MFMA_16x16x32 __builtin_amdgcn_mfma_f32_16x16x32_f16
+#define VLB_MFMA_32x32x16 __builtin_amdgcn_mfma_f32_32x32x16_f16
 #define VLB_ACT_IS_F16 1
 #else
 typedef __bf16 vlb_h16;
 #define VLB_MFMA_16x16x32 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#define VLB_MFMA_32x32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16
 #define VLB_ACT_IS_F16 0
 #endif
 typedef __attribute__((ext_vector_type(8))) vlb_h16 bf16x8;
