@@ -608,6 +608,50 @@ def test_wgrad_tn_grouped_layer_uneven_cut(ops, R):
         report("grouped wgrad %d uneven vs equal cut" % k, got[1][k][2], got[0][k][2].cpu(), 1e-3, 2e-4)
 
 
+@pytest.mark.parametrize("R", [25856, 3328])
+def test_wgrad_tn_core_variants(ops, R):
+    """The large-tile weight-gradient core with both matrix instructions (round 6: `tn8_m32` 0 = 16x16x32, the default; 1 = 32x32x16) as the
+    grouped launch of an encoder layer, as a ragged single product (Mo, No not multiples of the tile), and as the TABLE launch of two
+    layers' products over full K (what the engine issues per layer pair): each against an fp32 torch.mm of the same bf16 operands."""
+    from importlib import import_module
+    lib = import_module("vl-bert_amd._lib")
+    H, I = 768, 3072
+    shapes = [(H, I), (I, H), (H, H), (3 * H, H)]
+    ins = [(to_gpu_bf16(rnd(R, Mo, seed=160 + k, scale=0.5)), to_gpu_bf16(rnd(R, No, seed=170 + k, scale=0.2))) for k, (Mo, No) in enumerate(shapes * 2)]
+    rag = (to_gpu_bf16(rnd(4096, 1000, seed=180, scale=0.5)), to_gpu_bf16(rnd(4096, 520, seed=181, scale=0.2)))
+    work = torch.empty(3 * sum(a * b for a, b in shapes) + 64, dtype=torch.float32, device=dev())
+    got = {}
+    try:
+        for m32 in (0, 1):
+            lib.gemm_set_option("tn8_m32", m32)
+            mk = lambda Mo, No, c: (torch.full((Mo, No), c, dtype=torch.float32, device=dev()), torch.ones(Mo, dtype=torch.float32, device=dev()))
+            items = [(dY, X) + mk(Mo, No, 0.5) for (dY, X), (Mo, No) in zip(ins[:4], shapes)]
+            ops.wgrad_tn_group(items, workspace=work, accumulate=True)
+            one = [(rag[0], rag[1], torch.full((1000, 520), -0.25, dtype=torch.float32, device=dev()), torch.zeros(1000, dtype=torch.float32, device=dev()))]
+            ops.wgrad_tn_group(one, workspace=work, accumulate=True)
+            pair = [(dY, X) + mk(Mo, No, 0.5) + (None,) for (dY, X), (Mo, No) in zip(ins, shapes * 2)]
+            tab = ops.WgradTable(pair, dev(), accumulate=True)
+            assert tab.ok and tab.nitems == 216
+            tab.run()
+            torch.cuda.synchronize()
+            got[m32] = (items + one, pair)
+    finally:
+        lib.gemm_set_option("tn8_m32", 0)
+    for k, (dY, X) in enumerate(ins[:4] + [rag]):
+        base, cbase = (0.5, 1.0) if k < 4 else (-0.25, 0.0)
+        ref = (base + dY.float().t() @ X.float()).cpu()
+        refb = (cbase + dY.float().sum(0)).cpu()
+        for m32 in (0, 1):
+            report("wgrad core m32=%d product %d (R=%d)" % (m32, k, R), got[m32][0][k][2], ref, 1e-3, 2e-4)
+            report("wgrad core m32=%d colsum %d" % (m32, k), got[m32][0][k][3], refb, 1e-3, 2e-4)
+    for k, (dY, X) in enumerate(ins):
+        ref = (0.5 + dY.float().t() @ X.float()).cpu()
+        refb = (1.0 + dY.float().sum(0)).cpu()
+        for m32 in (0, 1):
+            report("wgrad pair table m32=%d product %d (R=%d)" % (m32, k, R), got[m32][1][k][2], ref, 1e-3, 2e-4)
+            report("wgrad pair table m32=%d colsum %d" % (m32, k), got[m32][1][k][3], refb, 1e-3, 2e-4)
+
+
 @pytest.mark.parametrize("accumulate", [True, False])
 def test_wgrad_tn_table_many_products_one_launch(ops, accumulate):
     """vlb_wgrad_tn_table_*: weight gradients with DIFFERENT row counts, ragged output shapes (Mo / No below, at and beyond one

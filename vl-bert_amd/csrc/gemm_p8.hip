@@ -896,7 +896,7 @@ extern "C" int vlb_gemm_set_option(const char* name, int value) {
     vlb_tn8_set_uneven(value);
     return VLB_OK;
   }
-  if (!strcmp(name, "tn8_m32")) {          // weight-gradient core: 1 = 32x32x16 matrix instructions (default), 0 = 16x16x32
+  if (!strcmp(name, "tn8_m32")) {          // weight-gradient core: 1 = 32x32x16 matrix instructions, 0 = 16x16x32 (default)
     vlb_tn8_set_m32(value);
     return VLB_OK;
   }

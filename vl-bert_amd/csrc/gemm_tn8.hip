@@ -88,7 +88,11 @@ struct Tn8Group {
 // 32 x 32 blocks; a fragment of k-step s (16 reduction rows) is rows 16 s + 8 (lane >> 5) + [0, 8) of column lane & 31, i.e. the
 // 16-lane groups of a transpose read take (k half, 16-column half) = (lane >> 5, (lane >> 4) & 1); the 32-B column units are swizzled
 // by f(row) = (row & 3) << 1, which spreads the 4 rows x 2 units of a 32-lane read group over all 64 banks.
-// ABL (measurement builds only, -DVLB_TN8_PROBE): bit 0 no LDS-DMA, bit 1 no fragment reads, bit 2 no MFMAs (results WRONG).
+// Measured (tools/tn8_probe.py, profiles/r06_tn8_probe.txt): 11 % fewer shader cycles per K tile (2900 vs 3270) at an 11 % lower clock
+// (1.99 vs 2.23 GHz) -- the chip is power-limited under this kernel and the launch takes the same 355-365 us either way; the whole step
+// was 0.1 ms slower with it.  Default: the 16x16x32 form (VLB_GEMM_TN8_M32=1 / option "tn8_m32" selects this one).
+// ABL (measurement builds only, -DVLB_TN8_PROBE): bit 0 no LDS-DMA, bit 1 no fragment reads, bit 2 no MFMAs, bit 3 every workgroup
+// streams the operand panels of work item 0 (an all-L2-hit operand stream) -- results WRONG.
 template <bool TABLE, bool M32, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(const Tn8Group grp, const Tn8Desc* __restrict__ tab) {
   auto D = [&](int gi) -> Tn8Desc {
@@ -176,6 +180,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(const Tn8Group grp, co
   auto setup = [&](int w) {
     int gi;
     item_of(w, gi, pm0, pn0, kt0_p, nk_p);
+    if constexpr ((ABL & 8) != 0) { gi = 0; pm0 = 0; pn0 = 0; kt0_p = 0; }      // every workgroup streams the SAME panels: L2 hits only
     const Tn8Desc d = D(gi);
     rsA = __builtin_amdgcn_make_buffer_rsrc((void*)d.A, 0, 0x7FFFFFFF, 0x00020000);
     rsB = __builtin_amdgcn_make_buffer_rsrc((void*)d.B, 0, 0x7FFFFFFF, 0x00020000);
@@ -494,7 +499,7 @@ static int g_tn8_uneven = -1;   // VLB_GEMM_TN8_UNEVEN: 1 = the uneven three-sli
 static int g_tn8_wgs = -1;       // VLB_GEMM_TN8_WGS: persistent workgroups per launch (default 256 = one per CU)
 void vlb_tn8_set_wgs(int v) { g_tn8_wgs = v; }
 void vlb_tn8_set_uneven(int v) { g_tn8_uneven = v; }
-static int g_tn8_m32 = -1;       // VLB_GEMM_TN8_M32: 1 = v_mfma_f32_32x32x16 form of the quadrant products (run-time: "tn8_m32")
+static int g_tn8_m32 = -1;       // VLB_GEMM_TN8_M32: 1 = v_mfma_f32_32x32x16 form of the quadrant products, 0 (default) 16x16x32 (run-time: "tn8_m32")
 void vlb_tn8_set_m32(int v) { g_tn8_m32 = v; }
 static int g_tn8_ablate = 0;     // measurement builds (-DVLB_TN8_PROBE) only: see the kernel's ABL parameter
 void vlb_tn8_set_ablate(int v) { g_tn8_ablate = v; }
@@ -554,27 +559,18 @@ static int tn8_launch_k(Tn8Group& grp, const Tn8Desc* tab, int gx, hipStream_t s
 template <bool TABLE>
 static int tn8_launch_t(Tn8Group& grp, const Tn8Desc* tab, hipStream_t stream) {
   if (g_tn8_wgs < 0) g_tn8_wgs = env_int("VLB_GEMM_TN8_WGS", 256);
-  if (g_tn8_m32 < 0) g_tn8_m32 = env_int("VLB_GEMM_TN8_M32", 1);
+  if (g_tn8_m32 < 0) g_tn8_m32 = env_int("VLB_GEMM_TN8_M32", 0);
   const int cap = (g_tn8_wgs >= 8 && g_tn8_wgs <= 256) ? g_tn8_wgs : 256;
   const int gx = grp.nitems > cap ? cap : grp.nitems;
   grp.stamps = g_tn8_stamps;
 #ifdef VLB_TN8_PROBE
   if (!TABLE && g_tn8_ablate) {
-    switch ((g_tn8_m32 ? 8 : 0) | (g_tn8_ablate & 7)) {
-      case 1: return tn8_launch_k<false, false, 1>(grp, tab, gx, stream);
-      case 2: return tn8_launch_k<false, false, 2>(grp, tab, gx, stream);
-      case 3: return tn8_launch_k<false, false, 3>(grp, tab, gx, stream);
-      case 4: return tn8_launch_k<false, false, 4>(grp, tab, gx, stream);
-      case 5: return tn8_launch_k<false, false, 5>(grp, tab, gx, stream);
-      case 6: return tn8_launch_k<false, false, 6>(grp, tab, gx, stream);
-      case 9: return tn8_launch_k<false, true, 1>(grp, tab, gx, stream);
-      case 10: return tn8_launch_k<false, true, 2>(grp, tab, gx, stream);
-      case 11: return tn8_launch_k<false, true, 3>(grp, tab, gx, stream);
-      case 12: return tn8_launch_k<false, true, 4>(grp, tab, gx, stream);
-      case 13: return tn8_launch_k<false, true, 5>(grp, tab, gx, stream);
-      case 14: return tn8_launch_k<false, true, 6>(grp, tab, gx, stream);
-      default: break;
-    }
+#define TN8_ABL(M, A) \
+  if ((g_tn8_m32 != 0) == (M != 0) && (g_tn8_ablate & 15) == A) return tn8_launch_k<false, M != 0, A>(grp, tab, gx, stream);
+#define TN8_ABLS(M) TN8_ABL(M, 1) TN8_ABL(M, 2) TN8_ABL(M, 3) TN8_ABL(M, 4) TN8_ABL(M, 5) TN8_ABL(M, 6) TN8_ABL(M, 8) TN8_ABL(M, 12) TN8_ABL(M, 14)
+    TN8_ABLS(0) TN8_ABLS(1)
+#undef TN8_ABLS
+#undef TN8_ABL
   }
 #endif
   return g_tn8_m32 ? tn8_launch_k<TABLE, true, 0>(grp, tab, gx, stream) : tn8_launch_k<TABLE, false, 0>(grp, tab, gx, stream);

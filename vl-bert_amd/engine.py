@@ -355,9 +355,15 @@ class PretrainEngine:
         # gradient operands (LN2 / LN1 outputs through dropout, dU, dQKV) stay alive until then and are double-buffered by layer
         # parity: the next layer writes the other set while the group still reads this one.
         self.dZ = zb(M, H)
-        self.dD2, self.dD1 = [zbm(H), zbm(H)], [zbm(H), zbm(H)]
-        self.dU2 = [zbm(I), zbm(I)]
-        self.dQKV2 = [zbm(3 * H), zbm(3 * H)]
+        # Round 6: the weight gradients of TWO layers go out as one table launch of full-K work items (216 items for 256 CUs like the
+        # grouped launch of one layer, but no K slices: no fp32 slabs, no reduce launch) -- the upper layer of a pair keeps its operands
+        # until the lower one is done, so there are four sets (layer & 3) instead of two.  VLB_WGRAD_PAIRS=0: one grouped launch per layer.
+        self._pairs = os.environ.get("VLB_WGRAD_PAIRS", "1") != "0" and os.environ.get("VLB_WGRAD_TN", "1") != "0"
+        self._pair_tables = {}
+        nset = 4 if self._pairs else 2
+        self.dD2, self.dD1 = [zbm(H) for _ in range(nset)], [zbm(H) for _ in range(nset)]
+        self.dU2 = [zbm(I) for _ in range(nset)]
+        self.dQKV2 = [zbm(3 * H) for _ in range(nset)]
         self.dCTX = zb(M, H)
         self.tG = zb(max(3 * H, I), self.Mp)       # transposed gradients (zero padded columns persist)
         self.tA = zb(max(H, I), self.Mp)           # transposed activations
@@ -367,8 +373,8 @@ class PretrainEngine:
         self.d_text_out, self.d_obj_out = zb(BT, H), zb(BR, H)
         self.d_mvrc_u = zb(BR, H)
         self.d_textvis, self.d_objvis = zf(Bt, H), zf(BR, H)
-        # embedding backward: slots / partial vectors of the batch-shared sums (ops.embed_bwd scratch form; VLB_EMBED_BWD_PS=0: atomics)
-        self.emb_scratch = ops.embed_bwd_scratch(Bt, T, H, dev) if os.environ.get("VLB_EMBED_BWD_PS", "1") != "0" else None
+        # embedding backward: slots / partial vectors of the batch-shared sums (ops.embed_bwd scratch form, VLB_EMBED_BWD_PS=1; default: atomics -- measured 320 vs 308 us, the word-embedding scatter is what costs)
+        self.emb_scratch = ops.embed_bwd_scratch(Bt, T, H, self.dev) if os.environ.get("VLB_EMBED_BWD_PS", "0") == "1" else None
         self.d_obj_reps = zf(BR, H)
         self.d_yds = zb(BR, H)
         self.d_afeat = zb(BR, VIS_DIM)
@@ -404,7 +410,6 @@ class PretrainEngine:
         self._ln_pending = []
         self.graph = None
         self._weights_dirty = True
-        import os
         self.use_tn_wgrad = os.environ.get("VLB_WGRAD_TN", "1") != "0"
         self.buckets = None
         # sharded optimizer: the weight gather of the last update may still be in flight (forward waits per bucket); the transposed /
@@ -795,6 +800,39 @@ class PretrainEngine:
         for dy, _, _, _ in items:
             self._pending[dy.data_ptr()] = done              # whoever overwrites an operand next must wait for the group
 
+    def _wgrad_pair(self, items):
+        """items: [(dy, x, gw, gb)] of TWO encoder layers (8 products over the same rows) as ONE table launch of full-K 256 x 256 work
+        items on the side stream (ops.WgradTable: no K slices, no slabs, no reduce).  The descriptor table of a pair is built once per
+        (buffers, accumulate) and replayed.  False: not taken (a product outside what the table kernel covers, or a table that would
+        have to be built during stream capture) -- the caller falls back to one grouped launch per layer."""
+        acc = not self._fresh_grads
+        pad = self._row_padded
+        items = [(pad.get(dy.data_ptr(), dy), pad.get(x.data_ptr(), x), gw, gb) for dy, x, gw, gb in items]
+        key = (acc,) + tuple(t.data_ptr() for it in items for t in it)
+        tab = self._pair_tables.get(key)
+        if tab is None:
+            if self.dev.type == "cuda" and torch.cuda.is_current_stream_capturing():
+                return False
+            if len({t.shape[0] for it in items for t in it[:2]}) != 1:
+                return False
+            tab = ops.WgradTable([(dy, x, gw, gb, None) for dy, x, gw, gb in items], self.dev, accumulate=acc)
+            self._pair_tables[key] = tab
+        if not tab.ok:
+            return False
+        if self.side is None:
+            tab.run()
+            return True
+        ready = torch.cuda.Event()
+        ready.record()
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ready)
+            tab.run()
+            done = torch.cuda.Event()
+            done.record()
+        for dy, _, _, _ in items:
+            self._pending[dy.data_ptr()] = done              # whoever overwrites an operand next must wait for the launch
+        return True
+
     def _before_write(self, *bufs):
         """Main stream is about to overwrite these buffers: wait for side-stream weight gradients still reading them."""
         for b in bufs:
@@ -900,10 +938,11 @@ class PretrainEngine:
         mask = self.lay["attn_mask"]
         if self.enc32 is not None:
             dx = self.enc32.backward(dx, p_h, p_a, on_layer_done, will_launch)
+        held = None      # (layer, weight-gradient items) of an odd layer waiting for the layer below it (self._pairs)
         for l in reversed(range(L if self.enc32 is None else 0)):
             p = "vlbert.encoder.layer.%d." % l
             dx_next = self.dXb if dx is self.dXa else self.dXa
-            par = l & 1
+            par = l & (len(self.dD2) - 1)
             dD2, dD1, dU, dQKV = self.dD2[par], self.dD1[par], self.dU2[par], self.dQKV2[par]
             # LN2: dZ2 (residual branch) and dD2 (into output.dense, through its dropout; a plain copy when dropout is off --
             # dZ is reused inside the layer, the grouped weight gradient at its end needs its own operand)
@@ -925,15 +964,29 @@ class PretrainEngine:
             gwqkv = self.P.view(self.P.grad, p + "attention.self.query.weight", (3 * H, H), span=3)
             gbqkv = self.P.view(self.P.grad, p + "attention.self.query.bias", (3 * H,), span=3)
             ops.gemm_nt(dQKV, wT[p + "qkv"], dx_next, res=self.dZ)                                  # dX_l (overwrites dY1)
-            # the layer's four weight gradients: one grouped launch (side stream), off the critical dgrad chain
-            self._wgrad_group([(dD2, self.G[l], g32[p + "output.dense.weight"], g32[p + "output.dense.bias"]),
-                               (dU, self.Y1[l], g32[p + "intermediate.dense.weight"], g32[p + "intermediate.dense.bias"]),
-                               (dD1, self.CTX[l], g32[p + "attention.output.dense.weight"], g32[p + "attention.output.dense.bias"]),
-                               (dQKV, self.X[l], gwqkv, gbqkv)])
+            # the layer's four weight gradients on the side stream, off the critical dgrad chain: with the layer below as ONE table launch
+            # (an odd layer waits for its partner), or as one grouped launch per layer
+            wg = [(dD2, self.G[l], g32[p + "output.dense.weight"], g32[p + "output.dense.bias"]),
+                  (dU, self.Y1[l], g32[p + "intermediate.dense.weight"], g32[p + "intermediate.dense.bias"]),
+                  (dD1, self.CTX[l], g32[p + "attention.output.dense.weight"], g32[p + "attention.output.dense.bias"]),
+                  (dQKV, self.X[l], gwqkv, gbqkv)]
             dx = dx_next
-            if on_layer_done and (will_launch is None or will_launch(l)):
-                self._join_side()           # the bucket's weight gradients must be complete before its all-reduce reads them
-                on_layer_done(l)
+            if self._pairs and (l & 1):
+                held = (l, wg)              # (its hook fires behind the pair's launch)
+                continue
+            finished = [l]
+            if held is not None:
+                if not self._wgrad_pair(held[1] + wg):
+                    self._wgrad_group(held[1])
+                    self._wgrad_group(wg)
+                finished = [held[0], l]
+                held = None
+            else:
+                self._wgrad_group(wg)
+            for lf in finished:
+                if on_layer_done and (will_launch is None or will_launch(lf)):
+                    self._join_side()       # the bucket's weight gradients must be complete before its all-reduce reads them
+                    on_layer_done(lf)
         self._join_side()               # embed_bwd adds into the word-embedding gradient the decoder wgrad wrote
         if self.core:
             self._front_core_bwd(dx, p_h)
