@@ -553,6 +553,52 @@ def sustained_clock_mhz(ops, lib, dev):
         return None
 
 
+class LadderExhausted(RuntimeError):
+    """every rung of run_ladder failed; .failures = [{"rung": name, "reason": text}]"""
+
+    def __init__(self, failures):
+        RuntimeError.__init__(self, "; ".join("%s: %s" % (f["rung"], f["reason"]) for f in failures))
+        self.failures = failures
+
+
+def run_ladder(rungs, attempt, agree=None, log=None):
+    """First-contact insurance of the data-parallel bench (round 6): try the configurations of the gradient exchange from the fastest to
+    the plainest and keep the first that EVERY rank completes.  rungs = [(name, spec)]; attempt(spec) returns a result or raises;
+    agree(ok) -> True only when all ranks report ok (an all-reduce MIN over a gloo control group; None: single process).  Returns
+    (name, result, failures) where failures lists the rungs given up with the local reason; raises LadderExhausted when none survives.
+    A rank whose own attempt succeeded but whose peer failed discards its result and follows the peer down (reason "another rank failed").
+    Host logic only -- tests/test_parallel_cpu.py drives it over gloo with injected failures."""
+    failures = []
+    for name, spec in rungs:
+        try:
+            res, ok, why = attempt(spec), True, None
+        except Exception as e:      # noqa: BLE001 -- whatever a first contact with RCCL / graph capture raises
+            res, ok, why = None, False, "%s: %s" % (type(e).__name__, str(e).replace("\n", " ")[:240])
+        all_ok = bool(agree(ok)) if agree is not None else ok
+        if all_ok:
+            return name, res, failures
+        failures.append({"rung": name, "reason": why or "another rank failed"})
+        if log is not None:
+            log("rung '%s' given up (%s)%s" % (name, failures[-1]["reason"], "" if (name, spec) == rungs[-1] else " -- trying the next one"))
+        del res
+    raise LadderExhausted(failures)
+
+
+def dp_rungs(dp_mode, graph):
+    """The ladder of `bench.py --gpus N`: sharded optimizer inside segmented hipGraphs -> the same exchange launched eagerly ->
+    bucketed all-reduce with replicated AdamW, eager, fp32 on the wire (the plainest torch.distributed program there is).
+    --dp-mode allreduce starts at the all-reduce rungs; --no-graph drops the graph rungs."""
+    rungs = []
+    if dp_mode in ("default", "sharded"):
+        if graph:
+            rungs.append(("sharded + segmented hipGraph", {"dp_mode": "sharded", "graph": True, "wire": None}))
+        rungs.append(("sharded, eager", {"dp_mode": "sharded", "graph": False, "wire": None}))
+    elif graph:
+        rungs.append(("all-reduce + segmented hipGraph", {"dp_mode": "allreduce", "graph": True, "wire": None}))
+    rungs.append(("all-reduce, eager, fp32 wire", {"dp_mode": "allreduce", "graph": False, "wire": "fp32"}))
+    return rungs
+
+
 def _fail(reason, code=1):
     """One line with the reason on stderr, non-zero exit code, no clean-up that could block (a hung collective cannot be joined)."""
     print("bench.py: FAILED: " + reason.replace("\n", " "), file=sys.stderr, flush=True)
@@ -688,6 +734,12 @@ def main():
                 raise RuntimeError("probe all-reduce returned %s for %d ranks" % (probe.item(), world))
         except Exception as e:
             _fail("rank %d: %s communicator over %d ranks could not be formed: %s: %s" % (rank, backend, world, type(e).__name__, str(e)[:300]))
+        # control plane of the fall-back ladder: a host-side gloo group, so that ranks can agree on "that rung failed somewhere" even when
+        # the RCCL communicator is what failed
+        try:
+            ctl = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=600))
+        except Exception as e:
+            _fail("rank %d: gloo control group could not be formed: %s: %s" % (rank, type(e).__name__, str(e)[:300]))
 
     args.world, args.rank, args.dist = world, rank, dist
     wd = _watchdog(int(os.environ.get("VLB_BENCH_WATCHDOG_S", "1500"))) if multi else {"phase": ""}
@@ -715,65 +767,100 @@ def main():
                                  multitask=aux > 0)
     else:
         cfg = engine.ModelConfig(num_hidden_layers=args.layers, e2e=args.e2e, multitask=aux > 0)
-    eng = engine.PretrainEngine(cfg, per_gpu, T, R, device="cuda:%d" % local_rank, train=True, lr=1e-4, weight_decay=1e-4,
-                                max_grad_norm=10.0, seed=1234 + rank, image_size=tuple(args.image_size) if args.e2e else None,
-                                B_aux=aux, dp_mode=args.dp_mode)
-    eng.init_random(seed=rank, visual_ln_init=1.0 if args.e2e else 0.0)
-    eng.broadcast_parameters(src=0)      # rank 0's parameters everywhere (the DDP start-up broadcast, pretrain/function/train.py:331-334)
-    batch = syn.make_batch(per_gpu, T, R, seed=100 + rank)
-    kw = {}
-    if aux:           # the text-only corpus batch of the multitask wrapper (general_corpus.py): SEQ_LEN 64, no regions
-        aux_text, aux_lab = syn.make_aux_text(aux, T, seed=300 + rank)
-        kw.update(aux_text=aux_text.cuda(non_blocking=True), aux_mlm_labels=aux_lab.cuda(non_blocking=True))
-    if args.e2e:      # images as the dataset hands them over (mean-subtracted pixels), boxes inside the image
-        gi = torch.Generator().manual_seed(200 + rank)
-        Hi, Wi = args.image_size
-        image = torch.randn(per_gpu, 3, Hi, Wi, generator=gi) * 50.0
-        bx = batch[0]
-        bx[:, :, 0].clamp_(0, Wi - 170)
-        bx[:, :, 1].clamp_(0, Hi - 170)
-        bx[:, :, 2] = torch.minimum(bx[:, :, 2], torch.full_like(bx[:, :, 2], Wi - 1.0))
-        bx[:, :, 3] = torch.minimum(bx[:, :, 3], torch.full_like(bx[:, :, 3], Hi - 1.0))
-        bx[:, 0, :4] = torch.tensor([0.0, 0.0, Wi - 1.0, Hi - 1.0])
-        batch[1][:, 0], batch[1][:, 1] = Wi, Hi
-        kw["image"] = image.cuda(non_blocking=True)
-        kw["mask_raw_pixels"] = True      # the dataset's MASK_RAW_PIXELS step (conceptual_captions.py:201-206), on the device copy
-    eng.set_batch(*[t.cuda(non_blocking=True) for t in batch], **kw)
-    eng.sync_weights()
-    torch.cuda.synchronize()
-
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    use_graph = (args.graph or multi) and not args.no_graph
-    step = eng.train_step
-    graph_info = None
-    if use_graph:
-        eng.train_step()                            # lazy one-time setup + steady-state flags outside capture
-        torch.cuda.synchronize()
-        try:
-            step = eng.make_step_graph()            # one graph (1 rank) / segments cut at the collectives (data parallel)
-            graph_info = "%d graph segment(s) + %d host-side collective calls per step" % (step.n_graphs, step.n_calls)
-        except Exception as e:                      # (a capture restriction of the installed runtime: the eager step is the same arithmetic)
-            print("bench.py: rank %d: graph capture failed (%s: %s) -- running the step eagerly" % (rank, type(e).__name__, str(e)[:200]),
-                  file=sys.stderr, flush=True)
-            torch.cuda.synchronize()
-            step, use_graph = eng.train_step, False
-            if eng.buckets is not None and (eng.buckets.pending or eng.buckets.launched):
-                _fail("rank %d: graph capture failed with a gradient exchange half recorded (%s: %s)" % (rank, type(e).__name__, str(e)[:200]))
-    wd["phase"] = "warm-up steps"
+    inject = [x.strip() for x in os.environ.get("VLB_BENCH_INJECT_FAIL", "").split(";") if x.strip()]      # (tests: ';'-separated rung names that must fail)
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    wd["phase"] = "timed steps"
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    def attempt(spec):
+        """Engine + warm-up + the timed region under one configuration of the gradient exchange (spec = a dp_rungs() entry; world 1: the
+        one configuration the command line asks for).  Raises when anything in it fails; the caller decides what to try next."""
+        if spec.get("wire"):
+            os.environ["VLB_DP_WIRE"] = spec["wire"]
+        eng = engine.PretrainEngine(cfg, per_gpu, T, R, device="cuda:%d" % local_rank, train=True, lr=1e-4, weight_decay=1e-4,
+                                    max_grad_norm=10.0, seed=1234 + rank, image_size=tuple(args.image_size) if args.e2e else None,
+                                    B_aux=aux, dp_mode=spec["dp_mode"])
+        eng.init_random(seed=rank, visual_ln_init=1.0 if args.e2e else 0.0)
+        eng.broadcast_parameters(src=0)      # rank 0's parameters everywhere (the DDP start-up broadcast, pretrain/function/train.py:331-334)
+        batch = syn.make_batch(per_gpu, T, R, seed=100 + rank)
+        kw = {}
+        if aux:           # the text-only corpus batch of the multitask wrapper (general_corpus.py): SEQ_LEN 64, no regions
+            aux_text, aux_lab = syn.make_aux_text(aux, T, seed=300 + rank)
+            kw.update(aux_text=aux_text.cuda(non_blocking=True), aux_mlm_labels=aux_lab.cuda(non_blocking=True))
+        if args.e2e:      # images as the dataset hands them over (mean-subtracted pixels), boxes inside the image
+            gi = torch.Generator().manual_seed(200 + rank)
+            Hi, Wi = args.image_size
+            image = torch.randn(per_gpu, 3, Hi, Wi, generator=gi) * 50.0
+            bx = batch[0]
+            bx[:, :, 0].clamp_(0, Wi - 170)
+            bx[:, :, 1].clamp_(0, Hi - 170)
+            bx[:, :, 2] = torch.minimum(bx[:, :, 2], torch.full_like(bx[:, :, 2], Wi - 1.0))
+            bx[:, :, 3] = torch.minimum(bx[:, :, 3], torch.full_like(bx[:, :, 3], Hi - 1.0))
+            bx[:, 0, :4] = torch.tensor([0.0, 0.0, Wi - 1.0, Hi - 1.0])
+            batch[1][:, 0], batch[1][:, 1] = Wi, Hi
+            kw["image"] = image.cuda(non_blocking=True)
+            kw["mask_raw_pixels"] = True      # the dataset's MASK_RAW_PIXELS step (conceptual_captions.py:201-206), on the device copy
+        eng.set_batch(*[t.cuda(non_blocking=True) for t in batch], **kw)
+        eng.sync_weights()
+        torch.cuda.synchronize()
+
+        use_graph = bool(spec["graph"])
+        step = eng.train_step
+        graph_info = None
+        if use_graph:
+            eng.train_step()                            # lazy one-time setup + steady-state flags outside capture
+            torch.cuda.synchronize()
+            try:
+                step = eng.make_step_graph()            # one graph (1 rank) / segments cut at the collectives (data parallel)
+                graph_info = "%d graph segment(s) + %d host-side collective calls per step" % (step.n_graphs, step.n_calls)
+            except Exception as e:                      # (a capture restriction of the installed runtime: the eager step is the same arithmetic)
+                torch.cuda.synchronize()
+                if multi:                               # the ladder's next rung is the eager form on a FRESH engine
+                    raise RuntimeError("graph capture failed (%s: %s)" % (type(e).__name__, str(e)[:200]))
+                print("bench.py: rank %d: graph capture failed (%s: %s) -- running the step eagerly" % (rank, type(e).__name__, str(e)[:200]),
+                      file=sys.stderr, flush=True)
+                step, use_graph = eng.train_step, False
+        wd["phase"] = "warm-up steps (%s)" % spec.get("name", "single process")
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        if spec.get("name") in inject:
+            raise RuntimeError("injected failure (VLB_BENCH_INJECT_FAIL)")
+        wd["phase"] = "timed steps (%s)" % spec.get("name", "single process")
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        return {"eng": eng, "step": step, "elapsed": elapsed, "use_graph": use_graph, "graph_info": graph_info}
+
+    ladder = None
+    if multi:
+        rungs = [(n, dict(sp, name=n)) for n, sp in dp_rungs(args.dp_mode, not args.no_graph)]
+
+        def agree(ok):
+            t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=ctl)
+            if not int(t):      # leave nothing of the failed configuration behind: queued work, cached blocks
+                try:
+                    torch.cuda.synchronize()
+                except Exception:      # noqa: BLE001
+                    pass
+                import gc
+                gc.collect()
+                torch.cuda.empty_cache()
+            return bool(int(t))
+        try:
+            rung, res, given_up = run_ladder(rungs, attempt, agree,
+                                             log=lambda m: print("bench.py: rank %d: %s" % (rank, m), file=sys.stderr, flush=True))
+        except LadderExhausted as e:
+            _fail("rank %d: every configuration of the gradient exchange failed: %s" % (rank, e))
+        ladder = {"rung": rung, "given_up": given_up, "rungs": [n for n, _ in rungs]}
+    else:
+        res = attempt({"dp_mode": args.dp_mode, "graph": args.graph and not args.no_graph, "wire": None})
+    eng, step, elapsed, use_graph, graph_info = res["eng"], res["step"], res["elapsed"], res["use_graph"], res["graph_info"]
     wd["phase"] = "post-processing"
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -992,7 +1079,7 @@ def main():
     # the committed summary of those passes is reported here when it was taken on this workload, else null.
     traffic, traffic_unit = None, None
     pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    tname = next((n for n in ("r05_gemm_traffic.json", "r04_gemm_traffic.json", "r03_gemm_traffic.json", "r02_gemm_traffic.json")
+    tname = next((n for n in ("r06_gemm_traffic.json", "r05_gemm_traffic.json", "r04_gemm_traffic.json", "r03_gemm_traffic.json", "r02_gemm_traffic.json")
                   if os.path.isfile(os.path.join(pdir, n))), None)
     if world == 1 and args.global_batch == 256 and args.layers == 12 and not args.e2e and not args.large and tname:
         with open(os.path.join(pdir, tname)) as f:
@@ -1039,6 +1126,12 @@ def main():
                                         "the next forward" % world) if eng.buckets.sharded else "bucketed all-reduce, replicated AdamW")
                        if eng.buckets is not None else None,
                        "grad_wire_dtype": (str(eng.buckets.wire_dtype or torch.float32).replace("torch.", "") if eng.buckets is not None else None),
+                       # which configuration of the exchange produced this number (run_ladder: the first one every rank completed) and
+                       # the ones given up before it, with this rank's reason
+                       "dp_ladder": ladder,
+                       # RCCL channels = CUs a collective kernel holds while the persistent one-workgroup-per-CU GEMMs want all 256
+                       # (tools/contention_probe.py: +1-7 % on the GEMMs with 8-64 CUs held, independent of how many -- left at RCCL's default)
+                       "nccl_max_nchannels": os.environ.get("NCCL_MAX_NCHANNELS"),
                        "ranks_share_devices": bool(shared)},
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_p8_kernel + gemm_tn8_kernel (+ the 128x128 gemm_nt / gemm_tn kernels on the small head shapes): "
                                                        "all %d GEMM launches of one step" % len(rec),

@@ -458,6 +458,67 @@ def run_vcr_case(name="vcr_small", num_layers=50):
     print("%s -> %s (%.1f KB), %d gradient tensors" % (name, path, os.path.getsize(path) / 1024, len(keys)))
 
 
+def run_c2_case(name="c2_headline"):
+    """The reference at the BENCHED dimensions (BASELINE.json configs[1]: VL-BERT-base, 12 layers, H = 768, 12 heads, vocabulary
+    30522, 1601 region classes, 64 text + 36 regions), batch 2, in DIGEST form so that the fixture stays under 1 MB: the inputs are
+    regenerated from the seed by vl-bert_amd/synthetic.py (their digests are stored), logits as (norm, sum) + a 4096-sample stride,
+    every parameter gradient as (norm, sum) + a 256-sample stride, losses, global gradient norm.  Pins the oracle -- and, through
+    tests/test_engine_gpu.py, the HIP engine -- to /root/reference/pretrain/modules/resnet_vlbert_for_pretraining.py:93-216 run at the size
+    the metric is quoted on, not only at the toy shapes above."""
+    import time
+    RefModel, RefAdamW = ref_import.import_reference()
+    spec = dict(cfg=dict(hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072, vocab_size=30522,
+                         max_position_embeddings=512, visual_region_classes=1601),
+                B=2, T=64, R=36, ragged=True, seed=2026, pseed=17)
+    cfg = VLBertConfig(**spec["cfg"])
+    vocab_dir = ref_import.make_vocab_dir(os.path.join(tempfile.gettempdir(), "vlb_vocab_%s" % name), cfg.vocab_size)
+    torch.manual_seed(0)
+    model = RefModel(ref_import.make_reference_config(cfg, vocab_dir))
+    params = init_params(cfg, seed=spec["pseed"])
+    sd = dict(params)
+    sd["vlbert.mlm_head.predictions.decoder.weight"] = sd["vlbert.word_embeddings.weight"]
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected and not missing, (missing, unexpected)
+    model.eval()
+    batch = synthetic.make_batch(spec["B"], spec["T"], spec["R"], vocab_size=cfg.vocab_size, region_classes=cfg.visual_region_classes,
+                                 seed=spec["seed"], ragged=spec["ragged"])
+    t0 = time.time()
+    outputs, loss = model(None, *[t.clone() for t in batch])
+    model.zero_grad()
+    loss.backward()
+    dt = time.time() - t0
+    out = {"cfg_keys": np.array(list(spec["cfg"].keys())), "cfg_vals": np.array([float(v) for v in spec["cfg"].values()]),
+           "B": spec["B"], "T": spec["T"], "R": spec["R"], "ragged": spec["ragged"], "seed": spec["seed"], "pseed": spec["pseed"],
+           "reference_fwd_bwd_seconds": dt, "reference_threads": torch.get_num_threads()}
+    for k, t in zip(("boxes", "im_info", "text", "relationship_label", "mlm_labels", "mvrc_ops", "mvrc_labels"), batch):
+        out["in_stat/" + k] = digest(t)[0]
+    for k in ("mlm_logits", "mvrc_logits"):
+        out[k + "_shape"] = np.array(outputs[k].shape)
+        out[k + "_stat"], out[k + "_smp"] = digest(outputs[k])
+    for k in ("mlm_loss", "mvrc_loss"):
+        out[k] = float(outputs[k])
+    out["loss"] = float(loss)
+    named = dict(model.named_parameters())
+    total, names = 0.0, []
+    global SAMPLE
+    keep = SAMPLE
+    SAMPLE = 256
+    for n in sorted(params.keys()):
+        g = named[n].grad if named[n].grad is not None else torch.zeros_like(named[n])
+        total += float((g.double() ** 2).sum())
+        out["g_stat/" + n], out["g_smp/" + n] = digest(g)
+        out["p_stat/" + n] = digest(params[n])[0]
+        names.append(n)
+    SAMPLE = keep
+    out["names"] = np.array(names)
+    out["grad_norm"] = total ** 0.5
+    os.makedirs(os.path.join(ROOT, "tests", "golden", "c2"), exist_ok=True)
+    path = os.path.join(ROOT, "tests", "golden", "c2", name + ".npz")
+    np.savez_compressed(path, **out)
+    print("%s: loss %.6f grad_norm %.6f, reference forward + backward %.1f s on %d threads -> %s (%.1f KB)"
+          % (name, out["loss"], out["grad_norm"], dt, torch.get_num_threads(), path, os.path.getsize(path) / 1024))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     if len(sys.argv) > 1 and sys.argv[1] == "core":
@@ -468,6 +529,8 @@ if __name__ == "__main__":
         run_vqa_case()
     elif len(sys.argv) > 1 and sys.argv[1] == "vcr":
         run_vcr_case()
+    elif len(sys.argv) > 1 and sys.argv[1] == "c2":
+        run_c2_case()
     else:
         for name, spec in CASES.items():
             run_case(name, spec)

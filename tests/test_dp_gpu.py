@@ -213,6 +213,44 @@ def test_bench_multi_gpu_path_runs_over_rccl_in_a_world_of_one():
     assert d["value"] > 0 and math.isfinite(d["loss"]) and d["roofline"]["achieved"] > 0
 
 
+def _forced_bench(inject, extra=()):
+    env = dict(os.environ, VLB_DP_FORCE_EXCHANGE="1", OMP_NUM_THREADS="4", VLB_BENCH_INJECT_FAIL=inject)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--global-batch", "32",
+                           "--no-cpu-baseline", "--no-clock-probe"] + list(extra), env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+
+
+def test_bench_ladder_reaches_the_all_reduce_rung_and_names_it():
+    """First-contact insurance of `bench.py --gpus N` (round 6), on the real engine over RCCL at world 1 (VLB_DP_FORCE_EXCHANGE): with the
+    sharded + graph rung and the sharded eager rung made to fail after their warm-up steps (VLB_BENCH_INJECT_FAIL), the SAME invocation
+    tears both engines down, runs the bucketed all-reduce eagerly with an fp32 wire and still prints its JSON line -- naming the rung that
+    produced the number and the ones it gave up (config.dp_ladder)."""
+    import json
+    import math
+    r = _forced_bench("sharded + segmented hipGraph;sharded, eager")
+    print(r.stdout[-1500:])
+    print(r.stderr[-2500:])
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(next(l for l in reversed(r.stdout.splitlines()) if l.startswith("{")))
+    c = d["config"]
+    assert c["dp_ladder"]["rung"] == "all-reduce, eager, fp32 wire"
+    assert [f["rung"] for f in c["dp_ladder"]["given_up"]] == ["sharded + segmented hipGraph", "sharded, eager"]
+    assert all("injected failure" in f["reason"] for f in c["dp_ladder"]["given_up"])
+    assert c["dp_exchange"].startswith("bucketed all-reduce") and c["grad_wire_dtype"] == "float32" and c["hipgraph"] is False
+    assert d["value"] > 0 and math.isfinite(d["loss"])
+    assert "given up" in r.stderr
+
+
+def test_bench_ladder_exhausted_fails_loudly():
+    """All three rungs failing: non-zero exit code and ONE line saying which rungs failed and why."""
+    r = _forced_bench("sharded + segmented hipGraph;sharded, eager;all-reduce, eager, fp32 wire")
+    print(r.stderr[-1500:])
+    assert r.returncode != 0
+    assert "bench.py: FAILED:" in r.stderr and "every configuration of the gradient exchange failed" in r.stderr
+
+
 def test_bench_fails_loudly_when_the_communicator_cannot_form():
     """A rank whose peers never show up must end with a non-zero exit code and ONE line saying why -- not hang the driver's SCALE run:
     WORLD_SIZE = 2 with a single process, short rendezvous time-out."""

@@ -130,6 +130,52 @@ def test_engine_matches_reference_golden(path):
         assert err <= 4e-2, (n, err)
 
 
+def test_engine_matches_reference_at_the_benched_dimensions():
+    """The HIP engine DIRECTLY against what the real reference produced at BASELINE.json's headline model (12 layers, H = 768, 12 heads,
+    V = 30522, C = 1601, 64 text + 36 regions; batch 2, digest fixture tests/golden/c2/c2_headline.npz from oracle/make_golden.py c2):
+    losses and gradient norm at north_star's 1e-2, the stored 4096-sample strides of both logit tensors in relative Frobenius norm, the
+    256-sample stride of every parameter gradient -- the same statement test_engine_matches_reference_golden makes for the toy shapes."""
+    from tests.test_oracle_golden import c2_digest, load_c2_case
+    z, cfg, params, batch = load_c2_case()
+    B, T, R = int(z["B"]), int(z["T"]), int(z["R"])
+    eng = make_engine(cfg, B, T, R, train=False)
+    eng.load_state_dict({k: v.to(dev()) for k, v in params.items()})
+    eng.set_batch(*[t.to(dev()) for t in batch])
+    eng.zero_grad()
+    eng.forward(train=False)
+    eng.backward(train=False)
+    torch.cuda.synchronize()
+    V, C = cfg.vocab_size, cfg.visual_region_classes
+    lv = eng.loss_values()
+    for k in ("mlm_loss", "mvrc_loss", "loss"):
+        print("c2 dims %s: hip %.6f REFERENCE %.6f" % (k, lv[k], float(z[k])))
+        assert abs(lv[k] - float(z[k])) <= 1e-2 * max(1.0, abs(float(z[k]))), k
+    gn = eng.grad_norm()
+    print("c2 dims grad_norm: hip %.6f REFERENCE %.6f" % (gn, float(z["grad_norm"])))
+    assert abs(gn - float(z["grad_norm"])) <= 1e-2 * float(z["grad_norm"])
+    shape = tuple(int(v) for v in z["mvrc_logits_shape"])          # (B, max objects, C): the reference trims to the longest box list
+    for k, got in (("mlm_logits", eng.mlm_logits_copy[:, :V].view(B, T, V)), ("mvrc_logits", eng.mvrc_logits_copy[:, :C].view(B, R, C)[:, :shape[1]])):
+        assert tuple(got.shape) == tuple(int(v) for v in z[k + "_shape"]), k
+        smp = c2_digest(got.float().cpu(), 4096)[1]
+        ref = z[k + "_smp"]
+        err = np.linalg.norm(smp - ref) / np.linalg.norm(ref)
+        print("c2 dims %s sample rel-fro vs REFERENCE %.3e, max |err| %.3e of max |ref| %.3e" % (k, err, np.abs(smp - ref).max(), np.abs(ref).max()))
+        assert err <= 1e-2, (k, err)
+        assert np.abs(smp - ref).max() <= 2e-3 + 1e-2 * np.abs(ref).max(), k
+    worst = []
+    for n in z["names"]:
+        n = str(n)
+        ref = z["g_smp/" + n]
+        if float(z["g_stat/" + n][0]) < 1e-6 * float(z["grad_norm"]) or np.linalg.norm(ref) < 1e-9:
+            continue
+        smp = c2_digest(eng.g32[n].detach().cpu() / eng.loss_scale, 256)[1]
+        worst.append((float(np.linalg.norm(smp - ref) / np.linalg.norm(ref)), n))
+    worst.sort(reverse=True)
+    for e, n in worst[:6]:
+        print("   rel-fro (256 samples) grad err %.3e  %s" % (e, n))
+    assert worst[0][0] <= 8e-2, worst[:5]          # (256-sample strides at batch 2: noisier than the full-tensor 5e-2 of the oracle checks)
+
+
 def test_engine_multitask_matches_reference():
     """ResNetVLBERTForPretrainingMultitask: B image-caption samples + B_aux text-only samples in one
     encoder pass, three losses; against the oracle and the real reference's fixture."""

@@ -85,6 +85,51 @@ def test_oracle_adamw_matches_reference(path):
         np.testing.assert_allclose(_digest(p)[1], z["adamw_smp/" + n], rtol=1e-5, atol=1e-6, err_msg=n)
 
 
+def load_c2_case():
+    """tests/golden/c2/c2_headline.npz (oracle/make_golden.py c2): the reference at the benched dimensions, digest form."""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "c2", "c2_headline.npz"), allow_pickle=False)
+    cfg = O.VLBertConfig(**{str(k): int(v) for k, v in zip(z["cfg_keys"], z["cfg_vals"])})
+    params = O.init_params(cfg, seed=int(z["pseed"]))
+    syn = importlib.import_module("vl-bert_amd.synthetic")
+    batch = syn.make_batch(int(z["B"]), int(z["T"]), int(z["R"]), vocab_size=cfg.vocab_size, region_classes=cfg.visual_region_classes,
+                           seed=int(z["seed"]), ragged=bool(z["ragged"]))
+    return z, cfg, params, batch
+
+
+def c2_digest(t, sample):
+    t = t.detach().double().reshape(-1)
+    stride = max(1, t.numel() // sample)
+    return np.array([t.norm().item(), t.sum().item()]), t[::stride][:sample].float().numpy()
+
+
+def test_oracle_matches_reference_at_the_benched_dimensions():
+    """The oracle at BASELINE.json's headline model (12 layers, H = 768, 12 heads, V = 30522, C = 1601, 64 + 36 positions, batch 2)
+    against the fixture the REAL reference produced at that size: regenerated inputs and parameters (digests), logits (norm + 4096
+    samples), losses, the global gradient norm and every parameter gradient (norm + 256 samples)."""
+    z, cfg, params, batch = load_c2_case()
+    assert cfg.hidden_size == 768 and cfg.num_hidden_layers == 12 and cfg.vocab_size == 30522 and cfg.visual_region_classes == 1601
+    for k, t in zip(("boxes", "im_info", "text", "relationship_label", "mlm_labels", "mvrc_ops", "mvrc_labels"), batch):
+        np.testing.assert_allclose(c2_digest(t, 4096)[0], z["in_stat/" + k], rtol=1e-9, atol=0, err_msg=k)
+    for n in z["names"]:
+        np.testing.assert_allclose(c2_digest(params[str(n)], 256)[0], z["p_stat/" + str(n)], rtol=1e-6, atol=1e-7)
+    outputs, loss, grads, norm = O.loss_and_grads(params, cfg, batch, train=False)
+    for k in ("mlm_logits", "mvrc_logits"):
+        assert tuple(outputs[k].shape) == tuple(int(v) for v in z[k + "_shape"])
+        st, smp = c2_digest(outputs[k], 4096)
+        assert abs(st[0] - z[k + "_stat"][0]) <= 1e-5 * z[k + "_stat"][0], k
+        np.testing.assert_allclose(smp, z[k + "_smp"], rtol=1e-4, atol=5e-5, err_msg=k)
+    for k in ("mlm_loss", "mvrc_loss"):
+        assert abs(float(outputs[k]) - float(z[k])) <= 1e-5 * max(1.0, abs(float(z[k]))), k
+    assert abs(float(loss) - float(z["loss"])) <= 1e-5 * abs(float(z["loss"]))
+    assert abs(norm - float(z["grad_norm"])) <= 1e-5 * float(z["grad_norm"])
+    for n in z["names"]:
+        n = str(n)
+        st, smp = c2_digest(grads[n], 256)
+        ref = z["g_stat/" + n]
+        assert abs(st[0] - ref[0]) <= 1e-4 * max(ref[0], 1e-6) + 1e-7, n
+        np.testing.assert_allclose(smp, z["g_smp/" + n], rtol=2e-3, atol=2e-6, err_msg=n)
+
+
 def test_coordinate_embedding_shape_and_values():
     b = torch.tensor([[0.0, 0.0, 599.0, 599.0, 600.0, 600.0]])
     e = O.coordinate_embeddings(b, 256)

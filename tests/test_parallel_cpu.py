@@ -473,3 +473,67 @@ def _null_worker(rank, world, port):
 
 def test_null_collectives_issue_no_communication():
     mp.spawn(_null_worker, args=(2, _free_port()), nprocs=2, join=True)
+
+
+def _ladder_worker(rank, world, port, fail_on, q):
+    """One rank of bench.run_ladder over gloo: the rungs named in fail_on[rank] raise on this rank only."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("vlb_bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    dist.init_process_group("gloo", rank=rank, world_size=world, init_method="tcp://127.0.0.1:%d" % port)
+    rungs = [(n, dict(sp, name=n)) for n, sp in bench.dp_rungs("default", True)]
+    tried = []
+
+    def attempt(spec):
+        tried.append(spec["name"])
+        if spec["name"] in fail_on[rank]:
+            raise RuntimeError("injected on rank %d" % rank)
+        return {"dp_mode": spec["dp_mode"], "graph": spec["graph"], "wire": spec["wire"]}
+
+    def agree(ok):
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(int(t))
+    try:
+        name, res, given_up = bench.run_ladder(rungs, attempt, agree)
+        out = {"rung": name, "res": res, "given_up": given_up, "tried": tried}
+    except bench.LadderExhausted as e:
+        out = {"rung": None, "given_up": e.failures, "tried": tried}
+    # the JSON line of the bench carries the rung that produced the number: config.dp_ladder
+    import json
+    line = json.dumps({"config": {"dp_ladder": {"rung": out["rung"], "given_up": out["given_up"], "rungs": [n for n, _ in rungs]}}})
+    out["line"] = line
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["none", "rung1_rank1", "rung1_and_2", "all"])
+def test_bench_ladder_falls_back_together(case):
+    """bench.py --gpus N first-contact insurance (round 6): run_ladder tries sharded + segmented graph -> sharded eager -> all-reduce eager
+    with an fp32 wire and keeps the first configuration EVERY rank completes.  A failure injected on ONE rank moves BOTH ranks to the
+    next rung (the surviving rank discards its result, reason "another rank failed"); the rung that produced the number and the ones given
+    up are named in the JSON line (config.dp_ladder); with every rung failing the ladder raises (bench.py then exits through _fail)."""
+    import json
+    names = ["sharded + segmented hipGraph", "sharded, eager", "all-reduce, eager, fp32 wire"]
+    fail_on = {"none": ([], []), "rung1_rank1": ([], names[:1]), "rung1_and_2": (names[1:2], names[:1]), "all": (names, [])}[case]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    mp.spawn(_ladder_worker, args=(2, _free_port(), fail_on, q), nprocs=2, join=True)
+    got = dict(q.get(timeout=30) for _ in range(2))
+    expect = {"none": names[0], "rung1_rank1": names[1], "rung1_and_2": names[2], "all": None}[case]
+    for rank in (0, 1):
+        o = got[rank]
+        assert o["rung"] == expect, (rank, o)
+        d = json.loads(o["line"])["config"]["dp_ladder"]
+        assert d["rung"] == expect and d["rungs"] == names
+        n_up = {"none": 0, "rung1_rank1": 1, "rung1_and_2": 2, "all": 3}[case]
+        assert [f["rung"] for f in o["given_up"]] == names[:n_up]
+        assert o["tried"] == names[:min(n_up + 1, 3)]                 # both ranks walked the same rungs
+    if case == "rung1_rank1":
+        assert got[0]["given_up"][0]["reason"] == "another rank failed" and "injected on rank 1" in got[1]["given_up"][0]["reason"]
+        assert got[0]["res"] == {"dp_mode": "sharded", "graph": False, "wire": None}
+    if case == "rung1_and_2":
+        assert got[0]["res"] == {"dp_mode": "allreduce", "graph": False, "wire": "fp32"}
