@@ -200,19 +200,6 @@ int vlb_embed_bwd(const void* dy, const void* pre, const float* stats, const flo
                   long dov_sb, long dov_sr, float* d_obj_ling, long dol_sb, long dol_sr, int B, int T, int R, int S,
                   int H, int V, int P, float drop_p, const uint32_t* seed, uint32_t tag, int text_vis_zeroed,
                   vlb_stream_t stream);
-/* vlb_embed_bwd with the batch-shared destinations (position rows, end row, type rows, the objects' shared position row, the 2-row
- * linguistic table, d_gamma / d_beta) summed WITHOUT contended atomics: rows and per-workgroup accumulators go to `scratch` with plain
- * stores and a second launch column-sums them over the batch (the atomics of B workgroups on the same T position rows were two thirds
- * of the kernel's time at batch 256).  scratch: vlb_embed_bwd_scratch_floats(B, T, H) floats, 16-B aligned, contents irrelevant;
- * NULL / too small / P < T + 2: behaves as vlb_embed_bwd.  Same sums up to fp32 summation order. */
-long vlb_embed_bwd_scratch_floats(int B, int T, int H);
-int vlb_embed_bwd_ps(const void* dy, const void* pre, const float* stats, const float* gamma, const int32_t* code,
-                     const int32_t* text_len, const int64_t* text_ids, const int64_t* text_type,
-                     const int64_t* obj_ling_idx, float* d_word, float* d_pos, float* d_type, float* d_end,
-                     float* d_gamma, float* d_beta, float* d_text_vis, long dtv_sb, long dtv_st, float* d_obj_vis,
-                     long dov_sb, long dov_sr, float* d_obj_ling, long dol_sb, long dol_sr, int B, int T, int R, int S,
-                     int H, int V, int P, float drop_p, const uint32_t* seed, uint32_t tag, int text_vis_zeroed,
-                     float* scratch, long scratch_floats, vlb_stream_t stream);
 /* out[i] = src[idx[i]] (rows of H bf16; idx < 0 -> zero row): text/object split of
  * visual_linguistic_bert.py:146-166 */
 int vlb_gather_rows(const void* src, const int32_t* idx, void* out, int n, int H, vlb_stream_t stream);

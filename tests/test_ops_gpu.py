@@ -913,19 +913,6 @@ def test_seq_layout_and_embedding(ops):
     for name, a, b in (("d_word", d_word2, d_word), ("d_pos", d_pos2, d_pos), ("d_type", d_type2, d_type), ("d_end", d_end2, d_end),
                        ("d_gamma", d_g2, d_g), ("d_beta", d_b2, d_b), ("d_text_vis", d_tv2, d_tv), ("d_obj_vis", d_ov2, d_ov)):
         report("embed bwd split " + name, a, b.cpu(), 1e-4, 1e-4)
-    # scratch form (round 6): the batch-shared sums through position slots / per-workgroup partial vectors + a column reduce
-    for zeroed in (False, True):
-        d_word3, d_pos3, d_type3, d_end3, d_g3, d_b3 = z(V, H), z(P, H), z(3, H), z(1, H), z(H), z(H)
-        d_tv3, d_ov3, d_ol3 = z(B, H), z(B * R, H), z(B * R, H)
-        scratch = ops.embed_bwd_scratch(B, T, H, d)
-        scratch.fill_(float("nan"))          # (its contents are irrelevant: every slot that is read was written by this call)
-        ops.embed_bwd(to_gpu_bf16((dy * valid).reshape(B * S, H)), pre, stats, p["vlbert.embedding_LayerNorm.weight"].to(d), lay,
-                      text.to(d), None, None, d_word3, d_pos3, d_type3, d_end3, d_g3, d_b3, d_tv3, (H, 0), d_ov3, (R * H, H), d_ol3,
-                      (R * H, H), B, T, R, S, H, text_vis_zeroed=zeroed, scratch=scratch)
-        for name, a, b in (("d_word", d_word3, d_word), ("d_pos", d_pos3, d_pos), ("d_type", d_type3, d_type), ("d_end", d_end3, d_end),
-                           ("d_gamma", d_g3, d_g), ("d_beta", d_b3, d_b), ("d_text_vis", d_tv3, d_tv), ("d_obj_vis", d_ov3, d_ov),
-                           ("d_obj_ling", d_ol3, d_ol)):
-            report("embed bwd scratch%d %s" % (zeroed, name), a, b.cpu(), 1e-4, 1e-4)
     # table mode for the linguistic part
     table = bf(0.05 * torch.randn(2, H, generator=g))
     sel = mvrc_ops.clone()

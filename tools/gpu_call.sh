@@ -15,7 +15,7 @@
 #   stream           tools/ln_bench.py: LayerNorm forward / backward variants, squared norm, AdamW, wire cast (the HBM-bound kernels of the step)
 #   ntprobe          tools/nt_coherence_probe.hip (are non-temporal loads coherent with what other agents wrote since the last NT load?)
 #   hbm              tools/hbm_stream_probe.hip (attainable streaming rates by access pattern: copy / read / fill / the AdamW stream mix)
-#   tn8              tools/tn8_probe.py (weight-gradient core: matrix-instruction forms, in-kernel clock, ablations)  | embed  tools/embed_bench.py, atomics vs scratch form
+#   tn8              tools/tn8_probe.py (weight-gradient core: matrix-instruction forms, in-kernel clock, ablations)  | embed  tools/embed_bench.py
 #   e2e              config 3 eager / --graph / one vs three weight-gradient side streams     | clock   tools/clock_probe.py
 #   dp2              bench.py --gpus 2 on this box (2 ranks sharing the GPU over gloo; over RCCL where the box has 2 GPUs)
 #   trace            rocprofv3 --kernel-trace --stats of the headline workload -> kernel table (tools/kstats.py)
@@ -69,7 +69,7 @@ for what in "$@"; do
     hbm)      { hipcc --offload-arch=gfx950 -O3 tools/hbm_stream_probe.hip -o /tmp/hbm_probe && timeout 200 /tmp/hbm_probe; } 2>&1 | tee $OUT/hbm_stream_probe.txt | awk '/GB\/s/ { if ($(NF-1) > best[$1]) { best[$1] = $(NF-1); line[$1] = $0 } } END { for (k in line) print "best", line[k] }' ;;
     tn8)      # round 6: the grouped weight-gradient launch, 16x16x32 vs 32x32x16 matrix instructions, clock stamps, ablations (needs csrc/ab built with -DVLB_TN8_PROBE)
               VLB_LIB_PATH=$ROOT/vl-bert_amd/csrc/ab/libvlbert_hip.so timeout 400 python tools/tn8_probe.py 256 --ablate 2>&1 | grep -v amdgpu.ids | tee $OUT/tn8_probe.txt ;;
-    embed)    for v in 0 1; do VLB_EMBED_BWD_PS=$v timeout 200 python tools/embed_bench.py 2>&1 | grep -v amdgpu.ids | sed "s/^/PS=$v /"; done | tee $OUT/embed_bench.txt ;;
+    embed)    timeout 200 python tools/embed_bench.py 2>&1 | grep -v amdgpu.ids | tee $OUT/embed_bench.txt ;;
     clock)    timeout 300 python tools/clock_probe.py 4 2>&1 | grep -v amdgpu.ids | tee $OUT/clock_probe.txt ;;
     graphsmall) for b in 64 32; do timeout 300 python bench.py --no-cpu-baseline --global-batch $b --no-phase-times --graph 2>/dev/null | line "batch $b --graph"; done | tee $OUT/graphsmall.log ;;
     dp2)      timeout 600 python bench.py --gpus 2 --no-cpu-baseline --steps 10 > $OUT/dp2.json 2> $OUT/dp2.err; grep '^{' $OUT/dp2.json | cut -c1-1200; grep -v Gloo $OUT/dp2.err | tail -3

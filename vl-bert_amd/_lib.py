@@ -54,7 +54,6 @@ _SIGS = {
     "vlb_masked_colsum": "plpiipfpuuus",
     "vlb_embed_fwd": "pppp" "pppp" "pll" "pll" "pll" "p" "pp" "ppp" "iiiiiii" "f" "fpu" "s",
     "vlb_embed_bwd": "pppp" "ppppp" "pppppp" "pll" "pll" "pll" "iiiiiii" "fpu" "i" "s",
-    "vlb_embed_bwd_ps": "pppp" "ppppp" "pppppp" "pll" "pll" "pll" "iiiiiii" "fpu" "i" "pl" "s",
     "vlb_gather_rows": "pppiis",
     "vlb_scatter_rows": "pppiis",
     "vlb_mlm_compact": "ppiiiipppppps",
@@ -153,8 +152,6 @@ def load():
     lib.vlb_layernorm_bwd_slabs.argtypes = [_I]
     lib.vlb_wgrad_tn_table_desc_bytes.restype = _L
     lib.vlb_wgrad_tn_table_desc_bytes.argtypes = []
-    lib.vlb_embed_bwd_scratch_floats.restype = _L
-    lib.vlb_embed_bwd_scratch_floats.argtypes = [_I, _I, _I]
     lib.vlb_gemm_set_option.restype = _I
     lib.vlb_gemm_set_option.argtypes = [ctypes.c_char_p, _I]
     lib.vlb_gemm_sk_timeouts.restype = _L
@@ -194,7 +191,7 @@ def exported_names():
     return ["vlb_last_error", "vlb_version", "vlb_act_dtype", "vlb_device_info", "vlb_wgrad_workspace_floats",
             "vlb_layernorm_bwd_workspace_floats", "vlb_layernorm_bwd_slabs", "vlb_gemm_set_option",
             "vlb_roi_align_gather_workspace_bytes", "vlb_nonfinite_status", "vlb_wgrad_tn_table_desc_bytes",
-            "vlb_gemm_sk_timeouts", "vlb_embed_bwd_scratch_floats"] + sorted(_SIGS)
+            "vlb_gemm_sk_timeouts"] + sorted(_SIGS)
 
 
 def nonfinite_status(reset=True):

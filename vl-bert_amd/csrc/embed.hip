@@ -295,15 +295,7 @@ struct EmbedBwdParams {
   float* d_obj_ling; long dol_sb, dol_sr;  // table mode (obj_ling_idx): d_obj_ling is the [2,H] table grad
   int B, T, R, S, H, V, P;
   uint32_t drop_thr; float drop_scale; const uint32_t* seed; uint32_t tag;
-  // round 6: the BATCH-SHARED destinations without atomics.  Every sample's text row s adds into d_pos[s], every end row into d_end,
-  // every workgroup's LDS accumulators into the same 8 vectors: B workgroups issuing H device-scope atomics each on the same few rows at
-  // the same time (301 us at batch 256, 0.7 TB/s).  With pos_scratch != null the text / end rows store their gradient row into slot
-  // [b][position] of a [B][PS = T + 2][H] fp32 scratch, every workgroup stores its accumulators into its own [EMB_NPART][H] block of
-  // `partials` (plain 16-B / 4-B stores), and embed_bwd_reduce_kernel column-sums both over the batch.  Only the word-embedding rows
-  // (scattered over the vocabulary: few duplicates) keep their atomics.
-  float* pos_scratch; float* partials; int PS;
 };
-constexpr int EMB_NPART = 8;      // per-workgroup partial vectors: type 0..2 | objects' shared position row | 2-row linguistic table | d_gamma | d_beta
 
 // NIT = ceil(H/256) (register footprint follows H); 512 threads = 8 waves per sample.  The block-shared accumulators
 // live in LDS in LANE-MAJOR order (element (i,k) of lane l at (i*4+k)*64 + l): ds_add_f32 from consecutive lanes hits
@@ -327,10 +319,17 @@ __global__ __launch_bounds__(512) void embed_bwd_kernel(const EmbedBwdParams p) 
   const int tl = p.text_len[b];
   const uint32_t seed = (p.drop_thr && p.seed) ? *p.seed : 0u;
   float gs[NIT][4], bs[NIT][4];
+  // Round 6: the block-shared sums of the row loop are kept in REGISTERS per wave and go to LDS once, behind the loop.  Every row used to
+  // issue 24-36 LDS float atomics per lane (type row + object position / per-sample text-visual sum / linguistic table row); measured
+  // (VLB_EMBED_ABLATE build, batch 256): 306 us with them, 167 us without -- the LDS atomic unit, not the global atomics, was the bound
+  // (SQ_LDS_IDX_ACTIVE = 100 % of the kernel in profiles/r05_gemm_pmc.txt).  t0 / t1: text rows by token type (their sum is the
+  // per-sample text-visual gradient); ob: object rows (type 2, the shared object position row, and -- minus l0 -- table row 1);
+  // l0: object rows that select linguistic table row 0.  The single end row of a sample keeps its LDS atomics.
+  float t0[NIT][4], t1[NIT][4], ob[NIT][4], l0[NIT][4];
 #pragma unroll
   for (int i = 0; i < NIT; ++i)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) gs[i][k] = bs[i][k] = 0.f;
+    for (int k = 0; k < 4; ++k) gs[i][k] = bs[i][k] = t0[i][k] = t1[i][k] = ob[i][k] = l0[i][k] = 0.f;
 
   // gridDim.y workgroups share one sample: each takes a contiguous chunk of its S rows
   const int rows_per = (p.S + gridDim.y - 1) / gridDim.y, s_lo = blockIdx.y * rows_per, s_hi = min(p.S, s_lo + rows_per);
@@ -394,22 +393,17 @@ __global__ __launch_bounds__(512) void embed_bwd_kernel(const EmbedBwdParams p) 
     int type_id = 0, pos_id = s;
     float* w_dst = nullptr;   // global atomic destination for the "linguistic" row
     float* v_dst = nullptr;   // plain-store destination for the visual part
-    float* l_ling = nullptr;  // LDS accumulation for the linguistic part
-    bool tv_lds = false, pos_lds = false;
+    bool pos_lds = false;
     if (kind == KIND_TEXT) {
       long id = p.text_ids[b * p.T + idx];
       id = id < 0 ? 0 : (id >= p.V ? p.V - 1 : id);
       w_dst = p.d_word + id * H;
       type_id = p.text_type ? (int)p.text_type[b * p.T + idx] : 0;
-      if (p.d_text_vis) {
-        if (p.dtv_st == 0) tv_lds = true;
-        else v_dst = p.d_text_vis + b * p.dtv_sb + idx * p.dtv_st;
-      }
+      if (p.d_text_vis && p.dtv_st != 0) v_dst = p.d_text_vis + b * p.dtv_sb + idx * p.dtv_st;      // (dtv_st == 0: per-sample sum, below)
     } else if (kind == KIND_OBJ) {
       type_id = 2;
       pos_lds = true;
       if (p.d_obj_vis) v_dst = p.d_obj_vis + b * p.dov_sb + idx * p.dov_sr;
-      if (p.obj_ling_idx) l_ling = l_tab + (p.obj_ling_idx[b * p.R + idx] ? LWD : 0);
     } else {  // END
       type_id = 2;
       pos_id = tl + 1;
@@ -417,7 +411,9 @@ __global__ __launch_bounds__(512) void embed_bwd_kernel(const EmbedBwdParams p) 
     }
     pos_id = min(pos_id, p.P - 1);
     float* pos_dst = p.d_pos + (long)pos_id * H;
-    float* ps_dst = (p.pos_scratch && !pos_lds) ? p.pos_scratch + ((long)b * p.PS + pos_id) * H : nullptr;
+    // (wave-uniform: one row per wave -- made provably so for scalar branches)
+    const int ukind = __builtin_amdgcn_readfirstlane(kind), utype = __builtin_amdgcn_readfirstlane(type_id);
+    const bool ling0 = (ukind == KIND_OBJ) && p.obj_ling_idx && __builtin_amdgcn_readfirstlane((int)(p.obj_ling_idx[b * p.R + idx] == 0));
     float* dl_dst = (kind == KIND_OBJ && !p.obj_ling_idx && p.d_obj_ling) ? p.d_obj_ling + b * p.dol_sb + idx * p.dol_sr : nullptr;
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
@@ -427,15 +423,22 @@ __global__ __launch_bounds__(512) void embed_bwd_kernel(const EmbedBwdParams p) 
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           d[k] = rstd * (g[i][k] - s1 - xh[i][k] * s2);
-          const int q = (i * 4 + k) * 64 + lane;
-          atomicAdd(l_type + type_id * LWD + q, d[k]);
-          if (pos_lds) atomicAdd(l_objpos + q, d[k]);
-          if (tv_lds) atomicAdd(l_tv + q, d[k]);
-          if (l_ling) atomicAdd(l_ling + q, d[k]);
+          if (ukind == KIND_TEXT) {
+            if (utype == 0) t0[i][k] += d[k];
+            else if (utype == 1) t1[i][k] += d[k];
+            else {                                                                       // (a text token of type 2: no caller produces one)
+              atomicAdd(l_type + 2 * LWD + (i * 4 + k) * 64 + lane, d[k]);
+              if (p.d_text_vis && p.dtv_st == 0) atomicAdd(l_tv + (i * 4 + k) * 64 + lane, d[k]);
+            }
+          } else if (ukind == KIND_OBJ) {
+            ob[i][k] += d[k];
+            if (ling0) l0[i][k] += d[k];
+          } else {                                                                       // the end row
+            atomicAdd(l_type + 2 * LWD + (i * 4 + k) * 64 + lane, d[k]);
+          }
         }
         if (v_dst) *(float4*)(v_dst + c) = make_float4(d[0], d[1], d[2], d[3]);
         if (dl_dst) *(float4*)(dl_dst + c) = make_float4(d[0], d[1], d[2], d[3]);
-        if (ps_dst) *(float4*)(ps_dst + c) = make_float4(d[0], d[1], d[2], d[3]);
         *(float4*)(rowbuf + c) = make_float4(d[0], d[1], d[2], d[3]);
       }
     }
@@ -444,45 +447,42 @@ __global__ __launch_bounds__(512) void embed_bwd_kernel(const EmbedBwdParams p) 
     // i.e. four times the cache-line requests for the same data, and this kernel is bound by exactly that rate.
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the row image is wave-private: order the writes above before the reads below
     __builtin_amdgcn_wave_barrier();
-    const bool pos_at = !pos_lds && !ps_dst;
-    if (ps_dst && kind == KIND_END) w_dst = nullptr;      // (the reduce pass sums the end rows' slots into d_end)
-    if (pos_at || w_dst) {
+    if (!pos_lds || w_dst) {
       for (int c = lane; c < H; c += 64) {
         const float d = rowbuf[c];
-        if (pos_at) atomicAdd(pos_dst + c, d);
+        if (!pos_lds) atomicAdd(pos_dst + c, d);
         if (w_dst) atomicAdd(w_dst + c, d);
       }
     }
     __builtin_amdgcn_wave_barrier();
   }
+  // the waves add their register sums into the block's accumulators ONE WAVE AT A TIME with plain LDS reads / writes (a float atomic in
+  // LDS costs ~170 cycles per wave instruction on this chip and the unit is shared by the CU's 16 waves: 108 of them per wave were
+  // still 2/3 of what the row loop's used to cost)
+  __syncthreads();      // (the end rows' atomics of the loop above are complete)
+  for (int r = 0; r < nwave; ++r) {
+    if (wave == r) {
 #pragma unroll
-  for (int i = 0; i < NIT; ++i)
+      for (int i = 0; i < NIT; ++i)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int q = (i * 4 + k) * 64 + lane;
-      atomicAdd(l_g + q, gs[i][k]);
-      atomicAdd(l_b + q, bs[i][k]);
+        for (int k = 0; k < 4; ++k) {
+          const int q = (i * 4 + k) * 64 + lane;
+          l_g[q] += gs[i][k];
+          l_b[q] += bs[i][k];
+          l_type[q] += t0[i][k];
+          l_type[LWD + q] += t1[i][k];
+          l_type[2 * LWD + q] += ob[i][k];
+          l_objpos[q] += ob[i][k];
+          if (p.d_text_vis && p.dtv_st == 0) l_tv[q] += t0[i][k] + t1[i][k];
+          if (p.obj_ling_idx) {
+            l_tab[q] += l0[i][k];
+            l_tab[LWD + q] += ob[i][k] - l0[i][k];
+          }
+        }
     }
-  __syncthreads();
-  const int pos_obj = min(tl, p.P - 1);
-  if (p.partials) {      // this workgroup's accumulators -> its own block of the partial table (natural column order)
-    float* part = p.partials + ((long)(b * gridDim.y + blockIdx.y) * EMB_NPART) * H;
-    for (int c = threadIdx.x; c < H; c += blockDim.x) {
-      const int chunk = c >> 2, q = (((chunk >> 6) * 4 + (c & 3)) << 6) + (chunk & 63);   // natural column -> lane-major slot
-#pragma unroll
-      for (int t = 0; t < 3; ++t) part[t * H + c] = l_type[t * LWD + q];
-      part[3 * H + c] = l_objpos[q];
-      part[4 * H + c] = l_tab[q];
-      part[5 * H + c] = l_tab[LWD + q];
-      part[6 * H + c] = l_g[q];
-      part[7 * H + c] = l_b[q];
-      if (p.d_text_vis && p.dtv_st == 0) {
-        if (gridDim.y == 1) p.d_text_vis[b * p.dtv_sb + c] = l_tv[q];
-        else if (l_tv[q] != 0.f) atomicAdd(p.d_text_vis + b * p.dtv_sb + c, l_tv[q]);
-      }
-    }
-    return;
+    __syncthreads();
   }
+  const int pos_obj = min(tl, p.P - 1);
   for (int c = threadIdx.x; c < H; c += blockDim.x) {
     const int chunk = c >> 2, q = (((chunk >> 6) * 4 + (c & 3)) << 6) + (chunk & 63);   // natural column -> lane-major slot
 #pragma unroll
@@ -499,76 +499,6 @@ __global__ __launch_bounds__(512) void embed_bwd_kernel(const EmbedBwdParams p) 
     }
     atomicAdd(p.d_gamma + c, l_g[q]);
     atomicAdd(p.d_beta + c, l_b[q]);
-  }
-}
-
-// Second pass of the scratch form of embed_bwd_kernel: column sums over the batch, one role per blockIdx.x, a chunk of `chunk` samples
-// per blockIdx.y; a thread owns 4 columns (16-B loads: a whole 3-KiB row per 192 threads at H = 768), 8 rows in flight; one atomic per
-// (destination element, chunk).
-//   x <  PS      : d_pos[x]  += the slots [b][x] that sample b wrote -- its text rows (x < text_len[b]) and its end row (x == text_len[b] + 1)
-//                               -- and, where x == text_len[b], the objects' shared position row of b's workgroups (partial vector 3)
-//   x == PS      : d_end     += the end rows' slots [b][text_len[b] + 1]
-//   x == PS + 1+v: partial vector v of every workgroup of the chunk -> type rows (v = 0..2), linguistic table rows (4, 5), d_gamma (6), d_beta (7)
-__global__ __launch_bounds__(256) void embed_bwd_reduce_kernel(const float* __restrict__ scratch, const float* __restrict__ partials,
-                                                               const int32_t* __restrict__ text_len, float* __restrict__ d_pos,
-                                                               float* __restrict__ d_end, float* __restrict__ d_type,
-                                                               float* __restrict__ d_tab, float* __restrict__ d_gamma,
-                                                               float* __restrict__ d_beta, int B, int split, int PS, int H, int chunk) {
-  const int x = blockIdx.x, b0 = blockIdx.y * chunk, b1 = min(B, b0 + chunk);
-  float* dst = nullptr;
-  int v = -1;
-  if (x < PS) dst = d_pos + (long)x * H;
-  else if (x == PS) dst = d_end;
-  else {
-    v = x - PS - 1;
-    dst = v < 3 ? d_type + (long)v * H : (v == 4 || v == 5) ? (d_tab ? d_tab + (long)(v - 4) * H : nullptr) : v == 6 ? d_gamma : v == 7 ? d_beta : nullptr;
-  }
-  if (!dst) return;
-  for (int c = threadIdx.x * 4; c < H; c += blockDim.x * 4) {
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (v < 0) {
-      for (int bb = b0; bb < b1; bb += 8) {
-        float4 r[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int b = bb + u;
-          r[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (b < b1) {      // (block-uniform conditions)
-            const int tl = text_len[b];
-            const bool take = (x == PS) || (x < tl) || (x == tl + 1);
-            const int slot = (x == PS) ? tl + 1 : x;
-            if (take && slot < PS) r[u] = *(const float4*)(scratch + ((long)b * PS + slot) * H + c);
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { acc.x += r[u].x; acc.y += r[u].y; acc.z += r[u].z; acc.w += r[u].w; }
-      }
-      if (x < PS) {          // the objects of the samples whose text ends at x share position row x
-        for (int b = b0; b < b1; ++b) {
-          if (text_len[b] != x) continue;
-          for (int y = 0; y < split; ++y) {
-            const float4 r = *(const float4*)(partials + ((long)(b * split + y) * EMB_NPART + 3) * H + c);
-            acc.x += r.x; acc.y += r.y; acc.z += r.z; acc.w += r.w;
-          }
-        }
-      }
-    } else {
-      const int w0 = b0 * split, w1 = b1 * split;
-      for (int ww = w0; ww < w1; ww += 8) {
-        float4 r[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          r[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (ww + u < w1) r[u] = *(const float4*)(partials + ((long)(ww + u) * EMB_NPART + v) * H + c);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { acc.x += r[u].x; acc.y += r[u].y; acc.z += r[u].z; acc.w += r[u].w; }
-      }
-    }
-    if (acc.x != 0.f) atomicAdd(dst + c, acc.x);
-    if (acc.y != 0.f) atomicAdd(dst + c + 1, acc.y);
-    if (acc.z != 0.f) atomicAdd(dst + c + 2, acc.z);
-    if (acc.w != 0.f) atomicAdd(dst + c + 3, acc.w);
   }
 }
 
@@ -731,20 +661,13 @@ extern "C" int vlb_embed_fwd(const int32_t* code, const int32_t* text_len, const
   return VLB_OK;
 }
 
-// floats of scratch vlb_embed_bwd_ps wants for (B, T, H): the [B][T + 2][H] position slots + up to 8 workgroups' partial vectors per sample
-extern "C" long vlb_embed_bwd_scratch_floats(int B, int T, int H) {
-  int split = vlb_cdiv(512, B < 1 ? 1 : B);
-  if (split > 8) split = 8;
-  return (long)B * (T + 2) * H + (long)B * split * EMB_NPART * H;
-}
-
-static int embed_bwd_impl(const void* dy, const void* pre, const float* stats, const float* gamma, const int32_t* code,
-                          const int32_t* text_len, const int64_t* text_ids, const int64_t* text_type,
-                          const int64_t* obj_ling_idx, float* d_word, float* d_pos, float* d_type, float* d_end,
-                          float* d_gamma, float* d_beta, float* d_text_vis, long dtv_sb, long dtv_st, float* d_obj_vis,
-                          long dov_sb, long dov_sr, float* d_obj_ling, long dol_sb, long dol_sr, int B, int T, int R, int S,
-                          int H, int V, int P, float drop_p, const uint32_t* seed, uint32_t tag, int text_vis_zeroed,
-                          float* pos_scratch, long pos_scratch_floats, hipStream_t stream) {
+extern "C" int vlb_embed_bwd(const void* dy, const void* pre, const float* stats, const float* gamma, const int32_t* code,
+                             const int32_t* text_len, const int64_t* text_ids, const int64_t* text_type,
+                             const int64_t* obj_ling_idx, float* d_word, float* d_pos, float* d_type, float* d_end,
+                             float* d_gamma, float* d_beta, float* d_text_vis, long dtv_sb, long dtv_st, float* d_obj_vis,
+                             long dov_sb, long dov_sr, float* d_obj_ling, long dol_sb, long dol_sr, int B, int T, int R, int S,
+                             int H, int V, int P, float drop_p, const uint32_t* seed, uint32_t tag, int text_vis_zeroed,
+                             hipStream_t stream) {
   VLB_CHECK_ARG(H > 0 && (H % 4) == 0 && H <= 256 * EMB_MAX_IT, "vlb_embed_bwd: unsupported H=%d", H);
   VLB_CHECK_ARG(dy && pre && stats && gamma && code && text_len && text_ids && d_word && d_pos && d_type && d_end && d_gamma &&
                     d_beta, "vlb_embed_bwd: null input");
@@ -758,10 +681,6 @@ static int embed_bwd_impl(const void* dy, const void* pre, const float* stats, c
   p.d_obj_ling = d_obj_ling; p.dol_sb = dol_sb; p.dol_sr = dol_sr;
   p.B = B; p.T = T; p.R = R; p.S = S; p.H = H; p.V = V; p.P = P;
   p.drop_thr = vlb_drop_thr(drop_p); p.drop_scale = vlb_drop_scale(p.drop_thr); p.seed = seed; p.tag = tag;
-  // the scratch form needs one slot per (sample, position): positions are not clamped (P >= T + 2) and the scratch is large enough
-  p.PS = T + 2;
-  p.pos_scratch = nullptr;
-  p.partials = nullptr;
   VLB_CHECK_ARG((dtv_sb % 4) == 0 && (dtv_st % 4) == 0 && (dov_sb % 4) == 0 && (dov_sr % 4) == 0 && (dol_sb % 4) == 0 &&
                     (dol_sr % 4) == 0, "vlb_embed_bwd: output strides must be multiples of 4 floats");
   const int nit = vlb_cdiv(H, 256);
@@ -774,11 +693,6 @@ static int embed_bwd_impl(const void* dy, const void* pre, const float* stats, c
     if (split > S) split = S;
     if (split < 1) split = 1;
   }
-  if (pos_scratch && P >= T + 2 && ((uintptr_t)pos_scratch & 15) == 0 &&
-      pos_scratch_floats >= (long)B * (T + 2) * H + (long)B * split * EMB_NPART * H) {
-    p.pos_scratch = pos_scratch;
-    p.partials = pos_scratch + (long)B * (T + 2) * H;
-  }
 #define EMB_BWD(NIT)                                                                                                         \
   do {                                                                                                                       \
     constexpr int smem = (9 + 8) * NIT * 256 * (int)sizeof(float);                                                                 \
@@ -789,38 +703,7 @@ static int embed_bwd_impl(const void* dy, const void* pre, const float* stats, c
   if (nit <= 1) EMB_BWD(1); else if (nit == 2) EMB_BWD(2); else if (nit == 3) EMB_BWD(3); else if (nit == 4) EMB_BWD(4); else EMB_BWD(8);
 #undef EMB_BWD
   VLB_CHECK_LAUNCH("vlb_embed_bwd");
-  if (p.pos_scratch) {
-    const int chunk = 32, threads = ((H / 4 + 63) / 64 * 64) > 256 ? 256 : ((H / 4 + 63) / 64 * 64);
-    hipLaunchKernelGGL(embed_bwd_reduce_kernel, dim3(p.PS + 1 + EMB_NPART, vlb_cdiv(B, chunk)), dim3(threads), 0, stream, p.pos_scratch,
-                       p.partials, text_len, d_pos, d_end, d_type, (obj_ling_idx && d_obj_ling) ? d_obj_ling : (float*)nullptr, d_gamma,
-                       d_beta, B, split, p.PS, H, chunk);
-    VLB_CHECK_LAUNCH("vlb_embed_bwd(reduce)");
-  }
   return VLB_OK;
-}
-
-extern "C" int vlb_embed_bwd(const void* dy, const void* pre, const float* stats, const float* gamma, const int32_t* code,
-                             const int32_t* text_len, const int64_t* text_ids, const int64_t* text_type,
-                             const int64_t* obj_ling_idx, float* d_word, float* d_pos, float* d_type, float* d_end,
-                             float* d_gamma, float* d_beta, float* d_text_vis, long dtv_sb, long dtv_st, float* d_obj_vis,
-                             long dov_sb, long dov_sr, float* d_obj_ling, long dol_sb, long dol_sr, int B, int T, int R, int S,
-                             int H, int V, int P, float drop_p, const uint32_t* seed, uint32_t tag, int text_vis_zeroed,
-                             hipStream_t stream) {
-  return embed_bwd_impl(dy, pre, stats, gamma, code, text_len, text_ids, text_type, obj_ling_idx, d_word, d_pos, d_type, d_end, d_gamma,
-                        d_beta, d_text_vis, dtv_sb, dtv_st, d_obj_vis, dov_sb, dov_sr, d_obj_ling, dol_sb, dol_sr, B, T, R, S, H, V, P,
-                        drop_p, seed, tag, text_vis_zeroed, nullptr, 0, stream);
-}
-
-extern "C" int vlb_embed_bwd_ps(const void* dy, const void* pre, const float* stats, const float* gamma, const int32_t* code,
-                                const int32_t* text_len, const int64_t* text_ids, const int64_t* text_type,
-                                const int64_t* obj_ling_idx, float* d_word, float* d_pos, float* d_type, float* d_end,
-                                float* d_gamma, float* d_beta, float* d_text_vis, long dtv_sb, long dtv_st, float* d_obj_vis,
-                                long dov_sb, long dov_sr, float* d_obj_ling, long dol_sb, long dol_sr, int B, int T, int R, int S,
-                                int H, int V, int P, float drop_p, const uint32_t* seed, uint32_t tag, int text_vis_zeroed,
-                                float* pos_scratch, long pos_scratch_floats, hipStream_t stream) {
-  return embed_bwd_impl(dy, pre, stats, gamma, code, text_len, text_ids, text_type, obj_ling_idx, d_word, d_pos, d_type, d_end, d_gamma,
-                        d_beta, d_text_vis, dtv_sb, dtv_st, d_obj_vis, dov_sb, dov_sr, d_obj_ling, dol_sb, dol_sr, B, T, R, S, H, V, P,
-                        drop_p, seed, tag, text_vis_zeroed, pos_scratch, pos_scratch_floats, stream);
 }
 
 extern "C" int vlb_gather_rows(const void* src, const int32_t* idx, void* out, int n, int H, hipStream_t stream) {

@@ -373,8 +373,6 @@ class PretrainEngine:
         self.d_text_out, self.d_obj_out = zb(BT, H), zb(BR, H)
         self.d_mvrc_u = zb(BR, H)
         self.d_textvis, self.d_objvis = zf(Bt, H), zf(BR, H)
-        # embedding backward: slots / partial vectors of the batch-shared sums (ops.embed_bwd scratch form, VLB_EMBED_BWD_PS=1; default: atomics -- measured 320 vs 308 us, the word-embedding scatter is what costs)
-        self.emb_scratch = ops.embed_bwd_scratch(Bt, T, H, self.dev) if os.environ.get("VLB_EMBED_BWD_PS", "0") == "1" else None
         self.d_obj_reps = zf(BR, H)
         self.d_yds = zb(BR, H)
         self.d_afeat = zb(BR, VIS_DIM)
@@ -1011,7 +1009,7 @@ class PretrainEngine:
                       g32["vlbert.word_embeddings.weight"], g32["vlbert.position_embeddings.weight"],
                       g32["vlbert.token_type_embeddings.weight"], g32["vlbert.end_embedding.weight"], g32[pe + "weight"],
                       g32[pe + "bias"], self.d_tv_n, (T * H, H), self.d_objvis, (R * H, H), self.d_ol, (R * H, H), Bt, T, R, S, H,
-                      drop_p=p_h, seed=seed, tag=TAG_EMBED, scratch=self.emb_scratch)
+                      drop_p=p_h, seed=seed, tag=TAG_EMBED)
         # gradients of the two inputs (padded positions: zero rows, as the reference's masked scatter gives)
         ops.layernorm_bwd(self.d_tv_n, self.tv_in, self.st_tv, w32["vlbert.visual_ln_text.weight"], dx=self.d_tv_in,
                           dgamma=g32["vlbert.visual_ln_text.weight"], dbeta=g32["vlbert.visual_ln_text.bias"], workspace=self.ln_ws)
@@ -1035,7 +1033,7 @@ class PretrainEngine:
                       g32["vlbert.token_type_embeddings.weight"], g32["vlbert.end_embedding.weight"], g32[pe + "weight"],
                       g32[pe + "bias"], self.d_textvis, (H, 0), self.d_objvis, (R * H, H),
                       self.P.view(self.P.grad, "object_linguistic_embeddings.weight", (2, H), span=2), (0, 0), Bt, T, R, S, H,
-                      drop_p=p_h, seed=seed, tag=TAG_EMBED, text_vis_zeroed=True, scratch=self.emb_scratch)
+                      drop_p=p_h, seed=seed, tag=TAG_EMBED, text_vis_zeroed=True)
         if on_layer_done:      # the tied word-embedding gradient (decoder wgrad + this scatter-add) is complete: its 94 MB go out first
             on_layer_done("word_emb")
         ops.layernorm_bwd(self.d_objvis, self.obj_reps, self.st_objvis, w32["vlbert.visual_ln_object.weight"],

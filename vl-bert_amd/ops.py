@@ -338,27 +338,17 @@ def embed_fwd(lay, text_ids, text_type, word_emb, pos_emb, type_emb, end_emb, te
     return out
 
 
-def embed_bwd_scratch(B, T, H, device):
-    """fp32 scratch for embed_bwd(..., scratch=): position slots + per-workgroup partial vectors (vlb_embed_bwd_scratch_floats)."""
-    return torch.empty(int(_lib.load().vlb_embed_bwd_scratch_floats(B, T, H)), dtype=torch.float32, device=device)
-
-
 def embed_bwd(dy, pre, stats, gamma, lay, text_ids, text_type, obj_ling_idx, d_word, d_pos, d_type, d_end, d_gamma, d_beta,
               d_text_vis, dtv_strides, d_obj_vis, dov_strides, d_obj_ling, dol_strides, B, T, R, S, H, drop_p=0.0, seed=None,
-              tag=0, text_vis_zeroed=False, scratch=None):
-    """scratch (embed_bwd_scratch): the batch-shared destinations are column-summed over the batch in a second launch instead of
-    being hit by every workgroup's atomics (vlb_embed_bwd_ps); None: the one-launch atomic form."""
-    head = (_p(dy, BF16), _p(pre, BF16), _p(stats, torch.float32), _p(gamma, torch.float32), _p(lay["code"]),
-            _p(lay["text_len"]), _p(text_ids, torch.int64), _p(text_type, torch.int64), _p(obj_ling_idx, torch.int64),
-            _p(d_word, torch.float32), _p(d_pos, torch.float32), _p(d_type, torch.float32), _p(d_end, torch.float32),
-            _p(d_gamma, torch.float32), _p(d_beta, torch.float32),
-            _p(d_text_vis, torch.float32), dtv_strides[0], dtv_strides[1], _p(d_obj_vis, torch.float32), dov_strides[0],
-            dov_strides[1], _p(d_obj_ling, torch.float32), dol_strides[0], dol_strides[1],
-            B, T, R, S, H, d_word.shape[0], d_pos.shape[0], float(drop_p), _p(seed), int(tag), int(bool(text_vis_zeroed)))
-    if scratch is None:
-        _lib.call("vlb_embed_bwd", *head, _stream())
-    else:
-        _lib.call("vlb_embed_bwd_ps", *head, _p(scratch, torch.float32), scratch.numel(), _stream())
+              tag=0, text_vis_zeroed=False):
+    _lib.call("vlb_embed_bwd", _p(dy, BF16), _p(pre, BF16), _p(stats, torch.float32), _p(gamma, torch.float32), _p(lay["code"]),
+              _p(lay["text_len"]), _p(text_ids, torch.int64), _p(text_type, torch.int64), _p(obj_ling_idx, torch.int64),
+              _p(d_word, torch.float32), _p(d_pos, torch.float32), _p(d_type, torch.float32), _p(d_end, torch.float32),
+              _p(d_gamma, torch.float32), _p(d_beta, torch.float32),
+              _p(d_text_vis, torch.float32), dtv_strides[0], dtv_strides[1], _p(d_obj_vis, torch.float32), dov_strides[0],
+              dov_strides[1], _p(d_obj_ling, torch.float32), dol_strides[0], dol_strides[1],
+              B, T, R, S, H, d_word.shape[0], d_pos.shape[0], float(drop_p), _p(seed), int(tag), int(bool(text_vis_zeroed)),
+              _stream())
 
 
 def gather_rows(src, idx, out):
