@@ -80,15 +80,6 @@ int vlb_gemm_nt_bf16_splitk(const void* A, long lda, const void* B, long ldb, vo
  * vlb_layernorm_fwd: 1 / 2 / 4, 0 = by size), "ln_bwd4" (vlb_layernorm_bwd: 0 8-column kernel, 1 4-column, 2 two rows in flight). */
 int vlb_gemm_set_option(const char* name, int value);
 
-/* Stream-K form of vlb_gemm_nt_bf16 (selected inside that call; option "nt_sk": 0 off -- the DEFAULT: bit-checked but measured
- * 0.87-1.07x (hybrid) / 0.6-0.7x (pure) the whole-tile kernels at these sizes, csrc/gemm.hip --, 1 auto, 2 every covered shape with
- * the hybrid decomposition (whole tiles data-parallel, the remainder round cut by K), 3 the same with pure stream-K; auto =
- * N <= 1024, K >= 1536, 1024 <= M <= 8192: the long-K, few-tile launches of a 32-64-sample per-GPU batch -- nn.Linear at
- * external/pytorch_pretrained_bert/modeling.py:375 and the data gradients of :362 / :291-300).  The K loop of the launch is cut into
- * equal shares per CU; a tile's finisher adds the partial tiles its predecessors published through a library-owned slab.  A finisher
- * never waits unboundedly: this returns how many gave up since the library was loaded (0 = every hand-off completed; -1 on a
- * runtime error).  Synchronises the device. */
-long vlb_gemm_sk_timeouts(void);
 
 
 /* Weight-gradient form: C[M,N] (fp32) += A[M,K] B[N,K]^T for few output tiles and a very long K (K = padded

@@ -54,8 +54,7 @@ def test_ctypes_signatures_match_header():
     for name in protos:
         assert name in lib._SIGS or name in ("vlb_last_error", "vlb_version", "vlb_act_dtype", "vlb_device_info", "vlb_wgrad_workspace_floats",
                                             "vlb_layernorm_bwd_workspace_floats", "vlb_layernorm_bwd_slabs", "vlb_gemm_set_option",
-                                                "vlb_roi_align_gather_workspace_bytes", "vlb_nonfinite_status", "vlb_wgrad_tn_table_desc_bytes",
-                                                "vlb_gemm_sk_timeouts"), name
+                                                "vlb_roi_align_gather_workspace_bytes", "vlb_nonfinite_status", "vlb_wgrad_tn_table_desc_bytes"), name
 
 
 def test_library_loads_and_exports_every_symbol():

@@ -470,72 +470,3 @@ def test_traffic_stamp_hash_is_the_same_function_in_bench_and_profile_report():
     ns = {"os": os, "__file__": os.path.join(root, "tools", "profile_report.py")}
     exec(compile(ast.Module(body=[fn], type_ignores=[]), "profile_report.py", "exec"), ns)
     assert ns["gemm_sources_sha"]() == bench.gemm_sources_sha() and len(bench.gemm_sources_sha()) == 12
-
-
-def _sk_decomposition(ntx, ntk, P, two_per_cu=True, pure=False):
-    """The work decomposition of gemm_nt_sk_kernel (csrc/gemm.hip) for ONE XCD, restated in Python line by line from the kernel's index
-    arithmetic (dpr / half / sk_base / share_begin / seg_next / r_last): -> ({(tile, k): block}, {publisher block: tile}, {owner block:
-    (tile, [blocks it waits for])}).  Kept in step by hand; the GPU tests check the kernel itself, this checks the PLAN."""
-    Ph = P >> 1
-    dpr = 0 if pure else ntx // P
-    remt = ntx - dpr * P
-    half = two_per_cu and (not pure) and Ph > 0 and remt >= Ph
-    sk_base = dpr * P + (Ph if half else 0)
-    Ps = (P - Ph) if half else P
-    U = (ntx - sk_base) * ntk
-    sb = lambda r: (U * r) // Ps
-    cover, published, waits = {}, {}, {}
-    for rx in range(P):
-        ndp = dpr + (1 if (half and rx < Ph) else 0)
-        rs = rx - Ph if half else rx
-        ub, ue = (sb(rs), sb(rs + 1)) if (rs >= 0 and U > 0) else (0, 0)
-        segs = [((j * P + rx) if j < dpr else dpr * P + rx, 0, ntk) for j in range(ndp)]      # whole tiles first
-        u = ub
-        while u < ue:                                                                          # then the share, in unit order
-            tl = u // ntk
-            k0 = u - tl * ntk
-            k1 = min(ntk, k0 + (ue - u))
-            segs.append((sk_base + tl, k0, k1))
-            u += k1 - k0
-        for t, k0, k1 in segs:
-            assert 0 <= t < ntx
-            for k in range(k0, k1):
-                assert (t, k) not in cover, ("covered twice", t, k)
-                cover[(t, k)] = rx
-            if k0 != 0:
-                assert rx not in published, "a block publishes at most one partial"
-                published[rx] = t
-            elif k1 != ntk:
-                v = (t - sk_base + 1) * ntk - 1
-                r_last = (v * Ps) // U
-                while r_last + 1 < Ps and sb(r_last + 1) <= v:
-                    r_last += 1
-                while r_last > 0 and sb(r_last) > v:
-                    r_last -= 1
-                boff = Ph if half else 0
-                waits[rx] = (t, [c + boff for c in range(rs + 1, r_last + 1) if sb(c) < sb(c + 1)])
-    return cover, published, waits
-
-
-def test_stream_k_decomposition_covers_every_k_tile_once_and_pairs_every_partial_with_one_owner():
-    """Plan of the stream-K GEMM (round 5): for every (tiles per XCD, K tiles, blocks per XCD, hybrid | pure, one | two blocks per CU)
-    each K tile of each tile is computed exactly once; every block that publishes a partial is waited for by exactly ONE owner, which
-    owns the same tile; owners wait only for blocks with higher indices (contributors never wait: no cycle); at the headline's small-M
-    shapes the hybrid keeps 32 of 39 (M = 3232) and 64 of 77 (M = 6464) tiles per XCD whole."""
-    for P in (64, 32, 8, 2):
-        for two in (True, False):
-            for pure in (False, True):
-                for ntx in list(range(1, 70)) + [77, 100, 129, 257]:
-                    for ntk in (1, 2, 12, 36, 48):
-                        cover, published, waits = _sk_decomposition(ntx, ntk, P, two, pure)
-                        assert len(cover) == ntx * ntk, (ntx, ntk, P, two, pure)
-                        consumed = {}
-                        for owner, (t, ws) in waits.items():
-                            for c in ws:
-                                assert c > owner and published.get(c) == t and c not in consumed, (owner, c, t)
-                                consumed[c] = owner
-                        assert set(consumed) == set(published)
-    for ntx, whole in ((39, 32), (77, 64)):
-        cover, published, _ = _sk_decomposition(ntx, 48, 64)
-        split = {t for t in published.values()}
-        assert ntx - len(split) >= whole, (ntx, len(split))

@@ -104,35 +104,3 @@ def test_no_instruction_touches_an_lds_read_still_in_flight():
             assert not v, (src, name, v[:3])
             total += 1
     assert total >= 100
-
-
-def test_stream_k_handoff_instruction_sequence():
-    """gemm_nt_sk_kernel's in-launch hand-off (csrc/gemm.hip, round 5) as the guide's recipe prescribes it -- pinned in the ISA because the
-    failure modes are silent (stale slab reads under load, MI355X_MICROARCH.md "inter-workgroup visibility"): the partial tile is
-    published with WRITE-THROUGH 16-B stores (`buffer_store_dwordx4 ... sc1`), every storing wave drains them (`s_waitcnt vmcnt(0)`)
-    in front of the barrier, ONE flag store follows (`global_store_dword ... sc1`); the owner polls that word with relaxed agent-scope
-    loads (`sc1`) and a sleep, then ONE `buffer_inv sc1`; no `buffer_wbl2` walk over the L2 anywhere; no spill, and the K loop holds no
-    full drain and no scratch access."""
-    ks = L.kernels(L.compile_isa(os.path.join(CSRC, "gemm.hip")))
-    sk = {n: k for n, k in ks.items() if "gemm_nt_sk_kernel" in n}
-    assert len(sk) == 8, sorted(sk)                     # two tile configurations x four epilogues
-    for name, k in sk.items():
-        body = [l.strip() for l in k["body"]]
-        if "ILin1E" not in name:                        # (the run-time dispatched epilogue is allowed its register pressure)
-            assert k["spill"] == 0, name
-        lo, hi = L.mfma_region(k["body"])
-        inner = L.region_counts(k["body"], lo, hi)
-        assert inner["scratch"] == 0 and inner["vmcnt0"] == 0, (name, inner)
-        stores = [i for i, l in enumerate(body) if l.startswith("buffer_store_dwordx4") and l.endswith("sc1")]
-        assert len(stores) == 8, (name, len(stores))    # FM x FN = 8 accumulator fragments per lane
-        tail = body[stores[-1] + 1:stores[-1] + 40]
-        drain = next(i for i, l in enumerate(tail) if l.startswith("s_waitcnt") and "vmcnt(0)" in l)
-        barrier = next(i for i, l in enumerate(tail) if l.startswith("s_barrier"))
-        flag = next(i for i, l in enumerate(tail) if l.startswith("global_store_dword ") and l.endswith("sc1"))
-        assert drain < barrier < flag, (name, drain, barrier, flag)
-        polls = [i for i, l in enumerate(body) if l.startswith("global_load_dword ") and l.endswith("sc1")]
-        sleeps = [i for i, l in enumerate(body) if l.startswith("s_sleep")]
-        inv = [i for i, l in enumerate(body) if l.startswith("buffer_inv") and l.endswith("sc1")]
-        # (basic blocks are not laid out in execution order: presence and the wait glued to the invalidate are what can be pinned)
-        assert polls and sleeps and len(inv) == 1 and "vmcnt(0)" in body[inv[0] - 1], (name, len(polls), len(sleeps), inv)
-        assert not any(l.startswith("buffer_wbl2") for l in body), name

@@ -189,77 +189,6 @@ def test_gemm_ring_kernel_epilogues(ops, force_p8, ring, M, N, K):
         force_p8.gemm_set_option("nt_ring", 1)
 
 
-# (M, N, K): the shapes the auto rule claims (FFN2 forward / FFN1, QKV data gradients of 32- and 64-sample per-GPU batches), edge
-# tiles with N % 8 != 0, a launch with FEWER units than workgroups (empty shares; K = 64: whole tiles only, no hand-off at all), and
-# two tiles x 16 K tiles on 256 workgroups: every unit its own workgroup, 15 partial slabs per finisher
-@pytest.mark.parametrize("M,N,K", [(3232, 768, 3072), (6464, 768, 2304), (1000, 520, 512), (1300, 776, 3072), (130, 96, 64),
-                                   (200, 128, 1024), (12928, 768, 3072)])
-@pytest.mark.parametrize("mode", [2, 3], ids=["hybrid", "pure"])
-def test_gemm_stream_k_epilogues(ops, force_p8, M, N, K, mode):
-    """`gemm_nt_sk_kernel` (gemm.hip, round 5): the 128x128 ring kernel with the launch's K loop cut into equal shares per CU
-    (stream-K) -- a tile's finisher adds the partial tiles earlier workgroups published through the library's slabs (agent-scope
-    release / acquire hand-off) and runs the fused epilogue.  Every epilogue it instantiates (0 bias, 3 dropout + residual, 4 bias +
-    residual; the generic LayerNorm-residual form is in test_gemm_layernorm_residual_fp16_stream[stream-k]) against the fp32
-    statement; the other epilogues of the battery fall through to the kernels they ran on before.  Two runs give identical bits
-    (fixed summation order), and no finisher ever timed out.  mode 2 = the hybrid decomposition (whole tiles data-parallel, the
-    remainder round cut by K), 3 = pure stream-K (every K tile of the launch in equal shares)."""
-    force_p8.gemm_set_option("p8_mode", 0)
-    force_p8.gemm_set_option("nt_sk", mode)
-    try:
-        _epilogue_battery(ops, "stream-K[%d] %dx%dx%d " % (mode, M, N, K), M, N, K)
-        A, B = to_gpu_bf16(rnd(M, K, seed=31)), to_gpu_bf16(rnd(N, K, seed=32, scale=0.08))
-        bias = (0.3 * torch.randn(N, generator=torch.Generator().manual_seed(33))).to(dev())
-        ldc = (N + 63) // 64 * 64
-        outs = []
-        for _ in range(3):
-            C = torch.zeros((M, ldc), dtype=torch.bfloat16, device=dev())[:, :N]
-            ops.gemm_nt(A, B, C, bias=bias)
-            outs.append(C.clone())
-        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
-        # against the ring kernel on the same operands: same products, another summation order -> within one bf16 rounding
-        force_p8.gemm_set_option("nt_sk", 0)
-        Cr = torch.zeros((M, ldc), dtype=torch.bfloat16, device=dev())[:, :N]
-        ops.gemm_nt(A, B, Cr, bias=bias)
-        report("stream-K vs ring %dx%dx%d" % (M, N, K), outs[0], Cr.float(), 1e-3, 8e-3)
-        assert force_p8.gemm_sk_timeouts() == 0
-    finally:
-        force_p8.gemm_set_option("nt_sk", 0)
-
-
-def test_gemm_stream_k_handoff_under_uneven_load(ops, force_p8):
-    """The hand-off with the chip busy and lopsided: a second stream keeps streaming kernels in flight (HBM-bound fills and a large
-    GEMM of another shape) while 40 stream-K launches run back to back on the main stream, every output checked word for word against
-    the result of the idle chip -- stale slab reads (a missing release / acquire) show up as wrong words only under load
-    (MI355X_MICROARCH.md "test every hand-off under UNEVEN load")."""
-    force_p8.gemm_set_option("p8_mode", 0)
-    force_p8.gemm_set_option("nt_sk", 2)
-    try:
-        M, N, K = 3232, 768, 3072
-        A, B = to_gpu_bf16(rnd(M, K, seed=41)), to_gpu_bf16(rnd(N, K, seed=42, scale=0.08))
-        res = to_gpu_bf16(rnd(M, N, seed=43))
-        C0 = torch.zeros((M, N), dtype=torch.bfloat16, device=dev())
-        ops.gemm_nt(A, B, C0, res=res)
-        torch.cuda.synchronize()
-        side = torch.cuda.Stream()
-        big = torch.empty(256 << 20, dtype=torch.float32, device=dev())
-        X = torch.randn(4096, 4096, device=dev(), dtype=torch.bfloat16)
-        outs = [torch.zeros_like(C0) for _ in range(40)]
-        with torch.cuda.stream(side):
-            for i in range(30):
-                big.fill_(float(i))
-                X2 = X @ X
-        scratch = torch.zeros((1500, N), dtype=torch.bfloat16, device=dev())
-        for C in outs:                         # between launches another K / shape goes through the same slabs (stale lines to trip over)
-            ops.gemm_nt(A, B, C, res=res)
-            ops.gemm_nt(A[:1500, :1536], B[:, :1536], scratch)
-        torch.cuda.synchronize()
-        bad = [i for i, C in enumerate(outs) if not torch.equal(C, C0)]
-        assert not bad, "stream-K outputs differ from the idle-chip result in launches %s" % bad[:10]
-        assert force_p8.gemm_sk_timeouts() == 0
-    finally:
-        force_p8.gemm_set_option("nt_sk", 0)
-
-
 def _epilogue_battery(ops, tag, M, N, K, vision=False):
     A, B = rnd(M, K, seed=4), rnd(N, K, seed=5, scale=0.08)
     bias = 0.3 * torch.randn(N, generator=torch.Generator().manual_seed(6))
@@ -312,7 +241,7 @@ def _epilogue_battery(ops, tag, M, N, K, vision=False):
 
 
 @pytest.mark.parametrize("core", ["128x128", "p8-192", "p8-256", "p8-320", "p8-192-midstream", "p8-256-midstream", "p8-320-midstream",
-                                  "ring-128x128", "ring-128x64", "stream-k"])
+                                  "ring-128x128", "ring-128x64"])
 def test_gemm_layernorm_residual_fp16_stream(ops, force_p8, core):
     """vlb_gemm_nt_bf16_ex: residual = LayerNorm output re-materialised in fp32 from fp16 pre-LN rows + (mean, rstd) + gamma / beta,
     result stored as fp16 (the encoder's residual stream, BertSelfOutput / BertOutput); with and without dropout; and the LayerNorm
@@ -323,13 +252,10 @@ def test_gemm_layernorm_residual_fp16_stream(ops, force_p8, core):
         lib.gemm_set_option("p8_wgs", 8)
     lib.gemm_set_option("p8_mode", {"128x128": 0, "p8-192": 3, "p8-256": 4, "p8-320": 5}.get(core, 0))
     lib.gemm_set_option("nt_ring", {"ring-128x128": 2, "ring-128x64": 3}.get(core, 0))
-    lib.gemm_set_option("nt_sk", 2 if core == "stream-k" else 0)
     try:
         _ln_residual_checks(ops, core)
-        assert lib.gemm_sk_timeouts() == 0
     finally:
         lib.gemm_set_option("nt_ring", 1)
-        lib.gemm_set_option("nt_sk", 0)
 
 
 def _ln_residual_checks(ops, core):

@@ -20,8 +20,6 @@
 #   dp2              bench.py --gpus 2 on this box (2 ranks sharing the GPU over gloo; over RCCL where the box has 2 GPUs)
 #   trace            rocprofv3 --kernel-trace --stats of the headline workload -> kernel table (tools/kstats.py)
 #   profiles[:tag]   tools/make_profiles.sh (kernel stats, SQ PMC, FETCH / WRITE passes; summaries in gpurun_out/summary)
-#   sk               stream-K GEMM: its parity tests, tools/sk_bench.py (whole-tile launcher vs stream-K vs the ring variants at per-GPU
-#                    batches 32 / 64 / 128), and the batch-32 / 64 step with VLB_GEMM_SK=0 / 1
 #   mirror[:n]       tools/dp2_mirror_check.py n times (default 12) + 3 times with the pre-round-5 address-ordered norm (--address-order):
 #                    the replica-divergence root cause of round 4's red GPU test
 set -u
@@ -77,9 +75,6 @@ for what in "$@"; do
     trace)    ( cd /tmp && export TMPDIR=/tmp && VLB_WGRAD_STREAM=0 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/tr -o r -- python $ROOT/bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-phase-times --no-clock-probe > $OUT/tr.log 2>&1 )
               python tools/kstats.py $OUT/tr 5 24 | tee $OUT/kstats.txt; rm -rf $OUT/tr ;;
     profiles*) t="${what#profiles}"; t="${t#:}"; VLB_COMMIT=$(cat $ROOT/.commit_stamp 2>/dev/null || echo unknown) timeout 2000 bash tools/make_profiles.sh "${t:-r05}" small; ls $ROOT/gpurun_out/summary ;;
-    sk)       ( time timeout 600 python -m pytest tests -m gpu -q -x -k "stream_k or (layernorm_residual_fp16_stream and stream)" 2>&1 | tail -12 ) > $OUT/tests_sk.log 2>&1; tail -5 $OUT/tests_sk.log
-              timeout 400 python tools/sk_bench.py 32 64 128 2>&1 | grep -v amdgpu.ids | tee $OUT/sk_bench.txt
-              for b in 32 64; do for sk in 0 1; do VLB_GEMM_SK=$sk timeout 300 python bench.py --no-cpu-baseline --global-batch $b --no-phase-times --no-clock-probe 2>/dev/null | line "batch $b sk=$sk"; done; done | tee $OUT/small_sk.txt ;;
     mirror*)  n="${what#mirror}"; n="${n#:}"; n="${n:-12}"
               run_mirror() { tag=$1; shift
                 timeout 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port $((29600 + RANDOM % 300)) tools/dp2_mirror_check.py "$@" > $OUT/mirror_$tag.log 2>&1

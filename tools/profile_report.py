@@ -36,7 +36,7 @@ def family(n):
         return "gemm_nt_p8_kernel"            # large-tile 8-phase NT core (gemm_p8.hip): every epilogue / tile height
     if "gemm_tn8" in n:
         return "gemm_tn8_kernel"              # large-tile TN core (weight gradients, grouped per layer)
-    if "gemm_nt_bf16" in n or "gemm_nt_256" in n or "gemm_nt_ring" in n or "gemm_nt_sk" in n:
+    if "gemm_nt_bf16" in n or "gemm_nt_256" in n or "gemm_nt_ring" in n:
         return "gemm_nt_bf16_kernel"          # (incl. the 256x256-tile instantiation used by the decoder)
     if "gemm_tn_bf16" in n:
         return "gemm_tn_bf16_kernel"
@@ -123,7 +123,7 @@ def family_e2e(n):
         return "gemm_nt_p8_kernel"
     if "gemm_tn8" in n:
         return "gemm_tn8_kernel"
-    if "gemm_nt_bf16" in n or "gemm_nt_256" in n or "gemm_nt_ring" in n or "gemm_nt_sk" in n:
+    if "gemm_nt_bf16" in n or "gemm_nt_256" in n or "gemm_nt_ring" in n:
         return "gemm_nt_bf16_kernel<..,CONV>" if conv else "gemm_nt_bf16_kernel"
     if "gemm_tn_bf16" in n:
         return "gemm_tn_bf16_kernel<..,CONV>" if conv else "gemm_tn_bf16_kernel"

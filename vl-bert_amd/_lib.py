@@ -154,8 +154,6 @@ def load():
     lib.vlb_wgrad_tn_table_desc_bytes.argtypes = []
     lib.vlb_gemm_set_option.restype = _I
     lib.vlb_gemm_set_option.argtypes = [ctypes.c_char_p, _I]
-    lib.vlb_gemm_sk_timeouts.restype = _L
-    lib.vlb_gemm_sk_timeouts.argtypes = []
     lib.vlb_nonfinite_status.restype = _I
     lib.vlb_nonfinite_status.argtypes = [_I]
     lib.vlb_roi_align_gather_workspace_bytes.restype = _L
@@ -190,8 +188,7 @@ def act_torch_dtype():
 def exported_names():
     return ["vlb_last_error", "vlb_version", "vlb_act_dtype", "vlb_device_info", "vlb_wgrad_workspace_floats",
             "vlb_layernorm_bwd_workspace_floats", "vlb_layernorm_bwd_slabs", "vlb_gemm_set_option",
-            "vlb_roi_align_gather_workspace_bytes", "vlb_nonfinite_status", "vlb_wgrad_tn_table_desc_bytes",
-            "vlb_gemm_sk_timeouts"] + sorted(_SIGS)
+            "vlb_roi_align_gather_workspace_bytes", "vlb_nonfinite_status", "vlb_wgrad_tn_table_desc_bytes"] + sorted(_SIGS)
 
 
 def nonfinite_status(reset=True):
@@ -202,15 +199,6 @@ def nonfinite_status(reset=True):
     if v < 0:
         raise RuntimeError("vlb_nonfinite_status: %s" % lib.vlb_last_error().decode())
     return v
-
-
-def gemm_sk_timeouts():
-    """Stream-K GEMM hand-offs that timed out since the library was loaded (vlb_gemm_sk_timeouts; must be 0).  Synchronises."""
-    lib = load()
-    v = lib.vlb_gemm_sk_timeouts()
-    if v < 0:
-        raise RuntimeError("vlb_gemm_sk_timeouts: runtime error")
-    return int(v)
 
 
 def gemm_set_option(name, value):

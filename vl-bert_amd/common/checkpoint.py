@@ -165,15 +165,17 @@ def load_optimizer_state_dict(eng, osd):
     idx = [i for g in osd["param_groups"] for i in g["params"]]
     if len(idx) != len(order):
         raise ValueError("optimizer state has %d parameters, the engine's table %d%s" %
-                         (len(idx), len(order), " (e2e: the reference indexes the frozen image-branch tensors too; is IMAGE_NUM_LAYERS the "
-                                                "same?)" if eng.vision is not None else ""))
+                         (len(idx), len(order), " (e2e: the reference indexes the frozen image-branch tensors too; is IMAGE_NUM_LAYERS the same?  A run with "
+                                                "NETWORK.IMAGE_SEMANTIC or NETWORK.ENABLE_CNN_REG_LOSS has object_embed / regularizing_predictor tensors "
+                                                "this engine does not model: every later index shifts)" if eng.vision is not None else ""))
     m, v = eng.P.named(eng.P.m), eng.P.named(eng.P.v)
     steps = set()
     visn = eng._vision_names() if eng.vision is not None else ()
     frozen = set(own) - set(shapes)
     for i, n in zip(idx, order):
         if n in frozen:           # (e2e) frozen image-branch tensor: the engine keeps no moments for it; a reference file has no state either
-            if osd["state"].get(i) is not None and float(torch.as_tensor(osd["state"][i]["exp_avg"]).abs().sum()) != 0.0:
+            st_f = osd["state"].get(i)
+            if st_f is not None and any(float(torch.as_tensor(st_f[k]).abs().sum()) != 0.0 for k in ("exp_avg", "exp_avg_sq") if k in st_f):
                 raise ValueError("optimizer state holds moments for %s, which this engine keeps frozen (IMAGE_FROZEN_BACKBONE_STAGES / "
                                  "IMAGE_FROZEN_BN differ from the run that wrote the file)" % n)
             continue

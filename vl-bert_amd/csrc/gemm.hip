@@ -23,7 +23,6 @@
 #include <math.h>
 #include <stdlib.h>
 
-#include <mutex>
 #include <type_traits>
 
 #include "vlb_common.h"
@@ -629,331 +628,6 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_nt_ring_kernel(const G
   }
 }
 
-// ------------------------------------------------------------------------------------
-// STREAM-K form of the ring kernel (round 5; an OPTION, off by default -- see "MEASURED" below): the ring kernel's tiles and K loop
-// (128x64 tiles on four waves, 3-stage ring, TWO blocks per CU by default; 128x128 on eight waves, one block per CU, as the other
-// instantiation), with the K tiles of a launch's REMAINDER round -- or, in the pure form, of the whole launch -- cut into EQUAL
-// SHARES per block instead of whole tiles per block.
-//
-// Why it was built: the strong-scaling columns of the headline metric run 32-128 samples per GPU.  At M = 3232 the N = 768 GEMMs
-// with a long K (FFN2 forward, FFN1 / QKV data gradients: K = 3072 / 2304) are 312 tiles of 128x64 for 512 block slots: the 56 CUs
-// that hold two tiles set the launch time (25-34 us for 11-15 GFLOP, 450 TFLOP/s; profiles/r04_kernel_stats_batch32.txt), 48
-// launches per step.  Cut by K, every block gets the same number of K tiles.
-//
-// Decomposition (XCD-local; the kernel body has the details): block b runs on XCD b % 8 (MI355X_MICROARCH.md, observed placement --
-// a SPEED assumption only).  Each XCD owns a contiguous run of whole tiles (the grouped tile order of the kernels above).  HYBRID
-// (default): its blocks first take whole tiles, data-parallel, for as many full rounds as there are (+ a half round), all starting
-// at k = 0 together; only the tiles of the remaining partial round are cut into "units" (one K tile of one tile) and shared out
-// equally.  PURE (option nt_sk = 3): every tile is cut.  Inside its share a block walks [the tail of a tile an earlier block began]
-// [whole tiles] [the head of a tile later blocks complete].  The block that computes a tile's FIRST K tile owns it: it adds the
-// partial accumulators the later blocks of that tile published (at most a few; all on its own XCD) and runs the fused epilogue.  The
-// order matters: a later block works on the owner's tile at the START of its share and publishes at once, the owner reaches that
-// tile at the END of its own -- the partials are waiting when it gets there.  (The other way round -- the block that reaches the
-// tile's end finishes it -- makes block r wait at its start for the end of block r-1: a serial chain over the XCD's blocks,
-// measured 10x slower on the first GPU run of this kernel.)  Every block publishes at most ONE partial (the first segment of its
-// share), into its own fp32 slab (32 KiB for a 128x64 tile), lane-linear: 16 B per lane and fragment, coalesced both ways.
-//
-// Hand-off (cdna_hip_programming.md Guideline 16 / "in-launch split-K reduction", MI355X_MICROARCH.md "inter-workgroup
-// visibility"): WRITE-THROUGH (sc1) 16-B slab stores, so no release fence -> every storing wave s_waitcnt vmcnt(0) -> barrier ->
-// ONE lane's relaxed agent-scope flag store.  Owner: one lane polls the flags RELAXED with a sleep (bounded), ONE agent-scope
-// ACQUIRE fence, barrier, plain 16-B loads; then it clears the flags it consumed (each flag has exactly one consumer), so the flags
-// are all zero again when the launch ends: no per-launch host state, hipGraph replay safe.  Correct for any block -> XCD placement
-// (tests/test_isa_cpu.py pins the instruction sequence, tests/test_ops_gpu.py the results under uneven load).  Contributors never
-// wait for anybody; an owner may wait for blocks with HIGHER indices, so the grid never exceeds what is resident at once (one
-// 128-KiB or two 72-KiB blocks per CU: every block of the launch is resident, or becomes resident as soon as another kernel's
-// blocks leave), every spin is bounded, and two stream-K launches are never left to run concurrently (launcher, sk_order_*).
-// Summation order is fixed (the owner's own segment, then the contributors in block order): deterministic.
-//
-// MEASURED (MI355X, gpurun_out/r5c .. r5f, tools/sk_bench.py; us per launch: whole-tile launcher | PURE stream-K | HYBRID):
-//                         M = 3232 (32 samples)       M = 6464 (64)              M = 12928 (128)
-//   FFN2 fwd   K = 3072   34.9 | 49.3 | 33.6          58.0 | 92.3 | 61.9         68.8 | 183.7 | 100.5
-//   FFN1 dgrad K = 3072   31.4 | 46.0 | 29.3          51.8 | 87.8 | 55.1         66.5 | 180.7 |  92.4
-//   QKV dgrad  K = 2304   24.6 | 33.3 | 25.8          40.6 | 59.5 | 46.7         51.7 | 130.5 |  74.2
-//   attn-out   K =  768   14.5 | 21.5 | 23.8          25.3 | 30.8 | 36.5         (hand-off cost > the K loop: never)
-// Bit-checked against the fp32 statement on every epilogue, deterministic, no hand-off ever timed out -- and not faster: the
-// hybrid is 0.94-1.07x at 32 samples, 0.87-0.94x at 64, the pure form 0.6-0.7x; whole step at 32 samples 5.45 (off) vs 5.51 ms.
-// Why, in the order the measurements taught it:
-//  1. PURE stream-K loses the L2.  In the whole-tile kernels the ~64 blocks an XCD runs at a time sit on neighbouring tiles at
-//     the SAME K offset, so an operand slab comes from HBM / the memory-side cache once and is shared through the XCD's 4 MB L2;
-//     with equal unit shares block r starts at unit r * U / P -- every co-resident block at a DIFFERENT K offset, nothing shared in
-//     time.  Measured (rocprofv3 --pmc FETCH_SIZE, tools/sk_traffic.py -> profiles/r05_sk_traffic.txt), HBM reads per launch at
-//     K = 3072: M = 3232: whole tiles 78 MB | hybrid 106 MB | pure 242 MB;  M = 6464: 138 | 167 | 504 MB (5.6 TB/s over its 90 us:
-//     the pure form is HBM-bound).  (Operands are 24.6 / 44.4 MB; with eight private L2s the whole-tile floor is W once per XCD +
-//     A once = 57.6 / 77.5 MB.)  (The first version also made the block that reaches a tile's END its finisher: block r then waits
-//     at its start for the end of block r - 1, a serial chain -- 10x slower.)
-//  2. The HYBRID keeps whole tiles in step (they must also come FIRST in every block: a continuation segment in front of them
-//     staggers the K offsets by up to 5 us of streaming and the L2 has turned over before a neighbour reuses a slab: 57.5 -> 55.1
-//     us), so only the remainder round is cut by K.  It then matches the whole-tile kernels but cannot beat them: under full load a
-//     128x64x64 unit takes 0.73 us per block (two blocks per CU: 66 GB/s of operands per CU, ~17 TB/s over the chip -- the
-//     L2 -> LDS path is the bound, not the MFMA pipe and not the balance), while the lopsided TAIL of the whole-tile launch -- 56
-//     or 100 second tiles on a nearly idle chip -- runs at 0.33 us per unit.  Perfect balance saves ~8 us of that tail and the
-//     hand-off costs ~8 us (32 KiB write-through publish, flag, one acquire, 3-4 slab reads per owner).
-//  3. What would pay at these sizes is fewer operand bytes per FLOP, i.e. 256x128 tiles (half the L2 traffic) on the 8-phase
-//     schedule of gemm_p8.hip, K cut in 3 to fill the chip, with this file's hand-off -- a new large-tile core, not built.
-// Kept as an OPTION (VLB_GEMM_SK=1 auto / option "nt_sk": 2 hybrid, 3 pure), OFF by default.
-// ------------------------------------------------------------------------------------
-constexpr int SK_SLAB_BYTES = 128 * 128 * 4;      // workspace per CU: one 128x128 partial tile, or two 128x64 ones (two blocks per CU)
-typedef unsigned int sk_v4u __attribute__((ext_vector_type(4)));
-constexpr int SK_ERR_INDEX = 1024;                // flags[0 .. grid) hand-off flags (grid <= 1024), flags[SK_ERR_INDEX] = timed-out hand-offs
-constexpr unsigned SK_SPIN_LIMIT = 1u << 20;     // polls (~0.5-1 us each with the sleep) before a finisher gives up and flags an error
-
-// <BN, WGM, WGN, NS>: <128, 2, 4, 4> = 8 waves, 128 KiB of LDS, one block per CU | <64, 2, 2, 3> = 4 waves, 72 KiB, TWO blocks per CU
-// (the launcher's default: the 8-wave form runs its K tile in lockstep -- wait, barrier, fragment reads, MFMAs -- at 1.16 us per
-// 128x128x64 unit on the first measurement, 5x the MFMA time; two independent 4-wave blocks per CU cover each other's latency, which
-// is also why the whole-tile launcher prefers the 128x64 ring at these sizes)
-template <int BN, int WGM, int WGN, int NS, int EPI>
-__global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_nt_sk_kernel(const GemmParams p, float* __restrict__ slabs, unsigned* __restrict__ flags,
-                                                                       const int pure_sk) {
-  constexpr int BM = 128;
-  constexpr bool TWO_PER_CU = NS * (BM + BN) * 128 <= 81920;      // two blocks of this configuration fit a CU's 160 KiB of LDS
-  constexpr int SK_SLAB_FLOATS = BM * BN;
-  constexpr int BK = 64;
-  constexpr int NT = 64 * WGM * WGN;
-  constexpr int WM = BM / WGM, WN = BN / WGN;
-  constexpr int FM = WM / 16, FN = WN / 16;
-  constexpr int NA = BM * 8 / NT, NB = BN * 8 / NT;
-  constexpr int NL = NA + NB;
-  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WGN, wn = wave % WGN;
-  const int nt = p.ntm * p.ntn;
-  const int ntk = p.K / BK;
-  // ---- this block's work: XCD x owns tiles [t_lo, t_lo + ntx) of the grouped order; its P blocks take ---------------------------
-  //   (1) WHOLE tiles, data-parallel, as long as there are full rounds of them: tile j * P + rx for j < dpr = ntx / P -- and, when the
-  //       remainder is at least half a round (>= P / 2 tiles: one per CU with two blocks per CU), one more whole tile for the first
-  //       P / 2 blocks ("half round").  Whole tiles of co-resident blocks sit at the SAME K offset, so operand slabs are shared
-  //       through the XCD's L2 (the locality the pure stream-K form of this kernel lost: header, "MEASURED");
-  //   (2) an equal share of the K tiles ("units") of the REMAINING tiles, stream-K: over all P blocks, or over the second P / 2 blocks
-  //       when the first half took a half-round tile (a CU then carries one whole tile + one share either way).
-  //   Order inside a block: the whole tiles FIRST (all blocks of the XCD then run them in step from k = 0: a continuation segment
-  //   of 0-9 units in front of them staggered the blocks' K offsets by up to 5 us of streaming and the 4 MB L2 had turned over
-  //   before a neighbour reused a slab -- measured: 57.5 vs 51.3 us at M = 6464), then the share in unit order: the continuation
-  //   segment (published at once), whole remainder tiles, the owner segment last (its partials were published one segment earlier).
-  const int P = (int)gridDim.x >> 3;                       // blocks per XCD (gridDim.x is a multiple of 8)
-  const int Ph = P >> 1;
-  const int xcd = (int)blockIdx.x & 7, rx = (int)blockIdx.x >> 3;
-  const int q = nt >> 3, rem8 = nt & 7;
-  const int t_lo = xcd < rem8 ? xcd * (q + 1) : rem8 * (q + 1) + (xcd - rem8) * q;
-  const int ntx = q + (xcd < rem8 ? 1 : 0);
-  // (pure_sk: measurement switch, option nt_sk = 3 -- no whole tiles, every K tile of the launch in the equal shares)
-  const int dpr = pure_sk ? 0 : ntx / P;                   // full data-parallel rounds
-  const int remt = ntx - dpr * P;                          // tiles left after them
-  const bool half = TWO_PER_CU && !pure_sk && Ph > 0 && remt >= Ph;
-  const int ndp = dpr + ((half && rx < Ph) ? 1 : 0);       // whole tiles of this block
-  const int sk_base = dpr * P + (half ? Ph : 0);           // first stream-K tile (position in this XCD's run)
-  const int sk_tiles = ntx - sk_base;
-  const int Ps = half ? (P - Ph) : P;                      // blocks that share the stream-K units
-  const int rs = half ? rx - Ph : rx;                      // this block's index among them (< 0: takes no share)
-  const int U = sk_tiles * ntk;
-  auto share_begin = [&](int r) { return (int)(((long)U * r) / Ps); };   // first unit of stream-K block r (r = Ps: one past the end)
-  const int ub = (rs >= 0 && U > 0) ? share_begin(rs) : 0, ue = (rs >= 0 && U > 0) ? share_begin(rs + 1) : 0;
-  if (ndp == 0 && ub >= ue) return;                        // nothing to do; nobody waits for this block
-  auto tile_origin = [&](int t, int& m0, int& n0) {        // grouped order, as in gemm_nt_bf16_kernel (t = position in the order)
-    const int gm = p.tile_group, per_group = gm * p.ntn, gid = t / per_group, first = gid * gm;
-    const int gsz = min(p.ntm - first, gm), r2 = t - gid * per_group;
-    m0 = (first + r2 % gsz) * BM;
-    n0 = (r2 / gsz) * BN;
-  };
-  // segment enumerator: (tile position in the XCD's run, K tiles [k0, k1)); the producer and the consumer each walk it with a cursor
-  struct Cur { int phase, j, u; };
-  auto seg_next = [&](Cur& c, int& t, int& k0, int& k1) -> bool {
-    for (;;) {
-      if (c.phase == 0) {                                  // whole tiles first: every block of the XCD starts them together, at k = 0
-        if (c.j < ndp) {
-          t = (c.j < dpr) ? c.j * P + rx : dpr * P + rx;
-          k0 = 0; k1 = ntk;
-          ++c.j;
-          return true;
-        }
-        c.phase = 1;
-        c.u = ub;
-      } else if (c.phase == 1) {                           // then the stream-K share, in unit order (a continuation segment comes first)
-        if (c.u < ue) {
-          const int tl = c.u / ntk;
-          t = sk_base + tl; k0 = c.u - tl * ntk; k1 = min(ntk, k0 + (ue - c.u));
-          c.u += k1 - k0;
-          return true;
-        }
-        c.phase = 2;
-      } else {
-        return false;
-      }
-    }
-  };
-  // ---- producer: walks the segments in order, NS - 1 stages ahead of the consumer ----------------------------------------------
-  const bf16_t* a_src[NA];
-  const bf16_t* b_src[NB];
-  Cur pc = {0, 0, 0};
-  int kt_p = 0, kend_p = 0, issued = 0, slot_p = 0;
-  bool more_p = true;
-  auto setup = [&]() {                                     // next segment of the producer (more_p = false: none left)
-    int t, k0, k1;
-    more_p = seg_next(pc, t, k0, k1);
-    if (!more_p) return;
-    kt_p = k0; kend_p = k1;
-    int m0, n0;
-    tile_origin(t_lo + t, m0, n0);
-#pragma unroll
-    for (int it = 0; it < NA; ++it) {
-      const int Pc = it * NT + tid, r = Pc >> 3, kc = (Pc & 7) ^ ((r >> 1) & 7);
-      a_src[it] = p.A + (long)min(m0 + r, p.M - 1) * p.lda + kc * 8 + (long)k0 * BK;
-    }
-#pragma unroll
-    for (int it = 0; it < NB; ++it) {
-      const int Pc = it * NT + tid, r = Pc >> 3, kc = (Pc & 7) ^ ((r >> 1) & 7);
-      b_src[it] = p.B + (long)min(n0 + r, p.N - 1) * p.ldb + kc * 8 + (long)k0 * BK;
-    }
-  };
-  auto produce = [&]() {
-    if (!more_p) return;
-    char* sa = smem + slot_p * STAGE;
-    char* sb = sa + A_BYTES;
-#pragma unroll
-    for (int it = 0; it < NA; ++it) {
-      __builtin_amdgcn_global_load_lds(GLDS_PTR(a_src[it]), LDS_PTR(sa + (it * NT + wave * 64) * 16), 16, 0, 0);
-      a_src[it] += BK;
-    }
-#pragma unroll
-    for (int it = 0; it < NB; ++it) {
-      __builtin_amdgcn_global_load_lds(GLDS_PTR(b_src[it]), LDS_PTR(sb + (it * NT + wave * 64) * 16), 16, 0, 0);
-      b_src[it] += BK;
-    }
-    ++issued;
-    slot_p = (slot_p + 1 == NS) ? 0 : slot_p + 1;
-    if (++kt_p == kend_p) setup();                         // next segment of this block
-  };
-
-  f32x4 acc[FM][FN];
-  const int frow = lane & 15;
-  const int c0 = (((lane >> 4) ^ (frow >> 1)) << 4);
-  const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(smem);
-  const uint32_t a_rel = (uint32_t)((wm * WM + frow) * 128 + c0);
-  const uint32_t b_rel = (uint32_t)(A_BYTES + (wn * WN + frow) * 128 + c0);
-
-  setup();
-#pragma unroll
-  for (int s_ = 0; s_ < NS - 1; ++s_) produce();
-  int g = 0, slot_c = 0;
-  Cur cc = {0, 0, 0};
-  int tseg, k0, k1;
-  while (seg_next(cc, tseg, k0, k1)) {
-    const int tl = tseg - sk_base;                         // (stream-K segments: the tile's index among the stream-K tiles)
-    int m0, n0;
-    tile_origin(t_lo + tseg, m0, n0);
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-      for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int kt = k0; kt < k1; ++kt) {
-      const int ahead = issued - g - 1;
-      if (NS >= 4 && ahead >= 3) ring_wait_vm<3 * NL>();
-      else if (NS >= 3 && ahead == 2) ring_wait_vm<2 * NL>();
-      else if (ahead == 1) ring_wait_vm<NL>();
-      else ring_wait_vm<0>();
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      produce();
-      const uint32_t so = lds0 + (uint32_t)(slot_c * STAGE);
-      const uint32_t va0 = so + a_rel, vb0 = so + b_rel, va1 = so + (a_rel ^ 64u), vb1 = so + (b_rel ^ 64u);
-      bf16x8 af[2][FM], bfr[2][FN];
-      vlb_static_for<0, FN>([&](auto j_c) { constexpr int j = decltype(j_c)::value; ring_lds_read<j * 2048>(bfr[0][j], vb0); });
-      vlb_static_for<0, FM>([&](auto i_c) { constexpr int i = decltype(i_c)::value; ring_lds_read<i * 2048>(af[0][i], va0); });
-      vlb_static_for<0, FN>([&](auto j_c) { constexpr int j = decltype(j_c)::value; ring_lds_read<j * 2048>(bfr[1][j], vb1); });
-      vlb_static_for<0, FM>([&](auto i_c) { constexpr int i = decltype(i_c)::value; ring_lds_read<i * 2048>(af[1][i], va1); });
-      __builtin_amdgcn_s_waitcnt(0xC07F | ((FM + FN) << 8));
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j)
-          acc[i][j] = VLB_MFMA_16x16x32(bfr[0][j], af[0][i], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_waitcnt(0xC07F);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j)
-          acc[i][j] = VLB_MFMA_16x16x32(bfr[1][j], af[1][i], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      ++g;
-      slot_c = (slot_c + 1 == NS) ? 0 : slot_c + 1;
-    }
-    const bool starts = (k0 == 0), ends = (k1 == ntk);
-    if (!starts) {
-      // ---- this block's FIRST segment continues a tile an earlier block owns: publish the partial accumulators right away (the
-      //      owner reaches its own part of that tile at the END of its share, so it finds them waiting; see the header) -----------
-      // write-through (sc1) 16-B stores: the payload is at the coherence point when the stores retire, so no release fence (no
-      // buffer_wbl2 walk over the XCD's dirty L2 lines: 3.0 vs 8.2 us per 64 KiB publish, MI355X_MICROARCH.md "publish-large")
-      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(slabs + (long)blockIdx.x * SK_SLAB_FLOATS), 0, 0x7FFFFFFF, 0x00020000);
-#pragma unroll
-      for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j)
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(sk_v4u, acc[i][j]), rs, ((i * FN + j) * NT + tid) * 16, 0, 16);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // EVERY storing wave drains its stores ...
-      __syncthreads();                                       // ... before ONE lane raises the flag
-      if (tid == 0) __hip_atomic_store(flags + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      if (!ends) {
-        // ---- owner of a tile whose K loop later blocks complete: blocks rx+1 .. r_last of this XCD each publish one partial -------
-        const int v = (tl + 1) * ntk - 1;                  // last unit of the tile (stream-K unit space)
-        int r_last = (int)(((long)v * Ps) / U);
-        while (r_last + 1 < Ps && share_begin(r_last + 1) <= v) ++r_last;
-        while (r_last > 0 && share_begin(r_last) > v) --r_last;
-        const int boff = half ? Ph : 0;                    // stream-K block index -> block index inside the XCD
-        if (tid == 0) {
-          for (int c = rs + 1; c <= r_last; ++c) {
-            if (share_begin(c) >= share_begin(c + 1)) continue;      // (an empty share publishes nothing)
-            unsigned* f = flags + ((c + boff) * 8 + xcd);
-            unsigned spins = 0;
-            while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-              __builtin_amdgcn_s_sleep(2);
-              if (++spins > SK_SPIN_LIMIT) {               // never hang the chip: record the failure, take what is there
-                atomicAdd(flags + SK_ERR_INDEX, 1u);
-                break;
-              }
-            }
-          }
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        __syncthreads();
-        for (int c = rs + 1; c <= r_last; ++c) {
-          if (share_begin(c) >= share_begin(c + 1)) continue;
-          const float* slab = slabs + (long)((c + boff) * 8 + xcd) * SK_SLAB_FLOATS;
-#pragma unroll
-          for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int j = 0; j < FN; ++j) {
-              const f32x4 t4 = *(const f32x4*)(slab + ((i * FN + j) * NT + tid) * 4);
-              acc[i][j] += t4;
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                   // every lane has read every slab: the flags may be cleared
-        if (tid == 0)
-          for (int c = rs + 1; c <= r_last; ++c)
-            if (share_begin(c) < share_begin(c + 1))
-              __hip_atomic_store(flags + ((c + boff) * 8 + xcd), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      const int last = (slot_c == 0) ? NS - 1 : slot_c - 1;
-      const int mb = m0 + wm * WM + (lane & 15), nb = n0 + wn * WN + 4 * (lane >> 4);
-      const EpiStage st = {smem + last * STAGE, m0, n0, wm * WM + (lane & 15), wn * WN + 4 * (lane >> 4), tid, NT, BN};
-      if (m0 + BM <= p.M && n0 + BN <= p.N) {
-        __syncthreads();
-        gemm_epilogue_select<EPI, true, FM, FN>(p, acc, mb, nb, st);
-      } else {
-        gemm_epilogue_select<EPI, false, FM, FN>(p, acc, mb, nb, st);
-      }
-    }
-    __builtin_amdgcn_s_waitcnt(0x0F70);                    // one full drain per segment, where the compiler can see it (ring kernel note)
-  }
-}
 
 // ------------------------------------------------------------------------------------
 // NT GEMM with 256x256 tiles for the plain (bias-only, bf16-out) GEMMs with many output tiles: the tied decoder
@@ -1652,151 +1326,6 @@ static int gemm_ring_try(GemmParams& p, int splits, bool want_narrow, hipStream_
   return launch_ring_epi<128, 128, 2, 4, 4>(p, stream);
 }
 
-// ---- stream-K launcher (gemm_nt_sk_kernel) ------------------------------------------------------------------------------------
-// Workspace: one 64-KiB fp32 slab + one flag per block, owned by the library (the C ABI of vlb_gemm_nt_bf16 has no scratch
-// argument and the slabs never leave the launch).  Launches on ONE stream are ordered, so they share a workspace; up to SK_STREAMS
-// streams get their own (all allocated on the first use, which is never inside a stream capture: a call that would have to
-// allocate while its stream is capturing is simply not taken and runs on the ring kernel).
-static int g_nt_sk = -1;          // VLB_GEMM_SK: 0 off | 1 auto | 2 every shape the kernel covers | 3 the same, PURE stream-K (no whole tiles: the measured-slower form)
-static int g_sk_min_k = -1, g_sk_max_m = -1;
-void vlb_nt_set_sk(int v) { g_nt_sk = v; }
-constexpr int SK_STREAMS = 4;
-static struct { hipStream_t stream; float* slabs; unsigned* flags; } g_sk_ws[SK_STREAMS];
-static int g_sk_used = 0, g_sk_grid = 0;
-static bool g_sk_ready = false, g_sk_failed = false;
-static std::mutex g_sk_mutex;
-
-static int sk_workspace(hipStream_t stream, float** slabs, unsigned** flags) {      // 0: ok | 1: not available (caller falls back)
-  std::lock_guard<std::mutex> lock(g_sk_mutex);
-  if (g_sk_failed) return 1;
-  if (!g_sk_ready) {
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return 1; }
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) {
-      g_sk_failed = true;
-      return 1;
-    }
-    g_sk_grid = cus / 8 * 8;                 // CUs used (a multiple of 8: equal blocks per XCD); <= 512
-    if (2 * g_sk_grid > SK_ERR_INDEX) { g_sk_failed = true; return 1; }
-    const size_t slab_bytes = (size_t)g_sk_grid * SK_SLAB_BYTES, flag_bytes = (size_t)(SK_ERR_INDEX + 8) * sizeof(unsigned);
-    for (int i = 0; i < SK_STREAMS; ++i) {
-      if (hipMalloc((void**)&g_sk_ws[i].slabs, slab_bytes) != hipSuccess || hipMalloc((void**)&g_sk_ws[i].flags, flag_bytes) != hipSuccess ||
-          hipMemset(g_sk_ws[i].flags, 0, flag_bytes) != hipSuccess) {
-        (void)hipGetLastError();
-        g_sk_failed = true;
-        return 1;
-      }
-    }
-    if (hipDeviceSynchronize() != hipSuccess) { g_sk_failed = true; return 1; }
-    g_sk_ready = true;
-  }
-  for (int i = 0; i < g_sk_used; ++i)
-    if (g_sk_ws[i].stream == stream) { *slabs = g_sk_ws[i].slabs; *flags = g_sk_ws[i].flags; return 0; }
-  if (g_sk_used == SK_STREAMS) return 1;
-  g_sk_ws[g_sk_used].stream = stream;
-  *slabs = g_sk_ws[g_sk_used].slabs;
-  *flags = g_sk_ws[g_sk_used].flags;
-  ++g_sk_used;
-  return 0;
-}
-
-// finishers that gave up waiting for a partial since the library was loaded (0 = every hand-off completed); synchronises the device
-extern "C" long vlb_gemm_sk_timeouts(void) {
-  std::lock_guard<std::mutex> lock(g_sk_mutex);
-  if (!g_sk_ready) return 0;
-  if (hipDeviceSynchronize() != hipSuccess) return -1;
-  long total = 0;
-  for (int i = 0; i < SK_STREAMS; ++i) {
-    unsigned v = 0;
-    if (hipMemcpy(&v, g_sk_ws[i].flags + SK_ERR_INDEX, sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    total += v;
-  }
-  return total;
-}
-
-template <int BN, int WGM, int WGN, int NS, int EPI>
-static int launch_sk_cfg(GemmParams& p, float* slabs, unsigned* flags, hipStream_t stream) {
-  constexpr int smem = NS * (128 + BN) * 128;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_nt_sk_kernel<BN, WGM, WGN, NS, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr_set = true;
-  }
-  static const int group = env_int("VLB_GEMM_TILE_GROUP", 4);
-  p.ntm = vlb_cdiv(p.M, 128);
-  p.ntn = vlb_cdiv(p.N, BN);
-  p.tile_group = group < 1 ? 1 : group;
-  const int grid = g_sk_grid * (163840 / smem);      // one block per CU (128 KiB of LDS) or two (72 KiB): every block resident
-  hipLaunchKernelGGL((gemm_nt_sk_kernel<BN, WGM, WGN, NS, EPI>), dim3(grid), dim3(64 * WGM * WGN), smem, stream, p, slabs, flags,
-                     g_nt_sk == 3 ? 1 : 0);
-  VLB_CHECK_LAUNCH("vlb_gemm_nt_bf16(stream-K)");
-  return VLB_OK;
-}
-
-template <int EPI>
-static int launch_sk_tile(GemmParams& p, float* slabs, unsigned* flags, hipStream_t stream) {
-  static const int tile = env_int("VLB_GEMM_SK_TILE", 64);      // 64: 128x64 tiles, two 4-wave blocks per CU (default) | 128: 128x128, one 8-wave block
-  if (tile == 128) return launch_sk_cfg<128, 2, 4, 4, EPI>(p, slabs, flags, stream);
-  return launch_sk_cfg<64, 2, 2, 3, EPI>(p, slabs, flags, stream);
-}
-
-// Two stream-K launches must not run CONCURRENTLY: each wants every CU (one 128-KiB-LDS block per CU) and its tile owners wait for
-// blocks that may not be resident yet -- two such kernels interleaved on the chip could starve each other until the spin bound.
-// Launches on one stream are ordered anyway (the engine issues its NT GEMMs on one stream).  When a second stream shows up, its
-// launches are ordered behind the other stream's last stream-K launch with an event (outside stream capture; a capturing stream is
-// left alone: a captured step is replayed instead of, not beside, the eager one).
-static hipStream_t g_sk_last_stream = nullptr;
-static hipEvent_t g_sk_event = nullptr;
-static bool g_sk_have_last = false;
-
-static void sk_order_before(hipStream_t stream, bool capturing) {
-  std::lock_guard<std::mutex> lock(g_sk_mutex);
-  if (capturing || !g_sk_have_last || g_sk_last_stream == stream) return;
-  if (g_sk_event == nullptr) {      // first hand-over between streams: no event was being recorded yet -> one host-side join
-    if (hipEventCreateWithFlags(&g_sk_event, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); g_sk_event = nullptr; }
-    (void)hipStreamSynchronize(g_sk_last_stream);
-    return;
-  }
-  (void)hipStreamWaitEvent(stream, g_sk_event, 0);
-}
-
-static void sk_order_after(hipStream_t stream, bool capturing) {
-  std::lock_guard<std::mutex> lock(g_sk_mutex);
-  if (capturing) return;
-  if (g_sk_event != nullptr) (void)hipEventRecord(g_sk_event, stream);      // (only once a second stream has been seen)
-  g_sk_last_stream = stream;
-  g_sk_have_last = true;
-}
-
-// > 0: not taken
-static int gemm_sk_try(GemmParams& p, int splits, hipStream_t stream) {
-  if (g_nt_sk < 0) g_nt_sk = env_int("VLB_GEMM_SK", 0);
-  if (!g_nt_sk || splits != 1 || p.c_split_stride != 0 || p.k_per_split < p.K || p.out_f32 != 0) return 1;
-  if (g_sk_min_k < 0) { g_sk_min_k = env_int("VLB_GEMM_SK_MIN_K", 1536); g_sk_max_m = env_int("VLB_GEMM_SK_MAX_M", 8192); }
-  // auto: the launches whose whole-tile decomposition leaves most of the chip idle or lopsided and whose K loop is long enough
-  // to carry the ~4 us of a partial hand-off: N <= 1024 (6-8 column tiles), K >= 1536, 1024 <= M <= 8192 -- FFN2 forward and
-  // the FFN1 / QKV data gradients of a 32-64-sample per-GPU batch.  (Thresholds: VLB_GEMM_SK_MIN_K / VLB_GEMM_SK_MAX_M.)
-  if (g_nt_sk == 1 && !(p.N <= 1024 && p.K >= g_sk_min_k && p.M >= 1024 && p.M <= g_sk_max_m)) return 1;
-  const int ec = epi_class(p);
-  if (ec != 0 && ec != 3 && ec != 4 && ec != -1) return 1;
-  float* slabs = nullptr;
-  unsigned* flags = nullptr;
-  if (sk_workspace(stream, &slabs, &flags)) return 1;
-  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(stream, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
-  const bool capturing = cs != hipStreamCaptureStatusNone;
-  sk_order_before(stream, capturing);
-  int rc;
-  switch (ec) {
-    case 0: rc = launch_sk_tile<0>(p, slabs, flags, stream); break;
-    case 3: rc = launch_sk_tile<3>(p, slabs, flags, stream); break;
-    case 4: rc = launch_sk_tile<4>(p, slabs, flags, stream); break;
-    default: rc = launch_sk_tile<-1>(p, slabs, flags, stream); break;
-  }
-  sk_order_after(stream, capturing);
-  return rc;
-}
 
 template <int BM, int BN>
 static int launch_gemm(GemmParams& p, int splits, hipStream_t stream) {
@@ -1861,10 +1390,6 @@ static int gemm_nt_impl(const void* A, long lda, const void* B, long ldb, void* 
   p.k_per_split = per * 64;
   // large-tile 8-phase core (gemm_p8.hip): bf16 outputs with the fused epilogues of the training step, enough tiles to give
   // every CU a 256-row tile
-  if (splits == 1 && out_mode == 0) {      // stream-K first: its auto rule only claims launches the large-tile core cannot fill
-    const int took = gemm_sk_try(p, splits, stream);
-    if (took <= 0) return took;
-  }
   if (splits == 1 && out_mode == 0) {
     const int took = vlb_gemm_p8_try(p, stream);
     if (took != 0) return took < 0 ? took : VLB_OK;

@@ -876,10 +876,6 @@ extern "C" int vlb_gemm_set_option(const char* name, int value) {
     vlb_nt_set_stagger(value);
     return VLB_OK;
   }
-  if (!strcmp(name, "nt_sk")) {            // stream-K form of the 128x128 ring kernel: 0 off | 1 auto | 2 every shape it covers
-    vlb_nt_set_sk(value);
-    return VLB_OK;
-  }
   if (!strcmp(name, "tn8_wgs")) {
     vlb_tn8_set_wgs(value);
     return VLB_OK;

@@ -52,7 +52,6 @@ int vlb_gemm_tn8_group(int n, const void* const* A, const long* lda, const void*
                        long workspace_floats, int accumulate, int* slices, long* ws_off, hipStream_t stream);
 void vlb_nt_set_stagger(int v);
 void vlb_nt_set_ring(int v);
-void vlb_nt_set_sk(int v);
 void vlb_tn8_set_mode(int v);
 void vlb_tn8_set_wgs(int v);
 void vlb_tn8_set_uneven(int v);

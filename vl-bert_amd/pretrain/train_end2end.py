@@ -114,7 +114,7 @@ def parse_args(argv=None):
     ap = argparse.ArgumentParser("Train VL-BERT on the MI355X engine")
     ap.add_argument("--cfg", type=str, help="path to a reference-style config file (cfgs/pretrain/*.yaml)")
     ap.add_argument("--model-dir", type=str, help="root of the checkpoint directory (pretrain/train_end2end.py:21,39-40): epoch files "
-                    "`<model-dir>/<OUTPUT_PATH>/<cfg name>/<MODEL_PREFIX>-<epoch:04d>.model` in the reference's format are written every "
+                    "`<model-dir>/<OUTPUT_PATH>/<cfg name>/<image set>_train/<MODEL_PREFIX>-<epoch:04d>.model` in the reference's format are written every "
                     "CHECKPOINT_FREQUENT epochs (an epoch = --steps-per-epoch optimizer steps) and TRAIN.RESUME / TRAIN.AUTO_RESUME are "
                     "honoured (vl-bert_amd/common/checkpoint.py).  Without it nothing is written")
     ap.add_argument("--log-dir", type=str, help="accepted for command-line compatibility")
