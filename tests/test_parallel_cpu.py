@@ -537,3 +537,31 @@ def test_bench_ladder_falls_back_together(case):
         assert got[0]["res"] == {"dp_mode": "sharded", "graph": False, "wire": None}
     if case == "rung1_and_2":
         assert got[0]["res"] == {"dp_mode": "allreduce", "graph": False, "wire": "fp32"}
+
+
+def test_bench_ladder_rungs_follow_the_command_line():
+    """dp_rungs: --dp-mode allreduce starts at the all-reduce rungs, --no-graph drops the graph rungs; the last rung is always the plainest
+    program (bucketed all-reduce, eager, fp32 on the wire)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("vlb_bench2", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    names = lambda mode, graph: [n for n, _ in bench.dp_rungs(mode, graph)]
+    assert names("default", True) == ["sharded + segmented hipGraph", "sharded, eager", "all-reduce, eager, fp32 wire"]
+    assert names("sharded", False) == ["sharded, eager", "all-reduce, eager, fp32 wire"]
+    assert names("allreduce", True) == ["all-reduce + segmented hipGraph", "all-reduce, eager, fp32 wire"]
+    assert names("allreduce", False) == ["all-reduce, eager, fp32 wire"]
+    last = bench.dp_rungs("default", True)[-1][1]
+    assert last == {"dp_mode": "allreduce", "graph": False, "wire": "fp32"}
+    # a single process: run_ladder without an agreement function returns the first rung whose attempt does not raise
+    calls = []
+
+    def attempt(spec):
+        calls.append(spec["dp_mode"])
+        if spec["graph"]:
+            raise RuntimeError("capture refused")
+        return spec["dp_mode"]
+    name, res, given_up = bench.run_ladder(bench.dp_rungs("default", True), attempt)
+    assert (name, res) == ("sharded, eager", "sharded") and [f["rung"] for f in given_up] == ["sharded + segmented hipGraph"]
+    assert "capture refused" in given_up[0]["reason"] and calls == ["sharded", "sharded"]
