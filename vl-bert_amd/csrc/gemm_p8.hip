@@ -544,13 +544,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(const GemmParams p) 
 #else
   const int rowB = (tid >> 3) * ldbB + kcb, maxB = (p.N - 1) * ldbB + kcb;
 #endif
-  int w_p = blockIdx.x, kt_p = 0, tiles_issued = 0, pm0 = 0, pn0 = 0;
-  bool live = true;
+  int w_p = blockIdx.x, kt_p = 0, pm0 = 0, pn0 = 0;
   auto setup = [&](int w) { tile_of(w, pm0, pn0); };
   // half-image WHICH (0 A0 | 1 A1 | 2 B0 | 3 B1) of the producer's current K tile -> buffer `buf`
   auto stage = [&](auto which_c, auto buf_c) {
     constexpr int WHICH = decltype(which_c)::value, B_ = decltype(buf_c)::value;
-    if (!live) return;
+    // The producer never stops (round 6): past the end of its work it re-stages the last K tile of its last output tile into the slots
+    // the schedule frees anyway.  No branch in the load segment of a phase and none around the counted waits -- through round 5 a
+    // `live` flag put one in front of every stage() and a two-way wait into phase 4 (the vendor's K loop has no branch at all:
+    // profiles/r06_tn8_vs_vendor.txt); the one epilogue that lays its slab over the ring retires the surplus loads first.
     const int koff = kt_p * 128;
     if constexpr (WHICH < 2) {
       char* dst = smem + B_ * BUF + (WHICH == 0 ? OFF_A0 : OFF_A1);
@@ -575,14 +577,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(const GemmParams p) 
     }
   };
   auto advance = [&]() {     // the producer moves on to the next K tile (called in front of its first half-image)
-    if (!live) return;
     if (++kt_p == nk) {
-      kt_p = 0;
-      w_p += gridDim.x;
-      if (w_p < nt) setup(w_p);
-      else live = false;
+      if (w_p + (int)gridDim.x < nt) {
+        kt_p = 0;
+        w_p += gridDim.x;
+        setup(w_p);
+      } else {
+        kt_p = nk - 1;      // out of work: stay on the last K tile
+      }
     }
-    if (live) ++tiles_issued;
   };
   // staging order of the four half-images of a K tile: the first is always A0 (read first, free first)
   constexpr int ORD1 = KEEPB ? 2 : 3, ORD2 = KEEPB ? 3 : 1, ORD3 = KEEPB ? 1 : 2;   // KEEPB: A0 B0 B1 A1 | else: A0 B1 A1 B0
@@ -654,12 +657,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(const GemmParams p) 
 
   // ---------------- prologue: K tile 0 complete, the first two half-images of K tile 1 in flight ----------------
   setup(w_p);
-  tiles_issued = 1;
   stage(W0{}, I0{}); stage(W1{}, I0{}); stage(W2{}, I0{}); stage(W3{}, I0{});
   advance();
   stage(W0{}, I1{}); stage(W1{}, I1{});
-  if (live) __builtin_amdgcn_s_waitcnt(0x0F70 | VM_AHEAD);
-  else __builtin_amdgcn_s_waitcnt(0x0F70);
+  __builtin_amdgcn_s_waitcnt(0x0F70 | VM_AHEAD);
   p8_barrier();
   if (wm == 1) p8_barrier();       // the wm = 1 waves run one segment behind
 
@@ -698,8 +699,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(const GemmParams p) 
       // phase 4: (B0 again) -> (1,0); K tile g+1 retired
       if constexpr (!KEEPB) read_b(I0{}, I0{}, bfr);
       stage(W1{}, I0{});
-      if (tiles_issued >= g + 3) __builtin_amdgcn_s_waitcnt(0x0F70 | VM_AHEAD);
-      else __builtin_amdgcn_s_waitcnt(0x0F70);
+      __builtin_amdgcn_s_waitcnt(0x0F70 | VM_AHEAD);
       p8_barrier();
       if constexpr (KEEPB) compute(I1{}, I0{}, bkeep); else compute(I1{}, I0{}, bfr);
       p8_barrier();
@@ -724,8 +724,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(const GemmParams p) 
       p8_barrier();
       if constexpr (!KEEPB) read_b(I1{}, I0{}, bfr);
       stage(W1{}, I1{});
-      if (tiles_issued >= g + 4) __builtin_amdgcn_s_waitcnt(0x0F70 | VM_AHEAD);
-      else __builtin_amdgcn_s_waitcnt(0x0F70);
+      __builtin_amdgcn_s_waitcnt(0x0F70 | VM_AHEAD);
       p8_barrier();
       if constexpr (KEEPB) compute(I1{}, I0{}, bkeep); else compute(I1{}, I0{}, bfr);
       p8_barrier();
@@ -753,8 +752,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(const GemmParams p) 
       else p8_drain_w<FMH, EPI, true>(p, acc, lds0 + STG, m0, n0, wm, wn, tid, seed);
 #endif
     } else if (w + (int)gridDim.x >= nt) {
-      // last tile of this workgroup: nothing is in flight into the operand ring any more (the producer stopped at this tile and
-      // every K tile it issued has been consumed) -> drain through a 128-row slab laid over the ring
+      // last tile of this workgroup: every K tile the consumer needs has been consumed -> drain through a 128-row slab laid over the ring
+      __builtin_amdgcn_s_waitcnt(0x0F70);      // (the producer kept staging: retire its surplus half-images before the slab reuses their slots)
+      p8_barrier();
       p8_drain<FMH, EPI, (STG >= 131072 ? 4 : 3)>(p, acc, lds0, m0, n0, wm, wn, lane, tid, seed);      // 128 (96) slab rows of 1 KiB
     } else {
       p8_drain<FMH, EPI, (SR == 32 ? 1 : 0)>(p, acc, lds0 + STG, m0, n0, wm, wn, lane, tid, seed);
@@ -778,6 +778,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(const GemmParams p) 
     if (wm == 1 && w + (int)gridDim.x < nt) p8_barrier();   // re-establish the one-segment lag for the next output tile
     if (stamp) t_epi += __builtin_readcyclecounter() - t_mark;
   }
+  __builtin_amdgcn_s_waitcnt(0x0F70);      // surplus half-images of the branch-free producer (s_endpgm waits for them as well)
   if (stamp && tid == 0) {      // + the shader cycles this workgroup's wave 0 spent in K loops / in epilogues (incl. the tile-end barriers), tiles done
     unsigned long long* t = stamps + 8 * blockIdx.x;
     t[2] = __builtin_readcyclecounter();

@@ -11,8 +11,15 @@
 //   * few output tiles and a very long reduction: the work items of a launch are (tile, K slice) pairs, every slice writes its fp32
 //     partial tile to a slab (plain 16-B stores) and a streaming reduce adds the slabs (gemm.hip: splitk_reduce_kernel).  Items
 //     are ordered slice-major (all tiles of a slice are concurrent and share their operand rows in L2).
-// The column sums of A (bias gradients) are accumulated by the wn = 0 waves of the tile_n = 0 tiles from the A fragments with
-// v_dot2c_f32_bf16 behind the MFMAs of the phase that holds them.
+// The column sums of A (bias gradients) are taken from the A fragments with v_dot2c_f32_bf16 behind the MFMAs of the phase that holds
+// them.  The waves that hold the same A columns take turns: the ntn tiles of a tile row x the 4 wave columns wn of a workgroup are
+// ntn * 4 slots, slot tile_n * 4 + wn sums the K-tile PAIRS p with p % (ntn * 4) == slot (p counted from row 0 of the operand, so the K
+// slices of one gradient partition the pairs too), and every wave adds its partials to colsum[] with fp32 atomics at the end of the
+// item.  (Through round 5 the wn = 0 waves of the tile_n = 0 tiles did all of it: with one item per workgroup those 24 of 216
+// workgroups ran 17 % longer than the rest -- 3430 vs 2920 cycles per K tile -- and the launch ended with them: 364 us with the
+// sums, 331 us without; with the turns 341-345 us.  Splitting each phase's 32 v_dot2c over the four wn waves instead -- 8 each, in
+// the turns of the tile only -- measured the same launch time with four copies of the code, and its first form sent csum[] to
+// scratch: the compiler merged the four cases over a dynamic index.)
 #include <math.h>
 #include <stdlib.h>
 
@@ -175,8 +182,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(const Tn8Group grp, co
   const int lc = ((((sc >> 1) ^ sf) << 1) | (sc & 1)) * 8;      // logical column offset inside the 128-wide half-image
   __amdgpu_buffer_rsrc_t rsA, rsB;
   int ldaB = 0, ldbB = 0, clampA = 0, clampB = 0, rowA = 0, rowB = 0;
-  int w_p = blockIdx.x, kt_p = 0, nk_p = 0, kt0_p = 0, tiles_issued = 0, pm0 = 0, pn0 = 0;
-  bool live = true;
+  int w_p = blockIdx.x, kt_p = 0, nk_p = 0, kt0_p = 0, pm0 = 0, pn0 = 0;
   auto setup = [&](int w) {
     int gi;
     item_of(w, gi, pm0, pn0, kt0_p, nk_p);
@@ -190,7 +196,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(const Tn8Group grp, co
   };
   auto stage = [&](auto which_c, auto buf_c) {
     constexpr int WHICH = decltype(which_c)::value, B_ = decltype(buf_c)::value;
-    if (!live) return;
+    // The producer never stops (round 6): past the end of its work it keeps re-staging the last K tile of its last item into the slots
+    // the schedule frees anyway (nothing reads them; the per-item drain retires them before the workgroup exits).  Through round 5 a
+    // `live` flag put a branch in front of every phase's load segment and a two-way wait into phase 4; the vendor's 4-wave kernel has
+    // no branch in its K loop (profiles/r06_tn8_vs_vendor.txt).  Measured: 380 -> 365 us for the layer group, step -0.2 ms.
     if constexpr ((ABL & 1) != 0) return;
     const int kt = kt0_p + kt_p;
     if constexpr (WHICH < 2) {
@@ -209,14 +218,16 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(const Tn8Group grp, co
     }
   };
   auto advance = [&]() {
-    if (!live) return;
     if (++kt_p == nk_p) {
-      kt_p = 0;
-      w_p = (step >= (1 << 30)) ? nitems : w_p + step;
-      if (w_p < nitems) setup(w_p);
-      else live = false;
+      const int w_next = (step >= (1 << 30)) ? nitems : w_p + step;
+      if (w_next < nitems) {
+        kt_p = 0;
+        w_p = w_next;
+        setup(w_p);
+      } else {
+        kt_p = nk_p - 1;      // out of work: stay on the last K tile
+      }
     }
-    if (live) ++tiles_issued;
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
@@ -334,12 +345,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(const Tn8Group grp, co
 
   // ---------------- prologue ----------------
   setup(w_p);
-  tiles_issued = 1;
   stage(W0{}, I0{}); stage(W1{}, I0{}); stage(W2{}, I0{}); stage(W3{}, I0{});
   advance();
   stage(W0{}, I1{}); stage(W1{}, I1{});
-  if (live) __builtin_amdgcn_s_waitcnt(0x0F70 | 4);
-  else __builtin_amdgcn_s_waitcnt(0x0F70);
+  __builtin_amdgcn_s_waitcnt(0x0F70 | 4);
   tn8_barrier();
   if (wm == 1) tn8_barrier();
 
@@ -348,7 +357,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(const Tn8Group grp, co
     int gi, m0, n0, kt0, nk;
     item_of(w, gi, m0, n0, kt0, nk);
     float* const colsum = D(gi).colsum;
-    do_colsum = (colsum != nullptr) && (n0 == 0) && (wn == 0);
+    // column sums: this wave's turn comes every cs_slots K-tile pairs (see the header)
+    const int cs_slots = D(gi).ntn * 4;
+    int cs_wait = ((n0 >> 8) * 4 + wn - (kt0 >> 1)) % cs_slots;
+    if (cs_wait < 0) cs_wait += cs_slots;
 #pragma unroll
     for (int i = 0; i < 2 * NI; ++i) {
       csum[i] = 0.f;
@@ -364,6 +376,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(const Tn8Group grp, co
       }
     }
     for (int kt = 0; kt < nk; kt += 2, gk += 2) {
+      do_colsum = (colsum != nullptr) && (cs_wait == 0);
+      cs_wait = (cs_wait == 0 ? cs_slots : cs_wait) - 1;
       // ======== K tile gk (buffer 0): quadrants (0,0) (0,1) (1,1) (1,0) ========
       read_b(I0{}, I0{});
       __builtin_amdgcn_sched_barrier(0);
@@ -385,8 +399,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(const Tn8Group grp, co
       tn8_barrier();
       read_b(I0{}, I0{});
       stage(W1{}, I0{});
-      if (tiles_issued >= gk + 3) __builtin_amdgcn_s_waitcnt(0x0F70 | 4);
-      else __builtin_amdgcn_s_waitcnt(0x0F70);
+      __builtin_amdgcn_s_waitcnt(0x0F70 | 4);
       tn8_barrier();
       compute(I1{}, I0{}, F{});
       tn8_barrier();
@@ -411,8 +424,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(const Tn8Group grp, co
       tn8_barrier();
       read_b(I1{}, I0{});
       stage(W1{}, I1{});
-      if (tiles_issued >= gk + 4) __builtin_amdgcn_s_waitcnt(0x0F70 | 4);
-      else __builtin_amdgcn_s_waitcnt(0x0F70);
+      __builtin_amdgcn_s_waitcnt(0x0F70 | 4);
       tn8_barrier();
       compute(I1{}, I0{}, F{});
       tn8_barrier();
@@ -459,7 +471,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(const Tn8Group grp, co
           }
         }
       }
-      if (do_colsum) {      // per-lane partial sums cover 8 of a k-step's rows: reduce over the lanes that hold the other rows of the same column
+      if (colsum != nullptr) {      // per-lane partial sums cover 8 of a k-step's rows: reduce over the lanes that hold the other rows of the same column
 #pragma unroll
         for (int fi = 0; fi < 2 * NI; ++fi) {
           float v = csum[fi];
