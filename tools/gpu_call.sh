@@ -61,7 +61,7 @@ for what in "$@"; do
     e2e)      for v in "" "--graph" ; do timeout 400 python bench.py --e2e --no-cpu-baseline --no-phase-times --no-clock-probe $v 2>/dev/null | line "e2e $v"; done | tee $OUT/e2e.log
               VLB_VISION_WGRAD_STREAMS=1 timeout 400 python bench.py --e2e --no-cpu-baseline --no-phase-times --no-clock-probe 2>/dev/null | line "e2e 1 side stream" | tee -a $OUT/e2e.log
               VLB_VISION_WGRAD_STREAMS=1 timeout 400 python bench.py --e2e --no-cpu-baseline --no-phase-times --no-clock-probe --graph 2>/dev/null | line "e2e 1 side stream --graph" | tee -a $OUT/e2e.log ;;
-    phase)    { timeout 200 python tools/p8_phase_probe.py 256; timeout 200 python tools/p8_phase_probe.py 32; } 2>&1 | grep -v amdgpu.ids | tee $OUT/p8_phase_probe.txt ;;
+    phase)    { timeout 200 python tools/p8_phase_probe.py 256 --spread; timeout 200 python tools/p8_phase_probe.py 32; } 2>&1 | grep -v amdgpu.ids | tee $OUT/p8_phase_probe.txt ;;
     stream)   for v in "VLB_LN_BWD4=1 VLB_LN_FWD_ROWS=1" "VLB_LN_BWD4=2 VLB_LN_FWD_ROWS=2" "VLB_LN_BWD4=1 VLB_LN_FWD_ROWS=4"; do env $v timeout 200 python tools/ln_bench.py 25856 768 $( [ "$v" = "VLB_LN_BWD4=1 VLB_LN_FWD_ROWS=1" ] || echo noopt ) 2>&1 | grep -v amdgpu.ids; done | tee $OUT/stream_bench.txt ;;
     ntprobe)  { hipcc --offload-arch=gfx950 -O3 tools/nt_coherence_probe.hip -o /tmp/nt_probe && timeout 300 /tmp/nt_probe; } 2>&1 | tee $OUT/nt_coherence_probe.txt ;;
     hbm)      { hipcc --offload-arch=gfx950 -O3 tools/hbm_stream_probe.hip -o /tmp/hbm_probe && timeout 200 /tmp/hbm_probe; } 2>&1 | tee $OUT/hbm_stream_probe.txt | awk '/GB\/s/ { if ($(NF-1) > best[$1]) { best[$1] = $(NF-1); line[$1] = $0 } } END { for (k in line) print "best", line[k] }' ;;

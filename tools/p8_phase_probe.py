@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Where does a large-tile GEMM launch spend its time?  Measured INSIDE the kernel (run on the GPU box):
 
-    python tools/p8_phase_probe.py [batch]
+    python tools/p8_phase_probe.py [batch] [--spread]      (--spread: per-workgroup entry / exit times -- which workgroups end the launch)
 
 For each of the eight NT GEMMs of an encoder layer (M = batch x 101, the epilogue it carries in the step, the library's own kernel
 selection) one launch runs with p8_ablate = 4: wave 0 of every workgroup accumulates the shader cycles (s_memtime) it spends in the K
@@ -28,7 +28,8 @@ def rnd(*s, seed=0, scale=1.0):
 
 
 def main():
-    batch = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    batch = int(args[0]) if args else 256
     M = batch * 101
     shapes = [("qkv fwd", 2304, 768, "bias"), ("attn-out fwd", 768, 768, "lnres"), ("ffn1 fwd", 3072, 768, "gelu"), ("ffn2 fwd", 768, 3072, "lnres"),
               ("out dgrad", 768, 768, "plain"), ("qkv dgrad", 768, 2304, "res"), ("ffn1 dgrad", 768, 3072, "res"), ("ffn2 dgrad", 3072, 768, "mulaux")]
@@ -84,6 +85,20 @@ def main():
         epi_us = (full[:, 5].double() / tiles / clk).median()
         res_us = ((full[:, 3] - full[:, 1]).double() / 100.0).median()
         print("%-13s %6d %5d | %8d | %17.2f | %16.2f | %12.1f | %9.1f | %9.0f" % (name, N, K, int(tiles), main_us, epi_us, res_us, launch_us, clk), flush=True)
+        if "--spread" in sys.argv:      # which workgroups end the launch?  (100 MHz ticks -> us, relative to the first entry stamp)
+            ids = torch.nonzero(table.view(torch.int64).view(256, 8).cpu()[:, 3] > 0).flatten()
+            t0 = t[:, 1].min()
+            start, end = (t[:, 1] - t0).double() / 100.0, (t[:, 3] - t0).double() / 100.0
+            order = torch.argsort(end, descending=True)
+            print("    workgroups %d | entry spread %.1f us | exit: median %.1f, max %.1f us | tiles per workgroup: %s" % (
+                t.shape[0], float(start.max()), float(end.median()), float(end.max()),
+                ", ".join("%d x %d" % (int((t[:, 6] == k).sum()), int(k)) for k in sorted(set(t[:, 6].tolist()), reverse=True))))
+            print("    last to exit (block: exit us / tiles / main us / epilogue us): " + ", ".join(
+                "%d: %.1f / %d / %.1f / %.1f" % (int(ids[i]), float(end[i]), int(t[i, 6]), float(t[i, 4]) / float(clk), float(t[i, 5]) / float(clk))
+                for i in order[:6].tolist()))
+            print("    first to exit: " + ", ".join(
+                "%d: %.1f / %d / %.1f / %.1f" % (int(ids[i]), float(end[i]), int(t[i, 6]), float(t[i, 4]) / float(clk), float(t[i, 5]) / float(clk))
+                for i in order[-4:].tolist()))
 
 
 if __name__ == "__main__":
