@@ -6,6 +6,7 @@ in the attention backward before round 3's fix -- DESIGN.md §3, "Serialised pro
 occupancy step the launch geometry assumes, and that nothing spills.  tools/isa_lint.py extracts those facts; this test pins them."""
 import importlib.util
 import os
+import re
 
 import pytest
 
@@ -81,8 +82,31 @@ def test_grouped_weight_gradient_main_loop_is_clean():
         lo, hi = L.mfma_region(k["body"])
         inner = L.region_counts(k["body"], lo, hi)
         assert inner["mfma"] == mfmas and inner["scratch"] == 0     # two K tiles x four phases x 16 (8) MFMAs, no spill traffic in the loop
-        assert inner["vmcnt0"] <= 1                                  # (the end-of-stream drain; the steady state uses counted waits)
-        assert k["spill"] == 0 and k["vgpr"] <= 256, inst
+        assert inner["vmcnt0"] == 0                                  # the producer never stops (round 6): one form of the counted wait, no drain
+        assert k["spill"] == 0 and k["vgpr"] <= 256 and k["scratch"] == 0, inst      # (round 6: a four-way switch over csum[] once put it in scratch)
+        # round 6: no `live` flag in front of the load segments -- what is left are the item switch of the producer (taken once per
+        # item) and the four column-sum turns; 37 with the flag
+        assert inner["branches"] <= 28, (inst, inner["branches"])
+
+
+def test_large_tile_forward_core_has_no_producer_branches():
+    """gemm_nt_p8: the K loop of every instantiation stages its half-images unconditionally (round 6) and retires them with ONE counted
+    wait form: no vmcnt(0) between the first and the last MFMA of the two-K-tile loop body except in the epilogues that follow it."""
+    ks = L.kernels(L.compile_isa(os.path.join(CSRC, "gemm_p8.hip")))
+    seen = 0
+    for name, k in ks.items():
+        if "gemm_nt_p8_kernel" not in name:
+            continue
+        body = k["body"]
+        first = next(i for i, l in enumerate(body) if "v_mfma_" in l)
+        # the loop body = up to the 2 x 4 x 16 (12, 20) MFMAs after the first one
+        per_tile = 8 * {"ILi3E": 12, "ILi4E": 16, "ILi5E": 20}[re.search(r"kernel(ILi\dE)", name).group(1)]
+        idx = [i for i, l in enumerate(body) if "v_mfma_" in l][:per_tile]
+        inner = L.region_counts(body, first, idx[-1])
+        assert inner["mfma"] == per_tile and inner["lds_dma"] >= 12, (name, inner)
+        assert inner["vmcnt0"] == 0, (name, inner)
+        seen += 1
+    assert seen >= 30
 
 
 def test_no_instruction_touches_an_lds_read_still_in_flight():

@@ -159,7 +159,9 @@ def region_counts(body, lo, hi):
     return dict(scratch=sum(1 for l in seg if re.match(r"^\s+scratch_", l)),
                 vmcnt0=sum(1 for l in seg if (_WAIT.match(l) and int(_WAIT.match(l).group(1)) == 0)),
                 mfma=sum(1 for l in seg if "v_mfma_" in l),
-                barriers=sum(1 for l in seg if re.match(r"^\s+s_barrier", l)))
+                barriers=sum(1 for l in seg if re.match(r"^\s+s_barrier", l)),
+                branches=sum(1 for l in seg if re.match(r"^\s+s_cbranch", l)),
+                lds_dma=sum(1 for l in seg if re.match(r"^\s+buffer_load_dwordx4 .* lds", l)))
 
 
 def report(path, defines=()):

@@ -353,6 +353,7 @@ __device__ __forceinline__ void p8_drain(const GemmParams& p, f32x4 (&acc)[2 * F
     }
     if (r + 1 < ROUNDS) p8_barrier();      // the slab is free for the next round
   });
+  asm volatile("" ::"v"(b8[0]), "v"(b8[4]));      // the bias loads are consumed on every path (see the end of p8_drain_w)
 }
 
 // Drain WITHOUT workgroup barriers (default; -DVLB_P8_WDRAIN=0 selects the shared-slab drain above): every wave transposes its own
@@ -480,6 +481,12 @@ __device__ __forceinline__ void p8_drain_w(const GemmParams& p, f32x4 (&acc)[2 *
     if constexpr (u + 1 < NU) put(std::integral_constant<int, u + 1>{});
     finish(u, x0, x1, side[u % RING], mst[u % RING]);
   });
+  // The bias loads of consts() are CONSUMED on every path: on an edge tile whose units are all masked nothing read b8[], the loads stayed
+  // "in flight" in the compiler's scoreboard across the back edge of the tile loop, and hipcc protected the first fragment registers
+  // the K loop writes (the same VGPRs) with `s_waitcnt vmcnt(1)` / `vmcnt(0)` at the TOP OF EVERY K ITERATION of the bias-only forms
+  // (EPI 0 / 1 / 5) -- a drain of the operand ring every two K tiles, found by tests/test_isa_cpu.py in round 6.  Here the wait is a
+  // counted one behind stores that are long issued.
+  asm volatile("" ::"v"(b8[0]), "v"(b8[4]));
 }
 
 // FMH: 16-row accumulator fragments per wave per tile half (3 -> 192-row tiles, 4 -> 256-row tiles, 5 -> 320-row tiles)
